@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""bench.py — particle-steps/s of the LiquidWorld::step hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one `LiquidWorld::step(dt = 1/200, g = -9.81 y)` over the synthetic scene of BASELINE config[1]
+("3D DFSPH 1M particles, single fluid, XSPH viscosity, 1xMI355X", concretised in SURVEY.md §8d config 2 (A)):
+a 100^3 lattice block (spacing 2r, r = 0.025, h = 0.1, jitter +-0.1 r with LCG seed 42) resting in an open lattice
+tank (floor + 4 walls), rho0 = 1000, XSPHViscosity(0.5, 0), DFSPH defaults.  State is resident in HBM when the timed
+region starts; the timed region contains everything a step does (cell sort, neighbour lists, all solver passes,
+convergence read-backs) and nothing else.  One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from salva_amd import DFSPHSolver, Fluid, Boundary, LiquidWorld, XSPHViscosity, scenes  # noqa: E402
+
+R = 0.025
+DT = 1.0 / 200.0
+GRAVITY = (0.0, -9.81, 0.0)
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def build_scene(side: int):
+    fluid, shell = scenes.tank(side, side, side, R)
+    fluid = scenes.jitter(fluid, 0.1 * R, seed=42)
+    return fluid, shell
+
+
+def make_world(fluid, shell, device: int):
+    w = LiquidWorld(DFSPHSolver(), R, 2.0, device=device)
+    f = Fluid(fluid, R, 1000.0)
+    f.nonpressure_forces.append(XSPHViscosity(0.5, 0.0))
+    w.add_fluid(f)
+    w.add_boundary(Boundary(shell))
+    return w, f
+
+
+def cpu_baseline(fluid, shell, steps: int):
+    """The CPU oracle (C++ restatement of salva's CPU path, kind = "port") on the same scene, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+
+    cores = os.cpu_count() or 1
+    w = O.OracleWorld(R, 2.0, O.DFSPH, threads=cores)
+    fid = w.add_fluid(fluid, 1000.0)
+    w.add_xsph(fid, 0.5, 0.0)
+    w.add_boundary(shell)
+    w.step(DT, GRAVITY)  # warm-up (allocations)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w.step(DT, GRAVITY)
+    dt = time.perf_counter() - t0
+    return {"value": len(fluid) * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of the same {len(fluid)}-particle scene after 1 warm-up step, "
+                      f"oracle/salva_oracle.cpp f32, OpenMP {cores} threads ({dt / steps:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--side", type=int, default=100, help="particles per edge of the fluid block (100 -> 1M)")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path to measure")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    fluid, shell = build_scene(args.side)
+    n = len(fluid)
+    w, f = make_world(fluid, shell, local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    iters = []
+    for _ in range(args.warmup):
+        w.step(DT, GRAVITY)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = w.step(DT, GRAVITY)
+        iters.append((st.n_divergence_iters, st.n_pressure_iters, st.ncontacts, st.grid_ms, st.solver_ms))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant neighbour-sum kernel, timed live with HIP events on the world's own stream
+    it = np.asarray(iters, dtype=np.float64)
+    K = float(it[-1, 2]) / n  # mean directed contacts per fluid particle (ff + fb + bb) / N  ~ list entries per particle
+    kernel_us = w.time_pred_density(50)
+    kbar = float(w.contact_counts(f).mean() + w.contact_counts(f, True).mean())
+    algo_bytes = n * (4.0 * kbar + 52.0)  # k_pred_density moves N (4K + 52) bytes per launch
+    achieved = algo_bytes / (kernel_us * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_pred_density", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_us": kernel_us,
+                "algorithmic_bytes": algo_bytes, "mean_contacts": kbar}
+
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(fluid, shell, args.cpu_steps)
+        value = n * world * args.steps / elapsed
+        out = {
+            "metric": "particle-steps/sec (3D DFSPH)",
+            "value": value,
+            "unit": "particle-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"3D DFSPH {n} fluid particles (+{len(shell)} boundary), single fluid, XSPH viscosity, "
+                            f"lattice block in open tank, r=0.025 h=0.1 dt=1/200",
+                "particles_per_gpu": n,
+                "parallelism": "single domain" if world == 1 else f"{world} independent replicas (slab halo exchange not built yet)",
+                "mean_divergence_iters": float(it[:, 0].mean()),
+                "mean_pressure_iters": float(it[:, 1].mean()),
+                "mean_contacts_per_particle": kbar,
+                "grid_ms": float(it[:, 3].mean()),
+                "solver_ms": float(it[:, 4].mean()),
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

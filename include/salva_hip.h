@@ -1,0 +1,179 @@
+/* salva_hip.h — C ABI of libsalva_hip.so: an MI355X-native replacement for the body of
+ * salva3d's `LiquidWorld::step_with_coupling` (coupling = `()`).
+ *
+ * The reference (dimforge/salva, pure Rust) has no FFI for this path; its seams are Rust structs and
+ * traits.  Neighbour search runs inside `LiquidWorld::step_with_coupling` before the `PressureSolver`
+ * trait object is called (/root/reference/src/liquid_world.rs:88-128), so the drop-in unit is the whole
+ * step: a salva3d-compatible `LiquidWorld` whose `step` forwards to `salva_hip_step`.  Every entry point
+ * below names the reference interface it replaces.  The Rust binding a maintainer would add is shown in
+ * INTEGRATION.md; include/salva_hip.hpp and salva_amd/world.py are the C++ / Python mirrors used here
+ * (there is no cargo/rustc in this image).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; host arrays are caller-owned and borrowed for the duration of a call;
+ *    3-vectors are AoS [x,y,z] f32 = the memory layout of Vec<Point3<f32>> / Vec<Vector3<f32>>.
+ *  - return 0 on success, negative on error (SALVA_HIP_E_*); message via salva_hip_last_error().
+ *    The reference panics (assert!/unwrap, e.g. dfsph_solver.rs:92,145,662); this ABI never unwinds.
+ *  - a world may be used from any one thread at a time (LiquidWorld: Send + Sync, liquid_world.rs:283-287);
+ *    every entry point selects the world's device itself.
+ *  - there is no CPU fallback: without a usable HIP device salva_hip_create fails with SALVA_HIP_E_HIP.
+ */
+#ifndef SALVA_HIP_H
+#define SALVA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct SalvaHipWorld SalvaHipWorld;
+
+enum {
+    SALVA_HIP_OK = 0,
+    SALVA_HIP_E_HIP = -1,       /* a HIP runtime call failed / no device */
+    SALVA_HIP_E_INVALID = -2,   /* invalid argument */
+    SALVA_HIP_E_NUMERIC = -3,   /* zero density / boundary denominator / NaN — the reference's assert! cases */
+    SALVA_HIP_E_CAPACITY = -4   /* grid or neighbour list exceeds addressable size */
+};
+
+/* which pressure solver: solver::DFSPHSolver (dfsph_solver.rs) or solver::IISPHSolver (iisph_solver.rs) */
+enum { SALVA_HIP_SOLVER_DFSPH = 0, SALVA_HIP_SOLVER_IISPH = 1 };
+
+/* Mirrors `LiquidWorld::new(solver, particle_radius, smoothing_factor)` (liquid_world.rs:39-57) plus the
+ * pub tuning fields of DFSPHSolver (dfsph_solver.rs:21-38, defaults :54-70) / IISPHSolver (iisph_solver.rs:21-30,
+ * defaults :48-64). */
+typedef struct SalvaHipParams {
+    float particle_radius;
+    float smoothing_factor;          /* h = particle_radius * smoothing_factor * 2 */
+    int32_t solver;                  /* SALVA_HIP_SOLVER_* */
+    int32_t min_pressure_iter;       /* 1 */
+    int32_t max_pressure_iter;       /* 50 */
+    float max_density_error;         /* 0.05 */
+    int32_t min_divergence_iter;     /* 1   (DFSPH only) */
+    int32_t max_divergence_iter;     /* 50  (DFSPH only) */
+    float max_divergence_error;      /* 0.1 (DFSPH only) */
+    int32_t device;                  /* HIP device ordinal */
+    int32_t enable_timers;           /* fill the *_ms fields of SalvaHipStepStats (Counters, counters/mod.rs:17-72) */
+    int32_t reserved[7];
+} SalvaHipParams;
+
+/* Built-in `NonPressureForce` implementations that run on the device.  A `Fluid` holds a list of them
+ * (`fluid.nonpressure_forces`, object/fluid.rs:14); they are applied in list order by `predict_advection`
+ * (dfsph_solver.rs:565-604). */
+enum {
+    SALVA_HIP_FORCE_XSPH = 1,        /* solver::XSPHViscosity::new(fluid_coeff, boundary_coeff), xsph_viscosity.rs:22-28 */
+    SALVA_HIP_FORCE_ARTIFICIAL = 2,  /* solver::ArtificialViscosity::new(fluid_coeff, boundary_coeff), artificial_viscosity.rs:29-37 */
+    SALVA_HIP_FORCE_AKINCI2013 = 3   /* solver::Akinci2013SurfaceTension::new(tension, adhesion), akinci2013_surface_tension.rs:29-35 */
+};
+typedef struct SalvaHipForceDesc {
+    int32_t kind;
+    /* XSPH:       p[0] fluid_viscosity_coefficient, p[1] boundary_viscosity_coefficient
+     * ARTIFICIAL: p[0] fluid coeff, p[1] boundary coeff, p[2] alpha (1), p[3] beta (0), p[4] speed_of_sound (10)
+     * AKINCI2013: p[0] fluid_tension_coefficient, p[1] boundary_adhesion_coefficient */
+    float p[7];
+} SalvaHipForceDesc;
+
+/* dirty_mask bits of salva_hip_set_fluid: which host arrays changed since the last call */
+enum {
+    SALVA_HIP_DIRTY_POSITIONS = 1,
+    SALVA_HIP_DIRTY_VELOCITIES = 2,
+    SALVA_HIP_DIRTY_VOLUMES = 4,
+    SALVA_HIP_DIRTY_ACCELERATIONS = 8,
+    SALVA_HIP_DIRTY_ALL = 15
+};
+
+/* Per-step report; replaces the `Counters` the reference fills (counters/mod.rs:17-72, liquid_world.rs:73-156). */
+typedef struct SalvaHipStepStats {
+    int32_t n_divergence_iters;   /* compute_velocity_changes_for_divergence applications (dfsph_solver.rs:474-502) */
+    int32_t n_pressure_iters;     /* compute_velocity_changes applications (:439-463) / IISPH Jacobi iterations */
+    float divergence_error;       /* last evaluated average divergence error */
+    float density_error;          /* last evaluated average density error */
+    uint64_t ncontacts;           /* counters.cd.ncontacts (liquid_world.rs:119): ff + fb + bb directed contacts */
+    uint64_t nparticles;          /* fluid particles stepped */
+    float grid_ms;                /* counters.cd.grid_insertion_time + neighborhood_search_time equivalents */
+    float solver_ms;              /* counters.stages.solver_time */
+    float step_ms;                /* counters.step_time */
+    float reserved[5];
+} SalvaHipStepStats;
+
+/* fields of salva_hip_get_fluid_field (solver scratch the reference keeps private; exposed for parity tests) */
+enum {
+    SALVA_HIP_FIELD_DENSITY = 0,            /* densities            f32 x n */
+    SALVA_HIP_FIELD_ALPHA = 1,              /* alphas (DFSPH)       f32 x n */
+    SALVA_HIP_FIELD_NUM_FLUID_CONTACTS = 2, /* len of fluid_fluid_contacts[i]    (as f32) x n */
+    SALVA_HIP_FIELD_NUM_BOUNDARY_CONTACTS = 3, /* len of fluid_boundary_contacts[i] (as f32) x n */
+    SALVA_HIP_FIELD_VELOCITY_CHANGE = 4,    /* velocity_changes     f32 x 3n */
+    SALVA_HIP_FIELD_PRESSURE = 5,           /* pressures (IISPH)    f32 x n */
+    SALVA_HIP_FIELD_VOLUME = 6,             /* volumes              f32 x n */
+    SALVA_HIP_FIELD_ACCELERATION = 7        /* accelerations        f32 x 3n */
+};
+
+void salva_hip_default_params(SalvaHipParams* out);
+
+/* LiquidWorld::new — liquid_world.rs:39-57 */
+int salva_hip_create(const SalvaHipParams* params, SalvaHipWorld** out);
+void salva_hip_destroy(SalvaHipWorld* world);
+
+/* LiquidWorld::h / particle_radius — liquid_world.rs:201-208 */
+float salva_hip_h(const SalvaHipWorld* world);
+
+/* LiquidWorld::add_fluid (liquid_world.rs:161-163) when slot == current number of fluids, otherwise the
+ * upload half of `fluids_mut().get_mut(handle)` edits (pub fields of Fluid, object/fluid.rs:12-34).
+ * `slot` is the dense index of the FluidSet (object/contiguous_arena.rs).  velocities / volumes / accelerations
+ * may be NULL (zeros / Fluid::particle_volume = 0.8 (2r)^3, fluid.rs:110-120 / zeros).  When `n` differs from
+ * the stored count every array passed replaces the old one and the solver's velocity_changes of that fluid
+ * restart from zero (or from `velocity_changes` if non-NULL — used to carry init_with_fluids' compaction,
+ * dfsph_solver.rs:526-561). */
+int salva_hip_set_fluid(SalvaHipWorld* world, uint32_t slot, uint64_t n,
+                        const float* positions_xyz, const float* velocities_xyz, const float* volumes,
+                        const float* accelerations_xyz, const float* velocity_changes_xyz,
+                        float density0, uint32_t memberships, uint32_t filter, uint32_t dirty_mask);
+
+/* `fluid.nonpressure_forces` — object/fluid.rs:14 */
+int salva_hip_set_fluid_forces(SalvaHipWorld* world, uint32_t slot, const SalvaHipForceDesc* forces, uint32_t nforces);
+
+/* LiquidWorld::remove_fluid (liquid_world.rs:171-173): swap-remove, like ContiguousArena::remove */
+int salva_hip_remove_fluid(SalvaHipWorld* world, uint32_t slot);
+
+/* LiquidWorld::add_boundary (liquid_world.rs:166-168) / edits of Boundary's pub fields (object/boundary.rs:11-24).
+ * velocities may be NULL (zeros).  wants_forces != 0 <=> `boundary.forces = Some(..)`. */
+int salva_hip_set_boundary(SalvaHipWorld* world, uint32_t slot, uint64_t n,
+                           const float* positions_xyz, const float* velocities_xyz,
+                           uint32_t memberships, uint32_t filter, int32_t wants_forces);
+int salva_hip_remove_boundary(SalvaHipWorld* world, uint32_t slot);
+
+uint32_t salva_hip_num_fluids(const SalvaHipWorld* world);
+uint32_t salva_hip_num_boundaries(const SalvaHipWorld* world);
+uint64_t salva_hip_fluid_len(const SalvaHipWorld* world, uint32_t slot);
+uint64_t salva_hip_boundary_len(const SalvaHipWorld* world, uint32_t slot);
+
+/* LiquidWorld::step(dt, gravity) — liquid_world.rs:62-158 with the no-op `()` CouplingManager. */
+int salva_hip_step(SalvaHipWorld* world, float dt, const float gravity[3], SalvaHipStepStats* stats_or_null);
+
+/* Download half of `fluids().get(handle)`: positions / velocities after the step (any pointer may be NULL). */
+int salva_hip_get_fluid(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz);
+int salva_hip_get_fluid_field(SalvaHipWorld* world, uint32_t slot, int32_t field, float* out);
+
+/* `boundary.volumes` (recomputed every substep, dfsph_solver.rs:72-96) and `boundary.forces`
+ * (accumulated by Boundary::apply_force, boundary.rs:62-67).  Any pointer may be NULL. */
+int salva_hip_get_boundary(SalvaHipWorld* world, uint32_t slot, float* volumes, float* forces_xyz);
+/* Boundary::clear_forces — boundary.rs:70-82 */
+int salva_hip_clear_boundary_forces(SalvaHipWorld* world, uint32_t slot);
+
+/* Device residency helpers for benchmarks: bytes of HBM held by the world; algorithmic byte model of the last
+ * step evaluated with the measured mean contact count K and iteration counts. */
+uint64_t salva_hip_device_bytes(const SalvaHipWorld* world);
+
+/* Timing hook for bench.py's roofline leg: re-launches the last step's k_pred_density kernel `reps` times on
+ * the world's stream between two hipEvents and returns the average launch duration in microseconds
+ * (negative on error).  State is not modified (the kernel rewrites the same outputs from the same inputs). */
+float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps);
+
+const char* salva_hip_last_error(void);
+const char* salva_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SALVA_HIP_H */

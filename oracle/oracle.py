@@ -1,0 +1,226 @@
+"""ctypes front end of the CPU oracle (`oracle/salva_oracle.cpp`).
+
+TEST INFRASTRUCTURE ONLY: importable from `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline`
+leg of `bench.py`, never from `salva_amd/`.  PARITY UNPINNED (see the header of salva_oracle.cpp).
+
+The class mirrors the call sequence of the reference (`LiquidWorld::new / add_fluid / add_boundary / step`,
+/root/reference/src/liquid_world.rs:39-171) so the parity tests can drive oracle and HIP path alike.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsalva_oracle.so")
+
+DFSPH, IISPH = 0, 1
+FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013 = 1, 2, 3
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_div_iters", C.c_int32),
+        ("n_press_iters", C.c_int32),
+        ("div_error", C.c_double),
+        ("density_error", C.c_double),
+        ("ncontacts", C.c_uint64),
+        ("t_grid_ms", C.c_double),
+        ("t_contacts_ms", C.c_double),
+        ("t_kernels_ms", C.c_double),
+        ("t_solver_ms", C.c_double),
+        ("t_total_ms", C.c_double),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with the committed recipe (oracle/Makefile)."""
+    src = os.path.join(_HERE, "salva_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsalva_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        vp, u64, u32, i32, f32, f64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float, C.c_double
+        fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        L.so_create.restype = vp
+        L.so_create.argtypes = [i32, f32, f32, i32, i32]
+        L.so_destroy.argtypes = [vp]
+        L.so_set_shuffle_seed.argtypes = [vp, u64]
+        L.so_set_threads.argtypes = [vp, i32]
+        L.so_set_solver_params.argtypes = [vp, i32, i32, f32, i32, i32, f32]
+        L.so_h.restype = f64
+        L.so_h.argtypes = [vp]
+        L.so_add_fluid.argtypes = [vp, u64, fp, fp, f32, u32, u32]
+        L.so_add_boundary.argtypes = [vp, u64, fp, fp, u32, u32, i32]
+        L.so_add_force.argtypes = [vp, i32, i32, fp, i32]
+        L.so_set_fluid_velocities.argtypes = [vp, i32, fp]
+        L.so_set_fluid_volumes.argtypes = [vp, i32, fp]
+        L.so_step.argtypes = [vp, f32, f32, f32, f32, C.POINTER(Stats)]
+        L.so_fluid_len.restype = u64
+        L.so_fluid_len.argtypes = [vp, i32]
+        L.so_boundary_len.restype = u64
+        L.so_boundary_len.argtypes = [vp, i32]
+        L.so_get_fluid_vec.argtypes = [vp, i32, i32, dp]
+        L.so_get_fluid_scalar.argtypes = [vp, i32, i32, dp]
+        L.so_get_contact_counts.argtypes = [vp, i32, i32, C.POINTER(C.c_uint32)]
+        L.so_get_contacts_of.restype = u64
+        L.so_get_contacts_of.argtypes = [vp, i32, i32, u64, C.POINTER(C.c_uint64), u64]
+        L.so_get_boundary_vec.argtypes = [vp, i32, i32, dp]
+        L.so_get_boundary_volumes.argtypes = [vp, i32, dp]
+        L.so_clear_boundary_forces.argtypes = [vp, i32]
+        for name in ("so_kernel_w", "so_kernel_dw", "so_cohesion_kernel", "so_adhesion_kernel"):
+            getattr(L, name).restype = f32
+            getattr(L, name).argtypes = [f32, f32]
+        for name in ("so_kernel_w_f64", "so_kernel_dw_f64"):
+            getattr(L, name).restype = f64
+            getattr(L, name).argtypes = [f64, f64]
+        L.so_max_threads.restype = i32
+        _lib = L
+    return _lib
+
+
+def _f32(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if cols is not None:
+        assert a.ndim == 2 and a.shape[1] == cols, a.shape
+    return a
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class OracleWorld:
+    """CPU restatement of `salva3d::LiquidWorld` (f32 like the reference, or f64 for the noise floor)."""
+
+    VEC_FIELDS = {"positions": 0, "velocities": 1, "velocity_changes": 2, "accelerations": 3, "dii": 4,
+                  "dij_pjl": 5, "normals": 6}
+    SCALAR_FIELDS = {"densities": 0, "alphas": 1, "divergences": 2, "predicted_densities": 3, "volumes": 4,
+                     "aii": 5, "pressures": 6}
+
+    def __init__(self, particle_radius: float, smoothing_factor: float = 2.0, solver: int = DFSPH,
+                 f64: bool = False, threads: int = 1):
+        self._L = lib()
+        self._h = self._L.so_create(int(f64), particle_radius, smoothing_factor, solver, threads)
+        self.f64 = f64
+        self.last_stats = Stats()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.so_destroy(self._h)
+            self._h = None
+
+    @property
+    def h(self) -> float:
+        return self._L.so_h(self._h)
+
+    def set_threads(self, n: int):
+        self._L.so_set_threads(self._h, n)
+
+    def set_shuffle_seed(self, seed: int):
+        self._L.so_set_shuffle_seed(self._h, seed)
+
+    def set_solver_params(self, min_pressure_iter=1, max_pressure_iter=50, max_density_error=0.05,
+                          min_divergence_iter=1, max_divergence_iter=50, max_divergence_error=0.1):
+        self._L.so_set_solver_params(self._h, min_pressure_iter, max_pressure_iter, max_density_error,
+                                     min_divergence_iter, max_divergence_iter, max_divergence_error)
+
+    def add_fluid(self, positions, density0=1000.0, velocities=None, memberships=1, filter=0xFFFFFFFF) -> int:
+        pos = _f32(positions, 3)
+        vel = _f32(velocities, 3) if velocities is not None else None
+        return self._L.so_add_fluid(self._h, len(pos), _fp(pos), _fp(vel) if vel is not None else None,
+                                    density0, memberships, filter)
+
+    def add_boundary(self, positions, velocities=None, memberships=1, filter=0xFFFFFFFF, wants_forces=False) -> int:
+        pos = _f32(positions, 3)
+        vel = _f32(velocities, 3) if velocities is not None else None
+        return self._L.so_add_boundary(self._h, len(pos), _fp(pos), _fp(vel) if vel is not None else None,
+                                       memberships, filter, int(wants_forces))
+
+    def add_xsph(self, fluid, fluid_coeff, boundary_coeff):
+        p = _f32([fluid_coeff, boundary_coeff])
+        self._L.so_add_force(self._h, fluid, FORCE_XSPH, _fp(p), 2)
+
+    def add_artificial_viscosity(self, fluid, fluid_coeff, boundary_coeff, alpha=1.0, beta=0.0, speed_of_sound=10.0):
+        p = _f32([fluid_coeff, boundary_coeff, alpha, beta, speed_of_sound])
+        self._L.so_add_force(self._h, fluid, FORCE_ARTIFICIAL, _fp(p), 5)
+
+    def add_akinci2013(self, fluid, tension_coeff, adhesion_coeff):
+        p = _f32([tension_coeff, adhesion_coeff])
+        self._L.so_add_force(self._h, fluid, FORCE_AKINCI2013, _fp(p), 2)
+
+    def set_fluid_velocities(self, fluid, velocities):
+        v = _f32(velocities, 3)
+        assert len(v) == self.fluid_len(fluid)
+        self._L.so_set_fluid_velocities(self._h, fluid, _fp(v))
+
+    def set_fluid_volumes(self, fluid, volumes):
+        v = _f32(volumes)
+        assert len(v) == self.fluid_len(fluid)
+        self._L.so_set_fluid_volumes(self._h, fluid, _fp(v))
+
+    def step(self, dt, gravity=(0.0, -9.81, 0.0)) -> Stats:
+        self._L.so_step(self._h, dt, gravity[0], gravity[1], gravity[2], C.byref(self.last_stats))
+        return self.last_stats
+
+    def fluid_len(self, fluid) -> int:
+        return self._L.so_fluid_len(self._h, fluid)
+
+    def boundary_len(self, b) -> int:
+        return self._L.so_boundary_len(self._h, b)
+
+    def fluid_vec(self, fluid, field) -> np.ndarray:
+        out = np.zeros((self.fluid_len(fluid), 3), dtype=np.float64)
+        self._L.so_get_fluid_vec(self._h, fluid, self.VEC_FIELDS[field], out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def fluid_scalar(self, fluid, field) -> np.ndarray:
+        out = np.zeros(self.fluid_len(fluid), dtype=np.float64)
+        self._L.so_get_fluid_scalar(self._h, fluid, self.SCALAR_FIELDS[field], out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def contact_counts(self, fluid, boundary_contacts=False) -> np.ndarray:
+        out = np.zeros(self.fluid_len(fluid), dtype=np.uint32)
+        self._L.so_get_contact_counts(self._h, fluid, int(boundary_contacts), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return out
+
+    def contacts_of(self, fluid, i, boundary_contacts=False):
+        """Sorted list of (j_model, j) of particle i's contacts."""
+        buf = np.zeros(4096, dtype=np.uint64)
+        n = self._L.so_get_contacts_of(self._h, fluid, int(boundary_contacts), i,
+                                       buf.ctypes.data_as(C.POINTER(C.c_uint64)), len(buf))
+        return [(int(k) >> 32, int(k) & 0xFFFFFFFF) for k in buf[:n]]
+
+    def boundary_vec(self, b, field) -> np.ndarray:
+        out = np.zeros((self.boundary_len(b), 3), dtype=np.float64)
+        self._L.so_get_boundary_vec(self._h, b, {"positions": 0, "velocities": 1, "forces": 2}[field],
+                                    out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def boundary_volumes(self, b) -> np.ndarray:
+        out = np.zeros(self.boundary_len(b), dtype=np.float64)
+        self._L.so_get_boundary_volumes(self._h, b, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def clear_boundary_forces(self, b):
+        self._L.so_clear_boundary_forces(self._h, b)
+
+
+def kernel_w(r, h, f64=False):
+    return lib().so_kernel_w_f64(r, h) if f64 else lib().so_kernel_w(r, h)
+
+
+def kernel_dw(r, h, f64=False):
+    return lib().so_kernel_dw_f64(r, h) if f64 else lib().so_kernel_dw(r, h)

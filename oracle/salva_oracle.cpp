@@ -1,0 +1,1328 @@
+// salva_oracle.cpp — CPU restatement of dimforge/salva's `LiquidWorld::step` hot path.
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only `tests/`, `__graft_entry__.smoke()` and
+// `bench.py`'s `cpu_baseline` leg may load this library, and only as the checker / CPU baseline.
+// The shipped path (`salva_amd/csrc/libsalva_hip.so`) never links, loads or calls it.
+//
+// PARITY UNPINNED: the reference (pure Rust; needs cargo + nalgebra 0.33, rayon 1.8, fnv 1.0 …) cannot
+// be compiled in this environment, and its repository holds no golden vector, known-answer test or
+// fixture for this path (its only 3 `#[test]`s never touch the solver).  This file therefore restates
+// the algorithm from the source text alone; it is pinned only by the analytic self-checks in
+// `tests/test_oracle.py` (lattice K = 33, rho ~= rho0, kernel normalisation, contact symmetry, momentum)
+// and by the committed vectors under `tests/golden/` that were produced by *this* oracle.
+//
+// What is restated (paths relative to /root/reference):
+//   src/liquid_world.rs:62-158                      step_with_coupling  (coupling = `()`, no-op)
+//   src/geometry/hgrid.rs:41-63                     cell key = floor(x / h), hash grid of Vec<entry>
+//   src/geometry/contacts.rs:133-400                grid insertion, 14-cell half stencil, directed contacts
+//   src/solver/helper.rs:9-65                       weight / gradient evaluation for each stored contact
+//   src/kernel/kernel.rs:13-24, cubic_spline_kernel.rs:12-79
+//   src/solver/pressure/dfsph_solver.rs:54-708      DFSPH
+//   src/solver/pressure/iisph_solver.rs:48-711      IISPH
+//   src/solver/viscosity/xsph_viscosity.rs:31-95, artificial_viscosity.rs:29-124
+//   src/solver/surface_tension/akinci2013_surface_tension.rs:43-192
+//   src/timestep_manager.rs:23-94                   (CFL is bypassed upstream: one substep per step)
+//   src/object/{fluid,boundary,interaction_groups}.rs
+//
+// Third-party arithmetic that is NOT under /root/reference (nalgebra 0.33, semver range only, no lockfile):
+//   dot / norm_squared of a 3-vector = ((x0*y0 + x1*y1) + x2*y2); Unit::try_new_and_get(v, eps) returns
+//   None iff |v|^2 <= eps^2, else (v / |v| component-wise, |v|).  Rust never contracts a*b+c into an FMA,
+//   so this file must be compiled with -ffp-contract=off.
+//
+// The one thing that cannot be restated is the reference's *summation order*: contacts are pushed in
+// hashbrown-bucket (and, with `parallel`, thread-schedule) order.  Here cells are visited in first-insertion
+// order (deterministic); `shuffle_seed != 0` permutes the cell visit order so that tests can measure how
+// much a different—equally legitimate—order moves the result (the "self noise" of the reference).
+//
+// Build:  see oracle/Makefile (g++ -O2 -ffp-contract=off -fopenmp -shared -fPIC).
+
+#include <algorithm>
+#include <atomic>
+#include <cassert>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <unordered_map>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace so {
+
+// ---------------------------------------------------------------------------------------------------
+// Small vector type with nalgebra's evaluation order.
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+struct V3 {
+    R x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(R a, R b, R c) : x(a), y(b), z(c) {}
+    V3 operator+(const V3& o) const { return V3(x + o.x, y + o.y, z + o.z); }
+    V3 operator-(const V3& o) const { return V3(x - o.x, y - o.y, z - o.z); }
+    V3 operator-() const { return V3(-x, -y, -z); }
+    V3 operator*(R s) const { return V3(x * s, y * s, z * s); }
+    V3 operator/(R s) const { return V3(x / s, y / s, z / s); }
+    V3& operator+=(const V3& o) { x += o.x; y += o.y; z += o.z; return *this; }
+    V3& operator-=(const V3& o) { x -= o.x; y -= o.y; z -= o.z; return *this; }
+    V3& operator*=(R s) { x *= s; y *= s; z *= s; return *this; }
+    R dot(const V3& o) const { return (x * o.x + y * o.y) + z * o.z; }
+    R norm_squared() const { return (x * x + y * y) + z * z; }
+    R norm() const { return std::sqrt(norm_squared()); }
+    void fill(R v) { x = y = z = v; }
+};
+
+template <typename R> struct Eps;
+template <> struct Eps<float> { static constexpr float v = 1.1920929e-7f; };
+template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
+
+// llvm.powi / compiler-rt __powisf2: square-and-multiply.
+template <typename R>
+static inline R powi(R a, int b) {
+    const bool recip = b < 0;
+    R r = 1;
+    while (true) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1 / r : r;
+}
+
+// nalgebra Unit::try_new_and_get
+template <typename R>
+static inline bool try_new_and_get(const V3<R>& v, R min_norm, V3<R>& dir, R& norm) {
+    R sq = v.norm_squared();
+    if (sq > min_norm * min_norm) {
+        norm = std::sqrt(sq);
+        dir = v / norm;
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernel/cubic_spline_kernel.rs:12-33,55-79 ; kernel/kernel.rs:13-24
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+struct CubicSpline {
+    static constexpr R PI = (R)3.14159265358979323846264338327950288;
+    static R scalar_apply(R r, R h) {
+        R normalizer = (R)8.0 / (PI * h * h * h);
+        R q = r / h;
+        R rhs;
+        if (q <= (R)0.5) {
+            R q2 = q * q;
+            rhs = (R)1 + (q2 * q - q2) * (R)6.0;
+        } else if (q <= (R)1) {
+            rhs = powi<R>((R)1 - q, 3) * (R)2;
+        } else {
+            rhs = 0;
+        }
+        return normalizer * rhs;
+    }
+    static R scalar_apply_diff(R r, R h) {
+        R normalizer = (R)8.0 / (PI * h * h * h);
+        R q = r / h;
+        R rhs;
+        if (q > (R)1 || q <= (R)1.0e-5) {
+            rhs = 0;
+        } else if (q <= (R)0.5) {
+            rhs = (q * (R)3 - (R)2) * q * (R)6.0;
+        } else {
+            R one_q = (R)1 - q;
+            rhs = -one_q * one_q * (R)6.0;
+        }
+        return normalizer * rhs / h;
+    }
+    static R apply(const V3<R>& v, R h) { return scalar_apply(v.norm(), h); }
+    static V3<R> apply_diff(const V3<R>& v, R h) {
+        V3<R> dir; R n;
+        if (try_new_and_get<R>(v, Eps<R>::v, dir, n)) return dir * scalar_apply_diff(n, h);
+        return V3<R>();
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// object/interaction_groups.rs:64-69
+// ---------------------------------------------------------------------------------------------------
+struct Groups {
+    uint32_t memberships = 1u, filter = 0xffffffffu;  // default: GROUP_1 / ALL (:72-79)
+    bool test(const Groups& rhs) const {
+        return (memberships & rhs.filter) != 0 && (rhs.memberships & filter) != 0;
+    }
+};
+
+enum ForceKind { FORCE_XSPH = 1, FORCE_ARTIFICIAL = 2, FORCE_AKINCI2013 = 3 };
+
+template <typename R>
+struct Force {
+    int kind = 0;
+    // XSPH: p0 = fluid coeff, p1 = boundary coeff
+    // Artificial: p0 = fluid coeff, p1 = boundary coeff, p2 = alpha, p3 = beta, p4 = speed_of_sound
+    // Akinci2013: p0 = tension coeff, p1 = boundary adhesion coeff
+    R p[5] = {0, 0, 0, 0, 0};
+    std::vector<V3<R>> normals;  // Akinci state (akinci2013_surface_tension.rs:22)
+};
+
+template <typename R>
+struct Fluid {  // object/fluid.rs:12-34
+    std::vector<V3<R>> positions, velocities, accelerations;
+    std::vector<R> volumes;
+    R density0 = 1000;
+    Groups groups;
+    std::vector<Force<R>> forces;
+    size_t n() const { return positions.size(); }
+    R particle_mass(size_t i) const { return volumes[i] * density0; }  // fluid.rs:183-185
+};
+
+template <typename R>
+struct Boundary {  // object/boundary.rs:11-24
+    std::vector<V3<R>> positions, velocities;
+    std::vector<R> volumes;
+    bool has_forces = false;
+    std::vector<V3<R>> forces;
+    Groups groups;
+    size_t n() const { return positions.size(); }
+};
+
+template <typename R>
+struct Contact {  // geometry/contacts.rs:40-55
+    size_t i, i_model, j, j_model;
+    R weight;
+    V3<R> gradient;
+    Contact flip() const { return Contact{j, j_model, i, i_model, weight, -gradient}; }
+};
+
+struct SpinLock {
+    std::atomic_flag f = ATOMIC_FLAG_INIT;
+    void lock() { while (f.test_and_set(std::memory_order_acquire)) {} }
+    void unlock() { f.clear(std::memory_order_release); }
+};
+
+template <typename R>
+struct ParticleContacts {  // contacts.rs:83-130 (RwLock<Vec<Contact>> per particle)
+    std::vector<std::vector<Contact<R>>> contacts;
+    std::unique_ptr<SpinLock[]> locks;
+    size_t nlocks = 0;
+    void reset(size_t n) {
+        for (auto& c : contacts) c.clear();
+        contacts.resize(n);
+        if (nlocks < n) { locks.reset(new SpinLock[n]); nlocks = n; }
+    }
+    void push(size_t i, const Contact<R>& c, bool threaded) {
+        if (threaded) { locks[i].lock(); contacts[i].push_back(c); locks[i].unlock(); }
+        else contacts[i].push_back(c);
+    }
+    size_t len() const { size_t s = 0; for (auto& c : contacts) s += c.size(); return s; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// geometry/hgrid.rs — hash grid.  FNV-1a with key 1820 over the 24 little-endian bytes of the cell.
+// ---------------------------------------------------------------------------------------------------
+struct Cell { int64_t x, y, z; bool operator==(const Cell& o) const { return x == o.x && y == o.y && z == o.z; } };
+struct CellHash {
+    size_t operator()(const Cell& c) const {
+        uint64_t h = 1820ull;
+        const int64_t v[3] = {c.x, c.y, c.z};
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(v);
+        for (int i = 0; i < 24; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+        return (size_t)h;
+    }
+};
+struct Entry { uint32_t model; uint32_t particle; bool is_boundary; };  // contacts.rs:14-19
+
+struct HGrid {
+    std::unordered_map<Cell, uint32_t, CellHash> index;  // cell -> slot in `cells`
+    std::vector<Cell> keys;                               // first-insertion order
+    std::vector<std::vector<Entry>> cells;
+    size_t used = 0;
+    void clear() {  // hgrid.rs:55-57
+        index.clear(); keys.clear();
+        for (size_t i = 0; i < used; ++i) cells[i].clear();
+        used = 0;
+    }
+    template <typename R>
+    static int64_t quantify(R value, R cell_width) {  // hgrid.rs:41-43
+        return (int64_t)(double)std::floor(value / cell_width);
+    }
+    template <typename R>
+    void insert(const V3<R>& p, R w, Entry e) {  // hgrid.rs:60-63
+        Cell c{quantify<R>(p.x, w), quantify<R>(p.y, w), quantify<R>(p.z, w)};
+        auto it = index.find(c);
+        uint32_t slot;
+        if (it == index.end()) {
+            slot = (uint32_t)used++;
+            index.emplace(c, slot);
+            keys.push_back(c);
+            if (cells.size() < used) cells.emplace_back();
+        } else slot = it->second;
+        cells[slot].push_back(e);
+    }
+    const std::vector<Entry>* cell(const Cell& c) const {
+        auto it = index.find(c);
+        return it == index.end() ? nullptr : &cells[it->second];
+    }
+};
+
+struct StepStats {
+    int n_div_iters;        // number of compute_velocity_changes_for_divergence applications
+    int n_press_iters;      // number of compute_velocity_changes applications (DFSPH) / Jacobi iterations (IISPH)
+    double div_error;       // last evaluated average divergence error
+    double density_error;   // last evaluated average density error
+    uint64_t ncontacts;     // liquid_world.rs:119
+    double t_grid_ms, t_contacts_ms, t_kernels_ms, t_solver_ms, t_total_ms;
+};
+
+static inline double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The world.
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+struct World {
+    R particle_radius, h;
+    int solver_kind;  // 0 = DFSPH, 1 = IISPH
+    int nthreads = 1;
+    uint64_t shuffle_seed = 0;
+    std::vector<Fluid<R>> fluids;
+    std::vector<Boundary<R>> boundaries;
+    HGrid grid;
+    std::vector<ParticleContacts<R>> ff, fb, bb;  // contact_manager.rs:8-15
+    // timestep_manager.rs:11-34
+    R dt = 0, inv_dt = 0, total_step_size = 0, remaining_time = 0;
+
+    // DFSPH parameters (dfsph_solver.rs:54-70) / IISPH (iisph_solver.rs:48-64)
+    int min_pressure_iter = 1, max_pressure_iter = 50;
+    R max_density_error = (R)0.05;
+    int min_divergence_iter = 1, max_divergence_iter = 50;
+    R max_divergence_error = (R)0.1;
+    size_t min_neighbors_for_divergence_solve = 20;
+    R omega = (R)0.5;
+
+    // solver scratch, one vector per fluid
+    std::vector<std::vector<R>> alphas, densities, predicted_densities, divergences;
+    std::vector<std::vector<V3<R>>> velocity_changes;
+    std::vector<std::vector<R>> aii, pressures, next_pressures;
+    std::vector<std::vector<V3<R>>> dii, dij_pjl;
+
+    StepStats stats{};
+
+    World(R radius, R smoothing, int kind) : particle_radius(radius), solver_kind(kind) {
+        h = radius * smoothing * (R)2.0;  // liquid_world.rs:44
+    }
+
+    bool threaded() const { return nthreads > 1; }
+
+    // ------------------------------------------------------------------ init_with_fluids (dfsph :526-561, iisph :479-537)
+    void init_with_fluids() {
+        size_t nf = fluids.size();
+        alphas.resize(nf); densities.resize(nf); predicted_densities.resize(nf); divergences.resize(nf);
+        velocity_changes.resize(nf); aii.resize(nf); pressures.resize(nf); next_pressures.resize(nf);
+        dii.resize(nf); dij_pjl.resize(nf);
+        for (size_t f = 0; f < nf; ++f) {
+            size_t n = fluids[f].n();
+            alphas[f].resize(n, 0); densities[f].resize(n, 0); predicted_densities[f].resize(n, 0);
+            divergences[f].resize(n, 0); velocity_changes[f].resize(n, V3<R>());
+            aii[f].resize(n, 0); pressures[f].resize(n, 0); next_pressures[f].resize(n, 0);
+            dii[f].resize(n, V3<R>()); dij_pjl[f].resize(n, V3<R>());
+        }
+    }
+
+    // ------------------------------------------------------------------ contacts.rs:133-151
+    void insert_to_grid() {
+        for (size_t f = 0; f < fluids.size(); ++f)
+            for (size_t p = 0; p < fluids[f].n(); ++p)
+                grid.insert<R>(fluids[f].positions[p], h, Entry{(uint32_t)f, (uint32_t)p, false});
+        for (size_t b = 0; b < boundaries.size(); ++b)
+            for (size_t p = 0; p < boundaries[b].n(); ++p)
+                grid.insert<R>(boundaries[b].positions[p], h, Entry{(uint32_t)b, (uint32_t)p, true});
+    }
+
+    // ------------------------------------------------------------------ contacts.rs:254-400
+    void contacts_for_pair_of_cells(const Cell& curr_cell, const std::vector<Entry>& curr,
+                                    const Cell& nbr_cell, const std::vector<Entry>& nbr) {
+        const bool thr = threaded();
+        const bool same_cell = curr_cell == nbr_cell;
+        const R h2 = h * h;
+        for (const Entry& ei : curr) {
+            if (ei.is_boundary) {
+                for (const Entry& ej : nbr) {
+                    if (ej.is_boundary) {
+                        const Boundary<R>& bi = boundaries[ei.model];
+                        const Boundary<R>& bj = boundaries[ej.model];
+                        if (ei.model != ej.model && !bi.groups.test(bj.groups)) continue;
+                        const V3<R>& pi = bi.positions[ei.particle];
+                        const V3<R>& pj = bj.positions[ej.particle];
+                        if ((pi - pj).norm_squared() <= h2) {
+                            Contact<R> c{ei.particle, ei.model, ej.particle, ej.model, 0, V3<R>()};
+                            bb[ei.model].push(ei.particle, c, thr);
+                            if (!same_cell) bb[ej.model].push(ej.particle, c.flip(), thr);
+                        }
+                    } else {
+                        if (same_cell) continue;  // handled when particle_i is the fluid particle
+                        const Boundary<R>& bi = boundaries[ei.model];
+                        const Fluid<R>& fj = fluids[ej.model];
+                        if (!bi.groups.test(fj.groups)) continue;
+                        const V3<R>& pi = bi.positions[ei.particle];
+                        const V3<R>& pj = fj.positions[ej.particle];
+                        if ((pi - pj).norm_squared() <= h2) {
+                            Contact<R> c{ej.particle, ej.model, ei.particle, ei.model, 0, V3<R>()};
+                            fb[ej.model].push(ej.particle, c, thr);
+                        }
+                    }
+                }
+            } else {
+                for (const Entry& ej : nbr) {
+                    const Fluid<R>& fi = fluids[ei.model];
+                    const V3<R> pi = fi.positions[ei.particle];
+                    V3<R> pj;
+                    if (ej.is_boundary) {
+                        const Boundary<R>& bj = boundaries[ej.model];
+                        if (!fi.groups.test(bj.groups)) continue;
+                        pj = bj.positions[ej.particle];
+                    } else {
+                        if (ei.model != ej.model) {
+                            if (!fi.groups.test(fluids[ej.model].groups)) continue;
+                        }
+                        pj = fluids[ej.model].positions[ej.particle];
+                    }
+                    if ((pi - pj).norm_squared() <= h2) {
+                        Contact<R> c{ei.particle, ei.model, ej.particle, ej.model, 0, V3<R>()};
+                        if (ej.is_boundary) {
+                            fb[ei.model].push(ei.particle, c, thr);
+                        } else {
+                            ff[ei.model].push(ei.particle, c, thr);
+                            if (!same_cell) ff[ej.model].push(ej.particle, c.flip(), thr);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ contacts.rs:154-252
+    void compute_contacts() {
+        ff.resize(fluids.size()); fb.resize(fluids.size()); bb.resize(boundaries.size());
+        for (size_t f = 0; f < fluids.size(); ++f) { ff[f].reset(fluids[f].n()); fb[f].reset(fluids[f].n()); }
+        for (size_t b = 0; b < boundaries.size(); ++b) bb[b].reset(boundaries[b].n());
+
+        static const int nb[14][3] = {{0, 0, 0},  {0, 0, 1},  {0, 1, -1}, {0, 1, 0},  {0, 1, 1},
+                                      {1, -1, -1}, {1, -1, 0}, {1, -1, 1}, {1, 0, -1}, {1, 0, 0},
+                                      {1, 0, 1},  {1, 1, -1}, {1, 1, 0},  {1, 1, 1}};
+        std::vector<uint32_t> order(grid.used);
+        for (size_t i = 0; i < grid.used; ++i) order[i] = (uint32_t)i;
+        if (shuffle_seed) {
+            std::mt19937_64 rng(shuffle_seed);
+            std::shuffle(order.begin(), order.end(), rng);
+        }
+        const long ncells = (long)grid.used;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads) if (nthreads > 1)
+        for (long ci = 0; ci < ncells; ++ci) {
+            const Cell& cc = grid.keys[order[ci]];
+            const std::vector<Entry>& cp = grid.cells[order[ci]];
+            for (int s = 0; s < 14; ++s) {
+                Cell nc{cc.x + nb[s][0], cc.y + nb[s][1], cc.z + nb[s][2]};
+                const std::vector<Entry>* np = grid.cell(nc);
+                if (np) contacts_for_pair_of_cells(cc, cp, nc, *np);
+            }
+        }
+    }
+
+    uint64_t ncontacts() const {  // contact_manager.rs:31-47
+        uint64_t s = 0;
+        for (auto& c : ff) s += c.len();
+        for (auto& c : fb) s += c.len();
+        for (auto& c : bb) s += c.len();
+        return s;
+    }
+
+    // ------------------------------------------------------------------ helper.rs:9-65
+    void evaluate_kernels() {
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const long n = (long)fluids[f].n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                for (auto& c : ff[f].contacts[i]) {
+                    const V3<R>& pi = fluids[c.i_model].positions[c.i];
+                    const V3<R>& pj = fluids[c.j_model].positions[c.j];
+                    c.weight = CubicSpline<R>::apply(pi - pj, h);
+                    c.gradient = CubicSpline<R>::apply_diff(pi - pj, h);
+                }
+                for (auto& c : fb[f].contacts[i]) {
+                    const V3<R>& pi = fluids[c.i_model].positions[c.i];
+                    const V3<R>& pj = boundaries[c.j_model].positions[c.j];
+                    c.weight = CubicSpline<R>::apply(pi - pj, h);
+                    c.gradient = CubicSpline<R>::apply_diff(pi - pj, h);
+                }
+            }
+        }
+        for (size_t b = 0; b < boundaries.size(); ++b) {
+            const long n = (long)boundaries[b].n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                for (auto& c : bb[b].contacts[i]) {
+                    const V3<R>& pi = boundaries[c.i_model].positions[c.i];
+                    const V3<R>& pj = boundaries[c.j_model].positions[c.j];
+                    c.weight = CubicSpline<R>::apply(pi - pj, h);
+                    c.gradient = CubicSpline<R>::apply_diff(pi - pj, h);
+                }
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ dfsph_solver.rs:72-96 / iisph :66-90
+    void compute_boundary_volumes() {
+        for (size_t b = 0; b < boundaries.size(); ++b) {
+            const long n = (long)boundaries[b].n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                R denominator = 0;
+                for (auto& c : bb[b].contacts[i]) denominator += c.weight;
+                assert(denominator != 0);
+                boundaries[b].volumes[i] = (R)1 / denominator;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ dfsph_solver.rs:628-665 / iisph :598-640
+    void compute_densities() {
+        compute_boundary_volumes();
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const long n = (long)fluids[f].n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                R density = 0;
+                for (auto& c : ff[f].contacts[i]) density += fluids[c.j_model].particle_mass(c.j) * c.weight;
+                for (auto& c : fb[f].contacts[i])
+                    density += boundaries[c.j_model].volumes[c.j] * fluids[c.i_model].density0 * c.weight;
+                assert(density != 0);
+                densities[f][i] = density;
+            }
+        }
+    }
+
+    void apply_force(Boundary<R>& b, size_t i, const V3<R>& f) {  // boundary.rs:62-67
+        if (!b.has_forces) return;
+        if (threaded()) {
+#pragma omp critical(boundary_force)
+            b.forces[i] += f;
+        } else b.forces[i] += f;
+    }
+
+    // ================================================================== DFSPH
+    // dfsph_solver.rs:165-216
+    void compute_alphas() {
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const Fluid<R>& fluid_i = fluids[f];
+            const long n = (long)fluid_i.n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                V3<R> grad_sum; R squared_grad_sum = 0;
+                for (auto& c : ff[f].contacts[i]) {
+                    V3<R> grad_i = c.gradient * fluids[c.j_model].particle_mass(c.j);
+                    squared_grad_sum += grad_i.norm_squared();
+                    grad_sum += grad_i;
+                }
+                for (auto& c : fb[f].contacts[i]) {
+                    V3<R> grad_i = c.gradient * boundaries[c.j_model].volumes[c.j] * fluid_i.density0;
+                    squared_grad_sum += grad_i.norm_squared();
+                    grad_sum += grad_i;
+                }
+                R denominator = squared_grad_sum + grad_sum.norm_squared();
+                alphas[f][i] = (denominator <= (R)1.0e-5) ? (R)0 : (R)1 / denominator;
+            }
+        }
+    }
+
+    // dfsph_solver.rs:279-356
+    R compute_divergences() {
+        R max_error = 0;
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const Fluid<R>& fluid_i = fluids[f];
+            const long n = (long)fluid_i.n();
+            std::vector<R> errs(n);
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                R div = 0;
+                if (ff[f].contacts[i].size() + fb[f].contacts[i].size() < min_neighbors_for_divergence_solve) {
+                    divergences[f][i] = 0; errs[i] = 0; continue;
+                }
+                for (auto& c : ff[f].contacts[i]) {
+                    const Fluid<R>& fluid_j = fluids[c.j_model];
+                    V3<R> v_i = fluid_i.velocities[c.i] + velocity_changes[c.i_model][c.i];
+                    V3<R> v_j = fluid_j.velocities[c.j] + velocity_changes[c.j_model][c.j];
+                    V3<R> dvel = v_i - v_j;
+                    div += dvel.dot(c.gradient) * fluid_j.particle_mass(c.j);
+                }
+                for (auto& c : fb[f].contacts[i]) {
+                    V3<R> v_i = fluid_i.velocities[c.i] + velocity_changes[c.i_model][c.i];
+                    div += v_i.dot(c.gradient) * boundaries[c.j_model].volumes[c.j] * fluid_i.density0;
+                }
+                div = std::max(div, (R)0);
+                divergences[f][i] = div;
+                errs[i] = div / fluid_i.density0;
+            }
+            R err = 0;  // par_reduce_sum! (serial fold order)
+            for (long i = 0; i < n; ++i) err = err + errs[i];
+            if (n != 0) max_error = std::max(max_error, err / (R)(double)n);
+        }
+        return max_error;
+    }
+
+    // dfsph_solver.rs:358-409
+    void compute_velocity_changes_for_divergence() {
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const Fluid<R>& fluid1 = fluids[f];
+            const long n = (long)fluid1.n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                V3<R>& velocity_change = velocity_changes[f][i];
+                R ki = divergences[f][i] * alphas[f][i];
+                for (auto& c : ff[f].contacts[i]) {
+                    const Fluid<R>& fluid2 = fluids[c.j_model];
+                    R kj = divergences[c.j_model][c.j] * alphas[c.j_model][c.j];
+                    R coeff = -(ki + kj) * fluid2.particle_mass(c.j);
+                    velocity_change += c.gradient * coeff;
+                }
+                for (auto& c : fb[f].contacts[i]) {
+                    Boundary<R>& boundary2 = boundaries[c.j_model];
+                    R coeff = -ki * boundary2.volumes[c.j] * fluid1.density0;
+                    V3<R> delta = c.gradient * coeff;
+                    velocity_change += delta;
+                    R particle_mass = fluid1.particle_mass(c.i);
+                    apply_force(boundary2, c.j, delta * (-inv_dt * particle_mass));
+                }
+            }
+        }
+    }
+
+    // dfsph_solver.rs:98-162
+    R compute_predicted_densities_dfsph() {
+        R max_error = 0;
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const Fluid<R>& fluid_i = fluids[f];
+            const long n = (long)fluid_i.n();
+            std::vector<R> errs(n);
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                R delta = 0;
+                for (auto& c : ff[f].contacts[i]) {
+                    const Fluid<R>& fluid_j = fluids[c.j_model];
+                    V3<R> vi = fluid_i.velocities[c.i] + velocity_changes[c.i_model][c.i];
+                    V3<R> vj = fluid_j.velocities[c.j] + velocity_changes[c.j_model][c.j];
+                    delta += fluid_j.particle_mass(c.j) * (vi - vj).dot(c.gradient);
+                }
+                for (auto& c : fb[f].contacts[i]) {
+                    V3<R> vi = fluid_i.velocities[c.i] + velocity_changes[c.i_model][c.i];
+                    V3<R> vj = boundaries[c.j_model].velocities[c.j];
+                    delta += boundaries[c.j_model].volumes[c.j] * fluid_i.density0 * (vi - vj).dot(c.gradient);
+                }
+                R pd = densities[f][i] + delta * dt;
+                assert(pd != 0);
+                predicted_densities[f][i] = pd;
+                errs[i] = (pd < fluid_i.density0) ? (R)0 : pd / fluid_i.density0 - (R)1;
+            }
+            R err = 0;
+            for (long i = 0; i < n; ++i) err = err + errs[i];
+            if (n != 0) max_error = std::max(max_error, err / (R)(double)n);
+        }
+        return max_error;
+    }
+
+    // dfsph_solver.rs:218-277
+    void compute_velocity_changes_dfsph() {
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const Fluid<R>& fluid1 = fluids[f];
+            const long n = (long)fluid1.n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                V3<R>& velocity_change = velocity_changes[f][i];
+                R ki = (predicted_densities[f][i] - fluid1.density0) * alphas[f][i];
+                for (auto& c : ff[f].contacts[i]) {
+                    const Fluid<R>& fluid2 = fluids[c.j_model];
+                    R kj = (predicted_densities[c.j_model][c.j] - fluid2.density0) * alphas[c.j_model][c.j];
+                    R kij = std::max(ki, (R)0) + std::max(kj, (R)0);
+                    if (kij > (R)0) {
+                        R coeff = kij * fluid2.particle_mass(c.j);
+                        velocity_change -= c.gradient * (coeff * inv_dt);
+                    }
+                }
+                if (ki > (R)0) {
+                    for (auto& c : fb[f].contacts[i]) {
+                        R coeff = ki * boundaries[c.j_model].volumes[c.j] * fluid1.density0;
+                        V3<R> delta = c.gradient * (coeff * inv_dt);
+                        velocity_change -= delta;
+                        R particle_mass = fluid1.particle_mass(c.i);
+                        apply_force(boundaries[c.j_model], c.j, delta * (inv_dt * particle_mass));
+                    }
+                }
+            }
+        }
+    }
+
+    // ================================================================== non-pressure forces
+    // xsph_viscosity.rs:31-95
+    void solve_xsph(size_t f, Force<R>& force) {
+        Fluid<R>& fluid = fluids[f];
+        const R fc = force.p[0], bc = force.p[1];
+        const R density0 = fluid.density0;
+        const std::vector<R>& dens = densities[f];
+        const long n = (long)fluid.n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+        for (long i = 0; i < n; ++i) {
+            V3<R> added_fluid_vel, added_boundary_vel;
+            V3<R> vi = fluid.velocities[i];
+            if (fc != (R)0) {
+                for (auto& c : ff[f].contacts[i]) {
+                    if (c.i_model == c.j_model) {
+                        added_fluid_vel += (fluid.velocities[c.j] - vi) *
+                                           (fc * c.weight * fluid.volumes[c.j] * density0 / dens[c.j]);
+                    }
+                }
+            }
+            if (bc != (R)0) {
+                for (auto& c : fb[f].contacts[i]) {
+                    V3<R> delta = (boundaries[c.j_model].velocities[c.j] - vi) *
+                                  (bc * c.weight * boundaries[c.j_model].volumes[c.j] * density0 / dens[c.i]);
+                    added_boundary_vel += delta;
+                    R mi = fluid.volumes[c.i] * density0;
+                    apply_force(boundaries[c.j_model], c.j, delta * (-mi * inv_dt));
+                }
+            }
+            fluid.accelerations[i] += added_fluid_vel * inv_dt + added_boundary_vel * inv_dt;
+        }
+    }
+
+    // artificial_viscosity.rs:41-124
+    void solve_artificial(size_t f, Force<R>& force) {
+        Fluid<R>& fluid = fluids[f];
+        const R fc = force.p[0], bc = force.p[1], alpha = force.p[2], beta = force.p[3], speed_of_sound = force.p[4];
+        const R density0 = fluid.density0;
+        const std::vector<R>& dens = densities[f];
+        const R kernel_radius = h;
+        const long n = (long)fluid.n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+        for (long i = 0; i < n; ++i) {
+            V3<R> fluid_acc, boundary_acc;
+            if (fc != (R)0) {
+                for (auto& c : ff[f].contacts[i]) {
+                    if (c.i_model == c.j_model) {
+                        V3<R> r_ij = fluid.positions[c.i] - fluid.positions[c.j];
+                        V3<R> v_ij = fluid.velocities[c.i] - fluid.velocities[c.j];
+                        R vr = r_ij.dot(v_ij);
+                        if (vr < (R)0) {
+                            R density_average = (dens[c.i] + dens[c.j]) * (R)0.5;
+                            R eta2 = kernel_radius * kernel_radius * (R)0.01;
+                            R mu_ij = kernel_radius * vr / (r_ij.norm_squared() + eta2);
+                            fluid_acc += c.gradient * (fc * (speed_of_sound * alpha * mu_ij - beta * mu_ij * mu_ij) *
+                                                       (fluid.volumes[c.j] * density0 / density_average));
+                        }
+                    }
+                }
+            }
+            if (bc != (R)0) {
+                for (auto& c : fb[f].contacts[i]) {
+                    V3<R> r_ij = fluid.positions[c.i] - boundaries[c.j_model].positions[c.j];
+                    V3<R> v_ij = fluid.velocities[c.i] - boundaries[c.j_model].velocities[c.j];
+                    R vr = r_ij.dot(v_ij);
+                    if (vr < (R)0) {
+                        R density_average = dens[c.i];
+                        R eta2 = kernel_radius * kernel_radius * (R)0.01;
+                        R mu_ij = kernel_radius * vr / (r_ij.norm_squared() + eta2);
+                        boundary_acc += c.gradient * (bc * (speed_of_sound * alpha * mu_ij - beta * mu_ij * mu_ij) *
+                                                      (boundaries[c.j_model].volumes[c.j] * density0 / density_average));
+                        R mi = fluid.volumes[c.i] * density0;
+                        // NOTE: the reference applies the *running sum* here (artificial_viscosity.rs:117).
+                        apply_force(boundaries[c.j_model], c.j, boundary_acc * -mi);
+                    }
+                }
+            }
+            fluid.accelerations[i] += fluid_acc + boundary_acc;
+        }
+    }
+
+    // akinci2013_surface_tension.rs:71-88
+    static R cohesion_kernel(R r, R hh) {
+        R normalizer = (R)32.0 / (CubicSpline<R>::PI * powi<R>(hh, 9));
+        R coeff;
+        if (r <= hh / (R)2) coeff = (R)2 * powi<R>(hh - r, 3) * powi<R>(r, 3) - powi<R>(hh, 6) / (R)64.0;
+        else if (r <= hh) coeff = powi<R>(hh - r, 3) * powi<R>(r, 3);
+        else coeff = 0;
+        return normalizer * coeff;
+    }
+    // akinci2013_surface_tension.rs:90-111
+    static R adhesion_kernel(R r, R hh) {
+        if (r > hh / (R)2 && r <= hh) {
+            R normalizer = (R)0.007 / std::pow(hh, (R)3.25);
+            R coeff = std::pow(std::max((R)-4 * r * r / hh + (R)6 * r - (R)2 * hh, (R)0), (R)0.25);
+            return normalizer * coeff;
+        }
+        return 0;
+    }
+
+    // akinci2013_surface_tension.rs:43-68, 114-192
+    void solve_akinci(size_t f, Force<R>& force) {
+        Fluid<R>& fluid = fluids[f];
+        const R tc = force.p[0], ac = force.p[1];
+        const R density0 = fluid.density0;
+        const std::vector<R>& dens = densities[f];
+        const R kernel_radius = h;
+        const long n = (long)fluid.n();
+        if (force.normals.size() != (size_t)n) force.normals.resize(n, V3<R>());
+        std::vector<V3<R>>& normals = force.normals;
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+        for (long i = 0; i < n; ++i) {
+            V3<R> normal;
+            for (auto& c : ff[f].contacts[i])
+                if (c.i_model == c.j_model) normal += c.gradient * (fluid.particle_mass(c.j) / dens[c.j]);
+            normals[i] = normal * kernel_radius;
+        }
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+        for (long i = 0; i < n; ++i) {
+            V3<R>& acceleration_i = fluid.accelerations[i];
+            if (tc != (R)0) {
+                for (auto& c : ff[f].contacts[i]) {
+                    if (c.i_model == c.j_model) {
+                        V3<R> dpos = fluid.positions[c.i] - fluid.positions[c.j];
+                        V3<R> dir; R dist; V3<R> cohesion_vec;
+                        if (try_new_and_get<R>(dpos, Eps<R>::v, dir, dist)) cohesion_vec = dir * cohesion_kernel(dist, kernel_radius);
+                        V3<R> cohesion_acc = cohesion_vec * (-tc * fluid.volumes[c.j] * density0);
+                        V3<R> curvature_acc = (normals[c.i] - normals[c.j]) * -tc;
+                        R kij = (R)2 * density0 / (dens[c.i] + dens[c.j]);
+                        acceleration_i += (curvature_acc + cohesion_acc) * kij;
+                    }
+                }
+            }
+            if (ac != (R)0) {
+                for (auto& c : fb[f].contacts[i]) {
+                    V3<R> dpos = fluid.positions[c.i] - boundaries[c.j_model].positions[c.j];
+                    V3<R> dir; R dist; V3<R> adhesion_vec;
+                    if (try_new_and_get<R>(dpos, Eps<R>::v, dir, dist)) adhesion_vec = dir * adhesion_kernel(dist, kernel_radius);
+                    R mi = fluid.volumes[c.i] * density0;
+                    R mj = boundaries[c.j_model].volumes[c.j] * density0;
+                    V3<R> adhesion_acc = adhesion_vec * (ac * mj);
+                    acceleration_i -= adhesion_acc;
+                    apply_force(boundaries[c.j_model], c.j, adhesion_acc * mi);
+                }
+            }
+        }
+    }
+
+    // dfsph_solver.rs:565-604 / iisph_solver.rs:541-580
+    void predict_advection(const V3<R>& gravity) {
+        for (auto& fluid : fluids) {
+            const long n = (long)fluid.n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) fluid.accelerations[i] += gravity;
+        }
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            for (auto& force : fluids[f].forces) {
+                switch (force.kind) {
+                    case FORCE_XSPH: solve_xsph(f, force); break;
+                    case FORCE_ARTIFICIAL: solve_artificial(f, force); break;
+                    case FORCE_AKINCI2013: solve_akinci(f, force); break;
+                    default: break;
+                }
+            }
+        }
+    }
+
+    void advance() {  // timestep_manager.rs:76-94
+        R substep = total_step_size;
+        dt = substep;
+        inv_dt = (substep == (R)0) ? (R)0 : (R)1 / substep;
+        remaining_time -= dt;
+    }
+
+    // dfsph_solver.rs:505-519 / iisph :458-471
+    void integrate_and_clear_accelerations() {
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const long n = (long)fluids[f].n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                velocity_changes[f][i] += fluids[f].accelerations[i] * dt;
+                fluids[f].accelerations[i].fill(0);
+            }
+        }
+    }
+
+    // dfsph_solver.rs:667-708
+    void dfsph_step(const V3<R>& gravity) {
+        compute_alphas();
+        // divergence_solve :466-503
+        stats.n_div_iters = 0;
+        for (int i = 0; i < max_divergence_iter; ++i) {
+            R avg_err = compute_divergences();
+            stats.div_error = (double)avg_err;
+            R max_err = max_divergence_error * inv_dt * (R)0.01;
+            if (avg_err <= max_err && i >= min_divergence_iter) break;
+            compute_velocity_changes_for_divergence();
+            stats.n_div_iters++;
+        }
+        // update_velocities :422-430 ; zero velocity changes :689-691
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const long n = (long)fluids[f].n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                fluids[f].velocities[i] += velocity_changes[f][i];
+                velocity_changes[f][i].fill(0);
+            }
+        }
+        predict_advection(gravity);
+        advance();
+        integrate_and_clear_accelerations();
+        // pressure_solve :432-464
+        stats.n_press_iters = 0;
+        for (int i = 0; i < max_pressure_iter; ++i) {
+            R avg_err = compute_predicted_densities_dfsph();
+            stats.density_error = (double)avg_err;
+            if (avg_err <= max_density_error && i >= min_pressure_iter) break;
+            compute_velocity_changes_dfsph();
+            stats.n_press_iters++;
+        }
+        // update_positions :411-420
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const long n = (long)fluids[f].n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i)
+                fluids[f].positions[i] += (fluids[f].velocities[i] + velocity_changes[f][i]) * dt;
+        }
+    }
+
+    // ================================================================== IISPH
+    // iisph_solver.rs:92-142
+    void compute_predicted_densities_iisph() {
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const Fluid<R>& fluid_i = fluids[f];
+            const long n = (long)fluid_i.n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                R delta = 0;
+                for (auto& c : ff[f].contacts[i]) {
+                    const Fluid<R>& fluid_j = fluids[c.j_model];
+                    V3<R> vi = fluid_i.velocities[c.i] + velocity_changes[c.i_model][c.i];
+                    V3<R> vj = fluid_j.velocities[c.j] + velocity_changes[c.j_model][c.j];
+                    delta += fluid_j.particle_mass(c.j) * (vi - vj).dot(c.gradient);
+                }
+                for (auto& c : fb[f].contacts[i]) {
+                    V3<R> vi = fluid_i.velocities[c.i] + velocity_changes[c.i_model][c.i];
+                    V3<R> vj = boundaries[c.j_model].velocities[c.j];
+                    delta += boundaries[c.j_model].volumes[c.j] * fluid_i.density0 * (vi - vj).dot(c.gradient);
+                }
+                predicted_densities[f][i] = densities[f][i] + delta * dt;
+                assert(predicted_densities[f][i] != 0);
+            }
+        }
+    }
+    // iisph_solver.rs:144-186
+    void compute_dii() {
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const Fluid<R>& fluid_i = fluids[f];
+            const long n = (long)fluid_i.n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                V3<R> d;
+                R rhoi = densities[f][i];
+                R factor = -dt * dt / (rhoi * rhoi);
+                for (auto& c : ff[f].contacts[i]) {
+                    R mj = fluids[c.j_model].particle_mass(c.j);
+                    d += c.gradient * (mj * factor);
+                }
+                for (auto& c : fb[f].contacts[i]) {
+                    R mj = boundaries[c.j_model].volumes[c.j] * fluid_i.density0;
+                    d += c.gradient * (mj * factor);
+                }
+                dii[f][i] = d;
+            }
+        }
+    }
+    // iisph_solver.rs:188-233
+    void compute_aii() {
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const Fluid<R>& fluid_i = fluids[f];
+            const long n = (long)fluid_i.n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                R a = 0;
+                R rhoi = densities[f][i];
+                R mi = fluid_i.particle_mass(i);
+                R factor = dt * dt * mi / (rhoi * rhoi);
+                for (auto& c : ff[f].contacts[i]) {
+                    R mj = fluids[c.j_model].particle_mass(c.j);
+                    V3<R> dji = c.gradient * factor;
+                    a += mj * (dii[f][c.i] - dji).dot(c.gradient);
+                }
+                for (auto& c : fb[f].contacts[i]) {
+                    R mj = boundaries[c.j_model].volumes[c.j] * fluid_i.density0;
+                    V3<R> dji = c.gradient * factor;
+                    a += mj * (dii[f][c.i] - dji).dot(c.gradient);
+                }
+                aii[f][i] = a;
+            }
+        }
+    }
+    // iisph_solver.rs:235-268
+    void compute_dij_pjl() {
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const long n = (long)fluids[f].n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                V3<R> d;
+                for (auto& c : ff[f].contacts[i]) {
+                    R rhoj = densities[c.j_model][c.j];
+                    R mj = fluids[c.j_model].particle_mass(c.j);
+                    R p_jl = pressures[c.j_model][c.j];
+                    d += c.gradient * (-mj * p_jl / (rhoj * rhoj));
+                }
+                d *= dt * dt;
+                dij_pjl[f][i] = d;
+            }
+        }
+    }
+    // iisph_solver.rs:270-353
+    R compute_next_pressures() {
+        R max_error = 0;
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const Fluid<R>& fluid_i = fluids[f];
+            const long n = (long)fluid_i.n();
+            std::vector<R> errs(n);
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                R& next_pressure = next_pressures[f][i];
+                if (std::abs(aii[f][i]) > (R)1.0e-9) {
+                    R sum = 0;
+                    R pi = pressures[f][i];
+                    R mi = fluid_i.particle_mass(i);
+                    R rhoi = densities[f][i];
+                    R derr = fluid_i.density0 - predicted_densities[f][i];
+                    for (auto& c : ff[f].contacts[i]) {
+                        R mj = fluids[c.j_model].particle_mass(c.j);
+                        V3<R> dji = c.gradient * (dt * dt * mi / (rhoi * rhoi));
+                        V3<R> factor = dij_pjl[c.i_model][c.i] - dii[c.j_model][c.j] * pressures[c.j_model][c.j] -
+                                       (dij_pjl[c.j_model][c.j] - dji * pi);
+                        sum += mj * factor.dot(c.gradient);
+                    }
+                    for (auto& c : fb[f].contacts[i]) {
+                        R mj = boundaries[c.j_model].volumes[c.j] * fluid_i.density0;
+                        sum += mj * dij_pjl[c.i_model][c.i].dot(c.gradient);
+                    }
+                    next_pressure = ((R)1 - omega) * pi + omega * (derr - sum) / aii[f][i];
+                    if (next_pressure > (R)0) {
+                        errs[i] = (-sum - aii[f][i] * next_pressure) / fluid_i.density0;
+                    } else {
+                        next_pressure = 0; errs[i] = 0;
+                    }
+                } else {
+                    next_pressure = 0; errs[i] = 0;
+                }
+            }
+            R err = 0;
+            for (long i = 0; i < n; ++i) err = err + errs[i];
+            if (n != 0) max_error = std::max(max_error, err / (R)(double)n);
+        }
+        return max_error;
+    }
+    // iisph_solver.rs:355-404
+    void compute_velocity_changes_iisph() {
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const Fluid<R>& fluid_i = fluids[f];
+            const long n = (long)fluid_i.n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                V3<R>& velocity_change = velocity_changes[f][i];
+                R pi = pressures[f][i];
+                R rhoi = densities[f][i];
+                for (auto& c : ff[f].contacts[i]) {
+                    R mj = fluids[c.j_model].particle_mass(c.j);
+                    R pj = pressures[c.j_model][c.j];
+                    R rhoj = densities[c.j_model][c.j];
+                    velocity_change -= c.gradient * (dt * mj * (pi / (rhoi * rhoi) + pj / (rhoj * rhoj)));
+                }
+                for (auto& c : fb[f].contacts[i]) {
+                    R mj = boundaries[c.j_model].volumes[c.j] * fluid_i.density0;
+                    V3<R> acc = c.gradient * (mj * pi / (rhoi * rhoi));
+                    velocity_change -= acc * dt;
+                    R mi = fluid_i.particle_mass(c.i);
+                    apply_force(boundaries[c.j_model], c.j, acc * mi);
+                }
+            }
+        }
+    }
+    // iisph_solver.rs:643-711
+    void iisph_step(const V3<R>& gravity) {
+        stats.n_div_iters = 0; stats.div_error = 0;
+        predict_advection(gravity);
+        advance();
+        integrate_and_clear_accelerations();
+        compute_dii();
+        for (auto& v : pressures) for (auto& p : v) p *= (R)0.5;
+        compute_predicted_densities_iisph();
+        compute_aii();
+        // pressure_solve :422-456
+        stats.n_press_iters = 0;
+        for (int i = 0; i < max_pressure_iter; ++i) {
+            compute_dij_pjl();
+            R avg_err = compute_next_pressures();
+            stats.density_error = (double)avg_err;
+            std::swap(pressures, next_pressures);
+            stats.n_press_iters++;
+            if (avg_err <= max_density_error && i >= min_pressure_iter) break;
+        }
+        compute_velocity_changes_iisph();
+        // update_velocities_and_positions :406-420 ; zero velocity changes :707-709
+        for (size_t f = 0; f < fluids.size(); ++f) {
+            const long n = (long)fluids[f].n();
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+            for (long i = 0; i < n; ++i) {
+                fluids[f].velocities[i] += velocity_changes[f][i];
+                fluids[f].positions[i] += fluids[f].velocities[i] * dt;
+                velocity_changes[f][i].fill(0);
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ liquid_world.rs:67-158
+    void step(R step_dt, const V3<R>& gravity) {
+        double t0 = now_ms();
+        total_step_size = step_dt; remaining_time = step_dt;  // timestep_manager.reset
+        init_with_fluids();
+        stats = StepStats{};
+        while (!(remaining_time <= Eps<R>::v)) {  // is_done, timestep_manager.rs:56-58
+            double ta = now_ms();
+            grid.clear();
+            insert_to_grid();
+            double tb = now_ms();
+            compute_contacts();
+            stats.ncontacts = ncontacts();
+            double tc = now_ms();
+            evaluate_kernels();
+            double td = now_ms();
+            compute_densities();
+            if (solver_kind == 0) dfsph_step(gravity); else iisph_step(gravity);
+            double te = now_ms();
+            stats.t_grid_ms += tb - ta; stats.t_contacts_ms += tc - tb;
+            stats.t_kernels_ms += td - tc; stats.t_solver_ms += te - td;
+        }
+        stats.t_total_ms = now_ms() - t0;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Type-erased handle for the C ABI (f32 and f64 builds of the same restatement).
+// ---------------------------------------------------------------------------------------------------
+struct Handle {
+    bool f64;
+    World<float>* wf = nullptr;
+    World<double>* wd = nullptr;
+};
+
+}  // namespace so
+
+using namespace so;
+
+#define DISPATCH(h, expr_f, expr_d) do { if ((h)->f64) { auto& w = *(h)->wd; expr_d; } else { auto& w = *(h)->wf; expr_f; } } while (0)
+
+template <typename R>
+static int add_fluid_t(World<R>& w, uint64_t n, const float* pos, const float* vel, float density0, uint32_t mem, uint32_t filt) {
+    Fluid<R> f;
+    f.positions.resize(n); f.velocities.resize(n); f.accelerations.resize(n);
+    R pr = w.particle_radius;
+    R vol = pr * pr * pr * (R)(8.0 * 0.8);  // fluid.rs:110-120
+    f.volumes.assign(n, vol);
+    for (uint64_t i = 0; i < n; ++i) {
+        f.positions[i] = V3<R>((R)pos[3 * i], (R)pos[3 * i + 1], (R)pos[3 * i + 2]);
+        if (vel) f.velocities[i] = V3<R>((R)vel[3 * i], (R)vel[3 * i + 1], (R)vel[3 * i + 2]);
+    }
+    f.density0 = (R)density0;
+    f.groups.memberships = mem; f.groups.filter = filt;
+    w.fluids.push_back(std::move(f));
+    return (int)w.fluids.size() - 1;
+}
+
+template <typename R>
+static int add_boundary_t(World<R>& w, uint64_t n, const float* pos, const float* vel, uint32_t mem, uint32_t filt, int wants_forces) {
+    Boundary<R> b;
+    b.positions.resize(n); b.velocities.resize(n); b.volumes.assign(n, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        b.positions[i] = V3<R>((R)pos[3 * i], (R)pos[3 * i + 1], (R)pos[3 * i + 2]);
+        if (vel) b.velocities[i] = V3<R>((R)vel[3 * i], (R)vel[3 * i + 1], (R)vel[3 * i + 2]);
+    }
+    b.groups.memberships = mem; b.groups.filter = filt;
+    b.has_forces = wants_forces != 0;
+    if (b.has_forces) b.forces.assign(n, V3<R>());
+    w.boundaries.push_back(std::move(b));
+    return (int)w.boundaries.size() - 1;
+}
+
+template <typename R>
+static void copy_v3(const std::vector<V3<R>>& v, double* out) {
+    for (size_t i = 0; i < v.size(); ++i) { out[3 * i] = v[i].x; out[3 * i + 1] = v[i].y; out[3 * i + 2] = v[i].z; }
+}
+template <typename R>
+static void copy_s(const std::vector<R>& v, double* out) { for (size_t i = 0; i < v.size(); ++i) out[i] = v[i]; }
+
+extern "C" {
+
+struct so_stats {
+    int32_t n_div_iters, n_press_iters;
+    double div_error, density_error;
+    uint64_t ncontacts;
+    double t_grid_ms, t_contacts_ms, t_kernels_ms, t_solver_ms, t_total_ms;
+};
+
+void* so_create(int use_f64, float particle_radius, float smoothing_factor, int solver_kind, int nthreads) {
+    Handle* h = new Handle();
+    h->f64 = use_f64 != 0;
+    if (h->f64) { h->wd = new World<double>((double)particle_radius, (double)smoothing_factor, solver_kind); h->wd->nthreads = nthreads; }
+    else { h->wf = new World<float>(particle_radius, smoothing_factor, solver_kind); h->wf->nthreads = nthreads; }
+    return h;
+}
+void so_destroy(void* p) { Handle* h = (Handle*)p; delete h->wf; delete h->wd; delete h; }
+
+void so_set_shuffle_seed(void* p, uint64_t seed) { Handle* h = (Handle*)p; DISPATCH(h, w.shuffle_seed = seed, w.shuffle_seed = seed); }
+void so_set_threads(void* p, int n) { Handle* h = (Handle*)p; DISPATCH(h, w.nthreads = n, w.nthreads = n); }
+void so_set_solver_params(void* p, int min_p, int max_p, float max_derr, int min_d, int max_d, float max_diverr) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h,
+        (w.min_pressure_iter = min_p, w.max_pressure_iter = max_p, w.max_density_error = max_derr, w.min_divergence_iter = min_d, w.max_divergence_iter = max_d, w.max_divergence_error = max_diverr),
+        (w.min_pressure_iter = min_p, w.max_pressure_iter = max_p, w.max_density_error = max_derr, w.min_divergence_iter = min_d, w.max_divergence_iter = max_d, w.max_divergence_error = max_diverr));
+}
+double so_h(void* p) { Handle* h = (Handle*)p; double r = 0; DISPATCH(h, r = w.h, r = w.h); return r; }
+
+int so_add_fluid(void* p, uint64_t n, const float* pos, const float* vel, float density0, uint32_t mem, uint32_t filt) {
+    Handle* h = (Handle*)p; int r = -1;
+    DISPATCH(h, r = add_fluid_t(w, n, pos, vel, density0, mem, filt), r = add_fluid_t(w, n, pos, vel, density0, mem, filt));
+    return r;
+}
+int so_add_boundary(void* p, uint64_t n, const float* pos, const float* vel, uint32_t mem, uint32_t filt, int wants_forces) {
+    Handle* h = (Handle*)p; int r = -1;
+    DISPATCH(h, r = add_boundary_t(w, n, pos, vel, mem, filt, wants_forces), r = add_boundary_t(w, n, pos, vel, mem, filt, wants_forces));
+    return r;
+}
+// kind: 1 XSPH(p0 fluid coeff, p1 boundary coeff); 2 Artificial(p0, p1, alpha, beta, speed_of_sound); 3 Akinci2013(p0 tension, p1 adhesion)
+int so_add_force(void* p, int fluid, int kind, const float* params, int nparams) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h,
+        { Force<float> f; f.kind = kind; for (int i = 0; i < nparams && i < 5; ++i) f.p[i] = params[i]; w.fluids[fluid].forces.push_back(f); },
+        { Force<double> f; f.kind = kind; for (int i = 0; i < nparams && i < 5; ++i) f.p[i] = (double)params[i]; w.fluids[fluid].forces.push_back(f); });
+    return 0;
+}
+void so_set_fluid_velocities(void* p, int fluid, const float* vel) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h,
+        { auto& f = w.fluids[fluid]; for (size_t i = 0; i < f.n(); ++i) f.velocities[i] = V3<float>(vel[3*i], vel[3*i+1], vel[3*i+2]); },
+        { auto& f = w.fluids[fluid]; for (size_t i = 0; i < f.n(); ++i) f.velocities[i] = V3<double>(vel[3*i], vel[3*i+1], vel[3*i+2]); });
+}
+void so_set_fluid_volumes(void* p, int fluid, const float* vol) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h,
+        { auto& f = w.fluids[fluid]; for (size_t i = 0; i < f.n(); ++i) f.volumes[i] = vol[i]; },
+        { auto& f = w.fluids[fluid]; for (size_t i = 0; i < f.n(); ++i) f.volumes[i] = (double)vol[i]; });
+}
+
+void so_step(void* p, float dt, float gx, float gy, float gz, so_stats* out) {
+    Handle* h = (Handle*)p;
+    StepStats s{};
+    DISPATCH(h, (w.step(dt, V3<float>(gx, gy, gz)), s = w.stats), (w.step((double)dt, V3<double>(gx, gy, gz)), s = w.stats));
+    if (out) {
+        out->n_div_iters = s.n_div_iters; out->n_press_iters = s.n_press_iters;
+        out->div_error = s.div_error; out->density_error = s.density_error; out->ncontacts = s.ncontacts;
+        out->t_grid_ms = s.t_grid_ms; out->t_contacts_ms = s.t_contacts_ms; out->t_kernels_ms = s.t_kernels_ms;
+        out->t_solver_ms = s.t_solver_ms; out->t_total_ms = s.t_total_ms;
+    }
+}
+
+uint64_t so_fluid_len(void* p, int fluid) { Handle* h = (Handle*)p; uint64_t r = 0; DISPATCH(h, r = w.fluids[fluid].n(), r = w.fluids[fluid].n()); return r; }
+uint64_t so_boundary_len(void* p, int b) { Handle* h = (Handle*)p; uint64_t r = 0; DISPATCH(h, r = w.boundaries[b].n(), r = w.boundaries[b].n()); return r; }
+
+// field: 0 positions, 1 velocities, 2 velocity_changes, 3 accelerations, 4 dii, 5 dij_pjl, 6 akinci normals (force index 0..)
+void so_get_fluid_vec(void* p, int fluid, int field, double* out) {
+    Handle* h = (Handle*)p;
+#define GETV(w) do { switch (field) { \
+        case 0: copy_v3(w.fluids[fluid].positions, out); break; \
+        case 1: copy_v3(w.fluids[fluid].velocities, out); break; \
+        case 2: copy_v3(w.velocity_changes[fluid], out); break; \
+        case 3: copy_v3(w.fluids[fluid].accelerations, out); break; \
+        case 4: copy_v3(w.dii[fluid], out); break; \
+        case 5: copy_v3(w.dij_pjl[fluid], out); break; \
+        case 6: for (auto& f : w.fluids[fluid].forces) if (f.kind == FORCE_AKINCI2013) { copy_v3(f.normals, out); break; } break; \
+        default: break; } } while (0)
+    DISPATCH(h, GETV(w), GETV(w));
+#undef GETV
+}
+// field: 0 densities, 1 alphas, 2 divergences, 3 predicted_densities, 4 volumes, 5 aii, 6 pressures
+void so_get_fluid_scalar(void* p, int fluid, int field, double* out) {
+    Handle* h = (Handle*)p;
+#define GETS(w) do { switch (field) { \
+        case 0: copy_s(w.densities[fluid], out); break; \
+        case 1: copy_s(w.alphas[fluid], out); break; \
+        case 2: copy_s(w.divergences[fluid], out); break; \
+        case 3: copy_s(w.predicted_densities[fluid], out); break; \
+        case 4: copy_s(w.fluids[fluid].volumes, out); break; \
+        case 5: copy_s(w.aii[fluid], out); break; \
+        case 6: copy_s(w.pressures[fluid], out); break; \
+        default: break; } } while (0)
+    DISPATCH(h, GETS(w), GETS(w));
+#undef GETS
+}
+// number of fluid-fluid (which = 0) / fluid-boundary (which = 1) contacts of each particle of `fluid`
+void so_get_contact_counts(void* p, int fluid, int which, uint32_t* out) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h,
+        { auto& pc = which ? w.fb[fluid] : w.ff[fluid]; for (size_t i = 0; i < pc.contacts.size(); ++i) out[i] = (uint32_t)pc.contacts[i].size(); },
+        { auto& pc = which ? w.fb[fluid] : w.ff[fluid]; for (size_t i = 0; i < pc.contacts.size(); ++i) out[i] = (uint32_t)pc.contacts[i].size(); });
+}
+// Sorted (j_model << 32 | j) keys of the contacts of one particle; returns count (writes at most cap entries).
+uint64_t so_get_contacts_of(void* p, int fluid, int which, uint64_t i, uint64_t* out, uint64_t cap) {
+    Handle* h = (Handle*)p; uint64_t n = 0;
+#define GETC(w) do { auto& v = (which ? w.fb[fluid] : w.ff[fluid]).contacts[i]; n = v.size(); std::vector<uint64_t> k; \
+        for (auto& c : v) k.push_back(((uint64_t)c.j_model << 32) | (uint64_t)c.j); std::sort(k.begin(), k.end()); \
+        for (uint64_t q = 0; q < n && q < cap; ++q) out[q] = k[q]; } while (0)
+    DISPATCH(h, GETC(w), GETC(w));
+#undef GETC
+    return n;
+}
+// field: 0 positions, 1 velocities, 2 forces
+void so_get_boundary_vec(void* p, int b, int field, double* out) {
+    Handle* h = (Handle*)p;
+#define GETB(w) do { switch (field) { \
+        case 0: copy_v3(w.boundaries[b].positions, out); break; \
+        case 1: copy_v3(w.boundaries[b].velocities, out); break; \
+        case 2: copy_v3(w.boundaries[b].forces, out); break; default: break; } } while (0)
+    DISPATCH(h, GETB(w), GETB(w));
+#undef GETB
+}
+void so_get_boundary_volumes(void* p, int b, double* out) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, copy_s(w.boundaries[b].volumes, out), copy_s(w.boundaries[b].volumes, out));
+}
+void so_clear_boundary_forces(void* p, int b) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, { for (auto& f : w.boundaries[b].forces) f.fill(0); }, { for (auto& f : w.boundaries[b].forces) f.fill(0); });
+}
+
+// Scalar kernel evaluations, for the analytic self-checks (f32 build).
+float so_kernel_w(float r, float h) { return CubicSpline<float>::scalar_apply(r, h); }
+float so_kernel_dw(float r, float h) { return CubicSpline<float>::scalar_apply_diff(r, h); }
+double so_kernel_w_f64(double r, double h) { return CubicSpline<double>::scalar_apply(r, h); }
+double so_kernel_dw_f64(double r, double h) { return CubicSpline<double>::scalar_apply_diff(r, h); }
+float so_cohesion_kernel(float r, float h) { return World<float>::cohesion_kernel(r, h); }
+float so_adhesion_kernel(float r, float h) { return World<float>::adhesion_kernel(r, h); }
+int so_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"

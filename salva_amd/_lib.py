@@ -1,0 +1,136 @@
+"""ctypes binding of `libsalva_hip.so` (C ABI: include/salva_hip.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises — there is no Python,
+PyTorch or CPU fallback for the fluid step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsalva_hip.so")
+
+OK, E_HIP, E_INVALID, E_NUMERIC, E_CAPACITY = 0, -1, -2, -3, -4
+SOLVER_DFSPH, SOLVER_IISPH = 0, 1
+FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013 = 1, 2, 3
+DIRTY_POSITIONS, DIRTY_VELOCITIES, DIRTY_VOLUMES, DIRTY_ACCELERATIONS, DIRTY_ALL = 1, 2, 4, 8, 15
+(FIELD_DENSITY, FIELD_ALPHA, FIELD_NUM_FLUID_CONTACTS, FIELD_NUM_BOUNDARY_CONTACTS, FIELD_VELOCITY_CHANGE,
+ FIELD_PRESSURE, FIELD_VOLUME, FIELD_ACCELERATION) = range(8)
+
+# every symbol include/salva_hip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTED_SYMBOLS = [
+    "salva_hip_default_params", "salva_hip_create", "salva_hip_destroy", "salva_hip_h", "salva_hip_set_fluid",
+    "salva_hip_set_fluid_forces", "salva_hip_remove_fluid", "salva_hip_set_boundary", "salva_hip_remove_boundary",
+    "salva_hip_num_fluids", "salva_hip_num_boundaries", "salva_hip_fluid_len", "salva_hip_boundary_len",
+    "salva_hip_step", "salva_hip_get_fluid", "salva_hip_get_fluid_field", "salva_hip_get_boundary",
+    "salva_hip_clear_boundary_forces", "salva_hip_device_bytes", "salva_hip_time_pred_density",
+    "salva_hip_last_error", "salva_hip_version",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("particle_radius", C.c_float),
+        ("smoothing_factor", C.c_float),
+        ("solver", C.c_int32),
+        ("min_pressure_iter", C.c_int32),
+        ("max_pressure_iter", C.c_int32),
+        ("max_density_error", C.c_float),
+        ("min_divergence_iter", C.c_int32),
+        ("max_divergence_iter", C.c_int32),
+        ("max_divergence_error", C.c_float),
+        ("device", C.c_int32),
+        ("enable_timers", C.c_int32),
+        ("reserved", C.c_int32 * 7),
+    ]
+
+
+class ForceDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("p", C.c_float * 7)]
+
+
+class StepStats(C.Structure):
+    _fields_ = [
+        ("n_divergence_iters", C.c_int32),
+        ("n_pressure_iters", C.c_int32),
+        ("divergence_error", C.c_float),
+        ("density_error", C.c_float),
+        ("ncontacts", C.c_uint64),
+        ("nparticles", C.c_uint64),
+        ("grid_ms", C.c_float),
+        ("solver_ms", C.c_float),
+        ("step_ms", C.c_float),
+        ("reserved", C.c_float * 5),
+    ]
+
+
+class SalvaHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"salva_hip error {code}: {message}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 with the committed Makefile (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(salva_amd has no fallback path)")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float
+    fp = C.POINTER(C.c_float)
+    L.salva_hip_default_params.argtypes = [C.POINTER(Params)]
+    L.salva_hip_default_params.restype = None
+    L.salva_hip_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.salva_hip_destroy.argtypes = [vp]
+    L.salva_hip_destroy.restype = None
+    L.salva_hip_h.argtypes = [vp]
+    L.salva_hip_h.restype = f32
+    L.salva_hip_set_fluid.argtypes = [vp, u32, u64, fp, fp, fp, fp, fp, f32, u32, u32, u32]
+    L.salva_hip_set_fluid_forces.argtypes = [vp, u32, C.POINTER(ForceDesc), u32]
+    L.salva_hip_remove_fluid.argtypes = [vp, u32]
+    L.salva_hip_set_boundary.argtypes = [vp, u32, u64, fp, fp, u32, u32, i32]
+    L.salva_hip_remove_boundary.argtypes = [vp, u32]
+    L.salva_hip_num_fluids.argtypes = [vp]
+    L.salva_hip_num_fluids.restype = u32
+    L.salva_hip_num_boundaries.argtypes = [vp]
+    L.salva_hip_num_boundaries.restype = u32
+    L.salva_hip_fluid_len.argtypes = [vp, u32]
+    L.salva_hip_fluid_len.restype = u64
+    L.salva_hip_boundary_len.argtypes = [vp, u32]
+    L.salva_hip_boundary_len.restype = u64
+    L.salva_hip_step.argtypes = [vp, f32, fp, C.POINTER(StepStats)]
+    L.salva_hip_get_fluid.argtypes = [vp, u32, fp, fp]
+    L.salva_hip_get_fluid_field.argtypes = [vp, u32, i32, fp]
+    L.salva_hip_get_boundary.argtypes = [vp, u32, fp, fp]
+    L.salva_hip_clear_boundary_forces.argtypes = [vp, u32]
+    L.salva_hip_device_bytes.argtypes = [vp]
+    L.salva_hip_device_bytes.restype = u64
+    L.salva_hip_time_pred_density.argtypes = [vp, i32]
+    L.salva_hip_time_pred_density.restype = f32
+    L.salva_hip_last_error.restype = C.c_char_p
+    L.salva_hip_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(code: int):
+    if code != OK:
+        raise SalvaHipError(code, lib().salva_hip_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,176 @@
+// capi.hip — the extern "C" boundary of libsalva_hip.so (declared in include/salva_hip.h).
+// Exceptions never cross the ABI: every entry point maps them to an error code + thread-local message.
+#include <cstring>
+#include <string>
+
+#include "world.h"
+
+using salva::World;
+
+struct SalvaHipWorld {
+    World* w;
+};
+
+static thread_local std::string g_last_error;
+
+template <typename F>
+static int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const salva::HipError& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return SALVA_HIP_E_HIP;
+    } catch (...) {
+        g_last_error = "unknown error";
+        return SALVA_HIP_E_HIP;
+    }
+}
+
+extern "C" {
+
+void salva_hip_default_params(SalvaHipParams* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->particle_radius = 0.05f;
+    p->smoothing_factor = 2.0f;
+    p->solver = SALVA_HIP_SOLVER_DFSPH;
+    p->min_pressure_iter = 1;      // dfsph_solver.rs:56 / iisph_solver.rs:50
+    p->max_pressure_iter = 50;     // :57 / :51
+    p->max_density_error = 0.05f;  // :58 / :52
+    p->min_divergence_iter = 1;    // :59
+    p->max_divergence_iter = 50;   // :60
+    p->max_divergence_error = 0.1f;  // :61
+    p->device = 0;
+    p->enable_timers = 0;
+}
+
+int salva_hip_create(const SalvaHipParams* params, SalvaHipWorld** out) {
+    return guarded([&]() -> int {
+        if (!params || !out) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        *out = nullptr;
+        World* w = new World(*params);
+        *out = new SalvaHipWorld{w};
+        return SALVA_HIP_OK;
+    });
+}
+
+void salva_hip_destroy(SalvaHipWorld* world) {
+    if (!world) return;
+    try { delete world->w; } catch (...) {}
+    delete world;
+}
+
+float salva_hip_h(const SalvaHipWorld* world) { return world ? world->w->sc.h : 0.0f; }
+
+int salva_hip_set_fluid(SalvaHipWorld* world, uint32_t slot, uint64_t n, const float* positions_xyz,
+                        const float* velocities_xyz, const float* volumes, const float* accelerations_xyz,
+                        const float* velocity_changes_xyz, float density0, uint32_t memberships, uint32_t filter,
+                        uint32_t dirty_mask) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->set_fluid(slot, n, positions_xyz, velocities_xyz, volumes, accelerations_xyz, velocity_changes_xyz,
+                            density0, memberships, filter, dirty_mask);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_set_fluid_forces(SalvaHipWorld* world, uint32_t slot, const SalvaHipForceDesc* forces, uint32_t nforces) {
+    return guarded([&]() -> int {
+        if (!world || (nforces && !forces)) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        world->w->set_fluid_forces(slot, forces, nforces);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_remove_fluid(SalvaHipWorld* world, uint32_t slot) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->remove_fluid(slot);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_set_boundary(SalvaHipWorld* world, uint32_t slot, uint64_t n, const float* positions_xyz,
+                           const float* velocities_xyz, uint32_t memberships, uint32_t filter, int32_t wants_forces) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->set_boundary(slot, n, positions_xyz, velocities_xyz, memberships, filter, wants_forces != 0);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_remove_boundary(SalvaHipWorld* world, uint32_t slot) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->remove_boundary(slot);
+        return SALVA_HIP_OK;
+    });
+}
+
+uint32_t salva_hip_num_fluids(const SalvaHipWorld* world) { return world ? (uint32_t)world->w->fluids.size() : 0; }
+uint32_t salva_hip_num_boundaries(const SalvaHipWorld* world) { return world ? (uint32_t)world->w->bounds.size() : 0; }
+uint64_t salva_hip_fluid_len(const SalvaHipWorld* world, uint32_t slot) {
+    return (world && slot < world->w->fluids.size()) ? world->w->fluids[slot].n : 0;
+}
+uint64_t salva_hip_boundary_len(const SalvaHipWorld* world, uint32_t slot) {
+    return (world && slot < world->w->bounds.size()) ? world->w->bounds[slot].n : 0;
+}
+
+int salva_hip_step(SalvaHipWorld* world, float dt, const float gravity[3], SalvaHipStepStats* stats) {
+    return guarded([&]() -> int {
+        if (!world || !gravity) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        return world->w->step(dt, gravity, stats);
+    });
+}
+
+int salva_hip_get_fluid(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->get_fluid(slot, positions_xyz, velocities_xyz);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_get_fluid_field(SalvaHipWorld* world, uint32_t slot, int32_t field, float* out) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->get_fluid_field(slot, field, out);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_get_boundary(SalvaHipWorld* world, uint32_t slot, float* volumes, float* forces_xyz) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->get_boundary(slot, volumes, forces_xyz);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_clear_boundary_forces(SalvaHipWorld* world, uint32_t slot) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->clear_boundary_forces(slot);
+        return SALVA_HIP_OK;
+    });
+}
+
+uint64_t salva_hip_device_bytes(const SalvaHipWorld* world) { return world ? world->w->device_bytes() : 0; }
+
+float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps) {
+    float us = -1.0f;
+    int rc = guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        us = world->w->time_pred_density(reps);
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? us : (float)rc;
+}
+
+const char* salva_hip_last_error(void) { return g_last_error.c_str(); }
+const char* salva_hip_version(void) { return "salva_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

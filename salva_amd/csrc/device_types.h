@@ -1,0 +1,94 @@
+// device_types.h — kernel argument bundles and the launcher interface between world.hip (host
+// orchestration) and the kernel translation units (grid.hip, dfsph.hip, iisph.hip, forces.hip).
+//
+// Data layout in HBM: every per-particle array is SoA over the *cell-sorted* particle
+// order; 3-vectors are float4 so that one 16-byte gather fetches everything a neighbour contributes:
+//   posm = (x, y, z, mass)            gathered by every neighbour pass
+//   w    = (v+dv x, y, z, model id)   gathered by the evaluate passes and by the viscosity/tension forces
+//   vel  = (v x, y, z, volume)        streamed only
+//   dv   = (dv x, y, z, pressure)     streamed only (pressure = IISPH warm start, carried across steps)
+// Neighbour lists are sliced-ELL with slice = one wavefront: entry k of the particle handled by lane l of
+// wave s is nbr[slice_off[s] + 64 k + l], so a wave reads 256 contiguous bytes per k.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "sph_math.h"
+
+namespace salva {
+
+// Dense cell table over the bounding box of one particle class.  cell_start has ncells+1 entries with
+// lower-bound semantics: cell_start[c] = first sorted index whose key >= c, so a run of consecutive cells
+// [c0, c1] is the index range [cell_start[c0], cell_start[c1 + 1]).  key = (ix * ny + iy) * nz + iz with
+// (ix,iy,iz) = floor(p / h) - origin (hgrid.rs:41-52): x is the slowest axis — the slab axis of the
+// multi-GPU decomposition — and z-neighbours are adjacent keys, so a 27-cell stencil is 9 contiguous runs.
+struct GridView {
+    int ox, oy, oz;
+    int nx, ny, nz;
+    const uint32_t* cell_start;
+};
+
+struct StepCtx {
+    SphConsts sc;
+    int xcd;  // XCD-aware block remap on/off
+
+    // ---- fluid particles, cell-sorted order ----
+    uint32_t n;
+    float4* posm;
+    float4* vel;
+    float4* dv;
+    float4* acc;
+    float4* w;
+    float4* normal;      // Akinci normals (xyz, unused)
+    uint32_t* model;
+    uint32_t* perm;      // sorted index -> canonical (host-order) index
+    float* rho;
+    float* alpha;
+    float* kappa;        // DFSPH: div*alpha or (rho* - rho0)*alpha ; IISPH: pressure p
+    float* kappa2;       // IISPH: next pressure
+    float* rho_star;     // IISPH predicted density
+    float* aii;          // IISPH
+    float4* dii;         // IISPH (xyz, unused)
+    float4* dijpj;       // IISPH sum_j d_ij p_j (xyz, unused)
+    uint32_t* nff;       // # fluid-fluid contacts of each particle (self included)
+    uint32_t* nfb;       // # fluid-boundary contacts
+    const uint64_t* slice_ff;
+    const uint32_t* nbr_ff;
+    const uint64_t* slice_fb;
+    const uint32_t* nbr_fb;
+    GridView gf;
+
+    // ---- boundary particles, cell-sorted order ----
+    uint32_t nb;
+    float4* bposv;       // (x, y, z, volume V_b)
+    float4* bvel;        // (vx, vy, vz, boundary model id)
+    uint32_t* bperm;     // sorted -> canonical boundary index
+    float4* bforce;      // canonical order accumulators (nullptr if no boundary wants forces)
+    const uint8_t* bwants;  // per boundary model: forces requested?
+    GridView gb;
+
+    // ---- per-model tables ----
+    uint32_t nmodels, nbmodels;
+    const float* rho0_tab;     // density0 of each fluid model
+    const uint8_t* ff_ok;      // [nmodels*nmodels] InteractionGroups::test between fluids (diagonal = 1)
+    const uint8_t* fb_ok;      // [nmodels*nbmodels]
+    const uint8_t* bb_ok;      // [nbmodels*nbmodels] (diagonal = 1)
+
+    // ---- reductions / flags ----
+    float* partials;     // [nblocks * nmodels] per-block error sums
+    uint32_t* flags;     // bit 0: numeric error (zero density / NaN), bit 1: particle outside grid
+    uint32_t min_neighbors_for_divergence;
+};
+
+// Result block the host reads back (pinned mirror).
+struct Readback {
+    float err;            // max over models of (sum / nparticles)
+    uint32_t flags;
+    int32_t bbox[6];      // fluid cell bbox (min xyz, max xyz)
+    int32_t bbbox[6];     // boundary cell bbox
+    uint64_t nbr_total_ff, nbr_total_fb;  // padded sliced-ELL entry counts
+    uint64_t ncontacts_ff, ncontacts_fb, ncontacts_bb;
+};
+
+}  // namespace salva

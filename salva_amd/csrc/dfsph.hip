@@ -1,0 +1,331 @@
+// dfsph.hip — DFSPH pressure solver passes as one-lane-per-particle gather kernels.
+//
+// Behaviour specified by /root/reference/src/solver/pressure/dfsph_solver.rs (line numbers cited per kernel)
+// and src/solver/helper.rs:9-65 (W / grad W are recomputed in-kernel from positions instead of being stored
+// per contact).  Every neighbour pass streams 4 B per contact (the index) plus the per-particle arrays, and
+// gathers the neighbour's 16-byte records through L1/L2.
+#include <climits>
+
+#include "kernels.h"
+#include "nbr_loops.h"
+
+namespace salva {
+
+unsigned num_blocks(uint32_t n) { return div_up(n, BLOCK); }
+
+// ------------------------------------------------------------------------------------------------
+// compute_densities (dfsph_solver.rs:628-665) fused with compute_alphas (:165-216): both depend on positions only.
+//   rho_i   = sum_j m_j W_ij + sum_b V_b rho0_i W_ib
+//   alpha_i = 1 / (sum |m_j grad W_ij|^2 + |sum m_j grad W_ij|^2), 0 if the denominator <= 1e-5
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_density_alpha(StepCtx c) {
+    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+    const uint32_t i = blk * BLOCK + threadIdx.x;
+    if (i >= c.n) return;
+    const float4 pi = c.posm[i];
+    const float rho0 = c.rho0_tab[c.model[i]];
+    float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f;
+    for_each_ff(c, i, [&](uint32_t j) {
+        const float4 pj = c.posm[j];
+        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
+        rho += pj.w * e.w;
+        const float gm = e.g * pj.w;
+        const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
+        sq += gx * gx + gy * gy + gz * gz;
+        gsx += gx; gsy += gy; gsz += gz;
+    });
+    for_each_fb(c, i, [&](uint32_t j) {
+        const float4 pj = c.bposv[j];
+        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
+        const float m = pj.w * rho0;
+        rho += m * e.w;
+        const float gm = e.g * m;
+        const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
+        sq += gx * gx + gy * gy + gz * gz;
+        gsx += gx; gsy += gy; gsz += gz;
+    });
+    if (!(rho > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!density.is_zero()) :662
+    const float denom = sq + (gsx * gsx + gsy * gsy + gsz * gsz);
+    c.rho[i] = rho;
+    c.alpha[i] = (denom <= 1.0e-5f) ? 0.0f : 1.0f / denom;
+}
+void launch_density_alpha(const StepCtx& c, hipStream_t s) {
+    if (c.n) k_density_alpha<<<num_blocks(c.n), BLOCK, 0, s>>>(c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// compute_divergences (:279-356): D rho_i = max(sum_j m_j (w_i - w_j).grad W_ij + sum_b V_b rho0 w_i.grad W_ib, 0),
+// skipped (0) when the particle has fewer than 20 contacts; stores kappa_i = D rho_i * alpha_i (the only use of
+// the divergence, :370,:382) and the per-particle error D rho_i / rho0.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_divergence(StepCtx c) {
+    __shared__ float red[BLOCK / WAVE];
+    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+    const uint32_t i = blk * BLOCK + threadIdx.x;
+    const bool active = i < c.n;
+    float err = 0.0f;
+    uint32_t mi = 0;
+    if (active) {
+        mi = c.model[i];
+        const float rho0 = c.rho0_tab[mi];
+        float div = 0.0f;
+        const uint32_t ncontacts = c.nff[i] + (c.nb ? c.nfb[i] : 0u);
+        if (ncontacts >= c.min_neighbors_for_divergence) {
+            const float4 pi = c.posm[i];
+            const float4 wi = c.w[i];
+            for_each_ff(c, i, [&](uint32_t j) {
+                const float4 pj = c.posm[j];
+                const float4 wj = c.w[j];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                div += ((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g * pj.w;
+            });
+            for_each_fb(c, i, [&](uint32_t j) {
+                const float4 pj = c.bposv[j];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                div += (wi.x * dx + wi.y * dy + wi.z * dz) * g * (pj.w * rho0);  // boundary velocity ignored (:332-333)
+            });
+            div = fmaxf(div, 0.0f);
+        }
+        c.kappa[i] = div * c.alpha[i];
+        err = div / rho0;
+    }
+    reduce_error(c, blk, err, mi, active, red);
+}
+void launch_divergence(const StepCtx& c, hipStream_t s) {
+    if (c.n) k_divergence<<<num_blocks(c.n), BLOCK, 0, s>>>(c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// compute_velocity_changes_for_divergence (:358-409): dv_i += sum_j grad W_ij (-(k_i + k_j) m_j)
+//                                                           + sum_b grad W_ib (-k_i V_b rho0), boundary reaction force.
+// Also refreshes w_i = v_i + dv_i for the next evaluate pass.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_divergence_apply(StepCtx c, float inv_dt_prev) {
+    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+    const uint32_t i = blk * BLOCK + threadIdx.x;
+    if (i >= c.n) return;
+    const float4 pi = c.posm[i];
+    const uint32_t mi = c.model[i];
+    const float rho0 = c.rho0_tab[mi];
+    const float ki = c.kappa[i];
+    float4 d = c.dv[i];
+    for_each_ff(c, i, [&](uint32_t j) {
+        const float4 pj = c.posm[j];
+        const float kj = c.kappa[j];
+        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+        const float coeff = -(ki + kj) * pj.w * g;
+        d.x += dx * coeff; d.y += dy * coeff; d.z += dz * coeff;
+    });
+    for_each_fb(c, i, [&](uint32_t j) {
+        const float4 pj = c.bposv[j];
+        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+        const float coeff = -ki * pj.w * rho0 * g;
+        const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
+        d.x += ex; d.y += ey; d.z += ez;
+        const float fs = -inv_dt_prev * pi.w;  // delta * (-inv_dt * particle_mass) :404-406
+        apply_boundary_force(c, j, __float_as_uint(c.bvel[j].w), ex * fs, ey * fs, ez * fs);
+    });
+    c.dv[i] = d;
+    const float4 v = c.vel[i];
+    c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
+}
+void launch_divergence_apply(const StepCtx& c, float inv_dt_prev, hipStream_t s) {
+    if (c.n) k_divergence_apply<<<num_blocks(c.n), BLOCK, 0, s>>>(c, inv_dt_prev);
+}
+
+// ------------------------------------------------------------------------------------------------
+// update_velocities (:422-430) + zero velocity changes (:689-691) + `acceleration += gravity` (:574-578).
+// v_new = v + dv is exactly the w written by the last apply pass.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_finish_divergence(StepCtx c, float gx, float gy, float gz, int acc_has_user) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= c.n) return;
+    const float4 wi = c.w[i];
+    const float4 v = c.vel[i];
+    const float4 d = c.dv[i];
+    c.vel[i] = make_float4(wi.x, wi.y, wi.z, v.w);
+    c.dv[i] = make_float4(0.0f, 0.0f, 0.0f, d.w);
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (acc_has_user) a = c.acc[i];
+    c.acc[i] = make_float4(a.x + gx, a.y + gy, a.z + gz, 0.0f);
+}
+void launch_finish_divergence(const StepCtx& c, float gx, float gy, float gz, bool acc_has_user, hipStream_t s) {
+    if (c.n) k_finish_divergence<<<num_blocks(c.n), BLOCK, 0, s>>>(c, gx, gy, gz, acc_has_user ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// integrate_and_clear_accelerations (:505-519): dv += a dt ; a = 0.  Refreshes w = v + dv.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_integrate(StepCtx c, float dt) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= c.n) return;
+    const float4 a = c.acc[i];
+    float4 d = c.dv[i];
+    d.x += a.x * dt; d.y += a.y * dt; d.z += a.z * dt;
+    c.dv[i] = d;
+    c.acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 v = c.vel[i];
+    c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(c.model[i]));
+}
+void launch_integrate(const StepCtx& c, float dt, hipStream_t s) {
+    if (c.n) k_integrate<<<num_blocks(c.n), BLOCK, 0, s>>>(c, dt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// compute_predicted_densities (:98-162): rho*_i = rho_i + dt (sum_j m_j (w_i - w_j).grad W_ij
+//                                                 + sum_b V_b rho0 (w_i - v_b).grad W_ib)
+// error_i = max(rho*_i / rho0 - 1, 0); stores kappa_i = (rho*_i - rho0) alpha_i (:234,:245).
+// This is THE representative neighbour-sum kernel of the roofline: N (4K + 52) bytes per launch.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_pred_density(StepCtx c, float dt) {
+    __shared__ float red[BLOCK / WAVE];
+    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+    const uint32_t i = blk * BLOCK + threadIdx.x;
+    const bool active = i < c.n;
+    float err = 0.0f;
+    uint32_t mi = 0;
+    if (active) {
+        mi = c.model[i];
+        const float rho0 = c.rho0_tab[mi];
+        const float4 pi = c.posm[i];
+        const float4 wi = c.w[i];
+        float delta = 0.0f;
+        for_each_ff(c, i, [&](uint32_t j) {
+            const float4 pj = c.posm[j];
+            const float4 wj = c.w[j];
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+            delta += pj.w * (((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g);
+        });
+        for_each_fb(c, i, [&](uint32_t j) {
+            const float4 pj = c.bposv[j];
+            const float4 vj = c.bvel[j];
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+            delta += pj.w * rho0 * (((wi.x - vj.x) * dx + (wi.y - vj.y) * dy + (wi.z - vj.z) * dz) * g);
+        });
+        const float rs = c.rho[i] + delta * dt;
+        if (!(rs != 0.0f)) atomicOr(c.flags, 1u);  // assert!(!predicted_density.is_zero()) :145 (also catches NaN)
+        err = (rs < rho0) ? 0.0f : rs / rho0 - 1.0f;
+        c.kappa[i] = (rs - rho0) * c.alpha[i];
+    }
+    reduce_error(c, blk, err, mi, active, red);
+}
+void launch_pred_density(const StepCtx& c, float dt, hipStream_t s) {
+    if (c.n) k_pred_density<<<num_blocks(c.n), BLOCK, 0, s>>>(c, dt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// compute_velocity_changes (:218-277): k_ij = max(k_i,0) + max(k_j,0); if k_ij > 0: dv_i -= grad W_ij k_ij m_j / dt.
+// Boundary term only when k_i > 0, with the reaction force delta * (inv_dt * m_i).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_pressure_apply(StepCtx c, float inv_dt) {
+    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+    const uint32_t i = blk * BLOCK + threadIdx.x;
+    if (i >= c.n) return;
+    const float4 pi = c.posm[i];
+    const uint32_t mi = c.model[i];
+    const float rho0 = c.rho0_tab[mi];
+    const float ki = c.kappa[i];
+    const float kip = fmaxf(ki, 0.0f);
+    float4 d = c.dv[i];
+    for_each_ff(c, i, [&](uint32_t j) {
+        // both gathers issue back to back; k_ij == 0 contributes exactly nothing, so no branch is needed
+        const float4 pj = c.posm[j];
+        const float kij = kip + fmaxf(c.kappa[j], 0.0f);
+        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+        const float coeff = kij * pj.w * inv_dt * g;
+        d.x -= dx * coeff; d.y -= dy * coeff; d.z -= dz * coeff;
+    });
+    if (ki > 0.0f) {
+        for_each_fb(c, i, [&](uint32_t j) {
+            const float4 pj = c.bposv[j];
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+            const float coeff = ki * pj.w * rho0 * inv_dt * g;
+            const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
+            d.x -= ex; d.y -= ey; d.z -= ez;
+            const float fs = inv_dt * pi.w;
+            apply_boundary_force(c, j, __float_as_uint(c.bvel[j].w), ex * fs, ey * fs, ez * fs);
+        });
+    }
+    c.dv[i] = d;
+    const float4 v = c.vel[i];
+    c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
+}
+void launch_pressure_apply(const StepCtx& c, float inv_dt, hipStream_t s) {
+    if (c.n) k_pressure_apply<<<num_blocks(c.n), BLOCK, 0, s>>>(c, inv_dt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// update_positions (:411-420): x += (v + dv) dt = w dt.  (v is NOT updated here — the velocity lag of the
+// reference.)  Also reduces the cell bounding box of the new positions for the next step's grid.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cell_of(float x, float h) {
+    float f = floorf(__fdiv_rn(x, h));
+    if (!(f == f)) f = 0.0f;
+    f = fminf(fmaxf(f, -1073741824.0f), 1073741824.0f);
+    return (int)f;
+}
+__device__ __forceinline__ void bbox_accumulate(bool active, float x, float y, float z, float h, int32_t* bbox6) {
+    int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+    if (active) {
+        mn[0] = mx[0] = cell_of(x, h); mn[1] = mx[1] = cell_of(y, h); mn[2] = mx[2] = cell_of(z, h);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_min_i32(mn[a]); mx[a] = wave_max_i32(mx[a]); }
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (mn[a] != INT_MAX) atomicMin(&bbox6[a], mn[a]);
+            if (mx[a] != INT_MIN) atomicMax(&bbox6[3 + a], mx[a]);
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_update_positions(StepCtx c, float dt, int32_t* bbox6) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = i < c.n;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        p = c.posm[i];
+        const float4 wi = c.w[i];
+        p.x += wi.x * dt; p.y += wi.y * dt; p.z += wi.z * dt;
+        c.posm[i] = p;
+        if (!(p.x == p.x) || !(p.y == p.y) || !(p.z == p.z)) atomicOr(c.flags, 1u);
+    }
+    bbox_accumulate(active, p.x, p.y, p.z, c.sc.h, bbox6);
+}
+void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox6, hipStream_t s) {
+    if (c.n) k_update_positions<<<num_blocks(c.n), BLOCK, 0, s>>>(c, dt, bbox6);
+}
+
+// ------------------------------------------------------------------------------------------------
+// err = max over fluids of (sum of per-particle errors / nparticles)  (:153-158, :347-352).  One block,
+// fixed summation order => run-to-run deterministic iteration counts.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_finalize_error(const float* __restrict__ partials, unsigned nblocks,
+                                                          uint32_t nmodels, const uint32_t* __restrict__ model_counts,
+                                                          float* out_err) {
+    __shared__ float red[BLOCK / WAVE];
+    float best = 0.0f;
+    for (uint32_t m = 0; m < nmodels; ++m) {
+        float s = 0.0f;
+        for (unsigned b = threadIdx.x; b < nblocks; b += BLOCK) s += partials[(size_t)b * nmodels + m];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0 && model_counts[m] != 0) best = fmaxf(best, s / (float)model_counts[m]);
+    }
+    if (threadIdx.x == 0) *out_err = best;
+}
+void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
+                           float* out_err, hipStream_t s) {
+    k_finalize_error<<<1, BLOCK, 0, s>>>(partials, nblocks, nmodels, model_counts, out_err);
+}
+
+}  // namespace salva

@@ -1,0 +1,123 @@
+// world.h — host orchestration of the device-resident fluid world (the body of
+// /root/reference/src/liquid_world.rs:67-158 re-designed around HBM-resident, cell-sorted SoA state).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/salva_hip.h"
+#include "common.h"
+#include "device_types.h"
+#include "kernels.h"
+
+namespace salva {
+
+struct FluidSlot {
+    uint64_t n = 0;
+    float density0 = 1000.0f;
+    uint32_t memberships = 1u, filter = 0xffffffffu;
+    std::vector<SalvaHipForceDesc> forces;
+};
+struct BoundarySlot {
+    uint64_t n = 0;
+    uint32_t memberships = 1u, filter = 0xffffffffu;
+    bool wants_forces = false;
+};
+
+struct GridDims {
+    int o[3] = {0, 0, 0};
+    int d[3] = {1, 1, 1};
+    size_t ncells() const { return (size_t)d[0] * d[1] * d[2]; }
+};
+
+class World {
+  public:
+    explicit World(const SalvaHipParams& p);
+    ~World();
+
+    void set_fluid(uint32_t slot, uint64_t n, const float* pos, const float* vel, const float* vol, const float* acc,
+                   const float* dvs, float density0, uint32_t memberships, uint32_t filter, uint32_t dirty);
+    void set_fluid_forces(uint32_t slot, const SalvaHipForceDesc* f, uint32_t nf);
+    void remove_fluid(uint32_t slot);
+    void set_boundary(uint32_t slot, uint64_t n, const float* pos, const float* vel, uint32_t memberships,
+                      uint32_t filter, bool wants_forces);
+    void remove_boundary(uint32_t slot);
+    int step(float dt, const float g[3], SalvaHipStepStats* stats);
+    void get_fluid(uint32_t slot, float* pos, float* vel);
+    void get_fluid_field(uint32_t slot, int field, float* out);
+    void get_boundary(uint32_t slot, float* volumes, float* forces);
+    void clear_boundary_forces(uint32_t slot);
+    uint64_t device_bytes() const;
+    float time_pred_density(int reps);
+
+    SalvaHipParams prm;
+    SphConsts sc;
+    std::vector<FluidSlot> fluids;
+    std::vector<BoundarySlot> bounds;
+
+  private:
+    void use_device() const;
+    uint64_t fluid_offset(uint32_t slot) const;
+    uint64_t boundary_offset(uint32_t slot) const;
+    void ensure_staging_current();
+    void upload_tables();
+    void build_boundary_grid();
+    void ensure_cub_temp(size_t bytes);
+    StepCtx make_ctx();
+    float read_error(unsigned nblocks);
+    void run_forces(const StepCtx& c);
+    void dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
+    void iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
+    FluidArrays arrays(int which);
+
+    hipStream_t stream = nullptr;
+    uint32_t n = 0, nb = 0;
+
+    // canonical (host order) staging: st_pos = (x,y,z,volume), st_vel = (v,0), st_dv = (dv, pressure), st_acc
+    DevBuf<float4> st_pos, st_vel, st_dv, st_acc;
+    DevBuf<uint32_t> st_model;
+    bool staging_current = true, sorted_valid = false, acc_user = false;
+
+    // cell-sorted working set
+    DevBuf<float4> posm[2], vel[2], dv[2];
+    DevBuf<uint32_t> model[2], perm[2];
+    int cur = 0;
+    DevBuf<float4> acc, w, normal, dii, dijpj;
+    DevBuf<float> rho, alpha, kappa, kappa2, rho_star, aii;
+    DevBuf<uint32_t> nff, nfb, keys[2], idx[2], cell_start_f;
+    DevBuf<uint64_t> slice_w, slice_ff, slice_fb;
+    DevBuf<uint32_t> nbr_ff, nbr_fb;
+    DevBuf<char> cub_temp;
+    DevBuf<float> scratch_f;   // staging for AoS up/downloads and field unsorts
+    DevBuf<float4> scratch_f4;
+
+    // boundaries: canonical + sorted
+    DevBuf<float4> bst_pos, bst_vel;
+    DevBuf<float4> bposv, bvel, bforce;
+    DevBuf<uint32_t> bperm, cell_start_b, bkeys[2], bidx[2];
+    bool b_dirty = true;
+    uint64_t ncontacts_bb = 0;
+
+    GridDims gf, gb;
+    bool bbox_known = false;
+
+    // per-model tables
+    DevBuf<float> rho0_tab;
+    DevBuf<uint8_t> ff_ok, fb_ok, bb_ok, bwants;
+    DevBuf<uint32_t> model_counts;
+    bool tables_dirty = true, any_wants_forces = false;
+
+    // reductions / readback
+    DevBuf<float> partials;
+    DevBuf<Readback> d_rb;
+    DevBuf<uint32_t> d_flags;
+    DevBuf<unsigned long long> d_counters;
+    Readback* h_rb = nullptr;
+
+    float dt_prev = 0.0f, inv_dt_prev = 0.0f;  // TimestepManager::{dt, inv_dt} persist across steps (timestep_manager.rs:23-34)
+    StepCtx last_ctx{};
+    float last_dt = 0.0f;
+    bool have_last_ctx = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+};
+
+}  // namespace salva

@@ -1,0 +1,813 @@
+// world.hip — host side of libsalva_hip: device memory, the per-step launch sequence, up/download.
+//
+// Restates the control flow of /root/reference/src/liquid_world.rs:67-158 (step_with_coupling with the no-op
+// `()` coupling manager), src/solver/pressure/dfsph_solver.rs:667-708 (DFSPH step, iteration protocol :432-503)
+// and src/solver/pressure/iisph_solver.rs:643-711 on top of the kernels in grid/dfsph/iisph/forces.hip.
+// Host <-> device traffic happens only in set_* / get_*; `step` works on HBM-resident state and reads back a
+// few scalars (convergence errors, list sizes, the next cell bounding box).
+#include "world.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace salva {
+
+// ------------------------------------------------------------------------------------------------ small helpers
+__global__ void k_pack_xyz(uint32_t n, const float* __restrict__ src, float4* __restrict__ dst, int keep_w, float wval) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 d = dst[i];
+    d.x = src[3 * i]; d.y = src[3 * i + 1]; d.z = src[3 * i + 2];
+    if (!keep_w) d.w = wval;
+    dst[i] = d;
+}
+__global__ void k_pack_w(uint32_t n, const float* __restrict__ src, float4* __restrict__ dst) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) reinterpret_cast<float*>(&dst[i])[3] = src[i];
+}
+__global__ void k_fill_f4(uint32_t n, float4* __restrict__ dst, float4 v, int keep_w) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (keep_w) v.w = dst[i].w;
+    dst[i] = v;
+}
+__global__ void k_fill_w(uint32_t n, float4* __restrict__ dst, float v) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) reinterpret_cast<float*>(&dst[i])[3] = v;
+}
+__global__ void k_fill_u32(uint32_t n, uint32_t* __restrict__ dst, uint32_t v) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+__global__ void k_unpack_xyz(uint32_t n, const float4* __restrict__ src, float* __restrict__ dst) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 s = src[i];
+    dst[3 * i] = s.x; dst[3 * i + 1] = s.y; dst[3 * i + 2] = s.z;
+}
+__global__ void k_unpack_w(uint32_t n, const float4* __restrict__ src, float* __restrict__ dst) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[i].w;
+}
+__global__ void k_set_bmodel(uint32_t n, float4* __restrict__ bvel, uint32_t m) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) reinterpret_cast<float*>(&bvel[i])[3] = __uint_as_float(m);
+}
+
+static inline unsigned nblk(uint64_t n) { return div_up(n ? n : 1, BLOCK); }
+
+struct Piece { uint64_t src_off, len; bool from_old; };
+
+template <typename T>
+static void rebuild(DevBuf<T>& buf, const std::vector<Piece>& pieces, uint64_t new_total, hipStream_t s) {
+    DevBuf<T> nb;
+    nb.ensure(new_total ? new_total : 1);
+    uint64_t off = 0;
+    for (const Piece& p : pieces) {
+        if (p.from_old && p.len)
+            SALVA_HIP_CHECK(hipMemcpyAsync(nb.p + off, buf.p + p.src_off, p.len * sizeof(T), hipMemcpyDeviceToDevice, s));
+        off += p.len;
+    }
+    SALVA_HIP_CHECK(hipStreamSynchronize(s));
+    std::swap(buf.p, nb.p);
+    std::swap(buf.cap, nb.cap);
+}
+
+static int bits_for(uint64_t ncells) {
+    int b = 1;
+    while (b < 32 && ((uint64_t)1 << b) < ncells) ++b;
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------ ctor / dtor
+World::World(const SalvaHipParams& p) : prm(p) {
+    if (!(p.particle_radius > 0.0f) || !(p.smoothing_factor > 0.0f))
+        throw HipError(SALVA_HIP_E_INVALID, "particle_radius and smoothing_factor must be positive");
+    if (p.solver != SALVA_HIP_SOLVER_DFSPH && p.solver != SALVA_HIP_SOLVER_IISPH)
+        throw HipError(SALVA_HIP_E_INVALID, "unknown solver kind");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        throw HipError(SALVA_HIP_E_HIP, "no HIP device available: libsalva_hip has no CPU fallback");
+    if (p.device < 0 || p.device >= ndev) throw HipError(SALVA_HIP_E_INVALID, "device ordinal out of range");
+    use_device();
+    // h = particle_radius * smoothing_factor * 2 (liquid_world.rs:44)
+    const float h = p.particle_radius * p.smoothing_factor * 2.0f;
+    sc = make_sph_consts(h);
+    SALVA_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    SALVA_HIP_CHECK(hipHostMalloc((void**)&h_rb, sizeof(Readback), hipHostMallocDefault));
+    memset(h_rb, 0, sizeof(Readback));
+    d_rb.ensure(1);
+    d_flags.ensure(1);
+    d_counters.ensure(4);
+    for (auto& e2 : ev) SALVA_HIP_CHECK(hipEventCreate(&e2));
+}
+
+World::~World() {
+    (void)hipSetDevice(prm.device);
+    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    if (h_rb) (void)hipHostFree(h_rb);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+}
+
+void World::use_device() const { SALVA_HIP_CHECK(hipSetDevice(prm.device)); }
+
+uint64_t World::fluid_offset(uint32_t slot) const {
+    uint64_t o = 0;
+    for (uint32_t s = 0; s < slot; ++s) o += fluids[s].n;
+    return o;
+}
+uint64_t World::boundary_offset(uint32_t slot) const {
+    uint64_t o = 0;
+    for (uint32_t s = 0; s < slot; ++s) o += bounds[s].n;
+    return o;
+}
+
+FluidArrays World::arrays(int which) {
+    FluidArrays a;
+    a.posm = posm[which].p; a.vel = vel[which].p; a.dv = dv[which].p; a.model = model[which].p; a.perm = perm[which].p;
+    return a;
+}
+
+void World::ensure_cub_temp(size_t bytes) { cub_temp.ensure(bytes ? bytes : 1, stream, false, 1.25f); }
+
+// Bring the canonical (host-order) staging arrays up to date with the sorted working set.
+void World::ensure_staging_current() {
+    if (staging_current) return;
+    if (sorted_valid && n) {
+        launch_sorted_to_stage(n, arrays(cur), st_pos.p, st_vel.p, st_dv.p, stream);
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    staging_current = true;
+}
+
+// ------------------------------------------------------------------------------------------------ fluids
+void World::set_fluid(uint32_t slot, uint64_t nn, const float* pos, const float* vel_h, const float* vol,
+                      const float* acc_h, const float* dvs, float density0, uint32_t memberships, uint32_t filter,
+                      uint32_t dirty) {
+    use_device();
+    if (slot > fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range (slots are dense)");
+    const bool is_new = slot == fluids.size();
+    if ((uint64_t)n - (is_new ? 0 : fluids[slot].n) + nn >= 0xfffffff0ull)
+        throw HipError(SALVA_HIP_E_CAPACITY, "more than 2^32 fluid particles on one device");
+    ensure_staging_current();
+    const uint64_t old_n = is_new ? 0 : fluids[slot].n;
+    const bool resized = is_new || old_n != nn;
+    if (resized) {
+        if (nn && !pos) throw HipError(SALVA_HIP_E_INVALID, "positions are required when a fluid is created or resized");
+        dirty = SALVA_HIP_DIRTY_ALL;
+    }
+    if (is_new) fluids.emplace_back();
+    const uint64_t off = fluid_offset(slot);
+    const uint64_t old_total = n;
+    const uint64_t new_total = old_total - old_n + nn;
+    if (resized) {
+        std::vector<Piece> pieces = {{0, off, true}, {0, nn, false}, {off + old_n, old_total - off - old_n, true}};
+        rebuild(st_pos, pieces, new_total, stream);
+        rebuild(st_vel, pieces, new_total, stream);
+        rebuild(st_dv, pieces, new_total, stream);
+        rebuild(st_acc, pieces, new_total, stream);
+        rebuild(st_model, pieces, new_total, stream);
+        n = (uint32_t)new_total;
+        if (nn) {
+            // defaults: zero velocity / velocity change / acceleration, Fluid::particle_volume (fluid.rs:110-120)
+            const float r = prm.particle_radius;
+            const float default_vol = r * r * r * 6.4f;  // 8 * 0.8
+            k_fill_f4<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_pos.p + off, make_float4(0, 0, 0, default_vol), 0);
+            k_fill_f4<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_vel.p + off, make_float4(0, 0, 0, 0), 0);
+            k_fill_f4<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_dv.p + off, make_float4(0, 0, 0, 0), 0);
+            k_fill_f4<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_acc.p + off, make_float4(0, 0, 0, 0), 0);
+        }
+        // model ids of every slot at/after this one may have moved
+        fluids[slot].n = nn;
+        uint64_t o = 0;
+        for (uint32_t s = 0; s < fluids.size(); ++s) {
+            if (fluids[s].n) k_fill_u32<<<nblk(fluids[s].n), BLOCK, 0, stream>>>((uint32_t)fluids[s].n, st_model.p + o, s);
+            o += fluids[s].n;
+        }
+    }
+    FluidSlot& f = fluids[slot];
+    f.density0 = density0; f.memberships = memberships; f.filter = filter;
+    auto upload3 = [&](const float* src, float4* dst, int keep_w) {
+        scratch_f.ensure(3 * nn, stream, false, 1.1f);
+        SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, src, 3 * nn * sizeof(float), hipMemcpyHostToDevice, stream));
+        k_pack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, scratch_f.p, dst, keep_w, 0.0f);
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    };
+    if (nn) {
+        if ((dirty & SALVA_HIP_DIRTY_POSITIONS) && pos) upload3(pos, st_pos.p + off, 1);
+        if ((dirty & SALVA_HIP_DIRTY_VELOCITIES) && vel_h) upload3(vel_h, st_vel.p + off, 1);
+        if ((dirty & SALVA_HIP_DIRTY_VOLUMES) && vol) {
+            scratch_f.ensure(nn, stream, false, 1.1f);
+            SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, vol, nn * sizeof(float), hipMemcpyHostToDevice, stream));
+            k_pack_w<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, scratch_f.p, st_pos.p + off);
+            SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        if ((dirty & SALVA_HIP_DIRTY_ACCELERATIONS) && acc_h) {
+            // accelerations are zero between steps; the first user upload must not resurrect stale staging values
+            if (!acc_user) SALVA_HIP_CHECK(hipMemsetAsync(st_acc.p, 0, (size_t)n * sizeof(float4), stream));
+            upload3(acc_h, st_acc.p + off, 1);
+            acc_user = true;
+        }
+        if (dvs) upload3(dvs, st_dv.p + off, 1);
+    }
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    sorted_valid = false;
+    bbox_known = false;
+    tables_dirty = true;
+    have_last_ctx = false;
+}
+
+void World::set_fluid_forces(uint32_t slot, const SalvaHipForceDesc* f, uint32_t nf) {
+    if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
+    for (uint32_t k = 0; k < nf; ++k)
+        if (f[k].kind < SALVA_HIP_FORCE_XSPH || f[k].kind > SALVA_HIP_FORCE_AKINCI2013)
+            throw HipError(SALVA_HIP_E_INVALID, "unknown non-pressure force kind (only built-ins run on the device)");
+    fluids[slot].forces.assign(f, f + nf);
+}
+
+void World::remove_fluid(uint32_t slot) {
+    use_device();
+    if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
+    ensure_staging_current();
+    // ContiguousArena::remove is a swap-remove (contiguous_arena.rs): the last fluid takes the freed slot.
+    const uint32_t last = (uint32_t)fluids.size() - 1;
+    const uint64_t off = fluid_offset(slot), len = fluids[slot].n;
+    const uint64_t loff = fluid_offset(last), llen = fluids[last].n;
+    std::vector<Piece> pieces;
+    pieces.push_back({0, off, true});
+    if (slot != last) {
+        pieces.push_back({loff, llen, true});
+        pieces.push_back({off + len, loff - off - len, true});
+    }
+    const uint64_t new_total = n - len;
+    rebuild(st_pos, pieces, new_total, stream);
+    rebuild(st_vel, pieces, new_total, stream);
+    rebuild(st_dv, pieces, new_total, stream);
+    rebuild(st_acc, pieces, new_total, stream);
+    rebuild(st_model, pieces, new_total, stream);
+    if (slot != last) fluids[slot] = fluids[last];
+    fluids.pop_back();
+    n = (uint32_t)new_total;
+    uint64_t o = 0;
+    for (uint32_t s = 0; s < fluids.size(); ++s) {
+        if (fluids[s].n) k_fill_u32<<<nblk(fluids[s].n), BLOCK, 0, stream>>>((uint32_t)fluids[s].n, st_model.p + o, s);
+        o += fluids[s].n;
+    }
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    sorted_valid = false; bbox_known = false; tables_dirty = true; have_last_ctx = false;
+}
+
+// ------------------------------------------------------------------------------------------------ boundaries
+void World::set_boundary(uint32_t slot, uint64_t nn, const float* pos, const float* vel_h, uint32_t memberships,
+                         uint32_t filter, bool wants_forces) {
+    use_device();
+    if (slot > bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range (slots are dense)");
+    const bool is_new = slot == bounds.size();
+    const uint64_t old_n = is_new ? 0 : bounds[slot].n;
+    if ((uint64_t)nb - old_n + nn >= 0xfffffff0ull) throw HipError(SALVA_HIP_E_CAPACITY, "too many boundary particles");
+    if (nn && !pos) throw HipError(SALVA_HIP_E_INVALID, "boundary positions are required");
+    if (is_new) bounds.emplace_back();
+    const uint64_t off = boundary_offset(slot);
+    const uint64_t old_total = nb, new_total = old_total - old_n + nn;
+    const bool resized = is_new || old_n != nn;
+    if (resized) {
+        std::vector<Piece> pieces = {{0, off, true}, {0, nn, false}, {off + old_n, old_total - off - old_n, true}};
+        rebuild(bst_pos, pieces, new_total, stream);
+        rebuild(bst_vel, pieces, new_total, stream);
+        rebuild(bforce, pieces, new_total, stream);
+        nb = (uint32_t)new_total;
+        if (nn) {
+            k_fill_f4<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, bst_pos.p + off, make_float4(0, 0, 0, 0), 0);
+            k_fill_f4<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, bst_vel.p + off, make_float4(0, 0, 0, 0), 0);
+            k_fill_f4<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, bforce.p + off, make_float4(0, 0, 0, 0), 0);
+        }
+    }
+    BoundarySlot& b = bounds[slot];
+    b.n = nn; b.memberships = memberships; b.filter = filter; b.wants_forces = wants_forces;
+    if (nn) {
+        scratch_f.ensure(3 * nn, stream, false, 1.1f);
+        SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, pos, 3 * nn * sizeof(float), hipMemcpyHostToDevice, stream));
+        k_pack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, scratch_f.p, bst_pos.p + off, 0, 0.0f);
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        if (vel_h) {
+            SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, vel_h, 3 * nn * sizeof(float), hipMemcpyHostToDevice, stream));
+            k_pack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, scratch_f.p, bst_vel.p + off, 0, 0.0f);
+        } else {
+            k_fill_f4<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, bst_vel.p + off, make_float4(0, 0, 0, 0), 0);
+        }
+    }
+    // boundary model ids ride in bst_vel.w
+    uint64_t o = 0;
+    for (uint32_t s = 0; s < bounds.size(); ++s) {
+        if (bounds[s].n) k_set_bmodel<<<nblk(bounds[s].n), BLOCK, 0, stream>>>((uint32_t)bounds[s].n, bst_vel.p + o, s);
+        o += bounds[s].n;
+    }
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    b_dirty = true; tables_dirty = true; have_last_ctx = false;
+}
+
+void World::remove_boundary(uint32_t slot) {
+    use_device();
+    if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");
+    const uint32_t last = (uint32_t)bounds.size() - 1;
+    const uint64_t off = boundary_offset(slot), len = bounds[slot].n;
+    const uint64_t loff = boundary_offset(last), llen = bounds[last].n;
+    std::vector<Piece> pieces;
+    pieces.push_back({0, off, true});
+    if (slot != last) {
+        pieces.push_back({loff, llen, true});
+        pieces.push_back({off + len, loff - off - len, true});
+    }
+    const uint64_t new_total = nb - len;
+    rebuild(bst_pos, pieces, new_total, stream);
+    rebuild(bst_vel, pieces, new_total, stream);
+    rebuild(bforce, pieces, new_total, stream);
+    if (slot != last) bounds[slot] = bounds[last];
+    bounds.pop_back();
+    nb = (uint32_t)new_total;
+    uint64_t o = 0;
+    for (uint32_t s = 0; s < bounds.size(); ++s) {
+        if (bounds[s].n) k_set_bmodel<<<nblk(bounds[s].n), BLOCK, 0, stream>>>((uint32_t)bounds[s].n, bst_vel.p + o, s);
+        o += bounds[s].n;
+    }
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    b_dirty = true; tables_dirty = true; have_last_ctx = false;
+}
+
+// ------------------------------------------------------------------------------------------------ tables
+// InteractionGroups::test (interaction_groups.rs:64-69)
+static inline bool groups_test(uint32_t m1, uint32_t f1, uint32_t m2, uint32_t f2) {
+    return (m1 & f2) != 0 && (m2 & f1) != 0;
+}
+
+void World::upload_tables() {
+    if (!tables_dirty) return;
+    const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1), nbm = (uint32_t)std::max<size_t>(bounds.size(), 1);
+    std::vector<float> r0(nm, 1000.0f);
+    std::vector<uint32_t> counts(nm, 0);
+    std::vector<uint8_t> ff(nm * nm, 1), fb(nm * nbm, 1), bb(nbm * nbm, 1), bw(nbm, 0);
+    any_wants_forces = false;
+    for (uint32_t a = 0; a < fluids.size(); ++a) {
+        r0[a] = fluids[a].density0;
+        counts[a] = (uint32_t)fluids[a].n;
+        for (uint32_t b = 0; b < fluids.size(); ++b)  // a fluid always interacts with itself (contacts.rs:350-358)
+            ff[a * nm + b] = (a == b) || groups_test(fluids[a].memberships, fluids[a].filter, fluids[b].memberships, fluids[b].filter);
+        for (uint32_t b = 0; b < bounds.size(); ++b)
+            fb[a * nbm + b] = groups_test(fluids[a].memberships, fluids[a].filter, bounds[b].memberships, bounds[b].filter);
+    }
+    for (uint32_t a = 0; a < bounds.size(); ++a) {
+        bw[a] = bounds[a].wants_forces ? 1 : 0;
+        any_wants_forces |= bounds[a].wants_forces;
+        for (uint32_t b = 0; b < bounds.size(); ++b)
+            bb[a * nbm + b] = (a == b) || groups_test(bounds[a].memberships, bounds[a].filter, bounds[b].memberships, bounds[b].filter);
+    }
+    rho0_tab.ensure(nm); model_counts.ensure(nm); ff_ok.ensure(nm * nm); fb_ok.ensure(nm * nbm); bb_ok.ensure(nbm * nbm); bwants.ensure(nbm);
+    SALVA_HIP_CHECK(hipMemcpyAsync(rho0_tab.p, r0.data(), nm * sizeof(float), hipMemcpyHostToDevice, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(model_counts.p, counts.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(ff_ok.p, ff.data(), ff.size(), hipMemcpyHostToDevice, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(fb_ok.p, fb.data(), fb.size(), hipMemcpyHostToDevice, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(bb_ok.p, bb.data(), bb.size(), hipMemcpyHostToDevice, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(bwants.p, bw.data(), bw.size(), hipMemcpyHostToDevice, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors go out of scope
+    tables_dirty = false;
+    b_dirty = true;  // group changes alter the boundary-boundary sums
+}
+
+StepCtx World::make_ctx() {
+    StepCtx c{};
+    c.sc = sc;
+    c.xcd = 1;
+    c.n = n;
+    c.posm = posm[cur].p; c.vel = vel[cur].p; c.dv = dv[cur].p; c.acc = acc.p; c.w = w.p; c.normal = normal.p;
+    c.model = model[cur].p; c.perm = perm[cur].p;
+    c.rho = rho.p; c.alpha = alpha.p; c.kappa = kappa.p; c.kappa2 = kappa2.p; c.rho_star = rho_star.p; c.aii = aii.p;
+    c.dii = dii.p; c.dijpj = dijpj.p;
+    c.nff = nff.p; c.nfb = nfb.p;
+    c.slice_ff = slice_ff.p; c.nbr_ff = nbr_ff.p; c.slice_fb = slice_fb.p; c.nbr_fb = nbr_fb.p;
+    c.gf = GridView{gf.o[0], gf.o[1], gf.o[2], gf.d[0], gf.d[1], gf.d[2], cell_start_f.p};
+    c.nb = nb;
+    c.bposv = bposv.p; c.bvel = bvel.p; c.bperm = bperm.p;
+    c.bforce = any_wants_forces ? bforce.p : nullptr;
+    c.bwants = bwants.p;
+    c.gb = GridView{gb.o[0], gb.o[1], gb.o[2], gb.d[0], gb.d[1], gb.d[2], cell_start_b.p};
+    c.nmodels = (uint32_t)std::max<size_t>(fluids.size(), 1);
+    c.nbmodels = (uint32_t)std::max<size_t>(bounds.size(), 1);
+    c.rho0_tab = rho0_tab.p; c.ff_ok = ff_ok.p; c.fb_ok = fb_ok.p; c.bb_ok = bb_ok.p;
+    c.partials = partials.p;
+    c.flags = d_flags.p;
+    c.min_neighbors_for_divergence = 20;  // dfsph_solver.rs:62 (DIM == 3)
+    return c;
+}
+
+static void dims_from_bbox(const int32_t* bb, GridDims& g) {
+    for (int a = 0; a < 3; ++a) {
+        g.o[a] = bb[a];
+        const int64_t d = (int64_t)bb[3 + a] - (int64_t)bb[a] + 1;
+        if (d <= 0 || d > (1 << 30)) throw HipError(SALVA_HIP_E_CAPACITY, "cell bounding box is empty or too large");
+        g.d[a] = (int)d;
+    }
+    const double nc = (double)g.d[0] * (double)g.d[1] * (double)g.d[2];
+    if (nc >= 4.0e9) throw HipError(SALVA_HIP_E_CAPACITY, "dense cell table would exceed 2^32 cells; particles are too spread out");
+}
+
+// Sort the boundary particles by cell, build their cell table and volumes.  Runs when the boundary set changed
+// (the reference redoes this every substep, contacts.rs:142-151 + dfsph_solver.rs:72-96; for unchanged boundary
+// positions the result is identical).
+void World::build_boundary_grid() {
+    if (!b_dirty) return;
+    ncontacts_bb = 0;
+    if (nb == 0) { b_dirty = false; return; }
+    launch_bbox_init(d_rb.p->bbbox, stream);
+    launch_bbox(bst_pos.p, nb, sc.h, d_rb.p->bbbox, d_flags.p, stream);
+    SALVA_HIP_CHECK(hipMemcpyAsync(h_rb->bbbox, d_rb.p->bbbox, sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    dims_from_bbox(h_rb->bbbox, gb);
+    const size_t nc = gb.ncells();
+    bkeys[0].ensure(nb); bkeys[1].ensure(nb); bidx[0].ensure(nb); bidx[1].ensure(nb);
+    bposv.ensure(nb); bvel.ensure(nb); bperm.ensure(nb); cell_start_b.ensure(nc + 1);
+    GridView gv{gb.o[0], gb.o[1], gb.o[2], gb.d[0], gb.d[1], gb.d[2], nullptr};
+    launch_cell_keys(bst_pos.p, nb, sc.h, gv, bkeys[0].p, bidx[0].p, d_flags.p, stream);
+    const int end_bit = bits_for(nc);
+    const size_t tb = sort_pairs_temp_bytes(nb, end_bit);
+    ensure_cub_temp(tb);
+    sort_pairs(cub_temp.p, tb, bkeys[0].p, bkeys[1].p, bidx[0].p, bidx[1].p, nb, end_bit, stream);
+    launch_reorder_boundary(nb, bidx[1].p, bst_pos.p, bst_vel.p, nullptr, bposv.p, bvel.p, bperm.p, stream);
+    launch_cell_start(bkeys[1].p, nb, (uint32_t)nc, cell_start_b.p, stream);
+    StepCtx c = make_ctx();
+    SALVA_HIP_CHECK(hipMemsetAsync(d_counters.p + 2, 0, sizeof(unsigned long long), stream));
+    launch_boundary_volumes(c, d_counters.p + 2, stream);
+    SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_bb, d_counters.p + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    ncontacts_bb = h_rb->ncontacts_bb;
+    b_dirty = false;
+}
+
+float World::read_error(unsigned nblocks) {
+    launch_finalize_error(partials.p, nblocks, (uint32_t)std::max<size_t>(fluids.size(), 1), model_counts.p, &d_rb.p->err, stream);
+    SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->err, &d_rb.p->err, sizeof(float), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    return h_rb->err;
+}
+
+// predict_advection's loop over `fluid.nonpressure_forces` (dfsph_solver.rs:580-603): fluids in slot order, forces in list order.
+void World::run_forces(const StepCtx& c) {
+    for (uint32_t f = 0; f < fluids.size(); ++f) {
+        if (fluids[f].n == 0) continue;
+        for (const SalvaHipForceDesc& d : fluids[f].forces) {
+            switch (d.kind) {
+                case SALVA_HIP_FORCE_XSPH: launch_xsph(c, f, d.p[0], d.p[1], inv_dt_prev, stream); break;
+                case SALVA_HIP_FORCE_ARTIFICIAL: launch_artificial_viscosity(c, f, d.p[0], d.p[1], d.p[2], d.p[3], d.p[4], stream); break;
+                case SALVA_HIP_FORCE_AKINCI2013:
+                    launch_akinci_normals(c, f, stream);
+                    launch_akinci_forces(c, f, d.p[0], d.p[1], stream);
+                    break;
+                default: break;
+            }
+        }
+    }
+}
+
+// DFSPHSolver::step (dfsph_solver.rs:667-708)
+void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
+    const unsigned nblocks = num_blocks(n);
+    // divergence_solve (:466-503).  NOTE the dt lag: inv_dt is still the previous step's here (0 on the first step).
+    int nd = 0;
+    float err = 0.0f;
+    for (int i = 0; i < prm.max_divergence_iter; ++i) {
+        launch_divergence(c, stream);
+        err = read_error(nblocks);
+        const float max_err = prm.max_divergence_error * inv_dt_prev * 0.01f;
+        if (err <= max_err && i >= prm.min_divergence_iter) break;
+        launch_divergence_apply(c, inv_dt_prev, stream);
+        ++nd;
+    }
+    st.n_divergence_iters = nd;
+    st.divergence_error = err;
+    launch_finish_divergence(c, g[0], g[1], g[2], acc_user, stream);  // update_velocities + dv = 0 + gravity
+    run_forces(c);
+    // timestep.advance (:702): dt := total step, inv_dt := 1/dt
+    const float inv_dt = (dt == 0.0f) ? 0.0f : 1.0f / dt;
+    launch_integrate(c, dt, stream);
+    // pressure_solve (:432-464)
+    int np = 0;
+    err = 0.0f;
+    for (int i = 0; i < prm.max_pressure_iter; ++i) {
+        launch_pred_density(c, dt, stream);
+        err = read_error(nblocks);
+        if (err <= prm.max_density_error && i >= prm.min_pressure_iter) break;
+        launch_pressure_apply(c, inv_dt, stream);
+        ++np;
+    }
+    st.n_pressure_iters = np;
+    st.density_error = err;
+    launch_bbox_init(d_rb.p->bbox, stream);
+    launch_update_positions(c, dt, d_rb.p->bbox, stream);
+    dt_prev = dt;
+    inv_dt_prev = inv_dt;
+}
+
+// IISPHSolver::step (iisph_solver.rs:643-711)
+void World::iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
+    const unsigned nblocks = num_blocks(n);
+    st.n_divergence_iters = 0;
+    st.divergence_error = 0.0f;
+    launch_iisph_begin(c, g[0], g[1], g[2], acc_user, stream);
+    run_forces(c);  // forces still see the previous inv_dt (:654-662)
+    const float inv_dt = (dt == 0.0f) ? 0.0f : 1.0f / dt;
+    launch_integrate(c, dt, stream);
+    launch_iisph_dii(c, dt, stream);  // also p = 0.5 * p_prev
+    launch_iisph_pred_density(c, dt, stream);
+    launch_iisph_aii(c, dt, stream);
+    float* p = kappa.p;
+    float* pn = kappa2.p;
+    int it = 0;
+    float err = 0.0f;
+    const float omega = 0.5f;  // :53
+    for (int i = 0; i < prm.max_pressure_iter; ++i) {
+        launch_iisph_dij_pj(c, dt, p, stream);
+        launch_iisph_next_pressure(c, dt, omega, p, pn, stream);
+        err = read_error(nblocks);
+        std::swap(p, pn);
+        ++it;
+        if (err <= prm.max_density_error && i >= prm.min_pressure_iter) break;
+    }
+    st.n_pressure_iters = it;
+    st.density_error = err;
+    launch_iisph_velocity_changes(c, dt, p, stream);
+    launch_bbox_init(d_rb.p->bbox, stream);
+    launch_iisph_finish(c, dt, p, d_rb.p->bbox, stream);
+    dt_prev = dt;
+    inv_dt_prev = inv_dt;
+}
+
+// ------------------------------------------------------------------------------------------------ step
+int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
+    use_device();
+    SalvaHipStepStats st{};
+    st.nparticles = n;
+    // TimestepManager::is_done (timestep_manager.rs:56-58): no substep at all for dt <= eps
+    if (n == 0 || !(dt > FLT_EPSILON)) {
+        if (stats) *stats = st;
+        return SALVA_HIP_OK;
+    }
+    const bool timers = prm.enable_timers != 0;
+    if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
+    upload_tables();
+    SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));
+
+    // ---- working-set allocation
+    for (int k = 0; k < 2; ++k) {
+        posm[k].ensure(n); vel[k].ensure(n); dv[k].ensure(n); model[k].ensure(n); perm[k].ensure(n);
+        keys[k].ensure(n); idx[k].ensure(n);
+    }
+    acc.ensure(n); w.ensure(n); rho.ensure(n); alpha.ensure(n); kappa.ensure(n); nff.ensure(n); nfb.ensure(n);
+    bool has_akinci = false;
+    for (auto& f : fluids) for (auto& d : f.forces) has_akinci |= d.kind == SALVA_HIP_FORCE_AKINCI2013;
+    if (has_akinci) normal.ensure(n);
+    if (prm.solver == SALVA_HIP_SOLVER_IISPH) { kappa2.ensure(n); rho_star.ensure(n); aii.ensure(n); dii.ensure(n); dijpj.ensure(n); }
+    const unsigned nblocks = num_blocks(n);
+    partials.ensure((size_t)nblocks * std::max<size_t>(fluids.size(), 1));
+    const uint32_t nslices = div_up(n, WAVE);
+    slice_w.ensure(nslices + 1); slice_ff.ensure(nslices + 1); slice_fb.ensure(nslices + 1);
+
+    // ---- (re)build the sorted working set from the canonical arrays after host edits
+    if (!sorted_valid) {
+        launch_stage_to_sorted(n, st_pos.p, st_vel.p, st_dv.p, st_model.p, rho0_tab.p, arrays(cur), stream);
+        sorted_valid = true;
+    }
+    staging_current = false;
+
+    // ---- cell bounding box (known from the previous step's position update unless the host moved particles)
+    if (!bbox_known) {
+        launch_bbox_init(d_rb.p->bbox, stream);
+        launch_bbox(posm[cur].p, n, sc.h, d_rb.p->bbox, d_flags.p, stream);
+        SALVA_HIP_CHECK(hipMemcpyAsync(h_rb->bbox, d_rb.p->bbox, sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        bbox_known = true;
+    }
+    dims_from_bbox(h_rb->bbox, gf);
+    const size_t ncf = gf.ncells();
+    cell_start_f.ensure(ncf + 1, stream, false, 1.5f);
+
+    // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
+    {
+        GridView gv{gf.o[0], gf.o[1], gf.o[2], gf.d[0], gf.d[1], gf.d[2], nullptr};
+        launch_cell_keys(posm[cur].p, n, sc.h, gv, keys[0].p, idx[0].p, d_flags.p, stream);
+        const int end_bit = bits_for(ncf);
+        const size_t tb = sort_pairs_temp_bytes(n, end_bit);
+        ensure_cub_temp(tb);
+        sort_pairs(cub_temp.p, tb, keys[0].p, keys[1].p, idx[0].p, idx[1].p, n, end_bit, stream);
+        launch_reorder_fluid(n, idx[1].p, arrays(cur), arrays(cur ^ 1), w.p, stream);
+        cur ^= 1;
+        launch_cell_start(keys[1].p, n, (uint32_t)ncf, cell_start_f.p, stream);
+        if (acc_user) launch_gather_f4(n, perm[cur].p, st_acc.p, acc.p, stream);
+    }
+    build_boundary_grid();  // insert_boundaries_to_grid (liquid_world.rs:106) + boundary volumes, only when dirty
+
+    // ---- neighbour lists   (compute_contacts, contacts.rs:154-252)
+    StepCtx c = make_ctx();
+    SALVA_HIP_CHECK(hipMemsetAsync(d_counters.p, 0, 2 * sizeof(unsigned long long), stream));
+    SALVA_HIP_CHECK(hipMemsetAsync(slice_w.p + nslices, 0, sizeof(uint64_t), stream));
+    {
+        const size_t tb = scan_temp_bytes(nslices + 1);
+        ensure_cub_temp(tb);
+        launch_nbr_count(c, false, nff.p, slice_w.p, d_counters.p + 0, stream);
+        scan_u64(cub_temp.p, tb, slice_w.p, slice_ff.p, nslices + 1, stream);
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nbr_total_ff, slice_ff.p + nslices, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        if (nb) {
+            launch_nbr_count(c, true, nfb.p, slice_w.p, d_counters.p + 1, stream);
+            scan_u64(cub_temp.p, tb, slice_w.p, slice_fb.p, nslices + 1, stream);
+            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nbr_total_fb, slice_fb.p + nslices, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        } else {
+            h_rb->nbr_total_fb = 0;
+        }
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, d_counters.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        if (h_rb->nbr_total_ff >= (1ull << 40) || h_rb->nbr_total_fb >= (1ull << 40))
+            throw HipError(SALVA_HIP_E_CAPACITY, "neighbour list too large");
+        const bool r1 = nbr_ff.ensure(h_rb->nbr_total_ff ? h_rb->nbr_total_ff : 1, stream, false, 1.2f);
+        const bool r2 = nbr_fb.ensure(h_rb->nbr_total_fb ? h_rb->nbr_total_fb : 1, stream, false, 1.2f);
+        if (r1 || r2) c = make_ctx();
+        launch_nbr_fill(c, false, slice_ff.p, nbr_ff.p, stream);
+        if (nb) launch_nbr_fill(c, true, slice_fb.p, nbr_fb.p, stream);
+    }
+    st.ncontacts = h_rb->ncontacts_ff + (nb ? h_rb->ncontacts_fb : 0) + ncontacts_bb;
+    if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
+
+    // ---- solver   (evaluate_kernels + compute_densities + solver.step, liquid_world.rs:123-144)
+    launch_density_alpha(c, stream);
+    if (prm.solver == SALVA_HIP_SOLVER_DFSPH) dfsph_solve(c, dt, g, st);
+    else iisph_solve(c, dt, g, st);
+    acc_user = false;
+
+    // ---- end of step: next bbox + flags
+    SALVA_HIP_CHECK(hipMemcpyAsync(h_rb->bbox, d_rb.p->bbox, sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->flags, d_flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[2], stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    bbox_known = true;
+    last_ctx = c; last_dt = dt; have_last_ctx = true;
+    if (timers) {
+        float a = 0, b = 0;
+        (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+        st.grid_ms = a; st.solver_ms = b; st.step_ms = a + b;
+    }
+    if (stats) *stats = st;
+    if (h_rb->flags & 1u) {
+        bbox_known = false;
+        throw HipError(SALVA_HIP_E_NUMERIC, "zero density / boundary denominator or NaN detected (the reference would panic)");
+    }
+    if (h_rb->flags & 2u) {
+        bbox_known = false;
+        throw HipError(SALVA_HIP_E_HIP, "internal error: particle outside the cell table");
+    }
+    return SALVA_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ downloads
+void World::get_fluid(uint32_t slot, float* pos, float* vel_out) {
+    use_device();
+    if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
+    const uint64_t nn = fluids[slot].n, off = fluid_offset(slot);
+    if (nn == 0) return;
+    ensure_staging_current();
+    scratch_f.ensure(3 * nn, stream, false, 1.1f);
+    if (pos) {
+        k_unpack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_pos.p + off, scratch_f.p);
+        SALVA_HIP_CHECK(hipMemcpyAsync(pos, scratch_f.p, 3 * nn * sizeof(float), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    if (vel_out) {
+        k_unpack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_vel.p + off, scratch_f.p);
+        SALVA_HIP_CHECK(hipMemcpyAsync(vel_out, scratch_f.p, 3 * nn * sizeof(float), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+}
+
+void World::get_fluid_field(uint32_t slot, int field, float* out) {
+    use_device();
+    if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
+    if (!out) throw HipError(SALVA_HIP_E_INVALID, "null output");
+    const uint64_t nn = fluids[slot].n, off = fluid_offset(slot);
+    if (nn == 0) return;
+    const bool vec = field == SALVA_HIP_FIELD_VELOCITY_CHANGE || field == SALVA_HIP_FIELD_ACCELERATION;
+    const size_t width = vec ? 3 : 1;
+    scratch_f.ensure(std::max<size_t>(3 * nn, n), stream, false, 1.1f);
+    auto finish = [&](const float* src) {
+        SALVA_HIP_CHECK(hipMemcpyAsync(out, src, width * nn * sizeof(float), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    };
+    switch (field) {
+        case SALVA_HIP_FIELD_VELOCITY_CHANGE:
+            ensure_staging_current();
+            k_unpack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_dv.p + off, scratch_f.p);
+            finish(scratch_f.p);
+            return;
+        case SALVA_HIP_FIELD_PRESSURE:
+            ensure_staging_current();
+            k_unpack_w<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_dv.p + off, scratch_f.p);
+            finish(scratch_f.p);
+            return;
+        case SALVA_HIP_FIELD_VOLUME:
+            ensure_staging_current();
+            k_unpack_w<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_pos.p + off, scratch_f.p);
+            finish(scratch_f.p);
+            return;
+        case SALVA_HIP_FIELD_ACCELERATION:
+            // accelerations are zero after every step (integrate_and_clear_accelerations) unless the host set them
+            if (acc_user) {
+                k_unpack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_acc.p + off, scratch_f.p);
+                finish(scratch_f.p);
+            } else {
+                memset(out, 0, 3 * nn * sizeof(float));
+            }
+            return;
+        default: break;
+    }
+    // per-step solver scratch lives in sorted order: valid only right after a step
+    if (!sorted_valid || !have_last_ctx)
+        throw HipError(SALVA_HIP_E_INVALID, "solver scratch fields are only available right after a step");
+    switch (field) {
+        case SALVA_HIP_FIELD_DENSITY: launch_unsort_f32(n, perm[cur].p, rho.p, scratch_f.p, stream); break;
+        case SALVA_HIP_FIELD_ALPHA: launch_unsort_f32(n, perm[cur].p, alpha.p, scratch_f.p, stream); break;
+        case SALVA_HIP_FIELD_NUM_FLUID_CONTACTS: launch_unsort_u32_as_f32(n, perm[cur].p, nff.p, scratch_f.p, stream); break;
+        case SALVA_HIP_FIELD_NUM_BOUNDARY_CONTACTS:
+            if (nb == 0) { memset(out, 0, nn * sizeof(float)); return; }
+            launch_unsort_u32_as_f32(n, perm[cur].p, nfb.p, scratch_f.p, stream);
+            break;
+        default: throw HipError(SALVA_HIP_E_INVALID, "unknown field");
+    }
+    finish(scratch_f.p + off);
+}
+
+void World::get_boundary(uint32_t slot, float* volumes, float* forces) {
+    use_device();
+    if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");
+    const uint64_t nn = bounds[slot].n, off = boundary_offset(slot);
+    if (nn == 0) return;
+    if (volumes) {
+        upload_tables();
+        build_boundary_grid();
+        scratch_f4.ensure(nb);
+        scratch_f.ensure(nb, stream, false, 1.1f);
+        launch_unsort_f4(nb, bperm.p, bposv.p, scratch_f4.p, stream);
+        k_unpack_w<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, scratch_f4.p + off, scratch_f.p);
+        SALVA_HIP_CHECK(hipMemcpyAsync(volumes, scratch_f.p, nn * sizeof(float), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    if (forces) {
+        scratch_f.ensure(3 * nn, stream, false, 1.1f);
+        k_unpack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, bforce.p + off, scratch_f.p);
+        SALVA_HIP_CHECK(hipMemcpyAsync(forces, scratch_f.p, 3 * nn * sizeof(float), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+}
+
+void World::clear_boundary_forces(uint32_t slot) {
+    use_device();
+    if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");
+    const uint64_t nn = bounds[slot].n, off = boundary_offset(slot);
+    if (nn) {
+        SALVA_HIP_CHECK(hipMemsetAsync(bforce.p + off, 0, nn * sizeof(float4), stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+}
+
+uint64_t World::device_bytes() const {
+    uint64_t b = 0;
+    auto add = [&](size_t x) { b += x; };
+    add(st_pos.bytes()); add(st_vel.bytes()); add(st_dv.bytes()); add(st_acc.bytes()); add(st_model.bytes());
+    for (int k = 0; k < 2; ++k) {
+        add(posm[k].bytes()); add(vel[k].bytes()); add(dv[k].bytes()); add(model[k].bytes()); add(perm[k].bytes());
+        add(keys[k].bytes()); add(idx[k].bytes()); add(bkeys[k].bytes()); add(bidx[k].bytes());
+    }
+    add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes());
+    add(rho.bytes()); add(alpha.bytes()); add(kappa.bytes()); add(kappa2.bytes()); add(rho_star.bytes()); add(aii.bytes());
+    add(nff.bytes()); add(nfb.bytes()); add(cell_start_f.bytes()); add(slice_w.bytes()); add(slice_ff.bytes());
+    add(slice_fb.bytes()); add(nbr_ff.bytes()); add(nbr_fb.bytes()); add(cub_temp.bytes()); add(scratch_f.bytes());
+    add(scratch_f4.bytes()); add(bst_pos.bytes()); add(bst_vel.bytes()); add(bposv.bytes()); add(bvel.bytes());
+    add(bforce.bytes()); add(bperm.bytes()); add(cell_start_b.bytes()); add(partials.bytes());
+    return b;
+}
+
+// Average duration (microseconds) of one k_pred_density launch on the last step's lists, by HIP events on the
+// world's own stream.  The kernel only rewrites scratch (kappa, partials), so the world's state is unaffected.
+float World::time_pred_density(int reps) {
+    use_device();
+    if (!have_last_ctx || !sorted_valid || n == 0) throw HipError(SALVA_HIP_E_INVALID, "no completed step to time");
+    if (reps < 1) reps = 1;
+    launch_pred_density(last_ctx, last_dt, stream);  // warm-up
+    SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
+    for (int r = 0; r < reps; ++r) launch_pred_density(last_ctx, last_dt, stream);
+    SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    float ms = 0.0f;
+    SALVA_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    return ms * 1000.0f / (float)reps;
+}
+
+}  // namespace salva

@@ -1,0 +1,132 @@
+"""Synthetic scene generators (numpy, float32 arithmetic).
+
+`cube_fluid` restates /root/reference/examples3d/helper.rs:4-20 operation for operation; the boundary
+generators replace the reference's parry ray-casting sampler (src/sampling/ray_sampling.rs, out of scope)
+with plain lattice shells at the same 2r spacing.  The LCG generators implement the seeds named in
+SURVEY.md §8(d) (42 for position jitter, 12345 for velocities).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F = np.float32
+
+
+def cube_fluid_positions(ni: int, nj: int, nk: int, particle_rad: float) -> np.ndarray:
+    """examples3d/helper.rs:4-20 — ni*nj*nk lattice, spacing 2r, centred on the origin, i-major / k-minor."""
+    r = F(particle_rad)
+    i = np.arange(ni, dtype=F)[:, None, None]
+    j = np.arange(nj, dtype=F)[None, :, None]
+    k = np.arange(nk, dtype=F)[None, None, :]
+    half = np.array([F(ni) * r, F(nj) * r, F(nk) * r], dtype=F)
+    x = (i * r) * F(2.0)
+    y = (j * r) * F(2.0)
+    z = (k * r) * F(2.0)
+    pts = np.empty((ni, nj, nk, 3), dtype=F)
+    pts[..., 0] = (x + r) - half[0]
+    pts[..., 1] = (y + r) - half[1]
+    pts[..., 2] = (z + r) - half[2]
+    return pts.reshape(-1, 3)
+
+
+def lcg_uniform(n: int, seed: int) -> np.ndarray:
+    """Deterministic uniforms in [0, 1): Numerical-Recipes 32-bit LCG, top 24 bits.
+
+    State n is a closed form of state 0 (a^n * s + c * (a^n - 1)/(a - 1) mod 2^32) evaluated with a
+    vectorised doubling scan, so 10^7 values cost milliseconds and the sequence is a property of
+    (seed, index) only.
+    """
+    a, c = np.uint64(1664525), np.uint64(1013904223)
+    mask = np.uint64(0xFFFFFFFF)
+    # affine maps x -> A x + B composed by doubling: (A, B) for 2^k steps
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+    A = np.ones(n, dtype=np.uint64)
+    B = np.zeros(n, dtype=np.uint64)
+    pa, pb = a, c
+    bit = 0
+    with np.errstate(over="ignore"):
+        while (1 << bit) <= n:
+            sel = ((idx >> np.uint64(bit)) & np.uint64(1)).astype(bool)
+            # apply (pa, pb) after the current map on the selected lanes
+            A[sel] = (A[sel] * pa) & mask
+            B[sel] = (B[sel] * pa + pb) & mask
+            pb = (pb * pa + pb) & mask
+            pa = (pa * pa) & mask
+            bit += 1
+        x = (A * np.uint64(seed & 0xFFFFFFFF) + B) & mask
+    return ((x >> np.uint64(8)).astype(np.float64) / float(1 << 24)).astype(F)
+
+
+def jitter(positions: np.ndarray, amplitude: float, seed: int = 42) -> np.ndarray:
+    u = lcg_uniform(positions.size, seed).reshape(positions.shape)
+    return (positions + (u * F(2.0) - F(1.0)) * F(amplitude)).astype(F)
+
+
+def random_velocities(n: int, amplitude: float, seed: int = 12345) -> np.ndarray:
+    u = lcg_uniform(3 * n, seed).reshape(n, 3)
+    return ((u * F(2.0) - F(1.0)) * F(amplitude)).astype(F)
+
+
+def box_shell(mins, maxs, particle_rad: float, faces: str = "xXyYzZ", layers: int = 1) -> np.ndarray:
+    """Boundary particles on the faces of an axis-aligned box, lattice spacing 2r.
+
+    `faces` selects which faces are sampled (x = min-x face, X = max-x face, ...).  With `layers` > 1
+    further layers are stacked outwards.  Shared edges are emitted once.
+    """
+    r = F(particle_rad)
+    d = F(2.0) * r
+    mins = np.asarray(mins, dtype=F)
+    maxs = np.asarray(maxs, dtype=F)
+    n = np.maximum(np.round((maxs - mins) / d).astype(np.int64), 1) + 1
+    pts = set()
+    out = []
+    for face in faces:
+        axis = "xyz".index(face.lower())
+        hi = face.isupper()
+        u, v = [a for a in range(3) if a != axis]
+        for layer in range(layers):
+            for a in range(int(n[u])):
+                for b in range(int(n[v])):
+                    q = [0, 0, 0]
+                    q[axis] = (int(n[axis]) - 1 + layer) if hi else -layer
+                    q[u], q[v] = a, b
+                    q = tuple(q)
+                    if q in pts:
+                        continue
+                    pts.add(q)
+                    out.append(q)
+    q = np.asarray(out, dtype=F)
+    return (mins[None, :] + q * d).astype(F)
+
+
+def plane_lattice(nx: int, nz: int, y: float, particle_rad: float, x0: float, z0: float, layers: int = 1) -> np.ndarray:
+    """nx*nz boundary particles at height y (and layers below), spacing 2r — a vectorised floor."""
+    r = F(particle_rad)
+    d = F(2.0) * r
+    i = np.arange(nx, dtype=F)[:, None, None]
+    k = np.arange(nz, dtype=F)[None, :, None]
+    l = np.arange(layers, dtype=F)[None, None, :]
+    pts = np.empty((nx, nz, layers, 3), dtype=F)
+    pts[..., 0] = F(x0) + i * d
+    pts[..., 1] = F(y) - l * d
+    pts[..., 2] = F(z0) + k * d
+    return pts.reshape(-1, 3)
+
+
+def tank(nx: int, ny: int, nz: int, particle_rad: float, wall_cells: int = 0):
+    """A fluid block of nx*ny*nz particles resting in an open-top lattice tank.
+
+    Returns (fluid_positions, boundary_positions).  The tank floor/walls sit one lattice spacing outside
+    the fluid block; `wall_cells` extra spacings of head-room are left on +x so a dam-break has somewhere to go.
+    """
+    r = F(particle_rad)
+    d = F(2.0) * r
+    fluid = cube_fluid_positions(nx, ny, nz, particle_rad)
+    fmin = fluid.min(axis=0)
+    fmax = fluid.max(axis=0)
+    mins = fmin - d
+    maxs = fmax + d
+    maxs[0] += F(wall_cells) * d
+    maxs[1] += F(max(ny // 2, 4)) * d
+    shell = box_shell(mins, maxs, particle_rad, faces="xXyzZ")
+    return fluid, shell

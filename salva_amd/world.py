@@ -1,0 +1,580 @@
+"""Host-side mirror of the salva3d API for the `LiquidWorld::step` path, on top of libsalva_hip.
+
+Same names, argument meaning and error behaviour as the reference (paths relative to /root/reference):
+  LiquidWorld            src/liquid_world.rs:17-209
+  Fluid / Boundary       src/object/fluid.rs:12-185, src/object/boundary.rs:11-84
+  InteractionGroups      src/object/interaction_groups.rs:6-79
+  DFSPHSolver/IISPHSolver pub tuning fields: src/solver/pressure/dfsph_solver.rs:21-38,54-70; iisph_solver.rs:21-30,48-64
+  XSPHViscosity / ArtificialViscosity / Akinci2013SurfaceTension   src/solver/{viscosity,surface_tension}/*.rs
+
+State lives in HBM between steps.  `fluid.positions` / `fluid.velocities` are numpy views of host copies that are
+refreshed lazily from the device the first time they are read after a step, and uploaded again when assigned
+(`fluid.velocities = arr`) or after `fluid.mark_dirty()` for in-place edits.  This module never computes physics
+itself: everything goes through the C ABI, and importing it without the built library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+F32 = np.float32
+
+
+def _fp(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _as_vec3(a, n=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=F32).reshape(-1, 3)
+    if n is not None and len(a) != n:
+        raise ValueError(f"expected {n} 3-vectors, got {len(a)}")
+    return a
+
+
+@dataclass(frozen=True)
+class InteractionGroups:
+    """interaction_groups.rs: `test(a,b) = (a.m & b.f) != 0 && (b.m & a.f) != 0`; default = GROUP_1 / ALL."""
+    memberships: int = 1
+    filter: int = 0xFFFFFFFF
+
+    @staticmethod
+    def default() -> "InteractionGroups":
+        return InteractionGroups()
+
+    @staticmethod
+    def all() -> "InteractionGroups":
+        return InteractionGroups(0xFFFFFFFF, 0xFFFFFFFF)
+
+    @staticmethod
+    def none() -> "InteractionGroups":
+        return InteractionGroups(0, 0)
+
+    def test(self, rhs: "InteractionGroups") -> bool:
+        return (self.memberships & rhs.filter) != 0 and (rhs.memberships & self.filter) != 0
+
+
+# ------------------------------------------------------------------------------------------------ forces
+class NonPressureForce:
+    """solver/nonpressure_force.rs:10-30.  Only the built-ins below run on the device; an arbitrary user
+    implementation needs host contact lists (not built yet) and is rejected loudly."""
+
+    def _desc(self) -> L.ForceDesc:
+        raise NotImplementedError("custom NonPressureForce implementations are not supported on the device path")
+
+
+class XSPHViscosity(NonPressureForce):
+    def __init__(self, fluid_viscosity_coefficient: float, boundary_viscosity_coefficient: float):
+        self.fluid_viscosity_coefficient = fluid_viscosity_coefficient
+        self.boundary_viscosity_coefficient = boundary_viscosity_coefficient
+
+    def _desc(self):
+        d = L.ForceDesc()
+        d.kind = L.FORCE_XSPH
+        d.p[0], d.p[1] = self.fluid_viscosity_coefficient, self.boundary_viscosity_coefficient
+        return d
+
+
+class ArtificialViscosity(NonPressureForce):
+    def __init__(self, fluid_viscosity_coefficient: float, boundary_viscosity_coefficient: float):
+        self.alpha = 1.0
+        self.beta = 0.0
+        self.speed_of_sound = 10.0
+        self.fluid_viscosity_coefficient = fluid_viscosity_coefficient
+        self.boundary_viscosity_coefficient = boundary_viscosity_coefficient
+
+    def _desc(self):
+        d = L.ForceDesc()
+        d.kind = L.FORCE_ARTIFICIAL
+        d.p[0], d.p[1] = self.fluid_viscosity_coefficient, self.boundary_viscosity_coefficient
+        d.p[2], d.p[3], d.p[4] = self.alpha, self.beta, self.speed_of_sound
+        return d
+
+
+class Akinci2013SurfaceTension(NonPressureForce):
+    def __init__(self, fluid_tension_coefficient: float, boundary_adhesion_coefficient: float):
+        self.fluid_tension_coefficient = fluid_tension_coefficient
+        self.boundary_adhesion_coefficient = boundary_adhesion_coefficient
+
+    def _desc(self):
+        d = L.ForceDesc()
+        d.kind = L.FORCE_AKINCI2013
+        d.p[0], d.p[1] = self.fluid_tension_coefficient, self.boundary_adhesion_coefficient
+        return d
+
+
+# ------------------------------------------------------------------------------------------------ solvers
+class DFSPHSolver:
+    """dfsph_solver.rs:54-70 defaults."""
+    kind = L.SOLVER_DFSPH
+
+    def __init__(self):
+        self.min_pressure_iter = 1
+        self.max_pressure_iter = 50
+        self.max_density_error = 0.05
+        self.min_divergence_iter = 1
+        self.max_divergence_iter = 50
+        self.max_divergence_error = 0.1
+
+
+class IISPHSolver:
+    """iisph_solver.rs:48-64 defaults."""
+    kind = L.SOLVER_IISPH
+
+    def __init__(self):
+        self.min_pressure_iter = 1
+        self.max_pressure_iter = 50
+        self.max_density_error = 0.05
+        self.min_divergence_iter = 1
+        self.max_divergence_iter = 50
+        self.max_divergence_error = 0.1
+
+
+# ------------------------------------------------------------------------------------------------ objects
+class Fluid:
+    """object/fluid.rs.  `Fluid::new(positions, particle_radius, density0, interaction_groups)`."""
+
+    def __init__(self, particle_positions, particle_radius: float, density0: float,
+                 interaction_groups: InteractionGroups = InteractionGroups()):
+        pos = _as_vec3(particle_positions) if len(particle_positions) else np.zeros((0, 3), F32)
+        n = len(pos)
+        self.nonpressure_forces: List[NonPressureForce] = []
+        self._positions = pos.copy()
+        self._velocities = np.zeros((n, 3), F32)
+        self._accelerations = np.zeros((n, 3), F32)
+        self._volumes = np.full(n, self.particle_volume(particle_radius), F32)
+        self.density0 = float(density0)
+        self._deleted = np.zeros(n, bool)
+        self._particle_radius = float(particle_radius)
+        self.interaction_groups = interaction_groups
+        # device synchronisation state
+        self._world: Optional["LiquidWorld"] = None
+        self._slot = -1
+        self._dirty = L.DIRTY_ALL
+        self._resized = True
+        self._device_newer = False
+        self._acc_set = False
+
+    @staticmethod
+    def particle_volume(particle_radius: float) -> np.float32:
+        r = F32(particle_radius)  # fluid.rs:110-120
+        return F32(r * r * r * F32(8.0 * 0.8))
+
+    # ---- lazily synchronised pub fields
+    def _pull(self):
+        if self._device_newer and self._world is not None:
+            self._world._download_fluid(self)
+
+    @property
+    def positions(self) -> np.ndarray:
+        self._pull()
+        return self._positions
+
+    @positions.setter
+    def positions(self, v):
+        self._pull()
+        self._positions = _as_vec3(v, self.num_particles()).copy()
+        self._dirty |= L.DIRTY_POSITIONS
+
+    @property
+    def velocities(self) -> np.ndarray:
+        self._pull()
+        return self._velocities
+
+    @velocities.setter
+    def velocities(self, v):
+        self._pull()
+        self._velocities = _as_vec3(v, self.num_particles()).copy()
+        self._dirty |= L.DIRTY_VELOCITIES
+
+    @property
+    def accelerations(self) -> np.ndarray:
+        return self._accelerations
+
+    @accelerations.setter
+    def accelerations(self, v):
+        self._accelerations = _as_vec3(v, self.num_particles()).copy()
+        self._dirty |= L.DIRTY_ACCELERATIONS
+        self._acc_set = True
+
+    @property
+    def volumes(self) -> np.ndarray:
+        return self._volumes
+
+    @volumes.setter
+    def volumes(self, v):
+        v = np.ascontiguousarray(v, dtype=F32).reshape(-1)
+        if len(v) != self.num_particles():
+            raise ValueError("volumes length mismatch")
+        self._volumes = v.copy()
+        self._dirty |= L.DIRTY_VOLUMES
+
+    def mark_dirty(self, mask: int = L.DIRTY_POSITIONS | L.DIRTY_VELOCITIES | L.DIRTY_VOLUMES):
+        """Call after editing the arrays in place (numpy cannot observe element writes)."""
+        self._dirty |= mask
+
+    # ---- fluid.rs API
+    def particle_radius(self) -> float:
+        return self._particle_radius
+
+    def default_particle_volume(self) -> float:
+        return float(self.particle_volume(self._particle_radius))
+
+    def num_particles(self) -> int:
+        return len(self._positions)
+
+    def particle_mass(self, i: int) -> np.float32:
+        return F32(self._volumes[i] * F32(self.density0))
+
+    def delete_particle_at_next_timestep(self, particle: int):
+        self._deleted[particle] = True
+
+    def num_deleted_particles(self) -> int:
+        return int(self._deleted.sum())
+
+    def deleted_particles_mask(self) -> np.ndarray:
+        return self._deleted
+
+    def add_particles(self, positions, velocities=None):
+        """fluid.rs:126-150"""
+        self._pull()
+        pos = _as_vec3(positions)
+        k = len(pos)
+        vel = _as_vec3(velocities, k) if velocities is not None else np.zeros((k, 3), F32)
+        dv = self._world._fetch_velocity_changes(self) if (self._world is not None and not self._resized) else None
+        self._positions = np.concatenate([self._positions, pos])
+        self._velocities = np.concatenate([self._velocities, vel])
+        self._accelerations = np.concatenate([self._accelerations, np.zeros((k, 3), F32)])
+        self._volumes = np.concatenate([self._volumes, np.full(k, self.default_particle_volume(), F32)])
+        self._deleted = np.concatenate([self._deleted, np.zeros(k, bool)])
+        if dv is not None:  # init_with_fluids resizes velocity_changes with zeros (dfsph_solver.rs:548)
+            self._pending_dv = np.concatenate([dv, np.zeros((k, 3), F32)])
+        self._resized = True
+        self._dirty = L.DIRTY_ALL
+
+    def transform_by(self, rotation: Optional[np.ndarray] = None, translation: Sequence[float] = (0.0, 0.0, 0.0)):
+        """`Fluid::transform_by(&Isometry)`: p <- R p + t (fluid.rs:166-168)."""
+        self._pull()
+        p = self._positions
+        if rotation is not None:
+            p = (p @ np.asarray(rotation, F32).T).astype(F32)
+        self._positions = (p + np.asarray(translation, F32)[None, :]).astype(F32)
+        self._dirty |= L.DIRTY_POSITIONS
+
+    _pending_dv: Optional[np.ndarray] = None
+
+
+class Boundary:
+    """object/boundary.rs.  `Boundary::new(positions, interaction_groups)`; `forces = Some(..)` <=> wants_forces."""
+
+    def __init__(self, particle_positions, interaction_groups: InteractionGroups = InteractionGroups(),
+                 wants_forces: bool = False):
+        pos = _as_vec3(particle_positions) if len(particle_positions) else np.zeros((0, 3), F32)
+        self._positions = pos.copy()
+        self._velocities = np.zeros((len(pos), 3), F32)
+        self.interaction_groups = interaction_groups
+        self.wants_forces = wants_forces
+        self._world: Optional["LiquidWorld"] = None
+        self._slot = -1
+        self._dirty = True
+
+    @property
+    def positions(self):
+        return self._positions
+
+    @positions.setter
+    def positions(self, v):
+        self._positions = _as_vec3(v).copy()
+        if len(self._velocities) != len(self._positions):
+            self._velocities = np.zeros((len(self._positions), 3), F32)
+        self._dirty = True
+
+    @property
+    def velocities(self):
+        return self._velocities
+
+    @velocities.setter
+    def velocities(self, v):
+        self._velocities = _as_vec3(v, len(self._positions)).copy()
+        self._dirty = True
+
+    def mark_dirty(self):
+        self._dirty = True
+
+    def num_particles(self) -> int:
+        return len(self._positions)
+
+    @property
+    def volumes(self) -> np.ndarray:
+        """boundary.volumes: V_b = 1 / sum W (recomputed by the solver, dfsph_solver.rs:72-96)."""
+        if self._world is None:
+            return np.zeros(self.num_particles(), F32)
+        return self._world._boundary_field(self, volumes=True)
+
+    @property
+    def forces(self) -> Optional[np.ndarray]:
+        if not self.wants_forces:
+            return None
+        if self._world is None:
+            return np.zeros((self.num_particles(), 3), F32)
+        return self._world._boundary_field(self, volumes=False)
+
+    def clear_forces(self, resize_buffer: bool = False):
+        if self._world is not None and self.wants_forces:
+            self._world._sync_boundaries()
+            L.check(self._world._L.salva_hip_clear_boundary_forces(self._world._h, self._slot))
+
+
+@dataclass
+class Counters:
+    """Subset of counters/mod.rs filled from the device step report."""
+    nsubsteps: int = 0
+    ncontacts: int = 0
+    n_divergence_iters: int = 0
+    n_pressure_iters: int = 0
+    divergence_error: float = 0.0
+    density_error: float = 0.0
+    grid_ms: float = 0.0
+    solver_ms: float = 0.0
+    step_ms: float = 0.0
+    enabled: bool = False
+
+    def enable(self):
+        self.enabled = True
+
+
+class _ObjectSet:
+    """FluidSet / BoundarySet: dense slots with swap-remove (object/contiguous_arena.rs:12-135)."""
+
+    def __init__(self):
+        self._items: list = []
+
+    def as_slice(self):
+        return list(self._items)
+
+    def get(self, handle):
+        return handle if handle in self._items else None
+
+    def __iter__(self):
+        return iter(self._items)
+
+    def __len__(self):
+        return len(self._items)
+
+
+class LiquidWorld:
+    """liquid_world.rs:17-209.  `LiquidWorld::new(solver, particle_radius, smoothing_factor)`."""
+
+    def __init__(self, solver, particle_radius: float, smoothing_factor: float, device: int = 0):
+        self._L = L.lib()
+        self.solver = solver
+        p = L.Params()
+        self._L.salva_hip_default_params(C.byref(p))
+        p.particle_radius = particle_radius
+        p.smoothing_factor = smoothing_factor
+        p.solver = solver.kind
+        p.min_pressure_iter, p.max_pressure_iter = solver.min_pressure_iter, solver.max_pressure_iter
+        p.max_density_error = solver.max_density_error
+        p.min_divergence_iter, p.max_divergence_iter = solver.min_divergence_iter, solver.max_divergence_iter
+        p.max_divergence_error = solver.max_divergence_error
+        p.device = device
+        p.enable_timers = 1
+        self._params = p
+        h = C.c_void_p()
+        L.check(self._L.salva_hip_create(C.byref(p), C.byref(h)))
+        self._h = h
+        self._particle_radius = float(particle_radius)
+        self._fluids = _ObjectSet()
+        self._boundaries = _ObjectSet()
+        self.counters = Counters()
+        self.last_stats = L.StepStats()
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.salva_hip_destroy(h)
+            self._h = None
+
+    # ---- liquid_world.rs:161-208
+    def add_fluid(self, fluid: Fluid) -> Fluid:
+        fluid._world, fluid._slot = self, len(self._fluids._items)
+        fluid._resized, fluid._dirty = True, L.DIRTY_ALL
+        self._fluids._items.append(fluid)
+        return fluid  # the handle is the object itself
+
+    def add_boundary(self, boundary: Boundary) -> Boundary:
+        boundary._world, boundary._slot = self, len(self._boundaries._items)
+        boundary._dirty = True
+        self._boundaries._items.append(boundary)
+        return boundary
+
+    def remove_fluid(self, handle: Fluid) -> Optional[Fluid]:
+        if handle not in self._fluids._items:
+            return None
+        handle._pull()
+        slot = handle._slot
+        if slot < self._L.salva_hip_num_fluids(self._h):
+            L.check(self._L.salva_hip_remove_fluid(self._h, slot))
+        items = self._fluids._items
+        last = items.pop()
+        if last is not handle:
+            items[slot] = last
+            last._slot = slot
+        handle._world, handle._slot = None, -1
+        return handle
+
+    def remove_boundary(self, handle: Boundary) -> Optional[Boundary]:
+        if handle not in self._boundaries._items:
+            return None
+        slot = handle._slot
+        if slot < self._L.salva_hip_num_boundaries(self._h):
+            L.check(self._L.salva_hip_remove_boundary(self._h, slot))
+        items = self._boundaries._items
+        last = items.pop()
+        if last is not handle:
+            items[slot] = last
+            last._slot = slot
+        handle._world, handle._slot = None, -1
+        return handle
+
+    def fluids(self) -> _ObjectSet:
+        return self._fluids
+
+    def boundaries(self) -> _ObjectSet:
+        return self._boundaries
+
+    def h(self) -> float:
+        return float(self._L.salva_hip_h(self._h))
+
+    def particle_radius(self) -> float:
+        return self._particle_radius
+
+    # ---- host <-> device synchronisation
+    def _download_fluid(self, f: Fluid):
+        n = f.num_particles()
+        if n:
+            L.check(self._L.salva_hip_get_fluid(self._h, f._slot, _fp(f._positions), _fp(f._velocities)))
+        f._device_newer = False
+
+    def _fetch_velocity_changes(self, f: Fluid) -> np.ndarray:
+        out = np.zeros((f.num_particles(), 3), F32)
+        if f.num_particles() and f._slot < self._L.salva_hip_num_fluids(self._h) \
+                and self._L.salva_hip_fluid_len(self._h, f._slot) == f.num_particles():
+            L.check(self._L.salva_hip_get_fluid_field(self._h, f._slot, L.FIELD_VELOCITY_CHANGE, _fp(out)))
+        return out
+
+    def _apply_particles_removal(self, f: Fluid):
+        """fluid.rs:88-98 + the compaction of the solver's buffers (dfsph_solver.rs:550-560)."""
+        if not f._deleted.any():
+            return
+        f._pull()
+        dv = f._pending_dv if f._pending_dv is not None else (
+            self._fetch_velocity_changes(f) if not f._resized else np.zeros((f.num_particles(), 3), F32))
+        keep = ~f._deleted
+        f._positions = np.ascontiguousarray(f._positions[keep])
+        f._velocities = np.ascontiguousarray(f._velocities[keep])
+        f._accelerations = np.ascontiguousarray(f._accelerations[keep])
+        f._volumes = np.ascontiguousarray(f._volumes[keep])
+        f._pending_dv = np.ascontiguousarray(dv[keep])
+        f._deleted = np.zeros(len(f._positions), bool)
+        f._resized, f._dirty = True, L.DIRTY_ALL
+
+    def _sync_fluid(self, f: Fluid):
+        self._apply_particles_removal(f)
+        descs = (L.ForceDesc * max(len(f.nonpressure_forces), 1))()
+        for k, force in enumerate(f.nonpressure_forces):
+            descs[k] = force._desc()
+        if f._resized or f._dirty:
+            n = f.num_particles()
+            dirty = L.DIRTY_ALL if f._resized else f._dirty
+            acc = f._accelerations if (f._acc_set and (dirty & L.DIRTY_ACCELERATIONS)) else None
+            dv = f._pending_dv if f._resized else None
+            L.check(self._L.salva_hip_set_fluid(
+                self._h, f._slot, n, _fp(f._positions), _fp(f._velocities), _fp(f._volumes), _fp(acc), _fp(dv),
+                f.density0, f.interaction_groups.memberships, f.interaction_groups.filter, dirty))
+            f._resized, f._dirty, f._pending_dv, f._acc_set = False, 0, None, False
+        L.check(self._L.salva_hip_set_fluid_forces(self._h, f._slot, descs, len(f.nonpressure_forces)))
+
+    def _sync_boundaries(self):
+        for b in self._boundaries:
+            if b._dirty:
+                L.check(self._L.salva_hip_set_boundary(
+                    self._h, b._slot, b.num_particles(), _fp(b._positions), _fp(b._velocities),
+                    b.interaction_groups.memberships, b.interaction_groups.filter, int(b.wants_forces)))
+                b._dirty = False
+
+    def _boundary_field(self, b: Boundary, volumes: bool) -> np.ndarray:
+        self._sync_boundaries()
+        n = b.num_particles()
+        if volumes:
+            out = np.zeros(n, F32)
+            if n:
+                L.check(self._L.salva_hip_get_boundary(self._h, b._slot, _fp(out), None))
+        else:
+            out = np.zeros((n, 3), F32)
+            if n:
+                L.check(self._L.salva_hip_get_boundary(self._h, b._slot, None, _fp(out)))
+        return out
+
+    def sync_to_device(self):
+        for f in self._fluids:
+            self._sync_fluid(f)
+        self._sync_boundaries()
+
+    # ---- liquid_world.rs:62-158
+    def step(self, dt: float, gravity=(0.0, -9.81, 0.0)) -> L.StepStats:
+        self.sync_to_device()
+        g = (C.c_float * 3)(*[float(x) for x in gravity])
+        st = L.StepStats()
+        rc = self._L.salva_hip_step(self._h, dt, g, C.byref(st))
+        for f in self._fluids:
+            f._device_newer = True
+            f._accelerations[:] = 0  # integrate_and_clear_accelerations
+        L.check(rc)
+        self.last_stats = st
+        c = self.counters
+        c.nsubsteps = 1
+        c.ncontacts = int(st.ncontacts)
+        c.n_divergence_iters, c.n_pressure_iters = st.n_divergence_iters, st.n_pressure_iters
+        c.divergence_error, c.density_error = st.divergence_error, st.density_error
+        c.grid_ms, c.solver_ms, c.step_ms = st.grid_ms, st.solver_ms, st.step_ms
+        return st
+
+    # ---- solver scratch (private in the reference; exposed for the parity tests)
+    def fluid_field(self, f: Fluid, field: int) -> np.ndarray:
+        n = f.num_particles()
+        vec = field in (L.FIELD_VELOCITY_CHANGE, L.FIELD_ACCELERATION)
+        out = np.zeros((n, 3) if vec else n, F32)
+        if n:
+            L.check(self._L.salva_hip_get_fluid_field(self._h, f._slot, field, _fp(out)))
+        return out
+
+    def densities(self, f: Fluid) -> np.ndarray:
+        return self.fluid_field(f, L.FIELD_DENSITY)
+
+    def alphas(self, f: Fluid) -> np.ndarray:
+        return self.fluid_field(f, L.FIELD_ALPHA)
+
+    def velocity_changes(self, f: Fluid) -> np.ndarray:
+        return self.fluid_field(f, L.FIELD_VELOCITY_CHANGE)
+
+    def pressures(self, f: Fluid) -> np.ndarray:
+        return self.fluid_field(f, L.FIELD_PRESSURE)
+
+    def contact_counts(self, f: Fluid, boundary_contacts: bool = False) -> np.ndarray:
+        fld = L.FIELD_NUM_BOUNDARY_CONTACTS if boundary_contacts else L.FIELD_NUM_FLUID_CONTACTS
+        return self.fluid_field(f, fld).astype(np.uint32)
+
+    def device_bytes(self) -> int:
+        return int(self._L.salva_hip_device_bytes(self._h))
+
+    def time_pred_density(self, reps: int = 20) -> float:
+        """Average k_pred_density launch duration in microseconds (HIP events on the world's stream)."""
+        us = float(self._L.salva_hip_time_pred_density(self._h, reps))
+        if us < 0:
+            L.check(int(us))
+        return us

@@ -1,0 +1,101 @@
+"""Small seeded scenes shared by the golden-vector generator, the oracle tests and the GPU parity tests."""
+from __future__ import annotations
+
+import numpy as np
+
+from parity import DT, GRAVITY, Scene
+from salva_amd import scenes
+
+R = 0.025
+
+
+def scene_dfsph_xsph_block():
+    """Free jittered block with random velocities: DFSPH + XSPH(0.5, 0) — the shape of BASELINE config 2 (B)."""
+    s = Scene(R, 2.0, "dfsph")
+    pos = scenes.jitter(scenes.cube_fluid_positions(9, 9, 9, R), 0.1 * R, seed=42)
+    vel = scenes.random_velocities(len(pos), 0.1, seed=12345)
+    # volumes 1.7x the default: rest density ~1.35 rho0, so the pressure solver needs several iterations per step
+    vol = np.full(len(pos), 1.7 * 0.8 * (2 * R) ** 3, np.float32)
+    s.add_fluid(pos, vel, 1000.0, forces=[("xsph", 0.5, 0.0)], volumes=vol)
+    s.solver_params.update(max_density_error=0.002, max_divergence_iter=20)
+    return s
+
+
+def scene_dfsph_tank():
+    """Block resting in an open lattice tank: DFSPH + ArtificialViscosity(1, 0) as examples3d/basic3.rs + boundary forces."""
+    s = Scene(R, 2.0, "dfsph")
+    fluid, shell = scenes.tank(8, 10, 8, R)
+    fluid = scenes.jitter(fluid, 0.05 * R, seed=42)
+    s.add_fluid(fluid, None, 1000.0, forces=[("artificial", 1.0, 0.5)])
+    s.add_boundary(shell, wants_forces=True)
+    return s
+
+
+def scene_iisph_akinci():
+    """IISPH + Akinci2013(1, 10) + XSPH(0.5, 0.2) over a floor (BASELINE config 3 / faucet3.rs forces)."""
+    s = Scene(R, 2.0, "iisph")
+    pos = scenes.jitter(scenes.cube_fluid_positions(8, 8, 8, R), 0.1 * R, seed=42)
+    pos[:, 1] += np.float32(8 * R + 2 * R)
+    vel = scenes.random_velocities(len(pos), 0.05, seed=12345)
+    vol = np.full(len(pos), 1.6 * 0.8 * (2 * R) ** 3, np.float32)
+    s.add_fluid(pos, vel, 1000.0, forces=[("xsph", 0.5, 0.2), ("akinci", 1.0, 10.0)], volumes=vol)
+    floor = scenes.plane_lattice(14, 14, 0.0, R, -7 * 2 * R + R, -7 * 2 * R + R, layers=2)
+    s.add_boundary(floor, wants_forces=True)
+    return s
+
+
+def scene_two_phase():
+    """Two fluids, density ratio 2:1, stacked, each with XSPH (BASELINE config 4 in miniature) over a floor."""
+    s = Scene(R, 2.0, "dfsph")
+    a = scenes.jitter(scenes.cube_fluid_positions(8, 5, 8, R), 0.05 * R, seed=42)
+    b = scenes.jitter(scenes.cube_fluid_positions(8, 5, 8, R), 0.05 * R, seed=43)
+    a[:, 1] += np.float32(5 * R + 2 * R)
+    b[:, 1] += np.float32(15 * R + 2 * R)
+    vol = np.full(len(a), 1.28 * 0.8 * (2 * R) ** 3, np.float32)
+    s.add_fluid(a, None, 1000.0, forces=[("xsph", 0.5, 0.0)], volumes=vol)
+    s.add_fluid(b, None, 500.0, forces=[("xsph", 0.5, 0.0)], volumes=vol)
+    floor = scenes.plane_lattice(12, 12, 0.0, R, -6 * 2 * R + R, -6 * 2 * R + R, layers=1)
+    s.add_boundary(floor)
+    s.solver_params.update(max_density_error=0.005)
+    return s
+
+
+SCENES = {
+    "dfsph_xsph_block": (scene_dfsph_xsph_block, 6),
+    "dfsph_tank": (scene_dfsph_tank, 6),
+    "iisph_akinci": (scene_iisph_akinci, 6),
+    "two_phase": (scene_two_phase, 6),
+}
+
+
+def run_oracle(scene: Scene, nsteps: int, **kw):
+    """Step the oracle and collect everything the parity tests look at."""
+    w = scene.make_oracle(**kw)
+    out = {}
+    iters = []
+    for step in range(nsteps):
+        st = w.step(DT, GRAVITY)
+        iters.append([st.n_div_iters, st.n_press_iters, st.ncontacts])
+        if step == 0:
+            for f in range(len(scene.fluids)):
+                out[f"s1_density_{f}"] = w.fluid_scalar(f, "densities").astype(np.float32)
+                out[f"s1_alpha_{f}"] = w.fluid_scalar(f, "alphas").astype(np.float32)
+                out[f"s1_nff_{f}"] = w.contact_counts(f, False)
+                out[f"s1_nfb_{f}"] = w.contact_counts(f, True)
+                out[f"s1_pos_{f}"] = w.fluid_vec(f, "positions").astype(np.float32)
+                out[f"s1_vel_{f}"] = w.fluid_vec(f, "velocities").astype(np.float32)
+                out[f"s1_dv_{f}"] = w.fluid_vec(f, "velocity_changes").astype(np.float32)
+            for b in range(len(scene.boundaries)):
+                out[f"s1_bvol_{b}"] = w.boundary_volumes(b).astype(np.float32)
+    for f in range(len(scene.fluids)):
+        out[f"pos_{f}"] = w.fluid_vec(f, "positions").astype(np.float32)
+        out[f"vel_{f}"] = w.fluid_vec(f, "velocities").astype(np.float32)
+        out[f"dv_{f}"] = w.fluid_vec(f, "velocity_changes").astype(np.float32)
+        out[f"density_{f}"] = w.fluid_scalar(f, "densities").astype(np.float32)
+        if scene.solver == "iisph":
+            out[f"pressure_{f}"] = w.fluid_scalar(f, "pressures").astype(np.float32)
+    for b, bd in enumerate(scene.boundaries):
+        if bd["wants_forces"]:
+            out[f"bforce_{b}"] = w.boundary_vec(b, "forces").astype(np.float32)
+    out["iters"] = np.asarray(iters, dtype=np.int64)
+    return out

@@ -1,0 +1,100 @@
+"""Shared scene construction for the parity tests: the same inputs go to the CPU oracle and to the HIP path."""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import oracle as O
+from salva_amd import (Akinci2013SurfaceTension, ArtificialViscosity, Boundary, DFSPHSolver, Fluid, IISPHSolver,
+                       InteractionGroups, LiquidWorld, XSPHViscosity)
+
+GRAVITY = (0.0, -9.81, 0.0)
+DT = 1.0 / 200.0
+
+
+class Scene:
+    """A list of fluids / boundaries + forces, instantiable on either implementation."""
+
+    def __init__(self, radius=0.025, smoothing=2.0, solver="dfsph"):
+        self.radius, self.smoothing, self.solver = radius, smoothing, solver
+        # pub tuning fields of DFSPHSolver / IISPHSolver (dfsph_solver.rs:21-38)
+        self.solver_params = dict(min_pressure_iter=1, max_pressure_iter=50, max_density_error=0.05,
+                                  min_divergence_iter=1, max_divergence_iter=50, max_divergence_error=0.1)
+        self.fluids = []      # dict(pos, vel, density0, groups, forces=[("xsph", a, b), ...], volumes)
+        self.boundaries = []  # dict(pos, vel, groups, wants_forces)
+
+    def add_fluid(self, pos, vel=None, density0=1000.0, groups=(1, 0xFFFFFFFF), forces=(), volumes=None):
+        self.fluids.append(dict(pos=np.asarray(pos, np.float32), vel=None if vel is None else np.asarray(vel, np.float32),
+                                density0=density0, groups=groups, forces=list(forces), volumes=volumes))
+        return len(self.fluids) - 1
+
+    def add_boundary(self, pos, vel=None, groups=(1, 0xFFFFFFFF), wants_forces=False):
+        self.boundaries.append(dict(pos=np.asarray(pos, np.float32), vel=None if vel is None else np.asarray(vel, np.float32),
+                                    groups=groups, wants_forces=wants_forces))
+        return len(self.boundaries) - 1
+
+    # ---------------------------------------------------------------- oracle
+    def make_oracle(self, f64=False, threads=1, shuffle_seed=0) -> O.OracleWorld:
+        w = O.OracleWorld(self.radius, self.smoothing, O.DFSPH if self.solver == "dfsph" else O.IISPH, f64=f64, threads=threads)
+        if shuffle_seed:
+            w.set_shuffle_seed(shuffle_seed)
+        w.set_solver_params(**self.solver_params)
+        for f in self.fluids:
+            fid = w.add_fluid(f["pos"], f["density0"], f["vel"], f["groups"][0], f["groups"][1])
+            if f["volumes"] is not None:
+                w.set_fluid_volumes(fid, f["volumes"])
+            for frc in f["forces"]:
+                if frc[0] == "xsph":
+                    w.add_xsph(fid, frc[1], frc[2])
+                elif frc[0] == "artificial":
+                    w.add_artificial_viscosity(fid, *frc[1:])
+                elif frc[0] == "akinci":
+                    w.add_akinci2013(fid, frc[1], frc[2])
+                else:
+                    raise ValueError(frc)
+        for b in self.boundaries:
+            w.add_boundary(b["pos"], b["vel"], b["groups"][0], b["groups"][1], b["wants_forces"])
+        return w
+
+    # ---------------------------------------------------------------- HIP path (through the C ABI)
+    def make_hip(self):
+        solver = DFSPHSolver() if self.solver == "dfsph" else IISPHSolver()
+        for k, v in self.solver_params.items():
+            setattr(solver, k, v)
+        w = LiquidWorld(solver, self.radius, self.smoothing)
+        handles = []
+        for f in self.fluids:
+            fl = Fluid(f["pos"], self.radius, f["density0"], InteractionGroups(*f["groups"]))
+            if f["vel"] is not None:
+                fl.velocities = f["vel"]
+            if f["volumes"] is not None:
+                fl.volumes = f["volumes"]
+            for frc in f["forces"]:
+                if frc[0] == "xsph":
+                    fl.nonpressure_forces.append(XSPHViscosity(frc[1], frc[2]))
+                elif frc[0] == "artificial":
+                    av = ArtificialViscosity(frc[1], frc[2])
+                    if len(frc) > 3:
+                        av.alpha, av.beta, av.speed_of_sound = frc[3], frc[4], frc[5]
+                    fl.nonpressure_forces.append(av)
+                elif frc[0] == "akinci":
+                    fl.nonpressure_forces.append(Akinci2013SurfaceTension(frc[1], frc[2]))
+            handles.append(w.add_fluid(fl))
+        bhandles = []
+        for b in self.boundaries:
+            bo = Boundary(b["pos"], InteractionGroups(*b["groups"]), wants_forces=b["wants_forces"])
+            if b["vel"] is not None:
+                bo.velocities = b["vel"]
+            bhandles.append(w.add_boundary(bo))
+        return w, handles, bhandles
+
+
+def rel_err(a, b, floor=0.0):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
+
+
+def max_norm_diff(a, b):
+    a = np.asarray(a, np.float64).reshape(-1, 3)
+    b = np.asarray(b, np.float64).reshape(-1, 3)
+    return float(np.max(np.linalg.norm(a - b, axis=1))) if a.size else 0.0

@@ -1,0 +1,236 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the Python mirror of the salva3d API) against the CPU
+oracle on identical seeded inputs, and against the committed golden fixtures.
+
+Tolerances (f32; the reference's own summation order is unspecified):
+  contact counts ................ exact (the d^2 <= h^2 test is evaluated with the reference's rounding)
+  densities, boundary volumes ... rel 1e-5      alphas ... rel 1e-4
+  positions after N steps ....... 1e-4 * particle_radius * N   (the oracle's own f32/f64/order noise is ~1e-6 r per step,
+                                  tests/test_oracle.py::test_noise_floor_f64_order_threads)
+  velocities / velocity changes . 1e-4 * N * v_ref with v_ref = max(|v|, 2r/dt * 1e-2)
+  iteration counts .............. equal, +-1 tolerated where the error sits on the threshold
+"""
+import os
+
+import numpy as np
+import pytest
+
+from golden_scenes import R, SCENES, run_oracle
+from parity import DT, GRAVITY, Scene, max_norm_diff, rel_err
+from salva_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def run_hip(scene: Scene, nsteps: int):
+    """Mirror of golden_scenes.run_oracle on the HIP path."""
+    w, fl, bo = scene.make_hip()
+    out = {}
+    iters = []
+    for step in range(nsteps):
+        st = w.step(DT, GRAVITY)
+        iters.append([st.n_divergence_iters, st.n_pressure_iters, st.ncontacts])
+        if step == 0:
+            for f, h in enumerate(fl):
+                out[f"s1_density_{f}"] = w.densities(h)
+                out[f"s1_alpha_{f}"] = w.alphas(h)
+                out[f"s1_nff_{f}"] = w.contact_counts(h, False)
+                out[f"s1_nfb_{f}"] = w.contact_counts(h, True)
+                out[f"s1_pos_{f}"] = h.positions.copy()
+                out[f"s1_vel_{f}"] = h.velocities.copy()
+                out[f"s1_dv_{f}"] = w.velocity_changes(h)
+            for b, h in enumerate(bo):
+                out[f"s1_bvol_{b}"] = h.volumes
+    for f, h in enumerate(fl):
+        out[f"pos_{f}"] = h.positions.copy()
+        out[f"vel_{f}"] = h.velocities.copy()
+        out[f"dv_{f}"] = w.velocity_changes(h)
+        out[f"density_{f}"] = w.densities(h)
+        if scene.solver == "iisph":
+            out[f"pressure_{f}"] = w.pressures(h)
+    for b, h in enumerate(bo):
+        if h.wants_forces:
+            out[f"bforce_{b}"] = h.forces
+    out["iters"] = np.asarray(iters, dtype=np.int64)
+    return out
+
+
+def compare(got, ref, scene, nsteps, label):
+    nf = len(scene.fluids)
+    vref = max(2 * R / DT * 1e-2, max(float(np.abs(ref[f"vel_{f}"]).max()) for f in range(nf)))
+    for f in range(nf):
+        assert (got[f"s1_nff_{f}"] == ref[f"s1_nff_{f}"]).all(), f"{label}: fluid-fluid contact counts differ"
+        assert (got[f"s1_nfb_{f}"] == ref[f"s1_nfb_{f}"]).all(), f"{label}: fluid-boundary contact counts differ"
+        assert rel_err(got[f"s1_density_{f}"], ref[f"s1_density_{f}"]) < 1e-5, label
+        if scene.solver == "dfsph":
+            a, b = got[f"s1_alpha_{f}"], ref[f"s1_alpha_{f}"]
+            assert rel_err(a, b, floor=float(np.abs(b).max()) * 1e-3) < 1e-4, label
+        assert max_norm_diff(got[f"s1_pos_{f}"], ref[f"s1_pos_{f}"]) < 1e-4 * R, label
+        assert max_norm_diff(got[f"s1_vel_{f}"], ref[f"s1_vel_{f}"]) < 1e-4 * vref, label
+        assert max_norm_diff(got[f"s1_dv_{f}"], ref[f"s1_dv_{f}"]) < 1e-4 * vref, label
+        assert max_norm_diff(got[f"pos_{f}"], ref[f"pos_{f}"]) < 1e-4 * R * nsteps, label
+        assert max_norm_diff(got[f"vel_{f}"], ref[f"vel_{f}"]) < 1e-4 * vref * nsteps, label
+        assert max_norm_diff(got[f"dv_{f}"], ref[f"dv_{f}"]) < 1e-4 * vref * nsteps, label
+        assert rel_err(got[f"density_{f}"], ref[f"density_{f}"]) < 1e-4, label
+        if scene.solver == "iisph":
+            pr = ref[f"pressure_{f}"]
+            assert np.max(np.abs(got[f"pressure_{f}"] - pr)) < 1e-3 * max(1.0, float(pr.max())), label
+    for b, bd in enumerate(scene.boundaries):
+        assert rel_err(got[f"s1_bvol_{b}"], ref[f"s1_bvol_{b}"]) < 1e-5, label
+        if bd["wants_forces"]:
+            fr = ref[f"bforce_{b}"]
+            scale = max(float(np.abs(fr).max()), 1e-6)
+            assert np.max(np.abs(got[f"bforce_{b}"] - fr)) < 2e-3 * scale, label
+    gi, ri = got["iters"], ref["iters"]
+    assert (gi[:, 2] == ri[:, 2]).all(), f"{label}: ncontacts differ {gi[:, 2]} vs {ri[:, 2]}"
+    assert (np.abs(gi[:, :2] - ri[:, :2]) <= 1).all(), f"{label}: iteration counts {gi[:, :2].tolist()} vs {ri[:, :2].tolist()}"
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_against_live_oracle(name):
+    builder, nsteps = SCENES[name]
+    scene = builder()
+    compare(run_hip(scene, nsteps), run_oracle(scene, nsteps), scene, nsteps, f"{name} vs oracle")
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_against_golden_fixture(name):
+    builder, nsteps = SCENES[name]
+    scene = builder()
+    ref = dict(np.load(os.path.join(GOLDEN, f"{name}.npz")))
+    compare(run_hip(scene, nsteps), ref, scene, nsteps, f"{name} vs golden")
+
+
+def test_longer_trajectory_dam_break():
+    """60 steps of a 12x16x12 block collapsing in a tank (basic3-like: DFSPH + ArtificialViscosity)."""
+    s = Scene(R, 2.0, "dfsph")
+    fluid, shell = scenes.tank(12, 16, 12, R, wall_cells=10)
+    s.add_fluid(scenes.jitter(fluid, 0.05 * R, seed=42), None, 1000.0, forces=[("artificial", 1.0, 0.0)])
+    s.add_boundary(shell)
+    n = 60
+    w, (fl,), _ = s.make_hip()
+    o = s.make_oracle(threads=4)
+    worst = 0.0
+    for k in range(n):
+        st = w.step(DT, GRAVITY)
+        so = o.step(DT, GRAVITY)
+        assert st.ncontacts == so.ncontacts or k > 10, (k, st.ncontacts, so.ncontacts)
+        assert abs(st.n_pressure_iters - so.n_press_iters) <= 1 and abs(st.n_divergence_iters - so.n_div_iters) <= 2, k
+        if k in (0, 9, n - 1):
+            d = max_norm_diff(fl.positions, o.fluid_vec(0, "positions")) / R
+            worst = max(worst, d / (k + 1))
+    # chaotic growth is slow on this time scale: stay within 1e-3 r per step
+    assert worst < 1e-3, worst
+    assert fl.positions[:, 1].min() > shell[:, 1].min() - R  # nothing fell through the floor
+
+
+def test_api_semantics_match_reference():
+    """Velocity lag, dt lag, host edits between steps, add / delete particles, remove fluid (swap-remove)."""
+    from salva_amd import DFSPHSolver, Fluid, LiquidWorld, XSPHViscosity
+
+    pos = scenes.jitter(scenes.cube_fluid_positions(6, 6, 6, R), 0.1 * R)
+    vel = scenes.random_velocities(len(pos), 0.1)
+    s = Scene(R, 2.0, "dfsph")
+    s.add_fluid(pos, vel, 1000.0, forces=[("xsph", 0.5, 0.0)])
+    w, (fl,), _ = s.make_hip()
+    o = s.make_oracle()
+    x0 = fl.positions.copy()
+    st = w.step(DT, GRAVITY)
+    so = o.step(DT, GRAVITY)
+    assert st.n_divergence_iters == so.n_div_iters == 50  # first step: inv_dt = 0 -> tolerance 0
+    v, dv = fl.velocities, w.velocity_changes(fl)
+    assert np.allclose(fl.positions, x0 + (v + dv) * np.float32(DT), atol=1e-6)  # x += (v + dv) dt, v not updated (:411-420)
+    # host edit between steps (heightfield3.rs:40 overwrites velocities): assign + step on both sides
+    newv = scenes.random_velocities(len(pos), 0.05, seed=7)
+    fl.velocities = newv
+    o.set_fluid_velocities(0, newv)
+    w.step(DT, GRAVITY)
+    o.step(DT, GRAVITY)
+    assert max_norm_diff(fl.positions, o.fluid_vec(0, "positions")) < 2e-4 * R
+    assert max_norm_diff(w.velocity_changes(fl), o.fluid_vec(0, "velocity_changes")) < 1e-3
+    # add particles (faucet3.rs:99-103) then delete some (faucet3.rs:69-73)
+    extra = scenes.cube_fluid_positions(3, 3, 3, R) + np.float32([0.0, 0.6, 0.0])
+    fl.add_particles(extra, np.zeros_like(extra))
+    assert fl.num_particles() == len(pos) + 27
+    w.step(DT, GRAVITY)
+    assert fl.positions.shape == (len(pos) + 27, 3) and np.isfinite(fl.positions).all()
+    for i in (0, 5, 100):
+        fl.delete_particle_at_next_timestep(i)
+    before = fl.positions.copy()
+    w.step(DT, GRAVITY)
+    assert fl.num_particles() == len(pos) + 24
+    keep = np.ones(len(before), bool)
+    keep[[0, 5, 100]] = False
+    assert np.max(np.abs(fl.positions - before[keep])) < 0.05  # order-preserving compaction (helper.rs:4-12)
+    # second fluid + swap-remove of the first
+    f2 = Fluid(scenes.cube_fluid_positions(4, 4, 4, R) + np.float32([1.0, 0.0, 0.0]), R, 500.0)
+    f2.nonpressure_forces.append(XSPHViscosity(0.5, 0.0))
+    w.add_fluid(f2)
+    w.step(DT, GRAVITY)
+    assert w.remove_fluid(fl) is fl and len(w.fluids()) == 1 and f2._slot == 0
+    w.step(DT, GRAVITY)
+    assert np.isfinite(f2.positions).all() and f2.num_particles() == 64
+
+
+def test_edge_cases():
+    from salva_amd import Boundary, DFSPHSolver, Fluid, LiquidWorld, _lib
+
+    w = LiquidWorld(DFSPHSolver(), R, 2.0)
+    st = w.step(DT, GRAVITY)  # empty world
+    assert st.nparticles == 0
+    f = w.add_fluid(Fluid(np.zeros((0, 3), np.float32), R, 1000.0))  # empty fluid (faucet3.rs:39-44 starts like this)
+    w.step(DT, GRAVITY)
+    f.add_particles(np.float32([[0.0, 1.0, 0.0]]))  # a single particle: only the self contact, alpha = 0
+    st = w.step(DT, GRAVITY)
+    assert st.ncontacts == 1
+    y0 = float(f.positions[0, 1])
+    w.step(DT, GRAVITY)
+    assert f.positions[0, 1] < y0  # free fall
+    # two coincident particles: |d| = 0 -> gradient 0 (kernel.rs:18-24), W = W(0)
+    g = w.add_fluid(Fluid(np.float32([[5.0, 0.0, 0.0], [5.0, 0.0, 0.0]]), R, 1000.0))
+    st = w.step(DT, GRAVITY)
+    assert np.isfinite(g.positions).all()
+    assert (w.contact_counts(g) == 2).all()
+    # NaN positions are reported, not propagated silently (the reference would panic in hgrid.rs:42)
+    bad = LiquidWorld(DFSPHSolver(), R, 2.0)
+    bad.add_fluid(Fluid(np.float32([[np.nan, 0.0, 0.0], [0.0, 0.0, 0.0]]), R, 1000.0))
+    with pytest.raises(_lib.SalvaHipError) as e:
+        bad.step(DT, GRAVITY)
+    assert e.value.code == _lib.E_NUMERIC
+    # dt <= eps: no substep (timestep_manager.rs:56-58)
+    w2 = LiquidWorld(DFSPHSolver(), R, 2.0)
+    h = w2.add_fluid(Fluid(scenes.cube_fluid_positions(3, 3, 3, R), R, 1000.0))
+    x = h.positions.copy()
+    w2.step(0.0, GRAVITY)
+    assert np.array_equal(h.positions, x)
+
+
+def test_large_block_invariants():
+    """Size-independent properties at 64^3 = 262k particles (the oracle needs ~10 s per step there, so only step 1 is
+    compared directly): contact symmetry (sum of counts = ncontacts, even off-diagonal), momentum conservation of the
+    pressure solver, run-to-run determinism."""
+    n = 64
+    pos = scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.1 * R)
+    vel = scenes.random_velocities(len(pos), 0.1)
+    s = Scene(R, 2.0, "dfsph")
+    s.add_fluid(pos, vel, 1000.0)
+    s.solver_params.update(max_divergence_iter=3)
+    w, (fl,), _ = s.make_hip()
+    st = w.step(DT, (0.0, 0.0, 0.0))
+    cnt = w.contact_counts(fl)
+    assert int(cnt.sum()) == st.ncontacts and (st.ncontacts - len(pos)) % 2 == 0
+    m = np.float64(fl.particle_mass(0))
+    p0 = m * vel.astype(np.float64).sum(axis=0)
+    p1 = m * (fl.velocities.astype(np.float64) + w.velocity_changes(fl).astype(np.float64)).sum(axis=0)
+    assert np.max(np.abs(p1 - p0)) < 1e-5 * m * np.abs(vel).sum()
+    o = s.make_oracle(threads=8)
+    so = o.step(DT, (0.0, 0.0, 0.0))
+    assert so.ncontacts == st.ncontacts
+    assert (o.contact_counts(0) == cnt).all()
+    assert rel_err(w.densities(fl), o.fluid_scalar(0, "densities")) < 1e-5
+    assert max_norm_diff(fl.positions, o.fluid_vec(0, "positions")) < 1e-4 * R
+    # determinism: a second world fed the same input gives bit-identical output
+    w2, (fl2,), _ = s.make_hip()
+    w2.step(DT, (0.0, 0.0, 0.0))
+    assert np.array_equal(fl.positions, fl2.positions) and np.array_equal(w.velocity_changes(fl), w2.velocity_changes(fl2))

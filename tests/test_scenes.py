@@ -1,0 +1,35 @@
+import numpy as np
+
+from salva_amd import scenes
+
+
+def test_cube_fluid_matches_helper_rs():
+    """examples3d/helper.rs:4-20: i-major / k-minor, spacing 2r, centred on the origin."""
+    r = np.float32(0.05)
+    p = scenes.cube_fluid_positions(3, 2, 4, float(r))
+    assert p.shape == (24, 3) and p.dtype == np.float32
+    assert np.allclose(p.mean(axis=0), 0.0, atol=1e-6)
+    assert np.allclose(p[1] - p[0], [0, 0, 2 * r])          # k is the fastest index
+    assert np.allclose(p[4] - p[0], [0, 2 * r, 0])
+    assert np.allclose(p[8] - p[0], [2 * r, 0, 0])
+    assert np.allclose(p[0], [r - 3 * r, r - 2 * r, r - 4 * r])
+
+
+def test_lcg_is_the_numerical_recipes_sequence():
+    x, ref = 42, []
+    for _ in range(1000):
+        x = (1664525 * x + 1013904223) & 0xFFFFFFFF
+        ref.append((x >> 8) / float(1 << 24))
+    got = scenes.lcg_uniform(1000, 42)
+    assert np.array_equal(got, np.asarray(ref, np.float32))
+    v = scenes.random_velocities(10, 0.1)
+    assert v.shape == (10, 3) and np.abs(v).max() <= 0.1
+
+
+def test_box_shell_and_tank():
+    sh = scenes.box_shell([0, 0, 0], [1, 1, 1], 0.05, faces="y")
+    assert len(sh) == 11 * 11 and np.allclose(sh[:, 1], 0.0)
+    fluid, shell = scenes.tank(4, 4, 4, 0.05)
+    assert len(fluid) == 64
+    assert shell[:, 1].min() < fluid[:, 1].min()
+    assert len(np.unique(np.round((shell - shell.min(axis=0)) / 0.1).astype(int), axis=0)) == len(shell)
