@@ -27,7 +27,11 @@ def scene_dfsph_tank():
     fluid, shell = scenes.tank(8, 10, 8, R)
     fluid = scenes.jitter(fluid, 0.05 * R, seed=42)
     s.add_fluid(fluid, None, 1000.0, forces=[("artificial", 1.0, 0.5)])
-    s.add_boundary(shell, wants_forces=True)
+    # no force read-back here: with a boundary viscosity coefficient the reference applies the *running sum* of the
+    # boundary acceleration per contact (artificial_viscosity.rs:117), which makes boundary.forces depend on the
+    # (unspecified) contact order — the oracle itself moves by 20 % under shuffle_seed.  Forces are compared in the
+    # two_phase (DFSPH pressure) and iisph_akinci (IISPH pressure, XSPH, adhesion) scenes instead.
+    s.add_boundary(shell, wants_forces=False)
     return s
 
 
@@ -55,7 +59,7 @@ def scene_two_phase():
     s.add_fluid(a, None, 1000.0, forces=[("xsph", 0.5, 0.0)], volumes=vol)
     s.add_fluid(b, None, 500.0, forces=[("xsph", 0.5, 0.0)], volumes=vol)
     floor = scenes.plane_lattice(12, 12, 0.0, R, -6 * 2 * R + R, -6 * 2 * R + R, layers=1)
-    s.add_boundary(floor)
+    s.add_boundary(floor, wants_forces=True)
     s.solver_params.update(max_density_error=0.005)
     return s
 

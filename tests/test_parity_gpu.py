@@ -138,7 +138,11 @@ def test_api_semantics_match_reference():
     x0 = fl.positions.copy()
     st = w.step(DT, GRAVITY)
     so = o.step(DT, GRAVITY)
-    assert st.n_divergence_iters == so.n_div_iters == 50  # first step: inv_dt = 0 -> tolerance 0
+    # first step: inv_dt = 0 -> the divergence tolerance is exactly 0 (dt lag).  The loop then only stops early if
+    # every clamped divergence is *exactly* zero, which depends on f32 summation order (the oracle itself flips under
+    # shuffle_seed), so only the protocol bounds are asserted here; the states still agree to tolerance below.
+    assert 1 <= st.n_divergence_iters <= 50 and 1 <= so.n_div_iters <= 50
+    assert max_norm_diff(fl.positions, o.fluid_vec(0, "positions")) < 1e-4 * R
     v, dv = fl.velocities, w.velocity_changes(fl)
     assert np.allclose(fl.positions, x0 + (v + dv) * np.float32(DT), atol=1e-6)  # x += (v + dv) dt, v not updated (:411-420)
     # host edit between steps (heightfield3.rs:40 overwrites velocities): assign + step on both sides
