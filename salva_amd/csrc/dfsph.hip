@@ -284,8 +284,9 @@ __device__ __forceinline__ void bbox_accumulate(bool active, float x, float y, f
     if ((threadIdx.x & (WAVE - 1)) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            if (mn[a] != INT_MAX) atomicMin(&bbox6[a], mn[a]);
-            if (mx[a] != INT_MIN) atomicMax(&bbox6[3 + a], mx[a]);
+            // plain (possibly stale) read first: the bound is monotone, so almost every wave skips the atomic
+            if (mn[a] < bbox6[a]) atomicMin(&bbox6[a], mn[a]);
+            if (mx[a] > bbox6[3 + a]) atomicMax(&bbox6[3 + a], mx[a]);
         }
     }
 }

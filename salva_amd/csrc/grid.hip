@@ -43,8 +43,9 @@ __global__ __launch_bounds__(BLOCK) void k_bbox(const float4* __restrict__ pts, 
     if ((threadIdx.x & (WAVE - 1)) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            if (mn[a] != INT_MAX) atomicMin(&bbox6[a], mn[a]);
-            if (mx[a] != INT_MIN) atomicMax(&bbox6[3 + a], mx[a]);
+            // plain (possibly stale) read first: the bound is monotone, so almost every wave skips the atomic
+            if (mn[a] < bbox6[a]) atomicMin(&bbox6[a], mn[a]);
+            if (mx[a] > bbox6[3 + a]) atomicMax(&bbox6[3 + a], mx[a]);
         }
     }
     if (bad) atomicOr(flags, 1u);

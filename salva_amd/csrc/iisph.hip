@@ -251,8 +251,9 @@ __global__ __launch_bounds__(BLOCK) void k_iisph_finish(StepCtx c, float dt, con
     if ((threadIdx.x & (WAVE - 1)) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            if (mn[a] != INT_MAX) atomicMin(&bbox6[a], mn[a]);
-            if (mx[a] != INT_MIN) atomicMax(&bbox6[3 + a], mx[a]);
+            // plain (possibly stale) read first: the bound is monotone, so almost every wave skips the atomic
+            if (mn[a] < bbox6[a]) atomicMin(&bbox6[a], mn[a]);
+            if (mx[a] > bbox6[3 + a]) atomicMax(&bbox6[3 + a], mx[a]);
         }
     }
 }
