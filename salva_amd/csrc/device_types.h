@@ -7,8 +7,9 @@
 //   w    = (v+dv x, y, z, model id)   gathered by the evaluate passes and by the viscosity/tension forces
 //   vel  = (v x, y, z, volume)        streamed only
 //   dv   = (dv x, y, z, pressure)     streamed only (pressure = IISPH warm start, carried across steps)
-// Neighbour lists are sliced-ELL with slice = one wavefront: entry k of the particle handled by lane l of
-// wave s is nbr[slice_off[s] + 64 k + l], so a wave reads 256 contiguous bytes per k.
+// Neighbour lists are sliced-ELL with slice = 64 consecutive particles of one tile (one wavefront): entries 2q and
+// 2q+1 (16-bit LDS slots of the tile's halo, tile.h) of the particle handled by lane l of slice s live in the dword
+// nbr[slice_off[s] + 64 q + l], so a wave reads 256 contiguous bytes per pair of contacts.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -18,14 +19,15 @@
 
 namespace salva {
 
-// Dense cell table over the bounding box of one particle class.  cell_start has ncells+1 entries with
-// lower-bound semantics: cell_start[c] = first sorted index whose key >= c, so a run of consecutive cells
-// [c0, c1] is the index range [cell_start[c0], cell_start[c1 + 1]).  key = (ix * ny + iy) * nz + iz with
-// (ix,iy,iz) = floor(p / h) - origin (hgrid.rs:41-52): x is the slowest axis — the slab axis of the
-// multi-GPU decomposition — and z-neighbours are adjacent keys, so a 27-cell stencil is 9 contiguous runs.
-struct GridView {
+// Dense cell table over the (tile-aligned) bounding box of one particle class.  Cells are keyed tile-major:
+// key = tile_linear * 32 + cell_in_tile, tile_linear = (tx * nty + ty) * ntz + tz (x slowest), cell_in_tile =
+// (ux * 4 + uy) * 2 + uz, with (cx,cy,cz) = floor(p / h) (hgrid.rs:41-52) relative to the origin (ox,oy,oz), which
+// is a multiple of the tile shape in absolute cell coordinates.  cell_start has ncells+1 entries with lower-bound
+// semantics: cell_start[k] = first sorted index whose key >= k, so cell k is [cell_start[k], cell_start[k+1]) and a
+// whole tile is [cell_start[32 t], cell_start[32 t + 32)).
+struct TileGrid {
     int ox, oy, oz;
-    int nx, ny, nz;
+    int ntx, nty, ntz;
     const uint32_t* cell_start;
 };
 
@@ -53,11 +55,13 @@ struct StepCtx {
     float4* dijpj;       // IISPH sum_j d_ij p_j (xyz, unused)
     uint32_t* nff;       // # fluid-fluid contacts of each particle (self included)
     uint32_t* nfb;       // # fluid-boundary contacts
-    const uint64_t* slice_ff;
-    const uint32_t* nbr_ff;
+    const uint64_t* slice_ff;   // [nslices+1] dword offset of each slice's list
+    const uint32_t* nbr_ff;     // packed 16-bit halo slots
     const uint64_t* slice_fb;
     const uint32_t* nbr_fb;
-    GridView gf;
+    const uint32_t* tile_slice_base;  // [ntiles+1] first global slice of each tile
+    uint32_t ntiles;
+    TileGrid gf;
 
     // ---- boundary particles, cell-sorted order ----
     uint32_t nb;
@@ -66,7 +70,7 @@ struct StepCtx {
     uint32_t* bperm;     // sorted -> canonical boundary index
     float4* bforce;      // canonical order accumulators (nullptr if no boundary wants forces)
     const uint8_t* bwants;  // per boundary model: forces requested?
-    GridView gb;
+    TileGrid gb;
 
     // ---- per-model tables ----
     uint32_t nmodels, nbmodels;
@@ -87,7 +91,8 @@ struct Readback {
     uint32_t flags;
     int32_t bbox[6];      // fluid cell bbox (min xyz, max xyz)
     int32_t bbbox[6];     // boundary cell bbox
-    uint64_t nbr_total_ff, nbr_total_fb;  // padded sliced-ELL entry counts
+    uint64_t nbr_total_ff, nbr_total_fb;  // padded sliced-ELL sizes (dwords)
+    uint32_t max_halo_fluid, max_halo_boundary, nslices, pad;  // tile statistics of the current step
     uint64_t ncontacts_ff, ncontacts_fb, ncontacts_bb;
 };
 

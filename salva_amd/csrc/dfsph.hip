@@ -1,13 +1,15 @@
-// dfsph.hip — DFSPH pressure solver passes as one-lane-per-particle gather kernels.
+// dfsph.hip — DFSPH pressure solver passes on LDS-staged cell tiles (tile.h).
 //
 // Behaviour specified by /root/reference/src/solver/pressure/dfsph_solver.rs (line numbers cited per kernel)
-// and src/solver/helper.rs:9-65 (W / grad W are recomputed in-kernel from positions instead of being stored
-// per contact).  Every neighbour pass streams 4 B per contact (the index) plus the per-particle arrays, and
-// gathers the neighbour's 16-byte records through L1/L2.
+// and src/solver/helper.rs:9-65 (W / grad W are recomputed in-kernel from positions instead of being stored per
+// contact).  One workgroup per tile: the halo's 16-byte records are copied to LDS once, then one lane per particle
+// walks its list of 16-bit halo slots.  Contacts are directed (contacts.rs:40-55), so every fluid quantity is a
+// pure gather — no atomics; only the optional boundary reaction forces are accumulated atomically.
 #include <climits>
 
+#include "bbox.h"
 #include "kernels.h"
-#include "nbr_loops.h"
+#include "tile.h"
 
 namespace salva {
 
@@ -18,41 +20,47 @@ unsigned num_blocks(uint32_t n) { return div_up(n, BLOCK); }
 //   rho_i   = sum_j m_j W_ij + sum_b V_b rho0_i W_ib
 //   alpha_i = 1 / (sum |m_j grad W_ij|^2 + |sum m_j grad W_ij|^2), 0 if the denominator <= 1e-5
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_density_alpha(StepCtx c) {
-    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-    const uint32_t i = blk * BLOCK + threadIdx.x;
-    if (i >= c.n) return;
-    const float4 pi = c.posm[i];
-    const float rho0 = c.rho0_tab[c.model[i]];
-    float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f;
-    for_each_ff(c, i, [&](uint32_t j) {
-        const float4 pj = c.posm[j];
-        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
-        rho += pj.w * e.w;
-        const float gm = e.g * pj.w;
-        const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
-        sq += gx * gx + gy * gy + gz * gz;
-        gsx += gx; gsy += gy; gsz += gz;
+__global__ __launch_bounds__(TILE_THREADS) void k_density_alpha(StepCtx c) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* __restrict__ Lp = t.stage(c.posm);
+    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active) return;
+        const float4 pi = c.posm[i];
+        const float rho0 = c.rho0_tab[c.model[i]];
+        float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f;
+        for_each_ff(c, i, gs, [&](uint32_t s) {
+            const float4 pj = Lp[s];
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
+            rho += pj.w * e.w;
+            const float gm = e.g * pj.w;
+            const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
+            sq += gx * gx + gy * gy + gz * gz;
+            gsx += gx; gsy += gy; gsz += gz;
+        });
+        for_each_fb(c, t, i, gs, [&](uint32_t s) {
+            const float4 pj = Bp[s];
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
+            const float m = pj.w * rho0;
+            rho += m * e.w;
+            const float gm = e.g * m;
+            const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
+            sq += gx * gx + gy * gy + gz * gz;
+            gsx += gx; gsy += gy; gsz += gz;
+        });
+        if (!(rho > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!density.is_zero()) :662
+        const float denom = sq + (gsx * gsx + gsy * gsy + gsz * gsz);
+        c.rho[i] = rho;
+        c.alpha[i] = (denom <= 1.0e-5f) ? 0.0f : 1.0f / denom;
     });
-    for_each_fb(c, i, [&](uint32_t j) {
-        const float4 pj = c.bposv[j];
-        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
-        const float m = pj.w * rho0;
-        rho += m * e.w;
-        const float gm = e.g * m;
-        const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
-        sq += gx * gx + gy * gy + gz * gz;
-        gsx += gx; gsy += gy; gsz += gz;
-    });
-    if (!(rho > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!density.is_zero()) :662
-    const float denom = sq + (gsx * gsx + gsy * gsy + gsz * gsz);
-    c.rho[i] = rho;
-    c.alpha[i] = (denom <= 1.0e-5f) ? 0.0f : 1.0f / denom;
 }
-void launch_density_alpha(const StepCtx& c, hipStream_t s) {
-    if (c.n) k_density_alpha<<<num_blocks(c.n), BLOCK, 0, s>>>(c);
+void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_density_alpha, c, L.bytes(16, 16, 2), s, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -60,43 +68,52 @@ void launch_density_alpha(const StepCtx& c, hipStream_t s) {
 // skipped (0) when the particle has fewer than 20 contacts; stores kappa_i = D rho_i * alpha_i (the only use of
 // the divergence, :370,:382) and the per-particle error D rho_i / rho0.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_divergence(StepCtx c) {
-    __shared__ float red[BLOCK / WAVE];
-    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-    const uint32_t i = blk * BLOCK + threadIdx.x;
-    const bool active = i < c.n;
-    float err = 0.0f;
-    uint32_t mi = 0;
-    if (active) {
-        mi = c.model[i];
-        const float rho0 = c.rho0_tab[mi];
-        float div = 0.0f;
-        const uint32_t ncontacts = c.nff[i] + (c.nb ? c.nfb[i] : 0u);
-        if (ncontacts >= c.min_neighbors_for_divergence) {
-            const float4 pi = c.posm[i];
-            const float4 wi = c.w[i];
-            for_each_ff(c, i, [&](uint32_t j) {
-                const float4 pj = c.posm[j];
-                const float4 wj = c.w[j];
-                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-                div += ((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g * pj.w;
-            });
-            for_each_fb(c, i, [&](uint32_t j) {
-                const float4 pj = c.bposv[j];
-                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-                div += (wi.x * dx + wi.y * dy + wi.z * dz) * g * (pj.w * rho0);  // boundary velocity ignored (:332-333)
-            });
-            div = fmaxf(div, 0.0f);
+__global__ __launch_bounds__(TILE_THREADS) void k_divergence(StepCtx c) {
+    __shared__ float errtab[TILE_WAVES][MAX_MODELS];
+    Tile t;
+    t.setup(c);
+    if (t.empty()) { TileErr::zero(c, t.tile); return; }
+    const float4* __restrict__ Lp = t.stage(c.posm);
+    const float4* __restrict__ Lw = t.stage(c.w);
+    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    TileErr E;
+    E.init(errtab, c);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        float err = 0.0f;
+        uint32_t mi = 0;
+        if (active) {
+            mi = c.model[i];
+            const float rho0 = c.rho0_tab[mi];
+            float div = 0.0f;
+            const uint32_t ncontacts = c.nff[i] + (c.nb ? c.nfb[i] : 0u);
+            if (ncontacts >= c.min_neighbors_for_divergence) {
+                const float4 pi = c.posm[i];
+                const float4 wi = c.w[i];
+                for_each_ff(c, i, gs, [&](uint32_t s) {
+                    const float4 pj = Lp[s];
+                    const float4 wj = Lw[s];
+                    const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                    const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                    div += ((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g * pj.w;
+                });
+                for_each_fb(c, t, i, gs, [&](uint32_t s) {
+                    const float4 pj = Bp[s];
+                    const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                    const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                    div += (wi.x * dx + wi.y * dy + wi.z * dz) * g * (pj.w * rho0);  // boundary velocity ignored (:332-333)
+                });
+                div = fmaxf(div, 0.0f);
+            }
+            c.kappa[i] = div * c.alpha[i];
+            err = div / rho0;
         }
-        c.kappa[i] = div * c.alpha[i];
-        err = div / rho0;
-    }
-    reduce_error(c, blk, err, mi, active, red);
+        E.add(c, err, mi, active);
+    });
+    E.finish(c, t.tile);
 }
-void launch_divergence(const StepCtx& c, hipStream_t s) {
-    if (c.n) k_divergence<<<num_blocks(c.n), BLOCK, 0, s>>>(c);
+void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_divergence, c, L.bytes(32, 16, 3), s, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -104,39 +121,49 @@ void launch_divergence(const StepCtx& c, hipStream_t s) {
 //                                                           + sum_b grad W_ib (-k_i V_b rho0), boundary reaction force.
 // Also refreshes w_i = v_i + dv_i for the next evaluate pass.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_divergence_apply(StepCtx c, float inv_dt_prev) {
-    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-    const uint32_t i = blk * BLOCK + threadIdx.x;
-    if (i >= c.n) return;
-    const float4 pi = c.posm[i];
-    const uint32_t mi = c.model[i];
-    const float rho0 = c.rho0_tab[mi];
-    const float ki = c.kappa[i];
-    float4 d = c.dv[i];
-    for_each_ff(c, i, [&](uint32_t j) {
-        const float4 pj = c.posm[j];
-        const float kj = c.kappa[j];
-        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-        const float coeff = -(ki + kj) * pj.w * g;
-        d.x += dx * coeff; d.y += dy * coeff; d.z += dz * coeff;
+__global__ __launch_bounds__(TILE_THREADS) void k_divergence_apply(StepCtx c, float inv_dt_prev) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* __restrict__ Lp = t.stage(c.posm);
+    const float* __restrict__ Lk = t.stage(c.kappa);
+    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active) return;
+        const float4 pi = c.posm[i];
+        const uint32_t mi = c.model[i];
+        const float rho0 = c.rho0_tab[mi];
+        const float ki = c.kappa[i];
+        float4 d = c.dv[i];
+        for_each_ff(c, i, gs, [&](uint32_t s) {
+            const float4 pj = Lp[s];
+            const float kj = Lk[s];
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+            const float coeff = -(ki + kj) * pj.w * g;
+            d.x += dx * coeff; d.y += dy * coeff; d.z += dz * coeff;
+        });
+        for_each_fb(c, t, i, gs, [&](uint32_t s) {
+            const float4 pj = Bp[s];
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+            const float coeff = -ki * pj.w * rho0 * g;
+            const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
+            d.x += ex; d.y += ey; d.z += ez;
+            if (c.bforce) {
+                const float fs = -inv_dt_prev * pi.w;  // delta * (-inv_dt * particle_mass) :404-406
+                apply_boundary_force(c, boundary_global_of_slot(t, s), __float_as_uint(Bv[s].w), ex * fs, ey * fs, ez * fs);
+            }
+        });
+        c.dv[i] = d;
+        const float4 v = c.vel[i];
+        c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
     });
-    for_each_fb(c, i, [&](uint32_t j) {
-        const float4 pj = c.bposv[j];
-        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-        const float coeff = -ki * pj.w * rho0 * g;
-        const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
-        d.x += ex; d.y += ey; d.z += ez;
-        const float fs = -inv_dt_prev * pi.w;  // delta * (-inv_dt * particle_mass) :404-406
-        apply_boundary_force(c, j, __float_as_uint(c.bvel[j].w), ex * fs, ey * fs, ez * fs);
-    });
-    c.dv[i] = d;
-    const float4 v = c.vel[i];
-    c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
 }
-void launch_divergence_apply(const StepCtx& c, float inv_dt_prev, hipStream_t s) {
-    if (c.n) k_divergence_apply<<<num_blocks(c.n), BLOCK, 0, s>>>(c, inv_dt_prev);
+void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_divergence_apply, c, L.bytes(20, 32, 4), s, c, inv_dt_prev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -183,128 +210,132 @@ void launch_integrate(const StepCtx& c, float dt, hipStream_t s) {
 // error_i = max(rho*_i / rho0 - 1, 0); stores kappa_i = (rho*_i - rho0) alpha_i (:234,:245).
 // This is THE representative neighbour-sum kernel of the roofline: N (4K + 52) bytes per launch.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_pred_density(StepCtx c, float dt) {
-    __shared__ float red[BLOCK / WAVE];
-    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-    const uint32_t i = blk * BLOCK + threadIdx.x;
-    const bool active = i < c.n;
-    float err = 0.0f;
-    uint32_t mi = 0;
-    if (active) {
-        mi = c.model[i];
-        const float rho0 = c.rho0_tab[mi];
-        const float4 pi = c.posm[i];
-        const float4 wi = c.w[i];
-        float delta = 0.0f;
-        for_each_ff(c, i, [&](uint32_t j) {
-            const float4 pj = c.posm[j];
-            const float4 wj = c.w[j];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-            delta += pj.w * (((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g);
-        });
-        for_each_fb(c, i, [&](uint32_t j) {
-            const float4 pj = c.bposv[j];
-            const float4 vj = c.bvel[j];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-            delta += pj.w * rho0 * (((wi.x - vj.x) * dx + (wi.y - vj.y) * dy + (wi.z - vj.z) * dz) * g);
-        });
-        const float rs = c.rho[i] + delta * dt;
-        if (!(rs != 0.0f)) atomicOr(c.flags, 1u);  // assert!(!predicted_density.is_zero()) :145 (also catches NaN)
-        err = (rs < rho0) ? 0.0f : rs / rho0 - 1.0f;
-        c.kappa[i] = (rs - rho0) * c.alpha[i];
-    }
-    reduce_error(c, blk, err, mi, active, red);
+__global__ __launch_bounds__(TILE_THREADS) void k_pred_density(StepCtx c, float dt) {
+    __shared__ float errtab[TILE_WAVES][MAX_MODELS];
+    Tile t;
+    t.setup(c);
+    if (t.empty()) { TileErr::zero(c, t.tile); return; }
+    const float4* __restrict__ Lp = t.stage(c.posm);
+    const float4* __restrict__ Lw = t.stage(c.w);
+    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    TileErr E;
+    E.init(errtab, c);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        float err = 0.0f;
+        uint32_t mi = 0;
+        if (active) {
+            mi = c.model[i];
+            const float rho0 = c.rho0_tab[mi];
+            const float4 pi = c.posm[i];
+            const float4 wi = c.w[i];
+            float delta = 0.0f;
+            for_each_ff(c, i, gs, [&](uint32_t s) {
+                const float4 pj = Lp[s];
+                const float4 wj = Lw[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                delta += pj.w * (((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g);
+            });
+            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+                const float4 pj = Bp[s];
+                const float4 vj = Bv[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                delta += pj.w * rho0 * (((wi.x - vj.x) * dx + (wi.y - vj.y) * dy + (wi.z - vj.z) * dz) * g);
+            });
+            const float rs = c.rho[i] + delta * dt;
+            if (!(rs != 0.0f)) atomicOr(c.flags, 1u);  // assert!(!predicted_density.is_zero()) :145 (also catches NaN)
+            err = (rs < rho0) ? 0.0f : rs / rho0 - 1.0f;
+            c.kappa[i] = (rs - rho0) * c.alpha[i];
+        }
+        E.add(c, err, mi, active);
+    });
+    E.finish(c, t.tile);
 }
-void launch_pred_density(const StepCtx& c, float dt, hipStream_t s) {
-    if (c.n) k_pred_density<<<num_blocks(c.n), BLOCK, 0, s>>>(c, dt);
+void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_pred_density, c, L.bytes(32, 32, 4), s, c, dt);
 }
 
 // ------------------------------------------------------------------------------------------------
 // compute_velocity_changes (:218-277): k_ij = max(k_i,0) + max(k_j,0); if k_ij > 0: dv_i -= grad W_ij k_ij m_j / dt.
 // Boundary term only when k_i > 0, with the reaction force delta * (inv_dt * m_i).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_pressure_apply(StepCtx c, float inv_dt) {
-    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-    const uint32_t i = blk * BLOCK + threadIdx.x;
-    if (i >= c.n) return;
-    const float4 pi = c.posm[i];
-    const uint32_t mi = c.model[i];
-    const float rho0 = c.rho0_tab[mi];
-    const float ki = c.kappa[i];
-    const float kip = fmaxf(ki, 0.0f);
-    float4 d = c.dv[i];
-    for_each_ff(c, i, [&](uint32_t j) {
-        // both gathers issue back to back; k_ij == 0 contributes exactly nothing, so no branch is needed
-        const float4 pj = c.posm[j];
-        const float kij = kip + fmaxf(c.kappa[j], 0.0f);
-        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-        const float coeff = kij * pj.w * inv_dt * g;
-        d.x -= dx * coeff; d.y -= dy * coeff; d.z -= dz * coeff;
-    });
-    if (ki > 0.0f) {
-        for_each_fb(c, i, [&](uint32_t j) {
-            const float4 pj = c.bposv[j];
+__global__ __launch_bounds__(TILE_THREADS) void k_pressure_apply(StepCtx c, float inv_dt) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* __restrict__ Lp = t.stage(c.posm);
+    const float* __restrict__ Lk = t.stage(c.kappa);
+    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active) return;
+        const float4 pi = c.posm[i];
+        const uint32_t mi = c.model[i];
+        const float rho0 = c.rho0_tab[mi];
+        const float ki = c.kappa[i];
+        const float kip = fmaxf(ki, 0.0f);
+        float4 d = c.dv[i];
+        for_each_ff(c, i, gs, [&](uint32_t s) {
+            // k_ij == 0 contributes exactly nothing, so no branch is needed
+            const float4 pj = Lp[s];
+            const float kij = kip + fmaxf(Lk[s], 0.0f);
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-            const float coeff = ki * pj.w * rho0 * inv_dt * g;
-            const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
-            d.x -= ex; d.y -= ey; d.z -= ez;
-            const float fs = inv_dt * pi.w;
-            apply_boundary_force(c, j, __float_as_uint(c.bvel[j].w), ex * fs, ey * fs, ez * fs);
+            const float coeff = kij * pj.w * inv_dt * g;
+            d.x -= dx * coeff; d.y -= dy * coeff; d.z -= dz * coeff;
         });
-    }
-    c.dv[i] = d;
-    const float4 v = c.vel[i];
-    c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
+        if (ki > 0.0f) {
+            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+                const float4 pj = Bp[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                const float coeff = ki * pj.w * rho0 * inv_dt * g;
+                const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
+                d.x -= ex; d.y -= ey; d.z -= ez;
+                if (c.bforce) {
+                    const float fs = inv_dt * pi.w;
+                    apply_boundary_force(c, boundary_global_of_slot(t, s), __float_as_uint(Bv[s].w), ex * fs, ey * fs, ez * fs);
+                }
+            });
+        }
+        c.dv[i] = d;
+        const float4 v = c.vel[i];
+        c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
+    });
 }
-void launch_pressure_apply(const StepCtx& c, float inv_dt, hipStream_t s) {
-    if (c.n) k_pressure_apply<<<num_blocks(c.n), BLOCK, 0, s>>>(c, inv_dt);
+void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_pressure_apply, c, L.bytes(20, 32, 4), s, c, inv_dt);
 }
 
 // ------------------------------------------------------------------------------------------------
 // update_positions (:411-420): x += (v + dv) dt = w dt.  (v is NOT updated here — the velocity lag of the
 // reference.)  Also reduces the cell bounding box of the new positions for the next step's grid.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int cell_of(float x, float h) {
-    float f = floorf(__fdiv_rn(x, h));
-    if (!(f == f)) f = 0.0f;
-    f = fminf(fmaxf(f, -1073741824.0f), 1073741824.0f);
-    return (int)f;
-}
-__device__ __forceinline__ void bbox_accumulate(bool active, float x, float y, float z, float h, int32_t* bbox6) {
-    int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
-    if (active) {
-        mn[0] = mx[0] = cell_of(x, h); mn[1] = mx[1] = cell_of(y, h); mn[2] = mx[2] = cell_of(z, h);
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { mn[a] = wave_min_i32(mn[a]); mx[a] = wave_max_i32(mx[a]); }
-    if ((threadIdx.x & (WAVE - 1)) == 0) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            // plain (possibly stale) read first: the bound is monotone, so almost every wave skips the atomic
-            if (mn[a] < bbox6[a]) atomicMin(&bbox6[a], mn[a]);
-            if (mx[a] > bbox6[3 + a]) atomicMax(&bbox6[3 + a], mx[a]);
-        }
-    }
-}
-__global__ __launch_bounds__(BLOCK) void k_update_positions(StepCtx c, float dt, int32_t* bbox6) {
+__global__ __launch_bounds__(BLOCK) void k_update_positions(StepCtx c, float dt, int32_t* bbox_partials) {
+    __shared__ int red[6 * (BLOCK / WAVE)];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = i < c.n;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (active) {
-        p = c.posm[i];
+    int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+    if (i < c.n) {
+        float4 p = c.posm[i];
         const float4 wi = c.w[i];
         p.x += wi.x * dt; p.y += wi.y * dt; p.z += wi.z * dt;
         c.posm[i] = p;
-        if (!(p.x == p.x) || !(p.y == p.y) || !(p.z == p.z)) atomicOr(c.flags, 1u);
+        bool bad = false;
+        mn[0] = mx[0] = cell_coord(p.x, c.sc.h, bad);
+        mn[1] = mx[1] = cell_coord(p.y, c.sc.h, bad);
+        mn[2] = mx[2] = cell_coord(p.z, c.sc.h, bad);
+        if (bad) atomicOr(c.flags, 1u);
     }
-    bbox_accumulate(active, p.x, p.y, p.z, c.sc.h, bbox6);
+    block_bbox_store(mn, mx, red, bbox_partials + 6 * blockIdx.x);
 }
-void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox6, hipStream_t s) {
-    if (c.n) k_update_positions<<<num_blocks(c.n), BLOCK, 0, s>>>(c, dt, bbox6);
+void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox_partials, int32_t* bbox6, hipStream_t s) {
+    if (!c.n) return;
+    k_update_positions<<<num_blocks(c.n), BLOCK, 0, s>>>(c, dt, bbox_partials);
+    launch_bbox_final(bbox_partials, num_blocks(c.n), bbox6, s);
 }
 
 // ------------------------------------------------------------------------------------------------

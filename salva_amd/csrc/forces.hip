@@ -1,4 +1,4 @@
-// forces.hip — the built-in NonPressureForce implementations as neighbour-sum kernels.
+// forces.hip — the built-in NonPressureForce implementations as tile kernels (tile.h).
 //
 // Behaviour specified by /root/reference/src/solver/viscosity/xsph_viscosity.rs:31-95,
 // src/solver/viscosity/artificial_viscosity.rs:41-124 and
@@ -9,140 +9,164 @@
 // (DFSPH, dfsph_solver.rs:688-693) or v itself (IISPH, dv = 0), so neighbour velocities are read from w,
 // whose .w component carries the neighbour's model id.
 #include "kernels.h"
-#include "nbr_loops.h"
+#include "tile.h"
 
 namespace salva {
 
 // ------------------------------------------------------------------------------------------------ XSPH
 // a_i += inv_dt * [ sum_j (v_j - v_i) c_f W_ij m_j / rho_j  +  sum_b (v_b - v_i) c_b W_ib V_b rho0 / rho_i ]
 // inv_dt is the *previous* substep's (timestep.advance happens after predict_advection, dfsph_solver.rs:693-702).
-__global__ __launch_bounds__(BLOCK) void k_xsph(StepCtx c, uint32_t model, float fc, float bc, float inv_dt) {
-    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-    const uint32_t i = blk * BLOCK + threadIdx.x;
-    if (i >= c.n) return;
-    if (c.model[i] != model) return;
-    const float4 pi = c.posm[i];
-    const float4 vi = c.w[i];
-    const float rho0 = c.rho0_tab[model];
-    float fx = 0.f, fy = 0.f, fz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
-    if (fc != 0.0f) {
-        for_each_ff(c, i, [&](uint32_t j) {
-            const float4 pj = c.posm[j];
-            const float4 vj = c.w[j];
-            const float rj = c.rho[j];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
-            const float s = (__float_as_uint(vj.w) == model) ? fc * wgt * pj.w / rj : 0.0f;
-            fx += (vj.x - vi.x) * s; fy += (vj.y - vi.y) * s; fz += (vj.z - vi.z) * s;
-        });
-    }
-    if (bc != 0.0f) {
-        const float ri = c.rho[i];
-        for_each_fb(c, i, [&](uint32_t j) {
-            const float4 pj = c.bposv[j];
-            const float4 vj = c.bvel[j];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
-            const float s = bc * wgt * pj.w * rho0 / ri;
-            const float ex = (vj.x - vi.x) * s, ey = (vj.y - vi.y) * s, ez = (vj.z - vi.z) * s;
-            bx += ex; by += ey; bz += ez;
-            const float fs = -pi.w * inv_dt;  // delta * (-mi * inv_dt) :88-89
-            apply_boundary_force(c, j, __float_as_uint(vj.w), ex * fs, ey * fs, ez * fs);
-        });
-    }
-    float4 a = c.acc[i];
-    a.x += fx * inv_dt + bx * inv_dt;
-    a.y += fy * inv_dt + by * inv_dt;
-    a.z += fz * inv_dt + bz * inv_dt;
-    c.acc[i] = a;
+__global__ __launch_bounds__(TILE_THREADS) void k_xsph(StepCtx c, uint32_t model, float fc, float bc, float inv_dt) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* __restrict__ Lp = t.stage(c.posm);
+    const float4* __restrict__ Lw = t.stage(c.w);
+    const float* __restrict__ Lr = t.stage(c.rho);
+    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active || c.model[i] != model) return;
+        const float4 pi = c.posm[i];
+        const float4 vi = c.w[i];
+        const float rho0 = c.rho0_tab[model];
+        float fx = 0.f, fy = 0.f, fz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
+        if (fc != 0.0f) {
+            for_each_ff(c, i, gs, [&](uint32_t s) {
+                const float4 pj = Lp[s];
+                const float4 vj = Lw[s];
+                const float rj = Lr[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
+                const float sc = (__float_as_uint(vj.w) == model) ? fc * wgt * pj.w / rj : 0.0f;
+                fx += (vj.x - vi.x) * sc; fy += (vj.y - vi.y) * sc; fz += (vj.z - vi.z) * sc;
+            });
+        }
+        if (bc != 0.0f) {
+            const float ri = c.rho[i];
+            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+                const float4 pj = Bp[s];
+                const float4 vj = Bv[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
+                const float sc = bc * wgt * pj.w * rho0 / ri;
+                const float ex = (vj.x - vi.x) * sc, ey = (vj.y - vi.y) * sc, ez = (vj.z - vi.z) * sc;
+                bx += ex; by += ey; bz += ez;
+                if (c.bforce) {
+                    const float fs = -pi.w * inv_dt;  // delta * (-mi * inv_dt) :88-89
+                    apply_boundary_force(c, boundary_global_of_slot(t, s), __float_as_uint(vj.w), ex * fs, ey * fs, ez * fs);
+                }
+            });
+        }
+        float4 a = c.acc[i];
+        a.x += fx * inv_dt + bx * inv_dt;
+        a.y += fy * inv_dt + by * inv_dt;
+        a.z += fz * inv_dt + bz * inv_dt;
+        c.acc[i] = a;
+    });
 }
-void launch_xsph(const StepCtx& c, uint32_t model, float fluid_coeff, float boundary_coeff, float inv_dt_prev,
-                 hipStream_t s) {
-    if (c.n) k_xsph<<<num_blocks(c.n), BLOCK, 0, s>>>(c, model, fluid_coeff, boundary_coeff, inv_dt_prev);
+void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff,
+                 float inv_dt_prev, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_xsph, c, L.bytes(36, 32, 5), s, c, model, fluid_coeff, boundary_coeff, inv_dt_prev);
 }
 
 // ------------------------------------------------------------------------------------------------ Monaghan artificial viscosity
 // approaching pairs only (r.v < 0): mu = h r.v / (r^2 + 0.01 h^2);
 // a_i += grad W_ij c_f (c_s alpha mu - beta mu^2) m_j / ((rho_i + rho_j)/2)
-__global__ __launch_bounds__(BLOCK) void k_artificial_viscosity(StepCtx c, uint32_t model, float fc, float bc,
-                                                               float alpha, float beta, float cs) {
-    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-    const uint32_t i = blk * BLOCK + threadIdx.x;
-    if (i >= c.n) return;
-    if (c.model[i] != model) return;
-    const float4 pi = c.posm[i];
-    const float4 vi = c.w[i];
-    const float ri = c.rho[i];
-    const float rho0 = c.rho0_tab[model];
-    const float h = c.sc.h;
-    const float eta2 = h * h * 0.01f;
-    float fx = 0.f, fy = 0.f, fz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
-    if (fc != 0.0f) {
-        for_each_ff(c, i, [&](uint32_t j) {
-            const float4 pj = c.posm[j];
-            const float4 vj = c.w[j];
-            const float rj = c.rho[j];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float r2 = dx * dx + dy * dy + dz * dz;
-            const float vr = dx * (vi.x - vj.x) + dy * (vi.y - vj.y) + dz * (vi.z - vj.z);
-            if (__float_as_uint(vj.w) == model && vr < 0.0f) {
-                const float g = kernel_grad(r2, c.sc);
-                const float mu = h * vr / (r2 + eta2);
-                const float s = g * (fc * (cs * alpha * mu - beta * mu * mu) * (pj.w / ((ri + rj) * 0.5f)));
-                fx += dx * s; fy += dy * s; fz += dz * s;
-            }
-        });
-    }
-    if (bc != 0.0f) {
-        for_each_fb(c, i, [&](uint32_t j) {
-            const float4 pj = c.bposv[j];
-            const float4 vj = c.bvel[j];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float r2 = dx * dx + dy * dy + dz * dz;
-            const float vr = dx * (vi.x - vj.x) + dy * (vi.y - vj.y) + dz * (vi.z - vj.z);
-            if (vr < 0.0f) {
-                const float g = kernel_grad(r2, c.sc);
-                const float mu = h * vr / (r2 + eta2);
-                const float s = g * (bc * (cs * alpha * mu - beta * mu * mu) * (pj.w * rho0 / ri));
-                bx += dx * s; by += dy * s; bz += dz * s;
-                // the reference applies the *running sum* of the boundary acceleration here (:117)
-                apply_boundary_force(c, j, __float_as_uint(vj.w), bx * -pi.w, by * -pi.w, bz * -pi.w);
-            }
-        });
-    }
-    float4 a = c.acc[i];
-    a.x += fx + bx; a.y += fy + by; a.z += fz + bz;
-    c.acc[i] = a;
+__global__ __launch_bounds__(TILE_THREADS) void k_artificial_viscosity(StepCtx c, uint32_t model, float fc, float bc,
+                                                                      float alpha, float beta, float cs) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* __restrict__ Lp = t.stage(c.posm);
+    const float4* __restrict__ Lw = t.stage(c.w);
+    const float* __restrict__ Lr = t.stage(c.rho);
+    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active || c.model[i] != model) return;
+        const float4 pi = c.posm[i];
+        const float4 vi = c.w[i];
+        const float ri = c.rho[i];
+        const float rho0 = c.rho0_tab[model];
+        const float h = c.sc.h;
+        const float eta2 = h * h * 0.01f;
+        float fx = 0.f, fy = 0.f, fz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
+        if (fc != 0.0f) {
+            for_each_ff(c, i, gs, [&](uint32_t s) {
+                const float4 pj = Lp[s];
+                const float4 vj = Lw[s];
+                const float rj = Lr[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                const float vr = dx * (vi.x - vj.x) + dy * (vi.y - vj.y) + dz * (vi.z - vj.z);
+                if (__float_as_uint(vj.w) == model && vr < 0.0f) {
+                    const float g = kernel_grad(r2, c.sc);
+                    const float mu = h * vr / (r2 + eta2);
+                    const float sc = g * (fc * (cs * alpha * mu - beta * mu * mu) * (pj.w / ((ri + rj) * 0.5f)));
+                    fx += dx * sc; fy += dy * sc; fz += dz * sc;
+                }
+            });
+        }
+        if (bc != 0.0f) {
+            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+                const float4 pj = Bp[s];
+                const float4 vj = Bv[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                const float vr = dx * (vi.x - vj.x) + dy * (vi.y - vj.y) + dz * (vi.z - vj.z);
+                if (vr < 0.0f) {
+                    const float g = kernel_grad(r2, c.sc);
+                    const float mu = h * vr / (r2 + eta2);
+                    const float sc = g * (bc * (cs * alpha * mu - beta * mu * mu) * (pj.w * rho0 / ri));
+                    bx += dx * sc; by += dy * sc; bz += dz * sc;
+                    // the reference applies the *running sum* of the boundary acceleration here (:117)
+                    if (c.bforce)
+                        apply_boundary_force(c, boundary_global_of_slot(t, s), __float_as_uint(vj.w), bx * -pi.w, by * -pi.w, bz * -pi.w);
+                }
+            });
+        }
+        float4 a = c.acc[i];
+        a.x += fx + bx; a.y += fy + by; a.z += fz + bz;
+        c.acc[i] = a;
+    });
 }
-void launch_artificial_viscosity(const StepCtx& c, uint32_t model, float fluid_coeff, float boundary_coeff, float alpha,
-                                 float beta, float speed_of_sound, hipStream_t s) {
-    if (c.n)
-        k_artificial_viscosity<<<num_blocks(c.n), BLOCK, 0, s>>>(c, model, fluid_coeff, boundary_coeff, alpha, beta,
-                                                                speed_of_sound);
+void launch_artificial_viscosity(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff,
+                                 float boundary_coeff, float alpha, float beta, float speed_of_sound, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_artificial_viscosity, c, L.bytes(36, 32, 5), s, c, model, fluid_coeff, boundary_coeff, alpha, beta,
+                      speed_of_sound);
 }
 
 // ------------------------------------------------------------------------------------------------ Akinci 2013
 // pass 1 (compute_normals :43-68): n_i = h sum_{j same fluid} (m_j / rho_j) grad W_ij
-__global__ __launch_bounds__(BLOCK) void k_akinci_normals(StepCtx c, uint32_t model) {
-    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-    const uint32_t i = blk * BLOCK + threadIdx.x;
-    if (i >= c.n) return;
-    if (c.model[i] != model) return;
-    const float4 pi = c.posm[i];
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    for_each_ff(c, i, [&](uint32_t j) {
-        const float4 pj = c.posm[j];
-        const float rj = c.rho[j];
-        const uint32_t mj = __float_as_uint(c.w[j].w);
-        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-        const float s = (mj == model) ? g * (pj.w / rj) : 0.0f;
-        nx += dx * s; ny += dy * s; nz += dz * s;
+__global__ __launch_bounds__(TILE_THREADS) void k_akinci_normals(StepCtx c, uint32_t model) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* __restrict__ Lp = t.stage(c.posm);
+    const float* __restrict__ Lr = t.stage(c.rho);
+    const uint32_t* __restrict__ Lm = (c.nmodels > 1) ? t.stage(c.model) : nullptr;
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active || c.model[i] != model) return;
+        const float4 pi = c.posm[i];
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        for_each_ff(c, i, gs, [&](uint32_t s) {
+            const float4 pj = Lp[s];
+            const float rj = Lr[s];
+            const bool same = Lm ? (Lm[s] == model) : true;
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+            const float sc = same ? g * (pj.w / rj) : 0.0f;
+            nx += dx * sc; ny += dy * sc; nz += dz * sc;
+        });
+        c.normal[i] = make_float4(nx * c.sc.h, ny * c.sc.h, nz * c.sc.h, 0.0f);
     });
-    c.normal[i] = make_float4(nx * c.sc.h, ny * c.sc.h, nz * c.sc.h, 0.0f);
 }
-void launch_akinci_normals(const StepCtx& c, uint32_t model, hipStream_t s) {
-    if (c.n) k_akinci_normals<<<num_blocks(c.n), BLOCK, 0, s>>>(c, model);
+void launch_akinci_normals(const StepCtx& c, const TileLds& L, uint32_t model, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_akinci_normals, c, L.bytes(24, 0, 3), s, c, model);
 }
 
 // cohesion_kernel :71-88 — C(r) = 32/(pi h^9) * { 2 (h-r)^3 r^3 - h^6/64 | r <= h/2 ; (h-r)^3 r^3 | r <= h ; 0 }
@@ -155,71 +179,80 @@ __device__ __forceinline__ float cohesion_kernel(float r, float h, float norm, f
 // adhesion_kernel :90-111 — A(r) = 0.007 / h^3.25 * (-4 r^2/h + 6 r - 2 h)^(1/4) for h/2 < r <= h
 __device__ __forceinline__ float adhesion_kernel(float r, float h, float norm) {
     if (r > h * 0.5f && r <= h) {
-        const float t = fmaxf(-4.0f * r * r / h + 6.0f * r - 2.0f * h, 0.0f);
-        return norm * sqrtf(sqrtf(t));
+        const float tt = fmaxf(-4.0f * r * r / h + 6.0f * r - 2.0f * h, 0.0f);
+        return norm * sqrtf(sqrtf(tt));
     }
     return 0.0f;
 }
 
 // pass 2 (solve :114-192): cohesion + curvature between same-fluid particles, adhesion with boundaries.
-__global__ __launch_bounds__(BLOCK) void k_akinci_forces(StepCtx c, uint32_t model, float tc, float ac, float cnorm,
-                                                        float h6_64, float anorm) {
-    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-    const uint32_t i = blk * BLOCK + threadIdx.x;
-    if (i >= c.n) return;
-    if (c.model[i] != model) return;
-    const float4 pi = c.posm[i];
-    const float ri = c.rho[i];
-    const float rho0 = c.rho0_tab[model];
-    const float h = c.sc.h;
-    float4 a = c.acc[i];
-    if (tc != 0.0f) {
-        const float4 ni = c.normal[i];
-        for_each_ff(c, i, [&](uint32_t j) {
-            const float4 pj = c.posm[j];
-            const float4 nj = c.normal[j];
-            const float rj = c.rho[j];
-            const uint32_t mj = __float_as_uint(c.w[j].w);
-            if (mj == model) {
+__global__ __launch_bounds__(TILE_THREADS) void k_akinci_forces(StepCtx c, uint32_t model, float tc, float ac, float cnorm,
+                                                               float h6_64, float anorm) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* __restrict__ Lp = t.stage(c.posm);
+    const float4* __restrict__ Ln = t.stage(c.normal);
+    const float* __restrict__ Lr = t.stage(c.rho);
+    const uint32_t* __restrict__ Lm = (c.nmodels > 1) ? t.stage(c.model) : nullptr;
+    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active || c.model[i] != model) return;
+        const float4 pi = c.posm[i];
+        const float ri = c.rho[i];
+        const float rho0 = c.rho0_tab[model];
+        const float h = c.sc.h;
+        float4 a = c.acc[i];
+        if (tc != 0.0f) {
+            const float4 ni = c.normal[i];
+            for_each_ff(c, i, gs, [&](uint32_t s) {
+                const float4 pj = Lp[s];
+                const float4 nj = Ln[s];
+                const float rj = Lr[s];
+                const bool same = Lm ? (Lm[s] == model) : true;
+                if (same) {
+                    const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    float cs = 0.0f;  // cohesion_vec = dir * C(dist) ; cohesion_acc = cohesion_vec * (-tc * m_j)
+                    if (r2 > c.sc.eps2) {
+                        const float rinv = __builtin_amdgcn_rsqf(r2);
+                        cs = cohesion_kernel(r2 * rinv, h, cnorm, h6_64) * rinv * (-tc * pj.w);
+                    }
+                    const float kij = 2.0f * rho0 / (ri + rj);
+                    a.x += ((ni.x - nj.x) * -tc + dx * cs) * kij;
+                    a.y += ((ni.y - nj.y) * -tc + dy * cs) * kij;
+                    a.z += ((ni.z - nj.z) * -tc + dz * cs) * kij;
+                }
+            });
+        }
+        if (ac != 0.0f) {
+            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+                const float4 pj = Bp[s];
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float r2 = dx * dx + dy * dy + dz * dz;
-                float cs = 0.0f;  // cohesion_vec = dir * C(dist) ; cohesion_acc = cohesion_vec * (-tc * m_j)
+                float sc = 0.0f;
                 if (r2 > c.sc.eps2) {
                     const float rinv = __builtin_amdgcn_rsqf(r2);
-                    cs = cohesion_kernel(r2 * rinv, h, cnorm, h6_64) * rinv * (-tc * pj.w);
+                    sc = adhesion_kernel(r2 * rinv, h, anorm) * rinv * (ac * pj.w * rho0);
                 }
-                const float kij = 2.0f * rho0 / (ri + rj);
-                a.x += ((ni.x - nj.x) * -tc + dx * cs) * kij;
-                a.y += ((ni.y - nj.y) * -tc + dy * cs) * kij;
-                a.z += ((ni.z - nj.z) * -tc + dz * cs) * kij;
-            }
-        });
-    }
-    if (ac != 0.0f) {
-        for_each_fb(c, i, [&](uint32_t j) {
-            const float4 pj = c.bposv[j];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float r2 = dx * dx + dy * dy + dz * dz;
-            float s = 0.0f;
-            if (r2 > c.sc.eps2) {
-                const float rinv = __builtin_amdgcn_rsqf(r2);
-                s = adhesion_kernel(r2 * rinv, h, anorm) * rinv * (ac * pj.w * rho0);
-            }
-            const float ex = dx * s, ey = dy * s, ez = dz * s;
-            a.x -= ex; a.y -= ey; a.z -= ez;
-            apply_boundary_force(c, j, __float_as_uint(c.bvel[j].w), ex * pi.w, ey * pi.w, ez * pi.w);
-        });
-    }
-    c.acc[i] = a;
+                const float ex = dx * sc, ey = dy * sc, ez = dz * sc;
+                a.x -= ex; a.y -= ey; a.z -= ez;
+                if (c.bforce)
+                    apply_boundary_force(c, boundary_global_of_slot(t, s), __float_as_uint(Bv[s].w), ex * pi.w, ey * pi.w, ez * pi.w);
+            });
+        }
+        c.acc[i] = a;
+    });
 }
-void launch_akinci_forces(const StepCtx& c, uint32_t model, float tension, float adhesion, hipStream_t s) {
-    if (!c.n) return;
+void launch_akinci_forces(const StepCtx& c, const TileLds& L, uint32_t model, float tension, float adhesion, hipStream_t s) {
     const double h = c.sc.h;
-    // normalisers evaluated in f64 on the host then rounded once (h^9 underflows f32 precision for small h)
+    // normalisers evaluated in f64 on the host then rounded once
     const float cnorm = (float)(32.0 / (3.14159265358979323846 * pow(h, 9)));
     const float h6_64 = (float)(pow(h, 6) / 64.0);
     const float anorm = (float)(0.007 / pow(h, 3.25));
-    k_akinci_forces<<<num_blocks(c.n), BLOCK, 0, s>>>(c, model, tension, adhesion, cnorm, h6_64, anorm);
+    SALVA_LAUNCH_TILE(k_akinci_forces, c, L.bytes(40, 32, 6), s, c, model, tension, adhesion, cnorm, h6_64, anorm);
 }
 
 }  // namespace salva

@@ -3,33 +3,24 @@
 // Replaces (behaviour, not code) /root/reference/src/geometry/hgrid.rs:41-63 (cell = floor(x / h)),
 // src/geometry/contacts.rs:133-151 (grid insertion), :154-400 (14-cell half stencil, all-pairs test
 // d^2 <= h^2, interaction-group filter, directed contacts incl. the self contact) and the dead
-// src/z_order.rs / Fluid::z_sort (fluid.rs:153-163): particles are radix-sorted by dense cell key every step,
-// which is both the "hash grid" and the cache-locality sort.  The hash map + per-particle RwLock<Vec<Contact>>
-// of the reference becomes: sorted SoA arrays + a dense lower-bound cell table + a sliced-ELL index list.
+// src/z_order.rs / Fluid::z_sort (fluid.rs:153-163): particles are radix-sorted by tile-major cell key every step,
+// which is both the "hash grid" and the locality sort.  The hash map + per-particle RwLock<Vec<Contact>> of the
+// reference becomes: sorted SoA arrays + a dense lower-bound cell table + per-tile sliced-ELL lists of 16-bit LDS
+// slots (tile.h).
 #include <hipcub/hipcub.hpp>
 
 #include <climits>
 
+#include "bbox.h"
 #include "kernels.h"
+#include "tile.h"
 
 namespace salva {
 
-// floor(x / h) exactly as hgrid.rs:41-43 (IEEE f32 division, then floor), clamped to +-2^30.
-__device__ __forceinline__ int cell_coord(float x, float h, bool& bad) {
-    float f = floorf(__fdiv_rn(x, h));
-    if (!(f == f)) { bad = true; f = 0.0f; }
-    f = fminf(fmaxf(f, -1073741824.0f), 1073741824.0f);
-    return (int)f;
-}
-
 // ------------------------------------------------------------------------------------------------ bbox
-__global__ void k_bbox_init(int32_t* bbox6) {
-    if (threadIdx.x < 3) bbox6[threadIdx.x] = INT_MAX;
-    else if (threadIdx.x < 6) bbox6[threadIdx.x] = INT_MIN;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_bbox(const float4* __restrict__ pts, uint32_t n, float h,
-                                                int32_t* bbox6, uint32_t* flags) {
+__global__ __launch_bounds__(BLOCK) void k_bbox(const float4* __restrict__ pts, uint32_t n, float h, int32_t* partials,
+                                                uint32_t* flags) {
+    __shared__ int red[6 * (BLOCK / WAVE)];
     int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
     bool bad = false;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
@@ -38,49 +29,47 @@ __global__ __launch_bounds__(BLOCK) void k_bbox(const float4* __restrict__ pts, 
 #pragma unroll
         for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], c[a]); mx[a] = max(mx[a], c[a]); }
     }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { mn[a] = wave_min_i32(mn[a]); mx[a] = wave_max_i32(mx[a]); }
-    if ((threadIdx.x & (WAVE - 1)) == 0) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            // plain (possibly stale) read first: the bound is monotone, so almost every wave skips the atomic
-            if (mn[a] < bbox6[a]) atomicMin(&bbox6[a], mn[a]);
-            if (mx[a] > bbox6[3 + a]) atomicMax(&bbox6[3 + a], mx[a]);
-        }
-    }
+    block_bbox_store(mn, mx, red, partials + 6 * blockIdx.x);
     if (bad) atomicOr(flags, 1u);
 }
-
-void launch_bbox_init(int32_t* bbox6, hipStream_t s) { k_bbox_init<<<1, 64, 0, s>>>(bbox6); }
-
-void launch_bbox(const float4* pts, uint32_t n, float h, int32_t* bbox6, uint32_t* flags, hipStream_t s) {
+__global__ __launch_bounds__(BLOCK) void k_bbox_final(const int32_t* __restrict__ partials, unsigned nblocks, int32_t* bbox6) {
+    __shared__ int red[6 * (BLOCK / WAVE)];
+    int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+    for (unsigned b = threadIdx.x; b < nblocks; b += BLOCK) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], partials[6 * b + a]); mx[a] = max(mx[a], partials[6 * b + 3 + a]); }
+    }
+    block_bbox_store(mn, mx, red, bbox6);
+}
+unsigned bbox_blocks(uint32_t n) {
+    unsigned nb = div_up(n ? n : 1, BLOCK);
+    return nb > 1024 ? 1024 : nb;
+}
+void launch_bbox(const float4* pts, uint32_t n, float h, int32_t* partials, int32_t* bbox6, uint32_t* flags, hipStream_t s) {
     if (n == 0) return;
-    unsigned nb = div_up(n, BLOCK);
-    if (nb > 2048) nb = 2048;
-    k_bbox<<<nb, BLOCK, 0, s>>>(pts, n, h, bbox6, flags);
+    const unsigned nb = bbox_blocks(n);
+    k_bbox<<<nb, BLOCK, 0, s>>>(pts, n, h, partials, flags);
+    k_bbox_final<<<1, BLOCK, 0, s>>>(partials, nb, bbox6);
+}
+void launch_bbox_final(const int32_t* partials, unsigned nblocks, int32_t* bbox6, hipStream_t s) {
+    k_bbox_final<<<1, BLOCK, 0, s>>>(partials, nblocks, bbox6);
 }
 
 // ------------------------------------------------------------------------------------------------ keys
-__global__ __launch_bounds__(BLOCK) void k_cell_keys(const float4* __restrict__ pts, uint32_t n, float h, GridView g,
+__global__ __launch_bounds__(BLOCK) void k_cell_keys(const float4* __restrict__ pts, uint32_t n, float h, TileGrid g,
                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ idx,
                                                      uint32_t* flags) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float4 p = pts[i];
-    bool bad = false;
-    int ix = cell_coord(p.x, h, bad) - g.ox;
-    int iy = cell_coord(p.y, h, bad) - g.oy;
-    int iz = cell_coord(p.z, h, bad) - g.oz;
-    if ((unsigned)ix >= (unsigned)g.nx || (unsigned)iy >= (unsigned)g.ny || (unsigned)iz >= (unsigned)g.nz) {
-        atomicOr(flags, 2u);  // outside the table: the host recomputes the bbox and retries
-        ix = min(max(ix, 0), g.nx - 1); iy = min(max(iy, 0), g.ny - 1); iz = min(max(iz, 0), g.nz - 1);
-    }
+    bool bad = false, inside;
+    uint32_t k = tile_key(g, cell_coord(p.x, h, bad), cell_coord(p.y, h, bad), cell_coord(p.z, h, bad), inside);
+    if (!inside) { atomicOr(flags, 2u); k = 0; }  // cannot happen while the bbox is maintained with the positions
     if (bad) atomicOr(flags, 1u);
-    keys[i] = (uint32_t)(((size_t)ix * g.ny + iy) * g.nz + iz);
+    keys[i] = k;
     idx[i] = i;
 }
-
-void launch_cell_keys(const float4* pts, uint32_t n, float h, GridView g, uint32_t* keys, uint32_t* idx,
+void launch_cell_keys(const float4* pts, uint32_t n, float h, TileGrid g, uint32_t* keys, uint32_t* idx,
                       uint32_t* flags, hipStream_t s) {
     if (n == 0) return;
     k_cell_keys<<<div_up(n, BLOCK), BLOCK, 0, s>>>(pts, n, h, g, keys, idx, flags);
@@ -99,11 +88,15 @@ void sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t
                                                        end_bit, s));
 }
 size_t scan_temp_bytes(uint32_t n) {
-    size_t bytes = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n);
-    return bytes;
+    size_t a = 0, b = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    return a > b ? a : b;
 }
 void scan_u64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t s) {
+    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int)n, s));
+}
+void scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint32_t n, hipStream_t s) {
     SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int)n, s));
 }
 
@@ -145,7 +138,6 @@ void launch_reorder_fluid(uint32_t n, const uint32_t* idx, FluidArrays in, Fluid
 __global__ __launch_bounds__(BLOCK) void k_reorder_boundary(uint32_t n, const uint32_t* __restrict__ idx,
                                                             const float4* __restrict__ bpos_in,
                                                             const float4* __restrict__ bvel_in,
-                                                            const uint32_t* __restrict__ bperm_in,
                                                             float4* __restrict__ bposv_out, float4* __restrict__ bvel_out,
                                                             uint32_t* __restrict__ bperm_out) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -153,14 +145,12 @@ __global__ __launch_bounds__(BLOCK) void k_reorder_boundary(uint32_t n, const ui
     const uint32_t j = idx[i];
     bposv_out[i] = bpos_in[j];
     bvel_out[i] = bvel_in[j];
-    bperm_out[i] = bperm_in ? bperm_in[j] : j;
+    bperm_out[i] = j;
 }
 void launch_reorder_boundary(uint32_t n, const uint32_t* idx, const float4* bpos_in, const float4* bvel_in,
-                             const uint32_t* bperm_in, float4* bposv_out, float4* bvel_out, uint32_t* bperm_out,
-                             hipStream_t s) {
+                             float4* bposv_out, float4* bvel_out, uint32_t* bperm_out, hipStream_t s) {
     if (n == 0) return;
-    k_reorder_boundary<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, idx, bpos_in, bvel_in, bperm_in, bposv_out, bvel_out,
-                                                          bperm_out);
+    k_reorder_boundary<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, idx, bpos_in, bvel_in, bposv_out, bvel_out, bperm_out);
 }
 
 // canonical staging (host order; st_pos.w = volume, st_dv.w = pressure) -> working set with identity permutation
@@ -234,88 +224,140 @@ void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4
     if (n) k_gather_f4<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, perm, in, out);
 }
 
+// ------------------------------------------------------------------------------------------------ tile statistics
+// One thread per tile: number of 64-particle slices of the tile, and the size of its halo (fluid / boundary
+// particles in the 6x6x4 cell box) whose maxima size the LDS staging area of every tile kernel of this step.
+__global__ __launch_bounds__(BLOCK) void k_tile_info(StepCtx c, uint32_t* __restrict__ tile_nsl, uint32_t* max_halo /*[2]*/) {
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t hf = 0, hb = 0;
+    if (t < c.ntiles) {
+        const TileGrid& g = c.gf;
+        const uint32_t own = g.cell_start[(size_t)t * TCELLS + TCELLS] - g.cell_start[(size_t)t * TCELLS];
+        tile_nsl[t] = (own + WAVE - 1) / WAVE;
+        if (own) {
+            const int ttz = t % g.ntz, tty = (t / g.ntz) % g.nty, ttx = t / (g.ntz * g.nty);
+            const int hcx = g.ox + ttx * TX - 1, hcy = g.oy + tty * TY - 1, hcz = g.oz + ttz * TZ - 1;
+            for (int h = 0; h < HCELLS; ++h) {
+                const int hz = h % HZ, hy = (h / HZ) % HY, hx = h / (HZ * HY);
+                bool in;
+                const uint32_t k = tile_key(g, hcx + hx, hcy + hy, hcz + hz, in);
+                if (in) hf += g.cell_start[k + 1] - g.cell_start[k];
+                if (c.nb) {
+                    const uint32_t kb = tile_key(c.gb, hcx + hx, hcy + hy, hcz + hz, in);
+                    if (in) hb += c.gb.cell_start[kb + 1] - c.gb.cell_start[kb];
+                }
+            }
+        }
+    }
+    hf = wave_max_u32(hf);
+    hb = wave_max_u32(hb);
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        if (hf) atomicMax(&max_halo[0], hf);
+        if (hb) atomicMax(&max_halo[1], hb);
+    }
+}
+void launch_tile_info(const StepCtx& c, uint32_t* tile_nsl, uint32_t* max_halo2, hipStream_t s) {
+    k_tile_info<<<div_up(c.ntiles, BLOCK), BLOCK, 0, s>>>(c, tile_nsl, max_halo2);
+}
+
 // ------------------------------------------------------------------------------------------------ neighbour lists
-// Visit every candidate in the 3x3x3 cells around (cx,cy,cz) of grid g: 9 rows, each one contiguous index run.
-template <typename F>
-__device__ __forceinline__ void for_each_candidate(const GridView& g, int cx, int cy, int cz, F&& f) {
-    const int iz = cz - g.oz;
-    const int z0 = max(iz - 1, 0), z1 = min(iz + 1, g.nz - 1);
-    if (z0 > z1) return;
+// One workgroup per tile.  FILL=false: count fluid-fluid (contacts.rs:347-392) and fluid-boundary (:329-346,
+// :378-383) contacts of the tile's own particles -> nff / nfb and the slice widths.  FILL=true: write the halo slots
+// of the accepted candidates, in traversal order (9 rows of 3 z-adjacent halo cells), two 16-bit slots per dword.
+template <bool FILL>
+__global__ __launch_bounds__(TILE_THREADS) void k_nbr_tile(StepCtx c, uint64_t* __restrict__ slice_w_ff,
+                                                           uint64_t* __restrict__ slice_w_fb, uint32_t* __restrict__ nbr_ff,
+                                                           uint32_t* __restrict__ nbr_fb, unsigned long long* ncontacts) {
+    __shared__ float red[TILE_WAVES];
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* __restrict__ Lp = t.stage(c.posm);
+    const bool multi = c.nmodels > 1;
+    const uint32_t* __restrict__ Lm = multi ? t.stage(c.model) : nullptr;
+    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    float total_ff = 0.0f, total_fb = 0.0f;
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        uint32_t cnt = 0, cntb = 0;
+        if (active) {
+            const float4 pi = c.posm[i];
+            const uint32_t mi = c.model[i];
+            bool bad = false;
+            const int lx = cell_coord(pi.x, c.sc.h, bad) - t.hcx, ly = cell_coord(pi.y, c.sc.h, bad) - t.hcy,
+                      lz = cell_coord(pi.z, c.sc.h, bad) - t.hcz;
+            const uint64_t base = FILL ? c.slice_ff[gs] + lane : 0;
+            const uint64_t baseb = (FILL && t.SB) ? c.slice_fb[gs] + lane : 0;
+            uint32_t pend = 0, pendb = 0;
 #pragma unroll 1
-    for (int dx = -1; dx <= 1; ++dx) {
-        const int ix = cx + dx - g.ox;
-        if ((unsigned)ix >= (unsigned)g.nx) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
 #pragma unroll 1
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int iy = cy + dy - g.oy;
-            if ((unsigned)iy >= (unsigned)g.ny) continue;
-            const size_t base = ((size_t)ix * g.ny + iy) * g.nz;
-            const uint32_t b = g.cell_start[base + z0], e = g.cell_start[base + z1 + 1];
-            for (uint32_t c = b; c < e; ++c) f(c);
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int row = ((lx + dx) * HY + (ly + dy)) * HZ + (lz - 1);
+                    const uint32_t b = t.lstart[row], e = t.lstart[row + 3];
+                    for (uint32_t s = b; s < e; ++s) {
+                        const float4 pj = Lp[s];
+                        const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                        if (d2 <= c.sc.h2 && (!multi || c.ff_ok[mi * c.nmodels + Lm[s]])) {
+                            if (FILL) {
+                                if (cnt & 1u) nbr_ff[base + (uint64_t)(cnt >> 1) * WAVE] = pend | (s << 16);
+                                else pend = s;
+                            }
+                            ++cnt;
+                        }
+                    }
+                    if (t.SB) {
+                        const uint32_t bb = t.blstart[row], be = t.blstart[row + 3];
+                        for (uint32_t s = bb; s < be; ++s) {
+                            const float4 pj = Bp[s];
+                            const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                            if (d2 <= c.sc.h2 && c.fb_ok[mi * c.nbmodels + __float_as_uint(Bv[s].w)]) {
+                                if (FILL) {
+                                    if (cntb & 1u) nbr_fb[baseb + (uint64_t)(cntb >> 1) * WAVE] = pendb | (s << 16);
+                                    else pendb = s;
+                                }
+                                ++cntb;
+                            }
+                        }
+                    }
+                }
+            }
+            if (FILL) {
+                if (cnt & 1u) nbr_ff[base + (uint64_t)(cnt >> 1) * WAVE] = pend;
+                if (cntb & 1u) nbr_fb[baseb + (uint64_t)(cntb >> 1) * WAVE] = pendb;
+            } else {
+                c.nff[i] = cnt;
+                c.nfb[i] = cntb;
+            }
+        }
+        if (!FILL) {
+            const uint32_t wm = wave_max_u32(cnt), wmb = wave_max_u32(cntb);
+            if (lane == 0) {
+                slice_w_ff[gs] = (uint64_t)((wm + 1) >> 1) * WAVE;
+                slice_w_fb[gs] = (uint64_t)((wmb + 1) >> 1) * WAVE;
+            }
+            total_ff += (float)cnt;
+            total_fb += (float)cntb;
+        }
+    });
+    if (!FILL) {
+        // exact integer totals (per-block counts stay far below 2^24)
+        const float a = block_sum(total_ff, red), b = block_sum(total_fb, red);
+        if (threadIdx.x == 0) {
+            if (a > 0.0f) atomicAdd(ncontacts + 0, (unsigned long long)a);
+            if (b > 0.0f) atomicAdd(ncontacts + 1, (unsigned long long)b);
         }
     }
 }
 
-// One lane per fluid particle.  FILL=false: count contacts (d2 <= h2, groups ok) -> counts[i], slice width.
-// FILL=true: write the candidate indices into the sliced-ELL list in traversal order.
-// BOUNDARY selects fluid-boundary contacts (contacts.rs:329-346,378-383) instead of fluid-fluid (:347-392).
-template <bool FILL, bool BOUNDARY>
-__global__ __launch_bounds__(BLOCK) void k_nbr(StepCtx c, uint32_t* __restrict__ counts, uint64_t* __restrict__ slice_w,
-                                               const uint64_t* __restrict__ slice_off, uint32_t* __restrict__ nbr,
-                                               unsigned long long* ncontacts) {
-    __shared__ float red[BLOCK / WAVE];
-    const unsigned blk = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-    const uint32_t i = blk * BLOCK + threadIdx.x;
-    const bool active = i < c.n;
-    uint32_t cnt = 0;
-    if (active) {
-        const float4 pi = c.posm[i];
-        const uint32_t mi = c.model[i];
-        bool bad = false;
-        const int cx = cell_coord(pi.x, c.sc.h, bad), cy = cell_coord(pi.y, c.sc.h, bad), cz = cell_coord(pi.z, c.sc.h, bad);
-        const GridView g = BOUNDARY ? c.gb : c.gf;
-        const float4* __restrict__ pts = BOUNDARY ? c.bposv : c.posm;
-        const uint64_t base = FILL ? slice_off[i / WAVE] + (i & (WAVE - 1)) : 0;
-        const bool multi = BOUNDARY ? true : (c.nmodels > 1);
-        for_each_candidate(g, cx, cy, cz, [&](uint32_t j) {
-            const float4 pj = pts[j];
-            const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-            if (d2 <= c.sc.h2) {
-                bool ok = true;
-                if (multi) {
-                    if (BOUNDARY) ok = c.fb_ok[mi * c.nbmodels + __float_as_uint(c.bvel[j].w)] != 0;
-                    else ok = c.ff_ok[mi * c.nmodels + c.model[j]] != 0;
-                }
-                if (ok) {
-                    if (FILL) nbr[base + (uint64_t)WAVE * cnt] = j;
-                    ++cnt;
-                }
-            }
-        });
-    }
-    if (!FILL) {
-        if (active) counts[i] = cnt;
-        const unsigned wmax = wave_max_u32(cnt);
-        if ((threadIdx.x & (WAVE - 1)) == 0 && (blk * BLOCK + (threadIdx.x & ~(WAVE - 1))) < c.n)
-            slice_w[(blk * BLOCK + threadIdx.x) / WAVE] = (uint64_t)wmax * WAVE;
-        // exact integer total (counts < 2^24 per block, so the float tree sum is exact)
-        const float tot = block_sum((float)cnt, red);
-        if (threadIdx.x == 0 && tot > 0.0f) atomicAdd(ncontacts, (unsigned long long)tot);
-    }
+void launch_nbr_count(const StepCtx& c, const TileLds& L, uint64_t* slice_w_ff, uint64_t* slice_w_fb,
+                      unsigned long long* ncontacts2, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_nbr_tile<false>, c, L.bytes(20, 32, 4), s, c, slice_w_ff, slice_w_fb, nullptr, nullptr, ncontacts2);
 }
-
-void launch_nbr_count(const StepCtx& c, bool boundary, uint32_t* counts, uint64_t* slice_w,
-                      unsigned long long* ncontacts, hipStream_t s) {
-    if (c.n == 0) return;
-    const unsigned nb = div_up(c.n, BLOCK);
-    if (boundary) k_nbr<false, true><<<nb, BLOCK, 0, s>>>(c, counts, slice_w, nullptr, nullptr, ncontacts);
-    else k_nbr<false, false><<<nb, BLOCK, 0, s>>>(c, counts, slice_w, nullptr, nullptr, ncontacts);
-}
-void launch_nbr_fill(const StepCtx& c, bool boundary, const uint64_t* slice_off, uint32_t* nbr, hipStream_t s) {
-    if (c.n == 0) return;
-    const unsigned nb = div_up(c.n, BLOCK);
-    if (boundary) k_nbr<true, true><<<nb, BLOCK, 0, s>>>(c, nullptr, nullptr, slice_off, nbr, nullptr);
-    else k_nbr<true, false><<<nb, BLOCK, 0, s>>>(c, nullptr, nullptr, slice_off, nbr, nullptr);
+void launch_nbr_fill(const StepCtx& c, const TileLds& L, uint32_t* nbr_ff, uint32_t* nbr_fb, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_nbr_tile<true>, c, L.bytes(20, 32, 4), s, c, nullptr, nullptr, nbr_ff, nbr_fb, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ boundary volumes
@@ -332,18 +374,23 @@ __global__ __launch_bounds__(BLOCK) void k_boundary_volumes(StepCtx c, unsigned 
         bool bad = false;
         const int cx = cell_coord(pi.x, c.sc.h, bad), cy = cell_coord(pi.y, c.sc.h, bad), cz = cell_coord(pi.z, c.sc.h, bad);
         float denom = 0.0f;
-        for_each_candidate(c.gb, cx, cy, cz, [&](uint32_t j) {
-            const float4 pj = c.bposv[j];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float d2 = dist2_exact(dx, dy, dz);
-            if (d2 <= c.sc.h2) {
-                const uint32_t mj = __float_as_uint(c.bvel[j].w);
-                if (mi == mj || c.bb_ok[mi * c.nbmodels + mj]) {
-                    denom += kernel_weight(d2, c.sc);
-                    ++cnt;
+        for (int d = 0; d < 27; ++d) {
+            bool in;
+            const uint32_t k = tile_key(c.gb, cx + d / 9 - 1, cy + (d / 3) % 3 - 1, cz + d % 3 - 1, in);
+            if (!in) continue;
+            const uint32_t b = c.gb.cell_start[k], e = c.gb.cell_start[k + 1];
+            for (uint32_t j = b; j < e; ++j) {
+                const float4 pj = c.bposv[j];
+                const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                if (d2 <= c.sc.h2) {
+                    const uint32_t mj = __float_as_uint(c.bvel[j].w);
+                    if (mi == mj || c.bb_ok[mi * c.nbmodels + mj]) {
+                        denom += kernel_weight(d2, c.sc);
+                        ++cnt;
+                    }
                 }
             }
-        });
+        }
         if (!(denom > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!denominator.is_zero()) dfsph_solver.rs:92
         reinterpret_cast<float*>(&c.bposv[i])[3] = 1.0f / denom;
     }

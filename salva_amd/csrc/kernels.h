@@ -2,14 +2,16 @@
 #pragma once
 #include "common.h"
 #include "device_types.h"
+#include "tile.h"
 
 namespace salva {
 
 // ---------------------------------------------------------------- grid.hip (replaces geometry::HGrid + contacts)
-// cell bbox of `n` points (xyz of float4) -> bbox6 = {min x,y,z, max x,y,z} (must be pre-initialised by launch_bbox_init)
-void launch_bbox_init(int32_t* bbox6, hipStream_t s);
-void launch_bbox(const float4* pts, uint32_t n, float h, int32_t* bbox6, uint32_t* flags, hipStream_t s);
-void launch_cell_keys(const float4* pts, uint32_t n, float h, GridView g, uint32_t* keys, uint32_t* idx,
+// cell bbox of `n` points (xyz of float4) -> bbox6 = {min x,y,z, max x,y,z}; partials needs 6 * bbox_blocks(n) ints
+unsigned bbox_blocks(uint32_t n);
+void launch_bbox(const float4* pts, uint32_t n, float h, int32_t* partials, int32_t* bbox6, uint32_t* flags, hipStream_t s);
+void launch_bbox_final(const int32_t* partials, unsigned nblocks, int32_t* bbox6, hipStream_t s);
+void launch_cell_keys(const float4* pts, uint32_t n, float h, TileGrid g, uint32_t* keys, uint32_t* idx,
                       uint32_t* flags, hipStream_t s);
 size_t sort_pairs_temp_bytes(uint32_t n, int end_bit);
 void sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
@@ -22,8 +24,7 @@ struct FluidArrays {
 };
 void launch_reorder_fluid(uint32_t n, const uint32_t* idx, FluidArrays in, FluidArrays out, float4* w, hipStream_t s);
 void launch_reorder_boundary(uint32_t n, const uint32_t* idx, const float4* bpos_in, const float4* bvel_in,
-                             const uint32_t* bperm_in, float4* bposv_out, float4* bvel_out, uint32_t* bperm_out,
-                             hipStream_t s);
+                             float4* bposv_out, float4* bvel_out, uint32_t* bperm_out, hipStream_t s);
 // canonical (host order) staging <-> sorted working set
 void launch_stage_to_sorted(uint32_t n, const float4* st_pos /*xyz,vol*/, const float4* st_vel, const float4* st_dv,
                             const uint32_t* st_model, const float* rho0_tab, FluidArrays out, hipStream_t s);
@@ -33,45 +34,49 @@ void launch_unsort_u32_as_f32(uint32_t n, const uint32_t* perm, const uint32_t* 
 void launch_unsort_f4(uint32_t n, const uint32_t* perm, const float4* in, float4* out, hipStream_t s);
 void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4* out, hipStream_t s);
 
-// neighbour lists (sliced ELL).  count: fills counts[], slice_w[nslices] (= 64 * max count in the wave) and adds to *ncontacts
-void launch_nbr_count(const StepCtx& c, bool boundary, uint32_t* counts, uint64_t* slice_w,
-                      unsigned long long* ncontacts, hipStream_t s);
-void launch_nbr_fill(const StepCtx& c, bool boundary, const uint64_t* slice_off, uint32_t* nbr, hipStream_t s);
+// per-tile slice counts (-> scan -> tile_slice_base) and the largest fluid / boundary halo of the step
+void launch_tile_info(const StepCtx& c, uint32_t* tile_nsl, uint32_t* max_halo2, hipStream_t s);
+// neighbour lists (per-tile sliced ELL of 16-bit halo slots).  count: fills nff/nfb, slice widths (dwords), contact totals
+void launch_nbr_count(const StepCtx& c, const TileLds& L, uint64_t* slice_w_ff, uint64_t* slice_w_fb,
+                      unsigned long long* ncontacts2, hipStream_t s);
+void launch_nbr_fill(const StepCtx& c, const TileLds& L, uint32_t* nbr_ff, uint32_t* nbr_fb, hipStream_t s);
 size_t scan_temp_bytes(uint32_t n);
 void scan_u64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t s);
+void scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint32_t n, hipStream_t s);
 
 // V_b = 1 / sum_b' W_bb' (dfsph_solver.rs:72-96); also counts boundary-boundary contacts
 void launch_boundary_volumes(const StepCtx& c, unsigned long long* ncontacts_bb, hipStream_t s);
 
 // ---------------------------------------------------------------- dfsph.hip
 unsigned num_blocks(uint32_t n);
-void launch_density_alpha(const StepCtx& c, hipStream_t s);
-void launch_divergence(const StepCtx& c, hipStream_t s);                 // -> kappa = div*alpha, partials
-void launch_divergence_apply(const StepCtx& c, float inv_dt_prev, hipStream_t s);
+void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s);
+void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s);                 // -> kappa = div*alpha, partials
+void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s);
 void launch_finish_divergence(const StepCtx& c, float gx, float gy, float gz, bool acc_has_user, hipStream_t s);
 void launch_integrate(const StepCtx& c, float dt, hipStream_t s);       // dv += acc*dt ; acc = 0 ; w = vel + dv
-void launch_pred_density(const StepCtx& c, float dt, hipStream_t s);    // -> kappa = (rho*-rho0)*alpha, partials
-void launch_pressure_apply(const StepCtx& c, float inv_dt, hipStream_t s);
-void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox6, hipStream_t s);
-// err = max_m (sum_b partials[b][m] / count[m]) -> *out_err
+void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s);    // -> kappa = (rho*-rho0)*alpha, partials
+void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s);
+// x += w dt; per-block cell bounds into bbox_partials (6 * num_blocks(n) ints), folded into bbox6
+void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox_partials, int32_t* bbox6, hipStream_t s);
+// err = max_m (sum_b partials[b][m] / count[m]) -> *out_err   (nblocks = ntiles)
 void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
                            float* out_err, hipStream_t s);
 
 // ---------------------------------------------------------------- forces.hip
-void launch_xsph(const StepCtx& c, uint32_t model, float fluid_coeff, float boundary_coeff, float inv_dt_prev, hipStream_t s);
-void launch_artificial_viscosity(const StepCtx& c, uint32_t model, float fluid_coeff, float boundary_coeff, float alpha,
+void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff, float inv_dt_prev, hipStream_t s);
+void launch_artificial_viscosity(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff, float alpha,
                                  float beta, float speed_of_sound, hipStream_t s);
-void launch_akinci_normals(const StepCtx& c, uint32_t model, hipStream_t s);
-void launch_akinci_forces(const StepCtx& c, uint32_t model, float tension, float adhesion, hipStream_t s);
+void launch_akinci_normals(const StepCtx& c, const TileLds& L, uint32_t model, hipStream_t s);
+void launch_akinci_forces(const StepCtx& c, const TileLds& L, uint32_t model, float tension, float adhesion, hipStream_t s);
 
 // ---------------------------------------------------------------- iisph.hip
 void launch_iisph_begin(const StepCtx& c, float gx, float gy, float gz, bool acc_has_user, hipStream_t s);  // acc += g
-void launch_iisph_dii(const StepCtx& c, float dt, hipStream_t s);            // + p = 0.5 * dv.w
-void launch_iisph_pred_density(const StepCtx& c, float dt, hipStream_t s);   // rho_star
-void launch_iisph_aii(const StepCtx& c, float dt, hipStream_t s);
-void launch_iisph_dij_pj(const StepCtx& c, float dt, const float* p, hipStream_t s);
-void launch_iisph_next_pressure(const StepCtx& c, float dt, float omega, const float* p, float* p_next, hipStream_t s);
-void launch_iisph_velocity_changes(const StepCtx& c, float dt, const float* p, hipStream_t s);
-void launch_iisph_finish(const StepCtx& c, float dt, const float* p, int32_t* bbox6, hipStream_t s);
+void launch_iisph_dii(const StepCtx& c, const TileLds& L, float dt, hipStream_t s);            // + p = 0.5 * dv.w
+void launch_iisph_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s);   // rho_star
+void launch_iisph_aii(const StepCtx& c, const TileLds& L, float dt, hipStream_t s);
+void launch_iisph_dij_pj(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s);
+void launch_iisph_next_pressure(const StepCtx& c, const TileLds& L, float dt, float omega, const float* p, float* p_next, hipStream_t s);
+void launch_iisph_velocity_changes(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s);
+void launch_iisph_finish(const StepCtx& c, float dt, const float* p, int32_t* bbox_partials, int32_t* bbox6, hipStream_t s);
 
 }  // namespace salva

@@ -1,0 +1,280 @@
+// tile.h — LDS-staged cell tiles: the execution skeleton of every neighbour kernel.
+//
+// Why: a one-lane-per-particle gather straight from global memory issues ~25 M L2 requests per pass at 10^6
+// particles (measured: L1 hit rate 45 %, L2 request rate ~80 % of the tag-lookup ceiling, VALU 20-40 % busy —
+// profiles/r01a_v1_gather).  Here one workgroup owns one tile of 4x4x2 grid cells; it copies the particles of the
+// 6x6x4 halo box (own tile + one cell all round, the interaction range being exactly one cell, contacts.rs:164-165)
+// into LDS with coalesced loads, and the per-particle neighbour loops then read 16-byte records from LDS by slot.
+// Neighbour lists store 16-bit LDS slots (two per dword), so a pass streams 2 B per contact instead of 4.
+//
+// Particle order = tile-major cell key (tile linear index * 32 + cell-in-tile), x slowest.  A tile's own particles
+// are one contiguous index range; its halo is at most 144 cells, each a contiguous range (cell table with
+// lower-bound semantics).  Tiles sit on an absolute lattice (cell coords floor-divided by the tile shape) so the
+// fluid and the boundary tables, which have different origins, agree on tile membership.
+#pragma once
+#include "common.h"
+#include "device_types.h"
+
+namespace salva {
+
+constexpr int TX = 4, TY = 4, TZ = 2;                  // cells per tile
+constexpr int TCELLS = TX * TY * TZ;                   // 32
+constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;   // halo box
+constexpr int HCELLS = HX * HY * HZ;                   // 144
+constexpr int TILE_WAVES = 5;
+constexpr int TILE_THREADS = TILE_WAVES * WAVE;        // 320: a tile holds 256 (lattice) .. 320 (rest density) particles
+constexpr int STAGE_LANES = 16;                        // lanes that copy one halo cell (8-10 particles each)
+
+__host__ __device__ inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+constexpr uint32_t TILE_TABLE_BYTES = 4 * (2 * (HCELLS + 1) + 2 * HCELLS);
+constexpr uint32_t TILE_TABLE_PAD = (TILE_TABLE_BYTES + 15u) & ~15u;
+
+// Dynamic-LDS budget of a tile kernel: halo tables + staged arrays sized for the largest halo of this step.
+struct TileLds {
+    uint32_t max_halo_fluid = 0, max_halo_boundary = 0;
+    uint32_t bytes(uint32_t bytes_per_fluid_slot, uint32_t bytes_per_boundary_slot, uint32_t narrays) const {
+        return TILE_TABLE_PAD + max_halo_fluid * bytes_per_fluid_slot + max_halo_boundary * bytes_per_boundary_slot +
+               16u * narrays;
+    }
+};
+
+#ifdef __HIPCC__
+
+template <typename K>
+inline void ensure_tile_lds(K kernel, uint32_t bytes) {
+    if (bytes > 160u * 1024u)
+        throw HipError(-4, "a tile's halo does not fit the 160 KiB LDS (particles are compressed far beyond rest density)");
+    if (bytes > 48u * 1024u)
+        SALVA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+#define SALVA_LAUNCH_TILE(kernel, c, lds, s, ...)                          \
+    do {                                                                   \
+        if ((c).n) {                                                       \
+            const uint32_t _lds = (lds);                                   \
+            ::salva::ensure_tile_lds(kernel, _lds);                        \
+            kernel<<<(c).ntiles, ::salva::TILE_THREADS, _lds, s>>>(__VA_ARGS__); \
+        }                                                                  \
+    } while (0)
+
+// key of cell (cx,cy,cz) (absolute cell coords) in grid g, or inside = false
+__device__ __forceinline__ uint32_t tile_key(const TileGrid& g, int cx, int cy, int cz, bool& inside) {
+    const int ix = cx - g.ox, iy = cy - g.oy, iz = cz - g.oz;
+    inside = (unsigned)ix < (unsigned)(g.ntx * TX) && (unsigned)iy < (unsigned)(g.nty * TY) &&
+             (unsigned)iz < (unsigned)(g.ntz * TZ);
+    const uint32_t tile = ((uint32_t)(ix / TX) * g.nty + (uint32_t)(iy / TY)) * g.ntz + (uint32_t)(iz / TZ);
+    return tile * TCELLS + (uint32_t)(((ix % TX) * TY + (iy % TY)) * TZ + (iz % TZ));
+}
+
+// floor(x / h) exactly as hgrid.rs:41-43 (IEEE f32 division, then floor), clamped to +-2^30; NaN -> bad.
+__device__ __forceinline__ int cell_coord(float x, float h, bool& bad) {
+    float f = floorf(__fdiv_rn(x, h));
+    if (!(f == f)) { bad = true; f = 0.0f; }
+    f = fminf(fmaxf(f, -1073741824.0f), 1073741824.0f);
+    return (int)f;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+
+struct Tile {
+    uint32_t* lstart;    // [HCELLS+1] first LDS slot of each fluid halo cell (h = (hx*HY + hy)*HZ + hz)
+    uint32_t* gstart;    // [HCELLS]   first global (sorted) index of each fluid halo cell
+    uint32_t* blstart;   // same for the boundary particles
+    uint32_t* bgstart;
+    unsigned char* pool; // staged arrays, 16-byte aligned
+    uint32_t S, SB;      // staged slot counts
+    uint32_t tile;       // logical tile index
+    uint32_t own_begin, own_end, slice_base;
+    int hcx, hcy, hcz;   // absolute cell coords of halo cell (0,0,0)
+    uint32_t pool_used;
+
+    __device__ __forceinline__ bool empty() const { return own_begin == own_end; }
+
+    // Every thread of the block must call.  Returns with the halo tables in LDS (synchronised).
+    __device__ __forceinline__ void setup(const StepCtx& c) {
+        uint32_t* t = reinterpret_cast<uint32_t*>(tile_smem);
+        lstart = t; gstart = t + (HCELLS + 1); blstart = gstart + HCELLS; bgstart = blstart + (HCELLS + 1);
+        pool = tile_smem + TILE_TABLE_PAD;
+        pool_used = 0;
+        tile = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+        const TileGrid& g = c.gf;
+        const uint32_t ttz = tile % g.ntz, tty = (tile / g.ntz) % g.nty, ttx = tile / (g.ntz * g.nty);
+        own_begin = g.cell_start[(size_t)tile * TCELLS];
+        own_end = g.cell_start[(size_t)tile * TCELLS + TCELLS];
+        slice_base = c.tile_slice_base[tile];
+        hcx = g.ox + (int)ttx * TX - 1; hcy = g.oy + (int)tty * TY - 1; hcz = g.oz + (int)ttz * TZ - 1;
+        S = SB = 0;
+        if (own_begin == own_end) return;  // uniform across the block
+        const int h = threadIdx.x;
+        if (h < HCELLS) {
+            const int hz = h % HZ, hy = (h / HZ) % HY, hx = h / (HZ * HY);
+            bool in;
+            const uint32_t k = tile_key(g, hcx + hx, hcy + hy, hcz + hz, in);
+            uint32_t b = 0, e = 0;
+            if (in) { b = g.cell_start[k]; e = g.cell_start[k + 1]; }
+            gstart[h] = b; lstart[h] = e - b;
+            b = e = 0;
+            if (c.nb) {
+                const uint32_t kb = tile_key(c.gb, hcx + hx, hcy + hy, hcz + hz, in);
+                if (in) { b = c.gb.cell_start[kb]; e = c.gb.cell_start[kb + 1]; }
+            }
+            bgstart[h] = b; blstart[h] = e - b;
+        }
+        __syncthreads();
+        if (threadIdx.x < WAVE) {  // exclusive prefix of 144 counts by one wave: 3 per lane (lanes 0..47)
+            const int l = threadIdx.x;
+            uint32_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+            if (l < HCELLS / 3) {
+                a0 = lstart[3 * l]; a1 = lstart[3 * l + 1]; a2 = lstart[3 * l + 2];
+                b0 = blstart[3 * l]; b1 = blstart[3 * l + 1]; b2 = blstart[3 * l + 2];
+            }
+            uint32_t sa = a0 + a1 + a2, sb = b0 + b1 + b2;
+            uint32_t ia = sa, ib = sb;
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const uint32_t ta = (uint32_t)__shfl_up((int)ia, o, WAVE), tb = (uint32_t)__shfl_up((int)ib, o, WAVE);
+                if (l >= o) { ia += ta; ib += tb; }
+            }
+            const uint32_t ea = ia - sa, eb = ib - sb;
+            if (l < HCELLS / 3) {
+                lstart[3 * l] = ea; lstart[3 * l + 1] = ea + a0; lstart[3 * l + 2] = ea + a0 + a1;
+                blstart[3 * l] = eb; blstart[3 * l + 1] = eb + b0; blstart[3 * l + 2] = eb + b0 + b1;
+            }
+            if (l == HCELLS / 3 - 1) { lstart[HCELLS] = ia; blstart[HCELLS] = ib; }
+        }
+        __syncthreads();
+        S = lstart[HCELLS];
+        SB = blstart[HCELLS];
+    }
+
+    // Carve an array of `count` elements of T from the pool (uniform across the block).
+    template <typename T>
+    __device__ __forceinline__ T* carve(uint32_t count) {
+        T* p = reinterpret_cast<T*>(pool + pool_used);
+        pool_used += (count * (uint32_t)sizeof(T) + 15u) & ~15u;
+        return p;
+    }
+
+    // Copy the halo particles of a global per-particle array into LDS: 16 lanes per halo cell, so the loads of a
+    // cell (and of the cells that follow it in tile-major order) coalesce.  No barrier inside.
+    template <typename T>
+    __device__ __forceinline__ T* stage(const T* __restrict__ src) {
+        T* dst = carve<T>(S);
+        const int sub = threadIdx.x % STAGE_LANES, grp = threadIdx.x / STAGE_LANES;
+        for (int h = grp; h < HCELLS; h += TILE_THREADS / STAGE_LANES) {
+            const uint32_t l0 = lstart[h], cnt = lstart[h + 1] - l0, g0 = gstart[h];
+            for (uint32_t k = sub; k < cnt; k += STAGE_LANES) dst[l0 + k] = src[g0 + k];
+        }
+        return dst;
+    }
+    template <typename T>
+    __device__ __forceinline__ T* stage_boundary(const T* __restrict__ src) {
+        T* dst = carve<T>(SB);
+        if (SB == 0) return dst;
+        const int sub = threadIdx.x % STAGE_LANES, grp = threadIdx.x / STAGE_LANES;
+        for (int h = grp; h < HCELLS; h += TILE_THREADS / STAGE_LANES) {
+            const uint32_t l0 = blstart[h], cnt = blstart[h + 1] - l0, g0 = bgstart[h];
+            for (uint32_t k = sub; k < cnt; k += STAGE_LANES) dst[l0 + k] = src[g0 + k];
+        }
+        return dst;
+    }
+
+    // Visit the tile's own particles, one wave per 64-particle slice: f(i, global_slice, active).
+    template <typename F>
+    __device__ __forceinline__ void for_own(F&& f) const {
+        const uint32_t nsl = (own_end - own_begin + WAVE - 1) / WAVE;
+        const uint32_t lane = threadIdx.x & (WAVE - 1);
+        for (uint32_t s = threadIdx.x / WAVE; s < nsl; s += TILE_WAVES) {
+            const uint32_t i = own_begin + s * WAVE + lane;
+            f(i, slice_base + s, i < own_end);
+        }
+    }
+
+    // global sorted index of a fluid halo slot (used by the rare paths that need it)
+    __device__ __forceinline__ uint32_t global_of_slot(uint32_t slot) const {
+        int lo = 0, hi = HCELLS;  // largest h with lstart[h] <= slot
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lstart[mid] <= slot) lo = mid; else hi = mid; }
+        return gstart[lo] + (slot - lstart[lo]);
+    }
+};
+
+// Neighbour iteration: 16-bit LDS slots, two per dword, sliced-ELL per 64-particle slice.
+template <typename F>
+__device__ __forceinline__ void for_each_slot(const uint32_t* __restrict__ nbr, const uint64_t* __restrict__ slice_off,
+                                              uint32_t gslice, uint32_t cnt, F&& f) {
+    if (cnt == 0) return;
+    const uint32_t* __restrict__ p = nbr + slice_off[gslice] + (threadIdx.x & (WAVE - 1));
+    const uint32_t nq = (cnt + 1) >> 1;
+    uint32_t next = p[0];
+    for (uint32_t q = 0; q < nq; ++q) {
+        const uint32_t pr = next;
+        if (q + 1 < nq) next = p[(size_t)(q + 1) * WAVE];
+        f(pr & 0xffffu);
+        if (2 * q + 1 < cnt) f(pr >> 16);
+    }
+}
+template <typename F>
+__device__ __forceinline__ void for_each_ff(const StepCtx& c, uint32_t i, uint32_t gslice, F&& f) {
+    for_each_slot(c.nbr_ff, c.slice_ff, gslice, c.nff[i], f);
+}
+template <typename F>
+__device__ __forceinline__ void for_each_fb(const StepCtx& c, const Tile& t, uint32_t i, uint32_t gslice, F&& f) {
+    if (t.SB == 0) return;
+    for_each_slot(c.nbr_fb, c.slice_fb, gslice, c.nfb[i], f);
+}
+
+// Per-fluid error sums of one tile (par_reduce_sum!, lib.rs:75-83; the per-fluid average is taken by
+// k_finalize_error).  Each wave accumulates its slices, in order, into its own LDS row; the rows are then folded in
+// wave order, so the result does not depend on scheduling.
+constexpr int MAX_MODELS = 32;
+struct TileErr {
+    float (*tab)[MAX_MODELS];
+    __device__ __forceinline__ void init(float (*t)[MAX_MODELS], const StepCtx& c) {
+        tab = t;
+        const uint32_t lane = threadIdx.x & (WAVE - 1);
+        if (lane < c.nmodels) tab[threadIdx.x / WAVE][lane] = 0.0f;
+    }
+    // wave-uniform call
+    __device__ __forceinline__ void add(const StepCtx& c, float err, uint32_t mi, bool active) {
+        const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+        if (c.nmodels == 1) {
+            const float s = wave_sum(active ? err : 0.0f);
+            if (lane == 0) tab[wv][0] += s;
+        } else {
+            for (uint32_t m = 0; m < c.nmodels; ++m) {
+                const float s = wave_sum((active && mi == m) ? err : 0.0f);
+                if (lane == 0) tab[wv][m] += s;
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(const StepCtx& c, uint32_t tile) {
+        __syncthreads();
+        if (threadIdx.x < c.nmodels) {
+            float s = 0.0f;
+            for (int w = 0; w < TILE_WAVES; ++w) s += tab[w][threadIdx.x];
+            c.partials[(size_t)tile * c.nmodels + threadIdx.x] = s;
+        }
+    }
+    static __device__ __forceinline__ void zero(const StepCtx& c, uint32_t tile) {
+        if (threadIdx.x < c.nmodels) c.partials[(size_t)tile * c.nmodels + threadIdx.x] = 0.0f;
+    }
+};
+
+// Boundary::apply_force (boundary.rs:62-67): forces accumulate in canonical boundary order.  `jb` is the sorted
+// boundary index (t.bgstart-relative lookups are done by the caller).
+__device__ __forceinline__ void apply_boundary_force(const StepCtx& c, uint32_t jb_sorted, uint32_t bmodel, float fx,
+                                                     float fy, float fz) {
+    if (c.bforce == nullptr || !c.bwants[bmodel]) return;
+    float* f = reinterpret_cast<float*>(&c.bforce[c.bperm[jb_sorted]]);
+    atomicAdd(f + 0, fx);
+    atomicAdd(f + 1, fy);
+    atomicAdd(f + 2, fz);
+}
+__device__ __forceinline__ uint32_t boundary_global_of_slot(const Tile& t, uint32_t slot) {
+    int lo = 0, hi = HCELLS;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t.blstart[mid] <= slot) lo = mid; else hi = mid; }
+    return t.bgstart[lo] + (slot - t.blstart[lo]);
+}
+
+#endif  // __HIPCC__
+}  // namespace salva

@@ -23,10 +23,11 @@ struct BoundarySlot {
     bool wants_forces = false;
 };
 
-struct GridDims {
-    int o[3] = {0, 0, 0};
-    int d[3] = {1, 1, 1};
-    size_t ncells() const { return (size_t)d[0] * d[1] * d[2]; }
+struct GridDims {          // tile-aligned dense grid (tile.h)
+    int o[3] = {0, 0, 0};  // cell coords of the first cell, multiples of the tile shape
+    int nt[3] = {1, 1, 1}; // tiles per axis
+    size_t ntiles() const { return (size_t)nt[0] * nt[1] * nt[2]; }
+    size_t ncells() const { return ntiles() * TCELLS; }
 };
 
 class World {
@@ -63,7 +64,7 @@ class World {
     void build_boundary_grid();
     void ensure_cub_temp(size_t bytes);
     StepCtx make_ctx();
-    float read_error(unsigned nblocks);
+    float read_error();
     void run_forces(const StepCtx& c);
     void dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
     void iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
@@ -84,8 +85,11 @@ class World {
     DevBuf<float4> acc, w, normal, dii, dijpj;
     DevBuf<float> rho, alpha, kappa, kappa2, rho_star, aii;
     DevBuf<uint32_t> nff, nfb, keys[2], idx[2], cell_start_f;
-    DevBuf<uint64_t> slice_w, slice_ff, slice_fb;
+    DevBuf<uint32_t> tile_nsl, tile_slice_base, d_maxhalo;
+    DevBuf<uint64_t> slice_w_ff, slice_w_fb, slice_ff, slice_fb;
     DevBuf<uint32_t> nbr_ff, nbr_fb;
+    DevBuf<int32_t> bbox_partials;
+    TileLds lds;
     DevBuf<char> cub_temp;
     DevBuf<float> scratch_f;   // staging for AoS up/downloads and field unsorts
     DevBuf<float4> scratch_f4;

@@ -149,6 +149,7 @@ void World::set_fluid(uint32_t slot, uint64_t nn, const float* pos, const float*
                       uint32_t dirty) {
     use_device();
     if (slot > fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range (slots are dense)");
+    if (slot >= (uint32_t)MAX_MODELS) throw HipError(SALVA_HIP_E_CAPACITY, "at most 32 fluids per world");
     const bool is_new = slot == fluids.size();
     if ((uint64_t)n - (is_new ? 0 : fluids[slot].n) + nn >= 0xfffffff0ull)
         throw HipError(SALVA_HIP_E_CAPACITY, "more than 2^32 fluid particles on one device");
@@ -387,12 +388,14 @@ StepCtx World::make_ctx() {
     c.dii = dii.p; c.dijpj = dijpj.p;
     c.nff = nff.p; c.nfb = nfb.p;
     c.slice_ff = slice_ff.p; c.nbr_ff = nbr_ff.p; c.slice_fb = slice_fb.p; c.nbr_fb = nbr_fb.p;
-    c.gf = GridView{gf.o[0], gf.o[1], gf.o[2], gf.d[0], gf.d[1], gf.d[2], cell_start_f.p};
+    c.tile_slice_base = tile_slice_base.p;
+    c.ntiles = (uint32_t)gf.ntiles();
+    c.gf = TileGrid{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], cell_start_f.p};
     c.nb = nb;
     c.bposv = bposv.p; c.bvel = bvel.p; c.bperm = bperm.p;
     c.bforce = any_wants_forces ? bforce.p : nullptr;
     c.bwants = bwants.p;
-    c.gb = GridView{gb.o[0], gb.o[1], gb.o[2], gb.d[0], gb.d[1], gb.d[2], cell_start_b.p};
+    c.gb = TileGrid{gb.o[0], gb.o[1], gb.o[2], gb.nt[0], gb.nt[1], gb.nt[2], cell_start_b.p};
     c.nmodels = (uint32_t)std::max<size_t>(fluids.size(), 1);
     c.nbmodels = (uint32_t)std::max<size_t>(bounds.size(), 1);
     c.rho0_tab = rho0_tab.p; c.ff_ok = ff_ok.p; c.fb_ok = fb_ok.p; c.bb_ok = bb_ok.p;
@@ -403,13 +406,15 @@ StepCtx World::make_ctx() {
 }
 
 static void dims_from_bbox(const int32_t* bb, GridDims& g) {
+    static const int T[3] = {TX, TY, TZ};
+    double nc = TCELLS;
     for (int a = 0; a < 3; ++a) {
-        g.o[a] = bb[a];
-        const int64_t d = (int64_t)bb[3 + a] - (int64_t)bb[a] + 1;
-        if (d <= 0 || d > (1 << 30)) throw HipError(SALVA_HIP_E_CAPACITY, "cell bounding box is empty or too large");
-        g.d[a] = (int)d;
+        if (bb[a] > bb[3 + a]) throw HipError(SALVA_HIP_E_CAPACITY, "empty cell bounding box");
+        const int t0 = floor_div(bb[a], T[a]), t1 = floor_div(bb[3 + a], T[a]);
+        g.o[a] = t0 * T[a];
+        g.nt[a] = t1 - t0 + 1;
+        nc *= (double)g.nt[a];
     }
-    const double nc = (double)g.d[0] * (double)g.d[1] * (double)g.d[2];
     if (nc >= 4.0e9) throw HipError(SALVA_HIP_E_CAPACITY, "dense cell table would exceed 2^32 cells; particles are too spread out");
 }
 
@@ -420,21 +425,21 @@ void World::build_boundary_grid() {
     if (!b_dirty) return;
     ncontacts_bb = 0;
     if (nb == 0) { b_dirty = false; return; }
-    launch_bbox_init(d_rb.p->bbbox, stream);
-    launch_bbox(bst_pos.p, nb, sc.h, d_rb.p->bbbox, d_flags.p, stream);
+    bbox_partials.ensure(6 * std::max<size_t>(bbox_blocks(nb), 1024));
+    launch_bbox(bst_pos.p, nb, sc.h, bbox_partials.p, d_rb.p->bbbox, d_flags.p, stream);
     SALVA_HIP_CHECK(hipMemcpyAsync(h_rb->bbbox, d_rb.p->bbbox, sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipStreamSynchronize(stream));
     dims_from_bbox(h_rb->bbbox, gb);
     const size_t nc = gb.ncells();
     bkeys[0].ensure(nb); bkeys[1].ensure(nb); bidx[0].ensure(nb); bidx[1].ensure(nb);
     bposv.ensure(nb); bvel.ensure(nb); bperm.ensure(nb); cell_start_b.ensure(nc + 1);
-    GridView gv{gb.o[0], gb.o[1], gb.o[2], gb.d[0], gb.d[1], gb.d[2], nullptr};
+    TileGrid gv{gb.o[0], gb.o[1], gb.o[2], gb.nt[0], gb.nt[1], gb.nt[2], nullptr};
     launch_cell_keys(bst_pos.p, nb, sc.h, gv, bkeys[0].p, bidx[0].p, d_flags.p, stream);
     const int end_bit = bits_for(nc);
     const size_t tb = sort_pairs_temp_bytes(nb, end_bit);
     ensure_cub_temp(tb);
     sort_pairs(cub_temp.p, tb, bkeys[0].p, bkeys[1].p, bidx[0].p, bidx[1].p, nb, end_bit, stream);
-    launch_reorder_boundary(nb, bidx[1].p, bst_pos.p, bst_vel.p, nullptr, bposv.p, bvel.p, bperm.p, stream);
+    launch_reorder_boundary(nb, bidx[1].p, bst_pos.p, bst_vel.p, bposv.p, bvel.p, bperm.p, stream);
     launch_cell_start(bkeys[1].p, nb, (uint32_t)nc, cell_start_b.p, stream);
     StepCtx c = make_ctx();
     SALVA_HIP_CHECK(hipMemsetAsync(d_counters.p + 2, 0, sizeof(unsigned long long), stream));
@@ -445,8 +450,8 @@ void World::build_boundary_grid() {
     b_dirty = false;
 }
 
-float World::read_error(unsigned nblocks) {
-    launch_finalize_error(partials.p, nblocks, (uint32_t)std::max<size_t>(fluids.size(), 1), model_counts.p, &d_rb.p->err, stream);
+float World::read_error() {
+    launch_finalize_error(partials.p, (unsigned)gf.ntiles(), (uint32_t)std::max<size_t>(fluids.size(), 1), model_counts.p, &d_rb.p->err, stream);
     SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->err, &d_rb.p->err, sizeof(float), hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipStreamSynchronize(stream));
     return h_rb->err;
@@ -458,11 +463,11 @@ void World::run_forces(const StepCtx& c) {
         if (fluids[f].n == 0) continue;
         for (const SalvaHipForceDesc& d : fluids[f].forces) {
             switch (d.kind) {
-                case SALVA_HIP_FORCE_XSPH: launch_xsph(c, f, d.p[0], d.p[1], inv_dt_prev, stream); break;
-                case SALVA_HIP_FORCE_ARTIFICIAL: launch_artificial_viscosity(c, f, d.p[0], d.p[1], d.p[2], d.p[3], d.p[4], stream); break;
+                case SALVA_HIP_FORCE_XSPH: launch_xsph(c, lds, f, d.p[0], d.p[1], inv_dt_prev, stream); break;
+                case SALVA_HIP_FORCE_ARTIFICIAL: launch_artificial_viscosity(c, lds, f, d.p[0], d.p[1], d.p[2], d.p[3], d.p[4], stream); break;
                 case SALVA_HIP_FORCE_AKINCI2013:
-                    launch_akinci_normals(c, f, stream);
-                    launch_akinci_forces(c, f, d.p[0], d.p[1], stream);
+                    launch_akinci_normals(c, lds, f, stream);
+                    launch_akinci_forces(c, lds, f, d.p[0], d.p[1], stream);
                     break;
                 default: break;
             }
@@ -472,16 +477,15 @@ void World::run_forces(const StepCtx& c) {
 
 // DFSPHSolver::step (dfsph_solver.rs:667-708)
 void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
-    const unsigned nblocks = num_blocks(n);
     // divergence_solve (:466-503).  NOTE the dt lag: inv_dt is still the previous step's here (0 on the first step).
     int nd = 0;
     float err = 0.0f;
     for (int i = 0; i < prm.max_divergence_iter; ++i) {
-        launch_divergence(c, stream);
-        err = read_error(nblocks);
+        launch_divergence(c, lds, stream);
+        err = read_error();
         const float max_err = prm.max_divergence_error * inv_dt_prev * 0.01f;
         if (err <= max_err && i >= prm.min_divergence_iter) break;
-        launch_divergence_apply(c, inv_dt_prev, stream);
+        launch_divergence_apply(c, lds, inv_dt_prev, stream);
         ++nd;
     }
     st.n_divergence_iters = nd;
@@ -495,50 +499,47 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
     int np = 0;
     err = 0.0f;
     for (int i = 0; i < prm.max_pressure_iter; ++i) {
-        launch_pred_density(c, dt, stream);
-        err = read_error(nblocks);
+        launch_pred_density(c, lds, dt, stream);
+        err = read_error();
         if (err <= prm.max_density_error && i >= prm.min_pressure_iter) break;
-        launch_pressure_apply(c, inv_dt, stream);
+        launch_pressure_apply(c, lds, inv_dt, stream);
         ++np;
     }
     st.n_pressure_iters = np;
     st.density_error = err;
-    launch_bbox_init(d_rb.p->bbox, stream);
-    launch_update_positions(c, dt, d_rb.p->bbox, stream);
+    launch_update_positions(c, dt, bbox_partials.p, d_rb.p->bbox, stream);
     dt_prev = dt;
     inv_dt_prev = inv_dt;
 }
 
 // IISPHSolver::step (iisph_solver.rs:643-711)
 void World::iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
-    const unsigned nblocks = num_blocks(n);
     st.n_divergence_iters = 0;
     st.divergence_error = 0.0f;
     launch_iisph_begin(c, g[0], g[1], g[2], acc_user, stream);
     run_forces(c);  // forces still see the previous inv_dt (:654-662)
     const float inv_dt = (dt == 0.0f) ? 0.0f : 1.0f / dt;
     launch_integrate(c, dt, stream);
-    launch_iisph_dii(c, dt, stream);  // also p = 0.5 * p_prev
-    launch_iisph_pred_density(c, dt, stream);
-    launch_iisph_aii(c, dt, stream);
+    launch_iisph_dii(c, lds, dt, stream);  // also p = 0.5 * p_prev
+    launch_iisph_pred_density(c, lds, dt, stream);
+    launch_iisph_aii(c, lds, dt, stream);
     float* p = kappa.p;
     float* pn = kappa2.p;
     int it = 0;
     float err = 0.0f;
     const float omega = 0.5f;  // :53
     for (int i = 0; i < prm.max_pressure_iter; ++i) {
-        launch_iisph_dij_pj(c, dt, p, stream);
-        launch_iisph_next_pressure(c, dt, omega, p, pn, stream);
-        err = read_error(nblocks);
+        launch_iisph_dij_pj(c, lds, dt, p, stream);
+        launch_iisph_next_pressure(c, lds, dt, omega, p, pn, stream);
+        err = read_error();
         std::swap(p, pn);
         ++it;
         if (err <= prm.max_density_error && i >= prm.min_pressure_iter) break;
     }
     st.n_pressure_iters = it;
     st.density_error = err;
-    launch_iisph_velocity_changes(c, dt, p, stream);
-    launch_bbox_init(d_rb.p->bbox, stream);
-    launch_iisph_finish(c, dt, p, d_rb.p->bbox, stream);
+    launch_iisph_velocity_changes(c, lds, dt, p, stream);
+    launch_iisph_finish(c, dt, p, bbox_partials.p, d_rb.p->bbox, stream);
     dt_prev = dt;
     inv_dt_prev = inv_dt;
 }
@@ -568,10 +569,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     for (auto& f : fluids) for (auto& d : f.forces) has_akinci |= d.kind == SALVA_HIP_FORCE_AKINCI2013;
     if (has_akinci) normal.ensure(n);
     if (prm.solver == SALVA_HIP_SOLVER_IISPH) { kappa2.ensure(n); rho_star.ensure(n); aii.ensure(n); dii.ensure(n); dijpj.ensure(n); }
-    const unsigned nblocks = num_blocks(n);
-    partials.ensure((size_t)nblocks * std::max<size_t>(fluids.size(), 1));
-    const uint32_t nslices = div_up(n, WAVE);
-    slice_w.ensure(nslices + 1); slice_ff.ensure(nslices + 1); slice_fb.ensure(nslices + 1);
+    bbox_partials.ensure(6 * std::max<size_t>(std::max<size_t>(num_blocks(n), bbox_blocks(n)), 1024));
 
     // ---- (re)build the sorted working set from the canonical arrays after host edits
     if (!sorted_valid) {
@@ -582,19 +580,27 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
 
     // ---- cell bounding box (known from the previous step's position update unless the host moved particles)
     if (!bbox_known) {
-        launch_bbox_init(d_rb.p->bbox, stream);
-        launch_bbox(posm[cur].p, n, sc.h, d_rb.p->bbox, d_flags.p, stream);
+        launch_bbox(posm[cur].p, n, sc.h, bbox_partials.p, d_rb.p->bbox, d_flags.p, stream);
         SALVA_HIP_CHECK(hipMemcpyAsync(h_rb->bbox, d_rb.p->bbox, sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
         SALVA_HIP_CHECK(hipStreamSynchronize(stream));
         bbox_known = true;
     }
     dims_from_bbox(h_rb->bbox, gf);
     const size_t ncf = gf.ncells();
+    const uint32_t ntiles = (uint32_t)gf.ntiles();
     cell_start_f.ensure(ncf + 1, stream, false, 1.5f);
+    tile_nsl.ensure(ntiles + 1, stream, false, 1.5f);
+    tile_slice_base.ensure(ntiles + 1, stream, false, 1.5f);
+    d_maxhalo.ensure(2);
+    partials.ensure((size_t)ntiles * std::max<size_t>(fluids.size(), 1), stream, false, 1.5f);
+    // every tile wastes less than one 64-particle slice
+    const uint32_t ns_cap = n / WAVE + ntiles + 1;
+    slice_w_ff.ensure(ns_cap + 1, stream, false, 1.25f); slice_w_fb.ensure(ns_cap + 1, stream, false, 1.25f);
+    slice_ff.ensure(ns_cap + 1, stream, false, 1.25f); slice_fb.ensure(ns_cap + 1, stream, false, 1.25f);
 
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
     {
-        GridView gv{gf.o[0], gf.o[1], gf.o[2], gf.d[0], gf.d[1], gf.d[2], nullptr};
+        TileGrid gv{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], nullptr};
         launch_cell_keys(posm[cur].p, n, sc.h, gv, keys[0].p, idx[0].p, d_flags.p, stream);
         const int end_bit = bits_for(ncf);
         const size_t tb = sort_pairs_temp_bytes(n, end_bit);
@@ -607,23 +613,33 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     }
     build_boundary_grid();  // insert_boundaries_to_grid (liquid_world.rs:106) + boundary volumes, only when dirty
 
-    // ---- neighbour lists   (compute_contacts, contacts.rs:154-252)
+    // ---- tile table: slices per tile, largest halo (sizes the LDS staging area of every tile kernel)
     StepCtx c = make_ctx();
-    SALVA_HIP_CHECK(hipMemsetAsync(d_counters.p, 0, 2 * sizeof(unsigned long long), stream));
-    SALVA_HIP_CHECK(hipMemsetAsync(slice_w.p + nslices, 0, sizeof(uint64_t), stream));
     {
-        const size_t tb = scan_temp_bytes(nslices + 1);
+        const size_t tb = scan_temp_bytes(std::max<uint32_t>(ns_cap + 1, ntiles + 1));
         ensure_cub_temp(tb);
-        launch_nbr_count(c, false, nff.p, slice_w.p, d_counters.p + 0, stream);
-        scan_u64(cub_temp.p, tb, slice_w.p, slice_ff.p, nslices + 1, stream);
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nbr_total_ff, slice_ff.p + nslices, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        if (nb) {
-            launch_nbr_count(c, true, nfb.p, slice_w.p, d_counters.p + 1, stream);
-            scan_u64(cub_temp.p, tb, slice_w.p, slice_fb.p, nslices + 1, stream);
-            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nbr_total_fb, slice_fb.p + nslices, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        } else {
-            h_rb->nbr_total_fb = 0;
-        }
+        SALVA_HIP_CHECK(hipMemsetAsync(d_maxhalo.p, 0, 2 * sizeof(uint32_t), stream));
+        SALVA_HIP_CHECK(hipMemsetAsync(tile_nsl.p + ntiles, 0, sizeof(uint32_t), stream));
+        launch_tile_info(c, tile_nsl.p, d_maxhalo.p, stream);
+        scan_u32(cub_temp.p, tb, tile_nsl.p, tile_slice_base.p, ntiles + 1, stream);
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->max_halo_fluid, d_maxhalo.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nslices, tile_slice_base.p + ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        lds.max_halo_fluid = h_rb->max_halo_fluid;
+        lds.max_halo_boundary = h_rb->max_halo_boundary;
+        if (lds.max_halo_fluid >= 65536u || lds.max_halo_boundary >= 65536u)
+            throw HipError(SALVA_HIP_E_CAPACITY, "more than 65535 particles in one tile halo");
+        if (h_rb->nslices > ns_cap) throw HipError(SALVA_HIP_E_HIP, "internal error: slice count exceeds its bound");
+
+        // ---- neighbour lists   (compute_contacts, contacts.rs:154-252)
+        SALVA_HIP_CHECK(hipMemsetAsync(d_counters.p, 0, 2 * sizeof(unsigned long long), stream));
+        SALVA_HIP_CHECK(hipMemsetAsync(slice_w_ff.p, 0, (size_t)(ns_cap + 1) * sizeof(uint64_t), stream));
+        SALVA_HIP_CHECK(hipMemsetAsync(slice_w_fb.p, 0, (size_t)(ns_cap + 1) * sizeof(uint64_t), stream));
+        launch_nbr_count(c, lds, slice_w_ff.p, slice_w_fb.p, d_counters.p, stream);
+        scan_u64(cub_temp.p, tb, slice_w_ff.p, slice_ff.p, ns_cap + 1, stream);
+        scan_u64(cub_temp.p, tb, slice_w_fb.p, slice_fb.p, ns_cap + 1, stream);
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nbr_total_ff, slice_ff.p + ns_cap, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nbr_total_fb, slice_fb.p + ns_cap, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
         SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, d_counters.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
         SALVA_HIP_CHECK(hipStreamSynchronize(stream));
         if (h_rb->nbr_total_ff >= (1ull << 40) || h_rb->nbr_total_fb >= (1ull << 40))
@@ -631,14 +647,13 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         const bool r1 = nbr_ff.ensure(h_rb->nbr_total_ff ? h_rb->nbr_total_ff : 1, stream, false, 1.2f);
         const bool r2 = nbr_fb.ensure(h_rb->nbr_total_fb ? h_rb->nbr_total_fb : 1, stream, false, 1.2f);
         if (r1 || r2) c = make_ctx();
-        launch_nbr_fill(c, false, slice_ff.p, nbr_ff.p, stream);
-        if (nb) launch_nbr_fill(c, true, slice_fb.p, nbr_fb.p, stream);
+        launch_nbr_fill(c, lds, nbr_ff.p, nbr_fb.p, stream);
     }
     st.ncontacts = h_rb->ncontacts_ff + (nb ? h_rb->ncontacts_fb : 0) + ncontacts_bb;
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
 
     // ---- solver   (evaluate_kernels + compute_densities + solver.step, liquid_world.rs:123-144)
-    launch_density_alpha(c, stream);
+    launch_density_alpha(c, lds, stream);
     if (prm.solver == SALVA_HIP_SOLVER_DFSPH) dfsph_solve(c, dt, g, st);
     else iisph_solve(c, dt, g, st);
     acc_user = false;
@@ -787,7 +802,7 @@ uint64_t World::device_bytes() const {
     }
     add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes());
     add(rho.bytes()); add(alpha.bytes()); add(kappa.bytes()); add(kappa2.bytes()); add(rho_star.bytes()); add(aii.bytes());
-    add(nff.bytes()); add(nfb.bytes()); add(cell_start_f.bytes()); add(slice_w.bytes()); add(slice_ff.bytes());
+    add(nff.bytes()); add(nfb.bytes()); add(cell_start_f.bytes()); add(slice_w_ff.bytes()); add(slice_w_fb.bytes()); add(slice_ff.bytes());
     add(slice_fb.bytes()); add(nbr_ff.bytes()); add(nbr_fb.bytes()); add(cub_temp.bytes()); add(scratch_f.bytes());
     add(scratch_f4.bytes()); add(bst_pos.bytes()); add(bst_vel.bytes()); add(bposv.bytes()); add(bvel.bytes());
     add(bforce.bytes()); add(bperm.bytes()); add(cell_start_b.bytes()); add(partials.bytes());
@@ -800,9 +815,9 @@ float World::time_pred_density(int reps) {
     use_device();
     if (!have_last_ctx || !sorted_valid || n == 0) throw HipError(SALVA_HIP_E_INVALID, "no completed step to time");
     if (reps < 1) reps = 1;
-    launch_pred_density(last_ctx, last_dt, stream);  // warm-up
+    launch_pred_density(last_ctx, lds, last_dt, stream);  // warm-up
     SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
-    for (int r = 0; r < reps; ++r) launch_pred_density(last_ctx, last_dt, stream);
+    for (int r = 0; r < reps; ++r) launch_pred_density(last_ctx, lds, last_dt, stream);
     SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
     SALVA_HIP_CHECK(hipStreamSynchronize(stream));
     float ms = 0.0f;
