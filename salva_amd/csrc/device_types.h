@@ -31,6 +31,18 @@ struct TileGrid {
     const uint32_t* cell_start;
 };
 
+// per-tile sizes, prefix-summed over tiles in one scan
+struct TileAcc {
+    uint64_t s;     // fluid halo slots
+    uint64_t sb;    // boundary halo slots
+    uint32_t nsl;   // 64-particle slices
+    uint32_t max_s, max_sb, max_nsl;  // running maxima of the three (carried through the same scan)
+    __host__ __device__ TileAcc operator+(const TileAcc& o) const {
+        return TileAcc{s + o.s, sb + o.sb, nsl + o.nsl, max_s > o.max_s ? max_s : o.max_s,
+                       max_sb > o.max_sb ? max_sb : o.max_sb, max_nsl > o.max_nsl ? max_nsl : o.max_nsl};
+    }
+};
+
 struct StepCtx {
     SphConsts sc;
     int xcd;  // XCD-aware block remap on/off
@@ -59,7 +71,9 @@ struct StepCtx {
     const uint32_t* nbr_ff;     // packed 16-bit halo slots
     const uint64_t* slice_fb;
     const uint32_t* nbr_fb;
-    const uint32_t* tile_slice_base;  // [ntiles+1] first global slice of each tile
+    const TileAcc* tile_off;    // [ntiles+1] exclusive prefix of per-tile {halo slots, boundary halo slots, slices}
+    const uint32_t* halo_src;   // sorted fluid index of every halo slot of every tile (tile-major)
+    const uint32_t* bhalo_src;  // sorted boundary index of every boundary halo slot
     uint32_t ntiles;
     TileGrid gf;
 
@@ -92,7 +106,7 @@ struct Readback {
     int32_t bbox[6];      // fluid cell bbox (min xyz, max xyz)
     int32_t bbbox[6];     // boundary cell bbox
     uint64_t nbr_total_ff, nbr_total_fb;  // padded sliced-ELL sizes (dwords)
-    uint32_t max_halo_fluid, max_halo_boundary, nslices, pad;  // tile statistics of the current step
+    TileAcc tile_total;   // totals and maxima of halo slots / boundary halo slots / slices over the tiles
     uint64_t ncontacts_ff, ncontacts_fb, ncontacts_bb;
 };
 

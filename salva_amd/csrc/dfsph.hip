@@ -15,25 +15,30 @@ namespace salva {
 
 unsigned num_blocks(uint32_t n) { return div_up(n, BLOCK); }
 
+// staged neighbour records (LDS -> registers)
+struct RecPW { float4 p, w; };   // position+mass, v+dv
+struct RecPK { float4 p; float k; };  // position+mass, kappa
+
 // ------------------------------------------------------------------------------------------------
 // compute_densities (dfsph_solver.rs:628-665) fused with compute_alphas (:165-216): both depend on positions only.
 //   rho_i   = sum_j m_j W_ij + sum_b V_b rho0_i W_ib
 //   alpha_i = 1 / (sum |m_j grad W_ij|^2 + |sum m_j grad W_ij|^2), 0 if the denominator <= 1e-5
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TILE_THREADS) void k_density_alpha(StepCtx c) {
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* Lp = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), Lp);
+    const float4* Bp = nullptr;
+    t.stage_boundary(c, Bp);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
         const float4 pi = c.posm[i];
         const float rho0 = c.rho0_tab[c.model[i]];
         float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f;
-        for_each_ff(c, i, gs, [&](uint32_t s) {
-            const float4 pj = Lp[s];
+        for_each_ff(c, i, gs, [&](uint32_t s) { return Lp[s]; }, [&](const float4& pj) {
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
             rho += pj.w * e.w;
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_density_alpha(StepCtx c) {
     });
 }
 void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_density_alpha, c, L.bytes(16, 16, 2), s, c);
+    SALVA_LAUNCH_TILE(k_density_alpha, c, L, L.bytes(16, 16, 2), s, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -68,14 +73,16 @@ void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s) {
 // skipped (0) when the particle has fewer than 20 contacts; stores kappa_i = D rho_i * alpha_i (the only use of
 // the divergence, :370,:382) and the per-particle error D rho_i / rho0.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TILE_THREADS) void k_divergence(StepCtx c) {
-    __shared__ float errtab[TILE_WAVES][MAX_MODELS];
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
+    __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
     Tile t;
     t.setup(c);
     if (t.empty()) { TileErr::zero(c, t.tile); return; }
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float4* __restrict__ Lw = t.stage(c.w);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* Lp = nullptr;
+    const float4* Lw = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), Lp, Lw);
+    const float4* Bp = nullptr;
+    t.stage_boundary(c, Bp);
     TileErr E;
     E.init(errtab, c);
     __syncthreads();
@@ -90,9 +97,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_divergence(StepCtx c) {
             if (ncontacts >= c.min_neighbors_for_divergence) {
                 const float4 pi = c.posm[i];
                 const float4 wi = c.w[i];
-                for_each_ff(c, i, gs, [&](uint32_t s) {
-                    const float4 pj = Lp[s];
-                    const float4 wj = Lw[s];
+                for_each_ff(c, i, gs, [&](uint32_t s) { return RecPW{Lp[s], Lw[s]}; }, [&](const RecPW& r) {
+                    const float4 pj = r.p, wj = r.w;
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                     const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
                     div += ((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g * pj.w;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_divergence(StepCtx c) {
     E.finish(c, t.tile);
 }
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_divergence, c, L.bytes(32, 16, 3), s, c);
+    SALVA_LAUNCH_TILE(k_divergence, c, L, L.bytes(32, 16, 3), s, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -121,14 +127,16 @@ void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
 //                                                           + sum_b grad W_ib (-k_i V_b rho0), boundary reaction force.
 // Also refreshes w_i = v_i + dv_i for the next evaluate pass.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TILE_THREADS) void k_divergence_apply(StepCtx c, float inv_dt_prev) {
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c, float inv_dt_prev) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float* __restrict__ Lk = t.stage(c.kappa);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
-    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    const float4* Lp = nullptr;
+    const float* Lk = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), Lp, Lk);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    t.stage_boundary(c, Bp, Bv);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
@@ -137,9 +145,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_divergence_apply(StepCtx c, fl
         const float rho0 = c.rho0_tab[mi];
         const float ki = c.kappa[i];
         float4 d = c.dv[i];
-        for_each_ff(c, i, gs, [&](uint32_t s) {
-            const float4 pj = Lp[s];
-            const float kj = Lk[s];
+        for_each_ff(c, i, gs, [&](uint32_t s) { return RecPK{Lp[s], Lk[s]}; }, [&](const RecPK& r) {
+            const float4 pj = r.p;
+            const float kj = r.k;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
             const float coeff = -(ki + kj) * pj.w * g;
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_divergence_apply(StepCtx c, fl
             d.x += ex; d.y += ey; d.z += ez;
             if (c.bforce) {
                 const float fs = -inv_dt_prev * pi.w;  // delta * (-inv_dt * particle_mass) :404-406
-                apply_boundary_force(c, boundary_global_of_slot(t, s), __float_as_uint(Bv[s].w), ex * fs, ey * fs, ez * fs);
+                apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), ex * fs, ey * fs, ez * fs);
             }
         });
         c.dv[i] = d;
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_divergence_apply(StepCtx c, fl
     });
 }
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_divergence_apply, c, L.bytes(20, 32, 4), s, c, inv_dt_prev);
+    SALVA_LAUNCH_TILE(k_divergence_apply, c, L, L.bytes(20, 32, 4), s, c, inv_dt_prev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -210,15 +218,17 @@ void launch_integrate(const StepCtx& c, float dt, hipStream_t s) {
 // error_i = max(rho*_i / rho0 - 1, 0); stores kappa_i = (rho*_i - rho0) alpha_i (:234,:245).
 // This is THE representative neighbour-sum kernel of the roofline: N (4K + 52) bytes per launch.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TILE_THREADS) void k_pred_density(StepCtx c, float dt) {
-    __shared__ float errtab[TILE_WAVES][MAX_MODELS];
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, float dt) {
+    __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
     Tile t;
     t.setup(c);
     if (t.empty()) { TileErr::zero(c, t.tile); return; }
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float4* __restrict__ Lw = t.stage(c.w);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
-    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    const float4* Lp = nullptr;
+    const float4* Lw = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), Lp, Lw);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    t.stage_boundary(c, Bp, Bv);
     TileErr E;
     E.init(errtab, c);
     __syncthreads();
@@ -231,9 +241,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_pred_density(StepCtx c, float 
             const float4 pi = c.posm[i];
             const float4 wi = c.w[i];
             float delta = 0.0f;
-            for_each_ff(c, i, gs, [&](uint32_t s) {
-                const float4 pj = Lp[s];
-                const float4 wj = Lw[s];
+            for_each_ff(c, i, gs, [&](uint32_t s) { return RecPW{Lp[s], Lw[s]}; }, [&](const RecPW& r) {
+                const float4 pj = r.p, wj = r.w;
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
                 delta += pj.w * (((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g);
@@ -255,21 +264,23 @@ __global__ __launch_bounds__(TILE_THREADS) void k_pred_density(StepCtx c, float 
     E.finish(c, t.tile);
 }
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_pred_density, c, L.bytes(32, 32, 4), s, c, dt);
+    SALVA_LAUNCH_TILE(k_pred_density, c, L, L.bytes(32, 32, 4), s, c, dt);
 }
 
 // ------------------------------------------------------------------------------------------------
 // compute_velocity_changes (:218-277): k_ij = max(k_i,0) + max(k_j,0); if k_ij > 0: dv_i -= grad W_ij k_ij m_j / dt.
 // Boundary term only when k_i > 0, with the reaction force delta * (inv_dt * m_i).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TILE_THREADS) void k_pressure_apply(StepCtx c, float inv_dt) {
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, float inv_dt) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float* __restrict__ Lk = t.stage(c.kappa);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
-    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    const float4* Lp = nullptr;
+    const float* Lk = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), Lp, Lk);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    t.stage_boundary(c, Bp, Bv);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
@@ -279,10 +290,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_pressure_apply(StepCtx c, floa
         const float ki = c.kappa[i];
         const float kip = fmaxf(ki, 0.0f);
         float4 d = c.dv[i];
-        for_each_ff(c, i, gs, [&](uint32_t s) {
+        for_each_ff(c, i, gs, [&](uint32_t s) { return RecPK{Lp[s], Lk[s]}; }, [&](const RecPK& r) {
             // k_ij == 0 contributes exactly nothing, so no branch is needed
-            const float4 pj = Lp[s];
-            const float kij = kip + fmaxf(Lk[s], 0.0f);
+            const float4 pj = r.p;
+            const float kij = kip + fmaxf(r.k, 0.0f);
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
             const float coeff = kij * pj.w * inv_dt * g;
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_pressure_apply(StepCtx c, floa
                 d.x -= ex; d.y -= ey; d.z -= ez;
                 if (c.bforce) {
                     const float fs = inv_dt * pi.w;
-                    apply_boundary_force(c, boundary_global_of_slot(t, s), __float_as_uint(Bv[s].w), ex * fs, ey * fs, ez * fs);
+                    apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), ex * fs, ey * fs, ez * fs);
                 }
             });
         }
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_pressure_apply(StepCtx c, floa
     });
 }
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_pressure_apply, c, L.bytes(20, 32, 4), s, c, inv_dt);
+    SALVA_LAUNCH_TILE(k_pressure_apply, c, L, L.bytes(20, 32, 4), s, c, inv_dt);
 }
 
 // ------------------------------------------------------------------------------------------------

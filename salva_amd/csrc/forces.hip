@@ -16,15 +16,17 @@ namespace salva {
 // ------------------------------------------------------------------------------------------------ XSPH
 // a_i += inv_dt * [ sum_j (v_j - v_i) c_f W_ij m_j / rho_j  +  sum_b (v_b - v_i) c_b W_ib V_b rho0 / rho_i ]
 // inv_dt is the *previous* substep's (timestep.advance happens after predict_advection, dfsph_solver.rs:693-702).
-__global__ __launch_bounds__(TILE_THREADS) void k_xsph(StepCtx c, uint32_t model, float fc, float bc, float inv_dt) {
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t model, float fc, float bc, float inv_dt) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float4* __restrict__ Lw = t.stage(c.w);
-    const float* __restrict__ Lr = t.stage(c.rho);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
-    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    const float4* Lp = nullptr;
+    const float4* Lw = nullptr;
+    const float* Lr = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), static_cast<const float*>(c.rho), Lp, Lw, Lr);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    t.stage_boundary(c, Bp, Bv);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
@@ -33,10 +35,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_xsph(StepCtx c, uint32_t model
         const float rho0 = c.rho0_tab[model];
         float fx = 0.f, fy = 0.f, fz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
         if (fc != 0.0f) {
-            for_each_ff(c, i, gs, [&](uint32_t s) {
-                const float4 pj = Lp[s];
-                const float4 vj = Lw[s];
-                const float rj = Lr[s];
+            struct Rec { float4 p, w; float r; };
+            for_each_ff(c, i, gs, [&](uint32_t s) { return Rec{Lp[s], Lw[s], Lr[s]}; }, [&](const Rec& rc) {
+                const float4 pj = rc.p, vj = rc.w;
+                const float rj = rc.r;
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
                 const float sc = (__float_as_uint(vj.w) == model) ? fc * wgt * pj.w / rj : 0.0f;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_xsph(StepCtx c, uint32_t model
                 bx += ex; by += ey; bz += ez;
                 if (c.bforce) {
                     const float fs = -pi.w * inv_dt;  // delta * (-mi * inv_dt) :88-89
-                    apply_boundary_force(c, boundary_global_of_slot(t, s), __float_as_uint(vj.w), ex * fs, ey * fs, ez * fs);
+                    apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(vj.w), ex * fs, ey * fs, ez * fs);
                 }
             });
         }
@@ -68,22 +70,24 @@ __global__ __launch_bounds__(TILE_THREADS) void k_xsph(StepCtx c, uint32_t model
 }
 void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff,
                  float inv_dt_prev, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_xsph, c, L.bytes(36, 32, 5), s, c, model, fluid_coeff, boundary_coeff, inv_dt_prev);
+    SALVA_LAUNCH_TILE(k_xsph, c, L, L.bytes(36, 32, 5), s, c, model, fluid_coeff, boundary_coeff, inv_dt_prev);
 }
 
 // ------------------------------------------------------------------------------------------------ Monaghan artificial viscosity
 // approaching pairs only (r.v < 0): mu = h r.v / (r^2 + 0.01 h^2);
 // a_i += grad W_ij c_f (c_s alpha mu - beta mu^2) m_j / ((rho_i + rho_j)/2)
-__global__ __launch_bounds__(TILE_THREADS) void k_artificial_viscosity(StepCtx c, uint32_t model, float fc, float bc,
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_artificial_viscosity(StepCtx c, uint32_t model, float fc, float bc,
                                                                       float alpha, float beta, float cs) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float4* __restrict__ Lw = t.stage(c.w);
-    const float* __restrict__ Lr = t.stage(c.rho);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
-    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    const float4* Lp = nullptr;
+    const float4* Lw = nullptr;
+    const float* Lr = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), static_cast<const float*>(c.rho), Lp, Lw, Lr);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    t.stage_boundary(c, Bp, Bv);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_artificial_viscosity(StepCtx c
                     bx += dx * sc; by += dy * sc; bz += dz * sc;
                     // the reference applies the *running sum* of the boundary acceleration here (:117)
                     if (c.bforce)
-                        apply_boundary_force(c, boundary_global_of_slot(t, s), __float_as_uint(vj.w), bx * -pi.w, by * -pi.w, bz * -pi.w);
+                        apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(vj.w), bx * -pi.w, by * -pi.w, bz * -pi.w);
                 }
             });
         }
@@ -135,19 +139,21 @@ __global__ __launch_bounds__(TILE_THREADS) void k_artificial_viscosity(StepCtx c
 }
 void launch_artificial_viscosity(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff,
                                  float boundary_coeff, float alpha, float beta, float speed_of_sound, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_artificial_viscosity, c, L.bytes(36, 32, 5), s, c, model, fluid_coeff, boundary_coeff, alpha, beta,
+    SALVA_LAUNCH_TILE(k_artificial_viscosity, c, L, L.bytes(36, 32, 5), s, c, model, fluid_coeff, boundary_coeff, alpha, beta,
                       speed_of_sound);
 }
 
 // ------------------------------------------------------------------------------------------------ Akinci 2013
 // pass 1 (compute_normals :43-68): n_i = h sum_{j same fluid} (m_j / rho_j) grad W_ij
-__global__ __launch_bounds__(TILE_THREADS) void k_akinci_normals(StepCtx c, uint32_t model) {
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_normals(StepCtx c, uint32_t model) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float* __restrict__ Lr = t.stage(c.rho);
-    const uint32_t* __restrict__ Lm = (c.nmodels > 1) ? t.stage(c.model) : nullptr;
+    const float4* Lp = nullptr;
+    const float* Lr = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), Lp, Lr);
+    const uint32_t* Lm = nullptr;
+    if (c.nmodels > 1) t.stage(c, static_cast<const uint32_t*>(c.model), Lm);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_akinci_normals(StepCtx c, uint
     });
 }
 void launch_akinci_normals(const StepCtx& c, const TileLds& L, uint32_t model, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_akinci_normals, c, L.bytes(24, 0, 3), s, c, model);
+    SALVA_LAUNCH_TILE(k_akinci_normals, c, L, L.bytes(24, 0, 3), s, c, model);
 }
 
 // cohesion_kernel :71-88 — C(r) = 32/(pi h^9) * { 2 (h-r)^3 r^3 - h^6/64 | r <= h/2 ; (h-r)^3 r^3 | r <= h ; 0 }
@@ -186,17 +192,20 @@ __device__ __forceinline__ float adhesion_kernel(float r, float h, float norm) {
 }
 
 // pass 2 (solve :114-192): cohesion + curvature between same-fluid particles, adhesion with boundaries.
-__global__ __launch_bounds__(TILE_THREADS) void k_akinci_forces(StepCtx c, uint32_t model, float tc, float ac, float cnorm,
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, uint32_t model, float tc, float ac, float cnorm,
                                                                float h6_64, float anorm) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float4* __restrict__ Ln = t.stage(c.normal);
-    const float* __restrict__ Lr = t.stage(c.rho);
-    const uint32_t* __restrict__ Lm = (c.nmodels > 1) ? t.stage(c.model) : nullptr;
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
-    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    const float4* Lp = nullptr;
+    const float4* Ln = nullptr;
+    const float* Lr = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.normal), static_cast<const float*>(c.rho), Lp, Ln, Lr);
+    const uint32_t* Lm = nullptr;
+    if (c.nmodels > 1) t.stage(c, static_cast<const uint32_t*>(c.model), Lm);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    t.stage_boundary(c, Bp, Bv);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_akinci_forces(StepCtx c, uint3
                 const float ex = dx * sc, ey = dy * sc, ez = dz * sc;
                 a.x -= ex; a.y -= ey; a.z -= ez;
                 if (c.bforce)
-                    apply_boundary_force(c, boundary_global_of_slot(t, s), __float_as_uint(Bv[s].w), ex * pi.w, ey * pi.w, ez * pi.w);
+                    apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), ex * pi.w, ey * pi.w, ez * pi.w);
             });
         }
         c.acc[i] = a;
@@ -252,7 +261,7 @@ void launch_akinci_forces(const StepCtx& c, const TileLds& L, uint32_t model, fl
     const float cnorm = (float)(32.0 / (3.14159265358979323846 * pow(h, 9)));
     const float h6_64 = (float)(pow(h, 6) / 64.0);
     const float anorm = (float)(0.007 / pow(h, 3.25));
-    SALVA_LAUNCH_TILE(k_akinci_forces, c, L.bytes(40, 32, 6), s, c, model, tension, adhesion, cnorm, h6_64, anorm);
+    SALVA_LAUNCH_TILE(k_akinci_forces, c, L, L.bytes(40, 32, 6), s, c, model, tension, adhesion, cnorm, h6_64, anorm);
 }
 
 }  // namespace salva

@@ -224,40 +224,57 @@ void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4
     if (n) k_gather_f4<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, perm, in, out);
 }
 
-// ------------------------------------------------------------------------------------------------ tile statistics
-// One thread per tile: number of 64-particle slices of the tile, and the size of its halo (fluid / boundary
-// particles in the 6x6x4 cell box) whose maxima size the LDS staging area of every tile kernel of this step.
-__global__ __launch_bounds__(BLOCK) void k_tile_info(StepCtx c, uint32_t* __restrict__ tile_nsl, uint32_t* max_halo /*[2]*/) {
-    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
-    uint32_t hf = 0, hb = 0;
-    if (t < c.ntiles) {
-        const TileGrid& g = c.gf;
-        const uint32_t own = g.cell_start[(size_t)t * TCELLS + TCELLS] - g.cell_start[(size_t)t * TCELLS];
-        tile_nsl[t] = (own + WAVE - 1) / WAVE;
-        if (own) {
-            const int ttz = t % g.ntz, tty = (t / g.ntz) % g.nty, ttx = t / (g.ntz * g.nty);
-            const int hcx = g.ox + ttx * TX - 1, hcy = g.oy + tty * TY - 1, hcz = g.oz + ttz * TZ - 1;
-            for (int h = 0; h < HCELLS; ++h) {
-                const int hz = h % HZ, hy = (h / HZ) % HY, hx = h / (HZ * HY);
-                bool in;
-                const uint32_t k = tile_key(g, hcx + hx, hcy + hy, hcz + hz, in);
-                if (in) hf += g.cell_start[k + 1] - g.cell_start[k];
-                if (c.nb) {
-                    const uint32_t kb = tile_key(c.gb, hcx + hx, hcy + hy, hcz + hz, in);
-                    if (in) hb += c.gb.cell_start[kb + 1] - c.gb.cell_start[kb];
-                }
-            }
+// ------------------------------------------------------------------------------------------------ tile tables
+// One workgroup per tile.  k_tile_count: halo sizes (fluid / boundary particles in the 6x6x4 cell box) and number
+// of 64-particle slices of the tile -> tile_cnt[tile], plus their maxima (which size the LDS staging area and the
+// workgroup of every tile kernel of this step).  After an exclusive scan, k_tile_halo_fill writes the flat slot
+// tables: halo_src[tile_off[tile].s + slot] = sorted index of the particle staged in that slot.
+constexpr int TABLE_THREADS = 192;  // >= HCELLS
+
+__global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc* __restrict__ tile_cnt) {
+    Tile t;
+    t.setup_geom(c);
+    TileAcc a{0, 0, 0, 0, 0, 0};
+    if (!t.empty()) {
+        TileCells tc;
+        tc.build(c, t);
+        a.s = tc.lstart[HCELLS];
+        a.sb = tc.blstart[HCELLS];
+        a.nsl = (t.own_end - t.own_begin + WAVE - 1) / WAVE;
+        a.max_s = (uint32_t)a.s; a.max_sb = (uint32_t)a.sb; a.max_nsl = a.nsl;
+    }
+    if (threadIdx.x == 0) tile_cnt[t.tile] = a;
+}
+__global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uint32_t* __restrict__ halo_src,
+                                                                 uint32_t* __restrict__ bhalo_src) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    TileCells tc;
+    tc.build(c, t);
+    const int sub = threadIdx.x % 16, grp = threadIdx.x / 16;
+    for (int h = grp; h < HCELLS; h += TABLE_THREADS / 16) {
+        const uint32_t l0 = tc.lstart[h], cnt = tc.lstart[h + 1] - l0, g0 = tc.gstart[h];
+        for (uint32_t k = sub; k < cnt; k += 16) halo_src[t.hoff + l0 + k] = g0 + k;
+        if (t.SB) {
+            const uint32_t bl0 = tc.blstart[h], bcnt = tc.blstart[h + 1] - bl0, bg0 = tc.bgstart[h];
+            for (uint32_t k = sub; k < bcnt; k += 16) bhalo_src[t.hboff + bl0 + k] = bg0 + k;
         }
     }
-    hf = wave_max_u32(hf);
-    hb = wave_max_u32(hb);
-    if ((threadIdx.x & (WAVE - 1)) == 0) {
-        if (hf) atomicMax(&max_halo[0], hf);
-        if (hb) atomicMax(&max_halo[1], hb);
-    }
 }
-void launch_tile_info(const StepCtx& c, uint32_t* tile_nsl, uint32_t* max_halo2, hipStream_t s) {
-    k_tile_info<<<div_up(c.ntiles, BLOCK), BLOCK, 0, s>>>(c, tile_nsl, max_halo2);
+void launch_tile_count(const StepCtx& c, TileAcc* tile_cnt, hipStream_t s) {
+    k_tile_count<<<c.ntiles, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, tile_cnt);
+}
+void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, hipStream_t s) {
+    k_tile_halo_fill<<<c.ntiles, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, halo_src, bhalo_src);
+}
+size_t scan_tiles_temp_bytes(uint32_t n) {
+    size_t b = 0;
+    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0}, (int)n);
+    return b;
+}
+void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s) {
+    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0}, (int)n, s));
 }
 
 // ------------------------------------------------------------------------------------------------ neighbour lists
@@ -265,18 +282,22 @@ void launch_tile_info(const StepCtx& c, uint32_t* tile_nsl, uint32_t* max_halo2,
 // :378-383) contacts of the tile's own particles -> nff / nfb and the slice widths.  FILL=true: write the halo slots
 // of the accepted candidates, in traversal order (9 rows of 3 z-adjacent halo cells), two 16-bit slots per dword.
 template <bool FILL>
-__global__ __launch_bounds__(TILE_THREADS) void k_nbr_tile(StepCtx c, uint64_t* __restrict__ slice_w_ff,
-                                                           uint64_t* __restrict__ slice_w_fb, uint32_t* __restrict__ nbr_ff,
-                                                           uint32_t* __restrict__ nbr_fb, unsigned long long* ncontacts) {
-    __shared__ float red[TILE_WAVES];
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, uint64_t* __restrict__ slice_w_ff,
+                                                               uint64_t* __restrict__ slice_w_fb, uint32_t* __restrict__ nbr_ff,
+                                                               uint32_t* __restrict__ nbr_fb, unsigned long long* ncontacts) {
+    __shared__ float red[TILE_MAX_WAVES];
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
+    TileCells tc;
+    tc.build(c, t);
     const bool multi = c.nmodels > 1;
-    const uint32_t* __restrict__ Lm = multi ? t.stage(c.model) : nullptr;
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
-    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    float4* Lp = t.carve<float4>(t.S);
+    uint32_t* Lm = multi ? t.carve<uint32_t>(t.S) : nullptr;
+    float4* Bp = t.carve<float4>(t.SB);
+    float4* Bv = t.carve<float4>(t.SB);
+    t.for_halo(c, [&](uint32_t s, uint32_t g) { Lp[s] = c.posm[g]; if (multi) Lm[s] = c.model[g]; });
+    t.for_halo_boundary(c, [&](uint32_t s, uint32_t g) { Bp[s] = c.bposv[g]; Bv[s] = c.bvel[g]; });
     __syncthreads();
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     float total_ff = 0.0f, total_fb = 0.0f;
@@ -296,7 +317,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nbr_tile(StepCtx c, uint64_t* 
 #pragma unroll 1
                 for (int dy = -1; dy <= 1; ++dy) {
                     const int row = ((lx + dx) * HY + (ly + dy)) * HZ + (lz - 1);
-                    const uint32_t b = t.lstart[row], e = t.lstart[row + 3];
+                    const uint32_t b = tc.lstart[row], e = tc.lstart[row + 3];
                     for (uint32_t s = b; s < e; ++s) {
                         const float4 pj = Lp[s];
                         const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nbr_tile(StepCtx c, uint64_t* 
                         }
                     }
                     if (t.SB) {
-                        const uint32_t bb = t.blstart[row], be = t.blstart[row + 3];
+                        const uint32_t bb = tc.blstart[row], be = tc.blstart[row + 3];
                         for (uint32_t s = bb; s < be; ++s) {
                             const float4 pj = Bp[s];
                             const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
@@ -354,10 +375,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nbr_tile(StepCtx c, uint64_t* 
 
 void launch_nbr_count(const StepCtx& c, const TileLds& L, uint64_t* slice_w_ff, uint64_t* slice_w_fb,
                       unsigned long long* ncontacts2, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_nbr_tile<false>, c, L.bytes(20, 32, 4), s, c, slice_w_ff, slice_w_fb, nullptr, nullptr, ncontacts2);
+    SALVA_LAUNCH_TILE(k_nbr_tile<false>, c, L, L.bytes(20, 32, 4, true), s, c, slice_w_ff, slice_w_fb, nullptr, nullptr, ncontacts2);
 }
 void launch_nbr_fill(const StepCtx& c, const TileLds& L, uint32_t* nbr_ff, uint32_t* nbr_fb, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_nbr_tile<true>, c, L.bytes(20, 32, 4), s, c, nullptr, nullptr, nbr_ff, nbr_fb, nullptr);
+    SALVA_LAUNCH_TILE(k_nbr_tile<true>, c, L, L.bytes(20, 32, 4, true), s, c, nullptr, nullptr, nbr_ff, nbr_fb, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ boundary volumes

@@ -25,12 +25,14 @@ void launch_iisph_begin(const StepCtx& c, float gx, float gy, float gz, bool acc
 }
 
 // compute_dii (:144-186): d_ii = -dt^2 / rho_i^2 * sum_j m_j grad W_ij ; also p_i = 0.5 * p_i(previous step) (:673-677)
-__global__ __launch_bounds__(TILE_THREADS) void k_iisph_dii(StepCtx c, float dt) {
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dii(StepCtx c, float dt) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* Lp = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), Lp);
+    const float4* Bp = nullptr;
+    t.stage_boundary(c, Bp);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
@@ -56,18 +58,20 @@ __global__ __launch_bounds__(TILE_THREADS) void k_iisph_dii(StepCtx c, float dt)
     });
 }
 void launch_iisph_dii(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_iisph_dii, c, L.bytes(16, 16, 2), s, c, dt);
+    SALVA_LAUNCH_TILE(k_iisph_dii, c, L, L.bytes(16, 16, 2), s, c, dt);
 }
 
 // compute_predicted_densities (:92-142)
-__global__ __launch_bounds__(TILE_THREADS) void k_iisph_pred_density(StepCtx c, float dt) {
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_pred_density(StepCtx c, float dt) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float4* __restrict__ Lw = t.stage(c.w);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
-    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    const float4* Lp = nullptr;
+    const float4* Lw = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), Lp, Lw);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    t.stage_boundary(c, Bp, Bv);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
@@ -95,16 +99,18 @@ __global__ __launch_bounds__(TILE_THREADS) void k_iisph_pred_density(StepCtx c, 
     });
 }
 void launch_iisph_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_iisph_pred_density, c, L.bytes(32, 32, 4), s, c, dt);
+    SALVA_LAUNCH_TILE(k_iisph_pred_density, c, L, L.bytes(32, 32, 4), s, c, dt);
 }
 
 // compute_aii (:188-233): a_ii = sum_j m_j (d_ii - d_ji) . grad W_ij with d_ji = grad W_ij dt^2 m_i / rho_i^2
-__global__ __launch_bounds__(TILE_THREADS) void k_iisph_aii(StepCtx c, float dt) {
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_aii(StepCtx c, float dt) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* Lp = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), Lp);
+    const float4* Bp = nullptr;
+    t.stage_boundary(c, Bp);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
@@ -132,17 +138,18 @@ __global__ __launch_bounds__(TILE_THREADS) void k_iisph_aii(StepCtx c, float dt)
     });
 }
 void launch_iisph_aii(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_iisph_aii, c, L.bytes(16, 16, 2), s, c, dt);
+    SALVA_LAUNCH_TILE(k_iisph_aii, c, L, L.bytes(16, 16, 2), s, c, dt);
 }
 
 // compute_dij_pjl (:235-268): sum_j d_ij p_j = dt^2 sum_j grad W_ij (-m_j p_j / rho_j^2)   (fluid neighbours only)
-__global__ __launch_bounds__(TILE_THREADS) void k_iisph_dij_pj(StepCtx c, float dt, const float* __restrict__ p) {
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dij_pj(StepCtx c, float dt, const float* __restrict__ p) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float* __restrict__ Lr = t.stage(static_cast<const float*>(c.rho));
-    const float* __restrict__ Lq = t.stage(p);
+    const float4* Lp = nullptr;
+    const float* Lr = nullptr;
+    const float* Lq = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), static_cast<const float*>(p), Lp, Lr, Lq);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
@@ -161,21 +168,23 @@ __global__ __launch_bounds__(TILE_THREADS) void k_iisph_dij_pj(StepCtx c, float 
     });
 }
 void launch_iisph_dij_pj(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_iisph_dij_pj, c, L.bytes(24, 0, 3), s, c, dt, p);
+    SALVA_LAUNCH_TILE(k_iisph_dij_pj, c, L, L.bytes(24, 0, 3), s, c, dt, p);
 }
 
 // compute_next_pressures (:270-353)
-__global__ __launch_bounds__(TILE_THREADS) void k_iisph_next_pressure(StepCtx c, float dt, float omega,
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCtx c, float dt, float omega,
                                                                      const float* __restrict__ p, float* __restrict__ p_next) {
-    __shared__ float errtab[TILE_WAVES][MAX_MODELS];
+    __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
     Tile t;
     t.setup(c);
     if (t.empty()) { TileErr::zero(c, t.tile); return; }
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float4* __restrict__ Ld = t.stage(static_cast<const float4*>(c.dii));
-    const float4* __restrict__ Lj = t.stage(static_cast<const float4*>(c.dijpj));
-    const float* __restrict__ Lq = t.stage(p);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
+    const float4* Lp = nullptr;
+    const float4* Ld = nullptr;
+    const float4* Lj = nullptr;
+    const float* Lq = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.dii), static_cast<const float4*>(c.dijpj), static_cast<const float*>(p), Lp, Ld, Lj, Lq);
+    const float4* Bp = nullptr;
+    t.stage_boundary(c, Bp);
     TileErr E;
     E.init(errtab, c);
     __syncthreads();
@@ -227,19 +236,21 @@ __global__ __launch_bounds__(TILE_THREADS) void k_iisph_next_pressure(StepCtx c,
 }
 void launch_iisph_next_pressure(const StepCtx& c, const TileLds& L, float dt, float omega, const float* p, float* p_next,
                                 hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_iisph_next_pressure, c, L.bytes(52, 16, 5), s, c, dt, omega, p, p_next);
+    SALVA_LAUNCH_TILE(k_iisph_next_pressure, c, L, L.bytes(52, 16, 5), s, c, dt, omega, p, p_next);
 }
 
 // compute_velocity_changes (:355-404)
-__global__ __launch_bounds__(TILE_THREADS) void k_iisph_velocity_changes(StepCtx c, float dt, const float* __restrict__ p) {
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(StepCtx c, float dt, const float* __restrict__ p) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    const float4* __restrict__ Lp = t.stage(c.posm);
-    const float* __restrict__ Lr = t.stage(static_cast<const float*>(c.rho));
-    const float* __restrict__ Lq = t.stage(p);
-    const float4* __restrict__ Bp = t.stage_boundary(c.bposv);
-    const float4* __restrict__ Bv = t.stage_boundary(c.bvel);
+    const float4* Lp = nullptr;
+    const float* Lr = nullptr;
+    const float* Lq = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), static_cast<const float*>(p), Lp, Lr, Lq);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    t.stage_boundary(c, Bp, Bv);
     __syncthreads();
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
@@ -263,13 +274,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_iisph_velocity_changes(StepCtx
             const float ax = dx * sc, ay = dy * sc, az = dz * sc;
             d.x -= ax * dt; d.y -= ay * dt; d.z -= az * dt;
             if (c.bforce)
-                apply_boundary_force(c, boundary_global_of_slot(t, s), __float_as_uint(Bv[s].w), ax * pi.w, ay * pi.w, az * pi.w);
+                apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), ax * pi.w, ay * pi.w, az * pi.w);
         });
         c.dv[i] = d;
     });
 }
 void launch_iisph_velocity_changes(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_iisph_velocity_changes, c, L.bytes(24, 32, 5), s, c, dt, p);
+    SALVA_LAUNCH_TILE(k_iisph_velocity_changes, c, L, L.bytes(24, 32, 5), s, c, dt, p);
 }
 
 // update_velocities_and_positions (:406-420) + zero velocity changes (:707-709); stores the pressure for the

@@ -34,15 +34,18 @@ void launch_unsort_u32_as_f32(uint32_t n, const uint32_t* perm, const uint32_t* 
 void launch_unsort_f4(uint32_t n, const uint32_t* perm, const float4* in, float4* out, hipStream_t s);
 void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4* out, hipStream_t s);
 
-// per-tile slice counts (-> scan -> tile_slice_base) and the largest fluid / boundary halo of the step
-void launch_tile_info(const StepCtx& c, uint32_t* tile_nsl, uint32_t* max_halo2, hipStream_t s);
+// per-tile {halo slots, boundary halo slots, slices} (-> scan_tiles -> tile_off) and their maxima; then the flat
+// halo slot tables
+void launch_tile_count(const StepCtx& c, TileAcc* tile_cnt, hipStream_t s);
+void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, hipStream_t s);
+size_t scan_tiles_temp_bytes(uint32_t n);
+void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s);
 // neighbour lists (per-tile sliced ELL of 16-bit halo slots).  count: fills nff/nfb, slice widths (dwords), contact totals
 void launch_nbr_count(const StepCtx& c, const TileLds& L, uint64_t* slice_w_ff, uint64_t* slice_w_fb,
                       unsigned long long* ncontacts2, hipStream_t s);
 void launch_nbr_fill(const StepCtx& c, const TileLds& L, uint32_t* nbr_ff, uint32_t* nbr_fb, hipStream_t s);
 size_t scan_temp_bytes(uint32_t n);
 void scan_u64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t s);
-void scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint32_t n, hipStream_t s);
 
 // V_b = 1 / sum_b' W_bb' (dfsph_solver.rs:72-96); also counts boundary-boundary contacts
 void launch_boundary_volumes(const StepCtx& c, unsigned long long* ncontacts_bb, hipStream_t s);

@@ -21,21 +21,22 @@ constexpr int TX = 4, TY = 4, TZ = 2;                  // cells per tile
 constexpr int TCELLS = TX * TY * TZ;                   // 32
 constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;   // halo box
 constexpr int HCELLS = HX * HY * HZ;                   // 144
-constexpr int TILE_WAVES = 5;
-constexpr int TILE_THREADS = TILE_WAVES * WAVE;        // 320: a tile holds 256 (lattice) .. 320 (rest density) particles
-constexpr int STAGE_LANES = 16;                        // lanes that copy one halo cell (8-10 particles each)
+constexpr int TILE_MAX_WAVES = 8;                      // workgroup = one wave per 64-particle slice of the fullest tile,
+constexpr int TILE_MAX_THREADS = TILE_MAX_WAVES * WAVE; // clamped to [3, 8] waves (a tile holds 256 particles on the
+                                                       // 2r lattice, ~320 at rest density)
 
 __host__ __device__ inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-constexpr uint32_t TILE_TABLE_BYTES = 4 * (2 * (HCELLS + 1) + 2 * HCELLS);
-constexpr uint32_t TILE_TABLE_PAD = (TILE_TABLE_BYTES + 15u) & ~15u;
+constexpr uint32_t TILE_TABLE_BYTES = 4 * (2 * (HCELLS + 1) + 2 * HCELLS) + 16;
 
-// Dynamic-LDS budget of a tile kernel: halo tables + staged arrays sized for the largest halo of this step.
+// Launch geometry / dynamic-LDS budget of the tile kernels of one step: staged arrays are sized for the largest
+// halo, the workgroup for the fullest tile.
 struct TileLds {
-    uint32_t max_halo_fluid = 0, max_halo_boundary = 0;
-    uint32_t bytes(uint32_t bytes_per_fluid_slot, uint32_t bytes_per_boundary_slot, uint32_t narrays) const {
-        return TILE_TABLE_PAD + max_halo_fluid * bytes_per_fluid_slot + max_halo_boundary * bytes_per_boundary_slot +
-               16u * narrays;
+    uint32_t max_halo_fluid = 0, max_halo_boundary = 0, threads = 4 * WAVE;
+    uint32_t bytes(uint32_t bytes_per_fluid_slot, uint32_t bytes_per_boundary_slot, uint32_t narrays,
+                   bool with_cell_tables = false) const {
+        return (with_cell_tables ? TILE_TABLE_BYTES : 0u) + max_halo_fluid * bytes_per_fluid_slot +
+               max_halo_boundary * bytes_per_boundary_slot + 16u * narrays;
     }
 };
 
@@ -48,12 +49,12 @@ inline void ensure_tile_lds(K kernel, uint32_t bytes) {
     if (bytes > 48u * 1024u)
         SALVA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
-#define SALVA_LAUNCH_TILE(kernel, c, lds, s, ...)                          \
+#define SALVA_LAUNCH_TILE(kernel, c, L, lds, s, ...)                          \
     do {                                                                   \
         if ((c).n) {                                                       \
             const uint32_t _lds = (lds);                                   \
             ::salva::ensure_tile_lds(kernel, _lds);                        \
-            kernel<<<(c).ntiles, ::salva::TILE_THREADS, _lds, s>>>(__VA_ARGS__); \
+            kernel<<<(c).ntiles, (L).threads, _lds, s>>>(__VA_ARGS__);     \
         }                                                                  \
     } while (0)
 
@@ -76,46 +77,145 @@ __device__ __forceinline__ int cell_coord(float x, float h, bool& bad) {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
 
+// ---------------------------------------------------------------------------------------------------
+// Tile: what every tile kernel needs.  The halo of a tile (the particles of its 6x6x4 cell box, in halo-cell order)
+// is described once per step by k_tile_halo_fill as a flat table of sorted particle indices
+// (halo_src[halo_off[tile] + slot]); staging an array into LDS is then one coalesced index read plus one gather per
+// slot, all slots in flight at once.
+// ---------------------------------------------------------------------------------------------------
 struct Tile {
-    uint32_t* lstart;    // [HCELLS+1] first LDS slot of each fluid halo cell (h = (hx*HY + hy)*HZ + hz)
-    uint32_t* gstart;    // [HCELLS]   first global (sorted) index of each fluid halo cell
-    uint32_t* blstart;   // same for the boundary particles
-    uint32_t* bgstart;
-    unsigned char* pool; // staged arrays, 16-byte aligned
-    uint32_t S, SB;      // staged slot counts
-    uint32_t tile;       // logical tile index
-    uint32_t own_begin, own_end, slice_base;
-    int hcx, hcy, hcz;   // absolute cell coords of halo cell (0,0,0)
+    unsigned char* pool;  // staged arrays, 16-byte aligned
     uint32_t pool_used;
+    uint32_t S, SB;       // halo slot counts (fluid / boundary)
+    uint32_t tile;        // logical tile index
+    uint32_t own_begin, own_end, slice_base;
+    uint64_t hoff, hboff; // offsets of this tile's slot tables in halo_src / bhalo_src
+    int hcx, hcy, hcz;    // absolute cell coords of halo cell (0,0,0)
 
     __device__ __forceinline__ bool empty() const { return own_begin == own_end; }
 
-    // Every thread of the block must call.  Returns with the halo tables in LDS (synchronised).
-    __device__ __forceinline__ void setup(const StepCtx& c) {
-        uint32_t* t = reinterpret_cast<uint32_t*>(tile_smem);
-        lstart = t; gstart = t + (HCELLS + 1); blstart = gstart + HCELLS; bgstart = blstart + (HCELLS + 1);
-        pool = tile_smem + TILE_TABLE_PAD;
+    // geometry only (before the per-tile prefix table exists)
+    __device__ __forceinline__ void setup_geom(const StepCtx& c) {
+        pool = tile_smem;
         pool_used = 0;
         tile = xcd_block(blockIdx.x, gridDim.x, c.xcd);
         const TileGrid& g = c.gf;
         const uint32_t ttz = tile % g.ntz, tty = (tile / g.ntz) % g.nty, ttx = tile / (g.ntz * g.nty);
         own_begin = g.cell_start[(size_t)tile * TCELLS];
         own_end = g.cell_start[(size_t)tile * TCELLS + TCELLS];
-        slice_base = c.tile_slice_base[tile];
         hcx = g.ox + (int)ttx * TX - 1; hcy = g.oy + (int)tty * TY - 1; hcz = g.oz + (int)ttz * TZ - 1;
-        S = SB = 0;
-        if (own_begin == own_end) return;  // uniform across the block
+        S = SB = 0; slice_base = 0; hoff = hboff = 0;
+    }
+
+    __device__ __forceinline__ void setup(const StepCtx& c) {
+        pool = tile_smem;
+        pool_used = 0;
+        tile = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+        const TileGrid& g = c.gf;
+        const uint32_t ttz = tile % g.ntz, tty = (tile / g.ntz) % g.nty, ttx = tile / (g.ntz * g.nty);
+        own_begin = g.cell_start[(size_t)tile * TCELLS];
+        own_end = g.cell_start[(size_t)tile * TCELLS + TCELLS];
+        hcx = g.ox + (int)ttx * TX - 1; hcy = g.oy + (int)tty * TY - 1; hcz = g.oz + (int)ttz * TZ - 1;
+        const TileAcc a0 = c.tile_off[tile], a1 = c.tile_off[tile + 1];
+        slice_base = a0.nsl;
+        hoff = a0.s; S = (uint32_t)(a1.s - a0.s);
+        hboff = a0.sb; SB = (uint32_t)(a1.sb - a0.sb);
+    }
+
+    template <typename T>
+    __device__ __forceinline__ T* carve(uint32_t count) {
+        T* p = reinterpret_cast<T*>(pool + pool_used);
+        pool_used += (count * (uint32_t)sizeof(T) + 15u) & ~15u;
+        return p;
+    }
+
+    // f(slot, sorted_index) for every fluid halo slot; 4 independent index loads / gathers in flight per thread
+    template <typename F>
+    __device__ __forceinline__ void for_halo(const StepCtx& c, F&& f) const {
+        const uint32_t* __restrict__ src = c.halo_src + hoff;
+#pragma unroll 4
+        for (uint32_t s = threadIdx.x; s < S; s += blockDim.x) f(s, src[s]);
+    }
+    template <typename F>
+    __device__ __forceinline__ void for_halo_boundary(const StepCtx& c, F&& f) const {
+        const uint32_t* __restrict__ src = c.bhalo_src + hboff;
+#pragma unroll 2
+        for (uint32_t s = threadIdx.x; s < SB; s += blockDim.x) f(s, src[s]);
+    }
+
+    // Stage global per-particle arrays into LDS (one pass over the slot table for all of them).  No barrier inside.
+    template <typename T0>
+    __device__ __forceinline__ void stage(const StepCtx& c, const T0* __restrict__ s0, const T0*& d0) {
+        T0* a = carve<T0>(S);
+        for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; });
+        d0 = a;
+    }
+    template <typename T0, typename T1>
+    __device__ __forceinline__ void stage(const StepCtx& c, const T0* __restrict__ s0, const T1* __restrict__ s1,
+                                          const T0*& d0, const T1*& d1) {
+        T0* a = carve<T0>(S); T1* b = carve<T1>(S);
+        for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; });
+        d0 = a; d1 = b;
+    }
+    template <typename T0, typename T1, typename T2>
+    __device__ __forceinline__ void stage(const StepCtx& c, const T0* __restrict__ s0, const T1* __restrict__ s1,
+                                          const T2* __restrict__ s2, const T0*& d0, const T1*& d1, const T2*& d2) {
+        T0* a = carve<T0>(S); T1* b = carve<T1>(S); T2* e = carve<T2>(S);
+        for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; e[s] = s2[g]; });
+        d0 = a; d1 = b; d2 = e;
+    }
+    template <typename T0, typename T1, typename T2, typename T3>
+    __device__ __forceinline__ void stage(const StepCtx& c, const T0* __restrict__ s0, const T1* __restrict__ s1,
+                                          const T2* __restrict__ s2, const T3* __restrict__ s3, const T0*& d0,
+                                          const T1*& d1, const T2*& d2, const T3*& d3) {
+        T0* a = carve<T0>(S); T1* b = carve<T1>(S); T2* e = carve<T2>(S); T3* f = carve<T3>(S);
+        for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; e[s] = s2[g]; f[s] = s3[g]; });
+        d0 = a; d1 = b; d2 = e; d3 = f;
+    }
+    __device__ __forceinline__ void stage_boundary(const StepCtx& c, const float4*& bp) {
+        float4* a = carve<float4>(SB);
+        for_halo_boundary(c, [&](uint32_t s, uint32_t g) { a[s] = c.bposv[g]; });
+        bp = a;
+    }
+    __device__ __forceinline__ void stage_boundary(const StepCtx& c, const float4*& bp, const float4*& bv) {
+        float4* a = carve<float4>(SB); float4* b = carve<float4>(SB);
+        for_halo_boundary(c, [&](uint32_t s, uint32_t g) { a[s] = c.bposv[g]; b[s] = c.bvel[g]; });
+        bp = a; bv = b;
+    }
+
+    // Visit the tile's own particles, one wave per 64-particle slice: f(i, global_slice, active).
+    template <typename F>
+    __device__ __forceinline__ void for_own(F&& f) const {
+        const uint32_t nsl = (own_end - own_begin + WAVE - 1) / WAVE;
+        const uint32_t lane = threadIdx.x & (WAVE - 1), nw = blockDim.x / WAVE;
+        for (uint32_t s = threadIdx.x / WAVE; s < nsl; s += nw) {
+            const uint32_t i = own_begin + s * WAVE + lane;
+            f(i, slice_base + s, i < own_end);
+        }
+    }
+};
+
+// Per-cell slot tables of a tile's halo box, built in LDS from the global cell tables.  Needed only where the halo
+// is traversed cell by cell: the per-step table builders (k_tile_count / k_tile_halo_fill) and the neighbour-list
+// builder.  lstart[h] = first slot of halo cell h = (hx*HY + hy)*HZ + hz ; gstart[h] = its first sorted index.
+struct TileCells {
+    uint32_t *lstart, *gstart, *blstart, *bgstart;
+
+    // tables live at the start of dynamic LDS; returns the number of bytes they occupy
+    __device__ __forceinline__ void build(const StepCtx& c, Tile& t) {
+        uint32_t* tab = t.carve<uint32_t>(2 * (HCELLS + 1) + 2 * HCELLS);
+        lstart = tab; gstart = tab + (HCELLS + 1); blstart = gstart + HCELLS; bgstart = blstart + (HCELLS + 1);
         const int h = threadIdx.x;
         if (h < HCELLS) {
             const int hz = h % HZ, hy = (h / HZ) % HY, hx = h / (HZ * HY);
             bool in;
-            const uint32_t k = tile_key(g, hcx + hx, hcy + hy, hcz + hz, in);
+            const uint32_t k = tile_key(c.gf, t.hcx + hx, t.hcy + hy, t.hcz + hz, in);
             uint32_t b = 0, e = 0;
-            if (in) { b = g.cell_start[k]; e = g.cell_start[k + 1]; }
+            if (in) { b = c.gf.cell_start[k]; e = c.gf.cell_start[k + 1]; }
             gstart[h] = b; lstart[h] = e - b;
             b = e = 0;
             if (c.nb) {
-                const uint32_t kb = tile_key(c.gb, hcx + hx, hcy + hy, hcz + hz, in);
+                const uint32_t kb = tile_key(c.gb, t.hcx + hx, t.hcy + hy, t.hcz + hz, in);
                 if (in) { b = c.gb.cell_start[kb]; e = c.gb.cell_start[kb + 1]; }
             }
             bgstart[h] = b; blstart[h] = e - b;
@@ -128,7 +228,7 @@ struct Tile {
                 a0 = lstart[3 * l]; a1 = lstart[3 * l + 1]; a2 = lstart[3 * l + 2];
                 b0 = blstart[3 * l]; b1 = blstart[3 * l + 1]; b2 = blstart[3 * l + 2];
             }
-            uint32_t sa = a0 + a1 + a2, sb = b0 + b1 + b2;
+            const uint32_t sa = a0 + a1 + a2, sb = b0 + b1 + b2;
             uint32_t ia = sa, ib = sb;
 #pragma unroll
             for (int o = 1; o < WAVE; o <<= 1) {
@@ -143,84 +243,55 @@ struct Tile {
             if (l == HCELLS / 3 - 1) { lstart[HCELLS] = ia; blstart[HCELLS] = ib; }
         }
         __syncthreads();
-        S = lstart[HCELLS];
-        SB = blstart[HCELLS];
-    }
-
-    // Carve an array of `count` elements of T from the pool (uniform across the block).
-    template <typename T>
-    __device__ __forceinline__ T* carve(uint32_t count) {
-        T* p = reinterpret_cast<T*>(pool + pool_used);
-        pool_used += (count * (uint32_t)sizeof(T) + 15u) & ~15u;
-        return p;
-    }
-
-    // Copy the halo particles of a global per-particle array into LDS: 16 lanes per halo cell, so the loads of a
-    // cell (and of the cells that follow it in tile-major order) coalesce.  No barrier inside.
-    template <typename T>
-    __device__ __forceinline__ T* stage(const T* __restrict__ src) {
-        T* dst = carve<T>(S);
-        const int sub = threadIdx.x % STAGE_LANES, grp = threadIdx.x / STAGE_LANES;
-        for (int h = grp; h < HCELLS; h += TILE_THREADS / STAGE_LANES) {
-            const uint32_t l0 = lstart[h], cnt = lstart[h + 1] - l0, g0 = gstart[h];
-            for (uint32_t k = sub; k < cnt; k += STAGE_LANES) dst[l0 + k] = src[g0 + k];
-        }
-        return dst;
-    }
-    template <typename T>
-    __device__ __forceinline__ T* stage_boundary(const T* __restrict__ src) {
-        T* dst = carve<T>(SB);
-        if (SB == 0) return dst;
-        const int sub = threadIdx.x % STAGE_LANES, grp = threadIdx.x / STAGE_LANES;
-        for (int h = grp; h < HCELLS; h += TILE_THREADS / STAGE_LANES) {
-            const uint32_t l0 = blstart[h], cnt = blstart[h + 1] - l0, g0 = bgstart[h];
-            for (uint32_t k = sub; k < cnt; k += STAGE_LANES) dst[l0 + k] = src[g0 + k];
-        }
-        return dst;
-    }
-
-    // Visit the tile's own particles, one wave per 64-particle slice: f(i, global_slice, active).
-    template <typename F>
-    __device__ __forceinline__ void for_own(F&& f) const {
-        const uint32_t nsl = (own_end - own_begin + WAVE - 1) / WAVE;
-        const uint32_t lane = threadIdx.x & (WAVE - 1);
-        for (uint32_t s = threadIdx.x / WAVE; s < nsl; s += TILE_WAVES) {
-            const uint32_t i = own_begin + s * WAVE + lane;
-            f(i, slice_base + s, i < own_end);
-        }
-    }
-
-    // global sorted index of a fluid halo slot (used by the rare paths that need it)
-    __device__ __forceinline__ uint32_t global_of_slot(uint32_t slot) const {
-        int lo = 0, hi = HCELLS;  // largest h with lstart[h] <= slot
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lstart[mid] <= slot) lo = mid; else hi = mid; }
-        return gstart[lo] + (slot - lstart[lo]);
     }
 };
 
 // Neighbour iteration: 16-bit LDS slots, two per dword, sliced-ELL per 64-particle slice.
-template <typename F>
+// `load(slot)` fetches a neighbour's staged record(s) from LDS and `compute(record)` folds it in.  The two (or four)
+// loads of an iteration are issued before the first compute, so the LDS latency of one contact overlaps the
+// arithmetic of another; the odd tail reads slot 0 and discards it.
+template <typename L, typename C>
 __device__ __forceinline__ void for_each_slot(const uint32_t* __restrict__ nbr, const uint64_t* __restrict__ slice_off,
-                                              uint32_t gslice, uint32_t cnt, F&& f) {
+                                              uint32_t gslice, uint32_t cnt, L&& load, C&& compute) {
     if (cnt == 0) return;
     const uint32_t* __restrict__ p = nbr + slice_off[gslice] + (threadIdx.x & (WAVE - 1));
     const uint32_t nq = (cnt + 1) >> 1;
-    uint32_t next = p[0];
-    for (uint32_t q = 0; q < nq; ++q) {
-        const uint32_t pr = next;
-        if (q + 1 < nq) next = p[(size_t)(q + 1) * WAVE];
-        f(pr & 0xffffu);
-        if (2 * q + 1 < cnt) f(pr >> 16);
+    uint32_t q = 0;
+    uint32_t n0 = p[0], n1 = (nq > 1) ? p[WAVE] : 0u;
+    for (; q + 2 <= nq; q += 2) {
+        const uint32_t a = n0, b = n1;
+        if (q + 2 < nq) n0 = p[(size_t)(q + 2) * WAVE];
+        if (q + 3 < nq) n1 = p[(size_t)(q + 3) * WAVE];
+        const auto d0 = load(a & 0xffffu);
+        const auto d1 = load(a >> 16);
+        const auto d2 = load(b & 0xffffu);
+        const auto d3 = load(b >> 16);
+        compute(d0);
+        compute(d1);
+        compute(d2);
+        if (2 * q + 3 < cnt) compute(d3);
+    }
+    if (q < nq) {  // one dword left
+        const uint32_t a = n0;
+        const auto d0 = load(a & 0xffffu);
+        const auto d1 = load(a >> 16);
+        compute(d0);
+        if (2 * q + 1 < cnt) compute(d1);
     }
 }
+template <typename L, typename C>
+__device__ __forceinline__ void for_each_ff(const StepCtx& c, uint32_t i, uint32_t gslice, L&& load, C&& compute) {
+    for_each_slot(c.nbr_ff, c.slice_ff, gslice, c.nff[i], load, compute);
+}
+// single-lambda form (no load/compute split): f(slot)
 template <typename F>
 __device__ __forceinline__ void for_each_ff(const StepCtx& c, uint32_t i, uint32_t gslice, F&& f) {
-    for_each_slot(c.nbr_ff, c.slice_ff, gslice, c.nff[i], f);
+    for_each_slot(c.nbr_ff, c.slice_ff, gslice, c.nff[i], [](uint32_t s) { return s; }, f);
 }
 template <typename F>
 __device__ __forceinline__ void for_each_fb(const StepCtx& c, const Tile& t, uint32_t i, uint32_t gslice, F&& f) {
     if (t.SB == 0) return;
-    for_each_slot(c.nbr_fb, c.slice_fb, gslice, c.nfb[i], f);
+    for_each_slot(c.nbr_fb, c.slice_fb, gslice, c.nfb[i], [](uint32_t s) { return s; }, f);
 }
 
 // Per-fluid error sums of one tile (par_reduce_sum!, lib.rs:75-83; the per-fluid average is taken by
@@ -251,7 +322,7 @@ struct TileErr {
         __syncthreads();
         if (threadIdx.x < c.nmodels) {
             float s = 0.0f;
-            for (int w = 0; w < TILE_WAVES; ++w) s += tab[w][threadIdx.x];
+            for (int w = 0; w < (int)(blockDim.x / WAVE); ++w) s += tab[w][threadIdx.x];
             c.partials[(size_t)tile * c.nmodels + threadIdx.x] = s;
         }
     }
@@ -270,10 +341,8 @@ __device__ __forceinline__ void apply_boundary_force(const StepCtx& c, uint32_t 
     atomicAdd(f + 1, fy);
     atomicAdd(f + 2, fz);
 }
-__device__ __forceinline__ uint32_t boundary_global_of_slot(const Tile& t, uint32_t slot) {
-    int lo = 0, hi = HCELLS;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t.blstart[mid] <= slot) lo = mid; else hi = mid; }
-    return t.bgstart[lo] + (slot - t.blstart[lo]);
+__device__ __forceinline__ uint32_t boundary_sorted_of_slot(const StepCtx& c, const Tile& t, uint32_t slot) {
+    return c.bhalo_src[t.hboff + slot];
 }
 
 #endif  // __HIPCC__

@@ -85,7 +85,8 @@ class World {
     DevBuf<float4> acc, w, normal, dii, dijpj;
     DevBuf<float> rho, alpha, kappa, kappa2, rho_star, aii;
     DevBuf<uint32_t> nff, nfb, keys[2], idx[2], cell_start_f;
-    DevBuf<uint32_t> tile_nsl, tile_slice_base, d_maxhalo;
+    DevBuf<TileAcc> tile_cnt, tile_off;
+    DevBuf<uint32_t> d_maxhalo, halo_src, bhalo_src;
     DevBuf<uint64_t> slice_w_ff, slice_w_fb, slice_ff, slice_fb;
     DevBuf<uint32_t> nbr_ff, nbr_fb;
     DevBuf<int32_t> bbox_partials;

@@ -388,7 +388,7 @@ StepCtx World::make_ctx() {
     c.dii = dii.p; c.dijpj = dijpj.p;
     c.nff = nff.p; c.nfb = nfb.p;
     c.slice_ff = slice_ff.p; c.nbr_ff = nbr_ff.p; c.slice_fb = slice_fb.p; c.nbr_fb = nbr_fb.p;
-    c.tile_slice_base = tile_slice_base.p;
+    c.tile_off = tile_off.p; c.halo_src = halo_src.p; c.bhalo_src = bhalo_src.p;
     c.ntiles = (uint32_t)gf.ntiles();
     c.gf = TileGrid{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], cell_start_f.p};
     c.nb = nb;
@@ -589,9 +589,9 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     const size_t ncf = gf.ncells();
     const uint32_t ntiles = (uint32_t)gf.ntiles();
     cell_start_f.ensure(ncf + 1, stream, false, 1.5f);
-    tile_nsl.ensure(ntiles + 1, stream, false, 1.5f);
-    tile_slice_base.ensure(ntiles + 1, stream, false, 1.5f);
-    d_maxhalo.ensure(2);
+    tile_cnt.ensure(ntiles + 1, stream, false, 1.5f);
+    tile_off.ensure(ntiles + 1, stream, false, 1.5f);
+    d_maxhalo.ensure(4);
     partials.ensure((size_t)ntiles * std::max<size_t>(fluids.size(), 1), stream, false, 1.5f);
     // every tile wastes less than one 64-particle slice
     const uint32_t ns_cap = n / WAVE + ntiles + 1;
@@ -613,23 +613,26 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     }
     build_boundary_grid();  // insert_boundaries_to_grid (liquid_world.rs:106) + boundary volumes, only when dirty
 
-    // ---- tile table: slices per tile, largest halo (sizes the LDS staging area of every tile kernel)
+    // ---- tile tables: per-tile halo sizes / slice counts -> prefix -> flat halo slot tables
     StepCtx c = make_ctx();
     {
-        const size_t tb = scan_temp_bytes(std::max<uint32_t>(ns_cap + 1, ntiles + 1));
+        const size_t tb = std::max(scan_temp_bytes(ns_cap + 1), scan_tiles_temp_bytes(ntiles + 1));
         ensure_cub_temp(tb);
-        SALVA_HIP_CHECK(hipMemsetAsync(d_maxhalo.p, 0, 2 * sizeof(uint32_t), stream));
-        SALVA_HIP_CHECK(hipMemsetAsync(tile_nsl.p + ntiles, 0, sizeof(uint32_t), stream));
-        launch_tile_info(c, tile_nsl.p, d_maxhalo.p, stream);
-        scan_u32(cub_temp.p, tb, tile_nsl.p, tile_slice_base.p, ntiles + 1, stream);
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->max_halo_fluid, d_maxhalo.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nslices, tile_slice_base.p + ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipMemsetAsync(tile_cnt.p + ntiles, 0, sizeof(TileAcc), stream));
+        launch_tile_count(c, tile_cnt.p, stream);
+        scan_tiles(cub_temp.p, tb, tile_cnt.p, tile_off.p, ntiles + 1, stream);
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + ntiles, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
         SALVA_HIP_CHECK(hipStreamSynchronize(stream));
-        lds.max_halo_fluid = h_rb->max_halo_fluid;
-        lds.max_halo_boundary = h_rb->max_halo_boundary;
+        lds.max_halo_fluid = h_rb->tile_total.max_s;
+        lds.max_halo_boundary = h_rb->tile_total.max_sb;
+        lds.threads = WAVE * std::min<uint32_t>(std::max<uint32_t>(h_rb->tile_total.max_nsl, 3u), (uint32_t)TILE_MAX_WAVES);
         if (lds.max_halo_fluid >= 65536u || lds.max_halo_boundary >= 65536u)
             throw HipError(SALVA_HIP_E_CAPACITY, "more than 65535 particles in one tile halo");
-        if (h_rb->nslices > ns_cap) throw HipError(SALVA_HIP_E_HIP, "internal error: slice count exceeds its bound");
+        if (h_rb->tile_total.nsl > ns_cap) throw HipError(SALVA_HIP_E_HIP, "internal error: slice count exceeds its bound");
+        const bool g1 = halo_src.ensure(h_rb->tile_total.s ? h_rb->tile_total.s : 1, stream, false, 1.2f);
+        const bool g2 = bhalo_src.ensure(h_rb->tile_total.sb ? h_rb->tile_total.sb : 1, stream, false, 1.2f);
+        if (g1 || g2) c = make_ctx();
+        launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, stream);
 
         // ---- neighbour lists   (compute_contacts, contacts.rs:154-252)
         SALVA_HIP_CHECK(hipMemsetAsync(d_counters.p, 0, 2 * sizeof(unsigned long long), stream));
