@@ -104,6 +104,7 @@ def main():
     for _ in range(args.steps):
         st = w.step(DT, GRAVITY)
         iters.append((st.n_divergence_iters, st.n_pressure_iters, st.ncontacts, st.grid_ms, st.solver_ms))
+    tile_stats = {"max_halo_fluid": int(st.reserved[0]), "max_halo_boundary": int(st.reserved[1]), "tile_threads": int(st.reserved[2])}
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -150,6 +151,7 @@ def main():
                 "mean_contacts_per_particle": kbar,
                 "grid_ms": float(it[:, 3].mean()),
                 "solver_ms": float(it[:, 4].mean()),
+                "tiles": tile_stats,
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

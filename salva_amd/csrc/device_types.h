@@ -36,10 +36,11 @@ struct TileAcc {
     uint64_t s;     // fluid halo slots
     uint64_t sb;    // boundary halo slots
     uint32_t nsl;   // 64-particle slices
-    uint32_t max_s, max_sb, max_nsl;  // running maxima of the three (carried through the same scan)
+    uint32_t nonempty;  // tiles that own at least one particle
+    uint32_t max_s, max_sb, max_nsl, pad;  // running maxima of the three (carried through the same scan)
     __host__ __device__ TileAcc operator+(const TileAcc& o) const {
-        return TileAcc{s + o.s, sb + o.sb, nsl + o.nsl, max_s > o.max_s ? max_s : o.max_s,
-                       max_sb > o.max_sb ? max_sb : o.max_sb, max_nsl > o.max_nsl ? max_nsl : o.max_nsl};
+        return TileAcc{s + o.s, sb + o.sb, nsl + o.nsl, nonempty + o.nonempty, max_s > o.max_s ? max_s : o.max_s,
+                       max_sb > o.max_sb ? max_sb : o.max_sb, max_nsl > o.max_nsl ? max_nsl : o.max_nsl, 0u};
     }
 };
 

@@ -229,18 +229,20 @@ void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4
 // of 64-particle slices of the tile -> tile_cnt[tile], plus their maxima (which size the LDS staging area and the
 // workgroup of every tile kernel of this step).  After an exclusive scan, k_tile_halo_fill writes the flat slot
 // tables: halo_src[tile_off[tile].s + slot] = sorted index of the particle staged in that slot.
-constexpr int TABLE_THREADS = 192;  // >= HCELLS
+constexpr int TABLE_THREADS = 256;  // >= HCELLS
+static_assert(TABLE_THREADS >= HCELLS, "one thread per halo cell");
 
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc* __restrict__ tile_cnt) {
     Tile t;
     t.setup_geom(c);
-    TileAcc a{0, 0, 0, 0, 0, 0};
+    TileAcc a{0, 0, 0, 0, 0, 0, 0, 0};
     if (!t.empty()) {
         TileCells tc;
         tc.build(c, t);
         a.s = tc.lstart[HCELLS];
         a.sb = tc.blstart[HCELLS];
         a.nsl = (t.own_end - t.own_begin + WAVE - 1) / WAVE;
+        a.nonempty = 1;
         a.max_s = (uint32_t)a.s; a.max_sb = (uint32_t)a.sb; a.max_nsl = a.nsl;
     }
     if (threadIdx.x == 0) tile_cnt[t.tile] = a;
@@ -270,11 +272,11 @@ void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo
 }
 size_t scan_tiles_temp_bytes(uint32_t n) {
     size_t b = 0;
-    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0}, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0}, (int)n);
     return b;
 }
 void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s) {
-    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0}, (int)n, s));
+    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0}, (int)n, s));
 }
 
 // ------------------------------------------------------------------------------------------------ neighbour lists

@@ -17,11 +17,11 @@
 
 namespace salva {
 
-constexpr int TX = 4, TY = 4, TZ = 2;                  // cells per tile
+constexpr int TX = 4, TY = 4, TZ = 4;                  // cells per tile
 constexpr int TCELLS = TX * TY * TZ;                   // 32
 constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;   // halo box
 constexpr int HCELLS = HX * HY * HZ;                   // 144
-constexpr int TILE_MAX_WAVES = 8;                      // workgroup = one wave per 64-particle slice of the fullest tile,
+constexpr int TILE_MAX_WAVES = 12;                      // workgroup = one wave per 64-particle slice of the fullest tile,
 constexpr int TILE_MAX_THREADS = TILE_MAX_WAVES * WAVE; // clamped to [3, 8] waves (a tile holds 256 particles on the
                                                        // 2r lattice, ~320 at rest density)
 
@@ -42,12 +42,12 @@ struct TileLds {
 
 #ifdef __HIPCC__
 
+// hipFuncSetAttribute costs tens of microseconds of host time: raise a kernel's dynamic-LDS ceiling only when a
+// launch actually needs more than was granted before (48 KiB is the default).
+void raise_tile_lds_limit(const void* kernel, uint32_t bytes);  // world.hip
 template <typename K>
 inline void ensure_tile_lds(K kernel, uint32_t bytes) {
-    if (bytes > 160u * 1024u)
-        throw HipError(-4, "a tile's halo does not fit the 160 KiB LDS (particles are compressed far beyond rest density)");
-    if (bytes > 48u * 1024u)
-        SALVA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes > 48u * 1024u) raise_tile_lds_limit(reinterpret_cast<const void*>(kernel), bytes);
 }
 #define SALVA_LAUNCH_TILE(kernel, c, L, lds, s, ...)                          \
     do {                                                                   \
@@ -55,6 +55,7 @@ inline void ensure_tile_lds(K kernel, uint32_t bytes) {
             const uint32_t _lds = (lds);                                   \
             ::salva::ensure_tile_lds(kernel, _lds);                        \
             kernel<<<(c).ntiles, (L).threads, _lds, s>>>(__VA_ARGS__);     \
+            SALVA_HIP_CHECK(hipGetLastError());                            \
         }                                                                  \
     } while (0)
 
@@ -221,26 +222,32 @@ struct TileCells {
             bgstart[h] = b; blstart[h] = e - b;
         }
         __syncthreads();
-        if (threadIdx.x < WAVE) {  // exclusive prefix of 144 counts by one wave: 3 per lane (lanes 0..47)
+        if (threadIdx.x < WAVE) {  // exclusive prefix of the HCELLS counts by one wave, PER lane each
+            constexpr int PER = (HCELLS + WAVE - 1) / WAVE;
+            static_assert(HCELLS % PER == 0, "halo cell count must split evenly over the lanes");
             const int l = threadIdx.x;
-            uint32_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
-            if (l < HCELLS / 3) {
-                a0 = lstart[3 * l]; a1 = lstart[3 * l + 1]; a2 = lstart[3 * l + 2];
-                b0 = blstart[3 * l]; b1 = blstart[3 * l + 1]; b2 = blstart[3 * l + 2];
+            uint32_t a[PER], b[PER], sa = 0, sb = 0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                a[k] = (l < HCELLS / PER) ? lstart[PER * l + k] : 0u;
+                b[k] = (l < HCELLS / PER) ? blstart[PER * l + k] : 0u;
+                sa += a[k]; sb += b[k];
             }
-            const uint32_t sa = a0 + a1 + a2, sb = b0 + b1 + b2;
             uint32_t ia = sa, ib = sb;
 #pragma unroll
             for (int o = 1; o < WAVE; o <<= 1) {
                 const uint32_t ta = (uint32_t)__shfl_up((int)ia, o, WAVE), tb = (uint32_t)__shfl_up((int)ib, o, WAVE);
                 if (l >= o) { ia += ta; ib += tb; }
             }
-            const uint32_t ea = ia - sa, eb = ib - sb;
-            if (l < HCELLS / 3) {
-                lstart[3 * l] = ea; lstart[3 * l + 1] = ea + a0; lstart[3 * l + 2] = ea + a0 + a1;
-                blstart[3 * l] = eb; blstart[3 * l + 1] = eb + b0; blstart[3 * l + 2] = eb + b0 + b1;
+            uint32_t ea = ia - sa, eb = ib - sb;
+            if (l < HCELLS / PER) {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    lstart[PER * l + k] = ea; blstart[PER * l + k] = eb;
+                    ea += a[k]; eb += b[k];
+                }
             }
-            if (l == HCELLS / 3 - 1) { lstart[HCELLS] = ia; blstart[HCELLS] = ib; }
+            if (l == HCELLS / PER - 1) { lstart[HCELLS] = ia; blstart[HCELLS] = ib; }
         }
         __syncthreads();
     }

@@ -65,6 +65,7 @@ class World {
     void ensure_cub_temp(size_t bytes);
     StepCtx make_ctx();
     float read_error();
+    void wait_stream();  // low-latency wait for the world's stream (spins on an event)
     void run_forces(const StepCtx& c);
     void dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
     void iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
@@ -123,6 +124,7 @@ class World {
     float last_dt = 0.0f;
     bool have_last_ctx = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_sync = nullptr;
 };
 
 }  // namespace salva

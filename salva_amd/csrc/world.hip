@@ -12,7 +12,23 @@
 #include <cmath>
 #include <cstring>
 
+#include <mutex>
+#include <unordered_map>
+
 namespace salva {
+
+void raise_tile_lds_limit(const void* kernel, uint32_t bytes) {
+    if (bytes > 160u * 1024u)
+        throw HipError(SALVA_HIP_E_CAPACITY, "a tile's halo does not fit the 160 KiB LDS (particles are compressed far beyond rest density)");
+    static std::mutex mu;
+    static std::unordered_map<const void*, uint32_t> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    uint32_t& g = granted[kernel];
+    if (bytes <= g) return;
+    const uint32_t want = std::min<uint32_t>(160u * 1024u, std::max<uint32_t>(bytes + bytes / 4, 64u * 1024u));
+    SALVA_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+    g = want;
+}
 
 // ------------------------------------------------------------------------------------------------ small helpers
 __global__ void k_pack_xyz(uint32_t n, const float* __restrict__ src, float4* __restrict__ dst, int keep_w, float wval) {
@@ -103,6 +119,7 @@ World::World(const SalvaHipParams& p) : prm(p) {
     d_flags.ensure(1);
     d_counters.ensure(4);
     for (auto& e2 : ev) SALVA_HIP_CHECK(hipEventCreate(&e2));
+    SALVA_HIP_CHECK(hipEventCreateWithFlags(&ev_sync, hipEventDisableTiming));
 }
 
 World::~World() {
@@ -110,6 +127,7 @@ World::~World() {
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
     if (h_rb) (void)hipHostFree(h_rb);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (ev_sync) (void)hipEventDestroy(ev_sync);
 }
 
 void World::use_device() const { SALVA_HIP_CHECK(hipSetDevice(prm.device)); }
@@ -405,14 +423,19 @@ StepCtx World::make_ctx() {
     return c;
 }
 
+// Tile grid over a cell bounding box.  The origin is the box's own minimum corner, so a block of fluid is cut into
+// the same number of tiles wherever it sits (an absolute tile lattice would add a partially filled layer of tiles per
+// axis whenever the block is not aligned with it).  Fluid and boundary grids have independent origins: a fluid
+// tile looks boundary cells up by absolute cell coordinates.
 static void dims_from_bbox(const int32_t* bb, GridDims& g) {
     static const int T[3] = {TX, TY, TZ};
     double nc = TCELLS;
     for (int a = 0; a < 3; ++a) {
         if (bb[a] > bb[3 + a]) throw HipError(SALVA_HIP_E_CAPACITY, "empty cell bounding box");
-        const int t0 = floor_div(bb[a], T[a]), t1 = floor_div(bb[3 + a], T[a]);
-        g.o[a] = t0 * T[a];
-        g.nt[a] = t1 - t0 + 1;
+        const int64_t extent = (int64_t)bb[3 + a] - (int64_t)bb[a] + 1;
+        if (extent > (1 << 30)) throw HipError(SALVA_HIP_E_CAPACITY, "cell bounding box too large");
+        g.o[a] = bb[a];
+        g.nt[a] = (int)((extent + T[a] - 1) / T[a]);
         nc *= (double)g.nt[a];
     }
     if (nc >= 4.0e9) throw HipError(SALVA_HIP_E_CAPACITY, "dense cell table would exceed 2^32 cells; particles are too spread out");
@@ -450,10 +473,21 @@ void World::build_boundary_grid() {
     b_dirty = false;
 }
 
+// The convergence loops read one float back per iteration; an interrupt-driven hipStreamSynchronize costs tens of
+// microseconds per wake-up, polling an event a few.
+void World::wait_stream() {
+    SALVA_HIP_CHECK(hipEventRecord(ev_sync, stream));
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev_sync);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) SALVA_HIP_CHECK(e);
+    }
+}
+
 float World::read_error() {
     launch_finalize_error(partials.p, (unsigned)gf.ntiles(), (uint32_t)std::max<size_t>(fluids.size(), 1), model_counts.p, &d_rb.p->err, stream);
     SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->err, &d_rb.p->err, sizeof(float), hipMemcpyDeviceToHost, stream));
-    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    wait_stream();
     return h_rb->err;
 }
 
@@ -582,7 +616,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     if (!bbox_known) {
         launch_bbox(posm[cur].p, n, sc.h, bbox_partials.p, d_rb.p->bbox, d_flags.p, stream);
         SALVA_HIP_CHECK(hipMemcpyAsync(h_rb->bbox, d_rb.p->bbox, sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
-        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        wait_stream();
         bbox_known = true;
     }
     dims_from_bbox(h_rb->bbox, gf);
@@ -622,10 +656,17 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         launch_tile_count(c, tile_cnt.p, stream);
         scan_tiles(cub_temp.p, tb, tile_cnt.p, tile_off.p, ntiles + 1, stream);
         SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + ntiles, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
-        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        wait_stream();
         lds.max_halo_fluid = h_rb->tile_total.max_s;
         lds.max_halo_boundary = h_rb->tile_total.max_sb;
-        lds.threads = WAVE * std::min<uint32_t>(std::max<uint32_t>(h_rb->tile_total.max_nsl, 3u), (uint32_t)TILE_MAX_WAVES);
+        // one wave per 64-particle slice of the average non-empty tile (fuller tiles loop over their extra slices),
+        // never fewer waves than the halo-table build needs threads
+        {
+            const uint32_t avg = (n + h_rb->tile_total.nonempty - 1) / std::max<uint32_t>(h_rb->tile_total.nonempty, 1u);
+            const uint32_t lo = (HCELLS + WAVE - 1) / WAVE, hi = std::min<uint32_t>(std::max<uint32_t>(h_rb->tile_total.max_nsl, lo), (uint32_t)TILE_MAX_WAVES);
+            lds.threads = WAVE * std::min<uint32_t>(std::max<uint32_t>((avg + WAVE - 1) / WAVE, lo), hi);
+        }
+        if (const char* e = getenv("SALVA_HIP_TILE_THREADS")) lds.threads = (uint32_t)atoi(e);
         if (lds.max_halo_fluid >= 65536u || lds.max_halo_boundary >= 65536u)
             throw HipError(SALVA_HIP_E_CAPACITY, "more than 65535 particles in one tile halo");
         if (h_rb->tile_total.nsl > ns_cap) throw HipError(SALVA_HIP_E_HIP, "internal error: slice count exceeds its bound");
@@ -644,7 +685,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nbr_total_ff, slice_ff.p + ns_cap, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
         SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nbr_total_fb, slice_fb.p + ns_cap, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
         SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, d_counters.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        wait_stream();
         if (h_rb->nbr_total_ff >= (1ull << 40) || h_rb->nbr_total_fb >= (1ull << 40))
             throw HipError(SALVA_HIP_E_CAPACITY, "neighbour list too large");
         const bool r1 = nbr_ff.ensure(h_rb->nbr_total_ff ? h_rb->nbr_total_ff : 1, stream, false, 1.2f);
@@ -665,7 +706,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     SALVA_HIP_CHECK(hipMemcpyAsync(h_rb->bbox, d_rb.p->bbox, sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->flags, d_flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[2], stream));
-    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    wait_stream();
     bbox_known = true;
     last_ctx = c; last_dt = dt; have_last_ctx = true;
     if (timers) {
@@ -674,6 +715,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         (void)hipEventElapsedTime(&b, ev[1], ev[2]);
         st.grid_ms = a; st.solver_ms = b; st.step_ms = a + b;
     }
+    st.reserved[0] = (float)lds.max_halo_fluid; st.reserved[1] = (float)lds.max_halo_boundary; st.reserved[2] = (float)lds.threads;
     if (stats) *stats = st;
     if (h_rb->flags & 1u) {
         bbox_known = false;
