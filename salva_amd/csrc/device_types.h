@@ -7,9 +7,11 @@
 //   w    = (v+dv x, y, z, model id)   gathered by the evaluate passes and by the viscosity/tension forces
 //   vel  = (v x, y, z, volume)        streamed only
 //   dv   = (dv x, y, z, pressure)     streamed only (pressure = IISPH warm start, carried across steps)
-// Neighbour lists are sliced-ELL with slice = 64 consecutive particles of one tile (one wavefront): entries 2q and
+// Neighbour lists are ELL blocks per slice (64 consecutive particles of one tile = one wavefront): entries 2q and
 // 2q+1 (16-bit LDS slots of the tile's halo, tile.h) of the particle handled by lane l of slice s live in the dword
-// nbr[slice_off[s] + 64 q + l], so a wave reads 256 contiguous bytes per pair of contacts.
+// nbr[(s * cap + q) * 64 + l], so a wave reads 256 contiguous bytes per pair of contacts.  `cap` (dwords per
+// particle) is fixed per step, which lets the list be written in the same pass that finds the contacts; rows
+// beyond a slice's longest list are never touched.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -68,10 +70,9 @@ struct StepCtx {
     float4* dijpj;       // IISPH sum_j d_ij p_j (xyz, unused)
     uint32_t* nff;       // # fluid-fluid contacts of each particle (self included)
     uint32_t* nfb;       // # fluid-boundary contacts
-    const uint64_t* slice_ff;   // [nslices+1] dword offset of each slice's list
-    const uint32_t* nbr_ff;     // packed 16-bit halo slots
-    const uint64_t* slice_fb;
-    const uint32_t* nbr_fb;
+    uint32_t* nbr_ff;           // packed 16-bit halo slots: slice s owns dwords [s*cap_ff*64, (s+1)*cap_ff*64)
+    uint32_t* nbr_fb;
+    uint32_t cap_ff, cap_fb;    // dwords (= pairs of contacts) reserved per particle
     const TileAcc* tile_off;    // [ntiles+1] exclusive prefix of per-tile {halo slots, boundary halo slots, slices}
     const uint32_t* halo_src;   // sorted fluid index of every halo slot of every tile (tile-major)
     const uint32_t* bhalo_src;  // sorted boundary index of every boundary halo slot
@@ -106,9 +107,9 @@ struct Readback {
     uint32_t flags;
     int32_t bbox[6];      // fluid cell bbox (min xyz, max xyz)
     int32_t bbbox[6];     // boundary cell bbox
-    uint64_t nbr_total_ff, nbr_total_fb;  // padded sliced-ELL sizes (dwords)
     TileAcc tile_total;   // totals and maxima of halo slots / boundary halo slots / slices over the tiles
     uint64_t ncontacts_ff, ncontacts_fb, ncontacts_bb;
+    uint32_t max_cnt_ff, max_cnt_fb;   // longest contact lists of the step (capacity check)
 };
 
 }  // namespace salva

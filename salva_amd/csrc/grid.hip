@@ -280,17 +280,21 @@ void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, 
 }
 
 // ------------------------------------------------------------------------------------------------ neighbour lists
-// One workgroup per tile.  FILL=false: count fluid-fluid (contacts.rs:347-392) and fluid-boundary (:329-346,
-// :378-383) contacts of the tile's own particles -> nff / nfb and the slice widths.  FILL=true: write the halo slots
-// of the accepted candidates, in traversal order (9 rows of 3 z-adjacent halo cells), two 16-bit slots per dword.
-template <bool FILL>
-__global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, uint64_t* __restrict__ slice_w_ff,
-                                                               uint64_t* __restrict__ slice_w_fb, uint32_t* __restrict__ nbr_ff,
-                                                               uint32_t* __restrict__ nbr_fb, unsigned long long* ncontacts) {
-    __shared__ float red[TILE_MAX_WAVES];
+// One workgroup per tile, one pass: for every own particle, test the candidates of its 3x3x3 cells (9 rows of 3
+// z-adjacent halo cells) against d^2 <= h^2 and the interaction groups, and append the halo slots of the accepted
+// ones to the particle's ELL row, two 16-bit slots per dword: fluid-fluid contacts (contacts.rs:347-392) and
+// fluid-boundary contacts (:329-346, :378-383).  Writes nff / nfb, and per tile {sum, max} of the list lengths
+// (the sums are counters.cd.ncontacts; the maxima tell the host whether the fixed ELL capacity was enough).
+struct TileListStats { uint32_t sum_ff, sum_fb, max_ff, max_fb; };
+
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileListStats* __restrict__ tile_stats) {
+    __shared__ uint32_t red[4][TILE_MAX_WAVES];
     Tile t;
     t.setup(c);
-    if (t.empty()) return;
+    if (t.empty()) {
+        if (threadIdx.x == 0) tile_stats[t.tile] = TileListStats{0, 0, 0, 0};
+        return;
+    }
     TileCells tc;
     tc.build(c, t);
     const bool multi = c.nmodels > 1;
@@ -302,85 +306,105 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, uint64
     t.for_halo_boundary(c, [&](uint32_t s, uint32_t g) { Bp[s] = c.bposv[g]; Bv[s] = c.bvel[g]; });
     __syncthreads();
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    float total_ff = 0.0f, total_fb = 0.0f;
+    uint32_t sum_ff = 0, sum_fb = 0, max_ff = 0, max_fb = 0;
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active) return;
         uint32_t cnt = 0, cntb = 0;
-        if (active) {
-            const float4 pi = c.posm[i];
-            const uint32_t mi = c.model[i];
-            bool bad = false;
-            const int lx = cell_coord(pi.x, c.sc.h, bad) - t.hcx, ly = cell_coord(pi.y, c.sc.h, bad) - t.hcy,
-                      lz = cell_coord(pi.z, c.sc.h, bad) - t.hcz;
-            const uint64_t base = FILL ? c.slice_ff[gs] + lane : 0;
-            const uint64_t baseb = (FILL && t.SB) ? c.slice_fb[gs] + lane : 0;
-            uint32_t pend = 0, pendb = 0;
+        const float4 pi = c.posm[i];
+        const uint32_t mi = c.model[i];
+        bool bad = false;
+        const int lx = cell_coord(pi.x, c.sc.h, bad) - t.hcx, ly = cell_coord(pi.y, c.sc.h, bad) - t.hcy,
+                  lz = cell_coord(pi.z, c.sc.h, bad) - t.hcz;
+        uint32_t* __restrict__ out = c.nbr_ff + (size_t)gs * c.cap_ff * WAVE + lane;
+        uint32_t* __restrict__ outb = c.nbr_fb + (size_t)gs * c.cap_fb * WAVE + lane;
+        uint32_t pend = 0, pendb = 0;
 #pragma unroll 1
-            for (int dx = -1; dx <= 1; ++dx) {
+        for (int dx = -1; dx <= 1; ++dx) {
 #pragma unroll 1
-                for (int dy = -1; dy <= 1; ++dy) {
-                    const int row = ((lx + dx) * HY + (ly + dy)) * HZ + (lz - 1);
-                    const uint32_t b = tc.lstart[row], e = tc.lstart[row + 3];
-                    for (uint32_t s = b; s < e; ++s) {
-                        const float4 pj = Lp[s];
-                        const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                        if (d2 <= c.sc.h2 && (!multi || c.ff_ok[mi * c.nmodels + Lm[s]])) {
-                            if (FILL) {
-                                if (cnt & 1u) nbr_ff[base + (uint64_t)(cnt >> 1) * WAVE] = pend | (s << 16);
-                                else pend = s;
-                            }
-                            ++cnt;
-                        }
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int row = ((lx + dx) * HY + (ly + dy)) * HZ + (lz - 1);
+                const uint32_t b = tc.lstart[row], e = tc.lstart[row + 3];
+                for (uint32_t s = b; s < e; ++s) {
+                    const float4 pj = Lp[s];
+                    const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                    if (d2 <= c.sc.h2 && (!multi || c.ff_ok[mi * c.nmodels + Lm[s]])) {
+                        if (cnt & 1u) { if ((cnt >> 1) < c.cap_ff) out[(size_t)(cnt >> 1) * WAVE] = pend | (s << 16); }
+                        else pend = s;
+                        ++cnt;
                     }
-                    if (t.SB) {
-                        const uint32_t bb = tc.blstart[row], be = tc.blstart[row + 3];
-                        for (uint32_t s = bb; s < be; ++s) {
-                            const float4 pj = Bp[s];
-                            const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                            if (d2 <= c.sc.h2 && c.fb_ok[mi * c.nbmodels + __float_as_uint(Bv[s].w)]) {
-                                if (FILL) {
-                                    if (cntb & 1u) nbr_fb[baseb + (uint64_t)(cntb >> 1) * WAVE] = pendb | (s << 16);
-                                    else pendb = s;
-                                }
-                                ++cntb;
-                            }
+                }
+                if (t.SB) {
+                    const uint32_t bb = tc.blstart[row], be = tc.blstart[row + 3];
+                    for (uint32_t s = bb; s < be; ++s) {
+                        const float4 pj = Bp[s];
+                        const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                        if (d2 <= c.sc.h2 && c.fb_ok[mi * c.nbmodels + __float_as_uint(Bv[s].w)]) {
+                            if (cntb & 1u) { if ((cntb >> 1) < c.cap_fb) outb[(size_t)(cntb >> 1) * WAVE] = pendb | (s << 16); }
+                            else pendb = s;
+                            ++cntb;
                         }
                     }
                 }
             }
-            if (FILL) {
-                if (cnt & 1u) nbr_ff[base + (uint64_t)(cnt >> 1) * WAVE] = pend;
-                if (cntb & 1u) nbr_fb[baseb + (uint64_t)(cntb >> 1) * WAVE] = pendb;
-            } else {
-                c.nff[i] = cnt;
-                c.nfb[i] = cntb;
-            }
         }
-        if (!FILL) {
-            const uint32_t wm = wave_max_u32(cnt), wmb = wave_max_u32(cntb);
-            if (lane == 0) {
-                slice_w_ff[gs] = (uint64_t)((wm + 1) >> 1) * WAVE;
-                slice_w_fb[gs] = (uint64_t)((wmb + 1) >> 1) * WAVE;
-            }
-            total_ff += (float)cnt;
-            total_fb += (float)cntb;
-        }
+        if ((cnt & 1u) && (cnt >> 1) < c.cap_ff) out[(size_t)(cnt >> 1) * WAVE] = pend;
+        if ((cntb & 1u) && (cntb >> 1) < c.cap_fb) outb[(size_t)(cntb >> 1) * WAVE] = pendb;
+        c.nff[i] = cnt;
+        c.nfb[i] = cntb;
+        sum_ff += cnt; sum_fb += cntb;
+        max_ff = max(max_ff, cnt); max_fb = max(max_fb, cntb);
     });
-    if (!FILL) {
-        // exact integer totals (per-block counts stay far below 2^24)
-        const float a = block_sum(total_ff, red), b = block_sum(total_fb, red);
-        if (threadIdx.x == 0) {
-            if (a > 0.0f) atomicAdd(ncontacts + 0, (unsigned long long)a);
-            if (b > 0.0f) atomicAdd(ncontacts + 1, (unsigned long long)b);
+    // per-tile statistics (integer, order independent)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum_ff += (uint32_t)__shfl_xor((int)sum_ff, o, WAVE);
+        sum_fb += (uint32_t)__shfl_xor((int)sum_fb, o, WAVE);
+    }
+    max_ff = wave_max_u32(max_ff); max_fb = wave_max_u32(max_fb);
+    const uint32_t wv = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
+    if (lane == 0) { red[0][wv] = sum_ff; red[1][wv] = sum_fb; red[2][wv] = max_ff; red[3][wv] = max_fb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TileListStats st{0, 0, 0, 0};
+        for (uint32_t k = 0; k < nw; ++k) {
+            st.sum_ff += red[0][k]; st.sum_fb += red[1][k];
+            st.max_ff = max(st.max_ff, red[2][k]); st.max_fb = max(st.max_fb, red[3][k]);
         }
+        tile_stats[t.tile] = st;
+    }
+}
+// fold the per-tile list statistics: out = {ncontacts_ff, ncontacts_fb} (u64) and {max_ff, max_fb} (u32)
+__global__ __launch_bounds__(BLOCK) void k_list_stats(const TileListStats* __restrict__ ts, uint32_t ntiles,
+                                                      unsigned long long* totals2, uint32_t* maxima2) {
+    __shared__ unsigned long long sred[2][BLOCK / WAVE];
+    __shared__ uint32_t mred[2][BLOCK / WAVE];
+    unsigned long long a = 0, b = 0;
+    uint32_t ma = 0, mb = 0;
+    for (uint32_t k = threadIdx.x; k < ntiles; k += BLOCK) {
+        const TileListStats s = ts[k];
+        a += s.sum_ff; b += s.sum_fb; ma = max(ma, s.max_ff); mb = max(mb, s.max_fb);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, WAVE); b += __shfl_xor(b, o, WAVE);
+    }
+    ma = wave_max_u32(ma); mb = wave_max_u32(mb);
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    if (lane == 0) { sred[0][wv] = a; sred[1][wv] = b; mred[0][wv] = ma; mred[1][wv] = mb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long ta = 0, tb = 0; uint32_t xa = 0, xb = 0;
+        for (int k = 0; k < BLOCK / WAVE; ++k) { ta += sred[0][k]; tb += sred[1][k]; xa = max(xa, mred[0][k]); xb = max(xb, mred[1][k]); }
+        totals2[0] = ta; totals2[1] = tb; maxima2[0] = xa; maxima2[1] = xb;
     }
 }
 
-void launch_nbr_count(const StepCtx& c, const TileLds& L, uint64_t* slice_w_ff, uint64_t* slice_w_fb,
-                      unsigned long long* ncontacts2, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_nbr_tile<false>, c, L, L.bytes(20, 32, 4, true), s, c, slice_w_ff, slice_w_fb, nullptr, nullptr, ncontacts2);
-}
-void launch_nbr_fill(const StepCtx& c, const TileLds& L, uint32_t* nbr_ff, uint32_t* nbr_fb, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_nbr_tile<true>, c, L, L.bytes(20, 32, 4, true), s, c, nullptr, nullptr, nbr_ff, nbr_fb, nullptr);
+size_t tile_list_stats_bytes(uint32_t ntiles) { return (size_t)ntiles * sizeof(TileListStats); }
+void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsigned long long* totals2, uint32_t* maxima2,
+                      hipStream_t s) {
+    if (c.n == 0) return;
+    SALVA_LAUNCH_TILE(k_nbr_tile, c, L, L.bytes(20, 32, 4, true), s, c, static_cast<TileListStats*>(tile_stats));
+    k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.ntiles, totals2, maxima2);
 }
 
 // ------------------------------------------------------------------------------------------------ boundary volumes

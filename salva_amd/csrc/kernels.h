@@ -40,10 +40,11 @@ void launch_tile_count(const StepCtx& c, TileAcc* tile_cnt, hipStream_t s);
 void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, hipStream_t s);
 size_t scan_tiles_temp_bytes(uint32_t n);
 void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s);
-// neighbour lists (per-tile sliced ELL of 16-bit halo slots).  count: fills nff/nfb, slice widths (dwords), contact totals
-void launch_nbr_count(const StepCtx& c, const TileLds& L, uint64_t* slice_w_ff, uint64_t* slice_w_fb,
-                      unsigned long long* ncontacts2, hipStream_t s);
-void launch_nbr_fill(const StepCtx& c, const TileLds& L, uint32_t* nbr_ff, uint32_t* nbr_fb, hipStream_t s);
+// neighbour lists (per-slice ELL blocks of 16-bit halo slots, capacity c.cap_ff / c.cap_fb dwords per particle), built
+// in one pass; totals2 = {ff, fb} contact counts, maxima2 = longest {ff, fb} list (> 2*cap means overflow: rebuild)
+size_t tile_list_stats_bytes(uint32_t ntiles);
+void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsigned long long* totals2, uint32_t* maxima2,
+                      hipStream_t s);
 size_t scan_temp_bytes(uint32_t n);
 void scan_u64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t s);
 

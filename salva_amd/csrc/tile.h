@@ -258,10 +258,10 @@ struct TileCells {
 // loads of an iteration are issued before the first compute, so the LDS latency of one contact overlaps the
 // arithmetic of another; the odd tail reads slot 0 and discards it.
 template <typename L, typename C>
-__device__ __forceinline__ void for_each_slot(const uint32_t* __restrict__ nbr, const uint64_t* __restrict__ slice_off,
-                                              uint32_t gslice, uint32_t cnt, L&& load, C&& compute) {
+__device__ __forceinline__ void for_each_slot(const uint32_t* __restrict__ nbr, uint32_t cap, uint32_t gslice,
+                                              uint32_t cnt, L&& load, C&& compute) {
     if (cnt == 0) return;
-    const uint32_t* __restrict__ p = nbr + slice_off[gslice] + (threadIdx.x & (WAVE - 1));
+    const uint32_t* __restrict__ p = nbr + (size_t)gslice * cap * WAVE + (threadIdx.x & (WAVE - 1));
     const uint32_t nq = (cnt + 1) >> 1;
     uint32_t q = 0;
     uint32_t n0 = p[0], n1 = (nq > 1) ? p[WAVE] : 0u;
@@ -288,17 +288,17 @@ __device__ __forceinline__ void for_each_slot(const uint32_t* __restrict__ nbr, 
 }
 template <typename L, typename C>
 __device__ __forceinline__ void for_each_ff(const StepCtx& c, uint32_t i, uint32_t gslice, L&& load, C&& compute) {
-    for_each_slot(c.nbr_ff, c.slice_ff, gslice, c.nff[i], load, compute);
+    for_each_slot(c.nbr_ff, c.cap_ff, gslice, c.nff[i], load, compute);
 }
 // single-lambda form (no load/compute split): f(slot)
 template <typename F>
 __device__ __forceinline__ void for_each_ff(const StepCtx& c, uint32_t i, uint32_t gslice, F&& f) {
-    for_each_slot(c.nbr_ff, c.slice_ff, gslice, c.nff[i], [](uint32_t s) { return s; }, f);
+    for_each_slot(c.nbr_ff, c.cap_ff, gslice, c.nff[i], [](uint32_t s) { return s; }, f);
 }
 template <typename F>
 __device__ __forceinline__ void for_each_fb(const StepCtx& c, const Tile& t, uint32_t i, uint32_t gslice, F&& f) {
     if (t.SB == 0) return;
-    for_each_slot(c.nbr_fb, c.slice_fb, gslice, c.nfb[i], [](uint32_t s) { return s; }, f);
+    for_each_slot(c.nbr_fb, c.cap_fb, gslice, c.nfb[i], [](uint32_t s) { return s; }, f);
 }
 
 // Per-fluid error sums of one tile (par_reduce_sum!, lib.rs:75-83; the per-fluid average is taken by

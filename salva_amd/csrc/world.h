@@ -88,7 +88,8 @@ class World {
     DevBuf<uint32_t> nff, nfb, keys[2], idx[2], cell_start_f;
     DevBuf<TileAcc> tile_cnt, tile_off;
     DevBuf<uint32_t> d_maxhalo, halo_src, bhalo_src;
-    DevBuf<uint64_t> slice_w_ff, slice_w_fb, slice_ff, slice_fb;
+    DevBuf<char> tile_list_stats;
+    uint32_t cap_ff = 24, cap_fb = 8;  // ELL capacity (dwords per particle), grown on demand
     DevBuf<uint32_t> nbr_ff, nbr_fb;
     DevBuf<int32_t> bbox_partials;
     TileLds lds;

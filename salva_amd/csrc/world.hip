@@ -405,7 +405,7 @@ StepCtx World::make_ctx() {
     c.rho = rho.p; c.alpha = alpha.p; c.kappa = kappa.p; c.kappa2 = kappa2.p; c.rho_star = rho_star.p; c.aii = aii.p;
     c.dii = dii.p; c.dijpj = dijpj.p;
     c.nff = nff.p; c.nfb = nfb.p;
-    c.slice_ff = slice_ff.p; c.nbr_ff = nbr_ff.p; c.slice_fb = slice_fb.p; c.nbr_fb = nbr_fb.p;
+    c.nbr_ff = nbr_ff.p; c.nbr_fb = nbr_fb.p; c.cap_ff = cap_ff; c.cap_fb = cap_fb;
     c.tile_off = tile_off.p; c.halo_src = halo_src.p; c.bhalo_src = bhalo_src.p;
     c.ntiles = (uint32_t)gf.ntiles();
     c.gf = TileGrid{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], cell_start_f.p};
@@ -629,8 +629,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     partials.ensure((size_t)ntiles * std::max<size_t>(fluids.size(), 1), stream, false, 1.5f);
     // every tile wastes less than one 64-particle slice
     const uint32_t ns_cap = n / WAVE + ntiles + 1;
-    slice_w_ff.ensure(ns_cap + 1, stream, false, 1.25f); slice_w_fb.ensure(ns_cap + 1, stream, false, 1.25f);
-    slice_ff.ensure(ns_cap + 1, stream, false, 1.25f); slice_fb.ensure(ns_cap + 1, stream, false, 1.25f);
+    tile_list_stats.ensure(tile_list_stats_bytes(ntiles), stream, false, 1.5f);
 
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
     {
@@ -650,7 +649,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     // ---- tile tables: per-tile halo sizes / slice counts -> prefix -> flat halo slot tables
     StepCtx c = make_ctx();
     {
-        const size_t tb = std::max(scan_temp_bytes(ns_cap + 1), scan_tiles_temp_bytes(ntiles + 1));
+        const size_t tb = scan_tiles_temp_bytes(ntiles + 1);
         ensure_cub_temp(tb);
         SALVA_HIP_CHECK(hipMemsetAsync(tile_cnt.p + ntiles, 0, sizeof(TileAcc), stream));
         launch_tile_count(c, tile_cnt.p, stream);
@@ -675,23 +674,25 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         if (g1 || g2) c = make_ctx();
         launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, stream);
 
-        // ---- neighbour lists   (compute_contacts, contacts.rs:154-252)
-        SALVA_HIP_CHECK(hipMemsetAsync(d_counters.p, 0, 2 * sizeof(unsigned long long), stream));
-        SALVA_HIP_CHECK(hipMemsetAsync(slice_w_ff.p, 0, (size_t)(ns_cap + 1) * sizeof(uint64_t), stream));
-        SALVA_HIP_CHECK(hipMemsetAsync(slice_w_fb.p, 0, (size_t)(ns_cap + 1) * sizeof(uint64_t), stream));
-        launch_nbr_count(c, lds, slice_w_ff.p, slice_w_fb.p, d_counters.p, stream);
-        scan_u64(cub_temp.p, tb, slice_w_ff.p, slice_ff.p, ns_cap + 1, stream);
-        scan_u64(cub_temp.p, tb, slice_w_fb.p, slice_fb.p, ns_cap + 1, stream);
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nbr_total_ff, slice_ff.p + ns_cap, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->nbr_total_fb, slice_fb.p + ns_cap, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, d_counters.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        wait_stream();
-        if (h_rb->nbr_total_ff >= (1ull << 40) || h_rb->nbr_total_fb >= (1ull << 40))
-            throw HipError(SALVA_HIP_E_CAPACITY, "neighbour list too large");
-        const bool r1 = nbr_ff.ensure(h_rb->nbr_total_ff ? h_rb->nbr_total_ff : 1, stream, false, 1.2f);
-        const bool r2 = nbr_fb.ensure(h_rb->nbr_total_fb ? h_rb->nbr_total_fb : 1, stream, false, 1.2f);
-        if (r1 || r2) c = make_ctx();
-        launch_nbr_fill(c, lds, nbr_ff.p, nbr_fb.p, stream);
+        // ---- neighbour lists   (compute_contacts, contacts.rs:154-252): one pass into fixed-capacity ELL rows; if a list
+        // turns out longer than the capacity the pass is repeated with room to spare (rare: the capacity follows the
+        // longest list seen so far)
+        const uint32_t nslices = h_rb->tile_total.nsl;
+        for (int attempt = 0;; ++attempt) {
+            const bool r1 = nbr_ff.ensure((size_t)nslices * cap_ff * WAVE + 1, stream, false, 1.1f);
+            const bool r2 = nbr_fb.ensure(nb ? (size_t)nslices * cap_fb * WAVE + 1 : 1, stream, false, 1.1f);
+            (void)r1; (void)r2;
+            c = make_ctx();
+            launch_nbr_build(c, lds, tile_list_stats.p, d_counters.p, d_maxhalo.p, stream);
+            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, d_counters.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->max_cnt_ff, d_maxhalo.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            wait_stream();
+            const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;
+            if (need_ff <= cap_ff && need_fb <= cap_fb) break;
+            if (attempt >= 2) throw HipError(SALVA_HIP_E_HIP, "internal error: neighbour list capacity did not converge");
+            if (need_ff > cap_ff) cap_ff = need_ff + need_ff / 4 + 1;
+            if (need_fb > cap_fb) cap_fb = need_fb + need_fb / 4 + 1;
+        }
     }
     st.ncontacts = h_rb->ncontacts_ff + (nb ? h_rb->ncontacts_fb : 0) + ncontacts_bb;
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
@@ -847,8 +848,8 @@ uint64_t World::device_bytes() const {
     }
     add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes());
     add(rho.bytes()); add(alpha.bytes()); add(kappa.bytes()); add(kappa2.bytes()); add(rho_star.bytes()); add(aii.bytes());
-    add(nff.bytes()); add(nfb.bytes()); add(cell_start_f.bytes()); add(slice_w_ff.bytes()); add(slice_w_fb.bytes()); add(slice_ff.bytes());
-    add(slice_fb.bytes()); add(nbr_ff.bytes()); add(nbr_fb.bytes()); add(cub_temp.bytes()); add(scratch_f.bytes());
+    add(nff.bytes()); add(nfb.bytes()); add(cell_start_f.bytes()); add(halo_src.bytes()); add(bhalo_src.bytes());
+    add(nbr_ff.bytes()); add(nbr_fb.bytes()); add(cub_temp.bytes()); add(scratch_f.bytes());
     add(scratch_f4.bytes()); add(bst_pos.bytes()); add(bst_vel.bytes()); add(bposv.bytes()); add(bvel.bytes());
     add(bforce.bytes()); add(bperm.bytes()); add(cell_start_b.bytes()); add(partials.bytes());
     return b;
