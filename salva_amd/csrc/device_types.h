@@ -91,6 +91,7 @@ struct StepCtx {
     // ---- per-model tables ----
     uint32_t nmodels, nbmodels;
     const float* rho0_tab;     // density0 of each fluid model
+    float rho0_single;         // = rho0_tab[0]; used when nmodels == 1 (saves a dependent load)
     const uint8_t* ff_ok;      // [nmodels*nmodels] InteractionGroups::test between fluids (diagonal = 1)
     const uint8_t* fb_ok;      // [nmodels*nbmodels]
     const uint8_t* bb_ok;      // [nbmodels*nbmodels] (diagonal = 1)
@@ -99,6 +100,7 @@ struct StepCtx {
     float* partials;     // [nblocks * nmodels] per-block error sums
     uint32_t* flags;     // bit 0: numeric error (zero density / NaN), bit 1: particle outside grid
     uint32_t min_neighbors_for_divergence;
+    unsigned long long* dbg;   // optional per-tile phase timestamps (k_pred_density, SALVA_HIP_TILE_TIMING=1)
 };
 
 // Result block the host reads back (pinned mirror).

@@ -19,6 +19,10 @@ unsigned num_blocks(uint32_t n) { return div_up(n, BLOCK); }
 struct RecPW { float4 p, w; };   // position+mass, v+dv
 struct RecPK { float4 p; float k; };  // position+mass, kappa
 
+__device__ __forceinline__ float rho0_of(const StepCtx& c, uint32_t model) {
+    return (c.nmodels == 1) ? c.rho0_single : c.rho0_tab[model];
+}
+
 // ------------------------------------------------------------------------------------------------
 // compute_densities (dfsph_solver.rs:628-665) fused with compute_alphas (:165-216): both depend on positions only.
 //   rho_i   = sum_j m_j W_ij + sum_b V_b rho0_i W_ib
@@ -28,17 +32,23 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    struct Own { float4 pi; uint32_t mi, cnt; ListHead lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) { return Own{c.posm[i], c.model[i], c.nff[i], list_head(c, gs)}; };
+    uint32_t i0, gs0;
+    const bool a0 = t.first_own(i0, gs0);
+    Own own0{};
+    if (a0) own0 = load_own(i0, gs0);
     const float4* Lp = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), Lp);
     const float4* Bp = nullptr;
     t.stage_boundary(c, Bp);
     __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
-        const float4 pi = c.posm[i];
-        const float rho0 = c.rho0_tab[c.model[i]];
+        const float4 pi = o.pi;
+        const float rho0 = rho0_of(c, o.mi);
         float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f;
-        for_each_ff(c, i, gs, [&](uint32_t s) { return Lp[s]; }, [&](const float4& pj) {
+        for_each_ff(c, gs, o.cnt, o.lh, [&](uint32_t s) { return Lp[s]; }, [&](const float4& pj) {
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
             rho += pj.w * e.w;
@@ -78,6 +88,16 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     Tile t;
     t.setup(c);
     if (t.empty()) { TileErr::zero(c, t.tile); return; }
+    struct Own { float4 pi, wi; float alpha; uint32_t mi, cnt, cntb; ListHead lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.w[i], c.alpha[i], c.model[i], c.nff[i], c.nb ? c.nfb[i] : 0u, list_head(c, gs)};
+    };
+    uint32_t i0, gs0;
+    const bool a0 = t.first_own(i0, gs0);
+    Own own0{};
+    if (a0) own0 = load_own(i0, gs0);
+    // two separate 16-byte-strided arrays: a random 64-lane ds_read_b128 then spreads over all 16 bank groups
+    // (an interleaved 32-byte record would confine each read to 8 of them)
     const float4* Lp = nullptr;
     const float4* Lw = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), Lp, Lw);
@@ -86,19 +106,18 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     TileErr E;
     E.init(errtab, c);
     __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
-            mi = c.model[i];
-            const float rho0 = c.rho0_tab[mi];
+            mi = o.mi;
+            const float rho0 = rho0_of(c, mi);
             float div = 0.0f;
-            const uint32_t ncontacts = c.nff[i] + (c.nb ? c.nfb[i] : 0u);
-            if (ncontacts >= c.min_neighbors_for_divergence) {
-                const float4 pi = c.posm[i];
-                const float4 wi = c.w[i];
-                for_each_ff(c, i, gs, [&](uint32_t s) { return RecPW{Lp[s], Lw[s]}; }, [&](const RecPW& r) {
+            if (o.cnt + o.cntb >= c.min_neighbors_for_divergence) {
+                const float4 pi = o.pi, wi = o.wi;
+                for_each_ff(c, gs, o.cnt, o.lh, [&](uint32_t s) { return RecPW{Lp[s], Lw[s]}; }, [&](const RecPW& r) {
                     const float4 pj = r.p, wj = r.w;
+                    asm volatile("" ::"v"(wj.w));  // keep the read a single ds_read_b128 (a b96 costs 8 LDS cycles, a b128 4)
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                     const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
                     div += ((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g * pj.w;
@@ -111,7 +130,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
                 });
                 div = fmaxf(div, 0.0f);
             }
-            c.kappa[i] = div * c.alpha[i];
+            c.kappa[i] = div * o.alpha;
             err = div / rho0;
         }
         E.add(c, err, mi, active);
@@ -131,6 +150,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    struct Own { float4 pi, d, v; float ki; uint32_t mi, cnt; ListHead lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.dv[i], c.vel[i], c.kappa[i], c.model[i], c.nff[i], list_head(c, gs)};
+    };
+    uint32_t i0, gs0;
+    const bool a0 = t.first_own(i0, gs0);
+    Own own0{};
+    if (a0) own0 = load_own(i0, gs0);
     const float4* Lp = nullptr;
     const float* Lk = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), Lp, Lk);
@@ -138,14 +165,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
     const float4* Bv = nullptr;
     t.stage_boundary(c, Bp, Bv);
     __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
-        const float4 pi = c.posm[i];
-        const uint32_t mi = c.model[i];
-        const float rho0 = c.rho0_tab[mi];
-        const float ki = c.kappa[i];
-        float4 d = c.dv[i];
-        for_each_ff(c, i, gs, [&](uint32_t s) { return RecPK{Lp[s], Lk[s]}; }, [&](const RecPK& r) {
+        const float4 pi = o.pi;
+        const uint32_t mi = o.mi;
+        const float rho0 = rho0_of(c, mi);
+        const float ki = o.ki;
+        float4 d = o.d;
+        for_each_ff(c, gs, o.cnt, o.lh, [&](uint32_t s) { return RecPK{Lp[s], Lk[s]}; }, [&](const RecPK& r) {
             const float4 pj = r.p;
             const float kj = r.k;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -166,7 +193,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
             }
         });
         c.dv[i] = d;
-        const float4 v = c.vel[i];
+        const float4 v = o.v;
         c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
     });
 }
@@ -220,9 +247,21 @@ void launch_integrate(const StepCtx& c, float dt, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, float dt) {
     __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
+    const unsigned long long T0 = __builtin_readcyclecounter();
     Tile t;
     t.setup(c);
     if (t.empty()) { TileErr::zero(c, t.tile); return; }
+    const unsigned long long T1 = __builtin_readcyclecounter();
+    struct Own { float4 pi, wi; float rho, alpha; uint32_t mi, cnt; ListHead lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.w[i], c.rho[i], c.alpha[i], c.model[i], c.nff[i], list_head(c, gs)};
+    };
+    uint32_t i0, gs0;
+    const bool a0 = t.first_own(i0, gs0);
+    Own own0{};
+    if (a0) own0 = load_own(i0, gs0);
+    // two separate 16-byte-strided arrays: a random 64-lane ds_read_b128 then spreads over all 16 bank groups
+    // (an interleaved 32-byte record would confine each read to 8 of them)
     const float4* Lp = nullptr;
     const float4* Lw = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), Lp, Lw);
@@ -231,18 +270,20 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
     t.stage_boundary(c, Bp, Bv);
     TileErr E;
     E.init(errtab, c);
+    const unsigned long long T2 = __builtin_readcyclecounter();
     __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    const unsigned long long T3 = __builtin_readcyclecounter();
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
-            mi = c.model[i];
-            const float rho0 = c.rho0_tab[mi];
-            const float4 pi = c.posm[i];
-            const float4 wi = c.w[i];
+            mi = o.mi;
+            const float rho0 = rho0_of(c, mi);
+            const float4 pi = o.pi, wi = o.wi;
             float delta = 0.0f;
-            for_each_ff(c, i, gs, [&](uint32_t s) { return RecPW{Lp[s], Lw[s]}; }, [&](const RecPW& r) {
+            for_each_ff(c, gs, o.cnt, o.lh, [&](uint32_t s) { return RecPW{Lp[s], Lw[s]}; }, [&](const RecPW& r) {
                 const float4 pj = r.p, wj = r.w;
+                asm volatile("" ::"v"(wj.w));  // keep the read a single ds_read_b128 (a b96 costs 8 LDS cycles, a b128 4)
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
                 delta += pj.w * (((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g);
@@ -254,14 +295,19 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
                 const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
                 delta += pj.w * rho0 * (((wi.x - vj.x) * dx + (wi.y - vj.y) * dy + (wi.z - vj.z) * dz) * g);
             });
-            const float rs = c.rho[i] + delta * dt;
+            const float rs = o.rho + delta * dt;
             if (!(rs != 0.0f)) atomicOr(c.flags, 1u);  // assert!(!predicted_density.is_zero()) :145 (also catches NaN)
             err = (rs < rho0) ? 0.0f : rs / rho0 - 1.0f;
-            c.kappa[i] = (rs - rho0) * c.alpha[i];
+            c.kappa[i] = (rs - rho0) * o.alpha;
         }
         E.add(c, err, mi, active);
     });
+    const unsigned long long T4 = __builtin_readcyclecounter();
     E.finish(c, t.tile);
+    if (c.dbg && threadIdx.x == 0) {
+        unsigned long long* d = c.dbg + (size_t)t.tile * 8;
+        d[0] = T0; d[1] = T1; d[2] = T2; d[3] = T3; d[4] = T4; d[5] = __builtin_readcyclecounter(); d[6] = t.S; d[7] = t.own_end - t.own_begin;
+    }
 }
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_LAUNCH_TILE(k_pred_density, c, L, L.bytes(32, 32, 4), s, c, dt);
@@ -275,6 +321,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    struct Own { float4 pi, d, v; float ki; uint32_t mi, cnt; ListHead lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.dv[i], c.vel[i], c.kappa[i], c.model[i], c.nff[i], list_head(c, gs)};
+    };
+    uint32_t i0, gs0;
+    const bool a0 = t.first_own(i0, gs0);
+    Own own0{};
+    if (a0) own0 = load_own(i0, gs0);
     const float4* Lp = nullptr;
     const float* Lk = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), Lp, Lk);
@@ -282,15 +336,15 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
     const float4* Bv = nullptr;
     t.stage_boundary(c, Bp, Bv);
     __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
-        const float4 pi = c.posm[i];
-        const uint32_t mi = c.model[i];
-        const float rho0 = c.rho0_tab[mi];
-        const float ki = c.kappa[i];
+        const float4 pi = o.pi;
+        const uint32_t mi = o.mi;
+        const float rho0 = rho0_of(c, mi);
+        const float ki = o.ki;
         const float kip = fmaxf(ki, 0.0f);
-        float4 d = c.dv[i];
-        for_each_ff(c, i, gs, [&](uint32_t s) { return RecPK{Lp[s], Lk[s]}; }, [&](const RecPK& r) {
+        float4 d = o.d;
+        for_each_ff(c, gs, o.cnt, o.lh, [&](uint32_t s) { return RecPK{Lp[s], Lk[s]}; }, [&](const RecPK& r) {
             // k_ij == 0 contributes exactly nothing, so no branch is needed
             const float4 pj = r.p;
             const float kij = kip + fmaxf(r.k, 0.0f);
@@ -314,7 +368,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
             });
         }
         c.dv[i] = d;
-        const float4 v = c.vel[i];
+        const float4 v = o.v;
         c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
     });
 }

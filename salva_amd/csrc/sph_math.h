@@ -71,12 +71,19 @@ __device__ __forceinline__ KernelEval kernel_eval(float r2, const SphConsts& c) 
     return e;
 }
 
-// Gradient factor only.
+// Gradient factor only: g = gnorm * u(q) / r with u = (3q-2) q 6 for q <= 1/2, -6 (1-q)^2 for q <= 1, 0 beyond and for
+// q <= 1e-5 (cubic_spline_kernel.rs:63-77).  Trimmed for the hot loops: r2 is clamped away from 0 so that 1/r stays
+// finite (|d| = 0 then lands in the q <= 1e-5 case, kernel.rs:18-24 gives 0 there too), 1-q is clamped at 0 instead
+// of testing q > 1, and the factor 6 is folded into the constant.
 __device__ __forceinline__ float kernel_grad(float r2, const SphConsts& c) {
-    const bool nz = r2 > c.eps2;
-    const float rinv = nz ? __builtin_amdgcn_rsqf(r2) : 0.0f;
+    const float rinv = __builtin_amdgcn_rsqf(fmaxf(r2, 1.0e-30f));
     const float q = r2 * rinv * c.inv_h;
-    return c.gnorm * cubic_dw_unit(q) * rinv;
+    const float a = (q * 3.0f - 2.0f) * q;
+    const float omq = fmaxf(1.0f - q, 0.0f);
+    const float b = -omq * omq;
+    float u = (q <= 0.5f) ? a : b;
+    u = (q <= 1.0e-5f) ? 0.0f : u;
+    return (c.gnorm * 6.0f) * u * rinv;
 }
 
 // Weight only.

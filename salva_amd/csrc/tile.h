@@ -184,6 +184,30 @@ struct Tile {
         bp = a; bv = b;
     }
 
+    // This wave's first slice: own-particle index / global slice; false if the wave has no slice or the lane is idle.
+    __device__ __forceinline__ bool first_own(uint32_t& i, uint32_t& gs) const {
+        const uint32_t s = threadIdx.x / WAVE, nsl = (own_end - own_begin + WAVE - 1) / WAVE;
+        i = own_begin + s * WAVE + (threadIdx.x & (WAVE - 1));
+        gs = slice_base + s;
+        return s < nsl && i < own_end;
+    }
+    // Like for_own, but the per-particle inputs of the wave's first slice were loaded before the staging barrier
+    // (`pre0`), so their latency overlaps the halo copy; later slices (tiles fuller than the workgroup) load on demand.
+    template <typename Pre, typename LoadOwn, typename Body>
+    __device__ __forceinline__ void for_own_pre(const Pre& pre0, LoadOwn&& load_own, Body&& body) const {
+        const uint32_t nsl = (own_end - own_begin + WAVE - 1) / WAVE;
+        const uint32_t lane = threadIdx.x & (WAVE - 1), nw = blockDim.x / WAVE;
+        bool first = true;
+        for (uint32_t s = threadIdx.x / WAVE; s < nsl; s += nw) {
+            const uint32_t i = own_begin + s * WAVE + lane, gs = slice_base + s;
+            const bool active = i < own_end;
+            Pre p = pre0;
+            if (!first && active) p = load_own(i, gs);
+            first = false;
+            body(p, i, gs, active);
+        }
+    }
+
     // Visit the tile's own particles, one wave per 64-particle slice: f(i, global_slice, active).
     template <typename F>
     __device__ __forceinline__ void for_own(F&& f) const {
@@ -279,6 +303,42 @@ __device__ __forceinline__ void for_each_slot(const uint32_t* __restrict__ nbr, 
         if (2 * q + 3 < cnt) compute(d3);
     }
     if (q < nq) {  // one dword left
+        const uint32_t a = n0;
+        const auto d0 = load(a & 0xffffu);
+        const auto d1 = load(a >> 16);
+        compute(d0);
+        if (2 * q + 1 < cnt) compute(d1);
+    }
+}
+// the first two dwords of a particle's fluid-fluid list, loadable before the staging barrier (the ELL block of every
+// slice is allocated, so the read is always in bounds; its content is ignored when the list is shorter)
+struct ListHead { uint32_t n0, n1; };
+__device__ __forceinline__ ListHead list_head(const StepCtx& c, uint32_t gslice) {
+    const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
+    return ListHead{p[0], p[WAVE]};
+}
+template <typename L, typename C>
+__device__ __forceinline__ void for_each_ff(const StepCtx& c, uint32_t gslice, uint32_t cnt, const ListHead& lh, L&& load,
+                                            C&& compute) {
+    if (cnt == 0) return;
+    const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
+    const uint32_t nq = (cnt + 1) >> 1;
+    uint32_t q = 0;
+    uint32_t n0 = lh.n0, n1 = lh.n1;
+    for (; q + 2 <= nq; q += 2) {
+        const uint32_t a = n0, b = n1;
+        if (q + 2 < nq) n0 = p[(size_t)(q + 2) * WAVE];
+        if (q + 3 < nq) n1 = p[(size_t)(q + 3) * WAVE];
+        const auto d0 = load(a & 0xffffu);
+        const auto d1 = load(a >> 16);
+        const auto d2 = load(b & 0xffffu);
+        const auto d3 = load(b >> 16);
+        compute(d0);
+        compute(d1);
+        compute(d2);
+        if (2 * q + 3 < cnt) compute(d3);
+    }
+    if (q < nq) {
         const uint32_t a = n0;
         const auto d0 = load(a & 0xffffu);
         const auto d1 = load(a >> 16);

@@ -416,7 +416,7 @@ StepCtx World::make_ctx() {
     c.gb = TileGrid{gb.o[0], gb.o[1], gb.o[2], gb.nt[0], gb.nt[1], gb.nt[2], cell_start_b.p};
     c.nmodels = (uint32_t)std::max<size_t>(fluids.size(), 1);
     c.nbmodels = (uint32_t)std::max<size_t>(bounds.size(), 1);
-    c.rho0_tab = rho0_tab.p; c.ff_ok = ff_ok.p; c.fb_ok = fb_ok.p; c.bb_ok = bb_ok.p;
+    c.rho0_tab = rho0_tab.p; c.rho0_single = fluids.empty() ? 1000.0f : fluids[0].density0; c.ff_ok = ff_ok.p; c.fb_ok = fb_ok.p; c.bb_ok = bb_ok.p;
     c.partials = partials.p;
     c.flags = d_flags.p;
     c.min_neighbors_for_divergence = 20;  // dfsph_solver.rs:62 (DIM == 3)
@@ -861,6 +861,28 @@ float World::time_pred_density(int reps) {
     use_device();
     if (!have_last_ctx || !sorted_valid || n == 0) throw HipError(SALVA_HIP_E_INVALID, "no completed step to time");
     if (reps < 1) reps = 1;
+    if (getenv("SALVA_HIP_TILE_TIMING")) {
+        DevBuf<unsigned long long> dbg;
+        const size_t nt = gf.ntiles();
+        dbg.ensure(nt * 8);
+        SALVA_HIP_CHECK(hipMemsetAsync(dbg.p, 0, nt * 8 * sizeof(unsigned long long), stream));
+        StepCtx cd = last_ctx;
+        cd.dbg = dbg.p;
+        launch_pred_density(cd, lds, last_dt, stream);
+        std::vector<unsigned long long> h(nt * 8);
+        SALVA_HIP_CHECK(hipMemcpyAsync(h.data(), dbg.p, nt * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        double ph[5] = {0, 0, 0, 0, 0}; size_t cnt = 0; unsigned long long tmin = ~0ull, tmax = 0;
+        for (size_t t = 0; t < nt; ++t) {
+            const unsigned long long* d = &h[t * 8];
+            if (d[5] == 0) continue;
+            for (int k = 0; k < 5; ++k) ph[k] += (double)(d[k + 1] - d[k]);
+            tmin = std::min(tmin, d[0]); tmax = std::max(tmax, d[5]);
+            ++cnt;
+        }
+        fprintf(stderr, "[tile timing] %zu tiles: setup %.0f | stage issue %.0f | barrier wait %.0f | compute %.0f | finish %.0f cycles (avg per tile); kernel span %.0f cycles\n",
+                cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, (double)(tmax - tmin));
+    }
     launch_pred_density(last_ctx, lds, last_dt, stream);  // warm-up
     SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
     for (int r = 0; r < reps; ++r) launch_pred_density(last_ctx, lds, last_dt, stream);
