@@ -47,33 +47,39 @@ def make_world(fluid, shell, device: int):
     return w, f
 
 
-def cpu_baseline(fluid, shell, steps: int):
-    """The CPU oracle (C++ restatement of salva's CPU path, kind = "port") on the same scene, all host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def cpu_baseline(side: int, steps: int, warmup: int):
+    """The CPU oracle (C++ restatement of salva's CPU path, kind = "port") on a scaled-down copy of the same scene
+    (same spacing, tank, forces, dt, and the same warm-up + step count, so it goes through the same free-fall ->
+    impact regimes and iteration counts), all host cores."""
     from oracle import oracle as O
 
+    fluid, shell = build_scene(side)
     cores = os.cpu_count() or 1
     w = O.OracleWorld(R, 2.0, O.DFSPH, threads=cores)
     fid = w.add_fluid(fluid, 1000.0)
     w.add_xsph(fid, 0.5, 0.0)
     w.add_boundary(shell)
-    w.step(DT, GRAVITY)  # warm-up (allocations)
+    nd = []
+    for _ in range(warmup):
+        w.step(DT, GRAVITY)
     t0 = time.perf_counter()
     for _ in range(steps):
-        w.step(DT, GRAVITY)
+        st = w.step(DT, GRAVITY)
+        nd.append(st.n_div_iters)
     dt = time.perf_counter() - t0
     return {"value": len(fluid) * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of the same {len(fluid)}-particle scene after 1 warm-up step, "
-                      f"oracle/salva_oracle.cpp f32, OpenMP {cores} threads ({dt / steps:.2f} s/step)"}
+            "sample": f"{warmup}+{steps} steps of the same scene scaled to {side}^3 = {len(fluid)} fluid particles "
+                      f"(+{len(shell)} boundary), oracle/salva_oracle.cpp f32, OpenMP {cores} threads, "
+                      f"{dt:.1f} s, mean divergence iterations {float(np.mean(nd)):.1f}"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=50)   # SURVEY.md §8d: 5 warm-up + 50 timed steps
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--side", type=int, default=100, help="particles per edge of the fluid block (100 -> 1M)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-side", type=int, default=32, help="edge of the scaled-down block the CPU baseline runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,7 +132,7 @@ def main():
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(fluid, shell, args.cpu_steps)
+            cpu = cpu_baseline(args.cpu_side, args.steps, args.warmup)
         value = n * world * args.steps / elapsed
         out = {
             "metric": "particle-steps/sec (3D DFSPH)",

@@ -46,6 +46,20 @@ struct TileAcc {
     }
 };
 
+// Device-resident control block of an iterative solve (`for i in 0..max { err = evaluate(); if err <= tol && i >= min
+// { break }; apply(); }`, dfsph_solver.rs:439-463, :474-502).  The host enqueues several iterations at once; once
+// `done` is set every later evaluate / finalize / apply kernel of the batch returns immediately, so the protocol is
+// exactly the reference's while the host reads the block back once per batch instead of once per iteration.
+struct SolveCtl {
+    uint32_t done;       // set by k_finalize_error when the break condition holds
+    uint32_t iters;      // applies executed (DFSPH) / Jacobi iterations completed (IISPH)
+    float err;           // last evaluated error
+    float tol;
+    uint32_t min_iter;
+    uint32_t mode;       // 0: DFSPH protocol (test, then count the apply); 1: IISPH (count the iteration, then test)
+    uint32_t pad[2];
+};
+
 struct StepCtx {
     SphConsts sc;
     int xcd;  // XCD-aware block remap on/off
@@ -100,6 +114,7 @@ struct StepCtx {
     float* partials;     // [nblocks * nmodels] per-block error sums
     uint32_t* flags;     // bit 0: numeric error (zero density / NaN), bit 1: particle outside grid
     uint32_t min_neighbors_for_divergence;
+    const SolveCtl* ctl;       // non-null inside an iterative solve: kernels return at once when ctl->done
     unsigned long long* dbg;   // optional per-tile phase timestamps (k_pred_density, SALVA_HIP_TILE_TIMING=1)
 };
 

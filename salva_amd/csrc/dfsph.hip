@@ -84,6 +84,7 @@ void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s) {
 // the divergence, :370,:382) and the per-particle error D rho_i / rho0.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
+    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
     Tile t;
     t.setup(c);
@@ -147,6 +148,7 @@ void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
 // Also refreshes w_i = v_i + dv_i for the next evaluate pass.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c, float inv_dt_prev) {
+    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     Tile t;
     t.setup(c);
     if (t.empty()) return;
@@ -246,6 +248,7 @@ void launch_integrate(const StepCtx& c, float dt, hipStream_t s) {
 // This is THE representative neighbour-sum kernel of the roofline: N (4K + 52) bytes per launch.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, float dt) {
+    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
     const unsigned long long T0 = __builtin_readcyclecounter();
     Tile t;
@@ -318,6 +321,7 @@ void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream
 // Boundary term only when k_i > 0, with the reaction force delta * (inv_dt * m_i).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, float inv_dt) {
+    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     Tile t;
     t.setup(c);
     if (t.empty()) return;
@@ -409,8 +413,9 @@ void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox_partials,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_finalize_error(const float* __restrict__ partials, unsigned nblocks,
                                                           uint32_t nmodels, const uint32_t* __restrict__ model_counts,
-                                                          float* out_err) {
+                                                          SolveCtl* ctl) {
     __shared__ float red[BLOCK / WAVE];
+    if (ctl->done) return;
     float best = 0.0f;
     for (uint32_t m = 0; m < nmodels; ++m) {
         float s = 0.0f;
@@ -418,11 +423,21 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_error(const float* __restric
         s = block_sum(s, red);
         if (threadIdx.x == 0 && model_counts[m] != 0) best = fmaxf(best, s / (float)model_counts[m]);
     }
-    if (threadIdx.x == 0) *out_err = best;
+    if (threadIdx.x == 0) {
+        ctl->err = best;
+        if (ctl->mode == 0) {
+            if (best <= ctl->tol && ctl->iters >= ctl->min_iter) ctl->done = 1u;
+            else ctl->iters += 1u;  // the apply pass that follows runs
+        } else {
+            const uint32_t i = ctl->iters;
+            ctl->iters = i + 1u;
+            if (best <= ctl->tol && i >= ctl->min_iter) ctl->done = 1u;
+        }
+    }
 }
 void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
-                           float* out_err, hipStream_t s) {
-    k_finalize_error<<<1, BLOCK, 0, s>>>(partials, nblocks, nmodels, model_counts, out_err);
+                           SolveCtl* ctl, hipStream_t s) {
+    k_finalize_error<<<1, BLOCK, 0, s>>>(partials, nblocks, nmodels, model_counts, ctl);
 }
 
 }  // namespace salva

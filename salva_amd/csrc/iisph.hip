@@ -143,6 +143,7 @@ void launch_iisph_aii(const StepCtx& c, const TileLds& L, float dt, hipStream_t 
 
 // compute_dij_pjl (:235-268): sum_j d_ij p_j = dt^2 sum_j grad W_ij (-m_j p_j / rho_j^2)   (fluid neighbours only)
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dij_pj(StepCtx c, float dt, const float* __restrict__ p) {
+    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     Tile t;
     t.setup(c);
     if (t.empty()) return;
@@ -174,6 +175,7 @@ void launch_iisph_dij_pj(const StepCtx& c, const TileLds& L, float dt, const flo
 // compute_next_pressures (:270-353)
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCtx c, float dt, float omega,
                                                                      const float* __restrict__ p, float* __restrict__ p_next) {
+    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
     Tile t;
     t.setup(c);

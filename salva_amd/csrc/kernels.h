@@ -62,9 +62,9 @@ void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s);
 // x += w dt; per-block cell bounds into bbox_partials (6 * num_blocks(n) ints), folded into bbox6
 void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox_partials, int32_t* bbox6, hipStream_t s);
-// err = max_m (sum_b partials[b][m] / count[m]) -> *out_err   (nblocks = ntiles)
+// err = max_m (sum_b partials[b][m] / count[m]) -> ctl->err, then the break test of the solve (nblocks = ntiles)
 void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
-                           float* out_err, hipStream_t s);
+                           SolveCtl* ctl, hipStream_t s);
 
 // ---------------------------------------------------------------- forces.hip
 void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff, float inv_dt_prev, hipStream_t s);

@@ -64,7 +64,9 @@ class World {
     void build_boundary_grid();
     void ensure_cub_temp(size_t bytes);
     StepCtx make_ctx();
-    float read_error();
+    struct SolveResult { uint32_t iters; float err; };
+    template <typename Eval, typename Apply>
+    SolveResult run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval, Apply&& apply);
     void wait_stream();  // low-latency wait for the world's stream (spins on an event)
     void run_forces(const StepCtx& c);
     void dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
@@ -119,6 +121,8 @@ class World {
     DevBuf<uint32_t> d_flags;
     DevBuf<unsigned long long> d_counters;
     Readback* h_rb = nullptr;
+    DevBuf<SolveCtl> d_ctl;      // [0] divergence solve, [1] pressure solve
+    SolveCtl* h_ctl = nullptr;   // pinned: [0..1] read-back, [2..3] initial values
 
     float dt_prev = 0.0f, inv_dt_prev = 0.0f;  // TimestepManager::{dt, inv_dt} persist across steps (timestep_manager.rs:23-34)
     StepCtx last_ctx{};

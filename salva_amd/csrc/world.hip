@@ -115,6 +115,9 @@ World::World(const SalvaHipParams& p) : prm(p) {
     SALVA_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     SALVA_HIP_CHECK(hipHostMalloc((void**)&h_rb, sizeof(Readback), hipHostMallocDefault));
     memset(h_rb, 0, sizeof(Readback));
+    SALVA_HIP_CHECK(hipHostMalloc((void**)&h_ctl, 4 * sizeof(SolveCtl), hipHostMallocDefault));
+    memset(h_ctl, 0, 4 * sizeof(SolveCtl));
+    d_ctl.ensure(2);
     d_rb.ensure(1);
     d_flags.ensure(1);
     d_counters.ensure(4);
@@ -126,6 +129,7 @@ World::~World() {
     (void)hipSetDevice(prm.device);
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
     if (h_rb) (void)hipHostFree(h_rb);
+    if (h_ctl) (void)hipHostFree(h_ctl);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_sync) (void)hipEventDestroy(ev_sync);
 }
@@ -484,11 +488,35 @@ void World::wait_stream() {
     }
 }
 
-float World::read_error() {
-    launch_finalize_error(partials.p, (unsigned)gf.ntiles(), (uint32_t)std::max<size_t>(fluids.size(), 1), model_counts.p, &d_rb.p->err, stream);
-    SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->err, &d_rb.p->err, sizeof(float), hipMemcpyDeviceToHost, stream));
-    wait_stream();
-    return h_rb->err;
+// One iterative solve with the reference's protocol (dfsph_solver.rs:439-463 / :474-502 / iisph_solver.rs:422-456):
+//   for i in 0..max { err = evaluate(); if err <= tol && i >= min { break }; apply(); }
+// The break decision is taken on the device (k_finalize_error -> SolveCtl); iterations are enqueued in growing batches
+// and the control block is read back once per batch.  Kernels enqueued after convergence return immediately.
+template <typename Eval, typename Apply>
+World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval,
+                                    Apply&& apply) {
+    SolveCtl& init = h_ctl[2 + which];
+    init = SolveCtl{0u, 0u, 0.0f, tol, (uint32_t)std::max(min_iter, 0), mode, {0u, 0u}};
+    h_ctl[which] = init;
+    SALVA_HIP_CHECK(hipMemcpyAsync(d_ctl.p + which, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
+    c.ctl = d_ctl.p + which;
+    const unsigned ntiles = (unsigned)gf.ntiles();
+    const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1);
+    int i = 0, batch = 2;
+    while (i < max_iter) {
+        const int nbatch = std::min(batch, max_iter - i);
+        for (int k = 0; k < nbatch; ++k) {
+            eval(c, i + k);
+            launch_finalize_error(partials.p, ntiles, nm, model_counts.p, d_ctl.p + which, stream);
+            apply(c, i + k);
+        }
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_ctl[which], d_ctl.p + which, sizeof(SolveCtl), hipMemcpyDeviceToHost, stream));
+        wait_stream();
+        i += nbatch;
+        if (h_ctl[which].done) break;
+        batch = std::min(batch * 2, 8);
+    }
+    return SolveResult{h_ctl[which].iters, h_ctl[which].err};
 }
 
 // predict_advection's loop over `fluid.nonpressure_forces` (dfsph_solver.rs:580-603): fluids in slot order, forces in list order.
@@ -512,35 +540,25 @@ void World::run_forces(const StepCtx& c) {
 // DFSPHSolver::step (dfsph_solver.rs:667-708)
 void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
     // divergence_solve (:466-503).  NOTE the dt lag: inv_dt is still the previous step's here (0 on the first step).
-    int nd = 0;
-    float err = 0.0f;
-    for (int i = 0; i < prm.max_divergence_iter; ++i) {
-        launch_divergence(c, lds, stream);
-        err = read_error();
-        const float max_err = prm.max_divergence_error * inv_dt_prev * 0.01f;
-        if (err <= max_err && i >= prm.min_divergence_iter) break;
-        launch_divergence_apply(c, lds, inv_dt_prev, stream);
-        ++nd;
-    }
-    st.n_divergence_iters = nd;
-    st.divergence_error = err;
+    const float inv_dt_lag = inv_dt_prev;
+    const SolveResult rd = run_solve(
+        c, 0, prm.max_divergence_error * inv_dt_prev * 0.01f, prm.min_divergence_iter, prm.max_divergence_iter, 0u,
+        [&](const StepCtx& cc, int) { launch_divergence(cc, lds, stream); },
+        [&](const StepCtx& cc, int) { launch_divergence_apply(cc, lds, inv_dt_lag, stream); });
+    st.n_divergence_iters = (int32_t)rd.iters;
+    st.divergence_error = rd.err;
     launch_finish_divergence(c, g[0], g[1], g[2], acc_user, stream);  // update_velocities + dv = 0 + gravity
     run_forces(c);
     // timestep.advance (:702): dt := total step, inv_dt := 1/dt
     const float inv_dt = (dt == 0.0f) ? 0.0f : 1.0f / dt;
     launch_integrate(c, dt, stream);
     // pressure_solve (:432-464)
-    int np = 0;
-    err = 0.0f;
-    for (int i = 0; i < prm.max_pressure_iter; ++i) {
-        launch_pred_density(c, lds, dt, stream);
-        err = read_error();
-        if (err <= prm.max_density_error && i >= prm.min_pressure_iter) break;
-        launch_pressure_apply(c, lds, inv_dt, stream);
-        ++np;
-    }
-    st.n_pressure_iters = np;
-    st.density_error = err;
+    const SolveResult rp = run_solve(
+        c, 1, prm.max_density_error, prm.min_pressure_iter, prm.max_pressure_iter, 0u,
+        [&](const StepCtx& cc, int) { launch_pred_density(cc, lds, dt, stream); },
+        [&](const StepCtx& cc, int) { launch_pressure_apply(cc, lds, inv_dt, stream); });
+    st.n_pressure_iters = (int32_t)rp.iters;
+    st.density_error = rp.err;
     launch_update_positions(c, dt, bbox_partials.p, d_rb.p->bbox, stream);
     dt_prev = dt;
     inv_dt_prev = inv_dt;
@@ -557,21 +575,22 @@ void World::iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStat
     launch_iisph_dii(c, lds, dt, stream);  // also p = 0.5 * p_prev
     launch_iisph_pred_density(c, lds, dt, stream);
     launch_iisph_aii(c, lds, dt, stream);
-    float* p = kappa.p;
-    float* pn = kappa2.p;
-    int it = 0;
-    float err = 0.0f;
+    float* const pa = kappa.p;
+    float* const pb = kappa2.p;
     const float omega = 0.5f;  // :53
-    for (int i = 0; i < prm.max_pressure_iter; ++i) {
-        launch_iisph_dij_pj(c, lds, dt, p, stream);
-        launch_iisph_next_pressure(c, lds, dt, omega, p, pn, stream);
-        err = read_error();
-        std::swap(p, pn);
-        ++it;
-        if (err <= prm.max_density_error && i >= prm.min_pressure_iter) break;
-    }
-    st.n_pressure_iters = it;
-    st.density_error = err;
+    // pressure_solve (:422-456): iteration j reads p_j and writes p_{j+1}; the two buffers alternate (the reference swaps)
+    const SolveResult rp = run_solve(
+        c, 1, prm.max_density_error, prm.min_pressure_iter, prm.max_pressure_iter, 1u,
+        [&](const StepCtx& cc, int j) {
+            const float* pr = (j & 1) ? pb : pa;
+            float* pw = (j & 1) ? pa : pb;
+            launch_iisph_dij_pj(cc, lds, dt, pr, stream);
+            launch_iisph_next_pressure(cc, lds, dt, omega, pr, pw, stream);
+        },
+        [&](const StepCtx&, int) {});
+    st.n_pressure_iters = (int32_t)rp.iters;
+    st.density_error = rp.err;
+    const float* p = (rp.iters & 1u) ? pb : pa;
     launch_iisph_velocity_changes(c, lds, dt, p, stream);
     launch_iisph_finish(c, dt, p, bbox_partials.p, d_rb.p->bbox, stream);
     dt_prev = dt;
@@ -709,7 +728,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[2], stream));
     wait_stream();
     bbox_known = true;
-    last_ctx = c; last_dt = dt; have_last_ctx = true;
+    last_ctx = c; last_ctx.ctl = nullptr; last_dt = dt; have_last_ctx = true;
     if (timers) {
         float a = 0, b = 0;
         (void)hipEventElapsedTime(&a, ev[0], ev[1]);
@@ -868,6 +887,7 @@ float World::time_pred_density(int reps) {
         SALVA_HIP_CHECK(hipMemsetAsync(dbg.p, 0, nt * 8 * sizeof(unsigned long long), stream));
         StepCtx cd = last_ctx;
         cd.dbg = dbg.p;
+        cd.ctl = nullptr;
         launch_pred_density(cd, lds, last_dt, stream);
         std::vector<unsigned long long> h(nt * 8);
         SALVA_HIP_CHECK(hipMemcpyAsync(h.data(), dbg.p, nt * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
