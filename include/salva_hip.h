@@ -170,6 +170,26 @@ uint64_t salva_hip_device_bytes(const SalvaHipWorld* world);
  * (negative on error).  State is not modified (the kernel rewrites the same outputs from the same inputs). */
 float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps);
 
+/* ---- multi-GPU: one process and one world per GPU, the domain cut into slabs of grid-cell planes along x.
+ * No counterpart in the reference (single process).  A world owns the particles whose cell x = floor(x / h) lies in
+ * [cell_lo, cell_hi] (the first / last rank also keep whatever lies beyond their open end); every step it migrates
+ * leavers to rank-1 / rank+1, mirrors its two edge planes there as ghosts, refreshes the ghosts' fields before each
+ * neighbour pass and all-reduces the convergence sums, so iteration counts are global.  Each rank uploads only its own
+ * particles with salva_hip_set_fluid (same fluid slots everywhere) plus the boundary particles within two cells of its
+ * slab; `gid_offset` + upload index is the particle's global id.  After the first step per-fluid host-order access
+ * (salva_hip_get_fluid) is replaced by salva_hip_get_owned. */
+typedef struct SalvaHipComm SalvaHipComm;
+/* RCCL over xGMI: rank 0 creates the 128-byte id and distributes it (torch.distributed, MPI, a file ...) */
+int salva_hip_comm_rccl_unique_id(unsigned char* out128);
+int salva_hip_comm_rccl_create(int32_t rank, int32_t size, const unsigned char* id128, int32_t device, SalvaHipComm** out);
+/* in-process loopback for tests: `size` communicators sharing a mailbox; drive each from its own host thread */
+int salva_hip_comm_loopback_create(int32_t size, SalvaHipComm** out_ranks);
+void salva_hip_comm_destroy(SalvaHipComm* comm);
+int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_lo, int32_t cell_hi, uint32_t gid_offset);
+/* particles currently owned by this rank, in no particular order; returns their number (negative on error) */
+int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* gids, float* positions_xyz,
+                            float* velocities_xyz, uint32_t* fluid_slots);
+
 const char* salva_hip_last_error(void);
 const char* salva_hip_version(void);
 

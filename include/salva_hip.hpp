@@ -1,0 +1,274 @@
+// salva_hip.hpp — header-only C++ mirror of the salva3d host API for the `LiquidWorld::step` path, on top of the C ABI
+// (include/salva_hip.h).  The reference is Rust (no cargo/rustc in this image), so the host side above the ABI is
+// written in C++ with the reference's names, argument meaning and error behaviour:
+//
+//   salva::LiquidWorld              /root/reference/src/liquid_world.rs:17-209
+//   salva::Fluid / Boundary         src/object/fluid.rs:12-185, src/object/boundary.rs:11-84
+//   salva::InteractionGroups        src/object/interaction_groups.rs:6-79
+//   salva::DFSPHSolver/IISPHSolver  src/solver/pressure/dfsph_solver.rs:21-70, iisph_solver.rs:21-64 (pub tuning fields)
+//   salva::XSPHViscosity / ArtificialViscosity / Akinci2013SurfaceTension   src/solver/{viscosity,surface_tension}/*.rs
+//
+// `Fluid`'s pub fields stay plain std::vector members the caller may edit between steps (faucet3.rs:69-104,
+// heightfield3.rs:40); `LiquidWorld::step` uploads what changed (call `mark_dirty()` after in-place edits of
+// positions / velocities / volumes) and refreshes positions / velocities after the step, like the reference whose host
+// arrays are always current.  Panics of the reference (assert!/unwrap) become salva::Error exceptions.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "salva_hip.h"
+
+namespace salva {
+
+using Real = float;
+using Vec3 = std::array<Real, 3>;
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+inline void check(int rc) {
+    if (rc != SALVA_HIP_OK) throw Error(rc, salva_hip_last_error());
+}
+
+struct InteractionGroups {  // interaction_groups.rs:64-79
+    uint32_t memberships = 1u, filter = 0xffffffffu;
+    bool test(const InteractionGroups& rhs) const { return (memberships & rhs.filter) != 0 && (rhs.memberships & filter) != 0; }
+};
+
+// ---- solver::NonPressureForce built-ins (nonpressure_force.rs:10-30)
+struct NonPressureForce {
+    virtual ~NonPressureForce() = default;
+    virtual SalvaHipForceDesc desc() const = 0;  // arbitrary user forces need host contact lists: not on the device path
+};
+struct XSPHViscosity : NonPressureForce {
+    Real fluid_viscosity_coefficient, boundary_viscosity_coefficient;
+    XSPHViscosity(Real f, Real b) : fluid_viscosity_coefficient(f), boundary_viscosity_coefficient(b) {}
+    SalvaHipForceDesc desc() const override {
+        SalvaHipForceDesc d{SALVA_HIP_FORCE_XSPH, {fluid_viscosity_coefficient, boundary_viscosity_coefficient}};
+        return d;
+    }
+};
+struct ArtificialViscosity : NonPressureForce {
+    Real alpha = 1.0f, beta = 0.0f, speed_of_sound = 10.0f;  // artificial_viscosity.rs:29-37
+    Real fluid_viscosity_coefficient, boundary_viscosity_coefficient;
+    ArtificialViscosity(Real f, Real b) : fluid_viscosity_coefficient(f), boundary_viscosity_coefficient(b) {}
+    SalvaHipForceDesc desc() const override {
+        SalvaHipForceDesc d{SALVA_HIP_FORCE_ARTIFICIAL,
+                            {fluid_viscosity_coefficient, boundary_viscosity_coefficient, alpha, beta, speed_of_sound}};
+        return d;
+    }
+};
+struct Akinci2013SurfaceTension : NonPressureForce {
+    Real fluid_tension_coefficient, boundary_adhesion_coefficient;
+    Akinci2013SurfaceTension(Real t, Real a) : fluid_tension_coefficient(t), boundary_adhesion_coefficient(a) {}
+    SalvaHipForceDesc desc() const override {
+        SalvaHipForceDesc d{SALVA_HIP_FORCE_AKINCI2013, {fluid_tension_coefficient, boundary_adhesion_coefficient}};
+        return d;
+    }
+};
+
+// ---- pressure solvers: only the pub tuning fields exist on the host, the passes run on the device
+struct PressureSolver {
+    int kind = SALVA_HIP_SOLVER_DFSPH;
+    int min_pressure_iter = 1, max_pressure_iter = 50;
+    Real max_density_error = 0.05f;
+    int min_divergence_iter = 1, max_divergence_iter = 50;
+    Real max_divergence_error = 0.1f;
+};
+struct DFSPHSolver : PressureSolver { DFSPHSolver() { kind = SALVA_HIP_SOLVER_DFSPH; } };
+struct IISPHSolver : PressureSolver { IISPHSolver() { kind = SALVA_HIP_SOLVER_IISPH; } };
+
+class LiquidWorld;
+
+class Fluid {  // object/fluid.rs
+  public:
+    std::vector<std::shared_ptr<NonPressureForce>> nonpressure_forces;
+    std::vector<Vec3> positions, velocities, accelerations;
+    std::vector<Real> volumes;
+    Real density0;
+    InteractionGroups interaction_groups;
+
+    Fluid(std::vector<Vec3> particle_positions, Real particle_radius, Real density0_, InteractionGroups groups = {})
+        : positions(std::move(particle_positions)), density0(density0_), interaction_groups(groups),
+          particle_radius_(particle_radius) {
+        const size_t n = positions.size();
+        velocities.assign(n, Vec3{0, 0, 0});
+        accelerations.assign(n, Vec3{0, 0, 0});
+        volumes.assign(n, default_particle_volume());
+        deleted_.assign(n, false);
+    }
+    Real particle_radius() const { return particle_radius_; }
+    Real default_particle_volume() const { return particle_radius_ * particle_radius_ * particle_radius_ * 6.4f; }  // fluid.rs:110-120
+    size_t num_particles() const { return positions.size(); }
+    Real particle_mass(size_t i) const { return volumes[i] * density0; }
+    void delete_particle_at_next_timestep(size_t i) { deleted_[i] = true; structural_ = true; }
+    void add_particles(const std::vector<Vec3>& pos, const std::vector<Vec3>* vel = nullptr) {  // fluid.rs:126-150
+        if (vel && vel->size() != pos.size()) throw Error(SALVA_HIP_E_INVALID, "The provided positions and velocities arrays must have the same length.");
+        positions.insert(positions.end(), pos.begin(), pos.end());
+        if (vel) velocities.insert(velocities.end(), vel->begin(), vel->end());
+        velocities.resize(positions.size(), Vec3{0, 0, 0});
+        accelerations.resize(positions.size(), Vec3{0, 0, 0});
+        volumes.resize(positions.size(), default_particle_volume());
+        deleted_.resize(positions.size(), false);
+        structural_ = true;
+    }
+    void transform_by(const Vec3& translation) {
+        for (auto& p : positions) for (int a = 0; a < 3; ++a) p[a] += translation[a];
+        dirty_ |= SALVA_HIP_DIRTY_POSITIONS;
+    }
+    void mark_dirty(uint32_t mask = SALVA_HIP_DIRTY_POSITIONS | SALVA_HIP_DIRTY_VELOCITIES | SALVA_HIP_DIRTY_VOLUMES) { dirty_ |= mask; }
+
+  private:
+    friend class LiquidWorld;
+    Real particle_radius_;
+    std::vector<bool> deleted_;
+    uint32_t dirty_ = SALVA_HIP_DIRTY_ALL;
+    bool structural_ = true;  // particle count changed (new fluid, add_particles, deletions pending)
+};
+
+class Boundary {  // object/boundary.rs
+  public:
+    std::vector<Vec3> positions, velocities;
+    std::vector<Real> volumes;          // V_b, refreshed by LiquidWorld::sync_boundary()
+    std::vector<Vec3> forces;           // filled when wants_forces (boundary.forces = Some(..))
+    bool wants_forces = false;
+    InteractionGroups interaction_groups;
+    explicit Boundary(std::vector<Vec3> particle_positions, InteractionGroups groups = {})
+        : positions(std::move(particle_positions)), interaction_groups(groups) {
+        velocities.assign(positions.size(), Vec3{0, 0, 0});
+        volumes.assign(positions.size(), 0.0f);
+    }
+    size_t num_particles() const { return positions.size(); }
+    void mark_dirty() { dirty_ = true; }
+
+  private:
+    friend class LiquidWorld;
+    bool dirty_ = true;
+};
+
+using FluidHandle = size_t;     // dense index; remove_fluid is a swap-remove like ContiguousArena (contiguous_arena.rs)
+using BoundaryHandle = size_t;
+
+class LiquidWorld {  // liquid_world.rs
+  public:
+    LiquidWorld(const PressureSolver& solver, Real particle_radius, Real smoothing_factor, int device = 0)
+        : particle_radius_(particle_radius) {
+        SalvaHipParams p;
+        salva_hip_default_params(&p);
+        p.particle_radius = particle_radius;
+        p.smoothing_factor = smoothing_factor;
+        p.solver = solver.kind;
+        p.min_pressure_iter = solver.min_pressure_iter; p.max_pressure_iter = solver.max_pressure_iter;
+        p.max_density_error = solver.max_density_error;
+        p.min_divergence_iter = solver.min_divergence_iter; p.max_divergence_iter = solver.max_divergence_iter;
+        p.max_divergence_error = solver.max_divergence_error;
+        p.device = device;
+        check(salva_hip_create(&p, &w_));
+    }
+    ~LiquidWorld() { salva_hip_destroy(w_); }
+    LiquidWorld(const LiquidWorld&) = delete;
+    LiquidWorld& operator=(const LiquidWorld&) = delete;
+
+    FluidHandle add_fluid(Fluid f) { fluids_.push_back(std::move(f)); fluids_.back().structural_ = true; return fluids_.size() - 1; }
+    BoundaryHandle add_boundary(Boundary b) { boundaries_.push_back(std::move(b)); boundaries_.back().dirty_ = true; return boundaries_.size() - 1; }
+    void remove_fluid(FluidHandle h) {
+        if (h < salva_hip_num_fluids(w_)) check(salva_hip_remove_fluid(w_, (uint32_t)h));
+        fluids_[h] = std::move(fluids_.back());
+        fluids_.pop_back();
+    }
+    void remove_boundary(BoundaryHandle h) {
+        if (h < salva_hip_num_boundaries(w_)) check(salva_hip_remove_boundary(w_, (uint32_t)h));
+        boundaries_[h] = std::move(boundaries_.back());
+        boundaries_.pop_back();
+    }
+    std::vector<Fluid>& fluids() { return fluids_; }
+    std::vector<Boundary>& boundaries() { return boundaries_; }
+    Real h() const { return salva_hip_h(w_); }
+    Real particle_radius() const { return particle_radius_; }
+    const SalvaHipStepStats& counters() const { return stats_; }
+
+    // LiquidWorld::step(dt, gravity) — liquid_world.rs:62-158
+    void step(Real dt, const Vec3& gravity) {
+        for (size_t s = 0; s < fluids_.size(); ++s) upload(fluids_[s], (uint32_t)s);
+        for (size_t s = 0; s < boundaries_.size(); ++s) upload(boundaries_[s], (uint32_t)s);
+        const int rc = salva_hip_step(w_, dt, gravity.data(), &stats_);
+        for (size_t s = 0; s < fluids_.size(); ++s) {  // the reference's host arrays are current after every step
+            Fluid& f = fluids_[s];
+            if (f.num_particles())
+                check(salva_hip_get_fluid(w_, (uint32_t)s, f.positions[0].data(), f.velocities[0].data()));
+            for (auto& a : f.accelerations) a = Vec3{0, 0, 0};
+        }
+        check(rc);
+    }
+    // boundary.volumes / boundary.forces after a step
+    void sync_boundary(BoundaryHandle h) {
+        Boundary& b = boundaries_[h];
+        if (!b.num_particles()) return;
+        if (b.wants_forces) b.forces.resize(b.num_particles());
+        check(salva_hip_get_boundary(w_, (uint32_t)h, b.volumes.data(), b.wants_forces ? b.forces[0].data() : nullptr));
+    }
+
+  private:
+    void upload(Fluid& f, uint32_t slot) {
+        std::vector<Vec3> dv;  // solver.velocity_changes of the surviving particles (init_with_fluids, dfsph_solver.rs:526-561)
+        bool have_dv = false;
+        bool any_deleted = false;
+        for (bool d : f.deleted_) any_deleted |= d;
+        if (f.structural_ && slot < salva_hip_num_fluids(w_)) {
+            const uint64_t old_n = salva_hip_fluid_len(w_, slot);
+            if (old_n) {
+                dv.assign(old_n, Vec3{0, 0, 0});
+                check(salva_hip_get_fluid_field(w_, slot, SALVA_HIP_FIELD_VELOCITY_CHANGE, dv[0].data()));
+                dv.resize(f.num_particles(), Vec3{0, 0, 0});
+                have_dv = true;
+            }
+        }
+        if (any_deleted) {  // Fluid::apply_particles_removal (fluid.rs:88-98) = stable compaction (helper.rs:4-12)
+            size_t k = 0;
+            for (size_t i = 0; i < f.positions.size(); ++i) {
+                if (f.deleted_[i]) continue;
+                f.positions[k] = f.positions[i]; f.velocities[k] = f.velocities[i];
+                f.accelerations[k] = f.accelerations[i]; f.volumes[k] = f.volumes[i];
+                if (have_dv) dv[k] = dv[i];
+                ++k;
+            }
+            f.positions.resize(k); f.velocities.resize(k); f.accelerations.resize(k); f.volumes.resize(k);
+            if (have_dv) dv.resize(k);
+            f.deleted_.assign(k, false);
+        }
+        if (f.structural_ || f.dirty_) {
+            const size_t n = f.num_particles();
+            const float* acc = nullptr;
+            for (const Vec3& a : f.accelerations) if (a[0] != 0 || a[1] != 0 || a[2] != 0) { acc = f.accelerations[0].data(); break; }
+            check(salva_hip_set_fluid(w_, slot, n, n ? f.positions[0].data() : nullptr, n ? f.velocities[0].data() : nullptr,
+                                      n ? f.volumes.data() : nullptr, acc, (have_dv && n) ? dv[0].data() : nullptr, f.density0,
+                                      f.interaction_groups.memberships, f.interaction_groups.filter,
+                                      f.structural_ ? (uint32_t)SALVA_HIP_DIRTY_ALL : f.dirty_));
+            f.structural_ = false;
+            f.dirty_ = 0;
+        }
+        std::vector<SalvaHipForceDesc> descs;
+        for (auto& np : f.nonpressure_forces) descs.push_back(np->desc());
+        check(salva_hip_set_fluid_forces(w_, slot, descs.data(), (uint32_t)descs.size()));
+    }
+    void upload(Boundary& b, uint32_t slot) {
+        if (!b.dirty_) return;
+        const size_t n = b.num_particles();
+        check(salva_hip_set_boundary(w_, slot, n, n ? b.positions[0].data() : nullptr, n ? b.velocities[0].data() : nullptr,
+                                     b.interaction_groups.memberships, b.interaction_groups.filter, b.wants_forces ? 1 : 0));
+        b.dirty_ = false;
+    }
+
+    SalvaHipWorld* w_ = nullptr;
+    Real particle_radius_;
+    std::vector<Fluid> fluids_;
+    std::vector<Boundary> boundaries_;
+    SalvaHipStepStats stats_{};
+};
+
+}  // namespace salva

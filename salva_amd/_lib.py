@@ -27,7 +27,8 @@ EXPORTED_SYMBOLS = [
     "salva_hip_num_fluids", "salva_hip_num_boundaries", "salva_hip_fluid_len", "salva_hip_boundary_len",
     "salva_hip_step", "salva_hip_get_fluid", "salva_hip_get_fluid_field", "salva_hip_get_boundary",
     "salva_hip_clear_boundary_forces", "salva_hip_device_bytes", "salva_hip_time_pred_density",
-    "salva_hip_last_error", "salva_hip_version",
+    "salva_hip_last_error", "salva_hip_version", "salva_hip_comm_rccl_unique_id", "salva_hip_comm_rccl_create",
+    "salva_hip_comm_loopback_create", "salva_hip_comm_destroy", "salva_hip_set_domain", "salva_hip_get_owned",
 ]
 
 
@@ -125,6 +126,15 @@ def lib():
     L.salva_hip_device_bytes.restype = u64
     L.salva_hip_time_pred_density.argtypes = [vp, i32]
     L.salva_hip_time_pred_density.restype = f32
+    ubp = C.POINTER(C.c_ubyte)
+    L.salva_hip_comm_rccl_unique_id.argtypes = [ubp]
+    L.salva_hip_comm_rccl_create.argtypes = [i32, i32, ubp, i32, C.POINTER(vp)]
+    L.salva_hip_comm_loopback_create.argtypes = [i32, C.POINTER(vp)]
+    L.salva_hip_comm_destroy.argtypes = [vp]
+    L.salva_hip_comm_destroy.restype = None
+    L.salva_hip_set_domain.argtypes = [vp, vp, i32, i32, u32]
+    L.salva_hip_get_owned.argtypes = [vp, u32, C.POINTER(u32), fp, fp, C.POINTER(u32)]
+    L.salva_hip_get_owned.restype = C.c_int64
     L.salva_hip_last_error.restype = C.c_char_p
     L.salva_hip_version.restype = C.c_char_p
     _lib = L

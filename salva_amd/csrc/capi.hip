@@ -3,6 +3,8 @@
 #include <cstring>
 #include <string>
 
+#include <memory>
+
 #include "world.h"
 
 using salva::World;
@@ -168,6 +170,64 @@ float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps) {
         return SALVA_HIP_OK;
     });
     return rc == SALVA_HIP_OK ? us : (float)rc;
+}
+
+// ---- multi-GPU (x-slab decomposition) -------------------------------------------------------------------------
+struct SalvaHipComm {
+    std::shared_ptr<salva::LoopbackShared> group;  // loopback only
+    salva::Transport* t = nullptr;
+};
+
+int salva_hip_comm_rccl_unique_id(unsigned char* out128) {
+    return guarded([&]() -> int {
+        if (!out128) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        salva::rccl_unique_id(out128);
+        return SALVA_HIP_OK;
+    });
+}
+int salva_hip_comm_rccl_create(int32_t rank, int32_t size, const unsigned char* id128, int32_t device, SalvaHipComm** out) {
+    return guarded([&]() -> int {
+        if (!id128 || !out) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        auto* c = new SalvaHipComm();
+        c->t = salva::rccl_transport(rank, size, id128, device);
+        *out = c;
+        return SALVA_HIP_OK;
+    });
+}
+int salva_hip_comm_loopback_create(int32_t size, SalvaHipComm** out_ranks) {
+    return guarded([&]() -> int {
+        if (size < 1 || !out_ranks) throw salva::HipError(SALVA_HIP_E_INVALID, "bad argument");
+        auto g = salva::loopback_create(size);
+        for (int r = 0; r < size; ++r) {
+            auto* c = new SalvaHipComm();
+            c->group = g;
+            c->t = salva::loopback_transport(g, r);
+            out_ranks[r] = c;
+        }
+        return SALVA_HIP_OK;
+    });
+}
+void salva_hip_comm_destroy(SalvaHipComm* comm) {
+    if (!comm) return;
+    try { delete comm->t; } catch (...) {}
+    delete comm;
+}
+int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_lo, int32_t cell_hi, uint32_t gid_offset) {
+    return guarded([&]() -> int {
+        if (!world || !comm) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        world->w->set_domain(comm->t, cell_lo, cell_hi, gid_offset);
+        return SALVA_HIP_OK;
+    });
+}
+int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* gids, float* positions_xyz, float* velocities_xyz,
+                            uint32_t* fluid_slots) {
+    int64_t count = 0;
+    const int rc = guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        count = (int64_t)world->w->get_owned(capacity, gids, positions_xyz, velocities_xyz, fluid_slots);
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? count : (int64_t)rc;
 }
 
 const char* salva_hip_last_error(void) { return g_last_error.c_str(); }

@@ -1,0 +1,52 @@
+// comm.h — neighbour exchange between the x-slabs of a multi-GPU run (one process / one world per GPU).
+//
+// The reference has no distributed code at all; this layer exists only because the path shards
+// spatially: interactions have range h = one grid cell (contacts.rs:164-165), so a slab needs a one-cell-plane ghost
+// layer from each x-neighbour and nothing else.  Traffic per exchange is the particles of one or two cell planes
+// (10^4-10^5 particles, 4-64 bytes each), point to point between adjacent ranks over xGMI, plus one tiny all-reduce
+// per convergence test.  No large collective is ever needed.
+//
+// Two transports: RCCL (ncclSend/ncclRecv groups + ncclAllReduce on the world's stream) for real multi-GPU runs, and
+// an in-process loopback (one thread per world, device-to-device copies through a shared mailbox) that exercises the
+// identical code path on a single GPU for the tests.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+
+namespace salva {
+
+class Transport {
+  public:
+    virtual ~Transport() = default;
+    virtual int rank() const = 0;
+    virtual int size() const = 0;
+    bool has_lo() const { return rank() > 0; }
+    bool has_hi() const { return rank() + 1 < size(); }
+
+    // Send `n_lo` bytes at `send_lo` to rank-1 and `n_hi` bytes at `send_hi` to rank+1 (device pointers); receive
+    // exactly `m_lo` bytes from rank-1 into `recv_lo` and `m_hi` from rank+1 into `recv_hi`.  Sizes must match the
+    // peers'.  Enqueued on / ordered with `s`; the data is usable by work enqueued on `s` afterwards.
+    virtual void sendrecv(const void* send_lo, size_t n_lo, const void* send_hi, size_t n_hi, void* recv_lo, size_t m_lo,
+                          void* recv_hi, size_t m_hi, hipStream_t s) = 0;
+    // Host-visible exchange of two counters with the neighbours (blocks until complete): what each will send me.
+    virtual void exchange_counts(const uint64_t to_lo[2], const uint64_t to_hi[2], uint64_t from_lo[2], uint64_t from_hi[2],
+                                 hipStream_t s) = 0;
+    // In-place sum over all ranks of `n` floats / `n` uint64 at device pointer `buf`, ordered with `s`.
+    virtual void allreduce_sum_f32(float* buf, int n, hipStream_t s) = 0;
+    virtual void allreduce_sum_u64(unsigned long long* buf, int n, hipStream_t s) = 0;
+};
+
+// In-process loopback: `size` transports sharing one mailbox; each must be driven from its own host thread.
+struct LoopbackShared;
+std::shared_ptr<LoopbackShared> loopback_create(int size);
+Transport* loopback_transport(const std::shared_ptr<LoopbackShared>& group, int rank);
+
+// RCCL: unique id created by rank 0 (128 bytes) and distributed by the caller (e.g. torch.distributed / MPI / a file).
+constexpr size_t RCCL_ID_BYTES = 128;
+void rccl_unique_id(unsigned char out[RCCL_ID_BYTES]);
+Transport* rccl_transport(int rank, int size, const unsigned char id[RCCL_ID_BYTES], int device);
+
+}  // namespace salva

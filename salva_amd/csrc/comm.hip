@@ -1,0 +1,224 @@
+// comm.hip — the two Transport implementations (comm.h).
+#include "comm.h"
+
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace salva {
+
+// ---------------------------------------------------------------------------------------------------
+// Loopback: N worlds in one process, one host thread each.  A generation-counting barrier separates "everyone has
+// published its send pointers" from "everyone has finished copying".
+// ---------------------------------------------------------------------------------------------------
+struct LoopbackShared {
+    int size;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t generation = 0;
+    struct Box {
+        const void* send_lo = nullptr; size_t n_lo = 0;
+        const void* send_hi = nullptr; size_t n_hi = 0;
+        uint64_t cnt_to_lo[2] = {0, 0}, cnt_to_hi[2] = {0, 0};
+        double red_f64[64];
+        unsigned long long red_u64[64];
+    };
+    std::vector<Box> box;
+    explicit LoopbackShared(int n) : size(n), box(n) {}
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t gen = generation;
+        if (++waiting == size) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+    }
+};
+
+std::shared_ptr<LoopbackShared> loopback_create(int size) { return std::make_shared<LoopbackShared>(size); }
+
+class LoopbackTransport : public Transport {
+  public:
+    LoopbackTransport(std::shared_ptr<LoopbackShared> g, int r) : g_(std::move(g)), rank_(r) {}
+    int rank() const override { return rank_; }
+    int size() const override { return g_->size; }
+
+    void sendrecv(const void* send_lo, size_t n_lo, const void* send_hi, size_t n_hi, void* recv_lo, size_t m_lo, void* recv_hi,
+                  size_t m_hi, hipStream_t s) override {
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));  // my send buffers are complete
+        auto& me = g_->box[rank_];
+        me.send_lo = send_lo; me.n_lo = n_lo; me.send_hi = send_hi; me.n_hi = n_hi;
+        g_->barrier();
+        if (has_lo() && m_lo) {
+            const auto& nb = g_->box[rank_ - 1];
+            if (nb.n_hi != m_lo) throw HipError(-1, "loopback sendrecv: size mismatch with the lower neighbour");
+            SALVA_HIP_CHECK(hipMemcpyAsync(recv_lo, nb.send_hi, m_lo, hipMemcpyDeviceToDevice, s));
+        }
+        if (has_hi() && m_hi) {
+            const auto& nb = g_->box[rank_ + 1];
+            if (nb.n_lo != m_hi) throw HipError(-1, "loopback sendrecv: size mismatch with the upper neighbour");
+            SALVA_HIP_CHECK(hipMemcpyAsync(recv_hi, nb.send_lo, m_hi, hipMemcpyDeviceToDevice, s));
+        }
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        g_->barrier();  // neighbours may now reuse their send buffers
+    }
+
+    void exchange_counts(const uint64_t to_lo[2], const uint64_t to_hi[2], uint64_t from_lo[2], uint64_t from_hi[2],
+                         hipStream_t) override {
+        auto& me = g_->box[rank_];
+        memcpy(me.cnt_to_lo, to_lo, sizeof(me.cnt_to_lo));
+        memcpy(me.cnt_to_hi, to_hi, sizeof(me.cnt_to_hi));
+        g_->barrier();
+        from_lo[0] = from_lo[1] = from_hi[0] = from_hi[1] = 0;
+        if (has_lo()) memcpy(from_lo, g_->box[rank_ - 1].cnt_to_hi, 2 * sizeof(uint64_t));
+        if (has_hi()) memcpy(from_hi, g_->box[rank_ + 1].cnt_to_lo, 2 * sizeof(uint64_t));
+        g_->barrier();
+    }
+
+    void allreduce_sum_f32(float* buf, int n, hipStream_t s) override {
+        if (n > 64) throw HipError(-2, "loopback allreduce: too many values");
+        float h[64];
+        SALVA_HIP_CHECK(hipMemcpyAsync(h, buf, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        auto& me = g_->box[rank_];
+        for (int k = 0; k < n; ++k) me.red_f64[k] = h[k];
+        g_->barrier();
+        for (int k = 0; k < n; ++k) {  // every rank adds in rank order: identical result everywhere
+            float acc = 0.0f;
+            for (int r = 0; r < g_->size; ++r) acc += (float)g_->box[r].red_f64[k];
+            h[k] = acc;
+        }
+        g_->barrier();
+        SALVA_HIP_CHECK(hipMemcpyAsync(buf, h, n * sizeof(float), hipMemcpyHostToDevice, s));
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    void allreduce_sum_u64(unsigned long long* buf, int n, hipStream_t s) override {
+        if (n > 64) throw HipError(-2, "loopback allreduce: too many values");
+        unsigned long long h[64];
+        SALVA_HIP_CHECK(hipMemcpyAsync(h, buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        auto& me = g_->box[rank_];
+        for (int k = 0; k < n; ++k) me.red_u64[k] = h[k];
+        g_->barrier();
+        for (int k = 0; k < n; ++k) {
+            unsigned long long acc = 0;
+            for (int r = 0; r < g_->size; ++r) acc += g_->box[r].red_u64[k];
+            h[k] = acc;
+        }
+        g_->barrier();
+        SALVA_HIP_CHECK(hipMemcpyAsync(buf, h, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+    }
+
+  private:
+    std::shared_ptr<LoopbackShared> g_;
+    int rank_;
+};
+
+Transport* loopback_transport(const std::shared_ptr<LoopbackShared>& group, int rank) {
+    if (!group || rank < 0 || rank >= group->size) throw HipError(-2, "loopback transport: bad rank");
+    return new LoopbackTransport(group, rank);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RCCL over xGMI: point-to-point with the two slab neighbours, grouped so both directions progress together.
+// ---------------------------------------------------------------------------------------------------
+#define SALVA_NCCL_CHECK(expr)                                                                        \
+    do {                                                                                              \
+        ncclResult_t _r = (expr);                                                                     \
+        if (_r != ncclSuccess) {                                                                      \
+            char _b[256];                                                                             \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(_r), __FILE__, __LINE__); \
+            throw ::salva::HipError(-1, _b);                                                          \
+        }                                                                                             \
+    } while (0)
+
+void rccl_unique_id(unsigned char out[RCCL_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == RCCL_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    SALVA_NCCL_CHECK(ncclGetUniqueId(&id));
+    memcpy(out, &id, RCCL_ID_BYTES);
+}
+
+class RcclTransport : public Transport {
+  public:
+    RcclTransport(int rank, int size, const unsigned char idb[RCCL_ID_BYTES], int device) : rank_(rank), size_(size) {
+        SALVA_HIP_CHECK(hipSetDevice(device));
+        ncclUniqueId id;
+        memcpy(&id, idb, RCCL_ID_BYTES);
+        SALVA_NCCL_CHECK(ncclCommInitRank(&comm_, size, id, rank));
+        SALVA_HIP_CHECK(hipMalloc((void**)&d_cnt_, 8 * sizeof(uint64_t)));
+        SALVA_HIP_CHECK(hipHostMalloc((void**)&h_cnt_, 8 * sizeof(uint64_t), hipHostMallocDefault));
+    }
+    ~RcclTransport() override {
+        if (comm_) (void)ncclCommDestroy(comm_);
+        if (d_cnt_) (void)hipFree(d_cnt_);
+        if (h_cnt_) (void)hipHostFree(h_cnt_);
+    }
+    int rank() const override { return rank_; }
+    int size() const override { return size_; }
+
+    void sendrecv(const void* send_lo, size_t n_lo, const void* send_hi, size_t n_hi, void* recv_lo, size_t m_lo, void* recv_hi,
+                  size_t m_hi, hipStream_t s) override {
+        SALVA_NCCL_CHECK(ncclGroupStart());
+        if (has_lo()) {
+            if (n_lo) SALVA_NCCL_CHECK(ncclSend(send_lo, n_lo, ncclChar, rank_ - 1, comm_, s));
+            if (m_lo) SALVA_NCCL_CHECK(ncclRecv(recv_lo, m_lo, ncclChar, rank_ - 1, comm_, s));
+        }
+        if (has_hi()) {
+            if (n_hi) SALVA_NCCL_CHECK(ncclSend(send_hi, n_hi, ncclChar, rank_ + 1, comm_, s));
+            if (m_hi) SALVA_NCCL_CHECK(ncclRecv(recv_hi, m_hi, ncclChar, rank_ + 1, comm_, s));
+        }
+        SALVA_NCCL_CHECK(ncclGroupEnd());
+    }
+
+    void exchange_counts(const uint64_t to_lo[2], const uint64_t to_hi[2], uint64_t from_lo[2], uint64_t from_hi[2],
+                         hipStream_t s) override {
+        // d_cnt_: [0..1] to lo, [2..3] to hi, [4..5] from lo, [6..7] from hi
+        h_cnt_[0] = to_lo[0]; h_cnt_[1] = to_lo[1]; h_cnt_[2] = to_hi[0]; h_cnt_[3] = to_hi[1];
+        h_cnt_[4] = h_cnt_[5] = h_cnt_[6] = h_cnt_[7] = 0;
+        SALVA_HIP_CHECK(hipMemcpyAsync(d_cnt_, h_cnt_, 8 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        SALVA_NCCL_CHECK(ncclGroupStart());
+        if (has_lo()) {
+            SALVA_NCCL_CHECK(ncclSend(d_cnt_ + 0, 2, ncclUint64, rank_ - 1, comm_, s));
+            SALVA_NCCL_CHECK(ncclRecv(d_cnt_ + 4, 2, ncclUint64, rank_ - 1, comm_, s));
+        }
+        if (has_hi()) {
+            SALVA_NCCL_CHECK(ncclSend(d_cnt_ + 2, 2, ncclUint64, rank_ + 1, comm_, s));
+            SALVA_NCCL_CHECK(ncclRecv(d_cnt_ + 6, 2, ncclUint64, rank_ + 1, comm_, s));
+        }
+        SALVA_NCCL_CHECK(ncclGroupEnd());
+        SALVA_HIP_CHECK(hipMemcpyAsync(h_cnt_, d_cnt_, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        from_lo[0] = h_cnt_[4]; from_lo[1] = h_cnt_[5]; from_hi[0] = h_cnt_[6]; from_hi[1] = h_cnt_[7];
+    }
+
+    void allreduce_sum_f32(float* buf, int n, hipStream_t s) override {
+        SALVA_NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, comm_, s));
+    }
+    void allreduce_sum_u64(unsigned long long* buf, int n, hipStream_t s) override {
+        SALVA_NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclUint64, ncclSum, comm_, s));
+    }
+
+  private:
+    int rank_, size_;
+    ncclComm_t comm_ = nullptr;
+    uint64_t* d_cnt_ = nullptr;
+    uint64_t* h_cnt_ = nullptr;
+};
+
+Transport* rccl_transport(int rank, int size, const unsigned char id[RCCL_ID_BYTES], int device) {
+    if (size < 1 || rank < 0 || rank >= size) throw HipError(-2, "rccl transport: bad rank / size");
+    return new RcclTransport(rank, size, id, device);
+}
+
+}  // namespace salva

@@ -73,7 +73,8 @@ struct StepCtx {
     float4* w;
     float4* normal;      // Akinci normals (xyz, unused)
     uint32_t* model;
-    uint32_t* perm;      // sorted index -> canonical (host-order) index
+    uint32_t* perm;      // sorted index -> canonical (host-order) index; in a multi-GPU run: global particle id
+    const uint32_t* gtag; // multi-GPU runs only (else nullptr): ghost / border tags, dist.h
     float* rho;
     float* alpha;
     float* kappa;        // DFSPH: div*alpha or (rho* - rho0)*alpha ; IISPH: pressure p

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
             c.kappa[i] = div * o.alpha;
             err = div / rho0;
         }
-        E.add(c, err, mi, active);
+        E.add(c, err, mi, active && !is_ghost(c, i));  // a ghost's error belongs to the rank that owns it
     });
     E.finish(c, t.tile);
 }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
             err = (rs < rho0) ? 0.0f : rs / rho0 - 1.0f;
             c.kappa[i] = (rs - rho0) * o.alpha;
         }
-        E.add(c, err, mi, active);
+        E.add(c, err, mi, active && !is_ghost(c, i));  // a ghost's error belongs to the rank that owns it
     });
     const unsigned long long T4 = __builtin_readcyclecounter();
     E.finish(c, t.tile);
@@ -434,6 +434,42 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_error(const float* __restric
             if (best <= ctl->tol && i >= ctl->min_iter) ctl->done = 1u;
         }
     }
+}
+// multi-GPU: the same reduction split around an all-reduce over the ranks
+__global__ __launch_bounds__(BLOCK) void k_sum_partials(const float* __restrict__ partials, unsigned nblocks, uint32_t nmodels,
+                                                        const SolveCtl* ctl, float* sums) {
+    __shared__ float red[BLOCK / WAVE];
+    if (ctl->done) {  // keep the value finite; k_decide ignores it
+        if (threadIdx.x < nmodels) sums[threadIdx.x] = 0.0f;
+        return;
+    }
+    for (uint32_t m = 0; m < nmodels; ++m) {
+        float s = 0.0f;
+        for (unsigned b = threadIdx.x; b < nblocks; b += BLOCK) s += partials[(size_t)b * nmodels + m];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) sums[m] = s;
+    }
+}
+__global__ void k_decide(const float* __restrict__ sums, uint32_t nmodels, const uint32_t* __restrict__ model_counts, SolveCtl* ctl) {
+    if (threadIdx.x != 0 || ctl->done) return;
+    float best = 0.0f;
+    for (uint32_t m = 0; m < nmodels; ++m)
+        if (model_counts[m] != 0) best = fmaxf(best, sums[m] / (float)model_counts[m]);
+    ctl->err = best;
+    if (ctl->mode == 0) {
+        if (best <= ctl->tol && ctl->iters >= ctl->min_iter) ctl->done = 1u;
+        else ctl->iters += 1u;
+    } else {
+        const uint32_t i = ctl->iters;
+        ctl->iters = i + 1u;
+        if (best <= ctl->tol && i >= ctl->min_iter) ctl->done = 1u;
+    }
+}
+void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmodels, const SolveCtl* ctl, float* sums, hipStream_t s) {
+    k_sum_partials<<<1, BLOCK, 0, s>>>(partials, nblocks, nmodels, ctl, sums);
+}
+void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, hipStream_t s) {
+    k_decide<<<1, 64, 0, s>>>(sums, nmodels, model_counts, ctl);
 }
 void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
                            SolveCtl* ctl, hipStream_t s) {

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(BLOCK) void k_reorder_fluid(uint32_t n, const uint3
     out.dv[i] = d;
     out.model[i] = m;
     out.perm[i] = in.perm[j];
+    if (in.gtag) out.gtag[i] = in.gtag[j];
     // w = v + dv: what compute_divergences gathers (dfsph_solver.rs:323-324); model id rides in .w
     w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(m));
 }

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
             }
             p_next[i] = pn;
         }
-        E.add(c, err, mi, active);
+        E.add(c, err, mi, active && !is_ghost(c, i));
     });
     E.finish(c, t.tile);
 }

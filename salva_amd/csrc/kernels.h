@@ -21,6 +21,7 @@ void launch_cell_start(const uint32_t* keys_sorted, uint32_t n, uint32_t ncells,
 struct FluidArrays {
     float4 *posm, *vel, *dv;
     uint32_t *model, *perm;
+    uint32_t* gtag;  // nullptr outside multi-GPU runs
 };
 void launch_reorder_fluid(uint32_t n, const uint32_t* idx, FluidArrays in, FluidArrays out, float4* w, hipStream_t s);
 void launch_reorder_boundary(uint32_t n, const uint32_t* idx, const float4* bpos_in, const float4* bvel_in,
@@ -65,6 +66,9 @@ void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox_partials,
 // err = max_m (sum_b partials[b][m] / count[m]) -> ctl->err, then the break test of the solve (nblocks = ntiles)
 void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
                            SolveCtl* ctl, hipStream_t s);
+// multi-GPU form: per-fluid sums of this rank -> sums[nmodels]; (all-reduce over ranks); break test on the global sums
+void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmodels, const SolveCtl* ctl, float* sums, hipStream_t s);
+void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, hipStream_t s);
 
 // ---------------------------------------------------------------- forces.hip
 void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff, float inv_dt_prev, hipStream_t s);

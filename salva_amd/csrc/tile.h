@@ -361,6 +361,8 @@ __device__ __forceinline__ void for_each_fb(const StepCtx& c, const Tile& t, uin
     for_each_slot(c.nbr_fb, c.cap_fb, gslice, c.nfb[i], [](uint32_t s) { return s; }, f);
 }
 
+__device__ __forceinline__ bool is_ghost(const StepCtx& c, uint32_t i) { return c.gtag && (c.gtag[i] & 0x80000000u); }
+
 // Per-fluid error sums of one tile (par_reduce_sum!, lib.rs:75-83; the per-fluid average is taken by
 // k_finalize_error).  Each wave accumulates its slices, in order, into its own LDS row; the rows are then folded in
 // wave order, so the result does not depend on scheduling.

@@ -7,6 +7,8 @@
 #include "../../include/salva_hip.h"
 #include "common.h"
 #include "device_types.h"
+#include "comm.h"
+#include "dist.h"
 #include "kernels.h"
 
 namespace salva {
@@ -48,6 +50,10 @@ class World {
     void get_boundary(uint32_t slot, float* volumes, float* forces);
     void clear_boundary_forces(uint32_t slot);
     uint64_t device_bytes() const;
+    // multi-GPU: this world owns the cell planes [lo, hi] along x; neighbours are rank-1 / rank+1 of `transport`
+    void set_domain(Transport* transport, int lo, int hi, uint32_t gid_offset);
+    uint64_t get_owned(uint32_t cap, uint32_t* gids, float* pos, float* vel, uint32_t* models);
+    uint32_t owned_count() const { return comm ? n_owned : n; }
     float time_pred_density(int reps);
 
     SalvaHipParams prm;
@@ -72,6 +78,13 @@ class World {
     void dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
     void iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
     FluidArrays arrays(int which);
+    DistArrays dist_arrays(int which);
+    void dist_prepare();        // migration + ghost planes, before the grid is built
+    void dist_build_lists();    // after the cell sort
+    void refresh_f32(float* field);
+    void refresh_f4(float4* field);
+    void ensure_particle_capacity(size_t cap);
+    void finalize_solve(SolveCtl* ctl);
 
     hipStream_t stream = nullptr;
     uint32_t n = 0, nb = 0;
@@ -130,6 +143,19 @@ class World {
     bool have_last_ctx = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_sync = nullptr;
+
+    // ---- multi-GPU slab decomposition (comm.h / dist.h)
+    Transport* comm = nullptr;  // not owned
+    int slab_lo = 0, slab_hi = 0;
+    uint32_t gid_offset = 0, n_owned = 0;
+    bool dist_started = false;
+    DevBuf<uint32_t> gtag[2];
+    DevBuf<DistRec> xsend_lo, xsend_hi, xrecv_lo, xrecv_hi;
+    DevBuf<char> dsel, dpos;
+    DevBuf<uint32_t> send_lo_idx, send_hi_idx, ghost_lo_idx, ghost_hi_idx;
+    uint32_t nborder_lo = 0, nborder_hi = 0, nghost_lo = 0, nghost_hi = 0;
+    DevBuf<float4> fbuf_send, fbuf_recv;
+    DevBuf<float> d_sums;
 };
 
 }  // namespace salva

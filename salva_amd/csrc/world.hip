@@ -150,6 +150,7 @@ uint64_t World::boundary_offset(uint32_t slot) const {
 FluidArrays World::arrays(int which) {
     FluidArrays a;
     a.posm = posm[which].p; a.vel = vel[which].p; a.dv = dv[which].p; a.model = model[which].p; a.perm = perm[which].p;
+    a.gtag = comm ? gtag[which].p : nullptr;
     return a;
 }
 
@@ -158,6 +159,8 @@ void World::ensure_cub_temp(size_t bytes) { cub_temp.ensure(bytes ? bytes : 1, s
 // Bring the canonical (host-order) staging arrays up to date with the sorted working set.
 void World::ensure_staging_current() {
     if (staging_current) return;
+    if (comm && dist_started)
+        throw HipError(SALVA_HIP_E_INVALID, "host-order fluid arrays are not maintained in a multi-GPU run: use salva_hip_get_owned");
     if (sorted_valid && n) {
         launch_sorted_to_stage(n, arrays(cur), st_pos.p, st_vel.p, st_dv.p, stream);
         SALVA_HIP_CHECK(hipStreamSynchronize(stream));
@@ -405,7 +408,7 @@ StepCtx World::make_ctx() {
     c.xcd = 1;
     c.n = n;
     c.posm = posm[cur].p; c.vel = vel[cur].p; c.dv = dv[cur].p; c.acc = acc.p; c.w = w.p; c.normal = normal.p;
-    c.model = model[cur].p; c.perm = perm[cur].p;
+    c.model = model[cur].p; c.perm = perm[cur].p; c.gtag = comm ? gtag[cur].p : nullptr;
     c.rho = rho.p; c.alpha = alpha.p; c.kappa = kappa.p; c.kappa2 = kappa2.p; c.rho_star = rho_star.p; c.aii = aii.p;
     c.dii = dii.p; c.dijpj = dijpj.p;
     c.nff = nff.p; c.nfb = nfb.p;
@@ -500,14 +503,12 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
     h_ctl[which] = init;
     SALVA_HIP_CHECK(hipMemcpyAsync(d_ctl.p + which, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
     c.ctl = d_ctl.p + which;
-    const unsigned ntiles = (unsigned)gf.ntiles();
-    const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1);
     int i = 0, batch = 2;
     while (i < max_iter) {
         const int nbatch = std::min(batch, max_iter - i);
         for (int k = 0; k < nbatch; ++k) {
             eval(c, i + k);
-            launch_finalize_error(partials.p, ntiles, nm, model_counts.p, d_ctl.p + which, stream);
+            finalize_solve(d_ctl.p + which);
             apply(c, i + k);
         }
         SALVA_HIP_CHECK(hipMemcpyAsync(&h_ctl[which], d_ctl.p + which, sizeof(SolveCtl), hipMemcpyDeviceToHost, stream));
@@ -529,6 +530,7 @@ void World::run_forces(const StepCtx& c) {
                 case SALVA_HIP_FORCE_ARTIFICIAL: launch_artificial_viscosity(c, lds, f, d.p[0], d.p[1], d.p[2], d.p[3], d.p[4], stream); break;
                 case SALVA_HIP_FORCE_AKINCI2013:
                     launch_akinci_normals(c, lds, f, stream);
+                    if (comm) refresh_f4(normal.p);
                     launch_akinci_forces(c, lds, f, d.p[0], d.p[1], stream);
                     break;
                 default: break;
@@ -544,7 +546,11 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
     const SolveResult rd = run_solve(
         c, 0, prm.max_divergence_error * inv_dt_prev * 0.01f, prm.min_divergence_iter, prm.max_divergence_iter, 0u,
         [&](const StepCtx& cc, int) { launch_divergence(cc, lds, stream); },
-        [&](const StepCtx& cc, int) { launch_divergence_apply(cc, lds, inv_dt_lag, stream); });
+        [&](const StepCtx& cc, int) {
+            if (comm) refresh_f32(kappa.p);
+            launch_divergence_apply(cc, lds, inv_dt_lag, stream);
+            if (comm) refresh_f4(w.p);
+        });
     st.n_divergence_iters = (int32_t)rd.iters;
     st.divergence_error = rd.err;
     launch_finish_divergence(c, g[0], g[1], g[2], acc_user, stream);  // update_velocities + dv = 0 + gravity
@@ -552,11 +558,16 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
     // timestep.advance (:702): dt := total step, inv_dt := 1/dt
     const float inv_dt = (dt == 0.0f) ? 0.0f : 1.0f / dt;
     launch_integrate(c, dt, stream);
+    if (comm) refresh_f4(w.p);
     // pressure_solve (:432-464)
     const SolveResult rp = run_solve(
         c, 1, prm.max_density_error, prm.min_pressure_iter, prm.max_pressure_iter, 0u,
         [&](const StepCtx& cc, int) { launch_pred_density(cc, lds, dt, stream); },
-        [&](const StepCtx& cc, int) { launch_pressure_apply(cc, lds, inv_dt, stream); });
+        [&](const StepCtx& cc, int) {
+            if (comm) refresh_f32(kappa.p);
+            launch_pressure_apply(cc, lds, inv_dt, stream);
+            if (comm) refresh_f4(w.p);
+        });
     st.n_pressure_iters = (int32_t)rp.iters;
     st.density_error = rp.err;
     launch_update_positions(c, dt, bbox_partials.p, d_rb.p->bbox, stream);
@@ -566,6 +577,7 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
 
 // IISPHSolver::step (iisph_solver.rs:643-711)
 void World::iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
+    if (comm) throw HipError(SALVA_HIP_E_INVALID, "the IISPH solver is not available in multi-GPU runs yet");
     st.n_divergence_iters = 0;
     st.divergence_error = 0.0f;
     launch_iisph_begin(c, g[0], g[1], g[2], acc_user, stream);
@@ -603,7 +615,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     SalvaHipStepStats st{};
     st.nparticles = n;
     // TimestepManager::is_done (timestep_manager.rs:56-58): no substep at all for dt <= eps
-    if (n == 0 || !(dt > FLT_EPSILON)) {
+    if ((n == 0 && !comm) || !(dt > FLT_EPSILON)) {
         if (stats) *stats = st;
         return SALVA_HIP_OK;
     }
@@ -612,24 +624,30 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     upload_tables();
     SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));
 
-    // ---- working-set allocation
-    for (int k = 0; k < 2; ++k) {
-        posm[k].ensure(n); vel[k].ensure(n); dv[k].ensure(n); model[k].ensure(n); perm[k].ensure(n);
-        keys[k].ensure(n); idx[k].ensure(n);
-    }
-    acc.ensure(n); w.ensure(n); rho.ensure(n); alpha.ensure(n); kappa.ensure(n); nff.ensure(n); nfb.ensure(n);
-    bool has_akinci = false;
-    for (auto& f : fluids) for (auto& d : f.forces) has_akinci |= d.kind == SALVA_HIP_FORCE_AKINCI2013;
-    if (has_akinci) normal.ensure(n);
-    if (prm.solver == SALVA_HIP_SOLVER_IISPH) { kappa2.ensure(n); rho_star.ensure(n); aii.ensure(n); dii.ensure(n); dijpj.ensure(n); }
-    bbox_partials.ensure(6 * std::max<size_t>(std::max<size_t>(num_blocks(n), bbox_blocks(n)), 1024));
+    // ---- persistent particle arrays (double buffered for the sort)
+    ensure_particle_capacity(n);
 
     // ---- (re)build the sorted working set from the canonical arrays after host edits
     if (!sorted_valid) {
         launch_stage_to_sorted(n, st_pos.p, st_vel.p, st_dv.p, st_model.p, rho0_tab.p, arrays(cur), stream);
         sorted_valid = true;
+        if (comm) {  // global particle ids replace the host-order permutation; nothing is a ghost yet
+            launch_iota_u32(n, gid_offset, perm[cur].p, stream);
+            SALVA_HIP_CHECK(hipMemsetAsync(gtag[cur].p, 0, (size_t)n * sizeof(uint32_t), stream));
+        }
     }
     staging_current = false;
+    if (comm) { dist_prepare(); st.nparticles = n_owned; }  // migration + ghost planes: changes n
+
+    // ---- per-step scratch
+    acc.ensure(n, stream, false, 1.1f); w.ensure(n, stream, false, 1.1f); rho.ensure(n, stream, false, 1.1f);
+    alpha.ensure(n, stream, false, 1.1f); kappa.ensure(n, stream, false, 1.1f); nff.ensure(n, stream, false, 1.1f);
+    nfb.ensure(n, stream, false, 1.1f);
+    bool has_akinci = false;
+    for (auto& f : fluids) for (auto& d : f.forces) has_akinci |= d.kind == SALVA_HIP_FORCE_AKINCI2013;
+    if (has_akinci) normal.ensure(n, stream, false, 1.1f);
+    if (prm.solver == SALVA_HIP_SOLVER_IISPH) { kappa2.ensure(n); rho_star.ensure(n); aii.ensure(n); dii.ensure(n); dijpj.ensure(n); }
+    bbox_partials.ensure(6 * std::max<size_t>(std::max<size_t>(num_blocks(n), bbox_blocks(n)), 1024));
 
     // ---- cell bounding box (known from the previous step's position update unless the host moved particles)
     if (!bbox_known) {
@@ -661,7 +679,8 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         launch_reorder_fluid(n, idx[1].p, arrays(cur), arrays(cur ^ 1), w.p, stream);
         cur ^= 1;
         launch_cell_start(keys[1].p, n, (uint32_t)ncf, cell_start_f.p, stream);
-        if (acc_user) launch_gather_f4(n, perm[cur].p, st_acc.p, acc.p, stream);
+        if (acc_user && !comm) launch_gather_f4(n, perm[cur].p, st_acc.p, acc.p, stream);
+        if (comm) dist_build_lists();
     }
     build_boundary_grid();  // insert_boundaries_to_grid (liquid_world.rs:106) + boundary volumes, only when dirty
 
@@ -718,6 +737,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
 
     // ---- solver   (evaluate_kernels + compute_densities + solver.step, liquid_world.rs:123-144)
     launch_density_alpha(c, lds, stream);
+    if (comm) refresh_f32(rho.p);
     if (prm.solver == SALVA_HIP_SOLVER_DFSPH) dfsph_solve(c, dt, g, st);
     else iisph_solve(c, dt, g, st);
     acc_user = false;

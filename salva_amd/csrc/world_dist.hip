@@ -1,0 +1,189 @@
+// world_dist.hip — the multi-GPU (x-slab) side of World: migration, ghost planes, per-pass ghost refresh and the
+// globally reduced convergence test.  Protocol and sizes: comm.h, dist.h, DESIGN.md §6.
+#include <algorithm>
+
+#include "world.h"
+
+namespace salva {
+
+__global__ void k_iota_u32(uint32_t n, uint32_t base, uint32_t* out) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = base + i;
+}
+void launch_iota_u32(uint32_t n, uint32_t base, uint32_t* out, hipStream_t s) {
+    if (n) k_iota_u32<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, base, out);
+}
+__global__ void k_pack_owned(uint32_t n, const float4* __restrict__ posm, const float4* __restrict__ vel,
+                             const uint32_t* __restrict__ gtag, const uint32_t* __restrict__ gid, const uint32_t* __restrict__ model,
+                             unsigned int* counter, uint32_t cap, uint32_t* __restrict__ out_gid, float* __restrict__ out_pos,
+                             float* __restrict__ out_vel, uint32_t* __restrict__ out_model) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n || (gtag[i] & GTAG_GHOST)) return;
+    const uint32_t k = atomicAdd(counter, 1u);
+    if (k >= cap) return;
+    const float4 p = posm[i], v = vel[i];
+    out_gid[k] = gid[i];
+    out_model[k] = model[i];
+    out_pos[3 * k] = p.x; out_pos[3 * k + 1] = p.y; out_pos[3 * k + 2] = p.z;
+    out_vel[3 * k] = v.x; out_vel[3 * k + 1] = v.y; out_vel[3 * k + 2] = v.z;
+}
+
+void World::set_domain(Transport* transport, int lo, int hi, uint32_t gid_off) {
+    if (!transport) throw HipError(SALVA_HIP_E_INVALID, "null transport");
+    if (hi - lo < 1) throw HipError(SALVA_HIP_E_INVALID, "a slab must span at least two cell planes");
+    if (prm.solver != SALVA_HIP_SOLVER_DFSPH) throw HipError(SALVA_HIP_E_INVALID, "multi-GPU runs support the DFSPH solver only (so far)");
+    comm = transport;
+    slab_lo = lo; slab_hi = hi; gid_offset = gid_off;
+    sorted_valid = false; bbox_known = false; dist_started = false; tables_dirty = true;
+}
+
+DistArrays World::dist_arrays(int which) {
+    return DistArrays{posm[which].p, vel[which].p, dv[which].p, model[which].p, perm[which].p, gtag[which].p};
+}
+
+// posm / vel / dv / model / perm(gid) / gtag in both buffers, keys and idx: capacity for `cap` particles, contents kept
+void World::ensure_particle_capacity(size_t cap) {
+    const float slack = comm ? 1.25f : 1.0f;
+    for (int k = 0; k < 2; ++k) {
+        posm[k].ensure(cap, stream, true, slack); vel[k].ensure(cap, stream, true, slack); dv[k].ensure(cap, stream, true, slack);
+        model[k].ensure(cap, stream, true, slack); perm[k].ensure(cap, stream, true, slack);
+        keys[k].ensure(cap, stream, false, slack); idx[k].ensure(cap, stream, false, slack);
+        if (comm) gtag[k].ensure(cap, stream, true, slack);
+    }
+}
+
+// Phase 1: drop last step's ghosts, send away what left the slab, take in what entered.  Phase 2: mirror the edge
+// planes on the neighbours.  On return the arrays of `cur` hold [owned | ghosts from lo | ghosts from hi] and n counts all.
+void World::dist_prepare() {
+    // the per-fluid particle counts of the error averages are global and constant (no creation / deletion here)
+    if (!dist_started) {
+        const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1);
+        std::vector<unsigned long long> cnt(nm, 0);
+        for (uint32_t f = 0; f < fluids.size(); ++f) cnt[f] = fluids[f].n;
+        d_counters.ensure(std::max<size_t>(4, nm));
+        SALVA_HIP_CHECK(hipMemcpyAsync(d_counters.p, cnt.data(), nm * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+        comm->allreduce_sum_u64(d_counters.p, (int)nm, stream);
+        SALVA_HIP_CHECK(hipMemcpyAsync(cnt.data(), d_counters.p, nm * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<uint32_t> c32(nm);
+        for (uint32_t f = 0; f < nm; ++f) {
+            if (cnt[f] >= 0xffffffffull) throw HipError(SALVA_HIP_E_CAPACITY, "more than 2^32 particles in one fluid");
+            c32[f] = (uint32_t)cnt[f];
+        }
+        SALVA_HIP_CHECK(hipMemcpyAsync(model_counts.p, c32.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        d_sums.ensure(nm);
+        dist_started = true;
+    }
+    const bool has_lo = comm->has_lo(), has_hi = comm->has_hi();
+    for (int mode = 1; mode <= 2; ++mode) {
+        dsel.ensure(dist_sel_bytes(n), stream, false, 1.25f);
+        dpos.ensure(dist_sel_bytes(n), stream, false, 1.25f);
+        const size_t tb = dist_scan_temp_bytes(n + 1);
+        ensure_cub_temp(tb);
+        uint32_t tot[3] = {0, 0, 0};
+        launch_dist_select(n, posm[cur].p, gtag[cur].p, sc.h, slab_lo, slab_hi, has_lo, has_hi, mode, dsel.p, dpos.p, cub_temp.p, tb,
+                           d_flags.p, tot, stream);
+        xsend_lo.ensure(std::max<uint32_t>(tot[1], 1u), stream, false, 1.25f);
+        xsend_hi.ensure(std::max<uint32_t>(tot[2], 1u), stream, false, 1.25f);
+        launch_dist_pack(n, dist_arrays(cur), dist_arrays(cur ^ 1), dsel.p, dpos.p, mode, xsend_lo.p, xsend_hi.p, stream);
+        const uint64_t to_lo[2] = {tot[1], 0}, to_hi[2] = {tot[2], 0};
+        uint64_t from_lo[2] = {0, 0}, from_hi[2] = {0, 0};
+        comm->exchange_counts(to_lo, to_hi, from_lo, from_hi, stream);
+        const uint32_t base = (mode == 1) ? tot[0] : n;
+        const uint64_t total = (uint64_t)base + from_lo[0] + from_hi[0];
+        if (total >= 0xfffffff0ull) throw HipError(SALVA_HIP_E_CAPACITY, "too many particles in one slab");
+        ensure_particle_capacity(total);
+        xrecv_lo.ensure(std::max<uint64_t>(from_lo[0], 1), stream, false, 1.25f);
+        xrecv_hi.ensure(std::max<uint64_t>(from_hi[0], 1), stream, false, 1.25f);
+        comm->sendrecv(xsend_lo.p, tot[1] * sizeof(DistRec), xsend_hi.p, tot[2] * sizeof(DistRec), xrecv_lo.p,
+                       from_lo[0] * sizeof(DistRec), xrecv_hi.p, from_hi[0] * sizeof(DistRec), stream);
+        if (mode == 1) cur ^= 1;  // the kept particles were compacted into the other buffer
+        DistArrays dst = dist_arrays(cur);
+        launch_dist_unpack((uint32_t)from_lo[0], base, xrecv_lo.p, dst, mode == 2 ? (GTAG_GHOST | GTAG_BORDER_LO) : 0u, stream);
+        launch_dist_unpack((uint32_t)from_hi[0], base + (uint32_t)from_lo[0], xrecv_hi.p, dst,
+                           mode == 2 ? (GTAG_GHOST | GTAG_BORDER_HI) : 0u, stream);
+        if (mode == 1) {
+            n = (uint32_t)total;
+            n_owned = n;
+        } else {
+            nborder_lo = tot[1]; nborder_hi = tot[2];
+            nghost_lo = (uint32_t)from_lo[0]; nghost_hi = (uint32_t)from_hi[0];
+            n = (uint32_t)total;
+        }
+    }
+    if (n == 0) throw HipError(SALVA_HIP_E_INVALID, "a slab without any particle is not supported");
+    send_lo_idx.ensure(std::max(nborder_lo, 1u), stream, false, 1.25f); send_hi_idx.ensure(std::max(nborder_hi, 1u), stream, false, 1.25f);
+    ghost_lo_idx.ensure(std::max(nghost_lo, 1u), stream, false, 1.25f); ghost_hi_idx.ensure(std::max(nghost_hi, 1u), stream, false, 1.25f);
+    fbuf_send.ensure(std::max(nborder_lo + nborder_hi, 1u), stream, false, 1.25f);
+    fbuf_recv.ensure(std::max(nghost_lo + nghost_hi, 1u), stream, false, 1.25f);
+    bbox_known = false;  // ghosts and arrivals are not covered by the box reduced at the end of the last step
+}
+
+void World::dist_build_lists() {
+    launch_dist_lists(n, gtag[cur].p, send_lo_idx.p, send_hi_idx.p, ghost_lo_idx.p, ghost_hi_idx.p, stream);
+}
+
+// Refresh one per-particle field of the ghosts from its owners: gather the mirrored edge-plane particles into a dense
+// buffer, one sendrecv with both neighbours, scatter into the ghost slots.  All on the world's stream.
+void World::refresh_f32(float* field) {
+    float* sb = reinterpret_cast<float*>(fbuf_send.p);
+    float* rb = reinterpret_cast<float*>(fbuf_recv.p);
+    launch_gather_f32(nborder_lo, send_lo_idx.p, field, sb, stream);
+    launch_gather_f32(nborder_hi, send_hi_idx.p, field, sb + nborder_lo, stream);
+    comm->sendrecv(sb, nborder_lo * sizeof(float), sb + nborder_lo, nborder_hi * sizeof(float), rb, nghost_lo * sizeof(float),
+                   rb + nghost_lo, nghost_hi * sizeof(float), stream);
+    launch_scatter_f32(nghost_lo, ghost_lo_idx.p, rb, field, stream);
+    launch_scatter_f32(nghost_hi, ghost_hi_idx.p, rb + nghost_lo, field, stream);
+}
+void World::refresh_f4(float4* field) {
+    float4* sb = fbuf_send.p;
+    float4* rb = fbuf_recv.p;
+    launch_gather_idx_f4(nborder_lo, send_lo_idx.p, field, sb, stream);
+    launch_gather_idx_f4(nborder_hi, send_hi_idx.p, field, sb + nborder_lo, stream);
+    comm->sendrecv(sb, nborder_lo * sizeof(float4), sb + nborder_lo, nborder_hi * sizeof(float4), rb, nghost_lo * sizeof(float4),
+                   rb + nghost_lo, nghost_hi * sizeof(float4), stream);
+    launch_scatter_idx_f4(nghost_lo, ghost_lo_idx.p, rb, field, stream);
+    launch_scatter_idx_f4(nghost_hi, ghost_hi_idx.p, rb + nghost_lo, field, stream);
+}
+
+// Error reduction + break test of an iterative solve; with a transport the per-fluid sums are all-reduced first.
+void World::finalize_solve(SolveCtl* ctl) {
+    const unsigned ntiles = (unsigned)gf.ntiles();
+    const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1);
+    if (!comm) {
+        launch_finalize_error(partials.p, ntiles, nm, model_counts.p, ctl, stream);
+        return;
+    }
+    launch_sum_partials(partials.p, ntiles, nm, ctl, d_sums.p, stream);
+    comm->allreduce_sum_f32(d_sums.p, (int)nm, stream);
+    launch_decide(d_sums.p, nm, model_counts.p, ctl, stream);
+}
+
+// Download the particles this rank owns (unordered): global ids, positions, velocities, fluid slot.  Returns the count.
+uint64_t World::get_owned(uint32_t cap, uint32_t* gids, float* pos, float* vel_out, uint32_t* models) {
+    use_device();
+    if (!comm) throw HipError(SALVA_HIP_E_INVALID, "get_owned is for multi-GPU worlds (set_domain)");
+    if (!dist_started || !sorted_valid) throw HipError(SALVA_HIP_E_INVALID, "no step has run yet");
+    DevBuf<uint32_t> dg, dm;
+    DevBuf<float> dp, dvv;
+    DevBuf<unsigned int> cnt;
+    dg.ensure(std::max(cap, 1u)); dm.ensure(std::max(cap, 1u)); dp.ensure(3 * (size_t)std::max(cap, 1u)); dvv.ensure(3 * (size_t)std::max(cap, 1u));
+    cnt.ensure(1);
+    SALVA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(unsigned int), stream));
+    if (n) k_pack_owned<<<div_up(n, BLOCK), BLOCK, 0, stream>>>(n, posm[cur].p, vel[cur].p, gtag[cur].p, perm[cur].p, model[cur].p, cnt.p,
+                                                               cap, dg.p, dp.p, dvv.p, dm.p);
+    unsigned int h = 0;
+    SALVA_HIP_CHECK(hipMemcpyAsync(&h, cnt.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    const uint32_t m = std::min<uint32_t>(h, cap);
+    if (m) {
+        if (gids) SALVA_HIP_CHECK(hipMemcpy(gids, dg.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (models) SALVA_HIP_CHECK(hipMemcpy(models, dm.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (pos) SALVA_HIP_CHECK(hipMemcpy(pos, dp.p, 3 * (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+        if (vel_out) SALVA_HIP_CHECK(hipMemcpy(vel_out, dvv.p, 3 * (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return h;
+}
+
+}  // namespace salva

@@ -1,0 +1,94 @@
+"""Multi-GPU runs: one process (or, in tests, one host thread) and one `LiquidWorld` per GPU, the domain cut into slabs of
+grid-cell planes along x (include/salva_hip.h, "multi-GPU").  The reference is single-process; the only
+contract kept here is that N slabs step to the same particle states as one world holding everything.
+
+Host-side pieces: the communicator handles and the partition helpers (pure numpy, covered by CPU tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+F32 = np.float32
+
+
+class Comm:
+    """A rank's handle on the slab exchange transport (RCCL over xGMI, or the in-process loopback used by tests)."""
+
+    def __init__(self, handle, rank: int, size: int):
+        self._h, self.rank, self.size = handle, rank, size
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_ubyte * 128)()
+        L.check(L.lib().salva_hip_comm_rccl_unique_id(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def rccl(rank: int, size: int, unique_id: bytes, device: int) -> "Comm":
+        assert len(unique_id) == 128
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        L.check(L.lib().salva_hip_comm_rccl_create(rank, size, buf, device, C.byref(h)))
+        return Comm(h, rank, size)
+
+    @staticmethod
+    def loopback(size: int) -> List["Comm"]:
+        hs = (C.c_void_p * size)()
+        L.check(L.lib().salva_hip_comm_loopback_create(size, hs))
+        return [Comm(C.c_void_p(hs[r]), r, size) for r in range(size)]
+
+    def destroy(self):
+        if self._h:
+            L.lib().salva_hip_comm_destroy(self._h)
+            self._h = None
+
+
+def cell_x(positions: np.ndarray, h: float) -> np.ndarray:
+    """floor(x / h) in f32 arithmetic — the same cell coordinate the device computes (hgrid.rs:63-71)."""
+    x = np.asarray(positions, F32).reshape(-1, 3)[:, 0]
+    return np.floor(x / F32(h)).astype(np.int64)
+
+
+def split_slabs(cx: np.ndarray, nranks: int, min_planes: int = 2) -> List[Tuple[int, int]]:
+    """Cut the occupied cell planes [cx.min(), cx.max()] into `nranks` contiguous slabs [lo, hi] holding about the same
+    number of particles each, every slab at least `min_planes` planes thick (a particle must be in at most one edge
+    plane).  Raises when there are not enough planes."""
+    cx = np.asarray(cx, np.int64)
+    if cx.size == 0:
+        raise ValueError("no particles to partition")
+    lo, hi = int(cx.min()), int(cx.max())
+    planes = hi - lo + 1
+    if planes < nranks * min_planes:
+        raise ValueError(f"{planes} cell planes cannot be cut into {nranks} slabs of >= {min_planes} planes")
+    hist = np.bincount(cx - lo, minlength=planes)
+    csum = np.concatenate([[0], np.cumsum(hist)])
+    cuts = [0]
+    for r in range(1, nranks):
+        target = csum[-1] * r / nranks
+        c = int(np.searchsorted(csum, target, side="left"))
+        c = max(c, cuts[-1] + min_planes)                  # thick enough on the left ...
+        c = min(c, planes - (nranks - r) * min_planes)     # ... and room for the slabs still to come
+        cuts.append(c)
+    cuts.append(planes)
+    return [(lo + cuts[r], lo + cuts[r + 1] - 1) for r in range(nranks)]
+
+
+def owner_of(cx: np.ndarray, slabs: Sequence[Tuple[int, int]]) -> np.ndarray:
+    """Rank owning each cell-x (the first / last slab are open-ended)."""
+    his = np.array([s[1] for s in slabs[:-1]], np.int64)
+    return np.searchsorted(his, np.asarray(cx, np.int64), side="left").astype(np.int32)
+
+
+def boundary_subset(bpos: np.ndarray, h: float, slab: Tuple[int, int], rank: int, nranks: int, margin: int = 2) -> np.ndarray:
+    """Indices of the boundary particles a rank must hold: everything within `margin` cell planes of its slab (1 plane
+    for its particles' contacts + 1 so that those boundary particles see all their own neighbours, i.e. get the same
+    volume as in a single-domain run); open-ended at the two outer ranks."""
+    cx = cell_x(bpos, h)
+    lo = -(1 << 62) if rank == 0 else slab[0] - margin
+    hi = (1 << 62) if rank == nranks - 1 else slab[1] + margin
+    return np.nonzero((cx >= lo) & (cx <= hi))[0]

@@ -544,6 +544,33 @@ class LiquidWorld:
         c.grid_ms, c.solver_ms, c.step_ms = st.grid_ms, st.solver_ms, st.step_ms
         return st
 
+    # ---- multi-GPU (no counterpart in the reference; include/salva_hip.h "multi-GPU")
+    def set_domain(self, comm, cell_lo: int, cell_hi: int, gid_offset: int = 0):
+        """Make this world one x-slab [cell_lo, cell_hi] of a decomposed domain.  Call after adding this rank's fluids
+        and boundaries and before the first step; afterwards particles are read back with `owned()`."""
+        self.sync_to_device()
+        L.check(self._L.salva_hip_set_domain(self._h, comm._h, int(cell_lo), int(cell_hi), int(gid_offset)))
+        self._comm = comm
+
+    def owned(self):
+        """(gids, positions, velocities, fluid slots) of the particles this rank owns after the last step, sorted by gid."""
+        u32p = C.POINTER(C.c_uint32)
+        cap = max(int(self.last_stats.nparticles) + 1024, 1024)
+        while True:
+            gid = np.zeros(cap, np.uint32)
+            slot = np.zeros(cap, np.uint32)
+            pos = np.zeros((cap, 3), F32)
+            vel = np.zeros((cap, 3), F32)
+            m = int(self._L.salva_hip_get_owned(self._h, cap, gid.ctypes.data_as(u32p), _fp(pos), _fp(vel),
+                                                slot.ctypes.data_as(u32p)))
+            if m < 0:
+                L.check(m)
+            if m <= cap:
+                break
+            cap = m
+        o = np.argsort(gid[:m], kind="stable")
+        return gid[:m][o], pos[:m][o], vel[:m][o], slot[:m][o]
+
     # ---- solver scratch (private in the reference; exposed for the parity tests)
     def fluid_field(self, f: Fluid, field: int) -> np.ndarray:
         n = f.num_particles()

@@ -238,3 +238,18 @@ def test_large_block_invariants():
     w2, (fl2,), _ = s.make_hip()
     w2.step(DT, (0.0, 0.0, 0.0))
     assert np.array_equal(fl.positions, fl2.positions) and np.array_equal(w.velocity_changes(fl), w2.velocity_changes(fl2))
+
+
+def test_cpp_mirror_basic3_example():
+    """examples/basic3.cpp drives the scene of examples3d/basic3.rs through include/salva_hip.hpp (the C++ mirror of the
+    salva3d host API) and the C ABI; 120 steps of the dam break must run, keep the fluid above the ground and converge."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "basic3")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "examples")])
+    out = subprocess.run([exe, "120"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    last = out.stdout.strip().splitlines()[-1]
+    assert last.startswith("step 120: 3375 particles"), last
