@@ -756,6 +756,8 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         st.grid_ms = a; st.solver_ms = b; st.step_ms = a + b;
     }
     st.reserved[0] = (float)lds.max_halo_fluid; st.reserved[1] = (float)lds.max_halo_boundary; st.reserved[2] = (float)lds.threads;
+    st.reserved[3] = (float)((double)(h_rb->ncontacts_ff + (nb ? h_rb->ncontacts_fb : 0)) / (double)std::max<uint32_t>(n, 1u));  // list entries per local particle
+    st.reserved[4] = (float)(n - owned_count());  // ghosts
     if (stats) *stats = st;
     if (h_rb->flags & 1u) {
         bbox_known = false;
@@ -792,6 +794,7 @@ void World::get_fluid_field(uint32_t slot, int field, float* out) {
     use_device();
     if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
     if (!out) throw HipError(SALVA_HIP_E_INVALID, "null output");
+    if (comm && dist_started) throw HipError(SALVA_HIP_E_INVALID, "per-fluid host-order access is not available in a multi-GPU run: use salva_hip_get_owned");
     const uint64_t nn = fluids[slot].n, off = fluid_offset(slot);
     if (nn == 0) return;
     const bool vec = field == SALVA_HIP_FIELD_VELOCITY_CHANGE || field == SALVA_HIP_FIELD_ACCELERATION;

@@ -92,3 +92,21 @@ def boundary_subset(bpos: np.ndarray, h: float, slab: Tuple[int, int], rank: int
     lo = -(1 << 62) if rank == 0 else slab[0] - margin
     hi = (1 << 62) if rank == nranks - 1 else slab[1] + margin
     return np.nonzero((cx >= lo) & (cx <= hi))[0]
+
+
+# ---- host mirrors of the device-side selection rules (salva_amd/csrc/dist.hip, k_dist_flags), used by the CPU tests
+def select_migration(cx: np.ndarray, slab: Tuple[int, int], has_lo: bool, has_hi: bool):
+    """Phase 1: (keep, to_lo, to_hi) masks of a rank's owned particles.  A particle beyond an open end stays."""
+    cx = np.asarray(cx, np.int64)
+    to_lo = (cx < slab[0]) if has_lo else np.zeros(len(cx), bool)
+    to_hi = (cx > slab[1]) if has_hi else np.zeros(len(cx), bool)
+    return ~(to_lo | to_hi), to_lo, to_hi
+
+
+def select_ghost_planes(cx: np.ndarray, slab: Tuple[int, int], has_lo: bool, has_hi: bool):
+    """Phase 2: (to_lo, to_hi) masks of the owned particles mirrored on each neighbour: the edge plane facing it
+    (and, at an open-ended slab, nothing more — such a slab has no neighbour on that side)."""
+    cx = np.asarray(cx, np.int64)
+    to_lo = (cx <= slab[0]) if has_lo else np.zeros(len(cx), bool)
+    to_hi = (cx >= slab[1]) if has_hi else np.zeros(len(cx), bool)
+    return to_lo, to_hi

@@ -1,0 +1,122 @@
+"""Worker of tests/test_dist_cpu.py::test_two_rank_protocol_gloo — run under torch.distributed.run with the gloo
+backend, world_size 2, on CPU.  Each rank plays one slab: it runs the host mirror of the migration / ghost-plane
+protocol (salva_amd/dist.py, the rules of csrc/dist.hip) with real point-to-point messages, then checks with the CPU
+oracle that its local set (owned + ghosts) gives every owned particle exactly the contacts the undivided domain gives
+it, and that the all-reduced convergence sums are identical on both ranks.  Prints "OK <rank>" on success."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as td
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+from salva_amd import dist, scenes  # noqa: E402
+
+R, SF = 0.025, 2.0
+H = R * SF * 2
+
+
+def sendrecv_rows(rows_lo, rows_hi, rank, world):
+    """Exchange float64 row blocks with rank-1 / rank+1 (sizes first, then payload); returns (from_lo, from_hi)."""
+    out = [np.zeros((0, rows_lo.shape[1])), np.zeros((0, rows_lo.shape[1]))]
+    for side, peer, rows in ((0, rank - 1, rows_lo), (1, rank + 1, rows_hi)):
+        if peer < 0 or peer >= world:
+            continue
+        cnt_out = torch.tensor([len(rows)], dtype=torch.int64)
+        cnt_in = torch.zeros(1, dtype=torch.int64)
+        payload = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float64))
+        # lower rank sends first: no deadlock with blocking gloo send/recv
+        if rank < peer:
+            td.send(cnt_out, peer); td.recv(cnt_in, peer)
+            if len(rows): td.send(payload, peer)
+            buf = torch.zeros((int(cnt_in), rows.shape[1]), dtype=torch.float64)
+            if int(cnt_in): td.recv(buf, peer)
+        else:
+            td.recv(cnt_in, peer); td.send(cnt_out, peer)
+            buf = torch.zeros((int(cnt_in), rows.shape[1]), dtype=torch.float64)
+            if int(cnt_in): td.recv(buf, peer)
+            if len(rows): td.send(payload, peer)
+        out[side] = buf.numpy()
+    return out
+
+
+def main():
+    td.init_process_group("gloo")
+    rank, world = td.get_rank(), td.get_world_size()
+    assert world == 2
+
+    # the same global scene on both ranks; a deliberately stale assignment so that phase 1 has something to migrate
+    pos, bpos = scenes.tank(16, 6, 6, R, wall_cells=2)
+    pos = scenes.jitter(pos, 0.3 * R, seed=9)
+    gid = np.arange(len(pos))
+    cx = dist.cell_x(pos, H)
+    slabs = dist.split_slabs(cx, world)
+    stale_owner = dist.owner_of(dist.cell_x(pos - np.array([0.6 * H, 0, 0], np.float32), H), slabs)
+    mine = stale_owner == rank
+    rows = np.column_stack([gid[mine], pos[mine].astype(np.float64)])
+
+    # phase 1: migration
+    has_lo, has_hi = rank > 0, rank + 1 < world
+    keep, to_lo, to_hi = dist.select_migration(dist.cell_x(rows[:, 1:4], H), slabs[rank], has_lo, has_hi)
+    from_lo, from_hi = sendrecv_rows(rows[to_lo], rows[to_hi], rank, world)
+    owned = np.vstack([rows[keep], from_lo, from_hi])
+    n_moved = torch.tensor([int(to_lo.sum() + to_hi.sum())])
+    td.all_reduce(n_moved)
+    assert int(n_moved) > 0, "the stale assignment was meant to force migration"
+    ocx = dist.cell_x(owned[:, 1:4], H)
+    assert (dist.owner_of(ocx, slabs) == rank).all(), "after phase 1 every particle sits on its owner"
+    total = torch.tensor([len(owned)])
+    td.all_reduce(total)
+    assert int(total) == len(pos)
+
+    # phase 2: ghost planes
+    g_lo, g_hi = dist.select_ghost_planes(ocx, slabs[rank], has_lo, has_hi)
+    assert not (g_lo & g_hi).any(), "a particle is in at most one edge plane (slabs are >= 2 planes thick)"
+    ghosts_lo, ghosts_hi = sendrecv_rows(owned[g_lo], owned[g_hi], rank, world)
+    local = np.vstack([owned, ghosts_lo, ghosts_hi])
+
+    # the local set reproduces the undivided domain's contacts for every owned particle
+    bsub = dist.boundary_subset(bpos, H, slabs[rank], rank, world)
+
+    def counts(fluid_pos, boundary_pos):
+        w = O.OracleWorld(R, SF, O.DFSPH)
+        f = w.add_fluid(np.asarray(fluid_pos, np.float32), 1000.0)
+        w.add_boundary(np.asarray(boundary_pos, np.float32))
+        w.step(1e-4, (0.0, 0.0, 0.0))
+        return (w.contact_counts(f), w.contact_counts(f, True), w.fluid_scalar(f, "densities"), w.boundary_volumes(0))
+
+    gff, gfb, grho, gvol = counts(pos, bpos)
+    lff, lfb, lrho, lvol = counts(local[:, 1:4], bpos[bsub])
+    og = owned[:, 0].astype(int)
+    no = len(owned)
+    assert (lff[:no] == gff[og]).all(), "fluid-fluid contact counts differ from the undivided domain"
+    assert (lfb[:no] == gfb[og]).all(), "fluid-boundary contact counts differ from the undivided domain"
+    np.testing.assert_allclose(lrho[:no], grho[og], rtol=1e-5)
+    # boundary particles an owned fluid particle can touch (<= 1 plane away) have the undivided domain's volume
+    bcx = dist.cell_x(bpos[bsub], H)
+    lo = -(1 << 60) if rank == 0 else slabs[rank][0] - 1
+    hi = (1 << 60) if rank == world - 1 else slabs[rank][1] + 1
+    near = (bcx >= lo) & (bcx <= hi)
+    np.testing.assert_allclose(lvol[near], gvol[bsub][near], rtol=1e-5)
+
+    # the convergence test is global: same all-reduced sums, hence the same decision, on both ranks
+    err = np.maximum(lrho[:no] / 1000.0 - 1.0, 0.0).sum()
+    s = torch.tensor([err, float(no)], dtype=torch.float64)
+    td.all_reduce(s)
+    mean_err = float(s[0] / s[1])
+    gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    td.all_gather(gathered, torch.tensor([mean_err], dtype=torch.float64))
+    assert all(float(g) == mean_err for g in gathered)
+    np.testing.assert_allclose(mean_err, np.maximum(grho / 1000.0 - 1.0, 0.0).mean(), rtol=1e-5, atol=1e-12)
+
+    td.barrier()
+    print(f"OK {rank}", flush=True)
+    td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,3 +149,30 @@ def test_single_rank_domain_is_the_plain_world(hip_lib):
            [(s.n_divergence_iters, s.n_pressure_iters) for s in ref_stats]
     np.testing.assert_allclose(got_p, ref_p, atol=1e-6)
     np.testing.assert_allclose(got_v, ref_v, atol=1e-5)
+
+
+def test_rccl_transport_single_rank(hip_lib):
+    """The RCCL transport itself (communicator creation, all-reduce, empty neighbour exchange) with a 1-rank
+    communicator — all a 1-GPU box can run; the >1-rank protocol is the loopback-tested one above."""
+    pos, vel, bpos = make_scene(16, 8, 8)
+    ref_p, ref_v, ref_stats = run_single(pos, vel, bpos, 4, False)
+    comm = dist.Comm.rccl(0, 1, dist.Comm.unique_id(), 0)
+    w = LiquidWorld(solver(), R, SF)
+    f = Fluid(pos, R, 1000.0)
+    f.velocities = vel
+    f.nonpressure_forces.append(XSPHViscosity(0.5, 0.0))
+    w.add_fluid(f)
+    w.add_boundary(Boundary(bpos))
+    cx = dist.cell_x(pos, H)
+    w.set_domain(comm, int(cx.min()), int(cx.max()), 0)
+    stats = [w.step(DT, G) for _ in range(4)]
+    gid, p, v, _ = w.owned()
+    assert (gid == np.arange(len(pos))).all()
+    assert [(s.n_divergence_iters, s.n_pressure_iters) for s in stats] == \
+           [(s.n_divergence_iters, s.n_pressure_iters) for s in ref_stats]
+    np.testing.assert_allclose(p, ref_p, atol=1e-6)
+    np.testing.assert_allclose(v, ref_v, atol=1e-5)
+    with pytest.raises(Exception, match="multi-GPU"):
+        _ = f.positions  # host-order access is replaced by owned()
+    del w
+    comm.destroy()
