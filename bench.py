@@ -67,6 +67,23 @@ def make_world(fluid, shell, device: int):
     return w, f
 
 
+def effective_cores() -> int:
+    """Host cores this process may actually use: min(visible CPUs, scheduler affinity, cgroup CPU quota).  (The GPU
+    boxes show 256 CPUs but cap the container at 16; 256 OpenMP threads on a 16-CPU quota run 10x slower than 16.)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(n, 1)
+
+
 def cpu_baseline(side: int, steps: int, warmup: int):
     """The CPU oracle (C++ restatement of salva's CPU path, kind = "port") on a scaled-down copy of the same scene
     (same spacing, tank, forces, dt, and the same warm-up + step count, so it goes through the same free-fall ->
@@ -74,7 +91,7 @@ def cpu_baseline(side: int, steps: int, warmup: int):
     from oracle import oracle as O
 
     fluid, shell = build_scene(side)
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     w = O.OracleWorld(R, 2.0, O.DFSPH, threads=cores)
     fid = w.add_fluid(fluid, 1000.0)
     w.add_xsph(fid, 0.5, 0.0)
@@ -99,7 +116,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)   # 5 warm-up + 50 timed steps
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--side", type=int, default=100, help="particles per edge of the fluid block (100 -> 1M)")
-    ap.add_argument("--cpu-side", type=int, default=32, help="edge of the scaled-down block the CPU baseline runs")
+    ap.add_argument("--cpu-side", type=int, default=48, help="edge of the scaled-down block the CPU baseline runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-slabs", action="store_true",
                     help="take the decomposed (RCCL transport) code path even with one rank; a self-test aid, not a bench mode")

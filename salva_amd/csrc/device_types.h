@@ -91,6 +91,8 @@ struct StepCtx {
     const TileAcc* tile_off;    // [ntiles+1] exclusive prefix of per-tile {halo slots, boundary halo slots, slices}
     const uint32_t* halo_src;   // sorted fluid index of every halo slot of every tile (tile-major)
     const uint32_t* bhalo_src;  // sorted boundary index of every boundary halo slot
+    uint32_t halo_stride;       // > 0: tile t's slot table starts at t * halo_stride (address known before any load
+    uint32_t bhalo_stride;      //      returns); 0: compact tables at tile_off[t].s / .sb
     uint32_t ntiles;
     TileGrid gf;
 

@@ -309,14 +309,15 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     uint32_t sum_ff = 0, sum_fb = 0, max_ff = 0, max_fb = 0;
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
-        if (!active) return;
         uint32_t cnt = 0, cntb = 0;
+        uint32_t self_slot = 0;
+        uint32_t* __restrict__ out = c.nbr_ff + (size_t)gs * c.cap_ff * WAVE + lane;
+        if (active) {
         const float4 pi = c.posm[i];
         const uint32_t mi = c.model[i];
         bool bad = false;
         const int lx = cell_coord(pi.x, c.sc.h, bad) - t.hcx, ly = cell_coord(pi.y, c.sc.h, bad) - t.hcy,
                   lz = cell_coord(pi.z, c.sc.h, bad) - t.hcz;
-        uint32_t* __restrict__ out = c.nbr_ff + (size_t)gs * c.cap_ff * WAVE + lane;
         uint32_t* __restrict__ outb = c.nbr_fb + (size_t)gs * c.cap_fb * WAVE + lane;
         uint32_t pend = 0, pendb = 0;
 #pragma unroll 1
@@ -348,12 +349,24 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
                 }
             }
         }
-        if ((cnt & 1u) && (cnt >> 1) < c.cap_ff) out[(size_t)(cnt >> 1) * WAVE] = pend;
+        // an odd list is padded with the particle's own slot (for_each_ff2: the self contact adds nothing to gradient sums)
+        const int hself = (lx * HY + ly) * HZ + lz;
+        self_slot = tc.lstart[hself] + (i - tc.gstart[hself]);
+        if ((cnt & 1u) && (cnt >> 1) < c.cap_ff) out[(size_t)(cnt >> 1) * WAVE] = pend | (self_slot << 16);
         if ((cntb & 1u) && (cntb >> 1) < c.cap_fb) outb[(size_t)(cntb >> 1) * WAVE] = pendb;
         c.nff[i] = cnt;
         c.nfb[i] = cntb;
         sum_ff += cnt; sum_fb += cntb;
         max_ff = max(max_ff, cnt); max_fb = max(max_fb, cntb);
+        }
+        // Pad every list of the slice with self contacts up to the longest one: the gradient passes then run a
+        // wave-uniform trip count with no per-lane predicates (a lane with a shorter list would idle anyway).
+        const uint32_t nq = (cnt + 1) >> 1;
+        const uint32_t nq_max = min(wave_max_u32(nq), c.cap_ff);
+        if (active) {
+            const uint32_t pad = self_slot | (self_slot << 16);
+            for (uint32_t q = nq; q < nq_max; ++q) out[(size_t)q * WAVE] = pad;
+        }
     });
     // per-tile statistics (integer, order independent)
 #pragma unroll

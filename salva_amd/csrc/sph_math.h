@@ -16,6 +16,8 @@ struct SphConsts {
     float wnorm;   // 8 / (pi h^3)           cubic_spline_kernel.rs:18
     float gnorm;   // wnorm / h              cubic_spline_kernel.rs:78
     float eps2;    // f32::EPSILON^2         kernel.rs:19
+    float tiny_r2; // (1e-5 h)^2: below it the gradient is zero (cubic_spline_kernel.rs:63-65, q <= 1e-5)
+    float g18, g12, sg6;  // 18 gnorm, 12 gnorm, sqrt(6 gnorm): folded constants of kernel_grad2
 };
 
 __host__ inline SphConsts make_sph_consts(float h) {
@@ -26,6 +28,10 @@ __host__ inline SphConsts make_sph_consts(float h) {
     c.wnorm = 8.0f / (3.14159265358979323846f * h * h * h);
     c.gnorm = c.wnorm / h;
     c.eps2 = 1.1920929e-7f * 1.1920929e-7f;
+    c.tiny_r2 = (1.0e-5f * h) * (1.0e-5f * h);
+    c.g18 = 18.0f * c.gnorm;
+    c.g12 = 12.0f * c.gnorm;
+    c.sg6 = sqrtf(6.0f * c.gnorm);
     return c;
 }
 
@@ -84,6 +90,27 @@ __device__ __forceinline__ float kernel_grad(float r2, const SphConsts& c) {
     float u = (q <= 0.5f) ? a : b;
     u = (q <= 1.0e-5f) ? 0.0f : u;
     return (c.gnorm * 6.0f) * u * rinv;
+}
+
+// Two contacts at once in packed f32 (v_pk_mul_f32 / v_pk_fma_f32 issue at the scalar rate and carry two lanes' worth):
+// same function as kernel_grad.  The q <= 1e-5 case is folded into the reciprocal root (rinv := 0 makes q = 0, u = 0 and
+// g = 0), which also covers r2 = 0 without a clamp.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 kernel_grad2(f2 r2, const SphConsts& c) {
+    const float t2 = c.tiny_r2;  // (1e-5 h)^2
+    f2 rinv;
+    rinv.x = (r2.x > t2) ? __builtin_amdgcn_rsqf(r2.x) : 0.0f;
+    rinv.y = (r2.y > t2) ? __builtin_amdgcn_rsqf(r2.y) : 0.0f;
+    const f2 q = r2 * rinv * c.inv_h;
+    const f2 a = (q * c.g18 - c.g12) * q;  // 6 gnorm (3q - 2) q
+    f2 om = c.sg6 - q * c.sg6;             // sqrt(6 gnorm) (1 - q)
+    om.x = fmaxf(om.x, 0.0f);
+    om.y = fmaxf(om.y, 0.0f);
+    const f2 b = -om * om;
+    f2 u;
+    u.x = (q.x <= 0.5f) ? a.x : b.x;
+    u.y = (q.y <= 0.5f) ? a.y : b.y;
+    return u * rinv;
 }
 
 // Weight only.

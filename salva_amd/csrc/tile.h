@@ -45,6 +45,7 @@ struct TileLds {
 // hipFuncSetAttribute costs tens of microseconds of host time: raise a kernel's dynamic-LDS ceiling only when a
 // launch actually needs more than was granted before (48 KiB is the default).
 void raise_tile_lds_limit(const void* kernel, uint32_t bytes);  // world.hip
+uint32_t tile_lds_pad();  // world.hip: SALVA_HIP_LDS_PAD (experiments: extra dynamic LDS per block to force lower occupancy)
 template <typename K>
 inline void ensure_tile_lds(K kernel, uint32_t bytes) {
     if (bytes > 48u * 1024u) raise_tile_lds_limit(reinterpret_cast<const void*>(kernel), bytes);
@@ -52,7 +53,7 @@ inline void ensure_tile_lds(K kernel, uint32_t bytes) {
 #define SALVA_LAUNCH_TILE(kernel, c, L, lds, s, ...)                          \
     do {                                                                   \
         if ((c).n) {                                                       \
-            const uint32_t _lds = (lds);                                   \
+            const uint32_t _lds = (lds) + ::salva::tile_lds_pad();         \
             ::salva::ensure_tile_lds(kernel, _lds);                        \
             kernel<<<(c).ntiles, (L).threads, _lds, s>>>(__VA_ARGS__);     \
             SALVA_HIP_CHECK(hipGetLastError());                            \
@@ -92,6 +93,10 @@ struct Tile {
     uint32_t own_begin, own_end, slice_base;
     uint64_t hoff, hboff; // offsets of this tile's slot tables in halo_src / bhalo_src
     int hcx, hcy, hcz;    // absolute cell coords of halo cell (0,0,0)
+    // slot-table entries fetched speculatively by setup(), before the tile's sizes are known (strided tables only):
+    // the index fetch then overlaps the descriptor fetch and staging is two dependent round trips instead of three
+    static constexpr int PRE = 4;
+    uint32_t pre0, pre1, pre2, pre3, preb;
 
     __device__ __forceinline__ bool empty() const { return own_begin == own_end; }
 
@@ -117,10 +122,22 @@ struct Tile {
         own_begin = g.cell_start[(size_t)tile * TCELLS];
         own_end = g.cell_start[(size_t)tile * TCELLS + TCELLS];
         hcx = g.ox + (int)ttx * TX - 1; hcy = g.oy + (int)tty * TY - 1; hcz = g.oz + (int)ttz * TZ - 1;
+        pre0 = pre1 = pre2 = pre3 = preb = 0u;
+        if (c.halo_stride) {
+            const uint32_t* __restrict__ src = c.halo_src + (size_t)tile * c.halo_stride;
+            const uint32_t s0 = threadIdx.x, nt = blockDim.x, lim = c.halo_stride;
+            if (s0 < lim) pre0 = src[s0];
+            if (s0 + nt < lim) pre1 = src[s0 + nt];
+            if (s0 + 2 * nt < lim) pre2 = src[s0 + 2 * nt];
+            if (s0 + 3 * nt < lim) pre3 = src[s0 + 3 * nt];
+            if (c.bhalo_stride && s0 < c.bhalo_stride) preb = c.bhalo_src[(size_t)tile * c.bhalo_stride + s0];
+        }
         const TileAcc a0 = c.tile_off[tile], a1 = c.tile_off[tile + 1];
         slice_base = a0.nsl;
-        hoff = a0.s; S = (uint32_t)(a1.s - a0.s);
-        hboff = a0.sb; SB = (uint32_t)(a1.sb - a0.sb);
+        S = (uint32_t)(a1.s - a0.s);
+        SB = (uint32_t)(a1.sb - a0.sb);
+        hoff = c.halo_stride ? (uint64_t)tile * c.halo_stride : a0.s;
+        hboff = c.halo_stride ? (uint64_t)tile * c.bhalo_stride : a0.sb;
     }
 
     template <typename T>
@@ -134,12 +151,26 @@ struct Tile {
     template <typename F>
     __device__ __forceinline__ void for_halo(const StepCtx& c, F&& f) const {
         const uint32_t* __restrict__ src = c.halo_src + hoff;
+        if (c.halo_stride) {
+            const uint32_t s0 = threadIdx.x, nt = blockDim.x;
+            if (s0 < S) f(s0, pre0);
+            if (s0 + nt < S) f(s0 + nt, pre1);
+            if (s0 + 2 * nt < S) f(s0 + 2 * nt, pre2);
+            if (s0 + 3 * nt < S) f(s0 + 3 * nt, pre3);
+            for (uint32_t s = s0 + PRE * nt; s < S; s += nt) f(s, src[s]);
+        } else {
 #pragma unroll 4
-        for (uint32_t s = threadIdx.x; s < S; s += blockDim.x) f(s, src[s]);
+            for (uint32_t s = threadIdx.x; s < S; s += blockDim.x) f(s, src[s]);
+        }
     }
     template <typename F>
     __device__ __forceinline__ void for_halo_boundary(const StepCtx& c, F&& f) const {
         const uint32_t* __restrict__ src = c.bhalo_src + hboff;
+        if (c.halo_stride) {
+            if (threadIdx.x < SB) f(threadIdx.x, preb);
+            for (uint32_t s = threadIdx.x + blockDim.x; s < SB; s += blockDim.x) f(s, src[s]);
+            return;
+        }
 #pragma unroll 2
         for (uint32_t s = threadIdx.x; s < SB; s += blockDim.x) f(s, src[s]);
     }
@@ -184,12 +215,16 @@ struct Tile {
         bp = a; bv = b;
     }
 
-    // This wave's first slice: own-particle index / global slice; false if the wave has no slice or the lane is idle.
+    // This wave's first slice: own-particle index / global slice; false if the wave has no slice or the lane is idle —
+    // i / gs then name the tile's first particle / slice, so that the caller can load unconditionally (a conditional
+    // aggregate load makes the compiler park the record in scratch memory: 80 B/lane of dead HBM stores).
     __device__ __forceinline__ bool first_own(uint32_t& i, uint32_t& gs) const {
         const uint32_t s = threadIdx.x / WAVE, nsl = (own_end - own_begin + WAVE - 1) / WAVE;
         i = own_begin + s * WAVE + (threadIdx.x & (WAVE - 1));
         gs = slice_base + s;
-        return s < nsl && i < own_end;
+        const bool ok = s < nsl && i < own_end;
+        if (!ok) { i = own_begin; gs = slice_base; }
+        return ok;
     }
     // Like for_own, but the per-particle inputs of the wave's first slice were loaded before the staging barrier
     // (`pre0`), so their latency overlaps the halo copy; later slices (tiles fuller than the workgroup) load on demand.
@@ -197,13 +232,16 @@ struct Tile {
     __device__ __forceinline__ void for_own_pre(const Pre& pre0, LoadOwn&& load_own, Body&& body) const {
         const uint32_t nsl = (own_end - own_begin + WAVE - 1) / WAVE;
         const uint32_t lane = threadIdx.x & (WAVE - 1), nw = blockDim.x / WAVE;
-        bool first = true;
-        for (uint32_t s = threadIdx.x / WAVE; s < nsl; s += nw) {
+        uint32_t s = threadIdx.x / WAVE;
+        if (s < nsl) {
+            const uint32_t i = own_begin + s * WAVE + lane;
+            body(pre0, i, slice_base + s, i < own_end);
+            s += nw;
+        }
+        for (; s < nsl; s += nw) {  // tiles fuller than the workgroup
             const uint32_t i = own_begin + s * WAVE + lane, gs = slice_base + s;
             const bool active = i < own_end;
-            Pre p = pre0;
-            if (!first && active) p = load_own(i, gs);
-            first = false;
+            const Pre p = load_own(active ? i : own_begin, gs);
             body(p, i, gs, active);
         }
     }
@@ -345,6 +383,56 @@ __device__ __forceinline__ void for_each_ff(const StepCtx& c, uint32_t gslice, u
         compute(d0);
         if (2 * q + 1 < cnt) compute(d1);
     }
+}
+// Pair form for the gradient passes: compute2(A, B) handles two contacts at once (packed f32).  An odd list is padded
+// with the particle's own slot by k_nbr_tile — the self contact has d = 0 and contributes exactly nothing to any
+// gradient sum — so there is no validity test anywhere in the loop.
+// The first LIST_REGS dwords (2 contacts each) of a particle's list, loaded into registers BEFORE the staging barrier:
+// a list dword fetched inside the neighbour loop costs a full HBM/L2 round trip per iteration, which is longer than
+// the arithmetic of the iteration — measured at 15 of 54 us in k_pred_density.  Every ELL row has at least LIST_REGS
+// dwords allocated (cap_ff >= LIST_REGS), so the loads are unconditional; what lies beyond a lane's own list is ignored.
+constexpr int LIST_REGS = 20;
+struct ListRegs { uint32_t d[LIST_REGS]; };
+__device__ __forceinline__ ListRegs list_regs(const StepCtx& c, uint32_t gslice) {
+    const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
+    ListRegs r;
+#pragma unroll
+    for (int k = 0; k < LIST_REGS; ++k) r.d[k] = p[(size_t)k * WAVE];
+    return r;
+}
+// `nq` = dwords of the longest list in the slice (slice_list_dwords below): wave-uniform, so every branch here is scalar.
+template <typename L, typename C2>
+__device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, uint32_t nq, const ListRegs& lr, L&& load,
+                                             C2&& compute2) {
+#pragma unroll
+    for (int k = 0; k < LIST_REGS; k += 2) {
+        if ((uint32_t)k < nq) {
+            const uint32_t a = lr.d[k];
+            const bool two = (uint32_t)(k + 1) < nq;
+            const uint32_t b = two ? lr.d[k + 1] : a;
+            const auto d0 = load(a & 0xffffu);
+            const auto d1 = load(a >> 16);
+            const auto d2 = load(b & 0xffffu);
+            const auto d3 = load(b >> 16);
+            compute2(d0, d1);
+            if (two) compute2(d2, d3);
+        }
+    }
+    if (nq > (uint32_t)LIST_REGS) {  // unusually long lists: the rest comes from memory, one dword ahead
+        const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
+        uint32_t nx = p[(size_t)LIST_REGS * WAVE];
+        for (uint32_t q = LIST_REGS; q < nq; ++q) {
+            const uint32_t a = nx;
+            if (q + 1 < nq) nx = p[(size_t)(q + 1) * WAVE];
+            const auto d0 = load(a & 0xffffu);
+            const auto d1 = load(a >> 16);
+            compute2(d0, d1);
+        }
+    }
+}
+// Wave-uniform list length of a slice in dwords (k_nbr_tile pads the shorter lists with self contacts).  Call from all lanes.
+__device__ __forceinline__ uint32_t slice_list_dwords(uint32_t cnt, bool active) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(active ? ((cnt + 1) >> 1) : 0u));
 }
 template <typename L, typename C>
 __device__ __forceinline__ void for_each_ff(const StepCtx& c, uint32_t i, uint32_t gslice, L&& load, C&& compute) {

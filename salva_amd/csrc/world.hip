@@ -17,6 +17,10 @@
 
 namespace salva {
 
+uint32_t tile_lds_pad() {
+    static const uint32_t pad = [] { const char* e = getenv("SALVA_HIP_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
+    return pad;
+}
 void raise_tile_lds_limit(const void* kernel, uint32_t bytes) {
     if (bytes > 160u * 1024u)
         throw HipError(SALVA_HIP_E_CAPACITY, "a tile's halo does not fit the 160 KiB LDS (particles are compressed far beyond rest density)");
@@ -414,6 +418,7 @@ StepCtx World::make_ctx() {
     c.nff = nff.p; c.nfb = nfb.p;
     c.nbr_ff = nbr_ff.p; c.nbr_fb = nbr_fb.p; c.cap_ff = cap_ff; c.cap_fb = cap_fb;
     c.tile_off = tile_off.p; c.halo_src = halo_src.p; c.bhalo_src = bhalo_src.p;
+    c.halo_stride = halo_stride; c.bhalo_stride = bhalo_stride;
     c.ntiles = (uint32_t)gf.ntiles();
     c.gf = TileGrid{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], cell_start_f.p};
     c.nb = nb;
@@ -707,9 +712,20 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         if (lds.max_halo_fluid >= 65536u || lds.max_halo_boundary >= 65536u)
             throw HipError(SALVA_HIP_E_CAPACITY, "more than 65535 particles in one tile halo");
         if (h_rb->tile_total.nsl > ns_cap) throw HipError(SALVA_HIP_E_HIP, "internal error: slice count exceeds its bound");
-        const bool g1 = halo_src.ensure(h_rb->tile_total.s ? h_rb->tile_total.s : 1, stream, false, 1.2f);
-        const bool g2 = bhalo_src.ensure(h_rb->tile_total.sb ? h_rb->tile_total.sb : 1, stream, false, 1.2f);
-        if (g1 || g2) c = make_ctx();
+        // slot tables: one fixed-stride row per tile when that costs at most ~3x the compact size (dense scenes), so
+        // that a tile kernel can fetch its rows before it knows its sizes; compact rows otherwise (sparse scenes)
+        {
+            const uint64_t st_f = (lds.max_halo_fluid + 63u) & ~63u, st_b = nb ? ((lds.max_halo_boundary + 63u) & ~63u) : 0u;
+            const uint64_t strided = (uint64_t)ntiles * (st_f + st_b), compact = h_rb->tile_total.s + h_rb->tile_total.sb;
+            const bool use = strided <= 3 * compact + (1u << 20) && !getenv("SALVA_HIP_COMPACT_HALO");
+            halo_stride = use ? (uint32_t)st_f : 0u;
+            bhalo_stride = use ? (uint32_t)st_b : 0u;
+        }
+        const size_t need_f = halo_stride ? (size_t)ntiles * halo_stride : (size_t)h_rb->tile_total.s;
+        const size_t need_b = halo_stride ? (size_t)ntiles * bhalo_stride : (size_t)h_rb->tile_total.sb;
+        const bool g1 = halo_src.ensure(need_f ? need_f : 1, stream, false, 1.2f);
+        const bool g2 = bhalo_src.ensure(need_b ? need_b : 1, stream, false, 1.2f);
+        c = make_ctx();
         launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, stream);
 
         // ---- neighbour lists   (compute_contacts, contacts.rs:154-252): one pass into fixed-capacity ELL rows; if a list
@@ -925,6 +941,17 @@ float World::time_pred_density(int reps) {
         }
         fprintf(stderr, "[tile timing] %zu tiles: setup %.0f | stage issue %.0f | barrier wait %.0f | compute %.0f | finish %.0f cycles (avg per tile); kernel span %.0f cycles\n",
                 cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, (double)(tmax - tmin));
+    }
+    if (const char* em = getenv("SALVA_HIP_EXP_MODE")) {
+        const int mode = atoi(em);
+        launch_pd_exp(mode, last_ctx, lds, last_dt, stream);
+        SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
+        for (int r = 0; r < reps; ++r) launch_pd_exp(mode, last_ctx, lds, last_dt, stream);
+        SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        float ms = 0.0f;
+        SALVA_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        return ms * 1000.0f / (float)reps;
     }
     launch_pred_density(last_ctx, lds, last_dt, stream);  // warm-up
     SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));

@@ -9,7 +9,8 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 6 --warmup 2 --no-cpu-baseline $@"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $R/bench.py $ARGS > $OUT/trace.log 2>&1
+# the trace is taken over the bench's own default protocol (5 warm-up + 50 timed steps), the PMC passes over a shorter run
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $R/bench.py --no-cpu-baseline $@ > $OUT/trace.log 2>&1
 KRE='k_pred_density|k_divergence|k_pressure_apply|k_nbr|k_density_alpha|k_xsph|k_tile'
 i=0
 for PMC in \
