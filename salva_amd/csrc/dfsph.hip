@@ -147,16 +147,18 @@ void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // compute_velocity_changes_for_divergence (:358-409): dv_i += sum_j grad W_ij (-(k_i + k_j) m_j)
 //                                                           + sum_b grad W_ib (-k_i V_b rho0), boundary reaction force.
-// Also refreshes w_i = v_i + dv_i for the next evaluate pass.
+// Applied to w_i = v_i + dv_i directly (see the kernel).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c, float inv_dt_prev) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    struct Own { float4 pi, d, v; float ki; uint32_t mi, cnt; ListRegs lh; };
+    // Only w = v + dv is carried through the divergence solve: dv itself is zeroed right after it (:689-691) and v
+    // becomes w (:422-430), so updating w in place saves two 16-byte loads and one store per particle and pass.
+    struct Own { float4 pi, wi; float ki; uint32_t cnt; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.dv[i], c.vel[i], c.kappa[i], c.model[i], c.nff[i], list_regs(c, gs)};
+        return Own{c.posm[i], c.w[i], c.kappa[i], c.nff[i], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -172,10 +174,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
         if (!active) return;
         const float4 pi = o.pi;
-        const uint32_t mi = o.mi;
+        const uint32_t mi = __float_as_uint(o.wi.w);
         const float rho0 = rho0_of(c, mi);
         const float ki = o.ki;
-        float4 d = o.d;
+        float4 d = o.wi;
         f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
         for_each_ff2(c, gs, nqu, o.lh, [&](uint32_t s) { return RecPK{Lp[s], Lk[s]}; }, [&](const RecPK& A, const RecPK& B) {
             const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
@@ -198,9 +200,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
                 apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), ex * fs, ey * fs, ez * fs);
             }
         });
-        c.dv[i] = d;
-        const float4 v = o.v;
-        c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
+        c.w[i] = d;
     });
 }
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
