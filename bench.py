@@ -67,6 +67,22 @@ def make_world(fluid, shell, device: int):
     return w, f
 
 
+def committed_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*/hbm_traffic.json, written by
+    tools/summarize_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same scene, with the
+    gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside this process, so this is the
+    measured figure of the committed profile, not of this run; None if there is none."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "hbm_traffic.json")), reverse=True):
+        try:
+            k = json.load(open(f))["kernels"].get(kernel)
+        except (OSError, ValueError, KeyError):
+            continue
+        if k:
+            return float(k["bytes"]), os.path.relpath(f, ROOT)
+    return None, None
+
+
 def effective_cores() -> int:
     """Host cores this process may actually use: min(visible CPUs, scheduler affinity, cgroup CPU quota).  (The GPU
     boxes show 256 CPUs but cap the container at 16; 256 OpenMP threads on a 16-CPU quota run 10x slower than 16.)"""
@@ -116,7 +132,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)   # 5 warm-up + 50 timed steps
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--side", type=int, default=100, help="particles per edge of the fluid block (100 -> 1M)")
-    ap.add_argument("--cpu-side", type=int, default=48, help="edge of the scaled-down block the CPU baseline runs")
+    ap.add_argument("--cpu-side", type=int, default=64, help="edge of the scaled-down block the CPU baseline runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-slabs", action="store_true",
                     help="take the decomposed (RCCL transport) code path even with one rank; a self-test aid, not a bench mode")
@@ -183,8 +199,9 @@ def main():
         kbar = float(st.reserved[3])
     algo_bytes = n * (4.0 * kbar + 52.0)  # k_pred_density moves N (4K + 52) bytes per launch
     achieved = algo_bytes / (kernel_us * 1e-6) / 1e9
+    traffic, traffic_src = committed_traffic("k_pred_density") if n == 1000000 else (None, None)
     roofline = {"bound": "hbm", "kernel": "k_pred_density", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_us": kernel_us,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_us": kernel_us,
                 "algorithmic_bytes": algo_bytes, "mean_contacts": kbar}
 
     if rank == 0:
