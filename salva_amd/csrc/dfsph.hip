@@ -319,89 +319,6 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
         d[0] = T0; d[1] = T1; d[2] = T2; d[3] = T3; d[4] = T4; d[5] = __builtin_readcyclecounter(); d[6] = t.S; d[7] = t.own_end - t.own_begin;
     }
 }
-// ---- EXPERIMENT (temporary)
-template <int MODE>
-__global__ __launch_bounds__(TILE_MAX_THREADS) void k_pd_exp(StepCtx c, float dt) {
-    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
-    __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
-    const unsigned long long T0 = __builtin_readcyclecounter();
-    Tile t;
-    t.setup(c);
-    if (t.empty()) { TileErr::zero(c, t.tile); return; }
-    const unsigned long long T1 = __builtin_readcyclecounter();
-    struct Own { float4 pi, wi; float rho, alpha; uint32_t mi, cnt; ListRegs lh; };
-    auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.w[i], c.rho[i], c.alpha[i], c.model[i], c.nff[i], list_regs(c, gs)};
-    };
-    uint32_t i0, gs0;
-    t.first_own(i0, gs0);
-    const Own own0 = load_own(i0, gs0);
-    // two separate 16-byte-strided arrays: a random 64-lane ds_read_b128 then spreads over all 16 bank groups
-    // (an interleaved 32-byte record would confine each read to 8 of them)
-    const float4* Lp = nullptr;
-    const float4* Lw = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), Lp, Lw);
-    const float4* Bp = nullptr;
-    const float4* Bv = nullptr;
-    t.stage_boundary(c, Bp, Bv);
-    TileErr E;
-    E.init(errtab, c);
-    const unsigned long long T2 = __builtin_readcyclecounter();
-    __syncthreads();
-    const unsigned long long T3 = __builtin_readcyclecounter();
-    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
-        const uint32_t nqu = slice_list_dwords(o.cnt, active);
-        float err = 0.0f;
-        uint32_t mi = 0;
-        if (active) {
-            mi = o.mi;
-            const float rho0 = rho0_of(c, mi);
-            const float4 pi = o.pi, wi = o.wi;
-            float delta = 0.0f;
-            f2 acc2 = {0.0f, 0.0f};
-            if (MODE != 3) for_each_ff2(c, gs, nqu, o.lh, [&](uint32_t s) {
-                if (MODE == 4) { const float f = __uint_as_float(s); return RecPW{make_float4(f, f, f, f), make_float4(f, f, f, f)}; }
-                if (MODE == 2) { const float f = (float)s * 1.0e-3f; return RecPW{make_float4(pi.x + f, pi.y - f, pi.z + f, pi.w), make_float4(f, f, f, f)}; }
-                return RecPW{Lp[s], Lw[s]}; }, [&](const RecPW& A, const RecPW& B) {
-                if (MODE == 1) { acc2 += f2{A.p.x + A.w.y + A.p.w, B.p.y + B.w.x + B.p.w}; return; }
-                if (MODE == 4) { acc2 += f2{A.p.x, B.p.x}; return; }
-                asm volatile("" ::"v"(A.w.w), "v"(B.w.w));  // keep the reads single ds_read_b128s (a b96 costs 8 LDS cycles, a b128 4)
-                const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
-                const f2 g = kernel_grad2(dx * dx + dy * dy + dz * dz, c.sc);
-                const f2 ux = {wi.x - A.w.x, wi.x - B.w.x}, uy = {wi.y - A.w.y, wi.y - B.w.y}, uz = {wi.z - A.w.z, wi.z - B.w.z};
-                const f2 mj = {A.p.w, B.p.w};
-                acc2 += (ux * dx + uy * dy + uz * dz) * g * mj;
-            });
-            delta += acc2.x + acc2.y;
-            for_each_fb(c, t, i, gs, [&](uint32_t s) {
-                const float4 pj = Bp[s];
-                const float4 vj = Bv[s];
-                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-                delta += pj.w * rho0 * (((wi.x - vj.x) * dx + (wi.y - vj.y) * dy + (wi.z - vj.z) * dz) * g);
-            });
-            const float rs = o.rho + delta * dt;
-            if (!(rs != 0.0f)) atomicOr(c.flags, 1u);  // assert!(!predicted_density.is_zero()) :145 (also catches NaN)
-            err = (rs < rho0) ? 0.0f : rs / rho0 - 1.0f;
-            c.kappa[i] = (rs - rho0) * o.alpha;
-        }
-        E.add(c, err, mi, active && !is_ghost(c, i));  // a ghost's error belongs to the rank that owns it
-    });
-    const unsigned long long T4 = __builtin_readcyclecounter();
-    E.finish(c, t.tile);
-    if (c.dbg && threadIdx.x == 0) {
-        unsigned long long* d = c.dbg + (size_t)t.tile * 8;
-        d[0] = T0; d[1] = T1; d[2] = T2; d[3] = T3; d[4] = T4; d[5] = __builtin_readcyclecounter(); d[6] = t.S; d[7] = t.own_end - t.own_begin;
-    }
-}
-void launch_pd_exp(int mode, const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
-    if (mode == 1) { SALVA_LAUNCH_TILE(k_pd_exp<1>, c, L, L.bytes(32, 32, 4), s, c, dt); }
-    else if (mode == 2) { SALVA_LAUNCH_TILE(k_pd_exp<2>, c, L, L.bytes(32, 32, 4), s, c, dt); }
-    else if (mode == 3) { SALVA_LAUNCH_TILE(k_pd_exp<3>, c, L, L.bytes(32, 32, 4), s, c, dt); }
-    else if (mode == 4) { SALVA_LAUNCH_TILE(k_pd_exp<4>, c, L, L.bytes(32, 32, 4), s, c, dt); }
-    else { SALVA_LAUNCH_TILE(k_pd_exp<0>, c, L, L.bytes(32, 32, 4), s, c, dt); }
-}
-// ---- END EXPERIMENT
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_LAUNCH_TILE(k_pred_density, c, L, L.bytes(32, 32, 4), s, c, dt);
 }

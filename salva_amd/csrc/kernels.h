@@ -59,7 +59,6 @@ void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s);      
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s);
 void launch_finish_divergence(const StepCtx& c, float gx, float gy, float gz, bool acc_has_user, hipStream_t s);
 void launch_integrate(const StepCtx& c, float dt, hipStream_t s);       // dv += acc*dt ; acc = 0 ; w = vel + dv
-void launch_pd_exp(int mode, const StepCtx& c, const TileLds& L, float dt, hipStream_t s);
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s);    // -> kappa = (rho*-rho0)*alpha, partials
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s);
 // x += w dt; per-block cell bounds into bbox_partials (6 * num_blocks(n) ints), folded into bbox6

@@ -103,6 +103,7 @@ class World {
     DevBuf<uint32_t> nff, nfb, keys[2], idx[2], cell_start_f;
     DevBuf<TileAcc> tile_cnt, tile_off;
     DevBuf<uint32_t> d_maxhalo, halo_src, bhalo_src;
+    uint32_t last_iters[2] = {1u, 1u};  // iterations of the previous step's divergence / pressure solve (batch sizing)
     uint32_t halo_stride = 0, bhalo_stride = 0;  // fixed row stride of the slot tables (0 = compact)
     DevBuf<char> tile_list_stats;
     uint32_t cap_ff = 24, cap_fb = 8;  // ELL capacity (dwords per particle), grown on demand

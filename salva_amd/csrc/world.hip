@@ -508,7 +508,10 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
     h_ctl[which] = init;
     SALVA_HIP_CHECK(hipMemcpyAsync(d_ctl.p + which, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
     c.ctl = d_ctl.p + which;
-    int i = 0, batch = 2;
+    // First batch: what the previous step's solve needed (iters applies + the converged evaluate) — consecutive steps
+    // need about the same, so the usual cost is one read-back per solve; a batch that overshoots only enqueues kernels
+    // that return at once, one that falls short continues in doubling batches.
+    int i = 0, batch = std::max(2, std::min<int>((int)last_iters[which] + 1, max_iter));
     while (i < max_iter) {
         const int nbatch = std::min(batch, max_iter - i);
         for (int k = 0; k < nbatch; ++k) {
@@ -520,8 +523,9 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
         wait_stream();
         i += nbatch;
         if (h_ctl[which].done) break;
-        batch = std::min(batch * 2, 8);
+        batch = (i <= 2) ? 4 : 8;
     }
+    last_iters[which] = h_ctl[which].iters;
     return SolveResult{h_ctl[which].iters, h_ctl[which].err};
 }
 
@@ -941,17 +945,6 @@ float World::time_pred_density(int reps) {
         }
         fprintf(stderr, "[tile timing] %zu tiles: setup %.0f | stage issue %.0f | barrier wait %.0f | compute %.0f | finish %.0f cycles (avg per tile); kernel span %.0f cycles\n",
                 cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, (double)(tmax - tmin));
-    }
-    if (const char* em = getenv("SALVA_HIP_EXP_MODE")) {
-        const int mode = atoi(em);
-        launch_pd_exp(mode, last_ctx, lds, last_dt, stream);
-        SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
-        for (int r = 0; r < reps; ++r) launch_pd_exp(mode, last_ctx, lds, last_dt, stream);
-        SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
-        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
-        float ms = 0.0f;
-        SALVA_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
-        return ms * 1000.0f / (float)reps;
     }
     launch_pred_density(last_ctx, lds, last_dt, stream);  // warm-up
     SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));

@@ -152,6 +152,8 @@ void World::finalize_solve(SolveCtl* ctl) {
     const unsigned ntiles = (unsigned)gf.ntiles();
     const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1);
     if (!comm) {
+        // (folding this into the evaluate kernels through a last-workgroup reduction was measured 7x slower: the
+        // device-scope release every workgroup needs writes the XCD's whole L2 back)
         launch_finalize_error(partials.p, ntiles, nm, model_counts.p, ctl, stream);
         return;
     }
