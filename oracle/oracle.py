@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsalva_oracle.so")
 
 DFSPH, IISPH = 0, 1
-FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013 = 1, 2, 3
+FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013, FORCE_DFSPH_VISCOSITY = 1, 2, 3, 4
 
 
 class Stats(C.Structure):
@@ -77,6 +77,9 @@ def lib():
         L.so_get_contact_counts.argtypes = [vp, i32, i32, C.POINTER(C.c_uint32)]
         L.so_get_contacts_of.restype = u64
         L.so_get_contacts_of.argtypes = [vp, i32, i32, u64, C.POINTER(C.c_uint64), u64]
+        L.so_get_viscosity_stats.argtypes = [vp, i32, i32, C.POINTER(C.c_int), dp]
+        L.so_get_viscosity_betas.argtypes = [vp, i32, i32, dp]
+        L.so_test_lu6.argtypes = [dp, dp, dp]
         L.so_get_boundary_vec.argtypes = [vp, i32, i32, dp]
         L.so_get_boundary_volumes.argtypes = [vp, i32, dp]
         L.so_clear_boundary_forces.argtypes = [vp, i32]
@@ -160,6 +163,21 @@ class OracleWorld:
     def add_akinci2013(self, fluid, tension_coeff, adhesion_coeff):
         p = _f32([tension_coeff, adhesion_coeff])
         self._L.so_add_force(self._h, fluid, FORCE_AKINCI2013, _fp(p), 2)
+
+    def add_dfsph_viscosity(self, fluid, viscosity_coefficient, min_iter=1, max_iter=50, max_error=0.01):
+        """solver::DFSPHViscosity::new(coefficient) with its pub tuning fields (dfsph_viscosity.rs:89-125)."""
+        p = _f32([viscosity_coefficient, min_iter, max_iter, max_error])
+        self._L.so_add_force(self._h, fluid, FORCE_DFSPH_VISCOSITY, _fp(p), 4)
+
+    def viscosity_stats(self, fluid, force_index=0):
+        it, err = C.c_int(0), C.c_double(0)
+        self._L.so_get_viscosity_stats(self._h, fluid, force_index, C.byref(it), C.byref(err))
+        return it.value, err.value
+
+    def viscosity_betas(self, fluid, force_index=0) -> np.ndarray:
+        out = np.zeros((self.fluid_len(fluid), 6, 6), dtype=np.float64)
+        self._L.so_get_viscosity_betas(self._h, fluid, force_index, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
 
     def set_fluid_velocities(self, fluid, velocities):
         v = _f32(velocities, 3)

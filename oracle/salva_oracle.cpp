@@ -158,7 +158,7 @@ struct Groups {
     }
 };
 
-enum ForceKind { FORCE_XSPH = 1, FORCE_ARTIFICIAL = 2, FORCE_AKINCI2013 = 3 };
+enum ForceKind { FORCE_XSPH = 1, FORCE_ARTIFICIAL = 2, FORCE_AKINCI2013 = 3, FORCE_DFSPH_VISCOSITY = 4 };
 
 template <typename R>
 struct Force {
@@ -166,8 +166,13 @@ struct Force {
     // XSPH: p0 = fluid coeff, p1 = boundary coeff
     // Artificial: p0 = fluid coeff, p1 = boundary coeff, p2 = alpha, p3 = beta, p4 = speed_of_sound
     // Akinci2013: p0 = tension coeff, p1 = boundary adhesion coeff
+    // DFSPHViscosity: p0 = viscosity_coefficient, p1 = min_viscosity_iter, p2 = max_viscosity_iter, p3 = max_viscosity_error
     R p[5] = {0, 0, 0, 0, 0};
     std::vector<V3<R>> normals;  // Akinci state (akinci2013_surface_tension.rs:22)
+    // DFSPHViscosity state (dfsph_viscosity.rs:98-99): betas (6x6 row-major), strain-rate target / error (6 each)
+    std::vector<R> betas, strain_target, strain_error;
+    int last_visc_iters = 0;
+    R last_visc_error = 0;
 };
 
 template <typename R>
@@ -817,6 +822,214 @@ struct World {
         }
     }
 
+    // ---- viscosity/dfsph_viscosity.rs (viscous DFSPH).  3D: strain rates are 6-vectors, betas 6x6 matrices.
+    // compute_strain_rate (:38-58)
+    static inline void strain_rate(const V3<R>& g, const V3<R>& v, R out[6]) {
+        const R _2 = 2;
+        out[0] = _2 * v.x * g.x; out[1] = _2 * v.y * g.y; out[2] = _2 * v.z * g.z;
+        out[3] = v.x * g.y + v.y * g.x; out[4] = v.x * g.z + v.z * g.x; out[5] = v.y * g.z + v.z * g.y;
+    }
+    // compute_gradient_matrix (:60-83): 6x3, row-major
+    static inline void gradient_matrix(const V3<R>& g, R m[6][3]) {
+        const R _2 = 2;
+        m[0][0] = g.x * _2; m[0][1] = 0; m[0][2] = 0;
+        m[1][0] = 0; m[1][1] = g.y * _2; m[1][2] = 0;
+        m[2][0] = 0; m[2][1] = 0; m[2][2] = g.z * _2;
+        m[3][0] = g.y; m[3][1] = g.x; m[3][2] = 0;
+        m[4][0] = g.z; m[4][1] = 0; m[4][2] = g.x;
+        m[5][0] = 0; m[5][1] = g.z; m[5][2] = g.y;
+    }
+    // nalgebra 0.33 `Matrix6::lu()` (linalg/lu.rs: partial pivoting on the largest |.| of the column, multipliers = entry *
+    // (1 / pivot), trailing update y = (-p_k) * l + y) followed by `determinant()` and `try_inverse()` (linalg/solve.rs:
+    // column-oriented forward substitution with unit diagonal, then back substitution dividing by the diagonal).  nalgebra
+    // is an un-vendored dependency: restated from its published algorithm, not checked against its source here.
+    // Returns false when U has a zero on the diagonal (try_inverse -> None); det receives lu.determinant().
+    static bool lu_inverse6(const R a_in[6][6], R inv[6][6], R& det) {
+        R a[6][6];
+        int perm[6];
+        for (int i = 0; i < 6; ++i) { perm[i] = i; for (int j = 0; j < 6; ++j) a[i][j] = a_in[i][j]; }
+        int nswaps = 0;
+        for (int i = 0; i < 6; ++i) {
+            int piv = i;
+            R best = std::abs(a[i][i]);
+            for (int r = i + 1; r < 6; ++r) { const R v = std::abs(a[r][i]); if (v > best) { best = v; piv = r; } }  // icamax: first maximum
+            const R diag = a[piv][i];
+            if (diag == (R)0) continue;
+            if (piv != i) {
+                for (int j = 0; j < 6; ++j) std::swap(a[i][j], a[piv][j]);
+                std::swap(perm[i], perm[piv]);
+                ++nswaps;
+            }
+            const R inv_diag = (R)1 / diag;
+            for (int r = i + 1; r < 6; ++r) a[r][i] *= inv_diag;
+            for (int k = i + 1; k < 6; ++k) {
+                const R pk = a[i][k];
+                for (int r = i + 1; r < 6; ++r) a[r][k] = (-pk) * a[r][i] + a[r][k];
+            }
+        }
+        det = 1;
+        for (int i = 0; i < 6; ++i) det *= a[i][i];
+        if (nswaps & 1) det = -det;
+        for (int c = 0; c < 6; ++c) {
+            R b[6];
+            for (int r = 0; r < 6; ++r) b[r] = (perm[r] == c) ? (R)1 : (R)0;  // P * e_c
+            for (int i = 0; i < 5; ++i) {
+                const R coeff = b[i];
+                for (int r = i + 1; r < 6; ++r) b[r] = (-coeff) * a[r][i] + b[r];
+            }
+            for (int i = 5; i >= 0; --i) {
+                const R d = a[i][i];
+                if (d == (R)0) return false;
+                const R coeff = b[i] / d;
+                b[i] = coeff;
+                for (int r = 0; r < i; ++r) b[r] = (-coeff) * a[r][i] + b[r];
+            }
+            for (int r = 0; r < 6; ++r) inv[r][c] = b[r];
+        }
+        return true;
+    }
+    // compute_betas (:130-194)
+    void visc_compute_betas(size_t f, Force<R>& force) {
+        Fluid<R>& fluid = fluids[f];
+        const std::vector<R>& dens = densities[f];
+        const long n = (long)fluid.n();
+        const R _2 = 2;
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+        for (long i = 0; i < n; ++i) {
+            R grad_sum[6][3] = {}, sq[6][6] = {};
+            for (auto& c : ff[f].contacts[i]) {
+                if (c.i_model != c.j_model) continue;
+                R mat[6][3];
+                gradient_matrix(c.gradient, mat);
+                const R s = fluid.volumes[c.j] * fluid.density0 / (_2 * dens[c.i]);  // particle_mass(j) / (2 rho_i)
+                R gi[6][3];
+                for (int a = 0; a < 6; ++a) for (int b = 0; b < 3; ++b) gi[a][b] = mat[a][b] * s;
+                for (int a = 0; a < 6; ++a)
+                    for (int b = 0; b < 6; ++b) {
+                        R v = 0;
+                        for (int k = 0; k < 3; ++k) v += gi[a][k] * gi[b][k];
+                        sq[a][b] += v / dens[c.i];
+                    }
+                for (int a = 0; a < 6; ++a) for (int b = 0; b < 3; ++b) grad_sum[a][b] += gi[a][b];
+            }
+            R den[6][6];
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) {
+                    R v = 0;
+                    for (int k = 0; k < 3; ++k) v += grad_sum[a][k] * grad_sum[b][k];
+                    den[a][b] = sq[a][b] + v / dens[i];
+                }
+            // preconditioner (:163-175).  NOTE the reference loops over SPATIAL_DIM = 3 columns only, and scales the rows
+            // of each of them component-wise by inv_diag (column_mut(i).component_mul_assign(&inv_diag)).
+            R inv_diag[6];
+            for (int a = 0; a < 6; ++a) { const R d = den[a][a]; inv_diag[a] = (std::abs(d) < (R)1.0e-6) ? (R)1 : (R)1 / d; }
+            for (int col = 0; col < 3; ++col) for (int r = 0; r < 6; ++r) den[r][col] *= inv_diag[r];
+            // (:177-193) the dim3 determinant()/try_inverse() block is overwritten by the lu() block that follows it
+            R inv[6][6], det = 0;
+            R* beta = &force.betas[(size_t)i * 36];
+            const bool ok = lu_inverse6(den, inv, det);
+            if (std::abs(det) < (R)1.0e-6 || !ok) { for (int k = 0; k < 36; ++k) beta[k] = 0; }
+            else { for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) beta[a * 6 + b] = inv[a][b]; }
+            for (int col = 0; col < 3; ++col) for (int r = 0; r < 6; ++r) beta[r * 6 + col] *= inv_diag[col];
+        }
+    }
+    // compute_strain_rates (:196-247)
+    R visc_compute_strain_rates(size_t f, Force<R>& force, bool compute_error) {
+        Fluid<R>& fluid = fluids[f];
+        const std::vector<R>& dens = densities[f];
+        const long n = (long)fluid.n();
+        const R coef = force.p[0], _2 = 2;
+        const R tdt = dt;  // timestep.dt(): still the previous step's here (the dt lag)
+        std::vector<R> errs((size_t)n, 0);
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+        for (long i = 0; i < n; ++i) {
+            R rate[6] = {0, 0, 0, 0, 0, 0};
+            for (auto& c : ff[f].contacts[i]) {
+                if (c.i_model != c.j_model) continue;
+                const V3<R> v_i = fluid.velocities[c.i] + fluid.accelerations[c.i] * tdt;
+                const V3<R> v_j = fluid.velocities[c.j] + fluid.accelerations[c.j] * tdt;
+                R r[6];
+                strain_rate(c.gradient, v_j - v_i, r);
+                const R s = fluid.volumes[c.j] * fluid.density0 / (_2 * dens[c.i]);
+                for (int k = 0; k < 6; ++k) rate[k] += r[k] * s;
+            }
+            R* tgt = &force.strain_target[(size_t)i * 6];
+            R* err = &force.strain_error[(size_t)i * 6];
+            if (compute_error) {
+                R l1 = 0;
+                for (int k = 0; k < 6; ++k) { err[k] = rate[k] - tgt[k]; l1 += std::abs(err[k]); }
+                errs[i] = l1 / (R)6;
+            } else {
+                for (int k = 0; k < 6; ++k) tgt[k] = rate[k] * ((R)1 - coef);
+            }
+        }
+        R sum = 0;
+        for (long i = 0; i < n; ++i) sum += errs[i];
+        return n ? std::max((R)0, sum / (R)n) : (R)0;
+    }
+    // compute_accelerations (:249-287)
+    void visc_compute_accelerations(size_t f, Force<R>& force) {
+        Fluid<R>& fluid = fluids[f];
+        const std::vector<R>& dens = densities[f];
+        const long n = (long)fluid.n();
+        const R density0 = fluid.density0, _2 = 2;
+        std::vector<V3<R>> add((size_t)n);
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+        for (long i = 0; i < n; ++i) {
+            auto u_of = [&](size_t k, R u[6]) {
+                const R* b = &force.betas[k * 36];
+                const R* e = &force.strain_error[k * 6];
+                const R d2 = dens[k] * dens[k];
+                for (int a = 0; a < 6; ++a) {
+                    R v = 0;
+                    for (int q = 0; q < 6; ++q) v += b[a * 6 + q] * e[q];
+                    u[a] = v / d2;
+                }
+            };
+            R ui[6];
+            u_of((size_t)i, ui);
+            V3<R> acc;
+            for (auto& c : ff[f].contacts[i]) {
+                if (c.i_model != c.j_model) continue;
+                R uj[6], coeff[6];
+                u_of(c.j, uj);
+                const R s = fluid.volumes[c.j] * density0 / _2;
+                for (int a = 0; a < 6; ++a) coeff[a] = (ui[a] + uj[a]) * s;
+                const V3<R>& g = c.gradient;
+                // gradient.tr_mul(&coeff): M^T coeff
+                const V3<R> t((g.x * _2) * coeff[0] + g.y * coeff[3] + g.z * coeff[4],
+                              (g.y * _2) * coeff[1] + g.x * coeff[3] + g.z * coeff[5],
+                              (g.z * _2) * coeff[2] + g.x * coeff[4] + g.y * coeff[5]);
+                acc += t * (fluid.volumes[c.i] * density0 * inv_dt);
+            }
+            add[i] = acc;
+        }
+        // accelerations feed the next strain-rate pass of every particle: apply after the whole pass (the reference
+        // updates in place under rayon, i.e. a neighbour's acceleration may or may not be updated yet — order dependent;
+        // the strain pass only starts after this one has finished, so applying at the end is one of the legal orders
+        // only if nothing reads accelerations inside this pass — and nothing does)
+        for (long i = 0; i < n; ++i) fluid.accelerations[i] += add[i];
+    }
+    // NonPressureForce::solve (:290-327)
+    void solve_dfsph_viscosity(size_t f, Force<R>& force) {
+        const size_t n = fluids[f].n();
+        if (force.betas.size() != n * 36) { force.betas.assign(n * 36, 0); force.strain_target.assign(n * 6, 0); force.strain_error.assign(n * 6, 0); }
+        visc_compute_betas(f, force);
+        (void)visc_compute_strain_rates(f, force, false);
+        const int min_it = (int)force.p[1], max_it = (int)force.p[2];
+        const R max_err = force.p[3];
+        int it = 0;
+        R err = 0;
+        for (int i = 0; i < max_it; ++i) {
+            err = visc_compute_strain_rates(f, force, true);
+            if (err <= max_err && i >= min_it) break;
+            visc_compute_accelerations(f, force);
+            it = i + 1;
+        }
+        force.last_visc_iters = it;
+        force.last_visc_error = err;
+    }
+
     // dfsph_solver.rs:565-604 / iisph_solver.rs:541-580
     void predict_advection(const V3<R>& gravity) {
         for (auto& fluid : fluids) {
@@ -830,6 +1043,7 @@ struct World {
                     case FORCE_XSPH: solve_xsph(f, force); break;
                     case FORCE_ARTIFICIAL: solve_artificial(f, force); break;
                     case FORCE_AKINCI2013: solve_akinci(f, force); break;
+                    case FORCE_DFSPH_VISCOSITY: solve_dfsph_viscosity(f, force); break;
                     default: break;
                 }
             }
@@ -1208,7 +1422,8 @@ int so_add_boundary(void* p, uint64_t n, const float* pos, const float* vel, uin
     DISPATCH(h, r = add_boundary_t(w, n, pos, vel, mem, filt, wants_forces), r = add_boundary_t(w, n, pos, vel, mem, filt, wants_forces));
     return r;
 }
-// kind: 1 XSPH(p0 fluid coeff, p1 boundary coeff); 2 Artificial(p0, p1, alpha, beta, speed_of_sound); 3 Akinci2013(p0 tension, p1 adhesion)
+// kind: 1 XSPH(p0 fluid coeff, p1 boundary coeff); 2 Artificial(p0, p1, alpha, beta, speed_of_sound); 3 Akinci2013(p0 tension, p1 adhesion);
+// 4 DFSPHViscosity(p0 coefficient, p1 min iter, p2 max iter, p3 max error)
 int so_add_force(void* p, int fluid, int kind, const float* params, int nparams) {
     Handle* h = (Handle*)p;
     DISPATCH(h,
@@ -1290,6 +1505,27 @@ uint64_t so_get_contacts_of(void* p, int fluid, int which, uint64_t i, uint64_t*
     DISPATCH(h, GETC(w), GETC(w));
 #undef GETC
     return n;
+}
+// DFSPHViscosity: iterations / last error of the force at index `force` of `fluid` after the last step; betas (36 per
+// particle, row-major) of the same force.
+void so_get_viscosity_stats(void* p, int fluid, int force, int* iters, double* err) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, { auto& f = w.fluids[fluid].forces[force]; *iters = f.last_visc_iters; *err = (double)f.last_visc_error; },
+                { auto& f = w.fluids[fluid].forces[force]; *iters = f.last_visc_iters; *err = (double)f.last_visc_error; });
+}
+void so_get_viscosity_betas(void* p, int fluid, int force, double* out) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, { auto& f = w.fluids[fluid].forces[force]; for (size_t k = 0; k < f.betas.size(); ++k) out[k] = (double)f.betas[k]; },
+                { auto& f = w.fluids[fluid].forces[force]; for (size_t k = 0; k < f.betas.size(); ++k) out[k] = (double)f.betas[k]; });
+}
+// self-check hook: inverse of a 6x6 matrix with the oracle's LU (row-major in / out); returns 1 if invertible, det in *det
+int so_test_lu6(const double* a_in, double* inv_out, double* det) {
+    double a[6][6], inv[6][6], d = 0;
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) a[i][j] = a_in[i * 6 + j];
+    const bool ok = World<double>::lu_inverse6(a, inv, d);
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) inv_out[i * 6 + j] = inv[i][j];
+    *det = d;
+    return ok ? 1 : 0;
 }
 // field: 0 positions, 1 velocities, 2 forces
 void so_get_boundary_vec(void* p, int b, int field, double* out) {
