@@ -64,13 +64,16 @@ typedef struct SalvaHipParams {
 enum {
     SALVA_HIP_FORCE_XSPH = 1,        /* solver::XSPHViscosity::new(fluid_coeff, boundary_coeff), xsph_viscosity.rs:22-28 */
     SALVA_HIP_FORCE_ARTIFICIAL = 2,  /* solver::ArtificialViscosity::new(fluid_coeff, boundary_coeff), artificial_viscosity.rs:29-37 */
-    SALVA_HIP_FORCE_AKINCI2013 = 3   /* solver::Akinci2013SurfaceTension::new(tension, adhesion), akinci2013_surface_tension.rs:29-35 */
+    SALVA_HIP_FORCE_AKINCI2013 = 3,  /* solver::Akinci2013SurfaceTension::new(tension, adhesion), akinci2013_surface_tension.rs:29-35 */
+    SALVA_HIP_FORCE_DFSPH_VISCOSITY = 4 /* solver::DFSPHViscosity::new(viscosity_coefficient), dfsph_viscosity.rs:102-118 */
 };
 typedef struct SalvaHipForceDesc {
     int32_t kind;
     /* XSPH:       p[0] fluid_viscosity_coefficient, p[1] boundary_viscosity_coefficient
      * ARTIFICIAL: p[0] fluid coeff, p[1] boundary coeff, p[2] alpha (1), p[3] beta (0), p[4] speed_of_sound (10)
-     * AKINCI2013: p[0] fluid_tension_coefficient, p[1] boundary_adhesion_coefficient */
+     * AKINCI2013: p[0] fluid_tension_coefficient, p[1] boundary_adhesion_coefficient
+     * DFSPH_VISCOSITY: p[0] viscosity_coefficient (0..1), p[1] min_viscosity_iter (1), p[2] max_viscosity_iter (50),
+     *                  p[3] max_viscosity_error (0.01)          — the pub fields of DFSPHViscosity, dfsph_viscosity.rs:89-99 */
     float p[7];
 } SalvaHipForceDesc;
 
@@ -189,6 +192,10 @@ int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_
 /* particles currently owned by this rank, in no particular order; returns their number (negative on error) */
 int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* gids, float* positions_xyz,
                             float* velocities_xyz, uint32_t* fluid_slots);
+
+/* Iterations and last average error of an iterative NonPressureForce (DFSPHViscosity's solve loop, dfsph_viscosity.rs:307-323)
+ * in the last step; 0 / 0 for the other kinds.  `force` indexes the list given to salva_hip_set_fluid_forces. */
+int salva_hip_get_force_stats(SalvaHipWorld* world, uint32_t slot, uint32_t force, int32_t* iters, float* error);
 
 const char* salva_hip_last_error(void);
 const char* salva_hip_version(void);

@@ -72,6 +72,21 @@ struct Akinci2013SurfaceTension : NonPressureForce {
     }
 };
 
+struct DFSPHViscosity : NonPressureForce {  // viscosity/dfsph_viscosity.rs:85-125
+    int min_viscosity_iter = 1, max_viscosity_iter = 50;
+    Real max_viscosity_error = 0.01f;
+    Real viscosity_coefficient;
+    explicit DFSPHViscosity(Real coefficient) : viscosity_coefficient(coefficient) {
+        if (!(coefficient >= 0.0f && coefficient <= 1.0f))
+            throw std::invalid_argument("The viscosity coefficient must be between 0.0 and 1.0.");  // assert! :104-108
+    }
+    SalvaHipForceDesc desc() const override {
+        SalvaHipForceDesc d{SALVA_HIP_FORCE_DFSPH_VISCOSITY,
+                            {viscosity_coefficient, (Real)min_viscosity_iter, (Real)max_viscosity_iter, max_viscosity_error}};
+        return d;
+    }
+};
+
 // ---- pressure solvers: only the pub tuning fields exist on the host, the passes run on the device
 struct PressureSolver {
     int kind = SALVA_HIP_SOLVER_DFSPH;

@@ -11,6 +11,7 @@ from .world import (  # noqa: F401
     Boundary,
     Counters,
     DFSPHSolver,
+    DFSPHViscosity,
     Fluid,
     IISPHSolver,
     InteractionGroups,
@@ -20,6 +21,6 @@ from .world import (  # noqa: F401
 )
 
 __all__ = [
-    "Akinci2013SurfaceTension", "ArtificialViscosity", "Boundary", "Counters", "DFSPHSolver", "Fluid", "IISPHSolver",
+    "Akinci2013SurfaceTension", "ArtificialViscosity", "Boundary", "Counters", "DFSPHSolver", "DFSPHViscosity", "Fluid", "IISPHSolver",
     "InteractionGroups", "LiquidWorld", "NonPressureForce", "XSPHViscosity", "dist", "scenes",
 ]

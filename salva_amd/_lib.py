@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libsalva_hip.so")
 
 OK, E_HIP, E_INVALID, E_NUMERIC, E_CAPACITY = 0, -1, -2, -3, -4
 SOLVER_DFSPH, SOLVER_IISPH = 0, 1
-FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013 = 1, 2, 3
+FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013, FORCE_DFSPH_VISCOSITY = 1, 2, 3, 4
 DIRTY_POSITIONS, DIRTY_VELOCITIES, DIRTY_VOLUMES, DIRTY_ACCELERATIONS, DIRTY_ALL = 1, 2, 4, 8, 15
 (FIELD_DENSITY, FIELD_ALPHA, FIELD_NUM_FLUID_CONTACTS, FIELD_NUM_BOUNDARY_CONTACTS, FIELD_VELOCITY_CHANGE,
  FIELD_PRESSURE, FIELD_VOLUME, FIELD_ACCELERATION) = range(8)
@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_clear_boundary_forces", "salva_hip_device_bytes", "salva_hip_time_pred_density",
     "salva_hip_last_error", "salva_hip_version", "salva_hip_comm_rccl_unique_id", "salva_hip_comm_rccl_create",
     "salva_hip_comm_loopback_create", "salva_hip_comm_destroy", "salva_hip_set_domain", "salva_hip_get_owned",
+    "salva_hip_get_force_stats",
 ]
 
 
@@ -135,6 +136,7 @@ def lib():
     L.salva_hip_set_domain.argtypes = [vp, vp, i32, i32, u32]
     L.salva_hip_get_owned.argtypes = [vp, u32, C.POINTER(u32), fp, fp, C.POINTER(u32)]
     L.salva_hip_get_owned.restype = C.c_int64
+    L.salva_hip_get_force_stats.argtypes = [vp, u32, u32, C.POINTER(i32), fp]
     L.salva_hip_last_error.restype = C.c_char_p
     L.salva_hip_version.restype = C.c_char_p
     _lib = L

@@ -230,6 +230,14 @@ int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* g
     return rc == SALVA_HIP_OK ? count : (int64_t)rc;
 }
 
+int salva_hip_get_force_stats(SalvaHipWorld* world, uint32_t slot, uint32_t force, int32_t* iters, float* error) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->get_force_stats(slot, force, iters, error);
+        return SALVA_HIP_OK;
+    });
+}
+
 const char* salva_hip_last_error(void) { return g_last_error.c_str(); }
 const char* salva_hip_version(void) { return "salva_hip 0.1 (gfx950)"; }
 

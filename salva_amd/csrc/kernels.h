@@ -59,6 +59,13 @@ void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s);      
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s);
 void launch_finish_divergence(const StepCtx& c, float gx, float gy, float gz, bool acc_has_user, hipStream_t s);
 void launch_integrate(const StepCtx& c, float dt, hipStream_t s);       // dv += acc*dt ; acc = 0 ; w = vel + dv
+// visc.hip — DFSPHViscosity
+void launch_visc_betas(const StepCtx& c, const TileLds& L, uint32_t model, float* beta, hipStream_t s);
+void launch_visc_va(const StepCtx& c, float dt_prev, float4* va, hipStream_t s);
+void launch_visc_strain(const StepCtx& c, const TileLds& L, uint32_t model, int mode, float coef, const float4* va,
+                        const float* beta, float* target, float4* u0, float4* u1, hipStream_t s);
+void launch_visc_accel(const StepCtx& c, const TileLds& L, uint32_t model, float inv_dt_prev, float dt_prev, const float4* u0,
+                       const float4* u1, float4* va, hipStream_t s);
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s);    // -> kappa = (rho*-rho0)*alpha, partials
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s);
 // x += w dt; per-block cell bounds into bbox_partials (6 * num_blocks(n) ints), folded into bbox6

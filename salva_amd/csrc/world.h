@@ -18,6 +18,8 @@ struct FluidSlot {
     float density0 = 1000.0f;
     uint32_t memberships = 1u, filter = 0xffffffffu;
     std::vector<SalvaHipForceDesc> forces;
+    std::vector<uint32_t> force_iters;  // iterative forces (DFSPHViscosity): iterations / last error of the last step
+    std::vector<float> force_errs;
 };
 struct BoundarySlot {
     uint64_t n = 0;
@@ -46,6 +48,7 @@ class World {
     void remove_boundary(uint32_t slot);
     int step(float dt, const float g[3], SalvaHipStepStats* stats);
     void get_fluid(uint32_t slot, float* pos, float* vel);
+    void get_force_stats(uint32_t slot, uint32_t force, int32_t* iters, float* err);
     void get_fluid_field(uint32_t slot, int field, float* out);
     void get_boundary(uint32_t slot, float* volumes, float* forces);
     void clear_boundary_forces(uint32_t slot);
@@ -98,12 +101,15 @@ class World {
     DevBuf<float4> posm[2], vel[2], dv[2];
     DevBuf<uint32_t> model[2], perm[2];
     int cur = 0;
+    static constexpr int NUM_SOLVES = 3;  // divergence, pressure, viscosity
     DevBuf<float4> acc, w, normal, dii, dijpj;
+    DevBuf<float> visc_beta, visc_target;  // DFSPHViscosity scratch: betas [36][n], strain-rate targets [6][n]
+    DevBuf<float4> visc_u0, visc_u1, visc_va;
     DevBuf<float> rho, alpha, kappa, kappa2, rho_star, aii;
     DevBuf<uint32_t> nff, nfb, keys[2], idx[2], cell_start_f;
     DevBuf<TileAcc> tile_cnt, tile_off;
     DevBuf<uint32_t> d_maxhalo, halo_src, bhalo_src;
-    uint32_t last_iters[2] = {1u, 1u};  // iterations of the previous step's divergence / pressure solve (batch sizing)
+    uint32_t last_iters[NUM_SOLVES] = {1u, 1u, 1u};  // iterations of the previous step's divergence / pressure solve (batch sizing)
     uint32_t halo_stride = 0, bhalo_stride = 0;  // fixed row stride of the slot tables (0 = compact)
     DevBuf<char> tile_list_stats;
     uint32_t cap_ff = 24, cap_fb = 8;  // ELL capacity (dwords per particle), grown on demand
@@ -136,8 +142,8 @@ class World {
     DevBuf<uint32_t> d_flags;
     DevBuf<unsigned long long> d_counters;
     Readback* h_rb = nullptr;
-    DevBuf<SolveCtl> d_ctl;      // [0] divergence solve, [1] pressure solve
-    SolveCtl* h_ctl = nullptr;   // pinned: [0..1] read-back, [2..3] initial values
+    DevBuf<SolveCtl> d_ctl;      // [0] divergence solve, [1] pressure solve, [2] viscosity solve (DFSPHViscosity)
+    SolveCtl* h_ctl = nullptr;   // pinned: [0..NUM_SOLVES) read-back, [NUM_SOLVES..2 NUM_SOLVES) initial values
 
     float dt_prev = 0.0f, inv_dt_prev = 0.0f;  // TimestepManager::{dt, inv_dt} persist across steps (timestep_manager.rs:23-34)
     StepCtx last_ctx{};

@@ -119,9 +119,9 @@ World::World(const SalvaHipParams& p) : prm(p) {
     SALVA_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     SALVA_HIP_CHECK(hipHostMalloc((void**)&h_rb, sizeof(Readback), hipHostMallocDefault));
     memset(h_rb, 0, sizeof(Readback));
-    SALVA_HIP_CHECK(hipHostMalloc((void**)&h_ctl, 4 * sizeof(SolveCtl), hipHostMallocDefault));
-    memset(h_ctl, 0, 4 * sizeof(SolveCtl));
-    d_ctl.ensure(2);
+    SALVA_HIP_CHECK(hipHostMalloc((void**)&h_ctl, 2 * NUM_SOLVES * sizeof(SolveCtl), hipHostMallocDefault));
+    memset(h_ctl, 0, 2 * NUM_SOLVES * sizeof(SolveCtl));
+    d_ctl.ensure(NUM_SOLVES);
     d_rb.ensure(1);
     d_flags.ensure(1);
     d_counters.ensure(4);
@@ -253,8 +253,11 @@ void World::set_fluid(uint32_t slot, uint64_t nn, const float* pos, const float*
 void World::set_fluid_forces(uint32_t slot, const SalvaHipForceDesc* f, uint32_t nf) {
     if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
     for (uint32_t k = 0; k < nf; ++k)
-        if (f[k].kind < SALVA_HIP_FORCE_XSPH || f[k].kind > SALVA_HIP_FORCE_AKINCI2013)
+        if (f[k].kind < SALVA_HIP_FORCE_XSPH || f[k].kind > SALVA_HIP_FORCE_DFSPH_VISCOSITY)
             throw HipError(SALVA_HIP_E_INVALID, "unknown non-pressure force kind (only built-ins run on the device)");
+    for (uint32_t k = 0; k < nf; ++k)
+        if (f[k].kind == SALVA_HIP_FORCE_DFSPH_VISCOSITY && !(f[k].p[0] >= 0.0f && f[k].p[0] <= 1.0f))
+            throw HipError(SALVA_HIP_E_INVALID, "The viscosity coefficient must be between 0.0 and 1.0.");  // dfsph_viscosity.rs:104-108
     fluids[slot].forces.assign(f, f + nf);
 }
 
@@ -503,7 +506,7 @@ void World::wait_stream() {
 template <typename Eval, typename Apply>
 World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval,
                                     Apply&& apply) {
-    SolveCtl& init = h_ctl[2 + which];
+    SolveCtl& init = h_ctl[NUM_SOLVES + which];
     init = SolveCtl{0u, 0u, 0.0f, tol, (uint32_t)std::max(min_iter, 0), mode, {0u, 0u}};
     h_ctl[which] = init;
     SALVA_HIP_CHECK(hipMemcpyAsync(d_ctl.p + which, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
@@ -537,6 +540,32 @@ void World::run_forces(const StepCtx& c) {
             switch (d.kind) {
                 case SALVA_HIP_FORCE_XSPH: launch_xsph(c, lds, f, d.p[0], d.p[1], inv_dt_prev, stream); break;
                 case SALVA_HIP_FORCE_ARTIFICIAL: launch_artificial_viscosity(c, lds, f, d.p[0], d.p[1], d.p[2], d.p[3], d.p[4], stream); break;
+                case SALVA_HIP_FORCE_DFSPH_VISCOSITY: {
+                    // DFSPHViscosity::solve (dfsph_viscosity.rs:290-327); timestep.dt() / inv_dt() are the previous step's here
+                    const float coef = d.p[0], max_err = d.p[3];
+                    const int min_it = (int)d.p[1], max_it = (int)d.p[2];
+                    visc_beta.ensure((size_t)36 * n, stream, false, 1.1f); visc_target.ensure((size_t)6 * n, stream, false, 1.1f);
+                    visc_u0.ensure(n, stream, false, 1.1f); visc_u1.ensure(n, stream, false, 1.1f); visc_va.ensure(n, stream, false, 1.1f);
+                    launch_visc_betas(c, lds, f, visc_beta.p, stream);
+                    launch_visc_va(c, dt_prev, visc_va.p, stream);
+                    if (comm) refresh_f4(visc_va.p);
+                    launch_visc_strain(c, lds, f, 0, coef, visc_va.p, visc_beta.p, visc_target.p, visc_u0.p, visc_u1.p, stream);
+                    const SolveResult rv = run_solve(
+                        c, 2, max_err, min_it, max_it, 0u,
+                        [&](const StepCtx& cc, int) {
+                            launch_visc_strain(cc, lds, f, 1, coef, visc_va.p, visc_beta.p, visc_target.p, visc_u0.p, visc_u1.p, stream);
+                        },
+                        [&](const StepCtx& cc, int) {
+                            if (comm) { refresh_f4(visc_u0.p); refresh_f4(visc_u1.p); }
+                            launch_visc_accel(cc, lds, f, inv_dt_prev, dt_prev, visc_u0.p, visc_u1.p, visc_va.p, stream);
+                            if (comm) refresh_f4(visc_va.p);
+                        });
+                    fluids[f].force_iters.resize(fluids[f].forces.size(), 0u);
+                    fluids[f].force_errs.resize(fluids[f].forces.size(), 0.0f);
+                    fluids[f].force_iters[&d - fluids[f].forces.data()] = rv.iters;
+                    fluids[f].force_errs[&d - fluids[f].forces.data()] = rv.err;
+                    break;
+                }
                 case SALVA_HIP_FORCE_AKINCI2013:
                     launch_akinci_normals(c, lds, f, stream);
                     if (comm) refresh_f4(normal.p);
@@ -790,6 +819,13 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     return SALVA_HIP_OK;
 }
 
+void World::get_force_stats(uint32_t slot, uint32_t force, int32_t* iters, float* err) {
+    if (slot >= fluids.size() || force >= fluids[slot].forces.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot / force index out of range");
+    const FluidSlot& f = fluids[slot];
+    if (iters) *iters = force < f.force_iters.size() ? (int32_t)f.force_iters[force] : 0;
+    if (err) *err = force < f.force_errs.size() ? f.force_errs[force] : 0.0f;
+}
+
 // ------------------------------------------------------------------------------------------------ downloads
 void World::get_fluid(uint32_t slot, float* pos, float* vel_out) {
     use_device();
@@ -910,6 +946,7 @@ uint64_t World::device_bytes() const {
     }
     add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes());
     add(rho.bytes()); add(alpha.bytes()); add(kappa.bytes()); add(kappa2.bytes()); add(rho_star.bytes()); add(aii.bytes());
+    add(visc_beta.bytes()); add(visc_target.bytes()); add(visc_u0.bytes()); add(visc_u1.bytes()); add(visc_va.bytes());
     add(nff.bytes()); add(nfb.bytes()); add(cell_start_f.bytes()); add(halo_src.bytes()); add(bhalo_src.bytes());
     add(nbr_ff.bytes()); add(nbr_fb.bytes()); add(cub_temp.bytes()); add(scratch_f.bytes());
     add(scratch_f4.bytes()); add(bst_pos.bytes()); add(bst_vel.bytes()); add(bposv.bytes()); add(bvel.bytes());

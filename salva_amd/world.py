@@ -108,6 +108,29 @@ class Akinci2013SurfaceTension(NonPressureForce):
 
 
 # ------------------------------------------------------------------------------------------------ solvers
+class DFSPHViscosity(NonPressureForce):
+    """solver::DFSPHViscosity (viscous DFSPH), dfsph_viscosity.rs:85-125: `new(viscosity_coefficient)` + pub tuning fields.
+    After a step, `num_iterations` / `last_error` hold what its solve loop did (the reference only has a commented-out print)."""
+
+    def __init__(self, viscosity_coefficient: float):
+        # assert!(viscosity_coefficient >= 0 && <= 1, "The viscosity coefficient must be between 0.0 and 1.0.") :104-108
+        if not (0.0 <= viscosity_coefficient <= 1.0):
+            raise ValueError("The viscosity coefficient must be between 0.0 and 1.0.")
+        self.min_viscosity_iter = 1
+        self.max_viscosity_iter = 50
+        self.max_viscosity_error = 0.01
+        self.viscosity_coefficient = float(viscosity_coefficient)
+        self.num_iterations = 0
+        self.last_error = 0.0
+
+    def _desc(self):
+        d = L.ForceDesc()
+        d.kind = L.FORCE_DFSPH_VISCOSITY
+        d.p[0] = self.viscosity_coefficient
+        d.p[1], d.p[2], d.p[3] = self.min_viscosity_iter, self.max_viscosity_iter, self.max_viscosity_error
+        return d
+
+
 class DFSPHSolver:
     """dfsph_solver.rs:54-70 defaults."""
     kind = L.SOLVER_DFSPH
@@ -535,6 +558,12 @@ class LiquidWorld:
             f._device_newer = True
             f._accelerations[:] = 0  # integrate_and_clear_accelerations
         L.check(rc)
+        for f in self._fluids:
+            for k, force in enumerate(f.nonpressure_forces):
+                if isinstance(force, DFSPHViscosity):
+                    it, err = C.c_int32(0), C.c_float(0)
+                    L.check(self._L.salva_hip_get_force_stats(self._h, f._slot, k, C.byref(it), C.byref(err)))
+                    force.num_iterations, force.last_error = it.value, err.value
         self.last_stats = st
         c = self.counters
         c.nsubsteps = 1

@@ -64,11 +64,28 @@ def scene_two_phase():
     return s
 
 
+def scene_dfsph_viscous():
+    """Sheared free block with DFSPHViscosity(0.6) (viscous DFSPH) on top of the DFSPH pressure solver.
+
+    Only slightly perturbed (0.02 r, 0.01 m/s): as written in the reference the solve loop DIVERGES on a lattice jittered
+    by 0.1 r (strain error 0.1 -> 1e67 within one step, in f32 and f64 alike) — its preconditioner touches only the
+    first SPATIAL_DIM = 3 of the 6 columns (dfsph_viscosity.rs:173-175, :189-192), so beta is not the inverse it is meant
+    to be.  Restated as written; no example of the reference uses this force."""
+    s = Scene(R, 2.0, "dfsph")
+    pos = scenes.jitter(scenes.cube_fluid_positions(10, 10, 10, R), 0.02 * R, seed=42)
+    vel = scenes.random_velocities(len(pos), 0.01, seed=12345)
+    vel[:, 0] += np.float32(2.0) * pos[:, 1]
+    s.add_fluid(pos, vel, 1000.0, forces=[("dfsph_viscosity", 0.6)])
+    s.tol_scale = 20.0
+    return s
+
+
 SCENES = {
     "dfsph_xsph_block": (scene_dfsph_xsph_block, 6),
     "dfsph_tank": (scene_dfsph_tank, 6),
     "iisph_akinci": (scene_iisph_akinci, 6),
     "two_phase": (scene_two_phase, 6),
+    "dfsph_viscous": (scene_dfsph_viscous, 6),
 }
 
 
@@ -80,6 +97,10 @@ def run_oracle(scene: Scene, nsteps: int, **kw):
     for step in range(nsteps):
         st = w.step(DT, GRAVITY)
         iters.append([st.n_div_iters, st.n_press_iters, st.ncontacts])
+        for f, fd in enumerate(scene.fluids):
+            for k, frc in enumerate(fd["forces"]):
+                if frc[0] == "dfsph_viscosity":
+                    out.setdefault(f"visc_iters_{f}_{k}", []).append(w.viscosity_stats(f, k)[0])
         if step == 0:
             for f in range(len(scene.fluids)):
                 out[f"s1_density_{f}"] = w.fluid_scalar(f, "densities").astype(np.float32)
@@ -102,4 +123,6 @@ def run_oracle(scene: Scene, nsteps: int, **kw):
         if bd["wants_forces"]:
             out[f"bforce_{b}"] = w.boundary_vec(b, "forces").astype(np.float32)
     out["iters"] = np.asarray(iters, dtype=np.int64)
+    for k in [k for k in out if k.startswith("visc_iters_")]:
+        out[k] = np.asarray(out[k], dtype=np.int64)
     return out
