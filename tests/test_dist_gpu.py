@@ -138,6 +138,80 @@ def test_slabs_match_single_domain(hip_lib, nranks, two_fluids):
     assert dv < 5e-3, f"velocities differ by {dv:.2e} m/s"
 
 
+def test_slabs_with_iterative_viscosity(hip_lib):
+    """DFSPHViscosity adds a third globally-converged solve loop and three more ghost refreshes per iteration (v + a dt,
+    u); two slabs must follow the single domain, iteration counts included.  (Barely perturbed lattice: the force
+    diverges on rougher ones in the reference itself, tests/golden_scenes.py.)"""
+    from salva_amd import DFSPHViscosity
+
+    pos = scenes.jitter(scenes.cube_fluid_positions(24, 8, 8, R), 0.02 * R, 3).astype(np.float32)  # free block, no walls
+    bpos = np.zeros((0, 3), np.float32)
+    G = (0.0, 0.0, 0.0)
+    vel = scenes.random_velocities(len(pos), 0.01, 4).astype(np.float32)
+    vel[:, 0] += np.float32(2.0) * pos[:, 1]
+    nsteps = 4
+
+    def build(positions, velocities, boundary):
+        w = LiquidWorld(solver(), R, SF)
+        f = Fluid(positions, R, 1000.0)
+        f.velocities = velocities
+        f.nonpressure_forces.append(DFSPHViscosity(0.6))
+        w.add_fluid(f)
+        if len(boundary):
+            w.add_boundary(Boundary(boundary))
+        return w, f
+
+    w, f = build(pos, vel, bpos)
+    ref_iters = []
+    for _ in range(nsteps):
+        w.step(DT, G)
+        ref_iters.append(f.nonpressure_forces[0].num_iterations)
+    ref_p, ref_v = f.positions.copy(), f.velocities.copy()
+
+    cx = dist.cell_x(pos, H)
+    slabs = dist.split_slabs(cx, 2)
+    owner = dist.owner_of(cx, slabs)
+    comms = dist.Comm.loopback(2)
+    order = np.concatenate([np.nonzero(owner == r)[0] for r in range(2)])
+    offs = [0, int((owner == 0).sum())]
+    res, errs, iters = [None, None], [None, None], [None, None]
+
+    def rank_main(r):
+        try:
+            mine = np.nonzero(owner == r)[0]
+            wr, fr = build(pos[mine], vel[mine], bpos[dist.boundary_subset(bpos, H, slabs[r], r, 2)])
+            wr.set_domain(comms[r], slabs[r][0], slabs[r][1], offs[r])
+            it = []
+            for _ in range(nsteps):
+                wr.step(DT, G)
+                it.append(fr.nonpressure_forces[0].num_iterations)
+            iters[r] = it
+            res[r] = wr.owned()
+        except BaseException as e:  # noqa: BLE001
+            errs[r] = e
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts), "a rank hung"
+    for e in errs:
+        if e is not None:
+            raise e
+    assert iters[0] == iters[1] == ref_iters
+    got_p = np.full_like(pos, np.nan)
+    got_v = np.full_like(vel, np.nan)
+    for r in range(2):
+        gid, p, v, _ = res[r]
+        got_p[order[gid]] = p
+        got_v[order[gid]] = v
+    assert np.isfinite(got_p).all()
+    assert np.abs(got_p - ref_p).max() < 2e-3 * H and np.abs(got_v - ref_v).max() < 2e-2
+    for c in comms:
+        c.destroy()
+
+
 def test_single_rank_domain_is_the_plain_world(hip_lib):
     """A 1-rank communicator: no neighbours, no ghosts — must equal the plain world bit for bit in iteration counts and
     to rounding in state (the tile origin is the same, so this is in practice exact)."""
