@@ -226,7 +226,7 @@ void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4
 }
 
 // ------------------------------------------------------------------------------------------------ tile tables
-// One workgroup per tile.  k_tile_count: halo sizes (fluid / boundary particles in the 6x6x4 cell box) and number
+// One workgroup per tile.  k_tile_count: halo sizes (fluid / boundary particles in the 6x6x6 cell box) and number
 // of 64-particle slices of the tile -> tile_cnt[tile], plus their maxima (which size the LDS staging area and the
 // workgroup of every tile kernel of this step).  After an exclusive scan, k_tile_halo_fill writes the flat slot
 // tables: halo_src[tile_off[tile].s + slot] = sorted index of the particle staged in that slot.

@@ -2,15 +2,17 @@
 //
 // Why: a one-lane-per-particle gather straight from global memory issues ~25 M L2 requests per pass at 10^6
 // particles (measured: L1 hit rate 45 %, L2 request rate ~80 % of the tag-lookup ceiling, VALU 20-40 % busy —
-// profiles/r01a_v1_gather).  Here one workgroup owns one tile of 4x4x2 grid cells; it copies the particles of the
-// 6x6x4 halo box (own tile + one cell all round, the interaction range being exactly one cell, contacts.rs:164-165)
-// into LDS with coalesced loads, and the per-particle neighbour loops then read 16-byte records from LDS by slot.
-// Neighbour lists store 16-bit LDS slots (two per dword), so a pass streams 2 B per contact instead of 4.
+// profiles/r01a_v1_gather).  Here one workgroup owns one tile of 4x4x4 grid cells; it copies the particles of the
+// 6x6x6 halo box (own tile + one cell all round, the interaction range being exactly one cell, contacts.rs:164-165)
+// into LDS with coalesced index-gathers, and the per-particle neighbour loops then read 16-byte records from LDS by
+// slot.  Neighbour lists store 16-bit LDS slots (two per dword), so a pass streams 2 B per contact instead of 4.
 //
-// Particle order = tile-major cell key (tile linear index * 32 + cell-in-tile), x slowest.  A tile's own particles
-// are one contiguous index range; its halo is at most 144 cells, each a contiguous range (cell table with
-// lower-bound semantics).  Tiles sit on an absolute lattice (cell coords floor-divided by the tile shape) so the
-// fluid and the boundary tables, which have different origins, agree on tile membership.
+// Particle order = tile-major cell key (tile linear index * 64 + cell-in-tile), x slowest.  A tile's own particles
+// are one contiguous index range; its halo is at most 216 cells, each a contiguous range (cell table with
+// lower-bound semantics).  The tile grid is anchored at the minimum corner of the occupied cells' bounding box; the
+// boundary particles are sorted on the same grid, so fluid and boundary tables agree on tile membership.
+//
+// What bounds these kernels and what was tried: DESIGN.md §3.3.
 #pragma once
 #include "common.h"
 #include "device_types.h"
@@ -18,12 +20,12 @@
 namespace salva {
 
 constexpr int TX = 4, TY = 4, TZ = 4;                  // cells per tile
-constexpr int TCELLS = TX * TY * TZ;                   // 32
+constexpr int TCELLS = TX * TY * TZ;                   // 64
 constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;   // halo box
-constexpr int HCELLS = HX * HY * HZ;                   // 144
-constexpr int TILE_MAX_WAVES = 12;                      // workgroup = one wave per 64-particle slice of the fullest tile,
-constexpr int TILE_MAX_THREADS = TILE_MAX_WAVES * WAVE; // clamped to [3, 8] waves (a tile holds 256 particles on the
-                                                       // 2r lattice, ~320 at rest density)
+constexpr int HCELLS = HX * HY * HZ;                   // 216
+constexpr int TILE_MAX_WAVES = 12;                      // workgroup = one wave per 64-particle slice of the average non-empty
+constexpr int TILE_MAX_THREADS = TILE_MAX_WAVES * WAVE; // tile, clamped to [4, 12] waves (a tile holds 512 particles on the 2r
+                                                       // lattice: 8 waves; fuller tiles loop over their extra slices)
 
 __host__ __device__ inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
@@ -80,7 +82,7 @@ __device__ __forceinline__ int cell_coord(float x, float h, bool& bad) {
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
 
 // ---------------------------------------------------------------------------------------------------
-// Tile: what every tile kernel needs.  The halo of a tile (the particles of its 6x6x4 cell box, in halo-cell order)
+// Tile: what every tile kernel needs.  The halo of a tile (the particles of its 6x6x6 cell box, in halo-cell order)
 // is described once per step by k_tile_halo_fill as a flat table of sorted particle indices
 // (halo_src[halo_off[tile] + slot]); staging an array into LDS is then one coalesced index read plus one gather per
 // slot, all slots in flight at once.
