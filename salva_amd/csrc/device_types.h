@@ -23,10 +23,10 @@ namespace salva {
 
 // Dense cell table over the (tile-aligned) bounding box of one particle class.  Cells are keyed tile-major:
 // key = tile_linear * TCELLS (64) + cell_in_tile, tile_linear = (tx * nty + ty) * ntz + tz (x slowest), cell_in_tile =
-// (ux * 4 + uy) * 2 + uz, with (cx,cy,cz) = floor(p / h) (hgrid.rs:41-52) relative to the origin (ox,oy,oz), which
-// is a multiple of the tile shape in absolute cell coordinates.  cell_start has ncells+1 entries with lower-bound
-// semantics: cell_start[k] = first sorted index whose key >= k, so cell k is [cell_start[k], cell_start[k+1]) and a
-// whole tile is [cell_start[32 t], cell_start[32 t + 32)).
+// (ux * TY + uy) * TZ + uz, with (cx,cy,cz) = floor(p / h) (hgrid.rs:41-52) relative to the origin (ox,oy,oz) = the
+// minimum corner of the occupied cells' bounding box.  cell_start has ncells+1 entries with lower-bound semantics:
+// cell_start[k] = first sorted index whose key >= k, so cell k is [cell_start[k], cell_start[k+1]) and a whole tile
+// is [cell_start[64 t], cell_start[64 t + 64)).
 struct TileGrid {
     int ox, oy, oz;
     int ntx, nty, ntz;
