@@ -193,6 +193,15 @@ int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_
 int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* gids, float* positions_xyz,
                             float* velocities_xyz, uint32_t* fluid_slots);
 
+/* `ContactManager::fluid_fluid_contacts[slot]` / `fluid_boundary_contacts[slot]` (liquid_world.rs:26, geometry/contacts.rs:57-131)
+ * of the last step as a CSR structure in host order: offsets has fluid_len + 1 entries, contact k of particle i is
+ * (j_model[offsets[i] + k], j[offsets[i] + k]) — the model (fluid or boundary slot) and the index inside that model's host
+ * arrays; the self contact is included, as in the reference.  Returns the number of contacts (negative on error); entries
+ * are written only when `capacity` holds them all, so call once with capacity 0 to size the arrays.  This is what a host
+ * fallback for user-defined NonPressureForce implementations iterates. */
+int64_t salva_hip_get_fluid_contacts(SalvaHipWorld* world, uint32_t slot, int32_t boundary_contacts, uint64_t* offsets,
+                                     uint32_t* j_model, uint32_t* j, uint64_t capacity);
+
 /* Iterations and last average error of an iterative NonPressureForce (DFSPHViscosity's solve loop, dfsph_viscosity.rs:307-323)
  * in the last step; 0 / 0 for the other kinds.  `force` indexes the list given to salva_hip_set_fluid_forces. */
 int salva_hip_get_force_stats(SalvaHipWorld* world, uint32_t slot, uint32_t force, int32_t* iters, float* error);

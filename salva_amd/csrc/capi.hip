@@ -230,6 +230,17 @@ int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* g
     return rc == SALVA_HIP_OK ? count : (int64_t)rc;
 }
 
+int64_t salva_hip_get_fluid_contacts(SalvaHipWorld* world, uint32_t slot, int32_t boundary_contacts, uint64_t* offsets,
+                                     uint32_t* j_model, uint32_t* j, uint64_t capacity) {
+    int64_t total = 0;
+    const int rc = guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        total = (int64_t)world->w->get_fluid_contacts(slot, boundary_contacts, offsets, j_model, j, capacity);
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? total : (int64_t)rc;
+}
+
 int salva_hip_get_force_stats(SalvaHipWorld* world, uint32_t slot, uint32_t force, int32_t* iters, float* error) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");

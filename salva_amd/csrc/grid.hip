@@ -225,6 +225,58 @@ void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4
     if (n) k_gather_f4<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, perm, in, out);
 }
 
+// ------------------------------------------------------------------------------------------------ contact export
+// ParticlesContacts of one fluid as a CSR structure in HOST order (geometry/contacts.rs:57-131: what
+// `contacts.particle_contacts(i)` iterates): entry = (j_model, j) with j the index inside that model's host arrays.
+// A list entry is an LDS slot of the particle's tile; the tile's slot table maps it to a sorted index.  Not a hot path
+// (host-side custom forces, queries, and the parity tests, which compare contact SETS with it).
+__global__ __launch_bounds__(BLOCK) void k_export_contacts(StepCtx c, const uint32_t* __restrict__ keys, uint32_t slot, int boundary,
+                                                           const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ model_off,
+                                                           const uint32_t* __restrict__ bmodel_off, uint32_t* __restrict__ out_model,
+                                                           uint32_t* __restrict__ out_j) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= c.n || c.model[i] != slot) return;
+    const uint32_t host_local = c.perm[i] - model_off[slot];
+    uint64_t o = offsets[host_local];
+    const uint32_t cnt = boundary ? c.nfb[i] : c.nff[i];
+    const uint32_t tile = keys[i] / TCELLS;
+    const uint32_t own_begin = c.gf.cell_start[(size_t)tile * TCELLS];
+    const TileAcc a0 = c.tile_off[tile];
+    const uint32_t gs = a0.nsl + (i - own_begin) / WAVE, lane = (i - own_begin) % WAVE;
+    const uint32_t cap = boundary ? c.cap_fb : c.cap_ff;
+    const uint32_t* __restrict__ p = (boundary ? c.nbr_fb : c.nbr_ff) + (size_t)gs * cap * WAVE + lane;
+    const uint64_t hoff = boundary ? (c.halo_stride ? (uint64_t)tile * c.bhalo_stride : a0.sb)
+                                   : (c.halo_stride ? (uint64_t)tile * c.halo_stride : a0.s);
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t d = p[(size_t)(k >> 1) * WAVE];
+        const uint32_t s = (k & 1u) ? (d >> 16) : (d & 0xffffu);
+        if (boundary) {
+            const uint32_t g = c.bhalo_src[hoff + s];
+            const uint32_t bm = __float_as_uint(c.bvel[g].w);
+            out_model[o] = bm;
+            out_j[o] = c.bperm[g] - bmodel_off[bm];
+        } else {
+            const uint32_t g = c.halo_src[hoff + s];
+            const uint32_t m = c.model[g];
+            out_model[o] = m;
+            out_j[o] = c.perm[g] - model_off[m];
+        }
+        ++o;
+    }
+}
+void launch_export_contacts(const StepCtx& c, const uint32_t* keys, uint32_t slot, int boundary, const uint64_t* offsets,
+                            const uint32_t* model_off, const uint32_t* bmodel_off, uint32_t* out_model, uint32_t* out_j, hipStream_t s) {
+    if (c.n) k_export_contacts<<<div_up(c.n, BLOCK), BLOCK, 0, s>>>(c, keys, slot, boundary, offsets, model_off, bmodel_off, out_model, out_j);
+}
+__global__ __launch_bounds__(BLOCK) void k_unsort_u32(uint32_t n, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ in,
+                                                      uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[perm[i]] = in[i];
+}
+void launch_unsort_u32(uint32_t n, const uint32_t* perm, const uint32_t* in, uint32_t* out, hipStream_t s) {
+    if (n) k_unsort_u32<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, perm, in, out);
+}
+
 // ------------------------------------------------------------------------------------------------ tile tables
 // One workgroup per tile.  k_tile_count: halo sizes (fluid / boundary particles in the 6x6x6 cell box) and number
 // of 64-particle slices of the tile -> tile_cnt[tile], plus their maxima (which size the LDS staging area and the

@@ -49,6 +49,7 @@ class World {
     int step(float dt, const float g[3], SalvaHipStepStats* stats);
     void get_fluid(uint32_t slot, float* pos, float* vel);
     void get_force_stats(uint32_t slot, uint32_t force, int32_t* iters, float* err);
+    uint64_t get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity);
     void get_fluid_field(uint32_t slot, int field, float* out);
     void get_boundary(uint32_t slot, float* volumes, float* forces);
     void clear_boundary_forces(uint32_t slot);

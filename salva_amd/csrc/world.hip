@@ -819,6 +819,43 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     return SALVA_HIP_OK;
 }
 
+// The contact lists of the last step (they describe the positions the step started from, as the reference's
+// ContactManager does after `step`).  offsets: n+1 entries; entries are written only if `capacity` holds them all.
+uint64_t World::get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity) {
+    use_device();
+    if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
+    if (comm) throw HipError(SALVA_HIP_E_INVALID, "contact export is not available in a multi-GPU run");
+    if (!have_last_ctx || !sorted_valid) throw HipError(SALVA_HIP_E_INVALID, "no completed step: there are no contact lists yet");
+    const uint64_t nn = fluids[slot].n, off = fluid_offset(slot);
+    std::vector<uint32_t> cnt(nn, 0);
+    DevBuf<uint32_t> d_cnt;
+    d_cnt.ensure(std::max<size_t>(n, 1));
+    if (!(boundary && nb == 0) && nn) {
+        launch_unsort_u32(n, perm[cur].p, boundary ? nfb.p : nff.p, d_cnt.p, stream);
+        SALVA_HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt.p + off, nn * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    std::vector<uint64_t> offs(nn + 1, 0);
+    for (uint64_t k = 0; k < nn; ++k) offs[k + 1] = offs[k] + cnt[k];
+    const uint64_t total = offs[nn];
+    if (offsets) memcpy(offsets, offs.data(), (nn + 1) * sizeof(uint64_t));
+    if (!j_model || !j || capacity < total || total == 0) return total;
+    std::vector<uint32_t> moff(std::max<size_t>(fluids.size(), 1), 0), boff(std::max<size_t>(bounds.size(), 1), 0);
+    for (uint32_t s = 0; s < fluids.size(); ++s) moff[s] = (uint32_t)fluid_offset(s);
+    for (uint32_t s = 0; s < bounds.size(); ++s) boff[s] = (uint32_t)boundary_offset(s);
+    DevBuf<uint64_t> d_offs;
+    DevBuf<uint32_t> d_moff, d_boff, d_jm, d_j;
+    d_offs.ensure(nn + 1); d_moff.ensure(moff.size()); d_boff.ensure(boff.size()); d_jm.ensure(total); d_j.ensure(total);
+    SALVA_HIP_CHECK(hipMemcpyAsync(d_offs.p, offs.data(), (nn + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(d_moff.p, moff.data(), moff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(d_boff.p, boff.data(), boff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    launch_export_contacts(last_ctx, keys[1].p, slot, boundary, d_offs.p, d_moff.p, d_boff.p, d_jm.p, d_j.p, stream);
+    SALVA_HIP_CHECK(hipMemcpyAsync(j_model, d_jm.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(j, d_j.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    return total;
+}
+
 void World::get_force_stats(uint32_t slot, uint32_t force, int32_t* iters, float* err) {
     if (slot >= fluids.size() || force >= fluids[slot].forces.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot / force index out of range");
     const FluidSlot& f = fluids[slot];

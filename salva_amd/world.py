@@ -625,6 +625,23 @@ class LiquidWorld:
         fld = L.FIELD_NUM_BOUNDARY_CONTACTS if boundary_contacts else L.FIELD_NUM_FLUID_CONTACTS
         return self.fluid_field(f, fld).astype(np.uint32)
 
+    def fluid_contacts(self, f: Fluid, boundary_contacts: bool = False):
+        """(offsets, j_model, j): the fluid-fluid (or fluid-boundary) contacts of the last step in host order, CSR —
+        `contact_manager.fluid_fluid_contacts[handle].particle_contacts(i)` of the reference (geometry/contacts.rs:57-131)."""
+        n = f.num_particles()
+        offsets = np.zeros(n + 1, np.uint64)
+        u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        total = int(self._L.salva_hip_get_fluid_contacts(self._h, f._slot, int(boundary_contacts), offsets.ctypes.data_as(u64p), None, None, 0))
+        if total < 0:
+            L.check(total)
+        jm, j = np.zeros(total, np.uint32), np.zeros(total, np.uint32)
+        if total:
+            got = int(self._L.salva_hip_get_fluid_contacts(self._h, f._slot, int(boundary_contacts), offsets.ctypes.data_as(u64p),
+                                                           jm.ctypes.data_as(u32p), j.ctypes.data_as(u32p), total))
+            if got < 0:
+                L.check(got)
+        return offsets, jm, j
+
     def device_bytes(self) -> int:
         return int(self._L.salva_hip_device_bytes(self._h))
 

@@ -262,3 +262,30 @@ def test_cpp_mirror_basic3_example():
     assert out.returncode == 0, out.stderr + out.stdout
     last = out.stdout.strip().splitlines()[-1]
     assert last.startswith("step 120: 3375 particles"), last
+
+
+@pytest.mark.parametrize("name", ["two_phase", "iisph_akinci", "dfsph_tank"])
+def test_contact_sets_match_oracle(name):
+    """Not just the counts: the exported contact lists (salva_hip_get_fluid_contacts) name exactly the partners the
+    oracle's contact manager holds — fluid-fluid across models, fluid-boundary, self contacts included."""
+    builder, _ = SCENES[name]
+    scene = builder()
+    w, fls, _ = scene.make_hip()
+    o = scene.make_oracle()
+    w.step(DT, GRAVITY)
+    o.step(DT, GRAVITY)
+    for f, h in enumerate(fls):
+        for boundary in (False, True):
+            if boundary and not scene.boundaries:
+                continue
+            off, jm, j = w.fluid_contacts(h, boundary)
+            assert len(off) == h.num_particles() + 1 and off[-1] == len(j)
+            keys = (jm.astype(np.uint64) << np.uint64(32)) | j.astype(np.uint64)
+            for i in range(h.num_particles()):
+                got = sorted(int(k) for k in keys[int(off[i]):int(off[i + 1])])
+                ref = [(m << 32) | k for m, k in o.contacts_of(f, i, boundary)]
+                assert got == ref, f"{name}: fluid {f} particle {i} boundary={boundary}"
+            if not boundary:
+                # every particle lists itself
+                self_key = (np.uint64(f) << np.uint64(32)) | np.arange(h.num_particles(), dtype=np.uint64)
+                assert all(self_key[i] in keys[int(off[i]):int(off[i + 1])] for i in range(0, h.num_particles(), 37))
