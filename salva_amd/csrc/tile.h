@@ -47,7 +47,6 @@ struct TileLds {
 // hipFuncSetAttribute costs tens of microseconds of host time: raise a kernel's dynamic-LDS ceiling only when a
 // launch actually needs more than was granted before (48 KiB is the default).
 void raise_tile_lds_limit(const void* kernel, uint32_t bytes);  // world.hip
-uint32_t tile_lds_pad();  // world.hip: SALVA_HIP_LDS_PAD (experiments: extra dynamic LDS per block to force lower occupancy)
 template <typename K>
 inline void ensure_tile_lds(K kernel, uint32_t bytes) {
     if (bytes > 48u * 1024u) raise_tile_lds_limit(reinterpret_cast<const void*>(kernel), bytes);
@@ -55,7 +54,7 @@ inline void ensure_tile_lds(K kernel, uint32_t bytes) {
 #define SALVA_LAUNCH_TILE(kernel, c, L, lds, s, ...)                          \
     do {                                                                   \
         if ((c).n) {                                                       \
-            const uint32_t _lds = (lds) + ::salva::tile_lds_pad();         \
+            const uint32_t _lds = (lds);                                   \
             ::salva::ensure_tile_lds(kernel, _lds);                        \
             kernel<<<(c).ntiles, (L).threads, _lds, s>>>(__VA_ARGS__);     \
             SALVA_HIP_CHECK(hipGetLastError());                            \

@@ -17,10 +17,6 @@
 
 namespace salva {
 
-uint32_t tile_lds_pad() {
-    static const uint32_t pad = [] { const char* e = getenv("SALVA_HIP_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
-    return pad;
-}
 void raise_tile_lds_limit(const void* kernel, uint32_t bytes) {
     if (bytes > 160u * 1024u)
         throw HipError(SALVA_HIP_E_CAPACITY, "a tile's halo does not fit the 160 KiB LDS (particles are compressed far beyond rest density)");
