@@ -289,3 +289,26 @@ def test_contact_sets_match_oracle(name):
                 # every particle lists itself
                 self_key = (np.uint64(f) << np.uint64(32)) | np.arange(h.num_particles(), dtype=np.uint64)
                 assert all(self_key[i] in keys[int(off[i]):int(off[i + 1])] for i in range(0, h.num_particles(), 37))
+
+
+def _sparse_scene():
+    """A dense block plus a spray of isolated particles over a 60x larger box: thousands of tiles, almost all empty or
+    holding a single particle — the shape that makes fixed-stride slot tables too wasteful, so the compact ones are used."""
+    s = Scene(R, 2.0, "dfsph")
+    block = scenes.jitter(scenes.cube_fluid_positions(8, 8, 8, R), 0.1 * R, seed=42)
+    u = scenes.lcg_uniform(3 * 1500, 99).reshape(-1, 3)
+    spray = ((u - np.float32(0.5)) * np.float32(6.0)).astype(np.float32)
+    pos = np.concatenate([block, spray]).astype(np.float32)
+    vel = scenes.random_velocities(len(pos), 0.2, seed=5)
+    s.add_fluid(pos, vel, 1000.0, forces=[("xsph", 0.5, 0.0)])
+    return s
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_sparse_scene_and_compact_slot_tables(compact, monkeypatch):
+    """Isolated particles (lists holding only the self contact, below the 20-contact divergence threshold), empty
+    tiles, and both layouts of the per-tile slot tables give the oracle's trajectory."""
+    if compact:
+        monkeypatch.setenv("SALVA_HIP_COMPACT_HALO", "1")
+    for scene, nsteps in ((_sparse_scene(), 4), (SCENES["dfsph_tank"][0](), 4)):
+        compare(run_hip(scene, nsteps), run_oracle(scene, nsteps), scene, nsteps, f"sparse/compact={compact}")
