@@ -8,6 +8,7 @@
 // reference becomes: sorted SoA arrays + a dense lower-bound cell table + per-tile sliced-ELL lists of 16-bit LDS
 // slots (tile.h).
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <climits>
 
@@ -76,16 +77,20 @@ void launch_cell_keys(const float4* pts, uint32_t n, float h, TileGrid g, uint32
 }
 
 // ------------------------------------------------------------------------------------------------ sort / scan (rocPRIM via hipCUB)
+// rocPRIM's default switches from its merge sort to the one-sweep radix sort only above 2^20 items; at 10^6 particles
+// the merge path costs 10 merge passes (~140 us) where three 8-bit radix passes over 22-bit keys cost ~40.  Lower the
+// switch-over to 64 Ki items.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
 size_t sort_pairs_temp_bytes(uint32_t n, int end_bit) {
     size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, end_bit);
+    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                                (uint32_t*)nullptr, (size_t)n, 0u, (unsigned)end_bit);
     return bytes;
 }
 void sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
                 uint32_t* idx_out, uint32_t n, int end_bit, hipStream_t s) {
-    SALVA_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (int)n, 0,
-                                                       end_bit, s));
+    SALVA_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (size_t)n, 0u,
+                                                          (unsigned)end_bit, s));
 }
 size_t scan_temp_bytes(uint32_t n) {
     size_t a = 0, b = 0;
