@@ -88,12 +88,17 @@ struct StepCtx {
     uint32_t* nbr_ff;           // packed 16-bit halo slots: slice s owns dwords [s*cap_ff*64, (s+1)*cap_ff*64)
     uint32_t* nbr_fb;
     uint32_t cap_ff, cap_fb;    // dwords (= pairs of contacts) reserved per particle
-    const TileAcc* tile_off;    // [ntiles+1] exclusive prefix of per-tile {halo slots, boundary halo slots, slices}
+    const TileAcc* tile_off;    // [nslots+1] exclusive prefix of per-tile {halo slots, boundary halo slots, slices}, by SLOT
     const uint32_t* halo_src;   // sorted fluid index of every halo slot of every tile (tile-major)
     const uint32_t* bhalo_src;  // sorted boundary index of every boundary halo slot
     uint32_t halo_stride;       // > 0: tile t's slot table starts at t * halo_stride (address known before any load
     uint32_t bhalo_stride;      //      returns); 0: compact tables at tile_off[t].s / .sb
-    uint32_t ntiles;
+    uint32_t ntiles;            // tiles of the dense grid (only the cell table and one flag per tile are dense)
+    // Everything per tile lives in a compact table over the NON-EMPTY tiles ("slots", in dense-index order), and every
+    // tile kernel is launched over slots: widely scattered particles then cost nothing per empty tile.
+    const uint32_t* tile_ids;   // [nlaunch] dense tile index of slot k
+    const uint32_t* tile_rank;  // [ntiles+1] exclusive prefix of the non-empty flags: slot of a dense tile; [ntiles] = nlaunch
+    uint32_t nlaunch;           // number of slots (known to the host after the per-step read-back; 0 before)
     TileGrid gf;
 
     // ---- boundary particles, cell-sorted order ----

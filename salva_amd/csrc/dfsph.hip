@@ -87,7 +87,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
     Tile t;
     t.setup(c);
-    if (t.empty()) { TileErr::zero(c, t.tile); return; }
+    if (t.empty()) { TileErr::zero(c, t.slot); return; }
     struct Own { float4 pi, wi; float alpha; uint32_t mi, cnt, cntb; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
         return Own{c.posm[i], c.w[i], c.alpha[i], c.model[i], c.nff[i], c.nb ? c.nfb[i] : 0u, list_regs(c, gs)};
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
         }
         E.add(c, err, mi, active && !is_ghost(c, i));  // a ghost's error belongs to the rank that owns it
     });
-    E.finish(c, t.tile);
+    E.finish(c, t.slot);
 }
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
     SALVA_LAUNCH_TILE(k_divergence, c, L, L.bytes(32, 16, 3), s, c);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
     const unsigned long long T0 = __builtin_readcyclecounter();
     Tile t;
     t.setup(c);
-    if (t.empty()) { TileErr::zero(c, t.tile); return; }
+    if (t.empty()) { TileErr::zero(c, t.slot); return; }
     const unsigned long long T1 = __builtin_readcyclecounter();
     struct Own { float4 pi, wi; float rho, alpha; uint32_t mi, cnt; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
@@ -313,9 +313,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
         E.add(c, err, mi, active && !is_ghost(c, i));  // a ghost's error belongs to the rank that owns it
     });
     const unsigned long long T4 = __builtin_readcyclecounter();
-    E.finish(c, t.tile);
+    E.finish(c, t.slot);
     if (c.dbg && threadIdx.x == 0) {
-        unsigned long long* d = c.dbg + (size_t)t.tile * 8;
+        unsigned long long* d = c.dbg + (size_t)t.slot * 8;
         d[0] = T0; d[1] = T1; d[2] = T2; d[3] = T3; d[4] = T4; d[5] = __builtin_readcyclecounter(); d[6] = t.S; d[7] = t.own_end - t.own_begin;
     }
 }

@@ -106,17 +106,49 @@ void scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, 
 }
 
 // ------------------------------------------------------------------------------------------------ cell table
-// cell_start[c] = first sorted index with key >= c, for c in [0, ncells]; thread i owns the gap before key[i].
+// cell_start[c] = first sorted index with key >= c, for c in [0, ncells].  Thread i owns the gap of cells before key[i]
+// (all of them get the value i).  A gap is short in a dense scene, but a bounding box blown up by a few stray particles
+// has gaps of hundreds of millions of cells: there the thread fills only the two partial chunks at the ends of its gap,
+// and k_cell_start_chunks streams the value into the whole key-free chunks in between.
+constexpr uint32_t CELL_CHUNK = 4096;
 __global__ __launch_bounds__(BLOCK) void k_cell_start(const uint32_t* __restrict__ keys, uint32_t n, uint32_t ncells,
                                                       uint32_t* __restrict__ cell_start) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i > n) return;
     const uint32_t lo = (i == 0) ? 0u : keys[i - 1] + 1u;
     const uint32_t hi = (i == n) ? ncells : keys[i];  // inclusive
-    for (uint32_t c = lo; c <= hi; ++c) cell_start[c] = i;
+    if (lo > hi) return;
+    if (lo / CELL_CHUNK == hi / CELL_CHUNK) {
+        for (uint32_t c = lo; c <= hi; ++c) cell_start[c] = i;
+    } else {
+        const uint32_t lo_end = (lo / CELL_CHUNK + 1u) * CELL_CHUNK - 1u, hi_begin = (hi / CELL_CHUNK) * CELL_CHUNK;
+        for (uint32_t c = lo; c <= lo_end; ++c) cell_start[c] = i;
+        for (uint32_t c = hi_begin; c <= hi; ++c) cell_start[c] = i;
+    }
+}
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ keys, uint32_t lo, uint32_t hi, uint32_t v) {
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// one workgroup per chunk: a chunk without keys lies inside one gap and takes that gap's value
+__global__ __launch_bounds__(BLOCK) void k_cell_start_chunks(const uint32_t* __restrict__ keys, uint32_t n, uint32_t ncells,
+                                                             uint32_t* __restrict__ cell_start) {
+    __shared__ uint32_t bracket[2];
+    const uint64_t c0 = (uint64_t)blockIdx.x * CELL_CHUNK;
+    const uint64_t c1 = min(c0 + CELL_CHUNK, (uint64_t)ncells + 1);  // cells [c0, c1); the table has ncells + 1 entries
+    if (threadIdx.x < 2) bracket[threadIdx.x] = lower_bound_u32(keys, 0, n, threadIdx.x == 0 ? (uint32_t)c0 : (uint32_t)min(c1, (uint64_t)0xffffffffu));
+    __syncthreads();
+    if (bracket[0] != bracket[1]) return;  // the chunk holds keys: its cells were filled by k_cell_start
+    const uint32_t v = bracket[0];
+    for (uint64_t c = c0 + threadIdx.x; c < c1; c += BLOCK) cell_start[c] = v;
 }
 void launch_cell_start(const uint32_t* keys_sorted, uint32_t n, uint32_t ncells, uint32_t* cell_start, hipStream_t s) {
     k_cell_start<<<div_up((size_t)n + 1, BLOCK), BLOCK, 0, s>>>(keys_sorted, n, ncells, cell_start);
+    if ((size_t)ncells + 1 > CELL_CHUNK)  // with a single chunk no gap can span a whole one
+        k_cell_start_chunks<<<div_up((size_t)ncells + 1, CELL_CHUNK), BLOCK, 0, s>>>(keys_sorted, n, ncells, cell_start);
 }
 
 // ------------------------------------------------------------------------------------------------ reorder
@@ -246,12 +278,13 @@ __global__ __launch_bounds__(BLOCK) void k_export_contacts(StepCtx c, const uint
     const uint32_t cnt = boundary ? c.nfb[i] : c.nff[i];
     const uint32_t tile = keys[i] / TCELLS;
     const uint32_t own_begin = c.gf.cell_start[(size_t)tile * TCELLS];
-    const TileAcc a0 = c.tile_off[tile];
+    const uint32_t slot_t = c.tile_rank[tile];
+    const TileAcc a0 = c.tile_off[slot_t];
     const uint32_t gs = a0.nsl + (i - own_begin) / WAVE, lane = (i - own_begin) % WAVE;
     const uint32_t cap = boundary ? c.cap_fb : c.cap_ff;
     const uint32_t* __restrict__ p = (boundary ? c.nbr_fb : c.nbr_ff) + (size_t)gs * cap * WAVE + lane;
-    const uint64_t hoff = boundary ? (c.halo_stride ? (uint64_t)tile * c.bhalo_stride : a0.sb)
-                                   : (c.halo_stride ? (uint64_t)tile * c.halo_stride : a0.s);
+    const uint64_t hoff = boundary ? (c.halo_stride ? (uint64_t)slot_t * c.bhalo_stride : a0.sb)
+                                   : (c.halo_stride ? (uint64_t)slot_t * c.halo_stride : a0.s);
     for (uint32_t k = 0; k < cnt; ++k) {
         const uint32_t d = p[(size_t)(k >> 1) * WAVE];
         const uint32_t s = (k & 1u) ? (d >> 16) : (d & 0xffffu);
@@ -290,11 +323,28 @@ void launch_unsort_u32(uint32_t n, const uint32_t* perm, const uint32_t* in, uin
 constexpr int TABLE_THREADS = 256;  // >= HCELLS
 static_assert(TABLE_THREADS >= HCELLS, "one thread per halo cell");
 
+// one thread per tile of the dense grid: does it hold particles?
+__global__ __launch_bounds__(BLOCK) void k_tile_flags(const uint32_t* __restrict__ cell_start, uint32_t ntiles, uint32_t* __restrict__ flags) {
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t < ntiles) flags[t] = cell_start[(size_t)t * TCELLS + TCELLS] > cell_start[(size_t)t * TCELLS] ? 1u : 0u;
+    if (t == ntiles) flags[t] = 0u;
+}
+__global__ __launch_bounds__(BLOCK) void k_tile_ids(const uint32_t* __restrict__ rank, uint32_t ntiles, uint32_t* __restrict__ tile_ids) {
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t < ntiles && rank[t + 1] != rank[t]) tile_ids[rank[t]] = t;
+}
+void launch_tile_slots(const uint32_t* cell_start, uint32_t ntiles, uint32_t* flags, uint32_t* rank, uint32_t* tile_ids, void* temp,
+                       size_t temp_bytes, hipStream_t s) {
+    k_tile_flags<<<div_up((size_t)ntiles + 1, BLOCK), BLOCK, 0, s>>>(cell_start, ntiles, flags);
+    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, flags, rank, (int)(ntiles + 1), s));
+    k_tile_ids<<<div_up((size_t)ntiles, BLOCK), BLOCK, 0, s>>>(rank, ntiles, tile_ids);
+}
+
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc* __restrict__ tile_cnt) {
     Tile t;
-    t.setup_geom(c);
+    if (!t.setup_geom(c)) return;  // surplus workgroup: its entry was zeroed by the host
     TileAcc a{0, 0, 0, 0, 0, 0, 0, 0};
-    if (!t.empty()) {
+    {
         TileCells tc;
         tc.build(c, t);
         a.s = tc.lstart[HCELLS];
@@ -303,13 +353,12 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc
         a.nonempty = 1;
         a.max_s = (uint32_t)a.s; a.max_sb = (uint32_t)a.sb; a.max_nsl = a.nsl;
     }
-    if (threadIdx.x == 0) tile_cnt[t.tile] = a;
+    if (threadIdx.x == 0) tile_cnt[t.slot] = a;
 }
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uint32_t* __restrict__ halo_src,
                                                                  uint32_t* __restrict__ bhalo_src) {
     Tile t;
     t.setup(c);
-    if (t.empty()) return;
     TileCells tc;
     tc.build(c, t);
     const int sub = threadIdx.x % 16, grp = threadIdx.x / 16;
@@ -322,11 +371,12 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uin
         }
     }
 }
-void launch_tile_count(const StepCtx& c, TileAcc* tile_cnt, hipStream_t s) {
-    k_tile_count<<<c.ntiles, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, tile_cnt);
+// `nslots_bound` >= number of non-empty tiles (the host does not know the exact count yet)
+void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, hipStream_t s) {
+    if (nslots_bound) k_tile_count<<<nslots_bound, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, tile_cnt);
 }
 void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, hipStream_t s) {
-    k_tile_halo_fill<<<c.ntiles, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, halo_src, bhalo_src);
+    if (c.nlaunch) k_tile_halo_fill<<<c.nlaunch, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, halo_src, bhalo_src);
 }
 size_t scan_tiles_temp_bytes(uint32_t n) {
     size_t b = 0;
@@ -350,7 +400,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
     Tile t;
     t.setup(c);
     if (t.empty()) {
-        if (threadIdx.x == 0) tile_stats[t.tile] = TileListStats{0, 0, 0, 0};
+        if (threadIdx.x == 0) tile_stats[t.slot] = TileListStats{0, 0, 0, 0};
         return;
     }
     TileCells tc;
@@ -441,7 +491,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
             st.sum_ff += red[0][k]; st.sum_fb += red[1][k];
             st.max_ff = max(st.max_ff, red[2][k]); st.max_fb = max(st.max_fb, red[3][k]);
         }
-        tile_stats[t.tile] = st;
+        tile_stats[t.slot] = st;
     }
 }
 // fold the per-tile list statistics: out = {ncontacts_ff, ncontacts_fb} (u64) and {max_ff, max_fb} (u32)
@@ -475,7 +525,7 @@ void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsi
                       hipStream_t s) {
     if (c.n == 0) return;
     SALVA_LAUNCH_TILE(k_nbr_tile, c, L, L.bytes(20, 32, 4, true), s, c, static_cast<TileListStats*>(tile_stats));
-    k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.ntiles, totals2, maxima2);
+    k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.nlaunch, totals2, maxima2);
 }
 
 // ------------------------------------------------------------------------------------------------ boundary volumes

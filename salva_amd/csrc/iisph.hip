@@ -179,7 +179,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
     __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
     Tile t;
     t.setup(c);
-    if (t.empty()) { TileErr::zero(c, t.tile); return; }
+    if (t.empty()) { TileErr::zero(c, t.slot); return; }
     const float4* Lp = nullptr;
     const float4* Ld = nullptr;
     const float4* Lj = nullptr;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
         }
         E.add(c, err, mi, active && !is_ghost(c, i));
     });
-    E.finish(c, t.tile);
+    E.finish(c, t.slot);
 }
 void launch_iisph_next_pressure(const StepCtx& c, const TileLds& L, float dt, float omega, const float* p, float* p_next,
                                 hipStream_t s) {

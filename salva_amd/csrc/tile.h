@@ -53,10 +53,10 @@ inline void ensure_tile_lds(K kernel, uint32_t bytes) {
 }
 #define SALVA_LAUNCH_TILE(kernel, c, L, lds, s, ...)                          \
     do {                                                                   \
-        if ((c).n) {                                                       \
+        if ((c).n && (c).nlaunch) {                                        \
             const uint32_t _lds = (lds);                                   \
             ::salva::ensure_tile_lds(kernel, _lds);                        \
-            kernel<<<(c).ntiles, (L).threads, _lds, s>>>(__VA_ARGS__);     \
+            kernel<<<(c).nlaunch, (L).threads, _lds, s>>>(__VA_ARGS__);    \
             SALVA_HIP_CHECK(hipGetLastError());                            \
         }                                                                  \
     } while (0)
@@ -90,7 +90,8 @@ struct Tile {
     unsigned char* pool;  // staged arrays, 16-byte aligned
     uint32_t pool_used;
     uint32_t S, SB;       // halo slot counts (fluid / boundary)
-    uint32_t tile;        // logical tile index
+    uint32_t tile;        // index in the dense tile grid
+    uint32_t slot;        // index among the launched (non-empty) tiles: per-workgroup outputs (error partials, list stats)
     uint32_t own_begin, own_end, slice_base;
     uint64_t hoff, hboff; // offsets of this tile's slot tables in halo_src / bhalo_src
     int hcx, hcy, hcz;    // absolute cell coords of halo cell (0,0,0)
@@ -101,44 +102,51 @@ struct Tile {
 
     __device__ __forceinline__ bool empty() const { return own_begin == own_end; }
 
-    // geometry only (before the per-tile prefix table exists)
-    __device__ __forceinline__ void setup_geom(const StepCtx& c) {
+    // geometry only (k_tile_count: before the per-slot prefix table exists).  Launched over an upper bound of the slot
+    // count (the host does not know it yet): returns false for the surplus workgroups.
+    __device__ __forceinline__ bool setup_geom(const StepCtx& c) {
         pool = tile_smem;
         pool_used = 0;
-        tile = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+        slot = blockIdx.x;
+        S = SB = 0; slice_base = 0; hoff = hboff = 0;
+        pre0 = pre1 = pre2 = pre3 = preb = 0u;
+        own_begin = own_end = 0; tile = 0; hcx = hcy = hcz = 0;
+        if (slot >= c.tile_rank[c.ntiles]) return false;
+        tile = c.tile_ids[slot];
+        geometry(c);
+        return true;
+    }
+    __device__ __forceinline__ void geometry(const StepCtx& c) {
         const TileGrid& g = c.gf;
         const uint32_t ttz = tile % g.ntz, tty = (tile / g.ntz) % g.nty, ttx = tile / (g.ntz * g.nty);
         own_begin = g.cell_start[(size_t)tile * TCELLS];
         own_end = g.cell_start[(size_t)tile * TCELLS + TCELLS];
         hcx = g.ox + (int)ttx * TX - 1; hcy = g.oy + (int)tty * TY - 1; hcz = g.oz + (int)ttz * TZ - 1;
-        S = SB = 0; slice_base = 0; hoff = hboff = 0;
     }
 
+    // workgroup k of a launch works on slot k = the k-th non-empty tile (XCD-remapped so that neighbours share an L2)
     __device__ __forceinline__ void setup(const StepCtx& c) {
         pool = tile_smem;
         pool_used = 0;
-        tile = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-        const TileGrid& g = c.gf;
-        const uint32_t ttz = tile % g.ntz, tty = (tile / g.ntz) % g.nty, ttx = tile / (g.ntz * g.nty);
-        own_begin = g.cell_start[(size_t)tile * TCELLS];
-        own_end = g.cell_start[(size_t)tile * TCELLS + TCELLS];
-        hcx = g.ox + (int)ttx * TX - 1; hcy = g.oy + (int)tty * TY - 1; hcz = g.oz + (int)ttz * TZ - 1;
+        slot = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+        tile = c.tile_ids[slot];
         pre0 = pre1 = pre2 = pre3 = preb = 0u;
         if (c.halo_stride) {
-            const uint32_t* __restrict__ src = c.halo_src + (size_t)tile * c.halo_stride;
+            const uint32_t* __restrict__ src = c.halo_src + (size_t)slot * c.halo_stride;
             const uint32_t s0 = threadIdx.x, nt = blockDim.x, lim = c.halo_stride;
             if (s0 < lim) pre0 = src[s0];
             if (s0 + nt < lim) pre1 = src[s0 + nt];
             if (s0 + 2 * nt < lim) pre2 = src[s0 + 2 * nt];
             if (s0 + 3 * nt < lim) pre3 = src[s0 + 3 * nt];
-            if (c.bhalo_stride && s0 < c.bhalo_stride) preb = c.bhalo_src[(size_t)tile * c.bhalo_stride + s0];
+            if (c.bhalo_stride && s0 < c.bhalo_stride) preb = c.bhalo_src[(size_t)slot * c.bhalo_stride + s0];
         }
-        const TileAcc a0 = c.tile_off[tile], a1 = c.tile_off[tile + 1];
+        geometry(c);
+        const TileAcc a0 = c.tile_off[slot], a1 = c.tile_off[slot + 1];
         slice_base = a0.nsl;
         S = (uint32_t)(a1.s - a0.s);
         SB = (uint32_t)(a1.sb - a0.sb);
-        hoff = c.halo_stride ? (uint64_t)tile * c.halo_stride : a0.s;
-        hboff = c.halo_stride ? (uint64_t)tile * c.bhalo_stride : a0.sb;
+        hoff = c.halo_stride ? (uint64_t)slot * c.halo_stride : a0.s;
+        hboff = c.halo_stride ? (uint64_t)slot * c.bhalo_stride : a0.sb;
     }
 
     template <typename T>

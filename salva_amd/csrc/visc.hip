@@ -187,7 +187,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_strain(StepCtx c, uin
     __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
     Tile t;
     t.setup(c);
-    if (t.empty()) { if (mode == 1) TileErr::zero(c, t.tile); return; }
+    if (t.empty()) { if (mode == 1) TileErr::zero(c, t.slot); return; }
     const float4* Lp = nullptr;
     const float4* Lv = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), va, Lp, Lv);
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_strain(StepCtx c, uin
         }
         if (mode == 1) E.add(c, err1, model, mine && !is_ghost(c, i));
     });
-    if (mode == 1) E.finish(c, t.tile);
+    if (mode == 1) E.finish(c, t.slot);
 }
 void launch_visc_strain(const StepCtx& c, const TileLds& L, uint32_t model, int mode, float coef, const float4* va,
                         const float* beta, float* target, float4* u0, float4* u1, hipStream_t s) {

@@ -109,7 +109,8 @@ class World {
     DevBuf<float> rho, alpha, kappa, kappa2, rho_star, aii;
     DevBuf<uint32_t> nff, nfb, keys[2], idx[2], cell_start_f;
     DevBuf<TileAcc> tile_cnt, tile_off;
-    DevBuf<uint32_t> d_maxhalo, halo_src, bhalo_src;
+    DevBuf<uint32_t> d_maxhalo, halo_src, bhalo_src, tile_ids, tile_flags, tile_rank;
+    uint32_t nlaunch = 0;  // non-empty tiles of the current step = grid size of the solver kernels
     uint32_t last_iters[NUM_SOLVES] = {1u, 1u, 1u};  // iterations of the previous step's divergence / pressure solve (batch sizing)
     uint32_t halo_stride = 0, bhalo_stride = 0;  // fixed row stride of the slot tables (0 = compact)
     DevBuf<char> tile_list_stats;

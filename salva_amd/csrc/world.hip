@@ -419,6 +419,7 @@ StepCtx World::make_ctx() {
     c.tile_off = tile_off.p; c.halo_src = halo_src.p; c.bhalo_src = bhalo_src.p;
     c.halo_stride = halo_stride; c.bhalo_stride = bhalo_stride;
     c.ntiles = (uint32_t)gf.ntiles();
+    c.tile_ids = tile_ids.p; c.tile_rank = tile_rank.p; c.nlaunch = nlaunch;
     c.gf = TileGrid{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], cell_start_f.p};
     c.nb = nb;
     c.bposv = bposv.p; c.bvel = bvel.p; c.bperm = bperm.p;
@@ -693,14 +694,20 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     dims_from_bbox(h_rb->bbox, gf);
     const size_t ncf = gf.ncells();
     const uint32_t ntiles = (uint32_t)gf.ntiles();
+    // only the cell table and one flag per tile are dense over the bounding box; every other per-tile table is compact
+    // over the non-empty tiles ("slots"), of which there are at most min(ntiles, n)
+    const uint32_t nslots_bound = (uint32_t)std::min<uint64_t>(ntiles, n);
     cell_start_f.ensure(ncf + 1, stream, false, 1.5f);
-    tile_cnt.ensure(ntiles + 1, stream, false, 1.5f);
-    tile_off.ensure(ntiles + 1, stream, false, 1.5f);
+    tile_flags.ensure((size_t)ntiles + 1, stream, false, 1.5f);
+    tile_rank.ensure((size_t)ntiles + 1, stream, false, 1.5f);
+    tile_ids.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
+    tile_cnt.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
+    tile_off.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
     d_maxhalo.ensure(4);
-    partials.ensure((size_t)ntiles * std::max<size_t>(fluids.size(), 1), stream, false, 1.5f);
+    partials.ensure((size_t)std::max<uint32_t>(nslots_bound, 1u) * std::max<size_t>(fluids.size(), 1), stream, false, 1.5f);
     // every tile wastes less than one 64-particle slice
-    const uint32_t ns_cap = n / WAVE + ntiles + 1;
-    tile_list_stats.ensure(tile_list_stats_bytes(ntiles), stream, false, 1.5f);
+    const uint32_t ns_cap = n / WAVE + nslots_bound + 1;
+    tile_list_stats.ensure(tile_list_stats_bytes(std::max<uint32_t>(nslots_bound, 1u)), stream, false, 1.5f);
 
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
     {
@@ -719,15 +726,18 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     build_boundary_grid();  // insert_boundaries_to_grid (liquid_world.rs:106) + boundary volumes, only when dirty
 
     // ---- tile tables: per-tile halo sizes / slice counts -> prefix -> flat halo slot tables
+    nlaunch = 0;  // not known yet
     StepCtx c = make_ctx();
     {
-        const size_t tb = scan_tiles_temp_bytes(ntiles + 1);
+        const size_t tb = std::max(scan_tiles_temp_bytes(nslots_bound + 1), scan_temp_bytes(ntiles + 1));
         ensure_cub_temp(tb);
-        SALVA_HIP_CHECK(hipMemsetAsync(tile_cnt.p + ntiles, 0, sizeof(TileAcc), stream));
-        launch_tile_count(c, tile_cnt.p, stream);
-        scan_tiles(cub_temp.p, tb, tile_cnt.p, tile_off.p, ntiles + 1, stream);
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + ntiles, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
+        launch_tile_slots(cell_start_f.p, ntiles, tile_flags.p, tile_rank.p, tile_ids.p, cub_temp.p, tb, stream);
+        SALVA_HIP_CHECK(hipMemsetAsync(tile_cnt.p, 0, ((size_t)nslots_bound + 1) * sizeof(TileAcc), stream));
+        launch_tile_count(c, nslots_bound, tile_cnt.p, stream);
+        scan_tiles(cub_temp.p, tb, tile_cnt.p, tile_off.p, nslots_bound + 1, stream);
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + nslots_bound, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
         wait_stream();
+        nlaunch = h_rb->tile_total.nonempty;
         lds.max_halo_fluid = h_rb->tile_total.max_s;
         lds.max_halo_boundary = h_rb->tile_total.max_sb;
         // one wave per 64-particle slice of the average non-empty tile (fuller tiles loop over their extra slices),
@@ -745,15 +755,15 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         // that a tile kernel can fetch its rows before it knows its sizes; compact rows otherwise (sparse scenes)
         {
             const uint64_t st_f = (lds.max_halo_fluid + 63u) & ~63u, st_b = nb ? ((lds.max_halo_boundary + 63u) & ~63u) : 0u;
-            const uint64_t strided = (uint64_t)ntiles * (st_f + st_b), compact = h_rb->tile_total.s + h_rb->tile_total.sb;
+            const uint64_t strided = (uint64_t)nlaunch * (st_f + st_b), compact = h_rb->tile_total.s + h_rb->tile_total.sb;
             const bool use = strided <= 3 * compact + (1u << 20) && !getenv("SALVA_HIP_COMPACT_HALO");
             halo_stride = use ? (uint32_t)st_f : 0u;
             bhalo_stride = use ? (uint32_t)st_b : 0u;
         }
-        const size_t need_f = halo_stride ? (size_t)ntiles * halo_stride : (size_t)h_rb->tile_total.s;
-        const size_t need_b = halo_stride ? (size_t)ntiles * bhalo_stride : (size_t)h_rb->tile_total.sb;
-        const bool g1 = halo_src.ensure(need_f ? need_f : 1, stream, false, 1.2f);
-        const bool g2 = bhalo_src.ensure(need_b ? need_b : 1, stream, false, 1.2f);
+        const size_t need_f = halo_stride ? (size_t)nlaunch * halo_stride : (size_t)h_rb->tile_total.s;
+        const size_t need_b = halo_stride ? (size_t)nlaunch * bhalo_stride : (size_t)h_rb->tile_total.sb;
+        halo_src.ensure(need_f ? need_f : 1, stream, false, 1.2f);
+        bhalo_src.ensure(need_b ? need_b : 1, stream, false, 1.2f);
         c = make_ctx();
         launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, stream);
 
@@ -995,7 +1005,7 @@ float World::time_pred_density(int reps) {
     if (reps < 1) reps = 1;
     if (getenv("SALVA_HIP_TILE_TIMING")) {
         DevBuf<unsigned long long> dbg;
-        const size_t nt = gf.ntiles();
+        const size_t nt = std::max<uint32_t>(last_ctx.nlaunch, 1u);
         dbg.ensure(nt * 8);
         SALVA_HIP_CHECK(hipMemsetAsync(dbg.p, 0, nt * 8 * sizeof(unsigned long long), stream));
         StepCtx cd = last_ctx;

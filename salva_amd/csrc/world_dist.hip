@@ -149,7 +149,7 @@ void World::refresh_f4(float4* field) {
 
 // Error reduction + break test of an iterative solve; with a transport the per-fluid sums are all-reduced first.
 void World::finalize_solve(SolveCtl* ctl) {
-    const unsigned ntiles = (unsigned)gf.ntiles();
+    const unsigned ntiles = nlaunch;  // one partial per launched (non-empty) tile
     const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1);
     if (!comm) {
         // (folding this into the evaluate kernels through a last-workgroup reduction was measured 7x slower: the
