@@ -249,4 +249,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:  # noqa: BLE001
+        # in a multi-rank run the other ranks are blocked in a neighbour exchange: die at once so that the launcher
+        # tears the job down instead of waiting for a timeout
+        import traceback
+
+        traceback.print_exc()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)
