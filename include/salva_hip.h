@@ -193,6 +193,17 @@ int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_
 int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* gids, float* positions_xyz,
                             float* velocities_xyz, uint32_t* fluid_slots);
 
+/* `Fluid::add_particles(positions, velocities)` (object/fluid.rs:126-150): append to the fluid on the device — default
+ * volume, zero acceleration and velocity change — without re-uploading the particles it already holds.
+ * velocities_xyz may be NULL (zeros). */
+int salva_hip_add_particles(SalvaHipWorld* world, uint32_t slot, uint64_t n_add, const float* positions_xyz,
+                            const float* velocities_xyz);
+/* `Fluid::delete_particle_at_next_timestep` + `apply_particles_removal` (fluid.rs:71-98) and the solver's matching
+ * compaction of its velocity_changes (dfsph_solver.rs:550-560): stable compaction of every per-particle array of the
+ * fluid on the device.  deleted_mask has fluid_len bytes, non-zero = delete.  Returns the remaining count (negative on
+ * error); the survivors keep their order, so the host compacts its copies with the same mask. */
+int64_t salva_hip_delete_particles(SalvaHipWorld* world, uint32_t slot, const uint8_t* deleted_mask);
+
 /* `ContactManager::fluid_fluid_contacts[slot]` / `fluid_boundary_contacts[slot]` (liquid_world.rs:26, geometry/contacts.rs:57-131)
  * of the last step as a CSR structure in host order: offsets has fluid_len + 1 entries, contact k of particle i is
  * (j_model[offsets[i] + k], j[offsets[i] + k]) — the model (fluid or boundary slot) and the index inside that model's host

@@ -230,6 +230,23 @@ int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* g
     return rc == SALVA_HIP_OK ? count : (int64_t)rc;
 }
 
+int salva_hip_add_particles(SalvaHipWorld* world, uint32_t slot, uint64_t n_add, const float* positions_xyz, const float* velocities_xyz) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->add_particles(slot, n_add, positions_xyz, velocities_xyz);
+        return SALVA_HIP_OK;
+    });
+}
+int64_t salva_hip_delete_particles(SalvaHipWorld* world, uint32_t slot, const uint8_t* deleted_mask) {
+    int64_t kept = 0;
+    const int rc = guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        kept = (int64_t)world->w->delete_particles(slot, deleted_mask);
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? kept : (int64_t)rc;
+}
+
 int64_t salva_hip_get_fluid_contacts(SalvaHipWorld* world, uint32_t slot, int32_t boundary_contacts, uint64_t* offsets,
                                      uint32_t* j_model, uint32_t* j, uint64_t capacity) {
     int64_t total = 0;

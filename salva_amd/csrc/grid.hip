@@ -92,6 +92,16 @@ void sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t
     SALVA_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (size_t)n, 0u,
                                                           (unsigned)end_bit, s));
 }
+size_t select_flagged_temp_bytes(uint32_t n) {
+    size_t b = 0;
+    (void)hipcub::DeviceSelect::Flagged(nullptr, b, (const float4*)nullptr, (const uint8_t*)nullptr, (float4*)nullptr, (uint32_t*)nullptr, (int)n);
+    return b;
+}
+// stable compaction of the flagged items (filter_from_mask, solver/helper.rs:4-12)
+void select_flagged_f4(void* temp, size_t temp_bytes, const float4* in, const uint8_t* flags, float4* out, uint32_t* num_selected,
+                       uint32_t n, hipStream_t s) {
+    SALVA_HIP_CHECK(hipcub::DeviceSelect::Flagged(temp, temp_bytes, in, flags, out, num_selected, (int)n, s));
+}
 size_t scan_temp_bytes(uint32_t n) {
     size_t a = 0, b = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n);

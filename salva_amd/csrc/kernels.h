@@ -51,6 +51,9 @@ void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, 
 size_t tile_list_stats_bytes(uint32_t ntiles);
 void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsigned long long* totals2, uint32_t* maxima2,
                       hipStream_t s);
+size_t select_flagged_temp_bytes(uint32_t n);
+void select_flagged_f4(void* temp, size_t temp_bytes, const float4* in, const uint8_t* flags, float4* out, uint32_t* num_selected,
+                       uint32_t n, hipStream_t s);
 size_t scan_temp_bytes(uint32_t n);
 void scan_u64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* out, uint32_t n, hipStream_t s);
 

@@ -47,6 +47,8 @@ class World {
                       uint32_t filter, bool wants_forces);
     void remove_boundary(uint32_t slot);
     int step(float dt, const float g[3], SalvaHipStepStats* stats);
+    void add_particles(uint32_t slot, uint64_t n_add, const float* pos, const float* vel);
+    uint64_t delete_particles(uint32_t slot, const uint8_t* mask);
     void get_fluid(uint32_t slot, float* pos, float* vel);
     void get_force_stats(uint32_t slot, uint32_t force, int32_t* iters, float* err);
     uint64_t get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity);

@@ -246,6 +246,90 @@ void World::set_fluid(uint32_t slot, uint64_t nn, const float* pos, const float*
     have_last_ctx = false;
 }
 
+// Fluid::add_particles (fluid.rs:126-150): append to the fluid's arrays — default volume, zero acceleration, zero
+// velocity change (the solver's buffers grow with zeros, dfsph_solver.rs:526-549) — without re-uploading the rest.
+void World::add_particles(uint32_t slot, uint64_t n_add, const float* pos, const float* vel_h) {
+    use_device();
+    if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
+    if (comm) throw HipError(SALVA_HIP_E_INVALID, "particles cannot be added in a multi-GPU run yet");
+    if (n_add == 0) return;
+    if (!pos) throw HipError(SALVA_HIP_E_INVALID, "positions are required");
+    if ((uint64_t)n + n_add >= 0xfffffff0ull) throw HipError(SALVA_HIP_E_CAPACITY, "more than 2^32 fluid particles on one device");
+    ensure_staging_current();
+    const uint64_t old_n = fluids[slot].n, off = fluid_offset(slot), at = off + old_n, old_total = n, new_total = old_total + n_add;
+    std::vector<Piece> pieces = {{0, at, true}, {0, n_add, false}, {at, old_total - at, true}};
+    rebuild(st_pos, pieces, new_total, stream);
+    rebuild(st_vel, pieces, new_total, stream);
+    rebuild(st_dv, pieces, new_total, stream);
+    rebuild(st_acc, pieces, new_total, stream);
+    rebuild(st_model, pieces, new_total, stream);
+    n = (uint32_t)new_total;
+    fluids[slot].n = old_n + n_add;
+    const float r = prm.particle_radius;
+    k_fill_f4<<<nblk(n_add), BLOCK, 0, stream>>>((uint32_t)n_add, st_pos.p + at, make_float4(0, 0, 0, r * r * r * 6.4f), 0);
+    k_fill_f4<<<nblk(n_add), BLOCK, 0, stream>>>((uint32_t)n_add, st_vel.p + at, make_float4(0, 0, 0, 0), 0);
+    k_fill_f4<<<nblk(n_add), BLOCK, 0, stream>>>((uint32_t)n_add, st_dv.p + at, make_float4(0, 0, 0, 0), 0);
+    k_fill_f4<<<nblk(n_add), BLOCK, 0, stream>>>((uint32_t)n_add, st_acc.p + at, make_float4(0, 0, 0, 0), 0);
+    uint64_t o = 0;
+    for (uint32_t s = 0; s < fluids.size(); ++s) {
+        if (fluids[s].n) k_fill_u32<<<nblk(fluids[s].n), BLOCK, 0, stream>>>((uint32_t)fluids[s].n, st_model.p + o, s);
+        o += fluids[s].n;
+    }
+    scratch_f.ensure(3 * n_add, stream, false, 1.1f);
+    SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, pos, 3 * n_add * sizeof(float), hipMemcpyHostToDevice, stream));
+    k_pack_xyz<<<nblk(n_add), BLOCK, 0, stream>>>((uint32_t)n_add, scratch_f.p, st_pos.p + at, 1, 0.0f);
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    if (vel_h) {
+        SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, vel_h, 3 * n_add * sizeof(float), hipMemcpyHostToDevice, stream));
+        k_pack_xyz<<<nblk(n_add), BLOCK, 0, stream>>>((uint32_t)n_add, scratch_f.p, st_vel.p + at, 1, 0.0f);
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    sorted_valid = false; bbox_known = false; tables_dirty = true; have_last_ctx = false;
+}
+
+// Fluid::apply_particles_removal (fluid.rs:88-98) together with the compaction of the solver's velocity_changes
+// (dfsph_solver.rs:550-560 / iisph_solver.rs:505-537): a stable compaction (`filter_from_mask`, helper.rs:4-12) of every
+// per-particle array of the fluid, on the device.  `mask[i] != 0` deletes particle i.  Returns the remaining count.
+uint64_t World::delete_particles(uint32_t slot, const uint8_t* mask) {
+    use_device();
+    if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
+    if (comm) throw HipError(SALVA_HIP_E_INVALID, "particles cannot be deleted in a multi-GPU run yet");
+    const uint64_t nn = fluids[slot].n, off = fluid_offset(slot);
+    if (nn == 0 || !mask) return nn;
+    ensure_staging_current();
+    // keep flags over the whole staging range (other fluids are kept)
+    std::vector<uint8_t> keep((size_t)n, 1);
+    uint64_t kept = 0;
+    for (uint64_t k = 0; k < nn; ++k) { keep[off + k] = mask[k] ? 0 : 1; kept += keep[off + k]; }
+    if (kept == nn) return nn;
+    DevBuf<uint8_t> d_keep;
+    DevBuf<uint32_t> d_num;
+    d_keep.ensure(n); d_num.ensure(1);
+    SALVA_HIP_CHECK(hipMemcpyAsync(d_keep.p, keep.data(), (size_t)n, hipMemcpyHostToDevice, stream));
+    const uint64_t new_total = (uint64_t)n - (nn - kept);
+    auto compact = [&](DevBuf<float4>& buf) {
+        DevBuf<float4> out;
+        out.ensure(std::max<uint64_t>(new_total, 1));
+        const size_t tb = select_flagged_temp_bytes(n);
+        ensure_cub_temp(tb);
+        select_flagged_f4(cub_temp.p, tb, buf.p, d_keep.p, out.p, d_num.p, n, stream);
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        std::swap(buf.p, out.p);
+        std::swap(buf.cap, out.cap);
+    };
+    compact(st_pos); compact(st_vel); compact(st_dv); compact(st_acc);
+    n = (uint32_t)new_total;
+    fluids[slot].n = kept;
+    uint64_t o = 0;
+    for (uint32_t s = 0; s < fluids.size(); ++s) {
+        if (fluids[s].n) k_fill_u32<<<nblk(fluids[s].n), BLOCK, 0, stream>>>((uint32_t)fluids[s].n, st_model.p + o, s);
+        o += fluids[s].n;
+    }
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    sorted_valid = false; bbox_known = false; tables_dirty = true; have_last_ctx = false;
+    return kept;
+}
+
 void World::set_fluid_forces(uint32_t slot, const SalvaHipForceDesc* f, uint32_t nf) {
     if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
     for (uint32_t k = 0; k < nf; ++k)

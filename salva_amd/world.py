@@ -263,11 +263,21 @@ class Fluid:
         return self._deleted
 
     def add_particles(self, positions, velocities=None):
-        """fluid.rs:126-150"""
-        self._pull()
+        """fluid.rs:126-150.  A fluid that already lives on the device grows there (salva_hip_add_particles): nothing it
+        holds is re-uploaded or downloaded."""
         pos = _as_vec3(positions)
         k = len(pos)
         vel = _as_vec3(velocities, k) if velocities is not None else np.zeros((k, 3), F32)
+        w = self._world
+        if w is not None and not self._resized and not self._dirty and not self._deleted.any() and k:
+            L.check(w._L.salva_hip_add_particles(w._h, self._slot, k, _fp(pos), _fp(vel)))
+            self._positions = np.concatenate([self._positions, pos])  # stale rows are refreshed by the next _pull()
+            self._velocities = np.concatenate([self._velocities, vel])
+            self._accelerations = np.concatenate([self._accelerations, np.zeros((k, 3), F32)])
+            self._volumes = np.concatenate([self._volumes, np.full(k, self.default_particle_volume(), F32)])
+            self._deleted = np.concatenate([self._deleted, np.zeros(k, bool)])
+            return
+        self._pull()
         dv = self._world._fetch_velocity_changes(self) if (self._world is not None and not self._resized) else None
         self._positions = np.concatenate([self._positions, pos])
         self._velocities = np.concatenate([self._velocities, vel])
@@ -493,6 +503,21 @@ class LiquidWorld:
     def _apply_particles_removal(self, f: Fluid):
         """fluid.rs:88-98 + the compaction of the solver's buffers (dfsph_solver.rs:550-560)."""
         if not f._deleted.any():
+            return
+        if not f._resized and not f._dirty and f._pending_dv is None:
+            # the fluid is current on the device: compact it there (salva_hip_delete_particles) and the host copies
+            # with the same mask — no download, no re-upload
+            mask = np.ascontiguousarray(f._deleted, np.uint8)
+            kept = int(self._L.salva_hip_delete_particles(self._h, f._slot, mask.ctypes.data_as(C.POINTER(C.c_uint8))))
+            if kept < 0:
+                L.check(kept)
+            keep = ~f._deleted
+            f._positions = np.ascontiguousarray(f._positions[keep])
+            f._velocities = np.ascontiguousarray(f._velocities[keep])
+            f._accelerations = np.ascontiguousarray(f._accelerations[keep])
+            f._volumes = np.ascontiguousarray(f._volumes[keep])
+            f._deleted = np.zeros(kept, bool)
+            assert kept == len(f._positions)
             return
         f._pull()
         dv = f._pending_dv if f._pending_dv is not None else (

@@ -329,3 +329,46 @@ def test_stray_particles_far_from_the_bulk():
     w, (fl,), _ = s.make_hip()
     st = w.step(DT, GRAVITY)
     assert st.step_ms < 20.0, f"a step over a mostly empty 30M-cell box took {st.step_ms:.1f} ms"
+
+
+def test_device_side_add_and_delete_match_the_host_path():
+    """Fluid::add_particles / delete_particle_at_next_timestep (fluid.rs:71-150; SURVEY.md §8 row f4).  A faucet-like loop
+    run twice: once growing / compacting the fluid on the device (salva_hip_add_particles / salva_hip_delete_particles),
+    once through the host path (download, edit the arrays, re-upload everything with the survivors' velocity_changes).
+    Both are the same stable compaction of the same data, so the trajectories must be bit-identical."""
+    from salva_amd import Boundary, DFSPHSolver, Fluid, LiquidWorld, XSPHViscosity
+    from salva_amd import _lib as L
+
+    fluid, shell = scenes.tank(10, 10, 10, R)
+    fluid = scenes.jitter(fluid, 0.05 * R, seed=42)
+    nozzle = scenes.cube_fluid_positions(3, 1, 3, R) + np.float32([0.0, 0.55, 0.0])
+
+    def run(host_path):
+        w = LiquidWorld(DFSPHSolver(), R, 2.0)
+        f = Fluid(fluid, R, 1000.0)
+        f.nonpressure_forces.append(XSPHViscosity(0.5, 0.0))
+        w.add_fluid(f)
+        w.add_boundary(Boundary(shell))
+        counts = []
+        for k in range(12):
+            w.step(DT, GRAVITY)
+            if k % 2 == 1:
+                if host_path:
+                    _ = f.positions
+                    f._dirty |= L.DIRTY_POSITIONS  # pretend the host edited something: forces the re-upload path
+                f.add_particles(nozzle, np.tile(np.float32([0.0, -1.0, 0.0]), (len(nozzle), 1)))
+            if k % 3 == 2:
+                for i in range(0, f.num_particles(), 17):
+                    f.delete_particle_at_next_timestep(i)
+                if host_path:
+                    _ = f.positions
+                    f._dirty |= L.DIRTY_POSITIONS
+            counts.append(f.num_particles() - f.num_deleted_particles())
+        w.step(DT, GRAVITY)
+        return f.positions.copy(), f.velocities.copy(), w.velocity_changes(f), counts
+
+    pa, va, da, ca = run(False)
+    pb, vb, db, cb = run(True)
+    assert ca == cb and len(pa) == ca[-1] and ca[-1] != 1000
+    assert np.array_equal(pa, pb) and np.array_equal(va, vb) and np.array_equal(da, db)
+    assert np.isfinite(pa).all()
