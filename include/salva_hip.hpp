@@ -121,7 +121,7 @@ class Fluid {  // object/fluid.rs
     Real default_particle_volume() const { return particle_radius_ * particle_radius_ * particle_radius_ * 6.4f; }  // fluid.rs:110-120
     size_t num_particles() const { return positions.size(); }
     Real particle_mass(size_t i) const { return volumes[i] * density0; }
-    void delete_particle_at_next_timestep(size_t i) { deleted_[i] = true; structural_ = true; }
+    void delete_particle_at_next_timestep(size_t i) { deleted_[i] = true; }
     void add_particles(const std::vector<Vec3>& pos, const std::vector<Vec3>* vel = nullptr) {  // fluid.rs:126-150
         if (vel && vel->size() != pos.size()) throw Error(SALVA_HIP_E_INVALID, "The provided positions and velocities arrays must have the same length.");
         positions.insert(positions.end(), pos.begin(), pos.end());
@@ -129,8 +129,8 @@ class Fluid {  // object/fluid.rs
         velocities.resize(positions.size(), Vec3{0, 0, 0});
         accelerations.resize(positions.size(), Vec3{0, 0, 0});
         volumes.resize(positions.size(), default_particle_volume());
+        if (appended_from_ == kNone) appended_from_ = deleted_.size();  // [appended_from_, size) is not on the device yet
         deleted_.resize(positions.size(), false);
-        structural_ = true;
     }
     void transform_by(const Vec3& translation) {
         for (auto& p : positions) for (int a = 0; a < 3; ++a) p[a] += translation[a];
@@ -143,7 +143,9 @@ class Fluid {  // object/fluid.rs
     Real particle_radius_;
     std::vector<bool> deleted_;
     uint32_t dirty_ = SALVA_HIP_DIRTY_ALL;
-    bool structural_ = true;  // particle count changed (new fluid, add_particles, deletions pending)
+    static constexpr size_t kNone = (size_t)-1;
+    size_t appended_from_ = kNone;  // add_particles since the last upload
+    bool structural_ = true;        // the whole fluid must be (re)uploaded: new fluid, or edits that the device cannot replay
 };
 
 class Boundary {  // object/boundary.rs
@@ -234,7 +236,36 @@ class LiquidWorld {  // liquid_world.rs
         bool have_dv = false;
         bool any_deleted = false;
         for (bool d : f.deleted_) any_deleted |= d;
-        if (f.structural_ && slot < salva_hip_num_fluids(w_)) {
+        const bool on_device = slot < salva_hip_num_fluids(w_);
+        if (on_device && !f.structural_ && !f.dirty_ && (any_deleted || f.appended_from_ != Fluid::kNone)) {
+            // replay the edits on the device: append (fluid.rs:126-150), then compact (fluid.rs:88-98) — nothing the
+            // fluid already holds travels over PCIe
+            if (f.appended_from_ != Fluid::kNone) {
+                const size_t a = f.appended_from_, k = f.positions.size() - a;
+                if (k) check(salva_hip_add_particles(w_, slot, k, f.positions[a].data(), f.velocities[a].data()));
+                f.appended_from_ = Fluid::kNone;
+            }
+            if (any_deleted) {
+                std::vector<uint8_t> mask(f.deleted_.size());
+                for (size_t i = 0; i < mask.size(); ++i) mask[i] = f.deleted_[i] ? 1 : 0;
+                const int64_t kept = salva_hip_delete_particles(w_, slot, mask.data());
+                if (kept < 0) check((int)kept);
+                size_t k = 0;
+                for (size_t i = 0; i < f.positions.size(); ++i) {
+                    if (f.deleted_[i]) continue;
+                    f.positions[k] = f.positions[i]; f.velocities[k] = f.velocities[i];
+                    f.accelerations[k] = f.accelerations[i]; f.volumes[k] = f.volumes[i];
+                    ++k;
+                }
+                f.positions.resize(k); f.velocities.resize(k); f.accelerations.resize(k); f.volumes.resize(k);
+                f.deleted_.assign(k, false);
+                any_deleted = false;
+            }
+        } else if (any_deleted || f.appended_from_ != Fluid::kNone) {
+            f.structural_ = true;  // mixed with other host edits: take the full re-upload path below
+            f.appended_from_ = Fluid::kNone;
+        }
+        if (f.structural_ && on_device) {
             const uint64_t old_n = salva_hip_fluid_len(w_, slot);
             if (old_n) {
                 dv.assign(old_n, Vec3{0, 0, 0});
