@@ -193,6 +193,14 @@ int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_
 int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* gids, float* positions_xyz,
                             float* velocities_xyz, uint32_t* fluid_slots);
 
+/* `LiquidWorld::particles_intersecting_aabb(aabb)` (liquid_world.rs:210-243): the particles whose distance to the box
+ * [mins, maxs] is below the particle radius, as (kind, slot, index) triples sorted by kind (0 = ParticleId::FluidParticle,
+ * 1 = BoundaryParticle), slot and index.  Returns how many there are (negative on error); at most `capacity` are written.
+ * The reference filters the cells of the grid of its last step; this tests current positions, so it also finds particles
+ * that entered the box's cells since then. */
+int64_t salva_hip_particles_intersecting_aabb(SalvaHipWorld* world, const float mins[3], const float maxs[3], uint64_t capacity,
+                                             uint32_t* kinds, uint32_t* slots, uint32_t* indices);
+
 /* `Fluid::add_particles(positions, velocities)` (object/fluid.rs:126-150): append to the fluid on the device — default
  * volume, zero acceleration and velocity change — without re-uploading the particles it already holds.
  * velocities_xyz may be NULL (zeros). */

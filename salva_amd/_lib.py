@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_last_error", "salva_hip_version", "salva_hip_comm_rccl_unique_id", "salva_hip_comm_rccl_create",
     "salva_hip_comm_loopback_create", "salva_hip_comm_destroy", "salva_hip_set_domain", "salva_hip_get_owned",
     "salva_hip_get_force_stats", "salva_hip_get_fluid_contacts", "salva_hip_add_particles", "salva_hip_delete_particles",
+    "salva_hip_particles_intersecting_aabb",
 ]
 
 
@@ -136,6 +137,8 @@ def lib():
     L.salva_hip_set_domain.argtypes = [vp, vp, i32, i32, u32]
     L.salva_hip_get_owned.argtypes = [vp, u32, C.POINTER(u32), fp, fp, C.POINTER(u32)]
     L.salva_hip_get_owned.restype = C.c_int64
+    L.salva_hip_particles_intersecting_aabb.argtypes = [vp, fp, fp, u64, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.salva_hip_particles_intersecting_aabb.restype = C.c_int64
     L.salva_hip_add_particles.argtypes = [vp, u32, u64, fp, fp]
     L.salva_hip_delete_particles.argtypes = [vp, u32, C.POINTER(C.c_uint8)]
     L.salva_hip_delete_particles.restype = C.c_int64

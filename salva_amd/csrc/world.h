@@ -49,6 +49,8 @@ class World {
     int step(float dt, const float g[3], SalvaHipStepStats* stats);
     void add_particles(uint32_t slot, uint64_t n_add, const float* pos, const float* vel);
     uint64_t delete_particles(uint32_t slot, const uint8_t* mask);
+    uint64_t particles_in_aabb(const float mins[3], const float maxs[3], uint64_t capacity, uint32_t* kinds, uint32_t* slots,
+                               uint32_t* indices);
     void get_fluid(uint32_t slot, float* pos, float* vel);
     void get_force_stats(uint32_t slot, uint32_t force, int32_t* iters, float* err);
     uint64_t get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity);

@@ -909,6 +909,58 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     return SALVA_HIP_OK;
 }
 
+// LiquidWorld::particles_intersecting_aabb (liquid_world.rs:210-243): particles whose distance to the box is below the
+// particle radius.  The reference walks the cells of its (last step's) grid; here every particle's current position is
+// tested, which finds the same particles plus those that entered the box's cells since the grid was built.
+__global__ __launch_bounds__(BLOCK) void k_aabb_query(const float4* __restrict__ pos, uint32_t n, float3 lo, float3 hi, float r2,
+                                                      uint32_t kind, unsigned int* __restrict__ counter, uint32_t cap,
+                                                      uint32_t* __restrict__ out_kind, uint32_t* __restrict__ out_index) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pos[i];
+    const float dx = fmaxf(fmaxf(lo.x - p.x, p.x - hi.x), 0.0f), dy = fmaxf(fmaxf(lo.y - p.y, p.y - hi.y), 0.0f),
+                dz = fmaxf(fmaxf(lo.z - p.z, p.z - hi.z), 0.0f);
+    if (!(dx * dx + dy * dy + dz * dz < r2)) return;
+    const uint32_t k = atomicAdd(counter, 1u);
+    if (k < cap) { out_kind[k] = kind; out_index[k] = i; }
+}
+uint64_t World::particles_in_aabb(const float mins[3], const float maxs[3], uint64_t capacity, uint32_t* kinds, uint32_t* slots,
+                                  uint32_t* indices) {
+    use_device();
+    if (comm) throw HipError(SALVA_HIP_E_INVALID, "queries are not available in a multi-GPU run");
+    ensure_staging_current();
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(capacity, 0xfffffff0ull);
+    DevBuf<unsigned int> cnt;
+    DevBuf<uint32_t> dk, di;
+    cnt.ensure(1); dk.ensure(std::max(cap, 1u)); di.ensure(std::max(cap, 1u));
+    SALVA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(unsigned int), stream));
+    const float r = prm.particle_radius;
+    const float3 lo = make_float3(mins[0], mins[1], mins[2]), hi = make_float3(maxs[0], maxs[1], maxs[2]);
+    if (n) k_aabb_query<<<nblk(n), BLOCK, 0, stream>>>(st_pos.p, n, lo, hi, r * r, 0u, cnt.p, cap, dk.p, di.p);
+    if (nb) k_aabb_query<<<nblk(nb), BLOCK, 0, stream>>>(bst_pos.p, nb, lo, hi, r * r, 1u, cnt.p, cap, dk.p, di.p);
+    unsigned int total = 0;
+    SALVA_HIP_CHECK(hipMemcpyAsync(&total, cnt.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    const uint32_t m = std::min<uint32_t>(total, cap);
+    if (m == 0 || !kinds || !slots || !indices) return total;
+    std::vector<uint32_t> hk(m), hi_(m);
+    SALVA_HIP_CHECK(hipMemcpy(hk.data(), dk.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SALVA_HIP_CHECK(hipMemcpy(hi_.data(), di.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // (kind, global index) -> sorted, then split the global index into (slot, index inside the slot)
+    std::vector<uint64_t> keys(m);
+    for (uint32_t k = 0; k < m; ++k) keys[k] = ((uint64_t)hk[k] << 32) | hi_[k];
+    std::sort(keys.begin(), keys.end());
+    for (uint32_t k = 0; k < m; ++k) {
+        const uint32_t kind = (uint32_t)(keys[k] >> 32);
+        uint64_t g = keys[k] & 0xffffffffull;
+        uint32_t s = 0;
+        if (kind == 0) { while (s + 1 < fluids.size() && g >= fluids[s].n) { g -= fluids[s].n; ++s; } }
+        else { while (s + 1 < bounds.size() && g >= bounds[s].n) { g -= bounds[s].n; ++s; } }
+        kinds[k] = kind; slots[k] = s; indices[k] = (uint32_t)g;
+    }
+    return total;
+}
+
 // The contact lists of the last step (they describe the positions the step started from, as the reference's
 // ContactManager does after `step`).  offsets: n+1 entries; entries are written only if `capacity` holds them all.
 uint64_t World::get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity) {

@@ -667,6 +667,29 @@ class LiquidWorld:
                 L.check(got)
         return offsets, jm, j
 
+    def particles_intersecting_aabb(self, mins, maxs):
+        """liquid_world.rs:210-243: list of ("fluid" | "boundary", handle, particle index) whose distance to the box is
+        below the particle radius (current positions)."""
+        self.sync_to_device()
+        lo = (C.c_float * 3)(*[float(x) for x in mins])
+        hi = (C.c_float * 3)(*[float(x) for x in maxs])
+        u32p = C.POINTER(C.c_uint32)
+        cap = 1024
+        while True:
+            k, s, i = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+            total = int(self._L.salva_hip_particles_intersecting_aabb(self._h, lo, hi, cap, k.ctypes.data_as(u32p),
+                                                                       s.ctypes.data_as(u32p), i.ctypes.data_as(u32p)))
+            if total < 0:
+                L.check(total)
+            if total <= cap:
+                break
+            cap = total
+        out = []
+        for q in range(total):
+            owner = self._boundaries._items[int(s[q])] if k[q] else self._fluids._items[int(s[q])]
+            out.append(("boundary" if k[q] else "fluid", owner, int(i[q])))
+        return out
+
     def device_bytes(self) -> int:
         return int(self._L.salva_hip_device_bytes(self._h))
 

@@ -392,3 +392,34 @@ def test_cpp_mirror_faucet_example():
     n, added, deleted, ymin, ymax = int(m[1]), int(m[2]), int(m[3]), float(m[4]), float(m[5])
     assert added == 30 * 25 and n == added - deleted and n > 100
     assert ymin < 0.1 and ymax <= 0.61
+
+
+def test_particles_intersecting_aabb():
+    """LiquidWorld::particles_intersecting_aabb (liquid_world.rs:210-243): distance to the box < particle radius, for fluid
+    and boundary particles, before and after steps (the device answers from current positions)."""
+    from salva_amd import Boundary, DFSPHSolver, Fluid, LiquidWorld
+
+    fluid, shell = scenes.tank(8, 8, 8, R)
+    w = LiquidWorld(DFSPHSolver(), R, 2.0)
+    f = w.add_fluid(Fluid(scenes.jitter(fluid, 0.1 * R, seed=1), R, 1000.0))
+    f2 = w.add_fluid(Fluid(fluid + np.float32([1.0, 0.0, 0.0]), R, 800.0))
+    b = w.add_boundary(Boundary(shell))
+    mins, maxs = np.float32([-0.11, -0.3, -0.05]), np.float32([0.07, 0.02, 0.3])
+
+    def expected():
+        out = []
+        for kind, objs in (("fluid", [f, f2]), ("boundary", [b])):
+            for o in objs:
+                p = np.asarray(o.positions, np.float32)
+                d = np.maximum(np.maximum(mins - p, p - maxs), np.float32(0))
+                hit = np.nonzero((d * d).sum(1, dtype=np.float32) < np.float32(R) * np.float32(R))[0]
+                out += [(kind, o, int(i)) for i in hit]
+        return out
+
+    for steps in (0, 3):
+        for _ in range(steps):
+            w.step(DT, GRAVITY)
+        got, ref = w.particles_intersecting_aabb(mins, maxs), expected()
+        assert len(ref) > 20 and any(k == "boundary" for k, _, _ in ref)
+        assert [(k, id(o), i) for k, o, i in got] == [(k, id(o), i) for k, o, i in ref]
+    assert w.particles_intersecting_aabb([50, 50, 50], [51, 51, 51]) == []
