@@ -696,14 +696,15 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
 
 // IISPHSolver::step (iisph_solver.rs:643-711)
 void World::iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
-    if (comm) throw HipError(SALVA_HIP_E_INVALID, "the IISPH solver is not available in multi-GPU runs yet");
     st.n_divergence_iters = 0;
     st.divergence_error = 0.0f;
     launch_iisph_begin(c, g[0], g[1], g[2], acc_user, stream);
     run_forces(c);  // forces still see the previous inv_dt (:654-662)
     const float inv_dt = (dt == 0.0f) ? 0.0f : 1.0f / dt;
     launch_integrate(c, dt, stream);
-    launch_iisph_dii(c, lds, dt, stream);  // also p = 0.5 * p_prev
+    if (comm) refresh_f4(w.p);             // a ghost's own forces were summed over an incomplete neighbourhood
+    launch_iisph_dii(c, lds, dt, stream);  // also p = 0.5 * p_prev (a per-particle operation: right for ghosts too)
+    if (comm) refresh_f4(dii.p);
     launch_iisph_pred_density(c, lds, dt, stream);
     launch_iisph_aii(c, lds, dt, stream);
     float* const pa = kappa.p;
@@ -716,7 +717,9 @@ void World::iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStat
             const float* pr = (j & 1) ? pb : pa;
             float* pw = (j & 1) ? pa : pb;
             launch_iisph_dij_pj(cc, lds, dt, pr, stream);
+            if (comm) refresh_f4(dijpj.p);
             launch_iisph_next_pressure(cc, lds, dt, omega, pr, pw, stream);
+            if (comm) refresh_f32(pw);
         },
         [&](const StepCtx&, int) {});
     st.n_pressure_iters = (int32_t)rp.iters;

@@ -31,7 +31,6 @@ __global__ void k_pack_owned(uint32_t n, const float4* __restrict__ posm, const 
 void World::set_domain(Transport* transport, int lo, int hi, uint32_t gid_off) {
     if (!transport) throw HipError(SALVA_HIP_E_INVALID, "null transport");
     if (hi - lo < 1) throw HipError(SALVA_HIP_E_INVALID, "a slab must span at least two cell planes");
-    if (prm.solver != SALVA_HIP_SOLVER_DFSPH) throw HipError(SALVA_HIP_E_INVALID, "multi-GPU runs support the DFSPH solver only (so far)");
     comm = transport;
     slab_lo = lo; slab_hi = hi; gid_offset = gid_off;
     sorted_valid = false; bbox_known = false; dist_started = false; tables_dirty = true;

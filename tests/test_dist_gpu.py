@@ -24,9 +24,13 @@ def make_scene(nx=40, ny=10, nz=10, seed=5):
     return pos.astype(np.float32), vel.astype(np.float32), bpos.astype(np.float32)
 
 
+SOLVER = {"kind": "dfsph"}  # switched by the IISPH test
+
+
 def solver():
-    s = DFSPHSolver()
-    return s
+    from salva_amd import IISPHSolver
+
+    return IISPHSolver() if SOLVER["kind"] == "iisph" else DFSPHSolver()
 
 
 def run_single(pos, vel, bpos, nsteps, two_fluids):
@@ -136,6 +140,24 @@ def test_slabs_match_single_domain(hip_lib, nranks, two_fluids):
     dv = np.abs(got_v - ref_v).max()
     assert dp < 2e-4 * H, f"positions differ by {dp / H:.2e} h"
     assert dv < 5e-3, f"velocities differ by {dv:.2e} m/s"
+
+
+def test_slabs_match_single_domain_iisph(hip_lib):
+    """The same comparison with the IISPH solver (its d_ii, sum d_ij p_j and pressure fields are refreshed per pass)."""
+    SOLVER["kind"] = "iisph"
+    try:
+        pos, vel, bpos = make_scene()
+        nsteps = 10
+        ref_p, ref_v, ref_stats = run_single(pos, vel, bpos, nsteps, False)
+        got_p, got_v, stats, seen, counts, slabs = run_slabs(pos, vel, bpos, nsteps, 2, False)
+    finally:
+        SOLVER["kind"] = "dfsph"
+    assert (seen == 1).all()
+    for k in range(nsteps):
+        assert len({s[k].n_pressure_iters for s in stats}) == 1
+    n_same = sum(stats[0][k].n_pressure_iters == ref_stats[k].n_pressure_iters for k in range(nsteps))
+    assert n_same >= nsteps - 2
+    assert np.abs(got_p - ref_p).max() < 2e-4 * H and np.abs(got_v - ref_v).max() < 5e-3
 
 
 def test_slabs_with_iterative_viscosity(hip_lib):
