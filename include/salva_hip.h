@@ -176,9 +176,10 @@ float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps);
 /* ---- multi-GPU: one process and one world per GPU, the domain cut into slabs of grid-cell planes along x.
  * No counterpart in the reference (single process).  A world owns the particles whose cell x = floor(x / h) lies in
  * [cell_lo, cell_hi] (the first / last rank also keep whatever lies beyond their open end); every step it migrates
- * leavers to rank-1 / rank+1, mirrors its two edge planes there as ghosts, refreshes the ghosts' fields before each
- * neighbour pass and all-reduces the convergence sums, so iteration counts are global.  Each rank uploads only its own
- * particles with salva_hip_set_fluid (same fluid slots everywhere) plus the boundary particles within two cells of its
+ * leavers to rank-1 / rank+1, mirrors the two cell planes at each face there as ghosts, refreshes the ghosts' fields
+ * once per solver iteration and all-reduces the convergence sums, so iteration counts are global (a slab must span at
+ * least four planes).  Each rank uploads only its own
+ * particles with salva_hip_set_fluid (same fluid slots everywhere) plus the boundary particles within three cells of its
  * slab; `gid_offset` + upload index is the particle's global id.  After the first step per-fluid host-order access
  * (salva_hip_get_fluid) is replaced by salva_hip_get_owned. */
 typedef struct SalvaHipComm SalvaHipComm;

@@ -11,6 +11,8 @@ constexpr uint32_t GTAG_BORDER_LO = 0x40000000u;  // owned particle mirrored on 
 constexpr uint32_t GTAG_BORDER_HI = 0x20000000u;  // same towards rank+1
 constexpr uint32_t GTAG_SLOT_MASK = 0x1fffffffu;  // position in the exchange buffer of that face
 
+constexpr int GHOST_PLANES = 2;  // cell planes mirrored per face (see dist.hip)
+
 struct DistRec {  // one particle on the wire (64 bytes)
     float4 posm, vel, dv;
     uint32_t model, gid, pad0, pad1;

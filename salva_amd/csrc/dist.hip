@@ -4,8 +4,10 @@
 // A rank owns the particles whose cell x-coordinate lies in [lo, hi].  Each step, before the grid is built:
 //   phase 1  owned particles that left the slab (cx < lo or cx > hi) are removed and sent to that neighbour; last
 //            step's ghosts are dropped; arrivals are appended as owned
-//   phase 2  owned particles in the edge planes (cx == lo / cx == hi) are copied to the neighbour, which appends them
-//            as ghosts.  Sender and receiver remember the slot of every such particle (gtag), so later refreshes of a
+//   phase 2  owned particles in the TWO edge planes of each face are copied to the neighbour, which appends them as
+//            ghosts.  Two planes, although the interaction range is one: a ghost of the inner plane then has its whole
+//            neighbourhood on this rank, so whatever a pass computes for it from refreshed inputs is right, and only every
+//            second pass of a solver iteration needs an exchange (world.hip: the refresh_* calls say which).  Sender and receiver remember the slot of every such particle (gtag), so later refreshes of a
 //            single field are a gather into a dense buffer, one sendrecv, and a scatter — no searching, no sorting.
 #include <hipcub/hipcub.hpp>
 
@@ -38,8 +40,9 @@ __global__ __launch_bounds__(BLOCK) void k_dist_flags(uint32_t n, const float4* 
             else if (has_hi && cx > hi) { s.hi = 1; if (cx > hi + 1) atomicOr(flags, 4u); }
             else s.keep = 1;
         } else {
-            if (has_lo && cx <= lo) s.lo = 1;   // <= : the open-ended first/last slab may hold particles beyond its nominal planes
-            if (has_hi && cx >= hi) s.hi = 1;
+            // two planes per face (GHOST_PLANES); <= / >= : an open-ended first / last slab may hold particles beyond its planes
+            if (has_lo && cx <= lo + (GHOST_PLANES - 1)) s.lo = 1;
+            if (has_hi && cx >= hi - (GHOST_PLANES - 1)) s.hi = 1;
         }
     }
     sel[i] = s;
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(BLOCK) void k_dist_pack(uint32_t n, DistArrays in, 
             out.gtag[p.keep] = 0u;
         }
     } else {
-        // in place: remember the send slot (a particle is in at most one edge plane: slabs are >= 2 planes thick)
+        // in place: remember the send slot (a particle is mirrored to at most one side: slabs are >= 2 GHOST_PLANES thick)
         uint32_t t = 0u;
         if (s.lo) t = GTAG_BORDER_LO | p.lo;
         else if (s.hi) t = GTAG_BORDER_HI | p.hi;

@@ -637,7 +637,7 @@ void World::run_forces(const StepCtx& c) {
                             launch_visc_strain(cc, lds, f, 1, coef, visc_va.p, visc_beta.p, visc_target.p, visc_u0.p, visc_u1.p, stream);
                         },
                         [&](const StepCtx& cc, int) {
-                            if (comm) { refresh_f4(visc_u0.p); refresh_f4(visc_u1.p); }
+                            // (u of the inner ghost plane was computed here from refreshed v + a dt: no exchange needed)
                             launch_visc_accel(cc, lds, f, inv_dt_prev, dt_prev, visc_u0.p, visc_u1.p, visc_va.p, stream);
                             if (comm) refresh_f4(visc_va.p);
                         });
@@ -649,7 +649,7 @@ void World::run_forces(const StepCtx& c) {
                 }
                 case SALVA_HIP_FORCE_AKINCI2013:
                     launch_akinci_normals(c, lds, f, stream);
-                    if (comm) refresh_f4(normal.p);
+                    // (normals of the inner ghost plane are complete: rho was refreshed on both planes)
                     launch_akinci_forces(c, lds, f, d.p[0], d.p[1], stream);
                     break;
                 default: break;
@@ -666,7 +666,8 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
         c, 0, prm.max_divergence_error * inv_dt_prev * 0.01f, prm.min_divergence_iter, prm.max_divergence_iter, 0u,
         [&](const StepCtx& cc, int) { launch_divergence(cc, lds, stream); },
         [&](const StepCtx& cc, int) {
-            if (comm) refresh_f32(kappa.p);
+            // decomposed runs: kappa of the inner ghost plane was computed here from refreshed w — the applies of the
+            // owned particles read nothing else, so only w travels, once per iteration
             launch_divergence_apply(cc, lds, inv_dt_lag, stream);
             if (comm) refresh_f4(w.p);
         });
@@ -683,7 +684,6 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
         c, 1, prm.max_density_error, prm.min_pressure_iter, prm.max_pressure_iter, 0u,
         [&](const StepCtx& cc, int) { launch_pred_density(cc, lds, dt, stream); },
         [&](const StepCtx& cc, int) {
-            if (comm) refresh_f32(kappa.p);
             launch_pressure_apply(cc, lds, inv_dt, stream);
             if (comm) refresh_f4(w.p);
         });
@@ -704,7 +704,7 @@ void World::iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStat
     launch_integrate(c, dt, stream);
     if (comm) refresh_f4(w.p);             // a ghost's own forces were summed over an incomplete neighbourhood
     launch_iisph_dii(c, lds, dt, stream);  // also p = 0.5 * p_prev (a per-particle operation: right for ghosts too)
-    if (comm) refresh_f4(dii.p);
+    // (d_ii depends on positions only: right on the inner ghost plane without an exchange)
     launch_iisph_pred_density(c, lds, dt, stream);
     launch_iisph_aii(c, lds, dt, stream);
     float* const pa = kappa.p;
@@ -717,7 +717,6 @@ void World::iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStat
             const float* pr = (j & 1) ? pb : pa;
             float* pw = (j & 1) ? pa : pb;
             launch_iisph_dij_pj(cc, lds, dt, pr, stream);
-            if (comm) refresh_f4(dijpj.p);
             launch_iisph_next_pressure(cc, lds, dt, omega, pr, pw, stream);
             if (comm) refresh_f32(pw);
         },

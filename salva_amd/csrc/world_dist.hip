@@ -30,7 +30,7 @@ __global__ void k_pack_owned(uint32_t n, const float4* __restrict__ posm, const 
 
 void World::set_domain(Transport* transport, int lo, int hi, uint32_t gid_off) {
     if (!transport) throw HipError(SALVA_HIP_E_INVALID, "null transport");
-    if (hi - lo < 1) throw HipError(SALVA_HIP_E_INVALID, "a slab must span at least two cell planes");
+    if (hi - lo + 1 < 2 * GHOST_PLANES) throw HipError(SALVA_HIP_E_INVALID, "a slab must span at least four cell planes");
     comm = transport;
     slab_lo = lo; slab_hi = hi; gid_offset = gid_off;
     sorted_valid = false; bbox_known = false; dist_started = false; tables_dirty = true;

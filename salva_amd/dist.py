@@ -54,10 +54,13 @@ def cell_x(positions: np.ndarray, h: float) -> np.ndarray:
     return np.floor(x / F32(h)).astype(np.int64)
 
 
-def split_slabs(cx: np.ndarray, nranks: int, min_planes: int = 2) -> List[Tuple[int, int]]:
+GHOST_PLANES = 2  # cell planes mirrored on the neighbour per face (salva_amd/csrc/dist.h)
+
+
+def split_slabs(cx: np.ndarray, nranks: int, min_planes: int = 2 * GHOST_PLANES) -> List[Tuple[int, int]]:
     """Cut the occupied cell planes [cx.min(), cx.max()] into `nranks` contiguous slabs [lo, hi] holding about the same
-    number of particles each, every slab at least `min_planes` planes thick (a particle must be in at most one edge
-    plane).  Raises when there are not enough planes."""
+    number of particles each, every slab at least `min_planes` planes thick (a particle must be mirrored to at most
+    one neighbour).  Raises when there are not enough planes."""
     cx = np.asarray(cx, np.int64)
     if cx.size == 0:
         raise ValueError("no particles to partition")
@@ -84,10 +87,12 @@ def owner_of(cx: np.ndarray, slabs: Sequence[Tuple[int, int]]) -> np.ndarray:
     return np.searchsorted(his, np.asarray(cx, np.int64), side="left").astype(np.int32)
 
 
-def boundary_subset(bpos: np.ndarray, h: float, slab: Tuple[int, int], rank: int, nranks: int, margin: int = 2) -> np.ndarray:
-    """Indices of the boundary particles a rank must hold: everything within `margin` cell planes of its slab (1 plane
-    for its particles' contacts + 1 so that those boundary particles see all their own neighbours, i.e. get the same
-    volume as in a single-domain run); open-ended at the two outer ranks."""
+def boundary_subset(bpos: np.ndarray, h: float, slab: Tuple[int, int], rank: int, nranks: int,
+                    margin: int = GHOST_PLANES + 1) -> np.ndarray:
+    """Indices of the boundary particles a rank must hold: everything within `margin` cell planes of its slab — the
+    contacts of its own particles and of its inner ghost plane (which computes its own fields here) reach 2 planes out,
+    and those boundary particles need all their own neighbours (one more plane) to get the volume they have in a
+    single-domain run; open-ended at the two outer ranks."""
     cx = cell_x(bpos, h)
     lo = -(1 << 62) if rank == 0 else slab[0] - margin
     hi = (1 << 62) if rank == nranks - 1 else slab[1] + margin
@@ -104,9 +109,9 @@ def select_migration(cx: np.ndarray, slab: Tuple[int, int], has_lo: bool, has_hi
 
 
 def select_ghost_planes(cx: np.ndarray, slab: Tuple[int, int], has_lo: bool, has_hi: bool):
-    """Phase 2: (to_lo, to_hi) masks of the owned particles mirrored on each neighbour: the edge plane facing it
-    (and, at an open-ended slab, nothing more — such a slab has no neighbour on that side)."""
+    """Phase 2: (to_lo, to_hi) masks of the owned particles mirrored on each neighbour: the GHOST_PLANES edge planes
+    facing it (and, at an open-ended slab, nothing more — such a slab has no neighbour on that side)."""
     cx = np.asarray(cx, np.int64)
-    to_lo = (cx <= slab[0]) if has_lo else np.zeros(len(cx), bool)
-    to_hi = (cx >= slab[1]) if has_hi else np.zeros(len(cx), bool)
+    to_lo = (cx <= slab[0] + GHOST_PLANES - 1) if has_lo else np.zeros(len(cx), bool)
+    to_hi = (cx >= slab[1] - GHOST_PLANES + 1) if has_hi else np.zeros(len(cx), bool)
     return to_lo, to_hi

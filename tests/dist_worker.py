@@ -50,7 +50,7 @@ def main():
     assert world == 2
 
     # the same global scene on both ranks; a deliberately stale assignment so that phase 1 has something to migrate
-    pos, bpos = scenes.tank(16, 6, 6, R, wall_cells=2)
+    pos, bpos = scenes.tank(24, 6, 6, R, wall_cells=2)
     pos = scenes.jitter(pos, 0.3 * R, seed=9)
     gid = np.arange(len(pos))
     cx = dist.cell_x(pos, H)
@@ -75,7 +75,7 @@ def main():
 
     # phase 2: ghost planes
     g_lo, g_hi = dist.select_ghost_planes(ocx, slabs[rank], has_lo, has_hi)
-    assert not (g_lo & g_hi).any(), "a particle is in at most one edge plane (slabs are >= 2 planes thick)"
+    assert not (g_lo & g_hi).any(), "a particle is mirrored to at most one neighbour (slabs are >= 4 planes thick)"
     ghosts_lo, ghosts_hi = sendrecv_rows(owned[g_lo], owned[g_hi], rank, world)
     local = np.vstack([owned, ghosts_lo, ghosts_hi])
 
@@ -96,6 +96,16 @@ def main():
     assert (lff[:no] == gff[og]).all(), "fluid-fluid contact counts differ from the undivided domain"
     assert (lfb[:no] == gfb[og]).all(), "fluid-boundary contact counts differ from the undivided domain"
     np.testing.assert_allclose(lrho[:no], grho[og], rtol=1e-5)
+    # two planes are mirrored although the interaction range is one: the INNER ghost plane then has its whole
+    # neighbourhood here too, so whatever a pass computes for it locally is what its owner computes
+    ghosts = local[no:]
+    gcx = dist.cell_x(ghosts[:, 1:4], H)
+    inner = (gcx == slabs[rank][0] - 1) | (gcx == slabs[rank][1] + 1)
+    assert inner.any() and (~inner).any()
+    gi = ghosts[inner, 0].astype(int)
+    li = no + np.nonzero(inner)[0]
+    assert (lff[li] == gff[gi]).all() and (lfb[li] == gfb[gi]).all(), "inner ghost plane: incomplete neighbourhoods"
+    np.testing.assert_allclose(lrho[li], grho[gi], rtol=1e-5)
     # boundary particles an owned fluid particle can touch (<= 1 plane away) have the undivided domain's volume
     bcx = dist.cell_x(bpos[bsub], H)
     lo = -(1 << 60) if rank == 0 else slabs[rank][0] - 1

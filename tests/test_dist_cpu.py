@@ -23,7 +23,7 @@ def test_split_slabs_covers_and_balances():
         assert slabs[0][0] == cx.min() and slabs[-1][1] == cx.max()
         for (lo, hi), (lo2, _hi2) in zip(slabs, slabs[1:]):
             assert lo2 == hi + 1
-        assert all(hi - lo + 1 >= 2 for lo, hi in slabs)
+        assert all(hi - lo + 1 >= 4 for lo, hi in slabs)
         owner = dist.owner_of(cx, slabs)
         for r, (lo, hi) in enumerate(slabs):
             assert ((cx >= lo) & (cx <= hi) == (owner == r)).all()
@@ -32,12 +32,12 @@ def test_split_slabs_covers_and_balances():
 
 
 def test_split_slabs_skewed_and_degenerate():
-    # almost everything in one plane: the cuts still leave every slab two planes
-    cx = np.concatenate([np.full(1000, 3), np.arange(0, 8)])
+    # almost everything in one plane: the cuts still leave every slab four planes (two mirrored planes per face)
+    cx = np.concatenate([np.full(1000, 3), np.arange(0, 16)])
     slabs = dist.split_slabs(cx, 3)
-    assert all(hi - lo + 1 >= 2 for lo, hi in slabs) and slabs[0][0] == 0 and slabs[-1][1] == 7
+    assert all(hi - lo + 1 >= 4 for lo, hi in slabs) and slabs[0][0] == 0 and slabs[-1][1] == 15
     with pytest.raises(ValueError):
-        dist.split_slabs(np.arange(5), 3)  # 5 planes cannot hold 3 slabs of 2
+        dist.split_slabs(np.arange(11), 3)  # 11 planes cannot hold 3 slabs of 4
     with pytest.raises(ValueError):
         dist.split_slabs(np.array([], int), 2)
     # beyond the ends: open-ended ownership
@@ -59,7 +59,7 @@ def test_selection_rules():
     keep, lo, hi = dist.select_migration(cx, slab, False, True)   # first rank: open towards -x
     assert cx[keep].min() == -2 and not lo.any()
     glo, ghi = dist.select_ghost_planes(np.array([3, 4, 5, 6]), slab, True, True)
-    assert glo.tolist() == [True, False, False, False] and ghi.tolist() == [False, False, False, True]
+    assert glo.tolist() == [True, True, False, False] and ghi.tolist() == [False, False, True, True]
     glo, ghi = dist.select_ghost_planes(np.array([1, 3, 6, 9]), slab, False, True)  # open end holds strays, mirrors none there
     assert not glo.any() and ghi.tolist() == [False, False, True, True]
 
@@ -67,7 +67,7 @@ def test_selection_rules():
 def test_boundary_subset_closes_the_neighbourhoods():
     """Every boundary particle an owned fluid particle can touch is in the rank's subset, and so is every boundary
     neighbour of such a particle (so that its volume is the undivided domain's)."""
-    pos, bpos = scenes.tank(24, 5, 5, R, wall_cells=3)
+    pos, bpos = scenes.tank(40, 5, 5, R, wall_cells=3)
     cx = dist.cell_x(pos, H)
     slabs = dist.split_slabs(cx, 3)
     owner = dist.owner_of(cx, slabs)
@@ -96,7 +96,7 @@ def test_bench_slab_scene_is_consistent():
         cx = dist.cell_x(fluid, H)
         # everything a rank uploads is inside its slab or at most one plane outside (first-step migration handles that)
         assert cx.min() >= slab[0] - 1 and cx.max() <= slab[1] + 1
-        assert slab[1] - slab[0] + 1 >= 2
+        assert slab[1] - slab[0] + 1 >= 4
         seen.append(slab)
         assert len(shell) <= nshell
     for a, b in zip(seen, seen[1:]):
