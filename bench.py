@@ -227,7 +227,8 @@ def main():
                             f"lattice block in open tank, r=0.025 h=0.1 dt=1/200",
                 "particles_per_gpu": n,
                 "parallelism": "single domain" if not decomposed else
-                f"{world} x-slabs, one per GPU: RCCL send/recv ghost planes with the 2 neighbours + all-reduced convergence test",
+                f"{world} x-slabs, one per GPU: RCCL send/recv of two ghost planes per face with the 2 neighbours (one exchange per "
+                f"solver iteration) + all-reduced convergence test",
                 "mean_divergence_iters": float(it[:, 0].mean()),
                 "mean_pressure_iters": float(it[:, 1].mean()),
                 "mean_contacts_per_particle": kbar,
