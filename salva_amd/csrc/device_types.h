@@ -97,6 +97,8 @@ struct StepCtx {
     // Everything per tile lives in a compact table over the NON-EMPTY tiles ("slots", in dense-index order), and every
     // tile kernel is launched over slots: widely scattered particles then cost nothing per empty tile.
     const uint32_t* tile_ids;   // [nlaunch] dense tile index of slot k
+    const uint4* slot_desc;     // [nlaunch] {dense tile index, first own particle, one past the last, -}: everything
+                                //           Tile::setup needs besides tile_off, in one load that depends on nothing
     const uint32_t* tile_rank;  // [ntiles+1] exclusive prefix of the non-empty flags: slot of a dense tile; [ntiles] = nlaunch
     uint32_t nlaunch;           // number of slots (known to the host after the per-step read-back; 0 before)
     TileGrid gf;

@@ -350,9 +350,10 @@ void launch_tile_slots(const uint32_t* cell_start, uint32_t ntiles, uint32_t* fl
     k_tile_ids<<<div_up((size_t)ntiles, BLOCK), BLOCK, 0, s>>>(rank, ntiles, tile_ids);
 }
 
-__global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc* __restrict__ tile_cnt) {
+__global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc* __restrict__ tile_cnt, uint4* __restrict__ slot_desc) {
     Tile t;
     if (!t.setup_geom(c)) return;  // surplus workgroup: its entry was zeroed by the host
+    if (threadIdx.x == 0) slot_desc[t.slot] = make_uint4(t.tile, t.own_begin, t.own_end, 0u);
     TileAcc a{0, 0, 0, 0, 0, 0, 0, 0};
     {
         TileCells tc;
@@ -382,8 +383,8 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uin
     }
 }
 // `nslots_bound` >= number of non-empty tiles (the host does not know the exact count yet)
-void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, hipStream_t s) {
-    if (nslots_bound) k_tile_count<<<nslots_bound, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, tile_cnt);
+void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, uint4* slot_desc, hipStream_t s) {
+    if (nslots_bound) k_tile_count<<<nslots_bound, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, tile_cnt, slot_desc);
 }
 void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, hipStream_t s) {
     if (c.nlaunch) k_tile_halo_fill<<<c.nlaunch, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, halo_src, bhalo_src);

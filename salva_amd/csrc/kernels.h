@@ -42,7 +42,7 @@ void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4
 // halo slot tables
 void launch_tile_slots(const uint32_t* cell_start, uint32_t ntiles, uint32_t* flags, uint32_t* rank, uint32_t* tile_ids, void* temp,
                        size_t temp_bytes, hipStream_t s);
-void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, hipStream_t s);
+void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, uint4* slot_desc, hipStream_t s);
 void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, hipStream_t s);
 size_t scan_tiles_temp_bytes(uint32_t n);
 void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s);

@@ -129,7 +129,7 @@ struct Tile {
         pool = tile_smem;
         pool_used = 0;
         slot = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-        tile = c.tile_ids[slot];
+        const uint4 desc = c.slot_desc[slot];
         pre0 = pre1 = pre2 = pre3 = preb = 0u;
         if (c.halo_stride) {
             const uint32_t* __restrict__ src = c.halo_src + (size_t)slot * c.halo_stride;
@@ -140,7 +140,12 @@ struct Tile {
             if (s0 + 3 * nt < lim) pre3 = src[s0 + 3 * nt];
             if (c.bhalo_stride && s0 < c.bhalo_stride) preb = c.bhalo_src[(size_t)slot * c.bhalo_stride + s0];
         }
-        geometry(c);
+        tile = desc.x; own_begin = desc.y; own_end = desc.z;
+        {
+            const TileGrid& g = c.gf;
+            const uint32_t ttz = tile % g.ntz, tty = (tile / g.ntz) % g.nty, ttx = tile / (g.ntz * g.nty);
+            hcx = g.ox + (int)ttx * TX - 1; hcy = g.oy + (int)tty * TY - 1; hcz = g.oz + (int)ttz * TZ - 1;
+        }
         const TileAcc a0 = c.tile_off[slot], a1 = c.tile_off[slot + 1];
         slice_base = a0.nsl;
         S = (uint32_t)(a1.s - a0.s);

@@ -113,6 +113,7 @@ class World {
     DevBuf<float> rho, alpha, kappa, kappa2, rho_star, aii;
     DevBuf<uint32_t> nff, nfb, keys[2], idx[2], cell_start_f;
     DevBuf<TileAcc> tile_cnt, tile_off;
+    DevBuf<uint4> slot_desc;
     DevBuf<uint32_t> d_maxhalo, halo_src, bhalo_src, tile_ids, tile_flags, tile_rank;
     uint32_t nlaunch = 0;  // non-empty tiles of the current step = grid size of the solver kernels
     uint32_t last_iters[NUM_SOLVES] = {1u, 1u, 1u};  // iterations of the previous step's divergence / pressure solve (batch sizing)

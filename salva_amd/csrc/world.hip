@@ -503,7 +503,7 @@ StepCtx World::make_ctx() {
     c.tile_off = tile_off.p; c.halo_src = halo_src.p; c.bhalo_src = bhalo_src.p;
     c.halo_stride = halo_stride; c.bhalo_stride = bhalo_stride;
     c.ntiles = (uint32_t)gf.ntiles();
-    c.tile_ids = tile_ids.p; c.tile_rank = tile_rank.p; c.nlaunch = nlaunch;
+    c.tile_ids = tile_ids.p; c.tile_rank = tile_rank.p; c.nlaunch = nlaunch; c.slot_desc = slot_desc.p;
     c.gf = TileGrid{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], cell_start_f.p};
     c.nb = nb;
     c.bposv = bposv.p; c.bvel = bvel.p; c.bperm = bperm.p;
@@ -787,6 +787,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     tile_flags.ensure((size_t)ntiles + 1, stream, false, 1.5f);
     tile_rank.ensure((size_t)ntiles + 1, stream, false, 1.5f);
     tile_ids.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
+    slot_desc.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
     tile_cnt.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
     tile_off.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
     d_maxhalo.ensure(4);
@@ -819,7 +820,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         ensure_cub_temp(tb);
         launch_tile_slots(cell_start_f.p, ntiles, tile_flags.p, tile_rank.p, tile_ids.p, cub_temp.p, tb, stream);
         SALVA_HIP_CHECK(hipMemsetAsync(tile_cnt.p, 0, ((size_t)nslots_bound + 1) * sizeof(TileAcc), stream));
-        launch_tile_count(c, nslots_bound, tile_cnt.p, stream);
+        launch_tile_count(c, nslots_bound, tile_cnt.p, slot_desc.p, stream);
         scan_tiles(cub_temp.p, tb, tile_cnt.p, tile_off.p, nslots_bound + 1, stream);
         SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + nslots_bound, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
         wait_stream();
