@@ -1,6 +1,6 @@
 """How many host threads does the oracle want on this box?  (run via gpurun; informs bench.py's cpu_baseline)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import oracle as O
 import bench

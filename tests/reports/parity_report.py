@@ -1,7 +1,7 @@
 """Parity report of SURVEY.md §8c: GPU vs oracle-f32 vs oracle-f64 after N in {1, 10, 100} steps — max and RMS of |dx| / r and
 of |d(v + dv)| / v_ref, and the iteration-count traces.  Run on the GPU box; the output is committed under profiles/."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from parity import DT, GRAVITY, Scene
