@@ -83,6 +83,16 @@ def committed_traffic(kernel: str):
     return None, None
 
 
+def flush_c_stdio():
+    """fflush(NULL): push whatever native libraries printf'ed (RCCL's banner) out before Python prints."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def effective_cores() -> int:
     """Host cores this process may actually use: min(visible CPUs, scheduler affinity, cgroup CPU quota).  (The GPU
     boxes show 256 CPUs but cap the container at 16; 256 OpenMP threads on a 16-CPU quota run 10x slower than 16.)"""
@@ -239,14 +249,25 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-    if comm is not None:
-        del w
-        comm.destroy()
-    if world > 1:
-        dist.destroy_process_group()
+    # Tear down first and print last: RCCL writes a version banner through C stdio (flushed when it pleases, typically at
+    # exit); the JSON line must be the last thing on stdout, after every rank has emptied its C buffers.
+    try:
+        if world > 1:
+            dist.barrier()
+        if comm is not None:
+            del w
+            comm.destroy()
+        flush_c_stdio()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        flush_c_stdio()
+    finally:
+        if rank == 0:
+            if world > 1:
+                time.sleep(0.5)  # the other ranks are past their last flush by now (no process group left to sync on)
+            sys.stdout.write(json.dumps(out) + "\n")
+            sys.stdout.flush()
 
 
 if __name__ == "__main__":
