@@ -65,7 +65,9 @@ enum {
     SALVA_HIP_FORCE_XSPH = 1,        /* solver::XSPHViscosity::new(fluid_coeff, boundary_coeff), xsph_viscosity.rs:22-28 */
     SALVA_HIP_FORCE_ARTIFICIAL = 2,  /* solver::ArtificialViscosity::new(fluid_coeff, boundary_coeff), artificial_viscosity.rs:29-37 */
     SALVA_HIP_FORCE_AKINCI2013 = 3,  /* solver::Akinci2013SurfaceTension::new(tension, adhesion), akinci2013_surface_tension.rs:29-35 */
-    SALVA_HIP_FORCE_DFSPH_VISCOSITY = 4 /* solver::DFSPHViscosity::new(viscosity_coefficient), dfsph_viscosity.rs:102-118 */
+    SALVA_HIP_FORCE_DFSPH_VISCOSITY = 4, /* solver::DFSPHViscosity::new(viscosity_coefficient), dfsph_viscosity.rs:102-118 */
+    SALVA_HIP_FORCE_HE2014 = 5,      /* solver::He2014SurfaceTension::new(fluid_tension, boundary_tension), he2014_surface_tension.rs:21-29 */
+    SALVA_HIP_FORCE_WCSPH_TENSION = 6 /* solver::WCSPHSurfaceTension::new(fluid_tension, boundary_tension), wcsph_surface_tension.rs:22-28 */
 };
 typedef struct SalvaHipForceDesc {
     int32_t kind;
@@ -73,7 +75,10 @@ typedef struct SalvaHipForceDesc {
      * ARTIFICIAL: p[0] fluid coeff, p[1] boundary coeff, p[2] alpha (1), p[3] beta (0), p[4] speed_of_sound (10)
      * AKINCI2013: p[0] fluid_tension_coefficient, p[1] boundary_adhesion_coefficient
      * DFSPH_VISCOSITY: p[0] viscosity_coefficient (0..1), p[1] min_viscosity_iter (1), p[2] max_viscosity_iter (50),
-     *                  p[3] max_viscosity_error (0.01)          — the pub fields of DFSPHViscosity, dfsph_viscosity.rs:89-99 */
+     *                  p[3] max_viscosity_error (0.01)          — the pub fields of DFSPHViscosity, dfsph_viscosity.rs:89-99
+     * HE2014:     p[0] fluid_tension_coefficient, p[1] boundary_tension_coefficient
+     * WCSPH_TENSION: p[0] fluid_tension_coefficient, p[1] boundary_tension_coefficient — must be 0: the reference's boundary
+     *                  loop (wcsph_surface_tension.rs:66-83) indexes the boundaries with fluid-fluid contacts and panics */
     float p[7];
 } SalvaHipForceDesc;
 

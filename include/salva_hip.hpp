@@ -71,6 +71,22 @@ struct Akinci2013SurfaceTension : NonPressureForce {
         return d;
     }
 };
+struct He2014SurfaceTension : NonPressureForce {  // surface_tension/he2014_surface_tension.rs:12-29
+    Real fluid_tension_coefficient, boundary_tension_coefficient;
+    He2014SurfaceTension(Real t, Real b) : fluid_tension_coefficient(t), boundary_tension_coefficient(b) {}
+    SalvaHipForceDesc desc() const override {
+        SalvaHipForceDesc d{SALVA_HIP_FORCE_HE2014, {fluid_tension_coefficient, boundary_tension_coefficient}};
+        return d;
+    }
+};
+struct WCSPHSurfaceTension : NonPressureForce {  // surface_tension/wcsph_surface_tension.rs:15-28
+    Real fluid_tension_coefficient, boundary_tension_coefficient;
+    WCSPHSurfaceTension(Real t, Real b) : fluid_tension_coefficient(t), boundary_tension_coefficient(b) {}
+    SalvaHipForceDesc desc() const override {
+        SalvaHipForceDesc d{SALVA_HIP_FORCE_WCSPH_TENSION, {fluid_tension_coefficient, boundary_tension_coefficient}};
+        return d;
+    }
+};
 
 struct DFSPHViscosity : NonPressureForce {  // viscosity/dfsph_viscosity.rs:85-125
     int min_viscosity_iter = 1, max_viscosity_iter = 50;

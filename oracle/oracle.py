@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsalva_oracle.so")
 
 DFSPH, IISPH = 0, 1
-FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013, FORCE_DFSPH_VISCOSITY = 1, 2, 3, 4
+FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013, FORCE_DFSPH_VISCOSITY, FORCE_HE2014, FORCE_WCSPH_TENSION = 1, 2, 3, 4, 5, 6
 
 
 class Stats(C.Structure):
@@ -79,6 +79,8 @@ def lib():
         L.so_get_contacts_of.argtypes = [vp, i32, i32, u64, C.POINTER(C.c_uint64), u64]
         L.so_get_viscosity_stats.argtypes = [vp, i32, i32, C.POINTER(C.c_int), dp]
         L.so_get_viscosity_betas.argtypes = [vp, i32, i32, dp]
+        L.so_reference_would_panic.restype = i32
+        L.so_reference_would_panic.argtypes = [vp]
         L.so_test_lu6.argtypes = [dp, dp, dp]
         L.so_get_boundary_vec.argtypes = [vp, i32, i32, dp]
         L.so_get_boundary_volumes.argtypes = [vp, i32, dp]
@@ -111,7 +113,7 @@ class OracleWorld:
     VEC_FIELDS = {"positions": 0, "velocities": 1, "velocity_changes": 2, "accelerations": 3, "dii": 4,
                   "dij_pjl": 5, "normals": 6}
     SCALAR_FIELDS = {"densities": 0, "alphas": 1, "divergences": 2, "predicted_densities": 3, "volumes": 4,
-                     "aii": 5, "pressures": 6}
+                     "aii": 5, "pressures": 6, "he2014_colors": 7, "he2014_gradcs": 8}
 
     def __init__(self, particle_radius: float, smoothing_factor: float = 2.0, solver: int = DFSPH,
                  f64: bool = False, threads: int = 1):
@@ -163,6 +165,19 @@ class OracleWorld:
     def add_akinci2013(self, fluid, tension_coeff, adhesion_coeff):
         p = _f32([tension_coeff, adhesion_coeff])
         self._L.so_add_force(self._h, fluid, FORCE_AKINCI2013, _fp(p), 2)
+
+    def add_he2014(self, fluid, fluid_tension_coeff, boundary_tension_coeff):
+        """solver::He2014SurfaceTension::new (he2014_surface_tension.rs:21-29)."""
+        p = _f32([fluid_tension_coeff, boundary_tension_coeff])
+        self._L.so_add_force(self._h, fluid, FORCE_HE2014, _fp(p), 2)
+
+    def add_wcsph_tension(self, fluid, fluid_tension_coeff, boundary_tension_coeff):
+        """solver::WCSPHSurfaceTension::new (wcsph_surface_tension.rs:22-28)."""
+        p = _f32([fluid_tension_coeff, boundary_tension_coeff])
+        self._L.so_add_force(self._h, fluid, FORCE_WCSPH_TENSION, _fp(p), 2)
+
+    def reference_would_panic(self) -> bool:
+        return bool(self._L.so_reference_would_panic(self._h))
 
     def add_dfsph_viscosity(self, fluid, viscosity_coefficient, min_iter=1, max_iter=50, max_error=0.01):
         """solver::DFSPHViscosity::new(coefficient) with its pub tuning fields (dfsph_viscosity.rs:89-125)."""

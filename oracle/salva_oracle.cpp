@@ -158,7 +158,7 @@ struct Groups {
     }
 };
 
-enum ForceKind { FORCE_XSPH = 1, FORCE_ARTIFICIAL = 2, FORCE_AKINCI2013 = 3, FORCE_DFSPH_VISCOSITY = 4 };
+enum ForceKind { FORCE_XSPH = 1, FORCE_ARTIFICIAL = 2, FORCE_AKINCI2013 = 3, FORCE_DFSPH_VISCOSITY = 4, FORCE_HE2014 = 5, FORCE_WCSPH_TENSION = 6 };
 
 template <typename R>
 struct Force {
@@ -168,7 +168,9 @@ struct Force {
     // Akinci2013: p0 = tension coeff, p1 = boundary adhesion coeff
     // DFSPHViscosity: p0 = viscosity_coefficient, p1 = min_viscosity_iter, p2 = max_viscosity_iter, p3 = max_viscosity_error
     R p[5] = {0, 0, 0, 0, 0};
+    // He2014 / WCSPHSurfaceTension: p0 = fluid tension coeff, p1 = boundary tension coeff
     std::vector<V3<R>> normals;  // Akinci state (akinci2013_surface_tension.rs:22)
+    std::vector<R> colors, gradcs;  // He2014 state (he2014_surface_tension.rs:15-16)
     // DFSPHViscosity state (dfsph_viscosity.rs:98-99): betas (6x6 row-major), strain-rate target / error (6 each)
     std::vector<R> betas, strain_target, strain_error;
     int last_visc_iters = 0;
@@ -822,6 +824,95 @@ struct World {
         }
     }
 
+    // surface_tension/he2014_surface_tension.rs:40-181 (compute_colors, compute_gradc, solve)
+    void solve_he2014(size_t f, Force<R>& force) {
+        Fluid<R>& fluid = fluids[f];
+        const R tc = force.p[0], bc = force.p[1];
+        const R density0 = fluid.density0;
+        const std::vector<R>& dens = densities[f];
+        const long n = (long)fluid.n();
+        if (force.gradcs.size() != (size_t)n) { force.gradcs.assign(n, (R)0); force.colors.assign(n, (R)0); }  // init :31-38
+        std::vector<R>& colors = force.colors;
+        std::vector<R>& gradcs = force.gradcs;
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+        for (long i = 0; i < n; ++i) {  // compute_colors :40-76
+            R color = 0;
+            for (auto& c : ff[f].contacts[i])
+                if (c.i_model == c.j_model) color += c.weight * fluid.particle_mass(c.j) / dens[c.j];
+            for (auto& c : fb[f].contacts[i]) color += c.weight * boundaries[c.j_model].volumes[c.j];
+            colors[i] = color;
+        }
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+        for (long i = 0; i < n; ++i) {  // compute_gradc :78-106
+            V3<R> gradc;
+            for (auto& c : ff[f].contacts[i])
+                if (c.i_model == c.j_model) gradc += c.gradient * colors[c.j] * fluid.particle_mass(c.j) / dens[c.j];
+            gradcs[i] = (gradc / colors[i]).norm_squared();
+        }
+        const R _2 = 2;
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+        for (long i = 0; i < n; ++i) {  // solve :132-178
+            V3<R>& acceleration_i = fluid.accelerations[i];
+            const R mi = fluid.volumes[i] * density0;
+            if (tc != (R)0) {
+                for (auto& c : ff[f].contacts[i]) {
+                    if (c.i_model == c.j_model) {
+                        const R mj = fluid.volumes[c.j] * density0;
+                        const R gradsum = gradcs[c.i] + gradcs[c.j];
+                        V3<R> fv = c.gradient * (mi / dens[c.i] * mj / dens[c.j] * gradsum / _2);
+                        acceleration_i += fv * (tc / (_2 * mi));
+                    }
+                }
+            }
+            if (bc != (R)0) {
+                for (auto& c : fb[f].contacts[i]) {
+                    const R mj = boundaries[c.j_model].volumes[c.j] * density0;
+                    const R gradsum = gradcs[c.i];
+                    V3<R> fv = c.gradient * (mi / dens[c.i] * mj / density0 * gradsum * bc * (R)0.25);
+                    acceleration_i += fv / mi;
+                    apply_force(boundaries[c.j_model], c.j, fv * (R)-1);
+                }
+            }
+        }
+    }
+
+    // surface_tension/wcsph_surface_tension.rs:32-87.  NOTE: the reference's boundary loop (:66-83) iterates the
+    // *fluid-fluid* contacts and indexes `boundaries[c.j_model].positions[c.j]` with them — it panics (index out of
+    // bounds) unless a boundary with that index and enough particles happens to exist.  Restated as written, with the
+    // out-of-bounds case reported through `reference_would_panic` instead of undefined behaviour.
+    bool reference_would_panic = false;
+    void solve_wcsph_tension(size_t f, Force<R>& force) {
+        Fluid<R>& fluid = fluids[f];
+        const R tc = force.p[0], bc = force.p[1];
+        const R density0 = fluid.density0;
+        const long n = (long)fluid.n();
+        bool oob = false;
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1) reduction(|| : oob)
+        for (long i = 0; i < n; ++i) {
+            V3<R>& acceleration_i = fluid.accelerations[i];
+            if (tc != (R)0) {
+                for (auto& c : ff[f].contacts[i]) {
+                    if (c.i_model == c.j_model) {
+                        V3<R> dpos = fluid.positions[c.i] - fluid.positions[c.j];
+                        V3<R> cohesion_acc = dpos * (-tc * c.weight * fluid.volumes[c.j] * density0 / (fluid.volumes[c.i] * density0));
+                        acceleration_i += cohesion_acc;
+                    }
+                }
+            }
+            if (bc != (R)0) {
+                for (auto& c : ff[f].contacts[i]) {
+                    if (c.j_model >= boundaries.size() || c.j >= boundaries[c.j_model].positions.size()) { oob = true; continue; }
+                    V3<R> dpos = fluid.positions[c.i] - boundaries[c.j_model].positions[c.j];
+                    const R mi = fluid.volumes[c.i] * density0;
+                    V3<R> cohesion_force = dpos * (bc * c.weight * boundaries[c.j_model].volumes[c.j] * density0);
+                    acceleration_i -= cohesion_force / mi;
+                    apply_force(boundaries[c.j_model], c.j, cohesion_force);
+                }
+            }
+        }
+        if (oob) reference_would_panic = true;
+    }
+
     // ---- viscosity/dfsph_viscosity.rs (viscous DFSPH).  3D: strain rates are 6-vectors, betas 6x6 matrices.
     // compute_strain_rate (:38-58)
     static inline void strain_rate(const V3<R>& g, const V3<R>& v, R out[6]) {
@@ -1044,6 +1135,8 @@ struct World {
                     case FORCE_ARTIFICIAL: solve_artificial(f, force); break;
                     case FORCE_AKINCI2013: solve_akinci(f, force); break;
                     case FORCE_DFSPH_VISCOSITY: solve_dfsph_viscosity(f, force); break;
+                    case FORCE_HE2014: solve_he2014(f, force); break;
+                    case FORCE_WCSPH_TENSION: solve_wcsph_tension(f, force); break;
                     default: break;
                 }
             }
@@ -1423,7 +1516,8 @@ int so_add_boundary(void* p, uint64_t n, const float* pos, const float* vel, uin
     return r;
 }
 // kind: 1 XSPH(p0 fluid coeff, p1 boundary coeff); 2 Artificial(p0, p1, alpha, beta, speed_of_sound); 3 Akinci2013(p0 tension, p1 adhesion);
-// 4 DFSPHViscosity(p0 coefficient, p1 min iter, p2 max iter, p3 max error)
+// 4 DFSPHViscosity(p0 coefficient, p1 min iter, p2 max iter, p3 max error); 5 He2014(p0 fluid tension, p1 boundary tension);
+// 6 WCSPHSurfaceTension(p0 fluid tension, p1 boundary tension)
 int so_add_force(void* p, int fluid, int kind, const float* params, int nparams) {
     Handle* h = (Handle*)p;
     DISPATCH(h,
@@ -1474,7 +1568,9 @@ void so_get_fluid_vec(void* p, int fluid, int field, double* out) {
     DISPATCH(h, GETV(w), GETV(w));
 #undef GETV
 }
-// field: 0 densities, 1 alphas, 2 divergences, 3 predicted_densities, 4 volumes, 5 aii, 6 pressures
+// 1 if a step hit a code path on which the reference would panic (WCSPHSurfaceTension's boundary loop, see solve_wcsph_tension)
+int so_reference_would_panic(void* p) { Handle* h = (Handle*)p; int r = 0; DISPATCH(h, r = w.reference_would_panic, r = w.reference_would_panic); return r; }
+// field: 0 densities, 1 alphas, 2 divergences, 3 predicted_densities, 4 volumes, 5 aii, 6 pressures, 7 He2014 colors, 8 He2014 gradcs
 void so_get_fluid_scalar(void* p, int fluid, int field, double* out) {
     Handle* h = (Handle*)p;
 #define GETS(w) do { switch (field) { \
@@ -1485,6 +1581,8 @@ void so_get_fluid_scalar(void* p, int fluid, int field, double* out) {
         case 4: copy_s(w.fluids[fluid].volumes, out); break; \
         case 5: copy_s(w.aii[fluid], out); break; \
         case 6: copy_s(w.pressures[fluid], out); break; \
+        case 7: for (auto& f : w.fluids[fluid].forces) if (f.kind == FORCE_HE2014) { copy_s(f.colors, out); break; } break; \
+        case 8: for (auto& f : w.fluids[fluid].forces) if (f.kind == FORCE_HE2014) { copy_s(f.gradcs, out); break; } break; \
         default: break; } } while (0)
     DISPATCH(h, GETS(w), GETS(w));
 #undef GETS

@@ -13,14 +13,16 @@ from .world import (  # noqa: F401
     DFSPHSolver,
     DFSPHViscosity,
     Fluid,
+    He2014SurfaceTension,
     IISPHSolver,
     InteractionGroups,
     LiquidWorld,
     NonPressureForce,
+    WCSPHSurfaceTension,
     XSPHViscosity,
 )
 
 __all__ = [
-    "Akinci2013SurfaceTension", "ArtificialViscosity", "Boundary", "Counters", "DFSPHSolver", "DFSPHViscosity", "Fluid", "IISPHSolver",
-    "InteractionGroups", "LiquidWorld", "NonPressureForce", "XSPHViscosity", "dist", "scenes",
+    "Akinci2013SurfaceTension", "ArtificialViscosity", "Boundary", "Counters", "DFSPHSolver", "DFSPHViscosity", "Fluid", "He2014SurfaceTension", "IISPHSolver",
+    "InteractionGroups", "LiquidWorld", "NonPressureForce", "WCSPHSurfaceTension", "XSPHViscosity", "dist", "scenes",
 ]

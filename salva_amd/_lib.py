@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libsalva_hip.so")
 
 OK, E_HIP, E_INVALID, E_NUMERIC, E_CAPACITY = 0, -1, -2, -3, -4
 SOLVER_DFSPH, SOLVER_IISPH = 0, 1
-FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013, FORCE_DFSPH_VISCOSITY = 1, 2, 3, 4
+FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013, FORCE_DFSPH_VISCOSITY, FORCE_HE2014, FORCE_WCSPH_TENSION = 1, 2, 3, 4, 5, 6
 DIRTY_POSITIONS, DIRTY_VELOCITIES, DIRTY_VOLUMES, DIRTY_ACCELERATIONS, DIRTY_ALL = 1, 2, 4, 8, 15
 (FIELD_DENSITY, FIELD_ALPHA, FIELD_NUM_FLUID_CONTACTS, FIELD_NUM_BOUNDARY_CONTACTS, FIELD_VELOCITY_CHANGE,
  FIELD_PRESSURE, FIELD_VOLUME, FIELD_ACCELERATION) = range(8)

@@ -264,4 +264,167 @@ void launch_akinci_forces(const StepCtx& c, const TileLds& L, uint32_t model, fl
     SALVA_LAUNCH_TILE(k_akinci_forces, c, L, L.bytes(40, 32, 6), s, c, model, tension, adhesion, cnorm, h6_64, anorm);
 }
 
+// ------------------------------------------------------------------------------------------------ He et al. 2014
+// surface_tension/he2014_surface_tension.rs.  Three dependent neighbour passes over the same fluid:
+// pass 1 (compute_colors :40-76): c_i = sum_{j same fluid} W_ij m_j / rho_j + sum_b W_ib V_b
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_colors(StepCtx c, uint32_t model, float* __restrict__ colors) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* Lp = nullptr;
+    const float* Lr = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), Lp, Lr);
+    const uint32_t* Lm = nullptr;
+    if (c.nmodels > 1) t.stage(c, static_cast<const uint32_t*>(c.model), Lm);
+    const float4* Bp = nullptr;
+    t.stage_boundary(c, Bp);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active || c.model[i] != model) return;
+        const float4 pi = c.posm[i];
+        float color = 0.0f;
+        for_each_ff(c, i, gs, [&](uint32_t s) {
+            const float4 pj = Lp[s];
+            const float rj = Lr[s];
+            const bool same = Lm ? (Lm[s] == model) : true;
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
+            color += same ? wgt * pj.w / rj : 0.0f;
+        });
+        for_each_fb(c, t, i, gs, [&](uint32_t s) {
+            const float4 pj = Bp[s];
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            color += kernel_weight(dx * dx + dy * dy + dz * dz, c.sc) * pj.w;
+        });
+        colors[i] = color;
+    });
+}
+// pass 2 (compute_gradc :78-106): g_i = | (sum_{j same fluid} grad W_ij c_j m_j / rho_j) / c_i |^2
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_gradc(StepCtx c, uint32_t model, const float* __restrict__ colors,
+                                                              float* __restrict__ gradcs) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* Lp = nullptr;
+    const float* Lr = nullptr;
+    const float* Lc = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), colors, Lp, Lr, Lc);
+    const uint32_t* Lm = nullptr;
+    if (c.nmodels > 1) t.stage(c, static_cast<const uint32_t*>(c.model), Lm);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active || c.model[i] != model) return;
+        const float4 pi = c.posm[i];
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        for_each_ff(c, i, gs, [&](uint32_t s) {
+            const float4 pj = Lp[s];
+            const float rj = Lr[s], cj = Lc[s];
+            const bool same = Lm ? (Lm[s] == model) : true;
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+            const float sc = same ? g * cj * pj.w / rj : 0.0f;
+            gx += dx * sc; gy += dy * sc; gz += dz * sc;
+        });
+        const float ci = colors[i];
+        gx /= ci; gy /= ci; gz /= ci;
+        gradcs[i] = gx * gx + gy * gy + gz * gz;
+    });
+}
+// pass 3 (solve :132-178): a_i += t_f/(2 m_i) sum_j grad W_ij (m_i/rho_i)(m_j/rho_j)(g_i+g_j)/2
+//                                 + sum_b grad W_ib (1/rho_i) V_b rho0 ... (g_i t_b / 4), reaction -f on the boundary
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_forces(StepCtx c, uint32_t model, float tc, float bc,
+                                                               const float* __restrict__ gradcs) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* Lp = nullptr;
+    const float* Lr = nullptr;
+    const float* Lg = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), gradcs, Lp, Lr, Lg);
+    const uint32_t* Lm = nullptr;
+    if (c.nmodels > 1) t.stage(c, static_cast<const uint32_t*>(c.model), Lm);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    t.stage_boundary(c, Bp, Bv);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active || c.model[i] != model) return;
+        const float4 pi = c.posm[i];
+        const float ri = c.rho[i], gi = gradcs[i];
+        const float rho0 = c.rho0_tab[model];
+        const float mi = pi.w;
+        float4 a = c.acc[i];
+        if (tc != 0.0f) {
+            const float ts = tc / (2.0f * mi);
+            float fx = 0.f, fy = 0.f, fz = 0.f;
+            for_each_ff(c, i, gs, [&](uint32_t s) {
+                const float4 pj = Lp[s];
+                const float rj = Lr[s], gj = Lg[s];
+                const bool same = Lm ? (Lm[s] == model) : true;
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                const float sc = same ? g * (mi / ri * pj.w / rj * (gi + gj) * 0.5f) * ts : 0.0f;
+                fx += dx * sc; fy += dy * sc; fz += dz * sc;
+            });
+            a.x += fx; a.y += fy; a.z += fz;
+        }
+        if (bc != 0.0f) {
+            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+                const float4 pj = Bp[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                const float sc = g * (mi / ri * (pj.w * rho0) / rho0 * gi * bc * 0.25f);
+                const float ex = dx * sc, ey = dy * sc, ez = dz * sc;
+                a.x += ex / mi; a.y += ey / mi; a.z += ez / mi;
+                if (c.bforce) apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), -ex, -ey, -ez);
+            });
+        }
+        c.acc[i] = a;
+    });
+}
+void launch_he2014_colors(const StepCtx& c, const TileLds& L, uint32_t model, float* colors, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_he2014_colors, c, L, L.bytes(24, 16, 4), s, c, model, colors);
+}
+void launch_he2014_gradc(const StepCtx& c, const TileLds& L, uint32_t model, const float* colors, float* gradcs, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_he2014_gradc, c, L, L.bytes(28, 0, 4), s, c, model, colors, gradcs);
+}
+void launch_he2014_forces(const StepCtx& c, const TileLds& L, uint32_t model, float tension, float boundary_tension,
+                          const float* gradcs, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_he2014_forces, c, L, L.bytes(28, 32, 6), s, c, model, tension, boundary_tension, gradcs);
+}
+
+// ------------------------------------------------------------------------------------------------ WCSPH surface tension
+// surface_tension/wcsph_surface_tension.rs:49-64: a_i += sum_{j same fluid} (x_i - x_j) (-t_f W_ij m_j / m_i).
+// (The reference's boundary loop :66-83 indexes the boundaries with fluid-fluid contacts and panics; the host rejects
+// a non-zero boundary coefficient before a kernel is launched.)
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_wcsph_tension(StepCtx c, uint32_t model, float tc) {
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    const float4* Lp = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), Lp);
+    const uint32_t* Lm = nullptr;
+    if (c.nmodels > 1) t.stage(c, static_cast<const uint32_t*>(c.model), Lm);
+    __syncthreads();
+    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+        if (!active || c.model[i] != model) return;
+        const float4 pi = c.posm[i];
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        for_each_ff(c, i, gs, [&](uint32_t s) {
+            const float4 pj = Lp[s];
+            const bool same = Lm ? (Lm[s] == model) : true;
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
+            const float sc = same ? -tc * wgt * pj.w / pi.w : 0.0f;
+            fx += dx * sc; fy += dy * sc; fz += dz * sc;
+        });
+        float4 a = c.acc[i];
+        a.x += fx; a.y += fy; a.z += fz;
+        c.acc[i] = a;
+    });
+}
+void launch_wcsph_tension(const StepCtx& c, const TileLds& L, uint32_t model, float tension, hipStream_t s) {
+    SALVA_LAUNCH_TILE(k_wcsph_tension, c, L, L.bytes(20, 0, 2), s, c, model, tension);
+}
+
 }  // namespace salva

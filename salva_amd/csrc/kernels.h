@@ -90,6 +90,11 @@ void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid
 void launch_artificial_viscosity(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff, float alpha,
                                  float beta, float speed_of_sound, hipStream_t s);
 void launch_akinci_normals(const StepCtx& c, const TileLds& L, uint32_t model, hipStream_t s);
+void launch_he2014_colors(const StepCtx& c, const TileLds& L, uint32_t model, float* colors, hipStream_t s);
+void launch_he2014_gradc(const StepCtx& c, const TileLds& L, uint32_t model, const float* colors, float* gradcs, hipStream_t s);
+void launch_he2014_forces(const StepCtx& c, const TileLds& L, uint32_t model, float tension, float boundary_tension,
+                          const float* gradcs, hipStream_t s);
+void launch_wcsph_tension(const StepCtx& c, const TileLds& L, uint32_t model, float tension, hipStream_t s);
 void launch_akinci_forces(const StepCtx& c, const TileLds& L, uint32_t model, float tension, float adhesion, hipStream_t s);
 
 // ---------------------------------------------------------------- iisph.hip

@@ -333,11 +333,15 @@ uint64_t World::delete_particles(uint32_t slot, const uint8_t* mask) {
 void World::set_fluid_forces(uint32_t slot, const SalvaHipForceDesc* f, uint32_t nf) {
     if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
     for (uint32_t k = 0; k < nf; ++k)
-        if (f[k].kind < SALVA_HIP_FORCE_XSPH || f[k].kind > SALVA_HIP_FORCE_DFSPH_VISCOSITY)
+        if (f[k].kind < SALVA_HIP_FORCE_XSPH || f[k].kind > SALVA_HIP_FORCE_WCSPH_TENSION)
             throw HipError(SALVA_HIP_E_INVALID, "unknown non-pressure force kind (only built-ins run on the device)");
     for (uint32_t k = 0; k < nf; ++k)
         if (f[k].kind == SALVA_HIP_FORCE_DFSPH_VISCOSITY && !(f[k].p[0] >= 0.0f && f[k].p[0] <= 1.0f))
             throw HipError(SALVA_HIP_E_INVALID, "The viscosity coefficient must be between 0.0 and 1.0.");  // dfsph_viscosity.rs:104-108
+    for (uint32_t k = 0; k < nf; ++k)
+        if (f[k].kind == SALVA_HIP_FORCE_WCSPH_TENSION && f[k].p[1] != 0.0f)
+            // wcsph_surface_tension.rs:66-83 walks the fluid-fluid contacts while indexing the boundaries: it panics
+            throw HipError(SALVA_HIP_E_INVALID, "WCSPHSurfaceTension: a non-zero boundary coefficient panics in the reference (index out of bounds)");
     fluids[slot].forces.assign(f, f + nf);
 }
 
@@ -647,6 +651,16 @@ void World::run_forces(const StepCtx& c) {
                     fluids[f].force_errs[&d - fluids[f].forces.data()] = rv.err;
                     break;
                 }
+                case SALVA_HIP_FORCE_HE2014:
+                    // He2014SurfaceTension::solve (he2014_surface_tension.rs:109-181): colors -> gradcs -> forces
+                    he_colors.ensure(n, stream, false, 1.1f); he_gradcs.ensure(n, stream, false, 1.1f);
+                    launch_he2014_colors(c, lds, f, he_colors.p, stream);
+                    // the outer ghost plane's colors are sums over an incomplete neighbourhood, and the inner plane's gradcs read them
+                    if (comm) refresh_f32(he_colors.p);
+                    launch_he2014_gradc(c, lds, f, he_colors.p, he_gradcs.p, stream);
+                    launch_he2014_forces(c, lds, f, d.p[0], d.p[1], he_gradcs.p, stream);
+                    break;
+                case SALVA_HIP_FORCE_WCSPH_TENSION: launch_wcsph_tension(c, lds, f, d.p[0], stream); break;
                 case SALVA_HIP_FORCE_AKINCI2013:
                     launch_akinci_normals(c, lds, f, stream);
                     // (normals of the inner ghost plane are complete: rho was refreshed on both planes)
@@ -1128,7 +1142,7 @@ uint64_t World::device_bytes() const {
     }
     add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes());
     add(rho.bytes()); add(alpha.bytes()); add(kappa.bytes()); add(kappa2.bytes()); add(rho_star.bytes()); add(aii.bytes());
-    add(visc_beta.bytes()); add(visc_target.bytes()); add(visc_u0.bytes()); add(visc_u1.bytes()); add(visc_va.bytes());
+    add(visc_beta.bytes()); add(visc_target.bytes()); add(visc_u0.bytes()); add(visc_u1.bytes()); add(visc_va.bytes()); add(he_colors.bytes()); add(he_gradcs.bytes());
     add(nff.bytes()); add(nfb.bytes()); add(cell_start_f.bytes()); add(halo_src.bytes()); add(bhalo_src.bytes());
     add(nbr_ff.bytes()); add(nbr_fb.bytes()); add(cub_temp.bytes()); add(scratch_f.bytes());
     add(scratch_f4.bytes()); add(bst_pos.bytes()); add(bst_vel.bytes()); add(bposv.bytes()); add(bvel.bytes());

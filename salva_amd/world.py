@@ -107,6 +107,35 @@ class Akinci2013SurfaceTension(NonPressureForce):
         return d
 
 
+class He2014SurfaceTension(NonPressureForce):
+    """solver::He2014SurfaceTension::new(fluid_tension_coefficient, boundary_tension_coefficient), he2014_surface_tension.rs:12-29."""
+
+    def __init__(self, fluid_tension_coefficient: float, boundary_tension_coefficient: float):
+        self.fluid_tension_coefficient = fluid_tension_coefficient
+        self.boundary_tension_coefficient = boundary_tension_coefficient
+
+    def _desc(self):
+        d = L.ForceDesc()
+        d.kind = L.FORCE_HE2014
+        d.p[0], d.p[1] = self.fluid_tension_coefficient, self.boundary_tension_coefficient
+        return d
+
+
+class WCSPHSurfaceTension(NonPressureForce):
+    """solver::WCSPHSurfaceTension::new(fluid_tension_coefficient, boundary_tension_coefficient), wcsph_surface_tension.rs:15-28.
+    A non-zero boundary coefficient is rejected at step time: the reference's boundary loop (:66-83) panics."""
+
+    def __init__(self, fluid_tension_coefficient: float, boundary_tension_coefficient: float):
+        self.fluid_tension_coefficient = fluid_tension_coefficient
+        self.boundary_tension_coefficient = boundary_tension_coefficient
+
+    def _desc(self):
+        d = L.ForceDesc()
+        d.kind = L.FORCE_WCSPH_TENSION
+        d.p[0], d.p[1] = self.fluid_tension_coefficient, self.boundary_tension_coefficient
+        return d
+
+
 # ------------------------------------------------------------------------------------------------ solvers
 class DFSPHViscosity(NonPressureForce):
     """solver::DFSPHViscosity (viscous DFSPH), dfsph_viscosity.rs:85-125: `new(viscosity_coefficient)` + pub tuning fields.

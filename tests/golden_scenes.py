@@ -80,12 +80,29 @@ def scene_dfsph_viscous():
     return s
 
 
+def scene_surface_tension():
+    """He2014SurfaceTension(1, 0.5) on a drop over a floor next to a second fluid with WCSPHSurfaceTension(0.3, 0)
+    (the remaining built-in surface tensions), IISPH pressure."""
+    s = Scene(R, 2.0, "iisph")
+    a = scenes.jitter(scenes.cube_fluid_positions(7, 7, 7, R), 0.1 * R, seed=42)
+    b = scenes.jitter(scenes.cube_fluid_positions(6, 6, 6, R), 0.1 * R, seed=43)
+    a[:, 1] += np.float32(7 * R + 2 * R)
+    b[:, 1] += np.float32(6 * R + 2 * R)
+    b[:, 0] += np.float32(14 * R)
+    s.add_fluid(a, scenes.random_velocities(len(a), 0.05, seed=1), 1000.0, forces=[("he2014", 1.0, 0.5)])
+    s.add_fluid(b, scenes.random_velocities(len(b), 0.05, seed=2), 800.0, forces=[("wcsph_tension", 0.3, 0.0)])
+    floor = scenes.plane_lattice(20, 12, 0.0, R, -6 * 2 * R + R, -6 * 2 * R + R, layers=1)
+    s.add_boundary(floor, wants_forces=True)
+    return s
+
+
 SCENES = {
     "dfsph_xsph_block": (scene_dfsph_xsph_block, 6),
     "dfsph_tank": (scene_dfsph_tank, 6),
     "iisph_akinci": (scene_iisph_akinci, 6),
     "two_phase": (scene_two_phase, 6),
     "dfsph_viscous": (scene_dfsph_viscous, 6),
+    "surface_tension": (scene_surface_tension, 6),
 }
 
 

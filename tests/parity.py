@@ -4,7 +4,8 @@ from __future__ import annotations
 import numpy as np
 
 from oracle import oracle as O
-from salva_amd import (Akinci2013SurfaceTension, ArtificialViscosity, Boundary, DFSPHSolver, DFSPHViscosity, Fluid, IISPHSolver,
+from salva_amd import (Akinci2013SurfaceTension, ArtificialViscosity, Boundary, DFSPHSolver, DFSPHViscosity, Fluid, He2014SurfaceTension,
+                       IISPHSolver, WCSPHSurfaceTension,
                        InteractionGroups, LiquidWorld, XSPHViscosity)
 
 GRAVITY = (0.0, -9.81, 0.0)
@@ -55,6 +56,10 @@ class Scene:
                     w.add_akinci2013(fid, frc[1], frc[2])
                 elif frc[0] == "dfsph_viscosity":
                     w.add_dfsph_viscosity(fid, *frc[1:])
+                elif frc[0] == "he2014":
+                    w.add_he2014(fid, frc[1], frc[2])
+                elif frc[0] == "wcsph_tension":
+                    w.add_wcsph_tension(fid, frc[1], frc[2])
                 else:
                     raise ValueError(frc)
         for b in self.boundaries:
@@ -84,6 +89,10 @@ class Scene:
                     fl.nonpressure_forces.append(av)
                 elif frc[0] == "akinci":
                     fl.nonpressure_forces.append(Akinci2013SurfaceTension(frc[1], frc[2]))
+                elif frc[0] == "he2014":
+                    fl.nonpressure_forces.append(He2014SurfaceTension(frc[1], frc[2]))
+                elif frc[0] == "wcsph_tension":
+                    fl.nonpressure_forces.append(WCSPHSurfaceTension(frc[1], frc[2]))
                 elif frc[0] == "dfsph_viscosity":
                     dv = DFSPHViscosity(frc[1])
                     if len(frc) > 2:

@@ -25,6 +25,7 @@ def make_scene(nx=40, ny=10, nz=10, seed=5):
 
 
 SOLVER = {"kind": "dfsph"}  # switched by the IISPH test
+FORCES = {"make": lambda: [XSPHViscosity(0.5, 0.0)]}  # switched by the surface-tension test
 
 
 def solver():
@@ -39,7 +40,7 @@ def run_single(pos, vel, bpos, nsteps, two_fluids):
     for part in split_fluids(pos, two_fluids):
         f = Fluid(pos[part], R, 1000.0 if len(fls) == 0 else 800.0)
         f.velocities = vel[part]
-        f.nonpressure_forces.append(XSPHViscosity(0.5, 0.0))
+        f.nonpressure_forces.extend(FORCES["make"]())
         fls.append((w.add_fluid(f), part))
     w.add_boundary(Boundary(bpos))
     stats = [w.step(DT, G) for _ in range(nsteps)]
@@ -81,7 +82,7 @@ def run_slabs(pos, vel, bpos, nsteps, nranks, two_fluids):
                 mine = part[owner[part] == r]
                 f = Fluid(pos[mine], R, 1000.0 if k == 0 else 800.0)
                 f.velocities = vel[mine]
-                f.nonpressure_forces.append(XSPHViscosity(0.5, 0.0))
+                f.nonpressure_forces.extend(FORCES["make"]())
                 w.add_fluid(f)
             w.add_boundary(Boundary(bpos[dist.boundary_subset(bpos, H, slabs[r], r, nranks)]))
             w.set_domain(comms[r], slabs[r][0], slabs[r][1], offsets[r])
@@ -157,6 +158,24 @@ def test_slabs_match_single_domain_iisph(hip_lib):
         assert len({s[k].n_pressure_iters for s in stats}) == 1
     n_same = sum(stats[0][k].n_pressure_iters == ref_stats[k].n_pressure_iters for k in range(nsteps))
     assert n_same >= nsteps - 2
+    assert np.abs(got_p - ref_p).max() < 2e-4 * H and np.abs(got_v - ref_v).max() < 5e-3
+
+
+def test_slabs_with_surface_tensions(hip_lib):
+    """He2014 (three dependent neighbour passes: the colours of the outer ghost plane are refreshed between them),
+    WCSPH cohesion and Akinci2013 (normals of the inner ghost plane computed locally) across a slab boundary."""
+    from salva_amd import Akinci2013SurfaceTension, He2014SurfaceTension, WCSPHSurfaceTension
+
+    FORCES["make"] = lambda: [He2014SurfaceTension(1.0, 0.5), WCSPHSurfaceTension(0.2, 0.0), Akinci2013SurfaceTension(0.5, 2.0)]
+    try:
+        pos, vel, bpos = make_scene()
+        nsteps = 8
+        ref_p, ref_v, ref_stats = run_single(pos, vel, bpos, nsteps, True)
+        got_p, got_v, stats, seen, counts, slabs = run_slabs(pos, vel, bpos, nsteps, 2, True)
+    finally:
+        FORCES["make"] = lambda: [XSPHViscosity(0.5, 0.0)]
+    assert (seen == 1).all()
+    assert np.isfinite(got_p).all()
     assert np.abs(got_p - ref_p).max() < 2e-4 * H and np.abs(got_v - ref_v).max() < 5e-3
 
 

@@ -211,6 +211,15 @@ def test_edge_cases():
     with pytest.raises(_lib.SalvaHipError) as e:
         bad.step(DT, GRAVITY)
     assert e.value.code == _lib.E_NUMERIC
+    # WCSPHSurfaceTension with a boundary coefficient panics in the reference (wcsph_surface_tension.rs:66-83): rejected
+    from salva_amd import WCSPHSurfaceTension
+    wt = LiquidWorld(DFSPHSolver(), R, 2.0)
+    ft = Fluid(scenes.cube_fluid_positions(3, 3, 3, R), R, 1000.0)
+    ft.nonpressure_forces.append(WCSPHSurfaceTension(0.5, 0.5))
+    wt.add_fluid(ft)
+    with pytest.raises(_lib.SalvaHipError) as e:
+        wt.step(DT, GRAVITY)
+    assert e.value.code == _lib.E_INVALID
     # dt <= eps: no substep (timestep_manager.rs:56-58)
     w2 = LiquidWorld(DFSPHSolver(), R, 2.0)
     h = w2.add_fluid(Fluid(scenes.cube_fluid_positions(3, 3, 3, R), R, 1000.0))
