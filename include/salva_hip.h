@@ -163,6 +163,38 @@ int salva_hip_step(SalvaHipWorld* world, float dt, const float gravity[3], Salva
 int salva_hip_get_fluid(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz);
 int salva_hip_get_fluid_field(SalvaHipWorld* world, uint32_t slot, int32_t field, float* out);
 
+/* ---- Rigid-body coupling on the device: the StaticSampling arm of salva's rapier integration
+ * (src/integrations/rapier/fluids_pipeline.rs).  The rigid-body engine stays on the host; per step it hands over one pose
+ * per coupled collider and receives one wrench back, instead of re-uploading every boundary particle and downloading
+ * every force. */
+typedef struct SalvaHipRigidPose {
+    float translation[3];   /* collider.position().translation */
+    float rotation[4];      /* collider.position().rotation as a unit quaternion (i, j, k, w) — nalgebra's storage order */
+    float linvel[3];        /* body.linvel() */
+    float angvel[3];        /* body.angvel() */
+    float world_com[3];     /* body.center_of_mass() (world space) */
+    int32_t has_body;       /* collider.parent() is Some: 0 -> velocities are zero and `forces` is left as it is */
+    int32_t is_dynamic;     /* body.is_dynamic(): the boundary receives forces iff set (fluids_pipeline.rs:163-171) */
+} SalvaHipRigidPose;
+
+/* ColliderCouplingSet::register_coupling(boundary, collider, ColliderSampling::StaticSampling(points))
+ * (fluids_pipeline.rs:36-41, 96-114): creates or resizes boundary `slot` (like salva_hip_set_boundary) and keeps the
+ * collider-local sample points on the device.  Until the first pose the boundary sits at the identity pose. */
+int salva_hip_set_boundary_sampling(SalvaHipWorld* world, uint32_t slot, uint64_t n, const float* local_points_xyz,
+                                    uint32_t memberships, uint32_t filter);
+/* ColliderCouplingManager::update_boundaries, StaticSampling arm (fluids_pipeline.rs:160-193, 262), as one kernel:
+ * positions[i] = pose * points[i]; velocities[i] = body.velocity_at_point(points[i]) = linvel + angvel x (points[i] -
+ * world_com) — the reference passes the LOCAL point there (:183), reproduced as written; forces are cleared.
+ * Call before salva_hip_step (the reference calls it at the top of the substep, liquid_world.rs:93-101). */
+int salva_hip_update_boundary_pose(SalvaHipWorld* world, uint32_t slot, const SalvaHipRigidPose* pose);
+/* Reads `boundary.positions` / `boundary.velocities` (object/boundary.rs:13-15) back, e.g. after a pose update.  Any pointer may be NULL. */
+int salva_hip_get_boundary_particles(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz);
+/* ColliderCouplingManager::transmit_forces (fluids_pipeline.rs:266-287) applies `force_i * dt` at `position_i` for every
+ * boundary particle; this returns the two sums that is equivalent to, reduced on the device:
+ *   force = sum_i f_i,  torque = sum_i (x_i - point) x f_i   ->  body.apply_impulse(force*dt), apply_torque_impulse(torque*dt)
+ * with point = body.center_of_mass().  Zero when the boundary does not receive forces. */
+int salva_hip_get_boundary_wrench(SalvaHipWorld* world, uint32_t slot, const float point[3], float force[3], float torque[3]);
+
 /* `boundary.volumes` (recomputed every substep, dfsph_solver.rs:72-96) and `boundary.forces`
  * (accumulated by Boundary::apply_force, boundary.rs:62-67).  Any pointer may be NULL. */
 int salva_hip_get_boundary(SalvaHipWorld* world, uint32_t slot, float* volumes, float* forces_xyz);

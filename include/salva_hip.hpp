@@ -18,6 +18,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "salva_hip.h"
@@ -176,12 +177,24 @@ class Boundary {  // object/boundary.rs
         velocities.assign(positions.size(), Vec3{0, 0, 0});
         volumes.assign(positions.size(), 0.0f);
     }
-    size_t num_particles() const { return positions.size(); }
+    // ColliderSampling::StaticSampling(points) (integrations/rapier/fluids_pipeline.rs:36-41): when set, positions and
+    // velocities are produced on the device from a pose (ColliderCouplingSet below) and `positions` above is only a
+    // read-back (LiquidWorld::sync_boundary)
+    std::vector<Vec3> sampling;
+    size_t num_particles() const { return sampling.empty() ? positions.size() : sampling.size(); }
     void mark_dirty() { dirty_ = true; }
 
   private:
     friend class LiquidWorld;
     bool dirty_ = true;
+};
+
+class LiquidWorld;
+// coupling/coupling_manager.rs:8-31
+struct CouplingManager {
+    virtual ~CouplingManager() = default;
+    virtual void update_boundaries(LiquidWorld& world) = 0;
+    virtual void transmit_forces(LiquidWorld& world, Real dt) = 0;
 };
 
 using FluidHandle = size_t;     // dense index; remove_fluid is a swap-remove like ContiguousArena (contiguous_arena.rs)
@@ -238,12 +251,33 @@ class LiquidWorld {  // liquid_world.rs
         }
         check(rc);
     }
-    // boundary.volumes / boundary.forces after a step
+    // LiquidWorld::step_with_coupling (liquid_world.rs:67-158): update_boundaries -> the substep -> transmit_forces
+    void step_with_coupling(Real dt, const Vec3& gravity, CouplingManager& coupling) {
+        for (size_t s = 0; s < boundaries_.size(); ++s) upload(boundaries_[s], (uint32_t)s);
+        coupling.update_boundaries(*this);
+        step(dt, gravity);
+        coupling.transmit_forces(*this, dt);
+    }
+    // boundary.volumes / boundary.forces (and, for sampled boundaries, positions / velocities) after a step
     void sync_boundary(BoundaryHandle h) {
         Boundary& b = boundaries_[h];
         if (!b.num_particles()) return;
+        b.volumes.resize(b.num_particles());
         if (b.wants_forces) b.forces.resize(b.num_particles());
         check(salva_hip_get_boundary(w_, (uint32_t)h, b.volumes.data(), b.wants_forces ? b.forces[0].data() : nullptr));
+        if (!b.sampling.empty()) {
+            b.positions.resize(b.num_particles()); b.velocities.resize(b.num_particles());
+            check(salva_hip_get_boundary_particles(w_, (uint32_t)h, b.positions[0].data(), b.velocities[0].data()));
+        }
+    }
+    // the two halves of ColliderCouplingManager for one boundary (fluids_pipeline.rs:160-193 / :266-287)
+    void update_boundary_pose(BoundaryHandle h, const SalvaHipRigidPose& pose) {
+        upload(boundaries_[h], (uint32_t)h);
+        if (pose.has_body) boundaries_[h].wants_forces = pose.is_dynamic != 0;
+        check(salva_hip_update_boundary_pose(w_, (uint32_t)h, &pose));
+    }
+    void boundary_wrench(BoundaryHandle h, const Vec3& point, Vec3& force, Vec3& torque) {
+        check(salva_hip_get_boundary_wrench(w_, (uint32_t)h, point.data(), force.data(), torque.data()));
     }
 
   private:
@@ -321,6 +355,12 @@ class LiquidWorld {  // liquid_world.rs
     void upload(Boundary& b, uint32_t slot) {
         if (!b.dirty_) return;
         const size_t n = b.num_particles();
+        if (!b.sampling.empty()) {
+            check(salva_hip_set_boundary_sampling(w_, slot, n, b.sampling[0].data(), b.interaction_groups.memberships,
+                                                  b.interaction_groups.filter));
+            b.dirty_ = false;
+            return;
+        }
         check(salva_hip_set_boundary(w_, slot, n, n ? b.positions[0].data() : nullptr, n ? b.velocities[0].data() : nullptr,
                                      b.interaction_groups.memberships, b.interaction_groups.filter, b.wants_forces ? 1 : 0));
         b.dirty_ = false;
@@ -331,6 +371,47 @@ class LiquidWorld {  // liquid_world.rs
     std::vector<Fluid> fluids_;
     std::vector<Boundary> boundaries_;
     SalvaHipStepStats stats_{};
+};
+
+// ColliderCouplingSet / ColliderCouplingManager (integrations/rapier/fluids_pipeline.rs:64-288) without the rapier types: each
+// entry reads the collider's pose through `pose()` and hands the step's impulse back through `apply(linear, angular)`
+// (= body.apply_impulse(force * dt), body.apply_torque_impulse(torque * dt) about pose.world_com).
+class ColliderCouplingSet : public CouplingManager {
+  public:
+    struct Entry {
+        BoundaryHandle boundary;
+        std::function<SalvaHipRigidPose()> pose;
+        std::function<void(const Vec3& impulse, const Vec3& torque_impulse)> apply;  // may be empty (kinematic / fixed bodies)
+    };
+    // register_coupling(boundary, collider, ColliderSampling::StaticSampling(points)): the points live in Boundary::sampling
+    void register_coupling(BoundaryHandle boundary, std::function<SalvaHipRigidPose()> pose,
+                           std::function<void(const Vec3&, const Vec3&)> apply = {}) {
+        entries_.push_back(Entry{boundary, std::move(pose), std::move(apply)});
+    }
+    void unregister_coupling(BoundaryHandle boundary) {
+        for (size_t k = 0; k < entries_.size(); ++k)
+            if (entries_[k].boundary == boundary) { entries_.erase(entries_.begin() + (long)k); return; }
+    }
+    void update_boundaries(LiquidWorld& world) override {
+        poses_.clear();
+        for (Entry& e : entries_) {
+            poses_.push_back(e.pose());
+            world.update_boundary_pose(e.boundary, poses_.back());
+        }
+    }
+    void transmit_forces(LiquidWorld& world, Real dt) override {
+        for (size_t k = 0; k < entries_.size(); ++k) {
+            const SalvaHipRigidPose& p = poses_[k];
+            if (!entries_[k].apply || !p.has_body || !p.is_dynamic) continue;
+            Vec3 f{0, 0, 0}, t{0, 0, 0};
+            world.boundary_wrench(entries_[k].boundary, Vec3{p.world_com[0], p.world_com[1], p.world_com[2]}, f, t);
+            entries_[k].apply(Vec3{f[0] * dt, f[1] * dt, f[2] * dt}, Vec3{t[0] * dt, t[1] * dt, t[2] * dt});
+        }
+    }
+
+  private:
+    std::vector<Entry> entries_;
+    std::vector<SalvaHipRigidPose> poses_;
 };
 
 }  // namespace salva

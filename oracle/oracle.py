@@ -79,6 +79,9 @@ def lib():
         L.so_get_contacts_of.argtypes = [vp, i32, i32, u64, C.POINTER(C.c_uint64), u64]
         L.so_get_viscosity_stats.argtypes = [vp, i32, i32, C.POINTER(C.c_int), dp]
         L.so_get_viscosity_betas.argtypes = [vp, i32, i32, dp]
+        L.so_set_boundary_sampling.argtypes = [vp, i32, u64, C.POINTER(C.c_float)]
+        L.so_update_boundary_pose.argtypes = [vp, i32, dp, i32, i32]
+        L.so_get_boundary_wrench.argtypes = [vp, i32, dp, dp, dp]
         L.so_reference_would_panic.restype = i32
         L.so_reference_would_panic.argtypes = [vp]
         L.so_test_lu6.argtypes = [dp, dp, dp]
@@ -153,6 +156,25 @@ class OracleWorld:
         vel = _f32(velocities, 3) if velocities is not None else None
         return self._L.so_add_boundary(self._h, len(pos), _fp(pos), _fp(vel) if vel is not None else None,
                                        memberships, filter, int(wants_forces))
+
+    # ---- integrations/rapier/fluids_pipeline.rs, StaticSampling arm
+    def set_boundary_sampling(self, boundary, local_points):
+        pts = _f32(local_points, 3)
+        self._L.so_set_boundary_sampling(self._h, boundary, len(pts), _fp(pts))
+
+    def update_boundary_pose(self, boundary, translation=(0, 0, 0), rotation=(0, 0, 0, 1), linvel=(0, 0, 0), angvel=(0, 0, 0),
+                             world_com=(0, 0, 0), has_body=True, is_dynamic=True):
+        """update_boundaries (:160-193, 262); values are rounded to f32 first, like the device ABI takes them."""
+        pose = np.concatenate([np.asarray(x, np.float32).astype(np.float64) for x in (translation, rotation, linvel, angvel, world_com)])
+        self._L.so_update_boundary_pose(self._h, boundary, pose.ctypes.data_as(C.POINTER(C.c_double)), int(has_body), int(is_dynamic))
+
+    def boundary_wrench(self, boundary, point):
+        """transmit_forces (:266-287) as (sum f, sum (x - point) x f)."""
+        c = np.asarray(point, np.float32).astype(np.float64)
+        f, t = np.zeros(3), np.zeros(3)
+        dp = C.POINTER(C.c_double)
+        self._L.so_get_boundary_wrench(self._h, boundary, c.ctypes.data_as(dp), f.ctypes.data_as(dp), t.ctypes.data_as(dp))
+        return f, t
 
     def add_xsph(self, fluid, fluid_coeff, boundary_coeff):
         p = _f32([fluid_coeff, boundary_coeff])

@@ -72,6 +72,7 @@ struct V3 {
     V3& operator*=(R s) { x *= s; y *= s; z *= s; return *this; }
     R dot(const V3& o) const { return (x * o.x + y * o.y) + z * o.z; }
     R norm_squared() const { return (x * x + y * y) + z * z; }
+    V3 cross(const V3& o) const { return V3(y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x); }
     R norm() const { return std::sqrt(norm_squared()); }
     void fill(R v) { x = y = z = v; }
 };
@@ -195,6 +196,7 @@ struct Boundary {  // object/boundary.rs:11-24
     bool has_forces = false;
     std::vector<V3<R>> forces;
     Groups groups;
+    std::vector<V3<R>> sampling;  // ColliderSampling::StaticSampling(points), integrations/rapier/fluids_pipeline.rs:36-41
     size_t n() const { return positions.size(); }
 };
 
@@ -1455,6 +1457,56 @@ static int add_fluid_t(World<R>& w, uint64_t n, const float* pos, const float* v
     return (int)w.fluids.size() - 1;
 }
 
+// ---- integrations/rapier/fluids_pipeline.rs (rapier itself is an un-vendored dependency: the two rigid-body formulas used
+// here are restated from rapier3d 0.22's published source, `RigidBody::velocity_at_point` = linvel + angvel x (pt - world_com)
+// and `apply_impulse_at_point` = apply_impulse(J) + apply_torque_impulse((pt - world_com) x J); nalgebra's
+// `Isometry3 * Point3` = UnitQuaternion * pt + translation with q * v = v + w t + q.vec x t, t = 2 q.vec x v).
+template <typename R>
+static void set_boundary_sampling_t(World<R>& w, int b, uint64_t n, const float* pts) {
+    Boundary<R>& bd = w.boundaries[b];
+    bd.sampling.resize(n);
+    for (uint64_t i = 0; i < n; ++i) bd.sampling[i] = V3<R>((R)pts[3 * i], (R)pts[3 * i + 1], (R)pts[3 * i + 2]);
+}
+// The StaticSampling arm of ColliderCouplingManager::update_boundaries (:160-193, :262):
+//   boundary.forces = Some/None by body.is_dynamic() (:163-171); positions[i] = collider.position() * pt (:182);
+//   velocities[i] = body.velocity_at_point(pt) — with the LOCAL point, as written (:183) — or zero without a body;
+//   volumes reset to 0 (:190); clear_forces(true) (:262).
+// pose = translation[3], rotation (i, j, k, w), linvel[3], angvel[3], world_com[3]
+template <typename R>
+static void update_boundary_pose_t(World<R>& w, int b, const double* pose, int has_body, int is_dynamic) {
+    Boundary<R>& bd = w.boundaries[b];
+    const V3<R> t((R)pose[0], (R)pose[1], (R)pose[2]);
+    const V3<R> qv((R)pose[3], (R)pose[4], (R)pose[5]);
+    const R qw = (R)pose[6];
+    const V3<R> linvel((R)pose[7], (R)pose[8], (R)pose[9]), angvel((R)pose[10], (R)pose[11], (R)pose[12]);
+    const V3<R> com((R)pose[13], (R)pose[14], (R)pose[15]);
+    if (has_body) {
+        bd.has_forces = is_dynamic != 0;
+        if (!bd.has_forces) bd.forces.clear();
+    }
+    const size_t n = bd.sampling.size();
+    bd.positions.resize(n); bd.velocities.resize(n); bd.volumes.assign(n, (R)0);
+    for (size_t i = 0; i < n; ++i) {
+        const V3<R> pt = bd.sampling[i];
+        const V3<R> tt = qv.cross(pt) * (R)2;
+        const V3<R> cr = qv.cross(tt);
+        bd.positions[i] = (tt * qw + cr + pt) + t;
+        bd.velocities[i] = has_body ? linvel + angvel.cross(pt - com) : V3<R>();
+    }
+    if (bd.has_forces) bd.forces.assign(n, V3<R>());
+}
+// transmit_forces (:266-287): body.apply_impulse_at_point(force * dt, pos) for every boundary particle, i.e. the sums
+// returned here times dt.  (rapier accumulates them one by one in f32 into linvel / angvel; sums are taken in R here.)
+template <typename R>
+static void boundary_wrench_t(World<R>& w, int b, const double* com, double* force, double* torque) {
+    Boundary<R>& bd = w.boundaries[b];
+    V3<R> F, T;
+    const V3<R> c((R)com[0], (R)com[1], (R)com[2]);
+    if (bd.has_forces)
+        for (size_t i = 0; i < bd.n(); ++i) { F += bd.forces[i]; T += (bd.positions[i] - c).cross(bd.forces[i]); }
+    force[0] = F.x; force[1] = F.y; force[2] = F.z; torque[0] = T.x; torque[1] = T.y; torque[2] = T.z;
+}
+
 template <typename R>
 static int add_boundary_t(World<R>& w, uint64_t n, const float* pos, const float* vel, uint32_t mem, uint32_t filt, int wants_forces) {
     Boundary<R> b;
@@ -1634,6 +1686,19 @@ void so_get_boundary_vec(void* p, int b, int field, double* out) {
         case 2: copy_v3(w.boundaries[b].forces, out); break; default: break; } } while (0)
     DISPATCH(h, GETB(w), GETB(w));
 #undef GETB
+}
+
+void so_set_boundary_sampling(void* p, int b, uint64_t n, const float* pts) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, set_boundary_sampling_t(w, b, n, pts), set_boundary_sampling_t(w, b, n, pts));
+}
+void so_update_boundary_pose(void* p, int b, const double* pose16, int has_body, int is_dynamic) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, update_boundary_pose_t(w, b, pose16, has_body, is_dynamic), update_boundary_pose_t(w, b, pose16, has_body, is_dynamic));
+}
+void so_get_boundary_wrench(void* p, int b, const double* com, double* force, double* torque) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, boundary_wrench_t(w, b, com, force, torque), boundary_wrench_t(w, b, com, force, torque));
 }
 void so_get_boundary_volumes(void* p, int b, double* out) {
     Handle* h = (Handle*)p;

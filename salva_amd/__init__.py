@@ -4,7 +4,7 @@ The product is `salva_amd/csrc/libsalva_hip.so` (C ABI in include/salva_hip.h); 
 the reference's host API used by the tests and the benchmark.  Importing the API objects does not load the
 library; creating a `LiquidWorld` does, and fails loudly when it is missing or no HIP device is usable.
 """
-from . import dist, scenes  # noqa: F401
+from . import coupling, dist, scenes  # noqa: F401
 from .world import (  # noqa: F401
     Akinci2013SurfaceTension,
     ArtificialViscosity,
@@ -24,5 +24,5 @@ from .world import (  # noqa: F401
 
 __all__ = [
     "Akinci2013SurfaceTension", "ArtificialViscosity", "Boundary", "Counters", "DFSPHSolver", "DFSPHViscosity", "Fluid", "He2014SurfaceTension", "IISPHSolver",
-    "InteractionGroups", "LiquidWorld", "NonPressureForce", "WCSPHSurfaceTension", "XSPHViscosity", "dist", "scenes",
+    "InteractionGroups", "LiquidWorld", "NonPressureForce", "WCSPHSurfaceTension", "XSPHViscosity", "coupling", "dist", "scenes",
 ]

@@ -30,7 +30,8 @@ EXPORTED_SYMBOLS = [
     "salva_hip_last_error", "salva_hip_version", "salva_hip_comm_rccl_unique_id", "salva_hip_comm_rccl_create",
     "salva_hip_comm_loopback_create", "salva_hip_comm_destroy", "salva_hip_set_domain", "salva_hip_get_owned",
     "salva_hip_get_force_stats", "salva_hip_get_fluid_contacts", "salva_hip_add_particles", "salva_hip_delete_particles",
-    "salva_hip_particles_intersecting_aabb",
+    "salva_hip_particles_intersecting_aabb", "salva_hip_set_boundary_sampling", "salva_hip_update_boundary_pose",
+    "salva_hip_get_boundary_particles", "salva_hip_get_boundary_wrench",
 ]
 
 
@@ -53,6 +54,12 @@ class Params(C.Structure):
 
 class ForceDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("p", C.c_float * 7)]
+
+
+class RigidPose(C.Structure):
+    """SalvaHipRigidPose (include/salva_hip.h)."""
+    _fields_ = [("translation", C.c_float * 3), ("rotation", C.c_float * 4), ("linvel", C.c_float * 3),
+                ("angvel", C.c_float * 3), ("world_com", C.c_float * 3), ("has_body", C.c_int32), ("is_dynamic", C.c_int32)]
 
 
 class StepStats(C.Structure):
@@ -124,6 +131,10 @@ def lib():
     L.salva_hip_get_fluid_field.argtypes = [vp, u32, i32, fp]
     L.salva_hip_get_boundary.argtypes = [vp, u32, fp, fp]
     L.salva_hip_clear_boundary_forces.argtypes = [vp, u32]
+    L.salva_hip_set_boundary_sampling.argtypes = [vp, u32, u64, fp, u32, u32]
+    L.salva_hip_update_boundary_pose.argtypes = [vp, u32, C.POINTER(RigidPose)]
+    L.salva_hip_get_boundary_particles.argtypes = [vp, u32, fp, fp]
+    L.salva_hip_get_boundary_wrench.argtypes = [vp, u32, fp, fp, fp]
     L.salva_hip_device_bytes.argtypes = [vp]
     L.salva_hip_device_bytes.restype = u64
     L.salva_hip_time_pred_density.argtypes = [vp, i32]

@@ -1,0 +1,158 @@
+"""Host mirror of salva's rigid-body coupling for the StaticSampling arm (src/integrations/rapier/fluids_pipeline.rs).
+
+rapier is not part of this project (and not available here): `RigidBody` below carries exactly the state the coupling
+reads and writes — pose, velocities, centre of mass, mass properties — with rapier's formulas for the three methods the
+coupling calls (`velocity_at_point`, `apply_impulse`, `apply_torque_impulse`).  A real integration passes rapier's values
+through `SalvaHipRigidPose` instead.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib as L
+
+F32 = np.float32
+
+
+def quat_rotate(q, v):
+    """nalgebra UnitQuaternion * Vector3, q = (i, j, k, w): t = 2 q.vec x v; v + w t + q.vec x t."""
+    qv = np.asarray(q[:3], F32)
+    v = np.asarray(v, F32)
+    t = np.cross(qv, v).astype(F32) * F32(2)
+    return (t * F32(q[3]) + np.cross(qv, t).astype(F32) + v).astype(F32)
+
+
+def quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], F32)
+
+
+@dataclass
+class RigidBody:
+    """The slice of rapier3d's RigidBody the coupling touches."""
+    translation: np.ndarray = field(default_factory=lambda: np.zeros(3, F32))
+    rotation: np.ndarray = field(default_factory=lambda: np.array([0, 0, 0, 1], F32))  # (i, j, k, w)
+    linvel: np.ndarray = field(default_factory=lambda: np.zeros(3, F32))
+    angvel: np.ndarray = field(default_factory=lambda: np.zeros(3, F32))
+    local_com: np.ndarray = field(default_factory=lambda: np.zeros(3, F32))
+    mass: float = 1.0
+    principal_inertia: np.ndarray = field(default_factory=lambda: np.ones(3, F32))  # body frame, about the centre of mass
+    dynamic: bool = True
+
+    def is_dynamic(self) -> bool:
+        return self.dynamic
+
+    def center_of_mass(self) -> np.ndarray:
+        return (quat_rotate(self.rotation, self.local_com) + self.translation).astype(F32)
+
+    def velocity_at_point(self, point) -> np.ndarray:
+        """rapier: linvel + angvel x (point - world_com)."""
+        return (self.linvel + np.cross(self.angvel, np.asarray(point, F32) - self.center_of_mass())).astype(F32)
+
+    def apply_impulse(self, impulse):
+        if self.dynamic:
+            self.linvel = (self.linvel + np.asarray(impulse, F32) / F32(self.mass)).astype(F32)
+
+    def apply_torque_impulse(self, torque_impulse):
+        if self.dynamic:
+            conj = np.array([-self.rotation[0], -self.rotation[1], -self.rotation[2], self.rotation[3]], F32)
+            local = quat_rotate(conj, torque_impulse) / self.principal_inertia
+            self.angvel = (self.angvel + quat_rotate(self.rotation, local)).astype(F32)
+
+    def integrate(self, dt: float, gravity=(0.0, -9.81, 0.0)):
+        """Symplectic Euler, enough for the examples and tests (collisions are the rigid-body engine's business)."""
+        if self.dynamic:
+            self.linvel = (self.linvel + np.asarray(gravity, F32) * F32(dt)).astype(F32)
+        self.translation = (self.translation + self.linvel * F32(dt)).astype(F32)
+        w = self.angvel * F32(dt)
+        ang = float(np.linalg.norm(w))
+        if ang > 0:
+            axis = w / ang
+            dq = np.concatenate([axis * np.sin(ang / 2), [np.cos(ang / 2)]]).astype(F32)
+            q = quat_mul(dq, self.rotation)
+            self.rotation = (q / np.linalg.norm(q)).astype(F32)
+
+    def pose(self) -> L.RigidPose:
+        p = L.RigidPose()
+        p.translation[:] = [float(x) for x in self.translation]
+        p.rotation[:] = [float(x) for x in self.rotation]
+        p.linvel[:] = [float(x) for x in self.linvel]
+        p.angvel[:] = [float(x) for x in self.angvel]
+        p.world_com[:] = [float(x) for x in self.center_of_mass()]
+        p.has_body, p.is_dynamic = 1, int(self.dynamic)
+        return p
+
+
+class StaticSampling:
+    """ColliderSampling::StaticSampling(points): collider-local sample points (fluids_pipeline.rs:36-41)."""
+
+    def __init__(self, points):
+        self.points = np.ascontiguousarray(points, F32).reshape(-1, 3)
+
+
+@dataclass
+class _Entry:
+    boundary: object
+    body: Optional[RigidBody]
+    sampling: StaticSampling
+    uploaded: bool = False
+
+
+class ColliderCouplingSet:
+    """fluids_pipeline.rs:64-136 — one entry per coupled collider; here the collider is identified by any hashable key
+    and its pose is the body's (a collider attached at the body origin)."""
+
+    def __init__(self):
+        self.entries: Dict[object, _Entry] = {}
+
+    def register_coupling(self, boundary, collider, body: Optional[RigidBody], sampling_method: StaticSampling):
+        old = self.entries.get(collider)
+        self.entries[collider] = _Entry(boundary, body, sampling_method)
+        return old.boundary if old else None
+
+    def unregister_coupling(self, collider):
+        e = self.entries.pop(collider, None)
+        return e.boundary if e else None
+
+    # CouplingManager::update_boundaries (:146-264), StaticSampling arm
+    def update_boundaries(self, world):
+        for e in self.entries.values():
+            b = e.boundary
+            if b._world is not world:
+                continue
+            if not e.uploaded:
+                b._sampled = True
+                L.check(world._L.salva_hip_set_boundary_sampling(
+                    world._h, b._slot, len(e.sampling.points), e.sampling.points.ctypes.data_as(C.POINTER(C.c_float)),
+                    b.interaction_groups.memberships, b.interaction_groups.filter))
+                b._n_sampled = len(e.sampling.points)
+                b._dirty = False
+                e.uploaded = True
+            if e.body is not None:
+                pose = e.body.pose()
+                b.wants_forces = e.body.is_dynamic()
+            else:
+                pose = L.RigidPose()
+                pose.rotation[3] = 1.0
+            L.check(world._L.salva_hip_update_boundary_pose(world._h, b._slot, C.byref(pose)))
+
+    # CouplingManager::transmit_forces (:266-287)
+    def transmit_forces(self, world, dt: float):
+        for e in self.entries.values():
+            b = e.boundary
+            if b._world is not world or e.body is None or not b.wants_forces or getattr(b, "_n_sampled", 0) == 0:
+                continue
+            com = e.body.center_of_mass()
+            f = np.zeros(3, F32)
+            t = np.zeros(3, F32)
+            fp = C.POINTER(C.c_float)
+            L.check(world._L.salva_hip_get_boundary_wrench(world._h, b._slot, com.ctypes.data_as(fp), f.ctypes.data_as(fp),
+                                                           t.ctypes.data_as(fp)))
+            e.body.apply_impulse(f * F32(dt))
+            e.body.apply_torque_impulse(t * F32(dt))

@@ -152,6 +152,41 @@ int salva_hip_get_boundary(SalvaHipWorld* world, uint32_t slot, float* volumes, 
     });
 }
 
+int salva_hip_set_boundary_sampling(SalvaHipWorld* world, uint32_t slot, uint64_t n, const float* local_points_xyz,
+                                    uint32_t memberships, uint32_t filter) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->set_boundary_sampling(slot, n, local_points_xyz, memberships, filter);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_update_boundary_pose(SalvaHipWorld* world, uint32_t slot, const SalvaHipRigidPose* pose) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        if (!pose) throw salva::HipError(SALVA_HIP_E_INVALID, "null pose");
+        world->w->update_boundary_pose(slot, *pose);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_get_boundary_particles(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->get_boundary_particles(slot, positions_xyz, velocities_xyz);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_get_boundary_wrench(SalvaHipWorld* world, uint32_t slot, const float point[3], float force[3], float torque[3]) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        if (!point || !force || !torque) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        world->w->get_boundary_wrench(slot, point, force, torque);
+        return SALVA_HIP_OK;
+    });
+}
+
 int salva_hip_clear_boundary_forces(SalvaHipWorld* world, uint32_t slot) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");

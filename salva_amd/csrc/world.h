@@ -2,6 +2,7 @@
 // /root/reference/src/liquid_world.rs:67-158 re-designed around HBM-resident, cell-sorted SoA state).
 #pragma once
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/salva_hip.h"
@@ -25,6 +26,8 @@ struct BoundarySlot {
     uint64_t n = 0;
     uint32_t memberships = 1u, filter = 0xffffffffu;
     bool wants_forces = false;
+    // ColliderSampling::StaticSampling(points): collider-local sample points (integrations/rapier/fluids_pipeline.rs:36-41)
+    std::shared_ptr<DevBuf<float4>> sampling;
 };
 
 struct GridDims {          // tile-aligned dense grid (tile.h)
@@ -56,6 +59,10 @@ class World {
     uint64_t get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity);
     void get_fluid_field(uint32_t slot, int field, float* out);
     void get_boundary(uint32_t slot, float* volumes, float* forces);
+    void set_boundary_sampling(uint32_t slot, uint64_t n, const float* local_points, uint32_t memberships, uint32_t filter);
+    void update_boundary_pose(uint32_t slot, const SalvaHipRigidPose& pose);
+    void get_boundary_particles(uint32_t slot, float* positions, float* velocities);
+    void get_boundary_wrench(uint32_t slot, const float point[3], float force[3], float torque[3]);
     void clear_boundary_forces(uint32_t slot);
     uint64_t device_bytes() const;
     // multi-GPU: this world owns the cell planes [lo, hi] along x; neighbours are rank-1 / rank+1 of `transport`

@@ -1122,6 +1122,128 @@ void World::get_boundary(uint32_t slot, float* volumes, float* forces) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ rigid-body coupling
+// integrations/rapier/fluids_pipeline.rs, StaticSampling arm.  q * v of nalgebra's UnitQuaternion (geometry/
+// quaternion_ops.rs): t = 2 q.vec x v; v' = v + w t + q.vec x t.
+__global__ void k_boundary_pose(uint32_t n, const float4* __restrict__ local, SalvaHipRigidPose p, float4* __restrict__ pos,
+                                float4* __restrict__ vel) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 pt = local[i];
+    const float qx = p.rotation[0], qy = p.rotation[1], qz = p.rotation[2], qw = p.rotation[3];
+    const float tx = (qy * pt.z - qz * pt.y) * 2.0f, ty = (qz * pt.x - qx * pt.z) * 2.0f, tz = (qx * pt.y - qy * pt.x) * 2.0f;
+    const float cx = qy * tz - qz * ty, cy = qz * tx - qx * tz, cz = qx * ty - qy * tx;
+    float4 o = pos[i];  // .w (volume slot) untouched
+    o.x = (tx * qw + cx + pt.x) + p.translation[0];
+    o.y = (ty * qw + cy + pt.y) + p.translation[1];
+    o.z = (tz * qw + cz + pt.z) + p.translation[2];
+    pos[i] = o;
+    float4 v = vel[i];  // .w carries the boundary's model id
+    if (p.has_body) {
+        // body.velocity_at_point(pt) with the local point, as the reference writes it (:183)
+        const float dx = pt.x - p.world_com[0], dy = pt.y - p.world_com[1], dz = pt.z - p.world_com[2];
+        v.x = p.linvel[0] + (p.angvel[1] * dz - p.angvel[2] * dy);
+        v.y = p.linvel[1] + (p.angvel[2] * dx - p.angvel[0] * dz);
+        v.z = p.linvel[2] + (p.angvel[0] * dy - p.angvel[1] * dx);
+    } else {
+        v.x = v.y = v.z = 0.0f;
+    }
+    vel[i] = v;
+}
+
+// per-block partial sums of f and (x - c) x f in f64 (6 doubles per block)
+__global__ void k_boundary_wrench(uint32_t n, const float4* __restrict__ pos, const float4* __restrict__ force, float cx, float cy,
+                                  float cz, double* __restrict__ partial) {
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = pos[i], f = force[i];
+        const float rx = p.x - cx, ry = p.y - cy, rz = p.z - cz;
+        a[0] += f.x; a[1] += f.y; a[2] += f.z;
+        a[3] += (double)(ry * f.z - rz * f.y); a[4] += (double)(rz * f.x - rx * f.z); a[5] += (double)(rx * f.y - ry * f.x);
+    }
+    __shared__ double sh[BLOCK / WAVE][6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double v = a[k];
+        for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+        if ((threadIdx.x & (WAVE - 1)) == 0) sh[threadIdx.x / WAVE][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = 0;
+        for (uint32_t w = 0; w < blockDim.x / WAVE; ++w) v += sh[w][threadIdx.x];
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+void World::set_boundary_sampling(uint32_t slot, uint64_t nn, const float* local_points, uint32_t memberships, uint32_t filter) {
+    const bool keep_forces = slot < bounds.size() ? bounds[slot].wants_forces : false;
+    set_boundary(slot, nn, local_points, nullptr, memberships, filter, keep_forces);
+    auto buf = std::make_shared<DevBuf<float4>>();
+    buf->ensure(nn ? nn : 1);
+    if (nn) {
+        SALVA_HIP_CHECK(hipMemcpyAsync(buf->p, bst_pos.p + boundary_offset(slot), nn * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    bounds[slot].sampling = buf;
+}
+
+void World::update_boundary_pose(uint32_t slot, const SalvaHipRigidPose& pose) {
+    use_device();
+    if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");
+    BoundarySlot& b = bounds[slot];
+    if (!b.sampling) throw HipError(SALVA_HIP_E_INVALID, "boundary has no sampling points (salva_hip_set_boundary_sampling)");
+    for (int k = 0; k < 4; ++k)
+        if (!std::isfinite(pose.rotation[k])) throw HipError(SALVA_HIP_E_INVALID, "non-finite pose");
+    const uint64_t off = boundary_offset(slot);
+    if (pose.has_body) {
+        const bool wants = pose.is_dynamic != 0;
+        if (wants != b.wants_forces) { b.wants_forces = wants; tables_dirty = true; }
+    }
+    if (b.n) {
+        k_boundary_pose<<<nblk(b.n), BLOCK, 0, stream>>>((uint32_t)b.n, b.sampling->p, pose, bst_pos.p + off, bst_vel.p + off);
+        SALVA_HIP_CHECK(hipGetLastError());
+        SALVA_HIP_CHECK(hipMemsetAsync(bforce.p + off, 0, b.n * sizeof(float4), stream));  // boundary.clear_forces(true) :262
+    }
+    b_dirty = true; have_last_ctx = false;
+}
+
+void World::get_boundary_particles(uint32_t slot, float* positions, float* velocities) {
+    use_device();
+    if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");
+    const uint64_t nn = bounds[slot].n, off = boundary_offset(slot);
+    if (nn == 0) return;
+    scratch_f.ensure(3 * nn, stream, false, 1.1f);
+    for (int k = 0; k < 2; ++k) {
+        float* out = k == 0 ? positions : velocities;
+        if (!out) continue;
+        k_unpack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, (k == 0 ? bst_pos.p : bst_vel.p) + off, scratch_f.p);
+        SALVA_HIP_CHECK(hipMemcpyAsync(out, scratch_f.p, 3 * nn * sizeof(float), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+}
+
+void World::get_boundary_wrench(uint32_t slot, const float point[3], float force[3], float torque[3]) {
+    use_device();
+    if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");
+    const BoundarySlot& b = bounds[slot];
+    for (int k = 0; k < 3; ++k) force[k] = torque[k] = 0.0f;
+    if (!b.n || !b.wants_forces) return;
+    const uint64_t off = boundary_offset(slot);
+    const uint32_t nblocks = (uint32_t)std::min<uint64_t>(nblk(b.n), 256);
+    DevBuf<double> partial;
+    partial.ensure((size_t)nblocks * 6);
+    k_boundary_wrench<<<nblocks, BLOCK, 0, stream>>>((uint32_t)b.n, bst_pos.p + off, bforce.p + off, point[0], point[1], point[2], partial.p);
+    SALVA_HIP_CHECK(hipGetLastError());
+    std::vector<double> h((size_t)nblocks * 6);
+    SALVA_HIP_CHECK(hipMemcpyAsync(h.data(), partial.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t k = 0; k < nblocks; ++k)
+        for (int j = 0; j < 6; ++j) acc[j] += h[(size_t)k * 6 + j];
+    for (int k = 0; k < 3; ++k) { force[k] = (float)acc[k]; torque[k] = (float)acc[3 + k]; }
+}
+
 void World::clear_boundary_forces(uint32_t slot) {
     use_device();
     if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");

@@ -343,9 +343,13 @@ class Boundary:
         self._world: Optional["LiquidWorld"] = None
         self._slot = -1
         self._dirty = True
+        self._sampled = False  # positions / velocities are produced on the device from a pose (salva_amd.coupling)
+        self._n_sampled = 0
 
     @property
     def positions(self):
+        if self._sampled and self._world is not None:
+            return self._world._boundary_particles(self)[0]
         return self._positions
 
     @positions.setter
@@ -357,6 +361,8 @@ class Boundary:
 
     @property
     def velocities(self):
+        if self._sampled and self._world is not None:
+            return self._world._boundary_particles(self)[1]
         return self._velocities
 
     @velocities.setter
@@ -368,7 +374,7 @@ class Boundary:
         self._dirty = True
 
     def num_particles(self) -> int:
-        return len(self._positions)
+        return self._n_sampled if self._sampled else len(self._positions)
 
     @property
     def volumes(self) -> np.ndarray:
@@ -578,11 +584,18 @@ class LiquidWorld:
 
     def _sync_boundaries(self):
         for b in self._boundaries:
-            if b._dirty:
+            if b._dirty and not b._sampled:
                 L.check(self._L.salva_hip_set_boundary(
                     self._h, b._slot, b.num_particles(), _fp(b._positions), _fp(b._velocities),
                     b.interaction_groups.memberships, b.interaction_groups.filter, int(b.wants_forces)))
                 b._dirty = False
+
+    def _boundary_particles(self, b: Boundary):
+        n = b.num_particles()
+        pos, vel = np.zeros((n, 3), F32), np.zeros((n, 3), F32)
+        if n:
+            L.check(self._L.salva_hip_get_boundary_particles(self._h, b._slot, _fp(pos), _fp(vel)))
+        return pos, vel
 
     def _boundary_field(self, b: Boundary, volumes: bool) -> np.ndarray:
         self._sync_boundaries()
@@ -625,6 +638,15 @@ class LiquidWorld:
         c.n_divergence_iters, c.n_pressure_iters = st.n_divergence_iters, st.n_pressure_iters
         c.divergence_error, c.density_error = st.divergence_error, st.density_error
         c.grid_ms, c.solver_ms, c.step_ms = st.grid_ms, st.solver_ms, st.step_ms
+        return st
+
+    def step_with_coupling(self, dt: float, gravity, coupling) -> L.StepStats:
+        """LiquidWorld::step_with_coupling (liquid_world.rs:67-158) for a `salva_amd.coupling.ColliderCouplingSet`:
+        update_boundaries -> the substep -> transmit_forces."""
+        self.sync_to_device()
+        coupling.update_boundaries(self)
+        st = self.step(dt, gravity)
+        coupling.transmit_forces(self, dt)
         return st
 
     # ---- multi-GPU (no counterpart in the reference; include/salva_hip.h "multi-GPU")
