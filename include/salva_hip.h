@@ -67,7 +67,9 @@ enum {
     SALVA_HIP_FORCE_AKINCI2013 = 3,  /* solver::Akinci2013SurfaceTension::new(tension, adhesion), akinci2013_surface_tension.rs:29-35 */
     SALVA_HIP_FORCE_DFSPH_VISCOSITY = 4, /* solver::DFSPHViscosity::new(viscosity_coefficient), dfsph_viscosity.rs:102-118 */
     SALVA_HIP_FORCE_HE2014 = 5,      /* solver::He2014SurfaceTension::new(fluid_tension, boundary_tension), he2014_surface_tension.rs:21-29 */
-    SALVA_HIP_FORCE_WCSPH_TENSION = 6 /* solver::WCSPHSurfaceTension::new(fluid_tension, boundary_tension), wcsph_surface_tension.rs:22-28 */
+    SALVA_HIP_FORCE_WCSPH_TENSION = 6, /* solver::WCSPHSurfaceTension::new(fluid_tension, boundary_tension), wcsph_surface_tension.rs:22-28 */
+    SALVA_HIP_FORCE_CUSTOM = 7       /* any other `impl NonPressureForce` (nonpressure_force.rs:10-30): runs on the host through
+                                        the callback of salva_hip_set_force_callback, at its place in the list */
 };
 typedef struct SalvaHipForceDesc {
     int32_t kind;
@@ -194,6 +196,23 @@ int salva_hip_get_boundary_particles(SalvaHipWorld* world, uint32_t slot, float*
  *   force = sum_i f_i,  torque = sum_i (x_i - point) x f_i   ->  body.apply_impulse(force*dt), apply_torque_impulse(torque*dt)
  * with point = body.center_of_mass().  Zero when the boundary does not receive forces. */
 int salva_hip_get_boundary_wrench(SalvaHipWorld* world, uint32_t slot, const float point[3], float force[3], float torque[3]);
+
+/* ---- User-defined `NonPressureForce`s (solver/nonpressure_force.rs:10-30; examples3d/custom_forces3.rs:67-90).
+ * A SALVA_HIP_FORCE_CUSTOM entry in a fluid's force list makes salva_hip_step call `cb` in the middle of the substep, at the
+ * point where `predict_advection` would call the force's `solve` (dfsph_solver.rs:580-603): after gravity and the forces
+ * listed before it were accumulated, with the contacts, densities and (divergence-corrected) velocities of this substep.
+ * `dt` / `inv_dt` are what `timestep.dt()` / `inv_dt()` return at that point (the previous substep's).
+ * Inside the callback — and only there — the host may call salva_hip_force_get_state, salva_hip_get_fluid_contacts (both
+ * kinds), salva_hip_get_boundary_particles / salva_hip_get_boundary (volumes) and salva_hip_force_add_accelerations; other
+ * entry points fail with SALVA_HIP_E_INVALID.  A non-zero return aborts the step with SALVA_HIP_E_INVALID.
+ * This is the slow path by construction (the state crosses PCIe twice per step); the built-in kinds never leave the device. */
+typedef int (*SalvaHipForceCallback)(void* user, SalvaHipWorld* world, uint32_t fluid_slot, uint32_t force_index, float dt,
+                                     float inv_dt);
+int salva_hip_set_force_callback(SalvaHipWorld* world, SalvaHipForceCallback cb, void* user);
+/* `fluid.positions`, `fluid.velocities`, `densities` as `NonPressureForce::solve` receives them (host order; NULL = skip). */
+int salva_hip_force_get_state(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz, float* densities);
+/* `fluid.accelerations[i] += acc[i]` */
+int salva_hip_force_add_accelerations(SalvaHipWorld* world, uint32_t slot, const float* accelerations_xyz);
 
 /* `boundary.volumes` (recomputed every substep, dfsph_solver.rs:72-96) and `boundary.forces`
  * (accumulated by Boundary::apply_force, boundary.rs:62-67).  Any pointer may be NULL. */

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsalva_oracle.so")
 
 DFSPH, IISPH = 0, 1
-FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013, FORCE_DFSPH_VISCOSITY, FORCE_HE2014, FORCE_WCSPH_TENSION = 1, 2, 3, 4, 5, 6
+FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013, FORCE_DFSPH_VISCOSITY, FORCE_HE2014, FORCE_WCSPH_TENSION, FORCE_CUSTOM = 1, 2, 3, 4, 5, 6, 7
 
 
 class Stats(C.Structure):
@@ -82,6 +82,9 @@ def lib():
         L.so_set_boundary_sampling.argtypes = [vp, i32, u64, C.POINTER(C.c_float)]
         L.so_update_boundary_pose.argtypes = [vp, i32, dp, i32, i32]
         L.so_get_boundary_wrench.argtypes = [vp, i32, dp, dp, dp]
+        L.so_set_force_callback.argtypes = [vp, FORCE_CB, vp]
+        L.so_num_forces.argtypes = [vp, i32]
+        L.so_num_forces.restype = i32
         L.so_reference_would_panic.restype = i32
         L.so_reference_would_panic.argtypes = [vp]
         L.so_test_lu6.argtypes = [dp, dp, dp]
@@ -97,6 +100,10 @@ def lib():
         L.so_max_threads.restype = i32
         _lib = L
     return _lib
+
+
+FORCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                       C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
 def _f32(a, cols=None):
@@ -197,6 +204,24 @@ class OracleWorld:
         """solver::WCSPHSurfaceTension::new (wcsph_surface_tension.rs:22-28)."""
         p = _f32([fluid_tension_coeff, boundary_tension_coeff])
         self._L.so_add_force(self._h, fluid, FORCE_WCSPH_TENSION, _fp(p), 2)
+
+    def add_custom_force(self, fluid, fn):
+        """A user NonPressureForce (nonpressure_force.rs:10-30): fn(world, fluid, positions, velocities, densities,
+        accelerations) edits `accelerations` (n x 3 float64 view) in place; contacts via world.contacts_of()."""
+        if not hasattr(self, "_custom"):
+            self._custom = {}
+
+            def trampoline(_user, f, k, n, pos, vel, dens, acc):
+                shape = (n, 3)
+                self._custom[(f, k)](self, f, np.ctypeslib.as_array(pos, shape), np.ctypeslib.as_array(vel, shape),
+                                     np.ctypeslib.as_array(dens, (n,)), np.ctypeslib.as_array(acc, shape))
+
+            self._cb = FORCE_CB(trampoline)
+            self._L.so_set_force_callback(self._h, self._cb, None)
+        p = _f32([0.0])
+        k = self._L.so_num_forces(self._h, fluid)
+        self._L.so_add_force(self._h, fluid, FORCE_CUSTOM, _fp(p), 1)
+        self._custom[(fluid, k)] = fn
 
     def reference_would_panic(self) -> bool:
         return bool(self._L.so_reference_would_panic(self._h))

@@ -159,7 +159,7 @@ struct Groups {
     }
 };
 
-enum ForceKind { FORCE_XSPH = 1, FORCE_ARTIFICIAL = 2, FORCE_AKINCI2013 = 3, FORCE_DFSPH_VISCOSITY = 4, FORCE_HE2014 = 5, FORCE_WCSPH_TENSION = 6 };
+enum ForceKind { FORCE_XSPH = 1, FORCE_ARTIFICIAL = 2, FORCE_AKINCI2013 = 3, FORCE_DFSPH_VISCOSITY = 4, FORCE_HE2014 = 5, FORCE_WCSPH_TENSION = 6, FORCE_CUSTOM = 7 };
 
 template <typename R>
 struct Force {
@@ -1123,6 +1123,28 @@ struct World {
         force.last_visc_error = err;
     }
 
+    // A user `NonPressureForce` (solver/nonpressure_force.rs:10-30, examples3d/custom_forces3.rs:67-90): the host callback
+    // sees the fluid as `solve` does (positions, velocities, densities of this substep; the contact lists through the
+    // contact accessors) and adds to `fluid.accelerations`.
+    typedef void (*custom_cb_t)(void* user, int fluid, int force_index, uint64_t n, const double* pos, const double* vel,
+                                const double* dens, double* acc);
+    custom_cb_t custom_cb = nullptr;
+    void* custom_user = nullptr;
+    void solve_custom(size_t f, size_t index) {
+        if (!custom_cb) return;
+        Fluid<R>& fluid = fluids[f];
+        const size_t n = fluid.n();
+        std::vector<double> pos(3 * n), vel(3 * n), dens(n), acc(3 * n);
+        for (size_t i = 0; i < n; ++i) {
+            pos[3 * i] = fluid.positions[i].x; pos[3 * i + 1] = fluid.positions[i].y; pos[3 * i + 2] = fluid.positions[i].z;
+            vel[3 * i] = fluid.velocities[i].x; vel[3 * i + 1] = fluid.velocities[i].y; vel[3 * i + 2] = fluid.velocities[i].z;
+            acc[3 * i] = fluid.accelerations[i].x; acc[3 * i + 1] = fluid.accelerations[i].y; acc[3 * i + 2] = fluid.accelerations[i].z;
+            dens[i] = densities[f][i];
+        }
+        custom_cb(custom_user, (int)f, (int)index, n, pos.data(), vel.data(), dens.data(), acc.data());
+        for (size_t i = 0; i < n; ++i) fluid.accelerations[i] = V3<R>((R)acc[3 * i], (R)acc[3 * i + 1], (R)acc[3 * i + 2]);
+    }
+
     // dfsph_solver.rs:565-604 / iisph_solver.rs:541-580
     void predict_advection(const V3<R>& gravity) {
         for (auto& fluid : fluids) {
@@ -1139,6 +1161,7 @@ struct World {
                     case FORCE_DFSPH_VISCOSITY: solve_dfsph_viscosity(f, force); break;
                     case FORCE_HE2014: solve_he2014(f, force); break;
                     case FORCE_WCSPH_TENSION: solve_wcsph_tension(f, force); break;
+                    case FORCE_CUSTOM: solve_custom(f, (size_t)(&force - fluids[f].forces.data())); break;
                     default: break;
                 }
             }
@@ -1621,6 +1644,12 @@ void so_get_fluid_vec(void* p, int fluid, int field, double* out) {
 #undef GETV
 }
 // 1 if a step hit a code path on which the reference would panic (WCSPHSurfaceTension's boundary loop, see solve_wcsph_tension)
+// user force callback for FORCE_CUSTOM entries (kind 7 of so_add_force)
+void so_set_force_callback(void* p, void (*cb)(void*, int, int, uint64_t, const double*, const double*, const double*, double*), void* user) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, { w.custom_cb = cb; w.custom_user = user; }, { w.custom_cb = cb; w.custom_user = user; });
+}
+int so_num_forces(void* p, int fluid) { Handle* h = (Handle*)p; int r = 0; DISPATCH(h, r = (int)w.fluids[fluid].forces.size(), r = (int)w.fluids[fluid].forces.size()); return r; }
 int so_reference_would_panic(void* p) { Handle* h = (Handle*)p; int r = 0; DISPATCH(h, r = w.reference_would_panic, r = w.reference_would_panic); return r; }
 // field: 0 densities, 1 alphas, 2 divergences, 3 predicted_densities, 4 volumes, 5 aii, 6 pressures, 7 He2014 colors, 8 He2014 gradcs
 void so_get_fluid_scalar(void* p, int fluid, int field, double* out) {

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libsalva_hip.so")
 
 OK, E_HIP, E_INVALID, E_NUMERIC, E_CAPACITY = 0, -1, -2, -3, -4
 SOLVER_DFSPH, SOLVER_IISPH = 0, 1
-FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013, FORCE_DFSPH_VISCOSITY, FORCE_HE2014, FORCE_WCSPH_TENSION = 1, 2, 3, 4, 5, 6
+FORCE_XSPH, FORCE_ARTIFICIAL, FORCE_AKINCI2013, FORCE_DFSPH_VISCOSITY, FORCE_HE2014, FORCE_WCSPH_TENSION, FORCE_CUSTOM = 1, 2, 3, 4, 5, 6, 7
 DIRTY_POSITIONS, DIRTY_VELOCITIES, DIRTY_VOLUMES, DIRTY_ACCELERATIONS, DIRTY_ALL = 1, 2, 4, 8, 15
 (FIELD_DENSITY, FIELD_ALPHA, FIELD_NUM_FLUID_CONTACTS, FIELD_NUM_BOUNDARY_CONTACTS, FIELD_VELOCITY_CHANGE,
  FIELD_PRESSURE, FIELD_VOLUME, FIELD_ACCELERATION) = range(8)
@@ -31,7 +31,8 @@ EXPORTED_SYMBOLS = [
     "salva_hip_comm_loopback_create", "salva_hip_comm_destroy", "salva_hip_set_domain", "salva_hip_get_owned",
     "salva_hip_get_force_stats", "salva_hip_get_fluid_contacts", "salva_hip_add_particles", "salva_hip_delete_particles",
     "salva_hip_particles_intersecting_aabb", "salva_hip_set_boundary_sampling", "salva_hip_update_boundary_pose",
-    "salva_hip_get_boundary_particles", "salva_hip_get_boundary_wrench",
+    "salva_hip_get_boundary_particles", "salva_hip_get_boundary_wrench", "salva_hip_set_force_callback",
+    "salva_hip_force_get_state", "salva_hip_force_add_accelerations",
 ]
 
 
@@ -54,6 +55,10 @@ class Params(C.Structure):
 
 class ForceDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("p", C.c_float * 7)]
+
+
+# SalvaHipForceCallback (include/salva_hip.h)
+FORCE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float)
 
 
 class RigidPose(C.Structure):
@@ -135,6 +140,9 @@ def lib():
     L.salva_hip_update_boundary_pose.argtypes = [vp, u32, C.POINTER(RigidPose)]
     L.salva_hip_get_boundary_particles.argtypes = [vp, u32, fp, fp]
     L.salva_hip_get_boundary_wrench.argtypes = [vp, u32, fp, fp, fp]
+    L.salva_hip_set_force_callback.argtypes = [vp, FORCE_CALLBACK, vp]
+    L.salva_hip_force_get_state.argtypes = [vp, u32, fp, fp, fp]
+    L.salva_hip_force_add_accelerations.argtypes = [vp, u32, fp]
     L.salva_hip_device_bytes.argtypes = [vp]
     L.salva_hip_device_bytes.restype = u64
     L.salva_hip_time_pred_density.argtypes = [vp, i32]

@@ -31,6 +31,11 @@ static int guarded(F&& f) {
     }
 }
 
+static void not_in_force_callback(const SalvaHipWorld* world) {
+    if (world->w->in_force_callback())
+        throw salva::HipError(SALVA_HIP_E_INVALID, "this entry point is not available inside a force callback");
+}
+
 extern "C" {
 
 void salva_hip_default_params(SalvaHipParams* p) {
@@ -73,6 +78,7 @@ int salva_hip_set_fluid(SalvaHipWorld* world, uint32_t slot, uint64_t n, const f
                         uint32_t dirty_mask) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
         world->w->set_fluid(slot, n, positions_xyz, velocities_xyz, volumes, accelerations_xyz, velocity_changes_xyz,
                             density0, memberships, filter, dirty_mask);
         return SALVA_HIP_OK;
@@ -82,6 +88,7 @@ int salva_hip_set_fluid(SalvaHipWorld* world, uint32_t slot, uint64_t n, const f
 int salva_hip_set_fluid_forces(SalvaHipWorld* world, uint32_t slot, const SalvaHipForceDesc* forces, uint32_t nforces) {
     return guarded([&]() -> int {
         if (!world || (nforces && !forces)) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        not_in_force_callback(world);
         world->w->set_fluid_forces(slot, forces, nforces);
         return SALVA_HIP_OK;
     });
@@ -90,6 +97,7 @@ int salva_hip_set_fluid_forces(SalvaHipWorld* world, uint32_t slot, const SalvaH
 int salva_hip_remove_fluid(SalvaHipWorld* world, uint32_t slot) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
         world->w->remove_fluid(slot);
         return SALVA_HIP_OK;
     });
@@ -99,6 +107,7 @@ int salva_hip_set_boundary(SalvaHipWorld* world, uint32_t slot, uint64_t n, cons
                            const float* velocities_xyz, uint32_t memberships, uint32_t filter, int32_t wants_forces) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
         world->w->set_boundary(slot, n, positions_xyz, velocities_xyz, memberships, filter, wants_forces != 0);
         return SALVA_HIP_OK;
     });
@@ -107,6 +116,7 @@ int salva_hip_set_boundary(SalvaHipWorld* world, uint32_t slot, uint64_t n, cons
 int salva_hip_remove_boundary(SalvaHipWorld* world, uint32_t slot) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
         world->w->remove_boundary(slot);
         return SALVA_HIP_OK;
     });
@@ -124,6 +134,7 @@ uint64_t salva_hip_boundary_len(const SalvaHipWorld* world, uint32_t slot) {
 int salva_hip_step(SalvaHipWorld* world, float dt, const float gravity[3], SalvaHipStepStats* stats) {
     return guarded([&]() -> int {
         if (!world || !gravity) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        not_in_force_callback(world);
         return world->w->step(dt, gravity, stats);
     });
 }
@@ -131,6 +142,7 @@ int salva_hip_step(SalvaHipWorld* world, float dt, const float gravity[3], Salva
 int salva_hip_get_fluid(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
         world->w->get_fluid(slot, positions_xyz, velocities_xyz);
         return SALVA_HIP_OK;
     });
@@ -156,6 +168,7 @@ int salva_hip_set_boundary_sampling(SalvaHipWorld* world, uint32_t slot, uint64_
                                     uint32_t memberships, uint32_t filter) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
         world->w->set_boundary_sampling(slot, n, local_points_xyz, memberships, filter);
         return SALVA_HIP_OK;
     });
@@ -165,7 +178,32 @@ int salva_hip_update_boundary_pose(SalvaHipWorld* world, uint32_t slot, const Sa
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         if (!pose) throw salva::HipError(SALVA_HIP_E_INVALID, "null pose");
+        not_in_force_callback(world);
         world->w->update_boundary_pose(slot, *pose);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_set_force_callback(SalvaHipWorld* world, SalvaHipForceCallback cb, void* user) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->set_force_callback(cb, user, world);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_force_get_state(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz, float* densities) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->force_get_state(slot, positions_xyz, velocities_xyz, densities);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_force_add_accelerations(SalvaHipWorld* world, uint32_t slot, const float* accelerations_xyz) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->force_add_accelerations(slot, accelerations_xyz);
         return SALVA_HIP_OK;
     });
 }
@@ -190,6 +228,7 @@ int salva_hip_get_boundary_wrench(SalvaHipWorld* world, uint32_t slot, const flo
 int salva_hip_clear_boundary_forces(SalvaHipWorld* world, uint32_t slot) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
         world->w->clear_boundary_forces(slot);
         return SALVA_HIP_OK;
     });
@@ -250,6 +289,7 @@ void salva_hip_comm_destroy(SalvaHipComm* comm) {
 int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_lo, int32_t cell_hi, uint32_t gid_offset) {
     return guarded([&]() -> int {
         if (!world || !comm) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        not_in_force_callback(world);
         world->w->set_domain(comm->t, cell_lo, cell_hi, gid_offset);
         return SALVA_HIP_OK;
     });
@@ -278,6 +318,7 @@ int64_t salva_hip_particles_intersecting_aabb(SalvaHipWorld* world, const float 
 int salva_hip_add_particles(SalvaHipWorld* world, uint32_t slot, uint64_t n_add, const float* positions_xyz, const float* velocities_xyz) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
         world->w->add_particles(slot, n_add, positions_xyz, velocities_xyz);
         return SALVA_HIP_OK;
     });
@@ -286,6 +327,7 @@ int64_t salva_hip_delete_particles(SalvaHipWorld* world, uint32_t slot, const ui
     int64_t kept = 0;
     const int rc = guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
         kept = (int64_t)world->w->delete_particles(slot, deleted_mask);
         return SALVA_HIP_OK;
     });

@@ -61,6 +61,10 @@ class World {
     void get_boundary(uint32_t slot, float* volumes, float* forces);
     void set_boundary_sampling(uint32_t slot, uint64_t n, const float* local_points, uint32_t memberships, uint32_t filter);
     void update_boundary_pose(uint32_t slot, const SalvaHipRigidPose& pose);
+    void set_force_callback(SalvaHipForceCallback cb, void* user, SalvaHipWorld* owner) { force_cb = cb; force_user = user; force_owner = owner; }
+    void force_get_state(uint32_t slot, float* positions, float* velocities, float* densities);
+    void force_add_accelerations(uint32_t slot, const float* acc);
+    bool in_force_callback() const { return in_force_cb; }
     void get_boundary_particles(uint32_t slot, float* positions, float* velocities);
     void get_boundary_wrench(uint32_t slot, const float point[3], float force[3], float torque[3]);
     void clear_boundary_forces(uint32_t slot);
@@ -160,6 +164,10 @@ class World {
     DevBuf<SolveCtl> d_ctl;      // [0] divergence solve, [1] pressure solve, [2] viscosity solve (DFSPHViscosity)
     SolveCtl* h_ctl = nullptr;   // pinned: [0..NUM_SOLVES) read-back, [NUM_SOLVES..2 NUM_SOLVES) initial values
 
+    SalvaHipForceCallback force_cb = nullptr;
+    void* force_user = nullptr;
+    SalvaHipWorld* force_owner = nullptr;
+    bool in_force_cb = false;
     float dt_prev = 0.0f, inv_dt_prev = 0.0f;  // TimestepManager::{dt, inv_dt} persist across steps (timestep_manager.rs:23-34)
     StepCtx last_ctx{};
     float last_dt = 0.0f;

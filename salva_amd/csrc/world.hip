@@ -333,7 +333,7 @@ uint64_t World::delete_particles(uint32_t slot, const uint8_t* mask) {
 void World::set_fluid_forces(uint32_t slot, const SalvaHipForceDesc* f, uint32_t nf) {
     if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
     for (uint32_t k = 0; k < nf; ++k)
-        if (f[k].kind < SALVA_HIP_FORCE_XSPH || f[k].kind > SALVA_HIP_FORCE_WCSPH_TENSION)
+        if (f[k].kind < SALVA_HIP_FORCE_XSPH || f[k].kind > SALVA_HIP_FORCE_CUSTOM)
             throw HipError(SALVA_HIP_E_INVALID, "unknown non-pressure force kind (only built-ins run on the device)");
     for (uint32_t k = 0; k < nf; ++k)
         if (f[k].kind == SALVA_HIP_FORCE_DFSPH_VISCOSITY && !(f[k].p[0] >= 0.0f && f[k].p[0] <= 1.0f))
@@ -661,6 +661,24 @@ void World::run_forces(const StepCtx& c) {
                     launch_he2014_forces(c, lds, f, d.p[0], d.p[1], he_gradcs.p, stream);
                     break;
                 case SALVA_HIP_FORCE_WCSPH_TENSION: launch_wcsph_tension(c, lds, f, d.p[0], stream); break;
+                case SALVA_HIP_FORCE_CUSTOM: {
+                    // a host `NonPressureForce::solve` at its place in the list (nonpressure_force.rs:10-30)
+                    if (!force_cb) throw HipError(SALVA_HIP_E_INVALID, "a SALVA_HIP_FORCE_CUSTOM entry needs salva_hip_set_force_callback");
+                    if (comm) throw HipError(SALVA_HIP_E_INVALID, "host force callbacks are not available in a multi-GPU run");
+                    last_ctx = c; last_ctx.ctl = nullptr; have_last_ctx = true;  // what the contact export reads
+                    wait_stream();
+                    in_force_cb = true;
+                    int rc = 0;
+                    try {
+                        rc = force_cb(force_user, force_owner, f, (uint32_t)(&d - fluids[f].forces.data()), dt_prev, inv_dt_prev);
+                    } catch (...) {
+                        in_force_cb = false; have_last_ctx = false;
+                        throw;
+                    }
+                    in_force_cb = false; have_last_ctx = false;
+                    if (rc != 0) throw HipError(SALVA_HIP_E_INVALID, "the force callback reported an error");
+                    break;
+                }
                 case SALVA_HIP_FORCE_AKINCI2013:
                     launch_akinci_normals(c, lds, f, stream);
                     // (normals of the inner ghost plane are complete: rho was refreshed on both planes)
@@ -1206,6 +1224,56 @@ void World::update_boundary_pose(uint32_t slot, const SalvaHipRigidPose& pose) {
         SALVA_HIP_CHECK(hipMemsetAsync(bforce.p + off, 0, b.n * sizeof(float4), stream));  // boundary.clear_forces(true) :262
     }
     b_dirty = true; have_last_ctx = false;
+}
+
+// ------------------------------------------------------------------------------------------------ host force callbacks
+__global__ void k_add_acc_from_host(uint32_t n, const uint32_t* __restrict__ perm, uint32_t off, uint32_t nn,
+                                    const float* __restrict__ in, float4* __restrict__ acc) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t g = perm[s] - off;  // host index within the fluid (wraps for other fluids)
+    if (g >= nn) return;
+    float4 a = acc[s];
+    a.x += in[3 * g]; a.y += in[3 * g + 1]; a.z += in[3 * g + 2];
+    acc[s] = a;
+}
+
+void World::force_get_state(uint32_t slot, float* positions, float* velocities, float* densities) {
+    use_device();
+    if (!in_force_cb) throw HipError(SALVA_HIP_E_INVALID, "only available inside a force callback");
+    if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
+    const uint64_t nn = fluids[slot].n, off = fluid_offset(slot);
+    if (nn == 0) return;
+    scratch_f4.ensure(n);
+    scratch_f.ensure(std::max<size_t>(3 * nn, n), stream, false, 1.1f);
+    for (int k = 0; k < 2; ++k) {
+        float* out = k == 0 ? positions : velocities;
+        if (!out) continue;
+        // fluid.velocities equal w = v + dv while the forces run (dfsph_solver.rs:688-693)
+        launch_unsort_f4(n, perm[cur].p, k == 0 ? last_ctx.posm : last_ctx.w, scratch_f4.p, stream);
+        k_unpack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, scratch_f4.p + off, scratch_f.p);
+        SALVA_HIP_CHECK(hipMemcpyAsync(out, scratch_f.p, 3 * nn * sizeof(float), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    if (densities) {
+        launch_unsort_f32(n, perm[cur].p, last_ctx.rho, scratch_f.p, stream);
+        SALVA_HIP_CHECK(hipMemcpyAsync(densities, scratch_f.p + off, nn * sizeof(float), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+}
+
+void World::force_add_accelerations(uint32_t slot, const float* acc_h) {
+    use_device();
+    if (!in_force_cb) throw HipError(SALVA_HIP_E_INVALID, "only available inside a force callback");
+    if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
+    if (!acc_h) throw HipError(SALVA_HIP_E_INVALID, "null accelerations");
+    const uint64_t nn = fluids[slot].n, off = fluid_offset(slot);
+    if (nn == 0) return;
+    scratch_f.ensure(3 * nn, stream, false, 1.1f);
+    SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, acc_h, 3 * nn * sizeof(float), hipMemcpyHostToDevice, stream));
+    k_add_acc_from_host<<<nblk(n), BLOCK, 0, stream>>>(n, perm[cur].p, (uint32_t)off, (uint32_t)nn, scratch_f.p, last_ctx.acc);
+    SALVA_HIP_CHECK(hipGetLastError());
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
 }
 
 void World::get_boundary_particles(uint32_t slot, float* positions, float* velocities) {

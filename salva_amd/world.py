@@ -60,11 +60,94 @@ class InteractionGroups:
 
 # ------------------------------------------------------------------------------------------------ forces
 class NonPressureForce:
-    """solver/nonpressure_force.rs:10-30.  Only the built-ins below run on the device; an arbitrary user
-    implementation needs host contact lists (not built yet) and is rejected loudly."""
+    """solver/nonpressure_force.rs:10-30.  The built-ins below run on the device.  A subclass that implements
+
+        solve(self, timestep, kernel_radius, fluid_fluid_contacts, fluid_boundaries_contacts, fluid, boundaries, densities)
+
+    like the trait (examples3d/custom_forces3.rs:67-90) runs on the host in the middle of the substep, at its place in
+    the fluid's force list (include/salva_hip.h, SALVA_HIP_FORCE_CUSTOM): `timestep.dt()` / `inv_dt()`, the two
+    `ParticlesContacts`, a view of the fluid with this substep's `positions` / `velocities` / `volumes` / `density0` and an
+    `accelerations` array to add to, the boundaries and the densities — the slow path, the state crosses PCIe."""
 
     def _desc(self) -> L.ForceDesc:
-        raise NotImplementedError("custom NonPressureForce implementations are not supported on the device path")
+        if not callable(getattr(self, "solve", None)):
+            raise NotImplementedError("a custom NonPressureForce must implement solve(...)")
+        d = L.ForceDesc()
+        d.kind = L.FORCE_CUSTOM
+        return d
+
+
+class TimestepView:
+    """The two TimestepManager getters forces use (timestep_manager.rs:60-72)."""
+
+    def __init__(self, dt, inv_dt):
+        self._dt, self._inv_dt = dt, inv_dt
+
+    def dt(self):
+        return self._dt
+
+    def inv_dt(self):
+        return self._inv_dt
+
+
+@dataclass
+class Contact:
+    """geometry/contacts.rs:40-55"""
+    i: int
+    i_model: int
+    j: int
+    j_model: int
+    weight: float
+    gradient: np.ndarray
+
+
+class ParticlesContacts:
+    """geometry/contacts.rs:57-131 over the device's exported CSR lists: `particle_contacts(i)` yields the reference's
+    `Contact`s (weight and gradient evaluated with the cubic spline, kernel/cubic_spline_kernel.rs); the raw arrays
+    (`offsets`, `j_model`, `j`) are there for vectorised forces."""
+
+    def __init__(self, i_model, offsets, j_model, j, positions_i, positions_of_model, h):
+        self.i_model, self.offsets, self.j_model, self.j = i_model, offsets, j_model, j
+        self._pi, self._pj, self._h = positions_i, positions_of_model, h
+
+    def len(self):
+        return len(self.offsets) - 1
+
+    def particle_contacts(self, i):
+        out = []
+        for k in range(int(self.offsets[i]), int(self.offsets[i + 1])):
+            jm, j = int(self.j_model[k]), int(self.j[k])
+            d = (self._pi[i] - self._pj(jm)[j]).astype(F32)
+            r = F32(np.sqrt(F32(d[0] * d[0] + d[1] * d[1]) + F32(d[2] * d[2])))
+            w, dw = _cubic_spline(r, F32(self._h))
+            grad = (d / r * dw).astype(F32) if r > np.finfo(F32).eps else np.zeros(3, F32)
+            out.append(Contact(i, self.i_model, j, jm, float(w), grad))
+        return out
+
+
+def _cubic_spline(r, h):
+    """CubicSplineKernel::{scalar_apply, scalar_apply_diff} (cubic_spline_kernel.rs:12-33, 55-79) in f32."""
+    q = F32(r / h)
+    norm = F32(8.0 / np.pi) / (h * h * h)
+    if q <= 0.5:
+        return norm * (F32(6) * (q * q * q - q * q) + F32(1)), norm * F32(6) * (F32(3) * q * q - F32(2) * q) / h
+    if q <= 1.0:
+        return norm * F32(2) * (F32(1) - q) ** 3, -norm * F32(6) * (F32(1) - q) ** 2 / h
+    return F32(0), F32(0)
+
+
+class FluidView:
+    """What `solve` sees of the `Fluid` (object/fluid.rs:12-34)."""
+
+    def __init__(self, positions, velocities, volumes, density0):
+        self.positions, self.velocities, self.volumes, self.density0 = positions, velocities, volumes, density0
+        self.accelerations = np.zeros_like(positions)
+
+    def num_particles(self):
+        return len(self.positions)
+
+    def particle_mass(self, i):
+        return self.volumes[i] * self.density0
 
 
 class XSPHViscosity(NonPressureForce):
@@ -571,6 +654,8 @@ class LiquidWorld:
         descs = (L.ForceDesc * max(len(f.nonpressure_forces), 1))()
         for k, force in enumerate(f.nonpressure_forces):
             descs[k] = force._desc()
+            if descs[k].kind == L.FORCE_CUSTOM:
+                self._install_force_callback()
         if f._resized or f._dirty:
             n = f.num_particles()
             dirty = L.DIRTY_ALL if f._resized else f._dirty
@@ -624,6 +709,9 @@ class LiquidWorld:
         for f in self._fluids:
             f._device_newer = True
             f._accelerations[:] = 0  # integrate_and_clear_accelerations
+        err, self._force_cb_error = getattr(self, "_force_cb_error", None), None
+        if err is not None:
+            raise err
         L.check(rc)
         for f in self._fluids:
             for k, force in enumerate(f.nonpressure_forces):
@@ -639,6 +727,53 @@ class LiquidWorld:
         c.divergence_error, c.density_error = st.divergence_error, st.density_error
         c.grid_ms, c.solver_ms, c.step_ms = st.grid_ms, st.solver_ms, st.step_ms
         return st
+
+    # ---- host NonPressureForce::solve in the middle of the substep (SALVA_HIP_FORCE_CUSTOM)
+    def _install_force_callback(self):
+        if getattr(self, "_force_cb", None) is not None:
+            return
+
+        def callback(_user, _world, slot, index, dt, inv_dt):
+            try:
+                f = next(x for x in self._fluids if x._slot == slot)
+                force = f.nonpressure_forces[index]
+                n = f.num_particles()
+                pos, vel, dens = np.zeros((n, 3), F32), np.zeros((n, 3), F32), np.zeros(n, F32)
+                L.check(self._L.salva_hip_force_get_state(self._h, slot, _fp(pos), _fp(vel), _fp(dens)))
+                fluid_pos = {}
+
+                def positions_of_fluid(m):
+                    if m == slot:
+                        return pos
+                    if m not in fluid_pos:
+                        g = next(x for x in self._fluids if x._slot == m)
+                        p = np.zeros((g.num_particles(), 3), F32)
+                        L.check(self._L.salva_hip_force_get_state(self._h, m, _fp(p), None, None))
+                        fluid_pos[m] = p
+                    return fluid_pos[m]
+
+                bpos = {}
+
+                def positions_of_boundary(m):
+                    if m not in bpos:
+                        b = next(x for x in self._boundaries if x._slot == m)
+                        bpos[m] = self._boundary_particles(b)[0]
+                    return bpos[m]
+
+                ff = ParticlesContacts(slot, *self.fluid_contacts(f, False), pos, positions_of_fluid, self.h())
+                fb = ParticlesContacts(slot, *self.fluid_contacts(f, True), pos, positions_of_boundary, self.h())
+                view = FluidView(pos, vel, np.asarray(f.volumes, F32), f.density0)
+                force.solve(TimestepView(dt, inv_dt), self.h(), ff, fb, view, list(self._boundaries), dens)
+                acc = np.ascontiguousarray(view.accelerations, F32)
+                L.check(self._L.salva_hip_force_add_accelerations(self._h, slot, _fp(acc)))
+                return 0
+            except BaseException as e:  # noqa: BLE001 - reported through the step's error
+                self._force_cb_error = e
+                return 1
+
+        self._force_cb = L.FORCE_CALLBACK(callback)
+        self._force_cb_error = None
+        L.check(self._L.salva_hip_set_force_callback(self._h, self._force_cb, None))
 
     def step_with_coupling(self, dt: float, gravity, coupling) -> L.StepStats:
         """LiquidWorld::step_with_coupling (liquid_world.rs:67-158) for a `salva_amd.coupling.ColliderCouplingSet`:
