@@ -293,6 +293,8 @@ class Fluid:
         self._resized = True
         self._device_newer = False
         self._acc_set = False
+        self._acc_touched = False   # host accelerations may be non-zero (cleared after the step only then: 12 MB at 10^6 particles)
+        self._maybe_deleted = False # delete_particle_at_next_timestep was called since the last removal
 
     @staticmethod
     def particle_volume(particle_radius: float) -> np.float32:
@@ -328,6 +330,7 @@ class Fluid:
 
     @property
     def accelerations(self) -> np.ndarray:
+        self._acc_touched = True  # the caller may write into the array
         return self._accelerations
 
     @accelerations.setter
@@ -335,6 +338,7 @@ class Fluid:
         self._accelerations = _as_vec3(v, self.num_particles()).copy()
         self._dirty |= L.DIRTY_ACCELERATIONS
         self._acc_set = True
+        self._acc_touched = True
 
     @property
     def volumes(self) -> np.ndarray:
@@ -367,11 +371,13 @@ class Fluid:
 
     def delete_particle_at_next_timestep(self, particle: int):
         self._deleted[particle] = True
+        self._maybe_deleted = True
 
     def num_deleted_particles(self) -> int:
         return int(self._deleted.sum())
 
     def deleted_particles_mask(self) -> np.ndarray:
+        self._maybe_deleted = True  # the caller may write into the mask
         return self._deleted
 
     def add_particles(self, positions, velocities=None):
@@ -620,6 +626,9 @@ class LiquidWorld:
 
     def _apply_particles_removal(self, f: Fluid):
         """fluid.rs:88-98 + the compaction of the solver's buffers (dfsph_solver.rs:550-560)."""
+        if not f._maybe_deleted:
+            return
+        f._maybe_deleted = False
         if not f._deleted.any():
             return
         if not f._resized and not f._dirty and f._pending_dv is None:
@@ -708,7 +717,9 @@ class LiquidWorld:
         rc = self._L.salva_hip_step(self._h, dt, g, C.byref(st))
         for f in self._fluids:
             f._device_newer = True
-            f._accelerations[:] = 0  # integrate_and_clear_accelerations
+            if f._acc_touched:
+                f._accelerations[:] = 0  # integrate_and_clear_accelerations
+                f._acc_touched = False
         err, self._force_cb_error = getattr(self, "_force_cb_error", None), None
         if err is not None:
             raise err

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -40 > gpurun_out/tests.log
-./examples/coupling3 400 > gpurun_out/coupling3.log 2>&1
+python tools/host_overhead.py 2>&1 | grep "python step" > gpurun_out/host_overhead.log
