@@ -214,6 +214,18 @@ int salva_hip_force_get_state(SalvaHipWorld* world, uint32_t slot, float* positi
 /* `fluid.accelerations[i] += acc[i]` */
 int salva_hip_force_add_accelerations(SalvaHipWorld* world, uint32_t slot, const float* accelerations_xyz);
 
+/* ---- Checkpoint / restart.  The state `LiquidWorld::step` carries from one call to the next is:
+ * positions, velocities and volumes of every fluid (salva_hip_get_fluid / get_fluid_field(VOLUME)), the solver's
+ * `velocity_changes` (dfsph_solver.rs:41, applied at the top of the next step) and, for IISPH, the `pressures` its Jacobi
+ * loop warm-starts from (iisph_solver.rs:35, :428-431) — readable with salva_hip_get_fluid_field and writable with
+ * salva_hip_set_fluid_field (fields VELOCITY_CHANGE and PRESSURE only) — plus the TimestepManager's `dt` / `inv_dt`
+ * (timestep_manager.rs:23-34), which the next step reads before advancing (the dt lag of divergence_solve and of the
+ * non-pressure forces).  A world rebuilt from these continues the run: same contacts and iteration counts, state equal up to
+ * f32 summation order (the order of particles within a cell restarts from host order). */
+int salva_hip_set_fluid_field(SalvaHipWorld* world, uint32_t slot, int32_t field, const float* data);
+int salva_hip_get_timestep(const SalvaHipWorld* world, float* dt, float* inv_dt);
+int salva_hip_set_timestep(SalvaHipWorld* world, float dt, float inv_dt);
+
 /* `boundary.volumes` (recomputed every substep, dfsph_solver.rs:72-96) and `boundary.forces`
  * (accumulated by Boundary::apply_force, boundary.rs:62-67).  Any pointer may be NULL. */
 int salva_hip_get_boundary(SalvaHipWorld* world, uint32_t slot, float* volumes, float* forces_xyz);

@@ -32,7 +32,8 @@ EXPORTED_SYMBOLS = [
     "salva_hip_get_force_stats", "salva_hip_get_fluid_contacts", "salva_hip_add_particles", "salva_hip_delete_particles",
     "salva_hip_particles_intersecting_aabb", "salva_hip_set_boundary_sampling", "salva_hip_update_boundary_pose",
     "salva_hip_get_boundary_particles", "salva_hip_get_boundary_wrench", "salva_hip_set_force_callback",
-    "salva_hip_force_get_state", "salva_hip_force_add_accelerations",
+    "salva_hip_force_get_state", "salva_hip_force_add_accelerations", "salva_hip_set_fluid_field", "salva_hip_get_timestep",
+    "salva_hip_set_timestep",
 ]
 
 
@@ -143,6 +144,9 @@ def lib():
     L.salva_hip_set_force_callback.argtypes = [vp, FORCE_CALLBACK, vp]
     L.salva_hip_force_get_state.argtypes = [vp, u32, fp, fp, fp]
     L.salva_hip_force_add_accelerations.argtypes = [vp, u32, fp]
+    L.salva_hip_set_fluid_field.argtypes = [vp, u32, i32, fp]
+    L.salva_hip_get_timestep.argtypes = [vp, fp, fp]
+    L.salva_hip_set_timestep.argtypes = [vp, f32, f32]
     L.salva_hip_device_bytes.argtypes = [vp]
     L.salva_hip_device_bytes.restype = u64
     L.salva_hip_time_pred_density.argtypes = [vp, i32]

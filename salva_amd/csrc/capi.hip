@@ -208,6 +208,30 @@ int salva_hip_force_add_accelerations(SalvaHipWorld* world, uint32_t slot, const
     });
 }
 
+int salva_hip_set_fluid_field(SalvaHipWorld* world, uint32_t slot, int32_t field, const float* data) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
+        world->w->set_fluid_field(slot, field, data);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_get_timestep(const SalvaHipWorld* world, float* dt, float* inv_dt) {
+    if (!world) return SALVA_HIP_E_INVALID;
+    world->w->get_timestep(dt, inv_dt);
+    return SALVA_HIP_OK;
+}
+
+int salva_hip_set_timestep(SalvaHipWorld* world, float dt, float inv_dt) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
+        world->w->set_timestep(dt, inv_dt);
+        return SALVA_HIP_OK;
+    });
+}
+
 int salva_hip_get_boundary_particles(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");

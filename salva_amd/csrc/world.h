@@ -65,6 +65,9 @@ class World {
     void force_get_state(uint32_t slot, float* positions, float* velocities, float* densities);
     void force_add_accelerations(uint32_t slot, const float* acc);
     bool in_force_callback() const { return in_force_cb; }
+    void set_fluid_field(uint32_t slot, int field, const float* data);
+    void get_timestep(float* dt, float* inv_dt) const { if (dt) *dt = dt_prev; if (inv_dt) *inv_dt = inv_dt_prev; }
+    void set_timestep(float dt, float inv_dt) { dt_prev = dt; inv_dt_prev = inv_dt; }
     void get_boundary_particles(uint32_t slot, float* positions, float* velocities);
     void get_boundary_wrench(uint32_t slot, const float point[3], float force[3], float torque[3]);
     void clear_boundary_forces(uint32_t slot);

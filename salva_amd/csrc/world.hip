@@ -1276,6 +1276,26 @@ void World::force_add_accelerations(uint32_t slot, const float* acc_h) {
     SALVA_HIP_CHECK(hipStreamSynchronize(stream));
 }
 
+// checkpoint restore: the two pieces of solver state that live next to the fluid arrays (velocity_changes, IISPH pressures)
+void World::set_fluid_field(uint32_t slot, int field, const float* data) {
+    use_device();
+    if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
+    if (!data) throw HipError(SALVA_HIP_E_INVALID, "null data");
+    if (field != SALVA_HIP_FIELD_VELOCITY_CHANGE && field != SALVA_HIP_FIELD_PRESSURE)
+        throw HipError(SALVA_HIP_E_INVALID, "only velocity_changes and pressures can be set");
+    const uint64_t nn = fluids[slot].n, off = fluid_offset(slot);
+    if (nn == 0) return;
+    ensure_staging_current();
+    const size_t width = field == SALVA_HIP_FIELD_VELOCITY_CHANGE ? 3 : 1;
+    scratch_f.ensure(width * nn, stream, false, 1.1f);
+    SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, data, width * nn * sizeof(float), hipMemcpyHostToDevice, stream));
+    if (field == SALVA_HIP_FIELD_VELOCITY_CHANGE) k_pack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, scratch_f.p, st_dv.p + off, 1, 0.0f);
+    else k_pack_w<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, scratch_f.p, st_dv.p + off);
+    SALVA_HIP_CHECK(hipGetLastError());
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    sorted_valid = false; bbox_known = false; have_last_ctx = false;
+}
+
 void World::get_boundary_particles(uint32_t slot, float* positions, float* velocities) {
     use_device();
     if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");

@@ -786,6 +786,54 @@ class LiquidWorld:
         self._force_cb_error = None
         L.check(self._L.salva_hip_set_force_callback(self._h, self._force_cb, None))
 
+    # ---- checkpoint / restart (include/salva_hip.h "Checkpoint / restart")
+    def checkpoint(self) -> dict:
+        """Everything `step` carries over to the next call, as numpy arrays (np.savez-able): fluid positions / velocities /
+        volumes, the solver's velocity_changes, IISPH pressures, boundary particles, and the TimestepManager's dt / inv_dt."""
+        self.sync_to_device()
+        dt, inv_dt = C.c_float(0), C.c_float(0)
+        L.check(self._L.salva_hip_get_timestep(self._h, C.byref(dt), C.byref(inv_dt)))
+        st = {"timestep": np.array([dt.value, inv_dt.value], F32), "nfluids": np.array(len(self._fluids)),
+              "nboundaries": np.array(len(self._boundaries))}
+        for k, f in enumerate(self._fluids):
+            st[f"fluid{k}_positions"] = f.positions.copy()
+            st[f"fluid{k}_velocities"] = f.velocities.copy()
+            st[f"fluid{k}_volumes"] = np.asarray(f.volumes, F32).copy()
+            st[f"fluid{k}_velocity_changes"] = self.velocity_changes(f)
+            st[f"fluid{k}_pressures"] = self.pressures(f)
+        for k, b in enumerate(self._boundaries):
+            st[f"boundary{k}_positions"] = np.asarray(b.positions, F32).copy()
+            st[f"boundary{k}_velocities"] = np.asarray(b.velocities, F32).copy()
+        return st
+
+    def restore(self, st: dict):
+        """Load a `checkpoint()` into a world built with the same fluids / boundaries (forces, densities, groups come from
+        the objects; particle counts may differ from the checkpoint's).  The run continues with the same contacts and
+        iteration counts, states equal up to f32 summation order (cells are re-sorted from host order)."""
+        if int(st["nfluids"]) != len(self._fluids) or int(st["nboundaries"]) != len(self._boundaries):
+            raise ValueError("the checkpoint was taken from a world with different fluids / boundaries")
+        for k, f in enumerate(self._fluids):
+            pos = np.ascontiguousarray(st[f"fluid{k}_positions"], F32)
+            n = len(pos)
+            f._positions = pos.copy()
+            f._velocities = np.ascontiguousarray(st[f"fluid{k}_velocities"], F32).copy()
+            f._volumes = np.ascontiguousarray(st[f"fluid{k}_volumes"], F32).copy()
+            f._accelerations = np.zeros((n, 3), F32)
+            f._deleted = np.zeros(n, bool)
+            f._pending_dv = np.ascontiguousarray(st[f"fluid{k}_velocity_changes"], F32).copy()
+            f._resized, f._dirty, f._device_newer, f._maybe_deleted, f._acc_touched = True, L.DIRTY_ALL, False, False, False
+        for k, b in enumerate(self._boundaries):
+            if not b._sampled:
+                b.positions = st[f"boundary{k}_positions"]
+                b.velocities = st[f"boundary{k}_velocities"]
+        self.sync_to_device()
+        for k, f in enumerate(self._fluids):
+            p = np.ascontiguousarray(st[f"fluid{k}_pressures"], F32)
+            if len(p):
+                L.check(self._L.salva_hip_set_fluid_field(self._h, f._slot, L.FIELD_PRESSURE, _fp(p)))
+        t = np.asarray(st["timestep"], F32)
+        L.check(self._L.salva_hip_set_timestep(self._h, float(t[0]), float(t[1])))
+
     def step_with_coupling(self, dt: float, gravity, coupling) -> L.StepStats:
         """LiquidWorld::step_with_coupling (liquid_world.rs:67-158) for a `salva_amd.coupling.ColliderCouplingSet`:
         update_boundaries -> the substep -> transmit_forces."""

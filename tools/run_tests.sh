@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
 timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -40 > gpurun_out/tests.log
-python tools/host_overhead.py 2>&1 | grep "python step" > gpurun_out/host_overhead.log
