@@ -31,6 +31,7 @@ def test_struct_layouts_match_header(hip_lib):
     assert C.sizeof(_lib.Params) == 4 * 18
     assert C.sizeof(_lib.ForceDesc) == 32
     assert C.sizeof(_lib.StepStats) == 4 * 4 + 8 * 2 + 4 * 8
+    assert C.sizeof(_lib.RigidPose) == 4 * (3 + 4 + 3 + 3 + 3 + 2)  # SalvaHipRigidPose
     p = _lib.Params()
     hip_lib.salva_hip_default_params(C.byref(p))
     # defaults of DFSPHSolver::new (dfsph_solver.rs:54-70)
