@@ -82,6 +82,9 @@ def lib():
         L.so_set_boundary_sampling.argtypes = [vp, i32, u64, C.POINTER(C.c_float)]
         L.so_update_boundary_pose.argtypes = [vp, i32, dp, i32, i32]
         L.so_get_boundary_wrench.argtypes = [vp, i32, dp, dp, dp]
+        L.so_add_particles.argtypes = [vp, i32, u64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.so_delete_particle.argtypes = [vp, i32, u64]
+        L.so_remove_fluid.argtypes = [vp, i32]
         L.so_set_force_callback.argtypes = [vp, FORCE_CB, vp]
         L.so_num_forces.argtypes = [vp, i32]
         L.so_num_forces.restype = i32
@@ -240,6 +243,22 @@ class OracleWorld:
         out = np.zeros((self.fluid_len(fluid), 6, 6), dtype=np.float64)
         self._L.so_get_viscosity_betas(self._h, fluid, force_index, out.ctypes.data_as(C.POINTER(C.c_double)))
         return out
+
+    def add_particles(self, fluid, positions, velocities=None):
+        """Fluid::add_particles (fluid.rs:126-150)."""
+        pos = _f32(positions, 3)
+        vel = _f32(velocities, 3) if velocities is not None else None
+        self._L.so_add_particles(self._h, fluid, len(pos), _fp(pos), _fp(vel) if vel is not None else None)
+
+    def delete_particle_at_next_timestep(self, fluid, i):
+        """fluid.rs:71-76; the removal happens at the top of the next step (liquid_world.rs:78-82)."""
+        self._L.so_delete_particle(self._h, fluid, int(i))
+
+    def remove_fluid(self, fluid):
+        """LiquidWorld::remove_fluid (liquid_world.rs:171-173): swap-remove; the solver's buffers stay positional."""
+        self._L.so_remove_fluid(self._h, fluid)
+        if hasattr(self, "_custom"):
+            self._custom = {}
 
     def set_fluid_velocities(self, fluid, velocities):
         v = _f32(velocities, 3)

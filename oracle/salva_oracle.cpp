@@ -185,8 +185,41 @@ struct Fluid {  // object/fluid.rs:12-34
     R density0 = 1000;
     Groups groups;
     std::vector<Force<R>> forces;
+    std::vector<char> deleted;  // deleted_particles (fluid.rs:28-30); sized lazily
+    size_t num_deleted = 0;
     size_t n() const { return positions.size(); }
     R particle_mass(size_t i) const { return volumes[i] * density0; }  // fluid.rs:183-185
+    // delete_particle_at_next_timestep (fluid.rs:71-76)
+    void delete_particle_at_next_timestep(size_t i) {
+        deleted.resize(n(), 0);
+        if (!deleted[i]) { deleted[i] = 1; ++num_deleted; }
+    }
+    // helper::filter_from_mask (helper.rs:4-12)
+    template <typename T>
+    void filter(std::vector<T>& v) const {
+        size_t k = 0;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (!(i < deleted.size() && deleted[i])) v[k++] = v[i];
+        v.resize(k);
+    }
+    // apply_particles_removal (fluid.rs:88-98)
+    void apply_particles_removal() {
+        if (num_deleted == 0) return;
+        filter(positions); filter(velocities); filter(accelerations); filter(volumes);
+        deleted.assign(positions.size(), 0);
+        num_deleted = 0;
+    }
+    // add_particles (fluid.rs:126-150); `default_volume` = default_particle_volume()
+    void add_particles(size_t k, const float* pos, const float* vel, R default_volume) {
+        const size_t n0 = n();
+        for (size_t i = 0; i < k; ++i) {
+            positions.push_back(V3<R>((R)pos[3 * i], (R)pos[3 * i + 1], (R)pos[3 * i + 2]));
+            velocities.push_back(vel ? V3<R>((R)vel[3 * i], (R)vel[3 * i + 1], (R)vel[3 * i + 2]) : V3<R>());
+        }
+        accelerations.resize(n0 + k, V3<R>());
+        volumes.resize(n0 + k, default_volume);
+        deleted.resize(n0 + k, 0);
+    }
 };
 
 template <typename R>
@@ -343,7 +376,21 @@ struct World {
             divergences[f].resize(n, 0); velocity_changes[f].resize(n, V3<R>());
             aii[f].resize(n, 0); pressures[f].resize(n, 0); next_pressures[f].resize(n, 0);
             dii[f].resize(n, V3<R>()); dij_pjl[f].resize(n, V3<R>());
+            if (fluids[f].num_deleted != 0) {  // dfsph :550-560 / iisph :503-536 (each solver filters the buffers it owns)
+                const Fluid<R>& fl = fluids[f];
+                fl.filter(alphas[f]); fl.filter(densities[f]); fl.filter(predicted_densities[f]); fl.filter(divergences[f]);
+                fl.filter(velocity_changes[f]); fl.filter(aii[f]); fl.filter(dii[f]); fl.filter(dij_pjl[f]);
+                fl.filter(pressures[f]); fl.filter(next_pressures[f]);
+            }
         }
+    }
+    // LiquidWorld::remove_fluid (liquid_world.rs:171-173) = ContiguousArena::remove (contiguous_arena.rs:118-135): a
+    // swap-remove of the OBJECT only.  The solver's per-fluid buffers are positional and stay where they are, so the
+    // fluid that moves into the freed slot inherits the removed fluid's velocity_changes / pressures (resized to its own
+    // particle count by the next init_with_fluids) — restated as it is.
+    void remove_fluid(size_t slot) {
+        if (slot + 1 != fluids.size()) std::swap(fluids[slot], fluids.back());
+        fluids.pop_back();
     }
 
     // ------------------------------------------------------------------ contacts.rs:133-151
@@ -1427,6 +1474,7 @@ struct World {
         double t0 = now_ms();
         total_step_size = step_dt; remaining_time = step_dt;  // timestep_manager.reset
         init_with_fluids();
+        for (auto& fl : fluids) fl.apply_particles_removal();  // liquid_world.rs:80-82
         stats = StepStats{};
         while (!(remaining_time <= Eps<R>::v)) {  // is_done, timestep_manager.rs:56-58
             double ta = now_ms();
@@ -1648,6 +1696,20 @@ void so_get_fluid_vec(void* p, int fluid, int field, double* out) {
 void so_set_force_callback(void* p, void (*cb)(void*, int, int, uint64_t, const double*, const double*, const double*, double*), void* user) {
     Handle* h = (Handle*)p;
     DISPATCH(h, { w.custom_cb = cb; w.custom_user = user; }, { w.custom_cb = cb; w.custom_user = user; });
+}
+void so_add_particles(void* p, int fluid, uint64_t n, const float* pos, const float* vel) {
+    Handle* h = (Handle*)p;
+#define ADDP(w, R) do { R pr = w.particle_radius; w.fluids[fluid].add_particles(n, pos, vel, pr * pr * pr * (R)(8.0 * 0.8)); } while (0)
+    DISPATCH(h, ADDP(w, float), ADDP(w, double));
+#undef ADDP
+}
+void so_delete_particle(void* p, int fluid, uint64_t i) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, w.fluids[fluid].delete_particle_at_next_timestep(i), w.fluids[fluid].delete_particle_at_next_timestep(i));
+}
+void so_remove_fluid(void* p, int fluid) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, w.remove_fluid(fluid), w.remove_fluid(fluid));
 }
 int so_num_forces(void* p, int fluid) { Handle* h = (Handle*)p; int r = 0; DISPATCH(h, r = (int)w.fluids[fluid].forces.size(), r = (int)w.fluids[fluid].forces.size()); return r; }
 int so_reference_would_panic(void* p) { Handle* h = (Handle*)p; int r = 0; DISPATCH(h, r = w.reference_would_panic, r = w.reference_would_panic); return r; }

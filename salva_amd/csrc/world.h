@@ -2,6 +2,7 @@
 // /root/reference/src/liquid_world.rs:67-158 re-designed around HBM-resident, cell-sorted SoA state).
 #pragma once
 #include <string>
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -167,6 +168,13 @@ class World {
     DevBuf<SolveCtl> d_ctl;      // [0] divergence solve, [1] pressure solve, [2] viscosity solve (DFSPHViscosity)
     SolveCtl* h_ctl = nullptr;   // pinned: [0..NUM_SOLVES) read-back, [NUM_SOLVES..2 NUM_SOLVES) initial values
 
+    // The reference's solver buffers (velocity_changes, IISPH pressures) are positional per fluid SLOT and outlive the object:
+    // remove_fluid swap-removes the fluid only, and the buffers are resized / truncated by the next init_with_fluids
+    // (dfsph_solver.rs:526-549, iisph_solver.rs:479-501).  Until the next step, `sticky[slot]` holds the content of such a
+    // buffer where it differs from what the fluid occupying the slot carries: a fluid moved or created into the slot, and
+    // particles added to it, inherit from it exactly as the reference's `resize` would hand it to them.
+    struct StickyBuf { std::shared_ptr<DevBuf<float4>> data; uint64_t len = 0; };
+    std::map<uint32_t, StickyBuf> sticky;
     SalvaHipForceCallback force_cb = nullptr;
     void* force_user = nullptr;
     SalvaHipWorld* force_owner = nullptr;

@@ -206,6 +206,14 @@ void World::set_fluid(uint32_t slot, uint64_t nn, const float* pos, const float*
             k_fill_f4<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_dv.p + off, make_float4(0, 0, 0, 0), 0);
             k_fill_f4<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, st_acc.p + off, make_float4(0, 0, 0, 0), 0);
         }
+        if (is_new && !dvs) {
+            auto it = sticky.find(slot);
+            if (it != sticky.end()) {  // buffer[slot] of a fluid removed since the last step: inherited (world.h `sticky`)
+                const uint64_t inherit = std::min<uint64_t>(it->second.len, nn);
+                if (inherit) SALVA_HIP_CHECK(hipMemcpyAsync(st_dv.p + off, it->second.data->p, inherit * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+                if (it->second.len <= nn) sticky.erase(it);
+            }
+        }
         // model ids of every slot at/after this one may have moved
         fluids[slot].n = nn;
         uint64_t o = 0;
@@ -270,6 +278,13 @@ void World::add_particles(uint32_t slot, uint64_t n_add, const float* pos, const
     k_fill_f4<<<nblk(n_add), BLOCK, 0, stream>>>((uint32_t)n_add, st_vel.p + at, make_float4(0, 0, 0, 0), 0);
     k_fill_f4<<<nblk(n_add), BLOCK, 0, stream>>>((uint32_t)n_add, st_dv.p + at, make_float4(0, 0, 0, 0), 0);
     k_fill_f4<<<nblk(n_add), BLOCK, 0, stream>>>((uint32_t)n_add, st_acc.p + at, make_float4(0, 0, 0, 0), 0);
+    {
+        auto it = sticky.find(slot);
+        if (it != sticky.end() && it->second.len > old_n) {  // `velocity_changes[slot].resize(n)` exposes the inherited tail
+            const uint64_t take = std::min<uint64_t>(it->second.len - old_n, n_add);
+            SALVA_HIP_CHECK(hipMemcpyAsync(st_dv.p + at, it->second.data->p + old_n, take * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+        }
+    }
     uint64_t o = 0;
     for (uint32_t s = 0; s < fluids.size(); ++s) {
         if (fluids[s].n) k_fill_u32<<<nblk(fluids[s].n), BLOCK, 0, stream>>>((uint32_t)fluids[s].n, st_model.p + o, s);
@@ -318,6 +333,28 @@ uint64_t World::delete_particles(uint32_t slot, const uint8_t* mask) {
         std::swap(buf.cap, out.cap);
     };
     compact(st_pos); compact(st_vel); compact(st_dv); compact(st_acc);
+    {
+        // an inherited solver buffer (world.h `sticky`) is filtered with the same mask by the reference — after its resize, so
+        // the entries beyond the fluid's particles (handed to particles added before the next step) just move down
+        auto it = sticky.find(slot);
+        if (it != sticky.end() && it->second.len) {
+            const uint64_t L = it->second.len, head = std::min<uint64_t>(L, nn);
+            std::vector<uint8_t> k2((size_t)L, 1);
+            uint64_t kept2 = 0;
+            for (uint64_t k = 0; k < L; ++k) { if (k < head) k2[k] = mask[k] ? 0 : 1; kept2 += k2[k]; }
+            DevBuf<uint8_t> d_k2;
+            d_k2.ensure(L);
+            SALVA_HIP_CHECK(hipMemcpyAsync(d_k2.p, k2.data(), (size_t)L, hipMemcpyHostToDevice, stream));
+            auto out = std::make_shared<DevBuf<float4>>();
+            out->ensure(std::max<uint64_t>(kept2, 1));
+            const size_t tb = select_flagged_temp_bytes((uint32_t)L);
+            ensure_cub_temp(tb);
+            select_flagged_f4(cub_temp.p, tb, it->second.data->p, d_k2.p, out->p, d_num.p, (uint32_t)L, stream);
+            SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+            it->second.data = out;
+            it->second.len = kept2;
+        }
+    }
     n = (uint32_t)new_total;
     fluids[slot].n = kept;
     uint64_t o = 0;
@@ -362,7 +399,46 @@ void World::remove_fluid(uint32_t slot) {
     const uint64_t new_total = n - len;
     rebuild(st_pos, pieces, new_total, stream);
     rebuild(st_vel, pieces, new_total, stream);
-    rebuild(st_dv, pieces, new_total, stream);
+    {
+        // The solver's per-fluid buffers are positional in the reference and are NOT swapped with the object
+        // (liquid_world.rs:171-173 removes from the arena only; init_with_fluids then resizes `velocity_changes[slot]` /
+        // `pressures[slot]` to the new occupant's particle count, dfsph_solver.rs:526-549 / iisph_solver.rs:479-501): the
+        // fluid that moves into the freed slot inherits the removed fluid's velocity changes and pressures, truncated
+        // or zero-extended, and the buffer of the last slot lives on until the next step (a fluid added before then
+        // inherits it).  Reproduced: results must match the reference's, quirks included.  See `sticky` in world.h.
+        auto content_of = [&](uint32_t sl, uint64_t o, uint64_t l) {
+            auto it = sticky.find(sl);
+            if (it != sticky.end()) return it->second;
+            StickyBuf b;
+            b.data = std::make_shared<DevBuf<float4>>();
+            b.len = l;
+            b.data->ensure(std::max<uint64_t>(l, 1));
+            if (l) SALVA_HIP_CHECK(hipMemcpyAsync(b.data->p, st_dv.p + o, l * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+            return b;
+        };
+        const StickyBuf A = content_of(slot, off, len);
+        const StickyBuf B = slot != last ? content_of(last, loff, llen) : StickyBuf{};
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<Piece> dvp;
+        dvp.push_back({0, off, true});
+        if (slot != last) {
+            dvp.push_back({0, llen, false});
+            dvp.push_back({off + len, loff - off - len, true});
+        }
+        rebuild(st_dv, dvp, new_total, stream);
+        sticky.erase(slot);
+        sticky.erase(last);
+        if (slot != last) {
+            const uint64_t inherit = std::min(A.len, llen);
+            if (inherit) SALVA_HIP_CHECK(hipMemcpyAsync(st_dv.p + off, A.data->p, inherit * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+            if (llen > inherit) SALVA_HIP_CHECK(hipMemsetAsync(st_dv.p + off + inherit, 0, (llen - inherit) * sizeof(float4), stream));
+            if (A.len > llen) sticky[slot] = A;  // its tail goes to particles added before the next step
+            sticky[last] = B;
+        } else {
+            sticky[last] = A;
+        }
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
     rebuild(st_acc, pieces, new_total, stream);
     rebuild(st_model, pieces, new_total, stream);
     if (slot != last) fluids[slot] = fluids[last];
@@ -767,6 +843,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     use_device();
     SalvaHipStepStats st{};
     st.nparticles = n;
+    sticky.clear();  // init_with_fluids runs at the top of every step, substeps or not (liquid_world.rs:76)
     // TimestepManager::is_done (timestep_manager.rs:56-58): no substep at all for dt <= eps
     if ((n == 0 && !comm) || !(dt > FLT_EPSILON)) {
         if (stats) *stats = st;

@@ -1,0 +1,89 @@
+"""Differential test of the object bookkeeping around the hot path: a seeded random sequence of LiquidWorld operations
+(step, Fluid::add_particles, delete_particle_at_next_timestep, remove_fluid, add_fluid, host edits of velocities) is
+applied to the HIP world and to the oracle; after every step particle counts and contacts must be equal and the states
+within the parity tolerance.  Covers the interplay the single-purpose tests cannot: which arrays travel, which solver
+buffers are compacted, inherited (remove_fluid's positional buffers) or restarted, and when."""
+import numpy as np
+import pytest
+
+from parity import DT, GRAVITY
+from oracle import oracle as O
+from salva_amd import Boundary, DFSPHSolver, Fluid, IISPHSolver, LiquidWorld, XSPHViscosity, scenes
+
+pytestmark = pytest.mark.gpu
+
+R = 0.025
+
+
+def _block(rng, nx, ny, nz, origin):
+    p = scenes.jitter(scenes.cube_fluid_positions(nx, ny, nz, R), 0.05 * R, seed=int(rng.integers(1 << 30)))
+    return (p + np.float32(origin)).astype(np.float32)
+
+
+@pytest.mark.parametrize("solver,seed", [("dfsph", 1), ("dfsph", 2), ("iisph", 3)])
+def test_random_operation_sequences_match_oracle(solver, seed):
+    rng = np.random.default_rng(seed)
+    o = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH)
+    w = LiquidWorld(DFSPHSolver() if solver == "dfsph" else IISPHSolver(), R, 2.0)
+    handles = []  # handles[slot] mirrors the FluidSet's dense order (swap-remove)
+
+    def add_fluid(origin, density):
+        pos = _block(rng, 4, 4, 4, origin)
+        vel = scenes.random_velocities(len(pos), 0.1, seed=int(rng.integers(1 << 30)))
+        f = Fluid(pos, R, density)
+        f.velocities = vel
+        f.nonpressure_forces.append(XSPHViscosity(0.5, 0.2))
+        handles.append(w.add_fluid(f))
+        k = o.add_fluid(pos, density, vel)
+        o.add_xsph(k, 0.5, 0.2)
+        assert k == len(handles) - 1
+
+    floor = scenes.plane_lattice(40, 12, 0.0, R, -6 * 2 * R + R, -6 * 2 * R + R, layers=1)
+    w.add_boundary(Boundary(floor))
+    o.add_boundary(floor)
+    add_fluid([0.0, 0.25, 0.0], 1000.0)
+    add_fluid([0.5, 0.25, 0.0], 800.0)
+    nsteps, log = 0, []
+    next_x = 1.0
+    for _ in range(40):
+        op = rng.choice(["step", "step", "step", "add_particles", "delete", "remove_fluid", "add_fluid", "set_velocities"])
+        log.append(op)
+        if op == "step":
+            so, sh = o.step(DT, GRAVITY), w.step(DT, GRAVITY)
+            nsteps += 1
+            assert so.ncontacts == sh.ncontacts, log
+            for k, h in enumerate(handles):
+                assert o.fluid_len(k) == h.num_particles(), log
+                ref_p, ref_v = o.fluid_vec(k, "positions"), o.fluid_vec(k, "velocities")
+                assert np.abs(h.positions - ref_p).max() < 1e-4 * R * nsteps, (log, k)
+                vref = max(np.abs(ref_v).max(), 2 * R / DT * 1e-2)
+                assert np.abs(h.velocities - ref_v).max() < 2e-4 * nsteps * vref, (log, k)
+        elif op == "add_particles" and handles:
+            k = int(rng.integers(len(handles)))
+            base = handles[k].positions.mean(0) + np.float32([0.0, 0.35, 0.0])
+            pos = _block(rng, 2, 2, 2, base)
+            vel = np.tile(np.float32([0.0, -0.5, 0.0]), (len(pos), 1)) if rng.random() < 0.5 else None
+            handles[k].add_particles(pos, vel)
+            o.add_particles(k, pos, vel)
+        elif op == "delete" and handles:
+            k = int(rng.integers(len(handles)))
+            n = handles[k].num_particles()
+            for i in rng.choice(n, size=min(5, n), replace=False):
+                handles[k].delete_particle_at_next_timestep(int(i))
+                o.delete_particle_at_next_timestep(k, int(i))
+        elif op == "remove_fluid" and len(handles) >= 2:
+            k = int(rng.integers(len(handles)))
+            w.remove_fluid(handles[k])
+            o.remove_fluid(k)
+            handles[k] = handles[-1]
+            handles.pop()
+        elif op == "add_fluid" and len(handles) < 4:
+            add_fluid([next_x, 0.25, 0.0], float(rng.choice([600.0, 1000.0, 1200.0])))
+            next_x += 0.5
+        elif op == "set_velocities" and handles:
+            k = int(rng.integers(len(handles)))
+            v = handles[k].velocities.copy()
+            v[:, 0] += np.float32(0.2)
+            handles[k].velocities = v
+            o.set_fluid_velocities(k, v)
+    assert nsteps >= 8, log
