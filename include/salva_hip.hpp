@@ -223,11 +223,13 @@ class LiquidWorld {  // liquid_world.rs
     FluidHandle add_fluid(Fluid f) { fluids_.push_back(std::move(f)); fluids_.back().structural_ = true; return fluids_.size() - 1; }
     BoundaryHandle add_boundary(Boundary b) { boundaries_.push_back(std::move(b)); boundaries_.back().dirty_ = true; return boundaries_.size() - 1; }
     void remove_fluid(FluidHandle h) {
+        upload_new_objects();
         if (h < salva_hip_num_fluids(w_)) check(salva_hip_remove_fluid(w_, (uint32_t)h));
         fluids_[h] = std::move(fluids_.back());
         fluids_.pop_back();
     }
     void remove_boundary(BoundaryHandle h) {
+        upload_new_objects();
         if (h < salva_hip_num_boundaries(w_)) check(salva_hip_remove_boundary(w_, (uint32_t)h));
         boundaries_[h] = std::move(boundaries_.back());
         boundaries_.pop_back();
@@ -281,8 +283,22 @@ class LiquidWorld {  // liquid_world.rs
     }
 
   private:
+    // Objects added since the last step exist only on the host: a swap-remove must see the same dense sets on both sides.
+    // Pending particle deletions stay pending (they are applied at the top of the next step, fluid.rs:88-98).
+    void upload_new_objects() {
+        for (size_t s = salva_hip_num_fluids(w_); s < fluids_.size(); ++s) {
+            Fluid& f = fluids_[s];
+            const size_t n = f.num_particles();
+            check(salva_hip_set_fluid(w_, (uint32_t)s, n, n ? f.positions[0].data() : nullptr, n ? f.velocities[0].data() : nullptr,
+                                      n ? f.volumes.data() : nullptr, n ? f.accelerations[0].data() : nullptr, nullptr, f.density0,
+                                      f.interaction_groups.memberships, f.interaction_groups.filter, (uint32_t)SALVA_HIP_DIRTY_ALL));
+            f.structural_ = false; f.dirty_ = 0; f.appended_from_ = Fluid::kNone;
+        }
+        for (size_t s = 0; s < boundaries_.size(); ++s) upload(boundaries_[s], (uint32_t)s);
+    }
     void upload(Fluid& f, uint32_t slot) {
         std::vector<Vec3> dv;  // solver.velocity_changes of the surviving particles (init_with_fluids, dfsph_solver.rs:526-561)
+        std::vector<Real> pr;  // ... and the pressures IISPH warm-starts from (iisph_solver.rs:35, :499-536)
         bool have_dv = false;
         bool any_deleted = false;
         for (bool d : f.deleted_) any_deleted |= d;
@@ -321,6 +337,9 @@ class LiquidWorld {  // liquid_world.rs
                 dv.assign(old_n, Vec3{0, 0, 0});
                 check(salva_hip_get_fluid_field(w_, slot, SALVA_HIP_FIELD_VELOCITY_CHANGE, dv[0].data()));
                 dv.resize(f.num_particles(), Vec3{0, 0, 0});
+                pr.assign(old_n, 0.0f);
+                check(salva_hip_get_fluid_field(w_, slot, SALVA_HIP_FIELD_PRESSURE, pr.data()));
+                pr.resize(f.num_particles(), 0.0f);
                 have_dv = true;
             }
         }
@@ -330,11 +349,11 @@ class LiquidWorld {  // liquid_world.rs
                 if (f.deleted_[i]) continue;
                 f.positions[k] = f.positions[i]; f.velocities[k] = f.velocities[i];
                 f.accelerations[k] = f.accelerations[i]; f.volumes[k] = f.volumes[i];
-                if (have_dv) dv[k] = dv[i];
+                if (have_dv) { dv[k] = dv[i]; pr[k] = pr[i]; }
                 ++k;
             }
             f.positions.resize(k); f.velocities.resize(k); f.accelerations.resize(k); f.volumes.resize(k);
-            if (have_dv) dv.resize(k);
+            if (have_dv) { dv.resize(k); pr.resize(k); }
             f.deleted_.assign(k, false);
         }
         if (f.structural_ || f.dirty_) {
@@ -345,6 +364,11 @@ class LiquidWorld {  // liquid_world.rs
                                       n ? f.volumes.data() : nullptr, acc, (have_dv && n) ? dv[0].data() : nullptr, f.density0,
                                       f.interaction_groups.memberships, f.interaction_groups.filter,
                                       f.structural_ ? (uint32_t)SALVA_HIP_DIRTY_ALL : f.dirty_));
+            if (have_dv && n) {
+                bool any = false;
+                for (Real x : pr) any |= x != 0.0f;
+                if (any) check(salva_hip_set_fluid_field(w_, slot, SALVA_HIP_FIELD_PRESSURE, pr.data()));
+            }
             f.structural_ = false;
             f.dirty_ = 0;
         }

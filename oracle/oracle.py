@@ -85,6 +85,8 @@ def lib():
         L.so_add_particles.argtypes = [vp, i32, u64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.so_delete_particle.argtypes = [vp, i32, u64]
         L.so_remove_fluid.argtypes = [vp, i32]
+        L.so_remove_boundary.argtypes = [vp, i32]
+        L.so_set_boundary_particles.argtypes = [vp, i32, u64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.so_set_force_callback.argtypes = [vp, FORCE_CB, vp]
         L.so_num_forces.argtypes = [vp, i32]
         L.so_num_forces.restype = i32
@@ -259,6 +261,15 @@ class OracleWorld:
         self._L.so_remove_fluid(self._h, fluid)
         if hasattr(self, "_custom"):
             self._custom = {}
+
+    def remove_boundary(self, boundary):
+        """LiquidWorld::remove_boundary (liquid_world.rs:176-178): swap-remove."""
+        self._L.so_remove_boundary(self._h, boundary)
+
+    def set_boundary_particles(self, boundary, positions, velocities=None):
+        pos = _f32(positions, 3)
+        vel = _f32(velocities, 3) if velocities is not None else None
+        self._L.so_set_boundary_particles(self._h, boundary, len(pos), _fp(pos), _fp(vel) if vel is not None else None)
 
     def set_fluid_velocities(self, fluid, velocities):
         v = _f32(velocities, 3)

@@ -1578,6 +1578,17 @@ static void boundary_wrench_t(World<R>& w, int b, const double* com, double* for
     force[0] = F.x; force[1] = F.y; force[2] = F.z; torque[0] = T.x; torque[1] = T.y; torque[2] = T.z;
 }
 
+// host edit of boundary.positions / boundary.velocities (pub fields, boundary.rs:13-15); same particle count
+template <typename R>
+static void set_boundary_particles_t(World<R>& w, int b, uint64_t n, const float* pos, const float* vel) {
+    Boundary<R>& bd = w.boundaries[b];
+    bd.positions.resize(n); bd.velocities.resize(n); bd.volumes.assign(n, (R)0);
+    if (bd.has_forces) bd.forces.resize(n, V3<R>());
+    for (uint64_t i = 0; i < n; ++i) {
+        bd.positions[i] = V3<R>((R)pos[3 * i], (R)pos[3 * i + 1], (R)pos[3 * i + 2]);
+        bd.velocities[i] = vel ? V3<R>((R)vel[3 * i], (R)vel[3 * i + 1], (R)vel[3 * i + 2]) : V3<R>();
+    }
+}
 template <typename R>
 static int add_boundary_t(World<R>& w, uint64_t n, const float* pos, const float* vel, uint32_t mem, uint32_t filt, int wants_forces) {
     Boundary<R> b;
@@ -1706,6 +1717,17 @@ void so_add_particles(void* p, int fluid, uint64_t n, const float* pos, const fl
 void so_delete_particle(void* p, int fluid, uint64_t i) {
     Handle* h = (Handle*)p;
     DISPATCH(h, w.fluids[fluid].delete_particle_at_next_timestep(i), w.fluids[fluid].delete_particle_at_next_timestep(i));
+}
+// LiquidWorld::remove_boundary (liquid_world.rs:176-178): swap-remove; boundaries carry no solver state between steps
+void so_remove_boundary(void* p, int b) {
+    Handle* h = (Handle*)p;
+#define RMB(w) do { if ((size_t)b + 1 != w.boundaries.size()) std::swap(w.boundaries[b], w.boundaries.back()); w.boundaries.pop_back(); } while (0)
+    DISPATCH(h, RMB(w), RMB(w));
+#undef RMB
+}
+void so_set_boundary_particles(void* p, int b, uint64_t n, const float* pos, const float* vel) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, set_boundary_particles_t(w, b, n, pos, vel), set_boundary_particles_t(w, b, n, pos, vel));
 }
 void so_remove_fluid(void* p, int fluid) {
     Handle* h = (Handle*)p;

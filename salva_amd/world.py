@@ -387,7 +387,7 @@ class Fluid:
         k = len(pos)
         vel = _as_vec3(velocities, k) if velocities is not None else np.zeros((k, 3), F32)
         w = self._world
-        if w is not None and not self._resized and not self._dirty and not self._deleted.any() and k:
+        if w is not None and not self._resized and not self._dirty and k:  # (pending deletions stay pending: indices are unchanged)
             L.check(w._L.salva_hip_add_particles(w._h, self._slot, k, _fp(pos), _fp(vel)))
             self._positions = np.concatenate([self._positions, pos])  # stale rows are refreshed by the next _pull()
             self._velocities = np.concatenate([self._velocities, vel])
@@ -402,8 +402,8 @@ class Fluid:
         self._accelerations = np.concatenate([self._accelerations, np.zeros((k, 3), F32)])
         self._volumes = np.concatenate([self._volumes, np.full(k, self.default_particle_volume(), F32)])
         self._deleted = np.concatenate([self._deleted, np.zeros(k, bool)])
-        if dv is not None:  # init_with_fluids resizes velocity_changes with zeros (dfsph_solver.rs:548)
-            self._pending_dv = np.concatenate([dv, np.zeros((k, 3), F32)])
+        if dv is not None:  # init_with_fluids resizes velocity_changes / pressures with zeros (dfsph_solver.rs:548, iisph_solver.rs:499)
+            self._pending_dv = np.concatenate([dv, np.zeros((k, 4), F32)])
         self._resized = True
         self._dirty = L.DIRTY_ALL
 
@@ -573,6 +573,7 @@ class LiquidWorld:
         if handle not in self._fluids._items:
             return None
         handle._pull()
+        self._upload_new_objects()
         slot = handle._slot
         if slot < self._L.salva_hip_num_fluids(self._h):
             L.check(self._L.salva_hip_remove_fluid(self._h, slot))
@@ -587,6 +588,7 @@ class LiquidWorld:
     def remove_boundary(self, handle: Boundary) -> Optional[Boundary]:
         if handle not in self._boundaries._items:
             return None
+        self._upload_new_objects()
         slot = handle._slot
         if slot < self._L.salva_hip_num_boundaries(self._h):
             L.check(self._L.salva_hip_remove_boundary(self._h, slot))
@@ -618,10 +620,15 @@ class LiquidWorld:
         f._device_newer = False
 
     def _fetch_velocity_changes(self, f: Fluid) -> np.ndarray:
-        out = np.zeros((f.num_particles(), 3), F32)
-        if f.num_particles() and f._slot < self._L.salva_hip_num_fluids(self._h) \
-                and self._L.salva_hip_fluid_len(self._h, f._slot) == f.num_particles():
-            L.check(self._L.salva_hip_get_fluid_field(self._h, f._slot, L.FIELD_VELOCITY_CHANGE, _fp(out)))
+        """The solver state that must survive a re-upload of the fluid, n x 4: velocity_changes (dfsph_solver.rs:41) and, in
+        the last column, the pressures IISPH warm-starts from (iisph_solver.rs:35)."""
+        n = f.num_particles()
+        out = np.zeros((n, 4), F32)
+        if n and f._slot < self._L.salva_hip_num_fluids(self._h) and self._L.salva_hip_fluid_len(self._h, f._slot) == n:
+            dv, p = np.zeros((n, 3), F32), np.zeros(n, F32)
+            L.check(self._L.salva_hip_get_fluid_field(self._h, f._slot, L.FIELD_VELOCITY_CHANGE, _fp(dv)))
+            L.check(self._L.salva_hip_get_fluid_field(self._h, f._slot, L.FIELD_PRESSURE, _fp(p)))
+            out[:, :3], out[:, 3] = dv, p
         return out
 
     def _apply_particles_removal(self, f: Fluid):
@@ -648,7 +655,7 @@ class LiquidWorld:
             return
         f._pull()
         dv = f._pending_dv if f._pending_dv is not None else (
-            self._fetch_velocity_changes(f) if not f._resized else np.zeros((f.num_particles(), 3), F32))
+            self._fetch_velocity_changes(f) if not f._resized else np.zeros((f.num_particles(), 4), F32))
         keep = ~f._deleted
         f._positions = np.ascontiguousarray(f._positions[keep])
         f._velocities = np.ascontiguousarray(f._velocities[keep])
@@ -658,8 +665,19 @@ class LiquidWorld:
         f._deleted = np.zeros(len(f._positions), bool)
         f._resized, f._dirty = True, L.DIRTY_ALL
 
-    def _sync_fluid(self, f: Fluid):
-        self._apply_particles_removal(f)
+    def _upload_new_objects(self):
+        """Objects added since the last sync exist only on the host; the swap-removes below must see the same dense sets
+        on both sides (found by tests/test_fuzz_gpu.py).  Pending particle deletions stay pending (fluid.rs:88-98: they are
+        applied at the top of the next step, and the indices the caller holds refer to the uncompacted arrays until then)."""
+        nf = self._L.salva_hip_num_fluids(self._h)
+        for f in self._fluids:
+            if f._slot >= nf:
+                self._sync_fluid(f, apply_removal=False)
+        self._sync_boundaries()
+
+    def _sync_fluid(self, f: Fluid, apply_removal: bool = True):
+        if apply_removal:
+            self._apply_particles_removal(f)
         descs = (L.ForceDesc * max(len(f.nonpressure_forces), 1))()
         for k, force in enumerate(f.nonpressure_forces):
             descs[k] = force._desc()
@@ -669,10 +687,13 @@ class LiquidWorld:
             n = f.num_particles()
             dirty = L.DIRTY_ALL if f._resized else f._dirty
             acc = f._accelerations if (f._acc_set and (dirty & L.DIRTY_ACCELERATIONS)) else None
-            dv = f._pending_dv if f._resized else None
+            state = f._pending_dv if f._resized else None
+            dv = np.ascontiguousarray(state[:, :3]) if state is not None else None
             L.check(self._L.salva_hip_set_fluid(
                 self._h, f._slot, n, _fp(f._positions), _fp(f._velocities), _fp(f._volumes), _fp(acc), _fp(dv),
                 f.density0, f.interaction_groups.memberships, f.interaction_groups.filter, dirty))
+            if state is not None and n and state[:, 3].any():
+                L.check(self._L.salva_hip_set_fluid_field(self._h, f._slot, L.FIELD_PRESSURE, _fp(np.ascontiguousarray(state[:, 3]))))
             f._resized, f._dirty, f._pending_dv, f._acc_set = False, 0, None, False
         L.check(self._L.salva_hip_set_fluid_forces(self._h, f._slot, descs, len(f.nonpressure_forces)))
 
@@ -820,17 +841,14 @@ class LiquidWorld:
             f._volumes = np.ascontiguousarray(st[f"fluid{k}_volumes"], F32).copy()
             f._accelerations = np.zeros((n, 3), F32)
             f._deleted = np.zeros(n, bool)
-            f._pending_dv = np.ascontiguousarray(st[f"fluid{k}_velocity_changes"], F32).copy()
+            f._pending_dv = np.concatenate([np.ascontiguousarray(st[f"fluid{k}_velocity_changes"], F32).reshape(n, 3),
+                                            np.ascontiguousarray(st[f"fluid{k}_pressures"], F32).reshape(n, 1)], axis=1)
             f._resized, f._dirty, f._device_newer, f._maybe_deleted, f._acc_touched = True, L.DIRTY_ALL, False, False, False
         for k, b in enumerate(self._boundaries):
             if not b._sampled:
                 b.positions = st[f"boundary{k}_positions"]
                 b.velocities = st[f"boundary{k}_velocities"]
         self.sync_to_device()
-        for k, f in enumerate(self._fluids):
-            p = np.ascontiguousarray(st[f"fluid{k}_pressures"], F32)
-            if len(p):
-                L.check(self._L.salva_hip_set_fluid_field(self._h, f._slot, L.FIELD_PRESSURE, _fp(p)))
         t = np.asarray(st["timestep"], F32)
         L.check(self._L.salva_hip_set_timestep(self._h, float(t[0]), float(t[1])))
 

@@ -20,7 +20,7 @@ def _block(rng, nx, ny, nz, origin):
     return (p + np.float32(origin)).astype(np.float32)
 
 
-@pytest.mark.parametrize("solver,seed", [("dfsph", 1), ("dfsph", 2), ("iisph", 3)])
+@pytest.mark.parametrize("solver,seed", [("dfsph", 1), ("dfsph", 2), ("iisph", 3), ("dfsph", 4), ("iisph", 5), ("dfsph", 6)])
 def test_random_operation_sequences_match_oracle(solver, seed):
     rng = np.random.default_rng(seed)
     o = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH)
@@ -39,14 +39,15 @@ def test_random_operation_sequences_match_oracle(solver, seed):
         assert k == len(handles) - 1
 
     floor = scenes.plane_lattice(40, 12, 0.0, R, -6 * 2 * R + R, -6 * 2 * R + R, layers=1)
-    w.add_boundary(Boundary(floor))
+    bounds = [w.add_boundary(Boundary(floor))]  # bounds[slot]: the BoundarySet's dense order
     o.add_boundary(floor)
     add_fluid([0.0, 0.25, 0.0], 1000.0)
     add_fluid([0.5, 0.25, 0.0], 800.0)
     nsteps, log = 0, []
     next_x = 1.0
-    for _ in range(40):
-        op = rng.choice(["step", "step", "step", "add_particles", "delete", "remove_fluid", "add_fluid", "set_velocities"])
+    for _ in range(60):
+        op = rng.choice(["step", "step", "step", "add_particles", "delete", "remove_fluid", "add_fluid", "set_velocities",
+                         "add_boundary", "move_boundary", "remove_boundary"])
         log.append(op)
         if op == "step":
             so, sh = o.step(DT, GRAVITY), w.step(DT, GRAVITY)
@@ -86,4 +87,24 @@ def test_random_operation_sequences_match_oracle(solver, seed):
             v[:, 0] += np.float32(0.2)
             handles[k].velocities = v
             o.set_fluid_velocities(k, v)
+        elif op == "add_boundary" and len(bounds) < 3:
+            # a small plate under one of the fluids, between it and the floor
+            k = int(rng.integers(len(handles))) if handles else 0
+            cx = float(handles[k].positions[:, 0].mean()) if handles else 0.0
+            plate = scenes.plane_lattice(6, 6, 0.0, R, cx - 3 * 2 * R + R, -3 * 2 * R + R, layers=1) + np.float32([0.0, 0.08, 0.0])
+            bounds.append(w.add_boundary(Boundary(plate)))
+            o.add_boundary(plate)
+        elif op == "move_boundary" and bounds:
+            k = int(rng.integers(len(bounds)))
+            pos = np.asarray(bounds[k].positions, np.float32) + np.float32([0.004, 0.0, 0.0])
+            vel = np.tile(np.float32([0.004 / DT, 0.0, 0.0]), (len(pos), 1))
+            bounds[k].positions = pos
+            bounds[k].velocities = vel
+            o.set_boundary_particles(k, pos, vel)
+        elif op == "remove_boundary" and len(bounds) >= 2:
+            k = int(rng.integers(1, len(bounds)))  # the floor stays
+            w.remove_boundary(bounds[k])
+            o.remove_boundary(k)
+            bounds[k] = bounds[-1]
+            bounds.pop()
     assert nsteps >= 8, log
