@@ -725,9 +725,11 @@ class LiquidWorld:
                 L.check(self._L.salva_hip_get_boundary(self._h, b._slot, None, _fp(out)))
         return out
 
-    def sync_to_device(self):
+    def sync_to_device(self, apply_removal: bool = True):
+        """Upload what the host changed.  `apply_removal=False` leaves particles marked with
+        delete_particle_at_next_timestep in place (they exist until the next step, fluid.rs:88-98)."""
         for f in self._fluids:
-            self._sync_fluid(f)
+            self._sync_fluid(f, apply_removal)
         self._sync_boundaries()
 
     # ---- liquid_world.rs:62-158
@@ -933,7 +935,7 @@ class LiquidWorld:
     def particles_intersecting_aabb(self, mins, maxs):
         """liquid_world.rs:210-243: list of ("fluid" | "boundary", handle, particle index) whose distance to the box is
         below the particle radius (current positions)."""
-        self.sync_to_device()
+        self.sync_to_device(apply_removal=False)  # a query is not a step: pending deletions stay pending
         lo = (C.c_float * 3)(*[float(x) for x in mins])
         hi = (C.c_float * 3)(*[float(x) for x in maxs])
         u32p = C.POINTER(C.c_uint32)
