@@ -156,6 +156,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        slab.single_node_rccl_env()  # one node by contract: keep RCCL's bootstrap off the (absent) network
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     comm = None

@@ -16,6 +16,17 @@ from . import _lib as L
 F32 = np.float32
 
 
+def single_node_rccl_env():
+    """RCCL's bootstrap probes the network interfaces (and InfiniBand) of the box before it talks to anybody; in a
+    container without a routable interface that probing can stall for minutes (measured: 5.7 s one run, 279 s the next, for
+    the same single-rank communicator).  All ranks of this project live on one node: pin the bootstrap to the loopback
+    interface unless the caller decided otherwise."""
+    import os
+
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
+
 class Comm:
     """A rank's handle on the slab exchange transport (RCCL over xGMI, or the in-process loopback used by tests)."""
 
@@ -24,6 +35,7 @@ class Comm:
 
     @staticmethod
     def unique_id() -> bytes:
+        single_node_rccl_env()
         buf = (C.c_ubyte * 128)()
         L.check(L.lib().salva_hip_comm_rccl_unique_id(buf))
         return bytes(buf)
@@ -31,6 +43,7 @@ class Comm:
     @staticmethod
     def rccl(rank: int, size: int, unique_id: bytes, device: int) -> "Comm":
         assert len(unique_id) == 128
+        single_node_rccl_env()
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         h = C.c_void_p()
         L.check(L.lib().salva_hip_comm_rccl_create(rank, size, buf, device, C.byref(h)))
