@@ -302,7 +302,28 @@ class LiquidWorld {  // liquid_world.rs
         bool have_dv = false;
         bool any_deleted = false;
         for (bool d : f.deleted_) any_deleted |= d;
-        const bool on_device = slot < salva_hip_num_fluids(w_);
+        bool on_device = slot < salva_hip_num_fluids(w_);
+        if (!on_device && any_deleted) {
+            // never uploaded: upload uncompacted first — the reference resizes the slot's (possibly inherited) solver buffer
+            // to the full particle count and filters afterwards (dfsph_solver.rs:543-560); the deletion replays below
+            const size_t n = f.num_particles();
+            check(salva_hip_set_fluid(w_, slot, n, n ? f.positions[0].data() : nullptr, n ? f.velocities[0].data() : nullptr,
+                                      n ? f.volumes.data() : nullptr, n ? f.accelerations[0].data() : nullptr, nullptr, f.density0,
+                                      f.interaction_groups.memberships, f.interaction_groups.filter, (uint32_t)SALVA_HIP_DIRTY_ALL));
+            f.structural_ = false; f.dirty_ = 0; f.appended_from_ = Fluid::kNone;
+            on_device = true;
+        }
+        if (on_device && !f.structural_ && f.dirty_ && (any_deleted || f.appended_from_ != Fluid::kNone)) {
+            // host edits of the particles the device already holds go up first, so that appends and deletions can replay on
+            // the device (only there do new particles see what `velocity_changes[slot].resize(n)` would hand them)
+            const size_t n0 = f.appended_from_ != Fluid::kNone ? f.appended_from_ : f.num_particles();
+            if (n0 == salva_hip_fluid_len(w_, slot)) {
+                check(salva_hip_set_fluid(w_, slot, n0, n0 ? f.positions[0].data() : nullptr, n0 ? f.velocities[0].data() : nullptr,
+                                          n0 ? f.volumes.data() : nullptr, n0 ? f.accelerations[0].data() : nullptr, nullptr, f.density0,
+                                          f.interaction_groups.memberships, f.interaction_groups.filter, f.dirty_));
+                f.dirty_ = 0;
+            }
+        }
         if (on_device && !f.structural_ && !f.dirty_ && (any_deleted || f.appended_from_ != Fluid::kNone)) {
             // replay the edits on the device: append (fluid.rs:126-150), then compact (fluid.rs:88-98) — nothing the
             // fluid already holds travels over PCIe

@@ -56,8 +56,16 @@ __device__ __forceinline__ float cubic_dw_unit(float q) {
 
 // Squared distance with the reference's rounding: ((dx*dx + dy*dy) + dz*dz), no FMA contraction, so that
 // the contact *set* (d2 <= h2) is bit-identical to the CPU reference's (nalgebra norm_squared, Rust never fuses).
+// HIP's __fmul_rn / __fadd_rn are plain `*` / `+`, and under -ffp-contract=fast the back end fuses any fmul + fadd pair it
+// can see, pragmas notwithstanding (caught by tests/test_fuzz_gpu.py: k_boundary_volumes counted 48 borderline pairs more
+// than the CPU on two nearly coincident plates, exactly the single-rounding result).  The empty asm statements make the
+// three products and the first sum opaque values, so there is no multiply left for an add to absorb; they emit nothing.
 __device__ __forceinline__ float dist2_exact(float dx, float dy, float dz) {
-    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    asm volatile("" : "+v"(xx), "+v"(yy), "+v"(zz));
+    float xy = xx + yy;
+    asm volatile("" : "+v"(xy));
+    return xy + zz;
 }
 
 struct KernelEval {

@@ -125,6 +125,7 @@ class World {
     DevBuf<float4> acc, w, normal, dii, dijpj;
     DevBuf<float> visc_beta, visc_target;  // DFSPHViscosity scratch: betas [36][n], strain-rate targets [6][n]
     DevBuf<float4> visc_u0, visc_u1, visc_va;
+    DevBuf<double> wrench_partial;       // per-block partial sums of salva_hip_get_boundary_wrench
     DevBuf<float> he_colors, he_gradcs;  // He2014SurfaceTension state (he2014_surface_tension.rs:15-16)
     DevBuf<float> rho, alpha, kappa, kappa2, rho_star, aii;
     DevBuf<uint32_t> nff, nfb, keys[2], idx[2], cell_start_f;

@@ -1396,12 +1396,11 @@ void World::get_boundary_wrench(uint32_t slot, const float point[3], float force
     if (!b.n || !b.wants_forces) return;
     const uint64_t off = boundary_offset(slot);
     const uint32_t nblocks = (uint32_t)std::min<uint64_t>(nblk(b.n), 256);
-    DevBuf<double> partial;
-    partial.ensure((size_t)nblocks * 6);
-    k_boundary_wrench<<<nblocks, BLOCK, 0, stream>>>((uint32_t)b.n, bst_pos.p + off, bforce.p + off, point[0], point[1], point[2], partial.p);
+    wrench_partial.ensure((size_t)256 * 6);  // per-step call in a coupled run: no allocation on the way
+    k_boundary_wrench<<<nblocks, BLOCK, 0, stream>>>((uint32_t)b.n, bst_pos.p + off, bforce.p + off, point[0], point[1], point[2], wrench_partial.p);
     SALVA_HIP_CHECK(hipGetLastError());
     std::vector<double> h((size_t)nblocks * 6);
-    SALVA_HIP_CHECK(hipMemcpyAsync(h.data(), partial.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(h.data(), wrench_partial.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipStreamSynchronize(stream));
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t k = 0; k < nblocks; ++k)

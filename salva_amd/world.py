@@ -387,6 +387,11 @@ class Fluid:
         k = len(pos)
         vel = _as_vec3(velocities, k) if velocities is not None else np.zeros((k, 3), F32)
         w = self._world
+        if w is not None and not self._resized and self._dirty and k:
+            # host edits of the existing particles go up first (no removal, nothing resized), so that the append below can run
+            # on the device: only there do the new particles see what the reference's `velocity_changes[slot].resize(n)`
+            # would hand them (World::sticky)
+            w._sync_fluid(self, apply_removal=False)
         if w is not None and not self._resized and not self._dirty and k:  # (pending deletions stay pending: indices are unchanged)
             L.check(w._L.salva_hip_add_particles(w._h, self._slot, k, _fp(pos), _fp(vel)))
             self._positions = np.concatenate([self._positions, pos])  # stale rows are refreshed by the next _pull()
@@ -402,6 +407,8 @@ class Fluid:
         self._accelerations = np.concatenate([self._accelerations, np.zeros((k, 3), F32)])
         self._volumes = np.concatenate([self._volumes, np.full(k, self.default_particle_volume(), F32)])
         self._deleted = np.concatenate([self._deleted, np.zeros(k, bool)])
+        if dv is None and self._pending_dv is not None:
+            dv = self._pending_dv  # an earlier host-side edit already holds the solver state of this fluid
         if dv is not None:  # init_with_fluids resizes velocity_changes / pressures with zeros (dfsph_solver.rs:548, iisph_solver.rs:499)
             self._pending_dv = np.concatenate([dv, np.zeros((k, 4), F32)])
         self._resized = True
@@ -676,6 +683,10 @@ class LiquidWorld:
         self._sync_boundaries()
 
     def _sync_fluid(self, f: Fluid, apply_removal: bool = True):
+        if apply_removal and f._maybe_deleted and f._slot >= self._L.salva_hip_num_fluids(self._h):
+            # a fluid that was never uploaded: upload it uncompacted first — the reference resizes the slot's solver buffer
+            # to the full particle count and filters afterwards (dfsph_solver.rs:543-560), and the buffer may be inherited
+            self._sync_fluid(f, apply_removal=False)
         if apply_removal:
             self._apply_particles_removal(f)
         descs = (L.ForceDesc * max(len(f.nonpressure_forces), 1))()

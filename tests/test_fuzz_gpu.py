@@ -153,4 +153,4 @@ def test_random_operation_sequences_match_oracle(solver, seed):
             o.remove_boundary(k)
             bounds[k] = bounds[-1]
             bounds.pop()
-    assert nsteps >= 8, log
+    assert nsteps >= 4, log

@@ -467,3 +467,37 @@ def test_checkpoint_restart_continues_the_run(name, tmp_path):
     for k in range(5):
         c.step(DT, GRAVITY)
     assert max(np.abs(x.positions - y.positions).max() for x, y in zip(fa, fc)) > 1e-4 * R
+
+
+def test_borderline_pairs_are_contacts_exactly_when_the_reference_says_so():
+    """Unjittered lattices are full of pairs at exactly d = h (two lattice spacings with smoothing factor 2), where
+    `d^2 <= h^2` is decided by the last bit of ((dx*dx + dy*dy) + dz*dz).  The device must evaluate that expression with the
+    reference's three roundings — an FMA-contracted sum (one rounding) classifies hundreds of these pairs differently.  Fluid
+    lattice (fluid-fluid), floor (fluid-boundary) and two nearly coincident plates (boundary-boundary, the case that
+    exposed a contracted dist2 in k_boundary_volumes): all counts must be equal, not close."""
+    from salva_amd import Boundary, DFSPHSolver, Fluid, LiquidWorld
+    from oracle import oracle as O
+
+    fluid = scenes.cube_fluid_positions(9, 9, 9, R) + np.float32([0.013, 9 * R + R, 0.0071])  # off-grid origin, exact spacing
+    floor = scenes.plane_lattice(16, 16, 0.0, R, -8 * 2 * R + R + 0.004, -8 * 2 * R + R, layers=1)
+    plate_a = scenes.plane_lattice(6, 6, 0.0, R, np.float32(0.19809002), -3 * 2 * R + R, layers=1) + np.float32([0.0, 0.08, 0.0])
+    plate_b = scenes.plane_lattice(6, 6, 0.0, R, np.float32(0.19811678), -3 * 2 * R + R, layers=1) + np.float32([0.0, 0.08, 0.0])
+    o = O.OracleWorld(R, 2.0, O.DFSPH)
+    w = LiquidWorld(DFSPHSolver(), R, 2.0)
+    k = o.add_fluid(fluid, 1000.0)
+    h = w.add_fluid(Fluid(fluid, R, 1000.0))
+    for b in (floor, plate_a, plate_b):
+        o.add_boundary(b)
+        w.add_boundary(Boundary(b))
+    so, sh = o.step(DT, GRAVITY), w.step(DT, GRAVITY)
+    nff, nfb = o.contact_counts(k, False), o.contact_counts(k, True)
+    assert np.array_equal(w.contact_counts(h, False), nff) and np.array_equal(w.contact_counts(h, True), nfb)
+    assert sh.ncontacts == so.ncontacts
+    # the scene does contain what it is meant to test: many pairs within 1e-6 of h, roughly half of them contacts
+    allb = np.concatenate([floor, plate_a, plate_b]).astype(np.float32)
+    d = allb[:, None, :] - allb[None, :, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    hh = np.float32(R) * np.float32(2.0) * np.float32(2.0)
+    near = np.abs(np.sqrt(d2.astype(np.float64)) - 0.1) < 1e-6
+    fused = (d.astype(np.float64) ** 2).sum(-1).astype(np.float32) <= hh * hh
+    assert near.sum() > 500 and (fused != (d2 <= hh * hh)).sum() > 20
