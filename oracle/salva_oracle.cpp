@@ -20,9 +20,17 @@
 //   src/solver/pressure/dfsph_solver.rs:54-708      DFSPH
 //   src/solver/pressure/iisph_solver.rs:48-711      IISPH
 //   src/solver/viscosity/xsph_viscosity.rs:31-95, artificial_viscosity.rs:29-124
+//   src/solver/viscosity/dfsph_viscosity.rs:38-327                      DFSPHViscosity (with nalgebra's 6x6 LU restated)
 //   src/solver/surface_tension/akinci2013_surface_tension.rs:43-192
+//   src/solver/surface_tension/he2014_surface_tension.rs:40-181, wcsph_surface_tension.rs:32-87
+//   src/solver/nonpressure_force.rs:10-30            user forces: a host callback at its place in the force list
 //   src/timestep_manager.rs:23-94                   (CFL is bypassed upstream: one substep per step)
-//   src/object/{fluid,boundary,interaction_groups}.rs
+//   src/object/{fluid,boundary,interaction_groups}.rs   incl. add_particles / delete_particle_at_next_timestep /
+//                                                   apply_particles_removal (fluid.rs:71-150), solver-side filter_from_mask
+//   src/liquid_world.rs:171-178, object/contiguous_arena.rs:118-135    remove_fluid / remove_boundary (swap-remove; the
+//                                                   solver's per-slot buffers stay positional)
+//   src/integrations/rapier/fluids_pipeline.rs:160-193, 262-287        StaticSampling arm of the rigid-body coupling
+//                                                   (rapier's velocity_at_point / apply_impulse_at_point restated)
 //
 // Third-party arithmetic that is NOT under /root/reference (nalgebra 0.33, semver range only, no lockfile):
 //   dot / norm_squared of a 3-vector = ((x0*y0 + x1*y1) + x2*y2); Unit::try_new_and_get(v, eps) returns
