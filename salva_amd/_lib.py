@@ -12,6 +12,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsalva_hip.so")
+if os.environ.get("SALVA_HIP_LIB_VARIANT"):  # kernel experiments only (tools/variant_probe.py): e.g. "t3" -> libsalva_hip_t3.so
+    LIB_PATH = os.path.join(CSRC, "libsalva_hip_%s.so" % os.environ["SALVA_HIP_LIB_VARIANT"])
 
 OK, E_HIP, E_INVALID, E_NUMERIC, E_CAPACITY = 0, -1, -2, -3, -4
 SOLVER_DFSPH, SOLVER_IISPH = 0, 1
@@ -33,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_particles_intersecting_aabb", "salva_hip_set_boundary_sampling", "salva_hip_update_boundary_pose",
     "salva_hip_get_boundary_particles", "salva_hip_get_boundary_wrench", "salva_hip_set_force_callback",
     "salva_hip_force_get_state", "salva_hip_force_add_accelerations", "salva_hip_set_fluid_field", "salva_hip_get_timestep",
-    "salva_hip_set_timestep",
+    "salva_hip_set_timestep", "salva_hip_time_variant",
 ]
 
 
@@ -151,6 +153,8 @@ def lib():
     L.salva_hip_device_bytes.restype = u64
     L.salva_hip_time_pred_density.argtypes = [vp, i32]
     L.salva_hip_time_pred_density.restype = f32
+    L.salva_hip_time_variant.argtypes = [vp, i32, u32, i32, C.POINTER(u64)]
+    L.salva_hip_time_variant.restype = f32
     ubp = C.POINTER(C.c_ubyte)
     L.salva_hip_comm_rccl_unique_id.argtypes = [ubp]
     L.salva_hip_comm_rccl_create.argtypes = [i32, i32, ubp, i32, C.POINTER(vp)]

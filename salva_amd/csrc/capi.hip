@@ -270,6 +270,16 @@ float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps) {
     return rc == SALVA_HIP_OK ? us : (float)rc;
 }
 
+float salva_hip_time_variant(SalvaHipWorld* world, int32_t variant, uint32_t param, int32_t reps, uint64_t* checksum) {
+    float us = -1.0f;
+    int rc = guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        us = world->w->time_variant(variant, param, reps, checksum);
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? us : (float)rc;
+}
+
 // ---- multi-GPU (x-slab decomposition) -------------------------------------------------------------------------
 struct SalvaHipComm {
     std::shared_ptr<salva::LoopbackShared> group;  // loopback only

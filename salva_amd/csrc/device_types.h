@@ -99,6 +99,8 @@ struct StepCtx {
     const uint32_t* tile_ids;   // [nlaunch] dense tile index of slot k
     const uint4* slot_desc;     // [nlaunch] {dense tile index, first own particle, one past the last, -}: everything
                                 //           Tile::setup needs besides tile_off, in one load that depends on nothing
+    const uint4* slot_info;     // [nlaunch] {first own particle, one past the last, first slice, S | SB << 16}: all a solver
+                                //           kernel needs to know about a tile's sizes, written by k_tile_halo_fill
     const uint32_t* tile_rank;  // [ntiles+1] exclusive prefix of the non-empty flags: slot of a dense tile; [ntiles] = nlaunch
     uint32_t nlaunch;           // number of slots (known to the host after the per-step read-back; 0 before)
     TileGrid gf;

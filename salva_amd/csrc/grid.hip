@@ -367,9 +367,10 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc
     if (threadIdx.x == 0) tile_cnt[t.slot] = a;
 }
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uint32_t* __restrict__ halo_src,
-                                                                 uint32_t* __restrict__ bhalo_src) {
+                                                                 uint32_t* __restrict__ bhalo_src, uint4* __restrict__ slot_info) {
     Tile t;
     t.setup(c);
+    if (threadIdx.x == 0) slot_info[t.slot] = make_uint4(t.own_begin, t.own_end, t.slice_base, t.S | (t.SB << 16));
     TileCells tc;
     tc.build(c, t);
     const int sub = threadIdx.x % 16, grp = threadIdx.x / 16;
@@ -386,8 +387,8 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uin
 void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, uint4* slot_desc, hipStream_t s) {
     if (nslots_bound) k_tile_count<<<nslots_bound, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, tile_cnt, slot_desc);
 }
-void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, hipStream_t s) {
-    if (c.nlaunch) k_tile_halo_fill<<<c.nlaunch, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, halo_src, bhalo_src);
+void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, uint4* slot_info, hipStream_t s) {
+    if (c.nlaunch) k_tile_halo_fill<<<c.nlaunch, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, halo_src, bhalo_src, slot_info);
 }
 size_t scan_tiles_temp_bytes(uint32_t n) {
     size_t b = 0;

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "device_types.h"
 #include "tile.h"
+#include "pipe.h"
 
 namespace salva {
 
@@ -43,7 +44,7 @@ void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4
 void launch_tile_slots(const uint32_t* cell_start, uint32_t ntiles, uint32_t* flags, uint32_t* rank, uint32_t* tile_ids, void* temp,
                        size_t temp_bytes, hipStream_t s);
 void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, uint4* slot_desc, hipStream_t s);
-void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, hipStream_t s);
+void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, uint4* slot_info, hipStream_t s);
 size_t scan_tiles_temp_bytes(uint32_t n);
 void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s);
 // neighbour lists (per-slice ELL blocks of 16-bit halo slots, capacity c.cap_ff / c.cap_fb dwords per particle), built
@@ -84,6 +85,13 @@ void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmo
 // multi-GPU form: per-fluid sums of this rank -> sums[nmodels]; (all-reduce over ranks); break test on the global sums
 void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmodels, const SolveCtl* ctl, float* sums, hipStream_t s);
 void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, hipStream_t s);
+
+// ---------------------------------------------------------------- dfsph_pipe.hip (persistent tile pipeline, pipe.h)
+void launch_pred_density_pipe(const StepCtx& c, const PipeCfg& P, float dt, hipStream_t s);
+// diagnostics: variant 0 = one tile per workgroup, 1 = + de-phased co-resident tiles (param = sleep in 64-cycle units),
+// 2 = pipeline, 3 = one tile per workgroup with LDS-DMA staging
+void launch_pred_density_variant(const StepCtx& c, const TileLds& L, const PipeCfg& P, float dt, int variant, uint32_t param,
+                                 uint32_t* cu_arrivals, hipStream_t s);
 
 // ---------------------------------------------------------------- forces.hip
 void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff, float inv_dt_prev, hipStream_t s);

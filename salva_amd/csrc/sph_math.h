@@ -121,6 +121,27 @@ __device__ __forceinline__ f2 kernel_grad2(f2 r2, const SphConsts& c) {
     return u * rinv;
 }
 
+// Two packed pairs at once, stage by stage (the two chains are independent: written interleaved so that the scheduler keeps
+// them interleaved and one chain's latencies are covered by the other's issue slots).
+__device__ __forceinline__ void kernel_grad2x2(f2 r2a, f2 r2b, const SphConsts& c, f2& ga, f2& gb) {
+    const float t2 = c.tiny_r2;
+    f2 ra, rb;
+    ra.x = (r2a.x > t2) ? __builtin_amdgcn_rsqf(r2a.x) : 0.0f;
+    rb.x = (r2b.x > t2) ? __builtin_amdgcn_rsqf(r2b.x) : 0.0f;
+    ra.y = (r2a.y > t2) ? __builtin_amdgcn_rsqf(r2a.y) : 0.0f;
+    rb.y = (r2b.y > t2) ? __builtin_amdgcn_rsqf(r2b.y) : 0.0f;
+    const f2 qa = r2a * ra * c.inv_h, qb = r2b * rb * c.inv_h;
+    const f2 aa = (qa * c.g18 - c.g12) * qa, ab = (qb * c.g18 - c.g12) * qb;
+    f2 oa = c.sg6 - qa * c.sg6, ob = c.sg6 - qb * c.sg6;
+    oa.x = fmaxf(oa.x, 0.0f); ob.x = fmaxf(ob.x, 0.0f);
+    oa.y = fmaxf(oa.y, 0.0f); ob.y = fmaxf(ob.y, 0.0f);
+    const f2 ba = -oa * oa, bb = -ob * ob;
+    f2 ua, ub;
+    ua.x = (qa.x <= 0.5f) ? aa.x : ba.x; ub.x = (qb.x <= 0.5f) ? ab.x : bb.x;
+    ua.y = (qa.y <= 0.5f) ? aa.y : ba.y; ub.y = (qb.y <= 0.5f) ? ab.y : bb.y;
+    ga = ua * ra; gb = ub * rb;
+}
+
 // Weight only.
 __device__ __forceinline__ float kernel_weight(float r2, const SphConsts& c) {
     const float r = __builtin_amdgcn_sqrtf(r2);

@@ -19,7 +19,10 @@
 
 namespace salva {
 
-constexpr int TX = 4, TY = 4, TZ = 4;                  // cells per tile
+#ifndef SALVA_TX
+#define SALVA_TX 4
+#endif
+constexpr int TX = SALVA_TX, TY = 4, TZ = 4;           // cells per tile
 constexpr int TCELLS = TX * TY * TZ;                   // 64
 constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;   // halo box
 constexpr int HCELLS = HX * HY * HZ;                   // 216
@@ -415,12 +418,74 @@ __device__ __forceinline__ ListRegs list_regs(const StepCtx& c, uint32_t gslice)
     return r;
 }
 // `nq` = dwords of the longest list in the slice (slice_list_dwords below): wave-uniform, so every branch here is scalar.
-template <typename L, typename C2>
+// AHEAD: the tail beyond the registers is fetched one dword ahead (right for the one-tile kernels).  The pipeline kernels
+// pass false: a load still pending at the end of the (rare) tail would make hipcc place a conservative vmcnt(0) on the
+// common path too, which there sits behind the next tile's DMA and drains it.
+// Four-contact form: compute4(A, B, C, D) handles the two packed pairs of a full step at once, so that the body can
+// interleave the two (independent) dependency chains stage by stage in source order; compute2 takes the odd last dword.
+template <bool AHEAD = true, typename L, typename C4, typename C2>
+__device__ __forceinline__ void for_each_ff4(const StepCtx& c, uint32_t gslice, uint32_t nq, const ListRegs& lr, L&& load,
+                                             C4&& compute4, C2&& compute2) {
+#pragma unroll
+    for (int k = 0; k < LIST_REGS; k += 2) {
+        if ((uint32_t)(k + 1) < nq) {
+            const uint32_t a = lr.d[k], b = lr.d[k + 1];
+            const auto d0 = load(a & 0xffffu);
+            const auto d1 = load(a >> 16);
+            const auto d2 = load(b & 0xffffu);
+            const auto d3 = load(b >> 16);
+            compute4(d0, d1, d2, d3);
+        } else if ((uint32_t)k < nq) {
+            const uint32_t a = lr.d[k];
+            const auto d0 = load(a & 0xffffu);
+            const auto d1 = load(a >> 16);
+            compute2(d0, d1);
+        }
+    }
+    if (nq > (uint32_t)LIST_REGS) {
+        const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
+        if (AHEAD) {
+            uint32_t nx = p[(size_t)LIST_REGS * WAVE];
+            for (uint32_t q = LIST_REGS; q < nq; ++q) {
+                const uint32_t a = nx;
+                if (q + 1 < nq) nx = p[(size_t)(q + 1) * WAVE];
+                const auto d0 = load(a & 0xffffu);
+                const auto d1 = load(a >> 16);
+                compute2(d0, d1);
+            }
+        } else {
+            for (uint32_t q = LIST_REGS; q < nq; ++q) {
+                const uint32_t a = p[(size_t)q * WAVE];
+                const auto d0 = load(a & 0xffffu);
+                const auto d1 = load(a >> 16);
+                compute2(d0, d1);
+            }
+        }
+    }
+}
+// FUSED: a step over two list dwords (four contacts) is ONE basic block — the two packed chains are independent, and only
+// inside one block can the scheduler interleave them (each chain alone is ~20 dependent packed operations deep).
+template <bool AHEAD = true, bool FUSED = false, typename L, typename C2>
 __device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, uint32_t nq, const ListRegs& lr, L&& load,
                                              C2&& compute2) {
 #pragma unroll
     for (int k = 0; k < LIST_REGS; k += 2) {
-        if ((uint32_t)k < nq) {
+        if (FUSED) {
+            if ((uint32_t)(k + 1) < nq) {
+                const uint32_t a = lr.d[k], b = lr.d[k + 1];
+                const auto d0 = load(a & 0xffffu);
+                const auto d1 = load(a >> 16);
+                const auto d2 = load(b & 0xffffu);
+                const auto d3 = load(b >> 16);
+                compute2(d0, d1);
+                compute2(d2, d3);
+            } else if ((uint32_t)k < nq) {
+                const uint32_t a = lr.d[k];
+                const auto d0 = load(a & 0xffffu);
+                const auto d1 = load(a >> 16);
+                compute2(d0, d1);
+            }
+        } else if ((uint32_t)k < nq) {
             const uint32_t a = lr.d[k];
             const bool two = (uint32_t)(k + 1) < nq;
             const uint32_t b = two ? lr.d[k + 1] : a;
@@ -434,13 +499,56 @@ __device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, 
     }
     if (nq > (uint32_t)LIST_REGS) {  // unusually long lists: the rest comes from memory, one dword ahead
         const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
-        uint32_t nx = p[(size_t)LIST_REGS * WAVE];
-        for (uint32_t q = LIST_REGS; q < nq; ++q) {
-            const uint32_t a = nx;
-            if (q + 1 < nq) nx = p[(size_t)(q + 1) * WAVE];
-            const auto d0 = load(a & 0xffffu);
-            const auto d1 = load(a >> 16);
-            compute2(d0, d1);
+        if (AHEAD) {
+            uint32_t nx = p[(size_t)LIST_REGS * WAVE];
+            for (uint32_t q = LIST_REGS; q < nq; ++q) {
+                const uint32_t a = nx;
+                if (q + 1 < nq) nx = p[(size_t)(q + 1) * WAVE];
+                const auto d0 = load(a & 0xffffu);
+                const auto d1 = load(a >> 16);
+                compute2(d0, d1);
+            }
+        } else {
+            for (uint32_t q = LIST_REGS; q < nq; ++q) {
+                const uint32_t a = p[(size_t)q * WAVE];
+                const auto d0 = load(a & 0xffffu);
+                const auto d1 = load(a >> 16);
+                compute2(d0, d1);
+            }
+        }
+    }
+}
+// The first FB_REGS dwords of a particle's fluid-boundary list, loadable before the staging barrier like ListRegs (every
+// ELL row has cap_fb >= FB_REGS dwords).  Without boundaries nbr_fb is a dummy: the loads then go to the fluid list.
+constexpr int FB_REGS = 6;
+struct FbRegs { uint32_t d[FB_REGS]; };
+__device__ __forceinline__ FbRegs fb_regs(const StepCtx& c, uint32_t gslice) {
+    const uint32_t* __restrict__ p = (c.nb ? c.nbr_fb + (size_t)gslice * c.cap_fb * WAVE : c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE) +
+                                     (threadIdx.x & (WAVE - 1));
+    FbRegs r;
+#pragma unroll
+    for (int k = 0; k < FB_REGS; ++k) r.d[k] = p[(size_t)k * WAVE];
+    return r;
+}
+// f(slot) over the fluid-boundary contacts of a particle whose list head is held in registers
+template <typename F>
+__device__ __forceinline__ void for_each_fb_regs(const StepCtx& c, uint32_t SB, uint32_t gslice, uint32_t cnt, const FbRegs& fr, F&& f) {
+    if (SB == 0 || cnt == 0) return;
+    const uint32_t nq = (cnt + 1) >> 1;
+#pragma unroll
+    for (int k = 0; k < FB_REGS; ++k) {
+        if ((uint32_t)k < nq) {
+            const uint32_t a = fr.d[k];
+            f(a & 0xffffu);
+            if (2u * (uint32_t)k + 1u < cnt) f(a >> 16);
+        }
+    }
+    if (nq > (uint32_t)FB_REGS) {
+        const uint32_t* __restrict__ p = c.nbr_fb + (size_t)gslice * c.cap_fb * WAVE + (threadIdx.x & (WAVE - 1));
+        for (uint32_t q = FB_REGS; q < nq; ++q) {
+            const uint32_t a = p[(size_t)q * WAVE];
+            f(a & 0xffffu);
+            if (2u * q + 1u < cnt) f(a >> 16);
         }
     }
 }

@@ -78,6 +78,8 @@ class World {
     uint64_t get_owned(uint32_t cap, uint32_t* gids, float* pos, float* vel, uint32_t* models);
     uint32_t owned_count() const { return comm ? n_owned : n; }
     float time_pred_density(int reps);
+    // diagnostics (salva_hip_time_variant): time variant `variant` of k_pred_density; *checksum = FNV-1a of the kappa it wrote
+    float time_variant(int variant, uint32_t param, int reps, uint64_t* checksum);
 
     SalvaHipParams prm;
     SphConsts sc;
@@ -130,7 +132,7 @@ class World {
     DevBuf<float> rho, alpha, kappa, kappa2, rho_star, aii;
     DevBuf<uint32_t> nff, nfb, keys[2], idx[2], cell_start_f;
     DevBuf<TileAcc> tile_cnt, tile_off;
-    DevBuf<uint4> slot_desc;
+    DevBuf<uint4> slot_desc, slot_info;
     DevBuf<uint32_t> d_maxhalo, halo_src, bhalo_src, tile_ids, tile_flags, tile_rank;
     uint32_t nlaunch = 0;  // non-empty tiles of the current step = grid size of the solver kernels
     uint32_t last_iters[NUM_SOLVES] = {1u, 1u, 1u};  // iterations of the previous step's divergence / pressure solve (batch sizing)
@@ -140,6 +142,8 @@ class World {
     DevBuf<uint32_t> nbr_ff, nbr_fb;
     DevBuf<int32_t> bbox_partials;
     TileLds lds;
+    PipeCfg pipe;          // launch shape of the persistent pipeline kernels of this step (pipe.h)
+    int num_cus = 256;
     DevBuf<char> cub_temp;
     DevBuf<float> scratch_f;   // staging for AoS up/downloads and field unsorts
     DevBuf<float4> scratch_f4;

@@ -113,6 +113,10 @@ World::World(const SalvaHipParams& p) : prm(p) {
     const float h = p.particle_radius * p.smoothing_factor * 2.0f;
     sc = make_sph_consts(h);
     SALVA_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device) == hipSuccess && cus > 0) num_cus = cus;
+    }
     SALVA_HIP_CHECK(hipHostMalloc((void**)&h_rb, sizeof(Readback), hipHostMallocDefault));
     memset(h_rb, 0, sizeof(Readback));
     SALVA_HIP_CHECK(hipHostMalloc((void**)&h_ctl, 2 * NUM_SOLVES * sizeof(SolveCtl), hipHostMallocDefault));
@@ -583,7 +587,7 @@ StepCtx World::make_ctx() {
     c.tile_off = tile_off.p; c.halo_src = halo_src.p; c.bhalo_src = bhalo_src.p;
     c.halo_stride = halo_stride; c.bhalo_stride = bhalo_stride;
     c.ntiles = (uint32_t)gf.ntiles();
-    c.tile_ids = tile_ids.p; c.tile_rank = tile_rank.p; c.nlaunch = nlaunch; c.slot_desc = slot_desc.p;
+    c.tile_ids = tile_ids.p; c.tile_rank = tile_rank.p; c.nlaunch = nlaunch; c.slot_desc = slot_desc.p; c.slot_info = slot_info.p;
     c.gf = TileGrid{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], cell_start_f.p};
     c.nb = nb;
     c.bposv = bposv.p; c.bvel = bvel.p; c.bperm = bperm.p;
@@ -897,6 +901,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     tile_rank.ensure((size_t)ntiles + 1, stream, false, 1.5f);
     tile_ids.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
     slot_desc.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
+    slot_info.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
     tile_cnt.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
     tile_off.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
     d_maxhalo.ensure(4);
@@ -956,12 +961,23 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             halo_stride = use ? (uint32_t)st_f : 0u;
             bhalo_stride = use ? (uint32_t)st_b : 0u;
         }
+        // persistent pipeline kernels (pipe.h): one wave per slice of the fullest tile, at most PIPE_MAX_WAVES
+        {
+            pipe.enabled = halo_stride > 0 && !getenv("SALVA_HIP_NO_PIPELINE");
+            pipe.scap = halo_stride;
+            pipe.sbcap = bhalo_stride;
+            pipe.num_cus = (uint32_t)num_cus;
+            pipe.nlaunch = nlaunch;
+            uint32_t waves = std::min<uint32_t>(std::max<uint32_t>(h_rb->tile_total.max_nsl, 4u), (uint32_t)PIPE_MAX_WAVES);
+            if (const char* e = getenv("SALVA_HIP_PIPE_WAVES")) waves = std::min<uint32_t>(std::max(atoi(e), 1), PIPE_MAX_WAVES);
+            pipe.threads = waves * WAVE;
+        }
         const size_t need_f = halo_stride ? (size_t)nlaunch * halo_stride : (size_t)h_rb->tile_total.s;
         const size_t need_b = halo_stride ? (size_t)nlaunch * bhalo_stride : (size_t)h_rb->tile_total.sb;
         halo_src.ensure(need_f ? need_f : 1, stream, false, 1.2f);
         bhalo_src.ensure(need_b ? need_b : 1, stream, false, 1.2f);
         c = make_ctx();
-        launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, stream);
+        launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, slot_info.p, stream);
 
         // ---- neighbour lists   (compute_contacts, contacts.rs:154-252): one pass into fixed-capacity ELL rows; if a list
         // turns out longer than the capacity the pass is repeated with room to spare (rare: the capacity follows the
@@ -1468,6 +1484,73 @@ float World::time_pred_density(int reps) {
     launch_pred_density(last_ctx, lds, last_dt, stream);  // warm-up
     SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
     for (int r = 0; r < reps; ++r) launch_pred_density(last_ctx, lds, last_dt, stream);
+    SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    float ms = 0.0f;
+    SALVA_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    return ms * 1000.0f / (float)reps;
+}
+
+
+// Diagnostics: one variant of k_pred_density on the last step's state; the checksum of the kappa it wrote lets the
+// caller verify that all variants compute the same bits.
+float World::time_variant(int variant, uint32_t param, int reps, uint64_t* checksum) {
+    use_device();
+    if (!have_last_ctx || !sorted_valid || n == 0) throw HipError(SALVA_HIP_E_INVALID, "no completed step to time");
+    if (reps < 1) reps = 1;
+    if (variant == 2 && !pipe.fits(2, 0, 2, true)) throw HipError(SALVA_HIP_E_CAPACITY, "the pipeline does not fit the LDS for this scene");
+    if (const char* e = getenv("SALVA_HIP_PIPE_WAVES")) pipe.threads = (uint32_t)std::min<int>(std::max(atoi(e), 1), PIPE_MAX_WAVES) * WAVE;
+    DevBuf<uint32_t> arrivals;
+    arrivals.ensure(4096);
+    SALVA_HIP_CHECK(hipMemsetAsync(kappa.p, 0xff, (size_t)n * sizeof(float), stream));
+    SALVA_HIP_CHECK(hipMemsetAsync(partials.p, 0xff, (size_t)last_ctx.nlaunch * last_ctx.nmodels * sizeof(float), stream));
+    if (getenv("SALVA_HIP_TILE_TIMING") && (variant == 2 || variant == 4)) {
+        // per-wave phase stamps of every tile: where a tile's time goes in the persistent kernels
+        DevBuf<unsigned long long> dbg;
+        const size_t nrec = (size_t)std::max<uint32_t>(last_ctx.nlaunch, 1u) * PIPE_MAX_WAVES;
+        dbg.ensure(nrec * 8);
+        SALVA_HIP_CHECK(hipMemsetAsync(dbg.p, 0, nrec * 8 * sizeof(unsigned long long), stream));
+        StepCtx cd = last_ctx;
+        cd.dbg = dbg.p;
+        launch_pred_density_variant(cd, lds, pipe, last_dt, variant, param, arrivals.p, stream);
+        std::vector<unsigned long long> h(nrec * 8);
+        SALVA_HIP_CHECK(hipMemcpyAsync(h.data(), dbg.p, nrec * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        double ph[5] = {0, 0, 0, 0, 0}, ph_max[5] = {0, 0, 0, 0, 0}; size_t cnt = 0; unsigned long long tmin = ~0ull, tmax = 0;
+        for (size_t r = 0; r < nrec; ++r) {
+            const unsigned long long* d = &h[r * 8];
+            if (d[5] == 0) continue;
+            for (int q = 0; q < 5; ++q) { const double v = (double)(d[q + 1] - d[q]); ph[q] += v; ph_max[q] = std::max(ph_max[q], v); }
+            tmin = std::min(tmin, d[0]); tmax = std::max(tmax, d[5]);
+            ++cnt;
+        }
+        if (cnt) {
+            if (variant == 4)
+                fprintf(stderr, "[variant 4 timing] %zu wave-tiles: top wait+barrier A %.0f | issue %.0f | vm wait %.0f | barrier B %.0f | compute %.0f cycles (avg per wave); kernel span %.0f\n",
+                        cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, (double)(tmax - tmin));
+            else
+                fprintf(stderr, "[variant 2 timing] %zu wave-tiles: top vm wait %.0f | barrier %.0f | issue+prefetch %.0f | - | compute %.0f cycles (avg per wave); kernel span %.0f\n",
+                        cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[4] / cnt, (double)(tmax - tmin));
+        }
+    }
+    launch_pred_density_variant(last_ctx, lds, pipe, last_dt, variant, param, arrivals.p, stream);  // warm-up + checksum run
+    std::vector<uint32_t> hk((size_t)n + (size_t)last_ctx.nlaunch * last_ctx.nmodels);
+    SALVA_HIP_CHECK(hipMemcpyAsync(hk.data(), kappa.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(hk.data() + n, partials.p, (size_t)last_ctx.nlaunch * last_ctx.nmodels * sizeof(float), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    if (checksum) {
+        uint64_t hsh = 1469598103934665603ull;
+        // kappa only: the per-tile error partials depend (in their last bits) on how slices map to waves
+        for (size_t q = 0; q < (size_t)n; ++q) { hsh ^= hk[q]; hsh *= 1099511628211ull; }
+        *checksum = hsh;
+        if (getenv("SALVA_HIP_VARIANT_VERBOSE")) {
+            double tot = 0.0;
+            for (size_t q = n; q < hk.size(); ++q) { float f; memcpy(&f, &hk[q], 4); tot += f; }
+            fprintf(stderr, "[variant %d] sum of error partials %.9g\n", variant, tot);
+        }
+    }
+    SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
+    for (int r = 0; r < reps; ++r) launch_pred_density_variant(last_ctx, lds, pipe, last_dt, variant, param, arrivals.p, stream);
     SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
     SALVA_HIP_CHECK(hipStreamSynchronize(stream));
     float ms = 0.0f;

@@ -969,6 +969,14 @@ class LiquidWorld:
     def device_bytes(self) -> int:
         return int(self._L.salva_hip_device_bytes(self._h))
 
+    def time_variant(self, variant: int, param: int = 0, reps: int = 20):
+        """Diagnostics: (microseconds per launch, checksum of the outputs) of execution variant `variant` of k_pred_density."""
+        cs = C.c_uint64(0)
+        us = float(self._L.salva_hip_time_variant(self._h, variant, param, reps, C.byref(cs)))
+        if us < 0:
+            L.check(int(us))
+        return us, int(cs.value)
+
     def time_pred_density(self, reps: int = 20) -> float:
         """Average k_pred_density launch duration in microseconds (HIP events on the world's stream)."""
         us = float(self._L.salva_hip_time_pred_density(self._h, reps))
