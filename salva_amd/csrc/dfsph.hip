@@ -32,8 +32,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    struct Own { float4 pi; uint32_t mi, cnt; ListHead lh; };
-    auto load_own = [&](uint32_t i, uint32_t gs) { return Own{c.posm[i], c.model[i], c.nff[i], list_head(c, gs)}; };
+    struct Own { float4 pi; uint32_t mi; ListOwn lo; };
+    auto load_own = [&](uint32_t i, uint32_t gs) { return Own{c.posm[i], c.model[i], list_own(c, i, gs)}; };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
     const Own own0 = load_own(i0, gs0);
@@ -41,13 +41,13 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
     t.stage(c, static_cast<const float4*>(c.posm), Lp);
     const float4* Bp = nullptr;
     t.stage_boundary(c, Bp);
-    __syncthreads();
+    Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
         const float4 pi = o.pi;
         const float rho0 = rho0_of(c, o.mi);
         float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f;
-        for_each_ff(c, gs, o.cnt, o.lh, [&](uint32_t s) { return Lp[s]; }, [&](const float4& pj) {
+        for_each_ff_regs(c, gs, o.lo, [&](uint32_t s) { return Lp[s]; }, [&](const float4& pj) {
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
             rho += pj.w * e.w;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     t.stage_boundary(c, Bp);
     TileErr E;
     E.init(errtab, c);
-    __syncthreads();
+    Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
         float err = 0.0f;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
     t.stage_boundary(c, Bp, Bv);
-    __syncthreads();
+    Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
         if (!active) return;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
     TileErr E;
     E.init(errtab, c);
     const unsigned long long T2 = __builtin_readcyclecounter();
-    __syncthreads();
+    Tile::staged_barrier();
     const unsigned long long T3 = __builtin_readcyclecounter();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
     t.stage_boundary(c, Bp, Bv);
-    __syncthreads();
+    Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
         if (!active) return;

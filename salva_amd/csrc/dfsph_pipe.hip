@@ -125,7 +125,8 @@ void k_pred_density_x(StepCtx c, float dt, uint32_t* cu_arrivals, uint32_t sleep
         }
     }
     Tile t;
-    t.setup(c);
+    if (VAR == 8) t.setup_at(c, cu_arrivals[blockIdx.x]);  // cu_arrivals = dispatch order (heaviest tiles first)
+    else t.setup(c);
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
     struct Own { float4 pi, wi; float rho, alpha; uint32_t mi, cnt; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
@@ -241,6 +242,7 @@ void launch_pred_density_variant(const StepCtx& c, const TileLds& L, const PipeC
         case 4: launch_pred_density_loop(c, P, dt, s); break;
         case 3: SALVA_LAUNCH_TILE(k_pred_density_x<3>, c, L, L.bytes(32, 32, 4) + 4096u, s, c, dt, cu_arrivals, param); break;
         case 5: SALVA_LAUNCH_TILE(k_pred_density_x<5>, c, L, L.bytes(32, 32, 4) + 4096u, s, c, dt, cu_arrivals, param); break;
+        case 8: SALVA_LAUNCH_TILE(k_pred_density_x<8>, c, L, L.bytes(32, 32, 4) + 4096u, s, c, dt, cu_arrivals, param); break;
         case 7: SALVA_LAUNCH_TILE(k_pred_density_x<7>, c, L, L.bytes(32, 32, 4) + 4096u, s, c, dt, cu_arrivals, param); break;
         case 6: SALVA_LAUNCH_TILE(k_pred_density_x<6>, c, L, L.bytes(32, 32, 4) + 4096u, s, c, dt, cu_arrivals, param); break;
         default: launch_pred_density(c, L, dt, s); break;

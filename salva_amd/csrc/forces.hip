@@ -20,6 +20,12 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    // own record and list head: in registers before the staging barrier
+    struct Own { float4 pi, vi; float ri; uint32_t cnt; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) { return Own{c.posm[i], c.w[i], c.rho[i], c.nff[i], list_regs(c, gs)}; };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
     const float4* Lp = nullptr;
     const float4* Lw = nullptr;
     const float* Lr = nullptr;
@@ -27,26 +33,29 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
     t.stage_boundary(c, Bp, Bv);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
-        if (!active || c.model[i] != model) return;
-        const float4 pi = c.posm[i];
-        const float4 vi = c.w[i];
+    Tile::staged_barrier();
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);  // (wave-uniform: before any lane drops out)
+        const float4 pi = o.pi;
+        const float4 vi = o.vi;
+        if (!active || __float_as_uint(vi.w) != model) return;
         const float rho0 = c.rho0_tab[model];
         float fx = 0.f, fy = 0.f, fz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
         if (fc != 0.0f) {
+            // wave-uniform trip count over the padded list: a padding entry is the particle itself, v_j - v_i = 0 exactly
             struct Rec { float4 p, w; float r; };
-            for_each_ff(c, i, gs, [&](uint32_t s) { return Rec{Lp[s], Lw[s], Lr[s]}; }, [&](const Rec& rc) {
+            auto one = [&](const Rec& rc) {
                 const float4 pj = rc.p, vj = rc.w;
                 const float rj = rc.r;
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
                 const float sc = (__float_as_uint(vj.w) == model) ? fc * wgt * pj.w / rj : 0.0f;
                 fx += (vj.x - vi.x) * sc; fy += (vj.y - vi.y) * sc; fz += (vj.z - vi.z) * sc;
-            });
+            };
+            for_each_ff2(c, gs, nqu, o.lh, [&](uint32_t s) { return Rec{Lp[s], Lw[s], Lr[s]}; }, [&](const Rec& A, const Rec& B) { one(A); one(B); });
         }
         if (bc != 0.0f) {
-            const float ri = c.rho[i];
+            const float ri = o.ri;
             for_each_fb(c, t, i, gs, [&](uint32_t s) {
                 const float4 pj = Bp[s];
                 const float4 vj = Bv[s];
@@ -81,6 +90,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_artificial_viscosity(StepC
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float4* Lw = nullptr;
     const float* Lr = nullptr;
@@ -88,8 +100,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_artificial_viscosity(StepC
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
     t.stage_boundary(c, Bp, Bv);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         const float4 vi = c.w[i];
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_artificial_viscosity(StepC
         const float eta2 = h * h * 0.01f;
         float fx = 0.f, fy = 0.f, fz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
         if (fc != 0.0f) {
-            for_each_ff(c, i, gs, [&](uint32_t s) {
+            for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
                 const float4 pj = Lp[s];
                 const float4 vj = Lw[s];
                 const float rj = Lr[s];
@@ -149,17 +161,20 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_normals(StepCtx c, 
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float* Lr = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), Lp, Lr);
     const uint32_t* Lm = nullptr;
     if (c.nmodels > 1) t.stage(c, static_cast<const uint32_t*>(c.model), Lm);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         float nx = 0.f, ny = 0.f, nz = 0.f;
-        for_each_ff(c, i, gs, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
             const float4 pj = Lp[s];
             const float rj = Lr[s];
             const bool same = Lm ? (Lm[s] == model) : true;
@@ -197,6 +212,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, u
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float4* Ln = nullptr;
     const float* Lr = nullptr;
@@ -206,8 +224,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, u
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
     t.stage_boundary(c, Bp, Bv);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         const float ri = c.rho[i];
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, u
         float4 a = c.acc[i];
         if (tc != 0.0f) {
             const float4 ni = c.normal[i];
-            for_each_ff(c, i, gs, [&](uint32_t s) {
+            for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
                 const float4 pj = Lp[s];
                 const float4 nj = Ln[s];
                 const float rj = Lr[s];
@@ -271,6 +289,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_colors(StepCtx c, u
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float* Lr = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), Lp, Lr);
@@ -278,12 +299,12 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_colors(StepCtx c, u
     if (c.nmodels > 1) t.stage(c, static_cast<const uint32_t*>(c.model), Lm);
     const float4* Bp = nullptr;
     t.stage_boundary(c, Bp);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         float color = 0.0f;
-        for_each_ff(c, i, gs, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
             const float4 pj = Lp[s];
             const float rj = Lr[s];
             const bool same = Lm ? (Lm[s] == model) : true;
@@ -305,18 +326,21 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_gradc(StepCtx c, ui
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float* Lr = nullptr;
     const float* Lc = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), colors, Lp, Lr, Lc);
     const uint32_t* Lm = nullptr;
     if (c.nmodels > 1) t.stage(c, static_cast<const uint32_t*>(c.model), Lm);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         float gx = 0.f, gy = 0.f, gz = 0.f;
-        for_each_ff(c, i, gs, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
             const float4 pj = Lp[s];
             const float rj = Lr[s], cj = Lc[s];
             const bool same = Lm ? (Lm[s] == model) : true;
@@ -337,6 +361,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_forces(StepCtx c, u
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float* Lr = nullptr;
     const float* Lg = nullptr;
@@ -346,8 +373,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_forces(StepCtx c, u
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
     t.stage_boundary(c, Bp, Bv);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         const float ri = c.rho[i], gi = gradcs[i];
@@ -357,7 +384,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_forces(StepCtx c, u
         if (tc != 0.0f) {
             const float ts = tc / (2.0f * mi);
             float fx = 0.f, fy = 0.f, fz = 0.f;
-            for_each_ff(c, i, gs, [&](uint32_t s) {
+            for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
                 const float4 pj = Lp[s];
                 const float rj = Lr[s], gj = Lg[s];
                 const bool same = Lm ? (Lm[s] == model) : true;
@@ -401,16 +428,19 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_wcsph_tension(StepCtx c, u
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), Lp);
     const uint32_t* Lm = nullptr;
     if (c.nmodels > 1) t.stage(c, static_cast<const uint32_t*>(c.model), Lm);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         float fx = 0.f, fy = 0.f, fz = 0.f;
-        for_each_ff(c, i, gs, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
             const float4 pj = Lp[s];
             const bool same = Lm ? (Lm[s] == model) : true;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;

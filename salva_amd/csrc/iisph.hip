@@ -29,19 +29,22 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dii(StepCtx c, float
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), Lp);
     const float4* Bp = nullptr;
     t.stage_boundary(c, Bp);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
         const float4 pi = c.posm[i];
         const float rho0 = c.rho0_tab[c.model[i]];
         const float rhoi = c.rho[i];
         const float factor = -dt * dt / (rhoi * rhoi);
         float x = 0.f, y = 0.f, z = 0.f;
-        for_each_ff(c, i, gs, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
             const float4 pj = Lp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (pj.w * factor);
@@ -66,20 +69,23 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_pred_density(StepCtx
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float4* Lw = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), Lp, Lw);
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
     t.stage_boundary(c, Bp, Bv);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
         const float4 pi = c.posm[i];
         const float4 wi = c.w[i];
         const float rho0 = c.rho0_tab[c.model[i]];
         float delta = 0.0f;
-        for_each_ff(c, i, gs, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
             const float4 pj = Lp[s];
             const float4 wj = Lw[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -107,12 +113,15 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_aii(StepCtx c, float
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), Lp);
     const float4* Bp = nullptr;
     t.stage_boundary(c, Bp);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
         const float4 pi = c.posm[i];
         const float rho0 = c.rho0_tab[c.model[i]];
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_aii(StepCtx c, float
         const float factor = dt * dt * pi.w / (rhoi * rhoi);
         const float4 di = c.dii[i];
         float a = 0.0f;
-        for_each_ff(c, i, gs, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
             const float4 pj = Lp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
@@ -147,16 +156,19 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dij_pj(StepCtx c, fl
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float* Lr = nullptr;
     const float* Lq = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), static_cast<const float*>(p), Lp, Lr, Lq);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
         const float4 pi = c.posm[i];
         float x = 0.f, y = 0.f, z = 0.f;
-        for_each_ff(c, i, gs, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
             const float4 pj = Lp[s];
             const float rhoj = Lr[s];
             const float pjl = Lq[s];
@@ -180,6 +192,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
     Tile t;
     t.setup(c);
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float4* Ld = nullptr;
     const float4* Lj = nullptr;
@@ -189,8 +204,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
     t.stage_boundary(c, Bp);
     TileErr E;
     E.init(errtab, c);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
                 const float4 dpi = c.dijpj[i];
                 const float fji = dt * dt * pi.w / (rhoi * rhoi);
                 float sum = 0.0f;
-                for_each_ff(c, i, gs, [&](uint32_t s) {
+                for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
                     const float4 pj = Lp[s];
                     const float4 dj = Ld[s];
                     const float4 dpj = Lj[s];
@@ -246,6 +261,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(Ste
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float* Lr = nullptr;
     const float* Lq = nullptr;
@@ -253,15 +271,15 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(Ste
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
     t.stage_boundary(c, Bp, Bv);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active) return;
         const float4 pi = c.posm[i];
         const float rho0 = c.rho0_tab[c.model[i]];
         const float rhoi = c.rho[i];
         const float pri = p[i] / (rhoi * rhoi);
         float4 d = c.dv[i];
-        for_each_ff(c, i, gs, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
             const float4 pj = Lp[s];
             const float rhoj = Lr[s];
             const float pjl = Lq[s];

@@ -49,15 +49,6 @@ struct PipeCfg {
 
 #ifdef __HIPCC__
 
-__device__ __forceinline__ void glds16(const float4* __restrict__ src, float4* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ void glds4(const float* __restrict__ src, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
-}
-
 // Tiles of one workgroup: the XCD that runs workgroup b (b % 8, observed) owns one contiguous eighth of the slots
 // (as xcd_block does for the one-tile kernels) and its workgroups sweep it side by side, so that the tiles in flight
 // on an XCD at any time are neighbours and share halo lines in that XCD's L2.

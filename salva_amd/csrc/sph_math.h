@@ -68,6 +68,13 @@ __device__ __forceinline__ float dist2_exact(float dx, float dy, float dz) {
     return xy + zz;
 }
 
+// A value the optimiser must treat as opaque: a product passed through it cannot be contracted into an FMA with a later
+// add (cf. dist2_exact).  For the few places whose results feed the exact contact test and must round like the CPU's.
+__device__ __forceinline__ float opaque(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 struct KernelEval {
     float w;  // W(|d|)
     float g;  // (dW/dr)/|d|  — gradient = g * d

@@ -40,7 +40,8 @@ struct TileLds {
     uint32_t max_halo_fluid = 0, max_halo_boundary = 0, threads = 4 * WAVE;
     uint32_t bytes(uint32_t bytes_per_fluid_slot, uint32_t bytes_per_boundary_slot, uint32_t narrays,
                    bool with_cell_tables = false) const {
-        return (with_cell_tables ? TILE_TABLE_BYTES : 0u) + max_halo_fluid * bytes_per_fluid_slot +
+        // (staged fluid arrays are filled by LDS-DMA in chunks of 64 slots: sized to the next multiple of 64)
+        return (with_cell_tables ? TILE_TABLE_BYTES : 0u) + ((max_halo_fluid + 63u) & ~63u) * bytes_per_fluid_slot +
                max_halo_boundary * bytes_per_boundary_slot + 16u * narrays;
     }
 };
@@ -82,6 +83,19 @@ __device__ __forceinline__ int cell_coord(float x, float h, bool& bad) {
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+
+// LDS-DMA (global_load_lds): every lane names its own global source, the 64 lanes' data land in LDS side by side from a
+// wave-uniform base — the shape of an index-gather into consecutive halo slots.  No VGPR round trip, no ds_write pass.
+// Completion is counted on vmcnt: wait for it before the barrier that publishes the staged data.
+__device__ __forceinline__ void glds16(const float4* __restrict__ src, float4* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* __restrict__ src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
 
 // ---------------------------------------------------------------------------------------------------
 // Tile: what every tile kernel needs.  The halo of a tile (the particles of its 6x6x6 cell box, in halo-cell order)
@@ -128,10 +142,11 @@ struct Tile {
     }
 
     // workgroup k of a launch works on slot k = the k-th non-empty tile (XCD-remapped so that neighbours share an L2)
-    __device__ __forceinline__ void setup(const StepCtx& c) {
+    __device__ __forceinline__ void setup(const StepCtx& c) { setup_at(c, xcd_block(blockIdx.x, gridDim.x, c.xcd)); }
+    __device__ __forceinline__ void setup_at(const StepCtx& c, uint32_t at_slot) {
         pool = tile_smem;
         pool_used = 0;
-        slot = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+        slot = at_slot;
         const uint4 desc = c.slot_desc[slot];
         pre0 = pre1 = pre2 = pre3 = preb = 0u;
         if (c.halo_stride) {
@@ -192,34 +207,70 @@ struct Tile {
         for (uint32_t s = threadIdx.x; s < SB; s += blockDim.x) f(s, src[s]);
     }
 
-    // Stage global per-particle arrays into LDS (one pass over the slot table for all of them).  No barrier inside.
+    // Stage global per-particle arrays into LDS (one pass over the slot table for all of them).  No barrier inside: follow
+    // with staged_barrier().  With strided slot tables (the indices are in registers already, setup()) the copy is LDS-DMA
+    // in 64-slot chunks; otherwise global_load + ds_write.
+    template <typename T>
+    static __device__ __forceinline__ void dma_chunk(const T* __restrict__ src, T* lds_wave_base) {
+        static_assert(sizeof(T) == 16 || sizeof(T) == 4, "LDS-DMA moves 4 or 16 bytes per lane");
+        if constexpr (sizeof(T) == 16) glds16(reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(lds_wave_base));
+        else glds4(reinterpret_cast<const float*>(src), reinterpret_cast<float*>(lds_wave_base));
+    }
+    // f(chunk_base_slot, source_index) for every 64-slot chunk this wave copies (wave-uniform control flow)
+    template <typename F>
+    __device__ __forceinline__ void for_halo_chunks(const StepCtx& c, F&& f) const {
+        const uint32_t nt = blockDim.x, lane = threadIdx.x & (WAVE - 1), nw = nt / WAVE;
+        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+        const uint32_t pre[PRE] = {pre0, pre1, pre2, pre3};
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            const uint32_t s0 = (wv + (uint32_t)k * nw) * WAVE;
+            if (s0 < S) f(s0, (s0 + lane < S) ? pre[k] : own_begin);
+        }
+        for (uint32_t s0 = (wv + (uint32_t)PRE * nw) * WAVE; s0 < S; s0 += nt)
+            f(s0, (s0 + lane < S) ? c.halo_src[hoff + s0 + lane] : own_begin);
+    }
+    __device__ __forceinline__ uint32_t stage_cap(const StepCtx& c) const { return c.halo_stride ? ((S + 63u) & ~63u) : S; }
     template <typename T0>
     __device__ __forceinline__ void stage(const StepCtx& c, const T0* __restrict__ s0, const T0*& d0) {
-        T0* a = carve<T0>(S);
-        for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; });
+        T0* a = carve<T0>(stage_cap(c));
+        if (c.halo_stride) for_halo_chunks(c, [&](uint32_t b, uint32_t g) { dma_chunk(s0 + g, a + b); });
+        else for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; });
         d0 = a;
     }
     template <typename T0, typename T1>
     __device__ __forceinline__ void stage(const StepCtx& c, const T0* __restrict__ s0, const T1* __restrict__ s1,
                                           const T0*& d0, const T1*& d1) {
-        T0* a = carve<T0>(S); T1* b = carve<T1>(S);
-        for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; });
+        T0* a = carve<T0>(stage_cap(c)); T1* b = carve<T1>(stage_cap(c));
+        if (c.halo_stride) for_halo_chunks(c, [&](uint32_t q, uint32_t g) { dma_chunk(s0 + g, a + q); dma_chunk(s1 + g, b + q); });
+        else for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; });
         d0 = a; d1 = b;
     }
     template <typename T0, typename T1, typename T2>
     __device__ __forceinline__ void stage(const StepCtx& c, const T0* __restrict__ s0, const T1* __restrict__ s1,
                                           const T2* __restrict__ s2, const T0*& d0, const T1*& d1, const T2*& d2) {
-        T0* a = carve<T0>(S); T1* b = carve<T1>(S); T2* e = carve<T2>(S);
-        for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; e[s] = s2[g]; });
+        T0* a = carve<T0>(stage_cap(c)); T1* b = carve<T1>(stage_cap(c)); T2* e = carve<T2>(stage_cap(c));
+        if (c.halo_stride)
+            for_halo_chunks(c, [&](uint32_t q, uint32_t g) { dma_chunk(s0 + g, a + q); dma_chunk(s1 + g, b + q); dma_chunk(s2 + g, e + q); });
+        else for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; e[s] = s2[g]; });
         d0 = a; d1 = b; d2 = e;
     }
     template <typename T0, typename T1, typename T2, typename T3>
     __device__ __forceinline__ void stage(const StepCtx& c, const T0* __restrict__ s0, const T1* __restrict__ s1,
                                           const T2* __restrict__ s2, const T3* __restrict__ s3, const T0*& d0,
                                           const T1*& d1, const T2*& d2, const T3*& d3) {
-        T0* a = carve<T0>(S); T1* b = carve<T1>(S); T2* e = carve<T2>(S); T3* f = carve<T3>(S);
-        for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; e[s] = s2[g]; f[s] = s3[g]; });
+        T0* a = carve<T0>(stage_cap(c)); T1* b = carve<T1>(stage_cap(c)); T2* e = carve<T2>(stage_cap(c)); T3* f = carve<T3>(stage_cap(c));
+        if (c.halo_stride)
+            for_halo_chunks(c, [&](uint32_t q, uint32_t g) {
+                dma_chunk(s0 + g, a + q); dma_chunk(s1 + g, b + q); dma_chunk(s2 + g, e + q); dma_chunk(s3 + g, f + q);
+            });
+        else for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; e[s] = s2[g]; f[s] = s3[g]; });
         d0 = a; d1 = b; d2 = e; d3 = f;
+    }
+    // the barrier that publishes the staged halo: the DMA of this wave has landed (vmcnt), then everybody's has
+    static __device__ __forceinline__ void staged_barrier() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
     __device__ __forceinline__ void stage_boundary(const StepCtx& c, const float4*& bp) {
         float4* a = carve<float4>(SB);
@@ -551,6 +602,42 @@ __device__ __forceinline__ void for_each_fb_regs(const StepCtx& c, uint32_t SB, 
             if (2u * q + 1u < cnt) f(a >> 16);
         }
     }
+}
+// Exact-count traversal with the list head in registers (the passes that use W itself: a padding entry would count).
+// `ListOwn` is loaded before the staging barrier (first_own / for_own_pre), so no list dword is fetched inside the loop
+// unless the list is longer than 2 * LIST_REGS contacts.
+struct ListOwn { uint32_t cnt; ListRegs lr; };
+__device__ __forceinline__ ListOwn list_own(const StepCtx& c, uint32_t i, uint32_t gslice) { return ListOwn{c.nff[i], list_regs(c, gslice)}; }
+template <typename L, typename C>
+__device__ __forceinline__ void for_each_ff_regs(const StepCtx& c, uint32_t gslice, const ListOwn& o, L&& load, C&& compute) {
+    const uint32_t cnt = o.cnt;
+#pragma unroll
+    for (int k = 0; k < LIST_REGS; ++k) {
+        if (2u * (uint32_t)k < cnt) {
+            const uint32_t a = o.lr.d[k];
+            const auto d0 = load(a & 0xffffu);
+            const auto d1 = load(a >> 16);  // (an odd list is padded with the particle's own slot: always a valid read)
+            compute(d0);
+            if (2u * (uint32_t)k + 1u < cnt) compute(d1);
+        }
+    }
+    if (cnt > 2u * (uint32_t)LIST_REGS) {
+        const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
+        const uint32_t nq = (cnt + 1u) >> 1;
+        uint32_t nx = p[(size_t)LIST_REGS * WAVE];
+        for (uint32_t q = LIST_REGS; q < nq; ++q) {
+            const uint32_t a = nx;
+            if (q + 1 < nq) nx = p[(size_t)(q + 1) * WAVE];
+            const auto d0 = load(a & 0xffffu);
+            const auto d1 = load(a >> 16);
+            compute(d0);
+            if (2u * q + 1u < cnt) compute(d1);
+        }
+    }
+}
+template <typename F>
+__device__ __forceinline__ void for_each_ff_regs(const StepCtx& c, uint32_t gslice, const ListOwn& o, F&& f) {
+    for_each_ff_regs(c, gslice, o, [](uint32_t s) { return s; }, f);
 }
 // Wave-uniform list length of a slice in dwords (k_nbr_tile pads the shorter lists with self contacts).  Call from all lanes.
 __device__ __forceinline__ uint32_t slice_list_dwords(uint32_t cnt, bool active) {

@@ -109,11 +109,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_betas(StepCtx c, uint
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const uint32_t* Lm = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), static_cast<const uint32_t*>(c.model), Lp, Lm);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         const float rho = c.rho[i];
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_betas(StepCtx c, uint
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
         float q[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         struct Rec { float4 p; uint32_t m; };
-        for_each_ff(c, i, gs, [&](uint32_t s) { return Rec{Lp[s], Lm[s]}; }, [&](const Rec& rc) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], Lm[s]}; }, [&](const Rec& rc) {
             const float4 pj = rc.p;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
@@ -188,13 +191,16 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_strain(StepCtx c, uin
     Tile t;
     t.setup(c);
     if (t.empty()) { if (mode == 1) TileErr::zero(c, t.slot); return; }
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float4* Lv = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), va, Lp, Lv);
     TileErr E;
     E.init(errtab, c);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         float err1 = 0.0f;
         const bool mine = active && c.model[i] == model;
         if (mine) {
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_strain(StepCtx c, uin
             const float half_inv_rho = 1.0f / (2.0f * c.rho[i]);
             float r[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             struct Rec { float4 p, v; };
-            for_each_ff(c, i, gs, [&](uint32_t s) { return Rec{Lp[s], Lv[s]}; }, [&](const Rec& rc) {
+            for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], Lv[s]}; }, [&](const Rec& rc) {
                 const float4 pj = rc.p, vj = rc.v;
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
@@ -255,19 +261,22 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_accel(StepCtx c, uint
     Tile t;
     t.setup(c);
     if (t.empty()) return;
+    uint32_t i0_, gs0_;
+    t.first_own(i0_, gs0_);
+    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
     const float4* La = nullptr;
     const float4* Lb = nullptr;
     t.stage(c, static_cast<const float4*>(c.posm), u0, u1, Lp, La, Lb);
-    __syncthreads();
-    t.for_own([&](uint32_t i, uint32_t gs, bool active) {
+    Tile::staged_barrier();
+    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         const float4 a0 = u0[i], a1 = u1[i];
         float ax = 0.0f, ay = 0.0f, az = 0.0f;
         struct Rec { float4 p, a, b; };
         const float mi_inv_dt = pi.w * inv_dt;
-        for_each_ff(c, i, gs, [&](uint32_t s) { return Rec{Lp[s], La[s], Lb[s]}; }, [&](const Rec& rc) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], La[s], Lb[s]}; }, [&](const Rec& rc) {
             const float4 pj = rc.p;
             if (__float_as_uint(rc.b.w) != model) return;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;

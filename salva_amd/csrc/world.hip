@@ -1242,20 +1242,24 @@ __global__ void k_boundary_pose(uint32_t n, const float4* __restrict__ local, Sa
     if (i >= n) return;
     const float4 pt = local[i];
     const float qx = p.rotation[0], qy = p.rotation[1], qz = p.rotation[2], qw = p.rotation[3];
-    const float tx = (qy * pt.z - qz * pt.y) * 2.0f, ty = (qz * pt.x - qx * pt.z) * 2.0f, tz = (qx * pt.y - qy * pt.x) * 2.0f;
-    const float cx = qy * tz - qz * ty, cy = qz * tx - qx * tz, cz = qx * ty - qy * tx;
+    // every product is rounded on its own (no FMA contraction): these positions feed the exact d^2 <= h^2 contact test, and
+    // sample points 2r apart make pairs that sit exactly on d = h (found by the literal basic3 scene: 250 boundary-boundary
+    // contacts fewer than the CPU with contracted products)
+    const float tx = (opaque(qy * pt.z) - opaque(qz * pt.y)) * 2.0f, ty = (opaque(qz * pt.x) - opaque(qx * pt.z)) * 2.0f,
+                tz = (opaque(qx * pt.y) - opaque(qy * pt.x)) * 2.0f;
+    const float cx = opaque(qy * tz) - opaque(qz * ty), cy = opaque(qz * tx) - opaque(qx * tz), cz = opaque(qx * ty) - opaque(qy * tx);
     float4 o = pos[i];  // .w (volume slot) untouched
-    o.x = (tx * qw + cx + pt.x) + p.translation[0];
-    o.y = (ty * qw + cy + pt.y) + p.translation[1];
-    o.z = (tz * qw + cz + pt.z) + p.translation[2];
+    o.x = ((opaque(tx * qw) + cx) + pt.x) + p.translation[0];
+    o.y = ((opaque(ty * qw) + cy) + pt.y) + p.translation[1];
+    o.z = ((opaque(tz * qw) + cz) + pt.z) + p.translation[2];
     pos[i] = o;
     float4 v = vel[i];  // .w carries the boundary's model id
     if (p.has_body) {
         // body.velocity_at_point(pt) with the local point, as the reference writes it (:183)
         const float dx = pt.x - p.world_com[0], dy = pt.y - p.world_com[1], dz = pt.z - p.world_com[2];
-        v.x = p.linvel[0] + (p.angvel[1] * dz - p.angvel[2] * dy);
-        v.y = p.linvel[1] + (p.angvel[2] * dx - p.angvel[0] * dz);
-        v.z = p.linvel[2] + (p.angvel[0] * dy - p.angvel[1] * dx);
+        v.x = p.linvel[0] + (opaque(p.angvel[1] * dz) - opaque(p.angvel[2] * dy));
+        v.y = p.linvel[1] + (opaque(p.angvel[2] * dx) - opaque(p.angvel[0] * dz));
+        v.z = p.linvel[2] + (opaque(p.angvel[0] * dy) - opaque(p.angvel[1] * dx));
     } else {
         v.x = v.y = v.z = 0.0f;
     }
@@ -1501,7 +1505,7 @@ float World::time_variant(int variant, uint32_t param, int reps, uint64_t* check
     if (variant == 2 && !pipe.fits(2, 0, 2, true)) throw HipError(SALVA_HIP_E_CAPACITY, "the pipeline does not fit the LDS for this scene");
     if (const char* e = getenv("SALVA_HIP_PIPE_WAVES")) pipe.threads = (uint32_t)std::min<int>(std::max(atoi(e), 1), PIPE_MAX_WAVES) * WAVE;
     DevBuf<uint32_t> arrivals;
-    arrivals.ensure(4096);
+    arrivals.ensure(std::max<uint32_t>(4096u, last_ctx.nlaunch));
     SALVA_HIP_CHECK(hipMemsetAsync(kappa.p, 0xff, (size_t)n * sizeof(float), stream));
     SALVA_HIP_CHECK(hipMemsetAsync(partials.p, 0xff, (size_t)last_ctx.nlaunch * last_ctx.nmodels * sizeof(float), stream));
     if (getenv("SALVA_HIP_TILE_TIMING") && (variant == 2 || variant == 4)) {
@@ -1532,6 +1536,27 @@ float World::time_variant(int variant, uint32_t param, int reps, uint64_t* check
                 fprintf(stderr, "[variant 2 timing] %zu wave-tiles: top vm wait %.0f | barrier %.0f | issue+prefetch %.0f | - | compute %.0f cycles (avg per wave); kernel span %.0f\n",
                         cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[4] / cnt, (double)(tmax - tmin));
         }
+    }
+    if (variant == 8) {
+        // dispatch order for the experiment "heaviest tiles first": block b works on order[b]; within the blocks of one XCD
+        // (b % 8) the slots of that XCD's contiguous eighth, by descending particle count (stable: neighbours stay together)
+        const uint32_t nl = last_ctx.nlaunch;
+        std::vector<uint4> info(nl);
+        SALVA_HIP_CHECK(hipMemcpy(info.data(), slot_info.p, (size_t)nl * sizeof(uint4), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> order(std::max<uint32_t>(nl, 4096u));
+        const uint32_t q = nl >> 3, r = nl & 7u;
+        for (uint32_t x = 0; x < 8; ++x) {
+            const uint32_t base = (x < r) ? x * (q + 1u) : r * (q + 1u) + (x - r) * q, len = q + (x < r ? 1u : 0u);
+            std::vector<uint32_t> sl(len);
+            for (uint32_t k = 0; k < len; ++k) sl[k] = base + k;
+            const int by = (int)param;
+            std::stable_sort(sl.begin(), sl.end(), [&](uint32_t a, uint32_t b) {
+                const uint32_t ca = by == 1 ? (info[a].w & 0xffffu) : info[a].y - info[a].x, cb = by == 1 ? (info[b].w & 0xffffu) : info[b].y - info[b].x;
+                return ca > cb;
+            });
+            for (uint32_t k = 0; k < len; ++k) order[x + 8u * k] = sl[k];
+        }
+        SALVA_HIP_CHECK(hipMemcpy(arrivals.p, order.data(), (size_t)nl * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     launch_pred_density_variant(last_ctx, lds, pipe, last_dt, variant, param, arrivals.p, stream);  // warm-up + checksum run
     std::vector<uint32_t> hk((size_t)n + (size_t)last_ctx.nlaunch * last_ctx.nmodels);

@@ -130,3 +130,85 @@ def tank(nx: int, ny: int, nz: int, particle_rad: float, wall_cells: int = 0):
     maxs[1] += F(max(ny // 2, 4)) * d
     shell = box_shell(mins, maxs, particle_rad, faces="xXyzZ")
     return fluid, shell
+
+
+def cuboid_surface_ray_sample(half_extents, particle_rad: float) -> np.ndarray:
+    """`shape_surface_ray_sample(&Cuboid::new(half_extents), particle_rad)` of /root/reference/src/sampling/ray_sampling.rs
+    (:9-15, surface_ray_sample :27-88, quantize_point :209-231, unquantize_points :187-207) for an axis-aligned cuboid, with
+    parry's ray cast (out of scope here) replaced by its closed form for a box: a ray along axis i on a lattice line that
+    crosses the box enters at -he_i and leaves at +he_i.
+
+    The sampler's lattice has spacing s = 2r and origin (aabb.mins - s) + s/2 per axis; an entry impact is quantised with
+    ceil, an exit impact with floor, the other two coordinates with round — so the samples are the outer shell of the
+    lattice origin + idx * s, idx = 1..N_i, i.e. they sit half a spacing INSIDE the faces.  Returned in lexicographic index
+    order (the reference's order is a HashSet's: unspecified).  All arithmetic in f32 as in the reference.
+    """
+    he = np.asarray(half_extents, dtype=F)
+    s = F(particle_rad) * F(2.0)
+    mins = (-he) - s                       # Aabb::loosened(subdivision_size)
+    maxs = he + s
+    origin = (mins + s / F(2.0)).astype(F)
+    pts = set()
+    # lattice lines of each axis pair: curr starts at origin and advances by s while curr < maxs (:62-76)
+    coords = []
+    for a in range(3):
+        c, line = origin[a], []
+        while c < maxs[a]:
+            line.append(c)
+            c = F(c + s)
+        coords.append(line)
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        for cj in coords[j]:
+            for ck in coords[k]:
+                if not (abs(cj) <= he[j] and abs(ck) <= he[k]):
+                    continue  # the ray misses the box
+                # round() of the two transverse coordinates of the impact (:222-224)
+                qj = int(np.round(F(F(cj - origin[j]) / s)))
+                qk = int(np.round(F(F(ck - origin[k]) / s)))
+                q_in = int(np.ceil(F(F(-he[i] - origin[i]) / s)))    # entry point: ceil (:218-219)
+                q_out = int(np.floor(F(F(he[i] - origin[i]) / s)))   # exit point: floor (:220-221)
+                for qi in (q_in, q_out):
+                    q = [0, 0, 0]
+                    q[i], q[j], q[k] = qi, qj, qk
+                    pts.add(tuple(q))
+    q = np.asarray(sorted(pts), dtype=np.float64)
+    return (origin[None, :] + (q.astype(F) * s)).astype(F)   # unquantize_points (:198-204)
+
+
+def quat_from_scaled_axis(v) -> np.ndarray:
+    """nalgebra `UnitQuaternion::from_scaled_axis` in f32, as (i, j, k, w): the rotation part of `Isometry3::new(t, v)`."""
+    v = np.asarray(v, dtype=F)
+    ang = F(np.sqrt(F(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])))
+    if ang == 0:
+        return np.array([0, 0, 0, 1], dtype=F)
+    half = F(ang * F(0.5))
+    sn, cs = F(np.sin(half)), F(np.cos(half))
+    return np.array([v[0] / ang * sn, v[1] / ang * sn, v[2] / ang * sn, cs], dtype=F)
+
+
+def basic3(nparticles: int = 15, particle_rad: float = 0.05):
+    """The literal scene of /root/reference/examples3d/basic3.rs:16-99: a cube of nparticles^3 fluid particles (helper.rs:4-20)
+    lifted by ground_thickness + nparticles * r, and five fixed cuboid colliders — four walls and the ground — each sampled
+    by `shape_surface_ray_sample` in its local frame and coupled by `ColliderSampling::StaticSampling`.
+
+    Returns (fluid_positions, [(local_samples, translation, rotation_quaternion_ijkw), ...]) in registration order
+    (walls first, ground last, basic3.rs:63-96).  BASELINE config[0]; forces: ArtificialViscosity(1.0, 0.0), DFSPH,
+    gravity (0, -9.81, 0), dt = 1/200 (basic3.rs:22,36-44,118).
+    """
+    r = F(particle_rad)
+    ground_thickness, ground_half_width, ground_half_height = F(0.2), F(2.5), F(0.7)
+    fluid = cube_fluid_positions(nparticles, nparticles, nparticles, particle_rad)
+    fluid = (fluid + np.array([0.0, ground_thickness + F(nparticles) * r, 0.0], dtype=F)[None, :]).astype(F)  # transform_by
+    wall = cuboid_surface_ray_sample([ground_thickness, ground_half_height, ground_half_width], particle_rad)
+    ground = cuboid_surface_ray_sample([ground_half_width, ground_thickness, ground_half_width], particle_rad)
+    half_pi_y = quat_from_scaled_axis([0.0, F(np.pi) / F(2.0), 0.0])
+    ident = np.array([0, 0, 0, 1], dtype=F)
+    colliders = [
+        (wall, np.array([0.0, ground_half_height, ground_half_width], dtype=F), half_pi_y),
+        (wall, np.array([0.0, ground_half_height, -ground_half_width], dtype=F), half_pi_y),
+        (wall, np.array([ground_half_width, ground_half_height, 0.0], dtype=F), ident),
+        (wall, np.array([-ground_half_width, ground_half_height, 0.0], dtype=F), ident),
+        (ground, np.zeros(3, dtype=F), ident),
+    ]
+    return fluid, colliders

@@ -124,7 +124,9 @@ def test_longer_trajectory_dam_break():
     for k in range(n):
         st = w.step(DT, GRAVITY)
         so = o.step(DT, GRAVITY)
-        assert st.ncontacts == so.ncontacts or k > 10, (k, st.ncontacts, so.ncontacts)
+        # identical positions give the identical contact set; once the two trajectories differ by rounding, a pair sitting
+        # on d = h may fall on either side: a bounded slack, never a waiver
+        assert abs(int(st.ncontacts) - int(so.ncontacts)) <= (0 if k == 0 else max(4, int(2e-5 * so.ncontacts) * (k + 1))), (k, st.ncontacts, so.ncontacts)
         assert abs(st.n_pressure_iters - so.n_press_iters) <= 1 and abs(st.n_divergence_iters - so.n_div_iters) <= 2, k
         if k in (0, 9, n - 1):
             d = max_norm_diff(fl.positions, o.fluid_vec(0, "positions")) / R
@@ -132,6 +134,81 @@ def test_longer_trajectory_dam_break():
     # chaotic growth is slow on this time scale: stay within 1e-3 r per step
     assert worst < 1e-3, worst
     assert fl.positions[:, 1].min() > shell[:, 1].min() - R  # nothing fell through the floor
+
+
+def _basic3_worlds():
+    """BASELINE config[0]: the literal scene of /root/reference/examples3d/basic3.rs on both implementations, colliders coupled
+    through ColliderSampling::StaticSampling exactly as the example registers them (fixed parent body: no forces)."""
+    from oracle import oracle as O
+    from salva_amd import ArtificialViscosity, Boundary, DFSPHSolver, Fluid, LiquidWorld
+    from salva_amd.coupling import ColliderCouplingSet, RigidBody, StaticSampling
+
+    r = 0.05
+    fluid, colliders = scenes.basic3(15, r)
+    w = LiquidWorld(DFSPHSolver(), r, 2.0)
+    fl = Fluid(fluid, r, 1000.0)
+    fl.nonpressure_forces.append(ArtificialViscosity(1.0, 0.0))
+    w.add_fluid(fl)
+    coupling = ColliderCouplingSet()
+    for k, (pts, t, q) in enumerate(colliders):
+        b = w.add_boundary(Boundary(np.zeros((0, 3), np.float32)))
+        coupling.register_coupling(b, k, RigidBody(translation=t, rotation=q, dynamic=False), StaticSampling(pts))
+
+    def make_oracle(f64=False):
+        o = O.OracleWorld(r, 2.0, O.DFSPH, f64=f64, threads=4)
+        f = o.add_fluid(fluid, 1000.0)
+        o.add_artificial_viscosity(f, 1.0, 0.0)
+        for pts, t, q in colliders:
+            b = o.add_boundary(np.zeros((0, 3), np.float32))
+            o.set_boundary_sampling(b, pts)
+        return o
+
+    def pose_oracle(o):
+        for b, (pts, t, q) in enumerate(colliders):
+            o.update_boundary_pose(b, t, q, (0, 0, 0), (0, 0, 0), t, True, False)
+
+    return r, fluid, colliders, w, fl, coupling, make_oracle, pose_oracle
+
+
+def test_basic3_literal_scene_200_steps():
+    """examples3d/basic3.rs:16-118 — 15^3 block, five ray-sampled cuboid shells, ArtificialViscosity(1.0, 0.0), 200 steps of
+    dt = 1/200: per-step contact counts and iteration counts against the oracle, positions against the stated tolerance
+    while the flow is regular and against the oracle's own f32-vs-f64 distance once the splash makes it chaotic."""
+    r, fluid, colliders, w, fl, coupling, make_oracle, pose_oracle = _basic3_worlds()
+    o, o64 = make_oracle(), make_oracle(f64=True)
+    n = 200
+    checkpoints = (1, 10, 50, 100, 200)
+    for k in range(n):
+        coupling.update_boundaries(w)
+        pose_oracle(o)
+        pose_oracle(o64)
+        st = w.step(DT, GRAVITY)
+        so = o.step(DT, GRAVITY)
+        o64.step(DT, GRAVITY)
+        if k == 0:
+            assert st.nparticles == 3375 and sum(len(c[0]) for c in colliders) == 5392 + 4 * 1648
+            assert st.ncontacts == so.ncontacts, (st.ncontacts, so.ncontacts)
+            assert (w.contact_counts(fl) == o.contact_counts(0)).all() and (w.contact_counts(fl, True) == o.contact_counts(0, True)).all()
+            for b, h in enumerate(w.boundaries()):
+                assert rel_err(h.volumes, o.boundary_volumes(b)) < 1e-5
+        d = max_norm_diff(fl.positions, o.fluid_vec(0, "positions")) / r
+        noise = max_norm_diff(o.fluid_vec(0, "positions"), o64.fluid_vec(0, "positions")) / r
+        # the two trajectories agree to rounding: contacts may differ only by pairs sitting on d = h
+        slack = 0 if k == 0 else max(4, int(1e-4 * so.ncontacts))
+        if d < 1e-2:
+            assert abs(int(st.ncontacts) - int(so.ncontacts)) <= slack, (k, st.ncontacts, so.ncontacts)
+            assert abs(st.n_pressure_iters - so.n_press_iters) <= 1 and abs(st.n_divergence_iters - so.n_div_iters) <= 2, (k, st, so)
+        if k + 1 in checkpoints:
+            # stated tolerance 1e-4 r per step, or what the reference's own arithmetic is worth on this flow (SURVEY.md §8c):
+            # the oracle's f32 and f64 runs are 1e-3 r apart after 50 steps, 0.08 r after 100 and decorrelated (6 r) after 200;
+            # two max-deviations of chaotic runs are compared, hence the factor 10 rather than 2
+            assert d < max(1e-4 * (k + 1), 10.0 * noise), f"after {k + 1} steps: {d:.3e} r vs oracle, oracle f32-f64 {noise:.3e} r"
+    # bulk state after the splash: centre of mass and kinetic energy agree to a few per cent whatever the chaos did to particles
+    po, vo = o.fluid_vec(0, "positions").astype(np.float64), o.fluid_vec(0, "velocities").astype(np.float64)
+    pg, vg = fl.positions.astype(np.float64), fl.velocities.astype(np.float64)
+    assert np.abs(pg.mean(axis=0) - po.mean(axis=0)).max() < 0.02
+    assert abs((vg ** 2).sum() - (vo ** 2).sum()) < 0.05 * max((vo ** 2).sum(), 1e-6)
+    assert pg[:, 1].min() > 0.1  # nothing fell through the ground (top face at y = 0.2, samples at 0.15)
 
 
 def test_api_semantics_match_reference():

@@ -14,7 +14,7 @@ struct RecPW { float4 p, w; };
 // MODE 0: for_each_ff2 as in k_pred_density; 1: four-contact interleaved step; 2: as 0 but every lane reads slot 0 (no bank
 // conflicts, broadcast); 3: as 0 with scalar (unpacked) arithmetic; 4: LDS reads only (no arithmetic)
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_loop(StepCtx c, const uint32_t* __restrict__ lists, float* out, unsigned long long* cyc,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_loop(StepCtx c, const uint32_t* __restrict__ lists, float* out, unsigned long long* cyc,
                                               uint32_t S, int reps, uint32_t nq) {
     float4* Lp = reinterpret_cast<float4*>(tile_smem);
     float4* Lw = Lp + S;
@@ -37,6 +37,10 @@ __global__ __launch_bounds__(1024) void k_loop(StepCtx c, const uint32_t* __rest
     float accs = 0.0f;
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int r = 0; r < reps; ++r) {
+        if (MODE != 2) {  // the list is opaque per pass: no address arithmetic may be hoisted out of the timed loop
+#pragma unroll
+            for (int k = 0; k < LIST_REGS; ++k) asm volatile("" : "+v"(lr.d[k]));
+        }
         if (MODE == 0 || MODE == 2) {
             for_each_ff2(c, 0, nq, lr, [&](uint32_t s) { return RecPW{Lp[s], Lw[s]}; }, [&](const RecPW& A, const RecPW& B) {
                 asm volatile("" ::"v"(A.w.w), "v"(B.w.w));
@@ -106,6 +110,38 @@ __global__ __launch_bounds__(1024) void k_loop(StepCtx c, const uint32_t* __rest
                 const f2 mj = {I0.p.w, I1.p.w};
                 acc2 += (ux * dx + uy * dy + uz * dz) * g * mj;
             });
+        } else if (MODE == 9 || MODE == 10) {
+            // depth-1 software pipeline with the LDS reads of step k+1 spread between the arithmetic of step k
+            auto ld = [&](uint32_t s) { return RecPW{Lp[s], Lw[s]}; };
+            auto c2 = [&](const RecPW& A, const RecPW& B) {
+                asm volatile("" ::"v"(A.w.w), "v"(B.w.w));
+                const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
+                const f2 g = kernel_grad2(dx * dx + dy * dy + dz * dz, c.sc);
+                const f2 ux = {wi.x - A.w.x, wi.x - B.w.x}, uy = {wi.y - A.w.y, wi.y - B.w.y}, uz = {wi.z - A.w.z, wi.z - B.w.z};
+                const f2 mj = {A.p.w, B.p.w};
+                acc2 += (ux * dx + uy * dy + uz * dz) * g * mj;
+            };
+            constexpr int NS = 9;
+            RecPW q[NS + 1][4];
+            q[0][0] = ld(lr.d[0] & 0xffffu); q[0][1] = ld(lr.d[0] >> 16);
+            q[0][2] = ld(lr.d[1] & 0xffffu); q[0][3] = ld(lr.d[1] >> 16);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (k + 1 < NS) {
+                    q[k + 1][0] = ld(lr.d[2 * k + 2] & 0xffffu); q[k + 1][1] = ld(lr.d[2 * k + 2] >> 16);
+                    q[k + 1][2] = ld(lr.d[2 * k + 3] & 0xffffu); q[k + 1][3] = ld(lr.d[2 * k + 3] >> 16);
+                }
+                c2(q[k][0], q[k][1]);
+                c2(q[k][2], q[k][3]);
+                if (k + 1 < NS) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // one DS read
+                        __builtin_amdgcn_sched_group_barrier(0x2, MODE == 9 ? 12 : 6, 0);     // then some VALU
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else if (MODE == 5 || MODE == 6) {
             // software pipeline with a compile-time trip count (9 steps of 4 contacts): the loads of step k+1 (MODE 5) or
             // k+2 (MODE 6) are issued before the arithmetic of step k
@@ -153,7 +189,7 @@ void run(const char* name, const StepCtx& c, const uint32_t* lists, float* out, 
     const int reps = 40;
     for (int cfg = 1; cfg < 4; cfg += 2) {
         // waves per workgroup, workgroups per CU
-        static const int W[5] = {4, 8, 16, 8, 12}, G[5] = {1, 1, 1, 2, 2};
+        static const int W[5] = {4, 8, 8, 8, 8}, G[5] = {1, 1, 2, 2, 2};
         const int threads = 64 * W[cfg], blocks = 256 * G[cfg];
         const uint32_t lds = S * 32;
         hipFuncSetAttribute((const void*)k_loop<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -223,8 +259,8 @@ int main(int argc, char** argv) {
     printf("list order %d\n", order);
     run<0>("packed pair loop (as shipped)", c, lists, out, cyc, S, nq);
     run<4>("LDS reads only", c, lists, out, cyc, S, nq);
-    run<7>("independent: math + b128 reads", c, lists, out, cyc, S, nq);
-    run<8>("independent: math + b32 reads", c, lists, out, cyc, S, nq);
+    run<9>("pipelined, 1 read per 12 VALU", c, lists, out, cyc, S, nq);
+    run<10>("pipelined, 1 read per 6 VALU", c, lists, out, cyc, S, nq);
     if (order == 0) {
         run<2>("as shipped, all lanes slot 0", c, lists, out, cyc, S, nq);
         run<3>("scalar arithmetic", c, lists, out, cyc, S, nq);
