@@ -246,6 +246,7 @@ def main():
                 "grid_ms": float(it[:, 3].mean()),
                 "solver_ms": float(it[:, 4].mean()),
                 "tiles": tile_stats,
+                "speculative_passes": int(w.counters.speculative_passes), "discarded_passes": int(w.counters.discarded_passes),
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -107,6 +107,37 @@ typedef struct SalvaHipStepStats {
     float reserved[5];
 } SalvaHipStepStats;
 
+/* `LiquidWorld::counters` — the reference's `Counters` tree, field for field (counters/mod.rs:17-30,
+ * stages_counters.rs:6-11, collision_detection_counters.rs:6-17, solver_counters.rs:6-11), as the testbed plugins read it
+ * (testbed_plugin.rs:508-510).  Times are milliseconds like the reference's `Timer::time()` (instant::now() is in ms),
+ * measured with HIP events on the world's stream, and only filled when SalvaHipParams::enable_timers is set
+ * (`Counters::enable`); the counts are always filled.  Filled by salva_hip_step, read with salva_hip_get_counters. */
+typedef struct SalvaHipCounters {
+    uint64_t nsubsteps;                       /* liquid_world.rs:86 — 1 per step (0 for dt <= eps): the reference never sub-steps */
+    double step_time;                         /* liquid_world.rs:74,156 */
+    double custom;                            /* dfsph_solver.rs:492-501: the divergence solve */
+    struct {
+        double collision_detection_time;      /* liquid_world.rs:88-120 */
+        double solver_time;                   /* liquid_world.rs:122-147 */
+    } stages;
+    struct {
+        uint64_t ncontacts;                   /* liquid_world.rs:119 */
+        double boundary_update_time;          /* liquid_world.rs:94-103: coupling.update_boundaries — here the caller's
+                                                 salva_hip_update_boundary_pose calls run before the step: 0 */
+        double grid_insertion_time;           /* liquid_world.rs:89-92,105-107: cell sort of fluids (+ boundaries when changed) */
+        double neighborhood_search_time;      /* contacts.rs:154-252 via update_contacts: tile tables + neighbour lists */
+        double contact_sorting_time;          /* never started in the reference: 0 */
+    } cd;
+    struct {
+        double non_pressure_resolution_time;  /* never started in the reference: 0 */
+        double pressure_resolution_time;      /* dfsph_solver.rs:677-707 / iisph_solver.rs:664-710: the whole solver.step */
+    } solver;
+    /* --- not in the reference: what this implementation adds to a step report --- */
+    int32_t n_divergence_iters, n_pressure_iters;
+    uint64_t speculative_passes;              /* steps whose table sizes were predicted from the previous step (no mid-step read-back) */
+    uint64_t discarded_passes;                /* ... of which the prediction failed and the step was repeated with exact sizes */
+} SalvaHipCounters;
+
 /* fields of salva_hip_get_fluid_field (solver scratch the reference keeps private; exposed for parity tests) */
 enum {
     SALVA_HIP_FIELD_DENSITY = 0,            /* densities            f32 x n */
@@ -240,6 +271,8 @@ uint64_t salva_hip_device_bytes(const SalvaHipWorld* world);
  * the world's stream between two hipEvents and returns the average launch duration in microseconds
  * (negative on error).  State is not modified (the kernel rewrites the same outputs from the same inputs). */
 float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps);
+/* `world.counters` after the last step — counters/mod.rs:17-72 */
+int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out);
 /* Diagnostics for kernel development (tools/variant_probe.py): times execution variant `variant` of the same kernel
  * (0: one tile per workgroup; 1: the same with co-resident workgroups de-phased by `param` x 64 cycles; 2: persistent
  * double-buffered pipeline; 3: one tile per workgroup with LDS-DMA staging) and returns a checksum of the kappa and

@@ -239,6 +239,12 @@ class LiquidWorld {  // liquid_world.rs
     Real h() const { return salva_hip_h(w_); }
     Real particle_radius() const { return particle_radius_; }
     const SalvaHipStepStats& counters() const { return stats_; }
+    // `world.counters` of the reference (counters/mod.rs:17-72): nsubsteps, step_time, custom, stages, cd, solver
+    SalvaHipCounters counters_tree() const {
+        SalvaHipCounters c{};
+        check(salva_hip_get_counters(w_, &c));
+        return c;
+    }
 
     // LiquidWorld::step(dt, gravity) — liquid_world.rs:62-158
     void step(Real dt, const Vec3& gravity) {

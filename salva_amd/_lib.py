@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_particles_intersecting_aabb", "salva_hip_set_boundary_sampling", "salva_hip_update_boundary_pose",
     "salva_hip_get_boundary_particles", "salva_hip_get_boundary_wrench", "salva_hip_set_force_callback",
     "salva_hip_force_get_state", "salva_hip_force_add_accelerations", "salva_hip_set_fluid_field", "salva_hip_get_timestep",
-    "salva_hip_set_timestep", "salva_hip_time_variant",
+    "salva_hip_set_timestep", "salva_hip_time_variant", "salva_hip_get_counters",
 ]
 
 
@@ -83,6 +83,26 @@ class StepStats(C.Structure):
         ("step_ms", C.c_float),
         ("reserved", C.c_float * 5),
     ]
+
+
+class _StagesCounters(C.Structure):
+    _fields_ = [("collision_detection_time", C.c_double), ("solver_time", C.c_double)]
+
+
+class _CollisionDetectionCounters(C.Structure):
+    _fields_ = [("ncontacts", C.c_uint64), ("boundary_update_time", C.c_double), ("grid_insertion_time", C.c_double),
+                ("neighborhood_search_time", C.c_double), ("contact_sorting_time", C.c_double)]
+
+
+class _SolverCounters(C.Structure):
+    _fields_ = [("non_pressure_resolution_time", C.c_double), ("pressure_resolution_time", C.c_double)]
+
+
+class CountersStruct(C.Structure):
+    """SalvaHipCounters (include/salva_hip.h) = the reference's Counters tree (counters/mod.rs:17-30)."""
+    _fields_ = [("nsubsteps", C.c_uint64), ("step_time", C.c_double), ("custom", C.c_double), ("stages", _StagesCounters),
+                ("cd", _CollisionDetectionCounters), ("solver", _SolverCounters), ("n_divergence_iters", C.c_int32),
+                ("n_pressure_iters", C.c_int32), ("speculative_passes", C.c_uint64), ("discarded_passes", C.c_uint64)]
 
 
 class SalvaHipError(RuntimeError):
@@ -153,6 +173,7 @@ def lib():
     L.salva_hip_device_bytes.restype = u64
     L.salva_hip_time_pred_density.argtypes = [vp, i32]
     L.salva_hip_time_pred_density.restype = f32
+    L.salva_hip_get_counters.argtypes = [vp, C.POINTER(CountersStruct)]
     L.salva_hip_time_variant.argtypes = [vp, i32, u32, i32, C.POINTER(u64)]
     L.salva_hip_time_variant.restype = f32
     ubp = C.POINTER(C.c_ubyte)

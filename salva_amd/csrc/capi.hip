@@ -270,6 +270,14 @@ float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps) {
     return rc == SALVA_HIP_OK ? us : (float)rc;
 }
 
+int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out) {
+    return guarded([&]() -> int {
+        if (!world || !out) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        *out = world->w->counters;
+        return SALVA_HIP_OK;
+    });
+}
+
 float salva_hip_time_variant(SalvaHipWorld* world, int32_t variant, uint32_t param, int32_t reps, uint64_t* checksum) {
     float us = -1.0f;
     int rc = guarded([&]() -> int {

@@ -57,7 +57,9 @@ struct SolveCtl {
     float tol;
     uint32_t min_iter;
     uint32_t mode;       // 0: DFSPH protocol (test, then count the apply); 1: IISPH (count the iteration, then test)
-    uint32_t pad[2];
+    uint32_t seq;        // convergence tests executed so far in this solve (k_finalize_error publishes the block to the host
+                         // after each one; the host waits for the count it enqueued)
+    uint32_t pad;
 };
 
 struct StepCtx {
@@ -102,7 +104,15 @@ struct StepCtx {
     const uint4* slot_info;     // [nlaunch] {first own particle, one past the last, first slice, S | SB << 16}: all a solver
                                 //           kernel needs to know about a tile's sizes, written by k_tile_halo_fill
     const uint32_t* tile_rank;  // [ntiles+1] exclusive prefix of the non-empty flags: slot of a dense tile; [ntiles] = nlaunch
-    uint32_t nlaunch;           // number of slots (known to the host after the per-step read-back; 0 before)
+    uint32_t nlaunch;           // number of slots launched (= the number of non-empty tiles, or in a speculative pass an upper bound)
+    // Speculative passes (World::step): launch shapes and buffers were cut from the previous step's totals, so every
+    // tile kernel clamps itself to what it was given — surplus slots are empty, a halo is cut at the staged capacity, a tile
+    // whose slices would not fit the list buffer is skipped.  Results are then wrong, and the host (which compares the true
+    // totals with its prediction at the end of the step) discards the pass and repeats it with exact sizes.
+    uint32_t spec;              // 0: exact sizes (no clamping needed)
+    uint32_t halo_cap, bhalo_cap;   // slots a tile may stage
+    uint32_t nslices_cap;           // slices the list buffers hold
+    uint64_t halo_len, bhalo_len;   // entries of halo_src / bhalo_src
     TileGrid gf;
 
     // ---- boundary particles, cell-sorted order ----

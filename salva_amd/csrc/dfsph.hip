@@ -420,11 +420,22 @@ void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox_partials,
 // err = max over fluids of (sum of per-particle errors / nparticles)  (:153-158, :347-352).  One block,
 // fixed summation order => run-to-run deterministic iteration counts.
 // ------------------------------------------------------------------------------------------------
+// Publishes the control block to host-mapped memory after every test (`pub`, may be null): the host then learns the
+// outcome of a batch while the batch's last apply pass is still running, instead of after a copy + an idle round trip.
+__device__ __forceinline__ void publish_ctl(const SolveCtl* ctl, SolveCtl* pub, uint32_t seq) {
+    if (!pub) return;
+    pub->done = ctl->done; pub->iters = ctl->iters; pub->err = ctl->err;
+    __threadfence_system();
+    __hip_atomic_store(&pub->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ __launch_bounds__(BLOCK) void k_finalize_error(const float* __restrict__ partials, unsigned nblocks,
                                                           uint32_t nmodels, const uint32_t* __restrict__ model_counts,
-                                                          SolveCtl* ctl) {
+                                                          SolveCtl* ctl, SolveCtl* pub) {
     __shared__ float red[BLOCK / WAVE];
-    if (ctl->done) return;
+    if (ctl->done) {
+        if (threadIdx.x == 0) { const uint32_t s = ctl->seq + 1u; ctl->seq = s; publish_ctl(ctl, pub, s); }
+        return;
+    }
     float best = 0.0f;
     for (uint32_t m = 0; m < nmodels; ++m) {
         float s = 0.0f;
@@ -442,6 +453,9 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_error(const float* __restric
             ctl->iters = i + 1u;
             if (best <= ctl->tol && i >= ctl->min_iter) ctl->done = 1u;
         }
+        const uint32_t s = ctl->seq + 1u;
+        ctl->seq = s;
+        publish_ctl(ctl, pub, s);
     }
 }
 // multi-GPU: the same reduction split around an all-reduce over the ranks
@@ -481,8 +495,8 @@ void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_co
     k_decide<<<1, 64, 0, s>>>(sums, nmodels, model_counts, ctl);
 }
 void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
-                           SolveCtl* ctl, hipStream_t s) {
-    k_finalize_error<<<1, BLOCK, 0, s>>>(partials, nblocks, nmodels, model_counts, ctl);
+                           SolveCtl* ctl, SolveCtl* pub, hipStream_t s) {
+    k_finalize_error<<<1, BLOCK, 0, s>>>(partials, nblocks, nmodels, model_counts, ctl, pub);
 }
 
 }  // namespace salva

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uin
     t.setup(c);
     if (threadIdx.x == 0) slot_info[t.slot] = make_uint4(t.own_begin, t.own_end, t.slice_base, t.S | (t.SB << 16));
     TileCells tc;
-    tc.build(c, t);
+    tc.build(c, t, true);
     const int sub = threadIdx.x % 16, grp = threadIdx.x / 16;
     for (int h = grp; h < HCELLS; h += TABLE_THREADS / 16) {
         const uint32_t l0 = tc.lstart[h], cnt = tc.lstart[h + 1] - l0, g0 = tc.gstart[h];
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
         return;
     }
     TileCells tc;
-    tc.build(c, t);
+    tc.build(c, t, true);
     const bool multi = c.nmodels > 1;
     float4* Lp = t.carve<float4>(t.S);
     uint32_t* Lm = multi ? t.carve<uint32_t>(t.S) : nullptr;

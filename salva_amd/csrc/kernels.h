@@ -81,7 +81,7 @@ void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hip
 void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox_partials, int32_t* bbox6, hipStream_t s);
 // err = max_m (sum_b partials[b][m] / count[m]) -> ctl->err, then the break test of the solve (nblocks = ntiles)
 void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
-                           SolveCtl* ctl, hipStream_t s);
+                           SolveCtl* ctl, SolveCtl* pub, hipStream_t s);
 // multi-GPU form: per-fluid sums of this rank -> sums[nmodels]; (all-reduce over ranks); break test on the global sums
 void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmodels, const SolveCtl* ctl, float* sums, hipStream_t s);
 void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, hipStream_t s);

@@ -170,6 +170,15 @@ struct Tile {
         SB = (uint32_t)(a1.sb - a0.sb);
         hoff = c.halo_stride ? (uint64_t)slot * c.halo_stride : a0.s;
         hboff = c.halo_stride ? (uint64_t)slot * c.bhalo_stride : a0.sb;
+        if (c.spec) {  // speculative pass: stay inside what the host allocated (device_types.h)
+            S = min(S, c.halo_cap);
+            SB = min(SB, c.bhalo_cap);
+            if (!c.halo_stride) {
+                S = (uint32_t)min((uint64_t)S, c.halo_len > hoff ? c.halo_len - hoff : 0ull);
+                SB = (uint32_t)min((uint64_t)SB, c.bhalo_len > hboff ? c.bhalo_len - hboff : 0ull);
+            }
+            if (slot >= c.tile_rank[c.ntiles] || a1.nsl > c.nslices_cap) { own_end = own_begin; S = SB = 0; }
+        }
     }
 
     template <typename T>
@@ -333,7 +342,7 @@ struct TileCells {
     uint32_t *lstart, *gstart, *blstart, *bgstart;
 
     // tables live at the start of dynamic LDS; returns the number of bytes they occupy
-    __device__ __forceinline__ void build(const StepCtx& c, Tile& t) {
+    __device__ __forceinline__ void build(const StepCtx& c, Tile& t, bool clamp_to_staged = false) {
         uint32_t* tab = t.carve<uint32_t>(2 * (HCELLS + 1) + 2 * HCELLS);
         lstart = tab; gstart = tab + (HCELLS + 1); blstart = gstart + HCELLS; bgstart = blstart + (HCELLS + 1);
         const int h = threadIdx.x;
@@ -380,6 +389,13 @@ struct TileCells {
             if (l == HCELLS / PER - 1) { lstart[HCELLS] = ia; blstart[HCELLS] = ib; }
         }
         __syncthreads();
+        if (clamp_to_staged && c.spec) {  // speculative pass: no cell range may reach beyond the slots that were staged
+            for (int q = threadIdx.x; q <= HCELLS; q += blockDim.x) {
+                lstart[q] = min(lstart[q], t.S);
+                blstart[q] = min(blstart[q], t.SB);
+            }
+            __syncthreads();
+        }
     }
 };
 

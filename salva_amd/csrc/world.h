@@ -81,6 +81,7 @@ class World {
     // diagnostics (salva_hip_time_variant): time variant `variant` of k_pred_density; *checksum = FNV-1a of the kappa it wrote
     float time_variant(int variant, uint32_t param, int reps, uint64_t* checksum);
 
+    SalvaHipCounters counters{};  // the reference's Counters tree of the last step (counters/mod.rs:17-72)
     SalvaHipParams prm;
     SphConsts sc;
     std::vector<FluidSlot> fluids;
@@ -109,7 +110,7 @@ class World {
     void refresh_f32(float* field);
     void refresh_f4(float4* field);
     void ensure_particle_capacity(size_t cap);
-    void finalize_solve(SolveCtl* ctl);
+    void finalize_solve(SolveCtl* ctl, SolveCtl* pub);
 
     hipStream_t stream = nullptr;
     uint32_t n = 0, nb = 0;
@@ -143,6 +144,14 @@ class World {
     DevBuf<int32_t> bbox_partials;
     TileLds lds;
     PipeCfg pipe;          // launch shape of the persistent pipeline kernels of this step (pipe.h)
+    // speculative sizing (World::step): the previous step's table totals, and what the current pass lets the kernels use
+    TileAcc pred_tt{};
+    uint32_t pred_n = 0;
+    bool pred_valid = false, spec_mode = false;
+    uint32_t halo_cap = 0xffffffffu, bhalo_cap = 0xffffffffu, nslices_cap = 0xffffffffu;
+    uint64_t halo_len = ~0ull, bhalo_len = ~0ull;
+    uint64_t spec_misses = 0;  // passes discarded because the prediction did not hold
+    bool spec_off = true, spec_tight = false;  // SALVA_HIP_SPECULATE / SALVA_HIP_SPEC_TIGHT, read at construction
     int num_cus = 256;
     DevBuf<char> cub_temp;
     DevBuf<float> scratch_f;   // staging for AoS up/downloads and field unsorts
@@ -172,6 +181,7 @@ class World {
     Readback* h_rb = nullptr;
     DevBuf<SolveCtl> d_ctl;      // [0] divergence solve, [1] pressure solve, [2] viscosity solve (DFSPHViscosity)
     SolveCtl* h_ctl = nullptr;   // pinned: [0..NUM_SOLVES) read-back, [NUM_SOLVES..2 NUM_SOLVES) initial values
+    SolveCtl* h_pub = nullptr;   // host memory mapped into the device: k_finalize_error publishes every test's outcome here
 
     // The reference's solver buffers (velocity_changes, IISPH pressures) are positional per fluid SLOT and outlive the object:
     // remove_fluid swap-removes the fluid only, and the buffers are resized / truncated by the next init_with_fluids
@@ -189,6 +199,8 @@ class World {
     float last_dt = 0.0f;
     bool have_last_ctx = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t evc[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // Counters: fluids in grid, boundaries in grid, densities done, custom on / off
+    uint64_t spec_passes = 0;
     hipEvent_t ev_sync = nullptr;
 
     // ---- multi-GPU slab decomposition (comm.h / dist.h)

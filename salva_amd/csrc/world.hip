@@ -113,6 +113,12 @@ World::World(const SalvaHipParams& p) : prm(p) {
     const float h = p.particle_radius * p.smoothing_factor * 2.0f;
     sc = make_sph_consts(h);
     SALVA_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    // Speculative sizing is OFF unless asked for (SALVA_HIP_SPECULATE=1).  Measured on the bench scene (10^6 particles): it
+    // removes two ~20 us host round trips from a ~0.9 ms free-fall step (-2 %), but a failed prediction costs a whole extra
+    // step, and at the impact — where the halo and the lists grow for a dozen steps in a row — two passes in twenty were
+    // discarded, 2.25 ms per step against 1.88 ms without speculation.  Kept as an option for steady flows.
+    spec_off = getenv("SALVA_HIP_SPECULATE") == nullptr || getenv("SALVA_HIP_NO_SPECULATION") != nullptr;
+    spec_tight = getenv("SALVA_HIP_SPEC_TIGHT") != nullptr;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device) == hipSuccess && cus > 0) num_cus = cus;
@@ -121,11 +127,14 @@ World::World(const SalvaHipParams& p) : prm(p) {
     memset(h_rb, 0, sizeof(Readback));
     SALVA_HIP_CHECK(hipHostMalloc((void**)&h_ctl, 2 * NUM_SOLVES * sizeof(SolveCtl), hipHostMallocDefault));
     memset(h_ctl, 0, 2 * NUM_SOLVES * sizeof(SolveCtl));
+    SALVA_HIP_CHECK(hipHostMalloc((void**)&h_pub, NUM_SOLVES * sizeof(SolveCtl), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h_pub, 0, NUM_SOLVES * sizeof(SolveCtl));
     d_ctl.ensure(NUM_SOLVES);
     d_rb.ensure(1);
     d_flags.ensure(1);
     d_counters.ensure(4);
     for (auto& e2 : ev) SALVA_HIP_CHECK(hipEventCreate(&e2));
+    for (auto& e2 : evc) SALVA_HIP_CHECK(hipEventCreate(&e2));
     SALVA_HIP_CHECK(hipEventCreateWithFlags(&ev_sync, hipEventDisableTiming));
 }
 
@@ -134,7 +143,9 @@ World::~World() {
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
     if (h_rb) (void)hipHostFree(h_rb);
     if (h_ctl) (void)hipHostFree(h_ctl);
+    if (h_pub) (void)hipHostFree(h_pub);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : evc) if (e) (void)hipEventDestroy(e);
     if (ev_sync) (void)hipEventDestroy(ev_sync);
 }
 
@@ -588,6 +599,8 @@ StepCtx World::make_ctx() {
     c.halo_stride = halo_stride; c.bhalo_stride = bhalo_stride;
     c.ntiles = (uint32_t)gf.ntiles();
     c.tile_ids = tile_ids.p; c.tile_rank = tile_rank.p; c.nlaunch = nlaunch; c.slot_desc = slot_desc.p; c.slot_info = slot_info.p;
+    c.spec = spec_mode ? 1u : 0u; c.halo_cap = halo_cap; c.bhalo_cap = bhalo_cap; c.nslices_cap = nslices_cap;
+    c.halo_len = halo_len; c.bhalo_len = bhalo_len;
     c.gf = TileGrid{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], cell_start_f.p};
     c.nb = nb;
     c.bposv = bposv.p; c.bvel = bvel.p; c.bperm = bperm.p;
@@ -672,10 +685,15 @@ template <typename Eval, typename Apply>
 World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval,
                                     Apply&& apply) {
     SolveCtl& init = h_ctl[NUM_SOLVES + which];
-    init = SolveCtl{0u, 0u, 0.0f, tol, (uint32_t)std::max(min_iter, 0), mode, {0u, 0u}};
+    init = SolveCtl{0u, 0u, 0.0f, tol, (uint32_t)std::max(min_iter, 0), mode, 0u, 0u};
     h_ctl[which] = init;
     SALVA_HIP_CHECK(hipMemcpyAsync(d_ctl.p + which, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
     c.ctl = d_ctl.p + which;
+    // Single domain: every convergence test publishes its outcome to host-mapped memory, and the host waits for the test
+    // count it enqueued — it then decides (and enqueues what follows) while the batch's last apply pass is still running.
+    // Decomposed runs keep the copy + wait (their decision kernel runs behind an all-reduce).
+    SolveCtl* const pub = comm ? nullptr : h_pub + which;
+    if (pub) { pub->done = 0u; pub->iters = 0u; pub->err = 0.0f; __atomic_store_n(&pub->seq, 0u, __ATOMIC_RELEASE); }
     // First batch: what the previous step's solve needed (iters applies + the converged evaluate) — consecutive steps
     // need about the same, so the usual cost is one read-back per solve; a batch that overshoots only enqueues kernels
     // that return at once, one that falls short continues in doubling batches.
@@ -684,11 +702,24 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
         const int nbatch = std::min(batch, max_iter - i);
         for (int k = 0; k < nbatch; ++k) {
             eval(c, i + k);
-            finalize_solve(d_ctl.p + which);
+            finalize_solve(d_ctl.p + which, pub);
             apply(c, i + k);
         }
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_ctl[which], d_ctl.p + which, sizeof(SolveCtl), hipMemcpyDeviceToHost, stream));
-        wait_stream();
+        if (pub) {
+            const uint32_t expect = (uint32_t)(i + nbatch);
+            for (uint64_t spins = 0; __atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) < expect; ++spins) {
+                if ((spins & 0xfffffu) == 0xfffffu) {  // a fault on the stream would otherwise spin forever
+                    const hipError_t e = hipStreamQuery(stream);
+                    if (e != hipSuccess && e != hipErrorNotReady) SALVA_HIP_CHECK(e);
+                    if (e == hipSuccess && __atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) < expect)
+                        throw HipError(SALVA_HIP_E_HIP, "internal error: a solver batch finished without publishing its control block");
+                }
+            }
+            h_ctl[which].done = pub->done; h_ctl[which].iters = pub->iters; h_ctl[which].err = pub->err;
+        } else {
+            SALVA_HIP_CHECK(hipMemcpyAsync(&h_ctl[which], d_ctl.p + which, sizeof(SolveCtl), hipMemcpyDeviceToHost, stream));
+            wait_stream();
+        }
         i += nbatch;
         if (h_ctl[which].done) break;
         batch = (i <= 2) ? 4 : 8;
@@ -774,6 +805,8 @@ void World::run_forces(const StepCtx& c) {
 void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
     // divergence_solve (:466-503).  NOTE the dt lag: inv_dt is still the previous step's here (0 on the first step).
     const float inv_dt_lag = inv_dt_prev;
+    const bool timers = prm.enable_timers != 0;
+    if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[3], stream));  // counters.custom (:492)
     const SolveResult rd = run_solve(
         c, 0, prm.max_divergence_error * inv_dt_prev * 0.01f, prm.min_divergence_iter, prm.max_divergence_iter, 0u,
         [&](const StepCtx& cc, int) { launch_divergence(cc, lds, stream); },
@@ -783,6 +816,7 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
             launch_divergence_apply(cc, lds, inv_dt_lag, stream);
             if (comm) refresh_f4(w.p);
         });
+    if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[4], stream));  // :501
     st.n_divergence_iters = (int32_t)rd.iters;
     st.divergence_error = rd.err;
     launch_finish_divergence(c, g[0], g[1], g[2], acc_user, stream);  // update_velocities + dv = 0 + gravity
@@ -847,6 +881,11 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     use_device();
     SalvaHipStepStats st{};
     st.nparticles = n;
+    {   // self.counters.reset() (liquid_world.rs:73); the pass counters of this implementation are cumulative
+        const uint64_t sp = counters.speculative_passes, dp = counters.discarded_passes;
+        counters = SalvaHipCounters{};
+        counters.speculative_passes = sp; counters.discarded_passes = dp;
+    }
     sticky.clear();  // init_with_fluids runs at the top of every step, substeps or not (liquid_world.rs:76)
     // TimestepManager::is_done (timestep_manager.rs:56-58): no substep at all for dt <= eps
     if ((n == 0 && !comm) || !(dt > FLT_EPSILON)) {
@@ -856,7 +895,6 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     const bool timers = prm.enable_timers != 0;
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
     upload_tables();
-    SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));
 
     // ---- persistent particle arrays (double buffered for the sort)
     ensure_particle_capacity(n);
@@ -910,6 +948,23 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     const uint32_t ns_cap = n / WAVE + nslots_bound + 1;
     tile_list_stats.ensure(tile_list_stats_bytes(std::max<uint32_t>(nslots_bound, 1u)), stream, false, 1.5f);
 
+    // ---- One pass over the step.  The sizes of the tile tables (number of non-empty tiles, largest halo, slices) and the
+    // longest neighbour list are results of this step's own kernels; waiting for them costs two host round trips with an
+    // idle GPU.  When nothing forbids it the step is SPECULATIVE: launch shapes, LDS sizes and buffers are taken from the
+    // previous step's totals plus a margin, the kernels clamp themselves to what they were given, and the true totals are
+    // read back once, at the end, with everything else.  If they exceeded the prediction (rare: they change by a few
+    // slots per step) the step is simply run again from the untouched pre-sort buffers with exact sizes.
+    bool has_custom = false;
+    for (auto& f : fluids) for (auto& d : f.forces) has_custom |= d.kind == SALVA_HIP_FORCE_CUSTOM;
+    const bool can_speculate = !spec_off && !comm && !any_wants_forces && !has_custom && !b_dirty && pred_valid && pred_n == n;
+    int32_t bbox_pre[6];
+    memcpy(bbox_pre, h_rb->bbox, sizeof(bbox_pre));
+    const float dt_prev0 = dt_prev, inv_dt_prev0 = inv_dt_prev;
+    const int cur0 = cur;
+    StepCtx c{};
+    for (int attempt = 0;; ++attempt) {
+    bool spec = can_speculate && attempt == 0;
+    SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
     {
         TileGrid gv{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], nullptr};
@@ -921,14 +976,19 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         launch_reorder_fluid(n, idx[1].p, arrays(cur), arrays(cur ^ 1), w.p, stream);
         cur ^= 1;
         launch_cell_start(keys[1].p, n, (uint32_t)ncf, cell_start_f.p, stream);
+        if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[0], stream));
         if (acc_user && !comm) launch_gather_f4(n, perm[cur].p, st_acc.p, acc.p, stream);
         if (comm) dist_build_lists();
     }
     build_boundary_grid();  // insert_boundaries_to_grid (liquid_world.rs:106) + boundary volumes, only when dirty
+    if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[1], stream));
 
     // ---- tile tables: per-tile halo sizes / slice counts -> prefix -> flat halo slot tables
     nlaunch = 0;  // not known yet
-    StepCtx c = make_ctx();
+    spec_mode = false; halo_cap = bhalo_cap = 0xffffffffu; nslices_cap = 0xffffffffu; halo_len = bhalo_len = ~0ull;
+    c = make_ctx();
+    TileAcc tt{};  // the totals the launch shapes and buffers of this pass are cut for
+    uint32_t nslices = 0;
     {
         const size_t tb = std::max(scan_tiles_temp_bytes(nslots_bound + 1), scan_temp_bytes(ntiles + 1));
         ensure_cub_temp(tb);
@@ -936,27 +996,43 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         SALVA_HIP_CHECK(hipMemsetAsync(tile_cnt.p, 0, ((size_t)nslots_bound + 1) * sizeof(TileAcc), stream));
         launch_tile_count(c, nslots_bound, tile_cnt.p, slot_desc.p, stream);
         scan_tiles(cub_temp.p, tb, tile_cnt.p, tile_off.p, nslots_bound + 1, stream);
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + nslots_bound, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
-        wait_stream();
-        nlaunch = h_rb->tile_total.nonempty;
-        lds.max_halo_fluid = h_rb->tile_total.max_s;
-        lds.max_halo_boundary = h_rb->tile_total.max_sb;
+        if (spec) {
+            // previous totals + margin; the LDS must hold the padded halo (else: no speculation this step)
+            const TileAcc& l = pred_tt;
+            tt = l;
+            const uint32_t m = spec_tight ? 0u : 1u;  // (SALVA_HIP_SPEC_TIGHT: no margin at all — the tests' way to force misses)
+            tt.nonempty = std::min<uint32_t>(nslots_bound, l.nonempty + m * std::max<uint32_t>(16u, l.nonempty / 16u));
+            tt.max_s = (l.max_s + m * std::max<uint32_t>(32u, l.max_s / 16u) + m * 63u) & ~(m * 63u);
+            tt.max_sb = nb ? ((l.max_sb + m * std::max<uint32_t>(32u, l.max_sb / 8u) + m * 63u) & ~(m * 63u)) : 0u;
+            tt.nsl = std::min<uint32_t>(n / WAVE + nslots_bound + 1, l.nsl + m * std::max<uint32_t>(64u, l.nsl / 32u));
+            tt.s = l.s + m * (l.s / 8 + 4096); tt.sb = l.sb + m * (l.sb / 4 + 4096);
+            TileLds probe; probe.max_halo_fluid = tt.max_s; probe.max_halo_boundary = tt.max_sb;
+            if (probe.bytes(52, 32, 6) > 160u * 1024u || tt.max_s >= 65536u || tt.max_sb >= 65536u) spec = false;
+        }
+        if (!spec) {
+            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + nslots_bound, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
+            wait_stream();
+            tt = h_rb->tile_total;
+        }
+        nlaunch = tt.nonempty;
+        lds.max_halo_fluid = tt.max_s;
+        lds.max_halo_boundary = tt.max_sb;
         // one wave per 64-particle slice of the average non-empty tile (fuller tiles loop over their extra slices),
         // never fewer waves than the halo-table build needs threads
         {
-            const uint32_t avg = (n + h_rb->tile_total.nonempty - 1) / std::max<uint32_t>(h_rb->tile_total.nonempty, 1u);
-            const uint32_t lo = (HCELLS + WAVE - 1) / WAVE, hi = std::min<uint32_t>(std::max<uint32_t>(h_rb->tile_total.max_nsl, lo), (uint32_t)TILE_MAX_WAVES);
+            const uint32_t avg = (n + tt.nonempty - 1) / std::max<uint32_t>(tt.nonempty, 1u);
+            const uint32_t lo = (HCELLS + WAVE - 1) / WAVE, hi = std::min<uint32_t>(std::max<uint32_t>(tt.max_nsl, lo), (uint32_t)TILE_MAX_WAVES);
             lds.threads = WAVE * std::min<uint32_t>(std::max<uint32_t>((avg + WAVE - 1) / WAVE, lo), hi);
         }
         if (const char* e = getenv("SALVA_HIP_TILE_THREADS")) lds.threads = (uint32_t)atoi(e);
         if (lds.max_halo_fluid >= 65536u || lds.max_halo_boundary >= 65536u)
             throw HipError(SALVA_HIP_E_CAPACITY, "more than 65535 particles in one tile halo");
-        if (h_rb->tile_total.nsl > ns_cap) throw HipError(SALVA_HIP_E_HIP, "internal error: slice count exceeds its bound");
+        if (tt.nsl > ns_cap) throw HipError(SALVA_HIP_E_HIP, "internal error: slice count exceeds its bound");
         // slot tables: one fixed-stride row per tile when that costs at most ~3x the compact size (dense scenes), so
         // that a tile kernel can fetch its rows before it knows its sizes; compact rows otherwise (sparse scenes)
         {
             const uint64_t st_f = (lds.max_halo_fluid + 63u) & ~63u, st_b = nb ? ((lds.max_halo_boundary + 63u) & ~63u) : 0u;
-            const uint64_t strided = (uint64_t)nlaunch * (st_f + st_b), compact = h_rb->tile_total.s + h_rb->tile_total.sb;
+            const uint64_t strided = (uint64_t)nlaunch * (st_f + st_b), compact = tt.s + tt.sb;
             const bool use = strided <= 3 * compact + (1u << 20) && !getenv("SALVA_HIP_COMPACT_HALO");
             halo_stride = use ? (uint32_t)st_f : 0u;
             bhalo_stride = use ? (uint32_t)st_b : 0u;
@@ -968,52 +1044,83 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             pipe.sbcap = bhalo_stride;
             pipe.num_cus = (uint32_t)num_cus;
             pipe.nlaunch = nlaunch;
-            uint32_t waves = std::min<uint32_t>(std::max<uint32_t>(h_rb->tile_total.max_nsl, 4u), (uint32_t)PIPE_MAX_WAVES);
+            uint32_t waves = std::min<uint32_t>(std::max<uint32_t>(tt.max_nsl, 4u), (uint32_t)PIPE_MAX_WAVES);
             if (const char* e = getenv("SALVA_HIP_PIPE_WAVES")) waves = std::min<uint32_t>(std::max(atoi(e), 1), PIPE_MAX_WAVES);
             pipe.threads = waves * WAVE;
         }
-        const size_t need_f = halo_stride ? (size_t)nlaunch * halo_stride : (size_t)h_rb->tile_total.s;
-        const size_t need_b = halo_stride ? (size_t)nlaunch * bhalo_stride : (size_t)h_rb->tile_total.sb;
+        const size_t need_f = halo_stride ? (size_t)nlaunch * halo_stride : (size_t)tt.s;
+        const size_t need_b = halo_stride ? (size_t)nlaunch * bhalo_stride : (size_t)tt.sb;
         halo_src.ensure(need_f ? need_f : 1, stream, false, 1.2f);
         bhalo_src.ensure(need_b ? need_b : 1, stream, false, 1.2f);
+        nslices = tt.nsl;
+        if (spec) {  // what the kernels clamp themselves to (StepCtx::spec)
+            spec_mode = true;
+            halo_cap = lds.max_halo_fluid; bhalo_cap = lds.max_halo_boundary; nslices_cap = nslices;
+            halo_len = need_f; bhalo_len = need_b;
+        }
         c = make_ctx();
         launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, slot_info.p, stream);
 
         // ---- neighbour lists   (compute_contacts, contacts.rs:154-252): one pass into fixed-capacity ELL rows; if a list
         // turns out longer than the capacity the pass is repeated with room to spare (rare: the capacity follows the
-        // longest list seen so far)
-        const uint32_t nslices = h_rb->tile_total.nsl;
-        for (int attempt = 0;; ++attempt) {
+        // longest list seen so far).  Speculative passes check at the end of the step instead.
+        for (int nattempt = 0;; ++nattempt) {
             const bool r1 = nbr_ff.ensure((size_t)nslices * cap_ff * WAVE + 1, stream, false, 1.1f);
             const bool r2 = nbr_fb.ensure(nb ? (size_t)nslices * cap_fb * WAVE + 1 : 1, stream, false, 1.1f);
             (void)r1; (void)r2;
             c = make_ctx();
             launch_nbr_build(c, lds, tile_list_stats.p, d_counters.p, d_maxhalo.p, stream);
+            if (spec) break;
             SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, d_counters.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
             SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->max_cnt_ff, d_maxhalo.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             wait_stream();
             const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;
             if (need_ff <= cap_ff && need_fb <= cap_fb) break;
-            if (attempt >= 2) throw HipError(SALVA_HIP_E_HIP, "internal error: neighbour list capacity did not converge");
+            if (nattempt >= 2) throw HipError(SALVA_HIP_E_HIP, "internal error: neighbour list capacity did not converge");
             if (need_ff > cap_ff) cap_ff = need_ff + need_ff / 4 + 1;
             if (need_fb > cap_fb) cap_fb = need_fb + need_fb / 4 + 1;
         }
     }
-    st.ncontacts = h_rb->ncontacts_ff + (nb ? h_rb->ncontacts_fb : 0) + ncontacts_bb;
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
 
     // ---- solver   (evaluate_kernels + compute_densities + solver.step, liquid_world.rs:123-144)
     launch_density_alpha(c, lds, stream);
     if (comm) refresh_f32(rho.p);
+    if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[2], stream));
     if (prm.solver == SALVA_HIP_SOLVER_DFSPH) dfsph_solve(c, dt, g, st);
     else iisph_solve(c, dt, g, st);
-    acc_user = false;
 
-    // ---- end of step: next bbox + flags
+    // ---- end of step: next bbox + flags (+ in a speculative pass: the true table totals and list statistics)
     SALVA_HIP_CHECK(hipMemcpyAsync(h_rb->bbox, d_rb.p->bbox, sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->flags, d_flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (spec) {
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + nslots_bound, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, d_counters.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->max_cnt_ff, d_maxhalo.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    }
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[2], stream));
     wait_stream();
+    if (spec) {
+        const TileAcc& a = h_rb->tile_total;
+        const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;
+        const bool ok = a.nonempty <= tt.nonempty && a.max_s <= tt.max_s && a.max_sb <= tt.max_sb && a.nsl <= tt.nsl &&
+                        (halo_stride || (a.s <= tt.s && a.sb <= tt.sb)) && need_ff <= cap_ff && need_fb <= cap_fb;
+        if (!ok) {
+            // the prediction did not hold: everything this pass computed is discarded; the pre-sort buffers are intact
+            ++spec_misses; ++counters.speculative_passes; ++counters.discarded_passes;
+            cur = cur0; dt_prev = dt_prev0; inv_dt_prev = inv_dt_prev0;
+            memcpy(h_rb->bbox, bbox_pre, sizeof(bbox_pre));
+            if (need_ff > cap_ff) cap_ff = need_ff + need_ff / 4 + 1;
+            if (need_fb > cap_fb) cap_fb = need_fb + need_fb / 4 + 1;
+            continue;
+        }
+    }
+    if (spec) ++counters.speculative_passes;
+    pred_tt = h_rb->tile_total; pred_n = n; pred_valid = true;
+    break;
+    }  // attempts
+    acc_user = false;
+    st.ncontacts = h_rb->ncontacts_ff + (nb ? h_rb->ncontacts_fb : 0) + ncontacts_bb;
     bbox_known = true;
     last_ctx = c; last_ctx.ctl = nullptr; last_dt = dt; have_last_ctx = true;
     if (timers) {
@@ -1021,7 +1128,19 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         (void)hipEventElapsedTime(&a, ev[0], ev[1]);
         (void)hipEventElapsedTime(&b, ev[1], ev[2]);
         st.grid_ms = a; st.solver_ms = b; st.step_ms = a + b;
+        // the reference's tree (liquid_world.rs:73-156); every interval is taken on the world's stream
+        auto ms = [&](hipEvent_t from, hipEvent_t to) { float t = 0; (void)hipEventElapsedTime(&t, from, to); return (double)t; };
+        counters.step_time = a + b;
+        counters.stages.collision_detection_time = a;
+        counters.stages.solver_time = b;
+        counters.cd.grid_insertion_time = ms(ev[0], evc[1]);
+        counters.cd.neighborhood_search_time = ms(evc[1], ev[1]);
+        counters.solver.pressure_resolution_time = ms(evc[2], ev[2]);
+        if (prm.solver == SALVA_HIP_SOLVER_DFSPH) counters.custom = ms(evc[3], evc[4]);
     }
+    counters.nsubsteps = 1;
+    counters.cd.ncontacts = st.ncontacts;
+    counters.n_divergence_iters = st.n_divergence_iters; counters.n_pressure_iters = st.n_pressure_iters;
     st.reserved[0] = (float)lds.max_halo_fluid; st.reserved[1] = (float)lds.max_halo_boundary; st.reserved[2] = (float)lds.threads;
     st.reserved[3] = (float)((double)(h_rb->ncontacts_ff + (nb ? h_rb->ncontacts_fb : 0)) / (double)std::max<uint32_t>(n, 1u));  // list entries per local particle
     st.reserved[4] = (float)(n - owned_count());  // ghosts

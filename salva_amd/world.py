@@ -15,7 +15,7 @@ itself: everything goes through the C ABI, and importing it without the built li
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -494,9 +494,41 @@ class Boundary:
 
 
 @dataclass
+class StagesCounters:
+    """counters/stages_counters.rs:6-11 (ms)."""
+    collision_detection_time: float = 0.0
+    solver_time: float = 0.0
+
+
+@dataclass
+class CollisionDetectionCounters:
+    """counters/collision_detection_counters.rs:6-17 (ms)."""
+    ncontacts: int = 0
+    boundary_update_time: float = 0.0
+    grid_insertion_time: float = 0.0
+    neighborhood_search_time: float = 0.0
+    contact_sorting_time: float = 0.0
+
+
+@dataclass
+class SolverCounters:
+    """counters/solver_counters.rs:6-11 (ms)."""
+    non_pressure_resolution_time: float = 0.0
+    pressure_resolution_time: float = 0.0
+
+
+@dataclass
 class Counters:
-    """Subset of counters/mod.rs filled from the device step report."""
+    """counters/mod.rs:17-72: `world.counters.{nsubsteps, step_time, custom, stages, cd, solver}` as the reference's plugins read
+    them (times in ms), plus the flat fields of the device step report this mirror has always carried."""
     nsubsteps: int = 0
+    step_time: float = 0.0
+    custom: float = 0.0
+    stages: StagesCounters = field(default_factory=StagesCounters)
+    cd: CollisionDetectionCounters = field(default_factory=CollisionDetectionCounters)
+    solver: SolverCounters = field(default_factory=SolverCounters)
+    speculative_passes: int = 0
+    discarded_passes: int = 0
     ncontacts: int = 0
     n_divergence_iters: int = 0
     n_pressure_iters: int = 0
@@ -509,6 +541,9 @@ class Counters:
 
     def enable(self):
         self.enabled = True
+
+    def disable(self):
+        self.enabled = False
 
 
 class _ObjectSet:
@@ -771,6 +806,14 @@ class LiquidWorld:
         c.n_divergence_iters, c.n_pressure_iters = st.n_divergence_iters, st.n_pressure_iters
         c.divergence_error, c.density_error = st.divergence_error, st.density_error
         c.grid_ms, c.solver_ms, c.step_ms = st.grid_ms, st.solver_ms, st.step_ms
+        t = L.CountersStruct()
+        L.check(self._L.salva_hip_get_counters(self._h, C.byref(t)))
+        c.nsubsteps, c.step_time, c.custom = int(t.nsubsteps), t.step_time, t.custom
+        c.stages = StagesCounters(t.stages.collision_detection_time, t.stages.solver_time)
+        c.cd = CollisionDetectionCounters(int(t.cd.ncontacts), t.cd.boundary_update_time, t.cd.grid_insertion_time,
+                                          t.cd.neighborhood_search_time, t.cd.contact_sorting_time)
+        c.solver = SolverCounters(t.solver.non_pressure_resolution_time, t.solver.pressure_resolution_time)
+        c.speculative_passes, c.discarded_passes = int(t.speculative_passes), int(t.discarded_passes)
         return st
 
     # ---- host NonPressureForce::solve in the middle of the substep (SALVA_HIP_FORCE_CUSTOM)

@@ -1,0 +1,68 @@
+"""Speculative sizing of a step (World::step, opt-in with SALVA_HIP_SPECULATE=1): launch shapes, LDS sizes and buffers taken from the previous step's table totals,
+true totals checked once at the end, the pass repeated with exact sizes when the prediction failed.  Whatever happens, the
+results must be bit-identical to a world that waits for its table sizes in the middle of every step; and the `Counters` tree
+(counters/mod.rs:17-72) must be filled."""
+import os
+
+import numpy as np
+import pytest
+
+from parity import DT, GRAVITY, Scene
+from salva_amd import scenes
+
+pytestmark = pytest.mark.gpu
+R = 0.025
+
+
+def _dam_break():
+    s = Scene(R, 2.0, "dfsph")
+    fluid, shell = scenes.tank(16, 24, 16, R, wall_cells=12)
+    s.add_fluid(scenes.jitter(fluid, 0.05 * R, seed=3), None, 1000.0, forces=[("xsph", 0.5, 0.0)])
+    s.add_boundary(shell)
+    return s
+
+
+def _run(env, nsteps=50):
+    old = {k: os.environ.get(k) for k in ("SALVA_HIP_SPECULATE", "SALVA_HIP_NO_SPECULATION", "SALVA_HIP_SPEC_TIGHT")}
+    for k in old:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        w, (fl,), _ = _dam_break().make_hip()  # the switches are read when the world is created
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    iters = []
+    for _ in range(nsteps):
+        st = w.step(DT, GRAVITY)
+        iters.append((st.n_divergence_iters, st.n_pressure_iters, int(st.ncontacts)))
+    return w, fl, iters
+
+
+def test_speculative_steps_are_bit_identical_to_exact_ones():
+    w0, f0, it0 = _run({})
+    w1, f1, it1 = _run({"SALVA_HIP_SPECULATE": "1"})
+    w2, f2, it2 = _run({"SALVA_HIP_SPECULATE": "1", "SALVA_HIP_SPEC_TIGHT": "1"})  # zero margin: the halo of a collapsing column outgrows it all the time
+    assert w0.counters.speculative_passes == 0
+    assert w1.counters.speculative_passes >= 40, w1.counters
+    assert w2.counters.discarded_passes >= 3, w2.counters  # the redo path really ran
+    assert w1.counters.discarded_passes <= w2.counters.discarded_passes
+    for w, f, it in ((w1, f1, it1), (w2, f2, it2)):
+        assert it == it0
+        assert np.array_equal(f.positions, f0.positions) and np.array_equal(f.velocities, f0.velocities)
+        assert np.array_equal(w.velocity_changes(f), w0.velocity_changes(f0))
+
+
+def test_counters_tree_is_filled_like_the_reference():
+    w, fl, _ = _run({}, nsteps=4)
+    c = w.counters
+    assert c.nsubsteps == 1 and c.cd.ncontacts == c.ncontacts > 0
+    assert c.step_time > 0 and abs(c.stages.collision_detection_time + c.stages.solver_time - c.step_time) < 1e-3 * c.step_time + 1e-6
+    assert 0 < c.cd.grid_insertion_time < c.stages.collision_detection_time
+    assert 0 < c.cd.neighborhood_search_time < c.stages.collision_detection_time
+    assert 0 < c.custom < c.solver.pressure_resolution_time <= c.stages.solver_time
+    assert c.cd.boundary_update_time == 0 and c.cd.contact_sorting_time == 0 and c.solver.non_pressure_resolution_time == 0
+    st = w.step(1e-9, GRAVITY)  # dt <= eps: no substep at all (timestep_manager.rs:56-58)
+    assert w.counters.nsubsteps == 0 and st.ncontacts == 0
