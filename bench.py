@@ -1,15 +1,23 @@
 #!/usr/bin/env python
 """bench.py — particle-steps/s of the LiquidWorld::step hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W [--config {2,3,4}]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one `LiquidWorld::step(dt = 1/200, g = -9.81 y)` over the synthetic scene of BASELINE config[1]
-("3D DFSPH 1M particles, single fluid, XSPH viscosity, 1xMI355X", concretised in SURVEY.md §8d config 2 (A)):
-a 100^3 lattice block (spacing 2r, r = 0.025, h = 0.1, jitter +-0.1 r with LCG seed 42) resting in an open lattice
-tank (floor + 4 walls), rho0 = 1000, XSPHViscosity(0.5, 0), DFSPH defaults.  State is resident in HBM when the timed
-region starts; the timed region contains everything a step does (cell sort, neighbour lists, all solver passes,
-convergence read-backs) and nothing else.  One JSON line is printed by rank 0.
+A "step" is one `LiquidWorld::step(dt = 1/200, g = -9.81 y)`.  Default workload = BASELINE config[1] ("3D DFSPH 1M particles,
+single fluid, XSPH viscosity, 1xMI355X", concretised in SURVEY.md §8d config 2 (A)): a 100^3 lattice block (spacing 2r,
+r = 0.025, h = 0.1, jitter +-0.1 r with LCG seed 42) resting in an open lattice tank (floor + 4 walls), rho0 = 1000,
+XSPHViscosity(0.5, 0), DFSPH defaults.  `--config 3` (IISPH + Akinci2013(1.0, 10.0), same tank) and `--config 4` (two stacked
+10^6-particle fluids, rho0 1000 / 500, XSPH, DFSPH) emit the same line for the other single-GPU configurations; they are
+profiling aids, not the headline (N=1 default stays config 2).  State is resident in HBM when the timed region starts; the
+timed region contains everything a step does (cell sort, neighbour lists, all solver passes, convergence read-backs) and
+nothing else.  One JSON line is printed by rank 0.
+
+The scene changes regime while it runs: free fall and impact (divergence solve converges in ~4 iterations), then — from
+about step 24 — a compressed column whose divergence solve no longer converges within its 50-iteration cap (the oracle does
+the same).  `value` is the whole-run mean the contract asks for and therefore depends on --steps; `regimes` and
+`per_step_ms` / `iters` make that explicit: `first20` = the first 20 timed steps, `settled` = the timed steps whose
+divergence solve hit the cap.
 """
 import argparse
 import json
@@ -67,6 +75,57 @@ def make_world(fluid, shell, device: int):
     return w, f
 
 
+CONFIGS = {
+    2: dict(metric="particle-steps/sec (3D DFSPH)", solver="dfsph", kernel=(0, "k_pred_density", 52.0),
+            what="single fluid, XSPH viscosity, lattice block in open tank"),
+    3: dict(metric="particle-steps/sec (3D IISPH)", solver="iisph", kernel=(2, "k_iisph_next_pressure", 60.0),
+            what="single fluid, IISPH + Akinci2013 surface tension (1.0, 10.0), lattice block in open tank"),
+    4: dict(metric="particle-steps/sec (3D DFSPH, two-phase)", solver="dfsph", kernel=(0, "k_pred_density", 52.0),
+            what="two stacked fluids (rho0 1000 below, 500 above), XSPH viscosity each, in one open tank"),
+}
+
+
+def build_config(config: int, side: int):
+    """(list of (positions, density0), boundary positions) of a single-GPU configuration."""
+    if config == 4:
+        fluid, shell = scenes.tank(side, 2 * side, side, R)
+        fluid = scenes.jitter(fluid, 0.1 * R, seed=42)
+        mid = 0.5 * (float(fluid[:, 1].min()) + float(fluid[:, 1].max()))
+        return [(np.ascontiguousarray(fluid[fluid[:, 1] < mid]), 1000.0), (np.ascontiguousarray(fluid[fluid[:, 1] >= mid]), 500.0)], shell
+    fluid, shell = build_scene(side)
+    return [(fluid, 1000.0)], shell
+
+
+def make_config_world(config: int, fluids, shell, device: int):
+    from salva_amd import Akinci2013SurfaceTension, IISPHSolver
+
+    w = LiquidWorld(IISPHSolver() if CONFIGS[config]["solver"] == "iisph" else DFSPHSolver(), R, 2.0, device=device)
+    handles = []
+    for pos, rho0 in fluids:
+        f = Fluid(pos, R, rho0)
+        if config == 3:
+            f.nonpressure_forces.append(Akinci2013SurfaceTension(1.0, 10.0))
+        else:
+            f.nonpressure_forces.append(XSPHViscosity(0.5, 0.0))
+        handles.append(w.add_fluid(f))
+    w.add_boundary(Boundary(shell))
+    return w, handles
+
+
+def make_config_oracle(config: int, fluids, shell, threads: int):
+    from oracle import oracle as O
+
+    w = O.OracleWorld(R, 2.0, O.IISPH if CONFIGS[config]["solver"] == "iisph" else O.DFSPH, threads=threads, native=True)
+    for pos, rho0 in fluids:
+        fid = w.add_fluid(pos, rho0)
+        if config == 3:
+            w.add_akinci2013(fid, 1.0, 10.0)
+        else:
+            w.add_xsph(fid, 0.5, 0.0)
+    w.add_boundary(shell)
+    return w
+
+
 def committed_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*/hbm_traffic.json, written by
     tools/summarize_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same scene, with the
@@ -110,30 +169,40 @@ def effective_cores() -> int:
     return max(n, 1)
 
 
-def cpu_baseline(side: int, steps: int, warmup: int):
-    """The CPU oracle (C++ restatement of salva's CPU path, kind = "port") on a scaled-down copy of the same scene
-    (same spacing, tank, forces, dt, and the same warm-up + step count, so it goes through the same free-fall ->
-    impact regimes and iteration counts), all host cores."""
-    from oracle import oracle as O
-
-    fluid, shell = build_scene(side)
+def cpu_baseline(config: int, side: int, steps: int, warmup: int, gpu_step_ms, budget_s: float = 25.0):
+    """The CPU oracle (C++ restatement of salva's CPU path, kind = "port") on THE SAME scene at the same size: the same
+    warm-up steps, then as many of the same timed steps as fit the time budget (at least two), on all usable host cores, in the
+    -O3 -march=native timing build compiled on this machine (oracle/Makefile; same -ffp-contract=off, same results); then a
+    few more steps on ONE thread — the reference's default build is serial (`parallel` is opt-in, build/salva3d/Cargo.toml:17-20).
+    `gpu_same_steps` is the device's rate over exactly the steps the CPU timed, so the two can be compared like for like."""
+    fluids, shell = build_config(config, side)
+    n = sum(len(p) for p, _ in fluids)
     cores = effective_cores()
-    w = O.OracleWorld(R, 2.0, O.DFSPH, threads=cores)
-    fid = w.add_fluid(fluid, 1000.0)
-    w.add_xsph(fid, 0.5, 0.0)
-    w.add_boundary(shell)
-    nd = []
+    w = make_config_oracle(config, fluids, shell, cores)
     for _ in range(warmup):
         w.step(DT, GRAVITY)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    done, iters = 0, []
+    while done < steps and (done < 2 or time.perf_counter() - t0 < budget_s):
         st = w.step(DT, GRAVITY)
-        nd.append(st.n_div_iters)
-    dt = time.perf_counter() - t0
-    return {"value": len(fluid) * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{warmup}+{steps} steps of the same scene scaled to {side}^3 = {len(fluid)} fluid particles "
-                      f"(+{len(shell)} boundary), oracle/salva_oracle.cpp f32, OpenMP {cores} threads, "
-                      f"{dt:.1f} s, mean divergence iterations {float(np.mean(nd)):.1f}"}
+        iters.append((st.n_div_iters, st.n_press_iters))
+        done += 1
+    dt_all = time.perf_counter() - t0
+    w.set_threads(1)
+    t1 = time.perf_counter()
+    done1 = 0
+    while done1 < 1 or (time.perf_counter() - t1 < 0.4 * budget_s and done1 < 3):
+        w.step(DT, GRAVITY)
+        done1 += 1
+    dt_one = time.perf_counter() - t1
+    gpu_same = n * done / (sum(gpu_step_ms[:done]) * 1e-3) if len(gpu_step_ms) >= done and done else None
+    return {"value": n * done / dt_all, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": f"the bench scene itself ({n} fluid particles + {len(shell)} boundary): {warmup} warm-up steps, then the first "
+                      f"{done} of the {steps} timed steps in {dt_all:.1f} s, oracle/salva_oracle.cpp f32, -O3 -march=native, "
+                      f"OpenMP {cores} threads; (divergence, pressure) iterations {iters[0]} .. {iters[-1]}",
+            "steps": done, "gpu_same_steps": gpu_same,
+            "single_thread": {"value": n * done1 / dt_one, "unit": "particle-steps/s", "cores": 1,
+                              "sample": f"the {done1} step(s) after those, same build, 1 thread, {dt_one:.1f} s"}}
 
 
 def main():
@@ -141,9 +210,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)   # 5 warm-up + 50 timed steps
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE configuration (SURVEY.md §8d): 2 DFSPH + XSPH (headline, default), 3 IISPH + Akinci2013, 4 two-phase DFSPH")
     ap.add_argument("--side", type=int, default=100, help="particles per edge of the fluid block (100 -> 1M)")
-    ap.add_argument("--cpu-side", type=int, default=64, help="edge of the scaled-down block the CPU baseline runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host time for the multi-thread CPU leg")
     ap.add_argument("--force-slabs", action="store_true",
                     help="take the decomposed (RCCL transport) code path even with one rank; a self-test aid, not a bench mode")
     args = ap.parse_args()
@@ -161,10 +232,14 @@ def main():
 
     comm = None
     decomposed = world > 1 or args.force_slabs
+    cfg = CONFIGS[args.config]
+    if decomposed and args.config != 2:
+        raise SystemExit("the decomposed run is BASELINE config 5 = config 2 per GPU: use --config 2")
     if not decomposed:
-        fluid, shell = build_scene(args.side)
+        fluids, shell = build_config(args.config, args.side)
         nshell_total = len(shell)
-        w, f = make_world(fluid, shell, local_rank)
+        w, handles = make_config_world(args.config, fluids, shell, local_rank)
+        n = sum(len(p) for p, _ in fluids)
     else:
         # slab decomposition along x: RCCL point-to-point with the two neighbours + one tiny all-reduce per convergence test
         fluid, shell, my_slab, nshell_total = build_slab_scene(args.side, rank, world)
@@ -175,21 +250,26 @@ def main():
             dist.broadcast(idt, 0)
         comm = slab.Comm.rccl(rank, world, bytes(idt.cpu().numpy().tobytes()), local_rank)
         w, f = make_world(fluid, shell, local_rank)
+        handles = [f]
         w.set_domain(comm, my_slab[0], my_slab[1], rank * len(fluid))
-    n = len(fluid)
+        n = len(fluid)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    iters = []
+    iters, step_ms = [], []
     for _ in range(args.warmup):
         w.step(DT, GRAVITY)
     barrier()
     t0 = time.perf_counter()
+    tp = t0
     for _ in range(args.steps):
-        st = w.step(DT, GRAVITY)
+        st = w.step(DT, GRAVITY)  # returns when the step has completed on the device (its last read-back)
+        tn = time.perf_counter()
+        step_ms.append((tn - tp) * 1e3)
+        tp = tn
         iters.append((st.n_divergence_iters, st.n_pressure_iters, st.ncontacts, st.grid_ms, st.solver_ms))
     tile_stats = {"max_halo_fluid": int(st.reserved[0]), "max_halo_boundary": int(st.reserved[1]), "tile_threads": int(st.reserved[2]),
                   "ghost_particles": int(st.reserved[4])}
@@ -202,26 +282,39 @@ def main():
 
     # ---- roofline of the dominant neighbour-sum kernel, timed live with HIP events on the world's own stream
     it = np.asarray(iters, dtype=np.float64)
-    K = float(it[-1, 2]) / n  # mean directed contacts per fluid particle (ff + fb + bb) / N  ~ list entries per particle
-    kernel_us = w.time_pred_density(50)
+    kid, kname, sbytes = cfg["kernel"]
+    kernel_us = w.time_kernel(kid, 50)
     if not decomposed:
-        kbar = float(w.contact_counts(f).mean() + w.contact_counts(f, True).mean())
+        kbar = float(sum(w.contact_counts(h).sum() + w.contact_counts(h, True).sum() for h in handles)) / n
     else:  # host-order fields do not exist in a decomposed run: list entries per local particle, from the step report
         kbar = float(st.reserved[3])
-    algo_bytes = n * (4.0 * kbar + 52.0)  # k_pred_density moves N (4K + 52) bytes per launch
+    algo_bytes = n * (4.0 * kbar + sbytes)  # N (4K + S) bytes per launch
     achieved = algo_bytes / (kernel_us * 1e-6) / 1e9
-    traffic, traffic_src = committed_traffic("k_pred_density") if n == 1000000 else (None, None)
-    roofline = {"bound": "hbm", "kernel": "k_pred_density", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    traffic, traffic_src = committed_traffic(kname) if (n == 1000000 and args.config == 2) else (None, None)
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_us": kernel_us,
                 "algorithmic_bytes": algo_bytes, "mean_contacts": kbar}
 
     if rank == 0:
+        # ---- the regimes the run went through (see the docstring): rates over the first 20 timed steps and over the timed
+        # steps whose divergence solve ran into its iteration cap
+        sm = np.asarray(step_ms)
+        cap = float(getattr(w.solver, "max_divergence_iter", 50))
+        first = sm[:20]
+        settled = sm[it[:, 0] >= cap] if cfg["solver"] == "dfsph" else sm[:0]
+        regimes = {
+            "first20": {"steps": int(len(first)), "ms_per_step": float(first.mean()), "value": float(n * world / (first.mean() * 1e-3)),
+                        "mean_divergence_iters": float(it[:20, 0].mean())},
+            "settled": None if len(settled) == 0 else
+            {"steps": int(len(settled)), "ms_per_step": float(settled.mean()), "value": float(n * world / (settled.mean() * 1e-3)),
+             "what": f"timed steps whose divergence solve used all {int(cap)} iterations"},
+        }
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(args.cpu_side, args.steps, args.warmup)
+            cpu = cpu_baseline(args.config, args.side, args.steps, args.warmup, step_ms, args.cpu_budget)
         value = n * world * args.steps / elapsed
         out = {
-            "metric": "particle-steps/sec (3D DFSPH)",
+            "metric": cfg["metric"],
             "value": value,
             "unit": "particle-steps/s",
             "n_gpus": world,
@@ -234,8 +327,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"3D DFSPH {n * world} fluid particles (+{nshell_total} boundary), single fluid, XSPH viscosity, "
-                            f"lattice block in open tank, r=0.025 h=0.1 dt=1/200",
+                "workload": f"BASELINE config {args.config if not decomposed else 5}: 3D {cfg['solver'].upper()} {n * world} fluid particles "
+                            f"(+{nshell_total} boundary), {cfg['what']}, r=0.025 h=0.1 dt=1/200",
                 "particles_per_gpu": n,
                 "parallelism": "single domain" if not decomposed else
                 f"{world} x-slabs, one per GPU: RCCL send/recv of two ghost planes per face with the 2 neighbours (one exchange per "
@@ -248,6 +341,9 @@ def main():
                 "tiles": tile_stats,
                 "speculative_passes": int(w.counters.speculative_passes), "discarded_passes": int(w.counters.discarded_passes),
             },
+            "regimes": regimes,
+            "per_step_ms": [round(float(x), 4) for x in step_ms],
+            "iters": [[int(a), int(b)] for a, b in it[:, :2]],
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

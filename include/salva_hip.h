@@ -271,6 +271,10 @@ uint64_t salva_hip_device_bytes(const SalvaHipWorld* world);
  * the world's stream between two hipEvents and returns the average launch duration in microseconds
  * (negative on error).  State is not modified (the kernel rewrites the same outputs from the same inputs). */
 float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps);
+/* The same for the other neighbour-sum kernels bench.py reports a roofline for: `kernel` = 0 k_pred_density (DFSPH, N (4K + 52)
+ * algorithmic bytes), 1 k_divergence (N (4K + 48)), 2 k_iisph_next_pressure (IISPH, N (4K + 60)), 3 k_iisph_dij_pj (N (4K + 36))
+ * — SURVEY.md §8d.  The IISPH kernels rewrite scratch only (next pressures into the spare buffer). */
+float salva_hip_time_kernel(SalvaHipWorld* world, int32_t kernel, int32_t reps);
 /* `world.counters` after the last step — counters/mod.rs:17-72 */
 int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out);
 /* Diagnostics for kernel development (tools/variant_probe.py): times execution variant `variant` of the same kernel
@@ -307,6 +311,19 @@ int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* g
  * that entered the box's cells since then. */
 int64_t salva_hip_particles_intersecting_aabb(SalvaHipWorld* world, const float mins[3], const float maxs[3], uint64_t capacity,
                                              uint32_t* kinds, uint32_t* slots, uint32_t* indices);
+
+/* `LiquidWorld::particles_intersecting_shape(pos, shape)` (liquid_world.rs:245-280) for the analytic shapes the examples use
+ * (parry itself is out of scope): the particles in the grid cells the posed shape's AABB touches whose distance to the
+ * (solid) shape is <= the particle radius.  `rotation_ijkw` is the unit quaternion of the isometry.  Output and return value
+ * as salva_hip_particles_intersecting_aabb; like it, current positions are tested. */
+enum { SALVA_HIP_SHAPE_BALL = 1 /* params[0] = radius */, SALVA_HIP_SHAPE_CUBOID = 2 /* params = half extents */ };
+typedef struct SalvaHipShape {
+    int32_t kind;
+    float params[3];
+} SalvaHipShape;
+int64_t salva_hip_particles_intersecting_shape(SalvaHipWorld* world, const float translation[3], const float rotation_ijkw[4],
+                                              const SalvaHipShape* shape, uint64_t capacity, uint32_t* kinds, uint32_t* slots,
+                                              uint32_t* indices);
 
 /* `Fluid::add_particles(positions, velocities)` (object/fluid.rs:126-150): append to the fluid on the device — default
  * volume, zero acceleration and velocity change — without re-uploading the particles it already holds.

@@ -239,6 +239,23 @@ class LiquidWorld {  // liquid_world.rs
     Real h() const { return salva_hip_h(w_); }
     Real particle_radius() const { return particle_radius_; }
     const SalvaHipStepStats& counters() const { return stats_; }
+    // ParticleId of liquid_world.rs:211-280: (is_boundary, handle = slot, particle index)
+    struct ParticleId { bool boundary; size_t handle; uint32_t index; };
+    // LiquidWorld::particles_intersecting_aabb — liquid_world.rs:210-243
+    std::vector<ParticleId> particles_intersecting_aabb(const Vec3& mins, const Vec3& maxs) {
+        sync_for_query();
+        return run_query([&](uint64_t cap, uint32_t* k, uint32_t* s, uint32_t* i) {
+            return salva_hip_particles_intersecting_aabb(w_, mins.data(), maxs.data(), cap, k, s, i);
+        });
+    }
+    // LiquidWorld::particles_intersecting_shape for a ball / cuboid — liquid_world.rs:245-280
+    std::vector<ParticleId> particles_intersecting_shape(const Vec3& translation, const std::array<Real, 4>& rotation_ijkw,
+                                                         const SalvaHipShape& shape) {
+        sync_for_query();
+        return run_query([&](uint64_t cap, uint32_t* k, uint32_t* s, uint32_t* i) {
+            return salva_hip_particles_intersecting_shape(w_, translation.data(), rotation_ijkw.data(), &shape, cap, k, s, i);
+        });
+    }
     // `world.counters` of the reference (counters/mod.rs:17-72): nsubsteps, step_time, custom, stages, cd, solver
     SalvaHipCounters counters_tree() const {
         SalvaHipCounters c{};
@@ -246,6 +263,27 @@ class LiquidWorld {  // liquid_world.rs
         return c;
     }
 
+  private:
+    void sync_for_query() {  // a query is not a step: objects are uploaded, pending deletions stay pending
+        for (size_t s = 0; s < fluids_.size(); ++s) upload(fluids_[s], (uint32_t)s);
+        for (size_t s = 0; s < boundaries_.size(); ++s) upload(boundaries_[s], (uint32_t)s);
+    }
+    template <typename F>
+    std::vector<ParticleId> run_query(F&& call) {
+        std::vector<uint32_t> k(1024), s(1024), i(1024);
+        int64_t total;
+        for (;;) {
+            total = call((uint64_t)k.size(), k.data(), s.data(), i.data());
+            if (total < 0) check((int)total);
+            if ((size_t)total <= k.size()) break;
+            k.resize(total); s.resize(total); i.resize(total);
+        }
+        std::vector<ParticleId> out((size_t)total);
+        for (size_t q = 0; q < out.size(); ++q) out[q] = ParticleId{k[q] != 0, s[q], i[q]};
+        return out;
+    }
+
+  public:
     // LiquidWorld::step(dt, gravity) — liquid_world.rs:62-158
     void step(Real dt, const Vec3& gravity) {
         for (size_t s = 0; s < fluids_.size(); ++s) upload(fluids_[s], (uint32_t)s);

@@ -44,14 +44,21 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+def lib(native: bool = False):
+    """`native`: the -O3 -march=native timing build (oracle/Makefile), compiled on this machine on first use."""
+    global _libs
+    if native not in _libs:
+        path = _LIB_PATH
+        if native:
+            path = os.path.join(_HERE, "libsalva_oracle_native.so")
+            # always rebuilt: -march=native belongs to the host it was compiled on, and the file travels with the tree
+            subprocess.check_call(["make", "-C", _HERE, "-B", "libsalva_oracle_native.so"], stdout=subprocess.DEVNULL)
+        else:
+            build()
+        L = C.CDLL(path)
         vp, u64, u32, i32, f32, f64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float, C.c_double
         fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
         L.so_create.restype = vp
@@ -103,8 +110,8 @@ def lib():
             getattr(L, name).restype = f64
             getattr(L, name).argtypes = [f64, f64]
         L.so_max_threads.restype = i32
-        _lib = L
-    return _lib
+        _libs[native] = L
+    return _libs[native]
 
 
 FORCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -131,8 +138,8 @@ class OracleWorld:
                      "aii": 5, "pressures": 6, "he2014_colors": 7, "he2014_gradcs": 8}
 
     def __init__(self, particle_radius: float, smoothing_factor: float = 2.0, solver: int = DFSPH,
-                 f64: bool = False, threads: int = 1):
-        self._L = lib()
+                 f64: bool = False, threads: int = 1, native: bool = False):
+        self._L = lib(native)
         self._h = self._L.so_create(int(f64), particle_radius, smoothing_factor, solver, threads)
         self.f64 = f64
         self.last_stats = Stats()

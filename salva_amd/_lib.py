@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_particles_intersecting_aabb", "salva_hip_set_boundary_sampling", "salva_hip_update_boundary_pose",
     "salva_hip_get_boundary_particles", "salva_hip_get_boundary_wrench", "salva_hip_set_force_callback",
     "salva_hip_force_get_state", "salva_hip_force_add_accelerations", "salva_hip_set_fluid_field", "salva_hip_get_timestep",
-    "salva_hip_set_timestep", "salva_hip_time_variant", "salva_hip_get_counters",
+    "salva_hip_set_timestep", "salva_hip_time_variant", "salva_hip_get_counters", "salva_hip_time_kernel", "salva_hip_particles_intersecting_shape",
 ]
 
 
@@ -103,6 +103,14 @@ class CountersStruct(C.Structure):
     _fields_ = [("nsubsteps", C.c_uint64), ("step_time", C.c_double), ("custom", C.c_double), ("stages", _StagesCounters),
                 ("cd", _CollisionDetectionCounters), ("solver", _SolverCounters), ("n_divergence_iters", C.c_int32),
                 ("n_pressure_iters", C.c_int32), ("speculative_passes", C.c_uint64), ("discarded_passes", C.c_uint64)]
+
+
+class Shape(C.Structure):
+    """SalvaHipShape (include/salva_hip.h)."""
+    _fields_ = [("kind", C.c_int32), ("params", C.c_float * 3)]
+
+
+SHAPE_BALL, SHAPE_CUBOID = 1, 2
 
 
 class SalvaHipError(RuntimeError):
@@ -173,6 +181,10 @@ def lib():
     L.salva_hip_device_bytes.restype = u64
     L.salva_hip_time_pred_density.argtypes = [vp, i32]
     L.salva_hip_time_pred_density.restype = f32
+    L.salva_hip_particles_intersecting_shape.argtypes = [vp, fp, fp, C.POINTER(Shape), u64, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.salva_hip_particles_intersecting_shape.restype = C.c_int64
+    L.salva_hip_time_kernel.argtypes = [vp, i32, i32]
+    L.salva_hip_time_kernel.restype = f32
     L.salva_hip_get_counters.argtypes = [vp, C.POINTER(CountersStruct)]
     L.salva_hip_time_variant.argtypes = [vp, i32, u32, i32, C.POINTER(u64)]
     L.salva_hip_time_variant.restype = f32

@@ -270,6 +270,16 @@ float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps) {
     return rc == SALVA_HIP_OK ? us : (float)rc;
 }
 
+float salva_hip_time_kernel(SalvaHipWorld* world, int32_t kernel, int32_t reps) {
+    float us = -1.0f;
+    int rc = guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        us = world->w->time_kernel(kernel, reps);
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? us : (float)rc;
+}
+
 int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out) {
     return guarded([&]() -> int {
         if (!world || !out) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
@@ -353,6 +363,17 @@ int64_t salva_hip_particles_intersecting_aabb(SalvaHipWorld* world, const float 
     const int rc = guarded([&]() -> int {
         if (!world || !mins || !maxs) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
         total = (int64_t)world->w->particles_in_aabb(mins, maxs, capacity, kinds, slots, indices);
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? total : (int64_t)rc;
+}
+int64_t salva_hip_particles_intersecting_shape(SalvaHipWorld* world, const float translation[3], const float rotation_ijkw[4],
+                                              const SalvaHipShape* shape, uint64_t capacity, uint32_t* kinds, uint32_t* slots,
+                                              uint32_t* indices) {
+    int64_t total = 0;
+    const int rc = guarded([&]() -> int {
+        if (!world || !translation || !rotation_ijkw || !shape) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        total = (int64_t)world->w->particles_in_shape(translation, rotation_ijkw, *shape, capacity, kinds, slots, indices);
         return SALVA_HIP_OK;
     });
     return rc == SALVA_HIP_OK ? total : (int64_t)rc;

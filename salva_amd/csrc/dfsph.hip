@@ -195,7 +195,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
             const float coeff = -ki * pj.w * rho0 * g;
             const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
             d.x += ex; d.y += ey; d.z += ez;
-            if (c.bforce) {
+            if (c.bforce && !is_ghost(c, i)) {
                 const float fs = -inv_dt_prev * pi.w;  // delta * (-inv_dt * particle_mass) :404-406
                 apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), ex * fs, ey * fs, ez * fs);
             }
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
                 const float coeff = ki * pj.w * rho0 * inv_dt * g;
                 const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
                 d.x -= ex; d.y -= ey; d.z -= ez;
-                if (c.bforce) {
+                if (c.bforce && !is_ghost(c, i)) {
                     const float fs = inv_dt * pi.w;
                     apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), ex * fs, ey * fs, ez * fs);
                 }

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
                 const float sc = bc * wgt * pj.w * rho0 / ri;
                 const float ex = (vj.x - vi.x) * sc, ey = (vj.y - vi.y) * sc, ez = (vj.z - vi.z) * sc;
                 bx += ex; by += ey; bz += ez;
-                if (c.bforce) {
+                if (c.bforce && !is_ghost(c, i)) {
                     const float fs = -pi.w * inv_dt;  // delta * (-mi * inv_dt) :88-89
                     apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(vj.w), ex * fs, ey * fs, ez * fs);
                 }
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_artificial_viscosity(StepC
                     const float sc = g * (bc * (cs * alpha * mu - beta * mu * mu) * (pj.w * rho0 / ri));
                     bx += dx * sc; by += dy * sc; bz += dz * sc;
                     // the reference applies the *running sum* of the boundary acceleration here (:117)
-                    if (c.bforce)
+                    if (c.bforce && !is_ghost(c, i))
                         apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(vj.w), bx * -pi.w, by * -pi.w, bz * -pi.w);
                 }
             });
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, u
                 }
                 const float ex = dx * sc, ey = dy * sc, ez = dz * sc;
                 a.x -= ex; a.y -= ey; a.z -= ez;
-                if (c.bforce)
+                if (c.bforce && !is_ghost(c, i))
                     apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), ex * pi.w, ey * pi.w, ez * pi.w);
             });
         }
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_forces(StepCtx c, u
                 const float sc = g * (mi / ri * (pj.w * rho0) / rho0 * gi * bc * 0.25f);
                 const float ex = dx * sc, ey = dy * sc, ez = dz * sc;
                 a.x += ex / mi; a.y += ey / mi; a.z += ez / mi;
-                if (c.bforce) apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), -ex, -ey, -ez);
+                if (c.bforce && !is_ghost(c, i)) apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), -ex, -ey, -ez);
             });
         }
         c.acc[i] = a;

@@ -177,7 +177,13 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dij_pj(StepCtx c, fl
             x += dx * sc; y += dy * sc; z += dz * sc;
         });
         const float dt2 = dt * dt;
-        c.dijpj[i] = make_float4(x * dt2, y * dt2, z * dt2, 0.0f);
+        const float4 dp = make_float4(x * dt2, y * dt2, z * dt2, 0.0f);
+        c.dijpj[i] = dp;
+        // what particle i contributes as a NEIGHBOUR in compute_next_pressures (:318-321): d_ii p_i + sum_k d_ik p_k — one
+        // 16-byte record instead of d_ii, sum d_ij p_j and p staged separately (52 B per halo slot: one tile per CU)
+        const float4 di = c.dii[i];
+        const float pl = p[i];
+        c.iisph_q[i] = make_float4(di.x * pl + dp.x, di.y * pl + dp.y, di.z * pl + dp.z, 0.0f);
     });
 }
 void launch_iisph_dij_pj(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s) {
@@ -196,10 +202,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
     t.first_own(i0_, gs0_);
     const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
-    const float4* Ld = nullptr;
-    const float4* Lj = nullptr;
-    const float* Lq = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.dii), static_cast<const float4*>(c.dijpj), static_cast<const float*>(p), Lp, Ld, Lj, Lq);
+    const float4* Lq = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.iisph_q), Lp, Lq);
     const float4* Bp = nullptr;
     t.stage_boundary(c, Bp);
     TileErr E;
@@ -221,18 +225,17 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
                 const float4 dpi = c.dijpj[i];
                 const float fji = dt * dt * pi.w / (rhoi * rhoi);
                 float sum = 0.0f;
-                for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
-                    const float4 pj = Lp[s];
-                    const float4 dj = Ld[s];
-                    const float4 dpj = Lj[s];
-                    const float pjl = Lq[s];
+                struct Rec { float4 p, q; };
+                for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], Lq[s]}; }, [&](const Rec& rc) {
+                    const float4 pj = rc.p;
+                    const float4 qj = rc.q;  // d_jj p_j + sum_k d_jk p_k (k_iisph_dij_pj)
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                     const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
                     const float gx = dx * g, gy = dy * g, gz = dz * g;
-                    // factor = dij_pjl[i] - dii[j] p_j - (dij_pjl[j] - dji p_i)   (:318-321)
-                    const float fx = dpi.x - dj.x * pjl - (dpj.x - gx * fji * prs);
-                    const float fy = dpi.y - dj.y * pjl - (dpj.y - gy * fji * prs);
-                    const float fz = dpi.z - dj.z * pjl - (dpj.z - gz * fji * prs);
+                    // factor = dij_pjl[i] - dii[j] p_j - (dij_pjl[j] - dji p_i)   (:318-321), the two neighbour terms pre-added
+                    const float fx = (dpi.x - qj.x) + gx * fji * prs;
+                    const float fy = (dpi.y - qj.y) + gy * fji * prs;
+                    const float fz = (dpi.z - qj.z) + gz * fji * prs;
                     sum += pj.w * (fx * gx + fy * gy + fz * gz);
                 });
                 for_each_fb(c, t, i, gs, [&](uint32_t s) {
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
 }
 void launch_iisph_next_pressure(const StepCtx& c, const TileLds& L, float dt, float omega, const float* p, float* p_next,
                                 hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_iisph_next_pressure, c, L, L.bytes(52, 16, 5), s, c, dt, omega, p, p_next);
+    SALVA_LAUNCH_TILE(k_iisph_next_pressure, c, L, L.bytes(32, 16, 3), s, c, dt, omega, p, p_next);
 }
 
 // compute_velocity_changes (:355-404)
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(Ste
             const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (pj.w * rho0 * pri);
             const float ax = dx * sc, ay = dy * sc, az = dz * sc;
             d.x -= ax * dt; d.y -= ay * dt; d.z -= az * dt;
-            if (c.bforce)
+            if (c.bforce && !is_ghost(c, i))
                 apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), ax * pi.w, ay * pi.w, az * pi.w);
         });
         c.dv[i] = d;

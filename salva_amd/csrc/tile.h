@@ -714,7 +714,9 @@ struct TileErr {
 };
 
 // Boundary::apply_force (boundary.rs:62-67): forces accumulate in canonical boundary order.  `jb` is the sorted
-// boundary index (t.bgstart-relative lookups are done by the caller).
+// boundary index (t.bgstart-relative lookups are done by the caller).  Callers skip ghost particles (is_ghost): in a
+// decomposed run the boundary particles near a slab face exist on both ranks, and a reaction force belongs to the rank that
+// owns the fluid particle — summed over ranks the forces then equal the single-domain run's.
 __device__ __forceinline__ void apply_boundary_force(const StepCtx& c, uint32_t jb_sorted, uint32_t bmodel, float fx,
                                                      float fy, float fz) {
     if (c.bforce == nullptr || !c.bwants[bmodel]) return;

@@ -55,6 +55,8 @@ class World {
     uint64_t delete_particles(uint32_t slot, const uint8_t* mask);
     uint64_t particles_in_aabb(const float mins[3], const float maxs[3], uint64_t capacity, uint32_t* kinds, uint32_t* slots,
                                uint32_t* indices);
+    uint64_t particles_in_shape(const float t[3], const float q[4], const SalvaHipShape& shape, uint64_t capacity, uint32_t* kinds,
+                                uint32_t* slots, uint32_t* indices);
     void get_fluid(uint32_t slot, float* pos, float* vel);
     void get_force_stats(uint32_t slot, uint32_t force, int32_t* iters, float* err);
     uint64_t get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity);
@@ -78,6 +80,7 @@ class World {
     uint64_t get_owned(uint32_t cap, uint32_t* gids, float* pos, float* vel, uint32_t* models);
     uint32_t owned_count() const { return comm ? n_owned : n; }
     float time_pred_density(int reps);
+    float time_kernel(int kernel, int reps);
     // diagnostics (salva_hip_time_variant): time variant `variant` of k_pred_density; *checksum = FNV-1a of the kappa it wrote
     float time_variant(int variant, uint32_t param, int reps, uint64_t* checksum);
 
@@ -89,6 +92,8 @@ class World {
 
   private:
     void use_device() const;
+    uint64_t collect_query(unsigned int* d_count, uint32_t* d_kind, uint32_t* d_index, uint32_t cap, uint32_t* kinds, uint32_t* slots,
+                           uint32_t* indices);
     uint64_t fluid_offset(uint32_t slot) const;
     uint64_t boundary_offset(uint32_t slot) const;
     void ensure_staging_current();
@@ -125,7 +130,7 @@ class World {
     DevBuf<uint32_t> model[2], perm[2];
     int cur = 0;
     static constexpr int NUM_SOLVES = 3;  // divergence, pressure, viscosity
-    DevBuf<float4> acc, w, normal, dii, dijpj;
+    DevBuf<float4> acc, w, normal, dii, dijpj, iisph_q;
     DevBuf<float> visc_beta, visc_target;  // DFSPHViscosity scratch: betas [36][n], strain-rate targets [6][n]
     DevBuf<float4> visc_u0, visc_u1, visc_va;
     DevBuf<double> wrench_partial;       // per-block partial sums of salva_hip_get_boundary_wrench

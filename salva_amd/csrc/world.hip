@@ -592,7 +592,7 @@ StepCtx World::make_ctx() {
     c.posm = posm[cur].p; c.vel = vel[cur].p; c.dv = dv[cur].p; c.acc = acc.p; c.w = w.p; c.normal = normal.p;
     c.model = model[cur].p; c.perm = perm[cur].p; c.gtag = comm ? gtag[cur].p : nullptr;
     c.rho = rho.p; c.alpha = alpha.p; c.kappa = kappa.p; c.kappa2 = kappa2.p; c.rho_star = rho_star.p; c.aii = aii.p;
-    c.dii = dii.p; c.dijpj = dijpj.p;
+    c.dii = dii.p; c.dijpj = dijpj.p; c.iisph_q = iisph_q.p;
     c.nff = nff.p; c.nfb = nfb.p;
     c.nbr_ff = nbr_ff.p; c.nbr_fb = nbr_fb.p; c.cap_ff = cap_ff; c.cap_fb = cap_fb;
     c.tile_off = tile_off.p; c.halo_src = halo_src.p; c.bhalo_src = bhalo_src.p;
@@ -692,7 +692,8 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
     // Single domain: every convergence test publishes its outcome to host-mapped memory, and the host waits for the test
     // count it enqueued — it then decides (and enqueues what follows) while the batch's last apply pass is still running.
     // Decomposed runs keep the copy + wait (their decision kernel runs behind an all-reduce).
-    SolveCtl* const pub = comm ? nullptr : h_pub + which;
+    static const bool no_publish = getenv("SALVA_HIP_NO_PUBLISH") != nullptr;  // (diagnostics: A/B against the copy + wait)
+    SolveCtl* const pub = (comm || no_publish) ? nullptr : h_pub + which;
     if (pub) { pub->done = 0u; pub->iters = 0u; pub->err = 0.0f; __atomic_store_n(&pub->seq, 0u, __ATOMIC_RELEASE); }
     // First batch: what the previous step's solve needed (iters applies + the converged evaluate) — consecutive steps
     // need about the same, so the usual cost is one read-back per solve; a batch that overshoots only enqueues kernels
@@ -892,9 +893,13 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         if (stats) *stats = st;
         return SALVA_HIP_OK;
     }
+    if (comm && acc_user)
+        throw HipError(SALVA_HIP_E_INVALID, "host-set accelerations (SALVA_HIP_DIRTY_ACCELERATIONS) are not carried through the slab decomposition: "
+                                            "apply them as velocity changes, or use a single domain");
     const bool timers = prm.enable_timers != 0;
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
     upload_tables();
+    SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));
 
     // ---- persistent particle arrays (double buffered for the sort)
     ensure_particle_capacity(n);
@@ -918,7 +923,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     bool has_akinci = false;
     for (auto& f : fluids) for (auto& d : f.forces) has_akinci |= d.kind == SALVA_HIP_FORCE_AKINCI2013;
     if (has_akinci) normal.ensure(n, stream, false, 1.1f);
-    if (prm.solver == SALVA_HIP_SOLVER_IISPH) { kappa2.ensure(n); rho_star.ensure(n); aii.ensure(n); dii.ensure(n); dijpj.ensure(n); }
+    if (prm.solver == SALVA_HIP_SOLVER_IISPH) { kappa2.ensure(n); rho_star.ensure(n); aii.ensure(n); dii.ensure(n); dijpj.ensure(n); iisph_q.ensure(n); }
     bbox_partials.ensure(6 * std::max<size_t>(std::max<size_t>(num_blocks(n), bbox_blocks(n)), 1024));
 
     // ---- cell bounding box (known from the previous step's position update unless the host moved particles)
@@ -964,7 +969,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     StepCtx c{};
     for (int attempt = 0;; ++attempt) {
     bool spec = can_speculate && attempt == 0;
-    SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));
+    if (attempt > 0) SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));  // (whatever the discarded pass flagged)
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
     {
         TileGrid gv{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], nullptr};
@@ -1153,6 +1158,11 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         bbox_known = false;
         throw HipError(SALVA_HIP_E_HIP, "internal error: particle outside the cell table");
     }
+    if (h_rb->flags & 4u)
+        // k_dist_flags: such a particle was handed to the adjacent rank, which does not own its cells either — it would
+        // never be mirrored as a ghost and its contacts across the next face would be lost
+        throw HipError(SALVA_HIP_E_INVALID, "a particle moved across more than one slab in a single step (slabs too thin for this time step): "
+                                            "results of this step are not reliable");
     return SALVA_HIP_OK;
 }
 
@@ -1171,6 +1181,31 @@ __global__ __launch_bounds__(BLOCK) void k_aabb_query(const float4* __restrict__
     const uint32_t k = atomicAdd(counter, 1u);
     if (k < cap) { out_kind[k] = kind; out_index[k] = i; }
 }
+// (kind, global index) pairs collected on the device -> sorted (kind, slot, index-in-slot) triples on the host
+uint64_t World::collect_query(unsigned int* d_count, uint32_t* d_kind, uint32_t* d_index, uint32_t cap, uint32_t* kinds, uint32_t* slots,
+                              uint32_t* indices) {
+    unsigned int total = 0;
+    SALVA_HIP_CHECK(hipMemcpyAsync(&total, d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    const uint32_t m = std::min<uint32_t>(total, cap);
+    if (m == 0 || !kinds || !slots || !indices) return total;
+    std::vector<uint32_t> hk(m), hi_(m);
+    SALVA_HIP_CHECK(hipMemcpy(hk.data(), d_kind, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SALVA_HIP_CHECK(hipMemcpy(hi_.data(), d_index, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> keys(m);
+    for (uint32_t k = 0; k < m; ++k) keys[k] = ((uint64_t)hk[k] << 32) | hi_[k];
+    std::sort(keys.begin(), keys.end());
+    for (uint32_t k = 0; k < m; ++k) {
+        const uint32_t kind = (uint32_t)(keys[k] >> 32);
+        uint64_t g = keys[k] & 0xffffffffull;
+        uint32_t s = 0;
+        if (kind == 0) { while (s + 1 < fluids.size() && g >= fluids[s].n) { g -= fluids[s].n; ++s; } }
+        else { while (s + 1 < bounds.size() && g >= bounds[s].n) { g -= bounds[s].n; ++s; } }
+        kinds[k] = kind; slots[k] = s; indices[k] = (uint32_t)g;
+    }
+    return total;
+}
+
 uint64_t World::particles_in_aabb(const float mins[3], const float maxs[3], uint64_t capacity, uint32_t* kinds, uint32_t* slots,
                                   uint32_t* indices) {
     use_device();
@@ -1185,27 +1220,79 @@ uint64_t World::particles_in_aabb(const float mins[3], const float maxs[3], uint
     const float3 lo = make_float3(mins[0], mins[1], mins[2]), hi = make_float3(maxs[0], maxs[1], maxs[2]);
     if (n) k_aabb_query<<<nblk(n), BLOCK, 0, stream>>>(st_pos.p, n, lo, hi, r * r, 0u, cnt.p, cap, dk.p, di.p);
     if (nb) k_aabb_query<<<nblk(nb), BLOCK, 0, stream>>>(bst_pos.p, nb, lo, hi, r * r, 1u, cnt.p, cap, dk.p, di.p);
-    unsigned int total = 0;
-    SALVA_HIP_CHECK(hipMemcpyAsync(&total, cnt.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
-    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
-    const uint32_t m = std::min<uint32_t>(total, cap);
-    if (m == 0 || !kinds || !slots || !indices) return total;
-    std::vector<uint32_t> hk(m), hi_(m);
-    SALVA_HIP_CHECK(hipMemcpy(hk.data(), dk.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    SALVA_HIP_CHECK(hipMemcpy(hi_.data(), di.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    // (kind, global index) -> sorted, then split the global index into (slot, index inside the slot)
-    std::vector<uint64_t> keys(m);
-    for (uint32_t k = 0; k < m; ++k) keys[k] = ((uint64_t)hk[k] << 32) | hi_[k];
-    std::sort(keys.begin(), keys.end());
-    for (uint32_t k = 0; k < m; ++k) {
-        const uint32_t kind = (uint32_t)(keys[k] >> 32);
-        uint64_t g = keys[k] & 0xffffffffull;
-        uint32_t s = 0;
-        if (kind == 0) { while (s + 1 < fluids.size() && g >= fluids[s].n) { g -= fluids[s].n; ++s; } }
-        else { while (s + 1 < bounds.size() && g >= bounds[s].n) { g -= bounds[s].n; ++s; } }
-        kinds[k] = kind; slots[k] = s; indices[k] = (uint32_t)g;
+    return collect_query(cnt.p, dk.p, di.p, cap, kinds, slots, indices);
+}
+
+// LiquidWorld::particles_intersecting_shape (liquid_world.rs:245-280) for a ball / cuboid posed by (t, q): the particle must lie
+// in a grid cell the shape's world AABB touches (hgrid.cells_intersecting_aabb: cell range floor(mins / h) .. floor(maxs / h),
+// hgrid.rs:122-133) and `shape.distance_to_point(pos, pt, solid = true) <= particle_radius`.  The point goes into the shape's
+// frame with the inverse isometry (conjugate quaternion); ball: max(|p| - radius, 0); cuboid: |max(|p| - half_extents, 0)|.
+struct ShapeQuery {
+    float t[3], q[4];       // isometry
+    int kind; float p[3];   // shape
+    int clo[3], chi[3];     // cell range of the world AABB
+    float h, r;             // cell width, particle radius
+};
+__global__ __launch_bounds__(BLOCK) void k_shape_query(const float4* __restrict__ pos, uint32_t n, ShapeQuery s, uint32_t kind,
+                                                       unsigned int* __restrict__ counter, uint32_t cap, uint32_t* __restrict__ out_kind,
+                                                       uint32_t* __restrict__ out_index) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 pt = pos[i];
+    bool bad = false;
+    const int cx = cell_coord(pt.x, s.h, bad), cy = cell_coord(pt.y, s.h, bad), cz = cell_coord(pt.z, s.h, bad);
+    if (bad || cx < s.clo[0] || cx > s.chi[0] || cy < s.clo[1] || cy > s.chi[1] || cz < s.clo[2] || cz > s.chi[2]) return;
+    // inverse isometry: q^-1 * (pt - t)
+    const float vx = pt.x - s.t[0], vy = pt.y - s.t[1], vz = pt.z - s.t[2];
+    const float qx = -s.q[0], qy = -s.q[1], qz = -s.q[2], qw = s.q[3];
+    const float tx = (qy * vz - qz * vy) * 2.0f, ty = (qz * vx - qx * vz) * 2.0f, tz = (qx * vy - qy * vx) * 2.0f;
+    const float lx = vx + qw * tx + (qy * tz - qz * ty), ly = vy + qw * ty + (qz * tx - qx * tz), lz = vz + qw * tz + (qx * ty - qy * tx);
+    float d;
+    if (s.kind == SALVA_HIP_SHAPE_BALL) {
+        d = fmaxf(sqrtf(lx * lx + ly * ly + lz * lz) - s.p[0], 0.0f);
+    } else {
+        const float dx = fmaxf(fabsf(lx) - s.p[0], 0.0f), dy = fmaxf(fabsf(ly) - s.p[1], 0.0f), dz = fmaxf(fabsf(lz) - s.p[2], 0.0f);
+        d = sqrtf(dx * dx + dy * dy + dz * dz);
     }
-    return total;
+    if (!(d <= s.r)) return;
+    const uint32_t k = atomicAdd(counter, 1u);
+    if (k < cap) { out_kind[k] = kind; out_index[k] = i; }
+}
+uint64_t World::particles_in_shape(const float t[3], const float q[4], const SalvaHipShape& shape, uint64_t capacity, uint32_t* kinds,
+                                   uint32_t* slots, uint32_t* indices) {
+    use_device();
+    if (comm) throw HipError(SALVA_HIP_E_INVALID, "queries are not available in a multi-GPU run");
+    if (shape.kind != SALVA_HIP_SHAPE_BALL && shape.kind != SALVA_HIP_SHAPE_CUBOID)
+        throw HipError(SALVA_HIP_E_INVALID, "unknown shape kind (ball and cuboid are built in; other parry shapes belong to the host)");
+    ensure_staging_current();
+    ShapeQuery s{};
+    for (int a = 0; a < 3; ++a) { s.t[a] = t[a]; s.p[a] = shape.params[a]; }
+    for (int a = 0; a < 4; ++a) s.q[a] = q[a];
+    s.kind = shape.kind; s.h = sc.h; s.r = prm.particle_radius;
+    // world AABB (parry compute_aabb): ball: t +- radius; cuboid: t +- |R| half_extents
+    float ext[3];
+    if (shape.kind == SALVA_HIP_SHAPE_BALL) {
+        ext[0] = ext[1] = ext[2] = shape.params[0];
+    } else {
+        const float x = q[0], y = q[1], z = q[2], w = q[3];
+        const float Rm[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
+                                {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
+                                {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+        for (int a = 0; a < 3; ++a)
+            ext[a] = fabsf(Rm[a][0]) * shape.params[0] + fabsf(Rm[a][1]) * shape.params[1] + fabsf(Rm[a][2]) * shape.params[2];
+    }
+    for (int a = 0; a < 3; ++a) {
+        s.clo[a] = (int)floorf((t[a] - ext[a]) / sc.h);
+        s.chi[a] = (int)floorf((t[a] + ext[a]) / sc.h);
+    }
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(capacity, 0xfffffff0ull);
+    DevBuf<unsigned int> cnt;
+    DevBuf<uint32_t> dk, di;
+    cnt.ensure(1); dk.ensure(std::max(cap, 1u)); di.ensure(std::max(cap, 1u));
+    SALVA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(unsigned int), stream));
+    if (n) k_shape_query<<<nblk(n), BLOCK, 0, stream>>>(st_pos.p, n, s, 0u, cnt.p, cap, dk.p, di.p);
+    if (nb) k_shape_query<<<nblk(nb), BLOCK, 0, stream>>>(bst_pos.p, nb, s, 1u, cnt.p, cap, dk.p, di.p);
+    return collect_query(cnt.p, dk.p, di.p, cap, kinds, slots, indices);
 }
 
 // The contact lists of the last step (they describe the positions the step started from, as the reference's
@@ -1565,7 +1652,7 @@ uint64_t World::device_bytes() const {
         add(posm[k].bytes()); add(vel[k].bytes()); add(dv[k].bytes()); add(model[k].bytes()); add(perm[k].bytes());
         add(keys[k].bytes()); add(idx[k].bytes()); add(bkeys[k].bytes()); add(bidx[k].bytes());
     }
-    add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes());
+    add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes()); add(iisph_q.bytes());
     add(rho.bytes()); add(alpha.bytes()); add(kappa.bytes()); add(kappa2.bytes()); add(rho_star.bytes()); add(aii.bytes());
     add(visc_beta.bytes()); add(visc_target.bytes()); add(visc_u0.bytes()); add(visc_u1.bytes()); add(visc_va.bytes()); add(he_colors.bytes()); add(he_gradcs.bytes());
     add(nff.bytes()); add(nfb.bytes()); add(cell_start_f.bytes()); add(halo_src.bytes()); add(bhalo_src.bytes());
@@ -1614,6 +1701,36 @@ float World::time_pred_density(int reps) {
     return ms * 1000.0f / (float)reps;
 }
 
+
+// Average duration (microseconds) of one launch of a neighbour-sum kernel on the last step's lists (HIP events on the world's
+// stream): 0 k_pred_density, 1 k_divergence, 2 k_iisph_next_pressure, 3 k_iisph_dij_pj.  Scratch outputs only.
+float World::time_kernel(int kernel, int reps) {
+    use_device();
+    if (!have_last_ctx || !sorted_valid || n == 0) throw HipError(SALVA_HIP_E_INVALID, "no completed step to time");
+    if (kernel == 0) return time_pred_density(reps);
+    if (reps < 1) reps = 1;
+    const bool iisph = prm.solver == SALVA_HIP_SOLVER_IISPH;
+    if ((kernel == 2 || kernel == 3) && !iisph) throw HipError(SALVA_HIP_E_INVALID, "an IISPH kernel needs an IISPH world");
+    if (kernel == 1 && iisph) throw HipError(SALVA_HIP_E_INVALID, "k_divergence needs a DFSPH world");
+    StepCtx cd = last_ctx;
+    cd.ctl = nullptr;
+    auto launch = [&]() {
+        switch (kernel) {
+            case 1: launch_divergence(cd, lds, stream); break;
+            case 2: launch_iisph_next_pressure(cd, lds, last_dt, 0.5f, kappa.p, kappa2.p, stream); break;
+            case 3: launch_iisph_dij_pj(cd, lds, last_dt, kappa.p, stream); break;
+            default: throw HipError(SALVA_HIP_E_INVALID, "unknown kernel id");
+        }
+    };
+    launch();  // warm-up
+    SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
+    for (int r = 0; r < reps; ++r) launch();
+    SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    float ms = 0.0f;
+    SALVA_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    return ms * 1000.0f / (float)reps;
+}
 
 // Diagnostics: one variant of k_pred_density on the last step's state; the checksum of the kappa it wrote lets the
 // caller verify that all variants compute the same bits.

@@ -1009,6 +1009,37 @@ class LiquidWorld:
             out.append(("boundary" if k[q] else "fluid", owner, int(i[q])))
         return out
 
+    def particles_intersecting_shape(self, translation, rotation, shape):
+        """liquid_world.rs:245-280 for `shape` = ("ball", radius) or ("cuboid", (hx, hy, hz)) posed by the isometry
+        (translation, unit quaternion (i, j, k, w)): particles within the particle radius of the solid shape."""
+        self.sync_to_device(apply_removal=False)
+        sh = L.Shape()
+        if shape[0] == "ball":
+            sh.kind, sh.params[0] = L.SHAPE_BALL, float(shape[1])
+        elif shape[0] == "cuboid":
+            sh.kind = L.SHAPE_CUBOID
+            sh.params[:] = [float(x) for x in shape[1]]
+        else:
+            raise ValueError("built-in shapes: ('ball', radius), ('cuboid', half_extents)")
+        t = (C.c_float * 3)(*[float(x) for x in translation])
+        q = (C.c_float * 4)(*[float(x) for x in rotation])
+        u32p = C.POINTER(C.c_uint32)
+        cap = 1024
+        while True:
+            k, s, i = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+            total = int(self._L.salva_hip_particles_intersecting_shape(self._h, t, q, C.byref(sh), cap, k.ctypes.data_as(u32p),
+                                                                        s.ctypes.data_as(u32p), i.ctypes.data_as(u32p)))
+            if total < 0:
+                L.check(total)
+            if total <= cap:
+                break
+            cap = total
+        out = []
+        for j in range(total):
+            owner = self._boundaries._items[int(s[j])] if k[j] else self._fluids._items[int(s[j])]
+            out.append(("boundary" if k[j] else "fluid", owner, int(i[j])))
+        return out
+
     def device_bytes(self) -> int:
         return int(self._L.salva_hip_device_bytes(self._h))
 
@@ -1019,6 +1050,13 @@ class LiquidWorld:
         if us < 0:
             L.check(int(us))
         return us, int(cs.value)
+
+    def time_kernel(self, kernel: int, reps: int = 20) -> float:
+        """Average launch duration (us) of 0 k_pred_density, 1 k_divergence, 2 k_iisph_next_pressure, 3 k_iisph_dij_pj."""
+        us = float(self._L.salva_hip_time_kernel(self._h, kernel, reps))
+        if us < 0:
+            L.check(int(us))
+        return us
 
     def time_pred_density(self, reps: int = 20) -> float:
         """Average k_pred_density launch duration in microseconds (HIP events on the world's stream)."""

@@ -291,3 +291,66 @@ def test_rccl_transport_single_rank(hip_lib):
         _ = f.positions  # host-order access is replaced by owned()
     del w
     comm.destroy()
+
+
+def test_boundary_forces_sum_to_the_single_domain_ones(hip_lib):
+    """`boundary.forces` (Boundary::apply_force, boundary.rs:62-67) in a decomposed run: the tank's particles near the cut exist
+    on both ranks, and ghosts run through every kernel — each reaction force must nevertheless be counted exactly once (by
+    the rank that owns the fluid particle), so that the per-particle sums over the ranks equal the single-domain run's."""
+    pos, vel, bpos = make_scene()
+    nsteps, nranks = 6, 2
+
+    w = LiquidWorld(solver(), R, SF)
+    f = Fluid(pos, R, 1000.0)
+    f.velocities = vel
+    f.nonpressure_forces.append(XSPHViscosity(0.5, 0.3))
+    w.add_fluid(f)
+    b = w.add_boundary(Boundary(bpos, wants_forces=True))
+    for _ in range(nsteps):
+        w.step(DT, G)
+    ref = b.forces.astype(np.float64)
+
+    cx = dist.cell_x(pos, H)
+    slabs = dist.split_slabs(cx, nranks)
+    owner = dist.owner_of(cx, slabs)
+    comms = dist.Comm.loopback(nranks)
+    got = np.zeros_like(ref)
+    errors = [None] * nranks
+    lock = threading.Lock()
+    offsets = np.concatenate([[0], np.cumsum([(owner == r).sum() for r in range(nranks)])])
+
+    def rank_main(r):
+        try:
+            wr = LiquidWorld(solver(), R, SF)
+            mine = np.nonzero(owner == r)[0]
+            fr = Fluid(pos[mine], R, 1000.0)
+            fr.velocities = vel[mine]
+            fr.nonpressure_forces.append(XSPHViscosity(0.5, 0.3))
+            wr.add_fluid(fr)
+            sub = dist.boundary_subset(bpos, H, slabs[r], r, nranks)
+            br = wr.add_boundary(Boundary(bpos[sub], wants_forces=True))
+            wr.set_domain(comms[r], slabs[r][0], slabs[r][1], int(offsets[r]))
+            for _ in range(nsteps):
+                wr.step(DT, G)
+            with lock:
+                got[sub] += br.forces.astype(np.float64)
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    for c in comms:
+        c.destroy()
+    for e in errors:
+        if e is not None:
+            raise e
+    scale = np.abs(ref).max()
+    assert scale > 0
+    # the particles both ranks hold are the interesting ones
+    shared = np.intersect1d(dist.boundary_subset(bpos, H, slabs[0], 0, nranks), dist.boundary_subset(bpos, H, slabs[1], 1, nranks))
+    assert len(shared) > 50 and np.abs(ref[shared]).max() > 0.01 * scale
+    assert np.abs(got - ref).max() < 5e-3 * scale, f"summed boundary forces differ by {np.abs(got - ref).max() / scale:.2e} of the largest force"

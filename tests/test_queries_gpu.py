@@ -1,0 +1,63 @@
+"""LiquidWorld::particles_intersecting_shape (liquid_world.rs:245-280) for the built-in ball and cuboid against a numpy
+restatement: cells of the posed shape's AABB (hgrid.rs:122-133), then distance to the solid shape <= particle radius."""
+import numpy as np
+import pytest
+
+from salva_amd import Boundary, DFSPHSolver, Fluid, LiquidWorld, scenes
+
+pytestmark = pytest.mark.gpu
+R = 0.025
+H = 4 * R
+F = np.float32
+
+
+def quat_rotate(q, v):
+    qv = np.asarray(q[:3], np.float64)
+    t = 2.0 * np.cross(qv, v)
+    return v + q[3] * t + np.cross(qv, t)
+
+
+def reference(points, t, q, shape):
+    p = points.astype(np.float64)
+    conj = np.array([-q[0], -q[1], -q[2], q[3]], np.float64)
+    local = quat_rotate(conj, p - np.asarray(t, np.float64))
+    if shape[0] == "ball":
+        d = np.maximum(np.linalg.norm(local, axis=1) - shape[1], 0.0)
+        ext = np.full(3, shape[1])
+    else:
+        he = np.asarray(shape[1], np.float64)
+        d = np.linalg.norm(np.maximum(np.abs(local) - he, 0.0), axis=1)
+        Rm = np.stack([quat_rotate(np.asarray(q, np.float64), e) for e in np.eye(3)], axis=1)
+        ext = np.abs(Rm) @ he
+    cell = np.floor(points.astype(np.float64) / H)
+    lo, hi = np.floor((np.asarray(t) - ext) / H), np.floor((np.asarray(t) + ext) / H)
+    inside = ((cell >= lo) & (cell <= hi)).all(axis=1)
+    return d, inside
+
+
+@pytest.mark.parametrize("shape", [("ball", 0.22), ("cuboid", (0.3, 0.1, 0.2))])
+def test_shape_query_matches_the_reference_formula(shape):
+    pos = scenes.jitter(scenes.cube_fluid_positions(20, 20, 20, R), 0.3 * R, seed=9)
+    bpos = scenes.plane_lattice(30, 30, -0.55, R, -0.75, -0.75)
+    w = LiquidWorld(DFSPHSolver(), R, 2.0)
+    f = w.add_fluid(Fluid(pos, R, 1000.0))
+    b = w.add_boundary(Boundary(bpos))
+    t = np.array([0.13, -0.42, 0.05], F)
+    ang = 0.7
+    axis = np.array([1.0, 2.0, -0.5]) / np.linalg.norm([1.0, 2.0, -0.5])
+    q = np.concatenate([axis * np.sin(ang / 2), [np.cos(ang / 2)]]).astype(F)
+    got = w.particles_intersecting_shape(t, q, shape)
+    gf = sorted(i for kind, h, i in got if kind == "fluid" and h is f)
+    gb = sorted(i for kind, h, i in got if kind == "boundary" and h is b)
+    assert len(gf) + len(gb) == len(got)
+    for pts, g in ((pos, gf), (bpos, gb)):
+        d, inside = reference(pts, t, q, shape)
+        must = set(np.nonzero(inside & (d <= R * (1 - 1e-4)))[0].tolist())     # clearly inside the criterion
+        may = set(np.nonzero(inside & (d <= R * (1 + 1e-4)))[0].tolist())      # f32 rounding band
+        # a particle whose cell sits exactly on the AABB's cell range edge may differ by the rounding of the range itself
+        edge = set(np.nonzero(~inside & (d <= R * (1 + 1e-4)))[0].tolist())
+        assert must <= set(g) <= (may | edge), (len(must), len(g), len(may))
+        assert len(set(g) - may) <= 2
+    assert len(gf) > 100 and len(gb) > 10
+    # the AABB query the reference pairs it with still answers (liquid_world.rs:210-243)
+    assert len(w.particles_intersecting_aabb(t - 0.1, t + 0.1)) > 0
