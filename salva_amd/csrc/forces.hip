@@ -183,7 +183,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_normals(StepCtx c, 
             const float sc = same ? g * (pj.w / rj) : 0.0f;
             nx += dx * sc; ny += dy * sc; nz += dz * sc;
         });
-        c.normal[i] = make_float4(nx * c.sc.h, ny * c.sc.h, nz * c.sc.h, 0.0f);
+        // .w carries rho_i: the force pass then stages (position, mass) + (normal, density) = 32 bytes per halo slot and two
+        // tiles share a CU (36-40 bytes made it one: 127 us per launch at 10^6 particles)
+        c.normal[i] = make_float4(nx * c.sc.h, ny * c.sc.h, nz * c.sc.h, c.rho[i]);
     });
 }
 void launch_akinci_normals(const StepCtx& c, const TileLds& L, uint32_t model, hipStream_t s) {
@@ -216,9 +218,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, u
     t.first_own(i0_, gs0_);
     const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
     const float4* Lp = nullptr;
-    const float4* Ln = nullptr;
-    const float* Lr = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.normal), static_cast<const float*>(c.rho), Lp, Ln, Lr);
+    const float4* Ln = nullptr;  // (normal, density) — only meaningful for particles of `model`, the only ones used
+    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.normal), Lp, Ln);
     const uint32_t* Lm = nullptr;
     if (c.nmodels > 1) t.stage(c, static_cast<const uint32_t*>(c.model), Lm);
     const float4* Bp = nullptr;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, u
             for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
                 const float4 pj = Lp[s];
                 const float4 nj = Ln[s];
-                const float rj = Lr[s];
+                const float rj = nj.w;
                 const bool same = Lm ? (Lm[s] == model) : true;
                 if (same) {
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -279,7 +280,7 @@ void launch_akinci_forces(const StepCtx& c, const TileLds& L, uint32_t model, fl
     const float cnorm = (float)(32.0 / (3.14159265358979323846 * pow(h, 9)));
     const float h6_64 = (float)(pow(h, 6) / 64.0);
     const float anorm = (float)(0.007 / pow(h, 3.25));
-    SALVA_LAUNCH_TILE(k_akinci_forces, c, L, L.bytes(40, 32, 6), s, c, model, tension, adhesion, cnorm, h6_64, anorm);
+    SALVA_LAUNCH_TILE(k_akinci_forces, c, L, L.bytes(36, 32, 5), s, c, model, tension, adhesion, cnorm, h6_64, anorm);
 }
 
 // ------------------------------------------------------------------------------------------------ He et al. 2014
