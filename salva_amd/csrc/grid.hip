@@ -292,11 +292,11 @@ __global__ __launch_bounds__(BLOCK) void k_export_contacts(StepCtx c, const uint
     const TileAcc a0 = c.tile_off[slot_t];
     const uint32_t gs = a0.nsl + (i - own_begin) / WAVE, lane = (i - own_begin) % WAVE;
     const uint32_t cap = boundary ? c.cap_fb : c.cap_ff;
-    const uint32_t* __restrict__ p = (boundary ? c.nbr_fb : c.nbr_ff) + (size_t)gs * cap * WAVE + lane;
+    const uint32_t* __restrict__ p = (boundary ? c.nbr_fb : c.nbr_ff) + (size_t)gs * cap * WAVE + 4u * lane;
     const uint64_t hoff = boundary ? (c.halo_stride ? (uint64_t)slot_t * c.bhalo_stride : a0.sb)
                                    : (c.halo_stride ? (uint64_t)slot_t * c.halo_stride : a0.s);
     for (uint32_t k = 0; k < cnt; ++k) {
-        const uint32_t d = p[(size_t)(k >> 1) * WAVE];
+        const uint32_t d = p[ellq(k >> 1)];
         const uint32_t s = (k & 1u) ? (d >> 16) : (d & 0xffffu);
         if (boundary) {
             const uint32_t g = c.bhalo_src[hoff + s];
@@ -430,14 +430,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         uint32_t cnt = 0, cntb = 0;
         uint32_t self_slot = 0;
-        uint32_t* __restrict__ out = c.nbr_ff + (size_t)gs * c.cap_ff * WAVE + lane;
+        uint32_t* __restrict__ out = c.nbr_ff + (size_t)gs * c.cap_ff * WAVE + 4u * lane;
         if (active) {
         const float4 pi = c.posm[i];
         const uint32_t mi = c.model[i];
         bool bad = false;
         const int lx = cell_coord(pi.x, c.sc.h, bad) - t.hcx, ly = cell_coord(pi.y, c.sc.h, bad) - t.hcy,
                   lz = cell_coord(pi.z, c.sc.h, bad) - t.hcz;
-        uint32_t* __restrict__ outb = c.nbr_fb + (size_t)gs * c.cap_fb * WAVE + lane;
+        uint32_t* __restrict__ outb = c.nbr_fb + (size_t)gs * c.cap_fb * WAVE + 4u * lane;
         uint32_t pend = 0, pendb = 0;
 #pragma unroll 1
         for (int dx = -1; dx <= 1; ++dx) {
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
                     const float4 pj = Lp[s];
                     const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
                     if (d2 <= c.sc.h2 && (!multi || c.ff_ok[mi * c.nmodels + Lm[s]])) {
-                        if (cnt & 1u) { if ((cnt >> 1) < c.cap_ff) out[(size_t)(cnt >> 1) * WAVE] = pend | (s << 16); }
+                        if (cnt & 1u) { if ((cnt >> 1) < c.cap_ff) out[ellq(cnt >> 1)] = pend | (s << 16); }
                         else pend = s;
                         ++cnt;
                     }
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
                         const float4 pj = Bp[s];
                         const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
                         if (d2 <= c.sc.h2 && c.fb_ok[mi * c.nbmodels + __float_as_uint(Bv[s].w)]) {
-                            if (cntb & 1u) { if ((cntb >> 1) < c.cap_fb) outb[(size_t)(cntb >> 1) * WAVE] = pendb | (s << 16); }
+                            if (cntb & 1u) { if ((cntb >> 1) < c.cap_fb) outb[ellq(cntb >> 1)] = pendb | (s << 16); }
                             else pendb = s;
                             ++cntb;
                         }
@@ -471,8 +471,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
         // an odd list is padded with the particle's own slot (for_each_ff2: the self contact adds nothing to gradient sums)
         const int hself = (lx * HY + ly) * HZ + lz;
         self_slot = tc.lstart[hself] + (i - tc.gstart[hself]);
-        if ((cnt & 1u) && (cnt >> 1) < c.cap_ff) out[(size_t)(cnt >> 1) * WAVE] = pend | (self_slot << 16);
-        if ((cntb & 1u) && (cntb >> 1) < c.cap_fb) outb[(size_t)(cntb >> 1) * WAVE] = pendb;
+        if ((cnt & 1u) && (cnt >> 1) < c.cap_ff) out[ellq(cnt >> 1)] = pend | (self_slot << 16);
+        if ((cntb & 1u) && (cntb >> 1) < c.cap_fb) outb[ellq(cntb >> 1)] = pendb;
         c.nff[i] = cnt;
         c.nfb[i] = cntb;
         sum_ff += cnt; sum_fb += cntb;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
         const uint32_t nq_max = min(wave_max_u32(nq), c.cap_ff);
         if (active) {
             const uint32_t pad = self_slot | (self_slot << 16);
-            for (uint32_t q = nq; q < nq_max; ++q) out[(size_t)q * WAVE] = pad;
+            for (uint32_t q = nq; q < nq_max; ++q) out[ellq(q)] = pad;
         }
     });
     // per-tile statistics (integer, order independent)

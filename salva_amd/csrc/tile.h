@@ -32,6 +32,12 @@ constexpr int TILE_MAX_THREADS = TILE_MAX_WAVES * WAVE; // tile, clamped to [4, 
 
 __host__ __device__ inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
+// ELL layout of a slice's list block (cap dwords per lane, cap a multiple of 4): dword q of lane l lives at
+// ((q >> 2) * WAVE + l) * 4 + (q & 3) — four consecutive dwords of a lane are contiguous, so a list head goes to registers
+// with 16-byte loads: 5 VMEM instructions per lane instead of 20, and the issue of those (~70 cycles each, measured) sits
+// on every tile's critical path before the staging barrier.  With p = block + 4 * lane, dword q is p[ellq(q)].
+__host__ __device__ inline uint32_t ellq(uint32_t q) { return (q >> 2) * (4u * (uint32_t)WAVE) + (q & 3u); }
+
 constexpr uint32_t TILE_TABLE_BYTES = 4 * (2 * (HCELLS + 1) + 2 * HCELLS) + 16;
 
 // Launch geometry / dynamic-LDS budget of the tile kernels of one step: staged arrays are sized for the largest
@@ -407,14 +413,14 @@ template <typename L, typename C>
 __device__ __forceinline__ void for_each_slot(const uint32_t* __restrict__ nbr, uint32_t cap, uint32_t gslice,
                                               uint32_t cnt, L&& load, C&& compute) {
     if (cnt == 0) return;
-    const uint32_t* __restrict__ p = nbr + (size_t)gslice * cap * WAVE + (threadIdx.x & (WAVE - 1));
+    const uint32_t* __restrict__ p = nbr + (size_t)gslice * cap * WAVE + 4u * (threadIdx.x & (WAVE - 1));
     const uint32_t nq = (cnt + 1) >> 1;
     uint32_t q = 0;
-    uint32_t n0 = p[0], n1 = (nq > 1) ? p[WAVE] : 0u;
+    uint32_t n0 = p[0], n1 = (nq > 1) ? p[ellq(1)] : 0u;
     for (; q + 2 <= nq; q += 2) {
         const uint32_t a = n0, b = n1;
-        if (q + 2 < nq) n0 = p[(size_t)(q + 2) * WAVE];
-        if (q + 3 < nq) n1 = p[(size_t)(q + 3) * WAVE];
+        if (q + 2 < nq) n0 = p[ellq(q + 2)];
+        if (q + 3 < nq) n1 = p[ellq(q + 3)];
         const auto d0 = load(a & 0xffffu);
         const auto d1 = load(a >> 16);
         const auto d2 = load(b & 0xffffu);
@@ -436,21 +442,21 @@ __device__ __forceinline__ void for_each_slot(const uint32_t* __restrict__ nbr, 
 // slice is allocated, so the read is always in bounds; its content is ignored when the list is shorter)
 struct ListHead { uint32_t n0, n1; };
 __device__ __forceinline__ ListHead list_head(const StepCtx& c, uint32_t gslice) {
-    const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
-    return ListHead{p[0], p[WAVE]};
+    const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + 4u * (threadIdx.x & (WAVE - 1));
+    return ListHead{p[0], p[ellq(1)]};
 }
 template <typename L, typename C>
 __device__ __forceinline__ void for_each_ff(const StepCtx& c, uint32_t gslice, uint32_t cnt, const ListHead& lh, L&& load,
                                             C&& compute) {
     if (cnt == 0) return;
-    const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
+    const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + 4u * (threadIdx.x & (WAVE - 1));
     const uint32_t nq = (cnt + 1) >> 1;
     uint32_t q = 0;
     uint32_t n0 = lh.n0, n1 = lh.n1;
     for (; q + 2 <= nq; q += 2) {
         const uint32_t a = n0, b = n1;
-        if (q + 2 < nq) n0 = p[(size_t)(q + 2) * WAVE];
-        if (q + 3 < nq) n1 = p[(size_t)(q + 3) * WAVE];
+        if (q + 2 < nq) n0 = p[ellq(q + 2)];
+        if (q + 3 < nq) n1 = p[ellq(q + 3)];
         const auto d0 = load(a & 0xffffu);
         const auto d1 = load(a >> 16);
         const auto d2 = load(b & 0xffffu);
@@ -478,10 +484,15 @@ __device__ __forceinline__ void for_each_ff(const StepCtx& c, uint32_t gslice, u
 constexpr int LIST_REGS = 20;
 struct ListRegs { uint32_t d[LIST_REGS]; };
 __device__ __forceinline__ ListRegs list_regs(const StepCtx& c, uint32_t gslice) {
-    const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
+    const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + 4u * (threadIdx.x & (WAVE - 1));
+    static_assert(LIST_REGS % 4 == 0, "the list head is fetched in 16-byte pieces");
+    const uint4* __restrict__ p4 = reinterpret_cast<const uint4*>(p);
     ListRegs r;
 #pragma unroll
-    for (int k = 0; k < LIST_REGS; ++k) r.d[k] = p[(size_t)k * WAVE];
+    for (int k = 0; k < LIST_REGS / 4; ++k) {
+        const uint4 v = p4[(size_t)k * WAVE];
+        r.d[4 * k] = v.x; r.d[4 * k + 1] = v.y; r.d[4 * k + 2] = v.z; r.d[4 * k + 3] = v.w;
+    }
     return r;
 }
 // `nq` = dwords of the longest list in the slice (slice_list_dwords below): wave-uniform, so every branch here is scalar.
@@ -510,19 +521,19 @@ __device__ __forceinline__ void for_each_ff4(const StepCtx& c, uint32_t gslice, 
         }
     }
     if (nq > (uint32_t)LIST_REGS) {
-        const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
+        const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + 4u * (threadIdx.x & (WAVE - 1));
         if (AHEAD) {
-            uint32_t nx = p[(size_t)LIST_REGS * WAVE];
+            uint32_t nx = p[ellq(LIST_REGS)];
             for (uint32_t q = LIST_REGS; q < nq; ++q) {
                 const uint32_t a = nx;
-                if (q + 1 < nq) nx = p[(size_t)(q + 1) * WAVE];
+                if (q + 1 < nq) nx = p[ellq(q + 1)];
                 const auto d0 = load(a & 0xffffu);
                 const auto d1 = load(a >> 16);
                 compute2(d0, d1);
             }
         } else {
             for (uint32_t q = LIST_REGS; q < nq; ++q) {
-                const uint32_t a = p[(size_t)q * WAVE];
+                const uint32_t a = p[ellq(q)];
                 const auto d0 = load(a & 0xffffu);
                 const auto d1 = load(a >> 16);
                 compute2(d0, d1);
@@ -565,19 +576,19 @@ __device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, 
         }
     }
     if (nq > (uint32_t)LIST_REGS) {  // unusually long lists: the rest comes from memory, one dword ahead
-        const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
+        const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + 4u * (threadIdx.x & (WAVE - 1));
         if (AHEAD) {
-            uint32_t nx = p[(size_t)LIST_REGS * WAVE];
+            uint32_t nx = p[ellq(LIST_REGS)];
             for (uint32_t q = LIST_REGS; q < nq; ++q) {
                 const uint32_t a = nx;
-                if (q + 1 < nq) nx = p[(size_t)(q + 1) * WAVE];
+                if (q + 1 < nq) nx = p[ellq(q + 1)];
                 const auto d0 = load(a & 0xffffu);
                 const auto d1 = load(a >> 16);
                 compute2(d0, d1);
             }
         } else {
             for (uint32_t q = LIST_REGS; q < nq; ++q) {
-                const uint32_t a = p[(size_t)q * WAVE];
+                const uint32_t a = p[ellq(q)];
                 const auto d0 = load(a & 0xffffu);
                 const auto d1 = load(a >> 16);
                 compute2(d0, d1);
@@ -587,14 +598,19 @@ __device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, 
 }
 // The first FB_REGS dwords of a particle's fluid-boundary list, loadable before the staging barrier like ListRegs (every
 // ELL row has cap_fb >= FB_REGS dwords).  Without boundaries nbr_fb is a dummy: the loads then go to the fluid list.
-constexpr int FB_REGS = 6;
+constexpr int FB_REGS = 8;
 struct FbRegs { uint32_t d[FB_REGS]; };
 __device__ __forceinline__ FbRegs fb_regs(const StepCtx& c, uint32_t gslice) {
     const uint32_t* __restrict__ p = (c.nb ? c.nbr_fb + (size_t)gslice * c.cap_fb * WAVE : c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE) +
-                                     (threadIdx.x & (WAVE - 1));
+                                     4u * (threadIdx.x & (WAVE - 1));
+    static_assert(FB_REGS % 4 == 0, "fetched in 16-byte pieces");
+    const uint4* __restrict__ p4 = reinterpret_cast<const uint4*>(p);
     FbRegs r;
 #pragma unroll
-    for (int k = 0; k < FB_REGS; ++k) r.d[k] = p[(size_t)k * WAVE];
+    for (int k = 0; k < FB_REGS / 4; ++k) {
+        const uint4 v = p4[(size_t)k * WAVE];
+        r.d[4 * k] = v.x; r.d[4 * k + 1] = v.y; r.d[4 * k + 2] = v.z; r.d[4 * k + 3] = v.w;
+    }
     return r;
 }
 // f(slot) over the fluid-boundary contacts of a particle whose list head is held in registers
@@ -611,9 +627,9 @@ __device__ __forceinline__ void for_each_fb_regs(const StepCtx& c, uint32_t SB, 
         }
     }
     if (nq > (uint32_t)FB_REGS) {
-        const uint32_t* __restrict__ p = c.nbr_fb + (size_t)gslice * c.cap_fb * WAVE + (threadIdx.x & (WAVE - 1));
+        const uint32_t* __restrict__ p = c.nbr_fb + (size_t)gslice * c.cap_fb * WAVE + 4u * (threadIdx.x & (WAVE - 1));
         for (uint32_t q = FB_REGS; q < nq; ++q) {
-            const uint32_t a = p[(size_t)q * WAVE];
+            const uint32_t a = p[ellq(q)];
             f(a & 0xffffu);
             if (2u * q + 1u < cnt) f(a >> 16);
         }
@@ -638,12 +654,12 @@ __device__ __forceinline__ void for_each_ff_regs(const StepCtx& c, uint32_t gsli
         }
     }
     if (cnt > 2u * (uint32_t)LIST_REGS) {
-        const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + (threadIdx.x & (WAVE - 1));
+        const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + 4u * (threadIdx.x & (WAVE - 1));
         const uint32_t nq = (cnt + 1u) >> 1;
-        uint32_t nx = p[(size_t)LIST_REGS * WAVE];
+        uint32_t nx = p[ellq(LIST_REGS)];
         for (uint32_t q = LIST_REGS; q < nq; ++q) {
             const uint32_t a = nx;
-            if (q + 1 < nq) nx = p[(size_t)(q + 1) * WAVE];
+            if (q + 1 < nq) nx = p[ellq(q + 1)];
             const auto d0 = load(a & 0xffffu);
             const auto d1 = load(a >> 16);
             compute(d0);

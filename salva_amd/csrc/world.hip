@@ -1082,8 +1082,8 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;
             if (need_ff <= cap_ff && need_fb <= cap_fb) break;
             if (nattempt >= 2) throw HipError(SALVA_HIP_E_HIP, "internal error: neighbour list capacity did not converge");
-            if (need_ff > cap_ff) cap_ff = need_ff + need_ff / 4 + 1;
-            if (need_fb > cap_fb) cap_fb = need_fb + need_fb / 4 + 1;
+            if (need_ff > cap_ff) cap_ff = (need_ff + need_ff / 4 + 4u) & ~3u;
+            if (need_fb > cap_fb) cap_fb = (need_fb + need_fb / 4 + 4u) & ~3u;
         }
     }
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
@@ -1115,8 +1115,8 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             ++spec_misses; ++counters.speculative_passes; ++counters.discarded_passes;
             cur = cur0; dt_prev = dt_prev0; inv_dt_prev = inv_dt_prev0;
             memcpy(h_rb->bbox, bbox_pre, sizeof(bbox_pre));
-            if (need_ff > cap_ff) cap_ff = need_ff + need_ff / 4 + 1;
-            if (need_fb > cap_fb) cap_fb = need_fb + need_fb / 4 + 1;
+            if (need_ff > cap_ff) cap_ff = (need_ff + need_ff / 4 + 4u) & ~3u;
+            if (need_fb > cap_fb) cap_fb = (need_fb + need_fb / 4 + 4u) & ~3u;
             continue;
         }
     }
