@@ -300,6 +300,12 @@ int salva_hip_comm_rccl_create(int32_t rank, int32_t size, const unsigned char* 
 int salva_hip_comm_loopback_create(int32_t size, SalvaHipComm** out_ranks);
 void salva_hip_comm_destroy(SalvaHipComm* comm);
 int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_lo, int32_t cell_hi, uint32_t gid_offset);
+/* Load balancing, collective (every rank calls it between two steps, after at least one step): the slabs are re-cut at cell
+ * planes so that every rank owns about the same number of particles (all-reduced histogram over the planes; a cut stays
+ * between the old cuts on either side, so a particle changes owner by one rank at most, and slabs stay four planes thick).
+ * The particles follow in the next step's migration phase.  Returns this rank's new [cell_lo, cell_hi]; the caller re-uploads
+ * the boundary particles its new slab needs (salva_hip_set_boundary), as it chose them for the old one. */
+int salva_hip_rebalance(SalvaHipWorld* world, int32_t* cell_lo, int32_t* cell_hi);
 /* particles currently owned by this rank, in no particular order; returns their number (negative on error) */
 int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* gids, float* positions_xyz,
                             float* velocities_xyz, uint32_t* fluid_slots);

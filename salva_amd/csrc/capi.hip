@@ -346,6 +346,13 @@ int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_
         return SALVA_HIP_OK;
     });
 }
+int salva_hip_rebalance(SalvaHipWorld* world, int32_t* cell_lo, int32_t* cell_hi) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->rebalance(cell_lo, cell_hi);
+        return SALVA_HIP_OK;
+    });
+}
 int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* gids, float* positions_xyz, float* velocities_xyz,
                             uint32_t* fluid_slots) {
     int64_t count = 0;

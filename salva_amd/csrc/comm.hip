@@ -52,8 +52,10 @@ class LoopbackTransport : public Transport {
     int rank() const override { return rank_; }
     int size() const override { return g_->size; }
 
+    static bool trace() { static const bool t = getenv("SALVA_HIP_DIST_TRACE") != nullptr; return t; }
     void sendrecv(const void* send_lo, size_t n_lo, const void* send_hi, size_t n_hi, void* recv_lo, size_t m_lo, void* recv_hi,
                   size_t m_hi, hipStream_t s) override {
+        if (trace()) fprintf(stderr, "[loopback %d] sendrecv send %zu/%zu recv %zu/%zu\n", rank_, n_lo, n_hi, m_lo, m_hi);
         SALVA_HIP_CHECK(hipStreamSynchronize(s));  // my send buffers are complete
         auto& me = g_->box[rank_];
         me.send_lo = send_lo; me.n_lo = n_lo; me.send_hi = send_hi; me.n_hi = n_hi;
@@ -74,6 +76,7 @@ class LoopbackTransport : public Transport {
 
     void exchange_counts(const uint64_t to_lo[2], const uint64_t to_hi[2], uint64_t from_lo[2], uint64_t from_hi[2],
                          hipStream_t) override {
+        if (trace()) fprintf(stderr, "[loopback %d] exchange_counts %llu %llu\n", rank_, (unsigned long long)to_lo[0], (unsigned long long)to_hi[0]);
         auto& me = g_->box[rank_];
         memcpy(me.cnt_to_lo, to_lo, sizeof(me.cnt_to_lo));
         memcpy(me.cnt_to_hi, to_hi, sizeof(me.cnt_to_hi));
@@ -85,7 +88,8 @@ class LoopbackTransport : public Transport {
     }
 
     void allreduce_sum_f32(float* buf, int n, hipStream_t s) override {
-        if (n > 64) throw HipError(-2, "loopback allreduce: too many values");
+        for (; n > 64; n -= 64, buf += 64) allreduce_sum_f32(buf, 64, s);  // longer vectors go piece by piece
+        if (trace()) fprintf(stderr, "[loopback %d] allreduce_f32 %d\n", rank_, n);
         float h[64];
         SALVA_HIP_CHECK(hipMemcpyAsync(h, buf, n * sizeof(float), hipMemcpyDeviceToHost, s));
         SALVA_HIP_CHECK(hipStreamSynchronize(s));
@@ -102,7 +106,8 @@ class LoopbackTransport : public Transport {
         SALVA_HIP_CHECK(hipStreamSynchronize(s));
     }
     void allreduce_sum_u64(unsigned long long* buf, int n, hipStream_t s) override {
-        if (n > 64) throw HipError(-2, "loopback allreduce: too many values");
+        for (; n > 64; n -= 64, buf += 64) allreduce_sum_u64(buf, 64, s);
+        if (trace()) fprintf(stderr, "[loopback %d] allreduce_u64 %d\n", rank_, n);
         unsigned long long h[64];
         SALVA_HIP_CHECK(hipMemcpyAsync(h, buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         SALVA_HIP_CHECK(hipStreamSynchronize(s));

@@ -137,6 +137,10 @@ struct StepCtx {
     float* partials;     // [nblocks * nmodels] per-block error sums
     uint32_t* flags;     // bit 0: numeric error (zero density / NaN), bit 1: particle outside grid
     uint32_t min_neighbors_for_divergence;
+    // Decomposed runs: an evaluate pass may be launched twice — once over the tiles whose halo box touches no ghost plane
+    // (phase 1, on a second stream, while the ghosts' fields are still in flight) and once over the rest (phase 2, after
+    // the exchange).  0: every tile.  ghost_lo_cx / ghost_hi_cx: the cell planes next to the slab that hold ghosts.
+    int32_t phase, ghost_lo_cx, ghost_hi_cx;
     const SolveCtl* ctl;       // non-null inside an iterative solve: kernels return at once when ctl->done
     unsigned long long* dbg;   // optional per-tile phase timestamps (k_pred_density, SALVA_HIP_TILE_TIMING=1)
 };

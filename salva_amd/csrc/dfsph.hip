@@ -87,6 +87,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
     Tile t;
     t.setup(c);
+    if (t.skipped()) return;  // the other launch of this pass handles the tile (decomposed runs)
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
     struct Own { float4 pi, wi; float alpha; uint32_t mi, cnt, cntb; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
     const unsigned long long T0 = __builtin_readcyclecounter();
     Tile t;
     t.setup(c);
+    if (t.skipped()) return;  // the other launch of this pass handles the tile (decomposed runs)
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
     const unsigned long long T1 = __builtin_readcyclecounter();
     struct Own { float4 pi, wi; float rho, alpha; uint32_t mi, cnt; ListRegs lh; };

@@ -25,8 +25,8 @@ struct Sel3 {
 // mode 1 (migration): keep = owned and still inside (or beyond an open end); lo/hi = owned and left through that face.
 // mode 2 (ghost planes): keep = everything; lo/hi = owned and in the edge plane facing that neighbour.
 __global__ __launch_bounds__(BLOCK) void k_dist_flags(uint32_t n, const float4* __restrict__ posm, const uint32_t* __restrict__ gtag,
-                                                      float h, int lo, int hi, int has_lo, int has_hi, int mode,
-                                                      Sel3* __restrict__ sel, uint32_t* flags) {
+                                                      float h, int lo, int hi, int has_lo, int has_hi, int mode, int nbr_lo_lo,
+                                                      int nbr_hi_hi, Sel3* __restrict__ sel, uint32_t* flags) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     Sel3 s{0, 0, 0, 0};
@@ -36,8 +36,10 @@ __global__ __launch_bounds__(BLOCK) void k_dist_flags(uint32_t n, const float4* 
         bool bad = false;
         const int cx = cell_coord(posm[i].x, h, bad);
         if (mode == 1) {
-            if (has_lo && cx < lo) { s.lo = 1; if (cx < lo - 1) atomicOr(flags, 4u); }
-            else if (has_hi && cx > hi) { s.hi = 1; if (cx > hi + 1) atomicOr(flags, 4u); }
+            // a leaver goes to the adjacent rank; flag 4 if even that rank's slab ([nbr_lo_lo, lo - 1] / [hi + 1, nbr_hi_hi],
+            // open ends = INT_MIN / INT_MAX) does not hold its cell: it would be owned where nobody mirrors it
+            if (has_lo && cx < lo) { s.lo = 1; if (cx < nbr_lo_lo) atomicOr(flags, 4u); }
+            else if (has_hi && cx > hi) { s.hi = 1; if (cx > nbr_hi_hi) atomicOr(flags, 4u); }
             else s.keep = 1;
         } else {
             // two planes per face (GHOST_PLANES); <= / >= : an open-ended first / last slab may hold particles beyond its planes
@@ -46,6 +48,21 @@ __global__ __launch_bounds__(BLOCK) void k_dist_flags(uint32_t n, const float4* 
         }
     }
     sel[i] = s;
+}
+
+// owned particles per cell plane (load balancing): hist[cx - base], planes outside [base, base + len) are clamped to the ends
+__global__ __launch_bounds__(BLOCK) void k_plane_hist(uint32_t n, const float4* __restrict__ posm, const uint32_t* __restrict__ gtag, float h,
+                                                      int base, int len, unsigned long long* __restrict__ hist) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n || (gtag[i] & GTAG_GHOST)) return;
+    bool bad = false;
+    int p = cell_coord(posm[i].x, h, bad) - base;
+    p = p < 0 ? 0 : (p >= len ? len - 1 : p);
+    atomicAdd(&hist[p], 1ull);
+}
+void launch_plane_hist(uint32_t n, const float4* posm, const uint32_t* gtag, float h, int base, int len, unsigned long long* hist,
+                       hipStream_t s) {
+    if (n) k_plane_hist<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, posm, gtag, h, base, len, hist);
 }
 
 // Move / copy the selected particles.  `pos` is the exclusive scan of `sel` (pos[n] = totals).
@@ -122,12 +139,12 @@ size_t dist_scan_temp_bytes(uint32_t n) {
 size_t dist_sel_bytes(uint32_t n) { return (size_t)(n + 1) * sizeof(Sel3); }
 
 void launch_dist_select(uint32_t n, const float4* posm, const uint32_t* gtag, float h, int lo, int hi, bool has_lo, bool has_hi,
-                        int mode, void* sel, void* pos, void* temp, size_t temp_bytes, uint32_t* flags, uint32_t totals_host[3],
-                        hipStream_t s) {
+                        int mode, int nbr_lo_lo, int nbr_hi_hi, void* sel, void* pos, void* temp, size_t temp_bytes, uint32_t* flags,
+                        uint32_t totals_host[3], hipStream_t s) {
     Sel3* se = static_cast<Sel3*>(sel);
     Sel3* po = static_cast<Sel3*>(pos);
     SALVA_HIP_CHECK(hipMemsetAsync(se + n, 0, sizeof(Sel3), s));
-    if (n) k_dist_flags<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, posm, gtag, h, lo, hi, has_lo ? 1 : 0, has_hi ? 1 : 0, mode, se, flags);
+    if (n) k_dist_flags<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, posm, gtag, h, lo, hi, has_lo ? 1 : 0, has_hi ? 1 : 0, mode, nbr_lo_lo, nbr_hi_hi, se, flags);
     SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, se, po, hipcub::Sum(), Sel3{0, 0, 0, 0}, (int)(n + 1), s));
     Sel3 tot;
     SALVA_HIP_CHECK(hipMemcpyAsync(&tot, po + n, sizeof(Sel3), hipMemcpyDeviceToHost, s));

@@ -122,14 +122,17 @@ struct Tile {
     // the index fetch then overlaps the descriptor fetch and staging is two dependent round trips instead of three
     static constexpr int PRE = 4;
     uint32_t pre0, pre1, pre2, pre3, preb;
+    bool skip;  // this launch is not the one that handles the tile (StepCtx::phase): leave every output alone
 
     __device__ __forceinline__ bool empty() const { return own_begin == own_end; }
+    __device__ __forceinline__ bool skipped() const { return skip; }
 
     // geometry only (k_tile_count: before the per-slot prefix table exists).  Launched over an upper bound of the slot
     // count (the host does not know it yet): returns false for the surplus workgroups.
     __device__ __forceinline__ bool setup_geom(const StepCtx& c) {
         pool = tile_smem;
         pool_used = 0;
+        skip = false;
         slot = blockIdx.x;
         S = SB = 0; slice_base = 0; hoff = hboff = 0;
         pre0 = pre1 = pre2 = pre3 = preb = 0u;
@@ -169,6 +172,11 @@ struct Tile {
             const TileGrid& g = c.gf;
             const uint32_t ttz = tile % g.ntz, tty = (tile / g.ntz) % g.nty, ttx = tile / (g.ntz * g.nty);
             hcx = g.ox + (int)ttx * TX - 1; hcy = g.oy + (int)tty * TY - 1; hcz = g.oz + (int)ttz * TZ - 1;
+        }
+        skip = false;
+        if (c.phase) {
+            const bool border = hcx <= c.ghost_lo_cx || hcx + HX - 1 >= c.ghost_hi_cx;
+            skip = border != (c.phase == 2);
         }
         const TileAcc a0 = c.tile_off[slot], a1 = c.tile_off[slot + 1];
         slice_base = a0.nsl;

@@ -77,6 +77,9 @@ class World {
     uint64_t device_bytes() const;
     // multi-GPU: this world owns the cell planes [lo, hi] along x; neighbours are rank-1 / rank+1 of `transport`
     void set_domain(Transport* transport, int lo, int hi, uint32_t gid_offset);
+    // collective: re-cut the slabs at cell planes so that every rank owns about the same number of particles; the
+    // particles follow in the next step's migration.  Returns this rank's new [lo, hi].
+    void rebalance(int32_t* new_lo, int32_t* new_hi);
     uint64_t get_owned(uint32_t cap, uint32_t* gids, float* pos, float* vel, uint32_t* models);
     uint32_t owned_count() const { return comm ? n_owned : n; }
     float time_pred_density(int reps);
@@ -118,6 +121,11 @@ class World {
     void finalize_solve(SolveCtl* ctl, SolveCtl* pub);
 
     hipStream_t stream = nullptr;
+    // decomposed runs: evaluate passes over interior tiles run here while the ghost exchange is in flight on `stream`
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_pre_refresh = nullptr, ev_interior = nullptr;
+    bool overlap_exchange = true;   // SALVA_HIP_NO_OVERLAP=1 turns it off (diagnostics)
+    template <typename Launch> void evaluate_split(const StepCtx& c, int iteration, Launch&& launch);
     uint32_t n = 0, nb = 0;
 
     // canonical (host order) staging: st_pos = (x,y,z,volume), st_vel = (v,0), st_dv = (dv, pressure), st_acc
@@ -211,6 +219,10 @@ class World {
     // ---- multi-GPU slab decomposition (comm.h / dist.h)
     Transport* comm = nullptr;  // not owned
     int slab_lo = 0, slab_hi = 0;
+    int nbr_lo_lo = INT32_MIN, nbr_hi_hi = INT32_MAX;  // far ends of the neighbours' slabs (open ends: MIN / MAX)
+    bool nbr_bounds_valid = false;
+    DevBuf<unsigned long long> plane_hist;
+    std::vector<uint32_t> global_counts;  // particles per fluid over all ranks (the denominators of the error averages)
     uint32_t gid_offset = 0, n_owned = 0;
     bool dist_started = false;
     DevBuf<uint32_t> gtag[2];

@@ -113,6 +113,10 @@ World::World(const SalvaHipParams& p) : prm(p) {
     const float h = p.particle_radius * p.smoothing_factor * 2.0f;
     sc = make_sph_consts(h);
     SALVA_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    SALVA_HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    SALVA_HIP_CHECK(hipEventCreateWithFlags(&ev_pre_refresh, hipEventDisableTiming));
+    SALVA_HIP_CHECK(hipEventCreateWithFlags(&ev_interior, hipEventDisableTiming));
+    overlap_exchange = getenv("SALVA_HIP_NO_OVERLAP") == nullptr;
     // Speculative sizing is OFF unless asked for (SALVA_HIP_SPECULATE=1).  Measured on the bench scene (10^6 particles): it
     // removes two ~20 us host round trips from a ~0.9 ms free-fall step (-2 %), but a failed prediction costs a whole extra
     // step, and at the impact — where the halo and the lists grow for a dozen steps in a row — two passes in twenty were
@@ -141,6 +145,9 @@ World::World(const SalvaHipParams& p) : prm(p) {
 World::~World() {
     (void)hipSetDevice(prm.device);
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+    if (ev_pre_refresh) (void)hipEventDestroy(ev_pre_refresh);
+    if (ev_interior) (void)hipEventDestroy(ev_interior);
     if (h_rb) (void)hipHostFree(h_rb);
     if (h_ctl) (void)hipHostFree(h_ctl);
     if (h_pub) (void)hipHostFree(h_pub);
@@ -574,6 +581,10 @@ void World::upload_tables() {
     }
     rho0_tab.ensure(nm); model_counts.ensure(nm); ff_ok.ensure(nm * nm); fb_ok.ensure(nm * nbm); bb_ok.ensure(nbm * nbm); bwants.ensure(nbm);
     SALVA_HIP_CHECK(hipMemcpyAsync(rho0_tab.p, r0.data(), nm * sizeof(float), hipMemcpyHostToDevice, stream));
+    // (decomposed runs: the error averages divide by the GLOBAL particle count of each fluid, all-reduced once by
+    // dist_prepare — a later table upload, e.g. after the caller re-uploaded boundaries for a re-cut slab, must not put the
+    // local counts back: the ranks would then disagree on convergence and fall out of step)
+    if (comm && dist_started && global_counts.size() == nm) counts = global_counts;
     SALVA_HIP_CHECK(hipMemcpyAsync(model_counts.p, counts.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(ff_ok.p, ff.data(), ff.size(), hipMemcpyHostToDevice, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(fb_ok.p, fb.data(), fb.size(), hipMemcpyHostToDevice, stream));
@@ -613,6 +624,9 @@ StepCtx World::make_ctx() {
     c.partials = partials.p;
     c.flags = d_flags.p;
     c.min_neighbors_for_divergence = 20;  // dfsph_solver.rs:62 (DIM == 3)
+    c.phase = 0;
+    c.ghost_lo_cx = (comm && comm->has_lo()) ? slab_lo - 1 : INT32_MIN;
+    c.ghost_hi_cx = (comm && comm->has_hi()) ? slab_hi + 1 : INT32_MAX;
     return c;
 }
 
@@ -802,6 +816,24 @@ void World::run_forces(const StepCtx& c) {
     }
 }
 
+// An evaluate pass of a decomposed run, overlapped with the ghost exchange that precedes it: the tiles whose halo box
+// touches no ghost plane (all but the two tile layers at the faces) start on the second stream as soon as everything before
+// the exchange is done; the exchange itself (gather, grouped send / recv with the neighbours, scatter: latency-bound, tens
+// of microseconds) proceeds on the main stream, followed by the border tiles; the main stream then waits for the interior.
+// (Not for the first evaluate of a solve: its control block is initialised on the main stream after the exchange was
+// enqueued, and the interior launch would read the previous solve's `done`.)
+template <typename Launch>
+void World::evaluate_split(const StepCtx& c, int iteration, Launch&& launch) {
+    if (!comm || !overlap_exchange || iteration == 0) { launch(c, stream); return; }
+    StepCtx ci = c, cb = c;
+    ci.phase = 1; cb.phase = 2;
+    SALVA_HIP_CHECK(hipStreamWaitEvent(stream2, ev_pre_refresh, 0));
+    launch(ci, stream2);
+    SALVA_HIP_CHECK(hipEventRecord(ev_interior, stream2));
+    launch(cb, stream);
+    SALVA_HIP_CHECK(hipStreamWaitEvent(stream, ev_interior, 0));
+}
+
 // DFSPHSolver::step (dfsph_solver.rs:667-708)
 void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
     // divergence_solve (:466-503).  NOTE the dt lag: inv_dt is still the previous step's here (0 on the first step).
@@ -810,7 +842,7 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
     if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[3], stream));  // counters.custom (:492)
     const SolveResult rd = run_solve(
         c, 0, prm.max_divergence_error * inv_dt_prev * 0.01f, prm.min_divergence_iter, prm.max_divergence_iter, 0u,
-        [&](const StepCtx& cc, int) { launch_divergence(cc, lds, stream); },
+        [&](const StepCtx& cc, int it) { evaluate_split(cc, it, [&](const StepCtx& cs, hipStream_t s) { launch_divergence(cs, lds, s); }); },
         [&](const StepCtx& cc, int) {
             // decomposed runs: kappa of the inner ghost plane was computed here from refreshed w — the applies of the
             // owned particles read nothing else, so only w travels, once per iteration
@@ -829,7 +861,7 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
     // pressure_solve (:432-464)
     const SolveResult rp = run_solve(
         c, 1, prm.max_density_error, prm.min_pressure_iter, prm.max_pressure_iter, 0u,
-        [&](const StepCtx& cc, int) { launch_pred_density(cc, lds, dt, stream); },
+        [&](const StepCtx& cc, int it) { evaluate_split(cc, it, [&](const StepCtx& cs, hipStream_t s) { launch_pred_density(cs, lds, dt, s); }); },
         [&](const StepCtx& cc, int) {
             launch_pressure_apply(cc, lds, inv_dt, stream);
             if (comm) refresh_f4(w.p);

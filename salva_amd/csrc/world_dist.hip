@@ -1,6 +1,7 @@
 // world_dist.hip — the multi-GPU (x-slab) side of World: migration, ghost planes, per-pass ghost refresh and the
 // globally reduced convergence test.  Protocol and sizes: comm.h, dist.h, DESIGN.md §6.
 #include <algorithm>
+#include <climits>
 
 #include "world.h"
 
@@ -33,7 +34,67 @@ void World::set_domain(Transport* transport, int lo, int hi, uint32_t gid_off) {
     if (hi - lo + 1 < 2 * GHOST_PLANES) throw HipError(SALVA_HIP_E_INVALID, "a slab must span at least four cell planes");
     comm = transport;
     slab_lo = lo; slab_hi = hi; gid_offset = gid_off;
-    sorted_valid = false; bbox_known = false; dist_started = false; tables_dirty = true;
+    sorted_valid = false; bbox_known = false; dist_started = false; tables_dirty = true; nbr_bounds_valid = false;
+}
+
+// Load balancing ("re-cut every M steps").  All ranks call it between two steps.  Every rank contributes the
+// histogram of its owned particles over the cell planes; the sums are all-reduced, and every rank computes the same new
+// cuts: the plane where the running count passes k N / size, kept between the old cuts on either side (so that a particle
+// changes owner by at most one rank, which is what the migration phase can move) and at least four planes apart.
+void World::rebalance(int32_t* new_lo, int32_t* new_hi) {
+    use_device();
+    if (!comm) throw HipError(SALVA_HIP_E_INVALID, "rebalance needs a domain (salva_hip_set_domain)");
+    if (!dist_started || !bbox_known) throw HipError(SALVA_HIP_E_INVALID, "rebalance needs a completed step");
+    const int size = comm->size(), rank = comm->rank();
+    const unsigned long long OFF = 1ull << 40;
+    // every rank's plane range: its slab, widened to what it actually holds at an open end
+    const int my_lo = comm->has_lo() ? slab_lo : std::min(slab_lo, (int)h_rb->bbox[0]);
+    const int my_hi = comm->has_hi() ? slab_hi : std::max(slab_hi, (int)h_rb->bbox[3]);
+    std::vector<unsigned long long> rng(2 * (size_t)size, 0ull);
+    rng[2 * rank] = (unsigned long long)((long long)my_lo + (long long)OFF);
+    rng[2 * rank + 1] = (unsigned long long)((long long)my_hi + (long long)OFF);
+    plane_hist.ensure(std::max<size_t>(2 * (size_t)size, 64));
+    SALVA_HIP_CHECK(hipMemcpyAsync(plane_hist.p, rng.data(), rng.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+    comm->allreduce_sum_u64(plane_hist.p, 2 * size, stream);
+    SALVA_HIP_CHECK(hipMemcpyAsync(rng.data(), plane_hist.p, rng.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<long long> lo(size), hi(size);
+    for (int r = 0; r < size; ++r) { lo[r] = (long long)rng[2 * r] - (long long)OFF; hi[r] = (long long)rng[2 * r + 1] - (long long)OFF; }
+    const long long base = lo[0], len = hi[size - 1] - lo[0] + 1;
+    if (len <= 0 || len > (1ll << 22)) throw HipError(SALVA_HIP_E_CAPACITY, "rebalance: the domain spans too many cell planes");
+    plane_hist.ensure((size_t)len);
+    SALVA_HIP_CHECK(hipMemsetAsync(plane_hist.p, 0, (size_t)len * sizeof(unsigned long long), stream));
+    launch_plane_hist(n, posm[cur].p, gtag[cur].p, sc.h, (int)base, (int)len, plane_hist.p, stream);
+    comm->allreduce_sum_u64(plane_hist.p, (int)len, stream);
+    std::vector<unsigned long long> hist((size_t)len);
+    SALVA_HIP_CHECK(hipMemcpyAsync(hist.data(), plane_hist.p, (size_t)len * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    unsigned long long total = 0;
+    for (auto v : hist) total += v;
+    // cut[r] = first plane of rank r (r = 1 .. size-1); old cuts are the current slab_lo's
+    std::vector<long long> cut(size + 1);
+    cut[0] = lo[0]; cut[size] = hi[size - 1] + 1;
+    unsigned long long run = 0;
+    long long p = 0;
+    for (int r = 1; r < size; ++r) {
+        const unsigned long long want = total * (unsigned long long)r / (unsigned long long)size;
+        while (p < len && run + hist[(size_t)p] <= want) run += hist[(size_t)p++];
+        long long cpl = base + p;
+        const long long old_prev = (r - 1 >= 1) ? lo[r - 1] : LLONG_MIN / 4, old_next = (r + 1 < size) ? lo[r + 1] : LLONG_MAX / 4;
+        cpl = std::max(cpl, old_prev);                                     // a particle changes owner by one rank at most
+        cpl = std::min(cpl, old_next);
+        cpl = std::max(cpl, cut[r - 1] + 2 * (long long)GHOST_PLANES);     // slabs stay >= four planes thick
+        cut[r] = cpl;
+    }
+    for (int r = size - 1; r >= 1; --r) cut[r] = std::min(cut[r], cut[r + 1] - 2 * (long long)GHOST_PLANES);
+    for (int r = 1; r < size; ++r)
+        if (cut[r] < cut[r - 1] + 2 * (long long)GHOST_PLANES || cut[r] < ((r - 1 >= 1) ? lo[r - 1] : LLONG_MIN / 4))
+            throw HipError(SALVA_HIP_E_CAPACITY, "rebalance: the domain is too short for four cell planes per rank");
+    if (comm->has_lo()) slab_lo = (int)cut[rank];
+    if (comm->has_hi()) slab_hi = (int)cut[rank + 1] - 1;
+    nbr_bounds_valid = false;
+    if (new_lo) *new_lo = slab_lo;
+    if (new_hi) *new_hi = slab_hi;
 }
 
 DistArrays World::dist_arrays(int which) {
@@ -69,20 +130,32 @@ void World::dist_prepare() {
             if (cnt[f] >= 0xffffffffull) throw HipError(SALVA_HIP_E_CAPACITY, "more than 2^32 particles in one fluid");
             c32[f] = (uint32_t)cnt[f];
         }
+        global_counts = c32;
         SALVA_HIP_CHECK(hipMemcpyAsync(model_counts.p, c32.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         SALVA_HIP_CHECK(hipStreamSynchronize(stream));
         d_sums.ensure(nm);
         dist_started = true;
     }
     const bool has_lo = comm->has_lo(), has_hi = comm->has_hi();
+    if (!nbr_bounds_valid) {
+        // the far ends of the neighbours' slabs: a leaver must land inside the adjacent slab (k_dist_flags, flag 4)
+        const unsigned long long OFF = 1ull << 40;
+        const uint64_t mine[2] = {(uint64_t)((long long)(has_lo ? slab_lo : INT32_MIN) + (long long)OFF),
+                                  (uint64_t)((long long)(has_hi ? slab_hi : INT32_MAX) + (long long)OFF)};
+        uint64_t from_lo[2] = {0, 0}, from_hi[2] = {0, 0};
+        comm->exchange_counts(mine, mine, from_lo, from_hi, stream);
+        nbr_lo_lo = has_lo ? (int)((long long)from_lo[0] - (long long)OFF) : INT32_MIN;
+        nbr_hi_hi = has_hi ? (int)((long long)from_hi[1] - (long long)OFF) : INT32_MAX;
+        nbr_bounds_valid = true;
+    }
     for (int mode = 1; mode <= 2; ++mode) {
         dsel.ensure(dist_sel_bytes(n), stream, false, 1.25f);
         dpos.ensure(dist_sel_bytes(n), stream, false, 1.25f);
         const size_t tb = dist_scan_temp_bytes(n + 1);
         ensure_cub_temp(tb);
         uint32_t tot[3] = {0, 0, 0};
-        launch_dist_select(n, posm[cur].p, gtag[cur].p, sc.h, slab_lo, slab_hi, has_lo, has_hi, mode, dsel.p, dpos.p, cub_temp.p, tb,
-                           d_flags.p, tot, stream);
+        launch_dist_select(n, posm[cur].p, gtag[cur].p, sc.h, slab_lo, slab_hi, has_lo, has_hi, mode, nbr_lo_lo, nbr_hi_hi, dsel.p, dpos.p,
+                           cub_temp.p, tb, d_flags.p, tot, stream);
         xsend_lo.ensure(std::max<uint32_t>(tot[1], 1u), stream, false, 1.25f);
         xsend_hi.ensure(std::max<uint32_t>(tot[2], 1u), stream, false, 1.25f);
         launch_dist_pack(n, dist_arrays(cur), dist_arrays(cur ^ 1), dsel.p, dpos.p, mode, xsend_lo.p, xsend_hi.p, stream);
@@ -126,6 +199,7 @@ void World::dist_build_lists() {
 // Refresh one per-particle field of the ghosts from its owners: gather the mirrored edge-plane particles into a dense
 // buffer, one sendrecv with both neighbours, scatter into the ghost slots.  All on the world's stream.
 void World::refresh_f32(float* field) {
+    SALVA_HIP_CHECK(hipEventRecord(ev_pre_refresh, stream));  // (what evaluate_split lets the interior tiles start after)
     float* sb = reinterpret_cast<float*>(fbuf_send.p);
     float* rb = reinterpret_cast<float*>(fbuf_recv.p);
     launch_gather_f32(nborder_lo, send_lo_idx.p, field, sb, stream);
@@ -136,6 +210,7 @@ void World::refresh_f32(float* field) {
     launch_scatter_f32(nghost_hi, ghost_hi_idx.p, rb + nghost_lo, field, stream);
 }
 void World::refresh_f4(float4* field) {
+    SALVA_HIP_CHECK(hipEventRecord(ev_pre_refresh, stream));
     float4* sb = fbuf_send.p;
     float4* rb = fbuf_recv.p;
     launch_gather_idx_f4(nborder_lo, send_lo_idx.p, field, sb, stream);

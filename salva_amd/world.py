@@ -925,6 +925,12 @@ class LiquidWorld:
         L.check(self._L.salva_hip_set_domain(self._h, comm._h, int(cell_lo), int(cell_hi), int(gid_offset)))
         self._comm = comm
 
+    def rebalance(self):
+        """Collective re-cut of the slabs for equal particle counts (salva_hip_rebalance): returns this rank's new (lo, hi)."""
+        lo, hi = C.c_int32(0), C.c_int32(0)
+        L.check(self._L.salva_hip_rebalance(self._h, C.byref(lo), C.byref(hi)))
+        return int(lo.value), int(hi.value)
+
     def owned(self):
         """(gids, positions, velocities, fluid slots) of the particles this rank owns after the last step, sorted by gid."""
         u32p = C.POINTER(C.c_uint32)

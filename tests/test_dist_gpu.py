@@ -91,15 +91,15 @@ def run_slabs(pos, vel, bpos, nsteps, nranks, two_fluids):
         except BaseException as e:  # noqa: BLE001 - reported by the main thread
             errors[r] = e
 
-    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=300)
-    assert not any(t.is_alive() for t in threads), "a rank hung"
+        t.join(timeout=120)
     for e in errors:
         if e is not None:
             raise e
+    assert not any(t.is_alive() for t in threads), "a rank hung"
     out_p = np.full_like(pos, np.nan)
     out_v = np.full_like(vel, np.nan)
     seen = np.zeros(len(pos), int)
@@ -231,11 +231,11 @@ def test_slabs_with_iterative_viscosity(hip_lib):
         except BaseException as e:  # noqa: BLE001
             errs[r] = e
 
-    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    ts = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(2)]
     for t in ts:
         t.start()
     for t in ts:
-        t.join(timeout=300)
+        t.join(timeout=120)
     assert not any(t.is_alive() for t in ts), "a rank hung"
     for e in errs:
         if e is not None:
@@ -337,20 +337,85 @@ def test_boundary_forces_sum_to_the_single_domain_ones(hip_lib):
         except BaseException as e:  # noqa: BLE001
             errors[r] = e
 
-    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=300)
+        t.join(timeout=120)
+    for e in errors:  # a rank that raised leaves its peers waiting in the next exchange: report the cause first
+        if e is not None:
+            raise e
     assert not any(t.is_alive() for t in threads), "a rank hung"
     for c in comms:
         c.destroy()
-    for e in errors:
-        if e is not None:
-            raise e
     scale = np.abs(ref).max()
     assert scale > 0
     # the particles both ranks hold are the interesting ones
     shared = np.intersect1d(dist.boundary_subset(bpos, H, slabs[0], 0, nranks), dist.boundary_subset(bpos, H, slabs[1], 1, nranks))
     assert len(shared) > 50 and np.abs(ref[shared]).max() > 0.01 * scale
     assert np.abs(got - ref).max() < 5e-3 * scale, f"summed boundary forces differ by {np.abs(got - ref).max() / scale:.2e} of the largest force"
+
+
+def test_rebalance_recuts_the_slabs_and_keeps_the_physics(hip_lib):
+    """salva_hip_rebalance: three ranks start from deliberately lopsided cuts (one rank owns 60 % of the particles), re-cut
+    every second step, and must end up within a few per cent of N / 3 each — while the particle states keep following the
+    undivided domain (the re-cut only changes who owns what; boundaries are re-uploaded for the new slabs by the caller)."""
+    pos, vel, bpos = make_scene(nx=60)
+    nsteps, nranks = 10, 3
+    ref_p, ref_v, ref_stats = run_single(pos, vel, bpos, nsteps, False)
+    cx = dist.cell_x(pos, H)
+    lo, hi = int(cx.min()), int(cx.max())
+    span = hi - lo + 1
+    slabs = [(lo, lo + span * 6 // 10 - 1), (lo + span * 6 // 10, lo + span * 8 // 10 - 1), (lo + span * 8 // 10, hi)]
+    owner = dist.owner_of(cx, slabs)
+    first_counts = [int((owner == r).sum()) for r in range(nranks)]
+    assert max(first_counts) > 1.5 * len(pos) / nranks
+    comms = dist.Comm.loopback(nranks)
+    offsets = np.concatenate([[0], np.cumsum(first_counts)])
+    order = np.concatenate([np.nonzero(owner == r)[0] for r in range(nranks)])
+    results, errors, counts, final_slabs = [None] * nranks, [None] * nranks, [None] * nranks, [None] * nranks
+
+    def rank_main(r):
+        try:
+            w = LiquidWorld(solver(), R, SF)
+            mine = np.nonzero(owner == r)[0]
+            f = Fluid(pos[mine], R, 1000.0)
+            f.velocities = vel[mine]
+            f.nonpressure_forces.extend(FORCES["make"]())
+            w.add_fluid(f)
+            b = w.add_boundary(Boundary(bpos[dist.boundary_subset(bpos, H, slabs[r], r, nranks)]))
+            w.set_domain(comms[r], slabs[r][0], slabs[r][1], int(offsets[r]))
+            my = slabs[r]
+            for k in range(nsteps):
+                w.step(DT, G)
+                if k % 2 == 1 and k + 1 < nsteps:
+                    my = w.rebalance()
+                    w.remove_boundary(b)
+                    b = w.add_boundary(Boundary(bpos[dist.boundary_subset(bpos, H, my, r, nranks)]))
+            results[r] = w.owned()
+            counts[r] = len(results[r][0])
+            final_slabs[r] = my
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    for e in errors:  # a rank that raised leaves its peers waiting in the next exchange: report the cause first
+        if e is not None:
+            raise e
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    for c in comms:
+        c.destroy()
+    assert sum(counts) == len(pos)
+    # cuts sit on cell planes (~ len(pos) / span particles each): within two planes of the ideal
+    per_plane = len(pos) / span
+    assert max(abs(c - len(pos) / nranks) for c in counts) < 2.5 * per_plane, (first_counts, counts, final_slabs)
+    assert final_slabs[0][1] + 1 == final_slabs[1][0] and final_slabs[1][1] + 1 == final_slabs[2][0]
+    got_p = np.full_like(pos, np.nan)
+    for gid, p, v, _slot in results:
+        got_p[order[gid]] = p
+    assert np.isfinite(got_p).all()
+    assert np.abs(got_p - ref_p).max() < 2e-4 * H, f"positions differ by {np.abs(got_p - ref_p).max() / H:.2e} h"
