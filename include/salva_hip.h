@@ -331,6 +331,22 @@ int64_t salva_hip_particles_intersecting_shape(SalvaHipWorld* world, const float
                                               const SalvaHipShape* shape, uint64_t capacity, uint32_t* kinds, uint32_t* slots,
                                               uint32_t* indices);
 
+/* ---- Rigid-body coupling, the DynamicContactSampling arm (src/integrations/rapier/fluids_pipeline.rs:42-43, 193-259) for
+ * ball and cuboid colliders: no sample points are kept; inside every salva_hip_step — after the fluids went into the grid and
+ * before the boundaries do, where `coupling.update_boundaries` runs (liquid_world.rs:94-103) — each fluid particle whose
+ * predicted position x + v*dt lies in the collider's AABB loosened by 1.5 h is projected onto the shape
+ * (`project_point_and_get_feature`); particles inside the shape are pushed out by depth + 0.1 r and lose their inward normal
+ * velocity; one boundary particle per projection within 1.5 h is emitted (velocity = body.velocity_at_point(projection)).
+ * As in the reference the grid is not rebuilt after the push-out: a pushed particle is searched from the cell of its old
+ * position for that substep.  The collider's pose is handed over with salva_hip_update_boundary_pose before the step.
+ * Registers boundary `slot` (created empty if slot == number of boundaries). */
+int salva_hip_set_boundary_dynamic_sampling(SalvaHipWorld* world, uint32_t slot, const SalvaHipShape* collider_shape,
+                                            uint32_t memberships, uint32_t filter);
+/* (salva_hip_boundary_len reports what the last step emitted.) */
+/* For a dynamically sampled boundary: (fluid slot, particle index) of the fluid particle behind each of its points, in the
+ * order of salva_hip_get_boundary_particles (the order itself is unspecified, as the reference's hash-grid walk is). */
+int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t* fluid_slots, uint32_t* indices);
+
 /* `Fluid::add_particles(positions, velocities)` (object/fluid.rs:126-150): append to the fluid on the device — default
  * volume, zero acceleration and velocity change — without re-uploading the particles it already holds.
  * velocities_xyz may be NULL (zeros). */

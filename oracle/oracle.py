@@ -69,6 +69,7 @@ def lib(native: bool = False):
         L.so_set_solver_params.argtypes = [vp, i32, i32, f32, i32, i32, f32]
         L.so_h.restype = f64
         L.so_h.argtypes = [vp]
+        L.so_set_timestep.argtypes = [vp, f32, f32]
         L.so_add_fluid.argtypes = [vp, u64, fp, fp, f32, u32, u32]
         L.so_add_boundary.argtypes = [vp, u64, fp, fp, u32, u32, i32]
         L.so_add_force.argtypes = [vp, i32, i32, fp, i32]
@@ -88,6 +89,8 @@ def lib(native: bool = False):
         L.so_get_viscosity_betas.argtypes = [vp, i32, i32, dp]
         L.so_set_boundary_sampling.argtypes = [vp, i32, u64, C.POINTER(C.c_float)]
         L.so_update_boundary_pose.argtypes = [vp, i32, dp, i32, i32]
+        L.so_set_boundary_dynamic_sampling.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]
+        L.so_get_boundary_sources.argtypes = [vp, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.so_get_boundary_wrench.argtypes = [vp, i32, dp, dp, dp]
         L.so_add_particles.argtypes = [vp, i32, u64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.so_delete_particle.argtypes = [vp, i32, u64]
@@ -153,6 +156,9 @@ class OracleWorld:
     def h(self) -> float:
         return self._L.so_h(self._h)
 
+    def set_timestep(self, dt: float, inv_dt: float):
+        self._L.so_set_timestep(self._h, dt, inv_dt)
+
     def set_threads(self, n: int):
         self._L.so_set_threads(self._h, n)
 
@@ -180,6 +186,20 @@ class OracleWorld:
     def set_boundary_sampling(self, boundary, local_points):
         pts = _f32(local_points, 3)
         self._L.so_set_boundary_sampling(self._h, boundary, len(pts), _fp(pts))
+
+    # ---- DynamicContactSampling arm (:193-259): shape kind 1 = ball (radius), 2 = cuboid (half extents)
+    def set_boundary_dynamic_sampling(self, boundary, kind, params):
+        prm = np.zeros(3, np.float32)
+        prm[:len(np.atleast_1d(params))] = np.atleast_1d(params)
+        self._L.so_set_boundary_dynamic_sampling(self._h, boundary, int(kind), _fp(prm))
+
+    def boundary_sources(self, boundary):
+        """(fluid, particle) each point of a dynamically sampled boundary was projected from, in emission order."""
+        n = self.boundary_len(boundary)
+        f, p = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        self._L.so_get_boundary_sources(self._h, boundary, f.ctypes.data_as(u32p), p.ctypes.data_as(u32p))
+        return f, p
 
     def update_boundary_pose(self, boundary, translation=(0, 0, 0), rotation=(0, 0, 0, 1), linvel=(0, 0, 0), angvel=(0, 0, 0),
                              world_com=(0, 0, 0), has_body=True, is_dynamic=True):

@@ -31,6 +31,8 @@
 //                                                   solver's per-slot buffers stay positional)
 //   src/integrations/rapier/fluids_pipeline.rs:160-193, 262-287        StaticSampling arm of the rigid-body coupling
 //                                                   (rapier's velocity_at_point / apply_impulse_at_point restated)
+//   src/integrations/rapier/fluids_pipeline.rs:193-259                 DynamicContactSampling arm for ball / cuboid colliders
+//                                                   (parry3d 0.18's compute_aabb / project_point restated, see update_boundaries_dynamic)
 //
 // Third-party arithmetic that is NOT under /root/reference (nalgebra 0.33, semver range only, no lockfile):
 //   dot / norm_squared of a 3-vector = ((x0*y0 + x1*y1) + x2*y2); Unit::try_new_and_get(v, eps) returns
@@ -52,6 +54,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <random>
 #include <unordered_map>
@@ -238,6 +241,14 @@ struct Boundary {  // object/boundary.rs:11-24
     std::vector<V3<R>> forces;
     Groups groups;
     std::vector<V3<R>> sampling;  // ColliderSampling::StaticSampling(points), integrations/rapier/fluids_pipeline.rs:36-41
+    // ColliderSampling::DynamicContactSampling (:42-43): the collider's shape (1 = ball(radius), 2 = cuboid(half extents))
+    // and its pose / body state as of the last so_update_boundary_pose; `source` = (fluid, particle) of each emitted point
+    int dyn_kind = 0;
+    R dyn_p[3] = {0, 0, 0};
+    V3<R> pose_t, pose_qv, pose_linvel, pose_angvel, pose_com;
+    R pose_qw = 1;
+    bool pose_has_body = false;
+    std::vector<std::pair<uint32_t, uint32_t>> dyn_source;
     size_t n() const { return positions.size(); }
 };
 
@@ -402,10 +413,119 @@ struct World {
     }
 
     // ------------------------------------------------------------------ contacts.rs:133-151
-    void insert_to_grid() {
+    void insert_fluids_to_grid() {  // contacts.rs:133-140, liquid_world.rs:91
         for (size_t f = 0; f < fluids.size(); ++f)
             for (size_t p = 0; p < fluids[f].n(); ++p)
                 grid.insert<R>(fluids[f].positions[p], h, Entry{(uint32_t)f, (uint32_t)p, false});
+    }
+
+    // ------------------------------------------------------------------ integrations/rapier/fluids_pipeline.rs:193-259
+    // The DynamicContactSampling arm of ColliderCouplingManager::update_boundaries, run where the reference runs it: after
+    // the fluids were inserted into the grid and before the boundaries are (liquid_world.rs:94-106).  The grid is NOT
+    // rebuilt afterwards, so a fluid particle pushed out of the shape stays registered in the cell of its old position for
+    // this substep's contact search — restated as it is.
+    // parry3d 0.18 is an un-vendored dependency; restated from its published source:
+    //   Ball::compute_aabb(pos)   = [t - r, t + r]                      (bounding_volume/aabb_ball.rs)
+    //   Cuboid::compute_aabb(pos) = t -+ |R| * half_extents, R = UnitQuaternion::to_rotation_matrix (aabb_cuboid.rs,
+    //                               nalgebra geometry/quaternion.rs), Aabb::loosened(m) = [mins - m, maxs + m]
+    //   Aabb::contains_local_point: mins <= p <= maxs on every axis
+    //   PointQuery::project_point_and_get_feature(m, pt) = project_local(m^-1 * pt) transformed back by m, with solid = false:
+    //     Ball (query/point/point_ball.rs): inside = |p|^2 <= r^2; proj = p * (r / |p|)
+    //     Cuboid = Aabb[-he, he] (query/point/point_aabb.rs do_project_local_point): shift = sup(mins - p, 0) - sup(p - maxs, 0);
+    //       outside iff shift != 0 -> p + shift; inside -> the nearest face (largest of mins - p, p - maxs over the axes)
+    void update_boundaries_dynamic() {
+        const R prediction = h * (R)0.5;
+        const R margin = particle_radius * (R)0.1;
+        const R amount = h + prediction;
+        for (size_t b = 0; b < boundaries.size(); ++b) {
+            Boundary<R>& bd = boundaries[b];
+            if (!bd.dyn_kind) continue;
+            bd.positions.clear(); bd.velocities.clear(); bd.volumes.clear(); bd.dyn_source.clear();
+            const V3<R> t = bd.pose_t, qv = bd.pose_qv;
+            const R qw = bd.pose_qw;
+            V3<R> ext;
+            if (bd.dyn_kind == 1) {
+                ext = V3<R>(bd.dyn_p[0], bd.dyn_p[0], bd.dyn_p[0]);
+            } else {
+                const R i = qv.x, j = qv.y, k = qv.z, w = qw;
+                const R ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+                const R ij = i * j * (R)2, wk = w * k * (R)2, wj = w * j * (R)2, ik = i * k * (R)2, jk = j * k * (R)2, wi = w * i * (R)2;
+                const R m[3][3] = {{ww + ii - jj - kk, ij - wk, wj + ik}, {wk + ij, ww - ii + jj - kk, jk - wi}, {ik - wj, wi + jk, ww - ii - jj + kk}};
+                const R he[3] = {bd.dyn_p[0], bd.dyn_p[1], bd.dyn_p[2]};
+                R e[3];
+                for (int a = 0; a < 3; ++a) e[a] = (std::fabs(m[a][0]) * he[0] + std::fabs(m[a][1]) * he[1]) + std::fabs(m[a][2]) * he[2];
+                ext = V3<R>(e[0], e[1], e[2]);
+            }
+            const V3<R> lo = (t - ext) - V3<R>(amount, amount, amount), hi = (t + ext) + V3<R>(amount, amount, amount);
+            const Cell start{HGrid::quantify<R>(lo.x, h), HGrid::quantify<R>(lo.y, h), HGrid::quantify<R>(lo.z, h)};
+            const Cell end{HGrid::quantify<R>(hi.x, h), HGrid::quantify<R>(hi.y, h), HGrid::quantify<R>(hi.z, h)};
+            for (size_t ci = 0; ci < grid.used; ++ci) {  // cells_intersecting_aabb (hgrid.rs:122-133): the existing cells of the range
+                const Cell& c = grid.keys[ci];
+                if (c.x < start.x || c.x > end.x || c.y < start.y || c.y > end.y || c.z < start.z || c.z > end.z) continue;
+                for (const Entry& e : grid.cells[ci]) {
+                    if (e.is_boundary) continue;  // "Not yet implemented." (:252-254)
+                    Fluid<R>& fl = fluids[e.model];
+                    const V3<R> pp = fl.positions[e.particle] + fl.velocities[e.particle] * dt;  // :206-207, dt of the last substep
+                    if (pp.x < lo.x || pp.x > hi.x || pp.y < lo.y || pp.y > hi.y || pp.z < lo.z || pp.z > hi.z) continue;
+                    // m^-1 * pt = q^-1 * (pt - t)
+                    const V3<R> d = pp - t, nq = -qv;
+                    const V3<R> t1 = nq.cross(d) * (R)2;
+                    const V3<R> lp = t1 * qw + nq.cross(t1) + d;
+                    V3<R> lproj;
+                    bool inside;
+                    if (bd.dyn_kind == 1) {
+                        const R r = bd.dyn_p[0], d2 = lp.norm_squared();
+                        inside = d2 <= r * r;
+                        lproj = lp * (r / std::sqrt(d2));
+                    } else {
+                        const R he[3] = {bd.dyn_p[0], bd.dyn_p[1], bd.dyn_p[2]}, p3[3] = {lp.x, lp.y, lp.z};
+                        R mins_pt[3], pt_maxs[3], shift[3];
+                        inside = true;
+                        for (int a = 0; a < 3; ++a) {
+                            mins_pt[a] = -he[a] - p3[a];
+                            pt_maxs[a] = p3[a] - he[a];
+                            shift[a] = std::max(mins_pt[a], (R)0) - std::max(pt_maxs[a], (R)0);
+                            if (shift[a] != (R)0) inside = false;
+                        }
+                        if (inside) {
+                            R best = -std::numeric_limits<R>::max();
+                            bool is_mins = false;
+                            int best_id = 0;
+                            for (int a = 0; a < 3; ++a) {
+                                if (mins_pt[a] < pt_maxs[a]) {
+                                    if (pt_maxs[a] > best) { best_id = a; is_mins = false; best = pt_maxs[a]; }
+                                } else if (mins_pt[a] > best) { best_id = a; is_mins = true; best = mins_pt[a]; }
+                            }
+                            shift[0] = shift[1] = shift[2] = 0;
+                            shift[best_id] = is_mins ? best : -best;
+                        }
+                        lproj = V3<R>(p3[0] + shift[0], p3[1] + shift[1], p3[2] + shift[2]);
+                    }
+                    const V3<R> t2 = qv.cross(lproj) * (R)2;
+                    const V3<R> proj = (t2 * qw + qv.cross(t2) + lproj) + t;
+                    const V3<R> dpt = pp - proj;
+                    V3<R> normal;
+                    R depth;
+                    if (try_new_and_get(dpt, Eps<R>::v, normal, depth)) {
+                        if (inside) {
+                            fl.positions[e.particle] -= normal * (depth + margin);
+                            const R vel_err = normal.dot(fl.velocities[e.particle]);
+                            if (vel_err > (R)0) fl.velocities[e.particle] -= normal * vel_err;
+                        } else if (depth > h + prediction) {
+                            continue;
+                        }
+                    }
+                    bd.velocities.push_back(bd.pose_has_body ? bd.pose_linvel + bd.pose_angvel.cross(proj - bd.pose_com) : V3<R>());
+                    bd.positions.push_back(proj);
+                    bd.volumes.push_back((R)0);
+                    bd.dyn_source.emplace_back(e.model, e.particle);
+                }
+            }
+            if (bd.has_forces) bd.forces.assign(bd.n(), V3<R>());  // clear_forces(true) :262
+        }
+    }
+
+    void insert_boundaries_to_grid() {  // contacts.rs:142-151, liquid_world.rs:106
         for (size_t b = 0; b < boundaries.size(); ++b)
             for (size_t p = 0; p < boundaries[b].n(); ++p)
                 grid.insert<R>(boundaries[b].positions[p], h, Entry{(uint32_t)b, (uint32_t)p, true});
@@ -1487,7 +1607,9 @@ struct World {
         while (!(remaining_time <= Eps<R>::v)) {  // is_done, timestep_manager.rs:56-58
             double ta = now_ms();
             grid.clear();
-            insert_to_grid();
+            insert_fluids_to_grid();
+            update_boundaries_dynamic();
+            insert_boundaries_to_grid();
             double tb = now_ms();
             compute_contacts();
             stats.ncontacts = ncontacts();
@@ -1537,7 +1659,7 @@ static int add_fluid_t(World<R>& w, uint64_t n, const float* pos, const float* v
 }
 
 // ---- integrations/rapier/fluids_pipeline.rs (rapier itself is an un-vendored dependency: the two rigid-body formulas used
-// here are restated from rapier3d 0.22's published source, `RigidBody::velocity_at_point` = linvel + angvel x (pt - world_com)
+// here are restated from rapier3d 0.23's published source, `RigidBody::velocity_at_point` = linvel + angvel x (pt - world_com)
 // and `apply_impulse_at_point` = apply_impulse(J) + apply_torque_impulse((pt - world_com) x J); nalgebra's
 // `Isometry3 * Point3` = UnitQuaternion * pt + translation with q * v = v + w t + q.vec x t, t = 2 q.vec x v).
 template <typename R>
@@ -1562,6 +1684,11 @@ static void update_boundary_pose_t(World<R>& w, int b, const double* pose, int h
     if (has_body) {
         bd.has_forces = is_dynamic != 0;
         if (!bd.has_forces) bd.forces.clear();
+    }
+    if (bd.dyn_kind) {  // DynamicContactSampling: the projection itself runs inside step() (update_boundaries_dynamic)
+        bd.pose_t = t; bd.pose_qv = qv; bd.pose_qw = qw; bd.pose_linvel = linvel; bd.pose_angvel = angvel; bd.pose_com = com;
+        bd.pose_has_body = has_body != 0;
+        return;
     }
     const size_t n = bd.sampling.size();
     bd.positions.resize(n); bd.velocities.resize(n); bd.volumes.assign(n, (R)0);
@@ -1644,6 +1771,11 @@ void so_set_solver_params(void* p, int min_p, int max_p, float max_derr, int min
     DISPATCH(h,
         (w.min_pressure_iter = min_p, w.max_pressure_iter = max_p, w.max_density_error = max_derr, w.min_divergence_iter = min_d, w.max_divergence_iter = max_d, w.max_divergence_error = max_diverr),
         (w.min_pressure_iter = min_p, w.max_pressure_iter = max_p, w.max_density_error = max_derr, w.min_divergence_iter = min_d, w.max_divergence_iter = max_d, w.max_divergence_error = max_diverr));
+}
+// TimestepManager::{dt, inv_dt} (timestep_manager.rs:14-15) as a previous run left them: what the next step reads before it advances
+void so_set_timestep(void* p, float dt, float inv_dt) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, { w.dt = dt; w.inv_dt = inv_dt; }, { w.dt = dt; w.inv_dt = inv_dt; });
 }
 double so_h(void* p) { Handle* h = (Handle*)p; double r = 0; DISPATCH(h, r = w.h, r = w.h); return r; }
 
@@ -1812,6 +1944,20 @@ void so_get_boundary_vec(void* p, int b, int field, double* out) {
 void so_set_boundary_sampling(void* p, int b, uint64_t n, const float* pts) {
     Handle* h = (Handle*)p;
     DISPATCH(h, set_boundary_sampling_t(w, b, n, pts), set_boundary_sampling_t(w, b, n, pts));
+}
+// ColliderSampling::DynamicContactSampling for boundary `b`: kind 1 = ball (params[0] = radius), 2 = cuboid (half extents)
+void so_set_boundary_dynamic_sampling(void* p, int b, int kind, const float* params) {
+    Handle* h = (Handle*)p;
+#define SETD(w) do { auto& bd = w.boundaries[b]; bd.dyn_kind = kind; for (int a = 0; a < 3; ++a) bd.dyn_p[a] = params[a]; } while (0)
+    DISPATCH(h, SETD(w), SETD(w));
+#undef SETD
+}
+// (fluid, particle) of the fluid particle each point of a dynamically sampled boundary was projected from
+void so_get_boundary_sources(void* p, int b, uint32_t* fluid, uint32_t* particle) {
+    Handle* h = (Handle*)p;
+#define GETS(w) do { auto& v = w.boundaries[b].dyn_source; for (size_t i = 0; i < v.size(); ++i) { fluid[i] = v[i].first; particle[i] = v[i].second; } } while (0)
+    DISPATCH(h, GETS(w), GETS(w));
+#undef GETS
 }
 void so_update_boundary_pose(void* p, int b, const double* pose16, int has_body, int is_dynamic) {
     Handle* h = (Handle*)p;

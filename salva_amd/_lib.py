@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_get_boundary_particles", "salva_hip_get_boundary_wrench", "salva_hip_set_force_callback",
     "salva_hip_force_get_state", "salva_hip_force_add_accelerations", "salva_hip_set_fluid_field", "salva_hip_get_timestep",
     "salva_hip_set_timestep", "salva_hip_time_variant", "salva_hip_get_counters", "salva_hip_time_kernel", "salva_hip_particles_intersecting_shape", "salva_hip_rebalance",
+    "salva_hip_set_boundary_dynamic_sampling", "salva_hip_get_boundary_sources",
 ]
 
 
@@ -169,6 +170,8 @@ def lib():
     L.salva_hip_clear_boundary_forces.argtypes = [vp, u32]
     L.salva_hip_set_boundary_sampling.argtypes = [vp, u32, u64, fp, u32, u32]
     L.salva_hip_update_boundary_pose.argtypes = [vp, u32, C.POINTER(RigidPose)]
+    L.salva_hip_set_boundary_dynamic_sampling.argtypes = [vp, u32, C.POINTER(Shape), u32, u32]
+    L.salva_hip_get_boundary_sources.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u32)]
     L.salva_hip_get_boundary_particles.argtypes = [vp, u32, fp, fp]
     L.salva_hip_get_boundary_wrench.argtypes = [vp, u32, fp, fp, fp]
     L.salva_hip_set_force_callback.argtypes = [vp, FORCE_CALLBACK, vp]

@@ -1,4 +1,5 @@
-"""Host mirror of salva's rigid-body coupling for the StaticSampling arm (src/integrations/rapier/fluids_pipeline.rs).
+"""Host mirror of salva's rigid-body coupling (src/integrations/rapier/fluids_pipeline.rs): the StaticSampling arm and, for ball
+and cuboid colliders, the DynamicContactSampling arm.
 
 rapier is not part of this project (and not available here): `RigidBody` below carries exactly the state the coupling
 reads and writes — pose, velocities, centre of mass, mass properties — with rapier's formulas for the three methods the
@@ -96,11 +97,27 @@ class StaticSampling:
         self.points = np.ascontiguousarray(points, F32).reshape(-1, 3)
 
 
+class DynamicContactSampling:
+    """ColliderSampling::DynamicContactSampling (fluids_pipeline.rs:42-43) for a collider of shape ("ball", radius) or
+    ("cuboid", (hx, hy, hz)): the boundary's particles are the projections of the nearby fluid particles onto the collider,
+    recomputed inside every step on the device (salva_hip_set_boundary_dynamic_sampling)."""
+
+    def __init__(self, shape):
+        self.shape = L.Shape()
+        if shape[0] == "ball":
+            self.shape.kind, self.shape.params[0] = L.SHAPE_BALL, float(shape[1])
+        elif shape[0] == "cuboid":
+            self.shape.kind = L.SHAPE_CUBOID
+            self.shape.params[:] = [float(x) for x in shape[1]]
+        else:
+            raise ValueError("built-in collider shapes: ('ball', radius), ('cuboid', half_extents)")
+
+
 @dataclass
 class _Entry:
     boundary: object
     body: Optional[RigidBody]
-    sampling: StaticSampling
+    sampling: object  # StaticSampling | DynamicContactSampling
     uploaded: bool = False
 
 
@@ -111,7 +128,7 @@ class ColliderCouplingSet:
     def __init__(self):
         self.entries: Dict[object, _Entry] = {}
 
-    def register_coupling(self, boundary, collider, body: Optional[RigidBody], sampling_method: StaticSampling):
+    def register_coupling(self, boundary, collider, body: Optional[RigidBody], sampling_method):
         old = self.entries.get(collider)
         self.entries[collider] = _Entry(boundary, body, sampling_method)
         return old.boundary if old else None
@@ -126,6 +143,12 @@ class ColliderCouplingSet:
             b = e.boundary
             if b._world is not world:
                 continue
+            if not e.uploaded and isinstance(e.sampling, DynamicContactSampling):
+                b._sampled = b._dynamic = True
+                L.check(world._L.salva_hip_set_boundary_dynamic_sampling(
+                    world._h, b._slot, C.byref(e.sampling.shape), b.interaction_groups.memberships, b.interaction_groups.filter))
+                b._dirty = False
+                e.uploaded = True
             if not e.uploaded:
                 b._sampled = True
                 L.check(world._L.salva_hip_set_boundary_sampling(
@@ -146,7 +169,7 @@ class ColliderCouplingSet:
     def transmit_forces(self, world, dt: float):
         for e in self.entries.values():
             b = e.boundary
-            if b._world is not world or e.body is None or not b.wants_forces or getattr(b, "_n_sampled", 0) == 0:
+            if b._world is not world or e.body is None or not b.wants_forces or b.num_particles() == 0:
                 continue
             com = e.body.center_of_mass()
             f = np.zeros(3, F32)

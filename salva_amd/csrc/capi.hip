@@ -184,6 +184,25 @@ int salva_hip_update_boundary_pose(SalvaHipWorld* world, uint32_t slot, const Sa
     });
 }
 
+int salva_hip_set_boundary_dynamic_sampling(SalvaHipWorld* world, uint32_t slot, const SalvaHipShape* collider_shape,
+                                            uint32_t memberships, uint32_t filter) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        if (!collider_shape) throw salva::HipError(SALVA_HIP_E_INVALID, "null shape");
+        not_in_force_callback(world);
+        world->w->set_boundary_dynamic_sampling(slot, *collider_shape, memberships, filter);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t* fluid_slots, uint32_t* indices) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->get_boundary_sources(slot, fluid_slots, indices);
+        return SALVA_HIP_OK;
+    });
+}
+
 int salva_hip_set_force_callback(SalvaHipWorld* world, SalvaHipForceCallback cb, void* user) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");

@@ -1,0 +1,30 @@
+// dcs.h — DynamicContactSampling (dcs.hip): launcher interface used by world.hip.
+#pragma once
+#include "common.h"
+#include "device_types.h"
+#include "../../include/salva_hip.h"
+
+namespace salva {
+
+struct DcsParams {
+    int kind;
+    float p[3];           // radius | half extents
+    float t[3], q[4];     // collider.position(): translation, unit quaternion (i, j, k, w)
+    float lo[3], hi[3];   // shape AABB loosened by h + prediction (fluids_pipeline.rs:196-199)
+    int clo[3], chi[3];   // HGrid::key(mins) .. key(maxs) (hgrid.rs:128-129)
+    float dt;             // timestep.dt(): the previous substep's length (0 before the first step)
+    float margin;         // particle_radius * 0.1 (:194)
+    float reach;          // h + prediction (:234)
+    float eps;            // f32::default_epsilon() (:223)
+};
+
+DcsParams dcs_params(const SalvaHipShape& shape, const SalvaHipRigidPose& pose, float h, float particle_radius, float dt);
+// one candidate (projection xyz, host particle index bits) and one flag per fluid particle; pushes particles inside the
+// shape out of it in place (positions and velocities of the sorted working set)
+void launch_dcs_project(uint32_t n, float4* posm, float4* vel, const uint32_t* keys, const uint32_t* perm, TileGrid g,
+                        const DcsParams& s, float4* cand, uint8_t* flag, hipStream_t st);
+// compacted candidates -> boundary rows (position, volume 0), (velocity at the point, boundary slot), source particle
+void launch_dcs_emit(uint32_t cnt, const float4* cand, const SalvaHipRigidPose& pose, uint32_t slot, float4* pos, float4* vel,
+                     uint32_t* src, hipStream_t st);
+
+}  // namespace salva

@@ -115,6 +115,10 @@ struct StepCtx {
     uint32_t nslices_cap;           // slices the list buffers hold
     uint64_t halo_len, bhalo_len;   // entries of halo_src / bhalo_src
     TileGrid gf;
+    // non-null when a DynamicContactSampling boundary pushed particles after the cell keys were taken: the sorted keys, from
+    // which the neighbour search takes each particle's (possibly stale) cell instead of its position — the reference does
+    // not re-insert pushed particles into its grid either (liquid_world.rs:90-106)
+    const uint32_t* stale_keys;
 
     // ---- boundary particles, cell-sorted order ----
     uint32_t nb;
@@ -154,6 +158,7 @@ struct Readback {
     TileAcc tile_total;   // totals and maxima of halo slots / boundary halo slots / slices over the tiles
     uint64_t ncontacts_ff, ncontacts_fb, ncontacts_bb;
     uint32_t max_cnt_ff, max_cnt_fb;   // longest contact lists of the step (capacity check)
+    uint32_t dcs_count, pad_;          // points emitted by the last DynamicContactSampling pass
 };
 
 }  // namespace salva

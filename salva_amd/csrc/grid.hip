@@ -435,8 +435,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
         const float4 pi = c.posm[i];
         const uint32_t mi = c.model[i];
         bool bad = false;
-        const int lx = cell_coord(pi.x, c.sc.h, bad) - t.hcx, ly = cell_coord(pi.y, c.sc.h, bad) - t.hcy,
-                  lz = cell_coord(pi.z, c.sc.h, bad) - t.hcz;
+        int lx, ly, lz;
+        if (c.stale_keys) {  // own cells sit one cell inside the halo box
+            const uint32_t loc = c.stale_keys[i] % TCELLS;
+            lx = 1 + (int)(loc / (TY * TZ)); ly = 1 + (int)((loc / TZ) % TY); lz = 1 + (int)(loc % TZ);
+        } else {
+            lx = cell_coord(pi.x, c.sc.h, bad) - t.hcx; ly = cell_coord(pi.y, c.sc.h, bad) - t.hcy;
+            lz = cell_coord(pi.z, c.sc.h, bad) - t.hcz;
+        }
         uint32_t* __restrict__ outb = c.nbr_fb + (size_t)gs * c.cap_fb * WAVE + 4u * lane;
         uint32_t pend = 0, pendb = 0;
 #pragma unroll 1

@@ -29,6 +29,12 @@ struct BoundarySlot {
     bool wants_forces = false;
     // ColliderSampling::StaticSampling(points): collider-local sample points (integrations/rapier/fluids_pipeline.rs:36-41)
     std::shared_ptr<DevBuf<float4>> sampling;
+    // ColliderSampling::DynamicContactSampling (:42-43): the collider's shape and its last pose; the boundary's particles are
+    // re-emitted by every step (World::run_dynamic_sampling), `dyn_src` = host index of the fluid particle behind each
+    int dyn_kind = 0;
+    SalvaHipShape dyn_shape{};
+    SalvaHipRigidPose dyn_pose{};
+    std::shared_ptr<DevBuf<uint32_t>> dyn_src;
 };
 
 struct GridDims {          // tile-aligned dense grid (tile.h)
@@ -64,6 +70,9 @@ class World {
     void get_boundary(uint32_t slot, float* volumes, float* forces);
     void set_boundary_sampling(uint32_t slot, uint64_t n, const float* local_points, uint32_t memberships, uint32_t filter);
     void update_boundary_pose(uint32_t slot, const SalvaHipRigidPose& pose);
+    void set_boundary_dynamic_sampling(uint32_t slot, const SalvaHipShape& shape, uint32_t memberships, uint32_t filter);
+    uint64_t boundary_len(uint32_t slot) const;
+    void get_boundary_sources(uint32_t slot, uint32_t* fluid_slots, uint32_t* indices);
     void set_force_callback(SalvaHipForceCallback cb, void* user, SalvaHipWorld* owner) { force_cb = cb; force_user = user; force_owner = owner; }
     void force_get_state(uint32_t slot, float* positions, float* velocities, float* densities);
     void force_add_accelerations(uint32_t slot, const float* acc);
@@ -102,6 +111,12 @@ class World {
     void ensure_staging_current();
     void upload_tables();
     void build_boundary_grid();
+    void resize_boundary_slot(uint32_t slot, uint64_t nn);
+    bool has_dynamic_sampling() const;
+    void run_dynamic_sampling();   // between the cell keys and the sort (fluids_pipeline.rs:193-259 inside liquid_world.rs:94-103)
+    DevBuf<float4> dcs_cand, dcs_out;
+    DevBuf<uint8_t> dcs_flag;
+    DevBuf<uint32_t> dcs_num;
     void ensure_cub_temp(size_t bytes);
     StepCtx make_ctx();
     struct SolveResult { uint32_t iters; float err; };

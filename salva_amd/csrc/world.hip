@@ -6,6 +6,7 @@
 // Host <-> device traffic happens only in set_* / get_*; `step` works on HBM-resident state and reads back a
 // few scalars (convergence errors, list sizes, the next cell bounding box).
 #include "world.h"
+#include "dcs.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -502,6 +503,7 @@ void World::set_boundary(uint32_t slot, uint64_t nn, const float* pos, const flo
     }
     BoundarySlot& b = bounds[slot];
     b.n = nn; b.memberships = memberships; b.filter = filter; b.wants_forces = wants_forces;
+    b.dyn_kind = 0;  // (re)uploading particles makes it a plain boundary; the sampling setters mark it again
     if (nn) {
         scratch_f.ensure(3 * nn, stream, false, 1.1f);
         SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, pos, 3 * nn * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -613,6 +615,7 @@ StepCtx World::make_ctx() {
     c.spec = spec_mode ? 1u : 0u; c.halo_cap = halo_cap; c.bhalo_cap = bhalo_cap; c.nslices_cap = nslices_cap;
     c.halo_len = halo_len; c.bhalo_len = bhalo_len;
     c.gf = TileGrid{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], cell_start_f.p};
+    c.stale_keys = has_dynamic_sampling() ? keys[1].p : nullptr;
     c.nb = nb;
     c.bposv = bposv.p; c.bvel = bvel.p; c.bperm = bperm.p;
     c.bforce = any_wants_forces ? bforce.p : nullptr;
@@ -993,7 +996,9 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     // slots per step) the step is simply run again from the untouched pre-sort buffers with exact sizes.
     bool has_custom = false;
     for (auto& f : fluids) for (auto& d : f.forces) has_custom |= d.kind == SALVA_HIP_FORCE_CUSTOM;
-    const bool can_speculate = !spec_off && !comm && !any_wants_forces && !has_custom && !b_dirty && pred_valid && pred_n == n;
+    const bool has_dyn = has_dynamic_sampling();
+    if (has_dyn && comm) throw HipError(SALVA_HIP_E_INVALID, "DynamicContactSampling is not available in a multi-GPU run");
+    const bool can_speculate = !spec_off && !comm && !any_wants_forces && !has_custom && !b_dirty && !has_dyn && pred_valid && pred_n == n;
     int32_t bbox_pre[6];
     memcpy(bbox_pre, h_rb->bbox, sizeof(bbox_pre));
     const float dt_prev0 = dt_prev, inv_dt_prev0 = inv_dt_prev;
@@ -1006,6 +1011,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     {
         TileGrid gv{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], nullptr};
         launch_cell_keys(posm[cur].p, n, sc.h, gv, keys[0].p, idx[0].p, d_flags.p, stream);
+        if (has_dyn) run_dynamic_sampling();  // coupling.update_boundaries (liquid_world.rs:94-103): may push particles, cells stay
         const int end_bit = bits_for(ncf);
         const size_t tb = sort_pairs_temp_bytes(n, end_bit);
         ensure_cub_temp(tb);
@@ -1545,9 +1551,18 @@ void World::update_boundary_pose(uint32_t slot, const SalvaHipRigidPose& pose) {
     use_device();
     if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");
     BoundarySlot& b = bounds[slot];
-    if (!b.sampling) throw HipError(SALVA_HIP_E_INVALID, "boundary has no sampling points (salva_hip_set_boundary_sampling)");
+    if (!b.sampling && !b.dyn_kind)
+        throw HipError(SALVA_HIP_E_INVALID, "boundary has no sampling method (salva_hip_set_boundary_sampling / _dynamic_sampling)");
     for (int k = 0; k < 4; ++k)
         if (!std::isfinite(pose.rotation[k])) throw HipError(SALVA_HIP_E_INVALID, "non-finite pose");
+    if (b.dyn_kind) {  // the projection itself runs inside the step, where the reference runs it
+        if (pose.has_body) {
+            const bool wants = pose.is_dynamic != 0;
+            if (wants != b.wants_forces) { b.wants_forces = wants; tables_dirty = true; }
+        }
+        b.dyn_pose = pose;
+        return;
+    }
     const uint64_t off = boundary_offset(slot);
     if (pose.has_body) {
         const bool wants = pose.is_dynamic != 0;
@@ -1559,6 +1574,112 @@ void World::update_boundary_pose(uint32_t slot, const SalvaHipRigidPose& pose) {
         SALVA_HIP_CHECK(hipMemsetAsync(bforce.p + off, 0, b.n * sizeof(float4), stream));  // boundary.clear_forces(true) :262
     }
     b_dirty = true; have_last_ctx = false;
+}
+
+// ------------------------------------------------------------------------------------------------ DynamicContactSampling
+// ColliderCouplingSet::register_coupling(boundary, collider, ColliderSampling::DynamicContactSampling) (fluids_pipeline.rs:42-43,
+// 96-114): the boundary starts empty; every step re-emits its particles from the fluid near the collider.
+void World::set_boundary_dynamic_sampling(uint32_t slot, const SalvaHipShape& shape, uint32_t memberships, uint32_t filter) {
+    if (comm) throw HipError(SALVA_HIP_E_INVALID, "DynamicContactSampling is not available in a multi-GPU run");
+    if (shape.kind != SALVA_HIP_SHAPE_BALL && shape.kind != SALVA_HIP_SHAPE_CUBOID)
+        throw HipError(SALVA_HIP_E_INVALID, "unknown shape kind (ball and cuboid are built in; other parry shapes belong to the host)");
+    const int np = shape.kind == SALVA_HIP_SHAPE_BALL ? 1 : 3;
+    for (int a = 0; a < np; ++a)
+        if (!(shape.params[a] > 0.0f) || !std::isfinite(shape.params[a])) throw HipError(SALVA_HIP_E_INVALID, "shape parameters must be positive");
+    const bool keep_forces = slot < bounds.size() ? bounds[slot].wants_forces : false;
+    set_boundary(slot, 0, nullptr, nullptr, memberships, filter, keep_forces);
+    BoundarySlot& b = bounds[slot];
+    b.sampling.reset();
+    b.dyn_kind = shape.kind;
+    b.dyn_shape = shape;
+    b.dyn_pose = SalvaHipRigidPose{};
+    b.dyn_pose.rotation[3] = 1.0f;
+    b.dyn_src = std::make_shared<DevBuf<uint32_t>>();
+}
+
+bool World::has_dynamic_sampling() const {
+    for (const BoundarySlot& b : bounds) if (b.dyn_kind) return true;
+    return false;
+}
+
+uint64_t World::boundary_len(uint32_t slot) const {
+    if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");
+    return bounds[slot].n;
+}
+
+// Change the particle count of one boundary in place: the rows of the boundaries behind it move, its own rows are left for
+// the caller to fill (forces zeroed).  No allocation once the buffers have grown.
+void World::resize_boundary_slot(uint32_t slot, uint64_t nn) {
+    BoundarySlot& b = bounds[slot];
+    const uint64_t old_n = b.n;
+    if (old_n == nn) return;
+    const uint64_t off = boundary_offset(slot), old_total = nb, new_total = old_total - old_n + nn;
+    if (new_total >= 0xfffffff0ull) throw HipError(SALVA_HIP_E_CAPACITY, "too many boundary particles");
+    const uint64_t tail_src = off + old_n, tail_len = old_total - tail_src;
+    DevBuf<float4>* bufs[3] = {&bst_pos, &bst_vel, &bforce};
+    for (DevBuf<float4>* buf : bufs) {
+        buf->ensure(std::max<uint64_t>(new_total, 1), stream, true, 1.5f);
+        if (tail_len) {
+            scratch_f4.ensure(tail_len, stream, false, 1.5f);
+            SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f4.p, buf->p + tail_src, tail_len * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+            SALVA_HIP_CHECK(hipMemcpyAsync(buf->p + off + nn, scratch_f4.p, tail_len * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+        }
+    }
+    b.n = nn;
+    nb = (uint32_t)new_total;
+    b_dirty = true; have_last_ctx = false;
+}
+
+// The DynamicContactSampling arm of ColliderCouplingManager::update_boundaries (fluids_pipeline.rs:193-259, :262) for every
+// boundary registered with it, in slot order, at the reference's point of the substep: the fluid cell keys exist (grid
+// insertion, liquid_world.rs:90-91), the boundaries are not in the grid yet (:106).  Works on the sorted working set of the
+// previous step (posm[cur] / vel[cur], keys[0] = this step's keys in that order).
+void World::run_dynamic_sampling() {
+    TileGrid gv{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], nullptr};
+    for (uint32_t slot = 0; slot < bounds.size(); ++slot) {
+        BoundarySlot& b = bounds[slot];
+        if (!b.dyn_kind) continue;
+        uint32_t cnt = 0;
+        if (n) {
+            const DcsParams prm_d = dcs_params(b.dyn_shape, b.dyn_pose, sc.h, prm.particle_radius, dt_prev);
+            dcs_cand.ensure(n, stream, false, 1.1f); dcs_out.ensure(n, stream, false, 1.1f); dcs_flag.ensure(n, stream, false, 1.1f);
+            dcs_num.ensure(1);
+            launch_dcs_project(n, posm[cur].p, vel[cur].p, keys[0].p, perm[cur].p, gv, prm_d, dcs_cand.p, dcs_flag.p, stream);
+            const size_t tb = select_flagged_temp_bytes(n);
+            ensure_cub_temp(tb);
+            select_flagged_f4(cub_temp.p, tb, dcs_cand.p, dcs_flag.p, dcs_out.p, dcs_num.p, n, stream);
+            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->dcs_count, dcs_num.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            wait_stream();
+            cnt = h_rb->dcs_count;
+        }
+        resize_boundary_slot(slot, cnt);
+        b_dirty = true;  // same count, new positions
+        if (cnt) {
+            const uint64_t off = boundary_offset(slot);
+            b.dyn_src->ensure(cnt, stream, false, 1.5f);
+            launch_dcs_emit(cnt, dcs_out.p, b.dyn_pose, slot, bst_pos.p + off, bst_vel.p + off, b.dyn_src->p, stream);
+            SALVA_HIP_CHECK(hipMemsetAsync(bforce.p + off, 0, (size_t)cnt * sizeof(float4), stream));  // clear_forces(true) :262
+        }
+    }
+}
+
+// (fluid slot, index) of the fluid particle each point of a dynamically sampled boundary was projected from
+void World::get_boundary_sources(uint32_t slot, uint32_t* fluid_slots, uint32_t* indices) {
+    use_device();
+    if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");
+    const BoundarySlot& b = bounds[slot];
+    if (!b.dyn_kind) throw HipError(SALVA_HIP_E_INVALID, "boundary is not dynamically sampled");
+    if (!b.n) return;
+    std::vector<uint32_t> src(b.n);
+    SALVA_HIP_CHECK(hipMemcpyAsync(src.data(), b.dyn_src->p, b.n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    for (uint64_t k = 0; k < b.n; ++k) {
+        uint32_t f = 0;
+        uint64_t o = 0;
+        while (f + 1 < fluids.size() && src[k] >= o + fluids[f].n) { o += fluids[f].n; ++f; }
+        if (fluid_slots) fluid_slots[k] = f;
+        if (indices) indices[k] = (uint32_t)(src[k] - o);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host force callbacks

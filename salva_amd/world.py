@@ -441,6 +441,7 @@ class Boundary:
         self._dirty = True
         self._sampled = False  # positions / velocities are produced on the device from a pose (salva_amd.coupling)
         self._n_sampled = 0
+        self._dynamic = False  # ColliderSampling::DynamicContactSampling: re-emitted by every step, the device knows the count
 
     @property
     def positions(self):
@@ -470,7 +471,18 @@ class Boundary:
         self._dirty = True
 
     def num_particles(self) -> int:
+        if self._dynamic and self._world is not None:
+            return int(self._world._L.salva_hip_boundary_len(self._world._h, self._slot))
         return self._n_sampled if self._sampled else len(self._positions)
+
+    def sources(self):
+        """Dynamically sampled boundaries: (fluid slot, particle index) behind each boundary particle."""
+        n = self.num_particles()
+        f, i = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        if n:
+            u32p = C.POINTER(C.c_uint32)
+            L.check(self._world._L.salva_hip_get_boundary_sources(self._world._h, self._slot, f.ctypes.data_as(u32p), i.ctypes.data_as(u32p)))
+        return f, i
 
     @property
     def volumes(self) -> np.ndarray:

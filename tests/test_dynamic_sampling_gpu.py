@@ -1,0 +1,213 @@
+"""ColliderSampling::DynamicContactSampling on the device (integrations/rapier/fluids_pipeline.rs:193-259)
+against the oracle's restatement: a tilted, parentless cuboid and a ball attached to a moving dynamic body, both overlapped
+by the fluid from the first step so that the push-out branch runs at once.
+
+Step 0 starts from identical state on both sides, so everything the arm produces is compared bit for bit: which particles
+emitted a boundary particle, the projected points and their velocities, the pushed-out fluid positions / velocities, and the
+contact set found from the stale cells.  The following steps (solver rounding differs) are compared like every other scene."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from parity import DT, GRAVITY, max_norm_diff
+from oracle import oracle as O
+from salva_amd import Boundary, DFSPHSolver, Fluid, IISPHSolver, LiquidWorld, NonPressureForce, XSPHViscosity, _lib, scenes
+from salva_amd.coupling import ColliderCouplingSet, DynamicContactSampling, RigidBody
+
+pytestmark = pytest.mark.gpu
+
+R = 0.025
+CUBOID_HE = (0.30, 0.04, 0.22)
+BALL_R = 0.11
+
+
+def _scene(n=14):
+    pos = scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.2 * R, seed=5)
+    pos[:, 1] += np.float32(n * R + 0.02)  # the block's lowest layer starts inside the slab's top face
+    vel = scenes.random_velocities(len(pos), 0.6, seed=6)
+    slab = RigidBody(translation=np.float32([0.03, -0.03, -0.02]), rotation=scenes.quat_from_scaled_axis((0.06, 0.02, 0.2)))
+    ball = RigidBody(translation=np.float32([0.08, 0.30, 0.05]), linvel=np.float32([0.3, 0.9, -0.2]), angvel=np.float32([1.0, -2.0, 0.5]),
+                     local_com=np.float32([0.01, 0.0, -0.02]), mass=0.8, principal_inertia=np.float32([0.004, 0.004, 0.004]))
+    return pos, vel, slab, ball
+
+
+BALL_V0 = np.float32([1.0, 0.1, 0.0])
+
+
+def _calm_scene(n=14):
+    """The block starts just above a slightly tilted slab and settles on it; a heavy ball drifts into its side."""
+    pos = scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.1 * R, seed=7)
+    pos[:, 1] += np.float32(n * R + 0.075)
+    vel = scenes.random_velocities(len(pos), 0.1, seed=8)
+    slab = RigidBody(translation=np.float32([0.0, -0.03, 0.0]), rotation=scenes.quat_from_scaled_axis((0.02, 0.0, 0.04)))
+    ball = RigidBody(translation=np.float32([-0.52, 0.30, 0.02]), linvel=BALL_V0.copy(), angvel=np.float32([0.0, 0.0, -3.0]),
+                     local_com=np.float32([0.0, 0.01, 0.0]), mass=20.0, principal_inertia=np.float32([0.1, 0.1, 0.1]))
+    return pos, vel, slab, ball
+
+
+class Probe(NonPressureForce):
+    """A user force that adds nothing: it records the positions the solver works on, i.e. the state right after
+    update_boundaries pushed particles out of the colliders (positions are integrated at the very end of the step)."""
+
+    def __init__(self):
+        self.positions = None
+
+    def solve(self, timestep, kernel_radius, ff, fb, fluid, boundaries, densities):
+        self.positions = fluid.positions.copy()
+
+
+def _oracle_world(solver, pos, vel, f64=False, probe=None):
+    w = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH, f64=f64)
+    f = w.add_fluid(pos, 1000.0, vel)
+    w.add_xsph(f, 0.5, 0.5)
+    if probe is not None:
+        w.add_custom_force(f, lambda world, fl, positions, velocities, densities, acc: probe.append(positions.astype(np.float32)))
+    empty = np.zeros((0, 3), np.float32)
+    b0, b1 = w.add_boundary(empty), w.add_boundary(empty)
+    w.set_boundary_dynamic_sampling(b0, 2, CUBOID_HE)
+    w.set_boundary_dynamic_sampling(b1, 1, [BALL_R])
+    return w, f
+
+
+def _oracle_pose(w, slab, ball):
+    w.update_boundary_pose(0, slab.translation, slab.rotation, has_body=False)
+    w.update_boundary_pose(1, ball.translation, ball.rotation, ball.linvel, ball.angvel, ball.center_of_mass(), True, True)
+
+
+def _hip_world(solver, pos, vel, slab, ball, probe=None):
+    w = LiquidWorld(DFSPHSolver() if solver == "dfsph" else IISPHSolver(), R, 2.0)
+    fl = Fluid(pos, R, 1000.0)
+    fl.velocities = vel
+    fl.nonpressure_forces.append(XSPHViscosity(0.5, 0.5))
+    if probe is not None:
+        fl.nonpressure_forces.append(probe)
+    h = w.add_fluid(fl)
+    bounds = [w.add_boundary(Boundary(np.zeros((0, 3), np.float32))) for _ in range(2)]
+    coupling = ColliderCouplingSet()
+    coupling.register_coupling(bounds[0], "slab", None, DynamicContactSampling(("cuboid", CUBOID_HE)))
+    coupling.register_coupling(bounds[1], "ball", ball, DynamicContactSampling(("ball", BALL_R)))
+    return w, h, bounds, coupling
+
+
+def _hip_pose(w, coupling, bounds, slab):
+    w.sync_to_device()
+    coupling.update_boundaries(w)
+    pose = slab.pose()  # the parentless collider's pose goes through the raw entry point (the set only knows bodies)
+    pose.has_body = 0
+    _lib.check(w._L.salva_hip_update_boundary_pose(w._h, bounds[0]._slot, pose))
+
+
+def _by_source(fluid_ids, particle_ids, *arrays):
+    order = np.lexsort((particle_ids, fluid_ids))
+    return [particle_ids[order]] + [a[order] for a in arrays]
+
+
+@pytest.mark.parametrize("solver", ["dfsph", "iisph"])
+def test_first_step_is_bit_exact(solver):
+    pos, vel, slab, ball = _scene()
+    oprobe, gprobe = [], Probe()
+    o, f = _oracle_world(solver, pos, vel, probe=oprobe)
+    w, h, bounds, coupling = _hip_world(solver, pos, vel, slab, ball, probe=gprobe)
+    # a previous substep length, as a continued run would carry it: the prediction x + v dt is exercised from the first step
+    o.set_timestep(DT, 1.0 / DT)
+    w.sync_to_device()
+    _lib.check(w._L.salva_hip_set_timestep(w._h, DT, 1.0 / DT))
+    _oracle_pose(o, slab, ball)
+    _hip_pose(w, coupling, bounds, slab)
+    so = o.step(DT, GRAVITY)
+    st = w.step(DT, GRAVITY)
+    for b in range(2):
+        n = o.boundary_len(b)
+        assert n > 50 and bounds[b].num_particles() == n, f"boundary {b}: {bounds[b].num_particles()} points vs {n}"
+        of, op = o.boundary_sources(b)
+        idx_o, po, vo = _by_source(of, op, o.boundary_vec(b, "positions").astype(np.float32), o.boundary_vec(b, "velocities").astype(np.float32))
+        gf, gp = bounds[b].sources()
+        idx_g, pg, vg = _by_source(gf, gp, bounds[b].positions, bounds[b].velocities)
+        assert np.array_equal(idx_o, idx_g), f"boundary {b}: different fluid particles were sampled"
+        assert np.array_equal(po, pg), f"boundary {b}: projections differ by {np.abs(po - pg).max():.3e}"
+        assert np.array_equal(vo, vg), f"boundary {b}: velocity_at_point differs by {np.abs(vo - vg).max():.3e}"
+        if b == 0:
+            assert not vo.any()
+        else:
+            assert np.abs(vo).max() > 0.5
+    # the pushed-out positions, as the solver saw them
+    assert len(oprobe) == 1 and gprobe.positions is not None
+    moved = np.abs(oprobe[0] - pos).max(axis=1) > 0
+    assert moved.sum() > 20, "the scene did not exercise the push-out branch"
+    assert np.array_equal(oprobe[0], gprobe.positions), f"pushed positions differ by {np.abs(oprobe[0] - gprobe.positions).max():.3e}"
+    # the contact search ran from the stale cells: identical contact sets
+    assert int(st.ncontacts) == int(so.ncontacts)
+    assert np.array_equal(w.contact_counts(h), o.contact_counts(f))
+    assert np.array_equal(w.contact_counts(h, True), o.contact_counts(f, True))
+    d = max_norm_diff(h.positions, o.fluid_vec(f, "positions")) / R
+    vref = max(float(np.abs(o.fluid_vec(f, "velocities")).max()), 2 * R / DT * 1e-2)
+    dv = max_norm_diff(h.velocities, o.fluid_vec(f, "velocities")) / vref
+    assert d < 1e-4 and dv < 1e-4, f"after the first step positions differ by {d:.2e} r, velocities by {dv:.2e} v_ref"
+
+
+@pytest.mark.parametrize("solver", ["dfsph", "iisph"])
+def test_thirty_steps_with_a_moving_ball(solver):
+    """The block settles on the slab while the ball (a dynamic body, slowed down by the fluid it displaces) enters its side."""
+    nsteps = 30
+    pos, vel, slab, ball_o = _calm_scene()
+    _, _, _, ball_g = _calm_scene()
+    o, f = _oracle_world(solver, pos, vel)
+    o64, f64 = _oracle_world(solver, pos, vel, f64=True)
+    _, _, _, ball_64 = _calm_scene()
+    w, h, bounds, coupling = _hip_world(solver, pos, vel, slab, ball_g)
+    counts = []
+    for k in range(nsteps):
+        _oracle_pose(o, slab, ball_o)
+        _oracle_pose(o64, slab, ball_64)
+        _hip_pose(w, coupling, bounds, slab)
+        so = o.step(DT, GRAVITY)
+        o64.step(DT, GRAVITY)
+        st = w.step(DT, GRAVITY)
+        for ow, body in ((o, ball_o), (o64, ball_64)):
+            F, T = ow.boundary_wrench(1, body.center_of_mass())
+            body.apply_impulse(np.float32(F) * np.float32(DT))
+            body.apply_torque_impulse(np.float32(T) * np.float32(DT))
+            body.integrate(DT, (0.0, 0.0, 0.0))
+        coupling.transmit_forces(w, DT)
+        ball_g.integrate(DT, (0.0, 0.0, 0.0))
+        n_o = [o.boundary_len(b) for b in range(2)]
+        n_g = [bounds[b].num_particles() for b in range(2)]
+        counts.append((n_g, n_o))
+        for b in range(2):
+            assert abs(n_g[b] - n_o[b]) <= max(3, n_o[b] // 50), f"step {k}: boundary {b} emitted {n_g[b]} points, oracle {n_o[b]}"
+        slack = 0 if k == 0 else max(8, int(2e-4 * so.ncontacts))
+        assert abs(int(st.ncontacts) - int(so.ncontacts)) <= slack, f"step {k}: contacts {st.ncontacts} vs {so.ncontacts}"
+    po, vo = o.fluid_vec(f, "positions"), o.fluid_vec(f, "velocities")
+    vref = max(float(np.abs(vo).max()), 2 * R / DT * 1e-2)
+    tol_p = max(1e-4 * nsteps, 2 * max_norm_diff(po, o64.fluid_vec(f64, "positions")) / R)
+    tol_v = max(1e-4 * nsteps, 2 * max_norm_diff(vo, o64.fluid_vec(f64, "velocities")) / vref)
+    d = max_norm_diff(h.positions, po) / R
+    dv = max_norm_diff(h.velocities, vo) / vref
+    assert d < tol_p, f"positions differ by {d:.2e} r (tolerance {tol_p:.2e})"
+    assert dv < tol_v, f"velocities differ by {dv:.2e} v_ref (tolerance {tol_v:.2e})"
+    # the ball felt the fluid: its velocity changed, the same way on both sides
+    assert np.abs(ball_o.linvel - BALL_V0).max() > 1e-3
+    scale = max(np.abs(ball_o.linvel - BALL_V0).max(), 1e-3)
+    tol_b = max(1e-3, 2 * np.abs(ball_o.linvel - ball_64.linvel).max() / scale)
+    assert np.abs(ball_g.linvel - ball_o.linvel).max() / scale < tol_b
+    print("emitted (gpu, oracle) per step:", counts)
+
+
+def test_rejected_uses():
+    w = LiquidWorld(DFSPHSolver(), R, 2.0)
+    w.add_fluid(Fluid(scenes.cube_fluid_positions(4, 4, 4, R), R, 1000.0))
+    b = w.add_boundary(Boundary(np.zeros((0, 3), np.float32)))
+    w.sync_to_device()
+    bad = _lib.Shape()
+    bad.kind = 7
+    with pytest.raises(_lib.SalvaHipError) as e:
+        _lib.check(w._L.salva_hip_set_boundary_dynamic_sampling(w._h, b._slot, C.byref(bad), 1, 0xFFFFFFFF))
+    assert e.value.code == _lib.E_INVALID
+    bad.kind, bad.params[0] = _lib.SHAPE_BALL, -1.0
+    with pytest.raises(_lib.SalvaHipError):
+        _lib.check(w._L.salva_hip_set_boundary_dynamic_sampling(w._h, b._slot, C.byref(bad), 1, 0xFFFFFFFF))
+    # a boundary with uploaded particles is not dynamically sampled: its sources cannot be asked for
+    u32p = C.POINTER(C.c_uint32)
+    with pytest.raises(_lib.SalvaHipError):
+        _lib.check(w._L.salva_hip_get_boundary_sources(w._h, b._slot, C.cast(None, u32p), C.cast(None, u32p)))
