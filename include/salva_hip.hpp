@@ -181,12 +181,27 @@ class Boundary {  // object/boundary.rs
     // velocities are produced on the device from a pose (ColliderCouplingSet below) and `positions` above is only a
     // read-back (LiquidWorld::sync_boundary)
     std::vector<Vec3> sampling;
-    size_t num_particles() const { return sampling.empty() ? positions.size() : sampling.size(); }
+    // ColliderSampling::DynamicContactSampling (:42-43) for a ball / cuboid collider: kind != 0 makes every step re-emit the
+    // boundary's particles on the device from the fluid near the collider (salva_hip_set_boundary_dynamic_sampling);
+    // positions / velocities are read back by LiquidWorld::sync_boundary
+    SalvaHipShape dynamic_shape{0, {0, 0, 0}};
+    static Boundary dynamic_ball(Real radius, InteractionGroups groups = {}) {
+        Boundary b({}, groups);
+        b.dynamic_shape = SalvaHipShape{SALVA_HIP_SHAPE_BALL, {radius, 0, 0}};
+        return b;
+    }
+    static Boundary dynamic_cuboid(const Vec3& half_extents, InteractionGroups groups = {}) {
+        Boundary b({}, groups);
+        b.dynamic_shape = SalvaHipShape{SALVA_HIP_SHAPE_CUBOID, {half_extents[0], half_extents[1], half_extents[2]}};
+        return b;
+    }
+    size_t num_particles() const { return dynamic_shape.kind ? dynamic_n_ : (sampling.empty() ? positions.size() : sampling.size()); }
     void mark_dirty() { dirty_ = true; }
 
   private:
     friend class LiquidWorld;
     bool dirty_ = true;
+    size_t dynamic_n_ = 0;  // what the last step emitted
 };
 
 class LiquidWorld;
@@ -307,11 +322,12 @@ class LiquidWorld {  // liquid_world.rs
     // boundary.volumes / boundary.forces (and, for sampled boundaries, positions / velocities) after a step
     void sync_boundary(BoundaryHandle h) {
         Boundary& b = boundaries_[h];
-        if (!b.num_particles()) return;
+        if (b.dynamic_shape.kind) b.dynamic_n_ = (size_t)salva_hip_boundary_len(w_, (uint32_t)h);
+        if (!b.num_particles()) { b.positions.clear(); b.velocities.clear(); b.volumes.clear(); b.forces.clear(); return; }
         b.volumes.resize(b.num_particles());
         if (b.wants_forces) b.forces.resize(b.num_particles());
         check(salva_hip_get_boundary(w_, (uint32_t)h, b.volumes.data(), b.wants_forces ? b.forces[0].data() : nullptr));
-        if (!b.sampling.empty()) {
+        if (!b.sampling.empty() || b.dynamic_shape.kind) {
             b.positions.resize(b.num_particles()); b.velocities.resize(b.num_particles());
             check(salva_hip_get_boundary_particles(w_, (uint32_t)h, b.positions[0].data(), b.velocities[0].data()));
         }
@@ -444,6 +460,12 @@ class LiquidWorld {  // liquid_world.rs
     void upload(Boundary& b, uint32_t slot) {
         if (!b.dirty_) return;
         const size_t n = b.num_particles();
+        if (b.dynamic_shape.kind) {
+            check(salva_hip_set_boundary_dynamic_sampling(w_, slot, &b.dynamic_shape, b.interaction_groups.memberships,
+                                                          b.interaction_groups.filter));
+            b.dirty_ = false;
+            return;
+        }
         if (!b.sampling.empty()) {
             check(salva_hip_set_boundary_sampling(w_, slot, n, b.sampling[0].data(), b.interaction_groups.memberships,
                                                   b.interaction_groups.filter));
@@ -472,7 +494,8 @@ class ColliderCouplingSet : public CouplingManager {
         std::function<SalvaHipRigidPose()> pose;
         std::function<void(const Vec3& impulse, const Vec3& torque_impulse)> apply;  // may be empty (kinematic / fixed bodies)
     };
-    // register_coupling(boundary, collider, ColliderSampling::StaticSampling(points)): the points live in Boundary::sampling
+    // register_coupling(boundary, collider, sampling_method): StaticSampling(points) -> the points live in Boundary::sampling;
+    // DynamicContactSampling -> the collider's shape lives in Boundary::dynamic_shape
     void register_coupling(BoundaryHandle boundary, std::function<SalvaHipRigidPose()> pose,
                            std::function<void(const Vec3&, const Vec3&)> apply = {}) {
         entries_.push_back(Entry{boundary, std::move(pose), std::move(apply)});

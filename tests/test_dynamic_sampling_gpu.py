@@ -211,3 +211,28 @@ def test_rejected_uses():
     u32p = C.POINTER(C.c_uint32)
     with pytest.raises(_lib.SalvaHipError):
         _lib.check(w._L.salva_hip_get_boundary_sources(w._h, b._slot, C.cast(None, u32p), C.cast(None, u32p)))
+
+
+def test_cpp_mirror_dynamic_coupling_example():
+    """examples/dynamic_coupling3.cpp: a half-density ball dropped on a pool through include/salva_hip.hpp's
+    Boundary::dynamic_ball + ColliderCouplingSet.  It must fall, meet the water (boundary particles appear), be slowed down and
+    stay above the pool floor."""
+    import os
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "dynamic_coupling3")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "examples")])
+    out = subprocess.run([exe, "400"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    lines = out.stdout.strip().splitlines()
+    rows = [re.match(r"step (\d+): ball y (-?[\d.]+) vy (-?[\d.]+) \|angvel\| ([\d.]+), lowest sample y (-?[\d.]+), (\d+) samples", ln) for ln in lines]
+    assert all(rows), lines
+    y = [float(m.group(2)) for m in rows]
+    vy = [float(m.group(3)) for m in rows]
+    samples = [int(m.group(6)) for m in rows]
+    assert y[0] > y[-1], lines                       # it fell
+    assert max(samples) > 20, lines                  # the fluid was projected onto it
+    assert abs(vy[-1]) < 1.0 and y[-1] > 0.1, lines  # free fall for 2 s would be 19.6 m/s and far below the floor
