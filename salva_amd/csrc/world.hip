@@ -649,6 +649,24 @@ static void dims_from_bbox(const int32_t* bb, GridDims& g) {
         nc *= (double)g.nt[a];
     }
     if (nc >= 4.0e9) throw HipError(SALVA_HIP_E_CAPACITY, "dense cell table would exceed 2^32 cells; particles are too spread out");
+    // The reference's hash grid costs memory per OCCUPIED cell; this table costs 4 bytes per cell of the bounding box (plus
+    // 8 bytes per tile of 64 cells).  A few stray particles far from the rest therefore cost memory here that they do not
+    // cost there: refuse beyond a budget, with a message that says what to do, rather than exhaust HBM.
+    static const double budget_gib = [] {
+        const char* e = getenv("SALVA_HIP_CELL_TABLE_GIB");
+        const double v = e ? atof(e) : 8.0;
+        return v > 0.0 ? v : 8.0;
+    }();
+    const double gib = (nc * 4.0 + nc / TCELLS * 8.0) / (1024.0 * 1024.0 * 1024.0);
+    if (gib > budget_gib) {
+        char msg[512];
+        snprintf(msg, sizeof msg,
+                 "the cell table over the particles' bounding box (%d x %d x %d tiles of %dx%dx%d cells) would take %.1f GiB, over the "
+                 "%.1f GiB budget: particles are too spread out for the dense grid — delete strays (salva_hip_particles_intersecting_aabb "
+                 "+ salva_hip_delete_particles) or raise SALVA_HIP_CELL_TABLE_GIB",
+                 g.nt[0], g.nt[1], g.nt[2], TX, TY, TZ, gib, budget_gib);
+        throw HipError(SALVA_HIP_E_CAPACITY, msg);
+    }
 }
 
 // Sort the boundary particles by cell, build their cell table and volumes.  Runs when the boundary set changed

@@ -417,6 +417,25 @@ def test_stray_particles_far_from_the_bulk():
     assert st.step_ms < 20.0, f"a step over a mostly empty 30M-cell box took {st.step_ms:.1f} ms"
 
 
+def test_strays_beyond_the_cell_table_budget_are_refused_with_advice():
+    """The dense cell table costs 4 bytes per cell of the bounding box (the reference's hash grid: per occupied cell).  Past
+    the budget (8 GiB, SALVA_HIP_CELL_TABLE_GIB) the step fails with E_CAPACITY and says what to do; the world stays usable
+    once the stray is gone."""
+    from salva_amd import _lib
+
+    s = Scene(R, 2.0, "dfsph")
+    block = scenes.jitter(scenes.cube_fluid_positions(6, 6, 6, R), 0.1 * R, seed=42)
+    pos = np.concatenate([block, np.float32([[150.0, 140.0, 160.0]])]).astype(np.float32)  # 1500 x 1400 x 1600 cells = 12.5 GiB
+    s.add_fluid(pos, None, 1000.0)
+    w, (fl,), _ = s.make_hip()
+    with pytest.raises(_lib.SalvaHipError) as e:
+        w.step(DT, GRAVITY)
+    assert e.value.code == _lib.E_CAPACITY and "SALVA_HIP_CELL_TABLE_GIB" in str(e.value) and "delete strays" in str(e.value)
+    fl.delete_particle_at_next_timestep(len(pos) - 1)
+    st = w.step(DT, GRAVITY)
+    assert st.nparticles == len(block)
+
+
 def test_device_side_add_and_delete_match_the_host_path():
     """Fluid::add_particles / delete_particle_at_next_timestep (fluid.rs:71-150; SURVEY.md §8 row f4).  A faucet-like loop
     run twice: once growing / compacting the fluid on the device (salva_hip_add_particles / salva_hip_delete_particles),

@@ -33,3 +33,18 @@ def test_box_shell_and_tank():
     assert len(fluid) == 64
     assert shell[:, 1].min() < fluid[:, 1].min()
     assert len(np.unique(np.round((shell - shell.min(axis=0)) / 0.1).astype(int), axis=0)) == len(shell)
+
+
+def test_committed_scene_files_match_the_python_builders(tmp_path):
+    """bench/rust_ref/scenes/*.scene (what the real salva3d is run on, tests/golden/compare_rust_dump.py) are the golden scenes."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "tests", "golden", "export_scenes.py"), "--out", str(tmp_path)],
+                          stdout=subprocess.DEVNULL)
+    names = sorted(os.listdir(tmp_path))
+    assert len(names) == 6
+    for n in names:
+        assert open(os.path.join(tmp_path, n), "rb").read() == open(os.path.join(root, "bench", "rust_ref", "scenes", n), "rb").read(), n
