@@ -113,7 +113,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_artificial_viscosity(StepC
         if (fc != 0.0f) {
             for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
                 const float4 pj = Lp[s];
-                const float4 vj = Lw[s];
+                const float4 vj = lds_f4(Lw + s);
                 const float rj = Lr[s];
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float r2 = dx * dx + dy * dy + dz * dz;

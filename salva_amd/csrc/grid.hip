@@ -407,6 +407,15 @@ void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, 
 // (the sums are counters.cd.ncontacts; the maxima tell the host whether the fixed ELL capacity was enough).
 struct TileListStats { uint32_t sum_ff, sum_fb, max_ff, max_fb; };
 
+// V = 0: one candidate per iteration, nested branches on every accepted candidate (the round-1 kernel; kept for comparison,
+//        SALVA_HIP_NBR_VARIANT=0).
+// V = 1: four candidates in flight per lane (independent LDS reads and distance chains) and a branch-light append: with 64
+//        lanes accepting candidates on different iterations the accept path runs on almost every iteration, and in V = 0 it
+//        is a ladder of ~5 scalar branches per candidate; here it is selects plus one predicated store.
+// Both write the same lists in the same order.  (Parking the completed dwords in a per-wave LDS buffer and writing them out
+// with 16-byte stores was tried too: the 6 KiB per wave halve the resident waves and the kernel time doubles — the loop is
+// bound by per-wave latency, not by the stores)
+template <int V>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileListStats* __restrict__ tile_stats) {
     __shared__ uint32_t red[4][TILE_MAX_WAVES];
     Tile t;
@@ -418,14 +427,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
     TileCells tc;
     tc.build(c, t, true);
     const bool multi = c.nmodels > 1;
-    float4* Lp = t.carve<float4>(t.S);
+    float4* Lp = t.carve<float4>(t.S + 3u);  // (+3: the four-wide candidate loop reads up to three slots past a row's end)
     uint32_t* Lm = multi ? t.carve<uint32_t>(t.S) : nullptr;
     float4* Bp = t.carve<float4>(t.SB);
     float4* Bv = t.carve<float4>(t.SB);
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
     t.for_halo(c, [&](uint32_t s, uint32_t g) { Lp[s] = c.posm[g]; if (multi) Lm[s] = c.model[g]; });
     t.for_halo_boundary(c, [&](uint32_t s, uint32_t g) { Bp[s] = c.bposv[g]; Bv[s] = c.bvel[g]; });
     __syncthreads();
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
     uint32_t sum_ff = 0, sum_fb = 0, max_ff = 0, max_fb = 0;
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         uint32_t cnt = 0, cntb = 0;
@@ -445,19 +454,65 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
         }
         uint32_t* __restrict__ outb = c.nbr_fb + (size_t)gs * c.cap_fb * WAVE + 4u * lane;
         uint32_t pend = 0, pendb = 0;
+        // interaction-group tests of this particle's model as bit masks (one bit per fluid / boundary model): no table load
+        // per accepted candidate
+        // (V = 1 is launched only when both model counts are <= 32)
+        uint32_t ffmask = 0xffffffffu, fbmask = 0u;
+        if (V != 0) {
+            if (multi) {
+                ffmask = 0u;
+                for (uint32_t m = 0; m < c.nmodels; ++m) ffmask |= (c.ff_ok[mi * c.nmodels + m] ? 1u : 0u) << m;
+            }
+            if (t.SB)
+                for (uint32_t m = 0; m < c.nbmodels; ++m) fbmask |= (c.fb_ok[mi * c.nbmodels + m] ? 1u : 0u) << m;
+        }
+        auto ff_allowed = [&](uint32_t s) -> bool {
+            return V != 0 ? ((ffmask >> Lm[s]) & 1u) != 0u : c.ff_ok[mi * c.nmodels + Lm[s]] != 0;
+        };
+        auto append = [&](uint32_t s) {
+            if (cnt & 1u) { if ((cnt >> 1) < c.cap_ff) out[ellq(cnt >> 1)] = pend | (s << 16); }
+            else pend = s;
+            ++cnt;
+        };
 #pragma unroll 1
         for (int dx = -1; dx <= 1; ++dx) {
 #pragma unroll 1
             for (int dy = -1; dy <= 1; ++dy) {
                 const int row = ((lx + dx) * HY + (ly + dy)) * HZ + (lz - 1);
                 const uint32_t b = tc.lstart[row], e = tc.lstart[row + 3];
-                for (uint32_t s = b; s < e; ++s) {
-                    const float4 pj = Lp[s];
-                    const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                    if (d2 <= c.sc.h2 && (!multi || c.ff_ok[mi * c.nmodels + Lm[s]])) {
-                        if (cnt & 1u) { if ((cnt >> 1) < c.cap_ff) out[ellq(cnt >> 1)] = pend | (s << 16); }
-                        else pend = s;
-                        ++cnt;
+                if (V == 0) {
+                    for (uint32_t s = b; s < e; ++s) {
+                        const float4 pj = Lp[s];
+                        const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                        if (d2 <= c.sc.h2 && (!multi || c.ff_ok[mi * c.nmodels + Lm[s]])) append(s);
+                    }
+                } else {
+                    // distance tests first, into one bit per candidate (four candidates in flight, addressed from one base:
+                    // the staged array is padded by three slots, bits past the row's end are cleared afterwards); then only
+                    // the accepted candidates — a sixth of them — go through the append path
+                    for (uint32_t base = b; base < e; base += 32u) {
+                        const uint32_t nc = min(e - base, 32u);
+                        uint32_t mask = 0u;
+                        const float4* __restrict__ lp = Lp + base;
+                        for (uint32_t k = 0; k < nc; k += 4u) {
+                            float4 p0 = lp[k], p1 = lp[k + 1], p2 = lp[k + 2], p3 = lp[k + 3];
+                            // keep the reads 16 bytes wide: ds_read_b128 occupies the LDS pipe for 4 cycles per wave, the
+                            // ds_read_b96 the compiler would pick for an unused .w for 8 (MI355X_MICROARCH.md, LDS table)
+                            asm volatile("" : "+v"(p0.w), "+v"(p1.w), "+v"(p2.w), "+v"(p3.w));
+                            const float d0 = dist2_exact(pi.x - p0.x, pi.y - p0.y, pi.z - p0.z);
+                            const float d1 = dist2_exact(pi.x - p1.x, pi.y - p1.y, pi.z - p1.z);
+                            const float d2 = dist2_exact(pi.x - p2.x, pi.y - p2.y, pi.z - p2.z);
+                            const float d3 = dist2_exact(pi.x - p3.x, pi.y - p3.y, pi.z - p3.z);
+                            const uint32_t nib = (d0 <= c.sc.h2 ? 1u : 0u) | (d1 <= c.sc.h2 ? 2u : 0u) | (d2 <= c.sc.h2 ? 4u : 0u) |
+                                                 (d3 <= c.sc.h2 ? 8u : 0u);
+                            mask |= nib << k;
+                        }
+                        mask &= nc >= 32u ? 0xffffffffu : ((1u << nc) - 1u);
+                        while (mask) {
+                            const uint32_t s = base + (uint32_t)__builtin_ctz(mask);
+                            mask &= mask - 1u;
+                            if (!multi || ff_allowed(s)) append(s);
+                        }
                     }
                 }
                 if (t.SB) {
@@ -465,7 +520,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
                     for (uint32_t s = bb; s < be; ++s) {
                         const float4 pj = Bp[s];
                         const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                        if (d2 <= c.sc.h2 && c.fb_ok[mi * c.nbmodels + __float_as_uint(Bv[s].w)]) {
+                        const uint32_t bm = __float_as_uint(Bv[s].w);
+                        if (d2 <= c.sc.h2 && (V != 0 ? ((fbmask >> bm) & 1u) != 0u : c.fb_ok[mi * c.nbmodels + bm] != 0)) {
                             if (cntb & 1u) { if ((cntb >> 1) < c.cap_fb) outb[ellq(cntb >> 1)] = pendb | (s << 16); }
                             else pendb = s;
                             ++cntb;
@@ -542,7 +598,13 @@ size_t tile_list_stats_bytes(uint32_t ntiles) { return (size_t)ntiles * sizeof(T
 void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsigned long long* totals2, uint32_t* maxima2,
                       hipStream_t s) {
     if (c.n == 0) return;
-    SALVA_LAUNCH_TILE(k_nbr_tile, c, L, L.bytes(20, 32, 4, true), s, c, static_cast<TileListStats*>(tile_stats));
+    static const int variant = [] { const char* e = getenv("SALVA_HIP_NBR_VARIANT"); return e ? atoi(e) : 1; }();
+    TileListStats* ts = static_cast<TileListStats*>(tile_stats);
+    if (variant == 0 || c.nmodels > 32u || c.nbmodels > 32u) {
+        SALVA_LAUNCH_TILE(k_nbr_tile<0>, c, L, L.bytes(20, 32, 4, true) + 64u, s, c, ts);
+    } else {
+        SALVA_LAUNCH_TILE(k_nbr_tile<1>, c, L, L.bytes(20, 32, 4, true) + 64u, s, c, ts);
+    }
     k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.nlaunch, totals2, maxima2);
 }
 

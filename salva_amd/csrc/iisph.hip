@@ -87,7 +87,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_pred_density(StepCtx
         float delta = 0.0f;
         for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
             const float4 pj = Lp[s];
-            const float4 wj = Lw[s];
+            const float4 wj = lds_f4(Lw + s);
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
             delta += pj.w * (((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
                 const float fji = dt * dt * pi.w / (rhoi * rhoi);
                 float sum = 0.0f;
                 struct Rec { float4 p, q; };
-                for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], Lq[s]}; }, [&](const Rec& rc) {
+                for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], lds_f4(Lq + s)}; }, [&](const Rec& rc) {
                     const float4 pj = rc.p;
                     const float4 qj = rc.q;  // d_jj p_j + sum_k d_jk p_k (k_iisph_dij_pj)
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;

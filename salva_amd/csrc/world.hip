@@ -1881,6 +1881,7 @@ float World::time_kernel(int kernel, int reps) {
     if (kernel == 0) return time_pred_density(reps);
     if (reps < 1) reps = 1;
     const bool iisph = prm.solver == SALVA_HIP_SOLVER_IISPH;
+    if (kernel == 4 && comm) throw HipError(SALVA_HIP_E_INVALID, "not available in a multi-GPU run");
     if ((kernel == 2 || kernel == 3) && !iisph) throw HipError(SALVA_HIP_E_INVALID, "an IISPH kernel needs an IISPH world");
     if (kernel == 1 && iisph) throw HipError(SALVA_HIP_E_INVALID, "k_divergence needs a DFSPH world");
     StepCtx cd = last_ctx;
@@ -1890,6 +1891,7 @@ float World::time_kernel(int kernel, int reps) {
             case 1: launch_divergence(cd, lds, stream); break;
             case 2: launch_iisph_next_pressure(cd, lds, last_dt, 0.5f, kappa.p, kappa2.p, stream); break;
             case 3: launch_iisph_dij_pj(cd, lds, last_dt, kappa.p, stream); break;
+            case 4: launch_nbr_build(cd, lds, tile_list_stats.p, d_counters.p, d_maxhalo.p, stream); break;  // rebuilds the same lists
             default: throw HipError(SALVA_HIP_E_INVALID, "unknown kernel id");
         }
     };
