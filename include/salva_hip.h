@@ -122,8 +122,9 @@ typedef struct SalvaHipCounters {
     } stages;
     struct {
         uint64_t ncontacts;                   /* liquid_world.rs:119 */
-        double boundary_update_time;          /* liquid_world.rs:94-103: coupling.update_boundaries — here the caller's
-                                                 salva_hip_update_boundary_pose calls run before the step: 0 */
+        double boundary_update_time;          /* liquid_world.rs:94-103: coupling.update_boundaries — the DynamicContactSampling
+                                                 pass inside the step; statically sampled boundaries are posed by the caller's
+                                                 salva_hip_update_boundary_pose before the step and add nothing here */
         double grid_insertion_time;           /* liquid_world.rs:89-92,105-107: cell sort of fluids (+ boundaries when changed) */
         double neighborhood_search_time;      /* contacts.rs:154-252 via update_contacts: tile tables + neighbour lists */
         double contact_sorting_time;          /* never started in the reference: 0 */

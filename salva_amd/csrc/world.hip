@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -1015,6 +1016,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     bool has_custom = false;
     for (auto& f : fluids) for (auto& d : f.forces) has_custom |= d.kind == SALVA_HIP_FORCE_CUSTOM;
     const bool has_dyn = has_dynamic_sampling();
+    double dcs_ms = 0.0;
     if (has_dyn && comm) throw HipError(SALVA_HIP_E_INVALID, "DynamicContactSampling is not available in a multi-GPU run");
     const bool can_speculate = !spec_off && !comm && !any_wants_forces && !has_custom && !b_dirty && !has_dyn && pred_valid && pred_n == n;
     int32_t bbox_pre[6];
@@ -1029,7 +1031,13 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     {
         TileGrid gv{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], nullptr};
         launch_cell_keys(posm[cur].p, n, sc.h, gv, keys[0].p, idx[0].p, d_flags.p, stream);
-        if (has_dyn) run_dynamic_sampling();  // coupling.update_boundaries (liquid_world.rs:94-103): may push particles, cells stay
+        if (has_dyn) {  // coupling.update_boundaries (liquid_world.rs:94-103): may push particles, cells stay
+            // (host clock: the pass ends with a read-back of the emitted count, so the stream is drained when it returns)
+            if (timers) wait_stream();
+            const auto t1 = std::chrono::steady_clock::now();
+            run_dynamic_sampling();
+            dcs_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        }
         const int end_bit = bits_for(ncf);
         const size_t tb = sort_pairs_temp_bytes(n, end_bit);
         ensure_cub_temp(tb);
@@ -1194,7 +1202,8 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         counters.step_time = a + b;
         counters.stages.collision_detection_time = a;
         counters.stages.solver_time = b;
-        counters.cd.grid_insertion_time = ms(ev[0], evc[1]);
+        counters.cd.boundary_update_time = dcs_ms;  // DynamicContactSampling runs inside the step (liquid_world.rs:94-103)
+        counters.cd.grid_insertion_time = std::max(0.0, (double)ms(ev[0], evc[1]) - dcs_ms);
         counters.cd.neighborhood_search_time = ms(evc[1], ev[1]);
         counters.solver.pressure_resolution_time = ms(evc[2], ev[2]);
         if (prm.solver == SALVA_HIP_SOLVER_DFSPH) counters.custom = ms(evc[3], evc[4]);

@@ -236,3 +236,20 @@ def test_cpp_mirror_dynamic_coupling_example():
     assert y[0] > y[-1], lines                       # it fell
     assert max(samples) > 20, lines                  # the fluid was projected onto it
     assert abs(vy[-1]) < 1.0 and y[-1] > 0.1, lines  # free fall for 2 s would be 19.6 m/s and far below the floor
+
+
+def test_counters_report_the_boundary_update():
+    pos, vel, slab, ball = _calm_scene(10)
+    w = LiquidWorld(DFSPHSolver(), R, 2.0)
+    fl = Fluid(pos, R, 1000.0)
+    h = w.add_fluid(fl)
+    b = w.add_boundary(Boundary(np.zeros((0, 3), np.float32)))
+    coupling = ColliderCouplingSet()
+    coupling.register_coupling(b, "slab", slab, DynamicContactSampling(("cuboid", CUBOID_HE)))
+    slab.dynamic = False
+    for _ in range(3):
+        w.step_with_coupling(DT, GRAVITY, coupling)
+    c = w.counters
+    assert c.cd.boundary_update_time > 0.0 and c.cd.grid_insertion_time >= 0.0
+    assert c.stages.collision_detection_time >= c.cd.boundary_update_time
+    assert b.num_particles() > 0 and h.num_particles() == len(pos)
