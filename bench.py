@@ -126,13 +126,17 @@ def make_config_oracle(config: int, fluids, shell, threads: int):
     return w
 
 
-def committed_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*/hbm_traffic.json, written by
-    tools/summarize_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same scene, with the
-    gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside this process, so this is the
-    measured figure of the committed profile, not of this run; None if there is none."""
+def committed_traffic(kernel: str, config: int, side: int):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of THIS workload (profiles/r*_cfg<config>/ for the
+    10^6-per-fluid configurations, profiles/r*_8m/ for side 200; newest round first), written by tools/summarize_pmc.py
+    from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 correction of MI355X_MICROARCH.md.
+    Counters cannot be read from inside this process, so this is the measured figure of the committed profile, not of
+    this run; None if there is none for this workload."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "hbm_traffic.json")), reverse=True):
+    tag = {100: f"cfg{config}", 200: "8m" if config == 2 else None}.get(side)
+    if tag is None:
+        return None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}", "hbm_traffic.json")), reverse=True):
         try:
             k = json.load(open(f))["kernels"].get(kernel)
         except (OSError, ValueError, KeyError):
@@ -290,7 +294,7 @@ def main():
         kbar = float(st.reserved[3])
     algo_bytes = n * (4.0 * kbar + sbytes)  # N (4K + S) bytes per launch
     achieved = algo_bytes / (kernel_us * 1e-6) / 1e9
-    traffic, traffic_src = committed_traffic(kname) if (n == 1000000 and args.config == 2) else (None, None)
+    traffic, traffic_src = committed_traffic(kname, args.config, args.side) if not decomposed else (None, None)
     roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_us": kernel_us,
                 "algorithmic_bytes": algo_bytes, "mean_contacts": kbar}
