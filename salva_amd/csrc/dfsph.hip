@@ -475,26 +475,32 @@ __global__ __launch_bounds__(BLOCK) void k_sum_partials(const float* __restrict_
         if (threadIdx.x == 0) sums[m] = s;
     }
 }
-__global__ void k_decide(const float* __restrict__ sums, uint32_t nmodels, const uint32_t* __restrict__ model_counts, SolveCtl* ctl) {
-    if (threadIdx.x != 0 || ctl->done) return;
-    float best = 0.0f;
-    for (uint32_t m = 0; m < nmodels; ++m)
-        if (model_counts[m] != 0) best = fmaxf(best, sums[m] / (float)model_counts[m]);
-    ctl->err = best;
-    if (ctl->mode == 0) {
-        if (best <= ctl->tol && ctl->iters >= ctl->min_iter) ctl->done = 1u;
-        else ctl->iters += 1u;
-    } else {
-        const uint32_t i = ctl->iters;
-        ctl->iters = i + 1u;
-        if (best <= ctl->tol && i >= ctl->min_iter) ctl->done = 1u;
+__global__ void k_decide(const float* __restrict__ sums, uint32_t nmodels, const uint32_t* __restrict__ model_counts, SolveCtl* ctl,
+                         SolveCtl* pub) {
+    if (threadIdx.x != 0) return;
+    if (!ctl->done) {
+        float best = 0.0f;
+        for (uint32_t m = 0; m < nmodels; ++m)
+            if (model_counts[m] != 0) best = fmaxf(best, sums[m] / (float)model_counts[m]);
+        ctl->err = best;
+        if (ctl->mode == 0) {
+            if (best <= ctl->tol && ctl->iters >= ctl->min_iter) ctl->done = 1u;
+            else ctl->iters += 1u;
+        } else {
+            const uint32_t i = ctl->iters;
+            ctl->iters = i + 1u;
+            if (best <= ctl->tol && i >= ctl->min_iter) ctl->done = 1u;
+        }
     }
+    const uint32_t s = ctl->seq + 1u;  // one tick per convergence test, converged or not: the host waits for the count it enqueued
+    ctl->seq = s;
+    publish_ctl(ctl, pub, s);
 }
 void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmodels, const SolveCtl* ctl, float* sums, hipStream_t s) {
     k_sum_partials<<<1, BLOCK, 0, s>>>(partials, nblocks, nmodels, ctl, sums);
 }
-void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, hipStream_t s) {
-    k_decide<<<1, 64, 0, s>>>(sums, nmodels, model_counts, ctl);
+void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, SolveCtl* pub, hipStream_t s) {
+    k_decide<<<1, 64, 0, s>>>(sums, nmodels, model_counts, ctl, pub);
 }
 void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
                            SolveCtl* ctl, SolveCtl* pub, hipStream_t s) {

@@ -84,7 +84,7 @@ void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmo
                            SolveCtl* ctl, SolveCtl* pub, hipStream_t s);
 // multi-GPU form: per-fluid sums of this rank -> sums[nmodels]; (all-reduce over ranks); break test on the global sums
 void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmodels, const SolveCtl* ctl, float* sums, hipStream_t s);
-void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, hipStream_t s);
+void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, SolveCtl* pub, hipStream_t s);
 
 // ---------------------------------------------------------------- dfsph_pipe.hip (persistent tile pipeline, pipe.h)
 void launch_pred_density_pipe(const StepCtx& c, const PipeCfg& P, float dt, hipStream_t s);

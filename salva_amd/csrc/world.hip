@@ -725,11 +725,11 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
     h_ctl[which] = init;
     SALVA_HIP_CHECK(hipMemcpyAsync(d_ctl.p + which, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
     c.ctl = d_ctl.p + which;
-    // Single domain: every convergence test publishes its outcome to host-mapped memory, and the host waits for the test
-    // count it enqueued — it then decides (and enqueues what follows) while the batch's last apply pass is still running.
-    // Decomposed runs keep the copy + wait (their decision kernel runs behind an all-reduce).
+    // Every convergence test publishes its outcome to host-mapped memory (k_finalize_error; in a decomposed run k_decide,
+    // behind the all-reduce), and the host waits for the test count it enqueued — it then decides (and enqueues what
+    // follows) while the batch's last apply pass is still running.
     static const bool no_publish = getenv("SALVA_HIP_NO_PUBLISH") != nullptr;  // (diagnostics: A/B against the copy + wait)
-    SolveCtl* const pub = (comm || no_publish) ? nullptr : h_pub + which;
+    SolveCtl* const pub = no_publish ? nullptr : h_pub + which;
     if (pub) { pub->done = 0u; pub->iters = 0u; pub->err = 0.0f; __atomic_store_n(&pub->seq, 0u, __ATOMIC_RELEASE); }
     // First batch: what the previous step's solve needed (iters applies + the converged evaluate) — consecutive steps
     // need about the same, so the usual cost is one read-back per solve; a batch that overshoots only enqueues kernels

@@ -2,6 +2,7 @@
 // globally reduced convergence test.  Protocol and sizes: comm.h, dist.h, DESIGN.md §6.
 #include <algorithm>
 #include <climits>
+#include <cstring>
 
 #include "world.h"
 
@@ -148,6 +149,25 @@ void World::dist_prepare() {
         nbr_hi_hi = has_hi ? (int)((long long)from_hi[1] - (long long)OFF) : INT32_MAX;
         nbr_bounds_valid = true;
     }
+    // The cell bounding box of the set this step works on, without a reduction pass over it: h_rb->bbox (if valid) covers
+    // every particle this rank held at the end of the last step, and what arrives — migrants and ghost planes — lies in the
+    // two cell planes beyond a face at most and inside the sender's own box in y and z, which rides along in the spare
+    // word of the two count exchanges (mode 1: y range, mode 2: z range; all-ones = "my box is not valid").
+    const bool had_bbox = bbox_known;
+    const uint64_t NO_BOX = ~0ull;
+    auto pack_range = [&](int a) -> uint64_t {
+        if (!had_bbox) return NO_BOX;
+        return ((uint64_t)(uint32_t)h_rb->bbox[a] << 32) | (uint64_t)(uint32_t)h_rb->bbox[3 + a];
+    };
+    int32_t merged[6];
+    memcpy(merged, h_rb->bbox, sizeof(merged));
+    bool box_ok = had_bbox;
+    auto merge_range = [&](int a, uint64_t w, bool present) {
+        if (!present) return;
+        if (w == NO_BOX) { box_ok = false; return; }
+        merged[a] = std::min(merged[a], (int)(int32_t)(uint32_t)(w >> 32));
+        merged[3 + a] = std::max(merged[3 + a], (int)(int32_t)(uint32_t)(w & 0xffffffffull));
+    };
     for (int mode = 1; mode <= 2; ++mode) {
         dsel.ensure(dist_sel_bytes(n), stream, false, 1.25f);
         dpos.ensure(dist_sel_bytes(n), stream, false, 1.25f);
@@ -159,9 +179,12 @@ void World::dist_prepare() {
         xsend_lo.ensure(std::max<uint32_t>(tot[1], 1u), stream, false, 1.25f);
         xsend_hi.ensure(std::max<uint32_t>(tot[2], 1u), stream, false, 1.25f);
         launch_dist_pack(n, dist_arrays(cur), dist_arrays(cur ^ 1), dsel.p, dpos.p, mode, xsend_lo.p, xsend_hi.p, stream);
-        const uint64_t to_lo[2] = {tot[1], 0}, to_hi[2] = {tot[2], 0};
+        const uint64_t range = pack_range(mode);  // (axis 1 = y with the migrants, axis 2 = z with the ghost planes)
+        const uint64_t to_lo[2] = {tot[1], range}, to_hi[2] = {tot[2], range};
         uint64_t from_lo[2] = {0, 0}, from_hi[2] = {0, 0};
         comm->exchange_counts(to_lo, to_hi, from_lo, from_hi, stream);
+        merge_range(mode, from_lo[1], has_lo);
+        merge_range(mode, from_hi[1], has_hi);
         const uint32_t base = (mode == 1) ? tot[0] : n;
         const uint64_t total = (uint64_t)base + from_lo[0] + from_hi[0];
         if (total >= 0xfffffff0ull) throw HipError(SALVA_HIP_E_CAPACITY, "too many particles in one slab");
@@ -189,7 +212,14 @@ void World::dist_prepare() {
     ghost_lo_idx.ensure(std::max(nghost_lo, 1u), stream, false, 1.25f); ghost_hi_idx.ensure(std::max(nghost_hi, 1u), stream, false, 1.25f);
     fbuf_send.ensure(std::max(nborder_lo + nborder_hi, 1u), stream, false, 1.25f);
     fbuf_recv.ensure(std::max(nghost_lo + nghost_hi, 1u), stream, false, 1.25f);
-    bbox_known = false;  // ghosts and arrivals are not covered by the box reduced at the end of the last step
+    if (box_ok) {
+        if (has_lo) merged[0] = std::min(merged[0], slab_lo - GHOST_PLANES);
+        if (has_hi) merged[3] = std::max(merged[3], slab_hi + GHOST_PLANES);
+        memcpy(h_rb->bbox, merged, sizeof(merged));
+        bbox_known = true;
+    } else {
+        bbox_known = false;  // first step / after host edits: reduce the box over the particles (World::step)
+    }
 }
 
 void World::dist_build_lists() {
@@ -233,7 +263,7 @@ void World::finalize_solve(SolveCtl* ctl, SolveCtl* pub) {
     }
     launch_sum_partials(partials.p, ntiles, nm, ctl, d_sums.p, stream);
     comm->allreduce_sum_f32(d_sums.p, (int)nm, stream);
-    launch_decide(d_sums.p, nm, model_counts.p, ctl, stream);
+    launch_decide(d_sums.p, nm, model_counts.p, ctl, pub, stream);
 }
 
 // Download the particles this rank owns (unordered): global ids, positions, velocities, fluid slot.  Returns the count.
