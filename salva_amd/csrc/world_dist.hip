@@ -178,7 +178,8 @@ void World::dist_prepare() {
                            cub_temp.p, tb, d_flags.p, tot, stream);
         xsend_lo.ensure(std::max<uint32_t>(tot[1], 1u), stream, false, 1.25f);
         xsend_hi.ensure(std::max<uint32_t>(tot[2], 1u), stream, false, 1.25f);
-        launch_dist_pack(n, dist_arrays(cur), dist_arrays(cur ^ 1), dsel.p, dpos.p, mode, xsend_lo.p, xsend_hi.p, stream);
+        launch_dist_pack(n, dist_arrays(cur), dist_arrays(cur ^ 1), sc.h, slab_lo, slab_hi, has_lo, has_hi, mode, nbr_lo_lo, nbr_hi_hi, dpos.p,
+                         xsend_lo.p, xsend_hi.p, stream);
         const uint64_t range = pack_range(mode);  // (axis 1 = y with the migrants, axis 2 = z with the ghost planes)
         const uint64_t to_lo[2] = {tot[1], range}, to_hi[2] = {tot[2], range};
         uint64_t from_lo[2] = {0, 0}, from_hi[2] = {0, 0};
