@@ -156,8 +156,9 @@ struct Readback {
     int32_t bbox[6];      // fluid cell bbox (min xyz, max xyz)
     int32_t bbbox[6];     // boundary cell bbox
     TileAcc tile_total;   // totals and maxima of halo slots / boundary halo slots / slices over the tiles
-    uint64_t ncontacts_ff, ncontacts_fb, ncontacts_bb;
-    uint32_t max_cnt_ff, max_cnt_fb;   // longest contact lists of the step (capacity check)
+    uint64_t ncontacts_bb;
+    uint64_t ncontacts_ff, ncontacts_fb;   // } written by k_list_stats and read back in one copy
+    uint32_t max_cnt_ff, max_cnt_fb;       // } longest contact lists of the step (capacity check)
     uint32_t dcs_count, pad_;          // points emitted by the last DynamicContactSampling pass
 };
 

@@ -204,7 +204,7 @@ class World {
     // reductions / readback
     DevBuf<float> partials;
     DevBuf<Readback> d_rb;
-    DevBuf<uint32_t> d_flags;
+    struct FlagsPtr { uint32_t* p = nullptr; } d_flags;  // = &d_rb.p->flags: flags and the next step's box come back in one copy
     DevBuf<unsigned long long> d_counters;
     Readback* h_rb = nullptr;
     DevBuf<SolveCtl> d_ctl;      // [0] divergence solve, [1] pressure solve, [2] viscosity solve (DFSPHViscosity)

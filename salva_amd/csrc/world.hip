@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstddef>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -137,7 +138,8 @@ World::World(const SalvaHipParams& p) : prm(p) {
     memset(h_pub, 0, NUM_SOLVES * sizeof(SolveCtl));
     d_ctl.ensure(NUM_SOLVES);
     d_rb.ensure(1);
-    d_flags.ensure(1);
+    d_flags.p = &d_rb.p->flags;
+    SALVA_HIP_CHECK(hipMemset(d_rb.p, 0, sizeof(Readback)));
     d_counters.ensure(4);
     for (auto& e2 : ev) SALVA_HIP_CHECK(hipEventCreate(&e2));
     for (auto& e2 : evc) SALVA_HIP_CHECK(hipEventCreate(&e2));
@@ -1138,10 +1140,10 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             const bool r2 = nbr_fb.ensure(nb ? (size_t)nslices * cap_fb * WAVE + 1 : 1, stream, false, 1.1f);
             (void)r1; (void)r2;
             c = make_ctx();
-            launch_nbr_build(c, lds, tile_list_stats.p, d_counters.p, d_maxhalo.p, stream);
+            launch_nbr_build(c, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff, stream);
             if (spec) break;
-            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, d_counters.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->max_cnt_ff, d_maxhalo.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            static_assert(offsetof(Readback, max_cnt_ff) == offsetof(Readback, ncontacts_ff) + 2 * sizeof(uint64_t), "list statistics travel in one copy");
+            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, &d_rb.p->ncontacts_ff, 2 * sizeof(uint64_t) + 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             wait_stream();
             const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;
             if (need_ff <= cap_ff && need_fb <= cap_fb) break;
@@ -1160,12 +1162,11 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     else iisph_solve(c, dt, g, st);
 
     // ---- end of step: next bbox + flags (+ in a speculative pass: the true table totals and list statistics)
-    SALVA_HIP_CHECK(hipMemcpyAsync(h_rb->bbox, d_rb.p->bbox, sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
-    SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->flags, d_flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    static_assert(offsetof(Readback, bbox) == offsetof(Readback, flags) + sizeof(uint32_t), "flags and bbox travel in one copy");
+    SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->flags, &d_rb.p->flags, sizeof(uint32_t) + sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
     if (spec) {
         SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + nslots_bound, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, d_counters.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->max_cnt_ff, d_maxhalo.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, &d_rb.p->ncontacts_ff, 2 * sizeof(uint64_t) + 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     }
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[2], stream));
     wait_stream();
@@ -1900,7 +1901,7 @@ float World::time_kernel(int kernel, int reps) {
             case 1: launch_divergence(cd, lds, stream); break;
             case 2: launch_iisph_next_pressure(cd, lds, last_dt, 0.5f, kappa.p, kappa2.p, stream); break;
             case 3: launch_iisph_dij_pj(cd, lds, last_dt, kappa.p, stream); break;
-            case 4: launch_nbr_build(cd, lds, tile_list_stats.p, d_counters.p, d_maxhalo.p, stream); break;  // rebuilds the same lists
+            case 4: launch_nbr_build(cd, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff, stream); break;  // rebuilds the same lists
             default: throw HipError(SALVA_HIP_E_INVALID, "unknown kernel id");
         }
     };
