@@ -526,4 +526,14 @@ class ColliderCouplingSet : public CouplingManager {
     std::vector<SalvaHipRigidPose> poses_;
 };
 
+// FluidsPipeline (integrations/rapier/fluids_pipeline.rs:18-61): the liquid world (always DFSPH there, :35) and the coupling
+// set in one object; step(gravity, dt) = liquid_world.step_with_coupling(dt, gravity, coupling manager) (:48-60).  The rapier
+// ColliderSet / RigidBodySet arguments of the reference are the closures held by the coupling entries here.
+struct FluidsPipeline {
+    LiquidWorld liquid_world;
+    ColliderCouplingSet coupling;
+    FluidsPipeline(Real particle_radius, Real smoothing_factor) : liquid_world(DFSPHSolver(), particle_radius, smoothing_factor) {}
+    void step(const Vec3& gravity, Real dt) { liquid_world.step_with_coupling(dt, gravity, coupling); }
+};
+
 }  // namespace salva

@@ -179,3 +179,19 @@ class ColliderCouplingSet:
                                                            t.ctypes.data_as(fp)))
             e.body.apply_impulse(f * F32(dt))
             e.body.apply_torque_impulse(t * F32(dt))
+
+
+class FluidsPipeline:
+    """integrations/rapier/fluids_pipeline.rs:18-61: the liquid world (always DFSPH there, :35) and the coupling set in one object.
+    `step(gravity, dt, colliders, bodies)` is `liquid_world.step_with_coupling(dt, gravity, &mut coupling.as_manager_mut(colliders,
+    bodies))` (:48-60); in this mirror the bodies hang on the coupling entries (`register_coupling(boundary, collider, body,
+    sampling)`), so the two set arguments are accepted for signature compatibility and not looked at."""
+
+    def __init__(self, particle_radius: float, smoothing_factor: float):
+        from .world import DFSPHSolver, LiquidWorld  # (world.py imports nothing from here: no cycle at call time)
+
+        self.liquid_world = LiquidWorld(DFSPHSolver(), particle_radius, smoothing_factor)
+        self.coupling = ColliderCouplingSet()
+
+    def step(self, gravity, dt: float, colliders=None, bodies=None):
+        return self.liquid_world.step_with_coupling(dt, gravity, self.coupling)

@@ -212,3 +212,17 @@ def basic3(nparticles: int = 15, particle_rad: float = 0.05):
         (ground, np.zeros(3, dtype=F), ident),
     ]
     return fluid, colliders
+
+
+def surface_tension3():
+    """The literal scene of /root/reference/examples3d/surface_tension3.rs:18-92: a 1 cm^3 droplet in decimetre units —
+    cube_fluid(7, 7, 7, r = 0.005, 1000) lifted by 0.08, Akinci2013SurfaceTension(1.0, 0.0) then ArtificialViscosity(0.01, 0.01),
+    gravity (0, -0.981, 0), dt = 1/200 — over a fixed cuboid ground (half extents 0.15 x 0.02 x 0.15 at the origin) coupled by
+    ColliderSampling::DynamicContactSampling to an initially empty boundary.
+
+    Returns dict(radius, fluid, forces, gravity, ground_half_extents)."""
+    r = 0.005
+    fluid = cube_fluid_positions(7, 7, 7, r)
+    fluid = (fluid + np.array([0.0, 0.08, 0.0], dtype=F)[None, :]).astype(F)  # transform_by(Isometry3::translation(0, 0.08, 0))
+    return dict(radius=r, fluid=fluid, forces=[("akinci", 1.0, 0.0), ("artificial", 0.01, 0.01)], gravity=(0.0, -0.981, 0.0),
+                ground_half_extents=(0.15, 0.02, 0.15))
