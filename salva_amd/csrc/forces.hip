@@ -49,7 +49,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
                 const float rj = rc.r;
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
-                const float sc = (__float_as_uint(vj.w) == model) ? fc * wgt * pj.w / rj : 0.0f;
+                const float sc = (__float_as_uint(vj.w) == model) ? fast_div(fc * wgt * pj.w, rj) : 0.0f;
                 fx += (vj.x - vi.x) * sc; fy += (vj.y - vi.y) * sc; fz += (vj.z - vi.z) * sc;
             };
             for_each_ff2(c, gs, nqu, o.lh, [&](uint32_t s) { return Rec{Lp[s], Lw[s], Lr[s]}; }, [&](const Rec& A, const Rec& B) { one(A); one(B); });
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
                 const float4 vj = Bv[s];
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
-                const float sc = bc * wgt * pj.w * rho0 / ri;
+                const float sc = fast_div(bc * wgt * pj.w * rho0, ri);
                 const float ex = (vj.x - vi.x) * sc, ey = (vj.y - vi.y) * sc, ez = (vj.z - vi.z) * sc;
                 bx += ex; by += ey; bz += ez;
                 if (c.bforce && !is_ghost(c, i)) {
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_artificial_viscosity(StepC
                 const float vr = dx * (vi.x - vj.x) + dy * (vi.y - vj.y) + dz * (vi.z - vj.z);
                 if (__float_as_uint(vj.w) == model && vr < 0.0f) {
                     const float g = kernel_grad(r2, c.sc);
-                    const float mu = h * vr / (r2 + eta2);
-                    const float sc = g * (fc * (cs * alpha * mu - beta * mu * mu) * (pj.w / ((ri + rj) * 0.5f)));
+                    const float mu = fast_div(h * vr, r2 + eta2);
+                    const float sc = g * (fc * (cs * alpha * mu - beta * mu * mu) * fast_div(pj.w, (ri + rj) * 0.5f));
                     fx += dx * sc; fy += dy * sc; fz += dz * sc;
                 }
             });
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_artificial_viscosity(StepC
                 const float vr = dx * (vi.x - vj.x) + dy * (vi.y - vj.y) + dz * (vi.z - vj.z);
                 if (vr < 0.0f) {
                     const float g = kernel_grad(r2, c.sc);
-                    const float mu = h * vr / (r2 + eta2);
-                    const float sc = g * (bc * (cs * alpha * mu - beta * mu * mu) * (pj.w * rho0 / ri));
+                    const float mu = fast_div(h * vr, r2 + eta2);
+                    const float sc = g * (bc * (cs * alpha * mu - beta * mu * mu) * fast_div(pj.w * rho0, ri));
                     bx += dx * sc; by += dy * sc; bz += dz * sc;
                     // the reference applies the *running sum* of the boundary acceleration here (:117)
                     if (c.bforce && !is_ghost(c, i))
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_normals(StepCtx c, 
             const bool same = Lm ? (Lm[s] == model) : true;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-            const float sc = same ? g * (pj.w / rj) : 0.0f;
+            const float sc = same ? g * fast_div(pj.w, rj) : 0.0f;
             nx += dx * sc; ny += dy * sc; nz += dz * sc;
         });
         // .w carries rho_i: the force pass then stages (position, mass) + (normal, density) = 32 bytes per halo slot and two
@@ -202,8 +202,8 @@ __device__ __forceinline__ float cohesion_kernel(float r, float h, float norm, f
 // adhesion_kernel :90-111 — A(r) = 0.007 / h^3.25 * (-4 r^2/h + 6 r - 2 h)^(1/4) for h/2 < r <= h
 __device__ __forceinline__ float adhesion_kernel(float r, float h, float norm) {
     if (r > h * 0.5f && r <= h) {
-        const float tt = fmaxf(-4.0f * r * r / h + 6.0f * r - 2.0f * h, 0.0f);
-        return norm * sqrtf(sqrtf(tt));
+        const float tt = fmaxf(fast_div(-4.0f * r * r, h) + 6.0f * r - 2.0f * h, 0.0f);
+        return norm * __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(tt));  // (1 ulp each: the sum it feeds is compared at 1e-5)
     }
     return 0.0f;
 }
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, u
                         const float rinv = __builtin_amdgcn_rsqf(r2);
                         cs = cohesion_kernel(r2 * rinv, h, cnorm, h6_64) * rinv * (-tc * pj.w);
                     }
-                    const float kij = 2.0f * rho0 / (ri + rj);
+                    const float kij = fast_div(2.0f * rho0, ri + rj);
                     a.x += ((ni.x - nj.x) * -tc + dx * cs) * kij;
                     a.y += ((ni.y - nj.y) * -tc + dy * cs) * kij;
                     a.z += ((ni.z - nj.z) * -tc + dz * cs) * kij;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_colors(StepCtx c, u
             const bool same = Lm ? (Lm[s] == model) : true;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
-            color += same ? wgt * pj.w / rj : 0.0f;
+            color += same ? fast_div(wgt * pj.w, rj) : 0.0f;
         });
         for_each_fb(c, t, i, gs, [&](uint32_t s) {
             const float4 pj = Bp[s];
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_gradc(StepCtx c, ui
             const bool same = Lm ? (Lm[s] == model) : true;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-            const float sc = same ? g * cj * pj.w / rj : 0.0f;
+            const float sc = same ? fast_div(g * cj * pj.w, rj) : 0.0f;
             gx += dx * sc; gy += dy * sc; gz += dz * sc;
         });
         const float ci = colors[i];
@@ -385,13 +385,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_forces(StepCtx c, u
         if (tc != 0.0f) {
             const float ts = tc / (2.0f * mi);
             float fx = 0.f, fy = 0.f, fz = 0.f;
+            const float mi_over_ri = mi / ri;  // (per own particle: correctly rounded, as the reference's left-to-right product starts)
             for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
                 const float4 pj = Lp[s];
                 const float rj = Lr[s], gj = Lg[s];
                 const bool same = Lm ? (Lm[s] == model) : true;
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-                const float sc = same ? g * (mi / ri * pj.w / rj * (gi + gj) * 0.5f) * ts : 0.0f;
+                const float sc = same ? g * (fast_div(mi_over_ri * pj.w, rj) * (gi + gj) * 0.5f) * ts : 0.0f;
                 fx += dx * sc; fy += dy * sc; fz += dz * sc;
             });
             a.x += fx; a.y += fy; a.z += fz;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_wcsph_tension(StepCtx c, u
             const bool same = Lm ? (Lm[s] == model) : true;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
-            const float sc = same ? -tc * wgt * pj.w / pi.w : 0.0f;
+            const float sc = same ? fast_div(-tc * wgt * pj.w, pi.w) : 0.0f;
             fx += dx * sc; fy += dy * sc; fz += dz * sc;
         });
         float4 a = c.acc[i];

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dij_pj(StepCtx c, fl
             const float rhoj = Lr[s];
             const float pjl = Lq[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (-pj.w * pjl / (rhoj * rhoj));
+            const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * fast_div(-pj.w * pjl, rhoj * rhoj);
             x += dx * sc; y += dy * sc; z += dz * sc;
         });
         const float dt2 = dt * dt;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(Ste
             const float rhoj = Lr[s];
             const float pjl = Lq[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (dt * pj.w * (pri + pjl / (rhoj * rhoj)));
+            const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (dt * pj.w * (pri + fast_div(pjl, rhoj * rhoj)));
             d.x -= dx * sc; d.y -= dy * sc; d.z -= dz * sc;
         });
         for_each_fb(c, t, i, gs, [&](uint32_t s) {

@@ -75,6 +75,11 @@ __device__ __forceinline__ float opaque(float x) {
     return x;
 }
 
+// a / b with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the 12-instruction correctly rounded sequence every
+// plain `/` (and __fdividef, on this toolchain) expands to.  For quotients inside neighbour sums — one per contact pair — whose
+// results are compared at 1e-5 relative; never for anything that feeds the exact d^2 <= h^2 test or a cell coordinate.
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
 struct KernelEval {
     float w;  // W(|d|)
     float g;  // (dW/dr)/|d|  — gradient = g * d
