@@ -1,0 +1,323 @@
+//! `LiquidWorld` with salva3d's surface (reference: src/liquid_world.rs:17-280) whose `step` runs on the device.
+//!
+//! SOURCE ONLY — never compiled (no Rust toolchain where it was written).  Design notes:
+//! * the host `FluidSet` / `BoundarySet` are salva3d's own; the device world mirrors them slot by slot (dense indices =
+//!   `as_slice()` order, which is what `ContiguousArena::remove`'s swap-remove preserves on both sides);
+//! * `fluids_mut()` / `boundaries_mut()` hand out `&mut` access, so everything is re-uploaded before the next step after
+//!   either was called; a run that only calls `step` uploads nothing;
+//! * after a step the new positions / velocities are downloaded into the host set (`auto_sync`, on by default: the
+//!   reference's users read `fluid.positions` every frame); headless runs switch it off and call `sync()` when they look.
+use crate::ffi;
+use na::Vector3;
+use nalgebra as na;
+use salva3d::counters::Counters;
+use salva3d::math::Real;
+use salva3d::object::{Boundary, BoundaryHandle, BoundarySet, Fluid, FluidHandle, FluidSet};
+use salva3d::solver::{DFSPHSolver, IISPHSolver};
+use std::ffi::CStr;
+
+#[derive(Debug)]
+pub struct Error {
+    pub code: i32,
+    pub message: String,
+}
+
+fn check(code: i32) -> Result<(), Error> {
+    if code == ffi::SALVA_HIP_OK {
+        return Ok(());
+    }
+    let message = unsafe { CStr::from_ptr(ffi::salva_hip_last_error()) }.to_string_lossy().into_owned();
+    Err(Error { code, message })
+}
+
+/// The two pressure solvers the device implements, recognised by their public tuning fields
+/// (dfsph_solver.rs:21-38, iisph_solver.rs:21-30).
+pub trait GpuPressureSolver {
+    fn params(&self, particle_radius: Real, smoothing_factor: Real) -> ffi::SalvaHipParams;
+}
+
+fn default_params() -> ffi::SalvaHipParams {
+    let mut p = std::mem::MaybeUninit::<ffi::SalvaHipParams>::uninit();
+    unsafe {
+        ffi::salva_hip_default_params(p.as_mut_ptr());
+        p.assume_init()
+    }
+}
+
+impl GpuPressureSolver for DFSPHSolver {
+    fn params(&self, particle_radius: Real, smoothing_factor: Real) -> ffi::SalvaHipParams {
+        let mut p = default_params();
+        p.particle_radius = particle_radius;
+        p.smoothing_factor = smoothing_factor;
+        p.solver = ffi::SALVA_HIP_SOLVER_DFSPH;
+        p.min_pressure_iter = self.min_pressure_iter as i32;
+        p.max_pressure_iter = self.max_pressure_iter as i32;
+        p.max_density_error = self.max_density_error;
+        p.min_divergence_iter = self.min_divergence_iter as i32;
+        p.max_divergence_iter = self.max_divergence_iter as i32;
+        p.max_divergence_error = self.max_divergence_error;
+        p
+    }
+}
+
+impl GpuPressureSolver for IISPHSolver {
+    fn params(&self, particle_radius: Real, smoothing_factor: Real) -> ffi::SalvaHipParams {
+        let mut p = default_params();
+        p.particle_radius = particle_radius;
+        p.smoothing_factor = smoothing_factor;
+        p.solver = ffi::SALVA_HIP_SOLVER_IISPH;
+        p.min_pressure_iter = self.min_pressure_iter as i32;
+        p.max_pressure_iter = self.max_pressure_iter as i32;
+        p.max_density_error = self.max_density_error;
+        p
+    }
+}
+
+pub struct LiquidWorld {
+    /// `world.counters` as the reference's plugins read it (counters/mod.rs:17-72); refreshed by every step.
+    pub counters: Counters,
+    raw: *mut ffi::SalvaHipWorld,
+    particle_radius: Real,
+    h: Real,
+    fluids: FluidSet,
+    boundaries: BoundarySet,
+    host_dirty: bool,    // fluids_mut() / boundaries_mut() / add_* was called since the last upload
+    device_newer: bool,  // a step ran since the last download
+    auto_sync: bool,
+    last_stats: ffi::SalvaHipStepStats,
+}
+
+// the C side keeps no thread-affine state: every entry point selects the world's device and stream itself
+// (the reference asserts the same of its own world, liquid_world.rs:283-287)
+unsafe impl Send for LiquidWorld {}
+unsafe impl Sync for LiquidWorld {}
+
+impl Drop for LiquidWorld {
+    fn drop(&mut self) {
+        unsafe { ffi::salva_hip_destroy(self.raw) }
+    }
+}
+
+impl LiquidWorld {
+    /// `LiquidWorld::new(solver, particle_radius, smoothing_factor)` (liquid_world.rs:39-57).
+    pub fn new(solver: impl GpuPressureSolver, particle_radius: Real, smoothing_factor: Real) -> Result<Self, Error> {
+        let mut params = solver.params(particle_radius, smoothing_factor);
+        params.enable_timers = 1;
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { ffi::salva_hip_create(&params, &mut raw) })?;
+        Ok(Self {
+            counters: Counters::new(),
+            raw,
+            particle_radius,
+            h: unsafe { ffi::salva_hip_h(raw) },
+            fluids: FluidSet::new(),
+            boundaries: BoundarySet::new(),
+            host_dirty: true,
+            device_newer: false,
+            auto_sync: true,
+            last_stats: unsafe { std::mem::zeroed() },
+        })
+    }
+
+    pub fn set_auto_sync(&mut self, on: bool) {
+        self.auto_sync = on;
+    }
+
+    pub fn h(&self) -> Real {
+        self.h
+    }
+    pub fn particle_radius(&self) -> Real {
+        self.particle_radius
+    }
+
+    pub fn add_fluid(&mut self, fluid: Fluid) -> FluidHandle {
+        self.host_dirty = true;
+        self.fluids.insert(fluid)
+    }
+    pub fn add_boundary(&mut self, boundary: Boundary) -> BoundaryHandle {
+        self.host_dirty = true;
+        self.boundaries.insert(boundary)
+    }
+
+    /// Swap-remove on both sides (liquid_world.rs:171-173; the solver's per-slot buffers stay positional there and here).
+    pub fn remove_fluid(&mut self, handle: FluidHandle) -> Result<Option<Fluid>, Error> {
+        self.sync()?;
+        let slot = self.fluids.iter().position(|(h, _)| h == handle);
+        if let Some(slot) = slot {
+            if (slot as u32) < unsafe { ffi::salva_hip_num_fluids(self.raw) } {
+                check(unsafe { ffi::salva_hip_remove_fluid(self.raw, slot as u32) })?;
+            }
+        }
+        self.host_dirty = true;
+        Ok(self.fluids.remove(handle))
+    }
+    pub fn remove_boundary(&mut self, handle: BoundaryHandle) -> Result<Option<Boundary>, Error> {
+        let slot = self.boundaries.iter().position(|(h, _)| h == handle);
+        if let Some(slot) = slot {
+            if (slot as u32) < unsafe { ffi::salva_hip_num_boundaries(self.raw) } {
+                check(unsafe { ffi::salva_hip_remove_boundary(self.raw, slot as u32) })?;
+            }
+        }
+        self.host_dirty = true;
+        Ok(self.boundaries.remove(handle))
+    }
+
+    pub fn fluids(&self) -> &FluidSet {
+        &self.fluids
+    }
+    /// Mutable access: the device state is downloaded first (the caller sees the current particles) and everything is
+    /// uploaded again before the next step.
+    pub fn fluids_mut(&mut self) -> Result<&mut FluidSet, Error> {
+        self.sync()?;
+        self.host_dirty = true;
+        Ok(&mut self.fluids)
+    }
+    pub fn boundaries(&self) -> &BoundarySet {
+        &self.boundaries
+    }
+    pub fn boundaries_mut(&mut self) -> &mut BoundarySet {
+        self.host_dirty = true;
+        &mut self.boundaries
+    }
+
+    /// Positions / velocities of every fluid, boundary volumes and forces: device -> host, if a step ran since the last time.
+    pub fn sync(&mut self) -> Result<(), Error> {
+        if !self.device_newer {
+            return Ok(());
+        }
+        for (slot, fluid) in self.fluids.as_mut_slice().iter_mut().enumerate() {
+            if fluid.num_particles() == 0 {
+                continue;
+            }
+            // Vec<Point3<f32>> / Vec<Vector3<f32>> are [x, y, z] f32 in memory
+            check(unsafe {
+                ffi::salva_hip_get_fluid(self.raw, slot as u32, fluid.positions.as_mut_ptr() as *mut f32, fluid.velocities.as_mut_ptr() as *mut f32)
+            })?;
+        }
+        for (slot, b) in self.boundaries.as_mut_slice().iter_mut().enumerate() {
+            let n = b.num_particles();
+            if n == 0 {
+                continue;
+            }
+            let forces_ptr = match &mut b.forces {
+                Some(lock) => {
+                    let f = lock.get_mut().unwrap();
+                    f.resize(n, Vector3::zeros());
+                    f.as_mut_ptr() as *mut f32
+                }
+                None => std::ptr::null_mut(),
+            };
+            check(unsafe { ffi::salva_hip_get_boundary(self.raw, slot as u32, b.volumes.as_mut_ptr(), forces_ptr) })?;
+        }
+        self.device_newer = false;
+        Ok(())
+    }
+
+    fn upload(&mut self) -> Result<(), Error> {
+        if !self.host_dirty {
+            return Ok(());
+        }
+        for (slot, fluid) in self.fluids.as_mut_slice().iter_mut().enumerate() {
+            // host-side half of apply_particles_removal + init_with_fluids (fluid.rs:88-98, dfsph_solver.rs:526-561): the
+            // survivors' velocity_changes are fetched, filtered with the same mask and sent back with the particles
+            let deleted: Vec<bool> = fluid.deleted_particles_mask().to_vec();
+            if fluid.num_deleted_particles() != 0 {
+                let mask: Vec<u8> = deleted.iter().map(|d| *d as u8).collect();
+                if (slot as u32) < unsafe { ffi::salva_hip_num_fluids(self.raw) } {
+                    let left = unsafe { ffi::salva_hip_delete_particles(self.raw, slot as u32, mask.as_ptr()) };
+                    if left < 0 {
+                        return check(left as i32);
+                    }
+                }
+                // (Fluid::apply_particles_removal is pub(crate) upstream: the wrapper crate needs it `pub`, see README.md)
+                fluid.apply_particles_removal();
+            }
+            let descs: Vec<ffi::SalvaHipForceDesc> = fluid
+                .nonpressure_forces
+                .iter()
+                .map(|f| {
+                    // `gpu_desc` is the one method the upstream trait gains (README.md): Some((kind, params)) for the built-ins,
+                    // None for user forces, which then run on the host through the force callback (kind 7) at their place
+                    // in the list
+                    let (kind, p) = f.gpu_desc().unwrap_or((ffi::SALVA_HIP_FORCE_CUSTOM, [0.0; 7]));
+                    ffi::SalvaHipForceDesc { kind, p }
+                })
+                .collect();
+            let n = fluid.num_particles() as u64;
+            check(unsafe {
+                ffi::salva_hip_set_fluid(
+                    self.raw,
+                    slot as u32,
+                    n,
+                    fluid.positions.as_ptr() as *const f32,
+                    fluid.velocities.as_ptr() as *const f32,
+                    fluid.volumes.as_ptr(),
+                    fluid.accelerations.as_ptr() as *const f32,
+                    std::ptr::null(), // velocity_changes stay where they are on the device
+                    fluid.density0,
+                    fluid.interaction_groups.memberships.bits(),
+                    fluid.interaction_groups.filter.bits(),
+                    ffi::SALVA_HIP_DIRTY_ALL as u32,
+                )
+            })?;
+            check(unsafe { ffi::salva_hip_set_fluid_forces(self.raw, slot as u32, descs.as_ptr(), descs.len() as u32) })?;
+        }
+        for (slot, b) in self.boundaries.as_slice().iter().enumerate() {
+            check(unsafe {
+                ffi::salva_hip_set_boundary(
+                    self.raw,
+                    slot as u32,
+                    b.num_particles() as u64,
+                    b.positions.as_ptr() as *const f32,
+                    b.velocities.as_ptr() as *const f32,
+                    b.interaction_groups.memberships.bits(),
+                    b.interaction_groups.filter.bits(),
+                    b.forces.is_some() as i32,
+                )
+            })?;
+        }
+        self.host_dirty = false;
+        Ok(())
+    }
+
+    /// `LiquidWorld::step(dt, gravity)` (liquid_world.rs:62-158 with the `()` coupling manager).
+    pub fn step(&mut self, dt: Real, gravity: &Vector3<Real>) -> Result<(), Error> {
+        self.upload()?;
+        let g = [gravity.x, gravity.y, gravity.z];
+        check(unsafe { ffi::salva_hip_step(self.raw, dt, g.as_ptr(), &mut self.last_stats) })?;
+        self.device_newer = true;
+        self.refresh_counters()?;
+        if self.auto_sync {
+            self.sync()?;
+        }
+        Ok(())
+    }
+
+    fn refresh_counters(&mut self) -> Result<(), Error> {
+        let mut c = std::mem::MaybeUninit::<ffi::SalvaHipCounters>::uninit();
+        check(unsafe { ffi::salva_hip_get_counters(self.raw, c.as_mut_ptr()) })?;
+        let c = unsafe { c.assume_init() };
+        // (the reference's timers have no setter: the wrapper crate needs `Timer::set_time(ms)` or pub fields, README.md)
+        self.counters.nsubsteps = c.nsubsteps as usize;
+        self.counters.cd.ncontacts = c.cd.ncontacts as usize;
+        self.counters.step_time.set_time(c.step_time);
+        self.counters.custom.set_time(c.custom);
+        self.counters.stages.collision_detection_time.set_time(c.stages.collision_detection_time);
+        self.counters.stages.solver_time.set_time(c.stages.solver_time);
+        self.counters.cd.boundary_update_time.set_time(c.cd.boundary_update_time);
+        self.counters.cd.grid_insertion_time.set_time(c.cd.grid_insertion_time);
+        self.counters.cd.neighborhood_search_time.set_time(c.cd.neighborhood_search_time);
+        self.counters.solver.pressure_resolution_time.set_time(c.solver.pressure_resolution_time);
+        Ok(())
+    }
+
+    /// Iteration counts, errors and contacts of the last step (not in the reference's API).
+    pub fn last_step(&self) -> &ffi::SalvaHipStepStats {
+        &self.last_stats
+    }
+
+    /// The raw handle, for the entry points this wrapper does not cover (coupling, queries, multi-GPU).
+    pub fn raw(&mut self) -> *mut ffi::SalvaHipWorld {
+        self.raw
+    }
+}

@@ -68,3 +68,19 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.lower() or f in ("sph_math.h",), os.path.join(dirpath, f)
+
+
+def test_rust_ffi_is_generated_from_the_header():
+    """bindings/rust/salva3d-hip/src/ffi.rs = tools/gen_rust_ffi.py(include/salva_hip.h): every exported entry point is declared
+    there, and the committed file is what the generator writes today."""
+    import re
+    import subprocess
+    import sys
+
+    from salva_amd import _lib
+
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"]) == 0, "run python tools/gen_rust_ffi.py"
+    src = open(os.path.join(ROOT, "bindings", "rust", "salva3d-hip", "src", "ffi.rs")).read()
+    assert set(re.findall(r"pub fn (salva_hip_\w+)", src)) == set(_lib.EXPORTED_SYMBOLS)
+    for s in ("SalvaHipParams", "SalvaHipForceDesc", "SalvaHipStepStats", "SalvaHipCounters", "SalvaHipRigidPose", "SalvaHipShape"):
+        assert f"pub struct {s} " in src
