@@ -136,7 +136,8 @@ typedef struct SalvaHipCounters {
     /* --- not in the reference: what this implementation adds to a step report --- */
     int32_t n_divergence_iters, n_pressure_iters;
     uint64_t speculative_passes;              /* steps whose table sizes were predicted from the previous step (no mid-step read-back) */
-    uint64_t discarded_passes;                /* ... of which the prediction failed and the step was repeated with exact sizes */
+    uint64_t discarded_passes;                /* passes discarded and repeated: a failed prediction, or a neighbour list longer than
+                                                 the capacity it was built with (checked at the end of the step) */
 } SalvaHipCounters;
 
 /* fields of salva_hip_get_fluid_field (solver scratch the reference keeps private; exposed for parity tests) */

@@ -535,8 +535,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
         self_slot = tc.lstart[hself] + (i - tc.gstart[hself]);
         if ((cnt & 1u) && (cnt >> 1) < c.cap_ff) out[ellq(cnt >> 1)] = pend | (self_slot << 16);
         if ((cntb & 1u) && (cntb >> 1) < c.cap_fb) outb[ellq(cntb >> 1)] = pendb;
-        c.nff[i] = cnt;
-        c.nfb[i] = cntb;
+        // (a list longer than the capacity was cut: the consumers must not walk past the rows that exist; the statistics below
+        // keep the true lengths, from which the host sees the overflow, grows the capacity and repeats the pass)
+        c.nff[i] = min(cnt, 2u * c.cap_ff);
+        c.nfb[i] = min(cntb, 2u * c.cap_fb);
         sum_ff += cnt; sum_fb += cntb;
         max_ff = max(max_ff, cnt); max_fb = max(max_fb, cntb);
         }

@@ -126,6 +126,8 @@ World::World(const SalvaHipParams& p) : prm(p) {
     // discarded, 2.25 ms per step against 1.88 ms without speculation.  Kept as an option for steady flows.
     spec_off = getenv("SALVA_HIP_SPECULATE") == nullptr || getenv("SALVA_HIP_NO_SPECULATION") != nullptr;
     spec_tight = getenv("SALVA_HIP_SPEC_TIGHT") != nullptr;
+    defer_off = getenv("SALVA_HIP_NO_DEFER_LISTS") != nullptr;
+    if (const char* e = getenv("SALVA_HIP_LIST_CAP0")) cap_ff = std::max<uint32_t>(LIST_REGS, ((uint32_t)atoi(e) + 3u) & ~3u);  // (tests: force an overflow)
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device) == hipSuccess && cus > 0) num_cus = cus;
@@ -1020,7 +1022,13 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     const bool has_dyn = has_dynamic_sampling();
     double dcs_ms = 0.0;
     if (has_dyn && comm) throw HipError(SALVA_HIP_E_INVALID, "DynamicContactSampling is not available in a multi-GPU run");
-    const bool can_speculate = !spec_off && !comm && !any_wants_forces && !has_custom && !b_dirty && !has_dyn && pred_valid && pred_n == n;
+    // a pass can be repeated from the untouched pre-sort buffers iff it has no side effect outside the world's own arrays
+    const bool can_redo = !comm && !any_wants_forces && !has_custom && !has_dyn;
+    const bool can_speculate = !spec_off && can_redo && !b_dirty && pred_valid && pred_n == n;
+    // The neighbour-list capacity check (longest list <= ELL capacity) costs a read-back with an idle GPU in the middle of the
+    // step although it fails about once per run (the capacity follows the longest list seen so far): where the pass can be
+    // repeated, check at the end of the step with the read-back that happens there anyway, and repeat on overflow.
+
     int32_t bbox_pre[6];
     memcpy(bbox_pre, h_rb->bbox, sizeof(bbox_pre));
     const float dt_prev0 = dt_prev, inv_dt_prev0 = inv_dt_prev;
@@ -1028,6 +1036,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     StepCtx c{};
     for (int attempt = 0;; ++attempt) {
     bool spec = can_speculate && attempt == 0;
+    const bool defer_lists = can_redo && !defer_off && attempt == 0;
     if (attempt > 0) SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));  // (whatever the discarded pass flagged)
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
     {
@@ -1141,7 +1150,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             (void)r1; (void)r2;
             c = make_ctx();
             launch_nbr_build(c, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff, stream);
-            if (spec) break;
+            if (spec || defer_lists) break;
             static_assert(offsetof(Readback, max_cnt_ff) == offsetof(Readback, ncontacts_ff) + 2 * sizeof(uint64_t), "list statistics travel in one copy");
             SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, &d_rb.p->ncontacts_ff, 2 * sizeof(uint64_t) + 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             wait_stream();
@@ -1164,12 +1173,23 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     // ---- end of step: next bbox + flags (+ in a speculative pass: the true table totals and list statistics)
     static_assert(offsetof(Readback, bbox) == offsetof(Readback, flags) + sizeof(uint32_t), "flags and bbox travel in one copy");
     SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->flags, &d_rb.p->flags, sizeof(uint32_t) + sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
-    if (spec) {
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + nslots_bound, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
+    if (spec) SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + nslots_bound, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
+    if (spec || defer_lists)
         SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, &d_rb.p->ncontacts_ff, 2 * sizeof(uint64_t) + 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    }
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[2], stream));
     wait_stream();
+    if (defer_lists && !spec) {
+        const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;
+        if (need_ff > cap_ff || need_fb > cap_fb) {
+            // a list was cut at the capacity: everything this pass computed is discarded; the pre-sort buffers are intact
+            ++counters.discarded_passes;
+            cur = cur0; dt_prev = dt_prev0; inv_dt_prev = inv_dt_prev0;
+            memcpy(h_rb->bbox, bbox_pre, sizeof(bbox_pre));
+            if (need_ff > cap_ff) cap_ff = (need_ff + need_ff / 4 + 4u) & ~3u;
+            if (need_fb > cap_fb) cap_fb = (need_fb + need_fb / 4 + 4u) & ~3u;
+            continue;
+        }
+    }
     if (spec) {
         const TileAcc& a = h_rb->tile_total;
         const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;

@@ -23,7 +23,8 @@ def _dam_break():
 
 
 def _run(env, nsteps=50):
-    old = {k: os.environ.get(k) for k in ("SALVA_HIP_SPECULATE", "SALVA_HIP_NO_SPECULATION", "SALVA_HIP_SPEC_TIGHT")}
+    old = {k: os.environ.get(k) for k in ("SALVA_HIP_SPECULATE", "SALVA_HIP_NO_SPECULATION", "SALVA_HIP_SPEC_TIGHT", "SALVA_HIP_NO_DEFER_LISTS",
+                                          "SALVA_HIP_LIST_CAP0")}
     for k in old:
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -53,6 +54,45 @@ def test_speculative_steps_are_bit_identical_to_exact_ones():
         assert it == it0
         assert np.array_equal(f.positions, f0.positions) and np.array_equal(f.velocities, f0.velocities)
         assert np.array_equal(w.velocity_changes(f), w0.velocity_changes(f0))
+
+
+def _run_scene(scene, env, nsteps):
+    keys = ("SALVA_HIP_NO_DEFER_LISTS", "SALVA_HIP_LIST_CAP0")
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        w, (fl,), _ = scene.make_hip()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    iters = []
+    for k in range(nsteps):
+        st = w.step(DT, (0.0, 0.0, 0.0))
+        iters.append((st.n_divergence_iters, st.n_pressure_iters, int(st.ncontacts), int(w.contact_counts(fl).max()) if k == 0 else 0))
+    return w, fl, iters
+
+
+def test_deferred_list_capacity_check_repeats_the_pass_on_overflow():
+    """The list-capacity check rides on the end-of-step read-back where a pass can be repeated (no mid-step sync for it); a list
+    cut at the capacity discards the pass, grows the capacity and runs the step again.  On a block compressed to 2.4x the rest
+    density (~75 contacts per particle) both the default capacity (48 contacts) and the smallest one (40) overflow in the first
+    step: the run must take the repeat path and still equal, bit for bit, a world that checks in the middle of every step."""
+    s = Scene(R, 2.0, "dfsph")
+    pos = (scenes.jitter(scenes.cube_fluid_positions(12, 12, 12, R), 0.05 * R, seed=9) * np.float32(0.75)).astype(np.float32)
+    s.add_fluid(pos, None, 1000.0, forces=[("xsph", 0.5, 0.0)])
+    w0, f0, it0 = _run_scene(s, {"SALVA_HIP_NO_DEFER_LISTS": "1"}, 4)
+    w1, f1, it1 = _run_scene(s, {"SALVA_HIP_LIST_CAP0": "20"}, 4)
+    w2, f2, it2 = _run_scene(s, {}, 4)
+    assert it0[0][3] > 48, it0[0]
+    assert w1.counters.discarded_passes >= 1 and w2.counters.discarded_passes >= 1 and w0.counters.discarded_passes == 0
+    for w, f, it in ((w1, f1, it1), (w2, f2, it2)):
+        assert it == it0
+        assert np.array_equal(f.positions, f0.positions) and np.array_equal(f.velocities, f0.velocities)
+        assert np.array_equal(w.contact_counts(f), w0.contact_counts(f0))
 
 
 def test_counters_tree_is_filled_like_the_reference():
