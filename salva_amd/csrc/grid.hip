@@ -80,17 +80,44 @@ void launch_cell_keys(const float4* pts, uint32_t n, float h, TileGrid g, uint32
 // rocPRIM's default switches from its merge sort to the one-sweep radix sort only above 2^20 items; at 10^6 particles
 // the merge path costs 10 merge passes (~140 us) where three 8-bit radix passes over 22-bit keys cost ~40.  Lower the
 // switch-over to 64 Ki items.
+// ... and the keys are short (18 bits at 10^6 particles, 21 at 8 x 10^6), so the number of passes is what counts: digits of 9 or
+// 10 bits (rocPRIM's tuned configurations stop at 8) sort 18 bits in two passes of 9 instead of three.
+template <int BITS>
+using OnesweepBits = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<512, 12>, BITS,
+                                                         rocprim::block_radix_rank_algorithm::match>;
+template <int BITS>
+using SortConfigBits = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, OnesweepBits<BITS>, 65536>;
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+static int sort_digit_bits(int end_bit) {
+    static const bool off = getenv("SALVA_HIP_SORT_DEFAULT_DIGITS") != nullptr;  // (A/B: rocPRIM's own 8-bit configuration)
+    // (measured: 18 bits in 2 x 9 instead of 3 passes saves 49 us per step at 10^6 particles; 21 bits in 2 x 11 is no faster than
+    // rocPRIM's 3 x 8 at 8 x 10^6, the 2048-bucket passes cost what they save: keep its configuration from 21 bits on)
+    if (off || end_bit <= 8 || end_bit > 20) return 8;
+    const int passes = (end_bit + 9) / 10;
+    const int bits = (end_bit + passes - 1) / passes;
+    return bits < 8 ? 8 : bits;
+}
+template <typename Cfg>
+static hipError_t sort_with(void* temp, size_t& temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in, uint32_t* idx_out,
+                            uint32_t n, int end_bit, hipStream_t s) {
+    return rocprim::radix_sort_pairs<Cfg>(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (size_t)n, 0u, (unsigned)end_bit, s);
+}
+static hipError_t sort_dispatch(void* temp, size_t& temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
+                                uint32_t* idx_out, uint32_t n, int end_bit, hipStream_t s) {
+    switch (sort_digit_bits(end_bit)) {
+        case 9: return sort_with<SortConfigBits<9>>(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, n, end_bit, s);
+        case 10: return sort_with<SortConfigBits<10>>(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, n, end_bit, s);
+        default: return sort_with<SortConfig>(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, n, end_bit, s);
+    }
+}
 size_t sort_pairs_temp_bytes(uint32_t n, int end_bit) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                                (uint32_t*)nullptr, (size_t)n, 0u, (unsigned)end_bit);
+    (void)sort_dispatch(nullptr, bytes, nullptr, nullptr, nullptr, nullptr, n, end_bit, nullptr);
     return bytes;
 }
 void sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
                 uint32_t* idx_out, uint32_t n, int end_bit, hipStream_t s) {
-    SALVA_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (size_t)n, 0u,
-                                                          (unsigned)end_bit, s));
+    SALVA_HIP_CHECK(sort_dispatch(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, n, end_bit, s));
 }
 size_t select_flagged_temp_bytes(uint32_t n) {
     size_t b = 0;
