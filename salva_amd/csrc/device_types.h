@@ -50,17 +50,19 @@ struct TileAcc {
 // { break }; apply(); }`, dfsph_solver.rs:439-463, :474-502).  The host enqueues several iterations at once; once
 // `done` is set every later evaluate / finalize / apply kernel of the batch returns immediately, so the protocol is
 // exactly the reference's while the host reads the block back once per batch instead of once per iteration.
-struct SolveCtl {
+struct alignas(16) SolveCtl {
+    // --- the first 16 bytes are what the host needs: published to host-mapped memory with ONE 16-byte store per test
     uint32_t done;       // set by k_finalize_error when the break condition holds
     uint32_t iters;      // applies executed (DFSPH) / Jacobi iterations completed (IISPH)
     float err;           // last evaluated error
+    uint32_t seq;        // convergence tests executed so far in this solve (the host waits for the count it enqueued)
+    // --- parameters of the solve
     float tol;
     uint32_t min_iter;
     uint32_t mode;       // 0: DFSPH protocol (test, then count the apply); 1: IISPH (count the iteration, then test)
-    uint32_t seq;        // convergence tests executed so far in this solve (k_finalize_error publishes the block to the host
-                         // after each one; the host waits for the count it enqueued)
     uint32_t pad;
 };
+static_assert(sizeof(SolveCtl) == 32, "SolveCtl: two 16-byte halves");
 
 struct StepCtx {
     SphConsts sc;

@@ -725,7 +725,7 @@ template <typename Eval, typename Apply>
 World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval,
                                     Apply&& apply) {
     SolveCtl& init = h_ctl[NUM_SOLVES + which];
-    init = SolveCtl{0u, 0u, 0.0f, tol, (uint32_t)std::max(min_iter, 0), mode, 0u, 0u};
+    init = SolveCtl{0u, 0u, 0.0f, 0u, tol, (uint32_t)std::max(min_iter, 0), mode, 0u};
     h_ctl[which] = init;
     SALVA_HIP_CHECK(hipMemcpyAsync(d_ctl.p + which, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
     c.ctl = d_ctl.p + which;

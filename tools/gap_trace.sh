@@ -4,9 +4,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/gaps
 mkdir -p $OUT
 cd $R
-timeout 300 python -m pytest tests/test_parity_gpu.py -q -m gpu -k "budget or stray" > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
+timeout 300 python -m pytest tests/test_abi.py -q -m gpu > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o trace -- python $R/bench.py --no-cpu-baseline --steps 25 --warmup 5 > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o trace -- python $R/bench.py --no-cpu-baseline --steps ${STEPS:-25} --warmup 5 > $OUT/trace.log 2>&1
 cd $R
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 python - <<PY
