@@ -84,3 +84,19 @@ def test_rust_ffi_is_generated_from_the_header():
     assert set(re.findall(r"pub fn (salva_hip_\w+)", src)) == set(_lib.EXPORTED_SYMBOLS)
     for s in ("SalvaHipParams", "SalvaHipForceDesc", "SalvaHipStepStats", "SalvaHipCounters", "SalvaHipRigidPose", "SalvaHipShape"):
         assert f"pub struct {s} " in src
+
+
+def test_cpp_mirror_header_compiles():
+    """include/salva_hip.hpp (header-only C++ mirror of the salva3d API, incl. FluidsPipeline and the dynamic-sampling
+    boundaries) is valid C++17 on its own: host compiler only, no HIP."""
+    import subprocess
+    import tempfile
+
+    with tempfile.NamedTemporaryFile("w", suffix=".cpp", delete=False) as f:
+        f.write('#include "%s"\nint main() { salva::FluidsPipeline* p = nullptr; salva::Boundary b = salva::Boundary::dynamic_ball(0.1f); (void)p; (void)b; return 0; }\n'
+                % os.path.join(ROOT, "include", "salva_hip.hpp"))
+        path = f.name
+    try:
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-fsyntax-only", path])
+    finally:
+        os.unlink(path)
