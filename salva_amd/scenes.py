@@ -226,3 +226,56 @@ def surface_tension3():
     fluid = (fluid + np.array([0.0, 0.08, 0.0], dtype=F)[None, :]).astype(F)  # transform_by(Isometry3::translation(0, 0.08, 0))
     return dict(radius=r, fluid=fluid, forces=[("akinci", 1.0, 0.0), ("artificial", 0.01, 0.01)], gravity=(0.0, -0.981, 0.0),
                 ground_half_extents=(0.15, 0.02, 0.15))
+
+
+def ball_surface_ray_sample(radius: float, particle_rad: float) -> np.ndarray:
+    """`shape_surface_ray_sample(&Ball::new(radius), particle_rad)` (/root/reference/src/sampling/ray_sampling.rs:9-88, 187-231)
+    with parry's ray cast replaced by its closed form for a ball at the origin: a ray along axis i through (c_j, c_k) with
+    c_j^2 + c_k^2 < R^2 enters at -sqrt(R^2 - c_j^2 - c_k^2) and leaves at +sqrt(..).  Same lattice, quantisation (entry: ceil,
+    exit: floor, transverse: round) and f32 arithmetic as `cuboid_surface_ray_sample`; lexicographic index order."""
+    R = F(radius)
+    s = F(particle_rad) * F(2.0)
+    mins = np.full(3, -R - s, dtype=F)
+    maxs = np.full(3, R + s, dtype=F)
+    origin = (mins + s / F(2.0)).astype(F)
+    coords = []
+    for a in range(3):
+        c, line = origin[a], []
+        while c < maxs[a]:
+            line.append(c)
+            c = F(c + s)
+        coords.append(line)
+    pts = set()
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        for cj in coords[j]:
+            for ck in coords[k]:
+                d2 = F(R * R) - F(F(cj * cj) + F(ck * ck))
+                if not d2 > 0:
+                    continue  # the ray misses (or grazes) the ball
+                half = F(np.sqrt(d2))
+                qj = int(np.round(F(F(cj - origin[j]) / s)))
+                qk = int(np.round(F(F(ck - origin[k]) / s)))
+                q_in = int(np.ceil(F(F(-half - origin[i]) / s)))
+                q_out = int(np.floor(F(F(half - origin[i]) / s)))
+                for qi in (q_in, q_out):
+                    q = [0, 0, 0]
+                    q[i], q[j], q[k] = qi, qj, qk
+                    pts.add(tuple(q))
+    q = np.asarray(sorted(pts), dtype=np.float64)
+    return (origin[None, :] + (q.astype(F) * s)).astype(F)
+
+
+def faucet3():
+    """The literal scene of /root/reference/examples3d/faucet3.rs:19-109: an initially EMPTY fluid (r = 0.0125, rho0 = 1000,
+    XSPHViscosity(0.5, 0) then Akinci2013SurfaceTension(1, 10)) fed by a callback that adds a 10 x 10 sheet of particles at
+    height 0.6 whenever 0.06 s have passed (:84-103: positions (i d - 10 r, 0.6, j d - 10 r), zero velocity) and deletes what
+    fell below y = -2 (:69-73); a fixed ball of radius 0.15 at the origin, ray-sampled and coupled with StaticSampling;
+    gravity (0, -9.81, 0), dt = 1/200.
+
+    Returns dict(radius, sheet, ball_samples, period, forces, gravity)."""
+    r = 0.025 / 2.0
+    d, shift = F(r) * F(2.0), F(-10.0) * F(r)
+    sheet = np.array([[F(i) * d + shift, F(0.6), F(j) * d + shift] for i in range(10) for j in range(10)], dtype=F)
+    return dict(radius=r, sheet=sheet, ball_samples=ball_surface_ray_sample(0.15, r), period=0.06,
+                forces=[("xsph", 0.5, 0.0), ("akinci", 1.0, 10.0)], gravity=(0.0, -9.81, 0.0))

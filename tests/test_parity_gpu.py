@@ -211,6 +211,63 @@ def test_basic3_literal_scene_200_steps():
     assert pg[:, 1].min() > 0.1  # nothing fell through the ground (top face at y = 0.2, samples at 0.15)
 
 
+def test_faucet3_literal_scene():
+    """examples3d/faucet3.rs:19-109 — an empty fluid fed with a 10 x 10 sheet of particles every 12 steps (`add_particles`), XSPH +
+    Akinci2013(1, 10), falling on a fixed ball whose boundary is 336 ray-sampled points coupled by StaticSampling; particles
+    below y = -2 are deleted.  140 steps through the FluidsPipeline mirror against the oracle: particle counts, contacts while
+    the two runs are the same flow, then the bulk state."""
+    from oracle import oracle as O
+    from salva_amd import Akinci2013SurfaceTension, Boundary, Fluid, XSPHViscosity
+    from salva_amd.coupling import FluidsPipeline, RigidBody, StaticSampling
+
+    sc = scenes.faucet3()
+    r, sheet, g = sc["radius"], sc["sheet"], sc["gravity"]
+    pipe = FluidsPipeline(r, 2.0)
+    fl = Fluid(np.zeros((0, 3), np.float32), r, 1000.0)
+    fl.nonpressure_forces.append(XSPHViscosity(0.5, 0.0))
+    fl.nonpressure_forces.append(Akinci2013SurfaceTension(1.0, 10.0))
+    h = pipe.liquid_world.add_fluid(fl)
+    bo = pipe.liquid_world.add_boundary(Boundary(np.zeros((0, 3), np.float32)))
+    pipe.coupling.register_coupling(bo, "ground", RigidBody(dynamic=False), StaticSampling(sc["ball_samples"]))
+
+    def oracle(f64):
+        o = O.OracleWorld(r, 2.0, O.DFSPH, f64=f64)
+        f = o.add_fluid(np.zeros((0, 3), np.float32), 1000.0)
+        o.add_xsph(f, 0.5, 0.0)
+        o.add_akinci2013(f, 1.0, 10.0)
+        b = o.add_boundary(np.zeros((0, 3), np.float32))
+        o.set_boundary_sampling(b, sc["ball_samples"])
+        o.update_boundary_pose(b, (0, 0, 0), (0, 0, 0, 1), (0, 0, 0), (0, 0, 0), (0, 0, 0), True, False)
+        return o
+
+    o, o64 = oracle(False), oracle(True)
+    nsteps = 140
+    same_flow_steps = 0
+    for k in range(nsteps):
+        if k > 0 and k % 12 == 0:  # the callback of :62-103, every 0.06 s
+            h.add_particles(sheet, np.zeros_like(sheet))
+            for ow in (o, o64):
+                ow.add_particles(0, sheet, np.zeros_like(sheet))
+        st = pipe.step(g, DT)
+        so = o.step(DT, g)
+        o64.step(DT, g)
+        assert h.num_particles() == o.fluid_len(0) == 100 * (k // 12)
+        if h.num_particles():
+            d = max_norm_diff(h.positions, o.fluid_vec(0, "positions")) / r
+            if d < 1e-2:
+                same_flow_steps += 1
+                assert abs(int(st.ncontacts) - int(so.ncontacts)) <= max(8, int(2e-4 * so.ncontacts)), (k, st.ncontacts, so.ncontacts)
+    assert same_flow_steps >= 40, same_flow_steps  # (a free sheet under Akinci cohesion wrinkles chaotically: the oracle's f32 and f64 runs part as early)
+    po = o.fluid_vec(0, "positions")
+    pg = h.positions
+    noise = max_norm_diff(po, o64.fluid_vec(0, "positions")) / r
+    d = max_norm_diff(pg, po) / r
+    assert d < max(1e-4 * nsteps, 10.0 * noise), f"after {nsteps} steps: {d:.3e} r vs oracle, oracle f32-f64 {noise:.3e} r"
+    # the sheets that reached the ball (top at y = 0.15) were deflected, not swallowed: nothing inside the sampled sphere
+    assert np.linalg.norm(pg, axis=1).min() > 0.12 and np.linalg.norm(po, axis=1).min() > 0.12
+    assert abs(pg[:, 1].mean() - po[:, 1].mean()) < 2 * r
+
+
 def test_api_semantics_match_reference():
     """Velocity lag, dt lag, host edits between steps, add / delete particles, remove fluid (swap-remove)."""
     from salva_amd import DFSPHSolver, Fluid, LiquidWorld, XSPHViscosity
