@@ -48,3 +48,19 @@ def test_committed_scene_files_match_the_python_builders(tmp_path):
     assert len(names) == 6
     for n in names:
         assert open(os.path.join(tmp_path, n), "rb").read() == open(os.path.join(root, "bench", "rust_ref", "scenes", n), "rb").read(), n
+
+
+def test_ball_ray_sampling_is_a_lattice_shell():
+    """ball_surface_ray_sample (ray_sampling.rs:27-88 with the ball's closed-form ray cast): points of the sampler's lattice
+    (spacing 2 r, origin aabb.mins - 2 r + r), entry impacts rounded inwards (ceil / floor), so every sample lies inside the
+    sphere within one lattice diagonal of its surface, and the set has the symmetries of the lattice."""
+    r, R = 0.0125, 0.15
+    pts = scenes.ball_surface_ray_sample(R, r)
+    assert len(pts) == len({tuple(p) for p in pts.tolist()}) == 336
+    d = np.linalg.norm(pts.astype(np.float64), axis=1)
+    assert d.max() <= R + 1e-6 and d.min() > R - 2 * r * np.sqrt(3)
+    origin = np.float32(-R - 2 * r + r)
+    idx = (pts - origin) / np.float32(2 * r)
+    assert np.abs(idx - np.round(idx)).max() < 1e-4
+    as_set = {tuple(np.round(p / r).astype(int)) for p in pts}
+    assert {(-a, b, c) for a, b, c in as_set} == as_set and {(b, c, a) for a, b, c in as_set} == as_set
