@@ -279,12 +279,6 @@ float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps);
 float salva_hip_time_kernel(SalvaHipWorld* world, int32_t kernel, int32_t reps);
 /* `world.counters` after the last step — counters/mod.rs:17-72 */
 int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out);
-/* Diagnostics for kernel development (tools/variant_probe.py): times execution variant `variant` of the same kernel
- * (0: one tile per workgroup; 1: the same with co-resident workgroups de-phased by `param` x 64 cycles; 2: persistent
- * double-buffered pipeline; 3: one tile per workgroup with LDS-DMA staging) and returns a checksum of the kappa and
- * error partials it wrote, so that variants can be checked for bit-identical results. */
-float salva_hip_time_variant(SalvaHipWorld* world, int32_t variant, uint32_t param, int32_t reps, uint64_t* checksum);
-
 /* ---- multi-GPU: one process and one world per GPU, the domain cut into slabs of grid-cell planes along x.
  * No counterpart in the reference (single process).  A world owns the particles whose cell x = floor(x / h) lies in
  * [cell_lo, cell_hi] (the first / last rank also keep whatever lies beyond their open end); every step it migrates

@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_particles_intersecting_aabb", "salva_hip_set_boundary_sampling", "salva_hip_update_boundary_pose",
     "salva_hip_get_boundary_particles", "salva_hip_get_boundary_wrench", "salva_hip_set_force_callback",
     "salva_hip_force_get_state", "salva_hip_force_add_accelerations", "salva_hip_set_fluid_field", "salva_hip_get_timestep",
-    "salva_hip_set_timestep", "salva_hip_time_variant", "salva_hip_get_counters", "salva_hip_time_kernel", "salva_hip_particles_intersecting_shape", "salva_hip_rebalance",
+    "salva_hip_set_timestep", "salva_hip_get_counters", "salva_hip_time_kernel", "salva_hip_particles_intersecting_shape", "salva_hip_rebalance",
     "salva_hip_set_boundary_dynamic_sampling", "salva_hip_get_boundary_sources",
 ]
 
@@ -190,8 +190,9 @@ def lib():
     L.salva_hip_time_kernel.argtypes = [vp, i32, i32]
     L.salva_hip_time_kernel.restype = f32
     L.salva_hip_get_counters.argtypes = [vp, C.POINTER(CountersStruct)]
-    L.salva_hip_time_variant.argtypes = [vp, i32, u32, i32, C.POINTER(u64)]
-    L.salva_hip_time_variant.restype = f32
+    if hasattr(L, "salva_hip_time_variant"):  # the kernel-development build only (SALVA_HIP_LIB_VARIANT=diag)
+        L.salva_hip_time_variant.argtypes = [vp, i32, u32, i32, C.POINTER(u64)]
+        L.salva_hip_time_variant.restype = f32
     ubp = C.POINTER(C.c_ubyte)
     L.salva_hip_comm_rccl_unique_id.argtypes = [ubp]
     L.salva_hip_comm_rccl_create.argtypes = [i32, i32, ubp, i32, C.POINTER(vp)]

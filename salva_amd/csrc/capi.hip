@@ -307,6 +307,8 @@ int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out) {
     });
 }
 
+#ifdef SALVA_HIP_DIAG
+// kernel experiments (declared in diag/salva_hip_diag.h; `make VARIANT=diag` only — not an entry point of libsalva_hip.so)
 float salva_hip_time_variant(SalvaHipWorld* world, int32_t variant, uint32_t param, int32_t reps, uint64_t* checksum) {
     float us = -1.0f;
     int rc = guarded([&]() -> int {
@@ -316,6 +318,7 @@ float salva_hip_time_variant(SalvaHipWorld* world, int32_t variant, uint32_t par
     });
     return rc == SALVA_HIP_OK ? us : (float)rc;
 }
+#endif
 
 // ---- multi-GPU (x-slab decomposition) -------------------------------------------------------------------------
 struct SalvaHipComm {

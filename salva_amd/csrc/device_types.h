@@ -39,10 +39,12 @@ struct TileAcc {
     uint64_t sb;    // boundary halo slots
     uint32_t nsl;   // 64-particle slices
     uint32_t nonempty;  // tiles that own at least one particle
-    uint32_t max_s, max_sb, max_nsl, pad;  // running maxima of the three (carried through the same scan)
+    uint32_t max_s, max_sb, max_nsl;  // running maxima of the three (carried through the same scan)
+    uint32_t max_sum;  // running maximum of (fluid halo slots padded to 64) + (boundary halo slots) of one tile (TileLds::max_sum)
     __host__ __device__ TileAcc operator+(const TileAcc& o) const {
         return TileAcc{s + o.s, sb + o.sb, nsl + o.nsl, nonempty + o.nonempty, max_s > o.max_s ? max_s : o.max_s,
-                       max_sb > o.max_sb ? max_sb : o.max_sb, max_nsl > o.max_nsl ? max_nsl : o.max_nsl, 0u};
+                       max_sb > o.max_sb ? max_sb : o.max_sb, max_nsl > o.max_nsl ? max_nsl : o.max_nsl,
+                       max_sum > o.max_sum ? max_sum : o.max_sum};
     }
 };
 
@@ -92,6 +94,7 @@ struct StepCtx {
     uint32_t* nfb;       // # fluid-boundary contacts
     uint32_t* nbr_ff;           // packed 16-bit halo slots: slice s owns dwords [s*cap_ff*64, (s+1)*cap_ff*64)
     uint32_t* nbr_fb;
+    uint32_t* slice_near;       // per slice: some particle has a neighbour closer than 1e-5 h (k_density_alpha; dfsph.hip)
     uint32_t cap_ff, cap_fb;    // dwords (= pairs of contacts) reserved per particle
     const TileAcc* tile_off;    // [nslots+1] exclusive prefix of per-tile {halo slots, boundary halo slots, slices}, by SLOT
     const uint32_t* halo_src;   // sorted fluid index of every halo slot of every tile (tile-major)
@@ -148,7 +151,9 @@ struct StepCtx {
     // the exchange).  0: every tile.  ghost_lo_cx / ghost_hi_cx: the cell planes next to the slab that hold ghosts.
     int32_t phase, ghost_lo_cx, ghost_hi_cx;
     const SolveCtl* ctl;       // non-null inside an iterative solve: kernels return at once when ctl->done
-    unsigned long long* dbg;   // optional per-tile phase timestamps (k_pred_density, SALVA_HIP_TILE_TIMING=1)
+#ifdef SALVA_HIP_DIAG
+    unsigned long long* dbg;   // kernel-development builds: per-tile phase timestamps (k_pred_density, SALVA_HIP_TILE_TIMING=1)
+#endif
 };
 
 // Result block the host reads back (pinned mirror).

@@ -24,11 +24,101 @@ __device__ __forceinline__ float rho0_of(const StepCtx& c, uint32_t model) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The pair loops of the four solver kernels below (the kernels the step lives in).
+//
+// LDS layout (tile.h, stage_pw / stage_pk): the first staged array starts at LDS byte 0 and the second at a distance that is
+// a compile-time constant in the DS != 0 instantiations, so a contact costs ONE address instruction (`v_lshlrev_b32_sdwa`:
+// 16-bit list entry -> byte offset) for both of its ds_reads; the boundary halo rides in the tails of the same arrays.
+// Arithmetic: kernel_gfac2 (sph_math.h) — 16.5 VALU per contact against 24 for the round-2 loop (ISA accounting in
+// profiles/r03_isa/).  Exactness: the fast form does not reproduce the reference's `q <= 1e-5 -> 0` rule; k_density_alpha
+// flags the slices that hold such a pair (c.slice_near) and those slices walk their lists with kernel_grad instead.
+// ------------------------------------------------------------------------------------------------
+template <uint32_t DS>
+__device__ __forceinline__ uint32_t pw_dist(const StepCtx& c, const Tile& t) { return DS ? DS * 16u : (t.stage_cap(c) + t.SB) * 16u; }
+template <uint32_t DS>
+__device__ __forceinline__ uint32_t pk_dist(const StepCtx& c, const Tile& t) { return DS ? DS * 16u : (t.stage_cap(c) + 2u * t.SB) * 16u; }
+
+// `o` = byte offset of the slot in a 16-byte-strided array (tile.h, entry_off16_*)
+__device__ __forceinline__ RecPW load_pw(uint32_t o, uint32_t dist) {
+    RecPW r{lds_ld16(o), lds_ld16(o + dist)};
+    asm volatile("" ::"v"(r.w.w));  // keep the read a single ds_read_b128 (a b96 costs 8 LDS cycles, a b128 4)
+    return r;
+}
+__device__ __forceinline__ RecPK load_pk(uint32_t o, uint32_t dist) { return RecPK{lds_ld16(o), lds_ld4((o >> 2) + dist)}; }
+
+// sum_j m_j (w_i - w_j) . grad W_ij over the padded list of a slice without near-coincident pairs
+__device__ __forceinline__ float pair_sum_velocity_divergence(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh,
+                                                              const float4& pi, const float4& wi, uint32_t dist) {
+    f2 acc2 = {0.0f, 0.0f};
+    const f2 tiny = {1.0e-30f, 1.0e-30f};
+    for_each_ff2<true, false, true>(c, gs, nqu, lh, [&](uint32_t o) { return load_pw(o, dist); }, [&](const RecPW& A, const RecPW& B) { SALVA_PAIR_MATH
+        const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
+        f2 r2 = dz * dz + tiny;
+        r2 = dy * dy + r2;
+        r2 = dx * dx + r2;
+        const f2 g = kernel_gfac2(r2, c.sc);
+        const f2 ux = {wi.x - A.w.x, wi.x - B.w.x}, uy = {wi.y - A.w.y, wi.y - B.w.y}, uz = {wi.z - A.w.z, wi.z - B.w.z};
+        const f2 gm = {g.x * A.p.w, g.y * B.p.w};
+        acc2 += (ux * dx + uy * dy + uz * dz) * gm;
+    });
+    return (acc2.x + acc2.y) * c.sc.gscale;
+}
+// the same sum with the reference's q <= 1e-5 rule (kernel_grad), over the exact list: slices flagged by k_density_alpha
+__device__ __forceinline__ float pair_sum_velocity_divergence_exact(const StepCtx& c, uint32_t i, uint32_t gs, const float4& pi,
+                                                                    const float4& wi, uint32_t dist) {
+    float acc = 0.0f;
+    for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+        const RecPW A = load_pw(s << 4, dist);
+        const float dx = pi.x - A.p.x, dy = pi.y - A.p.y, dz = pi.z - A.p.z;
+        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+        acc += ((wi.x - A.w.x) * dx + (wi.y - A.w.y) * dy + (wi.z - A.w.z) * dz) * g * A.p.w;
+    });
+    return acc;
+}
+// sum_j grad W_ij m_j k_ij with k_ij = f(k_j) supplied by `kij2` (two contacts at once) / `kij1`
+template <typename K2>
+__device__ __forceinline__ void pair_sum_gradient(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh, const float4& pi,
+                                                  uint32_t dist, K2&& kij2, float& sx, float& sy, float& sz) {
+    f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
+    const f2 tiny = {1.0e-30f, 1.0e-30f};
+    for_each_ff2<true, false, true>(c, gs, nqu, lh, [&](uint32_t o) { return load_pk(o, dist); }, [&](const RecPK& A, const RecPK& B) { SALVA_PAIR_MATH
+        const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
+        f2 r2 = dz * dz + tiny;
+        r2 = dy * dy + r2;
+        r2 = dx * dx + r2;
+        const f2 g = kernel_gfac2(r2, c.sc);
+        const f2 km = kij2(A.k, B.k) * f2{A.p.w, B.p.w};
+        const f2 coeff = km * g;
+        ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
+    });
+    sx = (ax.x + ax.y) * c.sc.gscale; sy = (ay.x + ay.y) * c.sc.gscale; sz = (az.x + az.y) * c.sc.gscale;
+}
+template <typename K1>
+__device__ __forceinline__ void pair_sum_gradient_exact(const StepCtx& c, uint32_t i, uint32_t gs, const float4& pi, uint32_t dist,
+                                                        K1&& kij1, float& sx, float& sy, float& sz) {
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+        const RecPK A = load_pk(s << 4, dist);
+        const float dx = pi.x - A.p.x, dy = pi.y - A.p.y, dz = pi.z - A.p.z;
+        const float coeff = kij1(A.k) * A.p.w * kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+        ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
+    });
+    sx = ax; sy = ay; sz = az;
+}
+__device__ __forceinline__ bool slice_is_near(uint32_t near_word) { return __builtin_amdgcn_readfirstlane((int)near_word) != 0; }
+__device__ __forceinline__ float (*carve_errtab(Tile& t))[MAX_MODELS] {
+    return reinterpret_cast<float (*)[MAX_MODELS]>(t.carve<float>(TILE_MAX_WAVES * MAX_MODELS));
+}
+
+// ------------------------------------------------------------------------------------------------
 // compute_densities (dfsph_solver.rs:628-665) fused with compute_alphas (:165-216): both depend on positions only.
 //   rho_i   = sum_j m_j W_ij + sum_b V_b rho0_i W_ib
 //   alpha_i = 1 / (sum |m_j grad W_ij|^2 + |sum m_j grad W_ij|^2), 0 if the denominator <= 1e-5
+// Also: c.slice_near[slice] = some particle of the slice has a neighbour (other than itself) with |d| <= 1e-5 h — the pairs for
+// which cubic_spline_kernel.rs:63-65 returns a zero gradient; the solver kernels pick their pair loop by it.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
+    lds_base_check();
     Tile t;
     t.setup(c);
     if (t.empty()) return;
@@ -38,43 +128,71 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
     t.first_own(i0, gs0);
     const Own own0 = load_own(i0, gs0);
     const float4* Lp = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), Lp);
+    t.stage(c, static_cast<const float4*>(c.posm), Lp);  // first carve: LDS byte 0 (lds_ld16)
     const float4* Bp = nullptr;
     t.stage_boundary(c, Bp);
     Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
-        if (!active) return;
-        const float4 pi = o.pi;
-        const float rho0 = rho0_of(c, o.mi);
-        float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f;
-        for_each_ff_regs(c, gs, o.lo, [&](uint32_t s) { return Lp[s]; }, [&](const float4& pj) {
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
-            rho += pj.w * e.w;
-            const float gm = e.g * pj.w;
-            const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
-            sq += gx * gx + gy * gy + gz * gz;
-            gsx += gx; gsy += gy; gsz += gz;
-        });
-        for_each_fb(c, t, i, gs, [&](uint32_t s) {
-            const float4 pj = Bp[s];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
-            const float m = pj.w * rho0;
-            rho += m * e.w;
-            const float gm = e.g * m;
-            const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
-            sq += gx * gx + gy * gy + gz * gz;
-            gsx += gx; gsy += gy; gsz += gz;
-        });
-        if (!(rho > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!density.is_zero()) :662
-        const float denom = sq + (gsx * gsx + gsy * gsy + gsz * gsz);
-        c.rho[i] = rho;
-        c.alpha[i] = (denom <= 1.0e-5f) ? 0.0f : 1.0f / denom;
+        uint32_t nnear = 0;
+        if (active) {
+            const float4 pi = o.pi;
+            const float rho0 = rho0_of(c, o.mi);
+            float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f;
+            for_each_ff_regs(c, gs, o.lo, [&](uint32_t s) { return lds_ld16(s << 4); }, [&](const float4& pj) { SALVA_PAIR_MATH
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                nnear += (r2 <= c.sc.tiny_r2) ? 1u : 0u;
+                const KernelEval e = kernel_eval(r2, c.sc);
+                rho += pj.w * e.w;
+                const float gm = e.g * pj.w;
+                const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
+                sq += gx * gx + gy * gy + gz * gz;
+                gsx += gx; gsy += gy; gsz += gz;
+            });
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const float4 pj = Bp[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
+                const float m = pj.w * rho0;
+                rho += m * e.w;
+                const float gm = e.g * m;
+                const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
+                sq += gx * gx + gy * gy + gz * gz;
+                gsx += gx; gsy += gy; gsz += gz;
+            });
+            if (!(rho > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!density.is_zero()) :662
+            const float denom = sq + (gsx * gsx + gsy * gsy + gsz * gsz);
+            c.rho[i] = rho;
+            c.alpha[i] = (denom <= 1.0e-5f) ? 0.0f : 1.0f / denom;
+        }
+        // (the self contact is always one of the pairs with r2 <= tiny)
+        const bool any_near = __builtin_amdgcn_ballot_w64(nnear > 1u) != 0ull;
+        if ((threadIdx.x & (WAVE - 1)) == 0) c.slice_near[gs] = any_near ? 1u : 0u;
     });
 }
 void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s) {
     SALVA_LAUNCH_TILE(k_density_alpha, c, L, L.bytes(16, 16, 2), s, c);
+}
+
+// launch one of the three layout instantiations of a solver kernel (tile.h: FIXED_DS_SMALL / _LARGE / runtime distance)
+#define SALVA_LAUNCH_FIXED(kernel, DSV, c, L, lds, s, ...)                                                         \
+    do {                                                                                                           \
+        if ((DSV) == FIXED_DS_SMALL) SALVA_LAUNCH_TILE(kernel<FIXED_DS_SMALL>, c, L, lds, s, __VA_ARGS__);         \
+        else if ((DSV) == FIXED_DS_LARGE) SALVA_LAUNCH_TILE(kernel<FIXED_DS_LARGE>, c, L, lds, s, __VA_ARGS__);    \
+        else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                             \
+    } while (0)
+static uint32_t pick_ds(uint32_t slots_needed) {
+    return slots_needed <= FIXED_DS_SMALL ? FIXED_DS_SMALL : (slots_needed <= FIXED_DS_LARGE ? FIXED_DS_LARGE : 0u);
+}
+// P | W kernels: both arrays hold fluid halo + boundary halo
+static uint32_t pw_slots(const TileLds& L) { return L.sum_slots(); }
+static uint32_t pw_bytes(const TileLds& L, uint32_t ds, bool errtab) {
+    return (ds ? 2u * ds : 2u * pw_slots(L)) * 16u + (errtab ? TILE_ERR_BYTES : 0u) + 32u;
+}
+// P | K kernels: P holds fluid halo + 2 x boundary halo, K the fluid halo (4 bytes each)
+static uint32_t pk_slots(const TileLds& L) { return L.sum_slots() + L.max_halo_boundary; }
+static uint32_t pk_bytes(const TileLds& L, uint32_t ds) {
+    return (ds ? ds : pk_slots(L)) * 16u + ((L.max_halo_fluid + 63u) & ~63u) * 4u + 32u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -82,32 +200,31 @@ void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s) {
 // skipped (0) when the particle has fewer than 20 contacts; stores kappa_i = D rho_i * alpha_i (the only use of
 // the divergence, :370,:382) and the per-particle error D rho_i / rho0.
 // ------------------------------------------------------------------------------------------------
+template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
-    __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
+    lds_base_check();
     Tile t;
     t.setup(c);
     if (t.skipped()) return;  // the other launch of this pass handles the tile (decomposed runs)
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
-    struct Own { float4 pi, wi; float alpha; uint32_t mi, cnt, cntb; ListRegs lh; };
+    struct Own { float4 pi, wi; float alpha; uint32_t mi, cnt, cntb, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.w[i], c.alpha[i], c.model[i], c.nff[i], c.nb ? c.nfb[i] : 0u, list_regs(c, gs)};
+        return Own{c.posm[i], c.w[i], c.alpha[i], c.model[i], c.nff[i], c.nb ? c.nfb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
     const Own own0 = load_own(i0, gs0);
-    // two separate 16-byte-strided arrays: a random 64-lane ds_read_b128 then spreads over all 16 bank groups
-    // (an interleaved 32-byte record would confine each read to 8 of them)
-    const float4* Lp = nullptr;
-    const float4* Lw = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), Lp, Lw);
+    const uint32_t dist = pw_dist<DS>(c, t);
     const float4* Bp = nullptr;
-    t.stage_boundary(c, Bp);
+    const float4* Bv = nullptr;
+    t.stage_pw(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), dist, Bp, Bv, false);
     TileErr E;
-    E.init(errtab, c);
+    E.init(carve_errtab(t), c);
     Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(o.near);
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
@@ -116,17 +233,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
             float div = 0.0f;
             if (o.cnt + o.cntb >= c.min_neighbors_for_divergence) {
                 const float4 pi = o.pi, wi = o.wi;
-                f2 acc2 = {0.0f, 0.0f};
-                for_each_ff2(c, gs, nqu, o.lh, [&](uint32_t s) { return RecPW{Lp[s], Lw[s]}; }, [&](const RecPW& A, const RecPW& B) {
-                    asm volatile("" ::"v"(A.w.w), "v"(B.w.w));  // keep the reads single ds_read_b128s (a b96 costs 8 LDS cycles, a b128 4)
-                    const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
-                    const f2 g = kernel_grad2(dx * dx + dy * dy + dz * dz, c.sc);
-                    const f2 ux = {wi.x - A.w.x, wi.x - B.w.x}, uy = {wi.y - A.w.y, wi.y - B.w.y}, uz = {wi.z - A.w.z, wi.z - B.w.z};
-                    const f2 mj = {A.p.w, B.p.w};
-                    acc2 += (ux * dx + uy * dy + uz * dz) * g * mj;
-                });
-                div += acc2.x + acc2.y;
-                for_each_fb(c, t, i, gs, [&](uint32_t s) {
+                div += near ? pair_sum_velocity_divergence_exact(c, i, gs, pi, wi, dist)
+                            : pair_sum_velocity_divergence(c, gs, nqu, o.lh, pi, wi, dist);
+                for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                     const float4 pj = Bp[s];
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                     const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
@@ -142,7 +251,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     E.finish(c, t.slot);
 }
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_divergence, c, L, L.bytes(32, 16, 3), s, c);
+    const uint32_t ds = pick_ds(pw_slots(L));
+    SALVA_LAUNCH_FIXED(k_divergence, ds, c, L, pw_bytes(L, ds, true), s, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -150,46 +260,41 @@ void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
 //                                                           + sum_b grad W_ib (-k_i V_b rho0), boundary reaction force.
 // Applied to w_i = v_i + dv_i directly (see the kernel).
 // ------------------------------------------------------------------------------------------------
+template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c, float inv_dt_prev) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
+    lds_base_check();
     Tile t;
     t.setup(c);
     if (t.empty()) return;
     // Only w = v + dv is carried through the divergence solve: dv itself is zeroed right after it (:689-691) and v
     // becomes w (:422-430), so updating w in place saves two 16-byte loads and one store per particle and pass.
-    struct Own { float4 pi, wi; float ki; uint32_t cnt; ListRegs lh; };
+    struct Own { float4 pi, wi; float ki; uint32_t cnt, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.w[i], c.kappa[i], c.nff[i], list_regs(c, gs)};
+        return Own{c.posm[i], c.w[i], c.kappa[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
     const Own own0 = load_own(i0, gs0);
-    const float4* Lp = nullptr;
-    const float* Lk = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), Lp, Lk);
+    const uint32_t dist = pk_dist<DS>(c, t);
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
-    t.stage_boundary(c, Bp, Bv);
+    t.stage_pk(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), dist, Bp, Bv);
     Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(o.near);
         if (!active) return;
         const float4 pi = o.pi;
         const uint32_t mi = __float_as_uint(o.wi.w);
         const float rho0 = rho0_of(c, mi);
         const float ki = o.ki;
         float4 d = o.wi;
-        f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
-        for_each_ff2(c, gs, nqu, o.lh, [&](uint32_t s) { return RecPK{Lp[s], Lk[s]}; }, [&](const RecPK& A, const RecPK& B) {
-            const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
-            const f2 g = kernel_grad2(dx * dx + dy * dy + dz * dz, c.sc);
-            const f2 kij = {ki + A.k, ki + B.k};
-            const f2 mj = {A.p.w, B.p.w};
-            const f2 coeff = kij * mj * g;
-            ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
-        });
-        d.x -= ax.x + ax.y; d.y -= ay.x + ay.y; d.z -= az.x + az.y;
-        for_each_fb(c, t, i, gs, [&](uint32_t s) {
+        float sx, sy, sz;
+        if (near) pair_sum_gradient_exact(c, i, gs, pi, dist, [&](float kj) { return ki + kj; }, sx, sy, sz);
+        else pair_sum_gradient(c, gs, nqu, o.lh, pi, dist, [&](float ka, float kb) { return f2{ki + ka, ki + kb}; }, sx, sy, sz);
+        d.x -= sx; d.y -= sy; d.z -= sz;
+        for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Bp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
@@ -205,7 +310,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
     });
 }
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_divergence_apply, c, L, L.bytes(20, 32, 4), s, c, inv_dt_prev);
+    const uint32_t ds = pick_ds(pk_slots(L));
+    SALVA_LAUNCH_FIXED(k_divergence_apply, ds, c, L, pk_bytes(L, ds), s, c, inv_dt_prev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -252,55 +358,51 @@ void launch_integrate(const StepCtx& c, float dt, hipStream_t s) {
 // error_i = max(rho*_i / rho0 - 1, 0); stores kappa_i = (rho*_i - rho0) alpha_i (:234,:245).
 // This is THE representative neighbour-sum kernel of the roofline: N (4K + 52) bytes per launch.
 // ------------------------------------------------------------------------------------------------
+#ifdef SALVA_HIP_DIAG
+#define SALVA_DIAG_STAMP(name) const unsigned long long name = __builtin_readcyclecounter()
+#else
+#define SALVA_DIAG_STAMP(name)
+#endif
+template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, float dt) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
-    __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
-    const unsigned long long T0 = __builtin_readcyclecounter();
+    lds_base_check();
+    SALVA_DIAG_STAMP(T0);
     Tile t;
     t.setup(c);
     if (t.skipped()) return;  // the other launch of this pass handles the tile (decomposed runs)
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
-    const unsigned long long T1 = __builtin_readcyclecounter();
-    struct Own { float4 pi, wi; float rho, alpha; uint32_t mi, cnt; ListRegs lh; };
+    SALVA_DIAG_STAMP(T1);
+    struct Own { float4 pi, wi; float rho, alpha; uint32_t mi, cnt, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.w[i], c.rho[i], c.alpha[i], c.model[i], c.nff[i], list_regs(c, gs)};
+        return Own{c.posm[i], c.w[i], c.rho[i], c.alpha[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
     const Own own0 = load_own(i0, gs0);
     // two separate 16-byte-strided arrays: a random 64-lane ds_read_b128 then spreads over all 16 bank groups
     // (an interleaved 32-byte record would confine each read to 8 of them)
-    const float4* Lp = nullptr;
-    const float4* Lw = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), Lp, Lw);
+    const uint32_t dist = pw_dist<DS>(c, t);
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
-    t.stage_boundary(c, Bp, Bv);
+    t.stage_pw(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), dist, Bp, Bv, true);
     TileErr E;
-    E.init(errtab, c);
-    const unsigned long long T2 = __builtin_readcyclecounter();
+    E.init(carve_errtab(t), c);
+    SALVA_DIAG_STAMP(T2);
     Tile::staged_barrier();
-    const unsigned long long T3 = __builtin_readcyclecounter();
+    SALVA_DIAG_STAMP(T3);
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(o.near);
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
             mi = o.mi;
             const float rho0 = rho0_of(c, mi);
             const float4 pi = o.pi, wi = o.wi;
-            float delta = 0.0f;
-            f2 acc2 = {0.0f, 0.0f};
-            for_each_ff2(c, gs, nqu, o.lh, [&](uint32_t s) { return RecPW{Lp[s], Lw[s]}; }, [&](const RecPW& A, const RecPW& B) {
-                asm volatile("" ::"v"(A.w.w), "v"(B.w.w));  // keep the reads single ds_read_b128s (a b96 costs 8 LDS cycles, a b128 4)
-                const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
-                const f2 g = kernel_grad2(dx * dx + dy * dy + dz * dz, c.sc);
-                const f2 ux = {wi.x - A.w.x, wi.x - B.w.x}, uy = {wi.y - A.w.y, wi.y - B.w.y}, uz = {wi.z - A.w.z, wi.z - B.w.z};
-                const f2 mj = {A.p.w, B.p.w};
-                acc2 += (ux * dx + uy * dy + uz * dz) * g * mj;
-            });
-            delta += acc2.x + acc2.y;
-            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+            float delta = near ? pair_sum_velocity_divergence_exact(c, i, gs, pi, wi, dist)
+                               : pair_sum_velocity_divergence(c, gs, nqu, o.lh, pi, wi, dist);
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Bp[s];
                 const float4 vj = Bv[s];
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -314,42 +416,46 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
         }
         E.add(c, err, mi, active && !is_ghost(c, i));  // a ghost's error belongs to the rank that owns it
     });
-    const unsigned long long T4 = __builtin_readcyclecounter();
+    SALVA_DIAG_STAMP(T4);
     E.finish(c, t.slot);
+#ifdef SALVA_HIP_DIAG
     if (c.dbg && threadIdx.x == 0) {
         unsigned long long* d = c.dbg + (size_t)t.slot * 8;
         d[0] = T0; d[1] = T1; d[2] = T2; d[3] = T3; d[4] = T4; d[5] = __builtin_readcyclecounter(); d[6] = t.S; d[7] = t.own_end - t.own_begin;
     }
+#endif
 }
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_pred_density, c, L, L.bytes(32, 32, 4), s, c, dt);
+    const uint32_t ds = pick_ds(pw_slots(L));
+    SALVA_LAUNCH_FIXED(k_pred_density, ds, c, L, pw_bytes(L, ds, true), s, c, dt);
 }
 
 // ------------------------------------------------------------------------------------------------
 // compute_velocity_changes (:218-277): k_ij = max(k_i,0) + max(k_j,0); if k_ij > 0: dv_i -= grad W_ij k_ij m_j / dt.
 // Boundary term only when k_i > 0, with the reaction force delta * (inv_dt * m_i).
 // ------------------------------------------------------------------------------------------------
+template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, float inv_dt) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
+    lds_base_check();
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    struct Own { float4 pi, d, v; float ki; uint32_t mi, cnt; ListRegs lh; };
+    struct Own { float4 pi, d, v; float ki; uint32_t mi, cnt, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.dv[i], c.vel[i], c.kappa[i], c.model[i], c.nff[i], list_regs(c, gs)};
+        return Own{c.posm[i], c.dv[i], c.vel[i], c.kappa[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
     const Own own0 = load_own(i0, gs0);
-    const float4* Lp = nullptr;
-    const float* Lk = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), Lp, Lk);
+    const uint32_t dist = pk_dist<DS>(c, t);
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
-    t.stage_boundary(c, Bp, Bv);
+    t.stage_pk(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), dist, Bp, Bv);
     Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(o.near);
         if (!active) return;
         const float4 pi = o.pi;
         const uint32_t mi = o.mi;
@@ -357,19 +463,13 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
         const float ki = o.ki;
         const float kip = fmaxf(ki, 0.0f);
         float4 d = o.d;
-        f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
-        for_each_ff2(c, gs, nqu, o.lh, [&](uint32_t s) { return RecPK{Lp[s], Lk[s]}; }, [&](const RecPK& A, const RecPK& B) {
-            // k_ij == 0 contributes exactly nothing, so no branch is needed
-            const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
-            const f2 g = kernel_grad2(dx * dx + dy * dy + dz * dz, c.sc);
-            const f2 kij = {kip + fmaxf(A.k, 0.0f), kip + fmaxf(B.k, 0.0f)};
-            const f2 mj = {A.p.w, B.p.w};
-            const f2 coeff = kij * mj * g;
-            ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
-        });
-        d.x -= (ax.x + ax.y) * inv_dt; d.y -= (ay.x + ay.y) * inv_dt; d.z -= (az.x + az.y) * inv_dt;
+        float sx, sy, sz;
+        // k_ij == 0 contributes exactly nothing, so no branch is needed
+        if (near) pair_sum_gradient_exact(c, i, gs, pi, dist, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, sx, sy, sz);
+        else pair_sum_gradient(c, gs, nqu, o.lh, pi, dist, [&](float ka, float kb) { return f2{kip + fmaxf(ka, 0.0f), kip + fmaxf(kb, 0.0f)}; }, sx, sy, sz);
+        d.x -= sx * inv_dt; d.y -= sy * inv_dt; d.z -= sz * inv_dt;
         if (ki > 0.0f) {
-            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Bp[s];
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
@@ -388,7 +488,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
     });
 }
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s) {
-    SALVA_LAUNCH_TILE(k_pressure_apply, c, L, L.bytes(20, 32, 4), s, c, inv_dt);
+    const uint32_t ds = pick_ds(pk_slots(L));
+    SALVA_LAUNCH_FIXED(k_pressure_apply, ds, c, L, pk_bytes(L, ds), s, c, inv_dt);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
         if (fc != 0.0f) {
             // wave-uniform trip count over the padded list: a padding entry is the particle itself, v_j - v_i = 0 exactly
             struct Rec { float4 p, w; float r; };
-            auto one = [&](const Rec& rc) {
+            auto one = [&](const Rec& rc) { SALVA_PAIR_MATH
                 const float4 pj = rc.p, vj = rc.w;
                 const float rj = rc.r;
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
         }
         if (bc != 0.0f) {
             const float ri = o.ri;
-            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Bp[s];
                 const float4 vj = Bv[s];
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_artificial_viscosity(StepC
         const float eta2 = h * h * 0.01f;
         float fx = 0.f, fy = 0.f, fz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
         if (fc != 0.0f) {
-            for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+            for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Lp[s];
                 const float4 vj = lds_f4(Lw + s);
                 const float rj = Lr[s];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_artificial_viscosity(StepC
             });
         }
         if (bc != 0.0f) {
-            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Bp[s];
                 const float4 vj = Bv[s];
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_normals(StepCtx c, 
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         float nx = 0.f, ny = 0.f, nz = 0.f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Lp[s];
             const float rj = Lr[s];
             const bool same = Lm ? (Lm[s] == model) : true;
@@ -194,6 +194,7 @@ void launch_akinci_normals(const StepCtx& c, const TileLds& L, uint32_t model, h
 
 // cohesion_kernel :71-88 — C(r) = 32/(pi h^9) * { 2 (h-r)^3 r^3 - h^6/64 | r <= h/2 ; (h-r)^3 r^3 | r <= h ; 0 }
 __device__ __forceinline__ float cohesion_kernel(float r, float h, float norm, float h6_64) {
+    SALVA_PAIR_MATH
     const float a = (h - r) * (h - r) * (h - r) * (r * r * r);
     float v = (r <= h * 0.5f) ? 2.0f * a - h6_64 : a;
     v = (r <= h) ? v : 0.0f;
@@ -201,6 +202,7 @@ __device__ __forceinline__ float cohesion_kernel(float r, float h, float norm, f
 }
 // adhesion_kernel :90-111 — A(r) = 0.007 / h^3.25 * (-4 r^2/h + 6 r - 2 h)^(1/4) for h/2 < r <= h
 __device__ __forceinline__ float adhesion_kernel(float r, float h, float norm) {
+    SALVA_PAIR_MATH
     if (r > h * 0.5f && r <= h) {
         const float tt = fmaxf(fast_div(-4.0f * r * r, h) + 6.0f * r - 2.0f * h, 0.0f);
         return norm * __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(tt));  // (1 ulp each: the sum it feeds is compared at 1e-5)
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, u
         float4 a = c.acc[i];
         if (tc != 0.0f) {
             const float4 ni = c.normal[i];
-            for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+            for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Lp[s];
                 const float4 nj = Ln[s];
                 const float rj = nj.w;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, u
             });
         }
         if (ac != 0.0f) {
-            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Bp[s];
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float r2 = dx * dx + dy * dy + dz * dz;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_colors(StepCtx c, u
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         float color = 0.0f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Lp[s];
             const float rj = Lr[s];
             const bool same = Lm ? (Lm[s] == model) : true;
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_colors(StepCtx c, u
             const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
             color += same ? fast_div(wgt * pj.w, rj) : 0.0f;
         });
-        for_each_fb(c, t, i, gs, [&](uint32_t s) {
+        for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Bp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             color += kernel_weight(dx * dx + dy * dy + dz * dz, c.sc) * pj.w;
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_gradc(StepCtx c, ui
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         float gx = 0.f, gy = 0.f, gz = 0.f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Lp[s];
             const float rj = Lr[s], cj = Lc[s];
             const bool same = Lm ? (Lm[s] == model) : true;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_forces(StepCtx c, u
             const float ts = tc / (2.0f * mi);
             float fx = 0.f, fy = 0.f, fz = 0.f;
             const float mi_over_ri = mi / ri;  // (per own particle: correctly rounded, as the reference's left-to-right product starts)
-            for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+            for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Lp[s];
                 const float rj = Lr[s], gj = Lg[s];
                 const bool same = Lm ? (Lm[s] == model) : true;
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_forces(StepCtx c, u
             a.x += fx; a.y += fy; a.z += fz;
         }
         if (bc != 0.0f) {
-            for_each_fb(c, t, i, gs, [&](uint32_t s) {
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Bp[s];
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_wcsph_tension(StepCtx c, u
         if (!active || c.model[i] != model) return;
         const float4 pi = c.posm[i];
         float fx = 0.f, fy = 0.f, fz = 0.f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Lp[s];
             const bool same = Lm ? (Lm[s] == model) : true;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;

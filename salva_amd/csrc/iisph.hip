@@ -44,13 +44,13 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dii(StepCtx c, float
         const float rhoi = c.rho[i];
         const float factor = -dt * dt / (rhoi * rhoi);
         float x = 0.f, y = 0.f, z = 0.f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Lp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (pj.w * factor);
             x += dx * sc; y += dy * sc; z += dz * sc;
         });
-        for_each_fb(c, t, i, gs, [&](uint32_t s) {
+        for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Bp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (pj.w * rho0 * factor);
@@ -85,14 +85,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_pred_density(StepCtx
         const float4 wi = c.w[i];
         const float rho0 = c.rho0_tab[c.model[i]];
         float delta = 0.0f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Lp[s];
             const float4 wj = lds_f4(Lw + s);
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
             delta += pj.w * (((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g);
         });
-        for_each_fb(c, t, i, gs, [&](uint32_t s) {
+        for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Bp[s];
             const float4 vj = Bv[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -129,14 +129,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_aii(StepCtx c, float
         const float factor = dt * dt * pi.w / (rhoi * rhoi);
         const float4 di = c.dii[i];
         float a = 0.0f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Lp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
             const float gx = dx * g, gy = dy * g, gz = dz * g;
             a += pj.w * ((di.x - gx * factor) * gx + (di.y - gy * factor) * gy + (di.z - gz * factor) * gz);
         });
-        for_each_fb(c, t, i, gs, [&](uint32_t s) {
+        for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Bp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dij_pj(StepCtx c, fl
         if (!active) return;
         const float4 pi = c.posm[i];
         float x = 0.f, y = 0.f, z = 0.f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Lp[s];
             const float rhoj = Lr[s];
             const float pjl = Lq[s];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
                 const float fji = dt * dt * pi.w / (rhoi * rhoi);
                 float sum = 0.0f;
                 struct Rec { float4 p, q; };
-                for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], lds_f4(Lq + s)}; }, [&](const Rec& rc) {
+                for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], lds_f4(Lq + s)}; }, [&](const Rec& rc) { SALVA_PAIR_MATH
                     const float4 pj = rc.p;
                     const float4 qj = rc.q;  // d_jj p_j + sum_k d_jk p_k (k_iisph_dij_pj)
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
                     const float fz = (dpi.z - qj.z) + gz * fji * prs;
                     sum += pj.w * (fx * gx + fy * gy + fz * gz);
                 });
-                for_each_fb(c, t, i, gs, [&](uint32_t s) {
+                for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                     const float4 pj = Bp[s];
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                     const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(Ste
         const float rhoi = c.rho[i];
         const float pri = p[i] / (rhoi * rhoi);
         float4 d = c.dv[i];
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Lp[s];
             const float rhoj = Lr[s];
             const float pjl = Lq[s];
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(Ste
             const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (dt * pj.w * (pri + fast_div(pjl, rhoj * rhoj)));
             d.x -= dx * sc; d.y -= dy * sc; d.z -= dz * sc;
         });
-        for_each_fb(c, t, i, gs, [&](uint32_t s) {
+        for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Bp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (pj.w * rho0 * pri);

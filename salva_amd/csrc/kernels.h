@@ -3,7 +3,9 @@
 #include "common.h"
 #include "device_types.h"
 #include "tile.h"
-#include "pipe.h"
+#ifdef SALVA_HIP_DIAG
+#include "diag/pipe.h"
+#endif
 
 namespace salva {
 
@@ -86,12 +88,14 @@ void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmo
 void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmodels, const SolveCtl* ctl, float* sums, hipStream_t s);
 void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, SolveCtl* pub, hipStream_t s);
 
-// ---------------------------------------------------------------- dfsph_pipe.hip (persistent tile pipeline, pipe.h)
+#ifdef SALVA_HIP_DIAG
+// ---------------------------------------------------------------- diag/dfsph_pipe.hip (kernel experiments, `make VARIANT=diag`: persistent tile pipeline, pipe.h)
 void launch_pred_density_pipe(const StepCtx& c, const PipeCfg& P, float dt, hipStream_t s);
 // diagnostics: variant 0 = one tile per workgroup, 1 = + de-phased co-resident tiles (param = sleep in 64-cycle units),
 // 2 = pipeline, 3 = one tile per workgroup with LDS-DMA staging
 void launch_pred_density_variant(const StepCtx& c, const TileLds& L, const PipeCfg& P, float dt, int variant, uint32_t param,
                                  uint32_t* cu_arrivals, hipStream_t s);
+#endif
 
 // ---------------------------------------------------------------- forces.hip
 void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff, float inv_dt_prev, hipStream_t s);

@@ -9,6 +9,13 @@
 
 namespace salva {
 
+// Contraction policy.  The library is compiled with -ffp-contract=off: a*b+c rounds twice everywhere, as in the reference
+// (Rust never fuses), so positions, velocities, cell coordinates and the d^2 <= h^2 test round like the CPU's by
+// construction.  The neighbour-sum loops opt back in locally: their results are sums over contacts in an order the reference
+// does not fix either (hash iteration, contacts.rs:222), compared at 1e-5 relative, and an FMA there is one VALU instead of two.
+// Put SALVA_PAIR_MATH first in the body of a per-contact lambda (the pragma is lexical: it covers that compound statement).
+#define SALVA_PAIR_MATH _Pragma("clang fp contract(fast)")
+
 struct SphConsts {
     float h;       // kernel radius = cell width (liquid_world.rs:44, contacts.rs:164-165)
     float inv_h;
@@ -18,6 +25,7 @@ struct SphConsts {
     float eps2;    // f32::EPSILON^2         kernel.rs:19
     float tiny_r2; // (1e-5 h)^2: below it the gradient is zero (cubic_spline_kernel.rs:63-65, q <= 1e-5)
     float g18, g12, sg6;  // 18 gnorm, 12 gnorm, sqrt(6 gnorm): folded constants of kernel_grad2
+    float gscale;         // 6 gnorm / h^2: the factor kernel_gfac2 leaves to its caller
 };
 
 __host__ inline SphConsts make_sph_consts(float h) {
@@ -32,11 +40,13 @@ __host__ inline SphConsts make_sph_consts(float h) {
     c.g18 = 18.0f * c.gnorm;
     c.g12 = 12.0f * c.gnorm;
     c.sg6 = sqrtf(6.0f * c.gnorm);
+    c.gscale = (float)(6.0 * (double)c.gnorm / ((double)h * (double)h));
     return c;
 }
 
 // W(q) / wnorm
 __device__ __forceinline__ float cubic_w_unit(float q) {
+    SALVA_PAIR_MATH
     const float q2 = q * q;
     const float a = 1.0f + (q2 * q - q2) * 6.0f;
     const float omq = 1.0f - q;
@@ -47,6 +57,7 @@ __device__ __forceinline__ float cubic_w_unit(float q) {
 
 // (dW/dr) / gnorm
 __device__ __forceinline__ float cubic_dw_unit(float q) {
+    SALVA_PAIR_MATH
     const float a = (q * 3.0f - 2.0f) * q * 6.0f;
     const float omq = 1.0f - q;
     const float b = -omq * omq * 6.0f;
@@ -87,6 +98,7 @@ struct KernelEval {
 
 // Full evaluation for one contact given d = xi - xj and r2 = |d|^2.
 __device__ __forceinline__ KernelEval kernel_eval(float r2, const SphConsts& c) {
+    SALVA_PAIR_MATH
     KernelEval e;
     const bool nz = r2 > c.eps2;
     const float rinv = nz ? __builtin_amdgcn_rsqf(r2) : 0.0f;
@@ -102,6 +114,7 @@ __device__ __forceinline__ KernelEval kernel_eval(float r2, const SphConsts& c) 
 // finite (|d| = 0 then lands in the q <= 1e-5 case, kernel.rs:18-24 gives 0 there too), 1-q is clamped at 0 instead
 // of testing q > 1, and the factor 6 is folded into the constant.
 __device__ __forceinline__ float kernel_grad(float r2, const SphConsts& c) {
+    SALVA_PAIR_MATH
     const float rinv = __builtin_amdgcn_rsqf(fmaxf(r2, 1.0e-30f));
     const float q = r2 * rinv * c.inv_h;
     const float a = (q * 3.0f - 2.0f) * q;
@@ -117,6 +130,7 @@ __device__ __forceinline__ float kernel_grad(float r2, const SphConsts& c) {
 // g = 0), which also covers r2 = 0 without a clamp.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 kernel_grad2(f2 r2, const SphConsts& c) {
+    SALVA_PAIR_MATH
     const float t2 = c.tiny_r2;  // (1e-5 h)^2
     f2 rinv;
     rinv.x = (r2.x > t2) ? __builtin_amdgcn_rsqf(r2.x) : 0.0f;
@@ -133,9 +147,37 @@ __device__ __forceinline__ f2 kernel_grad2(f2 r2, const SphConsts& c) {
     return u * rinv;
 }
 
+// The hot-loop form for LIST contacts (two at once): returns g' with (dW/dr)/r = c.gscale * g', from r2 = |d|^2 + 1e-30.
+//   (dW/dq) / (6 gnorm) = (1 - 2q)+^2 - (1 - q)+^2   — the cubic spline as a difference of two truncated quadratics, identical
+// to cubic_spline_kernel.rs:63-77's piecewise form ((3q - 2) q for q <= 1/2, -(1 - q)^2 beyond) as a polynomial; in r:
+//   (dW/dr)/r = (6 gnorm / h^2) [ max(h - 2r, 0)^2 - (h - r)^2 ] / r,
+// and the factor 6 gnorm / h^2 (SphConsts::gscale) is applied once per particle to the finished sum, so the loop needs a
+// single constant, h (one SGPR operand per packed instruction is all VOP3P takes).
+// What is NOT tested here, and why it need not be:
+//   * r > h: a list entry satisfies d^2 <= h^2 exactly (dist2_exact), so r <= h (1 + 2 ulp) and (h - r)^2 <= 1e-13 h^2;
+//   * r2 == 0 (the self contact and the self-padding of a slice's lists): the caller adds 1e-30 to r2 (for free, as the
+//     addend of the first FMA), so rinv is finite, r = 1e-15, both quadratics are h^2 exactly and g' = 0;
+//   * 0 < r <= 1e-5 h (the reference returns 0 there, cubic_spline_kernel.rs:63-65): NOT reproduced — the callers take this
+//     path only for slices in which k_density_alpha found no such pair (StepCtx::slice_near) and use kernel_grad otherwise.
+// 11 VALU per two contacts (2 rsq, 2 max, 7 packed) against 21 for kernel_grad2.
+__device__ __forceinline__ f2 kernel_gfac2(f2 r2, const SphConsts& c) {
+    SALVA_PAIR_MATH
+    f2 rinv;
+    rinv.x = __builtin_amdgcn_rsqf(r2.x);
+    rinv.y = __builtin_amdgcn_rsqf(r2.y);
+    const f2 r = r2 * rinv;
+    const f2 a1 = c.h - r;  // h - r
+    f2 a2 = a1 - r;         // h - 2r
+    a2.x = fmaxf(a2.x, 0.0f);
+    a2.y = fmaxf(a2.y, 0.0f);
+    const f2 u = a2 * a2 - a1 * a1;
+    return u * rinv;
+}
+
 // Two packed pairs at once, stage by stage (the two chains are independent: written interleaved so that the scheduler keeps
 // them interleaved and one chain's latencies are covered by the other's issue slots).
 __device__ __forceinline__ void kernel_grad2x2(f2 r2a, f2 r2b, const SphConsts& c, f2& ga, f2& gb) {
+    SALVA_PAIR_MATH
     const float t2 = c.tiny_r2;
     f2 ra, rb;
     ra.x = (r2a.x > t2) ? __builtin_amdgcn_rsqf(r2a.x) : 0.0f;
@@ -156,6 +198,7 @@ __device__ __forceinline__ void kernel_grad2x2(f2 r2a, f2 r2b, const SphConsts& 
 
 // Weight only.
 __device__ __forceinline__ float kernel_weight(float r2, const SphConsts& c) {
+    SALVA_PAIR_MATH
     const float r = __builtin_amdgcn_sqrtf(r2);
     return c.wnorm * cubic_w_unit(r * c.inv_h);
 }

@@ -44,13 +44,32 @@ constexpr uint32_t TILE_TABLE_BYTES = 4 * (2 * (HCELLS + 1) + 2 * HCELLS) + 16;
 // halo, the workgroup for the fullest tile.
 struct TileLds {
     uint32_t max_halo_fluid = 0, max_halo_boundary = 0, threads = 4 * WAVE;
+    // largest (fluid halo padded to 64) + (boundary halo) of any ONE tile: the tile with the fullest fluid halo sits inside
+    // the fluid and the tile with the most boundary particles at a wall, so this is well below the sum of the two maxima —
+    // 10 KB of LDS per workgroup in the bench scene, the difference between one and two resident tiles per CU for the
+    // 36-byte-per-slot force kernels
+    uint32_t max_sum = 0;
+    uint32_t sum_slots() const {
+        const uint32_t worst = ((max_halo_fluid + 63u) & ~63u) + max_halo_boundary;
+        return max_sum ? (max_sum < worst ? max_sum : worst) : worst;
+    }
     uint32_t bytes(uint32_t bytes_per_fluid_slot, uint32_t bytes_per_boundary_slot, uint32_t narrays,
                    bool with_cell_tables = false) const {
         // (staged fluid arrays are filled by LDS-DMA in chunks of 64 slots: sized to the next multiple of 64)
-        return (with_cell_tables ? TILE_TABLE_BYTES : 0u) + ((max_halo_fluid + 63u) & ~63u) * bytes_per_fluid_slot +
-               max_halo_boundary * bytes_per_boundary_slot + 16u * narrays;
+        const uint32_t separate = ((max_halo_fluid + 63u) & ~63u) * bytes_per_fluid_slot + max_halo_boundary * bytes_per_boundary_slot;
+        const uint32_t wide = bytes_per_fluid_slot > bytes_per_boundary_slot ? bytes_per_fluid_slot : bytes_per_boundary_slot;
+        const uint32_t joint = sum_slots() * wide;
+        return (with_cell_tables ? TILE_TABLE_BYTES : 0u) + (joint < separate ? joint : separate) + 16u * narrays;
     }
 };
+
+// Fixed LDS layouts of the four DFSPH solver kernels (dfsph.hip): the second staged array sits at a COMPILE-TIME distance
+// from the first, so both LDS reads of a contact take their address from one VGPR (the list entry << 4) plus an immediate
+// offset — one VALU instruction per contact instead of three.  Two instantiations: 2432 slots (two such workgroups still
+// share a CU's 160 KB) and 3968 (the 16-bit offset field ends at 65535); fuller halos take the runtime-distance
+// instantiation (DS = 0).
+constexpr uint32_t FIXED_DS_SMALL = 2432, FIXED_DS_LARGE = 3968;
+constexpr uint32_t TILE_ERR_BYTES = 12u * 32u * 4u;  // TileErr table (TILE_MAX_WAVES x MAX_MODELS floats), carved from the pool
 
 #ifdef __HIPCC__
 
@@ -97,6 +116,24 @@ __device__ __forceinline__ float4 lds_f4(const float4* p) {
     float4 v = *p;
     asm volatile("" : "+v"(v.w));
     return v;
+}
+
+// LDS reads by BYTE ADDRESS.  Dynamic LDS starts at byte 0 in a kernel that declares no static __shared__ variable, so the
+// first staged array of such a kernel starts at LDS address 0 and `slot << 4` IS the address: the compiler then folds any
+// compile-time displacement into the instruction's offset field (it cannot do that through the tile_smem symbol, whose
+// address it only learns after instruction selection).  Kernels that use these call lds_base_check() once: the comparison
+// folds away at compile time, or — if someone adds a static __shared__ array — becomes an unconditional trap that the first
+// GPU test hits (and `grep s_trap` on the ISA shows at build time).
+typedef float lds_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_base_check() {
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)tile_smem != 0u) __builtin_trap();
+}
+__device__ __forceinline__ float4 lds_ld16(uint32_t byte_addr) {
+    const lds_v4f v = *(const __attribute__((address_space(3))) lds_v4f*)(uintptr_t)byte_addr;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float lds_ld4(uint32_t byte_addr) {
+    return *(const __attribute__((address_space(3))) float*)(uintptr_t)byte_addr;
 }
 
 // LDS-DMA (global_load_lds): every lane names its own global source, the 64 lanes' data land in LDS side by side from a
@@ -298,6 +335,41 @@ struct Tile {
             });
         else for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; e[s] = s2[g]; f[s] = s3[g]; });
         d0 = a; d1 = b; d2 = e; d3 = f;
+    }
+    // ---- fixed-base layouts (lds_ld16 / lds_ld4): call on a fresh pool (nothing carved yet) ----
+    // P | W: two 16-byte arrays, P at byte 0 and W at byte `dist`; each holds the fluid halo in slots [0, cap) and the
+    // boundary halo in slots [cap, cap + SB) (b0 / b1: bposv / bvel; pass nullptr for b1 to leave W's tail unused).
+    // Requires dist >= (cap + SB) * 16.  Afterwards: *bp / *bv = the boundary parts, pool_used = the end of W.
+    template <typename T>
+    __device__ __forceinline__ void stage_pw(const StepCtx& c, const T* __restrict__ s0, const T* __restrict__ s1, uint32_t dist,
+                                             const float4*& bp, const float4*& bv, bool with_bv) {
+        static_assert(sizeof(T) == 16, "16-byte records");
+        const uint32_t cap = stage_cap(c);
+        T* a = reinterpret_cast<T*>(pool);
+        T* b = reinterpret_cast<T*>(pool + dist);
+        if (c.halo_stride) for_halo_chunks(c, [&](uint32_t q, uint32_t g) { dma_chunk(s0 + g, a + q); dma_chunk(s1 + g, b + q); });
+        else for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; });
+        float4* ba = reinterpret_cast<float4*>(a) + cap;
+        float4* bb = reinterpret_cast<float4*>(b) + cap;
+        if (with_bv) for_halo_boundary(c, [&](uint32_t s, uint32_t g) { ba[s] = c.bposv[g]; bb[s] = c.bvel[g]; });
+        else for_halo_boundary(c, [&](uint32_t s, uint32_t g) { ba[s] = c.bposv[g]; });
+        bp = ba; bv = bb;
+        pool_used = dist + (cap + SB) * 16u;
+    }
+    // P | K: one 16-byte array at byte 0 (fluid halo in [0, cap), then bposv in [cap, cap + SB), then bvel in
+    // [cap + SB, cap + 2 SB)) and one 4-byte array at byte `dist` (fluid halo only).  Requires dist >= (cap + 2 SB) * 16.
+    __device__ __forceinline__ void stage_pk(const StepCtx& c, const float4* __restrict__ s0, const float* __restrict__ s1, uint32_t dist,
+                                             const float4*& bp, const float4*& bv) {
+        const uint32_t cap = stage_cap(c);
+        float4* a = reinterpret_cast<float4*>(pool);
+        float* b = reinterpret_cast<float*>(pool + dist);
+        if (c.halo_stride) for_halo_chunks(c, [&](uint32_t q, uint32_t g) { dma_chunk(s0 + g, a + q); dma_chunk(s1 + g, b + q); });
+        else for_halo(c, [&](uint32_t s, uint32_t g) { a[s] = s0[g]; b[s] = s1[g]; });
+        float4* ba = a + cap;
+        float4* bb = a + cap + SB;
+        for_halo_boundary(c, [&](uint32_t s, uint32_t g) { ba[s] = c.bposv[g]; bb[s] = c.bvel[g]; });
+        bp = ba; bv = bb;
+        pool_used = dist + cap * 4u;
     }
     // the barrier that publishes the staged halo: the DMA of this wave has landed (vmcnt), then everybody's has
     static __device__ __forceinline__ void staged_barrier() {
@@ -558,9 +630,22 @@ __device__ __forceinline__ void for_each_ff4(const StepCtx& c, uint32_t gslice, 
         }
     }
 }
+// List entry -> what `load` is handed.  OFF = false: the 16-bit slot.  OFF = true: the slot's BYTE OFFSET in a 16-byte-strided
+// LDS array (slot * 16) from ONE instruction: v_mad_u32_u16 multiplies a 16-bit half of its first operand (op_sel picks the
+// half) by 16 — the plain C form `(a & 0xffff) << 4` is canonicalised to shift + and, two instructions.
+#ifndef SALVA_NO_MAD16
+__device__ __forceinline__ uint32_t entry_off16_lo(uint32_t a) { uint32_t o; asm("v_mad_u32_u16 %0, %1, 16, 0" : "=v"(o) : "v"(a)); return o; }
+__device__ __forceinline__ uint32_t entry_off16_hi(uint32_t a) { uint32_t o; asm("v_mad_u32_u16 %0, %1, 16, 0 op_sel:[1,0,0,0]" : "=v"(o) : "v"(a)); return o; }
+#else
+__device__ __forceinline__ uint32_t entry_off16_lo(uint32_t a) { return (a & 0xffffu) << 4; }
+__device__ __forceinline__ uint32_t entry_off16_hi(uint32_t a) { return (a >> 16) << 4; }
+#endif
+template <bool OFF> __device__ __forceinline__ uint32_t entry_lo(uint32_t a) { return OFF ? entry_off16_lo(a) : (a & 0xffffu); }
+template <bool OFF> __device__ __forceinline__ uint32_t entry_hi(uint32_t a) { return OFF ? entry_off16_hi(a) : (a >> 16); }
+
 // FUSED: a step over two list dwords (four contacts) is ONE basic block — the two packed chains are independent, and only
 // inside one block can the scheduler interleave them (each chain alone is ~20 dependent packed operations deep).
-template <bool AHEAD = true, bool FUSED = false, typename L, typename C2>
+template <bool AHEAD = true, bool FUSED = false, bool OFF = false, typename L, typename C2>
 __device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, uint32_t nq, const ListRegs& lr, L&& load,
                                              C2&& compute2) {
 #pragma unroll
@@ -568,26 +653,26 @@ __device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, 
         if (FUSED) {
             if ((uint32_t)(k + 1) < nq) {
                 const uint32_t a = lr.d[k], b = lr.d[k + 1];
-                const auto d0 = load(a & 0xffffu);
-                const auto d1 = load(a >> 16);
-                const auto d2 = load(b & 0xffffu);
-                const auto d3 = load(b >> 16);
+                const auto d0 = load(entry_lo<OFF>(a));
+                const auto d1 = load(entry_hi<OFF>(a));
+                const auto d2 = load(entry_lo<OFF>(b));
+                const auto d3 = load(entry_hi<OFF>(b));
                 compute2(d0, d1);
                 compute2(d2, d3);
             } else if ((uint32_t)k < nq) {
                 const uint32_t a = lr.d[k];
-                const auto d0 = load(a & 0xffffu);
-                const auto d1 = load(a >> 16);
+                const auto d0 = load(entry_lo<OFF>(a));
+                const auto d1 = load(entry_hi<OFF>(a));
                 compute2(d0, d1);
             }
         } else if ((uint32_t)k < nq) {
             const uint32_t a = lr.d[k];
             const bool two = (uint32_t)(k + 1) < nq;
             const uint32_t b = two ? lr.d[k + 1] : a;
-            const auto d0 = load(a & 0xffffu);
-            const auto d1 = load(a >> 16);
-            const auto d2 = load(b & 0xffffu);
-            const auto d3 = load(b >> 16);
+            const auto d0 = load(entry_lo<OFF>(a));
+            const auto d1 = load(entry_hi<OFF>(a));
+            const auto d2 = load(entry_lo<OFF>(b));
+            const auto d3 = load(entry_hi<OFF>(b));
             compute2(d0, d1);
             if (two) compute2(d2, d3);
         }
@@ -599,15 +684,15 @@ __device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, 
             for (uint32_t q = LIST_REGS; q < nq; ++q) {
                 const uint32_t a = nx;
                 if (q + 1 < nq) nx = p[ellq(q + 1)];
-                const auto d0 = load(a & 0xffffu);
-                const auto d1 = load(a >> 16);
+                const auto d0 = load(entry_lo<OFF>(a));
+                const auto d1 = load(entry_hi<OFF>(a));
                 compute2(d0, d1);
             }
         } else {
             for (uint32_t q = LIST_REGS; q < nq; ++q) {
                 const uint32_t a = p[ellq(q)];
-                const auto d0 = load(a & 0xffffu);
-                const auto d1 = load(a >> 16);
+                const auto d0 = load(entry_lo<OFF>(a));
+                const auto d1 = load(entry_hi<OFF>(a));
                 compute2(d0, d1);
             }
         }

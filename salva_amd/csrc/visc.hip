@@ -124,7 +124,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_betas(StepCtx c, uint
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
         float q[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         struct Rec { float4 p; uint32_t m; };
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], Lm[s]}; }, [&](const Rec& rc) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], Lm[s]}; }, [&](const Rec& rc) { SALVA_PAIR_MATH
             const float4 pj = rc.p;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_strain(StepCtx c, uin
             const float half_inv_rho = 1.0f / (2.0f * c.rho[i]);
             float r[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             struct Rec { float4 p, v; };
-            for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], Lv[s]}; }, [&](const Rec& rc) {
+            for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], Lv[s]}; }, [&](const Rec& rc) { SALVA_PAIR_MATH
                 const float4 pj = rc.p, vj = rc.v;
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
                 const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_accel(StepCtx c, uint
         float ax = 0.0f, ay = 0.0f, az = 0.0f;
         struct Rec { float4 p, a, b; };
         const float mi_inv_dt = pi.w * inv_dt;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], La[s], Lb[s]}; }, [&](const Rec& rc) {
+        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], La[s], Lb[s]}; }, [&](const Rec& rc) { SALVA_PAIR_MATH
             const float4 pj = rc.p;
             if (__float_as_uint(rc.b.w) != model) return;
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;

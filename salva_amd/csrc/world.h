@@ -93,8 +93,12 @@ class World {
     uint32_t owned_count() const { return comm ? n_owned : n; }
     float time_pred_density(int reps);
     float time_kernel(int kernel, int reps);
-    // diagnostics (salva_hip_time_variant): time variant `variant` of k_pred_density; *checksum = FNV-1a of the kappa it wrote
+#ifdef SALVA_HIP_DIAG
+    // kernel experiments (diag/world_diag.hip, salva_hip_time_variant): time variant `variant` of k_pred_density; *checksum =
+    // FNV-1a of the kappa it wrote
     float time_variant(int variant, uint32_t param, int reps, uint64_t* checksum);
+    void tile_timing_report();
+#endif
 
     SalvaHipCounters counters{};  // the reference's Counters tree of the last step (counters/mod.rs:17-72)
     SalvaHipParams prm;
@@ -169,9 +173,12 @@ class World {
     DevBuf<char> tile_list_stats;
     uint32_t cap_ff = 24, cap_fb = 8;  // ELL capacity (dwords per particle), grown on demand
     DevBuf<uint32_t> nbr_ff, nbr_fb;
+    DevBuf<uint32_t> slice_near;   // per slice: a pair closer than 1e-5 h exists (written by k_density_alpha, read by the DFSPH solver kernels)
     DevBuf<int32_t> bbox_partials;
     TileLds lds;
+#ifdef SALVA_HIP_DIAG
     PipeCfg pipe;          // launch shape of the persistent pipeline kernels of this step (pipe.h)
+#endif
     // speculative sizing (World::step): the previous step's table totals, and what the current pass lets the kernels use
     TileAcc pred_tt{};
     uint32_t pred_n = 0;

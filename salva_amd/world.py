@@ -1062,7 +1062,10 @@ class LiquidWorld:
         return int(self._L.salva_hip_device_bytes(self._h))
 
     def time_variant(self, variant: int, param: int = 0, reps: int = 20):
-        """Diagnostics: (microseconds per launch, checksum of the outputs) of execution variant `variant` of k_pred_density."""
+        """Kernel-development builds only (SALVA_HIP_LIB_VARIANT=diag): (microseconds per launch, checksum of the outputs) of
+        execution variant `variant` of k_pred_density."""
+        if not hasattr(self._L, "salva_hip_time_variant"):
+            raise RuntimeError("salva_hip_time_variant exists only in libsalva_hip_diag.so (make -C salva_amd/csrc VARIANT=diag)")
         cs = C.c_uint64(0)
         us = float(self._L.salva_hip_time_variant(self._h, variant, param, reps, C.byref(cs)))
         if us < 0:
