@@ -47,23 +47,34 @@ def build_scene(side: int):
     return fluid, shell
 
 
-def build_slab_scene(side: int, rank: int, world: int):
-    """Weak scaling: `world` copies of the N=1 block side by side along x in one long tank; rank r uploads block r and the
-    tank particles near its slab.  The cut between blocks r-1 and r is the cell plane under block r's lower face."""
+def slab_scene_geometry(side: int, world: int):
+    """BASELINE config 5's geometry: `world` blocks of side^3 particles side by side along x in one long open tank.
+    Returns (full boundary shell, [(first, last) cell plane of each slab]); block r is cut from block r-1 at the cell plane
+    under its lower face."""
     d = 2.0 * R
     h = R * 2.0 * 2.0
-    fluid = scenes.cube_fluid_positions(side, side, side, R)
-    fluid[:, 0] += np.float32(rank * side * d)
-    fluid = scenes.jitter(fluid, 0.1 * R, seed=42 + rank)
     fmin = np.array([-side * R + R] * 3, dtype=np.float64)
     fmax = fmin + np.array([world * side - 1, side - 1, side - 1], dtype=np.float64) * d
     mins, maxs = fmin - d, fmax + d
     maxs[1] += max(side // 2, 4) * d
     shell = scenes.box_shell(mins, maxs, R, faces="xXyzZ")
     cuts = [int(np.floor((fmin[0] - 0.5 * d + r * side * d) / h)) for r in range(world + 1)]
-    slabs = [(cuts[r], cuts[r + 1] - 1) for r in range(world)]
-    mine = slab.boundary_subset(shell, h, slabs[rank], rank, world)
-    return fluid, shell[mine], slabs[rank], len(shell)
+    return shell, [(cuts[r], cuts[r + 1] - 1) for r in range(world)]
+
+
+def slab_block(side: int, rank: int):
+    """The fluid block of rank `rank` in the long tank (jitter seed 42 + rank)."""
+    fluid = scenes.cube_fluid_positions(side, side, side, R)
+    fluid[:, 0] += np.float32(rank * side * 2.0 * R)
+    return scenes.jitter(fluid, 0.1 * R, seed=42 + rank)
+
+
+def build_slab_scene(side: int, rank: int, world: int):
+    """Weak scaling: `world` copies of the N=1 block side by side along x in one long tank; rank r uploads block r and the
+    tank particles near its slab."""
+    shell, slabs = slab_scene_geometry(side, world)
+    mine = slab.boundary_subset(shell, R * 4.0, slabs[rank], rank, world)
+    return slab_block(side, rank), shell[mine], slabs[rank], len(shell)
 
 
 def make_world(fluid, shell, device: int):

@@ -167,6 +167,7 @@ struct Readback {
     uint64_t ncontacts_ff, ncontacts_fb;   // } written by k_list_stats and read back in one copy
     uint32_t max_cnt_ff, max_cnt_fb;       // } longest contact lists of the step (capacity check)
     uint32_t dcs_count, pad_;          // points emitted by the last DynamicContactSampling pass
+    uint64_t ncontacts_own_ff, ncontacts_own_fb;  // list totals over the particles this rank owns (decomposed runs)
 };
 
 }  // namespace salva

@@ -433,7 +433,7 @@ void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, 
 // ones to the particle's ELL row, two 16-bit slots per dword: fluid-fluid contacts (contacts.rs:347-392) and
 // fluid-boundary contacts (:329-346, :378-383).  Writes nff / nfb, and per tile {sum, max} of the list lengths
 // (the sums are counters.cd.ncontacts; the maxima tell the host whether the fixed ELL capacity was enough).
-struct TileListStats { uint32_t sum_ff, sum_fb, max_ff, max_fb; };
+struct TileListStats { uint32_t sum_ff, sum_fb, max_ff, max_fb, own_ff, own_fb; };  // own_*: lists of particles this rank OWNS (no ghosts)
 
 // V = 0: one candidate per iteration, nested branches on every accepted candidate (the round-1 kernel; kept for comparison,
 //        SALVA_HIP_NBR_VARIANT=0).
@@ -445,11 +445,11 @@ struct TileListStats { uint32_t sum_ff, sum_fb, max_ff, max_fb; };
 // bound by per-wave latency, not by the stores)
 template <int V>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileListStats* __restrict__ tile_stats) {
-    __shared__ uint32_t red[4][TILE_MAX_WAVES];
+    __shared__ uint32_t red[6][TILE_MAX_WAVES];
     Tile t;
     t.setup(c);
     if (t.empty()) {
-        if (threadIdx.x == 0) tile_stats[t.slot] = TileListStats{0, 0, 0, 0};
+        if (threadIdx.x == 0) tile_stats[t.slot] = TileListStats{0, 0, 0, 0, 0, 0};
         return;
     }
     TileCells tc;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
     t.for_halo(c, [&](uint32_t s, uint32_t g) { Lp[s] = c.posm[g]; if (multi) Lm[s] = c.model[g]; });
     t.for_halo_boundary(c, [&](uint32_t s, uint32_t g) { Bp[s] = c.bposv[g]; Bv[s] = c.bvel[g]; });
     __syncthreads();
-    uint32_t sum_ff = 0, sum_fb = 0, max_ff = 0, max_fb = 0;
+    uint32_t sum_ff = 0, sum_fb = 0, max_ff = 0, max_fb = 0, own_ff = 0, own_fb = 0;
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
         uint32_t cnt = 0, cntb = 0;
         uint32_t self_slot = 0;
@@ -569,6 +569,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
         c.nfb[i] = min(cntb, 2u * c.cap_fb);
         sum_ff += cnt; sum_fb += cntb;
         max_ff = max(max_ff, cnt); max_fb = max(max_fb, cntb);
+        if (!is_ghost(c, i)) { own_ff += cnt; own_fb += cntb; }  // (a decomposed run reports the contacts of the particles it owns)
         }
         // Pad every list of the slice with self contacts up to the longest one: the gradient passes then run a
         // wave-uniform trip count with no per-lane predicates (a lane with a shorter list would idle anyway).
@@ -584,15 +585,17 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
     for (int o = 32; o > 0; o >>= 1) {
         sum_ff += (uint32_t)__shfl_xor((int)sum_ff, o, WAVE);
         sum_fb += (uint32_t)__shfl_xor((int)sum_fb, o, WAVE);
+        own_ff += (uint32_t)__shfl_xor((int)own_ff, o, WAVE);
+        own_fb += (uint32_t)__shfl_xor((int)own_fb, o, WAVE);
     }
     max_ff = wave_max_u32(max_ff); max_fb = wave_max_u32(max_fb);
     const uint32_t wv = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
-    if (lane == 0) { red[0][wv] = sum_ff; red[1][wv] = sum_fb; red[2][wv] = max_ff; red[3][wv] = max_fb; }
+    if (lane == 0) { red[0][wv] = sum_ff; red[1][wv] = sum_fb; red[2][wv] = max_ff; red[3][wv] = max_fb; red[4][wv] = own_ff; red[5][wv] = own_fb; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        TileListStats st{0, 0, 0, 0};
+        TileListStats st{0, 0, 0, 0, 0, 0};
         for (uint32_t k = 0; k < nw; ++k) {
-            st.sum_ff += red[0][k]; st.sum_fb += red[1][k];
+            st.sum_ff += red[0][k]; st.sum_fb += red[1][k]; st.own_ff += red[4][k]; st.own_fb += red[5][k];
             st.max_ff = max(st.max_ff, red[2][k]); st.max_fb = max(st.max_fb, red[3][k]);
         }
         tile_stats[t.slot] = st;
@@ -600,33 +603,37 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
 }
 // fold the per-tile list statistics: out = {ncontacts_ff, ncontacts_fb} (u64) and {max_ff, max_fb} (u32)
 __global__ __launch_bounds__(BLOCK) void k_list_stats(const TileListStats* __restrict__ ts, uint32_t ntiles,
-                                                      unsigned long long* totals2, uint32_t* maxima2) {
-    __shared__ unsigned long long sred[2][BLOCK / WAVE];
+                                                      unsigned long long* totals2, uint32_t* maxima2, unsigned long long* own2) {
+    __shared__ unsigned long long sred[4][BLOCK / WAVE];
     __shared__ uint32_t mred[2][BLOCK / WAVE];
-    unsigned long long a = 0, b = 0;
+    unsigned long long a = 0, b = 0, oa = 0, ob = 0;
     uint32_t ma = 0, mb = 0;
     for (uint32_t k = threadIdx.x; k < ntiles; k += BLOCK) {
         const TileListStats s = ts[k];
-        a += s.sum_ff; b += s.sum_fb; ma = max(ma, s.max_ff); mb = max(mb, s.max_fb);
+        a += s.sum_ff; b += s.sum_fb; oa += s.own_ff; ob += s.own_fb; ma = max(ma, s.max_ff); mb = max(mb, s.max_fb);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         a += __shfl_xor(a, o, WAVE); b += __shfl_xor(b, o, WAVE);
+        oa += __shfl_xor(oa, o, WAVE); ob += __shfl_xor(ob, o, WAVE);
     }
     ma = wave_max_u32(ma); mb = wave_max_u32(mb);
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    if (lane == 0) { sred[0][wv] = a; sred[1][wv] = b; mred[0][wv] = ma; mred[1][wv] = mb; }
+    if (lane == 0) { sred[0][wv] = a; sred[1][wv] = b; sred[2][wv] = oa; sred[3][wv] = ob; mred[0][wv] = ma; mred[1][wv] = mb; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long ta = 0, tb = 0; uint32_t xa = 0, xb = 0;
-        for (int k = 0; k < BLOCK / WAVE; ++k) { ta += sred[0][k]; tb += sred[1][k]; xa = max(xa, mred[0][k]); xb = max(xb, mred[1][k]); }
+        unsigned long long ta = 0, tb = 0, toa = 0, tob = 0; uint32_t xa = 0, xb = 0;
+        for (int k = 0; k < BLOCK / WAVE; ++k) {
+            ta += sred[0][k]; tb += sred[1][k]; toa += sred[2][k]; tob += sred[3][k]; xa = max(xa, mred[0][k]); xb = max(xb, mred[1][k]);
+        }
         totals2[0] = ta; totals2[1] = tb; maxima2[0] = xa; maxima2[1] = xb;
+        if (own2) { own2[0] = toa; own2[1] = tob; }
     }
 }
 
 size_t tile_list_stats_bytes(uint32_t ntiles) { return (size_t)ntiles * sizeof(TileListStats); }
 void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsigned long long* totals2, uint32_t* maxima2,
-                      hipStream_t s) {
+                      unsigned long long* own2, hipStream_t s) {
     if (c.n == 0) return;
     static const int variant = [] { const char* e = getenv("SALVA_HIP_NBR_VARIANT"); return e ? atoi(e) : 1; }();
     TileListStats* ts = static_cast<TileListStats*>(tile_stats);
@@ -635,7 +642,7 @@ void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsi
     } else {
         SALVA_LAUNCH_TILE(k_nbr_tile<1>, c, L, L.bytes(20, 32, 4, true) + 64u, s, c, ts);
     }
-    k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.nlaunch, totals2, maxima2);
+    k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.nlaunch, totals2, maxima2, own2);
 }
 
 // ------------------------------------------------------------------------------------------------ boundary volumes
@@ -670,6 +677,9 @@ __global__ __launch_bounds__(BLOCK) void k_boundary_volumes(StepCtx c, unsigned 
             }
         }
         if (!(denom > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!denominator.is_zero()) dfsph_solver.rs:92
+        // a decomposed run replicates the boundary particles near a slab face on both ranks: each contact is reported by the rank
+        // whose slab holds its first particle, so that the ranks' counts add up to the undivided domain's
+        if (!(cx > c.ghost_lo_cx && cx < c.ghost_hi_cx)) cnt = 0;
         reinterpret_cast<float*>(&c.bposv[i])[3] = 1.0f / denom;
     }
     const float tot = block_sum((float)cnt, red);

@@ -52,8 +52,9 @@ void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, 
 // neighbour lists (per-slice ELL blocks of 16-bit halo slots, capacity c.cap_ff / c.cap_fb dwords per particle), built
 // in one pass; totals2 = {ff, fb} contact counts, maxima2 = longest {ff, fb} list (> 2*cap means overflow: rebuild)
 size_t tile_list_stats_bytes(uint32_t ntiles);
+// own2 (may be null) = the same totals over the particles this rank owns (no ghosts)
 void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsigned long long* totals2, uint32_t* maxima2,
-                      hipStream_t s);
+                      unsigned long long* own2, hipStream_t s);
 size_t select_flagged_temp_bytes(uint32_t n);
 void select_flagged_f4(void* temp, size_t temp_bytes, const float4* in, const uint8_t* flags, float4* out, uint32_t* num_selected,
                        uint32_t n, hipStream_t s);

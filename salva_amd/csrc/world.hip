@@ -1154,10 +1154,12 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             slice_near.ensure((size_t)nslices + 1, stream, false, 1.1f);
             (void)r1; (void)r2;
             c = make_ctx();
-            launch_nbr_build(c, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff, stream);
+            launch_nbr_build(c, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff,
+                             comm ? reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_own_ff) : nullptr, stream);
             if (spec || defer_lists) break;
             static_assert(offsetof(Readback, max_cnt_ff) == offsetof(Readback, ncontacts_ff) + 2 * sizeof(uint64_t), "list statistics travel in one copy");
             SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, &d_rb.p->ncontacts_ff, 2 * sizeof(uint64_t) + 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            if (comm) SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_own_ff, &d_rb.p->ncontacts_own_ff, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
             wait_stream();
             const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;
             if (need_ff <= cap_ff && need_fb <= cap_fb) break;
@@ -1215,7 +1217,10 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     break;
     }  // attempts
     acc_user = false;
-    st.ncontacts = h_rb->ncontacts_ff + (nb ? h_rb->ncontacts_fb : 0) + ncontacts_bb;
+    // decomposed runs: the contacts whose first particle this rank owns (fluid) / whose first particle lies in its slab
+    // (boundary-boundary, k_boundary_volumes) — the ranks' counts add up to the undivided domain's counters.cd.ncontacts
+    st.ncontacts = comm ? h_rb->ncontacts_own_ff + (nb ? h_rb->ncontacts_own_fb : 0) + ncontacts_bb
+                        : h_rb->ncontacts_ff + (nb ? h_rb->ncontacts_fb : 0) + ncontacts_bb;
     bbox_known = true;
     last_ctx = c; last_ctx.ctl = nullptr; last_dt = dt; have_last_ctx = true;
     if (timers) {
@@ -1906,7 +1911,7 @@ float World::time_kernel(int kernel, int reps) {
             case 1: launch_divergence(cd, lds, stream); break;
             case 2: launch_iisph_next_pressure(cd, lds, last_dt, 0.5f, kappa.p, kappa2.p, stream); break;
             case 3: launch_iisph_dij_pj(cd, lds, last_dt, kappa.p, stream); break;
-            case 4: launch_nbr_build(cd, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff, stream); break;  // rebuilds the same lists
+            case 4: launch_nbr_build(cd, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff, nullptr, stream); break;  // rebuilds the same lists
             default: throw HipError(SALVA_HIP_E_INVALID, "unknown kernel id");
         }
     };

@@ -1,0 +1,253 @@
+"""A SECOND, independent reading of salva's DFSPH and IISPH steps — plain numpy, float64, dense O(N^2) neighbourhoods, at most
+a few hundred particles — written straight from the Rust, not from oracle/salva_oracle.cpp:
+
+  liquid_world.rs:62-158 (step order), timestep_manager.rs:36-95 (dt / inv_dt lag), geometry/contacts.rs:254-400 (contact
+  criterion d^2 <= h^2, self contacts included, directed lists), kernel/cubic_spline_kernel.rs:12-79 + kernel/kernel.rs:13-24,
+  solver/helper.rs:9-65, object/fluid.rs:105-115 (volume = 0.8 (2r)^3), solver/pressure/dfsph_solver.rs:72-708,
+  solver/pressure/iisph_solver.rs:92-711, solver/viscosity/xsph_viscosity.rs:31-95.
+
+Purpose: the oracle and the HIP kernels were written by the same hand from the same source, so a shared
+misreading passes every GPU-vs-oracle test.  This file shares no code and no data structure with either (no grid, no contact
+lists, no per-pass loops over contacts: every pass is a masked dense matrix expression), and tests/test_second_reading.py
+compares every intermediate field of the oracle's f64 build with it, step by step.  It does not pin anything to salva itself —
+no Rust toolchain here — but a transcription error would have to be made twice, independently, in two different formulations.
+
+Test infrastructure only."""
+import numpy as np
+
+EPS32 = float(np.finfo(np.float32).eps)  # Real::default_epsilon() of the reference's f32 build (kernel.rs:19)
+
+
+def spline_w(r, h):
+    """cubic_spline_kernel.rs:12-33 (dim3)."""
+    normalizer = 8.0 / (np.pi * h * h * h)
+    q = r / h
+    q2 = q * q
+    inner = 1.0 + (q2 * q - q2) * 6.0
+    outer = (1.0 - q) ** 3 * 2.0
+    return normalizer * np.where(q <= 0.5, inner, np.where(q <= 1.0, outer, 0.0))
+
+
+def spline_dw(r, h):
+    """cubic_spline_kernel.rs:55-79 (dim3): zero for q > 1 and for q <= 1e-5."""
+    normalizer = 8.0 / (np.pi * h * h * h)
+    q = r / h
+    inner = (q * 3.0 - 2.0) * q * 6.0
+    one_q = 1.0 - q
+    outer = -one_q * one_q * 6.0
+    rhs = np.where((q > 1.0) | (q <= 1.0e-5), 0.0, np.where(q <= 0.5, inner, outer))
+    return normalizer * rhs / h
+
+
+def pair_tables(xa, xb, h):
+    """For every (a, b): contact mask (contacts.rs: distance_squared <= h*h), weight (helper.rs: points_apply) and gradient
+    (points_apply_diff1 = apply_diff(pa - pb): direction * dW/dr, zero when the norm is <= eps, kernel.rs:18-24)."""
+    d = xa[:, None, :] - xb[None, :, :]
+    r2 = (d * d).sum(axis=2)
+    mask = r2 <= h * h
+    r = np.sqrt(r2)
+    w = np.where(mask, spline_w(r, h), 0.0)
+    safe = np.where(r > EPS32, r, 1.0)
+    g = np.where((mask & (r > EPS32))[:, :, None], d / safe[:, :, None] * spline_dw(r, h)[:, :, None], 0.0)
+    return mask, w, g
+
+
+class DenseWorld:
+    """One fluid + one boundary (either may be empty), default interaction groups, optional XSPHViscosity."""
+
+    def __init__(self, particle_radius, smoothing_factor=2.0, solver="dfsph"):
+        self.r = float(particle_radius)
+        self.h = float(particle_radius) * float(smoothing_factor) * 2.0  # liquid_world.rs:44
+        self.solver = solver
+        # pub fields of DFSPHSolver::new / IISPHSolver::new
+        self.min_pressure_iter, self.max_pressure_iter, self.max_density_error = 1, 50, 0.05
+        self.min_divergence_iter, self.max_divergence_iter, self.max_divergence_error = 1, 50, 0.1
+        self.min_neighbors = 20
+        self.omega = 0.5
+        self.dt = 0.0      # TimestepManager::new: dt = inv_dt = 0 until the first advance()
+        self.inv_dt = 0.0
+        self.xsph = None
+        self.x = np.zeros((0, 3)); self.v = np.zeros((0, 3)); self.a = np.zeros((0, 3)); self.vol = np.zeros(0)
+        self.density0 = 1000.0
+        self.xb = np.zeros((0, 3)); self.vb = np.zeros((0, 3))
+        self.dv = np.zeros((0, 3))   # solver.velocity_changes: persists across steps
+        self.p = np.zeros(0)         # IISPH pressures: persist across steps
+        self.trace = {}
+
+    def set_fluid(self, positions, density0=1000.0, velocities=None):
+        self.x = np.asarray(positions, np.float64).copy()
+        n = len(self.x)
+        self.v = np.zeros((n, 3)) if velocities is None else np.asarray(velocities, np.float64).copy()
+        self.a = np.zeros((n, 3))
+        self.vol = np.full(n, self.r ** 3 * 8.0 * 0.8)  # fluid.rs:105-115
+        self.density0 = float(density0)
+        self.dv = np.zeros((n, 3))
+        self.p = np.zeros(n)
+
+    def set_boundary(self, positions):
+        self.xb = np.asarray(positions, np.float64).copy()
+        self.vb = np.zeros_like(self.xb)
+
+    def set_xsph(self, fluid_coeff, boundary_coeff):
+        self.xsph = (float(fluid_coeff), float(boundary_coeff))
+
+    # ------------------------------------------------------------------------------------------------------------
+    def step(self, dt, gravity=(0.0, -9.81, 0.0)):
+        g = np.asarray(gravity, np.float64)
+        if dt <= EPS32:  # timestep_manager.is_done() before the first substep
+            return
+        h = self.h
+        m = self.vol * self.density0                          # Fluid::particle_mass
+        self.ff, self.wff, self.gff = pair_tables(self.x, self.x, h)
+        self.fb, self.wfb, self.gfb = pair_tables(self.x, self.xb, h)
+        bb, wbb, _ = pair_tables(self.xb, self.xb, h)
+        # compute_boundary_volumes (dfsph_solver.rs:72-96)
+        self.volb = 1.0 / wbb.sum(axis=1) if len(self.xb) else np.zeros(0)
+        mb = self.volb * self.density0                        # V_b * fluid_i.density0
+        # compute_densities (:628-665)
+        self.rho = self.wff @ m + self.wfb @ mb
+        self.ncontacts = int(self.ff.sum() + self.fb.sum() + bb.sum())
+        if self.solver == "dfsph":
+            self._dfsph(dt, g, m, mb)
+        else:
+            self._iisph(dt, g, m, mb)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _forces(self, m, mb):
+        """predict_advection after `acceleration += gravity`: XSPHViscosity::solve (xsph_viscosity.rs:31-95) with the
+        timestep's CURRENT inv_dt — the previous step's, advance() comes afterwards."""
+        if self.xsph is None:
+            return
+        cf, cb = self.xsph
+        add = np.zeros_like(self.a)
+        if cf != 0.0:
+            coef = cf * self.wff * (m / self.rho)[None, :]     # c.weight * volumes[j] * density0 / densities[j]
+            add += (coef[:, :, None] * (self.v[None, :, :] - self.v[:, None, :])).sum(axis=1) * self.inv_dt
+        if cb != 0.0:
+            coef = cb * self.wfb * mb[None, :] / self.rho[:, None]
+            add += (coef[:, :, None] * (self.vb[None, :, :] - self.v[:, None, :])).sum(axis=1) * self.inv_dt
+        self.a += add
+
+    def _advance(self, dt):
+        self.dt = dt
+        self.inv_dt = 0.0 if dt == 0.0 else 1.0 / dt
+
+    def _dfsph(self, dt, g, m, mb):
+        n = len(self.x)
+        rho0 = self.density0
+        ncon = self.ff.sum(axis=1) + self.fb.sum(axis=1)
+        # compute_alphas (:165-216)
+        gi = self.gff * m[None, :, None]
+        gbi = self.gfb * mb[None, :, None]
+        sq = (gi * gi).sum(axis=(1, 2)) + (gbi * gbi).sum(axis=(1, 2))
+        gs = gi.sum(axis=1) + gbi.sum(axis=1)
+        den = sq + (gs * gs).sum(axis=1)
+        self.alpha = np.where(den <= 1.0e-5, 0.0, 1.0 / np.where(den <= 1.0e-5, 1.0, den))
+        # divergence_solve (:466-503) — timestep.inv_dt() is still the previous step's
+        self.n_div = 0
+        for i in range(self.max_divergence_iter):
+            w = self.v + self.dv
+            dvel = w[:, None, :] - w[None, :, :]
+            div = ((dvel * self.gff).sum(axis=2) * m[None, :]).sum(axis=1) + ((w[:, None, :] * self.gfb).sum(axis=2) * mb[None, :]).sum(axis=1)
+            div = np.where(ncon < self.min_neighbors, 0.0, np.maximum(div, 0.0))
+            self.div = div
+            err = float((div / rho0).sum() / n) if n else 0.0
+            self.div_err = err
+            if err <= self.max_divergence_error * self.inv_dt * 0.01 and i >= self.min_divergence_iter:
+                break
+            k = div * self.alpha
+            kij = k[:, None] + k[None, :]
+            self.dv = self.dv + (self.gff * (-(kij) * m[None, :])[:, :, None]).sum(axis=1) + (self.gfb * (-k[:, None] * mb[None, :])[:, :, None]).sum(axis=1)
+            self.n_div += 1
+        # update_velocities + zero (:689-691)
+        self.v = self.v + self.dv
+        self.dv = np.zeros_like(self.dv)
+        # predict_advection (:565-604)
+        self.a = self.a + g[None, :]
+        self._forces(m, mb)
+        self._advance(dt)
+        # integrate_and_clear_accelerations (:505-519)
+        self.dv = self.dv + self.a * self.dt
+        self.a = np.zeros_like(self.a)
+        # pressure_solve (:432-464)
+        self.n_press = 0
+        for i in range(self.max_pressure_iter):
+            w = self.v + self.dv
+            dvel = w[:, None, :] - w[None, :, :]
+            delta = ((dvel * self.gff).sum(axis=2) * m[None, :]).sum(axis=1)
+            delta += (((w[:, None, :] - self.vb[None, :, :]) * self.gfb).sum(axis=2) * mb[None, :]).sum(axis=1)
+            self.rho_pred = self.rho + delta * self.dt
+            e = np.where(self.rho_pred < rho0, 0.0, self.rho_pred / rho0 - 1.0)
+            err = float(e.sum() / n) if n else 0.0
+            self.press_err = err
+            if err <= self.max_density_error and i >= self.min_pressure_iter:
+                break
+            k = (self.rho_pred - rho0) * self.alpha
+            kp = np.maximum(k, 0.0)
+            kij = kp[:, None] + kp[None, :]
+            self.dv = self.dv - (self.gff * (kij * m[None, :] * self.inv_dt)[:, :, None]).sum(axis=1)
+            coeff = np.where(k > 0.0, k, 0.0)[:, None] * mb[None, :] * self.inv_dt
+            self.dv = self.dv - (self.gfb * coeff[:, :, None]).sum(axis=1)
+            self.n_press += 1
+        # update_positions (:411-420): velocities are NOT updated here
+        self.x = self.x + (self.v + self.dv) * self.dt
+
+    def _iisph(self, dt, g, m, mb):
+        n = len(self.x)
+        rho0 = self.density0
+        # step (:643-711)
+        self.a = self.a + g[None, :]
+        self._forces(m, mb)
+        self._advance(dt)
+        self.dv = self.dv + self.a * self.dt
+        self.a = np.zeros_like(self.a)
+        dt2 = self.dt * self.dt
+        rho = self.rho
+        # compute_dii (:144-186)
+        fac = -dt2 / (rho * rho)
+        self.dii = (self.gff * m[None, :, None]).sum(axis=1) * fac[:, None] + (self.gfb * mb[None, :, None]).sum(axis=1) * fac[:, None]
+        self.p = self.p * 0.5
+        # compute_predicted_densities (:92-142)
+        w = self.v + self.dv
+        dvel = w[:, None, :] - w[None, :, :]
+        delta = ((dvel * self.gff).sum(axis=2) * m[None, :]).sum(axis=1)
+        delta += (((w[:, None, :] - self.vb[None, :, :]) * self.gfb).sum(axis=2) * mb[None, :]).sum(axis=1)
+        self.rho_pred = rho + delta * self.dt
+        # compute_aii (:188-233): a_ii = sum_j m_j (d_ii - d_ji) . grad W_ij, d_ji = grad W_ij dt^2 m_i / rho_i^2
+        fji = dt2 * m / (rho * rho)
+        dji = self.gff * fji[:, None, None]
+        self.aii = (((self.dii[:, None, :] - dji) * self.gff).sum(axis=2) * m[None, :]).sum(axis=1)
+        djib = self.gfb * fji[:, None, None]
+        self.aii += (((self.dii[:, None, :] - djib) * self.gfb).sum(axis=2) * mb[None, :]).sum(axis=1)
+        # pressure_solve (:422-456)
+        self.n_press = 0
+        for i in range(self.max_pressure_iter):
+            # compute_dij_pjl (:235-268)
+            coef = -m * self.p / (rho * rho)
+            self.dijpj = (self.gff * coef[None, :, None]).sum(axis=1) * dt2
+            # compute_next_pressures (:270-353)
+            factor = (self.dijpj[:, None, :] - self.dii[None, :, :] * self.p[None, :, None]
+                      - (self.dijpj[None, :, :] - dji * self.p[:, None, None]))
+            s = ((factor * self.gff).sum(axis=2) * m[None, :]).sum(axis=1)
+            s += ((self.dijpj[:, None, :] * self.gfb).sum(axis=2) * mb[None, :]).sum(axis=1)
+            active = np.abs(self.aii) > 1.0e-9
+            aii_safe = np.where(active, self.aii, 1.0)
+            pn = (1.0 - self.omega) * self.p + self.omega * (rho0 - self.rho_pred - s) / aii_safe
+            pos = active & (pn > 0.0)
+            e = np.where(pos, (-s - self.aii * pn) / rho0, 0.0)
+            self.p = np.where(pos, pn, 0.0)
+            err = float(e.sum() / n) if n else 0.0
+            self.press_err = err
+            self.n_press += 1
+            if err <= self.max_density_error and i >= self.min_pressure_iter:
+                break
+        # compute_velocity_changes (:355-404)
+        pr = self.p / (rho * rho)
+        cij = self.dt * m[None, :] * (pr[:, None] + pr[None, :])
+        self.dv = self.dv - (self.gff * cij[:, :, None]).sum(axis=1)
+        self.dv = self.dv - (self.gfb * (mb[None, :] * pr[:, None])[:, :, None]).sum(axis=1) * self.dt
+        # update_velocities_and_positions (:406-420) + zero
+        self.v = self.v + self.dv
+        self.x = self.x + self.v * self.dt
+        self.dv_last = self.dv.copy()
+        self.dv = np.zeros_like(self.dv)

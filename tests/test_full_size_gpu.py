@@ -178,3 +178,18 @@ def test_config4_two_phase_2m_30_steps():
     s.add_fluid(lower, scenes.random_velocities(len(lower), 0.1, seed=1), 1000.0, forces=[("xsph", 0.5, 0.0)])
     s.add_fluid(upper, scenes.random_velocities(len(upper), 0.1, seed=2), 500.0, forces=[("xsph", 0.5, 0.0)])
     long_run_against_oracle(s, 30, GRAVITY, "config 4, 30 steps")
+
+
+def test_config3_iisph_akinci_1m_tank_30_steps():
+    """BASELINE config 3 as bench.py --config 3 runs it — the 100^3 block in the open tank, IISPH defaults,
+    Akinci2013SurfaceTension(1.0, 10.0) (cohesion + curvature between fluid particles, adhesion to the tank) — for 30 steps
+    against the oracle, like configs 2 and 4: per-step contact counts, Jacobi iteration traces, final positions and velocities
+    within max(1e-4 r N, 2 x the oracle's own f32-vs-f64 distance)."""
+    import bench
+
+    fluids, shell = bench.build_config(3, 100)
+    s = Scene(R, 2.0, "iisph")
+    s.add_fluid(fluids[0][0], None, 1000.0, forces=[("akinci", 1.0, 10.0)])
+    s.add_boundary(shell)
+    trace = long_run_against_oracle(s, 30, GRAVITY, "config 3, 30 steps")
+    assert max(t[1] for t in trace) >= 2, f"the pressure solve never iterated: {trace}"
