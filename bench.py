@@ -141,19 +141,31 @@ def committed_traffic(kernel: str, config: int, side: int):
     """HBM bytes per launch of `kernel` from the committed PMC summary of THIS workload (profiles/r*_cfg<config>/ for the
     10^6-per-fluid configurations, profiles/r*_8m/ for side 200; newest round first), written by tools/summarize_pmc.py
     from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 correction of MI355X_MICROARCH.md.
-    Counters cannot be read from inside this process, so this is the measured figure of the committed profile, not of
-    this run; None if there is none for this workload."""
+    Counters cannot be read from inside this process, so this is the measured figure of a COMMITTED PROFILE, not of this run,
+    and the JSON line says so (`traffic_source` = "committed_profile:<file>").  The profile records the hash of the kernel
+    sources it was taken with (salva_amd.kernel_source_sha): when the sources have changed since, the figure is withheld
+    (traffic = null, traffic_source = "STALE ...") and a warning goes to stderr, instead of going stale silently.
+    Returns (bytes or None, source string or None)."""
     import glob
+
+    from salva_amd import kernel_source_sha
     tag = {100: f"cfg{config}", 200: "8m" if config == 2 else None}.get(side)
     if tag is None:
         return None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}", "hbm_traffic.json")), reverse=True):
         try:
-            k = json.load(open(f))["kernels"].get(kernel)
+            j = json.load(open(f))
+            k = j["kernels"].get(kernel)
         except (OSError, ValueError, KeyError):
             continue
         if k:
-            return float(k["bytes"]), os.path.relpath(f, ROOT)
+            rel = os.path.relpath(f, ROOT)
+            sha = j.get("kernel_src_sha")
+            if sha != kernel_source_sha():
+                sys.stderr.write(f"bench.py: WARNING: {rel} was taken with other kernel sources (profile {sha}, tree {kernel_source_sha()}): "
+                                 f"roofline.traffic withheld — re-run tools/profile_r03.sh and commit the summary\n")
+                return None, f"STALE committed_profile:{rel} (kernel sources changed since it was taken)"
+            return float(k["bytes"]), f"committed_profile:{rel}"
     return None, None
 
 

@@ -87,10 +87,11 @@ pub struct LiquidWorld {
     last_stats: ffi::SalvaHipStepStats,
 }
 
-// the C side keeps no thread-affine state: every entry point selects the world's device and stream itself
-// (the reference asserts the same of its own world, liquid_world.rs:283-287)
+// Send: the C side keeps no thread-affine state — every entry point selects the world's device and stream itself, and the
+// last-error string is thread-local.  NOT Sync: entry points that take `&self` here (queries, read-backs) still reuse scratch
+// buffers and the world's stream on the C side, so two threads must not call into the same world at once; share it behind a
+// Mutex like any other `!Sync` handle.  (salva3d's own LiquidWorld is Send + Sync by composition of plain data.)
 unsafe impl Send for LiquidWorld {}
-unsafe impl Sync for LiquidWorld {}
 
 impl Drop for LiquidWorld {
     fn drop(&mut self) {

@@ -26,3 +26,18 @@ __all__ = [
     "Akinci2013SurfaceTension", "ArtificialViscosity", "Boundary", "Counters", "DFSPHSolver", "DFSPHViscosity", "Fluid", "He2014SurfaceTension", "IISPHSolver",
     "InteractionGroups", "LiquidWorld", "NonPressureForce", "WCSPHSurfaceTension", "XSPHViscosity", "coupling", "dist", "scenes",
 ]
+
+
+def kernel_source_sha() -> str:
+    """sha256 (first 16 hex digits) over the device sources of libsalva_hip.so (salva_amd/csrc/*.hip, *.h): what a committed
+    rocprof summary records so that bench.py can tell whether its PMC figures still describe the kernels in the tree."""
+    import glob
+    import hashlib
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(here, "*.hip")) + glob.glob(os.path.join(here, "*.h"))):
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]

@@ -749,13 +749,19 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
         }
         if (pub) {
             const uint32_t expect = (uint32_t)(i + nbatch);
-            for (uint64_t spins = 0; __atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) < expect; ++spins) {
-                if ((spins & 0xfffffu) == 0xfffffu) {  // a fault on the stream would otherwise spin forever
-                    const hipError_t e = hipStreamQuery(stream);
-                    if (e != hipSuccess && e != hipErrorNotReady) SALVA_HIP_CHECK(e);
-                    if (e == hipSuccess && __atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) < expect)
-                        throw HipError(SALVA_HIP_E_HIP, "internal error: a solver batch finished without publishing its control block");
-                }
+            // spin on the host-mapped block; `pause` keeps the sibling hyper-thread usable (loopback tests run one host thread
+            // per rank), and every ~100 us the stream is queried so that a fault on it surfaces instead of spinning forever
+            auto last_query = std::chrono::steady_clock::now();
+            for (uint32_t spins = 0; __atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) < expect; ++spins) {
+                __builtin_ia32_pause();
+                if ((spins & 0xffu) != 0xffu) continue;
+                const auto now = std::chrono::steady_clock::now();
+                if (now - last_query < std::chrono::microseconds(100)) continue;
+                last_query = now;
+                const hipError_t e = hipStreamQuery(stream);
+                if (e != hipSuccess && e != hipErrorNotReady) SALVA_HIP_CHECK(e);
+                if (e == hipSuccess && __atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) < expect)
+                    throw HipError(SALVA_HIP_E_HIP, "internal error: a solver batch finished without publishing its control block");
             }
             h_ctl[which].done = pub->done; h_ctl[which].iters = pub->iters; h_ctl[which].err = pub->err;
         } else {
@@ -1360,6 +1366,21 @@ uint64_t World::particles_in_shape(const float t[3], const float q[4], const Sal
     if (comm) throw HipError(SALVA_HIP_E_INVALID, "queries are not available in a multi-GPU run");
     if (shape.kind != SALVA_HIP_SHAPE_BALL && shape.kind != SALVA_HIP_SHAPE_CUBOID)
         throw HipError(SALVA_HIP_E_INVALID, "unknown shape kind (ball and cuboid are built in; other parry shapes belong to the host)");
+    // the pose must be a rigid motion and the shape non-degenerate (the reference takes an Isometry and a parry shape, which
+    // cannot be anything else): NaN / huge values would otherwise reach an undefined float -> int conversion below
+    for (int a = 0; a < 3; ++a)
+        if (!std::isfinite(t[a])) throw HipError(SALVA_HIP_E_INVALID, "shape query: non-finite translation");
+    {
+        float qn = 0.0f;
+        for (int a = 0; a < 4; ++a) {
+            if (!std::isfinite(q[a])) throw HipError(SALVA_HIP_E_INVALID, "shape query: non-finite rotation");
+            qn += q[a] * q[a];
+        }
+        if (fabsf(qn - 1.0f) > 1.0e-3f) throw HipError(SALVA_HIP_E_INVALID, "shape query: the rotation must be a unit quaternion (x, y, z, w)");
+    }
+    for (int a = 0; a < (shape.kind == SALVA_HIP_SHAPE_BALL ? 1 : 3); ++a)
+        if (!(shape.params[a] > 0.0f) || !std::isfinite(shape.params[a]))
+            throw HipError(SALVA_HIP_E_INVALID, "shape query: radius / half extents must be positive and finite");
     ensure_staging_current();
     ShapeQuery s{};
     for (int a = 0; a < 3; ++a) { s.t[a] = t[a]; s.p[a] = shape.params[a]; }
@@ -1377,9 +1398,9 @@ uint64_t World::particles_in_shape(const float t[3], const float q[4], const Sal
         for (int a = 0; a < 3; ++a)
             ext[a] = fabsf(Rm[a][0]) * shape.params[0] + fabsf(Rm[a][1]) * shape.params[1] + fabsf(Rm[a][2]) * shape.params[2];
     }
-    for (int a = 0; a < 3; ++a) {
-        s.clo[a] = (int)floorf((t[a] - ext[a]) / sc.h);
-        s.chi[a] = (int)floorf((t[a] + ext[a]) / sc.h);
+    for (int a = 0; a < 3; ++a) {  // (clamped like the cell coordinates of the particles: tile.h cell_coord)
+        s.clo[a] = (int)std::min(std::max(floorf((t[a] - ext[a]) / sc.h), -1073741824.0f), 1073741824.0f);
+        s.chi[a] = (int)std::min(std::max(floorf((t[a] + ext[a]) / sc.h), -1073741824.0f), 1073741824.0f);
     }
     const uint32_t cap = (uint32_t)std::min<uint64_t>(capacity, 0xfffffff0ull);
     DevBuf<unsigned int> cnt;

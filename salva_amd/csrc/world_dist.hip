@@ -82,18 +82,26 @@ void World::rebalance(int32_t* new_lo, int32_t* new_hi) {
         while (p < len && run + hist[(size_t)p] <= want) run += hist[(size_t)p++];
         long long cpl = base + p;
         const long long old_prev = (r - 1 >= 1) ? lo[r - 1] : LLONG_MIN / 4, old_next = (r + 1 < size) ? lo[r + 1] : LLONG_MAX / 4;
-        cpl = std::max(cpl, old_prev);                                     // a particle changes owner by one rank at most
-        cpl = std::min(cpl, old_next);
+        // A particle changes owner by one rank at most — including the particles that crossed a face during the last step and
+        // have not migrated yet (they sit up to GHOST_PLANES planes inside the neighbour's old slab): a cut therefore stays
+        // GHOST_PLANES planes clear of the old cuts on either side (two adjacent slabs span >= 8 planes, so the range is never empty).
+        cpl = std::max(cpl, old_prev + (long long)GHOST_PLANES);
+        cpl = std::min(cpl, old_next - (long long)GHOST_PLANES);
         cpl = std::max(cpl, cut[r - 1] + 2 * (long long)GHOST_PLANES);     // slabs stay >= four planes thick
         cut[r] = cpl;
     }
     for (int r = size - 1; r >= 1; --r) cut[r] = std::min(cut[r], cut[r + 1] - 2 * (long long)GHOST_PLANES);
     for (int r = 1; r < size; ++r)
-        if (cut[r] < cut[r - 1] + 2 * (long long)GHOST_PLANES || cut[r] < ((r - 1 >= 1) ? lo[r - 1] : LLONG_MIN / 4))
+        if (cut[r] < cut[r - 1] + 2 * (long long)GHOST_PLANES || cut[r] < ((r - 1 >= 1) ? lo[r - 1] + (long long)GHOST_PLANES : LLONG_MIN / 4))
             throw HipError(SALVA_HIP_E_CAPACITY, "rebalance: the domain is too short for four cell planes per rank");
     if (comm->has_lo()) slab_lo = (int)cut[rank];
     if (comm->has_hi()) slab_hi = (int)cut[rank + 1] - 1;
     nbr_bounds_valid = false;
+    // The next step's arrivals are not "at most two planes beyond a face and inside the sender's previous y/z box" any more
+    // (dist_prepare's shortcut): migrants come from as deep inside a neighbour as its cut moved, and the planes a neighbour
+    // mirrors may hold particles it has just received from ITS far neighbour.  Every rank therefore announces "no box" in the
+    // next exchange and the step reduces the cell bounding box over the particles once (World::step).
+    bbox_known = false;
     if (new_lo) *new_lo = slab_lo;
     if (new_hi) *new_hi = slab_hi;
 }

@@ -419,3 +419,75 @@ def test_rebalance_recuts_the_slabs_and_keeps_the_physics(hip_lib):
         got_p[order[gid]] = p
     assert np.isfinite(got_p).all()
     assert np.abs(got_p - ref_p).max() < 2e-4 * H, f"positions differ by {np.abs(got_p - ref_p).max() / H:.2e} h"
+
+
+def test_rebalance_moves_cuts_by_whole_slabs_between_ranks_of_different_extent(hip_lib):
+    """a re-cut invalidates the shortcut by which dist_prepare derives the next cell bounding box (arrivals within
+    two planes of a face, inside the sender's previous y/z box).  Four ranks; ranks 0 and 1 start with thin slabs that hold a
+    LOW, WIDE part of the fluid, rank 3 with a thick slab under a tall column (larger y extent); the first re-cut moves two
+    adjacent cuts by more than a slab width, so rank 1 receives particles from deep inside rank 2 whose y range it has never
+    seen, and mirrors some of them to rank 0 in the same step.  Must neither raise (flags 2 / 4) nor lose particles, and
+    the states must keep following the undivided domain."""
+    pos, vel, bpos = make_scene(nx=56, ny=6, nz=10, seed=9)
+    # a tall column on top of the last third of the block
+    col = scenes.jitter(scenes.cube_fluid_positions(16, 10, 10, R), 0.1 * R, 10).astype(np.float32)
+    col[:, 0] += pos[:, 0].max() - col[:, 0].max()
+    col[:, 1] += pos[:, 1].max() - col[:, 1].min() + 2 * R
+    col[:, 2] += pos[:, 2].min() - col[:, 2].min()
+    pos = np.concatenate([pos, col])
+    vel = np.concatenate([vel, np.zeros_like(col)])
+    vel[:, 0] = 0.0  # (no drift: the owners change through the re-cut only)
+    nsteps, nranks = 8, 4
+    ref_p, ref_v, ref_stats = run_single(pos, vel, bpos, nsteps, False)
+    cx = dist.cell_x(pos, H)
+    lo, hi = int(cx.min()), int(cx.max())
+    slabs = [(lo, lo + 3), (lo + 4, lo + 7), (lo + 8, lo + 8 + (hi - lo - 8) // 2), (lo + 9 + (hi - lo - 8) // 2, hi)]
+    owner = dist.owner_of(cx, slabs)
+    first_counts = [int((owner == r).sum()) for r in range(nranks)]
+    comms = dist.Comm.loopback(nranks)
+    offsets = np.concatenate([[0], np.cumsum(first_counts)])
+    order = np.concatenate([np.nonzero(owner == r)[0] for r in range(nranks)])
+    results, errors, slabs_seen = [None] * nranks, [None] * nranks, [None] * nranks
+
+    def rank_main(r):
+        try:
+            w = LiquidWorld(solver(), R, SF)
+            mine = np.nonzero(owner == r)[0]
+            f = Fluid(pos[mine], R, 1000.0)
+            f.velocities = vel[mine]
+            f.nonpressure_forces.extend(FORCES["make"]())
+            w.add_fluid(f)
+            b = w.add_boundary(Boundary(bpos[dist.boundary_subset(bpos, H, slabs[r], r, nranks)]))
+            w.set_domain(comms[r], slabs[r][0], slabs[r][1], int(offsets[r]))
+            seen = [slabs[r]]
+            for k in range(nsteps):
+                w.step(DT, G)
+                if k in (0, 2, 4):
+                    my = w.rebalance()
+                    seen.append(my)
+                    w.remove_boundary(b)
+                    b = w.add_boundary(Boundary(bpos[dist.boundary_subset(bpos, H, my, r, nranks)]))
+            results[r] = w.owned()
+            slabs_seen[r] = seen
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    for e in errors:
+        if e is not None:
+            raise e
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    for c in comms:
+        c.destroy()
+    # the first re-cut moved the cut between ranks 1 and 2 by at least a whole (old) slab of rank 1
+    assert slabs_seen[2][1][0] - slabs_seen[2][0][0] >= 2, slabs_seen
+    assert sum(len(r[0]) for r in results) == len(pos)
+    got_p = np.full_like(pos, np.nan)
+    for gid, p, v, _slot in results:
+        got_p[order[gid]] = p
+    assert np.isfinite(got_p).all()
+    assert np.abs(got_p - ref_p).max() < 2e-4 * H, f"positions differ by {np.abs(got_p - ref_p).max() / H:.2e} h"

@@ -17,6 +17,7 @@ acc = defaultdict(lambda: [0, 0.0])
 for f in sorted(glob.glob(os.path.join(d, "pmc*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("salva::", "").replace("void ", "")
+        name = re.sub(r"<\d+u?>$", "", name)  # (layout / variant instantiations of one kernel are summed under its name)
         k = (name, r["Counter_Name"])
         acc[k][0] += 1
         acc[k][1] += float(r["Counter_Value"])
@@ -35,7 +36,11 @@ for name, t in traffic.items():
         rd = 2.0 * t["FETCH_SIZE"] * 1024.0
         wr = t["WRITE_SIZE"] * 1024.0
         res[name] = {"read_bytes": rd, "write_bytes": wr, "bytes": rd + wr}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from salva_amd import kernel_source_sha  # noqa: E402
+
 json.dump({"note": "per launch; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB (uncalibrated)",
+           "kernel_src_sha": kernel_source_sha(),  # bench.py refuses the figure when the kernel sources have changed since
            "kernels": res}, open(os.path.join(d, "hbm_traffic.json"), "w"), indent=1)
 for name, v in sorted(res.items()):
     print(f"{name:28s} read {v['read_bytes'] / 1e6:8.1f} MB  write {v['write_bytes'] / 1e6:7.1f} MB")
