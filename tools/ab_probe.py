@@ -10,15 +10,33 @@ can be checked for it, and builds whose arithmetic differs show how far apart th
 .npy via --ref / --save).
 """
 import argparse
+import faulthandler
 import hashlib
 import os
 import sys
 import time
 
+faulthandler.dump_traceback_later(int(os.environ.get("AB_PROBE_WATCHDOG", "100")), exit=True)  # a hang prints where, then exits
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
-import bench  # noqa: E402
+from salva_amd import (Akinci2013SurfaceTension, Boundary, DFSPHSolver, Fluid, IISPHSolver, LiquidWorld, XSPHViscosity,  # noqa: E402
+                       scenes)
+
+R, DT, GRAVITY = 0.025, 1.0 / 200.0, (0.0, -9.81, 0.0)
+
+
+def build_world(config, side):
+    """bench.py's scenes for configs 2 and 3 (without importing bench: that pulls in torch, a minute on a fresh box)."""
+    fluid, shell = scenes.tank(side, side, side, R)
+    fluid = scenes.jitter(fluid, 0.1 * R, seed=42)
+    w = LiquidWorld(IISPHSolver() if config == 3 else DFSPHSolver(), R, 2.0)
+    f = Fluid(fluid, R, 1000.0)
+    f.nonpressure_forces.append(Akinci2013SurfaceTension(1.0, 10.0) if config == 3 else XSPHViscosity(0.5, 0.0))
+    h = w.add_fluid(f)
+    w.add_boundary(Boundary(shell))
+    return w, [h]
 
 
 def main():
@@ -31,18 +49,21 @@ def main():
     ap.add_argument("--save", default="")
     ap.add_argument("--ref", default="")
     a = ap.parse_args()
-    fluids, shell = bench.build_config(a.config, a.side)
-    w, handles = bench.make_config_world(a.config, fluids, shell, 0)
+    assert a.config in (2, 3)
+    w, handles = build_world(a.config, a.side)
     iters = []
     ms = []
+    print("AB-progress world built", flush=True)
     for _ in range(a.steps):
         t0 = time.perf_counter()
-        st = w.step(bench.DT, bench.GRAVITY)
+        st = w.step(DT, GRAVITY)
         ms.append((time.perf_counter() - t0) * 1e3)
         iters.append((int(st.n_divergence_iters), int(st.n_pressure_iters)))
     kernels = [int(k) for k in a.kernels.split(",")] if a.kernels else ([2, 3, 4] if a.config == 3 else [0, 1, 4])
+    print("AB-progress stepped", iters[-1], flush=True)
     us = {}
     for k in kernels:
+        print("AB-progress timing kernel", k, flush=True)
         try:
             us[k] = w.time_kernel(k, a.reps)
         except Exception as e:  # noqa: BLE001
@@ -54,7 +75,7 @@ def main():
         np.save(a.save, pos)
     if a.ref and os.path.exists(a.ref):
         ref = np.load(a.ref)
-        extra = " max|dx|/r vs ref = %.3e" % (float(np.abs(pos - ref).max()) / bench.R)
+        extra = " max|dx|/r vs ref = %.3e" % (float(np.abs(pos - ref).max()) / R)
     tag = os.environ.get("SALVA_HIP_LIB_VARIANT", "product")
     print("AB lib=%s config=%d side=%d steps=%d | kernel us %s | step ms first5 %.3f last5 %.3f | iters last %s | halo %d bhalo %d threads %d | sha %s%s" % (
         tag, a.config, a.side, a.steps, " ".join("%d:%s" % (k, ("%.2f" % v) if isinstance(v, float) else v) for k, v in us.items()),
