@@ -51,7 +51,23 @@ __device__ __forceinline__ float pair_sum_velocity_divergence(const StepCtx& c, 
                                                               const float4& pi, const float4& wi, uint32_t dist) {
     f2 acc2 = {0.0f, 0.0f};
     const f2 tiny = {1.0e-30f, 1.0e-30f};
-    for_each_ff2<true, false, true>(c, gs, nqu, lh, [&](uint32_t o) { return load_pw(o, dist); }, [&](const RecPW& A, const RecPW& B) { SALVA_PAIR_MATH
+#ifdef SALVA_EXP  // kernel-time decomposition experiments (tools/gpu_r03c.sh; never defined in the product build)
+#if SALVA_EXP == 1   // no pair loop at all: what the per-tile phases cost
+    return pi.x * 0.0f;
+#elif SALVA_EXP == 2  // the LDS reads of the loop with (almost) no arithmetic
+    for_each_ff2<true, false, true>(c, gs, nqu, lh, [&](uint32_t o) { return load_pw(o, dist); }, [&](const RecPW& A, const RecPW& B) {
+        acc2 += f2{A.p.x + A.w.y, B.p.z + B.w.x};
+    });
+    return acc2.x + acc2.y;
+#endif
+#endif
+    for_each_ff2<true, false, true>(c, gs, nqu, lh, [&](uint32_t o) {
+#if defined(SALVA_EXP) && SALVA_EXP == 3  // the arithmetic of the loop with every lane reading slot 0 (no bank conflicts, reads hoistable)
+        return load_pw(o & 0u, dist);
+#else
+        return load_pw(o, dist);
+#endif
+    }, [&](const RecPW& A, const RecPW& B) { SALVA_PAIR_MATH
         const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
         f2 r2 = dz * dz + tiny;
         r2 = dy * dy + r2;

@@ -46,9 +46,17 @@ def main():
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--kernels", default="")
+    ap.add_argument("--sched", default="", help="comma list of SALVA_HIP_SCHED values: one world per value, same process")
     ap.add_argument("--save", default="")
     ap.add_argument("--ref", default="")
     a = ap.parse_args()
+    for sched in (a.sched.split(",") if a.sched else [None]):
+        if sched is not None:
+            os.environ["SALVA_HIP_SCHED"] = sched
+        run_one(a, sched)
+
+
+def run_one(a, sched):
     assert a.config in (2, 3)
     w, handles = build_world(a.config, a.side)
     iters = []
@@ -71,12 +79,12 @@ def main():
     pos = np.concatenate([np.asarray(h.positions, dtype=np.float32) for h in handles])
     hsh = hashlib.sha1(pos.tobytes() + repr(iters).encode()).hexdigest()[:12]
     extra = ""
-    if a.save:
-        np.save(a.save, pos)
     if a.ref and os.path.exists(a.ref):
         ref = np.load(a.ref)
         extra = " max|dx|/r vs ref = %.3e" % (float(np.abs(pos - ref).max()) / R)
-    tag = os.environ.get("SALVA_HIP_LIB_VARIANT", "product")
+    if a.save and not os.path.exists(a.save):  # (the first world of the first process is the reference)
+        np.save(a.save, pos)
+    tag = os.environ.get("SALVA_HIP_LIB_VARIANT", "product") + ("" if sched is None else "/sched=" + sched)
     print("AB lib=%s config=%d side=%d steps=%d | kernel us %s | step ms first5 %.3f last5 %.3f | iters last %s | halo %d bhalo %d threads %d | sha %s%s" % (
         tag, a.config, a.side, a.steps, " ".join("%d:%s" % (k, ("%.2f" % v) if isinstance(v, float) else v) for k, v in us.items()),
         float(np.mean(ms[1:6])), float(np.mean(ms[-5:])), iters[-3:], int(st.reserved[0]), int(st.reserved[1]), int(st.reserved[2]), hsh, extra), flush=True)
