@@ -2,7 +2,8 @@
 //
 // Same arithmetic, in the same order, as the one-tile-per-workgroup kernels of dfsph.hip (behaviour specified by
 // /root/reference/src/solver/pressure/dfsph_solver.rs, lines cited there): results are bit-identical between the two
-// skeletons, which is what tests/test_pipeline_gpu.py checks.
+// skeletons (salva_hip_time_variant returns a checksum of the outputs; tools/variant_probe.py compares them).
+// Kernel-development build only (`make VARIANT=diag`): rejected as a production skeleton in round 2.
 #include "kernels.h"
 #include "pipe.h"
 
