@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <type_traits>
 #include <stdexcept>
 #include <string>
 
@@ -80,29 +81,38 @@ __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nblocks, int 
     return base + rank;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-wide reductions by DPP: four row-local steps (quad swaps, half-row mirror, row mirror — after them every lane of a
+// 16-lane row holds the row's result), then the four rows through v_readlane.  `__shfl_xor` compiles to ds_bpermute_b32 — a
+// round trip through the LDS crossbar per step, six dependent ones per reduction, ~36 in k_pred_density: ~1.5 k cycles of the
+// ~3 k a tile spends outside its pair loop after the staging barrier (profiles/r03_experiments).  Fixed order: deterministic.
+// Every lane must call; every lane gets the result.
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce_dpp(T v, Op op) {
+    static_assert(sizeof(T) == 4, "32-bit values");
+    auto dpp = [](T x, auto ctrl) {
+        int i;
+        __builtin_memcpy(&i, &x, 4);
+        i = __builtin_amdgcn_update_dpp(i, i, decltype(ctrl)::value, 0xf, 0xf, false);
+        T r;
+        __builtin_memcpy(&r, &i, 4);
+        return r;
+    };
+    v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));   // quad_perm [1,0,3,2]
+    v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));   // quad_perm [2,3,0,1]
+    v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));  // row_half_mirror
+    v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));  // row_mirror
+    int i;
+    __builtin_memcpy(&i, &v, 4);
+    const int i0 = __builtin_amdgcn_readlane(i, 0), i1 = __builtin_amdgcn_readlane(i, 16), i2 = __builtin_amdgcn_readlane(i, 32),
+              i3 = __builtin_amdgcn_readlane(i, 48);
+    T r0, r1, r2, r3;
+    __builtin_memcpy(&r0, &i0, 4); __builtin_memcpy(&r1, &i1, 4); __builtin_memcpy(&r2, &i2, 4); __builtin_memcpy(&r3, &i3, 4);
+    return op(op(r0, r1), op(r2, r3));
 }
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned t = (unsigned)__shfl_xor((int)v, o, 64);
-        v = v > t ? v : t;
-    }
-    return v;
-}
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = v < t ? v : t; }
-    return v;
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = v > t ? v : t; }
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce_dpp(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return wave_reduce_dpp(v, [](unsigned a, unsigned b) { return a > b ? a : b; }); }
+__device__ __forceinline__ int wave_min_i32(int v) { return wave_reduce_dpp(v, [](int a, int b) { return a < b ? a : b; }); }
+__device__ __forceinline__ int wave_max_i32(int v) { return wave_reduce_dpp(v, [](int a, int b) { return a > b ? a : b; }); }
 
 // Deterministic block sum (fixed tree): every thread must call; result valid in thread 0.
 __device__ __forceinline__ float block_sum(float v, float* lds /* >= BLOCK/WAVE floats */) {

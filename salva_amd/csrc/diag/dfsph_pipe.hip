@@ -6,15 +6,9 @@
 // Kernel-development build only (`make VARIANT=diag`): rejected as a production skeleton in round 2.
 #include "kernels.h"
 #include "pipe.h"
+#include "../pairs.h"
 
 namespace salva {
-
-struct RecPW { float4 p, w; };        // position+mass, v+dv
-struct RecPK { float4 p; float k; };  // position+mass, kappa
-
-__device__ __forceinline__ float rho0_of(const StepCtx& c, uint32_t model) {
-    return (c.nmodels == 1) ? c.rho0_single : c.rho0_tab[model];
-}
 
 // ------------------------------------------------------------------------------------------------
 // compute_predicted_densities (dfsph_solver.rs:98-162), cf. k_pred_density in dfsph.hip
@@ -47,6 +41,11 @@ void k_pred_density_pipe(StepCtx c, float dt, uint32_t scap, uint32_t sbcap) {
                 const float rho0 = rho0_of(c, t, mi);
                 const float4 pi = o.pi, wi = o.wi;
                 float delta = 0.0f;
+                // round 3: the pair loop of the product kernel (pairs.h); the single-buffer pipeline stages P at LDS byte 0 and W
+                // scap slots behind it (the double-buffered one alternates: runtime base, kept on the round-2 loop)
+                if constexpr (!DOUBLE) {
+                    delta += pair_sum_velocity_divergence<false>(c, gs, nqu, o.lh, pi, wi, scap * 16u);
+                } else {
                 f2 acc2 = {0.0f, 0.0f};
                 for_each_ff2<false>(c, gs, nqu, o.lh, [&](uint32_t s) { return RecPW{Lp[s], Lw[s]}; }, [&](const RecPW& A, const RecPW& B) {
                     asm volatile("" ::"v"(A.w.w), "v"(B.w.w));  // keep the reads single ds_read_b128s
@@ -57,6 +56,7 @@ void k_pred_density_pipe(StepCtx c, float dt, uint32_t scap, uint32_t sbcap) {
                     acc2 += (ux * dx + uy * dy + uz * dz) * g * mj;
                 });
                 delta += acc2.x + acc2.y;
+                }
                 auto fb = [&](uint32_t s) {
                     const float4 pj = t.Bp[s];
                     const float4 vj = t.Bv[s];

@@ -1,4 +1,7 @@
-// sched.hip — bank-conflict-aware ordering of the neighbour lists.
+// sched.hip — bank-conflict-aware ordering of the neighbour lists.  KERNEL-DEVELOPMENT BUILD ONLY (`make VARIANT=diag`,
+// SALVA_HIP_SCHED=1): correct (the GPU parity, fuzz and decomposition suites pass with it on) and it does what the model says — but
+// the pair loops are only ~40 % of a neighbour kernel (the rest are per-tile phases), so a pass gains 6 % while this
+// kernel, latency-bound in its LDS hand-shakes, costs ~600 us per step at 10^6 particles (profiles/r03_experiments/r03c_ab_sched.log).
 //
 // Why.  The pair loops of the neighbour-sum kernels are bound by the CU's LDS pipe, not by VALU issue (round 3: cutting the
 // loop of k_pred_density from 24 to 16 VALU per contact moved the kernel from 55.9 to 52.6 us; the per-tile phase stamps show
@@ -23,8 +26,8 @@
 // more than 15 entries in one quad, keep their build order.
 //
 // One wave per 64-particle slice, launched per tile like every tile kernel; no staging.
-#include "kernels.h"
-#include "tile.h"
+#include "../kernels.h"
+#include "../tile.h"
 
 namespace salva {
 

@@ -55,8 +55,6 @@ size_t tile_list_stats_bytes(uint32_t ntiles);
 // own2 (may be null) = the same totals over the particles this rank owns (no ghosts)
 void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsigned long long* totals2, uint32_t* maxima2,
                       unsigned long long* own2, hipStream_t s);
-// sched.hip: permute every list's real entries so that the ds_read_b128 lane groups hit distinct LDS bank quads (or one slot)
-void launch_list_schedule(const StepCtx& c, const TileLds& L, hipStream_t s);
 size_t select_flagged_temp_bytes(uint32_t n);
 void select_flagged_f4(void* temp, size_t temp_bytes, const float4* in, const uint8_t* flags, float4* out, uint32_t* num_selected,
                        uint32_t n, hipStream_t s);
@@ -92,6 +90,9 @@ void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmode
 void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, SolveCtl* pub, hipStream_t s);
 
 #ifdef SALVA_HIP_DIAG
+// diag/sched.hip: permute every list's real entries so that the ds_read_b128 lane groups hit distinct LDS bank quads (or one
+// slot).  Measured (profiles/r03_experiments): -6 % per neighbour pass for ~600 us per step — never pays; kept as an experiment.
+void launch_list_schedule(const StepCtx& c, const TileLds& L, hipStream_t s);
 // ---------------------------------------------------------------- diag/dfsph_pipe.hip (kernel experiments, `make VARIANT=diag`: persistent tile pipeline, pipe.h)
 void launch_pred_density_pipe(const StepCtx& c, const PipeCfg& P, float dt, hipStream_t s);
 // diagnostics: variant 0 = one tile per workgroup, 1 = + de-phased co-resident tiles (param = sleep in 64-cycle units),

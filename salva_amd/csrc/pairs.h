@@ -1,0 +1,121 @@
+// pairs.h — the pair loops of the DFSPH solver kernels (dfsph.hip; shared with the kernel-development skeletons in diag/).
+#pragma once
+#include "tile.h"
+
+namespace salva {
+
+// staged neighbour records (LDS -> registers)
+struct RecPW { float4 p, w; };   // position+mass, v+dv
+struct RecPK { float4 p; float k; };  // position+mass, kappa
+
+__device__ __forceinline__ float rho0_of(const StepCtx& c, uint32_t model) {
+    return (c.nmodels == 1) ? c.rho0_single : c.rho0_tab[model];
+}
+
+// ------------------------------------------------------------------------------------------------
+// The pair loops of the four solver kernels below (the kernels the step lives in).
+//
+// LDS layout (tile.h, stage_pw / stage_pk): the first staged array starts at LDS byte 0 and the second at a distance that is
+// a compile-time constant in the DS != 0 instantiations, so a contact costs ONE address instruction (`v_lshlrev_b32_sdwa`:
+// 16-bit list entry -> byte offset) for both of its ds_reads; the boundary halo rides in the tails of the same arrays.
+// Arithmetic: kernel_gfac2 (sph_math.h) — 16.5 VALU per contact against 24 for the round-2 loop (ISA accounting in
+// profiles/r03_isa/).  Exactness: the fast form does not reproduce the reference's `q <= 1e-5 -> 0` rule; k_density_alpha
+// flags the slices that hold such a pair (c.slice_near) and those slices walk their lists with kernel_grad instead.
+// ------------------------------------------------------------------------------------------------
+template <uint32_t DS>
+__device__ __forceinline__ uint32_t pw_dist(const StepCtx& c, const Tile& t) { return DS ? DS * 16u : (t.stage_cap(c) + t.SB) * 16u; }
+template <uint32_t DS>
+__device__ __forceinline__ uint32_t pk_dist(const StepCtx& c, const Tile& t) { return DS ? DS * 16u : (t.stage_cap(c) + 2u * t.SB) * 16u; }
+
+// `o` = byte offset of the slot in a 16-byte-strided array (tile.h, entry_off16_*)
+__device__ __forceinline__ RecPW load_pw(uint32_t o, uint32_t dist) {
+    RecPW r{lds_ld16(o), lds_ld16(o + dist)};
+    asm volatile("" ::"v"(r.w.w));  // keep the read a single ds_read_b128 (a b96 costs 8 LDS cycles, a b128 4)
+    return r;
+}
+__device__ __forceinline__ RecPK load_pk(uint32_t o, uint32_t dist) { return RecPK{lds_ld16(o), lds_ld4((o >> 2) + dist)}; }
+
+// sum_j m_j (w_i - w_j) . grad W_ij over the padded list of a slice without near-coincident pairs
+// (AHEAD: tile.h for_each_ff2 — false inside the persistent skeletons, where a load pending at the end of the list tail would
+// make the compiler drain the next tile's prefetch)
+template <bool AHEAD = true>
+__device__ __forceinline__ float pair_sum_velocity_divergence(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh,
+                                                              const float4& pi, const float4& wi, uint32_t dist) {
+    f2 acc2 = {0.0f, 0.0f};
+    const f2 tiny = {1.0e-30f, 1.0e-30f};
+#ifdef SALVA_EXP  // kernel-time decomposition experiments (tools/gpu_r03c.sh; never defined in the product build)
+#if SALVA_EXP == 1   // no pair loop at all: what the per-tile phases cost
+    return pi.x * 0.0f;
+#elif SALVA_EXP == 2  // the LDS reads of the loop with (almost) no arithmetic
+    for_each_ff2<AHEAD, false, true>(c, gs, nqu, lh, [&](uint32_t o) { return load_pw(o, dist); }, [&](const RecPW& A, const RecPW& B) {
+        acc2 += f2{A.p.x + A.w.y, B.p.z + B.w.x};
+    });
+    return acc2.x + acc2.y;
+#endif
+#endif
+    for_each_ff2<AHEAD, false, true>(c, gs, nqu, lh, [&](uint32_t o) {
+#if defined(SALVA_EXP) && SALVA_EXP == 3  // the arithmetic of the loop with every lane reading slot 0 (no bank conflicts, reads hoistable)
+        return load_pw(o & 0u, dist);
+#else
+        return load_pw(o, dist);
+#endif
+    }, [&](const RecPW& A, const RecPW& B) { SALVA_PAIR_MATH
+        const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
+        f2 r2 = dz * dz + tiny;
+        r2 = dy * dy + r2;
+        r2 = dx * dx + r2;
+        const f2 g = kernel_gfac2(r2, c.sc);
+        const f2 ux = {wi.x - A.w.x, wi.x - B.w.x}, uy = {wi.y - A.w.y, wi.y - B.w.y}, uz = {wi.z - A.w.z, wi.z - B.w.z};
+        const f2 gm = {g.x * A.p.w, g.y * B.p.w};
+        acc2 += (ux * dx + uy * dy + uz * dz) * gm;
+    });
+    return (acc2.x + acc2.y) * c.sc.gscale;
+}
+// the same sum with the reference's q <= 1e-5 rule (kernel_grad), over the exact list: slices flagged by k_density_alpha
+__device__ __forceinline__ float pair_sum_velocity_divergence_exact(const StepCtx& c, uint32_t i, uint32_t gs, const float4& pi,
+                                                                    const float4& wi, uint32_t dist) {
+    float acc = 0.0f;
+    for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+        const RecPW A = load_pw(s << 4, dist);
+        const float dx = pi.x - A.p.x, dy = pi.y - A.p.y, dz = pi.z - A.p.z;
+        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+        acc += ((wi.x - A.w.x) * dx + (wi.y - A.w.y) * dy + (wi.z - A.w.z) * dz) * g * A.p.w;
+    });
+    return acc;
+}
+// sum_j grad W_ij m_j k_ij with k_ij = f(k_j) supplied by `kij2` (two contacts at once) / `kij1`
+template <typename K2>
+__device__ __forceinline__ void pair_sum_gradient(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh, const float4& pi,
+                                                  uint32_t dist, K2&& kij2, float& sx, float& sy, float& sz) {
+    f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
+    const f2 tiny = {1.0e-30f, 1.0e-30f};
+    for_each_ff2<true, false, true>(c, gs, nqu, lh, [&](uint32_t o) { return load_pk(o, dist); }, [&](const RecPK& A, const RecPK& B) { SALVA_PAIR_MATH
+        const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
+        f2 r2 = dz * dz + tiny;
+        r2 = dy * dy + r2;
+        r2 = dx * dx + r2;
+        const f2 g = kernel_gfac2(r2, c.sc);
+        const f2 km = kij2(A.k, B.k) * f2{A.p.w, B.p.w};
+        const f2 coeff = km * g;
+        ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
+    });
+    sx = (ax.x + ax.y) * c.sc.gscale; sy = (ay.x + ay.y) * c.sc.gscale; sz = (az.x + az.y) * c.sc.gscale;
+}
+template <typename K1>
+__device__ __forceinline__ void pair_sum_gradient_exact(const StepCtx& c, uint32_t i, uint32_t gs, const float4& pi, uint32_t dist,
+                                                        K1&& kij1, float& sx, float& sy, float& sz) {
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+        const RecPK A = load_pk(s << 4, dist);
+        const float dx = pi.x - A.p.x, dy = pi.y - A.p.y, dz = pi.z - A.p.z;
+        const float coeff = kij1(A.k) * A.p.w * kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+        ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
+    });
+    sx = ax; sy = ay; sz = az;
+}
+__device__ __forceinline__ bool slice_is_near(uint32_t near_word) { return __builtin_amdgcn_readfirstlane((int)near_word) != 0; }
+__device__ __forceinline__ float (*carve_errtab(Tile& t))[MAX_MODELS] {
+    return reinterpret_cast<float (*)[MAX_MODELS]>(t.carve<float>(TILE_MAX_WAVES * MAX_MODELS));
+}
+
+}  // namespace salva

@@ -168,10 +168,7 @@ class World {
     DevBuf<uint4> slot_desc, slot_info;
     DevBuf<uint32_t> d_maxhalo, halo_src, bhalo_src, tile_ids, tile_flags, tile_rank;
     uint32_t nlaunch = 0;  // non-empty tiles of the current step = grid size of the solver kernels
-    // list scheduling (sched.hip): -1 auto (when the previous step's solves took >= sched_min_iters iterations in total), 0 off, 1 on
-    int sched_mode = -1;
-    uint32_t sched_min_iters = 6;
-    bool schedule_lists(uint32_t prev_iters) const { return sched_mode > 0 || (sched_mode < 0 && prev_iters >= sched_min_iters); }
+    int sched_mode = 0;  // kernel-development builds: 1 = run diag/sched.hip after the list build (SALVA_HIP_SCHED)
     uint32_t last_iters[NUM_SOLVES] = {1u, 1u, 1u};  // iterations of the previous step's divergence / pressure solve (batch sizing)
     uint32_t halo_stride = 0, bhalo_stride = 0;  // fixed row stride of the slot tables (0 = compact)
     DevBuf<char> tile_list_stats;

@@ -127,7 +127,9 @@ World::World(const SalvaHipParams& p) : prm(p) {
     spec_off = getenv("SALVA_HIP_SPECULATE") == nullptr || getenv("SALVA_HIP_NO_SPECULATION") != nullptr;
     spec_tight = getenv("SALVA_HIP_SPEC_TIGHT") != nullptr;
     defer_off = getenv("SALVA_HIP_NO_DEFER_LISTS") != nullptr;
-    if (const char* e = getenv("SALVA_HIP_SCHED")) sched_mode = atoi(e);  // (A/B: 0 never, 1 always; default: when the solves iterate)
+#ifdef SALVA_HIP_DIAG
+    if (const char* e = getenv("SALVA_HIP_SCHED")) sched_mode = atoi(e);
+#endif
     if (const char* e = getenv("SALVA_HIP_LIST_CAP0")) cap_ff = std::max<uint32_t>(LIST_REGS, ((uint32_t)atoi(e) + 3u) & ~3u);  // (tests: force an overflow)
     {
         int cus = 0;
@@ -1174,9 +1176,10 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             if (need_ff > cap_ff) cap_ff = (need_ff + need_ff / 4 + 4u) & ~3u;
             if (need_fb > cap_fb) cap_fb = (need_fb + need_fb / 4 + 4u) & ~3u;
         }
-        // Bank-conflict-aware list order (sched.hip): one extra pass over the lists that makes every later neighbour pass
-        // ~20 % faster — worth it once the solves iterate (the previous step's iteration counts decide; run-to-run deterministic).
-        if (schedule_lists(last_iters[0] + last_iters[1] + last_iters[2])) launch_list_schedule(c, lds, stream);
+#ifdef SALVA_HIP_DIAG
+        // kernel-development builds: bank-conflict-aware list order (diag/sched.hip), SALVA_HIP_SCHED=1
+        if (sched_mode > 0) launch_list_schedule(c, lds, stream);
+#endif
     }
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
 
@@ -1942,7 +1945,9 @@ float World::time_kernel(int kernel, int reps) {
                 cd.stale_keys = keys[1].p;
                 launch_nbr_build(cd, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff, nullptr, stream);
                 break;
+#ifdef SALVA_HIP_DIAG
             case 5: launch_list_schedule(cd, lds, stream); break;  // re-schedules the (already scheduled or not) lists: same work
+#endif
             default: throw HipError(SALVA_HIP_E_INVALID, "unknown kernel id");
         }
     };
