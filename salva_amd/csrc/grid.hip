@@ -89,7 +89,11 @@ template <int BITS>
 using SortConfigBits = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, OnesweepBits<BITS>, 65536>;
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
 static int sort_digit_bits(int end_bit) {
+#ifdef SALVA_HIP_DIAG
     static const bool off = getenv("SALVA_HIP_SORT_DEFAULT_DIGITS") != nullptr;  // (A/B: rocPRIM's own 8-bit configuration)
+#else
+    constexpr bool off = false;
+#endif
     // (measured: 18 bits in 2 x 9 instead of 3 passes saves 49 us per step at 10^6 particles; 21 bits in 2 x 11 is no faster than
     // rocPRIM's 3 x 8 at 8 x 10^6, the 2048-bucket passes cost what they save: keep its configuration from 21 bits on)
     if (off || end_bit <= 8 || end_bit > 20) return 8;
@@ -435,17 +439,14 @@ void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, 
 // (the sums are counters.cd.ncontacts; the maxima tell the host whether the fixed ELL capacity was enough).
 struct TileListStats { uint32_t sum_ff, sum_fb, max_ff, max_fb, own_ff, own_fb; };  // own_*: lists of particles this rank OWNS (no ghosts)
 
-// V = 0: one candidate per iteration, nested branches on every accepted candidate (the round-1 kernel; kept for comparison,
-//        SALVA_HIP_NBR_VARIANT=0).
+// V = 0: one candidate per iteration, nested branches on every accepted candidate (the round-1 kernel; kept as the fallback for
+//        worlds with more than 32 fluid or boundary models).
 // V = 1: four candidates in flight per lane (independent LDS reads and distance chains) and a branch-light append: with 64
 //        lanes accepting candidates on different iterations the accept path runs on almost every iteration, and in V = 0 it
 //        is a ladder of ~5 scalar branches per candidate; here it is selects plus one predicated store.
 // Both write the same lists in the same order.  (Parking the completed dwords in a per-wave LDS buffer and writing them out
 // with 16-byte stores was tried too: the 6 KiB per wave halve the resident waves and the kernel time doubles — the loop is
 // bound by per-wave latency, not by the stores)
-#ifndef SALVA_NBR_DEFAULT_VARIANT
-#define SALVA_NBR_DEFAULT_VARIANT 1
-#endif
 template <int V>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileListStats* __restrict__ tile_stats) {
     __shared__ uint32_t red[6][TILE_MAX_WAVES];
@@ -500,23 +501,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
         auto ff_allowed = [&](uint32_t s) -> bool {
             return V != 0 ? ((ffmask >> Lm[s]) & 1u) != 0u : c.ff_ok[mi * c.nmodels + Lm[s]] != 0;
         };
-        // V = 2: completed list dwords are parked in a four-register window and leave as ONE 16-byte store per eight contacts
-        // (dwords 4g .. 4g+3 of a lane are adjacent in the ELL block, tile.h ellq): a quarter of the VMEM instructions of the
-        // dword-at-a-time append and no address arithmetic per dword.  Same lists, bit for bit.
-        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-        uint4* __restrict__ out4 = reinterpret_cast<uint4*>(c.nbr_ff + (size_t)gs * c.cap_ff * WAVE) + lane;
         auto append = [&](uint32_t s) {
-            if (V == 2) {
-                if (cnt & 1u) {
-                    w0 = w1; w1 = w2; w2 = w3; w3 = pend | (s << 16);
-                    if ((cnt & 7u) == 7u && (cnt >> 1) < c.cap_ff) out4[(size_t)(cnt >> 3) * WAVE] = make_uint4(w0, w1, w2, w3);
-                } else {
-                    pend = s;
-                }
-            } else {
-                if (cnt & 1u) { if ((cnt >> 1) < c.cap_ff) out[ellq(cnt >> 1)] = pend | (s << 16); }
-                else pend = s;
-            }
+            if (cnt & 1u) { if ((cnt >> 1) < c.cap_ff) out[ellq(cnt >> 1)] = pend | (s << 16); }
+            else pend = s;
             ++cnt;
         };
 #pragma unroll 1
@@ -578,16 +565,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
         // an odd list is padded with the particle's own slot (for_each_ff2: the self contact adds nothing to gradient sums)
         const int hself = (lx * HY + ly) * HZ + lz;
         self_slot = tc.lstart[hself] + (i - tc.gstart[hself]);
-        if (V == 2) {
-            // flush: the odd tail (padded with the self slot) completes its dword, then the 1-3 dwords of the unfinished group
-            // leave one by one (the finished groups have been stored as they filled up)
-            if (cnt & 1u) { w0 = w1; w1 = w2; w2 = w3; w3 = pend | (self_slot << 16); }
-            const uint32_t nd = (cnt + 1u) >> 1, r = nd & 3u, q0 = nd & ~3u;
-            if ((cnt & 1u) && r == 0u && q0 - 4u < c.cap_ff) out4[(size_t)((q0 - 4u) >> 2) * WAVE] = make_uint4(w0, w1, w2, w3);  // the padded dword closed a group
-            if (r >= 1u && q0 < c.cap_ff) out[ellq(q0)] = (r == 1u) ? w3 : (r == 2u) ? w2 : w1;
-            if (r >= 2u && q0 + 1u < c.cap_ff) out[ellq(q0 + 1u)] = (r == 2u) ? w3 : w2;
-            if (r == 3u && q0 + 2u < c.cap_ff) out[ellq(q0 + 2u)] = w3;
-        } else if ((cnt & 1u) && (cnt >> 1) < c.cap_ff) out[ellq(cnt >> 1)] = pend | (self_slot << 16);
+        if ((cnt & 1u) && (cnt >> 1) < c.cap_ff) out[ellq(cnt >> 1)] = pend | (self_slot << 16);
         if ((cntb & 1u) && (cntb >> 1) < c.cap_fb) outb[ellq(cntb >> 1)] = pendb;
         // (a list longer than the capacity was cut: the consumers must not walk past the rows that exist; the statistics below
         // keep the true lengths, from which the host sees the overflow, grows the capacity and repeats the pass)
@@ -661,12 +639,9 @@ size_t tile_list_stats_bytes(uint32_t ntiles) { return (size_t)ntiles * sizeof(T
 void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsigned long long* totals2, uint32_t* maxima2,
                       unsigned long long* own2, hipStream_t s) {
     if (c.n == 0) return;
-    static const int variant = [] { const char* e = getenv("SALVA_HIP_NBR_VARIANT"); return e ? atoi(e) : SALVA_NBR_DEFAULT_VARIANT; }();
     TileListStats* ts = static_cast<TileListStats*>(tile_stats);
-    if (variant == 0 || c.nmodels > 32u || c.nbmodels > 32u) {
+    if (c.nmodels > 32u || c.nbmodels > 32u) {  // (the bit-mask group tests of V = 1 hold 32 models)
         SALVA_LAUNCH_TILE(k_nbr_tile<0>, c, L, L.bytes(20, 32, 4, true) + 64u, s, c, ts);
-    } else if (variant == 2) {
-        SALVA_LAUNCH_TILE(k_nbr_tile<2>, c, L, L.bytes(20, 32, 4, true) + 64u, s, c, ts);
     } else {
         SALVA_LAUNCH_TILE(k_nbr_tile<1>, c, L, L.bytes(20, 32, 4, true) + 64u, s, c, ts);
     }

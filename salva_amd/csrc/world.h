@@ -108,6 +108,7 @@ class World {
 
   private:
     void use_device() const;
+    struct QuerySrc query_fluid_source();
     uint64_t collect_query(unsigned int* d_count, uint32_t* d_kind, uint32_t* d_index, uint32_t cap, uint32_t* kinds, uint32_t* slots,
                            uint32_t* indices);
     uint64_t fluid_offset(uint32_t slot) const;

@@ -1115,7 +1115,9 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             const uint32_t lo = (HCELLS + WAVE - 1) / WAVE, hi = std::min<uint32_t>(std::max<uint32_t>(tt.max_nsl, lo), (uint32_t)TILE_MAX_WAVES);
             lds.threads = WAVE * std::min<uint32_t>(std::max<uint32_t>((avg + WAVE - 1) / WAVE, lo), hi);
         }
+#ifdef SALVA_HIP_DIAG
         if (const char* e = getenv("SALVA_HIP_TILE_THREADS")) lds.threads = (uint32_t)atoi(e);
+#endif
         if (lds.max_halo_fluid >= 65536u || lds.max_halo_boundary >= 65536u)
             throw HipError(SALVA_HIP_E_CAPACITY, "more than 65535 particles in one tile halo");
         if (tt.nsl > ns_cap) throw HipError(SALVA_HIP_E_HIP, "internal error: slice count exceeds its bound");
@@ -1278,18 +1280,42 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
 // LiquidWorld::particles_intersecting_aabb (liquid_world.rs:210-243): particles whose distance to the box is below the
 // particle radius.  The reference walks the cells of its (last step's) grid; here every particle's current position is
 // tested, which finds the same particles plus those that entered the box's cells since the grid was built.
-__global__ __launch_bounds__(BLOCK) void k_aabb_query(const float4* __restrict__ pos, uint32_t n, float3 lo, float3 hi, float r2,
+// Where a query finds its fluid particles.  Single domain: the staging arrays (host order; index = position in the concatenation of
+// the fluids).  Decomposed run: the rank's working set after its last step — ghosts are skipped (their owner reports them), the
+// index is the particle's GLOBAL id and the fluid slot rides in bits 8.. of the kind word.
+struct QuerySrc {
+    const float4* pos; uint32_t n;
+    const uint32_t* gtag;   // nullptr: no ghosts in `pos`
+    const uint32_t* gid;    // nullptr: index = i
+    const uint32_t* model;  // nullptr: the slot follows from the index (collect_query)
+};
+__device__ __forceinline__ bool query_skip(const QuerySrc& q, uint32_t i) { return q.gtag && (q.gtag[i] & 0x80000000u); }
+__device__ __forceinline__ void query_emit(const QuerySrc& q, uint32_t i, uint32_t kind, unsigned int* counter, uint32_t cap, uint32_t* out_kind,
+                                           uint32_t* out_index) {
+    const uint32_t k = atomicAdd(counter, 1u);
+    if (k < cap) { out_kind[k] = kind | (q.model ? q.model[i] << 8 : 0u); out_index[k] = q.gid ? q.gid[i] : i; }
+}
+__global__ __launch_bounds__(BLOCK) void k_aabb_query(QuerySrc q, float3 lo, float3 hi, float r2,
                                                       uint32_t kind, unsigned int* __restrict__ counter, uint32_t cap,
                                                       uint32_t* __restrict__ out_kind, uint32_t* __restrict__ out_index) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pos[i];
+    if (i >= q.n || query_skip(q, i)) return;
+    const float4 p = q.pos[i];
     const float dx = fmaxf(fmaxf(lo.x - p.x, p.x - hi.x), 0.0f), dy = fmaxf(fmaxf(lo.y - p.y, p.y - hi.y), 0.0f),
                 dz = fmaxf(fmaxf(lo.z - p.z, p.z - hi.z), 0.0f);
     if (!(dx * dx + dy * dy + dz * dz < r2)) return;
-    const uint32_t k = atomicAdd(counter, 1u);
-    if (k < cap) { out_kind[k] = kind; out_index[k] = i; }
+    query_emit(q, i, kind, counter, cap, out_kind, out_index);
 }
+// Single domain: the staging arrays, refreshed from the working set.  Decomposed run (after its first step): the owned particles of
+// the working set with their global ids — a query is a per-rank operation there, each rank reports what it owns; the union over
+// the ranks is the undivided world's answer (boundary particles near a slab face are held, and reported, by both neighbours).
+QuerySrc World::query_fluid_source() {
+    if (comm && dist_started && sorted_valid) return QuerySrc{posm[cur].p, n, gtag[cur].p, perm[cur].p, model[cur].p};
+    if (comm) throw HipError(SALVA_HIP_E_INVALID, "a query in a decomposed run needs a completed step (global ids exist from then on)");
+    ensure_staging_current();
+    return QuerySrc{st_pos.p, n, nullptr, nullptr, nullptr};
+}
+
 // (kind, global index) pairs collected on the device -> sorted (kind, slot, index-in-slot) triples on the host
 uint64_t World::collect_query(unsigned int* d_count, uint32_t* d_kind, uint32_t* d_index, uint32_t cap, uint32_t* kinds, uint32_t* slots,
                               uint32_t* indices) {
@@ -1305,9 +1331,14 @@ uint64_t World::collect_query(unsigned int* d_count, uint32_t* d_kind, uint32_t*
     for (uint32_t k = 0; k < m; ++k) keys[k] = ((uint64_t)hk[k] << 32) | hi_[k];
     std::sort(keys.begin(), keys.end());
     for (uint32_t k = 0; k < m; ++k) {
-        const uint32_t kind = (uint32_t)(keys[k] >> 32);
+        uint32_t kind = (uint32_t)(keys[k] >> 32);
         uint64_t g = keys[k] & 0xffffffffull;
         uint32_t s = 0;
+        if (comm && (kind & 0xffu) == 0) {  // decomposed run: the slot came with the kind word, the index is a global id
+            kinds[k] = 0u; slots[k] = kind >> 8; indices[k] = (uint32_t)g;
+            continue;
+        }
+        kind &= 0xffu;
         if (kind == 0) { while (s + 1 < fluids.size() && g >= fluids[s].n) { g -= fluids[s].n; ++s; } }
         else { while (s + 1 < bounds.size() && g >= bounds[s].n) { g -= bounds[s].n; ++s; } }
         kinds[k] = kind; slots[k] = s; indices[k] = (uint32_t)g;
@@ -1318,8 +1349,7 @@ uint64_t World::collect_query(unsigned int* d_count, uint32_t* d_kind, uint32_t*
 uint64_t World::particles_in_aabb(const float mins[3], const float maxs[3], uint64_t capacity, uint32_t* kinds, uint32_t* slots,
                                   uint32_t* indices) {
     use_device();
-    if (comm) throw HipError(SALVA_HIP_E_INVALID, "queries are not available in a multi-GPU run");
-    ensure_staging_current();
+    const QuerySrc qf = query_fluid_source(), qb{bst_pos.p, nb, nullptr, nullptr, nullptr};
     const uint32_t cap = (uint32_t)std::min<uint64_t>(capacity, 0xfffffff0ull);
     DevBuf<unsigned int> cnt;
     DevBuf<uint32_t> dk, di;
@@ -1327,8 +1357,8 @@ uint64_t World::particles_in_aabb(const float mins[3], const float maxs[3], uint
     SALVA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(unsigned int), stream));
     const float r = prm.particle_radius;
     const float3 lo = make_float3(mins[0], mins[1], mins[2]), hi = make_float3(maxs[0], maxs[1], maxs[2]);
-    if (n) k_aabb_query<<<nblk(n), BLOCK, 0, stream>>>(st_pos.p, n, lo, hi, r * r, 0u, cnt.p, cap, dk.p, di.p);
-    if (nb) k_aabb_query<<<nblk(nb), BLOCK, 0, stream>>>(bst_pos.p, nb, lo, hi, r * r, 1u, cnt.p, cap, dk.p, di.p);
+    if (qf.n) k_aabb_query<<<nblk(qf.n), BLOCK, 0, stream>>>(qf, lo, hi, r * r, 0u, cnt.p, cap, dk.p, di.p);
+    if (nb) k_aabb_query<<<nblk(nb), BLOCK, 0, stream>>>(qb, lo, hi, r * r, 1u, cnt.p, cap, dk.p, di.p);
     return collect_query(cnt.p, dk.p, di.p, cap, kinds, slots, indices);
 }
 
@@ -1342,12 +1372,12 @@ struct ShapeQuery {
     int clo[3], chi[3];     // cell range of the world AABB
     float h, r;             // cell width, particle radius
 };
-__global__ __launch_bounds__(BLOCK) void k_shape_query(const float4* __restrict__ pos, uint32_t n, ShapeQuery s, uint32_t kind,
+__global__ __launch_bounds__(BLOCK) void k_shape_query(QuerySrc q, ShapeQuery s, uint32_t kind,
                                                        unsigned int* __restrict__ counter, uint32_t cap, uint32_t* __restrict__ out_kind,
                                                        uint32_t* __restrict__ out_index) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const float4 pt = pos[i];
+    if (i >= q.n || query_skip(q, i)) return;
+    const float4 pt = q.pos[i];
     bool bad = false;
     const int cx = cell_coord(pt.x, s.h, bad), cy = cell_coord(pt.y, s.h, bad), cz = cell_coord(pt.z, s.h, bad);
     if (bad || cx < s.clo[0] || cx > s.chi[0] || cy < s.clo[1] || cy > s.chi[1] || cz < s.clo[2] || cz > s.chi[2]) return;
@@ -1364,13 +1394,11 @@ __global__ __launch_bounds__(BLOCK) void k_shape_query(const float4* __restrict_
         d = sqrtf(dx * dx + dy * dy + dz * dz);
     }
     if (!(d <= s.r)) return;
-    const uint32_t k = atomicAdd(counter, 1u);
-    if (k < cap) { out_kind[k] = kind; out_index[k] = i; }
+    query_emit(q, i, kind, counter, cap, out_kind, out_index);
 }
 uint64_t World::particles_in_shape(const float t[3], const float q[4], const SalvaHipShape& shape, uint64_t capacity, uint32_t* kinds,
                                    uint32_t* slots, uint32_t* indices) {
     use_device();
-    if (comm) throw HipError(SALVA_HIP_E_INVALID, "queries are not available in a multi-GPU run");
     if (shape.kind != SALVA_HIP_SHAPE_BALL && shape.kind != SALVA_HIP_SHAPE_CUBOID)
         throw HipError(SALVA_HIP_E_INVALID, "unknown shape kind (ball and cuboid are built in; other parry shapes belong to the host)");
     // the pose must be a rigid motion and the shape non-degenerate (the reference takes an Isometry and a parry shape, which
@@ -1388,7 +1416,7 @@ uint64_t World::particles_in_shape(const float t[3], const float q[4], const Sal
     for (int a = 0; a < (shape.kind == SALVA_HIP_SHAPE_BALL ? 1 : 3); ++a)
         if (!(shape.params[a] > 0.0f) || !std::isfinite(shape.params[a]))
             throw HipError(SALVA_HIP_E_INVALID, "shape query: radius / half extents must be positive and finite");
-    ensure_staging_current();
+    const QuerySrc qf = query_fluid_source(), qb{bst_pos.p, nb, nullptr, nullptr, nullptr};
     ShapeQuery s{};
     for (int a = 0; a < 3; ++a) { s.t[a] = t[a]; s.p[a] = shape.params[a]; }
     for (int a = 0; a < 4; ++a) s.q[a] = q[a];
@@ -1414,8 +1442,8 @@ uint64_t World::particles_in_shape(const float t[3], const float q[4], const Sal
     DevBuf<uint32_t> dk, di;
     cnt.ensure(1); dk.ensure(std::max(cap, 1u)); di.ensure(std::max(cap, 1u));
     SALVA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(unsigned int), stream));
-    if (n) k_shape_query<<<nblk(n), BLOCK, 0, stream>>>(st_pos.p, n, s, 0u, cnt.p, cap, dk.p, di.p);
-    if (nb) k_shape_query<<<nblk(nb), BLOCK, 0, stream>>>(bst_pos.p, nb, s, 1u, cnt.p, cap, dk.p, di.p);
+    if (qf.n) k_shape_query<<<nblk(qf.n), BLOCK, 0, stream>>>(qf, s, 0u, cnt.p, cap, dk.p, di.p);
+    if (nb) k_shape_query<<<nblk(nb), BLOCK, 0, stream>>>(qb, s, 1u, cnt.p, cap, dk.p, di.p);
     return collect_query(cnt.p, dk.p, di.p, cap, kinds, slots, indices);
 }
 

@@ -491,3 +491,69 @@ def test_rebalance_moves_cuts_by_whole_slabs_between_ranks_of_different_extent(h
         got_p[order[gid]] = p
     assert np.isfinite(got_p).all()
     assert np.abs(got_p - ref_p).max() < 2e-4 * H, f"positions differ by {np.abs(got_p - ref_p).max() / H:.2e} h"
+
+
+def test_queries_in_a_decomposed_run(hip_lib):
+    """particles_intersecting_aabb / _shape are per-rank operations in a decomposed run: each rank reports the particles it OWNS
+    (ghosts are the neighbour's to report) with their global ids; the union over the ranks is the undivided world's answer."""
+    pos, vel, bpos = make_scene()
+    nsteps, nranks = 6, 2
+    w = LiquidWorld(solver(), R, SF)
+    f = Fluid(pos, R, 1000.0)
+    f.velocities = vel
+    f.nonpressure_forces.extend(FORCES["make"]())
+    fh = w.add_fluid(f)
+    w.add_boundary(Boundary(bpos))
+    for _ in range(nsteps):
+        w.step(DT, G)
+    cx = dist.cell_x(pos, H)
+    slabs = dist.split_slabs(cx, nranks)
+    cut_x = slabs[1][0] * H  # the box and the ball straddle the cut
+    p_now = np.array(fh.positions)
+    mid = p_now.mean(axis=0)
+    box = ((cut_x - 1.5 * H, mid[1] - 2 * H, mid[2] - 2 * H), (cut_x + 1.5 * H, mid[1] + 2 * H, mid[2] + 2 * H))
+    ball = ((cut_x + 0.3 * H, mid[1], mid[2]), (0.0, 0.0, 0.0, 1.0), ("ball", 2.2 * H))
+    ref_box = sorted(i for k, _, i in w.particles_intersecting_aabb(*box) if k == "fluid")
+    ref_ball = sorted(i for k, _, i in w.particles_intersecting_shape(*ball) if k == "fluid")
+    assert len(ref_box) > 50 and len(ref_ball) > 50
+    del w
+
+    owner = dist.owner_of(cx, slabs)
+    comms = dist.Comm.loopback(nranks)
+    offsets = np.concatenate([[0], np.cumsum([int((owner == r).sum()) for r in range(nranks)])])
+    order = np.concatenate([np.nonzero(owner == r)[0] for r in range(nranks)])  # global id -> index in `pos`
+    got_box, got_ball, errors = [None] * nranks, [None] * nranks, [None] * nranks
+
+    def rank_main(r):
+        try:
+            wr = LiquidWorld(solver(), R, SF)
+            mine = np.nonzero(owner == r)[0]
+            fr = Fluid(pos[mine], R, 1000.0)
+            fr.velocities = vel[mine]
+            fr.nonpressure_forces.extend(FORCES["make"]())
+            wr.add_fluid(fr)
+            wr.add_boundary(Boundary(bpos[dist.boundary_subset(bpos, H, slabs[r], r, nranks)]))
+            wr.set_domain(comms[r], slabs[r][0], slabs[r][1], int(offsets[r]))
+            for _ in range(nsteps):
+                wr.step(DT, G)
+            got_box[r] = [i for k, _, i in wr.particles_intersecting_aabb(*box) if k == "fluid"]
+            got_ball[r] = [i for k, _, i in wr.particles_intersecting_shape(*ball) if k == "fluid"]
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    for e in errors:
+        if e is not None:
+            raise e
+    for c in comms:
+        c.destroy()
+    assert all(len(g) > 0 for g in got_box), "both ranks own part of the box"
+    union_box = sorted(int(order[g]) for r in range(nranks) for g in got_box[r])
+    union_ball = sorted(int(order[g]) for r in range(nranks) for g in got_ball[r])
+    assert len(set(union_box)) == len(union_box), "a particle was reported by two ranks"
+    # positions agree to rounding between the two runs: a particle within 1e-4 h of the query surface may flip
+    assert len(set(union_box) ^ set(ref_box)) <= 2 and len(set(union_ball) ^ set(ref_ball)) <= 2, (len(union_box), len(ref_box))

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $R/bench.py $ARGS > $OUT/trace.log 2>&1
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/trace_kernel_stats.csv
 find $OUT/trace -name "*kernel_trace.csv" -delete
-KRE='k_pred_density|k_divergence|k_pressure_apply|k_nbr_tile|k_density_alpha|k_xsph|k_iisph|k_akinci'
+KRE='k_pred_density|k_divergence|k_pressure_apply|k_nbr_tile|k_density_alpha|k_xsph|k_iisph|k_akinci|k_tile|k_reorder'
 PARGS="--steps 6 --warmup 3 --no-cpu-baseline $@"
 i=0
 for PMC in \
