@@ -217,6 +217,14 @@ class World {
     struct FlagsPtr { uint32_t* p = nullptr; } d_flags;  // = &d_rb.p->flags: flags and the next step's box come back in one copy
     DevBuf<unsigned long long> d_counters;
     Readback* h_rb = nullptr;
+    // host-mapped copy of the words the host waits for twice per step (tile totals; flags + next box + list statistics): written by
+    // a one-wave kernel at the point of the stream where a hipMemcpyAsync + event used to sit, polled by the host (publish_wait)
+    struct HostPub { uint32_t seq, pad[3]; Readback rb; };
+    HostPub* h_hostpub = nullptr;
+    uint32_t hostpub_seq = 0;
+    uint32_t publish_enqueue(const TileAcc* totals, bool lists, bool end_of_step);
+    void publish_wait(uint32_t seq, bool totals, bool lists, bool end_of_step);
+    void publish_and_wait(const TileAcc* totals, bool lists, bool end_of_step);
     DevBuf<SolveCtl> d_ctl;      // [0] divergence solve, [1] pressure solve, [2] viscosity solve (DFSPHViscosity)
     SolveCtl* h_ctl = nullptr;   // pinned: [0..NUM_SOLVES) read-back, [NUM_SOLVES..2 NUM_SOLVES) initial values
     SolveCtl* h_pub = nullptr;   // host memory mapped into the device: k_finalize_error publishes every test's outcome here

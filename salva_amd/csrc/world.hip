@@ -141,6 +141,8 @@ World::World(const SalvaHipParams& p) : prm(p) {
     memset(h_ctl, 0, 2 * NUM_SOLVES * sizeof(SolveCtl));
     SALVA_HIP_CHECK(hipHostMalloc((void**)&h_pub, NUM_SOLVES * sizeof(SolveCtl), hipHostMallocMapped | hipHostMallocCoherent));
     memset(h_pub, 0, NUM_SOLVES * sizeof(SolveCtl));
+    SALVA_HIP_CHECK(hipHostMalloc((void**)&h_hostpub, sizeof(HostPub), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h_hostpub, 0, sizeof(HostPub));
     d_ctl.ensure(NUM_SOLVES);
     d_rb.ensure(1);
     d_flags.p = &d_rb.p->flags;
@@ -160,6 +162,7 @@ World::~World() {
     if (h_rb) (void)hipHostFree(h_rb);
     if (h_ctl) (void)hipHostFree(h_ctl);
     if (h_pub) (void)hipHostFree(h_pub);
+    if (h_hostpub) (void)hipHostFree(h_hostpub);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : evc) if (e) (void)hipEventDestroy(e);
     if (ev_sync) (void)hipEventDestroy(ev_sync);
@@ -712,6 +715,60 @@ void World::build_boundary_grid() {
 
 // The convergence loops read one float back per iteration; an interrupt-driven hipStreamSynchronize costs tens of
 // microseconds per wake-up, polling an event a few.
+// The per-step read-backs without a copy engine: one wave copies the few words the host is waiting for into host-mapped memory,
+// fences to system scope, then bumps the sequence word the host polls.  (A hipMemcpyAsync + event costs ~20 us of idle GPU each
+// time the host has to wait for it: tools/gap_tsv_report.py.)
+__global__ void k_publish_readback(const Readback* __restrict__ src, const TileAcc* __restrict__ totals, int lists, int end_of_step,
+                                   Readback* pub_rb, volatile uint32_t* pub_seq, uint32_t seq) {
+    if (threadIdx.x == 0) {
+        if (totals) pub_rb->tile_total = *totals;
+        if (lists) {
+            pub_rb->ncontacts_ff = src->ncontacts_ff; pub_rb->ncontacts_fb = src->ncontacts_fb;
+            pub_rb->max_cnt_ff = src->max_cnt_ff; pub_rb->max_cnt_fb = src->max_cnt_fb;
+            pub_rb->ncontacts_own_ff = src->ncontacts_own_ff; pub_rb->ncontacts_own_fb = src->ncontacts_own_fb;
+        }
+        if (end_of_step) {
+            pub_rb->flags = src->flags;
+            for (int a = 0; a < 6; ++a) pub_rb->bbox[a] = src->bbox[a];
+        }
+        __threadfence_system();
+        *pub_seq = seq;
+    }
+}
+// enqueue the publication on the world's stream ...
+uint32_t World::publish_enqueue(const TileAcc* totals, bool lists, bool end_of_step) {
+    const uint32_t seq = ++hostpub_seq;
+    k_publish_readback<<<1, WAVE, 0, stream>>>(d_rb.p, totals, lists ? 1 : 0, end_of_step ? 1 : 0, &h_hostpub->rb, &h_hostpub->seq, seq);
+    SALVA_HIP_CHECK(hipGetLastError());
+    return seq;
+}
+// ... and wait for it (kernels enqueued in between keep the GPU busy meanwhile); the published words are folded into h_rb
+void World::publish_wait(uint32_t seq, bool totals, bool lists, bool end_of_step) {
+    auto last_query = std::chrono::steady_clock::now();
+    // (sequence numbers only grow and one publication is outstanding at a time)
+    for (uint32_t spins = 0; __atomic_load_n(&h_hostpub->seq, __ATOMIC_ACQUIRE) != seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xffu) != 0xffu) continue;
+        const auto now = std::chrono::steady_clock::now();
+        if (now - last_query < std::chrono::microseconds(100)) continue;
+        last_query = now;
+        const hipError_t e = hipStreamQuery(stream);  // a fault on the stream would otherwise spin forever
+        if (e != hipSuccess && e != hipErrorNotReady) SALVA_HIP_CHECK(e);
+        if (e == hipSuccess && __atomic_load_n(&h_hostpub->seq, __ATOMIC_ACQUIRE) != seq)
+            throw HipError(SALVA_HIP_E_HIP, "internal error: the stream drained without publishing its read-back");
+    }
+    const Readback& p = h_hostpub->rb;
+    if (totals) h_rb->tile_total = p.tile_total;
+    if (lists) {
+        h_rb->ncontacts_ff = p.ncontacts_ff; h_rb->ncontacts_fb = p.ncontacts_fb; h_rb->max_cnt_ff = p.max_cnt_ff; h_rb->max_cnt_fb = p.max_cnt_fb;
+        h_rb->ncontacts_own_ff = p.ncontacts_own_ff; h_rb->ncontacts_own_fb = p.ncontacts_own_fb;
+    }
+    if (end_of_step) { h_rb->flags = p.flags; memcpy(h_rb->bbox, p.bbox, sizeof(p.bbox)); }
+}
+void World::publish_and_wait(const TileAcc* totals, bool lists, bool end_of_step) {
+    publish_wait(publish_enqueue(totals, lists, end_of_step), totals != nullptr, lists, end_of_step);
+}
+
 void World::wait_stream() {
     SALVA_HIP_CHECK(hipEventRecord(ev_sync, stream));
     for (;;) {
@@ -1063,13 +1120,17 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         const size_t tb = sort_pairs_temp_bytes(n, end_bit);
         ensure_cub_temp(tb);
         sort_pairs(cub_temp.p, tb, keys[0].p, keys[1].p, idx[0].p, idx[1].p, n, end_bit, stream);
+        launch_cell_start(keys[1].p, n, (uint32_t)ncf, cell_start_f.p, stream);
+    }
+    // The particle arrays are permuted into the sorted order AFTER the tile tables have been counted: those need the cell table
+    // only, and the host then waits for their totals while the GPU moves the 136 bytes per particle of the reorder.
+    auto reorder = [&]() {
         launch_reorder_fluid(n, idx[1].p, arrays(cur), arrays(cur ^ 1), w.p, stream);
         cur ^= 1;
-        launch_cell_start(keys[1].p, n, (uint32_t)ncf, cell_start_f.p, stream);
         if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[0], stream));
         if (acc_user && !comm) launch_gather_f4(n, perm[cur].p, st_acc.p, acc.p, stream);
         if (comm) dist_build_lists();
-    }
+    };
     build_boundary_grid();  // insert_boundaries_to_grid (liquid_world.rs:106) + boundary volumes, only when dirty
     if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[1], stream));
 
@@ -1100,9 +1161,12 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             if (probe.bytes(52, 32, 6) > 160u * 1024u || tt.max_s >= 65536u || tt.max_sb >= 65536u) spec = false;
         }
         if (!spec) {
-            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + nslots_bound, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
-            wait_stream();
+            const uint32_t seq = publish_enqueue(tile_off.p + nslots_bound, false, false);
+            reorder();
+            publish_wait(seq, true, false, false);
             tt = h_rb->tile_total;
+        } else {
+            reorder();
         }
         nlaunch = tt.nonempty;
         lds.max_halo_fluid = tt.max_s;
@@ -1169,9 +1233,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
                              comm ? reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_own_ff) : nullptr, stream);
             if (spec || defer_lists) break;
             static_assert(offsetof(Readback, max_cnt_ff) == offsetof(Readback, ncontacts_ff) + 2 * sizeof(uint64_t), "list statistics travel in one copy");
-            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, &d_rb.p->ncontacts_ff, 2 * sizeof(uint64_t) + 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            if (comm) SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_own_ff, &d_rb.p->ncontacts_own_ff, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-            wait_stream();
+            publish_and_wait(nullptr, true, false);
             const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;
             if (need_ff <= cap_ff && need_fb <= cap_fb) break;
             if (nattempt >= 2) throw HipError(SALVA_HIP_E_HIP, "internal error: neighbour list capacity did not converge");
@@ -1194,12 +1256,8 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
 
     // ---- end of step: next bbox + flags (+ in a speculative pass: the true table totals and list statistics)
     static_assert(offsetof(Readback, bbox) == offsetof(Readback, flags) + sizeof(uint32_t), "flags and bbox travel in one copy");
-    SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->flags, &d_rb.p->flags, sizeof(uint32_t) + sizeof(int32_t) * 6, hipMemcpyDeviceToHost, stream));
-    if (spec) SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->tile_total, tile_off.p + nslots_bound, sizeof(TileAcc), hipMemcpyDeviceToHost, stream));
-    if (spec || defer_lists)
-        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->ncontacts_ff, &d_rb.p->ncontacts_ff, 2 * sizeof(uint64_t) + 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[2], stream));
-    wait_stream();
+    publish_and_wait(spec ? tile_off.p + nslots_bound : nullptr, spec || defer_lists, true);
     if (defer_lists && !spec) {
         const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;
         if (need_ff > cap_ff || need_fb > cap_fb) {

@@ -601,7 +601,8 @@ class LiquidWorld:
         self._particle_radius = float(particle_radius)
         self._fluids = _ObjectSet()
         self._boundaries = _ObjectSet()
-        self.counters = Counters()
+        self._counters = Counters()
+        self._counters_stale = False
         self.last_stats = L.StepStats()
 
     def __del__(self):
@@ -790,6 +791,27 @@ class LiquidWorld:
             self._sync_fluid(f, apply_removal)
         self._sync_boundaries()
 
+    @property
+    def counters(self) -> Counters:
+        """liquid_world.counters (counters/mod.rs:17-72) of the last step; read from the device library on first access after
+        a step (a Python loop that only steps does not pay for it)."""
+        if self._counters_stale:
+            self._counters_stale = False
+            c, st = self._counters, self.last_stats
+            c.ncontacts = int(st.ncontacts)
+            c.n_divergence_iters, c.n_pressure_iters = st.n_divergence_iters, st.n_pressure_iters
+            c.divergence_error, c.density_error = st.divergence_error, st.density_error
+            c.grid_ms, c.solver_ms, c.step_ms = st.grid_ms, st.solver_ms, st.step_ms
+            t = L.CountersStruct()
+            L.check(self._L.salva_hip_get_counters(self._h, C.byref(t)))
+            c.nsubsteps, c.step_time, c.custom = int(t.nsubsteps), t.step_time, t.custom
+            c.stages = StagesCounters(t.stages.collision_detection_time, t.stages.solver_time)
+            c.cd = CollisionDetectionCounters(int(t.cd.ncontacts), t.cd.boundary_update_time, t.cd.grid_insertion_time,
+                                              t.cd.neighborhood_search_time, t.cd.contact_sorting_time)
+            c.solver = SolverCounters(t.solver.non_pressure_resolution_time, t.solver.pressure_resolution_time)
+            c.speculative_passes, c.discarded_passes = int(t.speculative_passes), int(t.discarded_passes)
+        return self._counters
+
     # ---- liquid_world.rs:62-158
     def step(self, dt: float, gravity=(0.0, -9.81, 0.0)) -> L.StepStats:
         self.sync_to_device()
@@ -812,20 +834,7 @@ class LiquidWorld:
                     L.check(self._L.salva_hip_get_force_stats(self._h, f._slot, k, C.byref(it), C.byref(err)))
                     force.num_iterations, force.last_error = it.value, err.value
         self.last_stats = st
-        c = self.counters
-        c.nsubsteps = 1
-        c.ncontacts = int(st.ncontacts)
-        c.n_divergence_iters, c.n_pressure_iters = st.n_divergence_iters, st.n_pressure_iters
-        c.divergence_error, c.density_error = st.divergence_error, st.density_error
-        c.grid_ms, c.solver_ms, c.step_ms = st.grid_ms, st.solver_ms, st.step_ms
-        t = L.CountersStruct()
-        L.check(self._L.salva_hip_get_counters(self._h, C.byref(t)))
-        c.nsubsteps, c.step_time, c.custom = int(t.nsubsteps), t.step_time, t.custom
-        c.stages = StagesCounters(t.stages.collision_detection_time, t.stages.solver_time)
-        c.cd = CollisionDetectionCounters(int(t.cd.ncontacts), t.cd.boundary_update_time, t.cd.grid_insertion_time,
-                                          t.cd.neighborhood_search_time, t.cd.contact_sorting_time)
-        c.solver = SolverCounters(t.solver.non_pressure_resolution_time, t.solver.pressure_resolution_time)
-        c.speculative_passes, c.discarded_passes = int(t.speculative_passes), int(t.discarded_passes)
+        self._counters_stale = True  # the Counters tree is fetched when somebody looks at it (`world.counters`), not on every step
         return st
 
     # ---- host NonPressureForce::solve in the middle of the substep (SALVA_HIP_FORCE_CUSTOM)
