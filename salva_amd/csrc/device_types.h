@@ -151,14 +151,6 @@ struct StepCtx {
     // the exchange).  0: every tile.  ghost_lo_cx / ghost_hi_cx: the cell planes next to the slab that hold ghosts.
     int32_t phase, ghost_lo_cx, ghost_hi_cx;
     const SolveCtl* ctl;       // non-null inside an iterative solve: kernels return at once when ctl->done
-    // Convergence test fused into the apply pass (single-domain DFSPH solves, tile.h fused_*): fuse_iter1 != 0 makes every workgroup
-    // of the apply kernel reduce the error partials of the evaluate pass itself (same order in every workgroup: same decision) and
-    // workgroup 0 update and publish the control block — instead of a one-block k_finalize_error launch between the two passes.
-    SolveCtl* ctl_rw;
-    SolveCtl* fuse_pub;        // host-mapped copy of the control block's first half (may be null)
-    const uint32_t* model_counts;
-    uint32_t fuse_nblocks;     // partials to reduce (= tiles launched by the evaluate pass)
-    uint32_t fuse_iter1;       // 1 + index of this iteration in the solve loop; 0: not fused (a zero-initialised StepCtx is safe)
 #ifdef SALVA_HIP_DIAG
     unsigned long long* dbg;   // kernel-development builds: per-tile phase timestamps (k_pred_density, SALVA_HIP_TILE_TIMING=1)
 #endif

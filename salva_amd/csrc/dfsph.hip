@@ -101,7 +101,7 @@ static uint32_t pw_bytes(const TileLds& L, uint32_t ds, bool errtab) {
 // P | K kernels: P holds fluid halo + 2 x boundary halo, K the fluid halo (4 bytes each)
 static uint32_t pk_slots(const TileLds& L) { return L.sum_slots() + L.max_halo_boundary; }
 static uint32_t pk_bytes(const TileLds& L, uint32_t ds) {
-    return (ds ? ds : pk_slots(L)) * 16u + ((L.max_halo_fluid + 63u) & ~63u) * 4u + 2u * TILE_MAX_WAVES * 4u + 48u;  // (+ the fused test's wave sums)
+    return (ds ? ds : pk_slots(L)) * 16u + ((L.max_halo_fluid + 63u) & ~63u) * 4u + 32u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -171,18 +171,11 @@ void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c, float inv_dt_prev) {
-    SolveCtl ctl0{};
-    if (c.ctl) {
-        ctl0 = *c.ctl;
-        if (ctl0.done) { fused_tick_done(c, ctl0); return; }  // the solve converged earlier in this batch
-    }
+    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     lds_base_check();
-    const bool fused = c.fuse_iter1 != 0u;
-    FusedSums fsum{0.0f, 0.0f};
-    if (fused) fsum = fused_partial_sums(c);  // (issued first: the loads overlap the tile's own)
     Tile t;
     t.setup(c);
-    if (t.empty()) { if (fused) fused_standalone(c, ctl0); return; }
+    if (t.empty()) return;
     // Only w = v + dv is carried through the divergence solve: dv itself is zeroed right after it (:689-691) and v
     // becomes w (:422-430), so updating w in place saves two 16-byte loads and one store per particle and pass.
     struct Own { float4 pi, wi; float ki; uint32_t cnt, near; ListRegs lh; };
@@ -196,10 +189,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
     t.stage_pk(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), dist, Bp, Bv);
-    float* wsum = t.carve<float>(2 * TILE_MAX_WAVES);
-    if (fused) fused_wave_sums(fsum, wsum);
     Tile::staged_barrier();
-    if (fused && fused_decide(c, wsum, ctl0)) return;  // converged: `break` before the apply (:487)
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
         const bool near = slice_is_near(o.near);
@@ -355,18 +345,11 @@ void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream
 // ------------------------------------------------------------------------------------------------
 template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, float inv_dt) {
-    SolveCtl ctl0{};
-    if (c.ctl) {
-        ctl0 = *c.ctl;
-        if (ctl0.done) { fused_tick_done(c, ctl0); return; }  // the solve converged earlier in this batch
-    }
+    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     lds_base_check();
-    const bool fused = c.fuse_iter1 != 0u;
-    FusedSums fsum{0.0f, 0.0f};
-    if (fused) fsum = fused_partial_sums(c);
     Tile t;
     t.setup(c);
-    if (t.empty()) { if (fused) fused_standalone(c, ctl0); return; }
+    if (t.empty()) return;
     struct Own { float4 pi, d, v; float ki; uint32_t mi, cnt, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
         return Own{c.posm[i], c.dv[i], c.vel[i], c.kappa[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
@@ -378,10 +361,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
     t.stage_pk(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), dist, Bp, Bv);
-    float* wsum = t.carve<float>(2 * TILE_MAX_WAVES);
-    if (fused) fused_wave_sums(fsum, wsum);
     Tile::staged_barrier();
-    if (fused && fused_decide(c, wsum, ctl0)) return;  // converged: `break` before the apply (:448)
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
         const bool near = slice_is_near(o.near);
@@ -458,6 +438,12 @@ void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox_partials,
 // fine-grained host memory), so the host, which spins on `seq` and then reads the others, never sees a newer `seq` with older
 // data — no system-scope fence (which writes the XCD's L2 back: a third of this one-workgroup kernel's time) is needed,
 // because nothing else the host reads was produced by this kernel.
+__device__ __forceinline__ void publish_ctl(const SolveCtl* ctl, SolveCtl* pub, uint32_t seq) {
+    if (!pub) return;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = {ctl->done, ctl->iters, __float_as_uint(ctl->err), seq};
+    *reinterpret_cast<volatile u32x4*>(pub) = v;  // (global_store_dwordx4)
+}
 __global__ __launch_bounds__(BLOCK) void k_finalize_error(const float* __restrict__ partials, unsigned nblocks,
                                                           uint32_t nmodels, const uint32_t* __restrict__ model_counts,
                                                           SolveCtl* ctl, SolveCtl* pub) {

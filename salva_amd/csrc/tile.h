@@ -831,71 +831,6 @@ struct TileErr {
     }
 };
 
-// ---- the convergence test of an iterative solve, fused into its apply pass (StepCtx::fuse_iter1 != 0) ---------------------------
-// `for i in 0..max { err = evaluate(); if err <= tol && i >= min { break }; apply(); }` (dfsph_solver.rs:439-463, :474-502): the
-// evaluate kernel leaves one error partial per tile and fluid; every workgroup of the apply kernel sums them — thread-strided
-// partial sums, DPP wave sums, wave sums folded in wave order after the staging barrier it has anyway: the same arithmetic in
-// every workgroup, hence the same decision — and returns without applying when the solve has converged.  Workgroup 0 also
-// writes the control block and publishes it to the host (k_finalize_error's job, 5 us + two launch gaps per iteration saved).
-// No atomics, no fences.  Up to two fluids (FUSE_MAX_MODELS); the host falls back to k_finalize_error otherwise.
-constexpr uint32_t FUSE_MAX_MODELS = 2;
-struct FusedSums { float s0, s1; };
-__device__ __forceinline__ void publish_ctl(const SolveCtl* ctl, SolveCtl* pub, uint32_t seq) {
-    if (!pub) return;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = {ctl->done, ctl->iters, __float_as_uint(ctl->err), seq};
-    *reinterpret_cast<volatile u32x4*>(pub) = v;  // one 16-byte store: the four words reach the host together (dfsph.hip)
-}
-// a workgroup of a kernel that runs after the solve has converged: only the tick the host counts
-__device__ __forceinline__ void fused_tick_done(const StepCtx& c, const SolveCtl& ctl0) {
-    if (c.fuse_iter1 != 0u && blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t s = ctl0.seq + 1u;
-        c.ctl_rw->seq = s;
-        publish_ctl(c.ctl_rw, c.fuse_pub, s);
-    }
-}
-__device__ __forceinline__ FusedSums fused_partial_sums(const StepCtx& c) {
-    FusedSums f{0.0f, 0.0f};
-    const uint32_t nm = c.nmodels;
-    for (uint32_t b = threadIdx.x; b < c.fuse_nblocks; b += blockDim.x) {
-        f.s0 += c.partials[(size_t)b * nm];
-        if (nm > 1u) f.s1 += c.partials[(size_t)b * nm + 1u];
-    }
-    return f;
-}
-// before the barrier: every thread calls; `wsum` holds 2 floats per wave
-__device__ __forceinline__ void fused_wave_sums(const FusedSums& f, float* wsum) {
-    const float a = wave_sum(f.s0), b = wave_sum(f.s1);
-    if ((threadIdx.x & (WAVE - 1)) == 0) { wsum[2u * (threadIdx.x / WAVE)] = a; wsum[2u * (threadIdx.x / WAVE) + 1u] = b; }
-}
-// after the barrier: true = converged (do not apply)
-__device__ __forceinline__ bool fused_decide(const StepCtx& c, const float* wsum, const SolveCtl& ctl0) {
-    float t0 = 0.0f, t1 = 0.0f;
-    for (uint32_t w = 0; w < blockDim.x / WAVE; ++w) { t0 += wsum[2u * w]; t1 += wsum[2u * w + 1u]; }
-    float best = 0.0f;
-    const uint32_t n0 = c.model_counts[0], n1 = c.nmodels > 1u ? c.model_counts[1] : 0u;
-    if (n0) best = fmaxf(best, t0 / (float)n0);
-    if (n1) best = fmaxf(best, t1 / (float)n1);
-    const bool conv = best <= ctl0.tol && c.fuse_iter1 - 1u >= ctl0.min_iter;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        SolveCtl* ctl = c.ctl_rw;
-        ctl->err = best;
-        if (conv) ctl->done = 1u;
-        else ctl->iters = c.fuse_iter1;  // the apply pass this kernel is runs
-        const uint32_t s = ctl0.seq + 1u;
-        ctl->seq = s;
-        publish_ctl(ctl, c.fuse_pub, s);
-    }
-    return conv;
-}
-// a workgroup without a tile (speculative launches): the same test on its own
-__device__ __forceinline__ void fused_standalone(const StepCtx& c, const SolveCtl& ctl0) {
-    float* wsum = reinterpret_cast<float*>(tile_smem);
-    fused_wave_sums(fused_partial_sums(c), wsum);
-    __syncthreads();
-    (void)fused_decide(c, wsum, ctl0);
-}
-
 // Boundary::apply_force (boundary.rs:62-67): forces accumulate in canonical boundary order.  `jb` is the sorted
 // boundary index (t.bgstart-relative lookups are done by the caller).  Callers skip ghost particles (is_ghost): in a
 // decomposed run the boundary particles near a slab face exist on both ranks, and a reaction force belongs to the rank that

@@ -126,7 +126,7 @@ class World {
     StepCtx make_ctx();
     struct SolveResult { uint32_t iters; float err; };
     template <typename Eval, typename Apply>
-    SolveResult run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval, Apply&& apply, bool apply_tests = false);
+    SolveResult run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval, Apply&& apply);
     void wait_stream();  // low-latency wait for the world's stream (spins on an event)
     void run_forces(const StepCtx& c);
     void dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);

@@ -784,7 +784,7 @@ void World::wait_stream() {
 // and the control block is read back once per batch.  Kernels enqueued after convergence return immediately.
 template <typename Eval, typename Apply>
 World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval,
-                                    Apply&& apply, bool apply_tests) {
+                                    Apply&& apply) {
     SolveCtl& init = h_ctl[NUM_SOLVES + which];
     init = SolveCtl{0u, 0u, 0.0f, 0u, tol, (uint32_t)std::max(min_iter, 0), mode, 0u};
     h_ctl[which] = init;
@@ -802,23 +802,10 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
     int i = 0, batch = std::max(2, std::min<int>((int)last_iters[which] + 1, max_iter));
     while (i < max_iter) {
         const int nbatch = std::min(batch, max_iter - i);
-        // `apply_tests`: the apply kernel of this solve carries the convergence test itself (tile.h fused_*: single domain, at
-        // most FUSE_MAX_MODELS fluids) — no k_finalize_error launch between the two passes
-        const bool fused = apply_tests && !comm && mode == 0u && fluids.size() <= FUSE_MAX_MODELS;
         for (int k = 0; k < nbatch; ++k) {
             eval(c, i + k);
-            if (fused) {
-                StepCtx cf = c;
-                cf.fuse_iter1 = (uint32_t)(i + k) + 1u;
-                cf.fuse_nblocks = nlaunch;
-                cf.ctl_rw = d_ctl.p + which;
-                cf.fuse_pub = pub;
-                cf.model_counts = model_counts.p;
-                apply(cf, i + k);
-            } else {
-                finalize_solve(d_ctl.p + which, pub);
-                apply(c, i + k);
-            }
+            finalize_solve(d_ctl.p + which, pub);
+            apply(c, i + k);
         }
         if (pub) {
             const uint32_t expect = (uint32_t)(i + nbatch);
@@ -954,7 +941,7 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
             // owned particles read nothing else, so only w travels, once per iteration
             launch_divergence_apply(cc, lds, inv_dt_lag, stream);
             if (comm) refresh_f4(w.p);
-        }, true);
+        });
     if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[4], stream));  // :501
     st.n_divergence_iters = (int32_t)rd.iters;
     st.divergence_error = rd.err;
@@ -971,7 +958,7 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
         [&](const StepCtx& cc, int) {
             launch_pressure_apply(cc, lds, inv_dt, stream);
             if (comm) refresh_f4(w.p);
-        }, true);
+        });
     st.n_pressure_iters = (int32_t)rp.iters;
     st.density_error = rp.err;
     launch_update_positions(c, dt, bbox_partials.p, d_rb.p->bbox, stream);
