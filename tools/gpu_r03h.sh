@@ -2,7 +2,7 @@
 # round 3, eighth GPU pass: read-backs through host-mapped publication, the reorder behind the tile-totals wait, lazy Python counters:
 # whole GPU suite, bench lines, free-fall timeline.
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-O=gpurun_out/r03h; mkdir -p $O
+O=gpurun_out/${TAG:-r03h}; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q -x > $O/tests.log 2>&1; tail -6 $O/tests.log | cut -c1-300
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_5_20.json 2> $O/bench_5_20.err
 timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_5_50.json 2> $O/bench_5_50.err
