@@ -318,7 +318,12 @@ int64_t salva_hip_particles_intersecting_aabb(SalvaHipWorld* world, const float 
  * (parry itself is out of scope): the particles in the grid cells the posed shape's AABB touches whose distance to the
  * (solid) shape is <= the particle radius.  `rotation_ijkw` is the unit quaternion of the isometry.  Output and return value
  * as salva_hip_particles_intersecting_aabb; like it, current positions are tested. */
-enum { SALVA_HIP_SHAPE_BALL = 1 /* params[0] = radius */, SALVA_HIP_SHAPE_CUBOID = 2 /* params = half extents */ };
+enum {
+    SALVA_HIP_SHAPE_BALL = 1,      /* params[0] = radius */
+    SALVA_HIP_SHAPE_CUBOID = 2,    /* params = half extents */
+    SALVA_HIP_SHAPE_CAPSULE = 3,   /* parry Capsule::new_y: params[0] = half height of the segment along the local y axis, params[1] = radius */
+    SALVA_HIP_SHAPE_CYLINDER = 4   /* parry Cylinder (axis = local y): params[0] = half height, params[1] = radius */
+};
 typedef struct SalvaHipShape {
     int32_t kind;
     float params[3];
@@ -328,7 +333,7 @@ int64_t salva_hip_particles_intersecting_shape(SalvaHipWorld* world, const float
                                               uint32_t* indices);
 
 /* ---- Rigid-body coupling, the DynamicContactSampling arm (src/integrations/rapier/fluids_pipeline.rs:42-43, 193-259) for
- * ball and cuboid colliders: no sample points are kept; inside every salva_hip_step — after the fluids went into the grid and
+ * ball, cuboid, capsule (y) and cylinder (y) colliders: no sample points are kept; inside every salva_hip_step — after the fluids went into the grid and
  * before the boundaries do, where `coupling.update_boundaries` runs (liquid_world.rs:94-103) — each fluid particle whose
  * predicted position x + v*dt lies in the collider's AABB loosened by 1.5 h is projected onto the shape
  * (`project_point_and_get_feature`); particles inside the shape are pushed out by depth + 0.1 r and lose their inward normal

@@ -181,7 +181,7 @@ class Boundary {  // object/boundary.rs
     // velocities are produced on the device from a pose (ColliderCouplingSet below) and `positions` above is only a
     // read-back (LiquidWorld::sync_boundary)
     std::vector<Vec3> sampling;
-    // ColliderSampling::DynamicContactSampling (:42-43) for a ball / cuboid collider: kind != 0 makes every step re-emit the
+    // ColliderSampling::DynamicContactSampling (:42-43) for a ball / cuboid / capsule / cylinder collider: kind != 0 makes every step re-emit the
     // boundary's particles on the device from the fluid near the collider (salva_hip_set_boundary_dynamic_sampling);
     // positions / velocities are read back by LiquidWorld::sync_boundary
     SalvaHipShape dynamic_shape{0, {0, 0, 0}};
@@ -193,6 +193,17 @@ class Boundary {  // object/boundary.rs
     static Boundary dynamic_cuboid(const Vec3& half_extents, InteractionGroups groups = {}) {
         Boundary b({}, groups);
         b.dynamic_shape = SalvaHipShape{SALVA_HIP_SHAPE_CUBOID, {half_extents[0], half_extents[1], half_extents[2]}};
+        return b;
+    }
+    // parry Capsule::new_y(half_height, radius) / Cylinder::new(half_height, radius): axis = the collider's local y
+    static Boundary dynamic_capsule(Real half_height, Real radius, InteractionGroups groups = {}) {
+        Boundary b({}, groups);
+        b.dynamic_shape = SalvaHipShape{SALVA_HIP_SHAPE_CAPSULE, {half_height, radius, 0}};
+        return b;
+    }
+    static Boundary dynamic_cylinder(Real half_height, Real radius, InteractionGroups groups = {}) {
+        Boundary b({}, groups);
+        b.dynamic_shape = SalvaHipShape{SALVA_HIP_SHAPE_CYLINDER, {half_height, radius, 0}};
         return b;
     }
     size_t num_particles() const { return dynamic_shape.kind ? dynamic_n_ : (sampling.empty() ? positions.size() : sampling.size()); }

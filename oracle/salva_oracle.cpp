@@ -446,12 +446,21 @@ struct World {
             V3<R> ext;
             if (bd.dyn_kind == 1) {
                 ext = V3<R>(bd.dyn_p[0], bd.dyn_p[0], bd.dyn_p[0]);
+            } else if (bd.dyn_kind == 3) {
+                // Capsule::aabb(pos) (shape/capsule.rs) = transform_by(pos).local_aabb(): the posed segment's ends A, B;
+                // mins = inf(A, B) - radius, maxs = sup(A, B) + radius.  Capsule::new_y: a = (0, -hh, 0), b = (0, hh, 0).
+                const V3<R> lb((R)0, bd.dyn_p[0], (R)0);
+                const V3<R> tb = qv.cross(lb) * (R)2;
+                const V3<R> u = tb * qw + qv.cross(tb) + lb;  // q * b ; q * a = -(q * b)
+                ext = V3<R>(std::fabs(u.x) + bd.dyn_p[1], std::fabs(u.y) + bd.dyn_p[1], std::fabs(u.z) + bd.dyn_p[1]);
             } else {
                 const R i = qv.x, j = qv.y, k = qv.z, w = qw;
                 const R ww = w * w, ii = i * i, jj = j * j, kk = k * k;
                 const R ij = i * j * (R)2, wk = w * k * (R)2, wj = w * j * (R)2, ik = i * k * (R)2, jk = j * k * (R)2, wi = w * i * (R)2;
                 const R m[3][3] = {{ww + ii - jj - kk, ij - wk, wj + ik}, {wk + ij, ww - ii + jj - kk, jk - wi}, {ik - wj, wi + jk, ww - ii - jj + kk}};
-                const R he[3] = {bd.dyn_p[0], bd.dyn_p[1], bd.dyn_p[2]};
+                // cuboid: its half extents; cylinder (shape/cylinder.rs local_aabb): half extents (radius, half_height, radius)
+                const R he[3] = {bd.dyn_kind == 4 ? bd.dyn_p[1] : bd.dyn_p[0], bd.dyn_kind == 4 ? bd.dyn_p[0] : bd.dyn_p[1],
+                                 bd.dyn_kind == 4 ? bd.dyn_p[1] : bd.dyn_p[2]};
                 R e[3];
                 for (int a = 0; a < 3; ++a) e[a] = (std::fabs(m[a][0]) * he[0] + std::fabs(m[a][1]) * he[1]) + std::fabs(m[a][2]) * he[2];
                 ext = V3<R>(e[0], e[1], e[2]);
@@ -477,6 +486,49 @@ struct World {
                         const R r = bd.dyn_p[0], d2 = lp.norm_squared();
                         inside = d2 <= r * r;
                         lproj = lp * (r / std::sqrt(d2));
+                    } else if (bd.dyn_kind == 3) {
+                        // Capsule (query/point/point_capsule.rs, solid = false) over Segment (point_segment.rs):
+                        //   ab = b - a, ap = pt - a; ab.ap <= 0 -> a; >= |ab|^2 -> b; else a + ab * (ab.ap / |ab|^2)
+                        //   dproj = pt - proj; Some((dir, dist)) = try_new_and_get(dproj, eps): inside = dist <= r, proj + dir * r
+                        //   None (the point is on the segment): proj + basis * r with basis = orthonormal_basis(ab / |ab|)[0] = (1, 0, 0), inside
+                        const R hh = bd.dyn_p[0], r = bd.dyn_p[1];
+                        const V3<R> a((R)0, -hh, (R)0), ab((R)0, hh - (-hh), (R)0);
+                        const V3<R> ap = lp - a;
+                        const R ab_ap = ab.dot(ap), sqnab = ab.norm_squared();
+                        V3<R> sp;
+                        if (ab_ap <= (R)0) sp = a;
+                        else if (ab_ap >= sqnab) sp = V3<R>((R)0, hh, (R)0);
+                        else sp = a + ab * (ab_ap / sqnab);
+                        const V3<R> dproj = lp - sp;
+                        V3<R> dir;
+                        R dist;
+                        if (try_new_and_get(dproj, Eps<R>::v, dir, dist)) {
+                            inside = dist <= r;
+                            lproj = sp + dir * r;
+                        } else {
+                            inside = true;
+                            lproj = sp + V3<R>((R)1, (R)0, (R)0) * r;
+                        }
+                    } else if (bd.dyn_kind == 4) {
+                        // Cylinder (query/point/point_cylinder.rs, solid = false), axis = local y
+                        const R hh = bd.dyn_p[0], r = bd.dyn_p[1];
+                        R dx = lp.x, dz = lp.z;
+                        const R planar = std::sqrt(dx * dx + dz * dz);  // normalize_mut returns the norm and divides by it
+                        dx = dx / planar; dz = dz / planar;
+                        if (planar <= Eps<R>::v) { dx = (R)1; dz = (R)0; }
+                        const R px = dx * r, pz = dz * r;
+                        if (lp.y >= -hh && lp.y <= hh && planar <= r) {
+                            inside = true;
+                            const R top = hh - lp.y, bottom = lp.y - (-hh), side = r - planar;
+                            if (top < bottom && top < side) lproj = V3<R>(lp.x, hh, lp.z);
+                            else if (bottom < top && bottom < side) lproj = V3<R>(lp.x, -hh, lp.z);
+                            else lproj = V3<R>(px, lp.y, pz);
+                        } else {
+                            inside = false;
+                            if (lp.y > hh) lproj = planar <= r ? V3<R>(lp.x, hh, lp.z) : V3<R>(px, hh, pz);
+                            else if (lp.y < -hh) lproj = planar <= r ? V3<R>(lp.x, -hh, lp.z) : V3<R>(px, -hh, pz);
+                            else lproj = V3<R>(px, lp.y, pz);
+                        }
                     } else {
                         const R he[3] = {bd.dyn_p[0], bd.dyn_p[1], bd.dyn_p[2]}, p3[3] = {lp.x, lp.y, lp.z};
                         R mins_pt[3], pt_maxs[3], shift[3];

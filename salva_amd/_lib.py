@@ -111,7 +111,7 @@ class Shape(C.Structure):
     _fields_ = [("kind", C.c_int32), ("params", C.c_float * 3)]
 
 
-SHAPE_BALL, SHAPE_CUBOID = 1, 2
+SHAPE_BALL, SHAPE_CUBOID, SHAPE_CAPSULE, SHAPE_CYLINDER = 1, 2, 3, 4
 
 
 class SalvaHipError(RuntimeError):

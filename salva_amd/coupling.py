@@ -97,20 +97,31 @@ class StaticSampling:
         self.points = np.ascontiguousarray(points, F32).reshape(-1, 3)
 
 
+def make_shape(shape) -> "L.Shape":
+    """("ball", r) | ("cuboid", (hx, hy, hz)) | ("capsule", half_height, radius) | ("cylinder", half_height, radius) -> SalvaHipShape"""
+    s = L.Shape()
+    if shape[0] == "ball":
+        s.kind, s.params[0] = L.SHAPE_BALL, float(shape[1])
+    elif shape[0] == "cuboid":
+        s.kind = L.SHAPE_CUBOID
+        s.params[:] = [float(x) for x in shape[1]]
+    elif shape[0] in ("capsule", "cylinder"):
+        s.kind = L.SHAPE_CAPSULE if shape[0] == "capsule" else L.SHAPE_CYLINDER
+        s.params[0], s.params[1] = float(shape[1]), float(shape[2])
+    else:
+        raise ValueError("built-in collider shapes: ('ball', radius), ('cuboid', half_extents), ('capsule', half_height, radius), "
+                         "('cylinder', half_height, radius)")
+    return s
+
+
 class DynamicContactSampling:
-    """ColliderSampling::DynamicContactSampling (fluids_pipeline.rs:42-43) for a collider of shape ("ball", radius) or
-    ("cuboid", (hx, hy, hz)): the boundary's particles are the projections of the nearby fluid particles onto the collider,
-    recomputed inside every step on the device (salva_hip_set_boundary_dynamic_sampling)."""
+    """ColliderSampling::DynamicContactSampling (fluids_pipeline.rs:42-43) for a collider of shape ("ball", radius),
+    ("cuboid", (hx, hy, hz)), ("capsule", half_height, radius) (parry Capsule::new_y) or ("cylinder", half_height, radius) (axis = local
+    y): the boundary's particles are the projections of the nearby fluid particles onto the collider, recomputed inside every step
+    on the device (salva_hip_set_boundary_dynamic_sampling)."""
 
     def __init__(self, shape):
-        self.shape = L.Shape()
-        if shape[0] == "ball":
-            self.shape.kind, self.shape.params[0] = L.SHAPE_BALL, float(shape[1])
-        elif shape[0] == "cuboid":
-            self.shape.kind = L.SHAPE_CUBOID
-            self.shape.params[:] = [float(x) for x in shape[1]]
-        else:
-            raise ValueError("built-in collider shapes: ('ball', radius), ('cuboid', half_extents)")
+        self.shape = make_shape(shape)
 
 
 @dataclass

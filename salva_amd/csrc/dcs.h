@@ -8,7 +8,7 @@ namespace salva {
 
 struct DcsParams {
     int kind;
-    float p[3];           // radius | half extents
+    float p[3];           // radius | half extents | (half height, radius) for capsule and cylinder
     float t[3], q[4];     // collider.position(): translation, unit quaternion (i, j, k, w)
     float lo[3], hi[3];   // shape AABB loosened by h + prediction (fluids_pipeline.rs:196-199)
     int clo[3], chi[3];   // HGrid::key(mins) .. key(maxs) (hgrid.rs:128-129)
@@ -18,6 +18,9 @@ struct DcsParams {
     float eps;            // f32::default_epsilon() (:223)
 };
 
+// number of parameters of a built-in collider shape (include/salva_hip.h); throws SALVA_HIP_E_INVALID for any other kind
+int shape_param_count(int kind);
+void shape_world_extent(const SalvaHipShape& shape, const float rotation_ijkw[4], float ext[3]);
 DcsParams dcs_params(const SalvaHipShape& shape, const SalvaHipRigidPose& pose, float h, float particle_radius, float dt);
 // one candidate (projection xyz, host particle index bits) and one flag per fluid particle; pushes particles inside the
 // shape out of it in place (positions and velocities of the sorted working set)

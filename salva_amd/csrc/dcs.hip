@@ -1,4 +1,4 @@
-// dcs.hip — ColliderSampling::DynamicContactSampling on the device for ball and cuboid colliders
+// dcs.hip — ColliderSampling::DynamicContactSampling on the device for ball, cuboid, capsule and cylinder colliders
 // (integrations/rapier/fluids_pipeline.rs:193-259).
 //
 // The reference walks the cells of the fluid grid that the collider's loosened AABB touches, projects every fluid particle
@@ -18,6 +18,13 @@
 //     Ball:   inside = |p|^2 <= r^2; proj = p * (r / |p|)
 //     Cuboid: shift = sup(mins - p, 0) - sup(p - maxs, 0); outside iff shift != 0 -> p + shift; inside -> the nearest face
 //             (the largest of mins - p, p - maxs over the axes)
+//     Capsule (new_y: segment a = (0, -hh, 0), b = (0, hh, 0)): s = the segment's closest point (ab.ap <= 0 -> a; >= |ab|^2 -> b;
+//             else a + ab (ab.ap / |ab|^2)); (dir, dist) = try_new_and_get(p - s, eps): inside = dist <= r, proj = s + dir r;
+//             a point ON the segment: s + (1, 0, 0) r (orthonormal_basis of the axis), inside
+//     Cylinder (axis y): planar = |(x, z)|, dir2 = (x, z) / planar ((1, 0) if planar <= eps); inside (|y| <= hh and planar <= r):
+//             the nearest of top / bottom / side (strict <, side wins ties); outside: clamp y to the caps and the plane
+//             point to the circle
+//   Capsule::aabb(pos) = [inf(A, B) - r, sup(A, B) + r] with A, B the posed segment ends; Cylinder::aabb(pos) = t -+ |R| (r, hh, r)
 // This file is compiled with -ffp-contract=off (see Makefile): Rust never fuses a*b+c, and the emitted points feed the
 // exact d^2 <= h^2 contact test.
 #include "dcs.h"
@@ -63,6 +70,45 @@ __global__ __launch_bounds__(BLOCK) void k_dcs_project(uint32_t n, float4* __res
         inside = d2 <= r * r;
         const float f = __fdiv_rn(r, sqrtf(d2));
         jx = lx * f; jy = ly * f; jz = lz * f;
+    } else if (s.kind == SALVA_HIP_SHAPE_CAPSULE) {
+        const float hh = s.p[0], r = s.p[1];
+        // a = (0, -hh, 0), ab = (0, hh - (-hh), 0), ap = p - a; dots as ((x0 y0 + x1 y1) + x2 y2)
+        const float aby = hh - (-hh);
+        const float apx = lx, apy = ly - (-hh), apz = lz;
+        const float ab_ap = (0.0f * apx + aby * apy) + 0.0f * apz;
+        const float sqnab = (0.0f * 0.0f + aby * aby) + 0.0f * 0.0f;
+        float sx = 0.0f, sy, sz = 0.0f;
+        if (ab_ap <= 0.0f) sy = -hh;
+        else if (ab_ap >= sqnab) sy = hh;
+        else { const float u = __fdiv_rn(ab_ap, sqnab); sx = 0.0f + 0.0f * u; sy = -hh + aby * u; sz = 0.0f + 0.0f * u; }
+        const float ex = lx - sx, ey = ly - sy, ez = lz - sz;
+        const float sq = (ex * ex + ey * ey) + ez * ez;
+        if (sq > s.eps * s.eps) {
+            const float dist = sqrtf(sq);
+            inside = dist <= r;
+            jx = sx + __fdiv_rn(ex, dist) * r; jy = sy + __fdiv_rn(ey, dist) * r; jz = sz + __fdiv_rn(ez, dist) * r;
+        } else {
+            inside = true;
+            jx = sx + 1.0f * r; jy = sy + 0.0f * r; jz = sz + 0.0f * r;
+        }
+    } else if (s.kind == SALVA_HIP_SHAPE_CYLINDER) {
+        const float hh = s.p[0], r = s.p[1];
+        const float planar = sqrtf(lx * lx + lz * lz);
+        float dx2 = __fdiv_rn(lx, planar), dz2 = __fdiv_rn(lz, planar);
+        if (planar <= s.eps) { dx2 = 1.0f; dz2 = 0.0f; }
+        const float qx = dx2 * r, qz = dz2 * r;
+        if (ly >= -hh && ly <= hh && planar <= r) {
+            inside = true;
+            const float top = hh - ly, bottom = ly - (-hh), side = r - planar;
+            if (top < bottom && top < side) { jx = lx; jy = hh; jz = lz; }
+            else if (bottom < top && bottom < side) { jx = lx; jy = -hh; jz = lz; }
+            else { jx = qx; jy = ly; jz = qz; }
+        } else {
+            inside = false;
+            if (ly > hh) { jy = hh; if (planar <= r) { jx = lx; jz = lz; } else { jx = qx; jz = qz; } }
+            else if (ly < -hh) { jy = -hh; if (planar <= r) { jx = lx; jz = lz; } else { jx = qx; jz = qz; } }
+            else { jx = qx; jy = ly; jz = qz; }
+        }
     } else {
         const float l3[3] = {lx, ly, lz};
         float mins_pt[3], pt_maxs[3], shift[3];
@@ -131,6 +177,32 @@ __global__ __launch_bounds__(BLOCK) void k_dcs_emit(uint32_t cnt, const float4* 
     src[i] = __float_as_uint(c.w);
 }
 
+// half extents of the posed shape's AABB about the pose's translation (parry compute_aabb, see the header of this file)
+void shape_world_extent(const SalvaHipShape& shape, const float q[4], float ext[3]) {
+    if (shape.kind == SALVA_HIP_SHAPE_BALL) {
+        ext[0] = ext[1] = ext[2] = shape.params[0];
+    } else if (shape.kind == SALVA_HIP_SHAPE_CAPSULE) {
+        // the posed segment ends are t -+ q * (0, hh, 0): extent = |q * b| + radius
+        const float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+        const float bx = 0.0f, by = shape.params[0], bz = 0.0f;
+        const float tx = (qy * bz - qz * by) * 2.0f, ty = (qz * bx - qx * bz) * 2.0f, tz = (qx * by - qy * bx) * 2.0f;
+        const float cx = qy * tz - qz * ty, cy = qz * tx - qx * tz, cz = qx * ty - qy * tx;
+        const float u[3] = {(tx * qw + cx) + bx, (ty * qw + cy) + by, (tz * qw + cz) + bz};
+        for (int a = 0; a < 3; ++a) ext[a] = std::fabs(u[a]) + shape.params[1];
+    } else {
+        // UnitQuaternion::to_rotation_matrix (nalgebra geometry/quaternion.rs), then |R| * half_extents
+        // (cylinder: the half extents of its local box are (radius, half_height, radius))
+        const float i = q[0], j = q[1], k = q[2], w = q[3];
+        const float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+        const float ij = i * j * 2.0f, wk = w * k * 2.0f, wj = w * j * 2.0f, ik = i * k * 2.0f, jk = j * k * 2.0f, wi = w * i * 2.0f;
+        const float m[3][3] = {{ww + ii - jj - kk, ij - wk, wj + ik}, {wk + ij, ww - ii + jj - kk, jk - wi}, {ik - wj, wi + jk, ww - ii - jj + kk}};
+        const bool cyl = shape.kind == SALVA_HIP_SHAPE_CYLINDER;
+        const float he[3] = {cyl ? shape.params[1] : shape.params[0], cyl ? shape.params[0] : shape.params[1], cyl ? shape.params[1] : shape.params[2]};
+        for (int a = 0; a < 3; ++a)
+            ext[a] = (std::fabs(m[a][0]) * he[0] + std::fabs(m[a][1]) * he[1]) + std::fabs(m[a][2]) * he[2];
+    }
+}
+
 // Ball::compute_aabb / Cuboid::compute_aabb of the posed shape, loosened by h + prediction (:196-199), and the cell range
 // HGrid::cells_intersecting_aabb walks (hgrid.rs:128-131).
 DcsParams dcs_params(const SalvaHipShape& shape, const SalvaHipRigidPose& pose, float h, float particle_radius, float dt) {
@@ -144,17 +216,7 @@ DcsParams dcs_params(const SalvaHipShape& shape, const SalvaHipRigidPose& pose, 
     s.dt = dt;
     s.eps = 1.1920929e-7f;
     float ext[3];
-    if (shape.kind == SALVA_HIP_SHAPE_BALL) {
-        ext[0] = ext[1] = ext[2] = shape.params[0];
-    } else {
-        // UnitQuaternion::to_rotation_matrix (nalgebra geometry/quaternion.rs), then |R| * half_extents
-        const float i = pose.rotation[0], j = pose.rotation[1], k = pose.rotation[2], w = pose.rotation[3];
-        const float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
-        const float ij = i * j * 2.0f, wk = w * k * 2.0f, wj = w * j * 2.0f, ik = i * k * 2.0f, jk = j * k * 2.0f, wi = w * i * 2.0f;
-        const float m[3][3] = {{ww + ii - jj - kk, ij - wk, wj + ik}, {wk + ij, ww - ii + jj - kk, jk - wi}, {ik - wj, wi + jk, ww - ii - jj + kk}};
-        for (int a = 0; a < 3; ++a)
-            ext[a] = (std::fabs(m[a][0]) * shape.params[0] + std::fabs(m[a][1]) * shape.params[1]) + std::fabs(m[a][2]) * shape.params[2];
-    }
+    shape_world_extent(shape, pose.rotation, ext);
     for (int a = 0; a < 3; ++a) {
         s.lo[a] = (pose.translation[a] - ext[a]) - s.reach;
         s.hi[a] = (pose.translation[a] + ext[a]) + s.reach;

@@ -1447,6 +1447,12 @@ __global__ __launch_bounds__(BLOCK) void k_shape_query(QuerySrc q, ShapeQuery s,
     float d;
     if (s.kind == SALVA_HIP_SHAPE_BALL) {
         d = fmaxf(sqrtf(lx * lx + ly * ly + lz * lz) - s.p[0], 0.0f);
+    } else if (s.kind == SALVA_HIP_SHAPE_CAPSULE) {  // distance to the segment (0, -hh..hh, 0), minus the radius
+        const float ey = ly - fminf(fmaxf(ly, -s.p[0]), s.p[0]);
+        d = fmaxf(sqrtf(lx * lx + ey * ey + lz * lz) - s.p[1], 0.0f);
+    } else if (s.kind == SALVA_HIP_SHAPE_CYLINDER) {  // beyond the caps and beyond the side
+        const float ey = fmaxf(fabsf(ly) - s.p[0], 0.0f), er = fmaxf(sqrtf(lx * lx + lz * lz) - s.p[1], 0.0f);
+        d = sqrtf(ey * ey + er * er);
     } else {
         const float dx = fmaxf(fabsf(lx) - s.p[0], 0.0f), dy = fmaxf(fabsf(ly) - s.p[1], 0.0f), dz = fmaxf(fabsf(lz) - s.p[2], 0.0f);
         d = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -1457,8 +1463,7 @@ __global__ __launch_bounds__(BLOCK) void k_shape_query(QuerySrc q, ShapeQuery s,
 uint64_t World::particles_in_shape(const float t[3], const float q[4], const SalvaHipShape& shape, uint64_t capacity, uint32_t* kinds,
                                    uint32_t* slots, uint32_t* indices) {
     use_device();
-    if (shape.kind != SALVA_HIP_SHAPE_BALL && shape.kind != SALVA_HIP_SHAPE_CUBOID)
-        throw HipError(SALVA_HIP_E_INVALID, "unknown shape kind (ball and cuboid are built in; other parry shapes belong to the host)");
+    const int nparams = shape_param_count(shape.kind);
     // the pose must be a rigid motion and the shape non-degenerate (the reference takes an Isometry and a parry shape, which
     // cannot be anything else): NaN / huge values would otherwise reach an undefined float -> int conversion below
     for (int a = 0; a < 3; ++a)
@@ -1471,7 +1476,7 @@ uint64_t World::particles_in_shape(const float t[3], const float q[4], const Sal
         }
         if (fabsf(qn - 1.0f) > 1.0e-3f) throw HipError(SALVA_HIP_E_INVALID, "shape query: the rotation must be a unit quaternion (x, y, z, w)");
     }
-    for (int a = 0; a < (shape.kind == SALVA_HIP_SHAPE_BALL ? 1 : 3); ++a)
+    for (int a = 0; a < nparams; ++a)
         if (!(shape.params[a] > 0.0f) || !std::isfinite(shape.params[a]))
             throw HipError(SALVA_HIP_E_INVALID, "shape query: radius / half extents must be positive and finite");
     const QuerySrc qf = query_fluid_source(), qb{bst_pos.p, nb, nullptr, nullptr, nullptr};
@@ -1479,18 +1484,9 @@ uint64_t World::particles_in_shape(const float t[3], const float q[4], const Sal
     for (int a = 0; a < 3; ++a) { s.t[a] = t[a]; s.p[a] = shape.params[a]; }
     for (int a = 0; a < 4; ++a) s.q[a] = q[a];
     s.kind = shape.kind; s.h = sc.h; s.r = prm.particle_radius;
-    // world AABB (parry compute_aabb): ball: t +- radius; cuboid: t +- |R| half_extents
+    // world AABB (parry compute_aabb; dcs.hip)
     float ext[3];
-    if (shape.kind == SALVA_HIP_SHAPE_BALL) {
-        ext[0] = ext[1] = ext[2] = shape.params[0];
-    } else {
-        const float x = q[0], y = q[1], z = q[2], w = q[3];
-        const float Rm[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
-                                {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
-                                {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
-        for (int a = 0; a < 3; ++a)
-            ext[a] = fabsf(Rm[a][0]) * shape.params[0] + fabsf(Rm[a][1]) * shape.params[1] + fabsf(Rm[a][2]) * shape.params[2];
-    }
+    shape_world_extent(shape, q, ext);
     for (int a = 0; a < 3; ++a) {  // (clamped like the cell coordinates of the particles: tile.h cell_coord)
         s.clo[a] = (int)std::min(std::max(floorf((t[a] - ext[a]) / sc.h), -1073741824.0f), 1073741824.0f);
         s.chi[a] = (int)std::min(std::max(floorf((t[a] + ext[a]) / sc.h), -1073741824.0f), 1073741824.0f);
@@ -1753,9 +1749,7 @@ void World::update_boundary_pose(uint32_t slot, const SalvaHipRigidPose& pose) {
 // 96-114): the boundary starts empty; every step re-emits its particles from the fluid near the collider.
 void World::set_boundary_dynamic_sampling(uint32_t slot, const SalvaHipShape& shape, uint32_t memberships, uint32_t filter) {
     if (comm) throw HipError(SALVA_HIP_E_INVALID, "DynamicContactSampling is not available in a multi-GPU run");
-    if (shape.kind != SALVA_HIP_SHAPE_BALL && shape.kind != SALVA_HIP_SHAPE_CUBOID)
-        throw HipError(SALVA_HIP_E_INVALID, "unknown shape kind (ball and cuboid are built in; other parry shapes belong to the host)");
-    const int np = shape.kind == SALVA_HIP_SHAPE_BALL ? 1 : 3;
+    const int np = shape_param_count(shape.kind);
     for (int a = 0; a < np; ++a)
         if (!(shape.params[a] > 0.0f) || !std::isfinite(shape.params[a])) throw HipError(SALVA_HIP_E_INVALID, "shape parameters must be positive");
     const bool keep_forces = slot < bounds.size() ? bounds[slot].wants_forces : false;
@@ -1767,6 +1761,16 @@ void World::set_boundary_dynamic_sampling(uint32_t slot, const SalvaHipShape& sh
     b.dyn_pose = SalvaHipRigidPose{};
     b.dyn_pose.rotation[3] = 1.0f;
     b.dyn_src = std::make_shared<DevBuf<uint32_t>>();
+}
+
+// parameters of a built-in collider shape (include/salva_hip.h); throws for any other kind
+int shape_param_count(int kind) {
+    switch (kind) {
+        case SALVA_HIP_SHAPE_BALL: return 1;
+        case SALVA_HIP_SHAPE_CUBOID: return 3;
+        case SALVA_HIP_SHAPE_CAPSULE: case SALVA_HIP_SHAPE_CYLINDER: return 2;
+        default: throw HipError(SALVA_HIP_E_INVALID, "unknown shape kind (ball, cuboid, capsule (y) and cylinder (y) are built in; other parry shapes belong to the host)");
+    }
 }
 
 bool World::has_dynamic_sampling() const {

@@ -1037,17 +1037,13 @@ class LiquidWorld:
         return out
 
     def particles_intersecting_shape(self, translation, rotation, shape):
-        """liquid_world.rs:245-280 for `shape` = ("ball", radius) or ("cuboid", (hx, hy, hz)) posed by the isometry
+        """liquid_world.rs:245-280 for `shape` = ("ball", radius), ("cuboid", (hx, hy, hz)), ("capsule", half_height, radius) or
+        ("cylinder", half_height, radius) (the last two along their local y axis) posed by the isometry
         (translation, unit quaternion (i, j, k, w)): particles within the particle radius of the solid shape."""
         self.sync_to_device(apply_removal=False)
-        sh = L.Shape()
-        if shape[0] == "ball":
-            sh.kind, sh.params[0] = L.SHAPE_BALL, float(shape[1])
-        elif shape[0] == "cuboid":
-            sh.kind = L.SHAPE_CUBOID
-            sh.params[:] = [float(x) for x in shape[1]]
-        else:
-            raise ValueError("built-in shapes: ('ball', radius), ('cuboid', half_extents)")
+        from .coupling import make_shape
+
+        sh = make_shape(shape)
         t = (C.c_float * 3)(*[float(x) for x in translation])
         q = (C.c_float * 4)(*[float(x) for x in rotation])
         u32p = C.POINTER(C.c_uint32)

@@ -20,6 +20,12 @@ pytestmark = pytest.mark.gpu
 R = 0.025
 CUBOID_HE = (0.30, 0.04, 0.22)
 BALL_R = 0.11
+# (oracle kind, oracle parameters, mirror shape) of the fixed collider under the block and of the body that enters it
+SHAPES = {
+    "cuboid+ball": ((2, CUBOID_HE, ("cuboid", CUBOID_HE)), (1, [BALL_R], ("ball", BALL_R))),
+    # a thin disc (cylinder along its local y) as the floor and a capsule as the body
+    "cylinder+capsule": ((4, [0.04, 0.34], ("cylinder", 0.04, 0.34)), (3, [0.07, 0.08], ("capsule", 0.07, 0.08))),
+}
 
 
 def _scene(n=14):
@@ -57,7 +63,7 @@ class Probe(NonPressureForce):
         self.positions = fluid.positions.copy()
 
 
-def _oracle_world(solver, pos, vel, f64=False, probe=None):
+def _oracle_world(solver, pos, vel, f64=False, probe=None, shapes="cuboid+ball"):
     w = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH, f64=f64)
     f = w.add_fluid(pos, 1000.0, vel)
     w.add_xsph(f, 0.5, 0.5)
@@ -65,8 +71,8 @@ def _oracle_world(solver, pos, vel, f64=False, probe=None):
         w.add_custom_force(f, lambda world, fl, positions, velocities, densities, acc: probe.append(positions.astype(np.float32)))
     empty = np.zeros((0, 3), np.float32)
     b0, b1 = w.add_boundary(empty), w.add_boundary(empty)
-    w.set_boundary_dynamic_sampling(b0, 2, CUBOID_HE)
-    w.set_boundary_dynamic_sampling(b1, 1, [BALL_R])
+    w.set_boundary_dynamic_sampling(b0, SHAPES[shapes][0][0], SHAPES[shapes][0][1])
+    w.set_boundary_dynamic_sampling(b1, SHAPES[shapes][1][0], SHAPES[shapes][1][1])
     return w, f
 
 
@@ -75,7 +81,7 @@ def _oracle_pose(w, slab, ball):
     w.update_boundary_pose(1, ball.translation, ball.rotation, ball.linvel, ball.angvel, ball.center_of_mass(), True, True)
 
 
-def _hip_world(solver, pos, vel, slab, ball, probe=None):
+def _hip_world(solver, pos, vel, slab, ball, probe=None, shapes="cuboid+ball"):
     w = LiquidWorld(DFSPHSolver() if solver == "dfsph" else IISPHSolver(), R, 2.0)
     fl = Fluid(pos, R, 1000.0)
     fl.velocities = vel
@@ -85,8 +91,8 @@ def _hip_world(solver, pos, vel, slab, ball, probe=None):
     h = w.add_fluid(fl)
     bounds = [w.add_boundary(Boundary(np.zeros((0, 3), np.float32))) for _ in range(2)]
     coupling = ColliderCouplingSet()
-    coupling.register_coupling(bounds[0], "slab", None, DynamicContactSampling(("cuboid", CUBOID_HE)))
-    coupling.register_coupling(bounds[1], "ball", ball, DynamicContactSampling(("ball", BALL_R)))
+    coupling.register_coupling(bounds[0], "slab", None, DynamicContactSampling(SHAPES[shapes][0][2]))
+    coupling.register_coupling(bounds[1], "ball", ball, DynamicContactSampling(SHAPES[shapes][1][2]))
     return w, h, bounds, coupling
 
 
@@ -103,12 +109,12 @@ def _by_source(fluid_ids, particle_ids, *arrays):
     return [particle_ids[order]] + [a[order] for a in arrays]
 
 
-@pytest.mark.parametrize("solver", ["dfsph", "iisph"])
-def test_first_step_is_bit_exact(solver):
+@pytest.mark.parametrize("solver,shapes", [("dfsph", "cuboid+ball"), ("iisph", "cuboid+ball"), ("dfsph", "cylinder+capsule")])
+def test_first_step_is_bit_exact(solver, shapes):
     pos, vel, slab, ball = _scene()
     oprobe, gprobe = [], Probe()
-    o, f = _oracle_world(solver, pos, vel, probe=oprobe)
-    w, h, bounds, coupling = _hip_world(solver, pos, vel, slab, ball, probe=gprobe)
+    o, f = _oracle_world(solver, pos, vel, probe=oprobe, shapes=shapes)
+    w, h, bounds, coupling = _hip_world(solver, pos, vel, slab, ball, probe=gprobe, shapes=shapes)
     # a previous substep length, as a continued run would carry it: the prediction x + v dt is exercised from the first step
     o.set_timestep(DT, 1.0 / DT)
     w.sync_to_device()

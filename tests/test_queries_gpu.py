@@ -1,4 +1,4 @@
-"""LiquidWorld::particles_intersecting_shape (liquid_world.rs:245-280) for the built-in ball and cuboid against a numpy
+"""LiquidWorld::particles_intersecting_shape (liquid_world.rs:245-280) for the built-in ball, cuboid, capsule and cylinder against a numpy
 restatement: cells of the posed shape's AABB (hgrid.rs:122-133), then distance to the solid shape <= particle radius."""
 import numpy as np
 import pytest
@@ -21,13 +21,23 @@ def reference(points, t, q, shape):
     p = points.astype(np.float64)
     conj = np.array([-q[0], -q[1], -q[2], q[3]], np.float64)
     local = quat_rotate(conj, p - np.asarray(t, np.float64))
+    Rm = np.stack([quat_rotate(np.asarray(q, np.float64), e) for e in np.eye(3)], axis=1)
     if shape[0] == "ball":
         d = np.maximum(np.linalg.norm(local, axis=1) - shape[1], 0.0)
         ext = np.full(3, shape[1])
+    elif shape[0] == "capsule":   # distance to the axis segment, minus the radius
+        hh, r = shape[1], shape[2]
+        seg = np.zeros_like(local)
+        seg[:, 1] = np.clip(local[:, 1], -hh, hh)
+        d = np.maximum(np.linalg.norm(local - seg, axis=1) - r, 0.0)
+        ext = np.abs(Rm @ np.array([0.0, hh, 0.0])) + r
+    elif shape[0] == "cylinder":  # beyond the caps and beyond the side
+        hh, r = shape[1], shape[2]
+        d = np.hypot(np.maximum(np.abs(local[:, 1]) - hh, 0.0), np.maximum(np.hypot(local[:, 0], local[:, 2]) - r, 0.0))
+        ext = np.abs(Rm) @ np.array([r, hh, r])
     else:
         he = np.asarray(shape[1], np.float64)
         d = np.linalg.norm(np.maximum(np.abs(local) - he, 0.0), axis=1)
-        Rm = np.stack([quat_rotate(np.asarray(q, np.float64), e) for e in np.eye(3)], axis=1)
         ext = np.abs(Rm) @ he
     cell = np.floor(points.astype(np.float64) / H)
     lo, hi = np.floor((np.asarray(t) - ext) / H), np.floor((np.asarray(t) + ext) / H)
@@ -35,7 +45,7 @@ def reference(points, t, q, shape):
     return d, inside
 
 
-@pytest.mark.parametrize("shape", [("ball", 0.22), ("cuboid", (0.3, 0.1, 0.2))])
+@pytest.mark.parametrize("shape", [("ball", 0.22), ("cuboid", (0.3, 0.1, 0.2)), ("capsule", 0.25, 0.12), ("cylinder", 0.12, 0.27)])
 def test_shape_query_matches_the_reference_formula(shape):
     pos = scenes.jitter(scenes.cube_fluid_positions(20, 20, 20, R), 0.3 * R, seed=9)
     bpos = scenes.plane_lattice(30, 30, -0.55, R, -0.75, -0.75)
