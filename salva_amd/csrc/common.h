@@ -70,15 +70,20 @@ inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b);
 // Device helpers
 // ---------------------------------------------------------------------------------------------------
 
-// MI355X dispatches workgroup b to XCD b % 8, each XCD with a private 4 MiB L2.  Particles are sorted by
-// cell, so neighbouring workgroups gather from overlapping cache lines: give each XCD one contiguous
-// eighth of the blocks (bijective for any grid size).  Placement only affects speed, never results.
-__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nblocks, int enabled) {
-    if (!enabled) return b;
-    const unsigned xcd = b & 7u, rank = b >> 3;
-    const unsigned q = nblocks >> 3, r = nblocks & 7u;
-    const unsigned base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-    return base + rank;
+// MI355X dispatches workgroup b to XCD b % 8, each XCD with a private 4 MiB L2.  Workgroup -> slot mapping of the tile
+// kernels: the XCDs take turns at groups of 2^(lg-1) consecutive slots (consecutive slots are neighbouring tiles, so a
+// group's halo lines meet in that XCD's L2), which spreads every part of the fluid evenly over the eight XCDs.  One
+// contiguous eighth per XCD (rounds 1-2) left the XCD with the fluid's half-empty +x face idle early: 4-6 % per
+// kernel at 10^6 and at 8 x 10^6; no remapping at all matches the grouped kernels' times but costs the apply kernels
+// their locality (3.66 vs 3.48 ms per settled step; profiles/r03_experiments/r03lm_xcd_groups.log).  Numbering the
+// slots so that the sparse tiles run last (a shorter tail in theory) and 4x4x4-tile bricks (more L2 reuse in theory)
+// were both measured slower (r03o_heavy_first*, r03k_brick_order*).  Bijective for any grid size (the tail that does not fill 8 whole
+// groups maps to itself).  Placement only affects speed, never results.  lg = 0: off.
+__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nblocks, unsigned lg) {
+    if (lg == 0u) return b;
+    const unsigned sh = lg - 1u, xcd = b & 7u, rank = b >> 3, span = 8u << sh;
+    if (b >= (nblocks & ~(span - 1u))) return b;
+    return ((((rank >> sh) << 3) | xcd) << sh) | (rank & ((1u << sh) - 1u));
 }
 
 // Wave-wide reductions by DPP: four row-local steps (quad swaps, half-row mirror, row mirror — after them every lane of a

@@ -68,7 +68,7 @@ static_assert(sizeof(SolveCtl) == 32, "SolveCtl: two 16-byte halves");
 
 struct StepCtx {
     SphConsts sc;
-    int xcd;  // XCD-aware block remap on/off
+    uint32_t xcd;  // workgroup -> slot mapping: 1 + log2 of the consecutive slots one XCD takes at a time (common.h xcd_block); 0 = off
 
     // ---- fluid particles, cell-sorted order ----
     uint32_t n;

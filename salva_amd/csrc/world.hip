@@ -611,7 +611,11 @@ void World::upload_tables() {
 StepCtx World::make_ctx() {
     StepCtx c{};
     c.sc = sc;
-    c.xcd = 1;
+    {   // groups of 64 slots (what one XCD's 32 CUs hold at a time), fewer for launches of less than 1024 tiles
+        uint32_t lg = 1u;
+        while (lg < 7u && (16u << lg) <= nlaunch) ++lg;
+        c.xcd = lg;
+    }
     c.n = n;
     c.posm = posm[cur].p; c.vel = vel[cur].p; c.dv = dv[cur].p; c.acc = acc.p; c.w = w.p; c.normal = normal.p;
     c.model = model[cur].p; c.perm = perm[cur].p; c.gtag = comm ? gtag[cur].p : nullptr;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B: groups of consecutive slots per XCD (SALVA_HIP_XCD_GROUPS = groups per XCD; 0 = no remapping)
+export TMPDIR=/tmp; O=gpurun_out/r03n; mkdir -p $O
+for rep in 1 2; do for k in 1 2 3 4 8 0; do
+  echo -n "groups/xcd=$k " >> $O/ab.log
+  SALVA_HIP_XCD_GROUPS=$k AB_PROBE_WATCHDOG=90 timeout 120 python tools/ab_probe.py --steps 25 --reps 30 --kernels 0,1,4 2>&1 | grep "^AB lib" >> $O/ab.log
+done; done
+for k in 1 2 4 8; do
+  echo -n "groups/xcd=$k " >> $O/ab8m.log
+  SALVA_HIP_XCD_GROUPS=$k AB_PROBE_WATCHDOG=90 timeout 120 python tools/ab_probe.py --side 200 --steps 8 --reps 10 --kernels 0,1,4 2>&1 | grep "^AB lib" >> $O/ab8m.log
+done
+for k in 1 2 4 8; do
+  echo -n "cfg3 groups/xcd=$k " >> $O/ab3.log
+  SALVA_HIP_XCD_GROUPS=$k AB_PROBE_WATCHDOG=90 timeout 120 python tools/ab_probe.py --config 3 --steps 15 --reps 10 --kernels 2,3 2>&1 | grep "^AB lib" >> $O/ab3.log
+done
+cat $O/ab.log $O/ab8m.log $O/ab3.log
