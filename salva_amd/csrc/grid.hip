@@ -401,7 +401,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uint32_t* __restrict__ halo_src,
                                                                  uint32_t* __restrict__ bhalo_src, uint4* __restrict__ slot_info) {
     Tile t;
-    t.setup(c);
+    t.setup(c, false);
     if (threadIdx.x == 0) slot_info[t.slot] = make_uint4(t.own_begin, t.own_end, t.slice_base, t.S | (t.SB << 16));
     TileCells tc;
     tc.build(c, t, true);
@@ -451,7 +451,7 @@ template <int V>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileListStats* __restrict__ tile_stats) {
     __shared__ uint32_t red[6][TILE_MAX_WAVES];
     Tile t;
-    t.setup(c);
+    t.setup(c, false);
     if (t.empty()) {
         if (threadIdx.x == 0) tile_stats[t.slot] = TileListStats{0, 0, 0, 0, 0, 0};
         return;

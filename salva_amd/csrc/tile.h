@@ -197,7 +197,20 @@ struct Tile {
     }
 
     // workgroup k of a launch works on slot k = the k-th non-empty tile (XCD-remapped so that neighbours share an L2)
-    __device__ __forceinline__ void setup(const StepCtx& c) { setup_at(c, xcd_block(blockIdx.x, gridDim.x, c.xcd)); }
+    // `stagger`: a 10^6-particle launch is ~4 rounds of resident tiles deep and its first round starts in lock step — every
+    // CU's tiles index, then stage (HBM busy, LDS idle), then sum (the reverse) at the same time, and the rounds after it
+    // inherit the rhythm.  Holding the first round's workgroups back in four phases (0 / 4 / 8 / 12 k cycles by rank)
+    // interleaves staging and summing from the start: -2..3 % on a settled step (k_divergence 50.2 -> 48.6 us); pointless
+    // for launches of fewer than two rounds and for k_nbr_tile, whose phases are not memory / LDS halves (it measured
+    // +2.5 %), which pass false (profiles/r03_experiments/r03qr_stagger.log).  Timing only.
+    __device__ __forceinline__ void setup(const StepCtx& c, bool stagger = true) {
+        if (stagger && gridDim.x >= 1024u) {
+            const unsigned rk = blockIdx.x >> 3;
+            if (rk < 64u)
+                for (unsigned i = 0; i < ((rk >> 4) & 3u); ++i) __builtin_amdgcn_s_sleep(64);
+        }
+        setup_at(c, xcd_block(blockIdx.x, gridDim.x, c.xcd));
+    }
     __device__ __forceinline__ void setup_at(const StepCtx& c, uint32_t at_slot) {
         pool = tile_smem;
         pool_used = 0;
