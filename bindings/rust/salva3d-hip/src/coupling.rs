@@ -17,14 +17,45 @@ pub enum ColliderSampling {
     /// Collider-local sample points (kept on the device: `salva_hip_set_boundary_sampling`).
     StaticSampling(Vec<Point<Real>>),
     /// Boundary particles = projections of the nearby fluid particles onto the collider, recomputed inside every step
-    /// (`salva_hip_set_boundary_dynamic_sampling`; Ball and Cuboid colliders).
+    /// (`salva_hip_set_boundary_dynamic_sampling` for Ball, Cuboid, Capsule (y) and Cylinder colliders — geometry on the
+    /// device; every other parry shape through `salva_hip_set_boundary_dynamic_sampling_host`: the loop on the device, the
+    /// shape's `compute_aabb` / `project_point_and_get_feature` called back here once per step).
     DynamicContactSampling,
+}
+
+/// What the host-shape callbacks see: the collider's shape and its pose as of this step's `update_boundaries`.
+struct HostShapeCtx {
+    shape: rapier3d::geometry::SharedShape,
+    position: na::Isometry3<Real>,
+}
+
+unsafe extern "C" fn host_aabb(user: *mut std::ffi::c_void, mins: *mut f32, maxs: *mut f32) {
+    let ctx = &*(user as *const HostShapeCtx);
+    let aabb = ctx.shape.compute_aabb(&ctx.position); // fluids_pipeline.rs:196-198 (the library loosens it)
+    for a in 0..3 {
+        *mins.add(a) = aabb.mins[a];
+        *maxs.add(a) = aabb.maxs[a];
+    }
+}
+
+unsafe extern "C" fn host_project(user: *mut std::ffi::c_void, n: u32, points: *const f32, projections: *mut f32, is_inside: *mut u8) {
+    let ctx = &*(user as *const HostShapeCtx);
+    for k in 0..n as usize {
+        let pt = Point::new(*points.add(3 * k), *points.add(3 * k + 1), *points.add(3 * k + 2));
+        let (proj, _feature) = ctx.shape.project_point_and_get_feature(&ctx.position, &pt); // :213-217
+        for a in 0..3 {
+            *projections.add(3 * k + a) = proj.point[a];
+        }
+        *is_inside.add(k) = proj.is_inside as u8;
+    }
 }
 
 struct Entry {
     sampling: ColliderSampling,
     boundary: BoundaryHandle,
     uploaded: bool,
+    /// `Some` for a collider whose shape is projected on the host; boxed so that the pointer the library holds stays valid
+    host_shape: Option<Box<HostShapeCtx>>,
 }
 
 /// fluids_pipeline.rs:64-136.
@@ -38,7 +69,7 @@ impl ColliderCouplingSet {
         Self::default()
     }
     pub fn register_coupling(&mut self, boundary: BoundaryHandle, collider: ColliderHandle, sampling: ColliderSampling) -> Option<BoundaryHandle> {
-        self.entries.insert(collider, Entry { sampling, boundary, uploaded: false }).map(|e| e.boundary)
+        self.entries.insert(collider, Entry { sampling, boundary, uploaded: false, host_shape: None }).map(|e| e.boundary)
     }
     pub fn unregister_coupling(&mut self, collider: ColliderHandle) -> Option<BoundaryHandle> {
         self.entries.remove(&collider).map(|e| e.boundary)
@@ -83,21 +114,40 @@ impl FluidsPipeline {
                         ffi::salva_hip_set_boundary_sampling(raw, slot, points.len() as u64, points.as_ptr() as *const f32, groups.memberships.bits(), groups.filter.bits())
                     })?,
                     ColliderSampling::DynamicContactSampling => {
-                        let shape = if let Some(b) = collider.shape().as_ball() {
-                            ffi::SalvaHipShape { kind: ffi::SALVA_HIP_SHAPE_BALL, params: [b.radius, 0.0, 0.0] }
+                        let builtin = if let Some(b) = collider.shape().as_ball() {
+                            Some(ffi::SalvaHipShape { kind: ffi::SALVA_HIP_SHAPE_BALL, params: [b.radius, 0.0, 0.0] })
                         } else if let Some(c) = collider.shape().as_cuboid() {
-                            ffi::SalvaHipShape { kind: ffi::SALVA_HIP_SHAPE_CUBOID, params: [c.half_extents.x, c.half_extents.y, c.half_extents.z] }
+                            Some(ffi::SalvaHipShape { kind: ffi::SALVA_HIP_SHAPE_CUBOID, params: [c.half_extents.x, c.half_extents.y, c.half_extents.z] })
+                        } else if let Some(c) = collider.shape().as_capsule().filter(|c| c.segment.a.x == 0.0 && c.segment.a.z == 0.0 && c.segment.b == -c.segment.a) {
+                            // Capsule::new_y; a capsule about another axis goes the host way below
+                            Some(ffi::SalvaHipShape { kind: ffi::SALVA_HIP_SHAPE_CAPSULE, params: [c.segment.b.y, c.radius, 0.0] })
+                        } else if let Some(c) = collider.shape().as_cylinder() {
+                            Some(ffi::SalvaHipShape { kind: ffi::SALVA_HIP_SHAPE_CYLINDER, params: [c.half_height, c.radius, 0.0] })
                         } else {
-                            // other parry shapes: project on the host (salva_hip_particles_intersecting_aabb + parry +
-                            // salva_hip_set_boundary), INTEGRATION.md §3
-                            return Err(Error { code: ffi::SALVA_HIP_E_INVALID, message: "DynamicContactSampling on the device: ball and cuboid colliders only".into() });
+                            None
                         };
-                        check(unsafe { ffi::salva_hip_set_boundary_dynamic_sampling(raw, slot, &shape, groups.memberships.bits(), groups.filter.bits()) })?
+                        match builtin {
+                            Some(shape) => check(unsafe { ffi::salva_hip_set_boundary_dynamic_sampling(raw, slot, &shape, groups.memberships.bits(), groups.filter.bits()) })?,
+                            None => {
+                                // any other parry shape: the two parry calls of the loop stay here
+                                let ctx = Box::new(HostShapeCtx { shape: collider.shared_shape().clone(), position: *collider.position() });
+                                let host = ffi::SalvaHipHostShape {
+                                    aabb: Some(host_aabb),
+                                    project: Some(host_project),
+                                    user: &*ctx as *const HostShapeCtx as *mut std::ffi::c_void,
+                                };
+                                check(unsafe { ffi::salva_hip_set_boundary_dynamic_sampling_host(raw, slot, &host, groups.memberships.bits(), groups.filter.bits()) })?;
+                                entry.host_shape = Some(ctx);
+                            }
+                        }
                     }
                 }
                 entry.uploaded = true;
             }
             let iso = collider.position();
+            if let Some(ctx) = entry.host_shape.as_mut() {
+                ctx.position = *iso; // what host_aabb / host_project apply during the step below
+            }
             let q = iso.rotation.coords; // (i, j, k, w): nalgebra's storage order
             let body = collider.parent().and_then(|p| bodies.get(p).map(|b| (p, b)));
             let mut pose = ffi::SalvaHipRigidPose {

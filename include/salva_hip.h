@@ -322,7 +322,8 @@ enum {
     SALVA_HIP_SHAPE_BALL = 1,      /* params[0] = radius */
     SALVA_HIP_SHAPE_CUBOID = 2,    /* params = half extents */
     SALVA_HIP_SHAPE_CAPSULE = 3,   /* parry Capsule::new_y: params[0] = half height of the segment along the local y axis, params[1] = radius */
-    SALVA_HIP_SHAPE_CYLINDER = 4   /* parry Cylinder (axis = local y): params[0] = half height, params[1] = radius */
+    SALVA_HIP_SHAPE_CYLINDER = 4,  /* parry Cylinder (axis = local y): params[0] = half height, params[1] = radius */
+    SALVA_HIP_SHAPE_HOST = 100     /* any other shape: its geometry stays with the host (SalvaHipHostShape below); never passed in a SalvaHipShape */
 };
 typedef struct SalvaHipShape {
     int32_t kind;
@@ -343,6 +344,23 @@ int64_t salva_hip_particles_intersecting_shape(SalvaHipWorld* world, const float
  * Registers boundary `slot` (created empty if slot == number of boundaries). */
 int salva_hip_set_boundary_dynamic_sampling(SalvaHipWorld* world, uint32_t slot, const SalvaHipShape* collider_shape,
                                             uint32_t memberships, uint32_t filter);
+/* The same arm for every other parry shape (triangle mesh, height field, convex polyhedron, compound, ...): the loop is the
+ * same, the two calls into parry stay on the host.  Inside every salva_hip_step, on the calling thread and at the same point
+ * of the step, the library calls `aabb` once (`collider.shape().compute_aabb(collider.position())`), copies the predicted
+ * positions of the fluid particles that pass the reference's two box tests (fluids_pipeline.rs:204-211) to the host, calls
+ * `project` once for all of them (`collider.shape().project_point_and_get_feature(collider.position(), &pt)` per point:
+ * world-space projection and `proj.is_inside`), and finishes the loop body — push-out, reach test, emission — on the device
+ * as for the built-in shapes.  Cost: two small PCIe round trips per step and collider.  The pose given to
+ * salva_hip_update_boundary_pose is used for `velocity_at_point` only.  Neither callback may call back into the world. */
+typedef void (*SalvaHipHostAabbFn)(void* user, float* mins_xyz, float* maxs_xyz);
+typedef void (*SalvaHipHostProjectFn)(void* user, uint32_t n, const float* points_xyz, float* projections_xyz, uint8_t* is_inside);
+typedef struct SalvaHipHostShape {
+    SalvaHipHostAabbFn aabb;
+    SalvaHipHostProjectFn project;
+    void* user;
+} SalvaHipHostShape;
+int salva_hip_set_boundary_dynamic_sampling_host(SalvaHipWorld* world, uint32_t slot, const SalvaHipHostShape* collider_shape,
+                                                 uint32_t memberships, uint32_t filter);
 /* (salva_hip_boundary_len reports what the last step emitted.) */
 /* For a dynamically sampled boundary: (fluid slot, particle index) of the fluid particle behind each of its points, in the
  * order of salva_hip_get_boundary_particles (the order itself is unspecified, as the reference's hash-grid walk is). */

@@ -206,6 +206,16 @@ class Boundary {  // object/boundary.rs
         b.dynamic_shape = SalvaHipShape{SALVA_HIP_SHAPE_CYLINDER, {half_height, radius, 0}};
         return b;
     }
+    // ... and for every other collider shape: the loop runs on the device, `aabb` / `project` (the two parry calls of the loop,
+    // see SalvaHipHostShape in salva_hip.h) are called back on the host once per step.  The callbacks and `user` must outlive
+    // the boundary's registration.
+    SalvaHipHostShape dynamic_host{nullptr, nullptr, nullptr};
+    static Boundary dynamic_host_shape(const SalvaHipHostShape& shape, InteractionGroups groups = {}) {
+        Boundary b({}, groups);
+        b.dynamic_shape = SalvaHipShape{SALVA_HIP_SHAPE_HOST, {0, 0, 0}};
+        b.dynamic_host = shape;
+        return b;
+    }
     size_t num_particles() const { return dynamic_shape.kind ? dynamic_n_ : (sampling.empty() ? positions.size() : sampling.size()); }
     void mark_dirty() { dirty_ = true; }
 
@@ -471,6 +481,12 @@ class LiquidWorld {  // liquid_world.rs
     void upload(Boundary& b, uint32_t slot) {
         if (!b.dirty_) return;
         const size_t n = b.num_particles();
+        if (b.dynamic_shape.kind == SALVA_HIP_SHAPE_HOST) {
+            check(salva_hip_set_boundary_dynamic_sampling_host(w_, slot, &b.dynamic_host, b.interaction_groups.memberships,
+                                                               b.interaction_groups.filter));
+            b.dirty_ = false;
+            return;
+        }
         if (b.dynamic_shape.kind) {
             check(salva_hip_set_boundary_dynamic_sampling(w_, slot, &b.dynamic_shape, b.interaction_groups.memberships,
                                                           b.interaction_groups.filter));

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_get_boundary_particles", "salva_hip_get_boundary_wrench", "salva_hip_set_force_callback",
     "salva_hip_force_get_state", "salva_hip_force_add_accelerations", "salva_hip_set_fluid_field", "salva_hip_get_timestep",
     "salva_hip_set_timestep", "salva_hip_get_counters", "salva_hip_time_kernel", "salva_hip_particles_intersecting_shape", "salva_hip_rebalance",
-    "salva_hip_set_boundary_dynamic_sampling", "salva_hip_get_boundary_sources",
+    "salva_hip_set_boundary_dynamic_sampling", "salva_hip_get_boundary_sources", "salva_hip_set_boundary_dynamic_sampling_host",
 ]
 
 
@@ -113,6 +113,14 @@ class Shape(C.Structure):
 
 SHAPE_BALL, SHAPE_CUBOID, SHAPE_CAPSULE, SHAPE_CYLINDER = 1, 2, 3, 4
 
+HOST_AABB_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float))
+HOST_PROJECT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint8))
+
+
+class HostShape(C.Structure):
+    """SalvaHipHostShape (include/salva_hip.h): a collider whose geometry stays with the host."""
+    _fields_ = [("aabb", HOST_AABB_FN), ("project", HOST_PROJECT_FN), ("user", C.c_void_p)]
+
 
 class SalvaHipError(RuntimeError):
     def __init__(self, code: int, message: str):
@@ -171,6 +179,7 @@ def lib():
     L.salva_hip_set_boundary_sampling.argtypes = [vp, u32, u64, fp, u32, u32]
     L.salva_hip_update_boundary_pose.argtypes = [vp, u32, C.POINTER(RigidPose)]
     L.salva_hip_set_boundary_dynamic_sampling.argtypes = [vp, u32, C.POINTER(Shape), u32, u32]
+    L.salva_hip_set_boundary_dynamic_sampling_host.argtypes = [vp, u32, C.POINTER(HostShape), u32, u32]
     L.salva_hip_get_boundary_sources.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u32)]
     L.salva_hip_get_boundary_particles.argtypes = [vp, u32, fp, fp]
     L.salva_hip_get_boundary_wrench.argtypes = [vp, u32, fp, fp, fp]

@@ -1,5 +1,6 @@
-"""Host mirror of salva's rigid-body coupling (src/integrations/rapier/fluids_pipeline.rs): the StaticSampling arm and, for ball
-and cuboid colliders, the DynamicContactSampling arm.
+"""Host mirror of salva's rigid-body coupling (src/integrations/rapier/fluids_pipeline.rs): the StaticSampling arm and the
+DynamicContactSampling arm — on the device for ball, cuboid, capsule and cylinder colliders, with the two parry calls left to the
+host for every other shape (HostShapeSampling).
 
 rapier is not part of this project (and not available here): `RigidBody` below carries exactly the state the coupling
 reads and writes — pose, velocities, centre of mass, mass properties — with rapier's formulas for the three methods the
@@ -124,11 +125,41 @@ class DynamicContactSampling:
         self.shape = make_shape(shape)
 
 
+class HostShapeSampling:
+    """ColliderSampling::DynamicContactSampling for a collider whose shape the library has no code for (triangle mesh, height
+    field, convex polyhedron, compound, ...): the loop of fluids_pipeline.rs:193-259 runs on the device, its two calls into the shape
+    come back to the host once per step (salva_hip_set_boundary_dynamic_sampling_host):
+
+      aabb()              -> (mins, maxs)               `collider.shape().compute_aabb(collider.position())`
+      project(points[n,3]) -> (projections[n,3], is_inside[n])
+                                                         `collider.shape().project_point_and_get_feature(collider.position(), pt)`
+
+    both in world space, f32.  The callables see the collider through their closure (e.g. the RigidBody whose pose they apply)."""
+
+    def __init__(self, aabb, project):
+        self._aabb, self._project = aabb, project
+
+        def aabb_cb(_user, mins, maxs):
+            lo, hi = self._aabb()
+            for a in range(3):
+                mins[a], maxs[a] = float(lo[a]), float(hi[a])
+
+        def project_cb(_user, n, pts, proj, inside):
+            p = np.ctypeslib.as_array(pts, shape=(n, 3))
+            out, ins = self._project(p.copy())
+            np.ctypeslib.as_array(proj, shape=(n, 3))[:] = np.asarray(out, F32).reshape(n, 3)
+            np.ctypeslib.as_array(inside, shape=(n,))[:] = np.asarray(ins).astype(np.uint8).reshape(n)
+
+        # (the ctypes thunks must outlive the registration: they hang on this object, which the coupling entry keeps)
+        self._thunks = (L.HOST_AABB_FN(aabb_cb), L.HOST_PROJECT_FN(project_cb))
+        self.shape = L.HostShape(self._thunks[0], self._thunks[1], None)
+
+
 @dataclass
 class _Entry:
     boundary: object
     body: Optional[RigidBody]
-    sampling: object  # StaticSampling | DynamicContactSampling
+    sampling: object  # StaticSampling | DynamicContactSampling | HostShapeSampling
     uploaded: bool = False
 
 
@@ -154,6 +185,12 @@ class ColliderCouplingSet:
             b = e.boundary
             if b._world is not world:
                 continue
+            if not e.uploaded and isinstance(e.sampling, HostShapeSampling):
+                b._sampled = b._dynamic = True
+                L.check(world._L.salva_hip_set_boundary_dynamic_sampling_host(
+                    world._h, b._slot, C.byref(e.sampling.shape), b.interaction_groups.memberships, b.interaction_groups.filter))
+                b._dirty = False
+                e.uploaded = True
             if not e.uploaded and isinstance(e.sampling, DynamicContactSampling):
                 b._sampled = b._dynamic = True
                 L.check(world._L.salva_hip_set_boundary_dynamic_sampling(

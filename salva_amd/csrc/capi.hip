@@ -195,6 +195,17 @@ int salva_hip_set_boundary_dynamic_sampling(SalvaHipWorld* world, uint32_t slot,
     });
 }
 
+int salva_hip_set_boundary_dynamic_sampling_host(SalvaHipWorld* world, uint32_t slot, const SalvaHipHostShape* collider_shape,
+                                                 uint32_t memberships, uint32_t filter) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        if (!collider_shape) throw salva::HipError(SALVA_HIP_E_INVALID, "null shape");
+        not_in_force_callback(world);
+        world->w->set_boundary_dynamic_sampling_host(slot, *collider_shape, memberships, filter);
+        return SALVA_HIP_OK;
+    });
+}
+
 int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t* fluid_slots, uint32_t* indices) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");

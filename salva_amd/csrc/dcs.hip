@@ -43,6 +43,41 @@ __device__ __forceinline__ void quat_rot(float qx, float qy, float qz, float qw,
     oz = (tz * qw + cz) + vz;
 }
 
+// the cell the particle was inserted under (hgrid.rs:122-133 filters CELLS by the box, then :211 tests the prediction)
+__device__ __forceinline__ bool dcs_in_cells(uint32_t k, const TileGrid& g, const DcsParams& s) {
+    const uint32_t tile = k / TCELLS, loc = k % TCELLS;
+    const int tz = (int)(tile % (uint32_t)g.ntz), ty = (int)((tile / (uint32_t)g.ntz) % (uint32_t)g.nty),
+              tx = (int)(tile / ((uint32_t)g.ntz * (uint32_t)g.nty));
+    const int cx = g.ox + tx * TX + (int)(loc / (TY * TZ)), cy = g.oy + ty * TY + (int)((loc / TZ) % TY),
+              cz = g.oz + tz * TZ + (int)(loc % TZ);
+    return !(cx < s.clo[0] || cx > s.chi[0] || cy < s.clo[1] || cy > s.chi[1] || cz < s.clo[2] || cz > s.chi[2]);
+}
+
+// :219-243 from the projection on: dpt = particle_pos - proj.point; a particle inside the shape is pushed out along dpt by
+// depth + margin and loses its velocity along it; one outside and farther than h + prediction emits nothing (false).
+__device__ __forceinline__ bool dcs_finish(uint32_t i, float4 p, float4 v, float px, float py, float pz, float wx, float wy, float wz,
+                                           bool inside, const DcsParams& s, float4* __restrict__ posm, float4* __restrict__ vel) {
+    const float dx = px - wx, dy = py - wy, dz = pz - wz;
+    const float sq = (dx * dx + dy * dy) + dz * dz;
+    if (sq > s.eps * s.eps) {  // Unit::try_new_and_get(dpt, f32::EPSILON)
+        const float depth = sqrtf(sq);
+        const float nx = __fdiv_rn(dx, depth), ny = __fdiv_rn(dy, depth), nz = __fdiv_rn(dz, depth);
+        if (inside) {
+            const float m = depth + s.margin;
+            p.x -= nx * m; p.y -= ny * m; p.z -= nz * m;
+            posm[i] = p;
+            const float vel_err = (nx * v.x + ny * v.y) + nz * v.z;
+            if (vel_err > 0.0f) {
+                v.x -= nx * vel_err; v.y -= ny * vel_err; v.z -= nz * vel_err;
+                vel[i] = v;
+            }
+        } else if (depth > s.reach) {
+            return false;
+        }
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_dcs_project(uint32_t n, float4* __restrict__ posm, float4* __restrict__ vel,
                                                        const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
                                                        TileGrid g, DcsParams s, float4* __restrict__ cand,
@@ -50,13 +85,7 @@ __global__ __launch_bounds__(BLOCK) void k_dcs_project(uint32_t n, float4* __res
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     flag[i] = 0;
-    // the cell the particle was inserted under (hgrid.rs:122-133 filters CELLS by the box, then :211 tests the prediction)
-    const uint32_t k = keys[i], tile = k / TCELLS, loc = k % TCELLS;
-    const int tz = (int)(tile % (uint32_t)g.ntz), ty = (int)((tile / (uint32_t)g.ntz) % (uint32_t)g.nty),
-              tx = (int)(tile / ((uint32_t)g.ntz * (uint32_t)g.nty));
-    const int cx = g.ox + tx * TX + (int)(loc / (TY * TZ)), cy = g.oy + ty * TY + (int)((loc / TZ) % TY),
-              cz = g.oz + tz * TZ + (int)(loc % TZ);
-    if (cx < s.clo[0] || cx > s.chi[0] || cy < s.clo[1] || cy > s.chi[1] || cz < s.clo[2] || cz > s.chi[2]) return;
+    if (!dcs_in_cells(keys[i], g, s)) return;
     float4 p = posm[i], v = vel[i];
     const float px = p.x + v.x * s.dt, py = p.y + v.y * s.dt, pz = p.z + v.z * s.dt;  // :206-207
     if (px < s.lo[0] || px > s.hi[0] || py < s.lo[1] || py > s.hi[1] || pz < s.lo[2] || pz > s.hi[2]) return;  // NaN: passes, as `<` / `>` do
@@ -138,26 +167,40 @@ __global__ __launch_bounds__(BLOCK) void k_dcs_project(uint32_t n, float4* __res
     float wx, wy, wz;
     quat_rot(s.q[0], s.q[1], s.q[2], s.q[3], jx, jy, jz, wx, wy, wz);
     wx += s.t[0]; wy += s.t[1]; wz += s.t[2];
-    const float dx = px - wx, dy = py - wy, dz = pz - wz;
-    const float sq = (dx * dx + dy * dy) + dz * dz;
-    if (sq > s.eps * s.eps) {  // Unit::try_new_and_get(dpt, f32::EPSILON)
-        const float depth = sqrtf(sq);
-        const float nx = __fdiv_rn(dx, depth), ny = __fdiv_rn(dy, depth), nz = __fdiv_rn(dz, depth);
-        if (inside) {
-            const float m = depth + s.margin;
-            p.x -= nx * m; p.y -= ny * m; p.z -= nz * m;
-            posm[i] = p;
-            const float vel_err = (nx * v.x + ny * v.y) + nz * v.z;
-            if (vel_err > 0.0f) {
-                v.x -= nx * vel_err; v.y -= ny * vel_err; v.z -= nz * vel_err;
-                vel[i] = v;
-            }
-        } else if (depth > s.reach) {
-            return;
-        }
+    if (dcs_finish(i, p, v, px, py, pz, wx, wy, wz, inside, s, posm, vel)) {
+        cand[i] = make_float4(wx, wy, wz, __uint_as_float(perm[i]));
+        flag[i] = 1;
     }
-    cand[i] = make_float4(wx, wy, wz, __uint_as_float(perm[i]));
+}
+
+// The host-shape arm (salva_hip_set_boundary_dynamic_sampling_host): the same pass cut in two around the host's
+// `project_point_and_get_feature`.  k_dcs_gather: the particles whose cell and predicted position pass the box tests
+// (:204-211), as (predicted position, sorted index); k_dcs_apply: the rest of the loop body for those, from the host's
+// (projection, is_inside).
+__global__ __launch_bounds__(BLOCK) void k_dcs_gather(uint32_t n, const float4* __restrict__ posm, const float4* __restrict__ vel,
+                                                      const uint32_t* __restrict__ keys, TileGrid g, DcsParams s,
+                                                      float4* __restrict__ cand, uint8_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = 0;
+    if (!dcs_in_cells(keys[i], g, s)) return;
+    const float4 p = posm[i], v = vel[i];
+    const float px = p.x + v.x * s.dt, py = p.y + v.y * s.dt, pz = p.z + v.z * s.dt;
+    if (px < s.lo[0] || px > s.hi[0] || py < s.lo[1] || py > s.hi[1] || pz < s.lo[2] || pz > s.hi[2]) return;
+    cand[i] = make_float4(px, py, pz, __uint_as_float(i));
     flag[i] = 1;
+}
+__global__ __launch_bounds__(BLOCK) void k_dcs_apply(uint32_t cnt, const float4* __restrict__ pred, const float4* __restrict__ proj,
+                                                     float4* __restrict__ posm, float4* __restrict__ vel, const uint32_t* __restrict__ perm,
+                                                     DcsParams s, float4* __restrict__ cand, uint8_t* __restrict__ flag) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= cnt) return;
+    const float4 pr = pred[k], w = proj[k];
+    const uint32_t i = __float_as_uint(pr.w);
+    const float4 p = posm[i], v = vel[i];
+    const bool keep = dcs_finish(i, p, v, pr.x, pr.y, pr.z, w.x, w.y, w.z, w.w != 0.0f, s, posm, vel);
+    flag[k] = keep ? 1 : 0;
+    if (keep) cand[k] = make_float4(w.x, w.y, w.z, __uint_as_float(perm[i]));
 }
 
 __global__ __launch_bounds__(BLOCK) void k_dcs_emit(uint32_t cnt, const float4* __restrict__ cand, SalvaHipRigidPose pose, uint32_t slot,
@@ -227,10 +270,42 @@ DcsParams dcs_params(const SalvaHipShape& shape, const SalvaHipRigidPose& pose, 
     return s;
 }
 
+// the host-shape arm: the box is the host's `collider.shape().compute_aabb(&collider_pos)`
+DcsParams dcs_params_host(const float mins[3], const float maxs[3], float h, float particle_radius, float dt) {
+    DcsParams s{};
+    s.kind = SALVA_HIP_SHAPE_HOST;
+    s.q[3] = 1.0f;
+    const float prediction = h * 0.5f;
+    s.margin = particle_radius * 0.1f;
+    s.reach = h + prediction;
+    s.dt = dt;
+    s.eps = 1.1920929e-7f;
+    for (int a = 0; a < 3; ++a) {
+        s.lo[a] = mins[a] - s.reach;
+        s.hi[a] = maxs[a] + s.reach;
+        const float fl = std::floor(s.lo[a] / h), fh = std::floor(s.hi[a] / h);
+        s.clo[a] = (int)std::fmin(std::fmax(fl, -1073741824.0f), 1073741824.0f);
+        s.chi[a] = (int)std::fmin(std::fmax(fh, -1073741824.0f), 1073741824.0f);
+    }
+    return s;
+}
+
 void launch_dcs_project(uint32_t n, float4* posm, float4* vel, const uint32_t* keys, const uint32_t* perm, TileGrid g,
                         const DcsParams& s, float4* cand, uint8_t* flag, hipStream_t st) {
     if (n == 0) return;
     k_dcs_project<<<div_up(n, BLOCK), BLOCK, 0, st>>>(n, posm, vel, keys, perm, g, s, cand, flag);
+    SALVA_HIP_CHECK(hipGetLastError());
+}
+void launch_dcs_gather(uint32_t n, const float4* posm, const float4* vel, const uint32_t* keys, TileGrid g, const DcsParams& s, float4* cand,
+                       uint8_t* flag, hipStream_t st) {
+    if (n == 0) return;
+    k_dcs_gather<<<div_up(n, BLOCK), BLOCK, 0, st>>>(n, posm, vel, keys, g, s, cand, flag);
+    SALVA_HIP_CHECK(hipGetLastError());
+}
+void launch_dcs_apply(uint32_t cnt, const float4* pred, const float4* proj, float4* posm, float4* vel, const uint32_t* perm,
+                      const DcsParams& s, float4* cand, uint8_t* flag, hipStream_t st) {
+    if (cnt == 0) return;
+    k_dcs_apply<<<div_up(cnt, BLOCK), BLOCK, 0, st>>>(cnt, pred, proj, posm, vel, perm, s, cand, flag);
     SALVA_HIP_CHECK(hipGetLastError());
 }
 void launch_dcs_emit(uint32_t cnt, const float4* cand, const SalvaHipRigidPose& pose, uint32_t slot, float4* pos, float4* vel,

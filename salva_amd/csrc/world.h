@@ -33,6 +33,7 @@ struct BoundarySlot {
     // re-emitted by every step (World::run_dynamic_sampling), `dyn_src` = host index of the fluid particle behind each
     int dyn_kind = 0;
     SalvaHipShape dyn_shape{};
+    SalvaHipHostShape dyn_host{};  // dyn_kind == SALVA_HIP_SHAPE_HOST: the host's compute_aabb / project_point callbacks
     SalvaHipRigidPose dyn_pose{};
     std::shared_ptr<DevBuf<uint32_t>> dyn_src;
 };
@@ -71,6 +72,7 @@ class World {
     void set_boundary_sampling(uint32_t slot, uint64_t n, const float* local_points, uint32_t memberships, uint32_t filter);
     void update_boundary_pose(uint32_t slot, const SalvaHipRigidPose& pose);
     void set_boundary_dynamic_sampling(uint32_t slot, const SalvaHipShape& shape, uint32_t memberships, uint32_t filter);
+    void set_boundary_dynamic_sampling_host(uint32_t slot, const SalvaHipHostShape& shape, uint32_t memberships, uint32_t filter);
     uint64_t boundary_len(uint32_t slot) const;
     void get_boundary_sources(uint32_t slot, uint32_t* fluid_slots, uint32_t* indices);
     void set_force_callback(SalvaHipForceCallback cb, void* user, SalvaHipWorld* owner) { force_cb = cb; force_user = user; force_owner = owner; }
@@ -119,7 +121,10 @@ class World {
     void resize_boundary_slot(uint32_t slot, uint64_t nn);
     bool has_dynamic_sampling() const;
     void run_dynamic_sampling();   // between the cell keys and the sort (fluids_pipeline.rs:193-259 inside liquid_world.rs:94-103)
-    DevBuf<float4> dcs_cand, dcs_out;
+    DevBuf<float4> dcs_cand, dcs_out, dcs_proj, dcs_cand2;  // (_proj, _cand2: the host-shape arm)
+    std::vector<float> dcs_h_pts, dcs_h_proj;
+    std::vector<float4> dcs_h_f4;
+    std::vector<uint8_t> dcs_h_inside;
     DevBuf<uint8_t> dcs_flag;
     DevBuf<uint32_t> dcs_num;
     void ensure_cub_temp(size_t bytes);

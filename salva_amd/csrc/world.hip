@@ -1767,6 +1767,21 @@ void World::set_boundary_dynamic_sampling(uint32_t slot, const SalvaHipShape& sh
     b.dyn_src = std::make_shared<DevBuf<uint32_t>>();
 }
 
+void World::set_boundary_dynamic_sampling_host(uint32_t slot, const SalvaHipHostShape& shape, uint32_t memberships, uint32_t filter) {
+    if (comm) throw HipError(SALVA_HIP_E_INVALID, "DynamicContactSampling is not available in a multi-GPU run");
+    if (!shape.aabb || !shape.project) throw HipError(SALVA_HIP_E_INVALID, "a host shape needs both callbacks");
+    const bool keep_forces = slot < bounds.size() ? bounds[slot].wants_forces : false;
+    set_boundary(slot, 0, nullptr, nullptr, memberships, filter, keep_forces);
+    BoundarySlot& b = bounds[slot];
+    b.sampling.reset();
+    b.dyn_kind = SALVA_HIP_SHAPE_HOST;
+    b.dyn_shape = SalvaHipShape{};
+    b.dyn_host = shape;
+    b.dyn_pose = SalvaHipRigidPose{};
+    b.dyn_pose.rotation[3] = 1.0f;
+    b.dyn_src = std::make_shared<DevBuf<uint32_t>>();
+}
+
 // parameters of a built-in collider shape (include/salva_hip.h); throws for any other kind
 int shape_param_count(int kind) {
     switch (kind) {
@@ -1820,7 +1835,42 @@ void World::run_dynamic_sampling() {
         BoundarySlot& b = bounds[slot];
         if (!b.dyn_kind) continue;
         uint32_t cnt = 0;
-        if (n) {
+        const float4* emit_src = nullptr;  // the compacted (projection, source particle) rows
+        if (n && b.dyn_kind == SALVA_HIP_SHAPE_HOST) {
+            // the host's shape: box tests on the device, the projections on the host, the rest of the loop body on the device
+            float mins[3], maxs[3];
+            b.dyn_host.aabb(b.dyn_host.user, mins, maxs);
+            for (int a = 0; a < 3; ++a)
+                if (!(mins[a] <= maxs[a])) throw HipError(SALVA_HIP_E_INVALID, "host shape: the aabb callback returned an empty or NaN box");
+            const DcsParams prm_d = dcs_params_host(mins, maxs, sc.h, prm.particle_radius, dt_prev);
+            dcs_cand.ensure(n, stream, false, 1.1f); dcs_out.ensure(n, stream, false, 1.1f); dcs_flag.ensure(n, stream, false, 1.1f);
+            dcs_num.ensure(1);
+            launch_dcs_gather(n, posm[cur].p, vel[cur].p, keys[0].p, gv, prm_d, dcs_cand.p, dcs_flag.p, stream);
+            const size_t tb = select_flagged_temp_bytes(n);
+            ensure_cub_temp(tb);
+            select_flagged_f4(cub_temp.p, tb, dcs_cand.p, dcs_flag.p, dcs_out.p, dcs_num.p, n, stream);
+            SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->dcs_count, dcs_num.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            wait_stream();
+            const uint32_t ng = h_rb->dcs_count;
+            if (ng) {
+                dcs_h_f4.resize(ng); dcs_h_pts.resize(3 * (size_t)ng); dcs_h_proj.assign(3 * (size_t)ng, 0.0f); dcs_h_inside.assign(ng, 0);
+                SALVA_HIP_CHECK(hipMemcpyAsync(dcs_h_f4.data(), dcs_out.p, (size_t)ng * sizeof(float4), hipMemcpyDeviceToHost, stream));
+                wait_stream();
+                for (uint32_t k = 0; k < ng; ++k) { dcs_h_pts[3 * k] = dcs_h_f4[k].x; dcs_h_pts[3 * k + 1] = dcs_h_f4[k].y; dcs_h_pts[3 * k + 2] = dcs_h_f4[k].z; }
+                b.dyn_host.project(b.dyn_host.user, ng, dcs_h_pts.data(), dcs_h_proj.data(), dcs_h_inside.data());
+                for (uint32_t k = 0; k < ng; ++k)
+                    dcs_h_f4[k] = make_float4(dcs_h_proj[3 * k], dcs_h_proj[3 * k + 1], dcs_h_proj[3 * k + 2], dcs_h_inside[k] ? 1.0f : 0.0f);
+                dcs_proj.ensure(ng, stream, false, 1.5f); dcs_cand2.ensure(ng, stream, false, 1.5f);
+                SALVA_HIP_CHECK(hipMemcpyAsync(dcs_proj.p, dcs_h_f4.data(), (size_t)ng * sizeof(float4), hipMemcpyHostToDevice, stream));
+                // (dcs_out holds the gathered candidates; its compaction goes back into dcs_cand, which is free again)
+                launch_dcs_apply(ng, dcs_out.p, dcs_proj.p, posm[cur].p, vel[cur].p, perm[cur].p, prm_d, dcs_cand2.p, dcs_flag.p, stream);
+                select_flagged_f4(cub_temp.p, tb, dcs_cand2.p, dcs_flag.p, dcs_cand.p, dcs_num.p, ng, stream);
+                SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->dcs_count, dcs_num.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                wait_stream();  // (also: dcs_h_f4 has been read)
+                cnt = h_rb->dcs_count;
+                emit_src = dcs_cand.p;
+            }
+        } else if (n) {
             const DcsParams prm_d = dcs_params(b.dyn_shape, b.dyn_pose, sc.h, prm.particle_radius, dt_prev);
             dcs_cand.ensure(n, stream, false, 1.1f); dcs_out.ensure(n, stream, false, 1.1f); dcs_flag.ensure(n, stream, false, 1.1f);
             dcs_num.ensure(1);
@@ -1831,13 +1881,14 @@ void World::run_dynamic_sampling() {
             SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->dcs_count, dcs_num.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             wait_stream();
             cnt = h_rb->dcs_count;
+            emit_src = dcs_out.p;
         }
         resize_boundary_slot(slot, cnt);
         b_dirty = true;  // same count, new positions
         if (cnt) {
             const uint64_t off = boundary_offset(slot);
             b.dyn_src->ensure(cnt, stream, false, 1.5f);
-            launch_dcs_emit(cnt, dcs_out.p, b.dyn_pose, slot, bst_pos.p + off, bst_vel.p + off, b.dyn_src->p, stream);
+            launch_dcs_emit(cnt, emit_src, b.dyn_pose, slot, bst_pos.p + off, bst_vel.p + off, b.dyn_src->p, stream);
             SALVA_HIP_CHECK(hipMemsetAsync(bforce.p + off, 0, (size_t)cnt * sizeof(float4), stream));  // clear_forces(true) :262
         }
     }

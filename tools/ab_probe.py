@@ -31,7 +31,7 @@ def build_world(config, side):
     """bench.py's scenes for configs 2 and 3 (without importing bench: that pulls in torch, a minute on a fresh box)."""
     fluid, shell = scenes.tank(side, side, side, R)
     fluid = scenes.jitter(fluid, 0.1 * R, seed=42)
-    w = LiquidWorld(IISPHSolver() if config == 3 else DFSPHSolver(), R, 2.0)
+    w = LiquidWorld(IISPHSolver() if config == 3 else DFSPHSolver(), R, float(os.environ.get("AB_SMOOTHING", "2.0")))
     f = Fluid(fluid, R, 1000.0)
     f.nonpressure_forces.append(Akinci2013SurfaceTension(1.0, 10.0) if config == 3 else XSPHViscosity(0.5, 0.0))
     h = w.add_fluid(f)
