@@ -44,12 +44,32 @@ fn default_params() -> ffi::SalvaHipParams {
     }
 }
 
-impl GpuPressureSolver for DFSPHSolver {
+/// The reference's kernels as the device knows them (`SALVA_HIP_KERNEL_*`): the solvers' `KernelDensity` / `KernelGradient`
+/// type parameters (dfsph_solver.rs:17-20, iisph_solver.rs:17-20) carry over unchanged.
+pub trait GpuKernel: salva3d::kernel::Kernel {
+    const KIND: i32;
+}
+impl GpuKernel for salva3d::kernel::CubicSplineKernel {
+    const KIND: i32 = ffi::SALVA_HIP_KERNEL_CUBIC_SPLINE;
+}
+impl GpuKernel for salva3d::kernel::Poly6Kernel {
+    const KIND: i32 = ffi::SALVA_HIP_KERNEL_POLY6;
+}
+impl GpuKernel for salva3d::kernel::SpikyKernel {
+    const KIND: i32 = ffi::SALVA_HIP_KERNEL_SPIKY;
+}
+impl GpuKernel for salva3d::kernel::ViscosityKernel {
+    const KIND: i32 = ffi::SALVA_HIP_KERNEL_VISCOSITY;
+}
+
+impl<KD: GpuKernel, KG: GpuKernel> GpuPressureSolver for DFSPHSolver<KD, KG> {
     fn params(&self, particle_radius: Real, smoothing_factor: Real) -> ffi::SalvaHipParams {
         let mut p = default_params();
         p.particle_radius = particle_radius;
         p.smoothing_factor = smoothing_factor;
         p.solver = ffi::SALVA_HIP_SOLVER_DFSPH;
+        p.kernel_density = KD::KIND;
+        p.kernel_gradient = KG::KIND;
         p.min_pressure_iter = self.min_pressure_iter as i32;
         p.max_pressure_iter = self.max_pressure_iter as i32;
         p.max_density_error = self.max_density_error;
@@ -60,12 +80,14 @@ impl GpuPressureSolver for DFSPHSolver {
     }
 }
 
-impl GpuPressureSolver for IISPHSolver {
+impl<KD: GpuKernel, KG: GpuKernel> GpuPressureSolver for IISPHSolver<KD, KG> {
     fn params(&self, particle_radius: Real, smoothing_factor: Real) -> ffi::SalvaHipParams {
         let mut p = default_params();
         p.particle_radius = particle_radius;
         p.smoothing_factor = smoothing_factor;
         p.solver = ffi::SALVA_HIP_SOLVER_IISPH;
+        p.kernel_density = KD::KIND;
+        p.kernel_gradient = KG::KIND;
         p.min_pressure_iter = self.min_pressure_iter as i32;
         p.max_pressure_iter = self.max_pressure_iter as i32;
         p.max_density_error = self.max_density_error;

@@ -39,6 +39,15 @@ enum {
 
 /* which pressure solver: solver::DFSPHSolver (dfsph_solver.rs) or solver::IISPHSolver (iisph_solver.rs) */
 enum { SALVA_HIP_SOLVER_DFSPH = 0, SALVA_HIP_SOLVER_IISPH = 1 };
+/* The `KernelDensity` / `KernelGradient` type parameters of DFSPHSolver<..> / IISPHSolver<..> (dfsph_solver.rs:17-20,
+ * iisph_solver.rs:17-20; src/kernel/{cubic_spline,poly6,spiky,viscosity}_kernel.rs).  Every contact's weight comes from the
+ * first and its gradient from the second (solver/helper.rs:9-63), for the solver and for every NonPressureForce. */
+enum {
+    SALVA_HIP_KERNEL_CUBIC_SPLINE = 0, /* the default of both parameters, and what every example and benchmark uses */
+    SALVA_HIP_KERNEL_POLY6 = 1,
+    SALVA_HIP_KERNEL_SPIKY = 2,
+    SALVA_HIP_KERNEL_VISCOSITY = 3
+};
 
 /* Mirrors `LiquidWorld::new(solver, particle_radius, smoothing_factor)` (liquid_world.rs:39-57) plus the
  * pub tuning fields of DFSPHSolver (dfsph_solver.rs:21-38, defaults :54-70) / IISPHSolver (iisph_solver.rs:21-30,
@@ -55,7 +64,9 @@ typedef struct SalvaHipParams {
     float max_divergence_error;      /* 0.1 (DFSPH only) */
     int32_t device;                  /* HIP device ordinal */
     int32_t enable_timers;           /* fill the *_ms fields of SalvaHipStepStats (Counters, counters/mod.rs:17-72) */
-    int32_t reserved[7];
+    int32_t kernel_density;          /* SALVA_HIP_KERNEL_* (0 = CubicSplineKernel) */
+    int32_t kernel_gradient;         /* SALVA_HIP_KERNEL_* (0 = CubicSplineKernel) */
+    int32_t reserved[5];
 } SalvaHipParams;
 
 /* Built-in `NonPressureForce` implementations that run on the device.  A `Fluid` holds a list of them

@@ -111,9 +111,23 @@ struct PressureSolver {
     Real max_density_error = 0.05f;
     int min_divergence_iter = 1, max_divergence_iter = 50;
     Real max_divergence_error = 0.1f;
+    int kernel_density = SALVA_HIP_KERNEL_CUBIC_SPLINE, kernel_gradient = SALVA_HIP_KERNEL_CUBIC_SPLINE;
 };
-struct DFSPHSolver : PressureSolver { DFSPHSolver() { kind = SALVA_HIP_SOLVER_DFSPH; } };
-struct IISPHSolver : PressureSolver { IISPHSolver() { kind = SALVA_HIP_SOLVER_IISPH; } };
+// src/kernel/*.rs as tags: the KernelDensity / KernelGradient type parameters of the solvers (dfsph_solver.rs:17-20)
+struct CubicSplineKernel { static constexpr int kind = SALVA_HIP_KERNEL_CUBIC_SPLINE; };
+struct Poly6Kernel { static constexpr int kind = SALVA_HIP_KERNEL_POLY6; };
+struct SpikyKernel { static constexpr int kind = SALVA_HIP_KERNEL_SPIKY; };
+struct ViscosityKernel { static constexpr int kind = SALVA_HIP_KERNEL_VISCOSITY; };
+template <class KernelDensity = CubicSplineKernel, class KernelGradient = CubicSplineKernel>
+struct DFSPHSolverT : PressureSolver {
+    DFSPHSolverT() { kind = SALVA_HIP_SOLVER_DFSPH; kernel_density = KernelDensity::kind; kernel_gradient = KernelGradient::kind; }
+};
+template <class KernelDensity = CubicSplineKernel, class KernelGradient = CubicSplineKernel>
+struct IISPHSolverT : PressureSolver {
+    IISPHSolverT() { kind = SALVA_HIP_SOLVER_IISPH; kernel_density = KernelDensity::kind; kernel_gradient = KernelGradient::kind; }
+};
+using DFSPHSolver = DFSPHSolverT<>;
+using IISPHSolver = IISPHSolverT<>;
 
 class LiquidWorld;
 
@@ -245,6 +259,7 @@ class LiquidWorld {  // liquid_world.rs
         p.particle_radius = particle_radius;
         p.smoothing_factor = smoothing_factor;
         p.solver = solver.kind;
+        p.kernel_density = solver.kernel_density; p.kernel_gradient = solver.kernel_gradient;
         p.min_pressure_iter = solver.min_pressure_iter; p.max_pressure_iter = solver.max_pressure_iter;
         p.max_density_error = solver.max_density_error;
         p.min_divergence_iter = solver.min_divergence_iter; p.max_divergence_iter = solver.max_divergence_iter;

@@ -66,6 +66,11 @@ def lib(native: bool = False):
         L.so_destroy.argtypes = [vp]
         L.so_set_shuffle_seed.argtypes = [vp, u64]
         L.so_set_threads.argtypes = [vp, i32]
+        L.so_set_kernels.argtypes = [vp, i32, i32]
+        L.so_kernel_scalar.argtypes = [i32, i32, C.c_float, C.c_float]
+        L.so_kernel_scalar.restype = C.c_float
+        L.so_kernel_scalar_f64.argtypes = [i32, i32, C.c_double, C.c_double]
+        L.so_kernel_scalar_f64.restype = C.c_double
         L.so_set_solver_params.argtypes = [vp, i32, i32, f32, i32, i32, f32]
         L.so_h.restype = f64
         L.so_h.argtypes = [vp]
@@ -158,6 +163,10 @@ class OracleWorld:
 
     def set_timestep(self, dt: float, inv_dt: float):
         self._L.so_set_timestep(self._h, dt, inv_dt)
+
+    def set_kernels(self, density: int, gradient: int):
+        """The solvers' KernelDensity / KernelGradient type parameters: 0 CubicSpline (default), 1 Poly6, 2 Spiky, 3 Viscosity."""
+        self._L.so_set_kernels(self._h, density, gradient)
 
     def set_threads(self, n: int):
         self._L.so_set_threads(self._h, n)

@@ -161,6 +161,74 @@ struct CubicSpline {
 };
 
 // ---------------------------------------------------------------------------------------------------
+// kernel/poly6_kernel.rs:8-40, kernel/spiky_kernel.rs:8-38, kernel/viscosity_kernel.rs:8-50 (dim3 normalizers)
+// ---------------------------------------------------------------------------------------------------
+template <typename R>
+struct Poly6 {
+    static R scalar_apply(R r, R h) {
+        R normalizer = (R)(315.0 / 64.0) / (CubicSpline<R>::PI * powi<R>(h, 9));
+        if (r <= h) return normalizer * powi<R>(h * h - r * r, 3);
+        return 0;
+    }
+    static R scalar_apply_diff(R r, R h) {
+        R normalizer = (R)(315.0 / 64.0) / (CubicSpline<R>::PI * powi<R>(h, 9));
+        if (r <= h) return normalizer * powi<R>(h * h - r * r, 2) * r * (R)-6.0;
+        return 0;
+    }
+};
+template <typename R>
+struct Spiky {
+    static R scalar_apply(R r, R h) {
+        R normalizer = (R)15.0 / (CubicSpline<R>::PI * powi<R>(h, 6));
+        if (r <= h) return normalizer * powi<R>(h - r, 3);
+        return 0;
+    }
+    static R scalar_apply_diff(R r, R h) {
+        R normalizer = (R)15.0 / (CubicSpline<R>::PI * powi<R>(h, 6));
+        if (r <= h) return -normalizer * powi<R>(h - r, 2) * (R)3.0;
+        return 0;
+    }
+};
+template <typename R>
+struct ViscosityK {
+    static R scalar_apply(R r, R h) {
+        const R _2 = 2, normalizer = (R)15.0 / (_2 * CubicSpline<R>::PI * powi<R>(h, 3));
+        if (r > (R)0 && r <= h) {
+            R rr_hh = r * r / (h * h);
+            return normalizer * (rr_hh * ((R)1 - r / (_2 * h)) + h / (_2 * r) - (R)1);
+        }
+        return 0;
+    }
+    static R scalar_apply_diff(R r, R h) {
+        const R _2 = 2, _3 = 3, normalizer = (R)15.0 / (_2 * CubicSpline<R>::PI * powi<R>(h, 3));
+        if (r > (R)0 && r <= h) {
+            R rr = r * r, hh = h * h, hhh = hh * h;
+            return normalizer * (-_3 * rr / (_2 * hhh) + _2 * r / hh - h / (_2 * rr));
+        }
+        return 0;
+    }
+};
+// the KernelDensity / KernelGradient type parameters of the solvers as run-time kinds (0 cubic spline, 1 poly6, 2 spiky,
+// 3 viscosity); Kernel::apply / apply_diff (kernel.rs:13-24)
+template <typename R>
+static R kernel_scalar(int kind, bool diff, R r, R h) {
+    switch (kind) {
+        case 1: return diff ? Poly6<R>::scalar_apply_diff(r, h) : Poly6<R>::scalar_apply(r, h);
+        case 2: return diff ? Spiky<R>::scalar_apply_diff(r, h) : Spiky<R>::scalar_apply(r, h);
+        case 3: return diff ? ViscosityK<R>::scalar_apply_diff(r, h) : ViscosityK<R>::scalar_apply(r, h);
+        default: return diff ? CubicSpline<R>::scalar_apply_diff(r, h) : CubicSpline<R>::scalar_apply(r, h);
+    }
+}
+template <typename R>
+static R kernel_apply(int kind, const V3<R>& v, R h) { return kernel_scalar<R>(kind, false, v.norm(), h); }
+template <typename R>
+static V3<R> kernel_apply_diff(int kind, const V3<R>& v, R h) {
+    V3<R> dir; R n;
+    if (try_new_and_get<R>(v, Eps<R>::v, dir, n)) return dir * kernel_scalar<R>(kind, true, n, h);
+    return V3<R>();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // object/interaction_groups.rs:64-69
 // ---------------------------------------------------------------------------------------------------
 struct Groups {
@@ -353,6 +421,7 @@ struct World {
     R particle_radius, h;
     int solver_kind;  // 0 = DFSPH, 1 = IISPH
     int nthreads = 1;
+    int kernel_density = 0, kernel_gradient = 0;  // KernelDensity / KernelGradient (dfsph_solver.rs:17-20): kinds of kernel_scalar
     uint64_t shuffle_seed = 0;
     std::vector<Fluid<R>> fluids;
     std::vector<Boundary<R>> boundaries;
@@ -690,14 +759,14 @@ struct World {
                 for (auto& c : ff[f].contacts[i]) {
                     const V3<R>& pi = fluids[c.i_model].positions[c.i];
                     const V3<R>& pj = fluids[c.j_model].positions[c.j];
-                    c.weight = CubicSpline<R>::apply(pi - pj, h);
-                    c.gradient = CubicSpline<R>::apply_diff(pi - pj, h);
+                    c.weight = kernel_apply<R>(kernel_density, pi - pj, h);
+                    c.gradient = kernel_apply_diff<R>(kernel_gradient, pi - pj, h);
                 }
                 for (auto& c : fb[f].contacts[i]) {
                     const V3<R>& pi = fluids[c.i_model].positions[c.i];
                     const V3<R>& pj = boundaries[c.j_model].positions[c.j];
-                    c.weight = CubicSpline<R>::apply(pi - pj, h);
-                    c.gradient = CubicSpline<R>::apply_diff(pi - pj, h);
+                    c.weight = kernel_apply<R>(kernel_density, pi - pj, h);
+                    c.gradient = kernel_apply_diff<R>(kernel_gradient, pi - pj, h);
                 }
             }
         }
@@ -708,8 +777,8 @@ struct World {
                 for (auto& c : bb[b].contacts[i]) {
                     const V3<R>& pi = boundaries[c.i_model].positions[c.i];
                     const V3<R>& pj = boundaries[c.j_model].positions[c.j];
-                    c.weight = CubicSpline<R>::apply(pi - pj, h);
-                    c.gradient = CubicSpline<R>::apply_diff(pi - pj, h);
+                    c.weight = kernel_apply<R>(kernel_density, pi - pj, h);
+                    c.gradient = kernel_apply_diff<R>(kernel_gradient, pi - pj, h);
                 }
             }
         }
@@ -1817,6 +1886,10 @@ void* so_create(int use_f64, float particle_radius, float smoothing_factor, int 
 void so_destroy(void* p) { Handle* h = (Handle*)p; delete h->wf; delete h->wd; delete h; }
 
 void so_set_shuffle_seed(void* p, uint64_t seed) { Handle* h = (Handle*)p; DISPATCH(h, w.shuffle_seed = seed, w.shuffle_seed = seed); }
+void so_set_kernels(void* p, int density, int gradient) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, { w.kernel_density = density; w.kernel_gradient = gradient; }, { w.kernel_density = density; w.kernel_gradient = gradient; });
+}
 void so_set_threads(void* p, int n) { Handle* h = (Handle*)p; DISPATCH(h, w.nthreads = n, w.nthreads = n); }
 void so_set_solver_params(void* p, int min_p, int max_p, float max_derr, int min_d, int max_d, float max_diverr) {
     Handle* h = (Handle*)p;
@@ -2033,6 +2106,8 @@ float so_kernel_w(float r, float h) { return CubicSpline<float>::scalar_apply(r,
 float so_kernel_dw(float r, float h) { return CubicSpline<float>::scalar_apply_diff(r, h); }
 double so_kernel_w_f64(double r, double h) { return CubicSpline<double>::scalar_apply(r, h); }
 double so_kernel_dw_f64(double r, double h) { return CubicSpline<double>::scalar_apply_diff(r, h); }
+double so_kernel_scalar_f64(int kind, int diff, double r, double h) { return kernel_scalar<double>(kind, diff != 0, r, h); }
+float so_kernel_scalar(int kind, int diff, float r, float h) { return kernel_scalar<float>(kind, diff != 0, r, h); }
 float so_cohesion_kernel(float r, float h) { return World<float>::cohesion_kernel(r, h); }
 float so_adhesion_kernel(float r, float h) { return World<float>::adhesion_kernel(r, h); }
 int so_max_threads(void) {

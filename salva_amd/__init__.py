@@ -10,6 +10,7 @@ from .world import (  # noqa: F401
     ArtificialViscosity,
     Boundary,
     Counters,
+    CubicSplineKernel,
     DFSPHSolver,
     DFSPHViscosity,
     Fluid,
@@ -18,13 +19,16 @@ from .world import (  # noqa: F401
     InteractionGroups,
     LiquidWorld,
     NonPressureForce,
+    Poly6Kernel,
+    SpikyKernel,
+    ViscosityKernel,
     WCSPHSurfaceTension,
     XSPHViscosity,
 )
 
 __all__ = [
-    "Akinci2013SurfaceTension", "ArtificialViscosity", "Boundary", "Counters", "DFSPHSolver", "DFSPHViscosity", "Fluid", "He2014SurfaceTension", "IISPHSolver",
-    "InteractionGroups", "LiquidWorld", "NonPressureForce", "WCSPHSurfaceTension", "XSPHViscosity", "coupling", "dist", "scenes",
+    "Akinci2013SurfaceTension", "ArtificialViscosity", "Boundary", "Counters", "CubicSplineKernel", "DFSPHSolver", "DFSPHViscosity", "Fluid", "He2014SurfaceTension", "IISPHSolver",
+    "InteractionGroups", "LiquidWorld", "NonPressureForce", "Poly6Kernel", "SpikyKernel", "ViscosityKernel", "WCSPHSurfaceTension", "XSPHViscosity", "coupling", "dist", "scenes",
 ]
 
 

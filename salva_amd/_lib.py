@@ -53,7 +53,9 @@ class Params(C.Structure):
         ("max_divergence_error", C.c_float),
         ("device", C.c_int32),
         ("enable_timers", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("kernel_density", C.c_int32),
+        ("kernel_gradient", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -111,6 +113,7 @@ class Shape(C.Structure):
     _fields_ = [("kind", C.c_int32), ("params", C.c_float * 3)]
 
 
+KERNEL_CUBIC_SPLINE, KERNEL_POLY6, KERNEL_SPIKY, KERNEL_VISCOSITY = 0, 1, 2, 3
 SHAPE_BALL, SHAPE_CUBOID, SHAPE_CAPSULE, SHAPE_CYLINDER = 1, 2, 3, 4
 
 HOST_AABB_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float))

@@ -63,6 +63,25 @@ struct DevBuf {
     size_t bytes() const { return cap * sizeof(T); }
 };
 
+// The kernel sources (dfsph.hip, iisph.hip, forces.hip, visc.hip) are compiled twice: as they are (namespace salva, the cubic
+// spline everywhere) and with -DSALVA_OTHER_KERNELS into namespace salva_ok, where sph_math.h also knows the reference's
+// other kernels.  Every launcher that ends in a kernel evaluation starts with SALVA_OK_DISPATCH: a world whose solver was
+// created with a non-default KernelDensity / KernelGradient is handed to the second compilation, and the default build's
+// kernels carry no trace of the choice (no branch, no extra register).
+#ifdef SALVA_OTHER_KERNELS
+#define SALVA_KNS salva_ok
+#define SALVA_OK_DISPATCH(fn, c, ...)
+#else
+#define SALVA_KNS salva
+#define SALVA_OK_DISPATCH(fn, c, ...)                 \
+    do {                                              \
+        if (((c).sc.kd | (c).sc.kg) != 0) {           \
+            salva_ok::fn(c, ##__VA_ARGS__);           \
+            return;                                   \
+        }                                             \
+    } while (0)
+#endif
+
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 #ifdef __HIPCC__

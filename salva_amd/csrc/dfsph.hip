@@ -11,13 +11,15 @@
 #include "kernels.h"
 #include "tile.h"
 
-namespace salva {
+namespace SALVA_KNS {
+using namespace salva;
 
 unsigned num_blocks(uint32_t n) { return div_up(n, BLOCK); }
 
-}  // namespace salva
+}  // namespace SALVA_KNS
 #include "pairs.h"
-namespace salva {
+namespace SALVA_KNS {
+using namespace salva;
 
 // ------------------------------------------------------------------------------------------------
 // compute_densities (dfsph_solver.rs:628-665) fused with compute_alphas (:165-216): both depend on positions only.
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
     });
 }
 void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_density_alpha, c, L, s);
     SALVA_LAUNCH_TILE(k_density_alpha, c, L, L.bytes(16, 16, 2), s, c);
 }
 
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
-        const bool near = slice_is_near(o.near);
+        const bool near = slice_is_near(c, o.near);
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     E.finish(c, t.slot);
 }
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_divergence, c, L, s);
     const uint32_t ds = pick_ds(pw_slots(L));
     SALVA_LAUNCH_FIXED(k_divergence, ds, c, L, pw_bytes(L, ds, true), s, c);
 }
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
     Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
-        const bool near = slice_is_near(o.near);
+        const bool near = slice_is_near(c, o.near);
         if (!active) return;
         const float4 pi = o.pi;
         const uint32_t mi = __float_as_uint(o.wi.w);
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
     });
 }
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_divergence_apply, c, L, inv_dt_prev, s);
     const uint32_t ds = pick_ds(pk_slots(L));
     SALVA_LAUNCH_FIXED(k_divergence_apply, ds, c, L, pk_bytes(L, ds), s, c, inv_dt_prev);
 }
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
     SALVA_DIAG_STAMP(T3);
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
-        const bool near = slice_is_near(o.near);
+        const bool near = slice_is_near(c, o.near);
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
 #endif
 }
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_pred_density, c, L, dt, s);
     const uint32_t ds = pick_ds(pw_slots(L));
     SALVA_LAUNCH_FIXED(k_pred_density, ds, c, L, pw_bytes(L, ds, true), s, c, dt);
 }
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
     Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
-        const bool near = slice_is_near(o.near);
+        const bool near = slice_is_near(c, o.near);
         if (!active) return;
         const float4 pi = o.pi;
         const uint32_t mi = o.mi;
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
     });
 }
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_pressure_apply, c, L, inv_dt, s);
     const uint32_t ds = pick_ds(pk_slots(L));
     SALVA_LAUNCH_FIXED(k_pressure_apply, ds, c, L, pk_bytes(L, ds), s, c, inv_dt);
 }
@@ -521,4 +528,50 @@ void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmo
     k_finalize_error<<<1, BLOCK, 0, s>>>(partials, nblocks, nmodels, model_counts, ctl, pub);
 }
 
-}  // namespace salva
+// ------------------------------------------------------------------------------------------------ boundary volumes
+// dfsph_solver.rs:72-96: V_b = 1 / sum over boundary-boundary contacts of W (same boundary always, other
+// boundaries when their interaction groups allow, contacts.rs:261-296).  No list is kept: the sum is evaluated
+// straight from the boundary cell table, once per change of the boundary set.
+__global__ __launch_bounds__(BLOCK) void k_boundary_volumes(StepCtx c, unsigned long long* ncontacts_bb) {
+    __shared__ float red[BLOCK / WAVE];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t cnt = 0;
+    if (i < c.nb) {
+        const float4 pi = c.bposv[i];
+        const uint32_t mi = __float_as_uint(c.bvel[i].w);
+        bool bad = false;
+        const int cx = cell_coord(pi.x, c.sc.h, bad), cy = cell_coord(pi.y, c.sc.h, bad), cz = cell_coord(pi.z, c.sc.h, bad);
+        float denom = 0.0f;
+        for (int d = 0; d < 27; ++d) {
+            bool in;
+            const uint32_t k = tile_key(c.gb, cx + d / 9 - 1, cy + (d / 3) % 3 - 1, cz + d % 3 - 1, in);
+            if (!in) continue;
+            const uint32_t b = c.gb.cell_start[k], e = c.gb.cell_start[k + 1];
+            for (uint32_t j = b; j < e; ++j) {
+                const float4 pj = c.bposv[j];
+                const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
+                if (d2 <= c.sc.h2) {
+                    const uint32_t mj = __float_as_uint(c.bvel[j].w);
+                    if (mi == mj || c.bb_ok[mi * c.nbmodels + mj]) {
+                        denom += kernel_weight(d2, c.sc);
+                        ++cnt;
+                    }
+                }
+            }
+        }
+        if (!(denom > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!denominator.is_zero()) dfsph_solver.rs:92
+        // a decomposed run replicates the boundary particles near a slab face on both ranks: each contact is reported by the rank
+        // whose slab holds its first particle, so that the ranks' counts add up to the undivided domain's
+        if (!(cx > c.ghost_lo_cx && cx < c.ghost_hi_cx)) cnt = 0;
+        reinterpret_cast<float*>(&c.bposv[i])[3] = 1.0f / denom;
+    }
+    const float tot = block_sum((float)cnt, red);
+    if (threadIdx.x == 0 && tot > 0.0f) atomicAdd(ncontacts_bb, (unsigned long long)tot);
+}
+void launch_boundary_volumes(const StepCtx& c, unsigned long long* ncontacts_bb, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_boundary_volumes, c, ncontacts_bb, s);
+    if (c.nb == 0) return;
+    k_boundary_volumes<<<div_up(c.nb, BLOCK), BLOCK, 0, s>>>(c, ncontacts_bb);
+}
+
+}  // namespace SALVA_KNS

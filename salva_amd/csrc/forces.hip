@@ -11,7 +11,8 @@
 #include "kernels.h"
 #include "tile.h"
 
-namespace salva {
+namespace SALVA_KNS {
+using namespace salva;
 
 // ------------------------------------------------------------------------------------------------ XSPH
 // a_i += inv_dt * [ sum_j (v_j - v_i) c_f W_ij m_j / rho_j  +  sum_b (v_b - v_i) c_b W_ib V_b rho0 / rho_i ]
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
 }
 void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff,
                  float inv_dt_prev, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_xsph, c, L, model, fluid_coeff, boundary_coeff, inv_dt_prev, s);
     SALVA_LAUNCH_TILE(k_xsph, c, L, L.bytes(36, 32, 5), s, c, model, fluid_coeff, boundary_coeff, inv_dt_prev);
 }
 
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_artificial_viscosity(StepC
 }
 void launch_artificial_viscosity(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff,
                                  float boundary_coeff, float alpha, float beta, float speed_of_sound, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_artificial_viscosity, c, L, model, fluid_coeff, boundary_coeff, alpha, beta, speed_of_sound, s);
     SALVA_LAUNCH_TILE(k_artificial_viscosity, c, L, L.bytes(36, 32, 5), s, c, model, fluid_coeff, boundary_coeff, alpha, beta,
                       speed_of_sound);
 }
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_normals(StepCtx c, 
     });
 }
 void launch_akinci_normals(const StepCtx& c, const TileLds& L, uint32_t model, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_akinci_normals, c, L, model, s);
     SALVA_LAUNCH_TILE(k_akinci_normals, c, L, L.bytes(24, 0, 3), s, c, model);
 }
 
@@ -277,6 +281,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, u
     });
 }
 void launch_akinci_forces(const StepCtx& c, const TileLds& L, uint32_t model, float tension, float adhesion, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_akinci_forces, c, L, model, tension, adhesion, s);
     const double h = c.sc.h;
     // normalisers evaluated in f64 on the host then rounded once
     const float cnorm = (float)(32.0 / (3.14159265358979323846 * pow(h, 9)));
@@ -414,13 +419,16 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_he2014_forces(StepCtx c, u
     });
 }
 void launch_he2014_colors(const StepCtx& c, const TileLds& L, uint32_t model, float* colors, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_he2014_colors, c, L, model, colors, s);
     SALVA_LAUNCH_TILE(k_he2014_colors, c, L, L.bytes(24, 16, 4), s, c, model, colors);
 }
 void launch_he2014_gradc(const StepCtx& c, const TileLds& L, uint32_t model, const float* colors, float* gradcs, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_he2014_gradc, c, L, model, colors, gradcs, s);
     SALVA_LAUNCH_TILE(k_he2014_gradc, c, L, L.bytes(28, 0, 4), s, c, model, colors, gradcs);
 }
 void launch_he2014_forces(const StepCtx& c, const TileLds& L, uint32_t model, float tension, float boundary_tension,
                           const float* gradcs, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_he2014_forces, c, L, model, tension, boundary_tension, gradcs, s);
     SALVA_LAUNCH_TILE(k_he2014_forces, c, L, L.bytes(28, 32, 6), s, c, model, tension, boundary_tension, gradcs);
 }
 
@@ -458,7 +466,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_wcsph_tension(StepCtx c, u
     });
 }
 void launch_wcsph_tension(const StepCtx& c, const TileLds& L, uint32_t model, float tension, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_wcsph_tension, c, L, model, tension, s);
     SALVA_LAUNCH_TILE(k_wcsph_tension, c, L, L.bytes(20, 0, 2), s, c, model, tension);
 }
 
-}  // namespace salva
+}  // namespace SALVA_KNS

@@ -648,49 +648,4 @@ void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsi
     k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.nlaunch, totals2, maxima2, own2);
 }
 
-// ------------------------------------------------------------------------------------------------ boundary volumes
-// dfsph_solver.rs:72-96: V_b = 1 / sum over boundary-boundary contacts of W (same boundary always, other
-// boundaries when their interaction groups allow, contacts.rs:261-296).  No list is kept: the sum is evaluated
-// straight from the boundary cell table, once per change of the boundary set.
-__global__ __launch_bounds__(BLOCK) void k_boundary_volumes(StepCtx c, unsigned long long* ncontacts_bb) {
-    __shared__ float red[BLOCK / WAVE];
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    uint32_t cnt = 0;
-    if (i < c.nb) {
-        const float4 pi = c.bposv[i];
-        const uint32_t mi = __float_as_uint(c.bvel[i].w);
-        bool bad = false;
-        const int cx = cell_coord(pi.x, c.sc.h, bad), cy = cell_coord(pi.y, c.sc.h, bad), cz = cell_coord(pi.z, c.sc.h, bad);
-        float denom = 0.0f;
-        for (int d = 0; d < 27; ++d) {
-            bool in;
-            const uint32_t k = tile_key(c.gb, cx + d / 9 - 1, cy + (d / 3) % 3 - 1, cz + d % 3 - 1, in);
-            if (!in) continue;
-            const uint32_t b = c.gb.cell_start[k], e = c.gb.cell_start[k + 1];
-            for (uint32_t j = b; j < e; ++j) {
-                const float4 pj = c.bposv[j];
-                const float d2 = dist2_exact(pi.x - pj.x, pi.y - pj.y, pi.z - pj.z);
-                if (d2 <= c.sc.h2) {
-                    const uint32_t mj = __float_as_uint(c.bvel[j].w);
-                    if (mi == mj || c.bb_ok[mi * c.nbmodels + mj]) {
-                        denom += kernel_weight(d2, c.sc);
-                        ++cnt;
-                    }
-                }
-            }
-        }
-        if (!(denom > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!denominator.is_zero()) dfsph_solver.rs:92
-        // a decomposed run replicates the boundary particles near a slab face on both ranks: each contact is reported by the rank
-        // whose slab holds its first particle, so that the ranks' counts add up to the undivided domain's
-        if (!(cx > c.ghost_lo_cx && cx < c.ghost_hi_cx)) cnt = 0;
-        reinterpret_cast<float*>(&c.bposv[i])[3] = 1.0f / denom;
-    }
-    const float tot = block_sum((float)cnt, red);
-    if (threadIdx.x == 0 && tot > 0.0f) atomicAdd(ncontacts_bb, (unsigned long long)tot);
-}
-void launch_boundary_volumes(const StepCtx& c, unsigned long long* ncontacts_bb, hipStream_t s) {
-    if (c.nb == 0) return;
-    k_boundary_volumes<<<div_up(c.nb, BLOCK), BLOCK, 0, s>>>(c, ncontacts_bb);
-}
-
 }  // namespace salva

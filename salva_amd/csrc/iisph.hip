@@ -10,7 +10,8 @@
 #include "kernels.h"
 #include "tile.h"
 
-namespace salva {
+namespace SALVA_KNS {
+using namespace salva;
 
 // `acceleration += gravity` (:550-554)
 __global__ __launch_bounds__(BLOCK) void k_iisph_begin(StepCtx c, float gx, float gy, float gz, int acc_has_user) {
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dii(StepCtx c, float
     });
 }
 void launch_iisph_dii(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_iisph_dii, c, L, dt, s);
     SALVA_LAUNCH_TILE(k_iisph_dii, c, L, L.bytes(16, 16, 2), s, c, dt);
 }
 
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_pred_density(StepCtx
     });
 }
 void launch_iisph_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_iisph_pred_density, c, L, dt, s);
     SALVA_LAUNCH_TILE(k_iisph_pred_density, c, L, L.bytes(32, 32, 4), s, c, dt);
 }
 
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_aii(StepCtx c, float
     });
 }
 void launch_iisph_aii(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_iisph_aii, c, L, dt, s);
     SALVA_LAUNCH_TILE(k_iisph_aii, c, L, L.bytes(16, 16, 2), s, c, dt);
 }
 
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dij_pj(StepCtx c, fl
     });
 }
 void launch_iisph_dij_pj(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_iisph_dij_pj, c, L, dt, p, s);
     SALVA_LAUNCH_TILE(k_iisph_dij_pj, c, L, L.bytes(24, 0, 3), s, c, dt, p);
 }
 
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
 }
 void launch_iisph_next_pressure(const StepCtx& c, const TileLds& L, float dt, float omega, const float* p, float* p_next,
                                 hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_iisph_next_pressure, c, L, dt, omega, p, p_next, s);
     SALVA_LAUNCH_TILE(k_iisph_next_pressure, c, L, L.bytes(32, 16, 3), s, c, dt, omega, p, p_next);
 }
 
@@ -303,6 +309,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(Ste
     });
 }
 void launch_iisph_velocity_changes(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_iisph_velocity_changes, c, L, dt, p, s);
     SALVA_LAUNCH_TILE(k_iisph_velocity_changes, c, L, L.bytes(24, 32, 5), s, c, dt, p);
 }
 
@@ -335,4 +342,4 @@ void launch_iisph_finish(const StepCtx& c, float dt, const float* p, int32_t* bb
     launch_bbox_final(bbox_partials, num_blocks(c.n), bbox6, s);
 }
 
-}  // namespace salva
+}  // namespace SALVA_KNS

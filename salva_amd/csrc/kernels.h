@@ -124,3 +124,36 @@ void launch_iisph_velocity_changes(const StepCtx& c, const TileLds& L, float dt,
 void launch_iisph_finish(const StepCtx& c, float dt, const float* p, int32_t* bbox_partials, int32_t* bbox6, hipStream_t s);
 
 }  // namespace salva
+
+// The same launchers as compiled a second time with -DSALVA_OTHER_KERNELS (common.h, SALVA_KNS): what SALVA_OK_DISPATCH
+// hands a world with a non-default KernelDensity / KernelGradient to.
+namespace salva_ok {
+using namespace salva;
+void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s);
+void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s);
+void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s);
+void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s);
+void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s);
+void launch_boundary_volumes(const StepCtx& c, unsigned long long* ncontacts_bb, hipStream_t s);
+void launch_iisph_dii(const StepCtx& c, const TileLds& L, float dt, hipStream_t s);
+void launch_iisph_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s);
+void launch_iisph_aii(const StepCtx& c, const TileLds& L, float dt, hipStream_t s);
+void launch_iisph_dij_pj(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s);
+void launch_iisph_next_pressure(const StepCtx& c, const TileLds& L, float dt, float omega, const float* p, float* p_next, hipStream_t s);
+void launch_iisph_velocity_changes(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s);
+void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff, float inv_dt_prev, hipStream_t s);
+void launch_artificial_viscosity(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff, float alpha,
+                                 float beta, float speed_of_sound, hipStream_t s);
+void launch_akinci_normals(const StepCtx& c, const TileLds& L, uint32_t model, hipStream_t s);
+void launch_akinci_forces(const StepCtx& c, const TileLds& L, uint32_t model, float tension, float adhesion, hipStream_t s);
+void launch_he2014_colors(const StepCtx& c, const TileLds& L, uint32_t model, float* colors, hipStream_t s);
+void launch_he2014_gradc(const StepCtx& c, const TileLds& L, uint32_t model, const float* colors, float* gradcs, hipStream_t s);
+void launch_he2014_forces(const StepCtx& c, const TileLds& L, uint32_t model, float tension, float boundary_tension,
+                          const float* gradcs, hipStream_t s);
+void launch_wcsph_tension(const StepCtx& c, const TileLds& L, uint32_t model, float tension, hipStream_t s);
+void launch_visc_betas(const StepCtx& c, const TileLds& L, uint32_t model, float* beta, hipStream_t s);
+void launch_visc_strain(const StepCtx& c, const TileLds& L, uint32_t model, int mode, float coef, const float4* va,
+                        const float* beta, float* target, float4* u0, float4* u1, hipStream_t s);
+void launch_visc_accel(const StepCtx& c, const TileLds& L, uint32_t model, float inv_dt_prev, float dt_prev, const float4* u0,
+                       const float4* u1, float4* va, hipStream_t s);
+}  // namespace salva_ok

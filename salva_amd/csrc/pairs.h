@@ -113,7 +113,14 @@ __device__ __forceinline__ void pair_sum_gradient_exact(const StepCtx& c, uint32
     });
     sx = ax; sy = ay; sz = az;
 }
-__device__ __forceinline__ bool slice_is_near(uint32_t near_word) { return __builtin_amdgcn_readfirstlane((int)near_word) != 0; }
+// (a KernelGradient other than the cubic spline takes the same exact walk: kernel_gfac2 is the spline's form only)
+__device__ __forceinline__ bool slice_is_near(const StepCtx& c, uint32_t near_word) {
+#ifdef SALVA_OTHER_KERNELS
+    return (__builtin_amdgcn_readfirstlane((int)near_word) | c.sc.kg) != 0;
+#else
+    return __builtin_amdgcn_readfirstlane((int)near_word) != 0;
+#endif
+}
 __device__ __forceinline__ float (*carve_errtab(Tile& t))[MAX_MODELS] {
     return reinterpret_cast<float (*)[MAX_MODELS]>(t.carve<float>(TILE_MAX_WAVES * MAX_MODELS));
 }

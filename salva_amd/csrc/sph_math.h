@@ -26,6 +26,11 @@ struct SphConsts {
     float tiny_r2; // (1e-5 h)^2: below it the gradient is zero (cubic_spline_kernel.rs:63-65, q <= 1e-5)
     float g18, g12, sg6;  // 18 gnorm, 12 gnorm, sqrt(6 gnorm): folded constants of kernel_grad2
     float gscale;         // 6 gnorm / h^2: the factor kernel_gfac2 leaves to its caller
+    // KernelDensity / KernelGradient of DFSPHSolver<..> / IISPHSolver<..> (dfsph_solver.rs:17-20, iisph_solver.rs:17-20):
+    // 0 = CubicSplineKernel (the default type parameters, everything above), 1 = Poly6Kernel, 2 = SpikyKernel,
+    // 3 = ViscosityKernel (SALVA_HIP_KERNEL_* in salva_hip.h).  Non-zero kinds take the generic paths below.
+    int kd, kg;
+    float n_poly6, n_spiky, n_visc;  // 315 / (64 pi h^9), 15 / (pi h^6), 15 / (2 pi h^3)  (kernel/{poly6,spiky,viscosity}_kernel.rs)
 };
 
 __host__ inline SphConsts make_sph_consts(float h) {
@@ -41,6 +46,11 @@ __host__ inline SphConsts make_sph_consts(float h) {
     c.g12 = 12.0f * c.gnorm;
     c.sg6 = sqrtf(6.0f * c.gnorm);
     c.gscale = (float)(6.0 * (double)c.gnorm / ((double)h * (double)h));
+    c.kd = c.kg = 0;
+    const float pi = 3.14159265358979323846f, h3 = h * h * h;
+    c.n_poly6 = (315.0f / 64.0f) / (pi * (h3 * h3 * h3));
+    c.n_spiky = 15.0f / (pi * (h3 * h3));
+    c.n_visc = 15.0f / (2.0f * pi * h3);
     return c;
 }
 
@@ -91,6 +101,34 @@ __device__ __forceinline__ float opaque(float x) {
 // results are compared at 1e-5 relative; never for anything that feeds the exact d^2 <= h^2 test or a cell coordinate.
 __device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
+// The reference's other kernels (kernel/poly6_kernel.rs:8-40, spiky_kernel.rs:8-38, viscosity_kernel.rs:8-50), selectable as
+// the solvers' KernelDensity / KernelGradient type parameters.  Plain scalar code: no configuration of BASELINE.json uses them,
+// so they get correctness, not tuning.  They exist only in the SECOND compilation of the kernel sources (-DSALVA_OTHER_KERNELS,
+// namespace salva_ok, see SALVA_KNS in common.h): as wave-uniform branches inside the default kernels they cost 2-16 VGPRs
+// per kernel and pushed a dozen of them over an occupancy step (k_divergence_apply 76 -> 91, k_density_alpha 59 -> 72, ...).
+__device__ __forceinline__ float other_kernel_w(int kind, float r, const SphConsts& c) {
+    if (!(r <= c.h)) return 0.0f;
+    if (kind == 1) { const float d = c.h * c.h - r * r; return c.n_poly6 * (d * d * d); }
+    if (kind == 2) { const float d = c.h - r; return c.n_spiky * (d * d * d); }
+    if (!(r > 0.0f)) return 0.0f;
+    const float rr_hh = r * r / (c.h * c.h);
+    return c.n_visc * (rr_hh * (1.0f - r / (2.0f * c.h)) + c.h / (2.0f * r) - 1.0f);
+}
+__device__ __forceinline__ float other_kernel_dw(int kind, float r, const SphConsts& c) {
+    if (!(r <= c.h)) return 0.0f;
+    if (kind == 1) { const float d = c.h * c.h - r * r; return c.n_poly6 * (d * d) * r * -6.0f; }
+    if (kind == 2) { const float d = c.h - r; return -c.n_spiky * (d * d) * 3.0f; }
+    if (!(r > 0.0f)) return 0.0f;
+    const float rr = r * r, hh = c.h * c.h, hhh = hh * c.h;
+    return c.n_visc * (-3.0f * rr / (2.0f * hhh) + 2.0f * r / hh - c.h / (2.0f * rr));
+}
+// Kernel::apply_diff (kernel.rs:18-24): dir * scalar_apply_diff(norm) when |v|^2 > eps^2, else 0 — as the factor of v
+__device__ __forceinline__ float other_kernel_g(int kind, float r2, const SphConsts& c) {
+    if (!(r2 > c.eps2)) return 0.0f;
+    const float r = __builtin_amdgcn_sqrtf(r2);
+    return other_kernel_dw(kind, r, c) / r;
+}
+
 struct KernelEval {
     float w;  // W(|d|)
     float g;  // (dW/dr)/|d|  — gradient = g * d
@@ -106,6 +144,10 @@ __device__ __forceinline__ KernelEval kernel_eval(float r2, const SphConsts& c) 
     const float q = r * c.inv_h;
     e.w = c.wnorm * cubic_w_unit(q);
     e.g = c.gnorm * cubic_dw_unit(q) * rinv;
+#ifdef SALVA_OTHER_KERNELS
+    if (c.kd) e.w = other_kernel_w(c.kd, __builtin_amdgcn_sqrtf(r2), c);
+    if (c.kg) e.g = other_kernel_g(c.kg, r2, c);
+#endif
     return e;
 }
 
@@ -115,6 +157,9 @@ __device__ __forceinline__ KernelEval kernel_eval(float r2, const SphConsts& c) 
 // of testing q > 1, and the factor 6 is folded into the constant.
 __device__ __forceinline__ float kernel_grad(float r2, const SphConsts& c) {
     SALVA_PAIR_MATH
+#ifdef SALVA_OTHER_KERNELS
+    if (c.kg) return other_kernel_g(c.kg, r2, c);
+#endif
     const float rinv = __builtin_amdgcn_rsqf(fmaxf(r2, 1.0e-30f));
     const float q = r2 * rinv * c.inv_h;
     const float a = (q * 3.0f - 2.0f) * q;
@@ -131,6 +176,9 @@ __device__ __forceinline__ float kernel_grad(float r2, const SphConsts& c) {
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 kernel_grad2(f2 r2, const SphConsts& c) {
     SALVA_PAIR_MATH
+#ifdef SALVA_OTHER_KERNELS
+    if (c.kg) { f2 g; g.x = other_kernel_g(c.kg, r2.x, c); g.y = other_kernel_g(c.kg, r2.y, c); return g; }
+#endif
     const float t2 = c.tiny_r2;  // (1e-5 h)^2
     f2 rinv;
     rinv.x = (r2.x > t2) ? __builtin_amdgcn_rsqf(r2.x) : 0.0f;
@@ -178,6 +226,13 @@ __device__ __forceinline__ f2 kernel_gfac2(f2 r2, const SphConsts& c) {
 // them interleaved and one chain's latencies are covered by the other's issue slots).
 __device__ __forceinline__ void kernel_grad2x2(f2 r2a, f2 r2b, const SphConsts& c, f2& ga, f2& gb) {
     SALVA_PAIR_MATH
+#ifdef SALVA_OTHER_KERNELS
+    if (c.kg) {
+        ga.x = other_kernel_g(c.kg, r2a.x, c); ga.y = other_kernel_g(c.kg, r2a.y, c);
+        gb.x = other_kernel_g(c.kg, r2b.x, c); gb.y = other_kernel_g(c.kg, r2b.y, c);
+        return;
+    }
+#endif
     const float t2 = c.tiny_r2;
     f2 ra, rb;
     ra.x = (r2a.x > t2) ? __builtin_amdgcn_rsqf(r2a.x) : 0.0f;
@@ -200,6 +255,9 @@ __device__ __forceinline__ void kernel_grad2x2(f2 r2a, f2 r2b, const SphConsts& 
 __device__ __forceinline__ float kernel_weight(float r2, const SphConsts& c) {
     SALVA_PAIR_MATH
     const float r = __builtin_amdgcn_sqrtf(r2);
+#ifdef SALVA_OTHER_KERNELS
+    if (c.kd) return other_kernel_w(c.kd, r, c);
+#endif
     return c.wnorm * cubic_w_unit(r * c.inv_h);
 }
 

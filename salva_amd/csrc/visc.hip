@@ -13,7 +13,8 @@
 #include "kernels.h"
 #include "tile.h"
 
-namespace salva {
+namespace SALVA_KNS {
+using namespace salva;
 
 // rows of M(g): (2gx,0,0) (0,2gy,0) (0,0,2gz) (gy,gx,0) (gz,0,gx) (0,gz,gy);  entry (a,b) of M(g) M(g)^T from the six
 // products q = {xx, yy, zz, xy, xz, yz}
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_betas(StepCtx c, uint
     });
 }
 void launch_visc_betas(const StepCtx& c, const TileLds& L, uint32_t model, float* beta, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_visc_betas, c, L, model, beta, s);
     SALVA_LAUNCH_TILE(k_visc_betas, c, L, L.bytes(20, 0, 3), s, c, model, beta);
 }
 
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_strain(StepCtx c, uin
 }
 void launch_visc_strain(const StepCtx& c, const TileLds& L, uint32_t model, int mode, float coef, const float4* va,
                         const float* beta, float* target, float4* u0, float4* u1, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_visc_strain, c, L, model, mode, coef, va, beta, target, u0, u1, s);
     SALVA_LAUNCH_TILE(k_visc_strain, c, L, L.bytes(32, 0, 3), s, c, model, mode, coef, va, beta, target, u0, u1);
 }
 
@@ -298,7 +301,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_visc_accel(StepCtx c, uint
 }
 void launch_visc_accel(const StepCtx& c, const TileLds& L, uint32_t model, float inv_dt_prev, float dt_prev, const float4* u0,
                        const float4* u1, float4* va, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_visc_accel, c, L, model, inv_dt_prev, dt_prev, u0, u1, va, s);
     SALVA_LAUNCH_TILE(k_visc_accel, c, L, L.bytes(48, 0, 4), s, c, model, inv_dt_prev, dt_prev, u0, u1, va);
 }
 
-}  // namespace salva
+}  // namespace SALVA_KNS

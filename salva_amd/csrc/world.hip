@@ -115,6 +115,10 @@ World::World(const SalvaHipParams& p) : prm(p) {
     // h = particle_radius * smoothing_factor * 2 (liquid_world.rs:44)
     const float h = p.particle_radius * p.smoothing_factor * 2.0f;
     sc = make_sph_consts(h);
+    if (p.kernel_density < 0 || p.kernel_density > SALVA_HIP_KERNEL_VISCOSITY || p.kernel_gradient < 0 || p.kernel_gradient > SALVA_HIP_KERNEL_VISCOSITY)
+        throw HipError(SALVA_HIP_E_INVALID, "unknown kernel kind");
+    sc.kd = p.kernel_density;
+    sc.kg = p.kernel_gradient;
     SALVA_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     SALVA_HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     SALVA_HIP_CHECK(hipEventCreateWithFlags(&ev_pre_refresh, hipEventDisableTiming));

@@ -243,11 +243,33 @@ class DFSPHViscosity(NonPressureForce):
         return d
 
 
+class CubicSplineKernel:
+    """kernel/cubic_spline_kernel.rs — the default KernelDensity and KernelGradient."""
+    kind = L.KERNEL_CUBIC_SPLINE
+
+
+class Poly6Kernel:
+    """kernel/poly6_kernel.rs"""
+    kind = L.KERNEL_POLY6
+
+
+class SpikyKernel:
+    """kernel/spiky_kernel.rs"""
+    kind = L.KERNEL_SPIKY
+
+
+class ViscosityKernel:
+    """kernel/viscosity_kernel.rs"""
+    kind = L.KERNEL_VISCOSITY
+
+
 class DFSPHSolver:
-    """dfsph_solver.rs:54-70 defaults."""
+    """dfsph_solver.rs:54-70 defaults.  `DFSPHSolver(KernelDensity, KernelGradient)` mirrors the type parameters of
+    `DFSPHSolver<KernelDensity, KernelGradient>` (:17-20); both default to CubicSplineKernel."""
     kind = L.SOLVER_DFSPH
 
-    def __init__(self):
+    def __init__(self, kernel_density=CubicSplineKernel, kernel_gradient=CubicSplineKernel):
+        self.kernel_density, self.kernel_gradient = kernel_density, kernel_gradient
         self.min_pressure_iter = 1
         self.max_pressure_iter = 50
         self.max_density_error = 0.05
@@ -257,10 +279,11 @@ class DFSPHSolver:
 
 
 class IISPHSolver:
-    """iisph_solver.rs:48-64 defaults."""
+    """iisph_solver.rs:48-64 defaults; `IISPHSolver(KernelDensity, KernelGradient)` as for DFSPHSolver (:17-20)."""
     kind = L.SOLVER_IISPH
 
-    def __init__(self):
+    def __init__(self, kernel_density=CubicSplineKernel, kernel_gradient=CubicSplineKernel):
+        self.kernel_density, self.kernel_gradient = kernel_density, kernel_gradient
         self.min_pressure_iter = 1
         self.max_pressure_iter = 50
         self.max_density_error = 0.05
@@ -588,6 +611,8 @@ class LiquidWorld:
         p.particle_radius = particle_radius
         p.smoothing_factor = smoothing_factor
         p.solver = solver.kind
+        p.kernel_density = getattr(solver, "kernel_density", CubicSplineKernel).kind
+        p.kernel_gradient = getattr(solver, "kernel_gradient", CubicSplineKernel).kind
         p.min_pressure_iter, p.max_pressure_iter = solver.min_pressure_iter, solver.max_pressure_iter
         p.max_density_error = solver.max_density_error
         p.min_divergence_iter, p.max_divergence_iter = solver.min_divergence_iter, solver.max_divergence_iter

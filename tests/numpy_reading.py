@@ -39,23 +39,63 @@ def spline_dw(r, h):
     return normalizer * rhs / h
 
 
-def pair_tables(xa, xb, h):
-    """For every (a, b): contact mask (contacts.rs: distance_squared <= h*h), weight (helper.rs: points_apply) and gradient
-    (points_apply_diff1 = apply_diff(pa - pb): direction * dW/dr, zero when the norm is <= eps, kernel.rs:18-24)."""
+def poly6_w(r, h):
+    """poly6_kernel.rs:9-21 (dim3)."""
+    return np.where(r <= h, 315.0 / 64.0 / (np.pi * h ** 9) * (h * h - r * r) ** 3, 0.0)
+
+
+def poly6_dw(r, h):
+    """poly6_kernel.rs:24-38."""
+    return np.where(r <= h, 315.0 / 64.0 / (np.pi * h ** 9) * (h * h - r * r) ** 2 * r * -6.0, 0.0)
+
+
+def spiky_w(r, h):
+    """spiky_kernel.rs:9-21."""
+    return np.where(r <= h, 15.0 / (np.pi * h ** 6) * (h - r) ** 3, 0.0)
+
+
+def spiky_dw(r, h):
+    """spiky_kernel.rs:23-36."""
+    return np.where(r <= h, -15.0 / (np.pi * h ** 6) * (h - r) ** 2 * 3.0, 0.0)
+
+
+def visc_w(r, h):
+    """viscosity_kernel.rs:9-27: zero at r = 0 as well."""
+    rs = np.where(r > 0.0, r, 1.0)
+    val = 15.0 / (2.0 * np.pi * h ** 3) * (rs * rs / (h * h) * (1.0 - rs / (2.0 * h)) + h / (2.0 * rs) - 1.0)
+    return np.where((r > 0.0) & (r <= h), val, 0.0)
+
+
+def visc_dw(r, h):
+    """viscosity_kernel.rs:29-49."""
+    rs = np.where(r > 0.0, r, 1.0)
+    val = 15.0 / (2.0 * np.pi * h ** 3) * (-3.0 * rs * rs / (2.0 * h ** 3) + 2.0 * rs / (h * h) - h / (2.0 * rs * rs))
+    return np.where((r > 0.0) & (r <= h), val, 0.0)
+
+
+# the solvers' KernelDensity / KernelGradient type parameters (dfsph_solver.rs:17-20) by name
+KERNELS = {"cubic": (spline_w, spline_dw), "poly6": (poly6_w, poly6_dw), "spiky": (spiky_w, spiky_dw), "viscosity": (visc_w, visc_dw)}
+
+
+def pair_tables(xa, xb, h, kernel_density="cubic", kernel_gradient="cubic"):
+    """For every (a, b): contact mask (contacts.rs: distance_squared <= h*h), weight (helper.rs: KernelDensity::points_apply) and
+    gradient (KernelGradient::points_apply_diff1 = apply_diff(pa - pb): direction * dW/dr, zero when the norm is <= eps,
+    kernel.rs:18-24)."""
     d = xa[:, None, :] - xb[None, :, :]
     r2 = (d * d).sum(axis=2)
     mask = r2 <= h * h
     r = np.sqrt(r2)
-    w = np.where(mask, spline_w(r, h), 0.0)
+    w = np.where(mask, KERNELS[kernel_density][0](r, h), 0.0)
     safe = np.where(r > EPS32, r, 1.0)
-    g = np.where((mask & (r > EPS32))[:, :, None], d / safe[:, :, None] * spline_dw(r, h)[:, :, None], 0.0)
+    g = np.where((mask & (r > EPS32))[:, :, None], d / safe[:, :, None] * KERNELS[kernel_gradient][1](r, h)[:, :, None], 0.0)
     return mask, w, g
 
 
 class DenseWorld:
     """One fluid + one boundary (either may be empty), default interaction groups, optional XSPHViscosity."""
 
-    def __init__(self, particle_radius, smoothing_factor=2.0, solver="dfsph"):
+    def __init__(self, particle_radius, smoothing_factor=2.0, solver="dfsph", kernel_density="cubic", kernel_gradient="cubic"):
+        self.kernels = (kernel_density, kernel_gradient)
         self.r = float(particle_radius)
         self.h = float(particle_radius) * float(smoothing_factor) * 2.0  # liquid_world.rs:44
         self.solver = solver
@@ -98,9 +138,9 @@ class DenseWorld:
             return
         h = self.h
         m = self.vol * self.density0                          # Fluid::particle_mass
-        self.ff, self.wff, self.gff = pair_tables(self.x, self.x, h)
-        self.fb, self.wfb, self.gfb = pair_tables(self.x, self.xb, h)
-        bb, wbb, _ = pair_tables(self.xb, self.xb, h)
+        self.ff, self.wff, self.gff = pair_tables(self.x, self.x, h, *self.kernels)
+        self.fb, self.wfb, self.gfb = pair_tables(self.x, self.xb, h, *self.kernels)
+        bb, wbb, _ = pair_tables(self.xb, self.xb, h, *self.kernels)
         # compute_boundary_volumes (dfsph_solver.rs:72-96)
         self.volb = 1.0 / wbb.sum(axis=1) if len(self.xb) else np.zeros(0)
         mb = self.volb * self.density0                        # V_b * fluid_i.density0

@@ -4,12 +4,17 @@ from __future__ import annotations
 import numpy as np
 
 from oracle import oracle as O
-from salva_amd import (Akinci2013SurfaceTension, ArtificialViscosity, Boundary, DFSPHSolver, DFSPHViscosity, Fluid, He2014SurfaceTension,
+from salva_amd import (CubicSplineKernel, Poly6Kernel, SpikyKernel, ViscosityKernel,
+                       Akinci2013SurfaceTension, ArtificialViscosity, Boundary, DFSPHSolver, DFSPHViscosity, Fluid, He2014SurfaceTension,
                        IISPHSolver, WCSPHSurfaceTension,
                        InteractionGroups, LiquidWorld, XSPHViscosity)
 
 GRAVITY = (0.0, -9.81, 0.0)
 DT = 1.0 / 200.0
+
+
+# the solvers' KernelDensity / KernelGradient type parameters (dfsph_solver.rs:17-20): (oracle kind, mirror class) by name
+KERNELS = {"cubic": (0, CubicSplineKernel), "poly6": (1, Poly6Kernel), "spiky": (2, SpikyKernel), "viscosity": (3, ViscosityKernel)}
 
 
 class Scene:
@@ -24,6 +29,7 @@ class Scene:
         # ill-conditioned: the oracle's own f32-vs-f64 distance is the yardstick, and it is ~5e-4 r after
         # 6 steps with DFSPHViscosity (6x6 inverses of badly scaled matrices, 50 fixed-point iterations per step).
         self.tol_scale = 1.0
+        self.kernels = ("cubic", "cubic")  # (KernelDensity, KernelGradient)
         self.fluids = []      # dict(pos, vel, density0, groups, forces=[("xsph", a, b), ...], volumes)
         self.boundaries = []  # dict(pos, vel, groups, wants_forces)
 
@@ -43,6 +49,7 @@ class Scene:
         if shuffle_seed:
             w.set_shuffle_seed(shuffle_seed)
         w.set_solver_params(**self.solver_params)
+        w.set_kernels(KERNELS[self.kernels[0]][0], KERNELS[self.kernels[1]][0])
         for f in self.fluids:
             fid = w.add_fluid(f["pos"], f["density0"], f["vel"], f["groups"][0], f["groups"][1])
             if f["volumes"] is not None:
@@ -68,7 +75,8 @@ class Scene:
 
     # ---------------------------------------------------------------- HIP path (through the C ABI)
     def make_hip(self):
-        solver = DFSPHSolver() if self.solver == "dfsph" else IISPHSolver()
+        kd, kg = KERNELS[self.kernels[0]][1], KERNELS[self.kernels[1]][1]
+        solver = DFSPHSolver(kd, kg) if self.solver == "dfsph" else IISPHSolver(kd, kg)
         for k, v in self.solver_params.items():
             setattr(solver, k, v)
         w = LiquidWorld(solver, self.radius, self.smoothing)

@@ -104,3 +104,58 @@ def test_iisph_step_by_step():
         for name, mine in [("dii", d.dii), ("dij_pjl", d.dijpj), ("velocities", d.v), ("positions", d.x)]:
             assert rel(o.fluid_vec(f, name), mine) < 1e-7, f"step {k}: {name}"
     assert max(iters) >= 3, f"the pressure solve was meant to iterate: {iters}"
+
+
+KINDS = {"cubic": 0, "poly6": 1, "spiky": 2, "viscosity": 3}
+
+
+def test_other_kernels_closed_forms():
+    """kernel/{poly6,spiky,viscosity}_kernel.rs as the oracle restates them: against the numpy reading's closed forms on a grid
+    of radii (incl. 0, h and beyond), the derivative against a central difference of the value, and the unit integral of the two
+    normalised ones."""
+    from numpy_reading import KERNELS
+    lib = O.lib()
+    h = 0.1
+    rs = np.concatenate([[0.0], np.linspace(1e-4, 1.2 * h, 400), [h]])
+    for name, kind in KINDS.items():
+        w = np.array([lib.so_kernel_scalar_f64(kind, 0, float(r), h) for r in rs])
+        dw = np.array([lib.so_kernel_scalar_f64(kind, 1, float(r), h) for r in rs])
+        ref_w, ref_dw = KERNELS[name][0](rs, h), KERNELS[name][1](rs, h)
+        assert np.allclose(w, ref_w, rtol=1e-12, atol=1e-14 * np.abs(ref_w).max()), name
+        assert np.allclose(dw, ref_dw, rtol=1e-12, atol=1e-14 * np.abs(ref_dw).max()), name  # (atol: the viscosity kernel's terms cancel to 0 at r = h)
+        mid = rs[(rs > 0.05 * h) & (rs < 0.95 * h)]
+        mid = mid[np.abs(mid - 0.5 * h) > 1e-3 * h]  # (the spline's second derivative jumps at h / 2)
+        e = 1e-6 * h
+        fd = np.array([(lib.so_kernel_scalar_f64(kind, 0, float(r + e), h) - lib.so_kernel_scalar_f64(kind, 0, float(r - e), h)) / (2 * e) for r in mid])
+        an = np.array([lib.so_kernel_scalar_f64(kind, 1, float(r), h) for r in mid])
+        assert np.allclose(fd, an, rtol=1e-5, atol=1e-6 * np.abs(an).max()), name
+        if name != "viscosity":  # (the viscosity kernel is not a density kernel: its integral diverges at r -> 0 ... it is 1/r there)
+            r = np.linspace(0, h, 200001)
+            integral = np.trapezoid(4 * np.pi * r * r * KERNELS[name][0](r, h), r)
+            assert abs(integral - 1.0) < 1e-6, (name, integral)
+
+
+@pytest.mark.parametrize("solver,kd,kg", [("dfsph", "poly6", "spiky"), ("iisph", "poly6", "spiky"), ("dfsph", "spiky", "viscosity"), ("dfsph", "cubic", "spiky")])
+def test_other_kernels_step_by_step(solver, kd, kg):
+    """DFSPHSolver<KernelDensity, KernelGradient> / IISPHSolver<..> with non-default type parameters: oracle f64 vs the numpy reading."""
+    pos, vel, bpos = make_scene(seed=7)
+    o = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH, f64=True)
+    o.set_kernels(KINDS[kd], KINDS[kg])
+    o.set_solver_params(max_divergence_iter=3, max_pressure_iter=3)
+    f = o.add_fluid(pos, 1000.0, vel)
+    o.add_xsph(f, 0.5, 0.3)
+    o.add_boundary(bpos)
+    d = DenseWorld(R32, 2.0, solver, kd, kg)
+    d.set_fluid(pos, 1000.0, vel)
+    d.set_boundary(bpos)
+    d.max_divergence_iter, d.max_pressure_iter = 3, 3
+    d.set_xsph(0.5, 0.3)
+    for k in range(4):
+        so = o.step(DT, G)
+        d.step(DT32, G32)
+        assert int(so.ncontacts) == d.ncontacts, f"step {k}: contacts"
+        for name, mine in [("densities", d.rho), ("predicted_densities", d.rho_pred)]:
+            assert rel(o.fluid_scalar(f, name), mine) < 1e-7, f"step {k}: {name}"
+        for name, mine in [("velocities", d.v), ("positions", d.x)]:
+            assert rel(o.fluid_vec(f, name), mine) < 1e-7, f"step {k}: {name}"
+        assert rel(o.boundary_volumes(0), d.volb) < 1e-12
