@@ -317,6 +317,17 @@ int salva_hip_rebalance(SalvaHipWorld* world, int32_t* cell_lo, int32_t* cell_hi
 int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* gids, float* positions_xyz,
                             float* velocities_xyz, uint32_t* fluid_slots);
 
+/* Creation and removal of particles in a RUNNING decomposed world (faucet3.rs:69-104-style emitters and sinks).  Both are
+ * collective: every rank calls them between the same two steps — with n = 0 where it has nothing to add or delete — because
+ * the particle counts the solvers' error averages divide by are global, and so are the ids.
+ *  - salva_hip_add_particles (below) appends to THIS rank: the positions must lie in its slab or the adjacent one (the next
+ *    step's migration hands them over); the new particles get the ids following the largest id in the run, rank by rank;
+ *  - salva_hip_delete_owned removes the particles of `gids` that this rank owns (ids owned elsewhere are ignored, so every rank
+ *    may pass the same list); like `Fluid::delete_particle_at_next_timestep` (fluid.rs:71-86) they are gone from the next step
+ *    on.  Returns the number of particles this rank still owns (negative on error).
+ * Before the first step of a decomposed world the ordinary host-order calls apply (the upload index is the id). */
+int64_t salva_hip_delete_owned(SalvaHipWorld* world, uint32_t n, const uint32_t* gids);
+
 /* `LiquidWorld::particles_intersecting_aabb(aabb)` (liquid_world.rs:210-243): the particles whose distance to the box
  * [mins, maxs] is below the particle radius, as (kind, slot, index) triples sorted by kind (0 = ParticleId::FluidParticle,
  * 1 = BoundaryParticle), slot and index.  Returns how many there are (negative on error); at most `capacity` are written.
@@ -379,7 +390,7 @@ int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t
 
 /* `Fluid::add_particles(positions, velocities)` (object/fluid.rs:126-150): append to the fluid on the device — default
  * volume, zero acceleration and velocity change — without re-uploading the particles it already holds.
- * velocities_xyz may be NULL (zeros). */
+ * velocities_xyz may be NULL (zeros).  In a running decomposed world: collective, see salva_hip_delete_owned above. */
 int salva_hip_add_particles(SalvaHipWorld* world, uint32_t slot, uint64_t n_add, const float* positions_xyz,
                             const float* velocities_xyz);
 /* `Fluid::delete_particle_at_next_timestep` + `apply_particles_removal` (fluid.rs:71-98) and the solver's matching

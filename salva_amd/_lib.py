@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_force_get_state", "salva_hip_force_add_accelerations", "salva_hip_set_fluid_field", "salva_hip_get_timestep",
     "salva_hip_set_timestep", "salva_hip_get_counters", "salva_hip_time_kernel", "salva_hip_particles_intersecting_shape", "salva_hip_rebalance",
     "salva_hip_set_boundary_dynamic_sampling", "salva_hip_get_boundary_sources", "salva_hip_set_boundary_dynamic_sampling_host",
+    "salva_hip_delete_owned",
 ]
 
 
@@ -198,6 +199,8 @@ def lib():
     L.salva_hip_time_pred_density.restype = f32
     L.salva_hip_particles_intersecting_shape.argtypes = [vp, fp, fp, C.POINTER(Shape), u64, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.salva_hip_particles_intersecting_shape.restype = C.c_int64
+    L.salva_hip_delete_owned.argtypes = [vp, u32, C.POINTER(u32)]
+    L.salva_hip_delete_owned.restype = C.c_int64
     L.salva_hip_rebalance.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.salva_hip_time_kernel.argtypes = [vp, i32, i32]
     L.salva_hip_time_kernel.restype = f32

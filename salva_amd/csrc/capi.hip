@@ -397,6 +397,17 @@ int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* g
     return rc == SALVA_HIP_OK ? count : (int64_t)rc;
 }
 
+int64_t salva_hip_delete_owned(SalvaHipWorld* world, uint32_t n, const uint32_t* gids) {
+    int64_t count = 0;
+    const int rc = guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
+        count = (int64_t)world->w->delete_owned(n, gids);
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? count : (int64_t)rc;
+}
+
 int64_t salva_hip_particles_intersecting_aabb(SalvaHipWorld* world, const float mins[3], const float maxs[3], uint64_t capacity,
                                              uint32_t* kinds, uint32_t* slots, uint32_t* indices) {
     int64_t total = 0;

@@ -92,6 +92,7 @@ class World {
     // particles follow in the next step's migration.  Returns this rank's new [lo, hi].
     void rebalance(int32_t* new_lo, int32_t* new_hi);
     uint64_t get_owned(uint32_t cap, uint32_t* gids, float* pos, float* vel, uint32_t* models);
+    uint64_t delete_owned(uint32_t n_ids, const uint32_t* gids);
     uint32_t owned_count() const { return comm ? n_owned : n; }
     float time_pred_density(int reps);
     float time_kernel(int kernel, int reps);
@@ -262,6 +263,9 @@ class World {
     DevBuf<unsigned long long> plane_hist;
     std::vector<uint32_t> global_counts;  // particles per fluid over all ranks (the denominators of the error averages)
     uint32_t gid_offset = 0, n_owned = 0;
+    uint64_t gid_next = 0;  // first global id not in use (dist_add_particles)
+    void dist_add_particles(uint32_t slot, uint64_t n_add, const float* pos, const float* vel_h);
+    void dist_update_counts(const std::vector<long long>& delta);
     bool dist_started = false;
     DevBuf<uint32_t> gtag[2];
     DevBuf<DistRec> xsend_lo, xsend_hi, xrecv_lo, xrecv_hi;

@@ -297,7 +297,7 @@ void World::set_fluid(uint32_t slot, uint64_t nn, const float* pos, const float*
 void World::add_particles(uint32_t slot, uint64_t n_add, const float* pos, const float* vel_h) {
     use_device();
     if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
-    if (comm) throw HipError(SALVA_HIP_E_INVALID, "particles cannot be added in a multi-GPU run yet");
+    if (comm && dist_started) { dist_add_particles(slot, n_add, pos, vel_h); return; }  // (collective, world_dist.hip)
     if (n_add == 0) return;
     if (!pos) throw HipError(SALVA_HIP_E_INVALID, "positions are required");
     if ((uint64_t)n + n_add >= 0xfffffff0ull) throw HipError(SALVA_HIP_E_CAPACITY, "more than 2^32 fluid particles on one device");
@@ -346,7 +346,7 @@ void World::add_particles(uint32_t slot, uint64_t n_add, const float* pos, const
 uint64_t World::delete_particles(uint32_t slot, const uint8_t* mask) {
     use_device();
     if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
-    if (comm) throw HipError(SALVA_HIP_E_INVALID, "particles cannot be deleted in a multi-GPU run yet");
+    if (comm && dist_started) throw HipError(SALVA_HIP_E_INVALID, "host indices do not exist in a running multi-GPU world: delete by global id (salva_hip_delete_owned)");
     const uint64_t nn = fluids[slot].n, off = fluid_offset(slot);
     if (nn == 0 || !mask) return nn;
     ensure_staging_current();

@@ -143,6 +143,19 @@ void World::dist_prepare() {
         SALVA_HIP_CHECK(hipMemcpyAsync(model_counts.p, c32.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         SALVA_HIP_CHECK(hipStreamSynchronize(stream));
         d_sums.ensure(nm);
+        // the first global id no particle has: where dist_add_particles continues numbering
+        {
+            const int size = comm->size(), rank = comm->rank();
+            std::vector<unsigned long long> top((size_t)size, 0ull);
+            top[rank] = (unsigned long long)gid_offset + n;
+            plane_hist.ensure(std::max<size_t>((size_t)size, 64));
+            SALVA_HIP_CHECK(hipMemcpyAsync(plane_hist.p, top.data(), top.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+            comm->allreduce_sum_u64(plane_hist.p, size, stream);
+            SALVA_HIP_CHECK(hipMemcpyAsync(top.data(), plane_hist.p, top.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+            gid_next = 0;
+            for (auto t : top) gid_next = std::max<uint64_t>(gid_next, t);
+        }
         dist_started = true;
     }
     const bool has_lo = comm->has_lo(), has_hi = comm->has_hi();
@@ -276,6 +289,123 @@ void World::finalize_solve(SolveCtl* ctl, SolveCtl* pub) {
 }
 
 // Download the particles this rank owns (unordered): global ids, positions, velocities, fluid slot.  Returns the count.
+// ---- particle creation and removal in a running decomposed world.  Both are COLLECTIVE: every rank calls them between the
+// same two steps (with nothing to add / delete where it has nothing), because the per-fluid particle counts the error
+// averages divide by are global (compute_divergences / compute_predicted_densities: `max_error / num_particles`,
+// dfsph_solver.rs:160,:355) and the new particles' global ids must not collide.
+__global__ __launch_bounds__(BLOCK) void k_dist_append(uint32_t n_add, uint32_t at, const float* __restrict__ pos, const float* __restrict__ vel_in,
+                                                       float vol, float rho0, uint32_t slot, uint32_t gid0, DistArrays a) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n_add) return;
+    const uint32_t i = at + k;
+    a.posm[i] = make_float4(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2], vol * rho0);  // particle_mass = volume * density0 (fluid.rs:183-185)
+    a.vel[i] = vel_in ? make_float4(vel_in[3 * k], vel_in[3 * k + 1], vel_in[3 * k + 2], vol) : make_float4(0.0f, 0.0f, 0.0f, vol);
+    a.dv[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    a.model[i] = slot;
+    a.gid[i] = gid0 + k;
+    a.gtag[i] = 0u;
+}
+
+// per-fluid count changes of this rank -> the global counts, on every rank
+void World::dist_update_counts(const std::vector<long long>& delta) {
+    const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1);
+    std::vector<unsigned long long> buf(2 * (size_t)nm, 0ull);  // [added | removed]
+    for (uint32_t f = 0; f < nm && f < delta.size(); ++f) {
+        if (delta[f] >= 0) buf[f] = (unsigned long long)delta[f];
+        else buf[nm + f] = (unsigned long long)(-delta[f]);
+    }
+    plane_hist.ensure(std::max<size_t>(2 * (size_t)nm, 64));
+    SALVA_HIP_CHECK(hipMemcpyAsync(plane_hist.p, buf.data(), buf.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+    comm->allreduce_sum_u64(plane_hist.p, (int)buf.size(), stream);
+    SALVA_HIP_CHECK(hipMemcpyAsync(buf.data(), plane_hist.p, buf.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    if (global_counts.size() != nm) global_counts.assign(nm, 0u);
+    for (uint32_t f = 0; f < nm; ++f) {
+        const unsigned long long c = (unsigned long long)global_counts[f] + buf[f] - std::min<unsigned long long>(buf[nm + f], (unsigned long long)global_counts[f] + buf[f]);
+        if (c >= 0xffffffffull) throw HipError(SALVA_HIP_E_CAPACITY, "more than 2^32 particles in one fluid");
+        global_counts[f] = (uint32_t)c;
+    }
+    SALVA_HIP_CHECK(hipMemcpyAsync(model_counts.p, global_counts.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+// Fluid::add_particles (fluid.rs:126-150) on the rank that owns the place (a particle may lie up to one slab away: the next
+// step's migration hands it over).  Ids continue after the largest id in the run, rank by rank.
+void World::dist_add_particles(uint32_t slot, uint64_t n_add, const float* pos, const float* vel_h) {
+    const int size = comm->size(), rank = comm->rank();
+    if (n_add && !pos) throw HipError(SALVA_HIP_E_INVALID, "positions are required");
+    std::vector<unsigned long long> adds((size_t)size, 0ull);
+    adds[rank] = n_add;
+    plane_hist.ensure(std::max<size_t>((size_t)size, 64));
+    SALVA_HIP_CHECK(hipMemcpyAsync(plane_hist.p, adds.data(), adds.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+    comm->allreduce_sum_u64(plane_hist.p, size, stream);
+    SALVA_HIP_CHECK(hipMemcpyAsync(adds.data(), plane_hist.p, adds.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    uint64_t before = 0, total = 0;
+    for (int r = 0; r < size; ++r) { if (r < rank) before += adds[r]; total += adds[r]; }
+    if (gid_next + total >= 0xfffffff0ull) throw HipError(SALVA_HIP_E_CAPACITY, "global particle ids exhausted");
+    const uint64_t gid0 = gid_next + before;
+    gid_next += total;
+    std::vector<long long> delta(std::max<size_t>(fluids.size(), 1), 0);
+    delta[slot] = (long long)n_add;
+    dist_update_counts(delta);
+    if (n_add == 0) return;
+    if ((uint64_t)n + n_add >= 0xfffffff0ull) throw HipError(SALVA_HIP_E_CAPACITY, "too many particles in one slab");
+    ensure_particle_capacity((size_t)n + n_add);
+    scratch_f.ensure(6 * n_add, stream, false, 1.1f);
+    SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, pos, 3 * n_add * sizeof(float), hipMemcpyHostToDevice, stream));
+    if (vel_h) SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p + 3 * n_add, vel_h, 3 * n_add * sizeof(float), hipMemcpyHostToDevice, stream));
+    const float r = prm.particle_radius, vol = r * r * r * 6.4f;  // Fluid::particle_volume default (fluid.rs:110-120)
+    k_dist_append<<<div_up(n_add, BLOCK), BLOCK, 0, stream>>>((uint32_t)n_add, n, scratch_f.p, vel_h ? scratch_f.p + 3 * n_add : nullptr, vol,
+                                                              fluids[slot].density0, slot, (uint32_t)gid0, dist_arrays(cur));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));  // (host buffers)
+    n += (uint32_t)n_add;
+    n_owned += (uint32_t)n_add;
+    bbox_known = false;      // the new particles may lie outside last step's box
+    have_last_ctx = false;   // lists and tables describe the old set
+}
+
+// `Fluid::delete_particle_at_next_timestep` by global id (host indices do not exist in a decomposed run): the particles of
+// `gids` this rank owns become ghosts, which the next step's first phase drops like every other ghost.
+__global__ __launch_bounds__(BLOCK) void k_dist_mark_deleted(uint32_t n, const uint32_t* __restrict__ gid, uint32_t* __restrict__ gtag,
+                                                             const uint32_t* __restrict__ model, const uint32_t* __restrict__ sorted_ids,
+                                                             uint32_t n_ids, unsigned long long* __restrict__ removed) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n || (gtag[i] & GTAG_GHOST)) return;
+    const uint32_t g = gid[i];
+    uint32_t lo = 0, hi = n_ids;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted_ids[mid] < g) lo = mid + 1; else hi = mid; }
+    if (lo < n_ids && sorted_ids[lo] == g) {
+        gtag[i] |= GTAG_GHOST;
+        atomicAdd(&removed[model[i]], 1ull);
+    }
+}
+uint64_t World::delete_owned(uint32_t n_ids, const uint32_t* gids) {
+    use_device();
+    if (!comm) throw HipError(SALVA_HIP_E_INVALID, "delete_owned is for multi-GPU worlds (a single domain deletes by host index: salva_hip_delete_particles)");
+    if (!dist_started || !sorted_valid) throw HipError(SALVA_HIP_E_INVALID, "no step has run yet");
+    if (n_ids && !gids) throw HipError(SALVA_HIP_E_INVALID, "null id list");
+    const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1);
+    std::vector<long long> delta(nm, 0);
+    if (n_ids && n) {
+        std::vector<uint32_t> ids(gids, gids + n_ids);
+        std::sort(ids.begin(), ids.end());
+        DevBuf<uint32_t> d_ids;
+        d_ids.ensure(n_ids);
+        d_counters.ensure(std::max<size_t>(4, nm));
+        SALVA_HIP_CHECK(hipMemcpyAsync(d_ids.p, ids.data(), (size_t)n_ids * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        SALVA_HIP_CHECK(hipMemsetAsync(d_counters.p, 0, nm * sizeof(unsigned long long), stream));
+        k_dist_mark_deleted<<<div_up(n, BLOCK), BLOCK, 0, stream>>>(n, perm[cur].p, gtag[cur].p, model[cur].p, d_ids.p, n_ids, d_counters.p);
+        std::vector<unsigned long long> rem(nm, 0ull);
+        SALVA_HIP_CHECK(hipMemcpyAsync(rem.data(), d_counters.p, nm * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        for (uint32_t f = 0; f < nm; ++f) { delta[f] = -(long long)rem[f]; n_owned -= (uint32_t)rem[f]; }
+        have_last_ctx = false;
+    }
+    dist_update_counts(delta);
+    return n_owned;
+}
+
 uint64_t World::get_owned(uint32_t cap, uint32_t* gids, float* pos, float* vel_out, uint32_t* models) {
     use_device();
     if (!comm) throw HipError(SALVA_HIP_E_INVALID, "get_owned is for multi-GPU worlds (set_domain)");

@@ -971,6 +971,22 @@ class LiquidWorld:
         L.check(self._L.salva_hip_set_domain(self._h, comm._h, int(cell_lo), int(cell_hi), int(gid_offset)))
         self._comm = comm
 
+    def delete_owned(self, gids) -> int:
+        """Collective (every rank, between the same two steps): remove the particles of `gids` this rank owns from the next
+        step on (salva_hip_delete_owned); returns how many particles the rank still owns."""
+        g = np.ascontiguousarray(gids, np.uint32).ravel()
+        m = int(self._L.salva_hip_delete_owned(self._h, len(g), g.ctypes.data_as(C.POINTER(C.c_uint32))))
+        if m < 0:
+            L.check(m)
+        return m
+
+    def add_owned(self, fluid, positions, velocities=None):
+        """Collective (every rank, between the same two steps; an empty array where there is nothing to add): append particles
+        to this rank of a running decomposed world (salva_hip_add_particles); they get the next free global ids."""
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        vel = None if velocities is None else np.ascontiguousarray(velocities, np.float32).reshape(-1, 3)
+        L.check(self._L.salva_hip_add_particles(self._h, fluid._slot, len(pos), _fp(pos) if len(pos) else None, _fp(vel) if vel is not None and len(pos) else None))
+
     def rebalance(self):
         """Collective re-cut of the slabs for equal particle counts (salva_hip_rebalance): returns this rank's new (lo, hi)."""
         lo, hi = C.c_int32(0), C.c_int32(0)

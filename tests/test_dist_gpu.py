@@ -557,3 +557,106 @@ def test_queries_in_a_decomposed_run(hip_lib):
     assert len(set(union_box)) == len(union_box), "a particle was reported by two ranks"
     # positions agree to rounding between the two runs: a particle within 1e-4 h of the query surface may flip
     assert len(set(union_box) ^ set(ref_box)) <= 2 and len(set(union_ball) ^ set(ref_ball)) <= 2, (len(union_box), len(ref_box))
+
+
+def test_particles_are_created_and_deleted_in_a_running_decomposed_world(hip_lib):
+    """An emitter and a sink in a decomposed run (faucet3.rs:69-104 in miniature): after 4 steps every rank adds a small block
+    above its part of the fluid (collective salva_hip_add_particles) and all ranks delete the same list of ids — a band of
+    particles that straddles the cut (collective salva_hip_delete_owned).  The undivided world does the same with
+    `Fluid::add_particles` and `delete_particle_at_next_timestep`; afterwards both run on and must agree like every other slab
+    test (ids: new particles are numbered after the largest id, rank by rank)."""
+    pos, vel, bpos = make_scene()
+    vel[:, 0] -= 2.0  # (no drift: the emitters stay above their ranks)
+    n0, nranks, before, after = len(pos), 2, 4, 6
+    cx = dist.cell_x(pos, H)
+    slabs = dist.split_slabs(cx, nranks)
+    owner = dist.owner_of(cx, slabs)
+    order = np.concatenate([np.nonzero(owner == r)[0] for r in range(nranks)])  # global id -> index in `pos`
+    inv = np.empty(n0, np.int64)
+    inv[order] = np.arange(n0)                                                   # index in `pos` -> global id
+    offsets = np.concatenate([[0], np.cumsum([int((owner == r).sum()) for r in range(nranks)])])
+    top = pos[:, 1].max()
+    # one 4x3x4 block per rank, two cells above the fluid, well inside the rank's slab
+    blocks = []
+    for r in range(nranks):
+        xm = 0.5 * (slabs[r][0] + slabs[r][1] + 1) * H
+        b = scenes.cube_fluid_positions(4, 3, 4, R) + np.float32([xm, top + 2 * H, pos[:, 2].mean()])
+        blocks.append(b.astype(np.float32))
+    # the sink: every particle whose x lies within 0.6 h of the cut and in the upper half of the block at the start
+    cut_x = slabs[1][0] * H
+    doomed = np.nonzero((np.abs(pos[:, 0] - cut_x) < 1.1 * H) & (pos[:, 1] > np.median(pos[:, 1])))[0]
+    assert len(doomed) >= 100 and {0, 1} <= set(owner[doomed].tolist())
+
+    # ---- undivided world
+    w = LiquidWorld(solver(), R, SF)
+    f = Fluid(pos, R, 1000.0)
+    f.velocities = vel
+    f.nonpressure_forces.extend(FORCES["make"]())
+    fh = w.add_fluid(f)
+    w.add_boundary(Boundary(bpos))
+    for _ in range(before):
+        w.step(DT, G)
+    for b in blocks:
+        fh.add_particles(b)
+    for i in doomed:
+        fh.delete_particle_at_next_timestep(int(i))
+    ref_stats = [w.step(DT, G) for _ in range(after)]
+    keep = np.ones(n0 + sum(len(b) for b in blocks), bool)
+    keep[doomed] = False
+    ref_pos = np.array(fh.positions)
+    assert len(ref_pos) == int(keep.sum())
+    # id of every surviving particle of the undivided world, in its (compacted) host order
+    new_ids = n0 + np.arange(sum(len(b) for b in blocks))
+    ref_ids = np.concatenate([inv, new_ids])[keep]
+    del w
+
+    # ---- two slabs
+    comms = dist.Comm.loopback(nranks)
+    results, errors, stats = [None] * nranks, [None] * nranks, [None] * nranks
+    doomed_ids = inv[doomed].astype(np.uint32)
+
+    def rank_main(r):
+        try:
+            wr = LiquidWorld(solver(), R, SF)
+            mine = np.nonzero(owner == r)[0]
+            fr = Fluid(pos[mine], R, 1000.0)
+            fr.velocities = vel[mine]
+            fr.nonpressure_forces.extend(FORCES["make"]())
+            hr = wr.add_fluid(fr)
+            wr.add_boundary(Boundary(bpos[dist.boundary_subset(bpos, H, slabs[r], r, nranks)]))
+            wr.set_domain(comms[r], slabs[r][0], slabs[r][1], int(offsets[r]))
+            for _ in range(before):
+                wr.step(DT, G)
+            wr.add_owned(hr, blocks[r])
+            left = wr.delete_owned(doomed_ids)  # the same list on every rank: each removes what it owns
+            assert left == int((owner == r).sum()) + len(blocks[r]) - int((owner[doomed] == r).sum()), left
+            stats[r] = [wr.step(DT, G) for _ in range(after)]
+            results[r] = wr.owned()
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    for e in errors:
+        if e is not None:
+            raise e
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    for c in comms:
+        c.destroy()
+    got = {}
+    for r in range(nranks):
+        gid, p, v, _slot = results[r]
+        for g, x in zip(gid.tolist(), p):
+            assert g not in got, "a particle is owned twice"
+            got[g] = x
+    assert sorted(got) == sorted(ref_ids.tolist()), "the sets of surviving ids differ"
+    got_pos = np.stack([got[int(g)] for g in ref_ids])
+    err = np.linalg.norm(got_pos - ref_pos, axis=1).max()
+    assert err < 2e-4 * H * after, f"positions differ by {err / H:.2e} h"
+    for k in range(after):
+        assert stats[0][k].n_divergence_iters == stats[1][k].n_divergence_iters
+        assert abs(stats[0][k].n_divergence_iters - ref_stats[k].n_divergence_iters) <= 2 and abs(stats[0][k].n_pressure_iters - ref_stats[k].n_pressure_iters) <= 1
+        assert sum(int(stats[r][k].nparticles) for r in range(nranks)) == len(ref_pos)
