@@ -201,8 +201,10 @@ def test_basic3_literal_scene_200_steps():
         if k + 1 in checkpoints:
             # stated tolerance 1e-4 r per step, or what the reference's own arithmetic is worth on this flow:
             # the oracle's f32 and f64 runs are 1e-3 r apart after 50 steps, 0.08 r after 100 and decorrelated (6 r) after 200;
-            # two max-deviations of chaotic runs are compared, hence the factor 10 rather than 2
-            assert d < max(1e-4 * (k + 1), 10.0 * noise), f"after {k + 1} steps: {d:.3e} r vs oracle, oracle f32-f64 {noise:.3e} r"
+            # measured (profiles/r03_experiments/r03x_literal_scene_ratios.log): the HIP run stays 0.02-0.7 of that distance from
+            # the oracle's f32 run at every checkpoint, so the bound is 2 x the oracle's own noise (round 2: 10 x)
+            print(f"basic3 checkpoint {k + 1}: |hip - oracle| = {d:.3e} r, oracle |f32 - f64| = {noise:.3e} r, ratio {d / max(noise, 1e-30):.2f}")
+            assert d < max(1e-4 * (k + 1), 2.0 * noise), f"after {k + 1} steps: {d:.3e} r vs oracle, oracle f32-f64 {noise:.3e} r"
     # bulk state after the splash: centre of mass and kinetic energy agree to a few per cent whatever the chaos did to particles
     po, vo = o.fluid_vec(0, "positions").astype(np.float64), o.fluid_vec(0, "velocities").astype(np.float64)
     pg, vg = fl.positions.astype(np.float64), fl.velocities.astype(np.float64)
@@ -254,6 +256,10 @@ def test_faucet3_literal_scene():
         assert h.num_particles() == o.fluid_len(0) == 100 * (k // 12)
         if h.num_particles():
             d = max_norm_diff(h.positions, o.fluid_vec(0, "positions")) / r
+            if k + 1 in (24, 48, 72, 96):  # while the sheets are still the same flow: the stated tolerance or 3 x the oracle's own noise
+                noise_k = max_norm_diff(o.fluid_vec(0, "positions"), o64.fluid_vec(0, "positions")) / r
+                print(f"faucet3 checkpoint {k + 1}: |hip - oracle| = {d:.3e} r, oracle |f32 - f64| = {noise_k:.3e} r")
+                assert d < max(1e-4 * (k + 1), 3.0 * noise_k), f"after {k + 1} steps: {d:.3e} r vs oracle, oracle f32-f64 {noise_k:.3e} r"
             if d < 1e-2:
                 same_flow_steps += 1
                 assert abs(int(st.ncontacts) - int(so.ncontacts)) <= max(8, int(2e-4 * so.ncontacts)), (k, st.ncontacts, so.ncontacts)
@@ -262,7 +268,11 @@ def test_faucet3_literal_scene():
     pg = h.positions
     noise = max_norm_diff(po, o64.fluid_vec(0, "positions")) / r
     d = max_norm_diff(pg, po) / r
-    assert d < max(1e-4 * nsteps, 10.0 * noise), f"after {nsteps} steps: {d:.3e} r vs oracle, oracle f32-f64 {noise:.3e} r"
+    print(f"faucet3 after {nsteps} steps: |hip - oracle| = {d:.3e} r, oracle |f32 - f64| = {noise:.3e} r, ratio {d / max(noise, 1e-30):.2f}, same-flow steps {same_flow_steps}")
+    # (by now the runs are decorrelated — tens of radii apart, the oracle's f32 and f64 runs as much as the HIP run: two maxima
+    # over chaotic trajectories are compared, measured ratio 2.0 — so the bound here stays a factor, 4 x, and the bulk checks
+    # below carry the meaning)
+    assert d < max(1e-4 * nsteps, 4.0 * noise), f"after {nsteps} steps: {d:.3e} r vs oracle, oracle f32-f64 {noise:.3e} r"
     # the sheets that reached the ball (top at y = 0.15) were deflected, not swallowed: nothing inside the sampled sphere
     assert np.linalg.norm(pg, axis=1).min() > 0.12 and np.linalg.norm(po, axis=1).min() > 0.12
     assert abs(pg[:, 1].mean() - po[:, 1].mean()) < 2 * r
