@@ -925,7 +925,8 @@ void World::run_forces(const StepCtx& c) {
 // enqueued, and the interior launch would read the previous solve's `done`.)
 template <typename Launch>
 void World::evaluate_split(const StepCtx& c, int iteration, Launch&& launch) {
-    if (!comm || !overlap_exchange || iteration == 0) { launch(c, stream); return; }
+    // (nothing to overlap with when no ghost is refreshed: a one-rank communicator, or a rank whose faces hold no particle)
+    if (!comm || !overlap_exchange || iteration == 0 || nghost_lo + nghost_hi + nborder_lo + nborder_hi == 0) { launch(c, stream); return; }
     StepCtx ci = c, cb = c;
     ci.phase = 1; cb.phase = 2;
     SALVA_HIP_CHECK(hipStreamWaitEvent(stream2, ev_pre_refresh, 0));

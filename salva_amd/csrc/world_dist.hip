@@ -159,6 +159,15 @@ void World::dist_prepare() {
         dist_started = true;
     }
     const bool has_lo = comm->has_lo(), has_hi = comm->has_hi();
+    if (!has_lo && !has_hi) {
+        // a communicator of one rank: nobody to hand particles to or to mirror — the set stays as it is (every particle owned,
+        // no ghost), and the step runs the single-domain schedule (finalize_solve, evaluate_split)
+        n_owned = n;
+        nborder_lo = nborder_hi = nghost_lo = nghost_hi = 0;
+        send_lo_idx.ensure(1); send_hi_idx.ensure(1); ghost_lo_idx.ensure(1); ghost_hi_idx.ensure(1);
+        fbuf_send.ensure(1); fbuf_recv.ensure(1);
+        return;
+    }
     if (!nbr_bounds_valid) {
         // the far ends of the neighbours' slabs: a leaver must land inside the adjacent slab (k_dist_flags, flag 4)
         const unsigned long long OFF = 1ull << 40;
@@ -251,6 +260,7 @@ void World::dist_build_lists() {
 // Refresh one per-particle field of the ghosts from its owners: gather the mirrored edge-plane particles into a dense
 // buffer, one sendrecv with both neighbours, scatter into the ghost slots.  All on the world's stream.
 void World::refresh_f32(float* field) {
+    if (!comm->has_lo() && !comm->has_hi()) return;
     SALVA_HIP_CHECK(hipEventRecord(ev_pre_refresh, stream));  // (what evaluate_split lets the interior tiles start after)
     float* sb = reinterpret_cast<float*>(fbuf_send.p);
     float* rb = reinterpret_cast<float*>(fbuf_recv.p);
@@ -262,6 +272,7 @@ void World::refresh_f32(float* field) {
     launch_scatter_f32(nghost_hi, ghost_hi_idx.p, rb + nghost_lo, field, stream);
 }
 void World::refresh_f4(float4* field) {
+    if (!comm->has_lo() && !comm->has_hi()) return;
     SALVA_HIP_CHECK(hipEventRecord(ev_pre_refresh, stream));
     float4* sb = fbuf_send.p;
     float4* rb = fbuf_recv.p;
@@ -277,7 +288,7 @@ void World::refresh_f4(float4* field) {
 void World::finalize_solve(SolveCtl* ctl, SolveCtl* pub) {
     const unsigned ntiles = nlaunch;  // one partial per launched (non-empty) tile
     const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1);
-    if (!comm) {
+    if (!comm || comm->size() == 1) {
         // (folding this into the evaluate kernels through a last-workgroup reduction was measured 7x slower: the
         // device-scope release every workgroup needs writes the XCD's whole L2 back)
         launch_finalize_error(partials.p, ntiles, nm, model_counts.p, ctl, pub, stream);
@@ -288,7 +299,6 @@ void World::finalize_solve(SolveCtl* ctl, SolveCtl* pub) {
     launch_decide(d_sums.p, nm, model_counts.p, ctl, pub, stream);
 }
 
-// Download the particles this rank owns (unordered): global ids, positions, velocities, fluid slot.  Returns the count.
 // ---- particle creation and removal in a running decomposed world.  Both are COLLECTIVE: every rank calls them between the
 // same two steps (with nothing to add / delete where it has nothing), because the per-fluid particle counts the error
 // averages divide by are global (compute_divergences / compute_predicted_densities: `max_error / num_particles`,
@@ -406,6 +416,7 @@ uint64_t World::delete_owned(uint32_t n_ids, const uint32_t* gids) {
     return n_owned;
 }
 
+// Download the particles this rank owns (unordered): global ids, positions, velocities, fluid slot.  Returns the count.
 uint64_t World::get_owned(uint32_t cap, uint32_t* gids, float* pos, float* vel_out, uint32_t* models) {
     use_device();
     if (!comm) throw HipError(SALVA_HIP_E_INVALID, "get_owned is for multi-GPU worlds (set_domain)");
