@@ -194,6 +194,8 @@ class World {
     uint32_t halo_cap = 0xffffffffu, bhalo_cap = 0xffffffffu, nslices_cap = 0xffffffffu;
     uint64_t halo_len = ~0ull, bhalo_len = ~0ull;
     uint64_t spec_misses = 0;  // passes discarded because the prediction did not hold
+    bool trust_cap0 = false;     // SALVA_HIP_LIST_CAP0 (tests)
+    bool lists_checked = false;  // the list capacity has held once since the last edit of the objects (upload_tables clears it)
     bool defer_off = false;  // SALVA_HIP_NO_DEFER_LISTS: check the list capacity in the middle of the step (read at construction)
     bool spec_off = true, spec_tight = false;  // SALVA_HIP_SPECULATE / SALVA_HIP_SPEC_TIGHT, read at construction
     int num_cus = 256;

@@ -134,7 +134,8 @@ World::World(const SalvaHipParams& p) : prm(p) {
 #ifdef SALVA_HIP_DIAG
     if (const char* e = getenv("SALVA_HIP_SCHED")) sched_mode = atoi(e);
 #endif
-    if (const char* e = getenv("SALVA_HIP_LIST_CAP0")) cap_ff = std::max<uint32_t>(LIST_REGS, ((uint32_t)atoi(e) + 3u) & ~3u);  // (tests: force an overflow)
+    // (tests: force an overflow — the given capacity also counts as checked, so that the very first step takes the deferred path)
+    if (const char* e = getenv("SALVA_HIP_LIST_CAP0")) { cap_ff = std::max<uint32_t>(LIST_REGS, ((uint32_t)atoi(e) + 3u) & ~3u); trust_cap0 = true; }
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device) == hipSuccess && cus > 0) num_cus = cus;
@@ -577,6 +578,7 @@ static inline bool groups_test(uint32_t m1, uint32_t f1, uint32_t m2, uint32_t f
 
 void World::upload_tables() {
     if (!tables_dirty) return;
+    lists_checked = trust_cap0;  // the objects changed: the next step checks the list capacity before it solves (World::step)
     const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1), nbm = (uint32_t)std::max<size_t>(bounds.size(), 1);
     std::vector<float> r0(nm, 1000.0f);
     std::vector<uint32_t> counts(nm, 0);
@@ -1105,14 +1107,30 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     // step although it fails about once per run (the capacity follows the longest list seen so far): where the pass can be
     // repeated, check at the end of the step with the read-back that happens there anyway, and repeat on overflow.
 
+    // It stays in the middle of the step until the capacity has held once for the current set of objects (`lists_checked`,
+    // cleared by every edit of the fluids or boundaries): the first step of a scene — whose lists are longer than the
+    // initial capacity in almost any dense scene — is then not computed twice.
+    //
+    // State a pass touches, and where a discarded pass leaves it (extend this list with every new side effect, or exclude the
+    // feature in can_redo):
+    //   particle arrays of buffer cur^1 (the sort's output: positions, velocities, dv / pressures, models, permutation) ....
+    //       recomputed by the repeated pass; buffer `cur` (the pre-sort state) is read-only until the pass commits
+    //   cur, dt_prev / inv_dt_prev, h_rb->bbox, last_iters ........ snapshot below, restored on discard
+    //   per-step scratch (acc, w, rho, alpha, kappa, lists, tables, partials, control blocks) ........ rewritten from the start
+    //   d_flags ........ cleared at the top of every attempt
+    //   counters / stats ........ filled after the loop; discarded_passes counts the discards
+    //   boundary force accumulators, host force callbacks, DynamicContactSampling push-outs, ghost exchanges ........ not
+    //       repeatable: can_redo is false for worlds that have them
     int32_t bbox_pre[6];
     memcpy(bbox_pre, h_rb->bbox, sizeof(bbox_pre));
     const float dt_prev0 = dt_prev, inv_dt_prev0 = inv_dt_prev;
     const int cur0 = cur;
+    uint32_t last_iters0[NUM_SOLVES];
+    memcpy(last_iters0, last_iters, sizeof(last_iters0));
     StepCtx c{};
     for (int attempt = 0;; ++attempt) {
     bool spec = can_speculate && attempt == 0;
-    const bool defer_lists = can_redo && !defer_off && attempt == 0;
+    const bool defer_lists = can_redo && !defer_off && attempt == 0 && lists_checked;
     if (attempt > 0) SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));  // (whatever the discarded pass flagged)
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
     {
@@ -1274,6 +1292,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             ++counters.discarded_passes;
             cur = cur0; dt_prev = dt_prev0; inv_dt_prev = inv_dt_prev0;
             memcpy(h_rb->bbox, bbox_pre, sizeof(bbox_pre));
+            memcpy(last_iters, last_iters0, sizeof(last_iters0));
             if (need_ff > cap_ff) cap_ff = (need_ff + need_ff / 4 + 4u) & ~3u;
             if (need_fb > cap_fb) cap_fb = (need_fb + need_fb / 4 + 4u) & ~3u;
             continue;
@@ -1289,6 +1308,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             ++spec_misses; ++counters.speculative_passes; ++counters.discarded_passes;
             cur = cur0; dt_prev = dt_prev0; inv_dt_prev = inv_dt_prev0;
             memcpy(h_rb->bbox, bbox_pre, sizeof(bbox_pre));
+            memcpy(last_iters, last_iters0, sizeof(last_iters0));
             if (need_ff > cap_ff) cap_ff = (need_ff + need_ff / 4 + 4u) & ~3u;
             if (need_fb > cap_fb) cap_fb = (need_fb + need_fb / 4 + 4u) & ~3u;
             continue;
@@ -1296,6 +1316,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     }
     if (spec) ++counters.speculative_passes;
     pred_tt = h_rb->tile_total; pred_n = n; pred_valid = true;
+    lists_checked = true;  // (every path to here has compared the longest lists with the capacity)
     break;
     }  // attempts
     acc_user = false;
