@@ -125,7 +125,7 @@ impl LiquidWorld {
     /// `LiquidWorld::new(solver, particle_radius, smoothing_factor)` (liquid_world.rs:39-57).
     pub fn new(solver: impl GpuPressureSolver, particle_radius: Real, smoothing_factor: Real) -> Result<Self, Error> {
         let mut params = solver.params(particle_radius, smoothing_factor);
-        params.enable_timers = 1;
+        params.enable_timers = 0; // `Counters::new`: timers disabled until `enable_counters(true)` (counters/timer.rs:11-18)
         let mut raw = std::ptr::null_mut();
         check(unsafe { ffi::salva_hip_create(&params, &mut raw) })?;
         Ok(Self {
@@ -314,6 +314,17 @@ impl LiquidWorld {
             self.sync()?;
         }
         Ok(())
+    }
+
+    /// `world.counters.enable()` / `.disable()` (counters/mod.rs:56-72): the device library has to know, because the timers are
+    /// HIP events it records inside the step.
+    pub fn enable_counters(&mut self, enabled: bool) -> Result<(), Error> {
+        if enabled {
+            self.counters.enable();
+        } else {
+            self.counters.disable();
+        }
+        check(unsafe { ffi::salva_hip_enable_counters(self.raw, enabled as i32) })
     }
 
     fn refresh_counters(&mut self) -> Result<(), Error> {

@@ -290,6 +290,10 @@ float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps);
 float salva_hip_time_kernel(SalvaHipWorld* world, int32_t kernel, int32_t reps);
 /* `world.counters` after the last step — counters/mod.rs:17-72 */
 int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out);
+/* `Counters::enable()` / `disable()` (counters/mod.rs:56-72): switches the timers (SalvaHipParams::enable_timers) from the next step
+ * on.  Off — the reference's default, `Timer::new` (counters/timer.rs:11-18) — a step records no events and the *_ms / *_time
+ * fields read 0; on, a step costs ~20 us more of host time (ten event records and their read-out). */
+int salva_hip_enable_counters(SalvaHipWorld* world, int32_t enabled);
 /* ---- multi-GPU: one process and one world per GPU, the domain cut into slabs of grid-cell planes along x.
  * No counterpart in the reference (single process).  A world owns the particles whose cell x = floor(x / h) lies in
  * [cell_lo, cell_hi] (the first / last rank also keep whatever lies beyond their open end); every step it migrates

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_force_get_state", "salva_hip_force_add_accelerations", "salva_hip_set_fluid_field", "salva_hip_get_timestep",
     "salva_hip_set_timestep", "salva_hip_get_counters", "salva_hip_time_kernel", "salva_hip_particles_intersecting_shape", "salva_hip_rebalance",
     "salva_hip_set_boundary_dynamic_sampling", "salva_hip_get_boundary_sources", "salva_hip_set_boundary_dynamic_sampling_host",
-    "salva_hip_delete_owned",
+    "salva_hip_delete_owned", "salva_hip_enable_counters",
 ]
 
 
@@ -205,6 +205,7 @@ def lib():
     L.salva_hip_time_kernel.argtypes = [vp, i32, i32]
     L.salva_hip_time_kernel.restype = f32
     L.salva_hip_get_counters.argtypes = [vp, C.POINTER(CountersStruct)]
+    L.salva_hip_enable_counters.argtypes = [vp, i32]
     if hasattr(L, "salva_hip_time_variant"):  # the kernel-development build only (SALVA_HIP_LIB_VARIANT=diag)
         L.salva_hip_time_variant.argtypes = [vp, i32, u32, i32, C.POINTER(u64)]
         L.salva_hip_time_variant.restype = f32

@@ -310,6 +310,13 @@ float salva_hip_time_kernel(SalvaHipWorld* world, int32_t kernel, int32_t reps) 
     return rc == SALVA_HIP_OK ? us : (float)rc;
 }
 
+int salva_hip_enable_counters(SalvaHipWorld* world, int32_t enabled) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->set_timers(enabled != 0);
+        return SALVA_HIP_OK;
+    });
+}
 int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out) {
     return guarded([&]() -> int {
         if (!world || !out) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");

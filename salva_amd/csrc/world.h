@@ -91,6 +91,7 @@ class World {
     // collective: re-cut the slabs at cell planes so that every rank owns about the same number of particles; the
     // particles follow in the next step's migration.  Returns this rank's new [lo, hi].
     void rebalance(int32_t* new_lo, int32_t* new_hi);
+    void set_timers(bool on) { prm.enable_timers = on ? 1 : 0; }
     uint64_t get_owned(uint32_t cap, uint32_t* gids, float* pos, float* vel, uint32_t* models);
     uint64_t delete_owned(uint32_t n_ids, const uint32_t* gids);
     uint32_t owned_count() const { return comm ? n_owned : n; }

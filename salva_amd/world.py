@@ -573,12 +573,19 @@ class Counters:
     solver_ms: float = 0.0
     step_ms: float = 0.0
     enabled: bool = False
+    _world: object = None
 
     def enable(self):
+        """Counters::enable (counters/mod.rs:56-63): the timers run from the next step on (salva_hip_enable_counters)."""
         self.enabled = True
+        if self._world is not None:
+            L.check(self._world._L.salva_hip_enable_counters(self._world._h, 1))
 
     def disable(self):
+        """Counters::disable (counters/mod.rs:65-72) — the default (`Timer::new`, counters/timer.rs:11-18)."""
         self.enabled = False
+        if self._world is not None:
+            L.check(self._world._L.salva_hip_enable_counters(self._world._h, 0))
 
 
 class _ObjectSet:
@@ -618,7 +625,7 @@ class LiquidWorld:
         p.min_divergence_iter, p.max_divergence_iter = solver.min_divergence_iter, solver.max_divergence_iter
         p.max_divergence_error = solver.max_divergence_error
         p.device = device
-        p.enable_timers = 1
+        p.enable_timers = 0  # Counters start disabled, as in the reference; `world.counters.enable()` switches the timers on
         self._params = p
         h = C.c_void_p()
         L.check(self._L.salva_hip_create(C.byref(p), C.byref(h)))
@@ -626,7 +633,7 @@ class LiquidWorld:
         self._particle_radius = float(particle_radius)
         self._fluids = _ObjectSet()
         self._boundaries = _ObjectSet()
-        self._counters = Counters()
+        self._counters = Counters(_world=self)
         self._counters_stale = False
         self.last_stats = L.StepStats()
 

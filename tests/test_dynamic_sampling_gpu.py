@@ -253,6 +253,7 @@ def test_counters_report_the_boundary_update():
     coupling = ColliderCouplingSet()
     coupling.register_coupling(b, "slab", slab, DynamicContactSampling(("cuboid", CUBOID_HE)))
     slab.dynamic = False
+    w.counters.enable()
     for _ in range(3):
         w.step_with_coupling(DT, GRAVITY, coupling)
     c = w.counters

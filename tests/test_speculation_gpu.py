@@ -22,7 +22,7 @@ def _dam_break():
     return s
 
 
-def _run(env, nsteps=50):
+def _run(env, nsteps=50, timers=False):
     old = {k: os.environ.get(k) for k in ("SALVA_HIP_SPECULATE", "SALVA_HIP_NO_SPECULATION", "SALVA_HIP_SPEC_TIGHT", "SALVA_HIP_NO_DEFER_LISTS",
                                           "SALVA_HIP_LIST_CAP0")}
     for k in old:
@@ -35,6 +35,8 @@ def _run(env, nsteps=50):
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+    if timers:
+        w.counters.enable()  # Counters::enable (counters/mod.rs:56-63); off by default, as in the reference
     iters = []
     for _ in range(nsteps):
         st = w.step(DT, GRAVITY)
@@ -98,7 +100,9 @@ def test_deferred_list_capacity_check_repeats_the_pass_on_overflow():
 
 
 def test_counters_tree_is_filled_like_the_reference():
-    w, fl, _ = _run({}, nsteps=4)
+    w0, _, _ = _run({}, nsteps=2)
+    assert w0.counters.step_time == 0 and w0.counters.cd.ncontacts > 0  # disabled timers read 0 (Timer::new), the counts are always there
+    w, fl, _ = _run({}, nsteps=4, timers=True)
     c = w.counters
     assert c.nsubsteps == 1 and c.cd.ncontacts == c.ncontacts > 0
     assert c.step_time > 0 and abs(c.stages.collision_detection_time + c.stages.solver_time - c.step_time) < 1e-3 * c.step_time + 1e-6
