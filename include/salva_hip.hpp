@@ -308,6 +308,8 @@ class LiquidWorld {  // liquid_world.rs
         });
     }
     // `world.counters` of the reference (counters/mod.rs:17-72): nsubsteps, step_time, custom, stages, cd, solver
+    // Counters::enable / disable (counters/mod.rs:56-72); disabled by default, as in the reference
+    void enable_counters(bool enabled = true) { check(salva_hip_enable_counters(w_, enabled ? 1 : 0)); }
     SalvaHipCounters counters_tree() const {
         SalvaHipCounters c{};
         check(salva_hip_get_counters(w_, &c));
