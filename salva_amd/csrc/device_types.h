@@ -90,6 +90,7 @@ struct StepCtx {
     float4* dii;         // IISPH (xyz, unused)
     float4* dijpj;       // IISPH sum_j d_ij p_j (xyz, unused)
     float4* iisph_q;     // IISPH d_ii p_i + sum_j d_ij p_j: what a neighbour contributes to compute_next_pressures in one record
+    float4* iisph_pr;    // IISPH (x, y, z, m / rho^2): what a neighbour contributes to compute_dij_pjl besides its pressure (k_iisph_dii)
     uint32_t* nff;       // # fluid-fluid contacts of each particle (self included)
     uint32_t* nfb;       // # fluid-boundary contacts
     uint32_t* nbr_ff;           // packed 16-bit halo slots: slice s owns dwords [s*cap_ff*64, (s+1)*cap_ff*64)

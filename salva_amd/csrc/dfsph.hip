@@ -86,27 +86,6 @@ void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s) {
     SALVA_LAUNCH_TILE(k_density_alpha, c, L, L.bytes(16, 16, 2), s, c);
 }
 
-// launch one of the three layout instantiations of a solver kernel (tile.h: FIXED_DS_SMALL / _LARGE / runtime distance)
-#define SALVA_LAUNCH_FIXED(kernel, DSV, c, L, lds, s, ...)                                                         \
-    do {                                                                                                           \
-        if ((DSV) == FIXED_DS_SMALL) SALVA_LAUNCH_TILE(kernel<FIXED_DS_SMALL>, c, L, lds, s, __VA_ARGS__);         \
-        else if ((DSV) == FIXED_DS_LARGE) SALVA_LAUNCH_TILE(kernel<FIXED_DS_LARGE>, c, L, lds, s, __VA_ARGS__);    \
-        else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                             \
-    } while (0)
-static uint32_t pick_ds(uint32_t slots_needed) {
-    return slots_needed <= FIXED_DS_SMALL ? FIXED_DS_SMALL : (slots_needed <= FIXED_DS_LARGE ? FIXED_DS_LARGE : 0u);
-}
-// P | W kernels: both arrays hold fluid halo + boundary halo
-static uint32_t pw_slots(const TileLds& L) { return L.sum_slots(); }
-static uint32_t pw_bytes(const TileLds& L, uint32_t ds, bool errtab) {
-    return (ds ? 2u * ds : 2u * pw_slots(L)) * 16u + (errtab ? TILE_ERR_BYTES : 0u) + 32u;
-}
-// P | K kernels: P holds fluid halo + 2 x boundary halo, K the fluid halo (4 bytes each)
-static uint32_t pk_slots(const TileLds& L) { return L.sum_slots() + L.max_halo_boundary; }
-static uint32_t pk_bytes(const TileLds& L, uint32_t ds) {
-    return (ds ? ds : pk_slots(L)) * 16u + ((L.max_halo_fluid + 63u) & ~63u) * 4u + 32u;
-}
-
 // ------------------------------------------------------------------------------------------------
 // compute_divergences (:279-356): D rho_i = max(sum_j m_j (w_i - w_j).grad W_ij + sum_b V_b rho0 w_i.grad W_ib, 0),
 // skipped (0) when the particle has fewer than 20 contacts; stores kappa_i = D rho_i * alpha_i (the only use of

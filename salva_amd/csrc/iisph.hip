@@ -9,6 +9,7 @@
 #include "bbox.h"
 #include "kernels.h"
 #include "tile.h"
+#include "pairs.h"
 
 namespace SALVA_KNS {
 using namespace salva;
@@ -59,6 +60,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dii(StepCtx c, float
         });
         c.dii[i] = make_float4(x, y, z, 0.0f);
         c.kappa[i] = c.dv[i].w * 0.5f;
+        // what particle i contributes as a NEIGHBOUR in compute_dij_pjl: its position and m_i / rho_i^2 — constant over the Jacobi
+        // loop, so k_iisph_dij_pj stages this record + the pressure instead of position, density and pressure
+        c.iisph_pr[i] = make_float4(pi.x, pi.y, pi.z, pi.w / (rhoi * rhoi));
     });
 }
 void launch_iisph_dii(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
@@ -66,34 +70,33 @@ void launch_iisph_dii(const StepCtx& c, const TileLds& L, float dt, hipStream_t 
     SALVA_LAUNCH_TILE(k_iisph_dii, c, L, L.bytes(16, 16, 2), s, c, dt);
 }
 
-// compute_predicted_densities (:92-142)
+// compute_predicted_densities (:92-142): the same sum as DFSPH's (pairs.h pair_sum_velocity_divergence), on the same skeleton
+template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_pred_density(StepCtx c, float dt) {
+    lds_base_check();
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    uint32_t i0_, gs0_;
-    t.first_own(i0_, gs0_);
-    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
-    const float4* Lp = nullptr;
-    const float4* Lw = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), Lp, Lw);
+    struct Own { float4 pi, wi; float rho; uint32_t mi, cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.w[i], c.rho[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist = pw_dist<DS>(c, t);
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
-    t.stage_boundary(c, Bp, Bv);
+    t.stage_pw(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), dist, Bp, Bv, true);
     Tile::staged_barrier();
-    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
         if (!active) return;
-        const float4 pi = c.posm[i];
-        const float4 wi = c.w[i];
-        const float rho0 = c.rho0_tab[c.model[i]];
-        float delta = 0.0f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
-            const float4 pj = Lp[s];
-            const float4 wj = lds_f4(Lw + s);
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-            delta += pj.w * (((wi.x - wj.x) * dx + (wi.y - wj.y) * dy + (wi.z - wj.z) * dz) * g);
-        });
+        const float4 pi = o.pi, wi = o.wi;
+        const float rho0 = rho0_of(c, o.mi);
+        float delta = near ? pair_sum_velocity_divergence_exact(c, i, gs, pi, wi, dist)
+                           : pair_sum_velocity_divergence(c, gs, nqu, o.lh, pi, wi, dist);
         for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Bp[s];
             const float4 vj = Bv[s];
@@ -101,14 +104,15 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_pred_density(StepCtx
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
             delta += pj.w * rho0 * (((wi.x - vj.x) * dx + (wi.y - vj.y) * dy + (wi.z - vj.z) * dz) * g);
         });
-        const float rs = c.rho[i] + delta * dt;
+        const float rs = o.rho + delta * dt;
         if (!(rs != 0.0f)) atomicOr(c.flags, 1u);  // :140
         c.rho_star[i] = rs;
     });
 }
 void launch_iisph_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_iisph_pred_density, c, L, dt, s);
-    SALVA_LAUNCH_TILE(k_iisph_pred_density, c, L, L.bytes(32, 32, 4), s, c, dt);
+    const uint32_t ds = pick_ds(pw_slots(L));
+    SALVA_LAUNCH_FIXED(k_iisph_pred_density, ds, c, L, pw_bytes(L, ds, false), s, c, dt);
 }
 
 // compute_aii (:188-233): a_ii = sum_j m_j (d_ii - d_ji) . grad W_ij with d_ji = grad W_ij dt^2 m_i / rho_i^2
@@ -154,32 +158,33 @@ void launch_iisph_aii(const StepCtx& c, const TileLds& L, float dt, hipStream_t 
     SALVA_LAUNCH_TILE(k_iisph_aii, c, L, L.bytes(16, 16, 2), s, c, dt);
 }
 
-// compute_dij_pjl (:235-268): sum_j d_ij p_j = dt^2 sum_j grad W_ij (-m_j p_j / rho_j^2)   (fluid neighbours only)
+// compute_dij_pjl (:235-268): sum_j d_ij p_j = dt^2 sum_j grad W_ij (-m_j p_j / rho_j^2)   (fluid neighbours only).
+// Fixed P | K layout (pairs.h pair_sum_gradient): P = (x_j, m_j / rho_j^2) written once per step by k_iisph_dii, K = p_j.
+template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dij_pj(StepCtx c, float dt, const float* __restrict__ p) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
+    lds_base_check();
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    uint32_t i0_, gs0_;
-    t.first_own(i0_, gs0_);
-    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
-    const float4* Lp = nullptr;
-    const float* Lr = nullptr;
-    const float* Lq = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), static_cast<const float*>(p), Lp, Lr, Lq);
+    struct Own { float4 pi; uint32_t cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) { return Own{c.posm[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)}; };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist = pk_dist<DS>(c, t);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    t.stage_pk(c, static_cast<const float4*>(c.iisph_pr), p, dist, Bp, Bv);
     Tile::staged_barrier();
-    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
         if (!active) return;
-        const float4 pi = c.posm[i];
-        float x = 0.f, y = 0.f, z = 0.f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
-            const float4 pj = Lp[s];
-            const float rhoj = Lr[s];
-            const float pjl = Lq[s];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * fast_div(-pj.w * pjl, rhoj * rhoj);
-            x += dx * sc; y += dy * sc; z += dz * sc;
-        });
+        const float4 pi = o.pi;
+        float x, y, z;
+        if (near) pair_sum_gradient_exact(c, i, gs, pi, dist, [&](float kj) { return -kj; }, x, y, z);
+        else pair_sum_gradient(c, gs, nqu, o.lh, pi, dist, [&](float ka, float kb) { return f2{-ka, -kb}; }, x, y, z);
         const float dt2 = dt * dt;
         const float4 dp = make_float4(x * dt2, y * dt2, z * dt2, 0.0f);
         c.dijpj[i] = dp;
@@ -192,57 +197,83 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dij_pj(StepCtx c, fl
 }
 void launch_iisph_dij_pj(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_iisph_dij_pj, c, L, dt, p, s);
-    SALVA_LAUNCH_TILE(k_iisph_dij_pj, c, L, L.bytes(24, 0, 3), s, c, dt, p);
+    const uint32_t ds = pick_ds(pk_slots(L));
+    SALVA_LAUNCH_FIXED(k_iisph_dij_pj, ds, c, L, pk_bytes(L, ds), s, c, dt, p);
 }
 
-// compute_next_pressures (:270-353)
+// compute_next_pressures (:270-353).  The pair loop of the Jacobi pass on the fixed-layout skeleton of the DFSPH solver kernels
+// (pairs.h): P at LDS byte 0, q = d_jj p_j + sum_k d_jk p_k at a compile-time distance, two contacts per step in packed
+// arithmetic with kernel_gfac2.  With grad W_ij = G d (G = gscale * gfac, d = x_i - x_j) the summand
+//   m_j (dpi - q_j + grad W_ij fji p_i) . grad W_ij  =  m_j G (dpi - q_j) . d  +  m_j G^2 |d|^2 fji p_i,
+// so the loop accumulates the two sums separately and the per-particle constants are applied once.  Slices that hold a pair
+// closer than 1e-5 h (StepCtx::slice_near) walk their exact lists with kernel_grad, as in dfsph.hip.
+template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCtx c, float dt, float omega,
                                                                      const float* __restrict__ p, float* __restrict__ p_next) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
-    __shared__ float errtab[TILE_MAX_WAVES][MAX_MODELS];
+    lds_base_check();
     Tile t;
     t.setup(c);
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
-    uint32_t i0_, gs0_;
-    t.first_own(i0_, gs0_);
-    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
-    const float4* Lp = nullptr;
-    const float4* Lq = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.iisph_q), Lp, Lq);
+    struct Own { float4 pi, dpi; float a, prs, rhoi, rstar; uint32_t mi, cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.dijpj[i], c.aii[i], p[i], c.rho[i], c.rho_star[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist = pw_dist<DS>(c, t);
     const float4* Bp = nullptr;
-    t.stage_boundary(c, Bp);
+    const float4* Bv = nullptr;
+    t.stage_pw(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.iisph_q), dist, Bp, Bv, false);
     TileErr E;
-    E.init(errtab, c);
+    E.init(carve_errtab(t), c);
     Tile::staged_barrier();
-    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
-            mi = c.model[i];
-            const float a = c.aii[i];
+            mi = o.mi;
+            const float a = o.a;
             float pn = 0.0f;
             if (fabsf(a) > 1.0e-9f) {
-                const float rho0 = c.rho0_tab[mi];
-                const float4 pi = c.posm[i];
-                const float prs = p[i];
-                const float rhoi = c.rho[i];
-                const float derr = rho0 - c.rho_star[i];
-                const float4 dpi = c.dijpj[i];
-                const float fji = dt * dt * pi.w / (rhoi * rhoi);
+                const float rho0 = rho0_of(c, mi);
+                const float4 pi = o.pi, dpi = o.dpi;
+                const float prs = o.prs;
+                const float derr = rho0 - o.rstar;
+                const float fji = dt * dt * pi.w / (o.rhoi * o.rhoi);
                 float sum = 0.0f;
-                struct Rec { float4 p, q; };
-                for_each_ff_regs(c, gs, lo, [&](uint32_t s) { return Rec{Lp[s], lds_f4(Lq + s)}; }, [&](const Rec& rc) { SALVA_PAIR_MATH
-                    const float4 pj = rc.p;
-                    const float4 qj = rc.q;  // d_jj p_j + sum_k d_jk p_k (k_iisph_dij_pj)
-                    const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                    const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-                    const float gx = dx * g, gy = dy * g, gz = dz * g;
-                    // factor = dij_pjl[i] - dii[j] p_j - (dij_pjl[j] - dji p_i)   (:318-321), the two neighbour terms pre-added
-                    const float fx = (dpi.x - qj.x) + gx * fji * prs;
-                    const float fy = (dpi.y - qj.y) + gy * fji * prs;
-                    const float fz = (dpi.z - qj.z) + gz * fji * prs;
-                    sum += pj.w * (fx * gx + fy * gy + fz * gz);
-                });
+                if (near) {
+                    for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                        const RecPW A = load_pw(s << 4, dist);
+                        const float dx = pi.x - A.p.x, dy = pi.y - A.p.y, dz = pi.z - A.p.z;
+                        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                        const float gx = dx * g, gy = dy * g, gz = dz * g;
+                        // factor = dij_pjl[i] - dii[j] p_j - (dij_pjl[j] - dji p_i)   (:318-321), the two neighbour terms pre-added
+                        const float fx = (dpi.x - A.w.x) + gx * fji * prs;
+                        const float fy = (dpi.y - A.w.y) + gy * fji * prs;
+                        const float fz = (dpi.z - A.w.z) + gz * fji * prs;
+                        sum += A.p.w * (fx * gx + fy * gy + fz * gz);
+                    });
+                } else {
+                    f2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+                    const f2 tiny = {1.0e-30f, 1.0e-30f};
+                    for_each_ff2<true, false, true>(c, gs, nqu, o.lh, [&](uint32_t off) { return load_pw(off, dist); },
+                                                    [&](const RecPW& A, const RecPW& B) { SALVA_PAIR_MATH
+                        const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
+                        f2 r2 = dz * dz + tiny;
+                        r2 = dy * dy + r2;
+                        r2 = dx * dx + r2;
+                        const f2 g = kernel_gfac2(r2, c.sc);
+                        const f2 ex = {dpi.x - A.w.x, dpi.x - B.w.x}, ey = {dpi.y - A.w.y, dpi.y - B.w.y}, ez = {dpi.z - A.w.z, dpi.z - B.w.z};
+                        const f2 gm = {g.x * A.p.w, g.y * B.p.w};
+                        sa += (ex * dx + ey * dy + ez * dz) * gm;
+                        sb += (g * gm) * r2;
+                    });
+                    sum = (sa.x + sa.y) * c.sc.gscale + (sb.x + sb.y) * (c.sc.gscale * c.sc.gscale) * (fji * prs);
+                }
                 for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                     const float4 pj = Bp[s];
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -262,40 +293,49 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
 void launch_iisph_next_pressure(const StepCtx& c, const TileLds& L, float dt, float omega, const float* p, float* p_next,
                                 hipStream_t s) {
     SALVA_OK_DISPATCH(launch_iisph_next_pressure, c, L, dt, omega, p, p_next, s);
-    SALVA_LAUNCH_TILE(k_iisph_next_pressure, c, L, L.bytes(32, 16, 3), s, c, dt, omega, p, p_next);
+    const uint32_t ds = pick_ds(pw_slots(L));
+    SALVA_LAUNCH_FIXED(k_iisph_next_pressure, ds, c, L, pw_bytes(L, ds, true), s, c, dt, omega, p, p_next);
 }
 
-// compute_velocity_changes (:355-404)
-__global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(StepCtx c, float dt, const float* __restrict__ p) {
+// compute_velocity_changes (:355-404): dv_i -= dt sum_j grad W_ij m_j (p_i / rho_i^2 + p_j / rho_j^2) (+ the boundary term with its
+// reaction force).  Fixed P | K layout: K = p_j / rho_j^2, written for every particle (ghosts included: their pressures were
+// refreshed) by k_iisph_pr2 just before — into StepCtx::alpha, which IISPH does not use.
+__global__ __launch_bounds__(BLOCK) void k_iisph_pr2(StepCtx c, const float* __restrict__ p) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= c.n) return;
+    const float r = c.rho[i];
+    c.alpha[i] = p[i] / (r * r);
+}
+template <uint32_t DS>
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(StepCtx c, float dt) {
+    lds_base_check();
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    uint32_t i0_, gs0_;
-    t.first_own(i0_, gs0_);
-    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
-    const float4* Lp = nullptr;
-    const float* Lr = nullptr;
-    const float* Lq = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.rho), static_cast<const float*>(p), Lp, Lr, Lq);
+    struct Own { float4 pi, d; float pri; uint32_t mi, cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.dv[i], c.alpha[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist = pk_dist<DS>(c, t);
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
-    t.stage_boundary(c, Bp, Bv);
+    t.stage_pk(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.alpha), dist, Bp, Bv);
     Tile::staged_barrier();
-    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
         if (!active) return;
-        const float4 pi = c.posm[i];
-        const float rho0 = c.rho0_tab[c.model[i]];
-        const float rhoi = c.rho[i];
-        const float pri = p[i] / (rhoi * rhoi);
-        float4 d = c.dv[i];
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
-            const float4 pj = Lp[s];
-            const float rhoj = Lr[s];
-            const float pjl = Lq[s];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (dt * pj.w * (pri + fast_div(pjl, rhoj * rhoj)));
-            d.x -= dx * sc; d.y -= dy * sc; d.z -= dz * sc;
-        });
+        const float4 pi = o.pi;
+        const float rho0 = rho0_of(c, o.mi);
+        const float pri = o.pri;
+        float4 d = o.d;
+        float sx, sy, sz;
+        if (near) pair_sum_gradient_exact(c, i, gs, pi, dist, [&](float kj) { return pri + kj; }, sx, sy, sz);
+        else pair_sum_gradient(c, gs, nqu, o.lh, pi, dist, [&](float ka, float kb) { return f2{pri + ka, pri + kb}; }, sx, sy, sz);
+        d.x -= sx * dt; d.y -= sy * dt; d.z -= sz * dt;
         for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Bp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -310,7 +350,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(Ste
 }
 void launch_iisph_velocity_changes(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_iisph_velocity_changes, c, L, dt, p, s);
-    SALVA_LAUNCH_TILE(k_iisph_velocity_changes, c, L, L.bytes(24, 32, 5), s, c, dt, p);
+    if (!c.n) return;
+    k_iisph_pr2<<<num_blocks(c.n), BLOCK, 0, s>>>(c, p);
+    const uint32_t ds = pick_ds(pk_slots(L));
+    SALVA_LAUNCH_FIXED(k_iisph_velocity_changes, ds, c, L, pk_bytes(L, ds), s, c, dt);
 }
 
 // update_velocities_and_positions (:406-420) + zero velocity changes (:707-709); stores the pressure for the

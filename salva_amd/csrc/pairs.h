@@ -125,4 +125,27 @@ __device__ __forceinline__ float (*carve_errtab(Tile& t))[MAX_MODELS] {
     return reinterpret_cast<float (*)[MAX_MODELS]>(t.carve<float>(TILE_MAX_WAVES * MAX_MODELS));
 }
 
+// ---- host side: launch shapes of the fixed-layout kernels (dfsph.hip, iisph.hip)
+// launch one of the three layout instantiations of a solver kernel (tile.h: FIXED_DS_SMALL / _LARGE / runtime distance)
+#define SALVA_LAUNCH_FIXED(kernel, DSV, c, L, lds, s, ...)                                                         \
+    do {                                                                                                           \
+        if ((DSV) == FIXED_DS_SMALL) SALVA_LAUNCH_TILE(kernel<FIXED_DS_SMALL>, c, L, lds, s, __VA_ARGS__);         \
+        else if ((DSV) == FIXED_DS_LARGE) SALVA_LAUNCH_TILE(kernel<FIXED_DS_LARGE>, c, L, lds, s, __VA_ARGS__);    \
+        else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                             \
+    } while (0)
+static inline uint32_t pick_ds(uint32_t slots_needed) {
+    return slots_needed <= FIXED_DS_SMALL ? FIXED_DS_SMALL : (slots_needed <= FIXED_DS_LARGE ? FIXED_DS_LARGE : 0u);
+}
+// P | W kernels: both arrays hold fluid halo + boundary halo
+static inline uint32_t pw_slots(const TileLds& L) { return L.sum_slots(); }
+static inline uint32_t pw_bytes(const TileLds& L, uint32_t ds, bool errtab) {
+    return (ds ? 2u * ds : 2u * pw_slots(L)) * 16u + (errtab ? TILE_ERR_BYTES : 0u) + 32u;
+}
+// P | K kernels: P holds fluid halo + 2 x boundary halo, K the fluid halo (4 bytes each)
+static inline uint32_t pk_slots(const TileLds& L) { return L.sum_slots() + L.max_halo_boundary; }
+static inline uint32_t pk_bytes(const TileLds& L, uint32_t ds) {
+    return (ds ? ds : pk_slots(L)) * 16u + ((L.max_halo_fluid + 63u) & ~63u) * 4u + 32u;
+}
+
+
 }  // namespace salva
