@@ -89,6 +89,7 @@ struct StepCtx {
     float* aii;          // IISPH
     float4* dii;         // IISPH (xyz, unused)
     float4* dijpj;       // IISPH sum_j d_ij p_j (xyz, unused)
+    float4* posmr;       // (x, y, z, m / rho) of this step (k_density_alpha): the neighbour record of volume-weighted sums (k_xsph)
     float4* iisph_q;     // IISPH d_ii p_i + sum_j d_ij p_j: what a neighbour contributes to compute_next_pressures in one record
     float4* iisph_pr;    // IISPH (x, y, z, m / rho^2): what a neighbour contributes to compute_dij_pjl besides its pressure (k_iisph_dii)
     uint32_t* nff;       // # fluid-fluid contacts of each particle (self included)

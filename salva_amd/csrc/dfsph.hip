@@ -28,13 +28,18 @@ using namespace salva;
 // Also: c.slice_near[slice] = some particle of the slice has a neighbour (other than itself) with |d| <= 1e-5 h — the pairs for
 // which cubic_spline_kernel.rs:63-65 returns a zero gradient; the solver kernels pick their pair loop by it.
 // ------------------------------------------------------------------------------------------------
+// Round 3: the fluid-fluid part walks the padded list two contacts at a time with kernel_wg2 (weight and gradient factor from the
+// same intermediates, no branch); a slice in which the walk meets a pair closer than 1e-5 h — where the reference's gradient is
+// zero — is summed again with kernel_eval over the exact lists.  The padding entries of a list are the particle itself: their
+// gradients vanish exactly and zero-distance weights are masked out of the sum (the self weight is added once, separately).
+// Also writes posmr = (x, m / rho): what a neighbour contributes to the sums that weigh by volume m_j / rho_j (XSPH).
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
     lds_base_check();
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    struct Own { float4 pi; uint32_t mi; ListOwn lo; };
-    auto load_own = [&](uint32_t i, uint32_t gs) { return Own{c.posm[i], c.model[i], list_own(c, i, gs)}; };
+    struct Own { float4 pi; uint32_t mi, cnt; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) { return Own{c.posm[i], c.model[i], c.nff[i], list_regs(c, gs)}; };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
     const Own own0 = load_own(i0, gs0);
@@ -44,22 +49,59 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
     t.stage_boundary(c, Bp);
     Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const float4 pi = o.pi;
+        float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f;
         uint32_t nnear = 0;
-        if (active) {
-            const float4 pi = o.pi;
-            const float rho0 = rho0_of(c, o.mi);
-            float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f;
-            for_each_ff_regs(c, gs, o.lo, [&](uint32_t s) { return lds_ld16(s << 4); }, [&](const float4& pj) { SALVA_PAIR_MATH
+        if (active) {  // (an idle lane's list row was never written)
+            f2 rw = {0.0f, 0.0f}, ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f}, s2 = {0.0f, 0.0f};
+            const f2 tiny = {1.0e-30f, 1.0e-30f};
+            for_each_ff2<true, false, true>(c, gs, nqu, o.lh, [&](uint32_t off) { return lds_ld16(off); }, [&](const float4& A, const float4& B) { SALVA_PAIR_MATH
+                const f2 dx = {pi.x - A.x, pi.x - B.x}, dy = {pi.y - A.y, pi.y - B.y}, dz = {pi.z - A.z, pi.z - B.z};
+                f2 r2 = dz * dz + tiny;
+                r2 = dy * dy + r2;
+                r2 = dx * dx + r2;
+                const bool za = r2.x <= c.sc.tiny_r2, zb = r2.y <= c.sc.tiny_r2;
+                nnear += (za ? 1u : 0u) + (zb ? 1u : 0u);
+                const KernelWG2 k = kernel_wg2(r2, c.sc);
+                const f2 m = {A.w, B.w};
+                // the particle itself — its one real self contact and the padding — adds nothing here: its weight, W(0) m_i, goes
+                // in once below, so that the sum does not depend on how long the slice's longest list is (a decomposed run cuts
+                // the slices differently and must still produce the same bits)
+                f2 wm = k.w * m;
+                wm.x = za ? 0.0f : wm.x; wm.y = zb ? 0.0f : wm.y;
+                rw += wm;
+                const f2 gm = k.g * m;
+                ax += dx * gm; ay += dy * gm; az += dz * gm;
+                s2 += (gm * gm) * r2;
+            });
+            const uint32_t npad = 2u * nqu - o.cnt;  // self contacts appended by k_nbr_tile
+            rho = (rw.x + rw.y) * c.sc.wscale + pi.w * c.sc.wnorm;
+            gsx = (ax.x + ax.y) * c.sc.gscale; gsy = (ay.x + ay.y) * c.sc.gscale; gsz = (az.x + az.y) * c.sc.gscale;
+            sq = (s2.x + s2.y) * (c.sc.gscale * c.sc.gscale);
+            nnear -= npad;  // (the self contact itself stays counted: "> 1" below means another particle)
+        }
+        // (the self contact is always one of the pairs with r2 <= tiny)
+#ifdef SALVA_OTHER_KERNELS  // (kernel_wg2 is the cubic spline: another KernelDensity / KernelGradient takes the exact walk)
+        const bool any_near = __builtin_amdgcn_ballot_w64(active && nnear > 1u) != 0ull || (c.sc.kd | c.sc.kg) != 0;
+#else
+        const bool any_near = __builtin_amdgcn_ballot_w64(active && nnear > 1u) != 0ull;
+#endif
+        if (any_near && active) {  // rare: the slice's sums again, the reference's way
+            rho = gsx = gsy = gsz = sq = 0.0f;
+            for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const float4 pj = lds_ld16(s << 4);
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                const float r2 = dx * dx + dy * dy + dz * dz;
-                nnear += (r2 <= c.sc.tiny_r2) ? 1u : 0u;
-                const KernelEval e = kernel_eval(r2, c.sc);
+                const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
                 rho += pj.w * e.w;
                 const float gm = e.g * pj.w;
                 const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
                 sq += gx * gx + gy * gy + gz * gz;
                 gsx += gx; gsy += gy; gsz += gz;
             });
+        }
+        if (active) {
+            const float rho0 = rho0_of(c, o.mi);
             for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Bp[s];
                 const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -75,9 +117,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
             const float denom = sq + (gsx * gsx + gsy * gsy + gsz * gsz);
             c.rho[i] = rho;
             c.alpha[i] = (denom <= 1.0e-5f) ? 0.0f : 1.0f / denom;
+            c.posmr[i] = make_float4(pi.x, pi.y, pi.z, pi.w / rho);
         }
-        // (the self contact is always one of the pairs with r2 <= tiny)
-        const bool any_near = __builtin_amdgcn_ballot_w64(nnear > 1u) != 0ull;
         if ((threadIdx.x & (WAVE - 1)) == 0) c.slice_near[gs] = any_near ? 1u : 0u;
     });
 }

@@ -10,6 +10,7 @@
 // whose .w component carries the neighbour's model id.
 #include "kernels.h"
 #include "tile.h"
+#include "pairs.h"
 
 namespace SALVA_KNS {
 using namespace salva;
@@ -17,7 +18,11 @@ using namespace salva;
 // ------------------------------------------------------------------------------------------------ XSPH
 // a_i += inv_dt * [ sum_j (v_j - v_i) c_f W_ij m_j / rho_j  +  sum_b (v_b - v_i) c_b W_ib V_b rho0 / rho_i ]
 // inv_dt is the *previous* substep's (timestep.advance happens after predict_advection, dfsph_solver.rs:693-702).
+// Round 3: fixed P | W layout (pairs.h): P = posmr = (x_j, m_j / rho_j) written by k_density_alpha, W = (v_j + dv_j, model id);
+// the weight comes from kernel_wg2 without a branch (W itself has no near-zero special case, so every slice takes this path).
+template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t model, float fc, float bc, float inv_dt) {
+    lds_base_check();
     Tile t;
     t.setup(c);
     if (t.empty()) return;
@@ -27,13 +32,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
     const Own own0 = load_own(i0, gs0);
-    const float4* Lp = nullptr;
-    const float4* Lw = nullptr;
-    const float* Lr = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), static_cast<const float*>(c.rho), Lp, Lw, Lr);
+    const uint32_t dist = pw_dist<DS>(c, t);
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
-    t.stage_boundary(c, Bp, Bv);
+    t.stage_pw(c, static_cast<const float4*>(c.posmr), static_cast<const float4*>(c.w), dist, Bp, Bv, true);
     Tile::staged_barrier();
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);  // (wave-uniform: before any lane drops out)
@@ -42,18 +44,37 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
         if (!active || __float_as_uint(vi.w) != model) return;
         const float rho0 = c.rho0_tab[model];
         float fx = 0.f, fy = 0.f, fz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
+#ifdef SALVA_OTHER_KERNELS  // (kernel_wg2 is the cubic spline: another KernelDensity evaluates W the general way)
+        if (fc != 0.0f && c.sc.kd != 0) {
+            for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const RecPW A = load_pw(s << 4, dist);
+                const float dx = pi.x - A.p.x, dy = pi.y - A.p.y, dz = pi.z - A.p.z;
+                const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
+                const float sc = (__float_as_uint(A.w.w) == model) ? fc * wgt * A.p.w : 0.0f;
+                fx += (A.w.x - vi.x) * sc; fy += (A.w.y - vi.y) * sc; fz += (A.w.z - vi.z) * sc;
+            });
+        } else
+#endif
         if (fc != 0.0f) {
             // wave-uniform trip count over the padded list: a padding entry is the particle itself, v_j - v_i = 0 exactly
-            struct Rec { float4 p, w; float r; };
-            auto one = [&](const Rec& rc) { SALVA_PAIR_MATH
-                const float4 pj = rc.p, vj = rc.w;
-                const float rj = rc.r;
-                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                const float wgt = kernel_weight(dx * dx + dy * dy + dz * dz, c.sc);
-                const float sc = (__float_as_uint(vj.w) == model) ? fast_div(fc * wgt * pj.w, rj) : 0.0f;
-                fx += (vj.x - vi.x) * sc; fy += (vj.y - vi.y) * sc; fz += (vj.z - vi.z) * sc;
-            };
-            for_each_ff2(c, gs, nqu, o.lh, [&](uint32_t s) { return Rec{Lp[s], Lw[s], Lr[s]}; }, [&](const Rec& A, const Rec& B) { one(A); one(B); });
+            f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
+            const f2 tiny = {1.0e-30f, 1.0e-30f};
+            for_each_ff2<true, false, true>(c, gs, nqu, o.lh, [&](uint32_t off) { return load_pw(off, dist); },
+                                            [&](const RecPW& A, const RecPW& B) { SALVA_PAIR_MATH
+                const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
+                f2 r2 = dz * dz + tiny;
+                r2 = dy * dy + r2;
+                r2 = dx * dx + r2;
+                const KernelWG2 k = kernel_wg2(r2, c.sc);
+                f2 sc = k.w * f2{A.p.w, B.p.w};  // W_ij m_j / rho_j (the common factors once per particle, below)
+                sc.x = (__float_as_uint(A.w.w) == model) ? sc.x : 0.0f;
+                sc.y = (__float_as_uint(B.w.w) == model) ? sc.y : 0.0f;
+                ax += f2{A.w.x - vi.x, B.w.x - vi.x} * sc;
+                ay += f2{A.w.y - vi.y, B.w.y - vi.y} * sc;
+                az += f2{A.w.z - vi.z, B.w.z - vi.z} * sc;
+            });
+            const float f = fc * c.sc.wscale;
+            fx = (ax.x + ax.y) * f; fy = (ay.x + ay.y) * f; fz = (az.x + az.y) * f;
         }
         if (bc != 0.0f) {
             const float ri = o.ri;
@@ -81,7 +102,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
 void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff,
                  float inv_dt_prev, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_xsph, c, L, model, fluid_coeff, boundary_coeff, inv_dt_prev, s);
-    SALVA_LAUNCH_TILE(k_xsph, c, L, L.bytes(36, 32, 5), s, c, model, fluid_coeff, boundary_coeff, inv_dt_prev);
+    const uint32_t ds = pick_ds(pw_slots(L));
+    SALVA_LAUNCH_FIXED(k_xsph, ds, c, L, pw_bytes(L, ds, false), s, c, model, fluid_coeff, boundary_coeff, inv_dt_prev);
 }
 
 // ------------------------------------------------------------------------------------------------ Monaghan artificial viscosity

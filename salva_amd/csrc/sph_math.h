@@ -26,6 +26,7 @@ struct SphConsts {
     float tiny_r2; // (1e-5 h)^2: below it the gradient is zero (cubic_spline_kernel.rs:63-65, q <= 1e-5)
     float g18, g12, sg6;  // 18 gnorm, 12 gnorm, sqrt(6 gnorm): folded constants of kernel_grad2
     float gscale;         // 6 gnorm / h^2: the factor kernel_gfac2 leaves to its caller
+    float wscale;         // wnorm / h^3: the factor kernel_wg2 leaves to its caller
     // KernelDensity / KernelGradient of DFSPHSolver<..> / IISPHSolver<..> (dfsph_solver.rs:17-20, iisph_solver.rs:17-20):
     // 0 = CubicSplineKernel (the default type parameters, everything above), 1 = Poly6Kernel, 2 = SpikyKernel,
     // 3 = ViscosityKernel (SALVA_HIP_KERNEL_* in salva_hip.h).  Non-zero kinds take the generic paths below.
@@ -46,6 +47,7 @@ __host__ inline SphConsts make_sph_consts(float h) {
     c.g12 = 12.0f * c.gnorm;
     c.sg6 = sqrtf(6.0f * c.gnorm);
     c.gscale = (float)(6.0 * (double)c.gnorm / ((double)h * (double)h));
+    c.wscale = (float)((double)c.wnorm / ((double)h * (double)h * (double)h));
     c.kd = c.kg = 0;
     const float pi = 3.14159265358979323846f, h3 = h * h * h;
     c.n_poly6 = (315.0f / 64.0f) / (pi * (h3 * h3 * h3));
@@ -220,6 +222,27 @@ __device__ __forceinline__ f2 kernel_gfac2(f2 r2, const SphConsts& c) {
     a2.y = fmaxf(a2.y, 0.0f);
     const f2 u = a2 * a2 - a1 * a1;
     return u * rinv;
+}
+
+// Weight and gradient factor of two contacts at once from the same intermediates as kernel_gfac2.  With a1 = h - r >= 0 and
+// a2 = (h - 2r)+ the cubic spline is W = (wnorm / h^3) (2 a1^3 - a2^3)  [q <= 1/2: 1 - 6q^2 + 6q^3; q <= 1: 2 (1 - q)^3] and
+// (dW/dr)/r = gscale (a2^2 - a1^2) / r.  Returns {2 a1^3 - a2^3, (a2^2 - a1^2) / r}: the callers apply wnorm / h^3 and gscale to
+// the finished sums.  r2 = 0 (self contact, padding; the caller adds 1e-30): weight h^3 exactly, gradient factor 0.
+struct KernelWG2 { f2 w, g; };
+__device__ __forceinline__ KernelWG2 kernel_wg2(f2 r2, const SphConsts& c) {
+    SALVA_PAIR_MATH
+    f2 rinv;
+    rinv.x = __builtin_amdgcn_rsqf(r2.x);
+    rinv.y = __builtin_amdgcn_rsqf(r2.y);
+    const f2 r = r2 * rinv;
+    const f2 a1 = c.h - r;
+    f2 a2 = a1 - r;
+    a2.x = fmaxf(a2.x, 0.0f); a2.y = fmaxf(a2.y, 0.0f);
+    const f2 a1s = a1 * a1, a2s = a2 * a2;
+    KernelWG2 o;
+    o.g = (a2s - a1s) * rinv;
+    o.w = (a1s * a1) * 2.0f - a2s * a2;
+    return o;
 }
 
 // Two packed pairs at once, stage by stage (the two chains are independent: written interleaved so that the scheduler keeps

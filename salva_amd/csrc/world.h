@@ -165,7 +165,7 @@ class World {
     DevBuf<uint32_t> model[2], perm[2];
     int cur = 0;
     static constexpr int NUM_SOLVES = 3;  // divergence, pressure, viscosity
-    DevBuf<float4> acc, w, normal, dii, dijpj, iisph_q, iisph_pr;
+    DevBuf<float4> acc, w, normal, dii, dijpj, iisph_q, iisph_pr, posmr;
     DevBuf<float> visc_beta, visc_target;  // DFSPHViscosity scratch: betas [36][n], strain-rate targets [6][n]
     DevBuf<float4> visc_u0, visc_u1, visc_va;
     DevBuf<double> wrench_partial;       // per-block partial sums of salva_hip_get_boundary_wrench

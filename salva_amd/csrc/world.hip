@@ -626,7 +626,7 @@ StepCtx World::make_ctx() {
     c.posm = posm[cur].p; c.vel = vel[cur].p; c.dv = dv[cur].p; c.acc = acc.p; c.w = w.p; c.normal = normal.p;
     c.model = model[cur].p; c.perm = perm[cur].p; c.gtag = comm ? gtag[cur].p : nullptr;
     c.rho = rho.p; c.alpha = alpha.p; c.kappa = kappa.p; c.kappa2 = kappa2.p; c.rho_star = rho_star.p; c.aii = aii.p;
-    c.dii = dii.p; c.dijpj = dijpj.p; c.iisph_q = iisph_q.p; c.iisph_pr = iisph_pr.p;
+    c.dii = dii.p; c.dijpj = dijpj.p; c.iisph_q = iisph_q.p; c.iisph_pr = iisph_pr.p; c.posmr = posmr.p;
     c.nff = nff.p; c.nfb = nfb.p;
     c.nbr_ff = nbr_ff.p; c.nbr_fb = nbr_fb.p; c.cap_ff = cap_ff; c.cap_fb = cap_fb;
     c.slice_near = slice_near.p;
@@ -1054,6 +1054,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
 
     // ---- per-step scratch
     acc.ensure(n, stream, false, 1.1f); w.ensure(n, stream, false, 1.1f); rho.ensure(n, stream, false, 1.1f);
+    posmr.ensure(n, stream, false, 1.1f);
     alpha.ensure(n, stream, false, 1.1f); kappa.ensure(n, stream, false, 1.1f); nff.ensure(n, stream, false, 1.1f);
     nfb.ensure(n, stream, false, 1.1f);
     bool has_akinci = false;
@@ -2062,7 +2063,7 @@ uint64_t World::device_bytes() const {
         add(posm[k].bytes()); add(vel[k].bytes()); add(dv[k].bytes()); add(model[k].bytes()); add(perm[k].bytes());
         add(keys[k].bytes()); add(idx[k].bytes()); add(bkeys[k].bytes()); add(bidx[k].bytes());
     }
-    add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes()); add(iisph_q.bytes()); add(iisph_pr.bytes());
+    add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes()); add(iisph_q.bytes()); add(iisph_pr.bytes()); add(posmr.bytes());
     add(rho.bytes()); add(alpha.bytes()); add(kappa.bytes()); add(kappa2.bytes()); add(rho_star.bytes()); add(aii.bytes());
     add(visc_beta.bytes()); add(visc_target.bytes()); add(visc_u0.bytes()); add(visc_u1.bytes()); add(visc_va.bytes()); add(he_colors.bytes()); add(he_gradcs.bytes());
     add(nff.bytes()); add(nfb.bytes()); add(cell_start_f.bytes()); add(halo_src.bytes()); add(bhalo_src.bytes());
