@@ -26,32 +26,53 @@ void launch_iisph_begin(const StepCtx& c, float gx, float gy, float gz, bool acc
     if (c.n) k_iisph_begin<<<num_blocks(c.n), BLOCK, 0, s>>>(c, gx, gy, gz, acc_has_user ? 1 : 0);
 }
 
-// compute_dii (:144-186): d_ii = -dt^2 / rho_i^2 * sum_j m_j grad W_ij ; also p_i = 0.5 * p_i(previous step) (:673-677)
+// compute_dii (:144-186): d_ii = -dt^2 / rho_i^2 * sum_j m_j grad W_ij ; also p_i = 0.5 * p_i(previous step) (:673-677).
+// Packed pair loop over P alone (kernel_gfac2; slices with a near-coincident pair take the exact walk).
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dii(StepCtx c, float dt) {
+    lds_base_check();
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    uint32_t i0_, gs0_;
-    t.first_own(i0_, gs0_);
-    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
+    struct Own { float4 pi; float rhoi; uint32_t mi, cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) { return Own{c.posm[i], c.rho[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)}; };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
     const float4* Lp = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), Lp);
+    t.stage(c, static_cast<const float4*>(c.posm), Lp);  // first carve: LDS byte 0 (lds_ld16)
     const float4* Bp = nullptr;
     t.stage_boundary(c, Bp);
     Tile::staged_barrier();
-    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
         if (!active) return;
-        const float4 pi = c.posm[i];
-        const float rho0 = c.rho0_tab[c.model[i]];
-        const float rhoi = c.rho[i];
+        const float4 pi = o.pi;
+        const float rho0 = rho0_of(c, o.mi);
+        const float rhoi = o.rhoi;
         const float factor = -dt * dt / (rhoi * rhoi);
         float x = 0.f, y = 0.f, z = 0.f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
-            const float4 pj = Lp[s];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (pj.w * factor);
-            x += dx * sc; y += dy * sc; z += dz * sc;
-        });
+        if (near) {
+            for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const float4 pj = lds_ld16(s << 4);
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * pj.w;
+                x += dx * sc; y += dy * sc; z += dz * sc;
+            });
+        } else {
+            f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
+            const f2 tiny = {1.0e-30f, 1.0e-30f};
+            for_each_ff2<true, false, true>(c, gs, nqu, o.lh, [&](uint32_t off) { return lds_ld16(off); }, [&](const float4& A, const float4& B) { SALVA_PAIR_MATH
+                const f2 dx = {pi.x - A.x, pi.x - B.x}, dy = {pi.y - A.y, pi.y - B.y}, dz = {pi.z - A.z, pi.z - B.z};
+                f2 r2 = dz * dz + tiny;
+                r2 = dy * dy + r2;
+                r2 = dx * dx + r2;
+                const f2 gm = kernel_gfac2(r2, c.sc) * f2{A.w, B.w};
+                ax += dx * gm; ay += dy * gm; az += dz * gm;
+            });
+            x = (ax.x + ax.y) * c.sc.gscale; y = (ay.x + ay.y) * c.sc.gscale; z = (az.x + az.y) * c.sc.gscale;
+        }
+        x *= factor; y *= factor; z *= factor;
         for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Bp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -115,34 +136,57 @@ void launch_iisph_pred_density(const StepCtx& c, const TileLds& L, float dt, hip
     SALVA_LAUNCH_FIXED(k_iisph_pred_density, ds, c, L, pw_bytes(L, ds, false), s, c, dt);
 }
 
-// compute_aii (:188-233): a_ii = sum_j m_j (d_ii - d_ji) . grad W_ij with d_ji = grad W_ij dt^2 m_i / rho_i^2
+// compute_aii (:188-233): a_ii = sum_j m_j (d_ii - d_ji) . grad W_ij with d_ji = grad W_ij dt^2 m_i / rho_i^2.
+// With grad W_ij = G d: m_j (d_ii - G d f) . G d = m_j G (d_ii . d) - f m_j G^2 |d|^2 — two packed sums over P alone.
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_aii(StepCtx c, float dt) {
+    lds_base_check();
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    uint32_t i0_, gs0_;
-    t.first_own(i0_, gs0_);
-    const ListOwn lo0_ = list_own(c, i0_, gs0_);  // list head and count: in registers before the staging barrier
+    struct Own { float4 pi, di; float rhoi; uint32_t mi, cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.dii[i], c.rho[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
     const float4* Lp = nullptr;
-    t.stage(c, static_cast<const float4*>(c.posm), Lp);
+    t.stage(c, static_cast<const float4*>(c.posm), Lp);  // first carve: LDS byte 0 (lds_ld16)
     const float4* Bp = nullptr;
     t.stage_boundary(c, Bp);
     Tile::staged_barrier();
-    t.for_own_pre(lo0_, [&](uint32_t i_, uint32_t gs_) { return list_own(c, i_, gs_); }, [&](const ListOwn& lo, uint32_t i, uint32_t gs, bool active) {
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
         if (!active) return;
-        const float4 pi = c.posm[i];
-        const float rho0 = c.rho0_tab[c.model[i]];
-        const float rhoi = c.rho[i];
+        const float4 pi = o.pi, di = o.di;
+        const float rho0 = rho0_of(c, o.mi);
+        const float rhoi = o.rhoi;
         const float factor = dt * dt * pi.w / (rhoi * rhoi);
-        const float4 di = c.dii[i];
         float a = 0.0f;
-        for_each_ff_regs(c, gs, lo, [&](uint32_t s) { SALVA_PAIR_MATH
-            const float4 pj = Lp[s];
-            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-            const float gx = dx * g, gy = dy * g, gz = dz * g;
-            a += pj.w * ((di.x - gx * factor) * gx + (di.y - gy * factor) * gy + (di.z - gz * factor) * gz);
-        });
+        if (near) {
+            for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const float4 pj = lds_ld16(s << 4);
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                const float gx = dx * g, gy = dy * g, gz = dz * g;
+                a += pj.w * ((di.x - gx * factor) * gx + (di.y - gy * factor) * gy + (di.z - gz * factor) * gz);
+            });
+        } else {
+            f2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+            const f2 tiny = {1.0e-30f, 1.0e-30f};
+            for_each_ff2<true, false, true>(c, gs, nqu, o.lh, [&](uint32_t off) { return lds_ld16(off); }, [&](const float4& A, const float4& B) { SALVA_PAIR_MATH
+                const f2 dx = {pi.x - A.x, pi.x - B.x}, dy = {pi.y - A.y, pi.y - B.y}, dz = {pi.z - A.z, pi.z - B.z};
+                f2 r2 = dz * dz + tiny;
+                r2 = dy * dy + r2;
+                r2 = dx * dx + r2;
+                const f2 g = kernel_gfac2(r2, c.sc);
+                const f2 gm = g * f2{A.w, B.w};
+                sa += (dx * di.x + dy * di.y + dz * di.z) * gm;
+                sb += (g * gm) * r2;
+            });
+            a = (sa.x + sa.y) * c.sc.gscale - (sb.x + sb.y) * (c.sc.gscale * c.sc.gscale) * factor;
+        }
         for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Bp[s];
             const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
