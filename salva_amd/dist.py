@@ -128,3 +128,18 @@ def select_ghost_planes(cx: np.ndarray, slab: Tuple[int, int], has_lo: bool, has
     to_lo = (cx <= slab[0] + GHOST_PLANES - 1) if has_lo else np.zeros(len(cx), bool)
     to_hi = (cx >= slab[1] - GHOST_PLANES + 1) if has_hi else np.zeros(len(cx), bool)
     return to_lo, to_hi
+
+
+def allocate_new_ids(adds_per_rank: Sequence[int], rank: int, gid_next: int) -> Tuple[int, int]:
+    """Global ids for particles created in a running decomposed world (world_dist.hip, World::dist_add_particles): every rank
+    contributes its count to one all-reduced vector; ids continue after the largest id in the run, rank by rank.
+    Returns (first id of THIS rank's new particles, the next free id afterwards) — the same pair on the host side of every
+    rank once `adds_per_rank` has been all-reduced."""
+    adds = [int(a) for a in adds_per_rank]
+    return int(gid_next) + sum(adds[:rank]), int(gid_next) + sum(adds)
+
+
+def apply_owned_deletions(owned_ids: np.ndarray, doomed_ids: np.ndarray) -> np.ndarray:
+    """`salva_hip_delete_owned`: every rank gets the same list and drops what it owns; ids owned elsewhere are ignored.
+    Returns the keep mask over `owned_ids`."""
+    return ~np.isin(np.asarray(owned_ids), np.asarray(doomed_ids))

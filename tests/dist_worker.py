@@ -123,6 +123,35 @@ def main():
     assert all(float(g) == mean_err for g in gathered)
     np.testing.assert_allclose(mean_err, np.maximum(grho / 1000.0 - 1.0, 0.0).mean(), rtol=1e-5, atol=1e-12)
 
+    # creation and removal in a running decomposed world are collective (salva_hip_add_particles / salva_hip_delete_owned): the
+    # new ids continue after the largest id, rank by rank; every rank drops the listed ids it owns; the per-fluid count the error
+    # averages divide by is all-reduced, so both ranks end up with the same total and no id exists twice
+    n_add = 3 + 2 * rank
+    adds = torch.zeros(world, dtype=torch.int64)
+    adds[rank] = n_add
+    td.all_reduce(adds)
+    first, gid_next = dist.allocate_new_ids(adds.tolist(), rank, len(pos))
+    my_ids = np.concatenate([owned[:, 0].astype(np.int64), first + np.arange(n_add)])
+    doomed = np.concatenate([np.arange(0, len(pos), 7), [len(pos) + 1, len(pos) + 4]])  # old ids of both ranks + two new ones
+    keep_mask = dist.apply_owned_deletions(my_ids, doomed)
+    delta = torch.tensor([n_add - int((~keep_mask).sum())], dtype=torch.int64)
+    td.all_reduce(delta)
+    my_ids = my_ids[keep_mask]
+    total_after = torch.tensor([len(my_ids)], dtype=torch.int64)
+    td.all_reduce(total_after)
+    expect = len(pos) + int(adds.sum()) - len(doomed)
+    assert int(total_after) == expect == len(pos) + int(delta), (int(total_after), expect, int(delta))
+    assert gid_next == len(pos) + int(adds.sum())
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    td.all_gather(sizes, torch.tensor([len(my_ids)], dtype=torch.int64))
+    padded = torch.full((max(int(x) for x in sizes),), -1, dtype=torch.int64)
+    padded[:len(my_ids)] = torch.from_numpy(my_ids)
+    everyone = [torch.zeros_like(padded) for _ in range(world)]
+    td.all_gather(everyone, padded)
+    allids = np.concatenate([e.numpy()[:int(n)] for e, n in zip(everyone, sizes)])
+    assert len(np.unique(allids)) == len(allids) == expect, "an id exists on two ranks or was lost"
+    assert not np.isin(doomed, allids).any()
+
     td.barrier()
     print(f"OK {rank}", flush=True)
     td.destroy_process_group()
