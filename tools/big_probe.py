@@ -9,6 +9,7 @@ for side in [int(x) for x in (sys.argv[1:] or ["200", "300"])]:
     t0 = time.perf_counter()
     fl, sh = bench.build_scene(side)
     w, f = bench.make_world(fl, sh, 0)
+    w.counters.enable()  # (step_ms comes from the stage timers, off by default)
     t1 = time.perf_counter()
     ms = []
     for k in range(8):

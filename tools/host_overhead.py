@@ -12,6 +12,7 @@ from salva_amd import _lib as L  # noqa: E402
 
 fluid, shell = bench.build_scene(100)
 w, f = bench.make_world(fluid, shell, 0)
+w.counters.enable()  # (step_ms / grid_ms come from the stage timers, off by default)
 for _ in range(5):
     w.step(bench.DT, bench.GRAVITY)
 N = 20

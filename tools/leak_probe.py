@@ -7,6 +7,7 @@ import bench
 from salva_amd import Boundary, DFSPHSolver, Fluid, LiquidWorld, XSPHViscosity, scenes
 fl, sh = scenes.tank(16, 100, 16, bench.R)
 w = LiquidWorld(DFSPHSolver(), bench.R, 2.0)
+w.counters.enable()  # (step_ms / grid_ms come from the stage timers, off by default)
 f = Fluid(scenes.jitter(fl, 0.1 * bench.R, 42), bench.R, 1000.0)
 f.nonpressure_forces.append(XSPHViscosity(0.5, 0.0))
 w.add_fluid(f); w.add_boundary(Boundary(sh))

@@ -20,11 +20,13 @@ def soak(name, w, f, steps, every):
 # 1M bench scene, 400 steps
 fl, sh = bench.build_scene(100)
 w, f = bench.make_world(fl, sh, 0)
+w.counters.enable()  # (step_ms / grid_ms come from the stage timers, off by default)
 soak("tank1M", w, f, 300, 100)
 del w
 # dam break: 60x60x40 column in a tank 3x as long, artificial viscosity with boundary term, 1500 steps
 fluid, shell = scenes.tank(60, 60, 40, bench.R, wall_cells=120)
 w = LiquidWorld(DFSPHSolver(), bench.R, 2.0)
+w.counters.enable()  # (step_ms / grid_ms come from the stage timers, off by default)
 f = Fluid(scenes.jitter(fluid, 0.05 * bench.R), bench.R, 1000.0)
 f.nonpressure_forces.append(ArtificialViscosity(0.5, 0.2))
 w.add_fluid(f); w.add_boundary(Boundary(shell))
@@ -33,6 +35,7 @@ del w
 # IISPH tank 200k, 600 steps
 fluid, shell = scenes.tank(60, 60, 60, bench.R)
 w = LiquidWorld(IISPHSolver(), bench.R, 2.0)
+w.counters.enable()  # (step_ms / grid_ms come from the stage timers, off by default)
 f = Fluid(scenes.jitter(fluid, 0.05 * bench.R), bench.R, 1000.0)
 f.nonpressure_forces.append(XSPHViscosity(0.5, 0.0))
 w.add_fluid(f); w.add_boundary(Boundary(shell))

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 fl, sh = bench.build_scene(100)
 w, f = bench.make_world(fl, sh, 0)
+w.counters.enable()  # (step_ms / grid_ms come from the stage timers, off by default)
 rows = []
 for k in range(int(sys.argv[1]) if len(sys.argv) > 1 else 16):
     t0 = time.perf_counter()
