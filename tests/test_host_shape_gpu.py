@@ -213,3 +213,22 @@ def test_host_shape_errors():
     c.register_coupling(b, "nan", None, HostShapeSampling(lambda: (F([np.nan] * 3), F([np.nan] * 3)), lambda p: (p, np.zeros(len(p), bool))))
     with pytest.raises(_lib.SalvaHipError):
         w.step_with_coupling(DT, GRAVITY, c)
+
+
+def test_cpp_mirror_host_shape_example():
+    """examples/host_shape3.cpp: the torus through include/salva_hip.hpp's `Boundary::dynamic_host_shape`, with
+    `DFSPHSolverT<Poly6Kernel, SpikyKernel>` as the solver (the C++ mirror of the two round-3 additions in one program)."""
+    import os
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples"), "host_shape3"], check=True, capture_output=True)
+    out = subprocess.run([os.path.join(root, "examples", "host_shape3"), "120"], check=True, capture_output=True, text=True, timeout=300).stdout
+    rows = [re.search(r"step (\d+): (\d+) boundary samples \(max (\d+)\), worst sample off the surface ([0-9.e+-]+), deepest fluid particle ([0-9.e+-]+) r, (\d+) particles below", l)
+            for l in out.strip().splitlines()]
+    assert len(rows) == 4 and all(rows), out
+    assert int(rows[-1].group(3)) > 100, out                       # the fluid was projected onto the torus
+    assert all(float(m.group(4)) < 1e-5 for m in rows), out        # every sample lies on its surface
+    assert all(float(m.group(5)) > -1.0 for m in rows), out        # no particle deeper than one radius inside it
+    assert int(rows[-1].group(6)) > 100, out                       # the part above the hole fell through
