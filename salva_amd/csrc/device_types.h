@@ -146,6 +146,14 @@ struct StepCtx {
 
     // ---- reductions / flags ----
     float* partials;     // [nblocks * nmodels] per-block error sums
+    // Speculative divergence applies (dfsph.hip k_divergence_apply, World::dfsph_solve): iteration k of the solve reads record
+    // spec_ring[k & 1] and the apply pass's workgroup 0 writes spec_ring[(k + 1) & 1]; w lives in w / w2 by the parity of the
+    // committed applies.  spec_k < 0: off (the control block `ctl` and one k_finalize_error launch per iteration).
+    int spec_k;
+    SolveCtl* spec_ring;
+    SolveCtl* spec_pub;            // host-mapped copy of the first half of the newest record (may be null)
+    const uint32_t* model_counts;  // particles per fluid: the denominators of the error averages
+    float4* w2;
     uint32_t* flags;     // bit 0: numeric error (zero density / NaN), bit 1: particle outside grid
     uint32_t min_neighbors_for_divergence;
     // Decomposed runs: an evaluate pass may be launched twice — once over the tiles whose halo box touches no ghost plane

@@ -128,13 +128,69 @@ void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Speculative applies (StepCtx::spec_k >= 0; single-domain divergence solves that ran more than a few iterations last step).
+// The convergence test needs the error sums of the WHOLE evaluate pass, which is why it was a one-workgroup kernel between
+// evaluate and apply — 4.7 us plus two launch gaps, a hundred times per settled step.  Here the apply pass does not wait for it:
+// every workgroup computes w_out = w_in + delta into the OTHER w buffer, and workgroup 0 also reduces the evaluate pass's
+// partials (same order as k_finalize_error: the same bits, hence the same decision) and writes the NEXT iteration's control
+// record: converged -> the output just produced is never looked at (w stays where it was); not converged -> iters + 1, and
+// the parity of iters is where w lives.  Records alternate (spec_ring[k & 1] is read by iteration k, [(k + 1) & 1] written), so
+// workgroups of this launch that start after workgroup 0 has finished still read the record this launch was enqueued for.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ const SolveCtl* solve_record(const StepCtx& c) { return c.spec_k >= 0 ? c.spec_ring + (c.spec_k & 1) : c.ctl; }
+__device__ __forceinline__ const float4* solve_w_in(const StepCtx& c, const SolveCtl* r) {
+    return (c.spec_k >= 0 && (r->iters & 1u)) ? c.w2 : c.w;
+}
+// all threads of workgroup 0 of an apply pass; `scratch`: 16 floats of LDS nobody uses yet
+__device__ __forceinline__ void spec_decide(const StepCtx& c, float* scratch) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const SolveCtl* rk = c.spec_ring + (c.spec_k & 1);
+    SolveCtl* rn = c.spec_ring + ((c.spec_k + 1) & 1);
+    const u32x4 c0 = reinterpret_cast<const u32x4*>(rk)[0], c1 = reinterpret_cast<const u32x4*>(rk)[1];
+    const uint32_t done = c0.x, iters = c0.y, seq = c0.w + 1u, min_iter = c1.y;
+    const float tol = __uint_as_float(c1.x);
+    u32x4 out = {1u, iters, c0.z, seq};
+    if (!done) {
+        // the sums of k_finalize_error's 1024 threads, on however many threads this workgroup has: virtual thread v = t + j T
+        // (T a multiple of 64: a virtual wave stays one real wave), wave sums by DPP, the 16 wave sums added in wave order
+        float best = 0.0f;
+        const uint32_t nb = c.nlaunch, nm = c.nmodels;
+        for (uint32_t m = 0; m < nm; ++m) {
+            for (uint32_t v = threadIdx.x; v < 1024u; v += blockDim.x) {
+                float s = 0.0f;
+                for (uint32_t b = v; b < nb; b += 1024u) s += c.partials[(size_t)b * nm + m];
+                s = wave_sum(s);
+                if ((v & 63u) == 0u) scratch[v >> 6] = s;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float tot = 0.0f;
+                for (int k = 0; k < 16; ++k) tot += scratch[k];
+                const uint32_t cnt = c.model_counts[m];
+                if (cnt != 0) best = fmaxf(best, tot / (float)cnt);
+            }
+            __syncthreads();
+        }
+        const bool ok = best <= tol && iters >= min_iter;
+        out = u32x4{ok ? 1u : 0u, ok ? iters : iters + 1u, __float_as_uint(best), seq};
+    }
+    if (threadIdx.x == 0) {
+        reinterpret_cast<u32x4*>(rn)[0] = out;
+        reinterpret_cast<u32x4*>(rn)[1] = c1;
+        if (c.spec_pub) *reinterpret_cast<volatile u32x4*>(c.spec_pub) = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // compute_divergences (:279-356): D rho_i = max(sum_j m_j (w_i - w_j).grad W_ij + sum_b V_b rho0 w_i.grad W_ib, 0),
 // skipped (0) when the particle has fewer than 20 contacts; stores kappa_i = D rho_i * alpha_i (the only use of
 // the divergence, :370,:382) and the per-particle error D rho_i / rho0.
 // ------------------------------------------------------------------------------------------------
 template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
-    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
+    const SolveCtl* const rec = solve_record(c);
+    if (rec && rec->done) return;  // the solve converged earlier in this batch
+    const float4* const win = rec ? solve_w_in(c, rec) : c.w;
     lds_base_check();
     Tile t;
     t.setup(c);
@@ -142,7 +198,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
     struct Own { float4 pi, wi; float alpha; uint32_t mi, cnt, cntb, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.w[i], c.alpha[i], c.model[i], c.nff[i], c.nb ? c.nfb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
+        return Own{c.posm[i], win[i], c.alpha[i], c.model[i], c.nff[i], c.nb ? c.nfb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -150,7 +206,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     const uint32_t dist = pw_dist<DS>(c, t);
     const float4* Bp = nullptr;
     const float4* Bv = nullptr;
-    t.stage_pw(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), dist, Bp, Bv, false);
+    t.stage_pw(c, static_cast<const float4*>(c.posm), win, dist, Bp, Bv, false);
     TileErr E;
     E.init(carve_errtab(t), c);
     Tile::staged_barrier();
@@ -195,8 +251,16 @@ void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c, float inv_dt_prev) {
-    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
+    const SolveCtl* const rec = solve_record(c);
+    const bool was_done = rec && rec->done;
+    const float4* const win = rec ? solve_w_in(c, rec) : c.w;
+    float4* const wout = c.spec_k >= 0 ? ((win == c.w) ? c.w2 : c.w) : c.w;  // (speculative: the other buffer; else in place)
     lds_base_check();
+    if (c.spec_k >= 0 && blockIdx.x == 0) {  // the convergence test of this iteration rides in workgroup 0 (spec_decide)
+        spec_decide(c, reinterpret_cast<float*>(tile_smem));
+        __syncthreads();
+    }
+    if (was_done) return;  // the solve converged earlier in this batch
     Tile t;
     t.setup(c);
     if (t.empty()) return;
@@ -204,7 +268,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
     // becomes w (:422-430), so updating w in place saves two 16-byte loads and one store per particle and pass.
     struct Own { float4 pi, wi; float ki; uint32_t cnt, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.w[i], c.kappa[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+        return Own{c.posm[i], win[i], c.kappa[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -239,7 +303,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
                 apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), ex * fs, ey * fs, ez * fs);
             }
         });
-        c.w[i] = d;
+        wout[i] = d;
     });
 }
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {

@@ -133,10 +133,14 @@ class World {
     StepCtx make_ctx();
     struct SolveResult { uint32_t iters; float err; };
     template <typename Eval, typename Apply>
-    SolveResult run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval, Apply&& apply);
+    SolveResult run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval, Apply&& apply,
+                          bool spec_apply = false);
+    DevBuf<float4> w2;            // the second w buffer of speculative divergence applies (dfsph.hip, spec_decide)
+    DevBuf<SolveCtl> spec_ring;   // their two alternating control records
+    bool spec_apply_off = false;  // SALVA_HIP_NO_SPEC_APPLY (A/B, tests)
     void wait_stream();  // low-latency wait for the world's stream (spins on an event)
     void run_forces(const StepCtx& c);
-    void dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
+    void dfsph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
     void iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
     FluidArrays arrays(int which);
     DistArrays dist_arrays(int which);

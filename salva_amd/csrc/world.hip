@@ -131,6 +131,7 @@ World::World(const SalvaHipParams& p) : prm(p) {
     spec_off = getenv("SALVA_HIP_SPECULATE") == nullptr || getenv("SALVA_HIP_NO_SPECULATION") != nullptr;
     spec_tight = getenv("SALVA_HIP_SPEC_TIGHT") != nullptr;
     defer_off = getenv("SALVA_HIP_NO_DEFER_LISTS") != nullptr;
+    spec_apply_off = getenv("SALVA_HIP_NO_SPEC_APPLY") != nullptr;
 #ifdef SALVA_HIP_DIAG
     if (const char* e = getenv("SALVA_HIP_SCHED")) sched_mode = atoi(e);
 #endif
@@ -647,6 +648,7 @@ StepCtx World::make_ctx() {
     c.nbmodels = (uint32_t)std::max<size_t>(bounds.size(), 1);
     c.rho0_tab = rho0_tab.p; c.rho0_single = fluids.empty() ? 1000.0f : fluids[0].density0; c.ff_ok = ff_ok.p; c.fb_ok = fb_ok.p; c.bb_ok = bb_ok.p;
     c.partials = partials.p;
+    c.spec_k = -1; c.spec_ring = spec_ring.p; c.spec_pub = nullptr; c.model_counts = model_counts.p; c.w2 = w2.p;
     c.flags = d_flags.p;
     c.min_neighbors_for_divergence = 20;  // dfsph_solver.rs:62 (DIM == 3)
     c.phase = 0;
@@ -794,12 +796,16 @@ void World::wait_stream() {
 // and the control block is read back once per batch.  Kernels enqueued after convergence return immediately.
 template <typename Eval, typename Apply>
 World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval,
-                                    Apply&& apply) {
+                                    Apply&& apply, bool spec_apply) {
     SolveCtl& init = h_ctl[NUM_SOLVES + which];
     init = SolveCtl{0u, 0u, 0.0f, 0u, tol, (uint32_t)std::max(min_iter, 0), mode, 0u};
     h_ctl[which] = init;
     SALVA_HIP_CHECK(hipMemcpyAsync(d_ctl.p + which, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
     c.ctl = d_ctl.p + which;
+    if (spec_apply) {  // (dfsph.hip spec_decide: the test rides in the apply pass; iteration k reads spec_ring[k & 1])
+        SALVA_HIP_CHECK(hipMemcpyAsync(spec_ring.p, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
+        SALVA_HIP_CHECK(hipMemcpyAsync(spec_ring.p + 1, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
+    }
     // Every convergence test publishes its outcome to host-mapped memory (k_finalize_error; in a decomposed run k_decide,
     // behind the all-reduce), and the host waits for the test count it enqueued — it then decides (and enqueues what
     // follows) while the batch's last apply pass is still running.
@@ -813,8 +819,9 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
     while (i < max_iter) {
         const int nbatch = std::min(batch, max_iter - i);
         for (int k = 0; k < nbatch; ++k) {
+            if (spec_apply) { c.spec_k = i + k; c.spec_pub = pub; }
             eval(c, i + k);
-            finalize_solve(d_ctl.p + which, pub);
+            if (!spec_apply) finalize_solve(d_ctl.p + which, pub);
             apply(c, i + k);
         }
         if (pub) {
@@ -835,7 +842,9 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
             }
             h_ctl[which].done = pub->done; h_ctl[which].iters = pub->iters; h_ctl[which].err = pub->err;
         } else {
-            SALVA_HIP_CHECK(hipMemcpyAsync(&h_ctl[which], d_ctl.p + which, sizeof(SolveCtl), hipMemcpyDeviceToHost, stream));
+            // (no publication: read the newest record back — after i + nbatch iterations that is spec_ring[(i + nbatch) & 1])
+            const SolveCtl* src = spec_apply ? spec_ring.p + ((i + nbatch) & 1) : d_ctl.p + which;
+            SALVA_HIP_CHECK(hipMemcpyAsync(&h_ctl[which], src, sizeof(SolveCtl), hipMemcpyDeviceToHost, stream));
             wait_stream();
         }
         i += nbatch;
@@ -939,11 +948,17 @@ void World::evaluate_split(const StepCtx& c, int iteration, Launch&& launch) {
 }
 
 // DFSPHSolver::step (dfsph_solver.rs:667-708)
-void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
+void World::dfsph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
     // divergence_solve (:466-503).  NOTE the dt lag: inv_dt is still the previous step's here (0 on the first step).
     const float inv_dt_lag = inv_dt_prev;
     const bool timers = prm.enable_timers != 0;
     if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[3], stream));  // counters.custom (:492)
+    // Speculative applies (dfsph.hip, spec_decide): the convergence test rides in the apply pass instead of a launch of its own.
+    // Worth ~3 us per iteration (measured: a 50-iteration step 5.13 -> 4.99 ms); the apply that follows the converging evaluate is
+    // then computed in vain (~30 us once per solve), so: only when the previous step's solve ran 16 iterations or more; not with boundary reaction forces (an
+    // apply that is thrown away must not have added to them) and not in decomposed runs (the test sits behind an all-reduce).
+    const bool spec_apply = !spec_apply_off && !comm && !any_wants_forces && last_iters[0] >= 16u;
+    if (spec_apply) { w2.ensure(n, stream, false, 1.1f); spec_ring.ensure(2); c.w2 = w2.p; c.spec_ring = spec_ring.p; }
     const SolveResult rd = run_solve(
         c, 0, prm.max_divergence_error * inv_dt_prev * 0.01f, prm.min_divergence_iter, prm.max_divergence_iter, 0u,
         [&](const StepCtx& cc, int it) { evaluate_split(cc, it, [&](const StepCtx& cs, hipStream_t s) { launch_divergence(cs, lds, s); }); },
@@ -952,7 +967,11 @@ void World::dfsph_solve(const StepCtx& c, float dt, const float g[3], SalvaHipSt
             // owned particles read nothing else, so only w travels, once per iteration
             launch_divergence_apply(cc, lds, inv_dt_lag, stream);
             if (comm) refresh_f4(w.p);
-        });
+        }, spec_apply);
+    if (spec_apply && (rd.iters & 1u)) {  // an odd number of committed applies: w lives in the second buffer
+        std::swap(w.p, w2.p); std::swap(w.cap, w2.cap);
+        c.w = w.p; c.w2 = w2.p;
+    }
     if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[4], stream));  // :501
     st.n_divergence_iters = (int32_t)rd.iters;
     st.divergence_error = rd.err;
@@ -2063,7 +2082,7 @@ uint64_t World::device_bytes() const {
         add(posm[k].bytes()); add(vel[k].bytes()); add(dv[k].bytes()); add(model[k].bytes()); add(perm[k].bytes());
         add(keys[k].bytes()); add(idx[k].bytes()); add(bkeys[k].bytes()); add(bidx[k].bytes());
     }
-    add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes()); add(iisph_q.bytes()); add(iisph_pr.bytes()); add(posmr.bytes());
+    add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes()); add(iisph_q.bytes()); add(iisph_pr.bytes()); add(posmr.bytes()); add(w2.bytes());
     add(rho.bytes()); add(alpha.bytes()); add(kappa.bytes()); add(kappa2.bytes()); add(rho_star.bytes()); add(aii.bytes());
     add(visc_beta.bytes()); add(visc_target.bytes()); add(visc_u0.bytes()); add(visc_u1.bytes()); add(visc_va.bytes()); add(he_colors.bytes()); add(he_gradcs.bytes());
     add(nff.bytes()); add(nfb.bytes()); add(cell_start_f.bytes()); add(halo_src.bytes()); add(bhalo_src.bytes());

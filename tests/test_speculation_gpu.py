@@ -99,6 +99,37 @@ def test_deferred_list_capacity_check_repeats_the_pass_on_overflow():
         assert np.array_equal(w.contact_counts(f), w0.contact_counts(f0))
 
 
+def test_speculative_applies_change_nothing_but_the_launch_count():
+    """Divergence solves that needed 16 or more iterations in the previous step let the apply pass run ahead of the convergence test
+    (dfsph.hip spec_decide: the test rides in workgroup 0 of the apply, w is double-buffered).  Same reduction order, same decisions:
+    a run with SALVA_HIP_NO_SPEC_APPLY=1 must agree bit for bit, iteration counts included."""
+    def run(env):
+        old = os.environ.pop("SALVA_HIP_NO_SPEC_APPLY", None)
+        os.environ.update(env)
+        try:
+            sc = Scene(R, 2.0, "dfsph")  # the bench scene in small: a 0.8 rho0 lattice block dropped into a tank
+            fluid, shell = scenes.tank(24, 24, 24, R)
+            sc.add_fluid(scenes.jitter(fluid, 0.1 * R, seed=42), None, 1000.0, forces=[("xsph", 0.5, 0.0)])
+            sc.add_boundary(shell)
+            w, (fl,), _ = sc.make_hip()
+        finally:
+            os.environ.pop("SALVA_HIP_NO_SPEC_APPLY", None)
+            if old is not None:
+                os.environ["SALVA_HIP_NO_SPEC_APPLY"] = old
+        iters = []
+        for _ in range(40):
+            st = w.step(DT, GRAVITY)
+            iters.append((st.n_divergence_iters, st.n_pressure_iters, int(st.ncontacts)))
+        return w, fl, iters
+
+    w0, f0, it0 = run({"SALVA_HIP_NO_SPEC_APPLY": "1"})
+    w1, f1, it1 = run({})
+    assert sum(i[0] >= 16 for i in it0) >= 5, it0  # the scene does reach the regime in which the speculative path switches on
+    assert w1.device_bytes() >= w0.device_bytes() + 16 * f0.num_particles()  # ... and it did: the second w buffer exists
+    assert it1 == it0
+    assert np.array_equal(f1.positions, f0.positions) and np.array_equal(f1.velocities, f0.velocities)
+
+
 def test_counters_tree_is_filled_like_the_reference():
     w0, _, _ = _run({}, nsteps=2)
     assert w0.counters.step_time == 0 and w0.counters.cd.ncontacts > 0  # disabled timers read 0 (Timer::new), the counts are always there
