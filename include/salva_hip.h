@@ -307,9 +307,27 @@ typedef struct SalvaHipComm SalvaHipComm;
 /* RCCL over xGMI: rank 0 creates the 128-byte id and distributes it (torch.distributed, MPI, a file ...) */
 int salva_hip_comm_rccl_unique_id(unsigned char* out128);
 int salva_hip_comm_rccl_create(int32_t rank, int32_t size, const unsigned char* id128, int32_t device, SalvaHipComm** out);
+/* xGMI peer-direct, for the ranks of ONE node (one process per rank): every exchange is a flagged store into a window of the
+ * neighbour's memory mapped through hipIpc, the convergence all-reduce a flagged store into every rank's window — a few
+ * microseconds instead of a collective-library round trip per solver iteration.  Two phases, because the windows' IPC handles
+ * must travel between the processes: _begin allocates this rank's window (4 receive slots of `slot_bytes`; longer messages
+ * go in rounds) and returns its 64-byte handle; the caller gathers the handles of all ranks in rank order (torch.distributed,
+ * MPI, a file ...) and passes the size x 64 bytes to _connect, which consumes the setup object (also when it fails; _abort
+ * frees a setup that is never connected).  At most 64 ranks.  Two ranks may share a GPU (how single-GPU boxes test it).
+ * A rank whose neighbour does not show up within 30 s gets SALVA_HIP_E_HIP from its next call instead of a hung kernel. */
+#define SALVA_HIP_PEER_HANDLE_BYTES 64
+typedef struct SalvaHipPeerSetup SalvaHipPeerSetup;
+int salva_hip_comm_peer_begin(int32_t rank, int32_t size, int32_t device, uint64_t slot_bytes, unsigned char* handle64,
+                              SalvaHipPeerSetup** out);
+int salva_hip_comm_peer_connect(SalvaHipPeerSetup* setup, const unsigned char* handles, SalvaHipComm** out);
+void salva_hip_comm_peer_abort(SalvaHipPeerSetup* setup);
 /* in-process loopback for tests: `size` communicators sharing a mailbox; drive each from its own host thread */
 int salva_hip_comm_loopback_create(int32_t size, SalvaHipComm** out_ranks);
 void salva_hip_comm_destroy(SalvaHipComm* comm);
+/* Collective self-test of a communicator, any transport: `rounds` patterned exchanges of different (odd, empty, up to
+ * `max_bytes`) lengths with both neighbours, a count exchange and both all-reduces per round, on a stream of its own.
+ * SALVA_HIP_OK, or SALVA_HIP_E_HIP with the first mismatch in salva_hip_last_error(). */
+int salva_hip_comm_selftest(SalvaHipComm* comm, uint64_t max_bytes, int32_t rounds);
 int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_lo, int32_t cell_hi, uint32_t gid_offset);
 /* Load balancing, collective (every rank calls it between two steps, after at least one step): the slabs are re-cut at cell
  * planes so that every rank owns about the same number of particles (all-reduced histogram over the planes; a cut stays

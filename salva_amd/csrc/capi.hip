@@ -360,6 +360,46 @@ int salva_hip_comm_rccl_create(int32_t rank, int32_t size, const unsigned char* 
         return SALVA_HIP_OK;
     });
 }
+struct SalvaHipPeerSetup {
+    salva::PeerSetup* s = nullptr;
+};
+int salva_hip_comm_peer_begin(int32_t rank, int32_t size, int32_t device, uint64_t slot_bytes, unsigned char* handle64,
+                              SalvaHipPeerSetup** out) {
+    return guarded([&]() -> int {
+        if (!handle64 || !out) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        static_assert(SALVA_HIP_PEER_HANDLE_BYTES == salva::PEER_HANDLE_BYTES, "handle size");
+        auto* p = new SalvaHipPeerSetup();
+        try {
+            p->s = salva::peer_begin(rank, size, device, (size_t)slot_bytes, handle64);
+        } catch (...) {
+            delete p;
+            throw;
+        }
+        *out = p;
+        return SALVA_HIP_OK;
+    });
+}
+int salva_hip_comm_peer_connect(SalvaHipPeerSetup* setup, const unsigned char* handles, SalvaHipComm** out) {
+    return guarded([&]() -> int {
+        if (!setup || !handles || !out) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        salva::PeerSetup* s = setup->s;
+        delete setup;  // consumed either way: peer_transport owns `s` from its first line on
+        auto* c = new SalvaHipComm();
+        try {
+            c->t = salva::peer_transport(s, handles);
+        } catch (...) {
+            delete c;
+            throw;
+        }
+        *out = c;
+        return SALVA_HIP_OK;
+    });
+}
+void salva_hip_comm_peer_abort(SalvaHipPeerSetup* setup) {
+    if (!setup) return;
+    try { salva::peer_abort(setup->s); } catch (...) {}
+    delete setup;
+}
 int salva_hip_comm_loopback_create(int32_t size, SalvaHipComm** out_ranks) {
     return guarded([&]() -> int {
         if (size < 1 || !out_ranks) throw salva::HipError(SALVA_HIP_E_INVALID, "bad argument");
@@ -377,6 +417,21 @@ void salva_hip_comm_destroy(SalvaHipComm* comm) {
     if (!comm) return;
     try { delete comm->t; } catch (...) {}
     delete comm;
+}
+int salva_hip_comm_selftest(SalvaHipComm* comm, uint64_t max_bytes, int32_t rounds) {
+    return guarded([&]() -> int {
+        if (!comm || !comm->t) throw salva::HipError(SALVA_HIP_E_INVALID, "null communicator");
+        hipStream_t s = nullptr;
+        SALVA_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        try {
+            salva::transport_selftest(*comm->t, (size_t)max_bytes, rounds, s);
+        } catch (...) {
+            (void)hipStreamDestroy(s);
+            throw;
+        }
+        SALVA_HIP_CHECK(hipStreamDestroy(s));
+        return SALVA_HIP_OK;
+    });
 }
 int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_lo, int32_t cell_hi, uint32_t gid_offset) {
     return guarded([&]() -> int {

@@ -6,9 +6,10 @@
 // (10^4-10^5 particles, 4-64 bytes each), point to point between adjacent ranks over xGMI, plus one tiny all-reduce
 // per convergence test.  No large collective is ever needed.
 //
-// Two transports: RCCL (ncclSend/ncclRecv groups + ncclAllReduce on the world's stream) for real multi-GPU runs, and
-// an in-process loopback (one thread per world, device-to-device copies through a shared mailbox) that exercises the
-// identical code path on a single GPU for the tests.
+// Three transports: RCCL (ncclSend/ncclRecv groups + ncclAllReduce on the world's stream), the default for multi-GPU runs;
+// xGMI peer-direct (comm_peer.hip: flagged stores into IPC-mapped windows of the other ranks' memory, for the ranks of one
+// node); and an in-process loopback (one thread per world, device-to-device copies through a shared mailbox) that exercises
+// the identical World code on a single GPU for the tests.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -48,5 +49,19 @@ Transport* loopback_transport(const std::shared_ptr<LoopbackShared>& group, int 
 constexpr size_t RCCL_ID_BYTES = 128;
 void rccl_unique_id(unsigned char out[RCCL_ID_BYTES]);
 Transport* rccl_transport(int rank, int size, const unsigned char id[RCCL_ID_BYTES], int device);
+
+// Collective self-test of a transport (patterned messages of `rounds` different lengths up to `max_bytes`, both all-reduces, the
+// count exchange); throws HipError describing the first mismatch.
+void transport_selftest(Transport& t, size_t max_bytes, int rounds, hipStream_t s);
+
+// xGMI peer-direct, the ranks of one node (one process per rank; two ranks may share a GPU, which is how the single-GPU boxes
+// test it).  Two phases, because the windows' IPC handles have to travel between the processes: peer_begin allocates this
+// rank's window and returns its handle; the caller gathers all ranks' handles (rank order) and hands them to peer_transport,
+// which takes ownership of the setup object.  `slot_bytes`: capacity of one receive slot (longer messages go in rounds).
+constexpr size_t PEER_HANDLE_BYTES = 64;
+struct PeerSetup;
+PeerSetup* peer_begin(int rank, int size, int device, size_t slot_bytes, unsigned char handle_out[PEER_HANDLE_BYTES]);
+void peer_abort(PeerSetup* setup);
+Transport* peer_transport(PeerSetup* setup, const unsigned char* handles);
 
 }  // namespace salva

@@ -221,6 +221,87 @@ class RcclTransport : public Transport {
     uint64_t* h_cnt_ = nullptr;
 };
 
+// ---------------------------------------------------------------------------------------------------
+// Self-test of a transport, collective: patterned messages of varying (odd, zero, longer-than-a-slot) lengths both ways,
+// both all-reduces over more values than one pass holds, the count exchange.  Throws with a description of the first
+// mismatch.  What tests/test_peer_transport_gpu.py and a deployment's "is the fabric wired as I think" check call.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+inline unsigned char selftest_byte(int rank, int towards_hi, int round, size_t i) {
+    return (unsigned char)(((size_t)rank * 131u + (size_t)towards_hi * 17u + (size_t)round * 29u + i * 7u + (i >> 8)) & 0xffu);
+}
+}  // namespace
+
+void transport_selftest(Transport& t, size_t max_bytes, int rounds, hipStream_t s) {
+    const int rank = t.rank(), size = t.size();
+    if (rounds < 1 || max_bytes < 16) throw HipError(-2, "transport self-test: rounds >= 1, max_bytes >= 16");
+    DevBuf<unsigned char> sl, sh, rl, rh;
+    sl.ensure(max_bytes); sh.ensure(max_bytes); rl.ensure(max_bytes); rh.ensure(max_bytes);
+    std::vector<unsigned char> h(max_bytes), g(max_bytes);
+    auto fail = [&](const char* what, int round, size_t i) {
+        char b[256];
+        snprintf(b, sizeof(b), "transport self-test, rank %d of %d: %s (round %d, index %zu)", rank, size, what, round, i);
+        throw HipError(-1, b);
+    };
+    for (int r = 0; r < rounds; ++r) {
+        // message length depends on the direction, the link and the round, and is 0 now and then: the link between ranks a and
+        // a+1 carries len(a, 1, r) upwards and len(a+1, 0, r) downwards
+        auto len = [&](int from, int towards_hi) -> size_t {
+            const size_t k = (size_t)(from * 7 + towards_hi * 3 + r * 5);
+            if (k % 6 == 5) return 0;
+            const size_t base = max_bytes * (size_t)(r + 1) / (size_t)rounds;
+            return base > (k % 13) ? base - (k % 13) : base;
+        };
+        const size_t n_lo = t.has_lo() ? len(rank, 0) : 0, n_hi = t.has_hi() ? len(rank, 1) : 0;
+        const size_t m_lo = t.has_lo() ? len(rank - 1, 1) : 0, m_hi = t.has_hi() ? len(rank + 1, 0) : 0;
+        for (size_t i = 0; i < n_lo; ++i) h[i] = selftest_byte(rank, 0, r, i);
+        SALVA_HIP_CHECK(hipMemcpyAsync(sl.p, h.data(), n_lo, hipMemcpyHostToDevice, s));
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < n_hi; ++i) h[i] = selftest_byte(rank, 1, r, i);
+        SALVA_HIP_CHECK(hipMemcpyAsync(sh.p, h.data(), n_hi, hipMemcpyHostToDevice, s));
+        SALVA_HIP_CHECK(hipMemsetAsync(rl.p, 0xEE, max_bytes, s));
+        SALVA_HIP_CHECK(hipMemsetAsync(rh.p, 0xEE, max_bytes, s));
+        t.sendrecv(sl.p, n_lo, sh.p, n_hi, rl.p, m_lo, rh.p, m_hi, s);
+        SALVA_HIP_CHECK(hipMemcpyAsync(g.data(), rl.p, max_bytes, hipMemcpyDeviceToHost, s));
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < m_lo; ++i)
+            if (g[i] != selftest_byte(rank - 1, 1, r, i)) fail("wrong byte from the lower neighbour", r, i);
+        for (size_t i = m_lo; i < max_bytes; ++i)
+            if (g[i] != 0xEE) fail("bytes written beyond the message from the lower neighbour", r, i);
+        SALVA_HIP_CHECK(hipMemcpyAsync(g.data(), rh.p, max_bytes, hipMemcpyDeviceToHost, s));
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < m_hi; ++i)
+            if (g[i] != selftest_byte(rank + 1, 0, r, i)) fail("wrong byte from the upper neighbour", r, i);
+        for (size_t i = m_hi; i < max_bytes; ++i)
+            if (g[i] != 0xEE) fail("bytes written beyond the message from the upper neighbour", r, i);
+
+        uint64_t to_lo[2] = {(uint64_t)rank * 10 + 1 + (uint64_t)r, 77}, to_hi[2] = {(uint64_t)rank * 10 + 2 + (uint64_t)r, 99}, from_lo[2], from_hi[2];
+        t.exchange_counts(to_lo, to_hi, from_lo, from_hi, s);
+        if (t.has_lo() && (from_lo[0] != (uint64_t)(rank - 1) * 10 + 2 + (uint64_t)r || from_lo[1] != 99)) fail("wrong counts from the lower neighbour", r, 0);
+        if (t.has_hi() && (from_hi[0] != (uint64_t)(rank + 1) * 10 + 1 + (uint64_t)r || from_hi[1] != 77)) fail("wrong counts from the upper neighbour", r, 0);
+
+        constexpr int NV = 600;  // more than one pass of any transport
+        DevBuf<float> df; DevBuf<unsigned long long> du;
+        df.ensure(NV); du.ensure(NV);
+        std::vector<float> hf(NV); std::vector<unsigned long long> hu(NV);
+        for (int k = 0; k < NV; ++k) { hf[k] = (float)(rank + 1) * 0.5f + (float)((k + r) % 17); hu[k] = (unsigned long long)(rank + 1) * 1000003ull + (unsigned long long)k * (unsigned long long)(r + 1); }
+        SALVA_HIP_CHECK(hipMemcpyAsync(df.p, hf.data(), NV * sizeof(float), hipMemcpyHostToDevice, s));
+        SALVA_HIP_CHECK(hipMemcpyAsync(du.p, hu.data(), NV * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        t.allreduce_sum_f32(df.p, NV, s);
+        t.allreduce_sum_u64(du.p, NV, s);
+        SALVA_HIP_CHECK(hipMemcpyAsync(hf.data(), df.p, NV * sizeof(float), hipMemcpyDeviceToHost, s));
+        SALVA_HIP_CHECK(hipMemcpyAsync(hu.data(), du.p, NV * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        for (int k = 0; k < NV; ++k) {
+            // halves and small integers: every partial sum is exact in f32, whatever order a transport adds in
+            float ef = 0.0f; unsigned long long eu = 0;
+            for (int q = 0; q < size; ++q) { ef += (float)(q + 1) * 0.5f + (float)((k + r) % 17); eu += (unsigned long long)(q + 1) * 1000003ull + (unsigned long long)k * (unsigned long long)(r + 1); }
+            if (hf[k] != ef) fail("wrong f32 all-reduce sum", r, (size_t)k);
+            if (hu[k] != eu) fail("wrong u64 all-reduce sum", r, (size_t)k);
+        }
+    }
+}
+
 Transport* rccl_transport(int rank, int size, const unsigned char id[RCCL_ID_BYTES], int device) {
     if (size < 1 || rank < 0 || rank >= size) throw HipError(-2, "rccl transport: bad rank / size");
     return new RcclTransport(rank, size, id, device);

@@ -49,11 +49,37 @@ class Comm:
         L.check(L.lib().salva_hip_comm_rccl_create(rank, size, buf, device, C.byref(h)))
         return Comm(h, rank, size)
 
+    PEER_HANDLE_BYTES = 64
+
+    @staticmethod
+    def peer(rank: int, size: int, device: int, gather, slot_bytes: int = 64 << 20) -> "Comm":
+        """xGMI peer-direct transport for the ranks of one node (salva_hip_comm_peer_begin / _connect).  `gather(handle: bytes)
+        -> list of every rank's handle in rank order` is the caller's all-gather (e.g. torch.distributed.all_gather_object);
+        it doubles as the barrier that makes every window exist before anybody writes to it."""
+        hb = (C.c_ubyte * Comm.PEER_HANDLE_BYTES)()
+        setup = C.c_void_p()
+        L.check(L.lib().salva_hip_comm_peer_begin(rank, size, device, slot_bytes, hb, C.byref(setup)))
+        try:
+            handles = [bytes(h) for h in gather(bytes(hb))]
+            if len(handles) != size or any(len(h) != Comm.PEER_HANDLE_BYTES for h in handles):
+                raise ValueError(f"peer transport: expected {size} handles of {Comm.PEER_HANDLE_BYTES} bytes")
+        except BaseException:
+            L.lib().salva_hip_comm_peer_abort(setup)
+            raise
+        allh = (C.c_ubyte * (size * Comm.PEER_HANDLE_BYTES)).from_buffer_copy(b"".join(handles))
+        h = C.c_void_p()
+        L.check(L.lib().salva_hip_comm_peer_connect(setup, allh, C.byref(h)))  # consumes `setup`, also on failure
+        return Comm(h, rank, size)
+
     @staticmethod
     def loopback(size: int) -> List["Comm"]:
         hs = (C.c_void_p * size)()
         L.check(L.lib().salva_hip_comm_loopback_create(size, hs))
         return [Comm(C.c_void_p(hs[r]), r, size) for r in range(size)]
+
+    def selftest(self, max_bytes: int = 1 << 20, rounds: int = 6):
+        """Collective: patterned exchanges, count exchange and both all-reduces through this transport (raises on a mismatch)."""
+        L.check(L.lib().salva_hip_comm_selftest(self._h, max_bytes, rounds))
 
     def destroy(self):
         if self._h:
