@@ -242,6 +242,9 @@ def main():
     ap.add_argument("--side", type=int, default=100, help="particles per edge of the fluid block (100 -> 1M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host time for the multi-thread CPU leg")
+    ap.add_argument("--transport", choices=("rccl", "peer"), default="rccl",
+                    help="slab exchange of a multi-GPU run: RCCL send/recv + all-reduce (default, what BASELINE.json names), or the "
+                         "xGMI peer-direct transport (flagged stores into hipIpc-mapped windows, salva_amd/csrc/comm_peer.hip)")
     ap.add_argument("--force-slabs", action="store_true",
                     help="take the decomposed (RCCL transport) code path even with one rank; a self-test aid, not a bench mode")
     args = ap.parse_args()
@@ -270,12 +273,22 @@ def main():
     else:
         # slab decomposition along x: RCCL point-to-point with the two neighbours + one tiny all-reduce per convergence test
         fluid, shell, my_slab, nshell_total = build_slab_scene(args.side, rank, world)
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(slab.Comm.unique_id()), dtype=torch.uint8))
-        if world > 1:
-            dist.broadcast(idt, 0)
-        comm = slab.Comm.rccl(rank, world, bytes(idt.cpu().numpy().tobytes()), local_rank)
+        if args.transport == "peer":
+            def gather(handle):
+                out = [None] * world
+                if world > 1:
+                    dist.all_gather_object(out, handle)
+                else:
+                    out[0] = handle
+                return out
+            comm = slab.Comm.peer(rank, world, local_rank, gather)
+        else:
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(slab.Comm.unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(idt, 0)
+            comm = slab.Comm.rccl(rank, world, bytes(idt.cpu().numpy().tobytes()), local_rank)
         w, f = make_world(fluid, shell, local_rank)
         handles = [f]
         w.set_domain(comm, my_slab[0], my_slab[1], rank * len(fluid))
@@ -364,8 +377,10 @@ def main():
                             f"(+{nshell_total} boundary), {cfg['what']}, r=0.025 h=0.1 dt=1/200",
                 "particles_per_gpu": n,
                 "parallelism": "single domain" if not decomposed else
-                f"{world} x-slabs, one per GPU: RCCL send/recv of two ghost planes per face with the 2 neighbours (one exchange per "
-                f"solver iteration) + all-reduced convergence test",
+                (f"{world} x-slabs, one per GPU: RCCL send/recv of two ghost planes per face with the 2 neighbours (one exchange per "
+                 f"solver iteration) + all-reduced convergence test" if args.transport == "rccl" else
+                 f"{world} x-slabs, one per GPU: xGMI peer-direct exchange (flagged stores into the neighbours' hipIpc-mapped windows) of two "
+                 f"ghost planes per face, one exchange per solver iteration, convergence sums through every rank's window"),
                 "mean_divergence_iters": float(it[:, 0].mean()),
                 "mean_pressure_iters": float(it[:, 1].mean()),
                 "mean_contacts_per_particle": kbar,

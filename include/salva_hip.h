@@ -328,6 +328,10 @@ void salva_hip_comm_destroy(SalvaHipComm* comm);
  * `max_bytes`) lengths with both neighbours, a count exchange and both all-reduces per round, on a stream of its own.
  * SALVA_HIP_OK, or SALVA_HIP_E_HIP with the first mismatch in salva_hip_last_error(). */
 int salva_hip_comm_selftest(SalvaHipComm* comm, uint64_t max_bytes, int32_t rounds);
+/* Collective: what one solver iteration of a decomposed run adds — average microseconds (host clock over `iters` back-to-back
+ * calls between two stream synchronisations) of one exchange of `bytes` bytes each way with both neighbours, and of one
+ * all-reduce of four floats. */
+int salva_hip_comm_time(SalvaHipComm* comm, uint64_t bytes, int32_t iters, float* us_exchange, float* us_allreduce);
 int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_lo, int32_t cell_hi, uint32_t gid_offset);
 /* Load balancing, collective (every rank calls it between two steps, after at least one step): the slabs are re-cut at cell
  * planes so that every rank owns about the same number of particles (all-reduced histogram over the planes; a cut stays

@@ -33,15 +33,20 @@ __all__ = [
 
 
 def kernel_source_sha() -> str:
-    """sha256 (first 16 hex digits) over the device sources of libsalva_hip.so (salva_amd/csrc/*.hip, *.h): what a committed
-    rocprof summary records so that bench.py can tell whether its PMC figures still describe the kernels in the tree."""
+    """sha256 (first 16 hex digits) over the sources of the kernels a single-GPU profile can contain: salva_amd/csrc/*.hip and
+    *.h except the exchange transports (comm.h, comm.hip, comm_peer.hip) and the extern "C" shims (capi.hip), which hold no
+    such kernel.  A committed rocprof summary records it so that bench.py can tell whether its PMC figures still describe the
+    kernels in the tree."""
     import glob
     import hashlib
     import os
 
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    skip = {"comm.h", "comm.hip", "comm_peer.hip", "capi.hip"}
     hsh = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(here, "*.hip")) + glob.glob(os.path.join(here, "*.h"))):
+        if os.path.basename(f) in skip:
+            continue
         hsh.update(os.path.basename(f).encode())
         hsh.update(open(f, "rb").read())
     return hsh.hexdigest()[:16]

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_set_timestep", "salva_hip_get_counters", "salva_hip_time_kernel", "salva_hip_particles_intersecting_shape", "salva_hip_rebalance",
     "salva_hip_set_boundary_dynamic_sampling", "salva_hip_get_boundary_sources", "salva_hip_set_boundary_dynamic_sampling_host",
     "salva_hip_delete_owned", "salva_hip_enable_counters", "salva_hip_comm_peer_begin", "salva_hip_comm_peer_connect",
-    "salva_hip_comm_peer_abort", "salva_hip_comm_selftest",
+    "salva_hip_comm_peer_abort", "salva_hip_comm_selftest", "salva_hip_comm_time",
 ]
 
 
@@ -219,6 +219,7 @@ def lib():
     L.salva_hip_comm_peer_abort.argtypes = [vp]
     L.salva_hip_comm_peer_abort.restype = None
     L.salva_hip_comm_selftest.argtypes = [vp, u64, i32]
+    L.salva_hip_comm_time.argtypes = [vp, u64, i32, C.POINTER(f32), C.POINTER(f32)]
     L.salva_hip_comm_destroy.argtypes = [vp]
     L.salva_hip_comm_destroy.restype = None
     L.salva_hip_set_domain.argtypes = [vp, vp, i32, i32, u32]

@@ -433,6 +433,21 @@ int salva_hip_comm_selftest(SalvaHipComm* comm, uint64_t max_bytes, int32_t roun
         return SALVA_HIP_OK;
     });
 }
+int salva_hip_comm_time(SalvaHipComm* comm, uint64_t bytes, int32_t iters, float* us_exchange, float* us_allreduce) {
+    return guarded([&]() -> int {
+        if (!comm || !comm->t) throw salva::HipError(SALVA_HIP_E_INVALID, "null communicator");
+        hipStream_t s = nullptr;
+        SALVA_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        try {
+            salva::transport_time(*comm->t, (size_t)bytes, iters, us_exchange, us_allreduce, s);
+        } catch (...) {
+            (void)hipStreamDestroy(s);
+            throw;
+        }
+        SALVA_HIP_CHECK(hipStreamDestroy(s));
+        return SALVA_HIP_OK;
+    });
+}
 int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_lo, int32_t cell_hi, uint32_t gid_offset) {
     return guarded([&]() -> int {
         if (!world || !comm) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");

@@ -54,6 +54,10 @@ Transport* rccl_transport(int rank, int size, const unsigned char id[RCCL_ID_BYT
 // count exchange); throws HipError describing the first mismatch.
 void transport_selftest(Transport& t, size_t max_bytes, int rounds, hipStream_t s);
 
+// Collective: average host-clock microseconds of one exchange of `bytes` bytes each way with both neighbours, and of one
+// all-reduce of four floats, over `iters` back-to-back calls each (what one solver iteration of a decomposed run adds).
+void transport_time(Transport& t, size_t bytes, int iters, float* us_sendrecv, float* us_allreduce, hipStream_t s);
+
 // xGMI peer-direct, the ranks of one node (one process per rank; two ranks may share a GPU, which is how the single-GPU boxes
 // test it).  Two phases, because the windows' IPC handles have to travel between the processes: peer_begin allocates this
 // rank's window and returns its handle; the caller gathers all ranks' handles (rank order) and hands them to peer_transport,

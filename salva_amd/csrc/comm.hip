@@ -3,6 +3,7 @@
 
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -300,6 +301,33 @@ void transport_selftest(Transport& t, size_t max_bytes, int rounds, hipStream_t 
             if (hu[k] != eu) fail("wrong u64 all-reduce sum", r, (size_t)k);
         }
     }
+}
+
+// Latency of the two operations a solver iteration of a decomposed run performs, collective: `iters` back-to-back exchanges
+// of `bytes` bytes each way with both neighbours, then `iters` back-to-back all-reduces of four floats, each batch between
+// two stream synchronisations; host wall clock / iters, in microseconds.
+void transport_time(Transport& t, size_t bytes, int iters, float* us_sendrecv, float* us_allreduce, hipStream_t s) {
+    if (iters < 1 || bytes < 4) throw HipError(-2, "transport timing: iters >= 1, bytes >= 4");
+    DevBuf<unsigned char> sl, sh, rl, rh;
+    sl.ensure(bytes); sh.ensure(bytes); rl.ensure(bytes); rh.ensure(bytes);
+    DevBuf<float> red;
+    red.ensure(4);
+    SALVA_HIP_CHECK(hipMemsetAsync(sl.p, 1, bytes, s));
+    SALVA_HIP_CHECK(hipMemsetAsync(sh.p, 2, bytes, s));
+    SALVA_HIP_CHECK(hipMemsetAsync(red.p, 0, 4 * sizeof(float), s));
+    const size_t lo = t.has_lo() ? bytes : 0, hi = t.has_hi() ? bytes : 0;
+    auto timed = [&](auto&& op) -> float {
+        for (int k = 0; k < 3; ++k) op();  // warm: first launches, and the ranks meet
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < iters; ++k) op();
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        return (float)(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / iters);
+    };
+    const float a = timed([&] { t.sendrecv(sl.p, lo, sh.p, hi, rl.p, lo, rh.p, hi, s); });
+    const float b = timed([&] { t.allreduce_sum_f32(red.p, 4, s); });
+    if (us_sendrecv) *us_sendrecv = a;
+    if (us_allreduce) *us_allreduce = b;
 }
 
 Transport* rccl_transport(int rank, int size, const unsigned char id[RCCL_ID_BYTES], int device) {

@@ -17,8 +17,8 @@
 // needs the neighbour's put(t+1), which follows its get(t)).  The same argument covers the all-reduce mailboxes.
 //
 // A wait that is not satisfied within PEER_TIMEOUT_TICKS of the 100 MHz wall clock (30 s: ranks reach their first exchange
-// seconds apart) gives up, records the fact in a
-// host-mapped word and lets the kernel finish: the host throws at its next call instead of leaving a kernel spinning.
+// seconds apart) gives up, records the fact in a host-mapped word and lets the kernel finish: the host throws at its next call
+// instead of leaving a kernel spinning.
 #include <cstring>
 #include <vector>
 

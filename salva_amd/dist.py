@@ -81,6 +81,12 @@ class Comm:
         """Collective: patterned exchanges, count exchange and both all-reduces through this transport (raises on a mismatch)."""
         L.check(L.lib().salva_hip_comm_selftest(self._h, max_bytes, rounds))
 
+    def time(self, nbytes: int = 64 << 10, iters: int = 200) -> Tuple[float, float]:
+        """Collective: (us per exchange of `nbytes` each way with both neighbours, us per all-reduce of four floats)."""
+        a, b = C.c_float(), C.c_float()
+        L.check(L.lib().salva_hip_comm_time(self._h, nbytes, iters, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def destroy(self):
         if self._h:
             L.lib().salva_hip_comm_destroy(self._h)

@@ -36,6 +36,10 @@ def main():
     small = dist.Comm.peer(rank, world, device, gather, slot_bytes=64 << 10)
     small.selftest(300_000, 6)
     td.barrier()
+    for nbytes in (4 << 10, 64 << 10):  # a refresh of 1 000 / 16 000 ghosts' scalar field
+        us_x, us_r = small.time(nbytes, 200)
+        print(f"PEER_TIMING rank {rank}/{world} on device {device}: exchange of {nbytes} B each way {us_x:.1f} us, all-reduce {us_r:.1f} us", flush=True)
+    td.barrier()
     small.destroy()
 
     # ---- a decomposed run over it
