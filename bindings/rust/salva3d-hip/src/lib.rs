@@ -5,8 +5,10 @@
 //! host changed, calls `salva_hip_step`, and reads back what the host looks at.  There is no CPU fallback — without the
 //! library or a device `LiquidWorld::new` returns the ABI's error.
 pub mod ffi;
+pub mod dist;
 mod liquid_world;
 #[cfg(feature = "rapier")]
 pub mod coupling;
 
+pub use dist::{Comm, OwnedParticles};
 pub use liquid_world::{Error, GpuPressureSolver, LiquidWorld};

@@ -22,7 +22,7 @@ pub struct Error {
     pub message: String,
 }
 
-fn check(code: i32) -> Result<(), Error> {
+pub(crate) fn check(code: i32) -> Result<(), Error> {
     if code == ffi::SALVA_HIP_OK {
         return Ok(());
     }
@@ -106,6 +106,7 @@ pub struct LiquidWorld {
     host_dirty: bool,    // fluids_mut() / boundaries_mut() / add_* was called since the last upload
     device_newer: bool,  // a step ran since the last download
     auto_sync: bool,
+    decomposed: bool,    // set_domain was called (dist.rs): particles are read with owned()
     last_stats: ffi::SalvaHipStepStats,
 }
 
@@ -138,6 +139,7 @@ impl LiquidWorld {
             host_dirty: true,
             device_newer: false,
             auto_sync: true,
+            decomposed: false,
             last_stats: unsafe { std::mem::zeroed() },
         })
     }
@@ -208,7 +210,8 @@ impl LiquidWorld {
         if !self.device_newer {
             return Ok(());
         }
-        for (slot, fluid) in self.fluids.as_mut_slice().iter_mut().enumerate() {
+        let nfluids = if self.decomposed { 0 } else { self.fluids.len() };  // host-order read-back does not exist in a decomposed run
+        for (slot, fluid) in self.fluids.as_mut_slice().iter_mut().enumerate().take(nfluids) {
             if fluid.num_particles() == 0 {
                 continue;
             }
@@ -240,7 +243,9 @@ impl LiquidWorld {
         if !self.host_dirty {
             return Ok(());
         }
-        for (slot, fluid) in self.fluids.as_mut_slice().iter_mut().enumerate() {
+        // in a decomposed run the fluids live on the device and change owner (dist.rs): only boundaries travel again
+        let nfluids = if self.decomposed { 0 } else { self.fluids.len() };
+        for (slot, fluid) in self.fluids.as_mut_slice().iter_mut().enumerate().take(nfluids) {
             // host-side half of apply_particles_removal + init_with_fluids (fluid.rs:88-98, dfsph_solver.rs:526-561): the
             // survivors' velocity_changes are fetched, filtered with the same mask and sent back with the particles
             let deleted: Vec<bool> = fluid.deleted_particles_mask().to_vec();
@@ -300,6 +305,13 @@ impl LiquidWorld {
             })?;
         }
         self.host_dirty = false;
+        Ok(())
+    }
+
+    /// What `set_domain` (dist.rs) needs: everything the host holds goes up once; afterwards only boundaries are re-uploaded.
+    pub(crate) fn upload_for_domain(&mut self) -> Result<(), Error> {
+        self.upload()?;
+        self.decomposed = true;
         Ok(())
     }
 

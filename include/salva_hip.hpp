@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <string>
 #include <functional>
+#include <utility>
 #include <vector>
 
 #include "salva_hip.h"
@@ -247,6 +248,82 @@ struct CouplingManager {
     virtual void transmit_forces(LiquidWorld& world, Real dt) = 0;
 };
 
+// ---- multi-GPU: a rank's handle on the slab exchange transport (salva_hip_comm_*; no counterpart in the reference, which is
+// single-process).  One process and one LiquidWorld per GPU; see LiquidWorld::set_domain.
+class Comm {
+  public:
+    Comm() = default;
+    Comm(Comm&& o) noexcept : h_(o.h_), rank_(o.rank_), size_(o.size_) { o.h_ = nullptr; }
+    Comm& operator=(Comm&& o) noexcept {
+        if (this != &o) { destroy(); h_ = o.h_; rank_ = o.rank_; size_ = o.size_; o.h_ = nullptr; }
+        return *this;
+    }
+    Comm(const Comm&) = delete;
+    Comm& operator=(const Comm&) = delete;
+    ~Comm() { destroy(); }
+    void destroy() {  // after the worlds that use it
+        if (h_) salva_hip_comm_destroy(h_);
+        h_ = nullptr;
+    }
+    // RCCL over xGMI (the default): rank 0 creates the id and distributes it (MPI_Bcast, a file ...)
+    static std::array<unsigned char, 128> rccl_unique_id() {
+        std::array<unsigned char, 128> id{};
+        check(salva_hip_comm_rccl_unique_id(id.data()));
+        return id;
+    }
+    static Comm rccl(int rank, int size, const std::array<unsigned char, 128>& id, int device) {
+        Comm c;
+        check(salva_hip_comm_rccl_create(rank, size, id.data(), device, &c.h_));
+        c.rank_ = rank; c.size_ = size;
+        return c;
+    }
+    // xGMI peer-direct, the ranks of one node: `all_gather(mine) -> every rank's 64-byte handle in rank order` is the caller's
+    // all-gather (MPI_Allgather ...); it doubles as the barrier that makes every window exist before anybody writes to it
+    using PeerHandle = std::array<unsigned char, SALVA_HIP_PEER_HANDLE_BYTES>;
+    template <class AllGather>
+    static Comm peer(int rank, int size, int device, AllGather&& all_gather, uint64_t slot_bytes = 64ull << 20) {
+        PeerHandle mine{};
+        SalvaHipPeerSetup* setup = nullptr;
+        check(salva_hip_comm_peer_begin(rank, size, device, slot_bytes, mine.data(), &setup));
+        std::vector<PeerHandle> all;
+        try {
+            all = all_gather(mine);
+            if ((int)all.size() != size) throw Error(SALVA_HIP_E_INVALID, "peer transport: one handle per rank, in rank order");
+        } catch (...) {
+            salva_hip_comm_peer_abort(setup);
+            throw;
+        }
+        Comm c;
+        check(salva_hip_comm_peer_connect(setup, all[0].data(), &c.h_));  // consumes `setup`, also when it fails
+        c.rank_ = rank; c.size_ = size;
+        return c;
+    }
+    // in-process loopback for tests: drive each rank from its own host thread
+    static std::vector<Comm> loopback(int size) {
+        std::vector<SalvaHipComm*> hs((size_t)size, nullptr);
+        check(salva_hip_comm_loopback_create(size, hs.data()));
+        std::vector<Comm> out((size_t)size);
+        for (int r = 0; r < size; ++r) { out[r].h_ = hs[r]; out[r].rank_ = r; out[r].size_ = size; }
+        return out;
+    }
+    // collective checks of the transport itself: patterned exchanges + count exchange + both all-reduces; (us per exchange of
+    // `bytes` each way with both neighbours, us per four-float all-reduce)
+    void selftest(uint64_t max_bytes = 1u << 20, int rounds = 6) { check(salva_hip_comm_selftest(h_, max_bytes, rounds)); }
+    std::pair<float, float> time(uint64_t bytes = 64u << 10, int iters = 200) {
+        float a = 0, b = 0;
+        check(salva_hip_comm_time(h_, bytes, iters, &a, &b));
+        return {a, b};
+    }
+    int rank() const { return rank_; }
+    int size() const { return size_; }
+    SalvaHipComm* handle() const { return h_; }
+
+  private:
+    SalvaHipComm* h_ = nullptr;
+    int rank_ = 0, size_ = 1;
+};
+static_assert(sizeof(Comm::PeerHandle) == SALVA_HIP_PEER_HANDLE_BYTES, "handles are gathered as one contiguous block");
+
 using FluidHandle = size_t;     // dense index; remove_fluid is a swap-remove like ContiguousArena (contiguous_arena.rs)
 using BoundaryHandle = size_t;
 
@@ -316,8 +393,64 @@ class LiquidWorld {  // liquid_world.rs
         return c;
     }
 
+    // ---- x-slab decomposition (salva_hip_set_domain).  This world becomes the slab of cell planes
+    // [cell_lo, cell_hi] (cell = floor(x / h)) of a domain cut along x; call after adding this rank's fluids (the same
+    // fluid slots on every rank) and the boundary particles within three cells of its slab, before the first step.
+    // `gid_offset` + upload index is a particle's global id.  From then on Fluid::positions / velocities are no longer
+    // refreshed (particles migrate between ranks): read them with owned().
+    void set_domain(Comm& comm, int cell_lo, int cell_hi, uint32_t gid_offset = 0) {
+        for (size_t s = 0; s < fluids_.size(); ++s) upload(fluids_[s], (uint32_t)s);
+        for (size_t s = 0; s < boundaries_.size(); ++s) upload(boundaries_[s], (uint32_t)s);
+        check(salva_hip_set_domain(w_, comm.handle(), cell_lo, cell_hi, gid_offset));
+        decomposed_ = true;
+    }
+    struct OwnedParticles {
+        std::vector<uint32_t> gids, fluid_slots;
+        std::vector<Vec3> positions, velocities;
+    };
+    // the particles this rank owns after the last step, in no particular order
+    OwnedParticles owned() {
+        OwnedParticles o;
+        size_t cap = (size_t)stats_.nparticles + 1024;
+        for (;;) {
+            o.gids.resize(cap); o.fluid_slots.resize(cap); o.positions.resize(cap); o.velocities.resize(cap);
+            const int64_t m = salva_hip_get_owned(w_, (uint32_t)cap, o.gids.data(), o.positions[0].data(), o.velocities[0].data(),
+                                                  o.fluid_slots.data());
+            if (m < 0) check((int)m);
+            if ((size_t)m <= cap) { cap = (size_t)m; break; }
+            cap = (size_t)m;
+        }
+        o.gids.resize(cap); o.fluid_slots.resize(cap); o.positions.resize(cap); o.velocities.resize(cap);
+        return o;
+    }
+    // collective re-cut of the slabs for equal particle counts; returns this rank's new [cell_lo, cell_hi] (the caller
+    // re-uploads the boundary particles the new slab needs)
+    std::pair<int, int> rebalance() {
+        int32_t lo = 0, hi = 0;
+        check(salva_hip_rebalance(w_, &lo, &hi));
+        return {lo, hi};
+    }
+    // collective, between the same two steps on every rank (empty where there is nothing to do): particles appended to this
+    // rank get the next free global ids; the listed ids this rank owns are gone from the next step on (faucet3.rs:69-104)
+    void add_owned(FluidHandle h, const std::vector<Vec3>& positions, const std::vector<Vec3>* velocities = nullptr) {
+        if (velocities && velocities->size() != positions.size())
+            throw Error(SALVA_HIP_E_INVALID, "The provided positions and velocities arrays must have the same length.");
+        const bool any = !positions.empty();
+        check(salva_hip_add_particles(w_, (uint32_t)h, positions.size(), any ? positions[0].data() : nullptr,
+                                      any && velocities ? (*velocities)[0].data() : nullptr));
+    }
+    int64_t delete_owned(const std::vector<uint32_t>& gids) {
+        const int64_t m = salva_hip_delete_owned(w_, (uint32_t)gids.size(), gids.empty() ? nullptr : gids.data());
+        if (m < 0) check((int)m);
+        return m;
+    }
+
   private:
     void sync_for_query() {  // a query is not a step: objects are uploaded, pending deletions stay pending
+        if (decomposed_) {
+            for (size_t s = 0; s < boundaries_.size(); ++s) upload(boundaries_[s], (uint32_t)s);
+            return;
+        }
         for (size_t s = 0; s < fluids_.size(); ++s) upload(fluids_[s], (uint32_t)s);
         for (size_t s = 0; s < boundaries_.size(); ++s) upload(boundaries_[s], (uint32_t)s);
     }
@@ -339,6 +472,11 @@ class LiquidWorld {  // liquid_world.rs
   public:
     // LiquidWorld::step(dt, gravity) — liquid_world.rs:62-158
     void step(Real dt, const Vec3& gravity) {
+        if (decomposed_) {  // the particles live on the device and change owner: read them with owned()
+            for (size_t s = 0; s < boundaries_.size(); ++s) upload(boundaries_[s], (uint32_t)s);
+            check(salva_hip_step(w_, dt, gravity.data(), &stats_));
+            return;
+        }
         for (size_t s = 0; s < fluids_.size(); ++s) upload(fluids_[s], (uint32_t)s);
         for (size_t s = 0; s < boundaries_.size(); ++s) upload(boundaries_[s], (uint32_t)s);
         const int rc = salva_hip_step(w_, dt, gravity.data(), &stats_);
@@ -526,6 +664,7 @@ class LiquidWorld {  // liquid_world.rs
     std::vector<Fluid> fluids_;
     std::vector<Boundary> boundaries_;
     SalvaHipStepStats stats_{};
+    bool decomposed_ = false;  // set_domain was called: particles are read with owned(), fluids are not re-uploaded
 };
 
 // ColliderCouplingSet / ColliderCouplingManager (integrations/rapier/fluids_pipeline.rs:64-288) without the rapier types: each
