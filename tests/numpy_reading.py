@@ -4,7 +4,8 @@ a few hundred particles — written straight from the Rust, not from oracle/salv
   liquid_world.rs:62-158 (step order), timestep_manager.rs:36-95 (dt / inv_dt lag), geometry/contacts.rs:254-400 (contact
   criterion d^2 <= h^2, self contacts included, directed lists), kernel/cubic_spline_kernel.rs:12-79 + kernel/kernel.rs:13-24,
   solver/helper.rs:9-65, object/fluid.rs:105-115 (volume = 0.8 (2r)^3), solver/pressure/dfsph_solver.rs:72-708,
-  solver/pressure/iisph_solver.rs:92-711, solver/viscosity/xsph_viscosity.rs:31-95.
+  solver/pressure/iisph_solver.rs:92-711, solver/viscosity/xsph_viscosity.rs:31-95, solver/viscosity/artificial_viscosity.rs:41-135,
+  solver/surface_tension/akinci2013_surface_tension.rs:44-203, he2014_surface_tension.rs:41-182, wcsph_surface_tension.rs:30-92, solver/viscosity/dfsph_viscosity.rs:38-322.
 
 Purpose: the oracle and the HIP kernels were written by the same hand from the same source, so a shared
 misreading passes every GPU-vs-oracle test.  This file shares no code and no data structure with either (no grid, no contact
@@ -92,7 +93,8 @@ def pair_tables(xa, xb, h, kernel_density="cubic", kernel_gradient="cubic"):
 
 
 class DenseWorld:
-    """One fluid + one boundary (either may be empty), default interaction groups, optional XSPHViscosity."""
+    """One fluid + one boundary (either may be empty), default interaction groups, optional XSPHViscosity and any list of the
+    other built-in NonPressureForces (`add_force`)."""
 
     def __init__(self, particle_radius, smoothing_factor=2.0, solver="dfsph", kernel_density="cubic", kernel_gradient="cubic"):
         self.kernels = (kernel_density, kernel_gradient)
@@ -107,9 +109,10 @@ class DenseWorld:
         self.dt = 0.0      # TimestepManager::new: dt = inv_dt = 0 until the first advance()
         self.inv_dt = 0.0
         self.xsph = None
+        self.forces = []   # fluid.nonpressure_forces after the XSPH entry, in order: (kind, params...)
         self.x = np.zeros((0, 3)); self.v = np.zeros((0, 3)); self.a = np.zeros((0, 3)); self.vol = np.zeros(0)
         self.density0 = 1000.0
-        self.xb = np.zeros((0, 3)); self.vb = np.zeros((0, 3))
+        self.xb = np.zeros((0, 3)); self.vb = np.zeros((0, 3)); self.bforce = np.zeros((0, 3))
         self.dv = np.zeros((0, 3))   # solver.velocity_changes: persists across steps
         self.p = np.zeros(0)         # IISPH pressures: persist across steps
         self.trace = {}
@@ -127,9 +130,17 @@ class DenseWorld:
     def set_boundary(self, positions):
         self.xb = np.asarray(positions, np.float64).copy()
         self.vb = np.zeros_like(self.xb)
+        # boundary.forces (boundary.rs:59-67, `Some` buffer): accumulated by every apply_force until the caller clears it
+        self.bforce = np.zeros_like(self.xb)
 
     def set_xsph(self, fluid_coeff, boundary_coeff):
         self.xsph = (float(fluid_coeff), float(boundary_coeff))
+
+    def add_force(self, kind, *params):
+        """kind in "artificial" (fluid, boundary, alpha = 1, beta = 0, speed_of_sound = 10), "akinci2013" (tension, adhesion),
+        "he2014" (fluid tension, boundary tension), "dfsph_viscosity" (coefficient, min_iter, max_iter, max_error), "wcsph" (fluid tension; the boundary arm of the reference indexes the
+        boundary set with fluid contacts, wcsph_surface_tension.rs:69-88, and is left at 0)."""
+        self.forces.append((kind,) + tuple(float(p) for p in params))
 
     # ------------------------------------------------------------------------------------------------------------
     def step(self, dt, gravity=(0.0, -9.81, 0.0)):
@@ -156,17 +167,143 @@ class DenseWorld:
     def _forces(self, m, mb):
         """predict_advection after `acceleration += gravity`: XSPHViscosity::solve (xsph_viscosity.rs:31-95) with the
         timestep's CURRENT inv_dt — the previous step's, advance() comes afterwards."""
-        if self.xsph is None:
-            return
-        cf, cb = self.xsph
-        add = np.zeros_like(self.a)
+        if self.xsph is not None:
+            cf, cb = self.xsph
+            add = np.zeros_like(self.a)
+            if cf != 0.0:
+                coef = cf * self.wff * (m / self.rho)[None, :]     # c.weight * volumes[j] * density0 / densities[j]
+                add += (coef[:, :, None] * (self.v[None, :, :] - self.v[:, None, :])).sum(axis=1) * self.inv_dt
+            if cb != 0.0:
+                coef = cb * self.wfb * mb[None, :] / self.rho[:, None]
+                delta = coef[:, :, None] * (self.vb[None, :, :] - self.v[:, None, :])
+                add += delta.sum(axis=1) * self.inv_dt
+                self.bforce += (delta * (-m * self.inv_dt)[:, None, None]).sum(axis=0)   # xsph_viscosity.rs:87-88
+            self.a += add
+        for force in self.forces:
+            self.a += getattr(self, "_force_" + force[0])(m, mb, *force[1:])
+
+    # ---- the other built-in NonPressureForces, as dense pair expressions.  Self contacts are in the lists (contacts.rs) and
+    # contribute nothing: r_ij = 0 makes v.r = 0 (not < 0), the gradient 0 and the unit direction undefined (-> zero vector).
+    def _pairs(self, other_x):
+        d = self.x[:, None, :] - other_x[None, :, :]
+        r2 = (d * d).sum(axis=2)
+        return d, r2, np.sqrt(r2)
+
+    def _force_artificial(self, m, mb, cf, cb, alpha=1.0, beta=0.0, speed_of_sound=10.0):
+        """artificial_viscosity.rs:62-131 (Monaghan 1992): only approaching pairs (v_ij . r_ij < 0)."""
+        h, rho = self.h, self.rho
+        acc = np.zeros_like(self.a)
+        eta2 = h * h * 0.01
         if cf != 0.0:
-            coef = cf * self.wff * (m / self.rho)[None, :]     # c.weight * volumes[j] * density0 / densities[j]
-            add += (coef[:, :, None] * (self.v[None, :, :] - self.v[:, None, :])).sum(axis=1) * self.inv_dt
-        if cb != 0.0:
-            coef = cb * self.wfb * mb[None, :] / self.rho[:, None]
-            add += (coef[:, :, None] * (self.vb[None, :, :] - self.v[:, None, :])).sum(axis=1) * self.inv_dt
-        self.a += add
+            d, r2, _ = self._pairs(self.x)
+            vr = (d * (self.v[:, None, :] - self.v[None, :, :])).sum(axis=2)
+            mu = h * vr / (r2 + eta2)
+            pi_ij = cf * (speed_of_sound * alpha * mu - beta * mu * mu) * (m[None, :] / ((rho[:, None] + rho[None, :]) * 0.5))
+            acc += (self.gff * np.where(self.ff & (vr < 0.0), pi_ij, 0.0)[:, :, None]).sum(axis=1)
+        if cb != 0.0 and len(self.xb):
+            d, r2, _ = self._pairs(self.xb)
+            vr = (d * (self.v[:, None, :] - self.vb[None, :, :])).sum(axis=2)
+            mu = h * vr / (r2 + eta2)
+            pi_ib = cb * (speed_of_sound * alpha * mu - beta * mu * mu) * (mb[None, :] / rho[:, None])
+            acc += (self.gfb * np.where(self.fb & (vr < 0.0), pi_ib, 0.0)[:, :, None]).sum(axis=1)
+        return acc
+
+    def _force_akinci2013(self, m, mb, tension, adhesion):
+        """akinci2013_surface_tension.rs: normals (:44-71), cohesion / adhesion splines (:74-117), forces (:146-198)."""
+        h, rho, rho0 = self.h, self.rho, self.density0
+        acc = np.zeros_like(self.a)
+        if tension != 0.0:
+            normals = (self.gff * (m / rho)[None, :, None]).sum(axis=1) * h
+            d, _, r = self._pairs(self.x)
+            inner = 2.0 * (h - r) ** 3 * r ** 3 - h ** 6 / 64.0
+            outer = (h - r) ** 3 * r ** 3
+            coh = 32.0 / (np.pi * h ** 9) * np.where(r <= h / 2.0, inner, np.where(r <= h, outer, 0.0))
+            unit = np.where((r > EPS32)[:, :, None], d / np.where(r > EPS32, r, 1.0)[:, :, None], 0.0)  # Unit::try_new_and_get(dpos, eps)
+            cohesion = unit * (coh * (-tension) * m[None, :])[:, :, None]
+            curvature = (normals[:, None, :] - normals[None, :, :]) * (-tension)
+            kij = 2.0 * rho0 / (rho[:, None] + rho[None, :])
+            acc += ((curvature + cohesion) * np.where(self.ff, kij, 0.0)[:, :, None]).sum(axis=1)
+        if adhesion != 0.0 and len(self.xb):
+            d, _, r = self._pairs(self.xb)
+            inside = (r > h / 2.0) & (r <= h)
+            poly = np.maximum(-4.0 * r * r / h + 6.0 * r - 2.0 * h, 0.0)
+            adh = np.where(inside, 0.007 / h ** 3.25 * poly ** 0.25, 0.0)
+            unit = np.where((r > EPS32)[:, :, None], d / np.where(r > EPS32, r, 1.0)[:, :, None], 0.0)
+            adhesion_acc = unit * np.where(self.fb, adh * adhesion * mb[None, :], 0.0)[:, :, None]
+            acc -= adhesion_acc.sum(axis=1)
+            self.bforce += (adhesion_acc * m[:, None, None]).sum(axis=0)                 # :187-188
+        return acc
+
+    def _force_he2014(self, m, mb, tension, boundary_tension):
+        """he2014_surface_tension.rs: colour field (:41-78, boundary volumes enter unweighted by a density), squared norm of its
+        normalised gradient (:80-108), forces (:137-176)."""
+        rho, rho0 = self.rho, self.density0
+        volf = m / rho
+        colors = self.wff @ volf + (self.wfb @ self.volb if len(self.xb) else 0.0)
+        gradc = (self.gff * (colors * volf)[None, :, None]).sum(axis=1) / colors[:, None]
+        gsq = (gradc * gradc).sum(axis=1)
+        acc = np.zeros_like(self.a)
+        if tension != 0.0:
+            f = volf[:, None] * volf[None, :] * (gsq[:, None] + gsq[None, :]) / 2.0
+            acc += (self.gff * f[:, :, None]).sum(axis=1) * (tension / (2.0 * m))[:, None]
+        if boundary_tension != 0.0 and len(self.xb):
+            f = self.gfb * (volf[:, None] * (mb / rho0)[None, :] * gsq[:, None] * boundary_tension * 0.25)[:, :, None]
+            acc += f.sum(axis=1) / m[:, None]
+            self.bforce -= f.sum(axis=0)                                                 # :176
+        return acc
+
+    def _force_dfsph_viscosity(self, m, mb, coefficient, min_iter=1.0, max_iter=50.0, max_error=0.01):
+        """dfsph_viscosity.rs: betas (:130-196, with the preconditioner that scales the FIRST THREE columns only, :166-168 and
+        :191-194), target strain rates (:198-246, once), then the error / acceleration loop (:297-322).  `timestep.dt()` and
+        `inv_dt()` are the previous step's here too (predict_advection runs before advance)."""
+        rho = self.rho
+        n = len(self.x)
+        g = self.gff                                            # zero outside the contact mask and on the diagonal
+        z = np.zeros_like(g[:, :, 0])
+        # compute_gradient_matrix: 6 x 3 per pair
+        G = np.stack([np.stack([2.0 * g[:, :, 0], z, z], axis=-1), np.stack([z, 2.0 * g[:, :, 1], z], axis=-1),
+                      np.stack([z, z, 2.0 * g[:, :, 2]], axis=-1), np.stack([g[:, :, 1], g[:, :, 0], z], axis=-1),
+                      np.stack([g[:, :, 2], z, g[:, :, 0]], axis=-1), np.stack([z, g[:, :, 2], g[:, :, 1]], axis=-1)], axis=-2)
+        half = (m[None, :] / (2.0 * rho[:, None]))              # particle_mass(j) / (2 densities[i])
+        Gi = G * half[:, :, None, None]
+        squared = np.einsum("ijab,ijcb->iac", Gi, Gi) / rho[:, None, None]
+        gsum = Gi.sum(axis=1)
+        den = squared + np.einsum("iab,icb->iac", gsum, gsum) / rho[:, None, None]
+        diag = np.einsum("iaa->ia", den)
+        inv_diag = np.where(np.abs(diag) < 1.0e-6, 1.0, 1.0 / np.where(np.abs(diag) < 1.0e-6, 1.0, diag))
+        den = den.copy()
+        den[:, :, :3] *= inv_diag[:, :, None]                   # column_mut(c).component_mul_assign(&inv_diag), c < SPATIAL_DIM
+        det = np.linalg.det(den)
+        ok = np.abs(det) >= 1.0e-6
+        betas = np.zeros_like(den)
+        betas[ok] = np.linalg.inv(den[ok])
+        betas[:, :, :3] *= inv_diag[:, None, :3]                # column c scaled by inv_diag[c], c < SPATIAL_DIM
+        self.visc_betas = betas
+
+        def rates(acc):
+            v = self.v + acc * self.dt
+            vji = v[None, :, :] - v[:, None, :]
+            return np.einsum("ijab,ijb->ia", Gi, vji)
+
+        a = self.a.copy()
+        target = rates(a) * (1.0 - coefficient)
+        self.visc_iters = 0
+        for i in range(int(max_iter)):
+            error = rates(a) - target
+            avg = float(np.abs(error).sum() / 6.0 / n) if n else 0.0
+            self.visc_err = avg
+            if avg <= max_error and i >= int(min_iter):
+                break
+            u = np.einsum("iab,ib->ia", betas, error) / (rho * rho)[:, None]
+            coeff = (u[:, None, :] + u[None, :, :]) * (m[None, :] / 2.0)[:, :, None]
+            a = a + np.einsum("ijab,ija->ib", G, coeff) * (m * self.inv_dt)[:, None]
+            self.visc_iters += 1
+        return a - self.a
+
+    def _force_wcsph(self, m, mb, tension):
+        """wcsph_surface_tension.rs:46-66: a weight-proportional attraction along r_ij."""
+        d, _, _ = self._pairs(self.x)
+        return (d * (self.wff * (-tension) * m[None, :] / m[:, None])[:, :, None]).sum(axis=1)
 
     def _advance(self, dt):
         self.dt = dt
@@ -197,7 +334,10 @@ class DenseWorld:
                 break
             k = div * self.alpha
             kij = k[:, None] + k[None, :]
-            self.dv = self.dv + (self.gff * (-(kij) * m[None, :])[:, :, None]).sum(axis=1) + (self.gfb * (-k[:, None] * mb[None, :])[:, :, None]).sum(axis=1)
+            delta_b = self.gfb * (-k[:, None] * mb[None, :])[:, :, None]
+            self.dv = self.dv + (self.gff * (-(kij) * m[None, :])[:, :, None]).sum(axis=1) + delta_b.sum(axis=1)
+            if len(self.xb):
+                self.bforce += (delta_b * (-self.inv_dt * m)[:, None, None]).sum(axis=0)  # :403-405, the lagged inv_dt
             self.n_div += 1
         # update_velocities + zero (:689-691)
         self.v = self.v + self.dv
@@ -227,7 +367,10 @@ class DenseWorld:
             kij = kp[:, None] + kp[None, :]
             self.dv = self.dv - (self.gff * (kij * m[None, :] * self.inv_dt)[:, :, None]).sum(axis=1)
             coeff = np.where(k > 0.0, k, 0.0)[:, None] * mb[None, :] * self.inv_dt
-            self.dv = self.dv - (self.gfb * coeff[:, :, None]).sum(axis=1)
+            delta_b = self.gfb * coeff[:, :, None]
+            self.dv = self.dv - delta_b.sum(axis=1)
+            if len(self.xb):
+                self.bforce += (delta_b * (self.inv_dt * m)[:, None, None]).sum(axis=0)   # :264-272
             self.n_press += 1
         # update_positions (:411-420): velocities are NOT updated here
         self.x = self.x + (self.v + self.dv) * self.dt
@@ -285,7 +428,10 @@ class DenseWorld:
         pr = self.p / (rho * rho)
         cij = self.dt * m[None, :] * (pr[:, None] + pr[None, :])
         self.dv = self.dv - (self.gff * cij[:, :, None]).sum(axis=1)
-        self.dv = self.dv - (self.gfb * (mb[None, :] * pr[:, None])[:, :, None]).sum(axis=1) * self.dt
+        acc_b = self.gfb * (mb[None, :] * pr[:, None])[:, :, None]
+        self.dv = self.dv - acc_b.sum(axis=1) * self.dt
+        if len(self.xb):
+            self.bforce += (acc_b * m[:, None, None]).sum(axis=0)                         # :394-400
         # update_velocities_and_positions (:406-420) + zero
         self.v = self.v + self.dv
         self.x = self.x + self.v * self.dt

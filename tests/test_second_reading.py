@@ -56,7 +56,7 @@ def test_dfsph_step_by_step(xsph, caps):
     f = o.add_fluid(pos, 1000.0, vel)
     if xsph:
         o.add_xsph(f, *xsph)
-    o.add_boundary(bpos)
+    b = o.add_boundary(bpos, wants_forces=True)
     d = DenseWorld(R32, 2.0, "dfsph")
     d.set_fluid(pos, 1000.0, vel)
     d.set_boundary(bpos)
@@ -76,6 +76,9 @@ def test_dfsph_step_by_step(xsph, caps):
         for name, mine in [("velocity_changes", d.dv), ("velocities", d.v), ("positions", d.x)]:
             assert rel(o.fluid_vec(f, name), mine) < tol, f"step {k}: {name}"
         assert rel(o.boundary_volumes(0), d.volb) < 1e-12
+        # boundary.forces: what the divergence and pressure applies and the XSPH boundary arm handed to the boundary particles
+        # (apply_force), accumulated over the steps so far (nobody clears them here)
+        assert np.abs(d.bforce).max() > 0 and rel(o.boundary_vec(b, "forces"), d.bforce) < 10 * tol, f"step {k}: boundary forces"
         assert abs(so.div_error - d.div_err) <= 10 * tol * max(abs(d.div_err), 1e-3) and abs(so.density_error - d.press_err) <= tol * max(abs(d.press_err), 1e-6)
     assert max(i[0] for i in iters) >= 2 and min(i[1] for i in iters) >= 1, f"the solves were meant to iterate: {iters}"
     if caps[0] == 50:
@@ -87,7 +90,7 @@ def test_iisph_step_by_step():
     o = O.OracleWorld(R, 2.0, O.IISPH, f64=True)
     f = o.add_fluid(pos, 1000.0, vel)
     o.add_xsph(f, 0.2, 0.1)
-    o.add_boundary(bpos)
+    b = o.add_boundary(bpos, wants_forces=True)
     d = DenseWorld(R32, 2.0, "iisph")
     d.set_fluid(pos, 1000.0, vel)
     d.set_boundary(bpos)
@@ -103,6 +106,7 @@ def test_iisph_step_by_step():
             assert rel(o.fluid_scalar(f, name), mine) < 1e-7, f"step {k}: {name}"
         for name, mine in [("dii", d.dii), ("dij_pjl", d.dijpj), ("velocities", d.v), ("positions", d.x)]:
             assert rel(o.fluid_vec(f, name), mine) < 1e-7, f"step {k}: {name}"
+        assert np.abs(d.bforce).max() > 0 and rel(o.boundary_vec(b, "forces"), d.bforce) < 1e-6, f"step {k}: boundary forces"
     assert max(iters) >= 3, f"the pressure solve was meant to iterate: {iters}"
 
 
@@ -159,3 +163,119 @@ def test_other_kernels_step_by_step(solver, kd, kg):
         for name, mine in [("velocities", d.v), ("positions", d.x)]:
             assert rel(o.fluid_vec(f, name), mine) < 1e-7, f"step {k}: {name}"
         assert rel(o.boundary_volumes(0), d.volb) < 1e-12
+
+
+def f32(x):
+    return float(np.float32(x))  # force parameters cross the oracle's C interface as f32
+
+
+FORCE_CASES = {
+    # name: (oracle call, numpy_reading kind, parameters)
+    "artificial": (lambda o, f: o.add_artificial_viscosity(f, 0.8, 0.4, alpha=1.0, beta=0.5, speed_of_sound=10.0),
+                   ("artificial", f32(0.8), f32(0.4), 1.0, 0.5, 10.0)),
+    "akinci2013": (lambda o, f: o.add_akinci2013(f, 0.7, 2.0), ("akinci2013", f32(0.7), 2.0)),
+    "he2014": (lambda o, f: o.add_he2014(f, 0.4, 0.6), ("he2014", f32(0.4), f32(0.6))),
+    "wcsph": (lambda o, f: o.add_wcsph_tension(f, 50.0, 0.0), ("wcsph", 50.0)),
+}
+
+
+@pytest.mark.parametrize("solver", ["dfsph", "iisph"])
+@pytest.mark.parametrize("force", sorted(FORCE_CASES))
+def test_nonpressure_forces_step_by_step(solver, force):
+    """ArtificialViscosity, Akinci2013SurfaceTension, He2014SurfaceTension and WCSPHSurfaceTension (fluid arm) as dense pair
+    expressions (numpy_reading.DenseWorld._force_*) against the oracle's per-contact loops, through both solvers: the force
+    enters the accelerations, so velocities, positions, densities and iteration counts of the following steps all carry it.
+    The floor and the wall of the scene give the boundary arms (viscosity against the wall, adhesion, the boundary term of the
+    colour field) something to act on."""
+    pos, vel, bpos = make_scene(seed=9, n=6)
+    add, spec = FORCE_CASES[force]
+    o = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH, f64=True)
+    o.set_solver_params(max_divergence_iter=4, max_pressure_iter=6)
+    f = o.add_fluid(pos, 1000.0, vel)
+    add(o, f)
+    b = o.add_boundary(bpos, wants_forces=True)
+    d = DenseWorld(R32, 2.0, solver)
+    d.max_divergence_iter, d.max_pressure_iter = 4, 6
+    d.set_fluid(pos, 1000.0, vel)
+    d.set_boundary(bpos)
+    d.add_force(*spec)
+    # what the force alone does to the first step: compare with a force-free twin to make sure the case is not vacuous
+    twin = DenseWorld(R32, 2.0, solver)
+    twin.max_divergence_iter, twin.max_pressure_iter = 4, 6
+    twin.set_fluid(pos, 1000.0, vel)
+    twin.set_boundary(bpos)
+    for k in range(6):
+        so = o.step(DT, G)
+        d.step(DT32, G32)
+        if k == 0:
+            twin.step(DT32, G32)
+            assert np.abs(d.x - twin.x).max() > 1e-7 * d.h, "the force did nothing"
+        assert int(so.ncontacts) == d.ncontacts, f"step {k}: contacts"
+        if solver == "dfsph":
+            assert (so.n_div_iters, so.n_press_iters) == (d.n_div, d.n_press), f"step {k}: iterations"
+        else:
+            assert so.n_press_iters == d.n_press, f"step {k}: iterations"
+        for name, mine in [("velocities", d.v), ("positions", d.x)]:
+            assert rel(o.fluid_vec(f, name), mine) < 1e-7, f"step {k}: {name} ({rel(o.fluid_vec(f, name), mine):.2e})"
+        assert rel(o.fluid_scalar(f, "densities"), d.rho) < 1e-7, f"step {k}: densities"
+        # boundary.forces (the reactions of the pressure solve + of this force's boundary arm).  Not for ArtificialViscosity: its
+        # boundary arm hands each boundary particle the RUNNING sum over the contact list (artificial_viscosity.rs:110-117 applies
+        # `boundary_acc`, not this contact's term), which depends on the list order a dense formulation does not have
+        if force != "artificial":
+            assert rel(o.boundary_vec(b, "forces"), d.bforce) < 1e-6, f"step {k}: boundary forces ({rel(o.boundary_vec(b, 'forces'), d.bforce):.2e})"
+
+
+@pytest.mark.parametrize("max_iter", [3, 50])
+def test_dfsph_viscosity_step_by_step(max_iter):
+    """DFSPHViscosity (dfsph_viscosity.rs) on a slightly perturbed sheared block: the 6 x 6 beta matrices with the reference's
+    three-column preconditioner, the strain-rate error the loop ends on, its iteration count, and the state that results — two
+    readings of an iteration that amplifies differences, agreeing to 1e-12."""
+    pos = scenes.jitter(scenes.cube_fluid_positions(7, 7, 7, R), 0.02 * R, seed=42).astype(np.float32)
+    vel = scenes.random_velocities(len(pos), 0.01, seed=12345).astype(np.float32)
+    vel[:, 0] += np.float32(2.0) * pos[:, 1]
+    o = O.OracleWorld(R, 2.0, O.DFSPH, f64=True)
+    o.set_solver_params(max_divergence_iter=4, max_pressure_iter=6)
+    f = o.add_fluid(pos, 1000.0, vel)
+    o.add_dfsph_viscosity(f, 0.6, 1, max_iter, 0.01)
+    d = DenseWorld(R32, 2.0, "dfsph")
+    d.max_divergence_iter, d.max_pressure_iter = 4, 6
+    d.set_fluid(pos, 1000.0, vel)
+    d.add_force("dfsph_viscosity", f32(0.6), 1, max_iter, f32(0.01))
+    for k in range(6):
+        so = o.step(DT, G)
+        d.step(DT32, G32)
+        it, err = o.viscosity_stats(f)
+        assert it == d.visc_iters and (so.n_div_iters, so.n_press_iters) == (d.n_div, d.n_press), f"step {k}: iterations"
+        assert abs(err - d.visc_err) <= 1e-10 * max(d.visc_err, 1e-3), f"step {k}: strain-rate error {err} vs {d.visc_err}"
+        assert rel(o.viscosity_betas(f), d.visc_betas) < 1e-11, f"step {k}: betas"
+        for name, mine in [("velocities", d.v), ("positions", d.x)]:
+            assert rel(o.fluid_vec(f, name), mine) < 1e-11, f"step {k}: {name}"
+    assert d.visc_err > 1e-3, "the viscosity loop was meant to have work"
+
+
+def test_dfsph_viscosity_diverges_in_both_readings():
+    """On a lattice jittered by 0.15 r the reference's viscosity loop does not converge but EXPLODES (tests/golden_scenes.py
+    scene_dfsph_viscous has the story: the preconditioner touches three of the six columns).  That is a property of the Rust as
+    written, so an independent reading must show it too: both readings reach the same astronomically large strain-rate error
+    (> 1e60) within two steps, agreeing to six digits."""
+    pos, vel, bpos = make_scene(seed=9, n=6)
+    o = O.OracleWorld(R, 2.0, O.DFSPH, f64=True)
+    o.set_solver_params(max_divergence_iter=4, max_pressure_iter=6)
+    f = o.add_fluid(pos, 1000.0, vel)
+    o.add_dfsph_viscosity(f, 0.5, 1, 50, 0.01)
+    o.add_boundary(bpos)
+    d = DenseWorld(R32, 2.0, "dfsph")
+    d.max_divergence_iter, d.max_pressure_iter = 4, 6
+    d.set_fluid(pos, 1000.0, vel)
+    d.set_boundary(bpos)
+    d.add_force("dfsph_viscosity", 0.5, 1, 50, f32(0.01))
+    worst = 0.0
+    for k in range(2):
+        o.step(DT, G)
+        d.step(DT32, G32)
+        it, err = o.viscosity_stats(f)
+        assert it == d.visc_iters == 50
+        assert abs(err - d.visc_err) <= 1e-6 * d.visc_err, f"step {k}: {err} vs {d.visc_err}"
+        assert rel(o.viscosity_betas(f), d.visc_betas) < 1e-10
+        worst = max(worst, d.visc_err)
+    assert worst > 1e60
