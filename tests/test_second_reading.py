@@ -279,3 +279,71 @@ def test_dfsph_viscosity_diverges_in_both_readings():
         assert rel(o.viscosity_betas(f), d.visc_betas) < 1e-10
         worst = max(worst, d.visc_err)
     assert worst > 1e60
+
+
+@pytest.mark.parametrize("solver", ["dfsph", "iisph"])
+def test_two_fluids_and_interaction_groups_step_by_step(solver):
+    """BASELINE config 4's ingredients in small: two fluids of different density0 in contact (a light block resting on a heavy
+    one), each with its own force list, two boundaries, and InteractionGroups that hide the wall from the light fluid.  What the
+    multi-object rules of the Rust decide — whose density0 weighs a boundary particle (`fluid_i.density0`), which fluid arms skip
+    foreign contacts (`c.i_model == c.j_model`), the per-fluid error averages and their maximum, which pairs exist at all
+    (contacts.rs:277-359) — read twice."""
+    n = 5
+    d = 2 * R
+    lower = (scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.12 * R, 21) * 0.9).astype(np.float32)
+    upper = (scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.12 * R, 22) * 0.9).astype(np.float32)
+    upper[:, 1] += np.float32(lower[:, 1].max() - upper[:, 1].min() + 0.9 * d)
+    v_lower = scenes.random_velocities(len(lower), 0.5, 23).astype(np.float32)
+    v_upper = scenes.random_velocities(len(upper), 0.5, 24).astype(np.float32)
+    v_upper[:, 1] -= 0.5
+    lo = lower.min(axis=0)
+    gx, gz = np.meshgrid(np.arange(-2, n + 2), np.arange(-2, n + 2), indexing="ij")
+    floor = np.stack([lo[0] + gx.ravel() * d, np.full(gx.size, lo[1] - d), lo[2] + gz.ravel() * d], axis=1).astype(np.float32)
+    gy, gz2 = np.meshgrid(np.arange(0, 2 * n + 1), np.arange(0, n), indexing="ij")
+    wall = np.stack([np.full(gy.size, lo[0] - d), lo[1] + gy.ravel() * d, lo[2] + gz2.ravel() * d], axis=1).astype(np.float32)
+    # groups: lower fluid 0b01, upper fluid 0b10 (both see everything that lets them); the wall only lets group 0b01 in
+    G_LOWER, G_UPPER, G_FLOOR, G_WALL = (1, 0xFFFFFFFF), (2, 0xFFFFFFFF), (1, 0xFFFFFFFF), (1, 1)
+
+    o = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH, f64=True)
+    o.set_solver_params(max_divergence_iter=5, max_pressure_iter=8)
+    f0 = o.add_fluid(lower, 1000.0, v_lower, memberships=G_LOWER[0], filter=G_LOWER[1])
+    f1 = o.add_fluid(upper, 500.0, v_upper, memberships=G_UPPER[0], filter=G_UPPER[1])
+    o.add_xsph(f0, 0.5, 0.2)
+    o.add_akinci2013(f0, 0.6, 1.5)
+    o.add_xsph(f1, 0.3, 0.4)
+    o.add_he2014(f1, 0.5, 0.3)
+    b0 = o.add_boundary(floor, memberships=G_FLOOR[0], filter=G_FLOOR[1], wants_forces=True)
+    b1 = o.add_boundary(wall, memberships=G_WALL[0], filter=G_WALL[1], wants_forces=True)
+
+    w = DenseWorld(R32, 2.0, solver)
+    w.max_divergence_iter, w.max_pressure_iter = 5, 8
+    w.add_fluid(lower, 1000.0, v_lower, *G_LOWER)
+    w.add_fluid(upper, 500.0, v_upper, *G_UPPER)
+    w.set_xsph(f32(0.5), f32(0.2), fluid=0)
+    w.add_force("akinci2013", f32(0.6), 1.5, fluid=0)
+    w.set_xsph(f32(0.3), f32(0.4), fluid=1)
+    w.add_force("he2014", 0.5, f32(0.3), fluid=1)
+    w.add_boundary(floor, *G_FLOOR)
+    w.add_boundary(wall, *G_WALL)
+    r0, r1 = w.fluid_rows(0), w.fluid_rows(1)
+    for k in range(6):
+        so = o.step(DT, G)
+        w.step(DT32, G32)
+        if k == 0:
+            # the scene does what it is for: the two fluids touch, the lower one touches the wall, the upper one is within reach
+            # of it but has no contact with it
+            assert w.ff[r0][:, r1].any() and w.fb[r0][:, w.bmodel == 1].any() and not w.fb[r1][:, w.bmodel == 1].any()
+            reach = ((upper[:, None, :].astype(np.float64) - wall[None, :, :]) ** 2).sum(axis=2) <= w.h ** 2
+            assert reach.any()
+        assert int(so.ncontacts) == w.ncontacts, f"step {k}: contacts {so.ncontacts} vs {w.ncontacts}"
+        if solver == "dfsph":
+            assert (so.n_div_iters, so.n_press_iters) == (w.n_div, w.n_press), f"step {k}: iterations"
+        else:
+            assert so.n_press_iters == w.n_press, f"step {k}: iterations"
+        for fid, rows in ((f0, r0), (f1, r1)):
+            assert rel(o.fluid_scalar(fid, "densities"), w.rho[rows]) < 1e-7, f"step {k}: densities of fluid {fid}"
+            for name, mine in [("velocities", w.v), ("positions", w.x)]:
+                assert rel(o.fluid_vec(fid, name), mine[rows]) < 1e-7, f"step {k}: {name} of fluid {fid}"
+        for bid in (b0, b1):
+            assert rel(o.boundary_volumes(bid), w.volb[w.bmodel == bid]) < 1e-12
+            assert rel(o.boundary_vec(bid, "forces"), w.bforce[w.bmodel == bid]) < 1e-6, f"step {k}: forces on boundary {bid}"
