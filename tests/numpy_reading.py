@@ -122,6 +122,7 @@ class DenseWorld:
         self.rho0 = np.zeros(0)                  # its fluid's density0
         self.groups = np.zeros((0, 2), np.uint64)  # its fluid's (memberships, filter)
         self.nfluids = 0
+        self.deleted = np.zeros(0, bool)           # delete_particle_at_next_timestep marks
         self.dv = np.zeros((0, 3))   # solver.velocity_changes: persists across steps
         self.p = np.zeros(0)         # IISPH pressures: persist across steps
 
@@ -143,6 +144,7 @@ class DenseWorld:
         self.rho0 = np.concatenate([self.rho0, np.full(n, float(density0))])
         self.groups = np.concatenate([self.groups, np.tile(np.array([[memberships, filter]], np.uint64), (n, 1))])
         self.dv = np.concatenate([self.dv, np.zeros((n, 3))]); self.p = np.concatenate([self.p, np.zeros(n)])
+        self.deleted = np.concatenate([self.deleted, np.zeros(n, bool)])
         self.nfluids += 1
         return self.nfluids - 1
 
@@ -154,6 +156,37 @@ class DenseWorld:
         self.bgroups = np.concatenate([self.bgroups, np.tile(np.array([[memberships, filter]], np.uint64), (len(xb), 1))])
         self.nboundaries += 1
         return self.nboundaries - 1
+
+    def add_particles(self, fluid, positions, velocities=None):
+        """Fluid::add_particles (fluid.rs:126-150): appended with default volume and zero acceleration; the solver's per-particle
+        buffers grow with zeros at the next step's init_with_fluids (dfsph_solver.rs:526-547: `resize(n, zero)`) — a new particle
+        starts with no velocity change and no IISPH pressure."""
+        x = np.asarray(positions, np.float64).reshape(-1, 3)
+        n = len(x)
+        rows = np.nonzero(self.model == fluid)[0]
+        if len(rows) == 0:
+            raise ValueError("add_particles: the fluid needs at least one particle to copy its density0 / groups from")
+        v = np.zeros((n, 3)) if velocities is None else np.asarray(velocities, np.float64).reshape(-1, 3)
+        self.x = np.concatenate([self.x, x]); self.v = np.concatenate([self.v, v]); self.a = np.concatenate([self.a, np.zeros((n, 3))])
+        self.vol = np.concatenate([self.vol, np.full(n, self.r ** 3 * 8.0 * 0.8)])
+        self.model = np.concatenate([self.model, np.full(n, fluid, np.int64)])
+        self.rho0 = np.concatenate([self.rho0, np.full(n, self.rho0[rows[0]])])
+        self.groups = np.concatenate([self.groups, np.tile(self.groups[rows[0]][None, :], (n, 1))])
+        self.dv = np.concatenate([self.dv, np.zeros((n, 3))]); self.p = np.concatenate([self.p, np.zeros(n)])
+        self.deleted = np.concatenate([self.deleted, np.zeros(n, bool)])
+
+    def delete_particle_at_next_timestep(self, fluid, i):
+        """fluid.rs:71-86: marked now, gone at the top of the next step — from the fluid (apply_particles_removal, :88-98) and
+        from the solver's buffers (filter_from_mask with the same mask, dfsph_solver.rs:549-560, iisph_solver.rs:502-536); the
+        survivors keep their order."""
+        self.deleted[np.nonzero(self.model == fluid)[0][i]] = True
+
+    def _apply_removal(self):
+        if self.deleted.any():
+            keep = ~self.deleted
+            for name in ("x", "v", "a", "vol", "model", "rho0", "groups", "dv", "p"):
+                setattr(self, name, getattr(self, name)[keep])
+            self.deleted = np.zeros(int(keep.sum()), bool)
 
     def set_fluid(self, positions, density0=1000.0, velocities=None):
         self._reset_fluids()
@@ -196,6 +229,7 @@ class DenseWorld:
     # ------------------------------------------------------------------------------------------------------------
     def step(self, dt, gravity=(0.0, -9.81, 0.0)):
         g = np.asarray(gravity, np.float64)
+        self._apply_removal()   # liquid_world.rs:76-80: before the substep loop, so also when the loop does not run
         if dt <= EPS32:  # timestep_manager.is_done() before the first substep
             return
         h = self.h

@@ -347,3 +347,54 @@ def test_two_fluids_and_interaction_groups_step_by_step(solver):
         for bid in (b0, b1):
             assert rel(o.boundary_volumes(bid), w.volb[w.bmodel == bid]) < 1e-12
             assert rel(o.boundary_vec(bid, "forces"), w.bforce[w.bmodel == bid]) < 1e-6, f"step {k}: forces on boundary {bid}"
+
+
+@pytest.mark.parametrize("solver", ["dfsph", "iisph"])
+def test_particles_added_and_deleted_between_steps(solver):
+    """The emitter / sink life cycle of examples3d/faucet3.rs:69-104 read twice: `Fluid::add_particles` between steps (the new
+    particles enter the solver with zero velocity change and zero IISPH pressure, the old ones keep theirs),
+    `delete_particle_at_next_timestep` (gone from the fluid AND from the solver's warm-start buffers at the top of the next step,
+    survivors in order) — including a particle that is added and deleted before it ever takes part in a step."""
+    pos, vel, bpos = make_scene(seed=13, n=5)
+    o = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH, f64=True)
+    o.set_solver_params(max_divergence_iter=4, max_pressure_iter=6)
+    f = o.add_fluid(pos, 1000.0, vel)
+    o.add_xsph(f, 0.4, 0.1)
+    o.add_boundary(bpos)
+    w = DenseWorld(R32, 2.0, solver)
+    w.max_divergence_iter, w.max_pressure_iter = 4, 6
+    w.set_fluid(pos, 1000.0, vel)
+    w.set_xsph(f32(0.4), f32(0.1))
+    w.set_boundary(bpos)
+    rng = np.random.default_rng(5)
+    top = float(pos[:, 1].max())
+    counts = []
+    for k in range(9):
+        if k in (2, 4, 5):  # a sheet of new particles just above the block, moving down
+            d = 2 * R
+            gx, gz = np.meshgrid(np.arange(4), np.arange(4), indexing="ij")
+            sheet = np.stack([pos[:, 0].min() + gx.ravel() * d, np.full(gx.size, top + (1.0 + 0.3 * k) * d), pos[:, 2].min() + gz.ravel() * d],
+                             axis=1).astype(np.float32)
+            sv = np.tile(np.array([[0.1, -1.0, 0.0]], np.float32), (len(sheet), 1))
+            o.add_particles(f, sheet, sv)
+            w.add_particles(0, sheet, sv)
+        if k in (3, 5, 6):  # delete a random handful, by index into the current host order
+            n_now = o.fluid_len(f)
+            assert n_now == int((w.model == 0).sum())
+            for i in sorted(set(int(x) for x in rng.integers(0, n_now, size=7))):
+                o.delete_particle_at_next_timestep(f, i)
+                w.delete_particle_at_next_timestep(0, i)
+            if k == 5:  # one of the particles added a moment ago, never stepped
+                o.delete_particle_at_next_timestep(f, n_now - 3)
+                w.delete_particle_at_next_timestep(0, n_now - 3)
+        so = o.step(DT, G)
+        w.step(DT32, G32)
+        counts.append(o.fluid_len(f))
+        assert o.fluid_len(f) == len(w.x), f"step {k}: {o.fluid_len(f)} vs {len(w.x)} particles"
+        assert int(so.ncontacts) == w.ncontacts, f"step {k}: contacts"
+        for name, mine in [("velocities", w.v), ("positions", w.x)]:
+            assert rel(o.fluid_vec(f, name), mine) < 1e-7, f"step {k}: {name} ({rel(o.fluid_vec(f, name), mine):.2e})"
+        assert rel(o.fluid_scalar(f, "densities"), w.rho) < 1e-7, f"step {k}: densities"
+        if solver == "iisph":
+            assert rel(o.fluid_scalar(f, "pressures"), w.p) < 1e-7, f"step {k}: pressures (the next step's warm start)"
+    assert len(set(counts)) >= 5, f"the particle count was meant to change: {counts}"
