@@ -7,6 +7,12 @@ a few hundred particles — written straight from the Rust, not from oracle/salv
   solver/pressure/iisph_solver.rs:92-711, solver/viscosity/xsph_viscosity.rs:31-95, solver/viscosity/artificial_viscosity.rs:41-135,
   solver/surface_tension/akinci2013_surface_tension.rs:44-203, he2014_surface_tension.rs:41-182, wcsph_surface_tension.rs:30-92, solver/viscosity/dfsph_viscosity.rs:38-322.
 
+Covered (tests/test_second_reading.py): both pressure solvers pass by pass; the four SPH kernels; XSPH, artificial viscosity,
+Akinci2013 / He2014 / WCSPH surface tension and DFSPHViscosity (including the divergence of its loop); boundary volumes and the
+reaction forces handed to boundary particles; several fluids and boundaries with InteractionGroups; particles added and deleted
+between steps.  Not covered: DynamicContactSampling (its own numpy geometry in tests/test_oracle.py) and the rigid-body pose /
+wrench arithmetic (tests/test_oracle.py::test_coupling_pose_velocity_and_wrench).
+
 Purpose: the oracle and the HIP kernels were written by the same hand from the same source, so a shared
 misreading passes every GPU-vs-oracle test.  This file shares no code and no data structure with either (no grid, no contact
 lists, no per-pass loops over contacts: every pass is a masked dense matrix expression), and tests/test_second_reading.py
