@@ -203,6 +203,10 @@ class DenseWorld:
                 setattr(self, name, getattr(self, name)[keep])
             self.deleted = np.zeros(int(keep.sum()), bool)
 
+    def set_fluid_volumes(self, fluid, volumes):
+        """`fluid.volumes` is a pub field (fluid.rs:24): scenes may override the default."""
+        self.vol[self.model == fluid] = np.asarray(volumes, np.float64)
+
     def set_fluid(self, positions, density0=1000.0, velocities=None):
         self._reset_fluids()
         self.add_fluid(positions, density0, velocities)
