@@ -119,3 +119,81 @@ def test_two_rank_protocol_gloo(oracle_lib):
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     assert "OK 0" in p.stdout and "OK 1" in p.stdout
+
+
+def test_peer_transport_protocol_model():
+    """The ordering argument of salva_amd/csrc/comm_peer.hip, as a model: every rank runs the same sequence of operations in order
+    on one stream — an exchange is put (write my message into the neighbour's slot of parity seq & 1, then raise its flag to seq)
+    followed by get (wait for my flags >= seq, read my slots of that parity); an all-reduce writes my row of parity seq & 1 into
+    every rank's mailbox, raises my flag there, waits for all flags in my own window and reads the rows.  Nothing acknowledges
+    a read.  Under every interleaving of the ranks' streams a read must find exactly the message of its own sequence number —
+    i.e. two slots per direction (and per mailbox row) are enough.  A random scheduler runs the ranks; a get / reduce whose flags
+    are not up blocks its rank; writes land word by word with other ranks' steps in between (a torn message is visible to a reader
+    that does not wait)."""
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        nranks = int(rng.integers(2, 6))
+        nops = int(rng.integers(5, 40))
+        ops = [("x" if rng.random() < 0.6 else "r") for _ in range(nops)]  # the same program on every rank
+        # windows: msg[rank][side][parity] = [seq written, words complete], flag[rank][side]; red[rank][parity][src], rflag[rank][src]
+        msg = [[[[0, True] for _ in range(2)] for _ in range(2)] for _ in range(nranks)]
+        flag = [[0, 0] for _ in range(nranks)]
+        red = [[[[0, True] for _ in range(nranks)] for _ in range(2)] for _ in range(nranks)]
+        rflag = [[0] * nranks for _ in range(nranks)]
+
+        def program(r):
+            xseq = [0, 0]  # per link: [with the lower, with the upper neighbour]
+            rseq = 0
+            for op in ops:
+                if op == "x":
+                    links = [(0, r - 1)] * (r > 0) + [(1, r + 1)] * (r + 1 < nranks)
+                    for l, _nb in links:
+                        xseq[l] += 1
+                    for l, nb in links:  # put: the two halves of the message land at different times
+                        slot = msg[nb][1 - l][xseq[l] & 1]
+                        slot[0], slot[1] = xseq[l], False
+                        yield
+                        slot[1] = True
+                        yield
+                        flag[nb][1 - l] = xseq[l]
+                    for l, _nb in links:  # get
+                        while flag[r][l] < xseq[l]:
+                            yield
+                        slot = msg[r][l][xseq[l] & 1]
+                        assert slot == [xseq[l], True], f"rank {r} link {l}: expected message {xseq[l]}, slot holds {slot}"
+                        yield
+                        assert slot == [xseq[l], True], f"rank {r} link {l}: message {xseq[l]} overwritten while being read ({slot})"
+                else:
+                    rseq += 1
+                    for dst in range(nranks):
+                        row = red[dst][rseq & 1][r]
+                        row[0], row[1] = rseq, False
+                        yield
+                        row[1] = True
+                    yield
+                    for dst in range(nranks):
+                        rflag[dst][r] = rseq
+                    for src in range(nranks):
+                        while rflag[r][src] < rseq:
+                            yield
+                    for src in range(nranks):
+                        assert red[r][rseq & 1][src] == [rseq, True], f"rank {r}: all-reduce {rseq}, row of rank {src} holds {red[r][rseq & 1][src]}"
+                        yield
+                        assert red[r][rseq & 1][src] == [rseq, True], f"rank {r}: all-reduce {rseq}, row of rank {src} overwritten while being read"
+
+        live = {r: program(r) for r in range(nranks)}
+        spins = 0
+        while live:
+            r = int(rng.choice(sorted(live)))
+            if rng.random() < 0.3:  # bursts: one rank runs far ahead when it can
+                steps = int(rng.integers(1, 200))
+            else:
+                steps = 1
+            for _ in range(steps):
+                try:
+                    next(live[r])
+                except StopIteration:
+                    del live[r]
+                    break
+            spins += 1
+            assert spins < 2_000_000, "deadlock in the model"
