@@ -56,7 +56,7 @@ def test_dfsph_step_by_step(xsph, caps):
     f = o.add_fluid(pos, 1000.0, vel)
     if xsph:
         o.add_xsph(f, *xsph)
-    o.add_boundary(bpos)
+    b = o.add_boundary(bpos, wants_forces=True)
     d = DenseWorld(R32, 2.0, "dfsph")
     d.set_fluid(pos, 1000.0, vel)
     d.set_boundary(bpos)
@@ -76,6 +76,9 @@ def test_dfsph_step_by_step(xsph, caps):
         for name, mine in [("velocity_changes", d.dv), ("velocities", d.v), ("positions", d.x)]:
             assert rel(o.fluid_vec(f, name), mine) < tol, f"step {k}: {name}"
         assert rel(o.boundary_volumes(0), d.volb) < 1e-12
+        # boundary.forces: what the divergence and pressure applies and the XSPH boundary arm handed to the boundary particles
+        # (apply_force), accumulated over the steps so far (nobody clears them here)
+        assert np.abs(d.bforce).max() > 0 and rel(o.boundary_vec(b, "forces"), d.bforce) < 10 * tol, f"step {k}: boundary forces"
         assert abs(so.div_error - d.div_err) <= 10 * tol * max(abs(d.div_err), 1e-3) and abs(so.density_error - d.press_err) <= tol * max(abs(d.press_err), 1e-6)
     assert max(i[0] for i in iters) >= 2 and min(i[1] for i in iters) >= 1, f"the solves were meant to iterate: {iters}"
     if caps[0] == 50:
@@ -87,7 +90,7 @@ def test_iisph_step_by_step():
     o = O.OracleWorld(R, 2.0, O.IISPH, f64=True)
     f = o.add_fluid(pos, 1000.0, vel)
     o.add_xsph(f, 0.2, 0.1)
-    o.add_boundary(bpos)
+    b = o.add_boundary(bpos, wants_forces=True)
     d = DenseWorld(R32, 2.0, "iisph")
     d.set_fluid(pos, 1000.0, vel)
     d.set_boundary(bpos)
@@ -103,6 +106,7 @@ def test_iisph_step_by_step():
             assert rel(o.fluid_scalar(f, name), mine) < 1e-7, f"step {k}: {name}"
         for name, mine in [("dii", d.dii), ("dij_pjl", d.dijpj), ("velocities", d.v), ("positions", d.x)]:
             assert rel(o.fluid_vec(f, name), mine) < 1e-7, f"step {k}: {name}"
+        assert np.abs(d.bforce).max() > 0 and rel(o.boundary_vec(b, "forces"), d.bforce) < 1e-6, f"step {k}: boundary forces"
     assert max(iters) >= 3, f"the pressure solve was meant to iterate: {iters}"
 
 
@@ -159,3 +163,238 @@ def test_other_kernels_step_by_step(solver, kd, kg):
         for name, mine in [("velocities", d.v), ("positions", d.x)]:
             assert rel(o.fluid_vec(f, name), mine) < 1e-7, f"step {k}: {name}"
         assert rel(o.boundary_volumes(0), d.volb) < 1e-12
+
+
+def f32(x):
+    return float(np.float32(x))  # force parameters cross the oracle's C interface as f32
+
+
+FORCE_CASES = {
+    # name: (oracle call, numpy_reading kind, parameters)
+    "artificial": (lambda o, f: o.add_artificial_viscosity(f, 0.8, 0.4, alpha=1.0, beta=0.5, speed_of_sound=10.0),
+                   ("artificial", f32(0.8), f32(0.4), 1.0, 0.5, 10.0)),
+    "akinci2013": (lambda o, f: o.add_akinci2013(f, 0.7, 2.0), ("akinci2013", f32(0.7), 2.0)),
+    "he2014": (lambda o, f: o.add_he2014(f, 0.4, 0.6), ("he2014", f32(0.4), f32(0.6))),
+    "wcsph": (lambda o, f: o.add_wcsph_tension(f, 50.0, 0.0), ("wcsph", 50.0)),
+}
+
+
+@pytest.mark.parametrize("solver", ["dfsph", "iisph"])
+@pytest.mark.parametrize("force", sorted(FORCE_CASES))
+def test_nonpressure_forces_step_by_step(solver, force):
+    """ArtificialViscosity, Akinci2013SurfaceTension, He2014SurfaceTension and WCSPHSurfaceTension (fluid arm) as dense pair
+    expressions (numpy_reading.DenseWorld._force_*) against the oracle's per-contact loops, through both solvers: the force
+    enters the accelerations, so velocities, positions, densities and iteration counts of the following steps all carry it.
+    The floor and the wall of the scene give the boundary arms (viscosity against the wall, adhesion, the boundary term of the
+    colour field) something to act on."""
+    pos, vel, bpos = make_scene(seed=9, n=6)
+    add, spec = FORCE_CASES[force]
+    o = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH, f64=True)
+    o.set_solver_params(max_divergence_iter=4, max_pressure_iter=6)
+    f = o.add_fluid(pos, 1000.0, vel)
+    add(o, f)
+    b = o.add_boundary(bpos, wants_forces=True)
+    d = DenseWorld(R32, 2.0, solver)
+    d.max_divergence_iter, d.max_pressure_iter = 4, 6
+    d.set_fluid(pos, 1000.0, vel)
+    d.set_boundary(bpos)
+    d.add_force(*spec)
+    # what the force alone does to the first step: compare with a force-free twin to make sure the case is not vacuous
+    twin = DenseWorld(R32, 2.0, solver)
+    twin.max_divergence_iter, twin.max_pressure_iter = 4, 6
+    twin.set_fluid(pos, 1000.0, vel)
+    twin.set_boundary(bpos)
+    for k in range(6):
+        so = o.step(DT, G)
+        d.step(DT32, G32)
+        if k == 0:
+            twin.step(DT32, G32)
+            assert np.abs(d.x - twin.x).max() > 1e-7 * d.h, "the force did nothing"
+        assert int(so.ncontacts) == d.ncontacts, f"step {k}: contacts"
+        if solver == "dfsph":
+            assert (so.n_div_iters, so.n_press_iters) == (d.n_div, d.n_press), f"step {k}: iterations"
+        else:
+            assert so.n_press_iters == d.n_press, f"step {k}: iterations"
+        for name, mine in [("velocities", d.v), ("positions", d.x)]:
+            assert rel(o.fluid_vec(f, name), mine) < 1e-7, f"step {k}: {name} ({rel(o.fluid_vec(f, name), mine):.2e})"
+        assert rel(o.fluid_scalar(f, "densities"), d.rho) < 1e-7, f"step {k}: densities"
+        # boundary.forces (the reactions of the pressure solve + of this force's boundary arm).  Not for ArtificialViscosity: its
+        # boundary arm hands each boundary particle the RUNNING sum over the contact list (artificial_viscosity.rs:110-117 applies
+        # `boundary_acc`, not this contact's term), which depends on the list order a dense formulation does not have
+        if force != "artificial":
+            assert rel(o.boundary_vec(b, "forces"), d.bforce) < 1e-6, f"step {k}: boundary forces ({rel(o.boundary_vec(b, 'forces'), d.bforce):.2e})"
+
+
+@pytest.mark.parametrize("max_iter", [3, 50])
+def test_dfsph_viscosity_step_by_step(max_iter):
+    """DFSPHViscosity (dfsph_viscosity.rs) on a slightly perturbed sheared block: the 6 x 6 beta matrices with the reference's
+    three-column preconditioner, the strain-rate error the loop ends on, its iteration count, and the state that results — two
+    readings of an iteration that amplifies differences, agreeing to 1e-12."""
+    pos = scenes.jitter(scenes.cube_fluid_positions(7, 7, 7, R), 0.02 * R, seed=42).astype(np.float32)
+    vel = scenes.random_velocities(len(pos), 0.01, seed=12345).astype(np.float32)
+    vel[:, 0] += np.float32(2.0) * pos[:, 1]
+    o = O.OracleWorld(R, 2.0, O.DFSPH, f64=True)
+    o.set_solver_params(max_divergence_iter=4, max_pressure_iter=6)
+    f = o.add_fluid(pos, 1000.0, vel)
+    o.add_dfsph_viscosity(f, 0.6, 1, max_iter, 0.01)
+    d = DenseWorld(R32, 2.0, "dfsph")
+    d.max_divergence_iter, d.max_pressure_iter = 4, 6
+    d.set_fluid(pos, 1000.0, vel)
+    d.add_force("dfsph_viscosity", f32(0.6), 1, max_iter, f32(0.01))
+    for k in range(6):
+        so = o.step(DT, G)
+        d.step(DT32, G32)
+        it, err = o.viscosity_stats(f)
+        assert it == d.visc_iters and (so.n_div_iters, so.n_press_iters) == (d.n_div, d.n_press), f"step {k}: iterations"
+        assert abs(err - d.visc_err) <= 1e-10 * max(d.visc_err, 1e-3), f"step {k}: strain-rate error {err} vs {d.visc_err}"
+        assert rel(o.viscosity_betas(f), d.visc_betas) < 1e-11, f"step {k}: betas"
+        for name, mine in [("velocities", d.v), ("positions", d.x)]:
+            assert rel(o.fluid_vec(f, name), mine) < 1e-11, f"step {k}: {name}"
+    assert d.visc_err > 1e-3, "the viscosity loop was meant to have work"
+
+
+def test_dfsph_viscosity_diverges_in_both_readings():
+    """On a lattice jittered by 0.15 r the reference's viscosity loop does not converge but EXPLODES (tests/golden_scenes.py
+    scene_dfsph_viscous has the story: the preconditioner touches three of the six columns).  That is a property of the Rust as
+    written, so an independent reading must show it too: both readings reach the same astronomically large strain-rate error
+    (> 1e60) within two steps, agreeing to six digits."""
+    pos, vel, bpos = make_scene(seed=9, n=6)
+    o = O.OracleWorld(R, 2.0, O.DFSPH, f64=True)
+    o.set_solver_params(max_divergence_iter=4, max_pressure_iter=6)
+    f = o.add_fluid(pos, 1000.0, vel)
+    o.add_dfsph_viscosity(f, 0.5, 1, 50, 0.01)
+    o.add_boundary(bpos)
+    d = DenseWorld(R32, 2.0, "dfsph")
+    d.max_divergence_iter, d.max_pressure_iter = 4, 6
+    d.set_fluid(pos, 1000.0, vel)
+    d.set_boundary(bpos)
+    d.add_force("dfsph_viscosity", 0.5, 1, 50, f32(0.01))
+    worst = 0.0
+    for k in range(2):
+        o.step(DT, G)
+        d.step(DT32, G32)
+        it, err = o.viscosity_stats(f)
+        assert it == d.visc_iters == 50
+        assert abs(err - d.visc_err) <= 1e-6 * d.visc_err, f"step {k}: {err} vs {d.visc_err}"
+        assert rel(o.viscosity_betas(f), d.visc_betas) < 1e-10
+        worst = max(worst, d.visc_err)
+    assert worst > 1e60
+
+
+@pytest.mark.parametrize("solver", ["dfsph", "iisph"])
+def test_two_fluids_and_interaction_groups_step_by_step(solver):
+    """BASELINE config 4's ingredients in small: two fluids of different density0 in contact (a light block resting on a heavy
+    one), each with its own force list, two boundaries, and InteractionGroups that hide the wall from the light fluid.  What the
+    multi-object rules of the Rust decide — whose density0 weighs a boundary particle (`fluid_i.density0`), which fluid arms skip
+    foreign contacts (`c.i_model == c.j_model`), the per-fluid error averages and their maximum, which pairs exist at all
+    (contacts.rs:277-359) — read twice."""
+    n = 5
+    d = 2 * R
+    lower = (scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.12 * R, 21) * 0.9).astype(np.float32)
+    upper = (scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.12 * R, 22) * 0.9).astype(np.float32)
+    upper[:, 1] += np.float32(lower[:, 1].max() - upper[:, 1].min() + 0.9 * d)
+    v_lower = scenes.random_velocities(len(lower), 0.5, 23).astype(np.float32)
+    v_upper = scenes.random_velocities(len(upper), 0.5, 24).astype(np.float32)
+    v_upper[:, 1] -= 0.5
+    lo = lower.min(axis=0)
+    gx, gz = np.meshgrid(np.arange(-2, n + 2), np.arange(-2, n + 2), indexing="ij")
+    floor = np.stack([lo[0] + gx.ravel() * d, np.full(gx.size, lo[1] - d), lo[2] + gz.ravel() * d], axis=1).astype(np.float32)
+    gy, gz2 = np.meshgrid(np.arange(0, 2 * n + 1), np.arange(0, n), indexing="ij")
+    wall = np.stack([np.full(gy.size, lo[0] - d), lo[1] + gy.ravel() * d, lo[2] + gz2.ravel() * d], axis=1).astype(np.float32)
+    # groups: lower fluid 0b01, upper fluid 0b10 (both see everything that lets them); the wall only lets group 0b01 in
+    G_LOWER, G_UPPER, G_FLOOR, G_WALL = (1, 0xFFFFFFFF), (2, 0xFFFFFFFF), (1, 0xFFFFFFFF), (1, 1)
+
+    o = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH, f64=True)
+    o.set_solver_params(max_divergence_iter=5, max_pressure_iter=8)
+    f0 = o.add_fluid(lower, 1000.0, v_lower, memberships=G_LOWER[0], filter=G_LOWER[1])
+    f1 = o.add_fluid(upper, 500.0, v_upper, memberships=G_UPPER[0], filter=G_UPPER[1])
+    o.add_xsph(f0, 0.5, 0.2)
+    o.add_akinci2013(f0, 0.6, 1.5)
+    o.add_xsph(f1, 0.3, 0.4)
+    o.add_he2014(f1, 0.5, 0.3)
+    b0 = o.add_boundary(floor, memberships=G_FLOOR[0], filter=G_FLOOR[1], wants_forces=True)
+    b1 = o.add_boundary(wall, memberships=G_WALL[0], filter=G_WALL[1], wants_forces=True)
+
+    w = DenseWorld(R32, 2.0, solver)
+    w.max_divergence_iter, w.max_pressure_iter = 5, 8
+    w.add_fluid(lower, 1000.0, v_lower, *G_LOWER)
+    w.add_fluid(upper, 500.0, v_upper, *G_UPPER)
+    w.set_xsph(f32(0.5), f32(0.2), fluid=0)
+    w.add_force("akinci2013", f32(0.6), 1.5, fluid=0)
+    w.set_xsph(f32(0.3), f32(0.4), fluid=1)
+    w.add_force("he2014", 0.5, f32(0.3), fluid=1)
+    w.add_boundary(floor, *G_FLOOR)
+    w.add_boundary(wall, *G_WALL)
+    r0, r1 = w.fluid_rows(0), w.fluid_rows(1)
+    for k in range(6):
+        so = o.step(DT, G)
+        w.step(DT32, G32)
+        if k == 0:
+            # the scene does what it is for: the two fluids touch, the lower one touches the wall, the upper one is within reach
+            # of it but has no contact with it
+            assert w.ff[r0][:, r1].any() and w.fb[r0][:, w.bmodel == 1].any() and not w.fb[r1][:, w.bmodel == 1].any()
+            reach = ((upper[:, None, :].astype(np.float64) - wall[None, :, :]) ** 2).sum(axis=2) <= w.h ** 2
+            assert reach.any()
+        assert int(so.ncontacts) == w.ncontacts, f"step {k}: contacts {so.ncontacts} vs {w.ncontacts}"
+        if solver == "dfsph":
+            assert (so.n_div_iters, so.n_press_iters) == (w.n_div, w.n_press), f"step {k}: iterations"
+        else:
+            assert so.n_press_iters == w.n_press, f"step {k}: iterations"
+        for fid, rows in ((f0, r0), (f1, r1)):
+            assert rel(o.fluid_scalar(fid, "densities"), w.rho[rows]) < 1e-7, f"step {k}: densities of fluid {fid}"
+            for name, mine in [("velocities", w.v), ("positions", w.x)]:
+                assert rel(o.fluid_vec(fid, name), mine[rows]) < 1e-7, f"step {k}: {name} of fluid {fid}"
+        for bid in (b0, b1):
+            assert rel(o.boundary_volumes(bid), w.volb[w.bmodel == bid]) < 1e-12
+            assert rel(o.boundary_vec(bid, "forces"), w.bforce[w.bmodel == bid]) < 1e-6, f"step {k}: forces on boundary {bid}"
+
+
+@pytest.mark.parametrize("solver", ["dfsph", "iisph"])
+def test_particles_added_and_deleted_between_steps(solver):
+    """The emitter / sink life cycle of examples3d/faucet3.rs:69-104 read twice: `Fluid::add_particles` between steps (the new
+    particles enter the solver with zero velocity change and zero IISPH pressure, the old ones keep theirs),
+    `delete_particle_at_next_timestep` (gone from the fluid AND from the solver's warm-start buffers at the top of the next step,
+    survivors in order) — including a particle that is added and deleted before it ever takes part in a step."""
+    pos, vel, bpos = make_scene(seed=13, n=5)
+    o = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH, f64=True)
+    o.set_solver_params(max_divergence_iter=4, max_pressure_iter=6)
+    f = o.add_fluid(pos, 1000.0, vel)
+    o.add_xsph(f, 0.4, 0.1)
+    o.add_boundary(bpos)
+    w = DenseWorld(R32, 2.0, solver)
+    w.max_divergence_iter, w.max_pressure_iter = 4, 6
+    w.set_fluid(pos, 1000.0, vel)
+    w.set_xsph(f32(0.4), f32(0.1))
+    w.set_boundary(bpos)
+    rng = np.random.default_rng(5)
+    top = float(pos[:, 1].max())
+    counts = []
+    for k in range(9):
+        if k in (2, 4, 5):  # a sheet of new particles just above the block, moving down
+            d = 2 * R
+            gx, gz = np.meshgrid(np.arange(4), np.arange(4), indexing="ij")
+            sheet = np.stack([pos[:, 0].min() + gx.ravel() * d, np.full(gx.size, top + (1.0 + 0.3 * k) * d), pos[:, 2].min() + gz.ravel() * d],
+                             axis=1).astype(np.float32)
+            sv = np.tile(np.array([[0.1, -1.0, 0.0]], np.float32), (len(sheet), 1))
+            o.add_particles(f, sheet, sv)
+            w.add_particles(0, sheet, sv)
+        if k in (3, 5, 6):  # delete a random handful, by index into the current host order
+            n_now = o.fluid_len(f)
+            assert n_now == int((w.model == 0).sum())
+            for i in sorted(set(int(x) for x in rng.integers(0, n_now, size=7))):
+                o.delete_particle_at_next_timestep(f, i)
+                w.delete_particle_at_next_timestep(0, i)
+            if k == 5:  # one of the particles added a moment ago, never stepped
+                o.delete_particle_at_next_timestep(f, n_now - 3)
+                w.delete_particle_at_next_timestep(0, n_now - 3)
+        so = o.step(DT, G)
+        w.step(DT32, G32)
+        counts.append(o.fluid_len(f))
+        assert o.fluid_len(f) == len(w.x), f"step {k}: {o.fluid_len(f)} vs {len(w.x)} particles"
+        assert int(so.ncontacts) == w.ncontacts, f"step {k}: contacts"
+        for name, mine in [("velocities", w.v), ("positions", w.x)]:
+            assert rel(o.fluid_vec(f, name), mine) < 1e-7, f"step {k}: {name} ({rel(o.fluid_vec(f, name), mine):.2e})"
+        assert rel(o.fluid_scalar(f, "densities"), w.rho) < 1e-7, f"step {k}: densities"
+        if solver == "iisph":
+            assert rel(o.fluid_scalar(f, "pressures"), w.p) < 1e-7, f"step {k}: pressures (the next step's warm start)"
+    assert len(set(counts)) >= 5, f"the particle count was meant to change: {counts}"
