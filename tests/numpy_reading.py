@@ -84,13 +84,20 @@ def visc_dw(r, h):
 KERNELS = {"cubic": (spline_w, spline_dw), "poly6": (poly6_w, poly6_dw), "spiky": (spiky_w, spiky_dw), "viscosity": (visc_w, visc_dw)}
 
 
-def pair_tables(xa, xb, h, kernel_density="cubic", kernel_gradient="cubic"):
+def pair_tables(xa, xb, h, kernel_density="cubic", kernel_gradient="cubic", f32_contacts=False):
     """For every (a, b): contact mask (contacts.rs: distance_squared <= h*h), weight (helper.rs: KernelDensity::points_apply) and
     gradient (KernelGradient::points_apply_diff1 = apply_diff(pa - pb): direction * dW/dr, zero when the norm is <= eps,
-    kernel.rs:18-24)."""
+    kernel.rs:18-24).  `f32_contacts`: decide the contact in the arithmetic of the reference's f32 build (positions rounded to
+    f32, (dx*dx + dy*dy) + dz*dz and h*h in f32) — lattice boundaries hold many pairs at exactly d = h, which f32 and f64
+    arithmetic put on different sides; everything else stays f64."""
     d = xa[:, None, :] - xb[None, :, :]
     r2 = (d * d).sum(axis=2)
-    mask = r2 <= h * h
+    if f32_contacts:
+        d32 = xa.astype(np.float32)[:, None, :] - xb.astype(np.float32)[None, :, :]
+        r2_32 = (d32[:, :, 0] * d32[:, :, 0] + d32[:, :, 1] * d32[:, :, 1]) + d32[:, :, 2] * d32[:, :, 2]
+        mask = r2_32 <= np.float32(h) * np.float32(h)
+    else:
+        mask = r2 <= h * h
     r = np.sqrt(r2)
     w = np.where(mask, KERNELS[kernel_density][0](r, h), 0.0)
     safe = np.where(r > EPS32, r, 1.0)
@@ -104,8 +111,10 @@ class DenseWorld:
     All fluid particles live in one set of arrays (`model` = the fluid a particle belongs to), all boundary particles in another:
     a pass over "the contacts of particle i" is a masked row of a dense pair table whatever the objects are."""
 
-    def __init__(self, particle_radius, smoothing_factor=2.0, solver="dfsph", kernel_density="cubic", kernel_gradient="cubic"):
+    def __init__(self, particle_radius, smoothing_factor=2.0, solver="dfsph", kernel_density="cubic", kernel_gradient="cubic",
+                 f32_contacts=False):
         self.kernels = (kernel_density, kernel_gradient)
+        self.f32_contacts = bool(f32_contacts)  # pair_tables: the contact criterion in f32 arithmetic (against f32 implementations)
         self.r = float(particle_radius)
         self.h = float(particle_radius) * float(smoothing_factor) * 2.0  # liquid_world.rs:44
         self.solver = solver
@@ -243,9 +252,9 @@ class DenseWorld:
         ok_ff = self._allowed(self.model, self.groups, self.model, self.groups, True)
         ok_fb = self._allowed(self.model, self.groups, self.bmodel, self.bgroups, False)
         ok_bb = self._allowed(self.bmodel, self.bgroups, self.bmodel, self.bgroups, True)
-        self.ff, self.wff, self.gff = pair_tables(self.x, self.x, h, *self.kernels)
-        self.fb, self.wfb, self.gfb = pair_tables(self.x, self.xb, h, *self.kernels)
-        bb, wbb, _ = pair_tables(self.xb, self.xb, h, *self.kernels)
+        self.ff, self.wff, self.gff = pair_tables(self.x, self.x, h, *self.kernels, f32_contacts=self.f32_contacts)
+        self.fb, self.wfb, self.gfb = pair_tables(self.x, self.xb, h, *self.kernels, f32_contacts=self.f32_contacts)
+        bb, wbb, _ = pair_tables(self.xb, self.xb, h, *self.kernels, f32_contacts=self.f32_contacts)
         self.ff, self.wff, self.gff = self.ff & ok_ff, np.where(ok_ff, self.wff, 0.0), np.where(ok_ff[:, :, None], self.gff, 0.0)
         self.fb, self.wfb, self.gfb = self.fb & ok_fb, np.where(ok_fb, self.wfb, 0.0), np.where(ok_fb[:, :, None], self.gfb, 0.0)
         bb, wbb = bb & ok_bb, np.where(ok_bb, wbb, 0.0)

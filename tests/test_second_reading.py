@@ -398,3 +398,69 @@ def test_particles_added_and_deleted_between_steps(solver):
         if solver == "iisph":
             assert rel(o.fluid_scalar(f, "pressures"), w.p) < 1e-7, f"step {k}: pressures (the next step's warm start)"
     assert len(set(counts)) >= 5, f"the particle count was meant to change: {counts}"
+
+
+def two_fluid_scene():
+    """The scene of test_two_fluids_and_interaction_groups_step_by_step, as (lower, upper, v_lower, v_upper, floor, wall, groups)."""
+    n = 5
+    d = 2 * R
+    lower = (scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.12 * R, 21) * 0.9).astype(np.float32)
+    upper = (scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.12 * R, 22) * 0.9).astype(np.float32)
+    upper[:, 1] += np.float32(lower[:, 1].max() - upper[:, 1].min() + 0.9 * d)
+    v_lower = scenes.random_velocities(len(lower), 0.5, 23).astype(np.float32)
+    v_upper = scenes.random_velocities(len(upper), 0.5, 24).astype(np.float32)
+    v_upper[:, 1] -= 0.5
+    lo = lower.min(axis=0)
+    gx, gz = np.meshgrid(np.arange(-2, n + 2), np.arange(-2, n + 2), indexing="ij")
+    floor = np.stack([lo[0] + gx.ravel() * d, np.full(gx.size, lo[1] - d), lo[2] + gz.ravel() * d], axis=1).astype(np.float32)
+    gy, gz2 = np.meshgrid(np.arange(0, 2 * n + 1), np.arange(0, n), indexing="ij")
+    wall = np.stack([np.full(gy.size, lo[0] - d), lo[1] + gy.ravel() * d, lo[2] + gz2.ravel() * d], axis=1).astype(np.float32)
+    groups = dict(lower=(1, 0xFFFFFFFF), upper=(2, 0xFFFFFFFF), floor=(1, 0xFFFFFFFF), wall=(1, 1))
+    return lower, upper, v_lower, v_upper, floor, wall, groups
+
+
+@pytest.mark.parametrize("solver", ["dfsph", "iisph"])
+def test_f32_build_against_the_reading_with_f32_contacts(solver):
+    """The oracle's f32 build — the arithmetic the HIP path is held to — against the numpy reading told to decide contacts in f32
+    (`f32_contacts`): the lattice floor and wall hold dozens of pairs at exactly d = h, which f32 and f64 arithmetic put on
+    different sides (8771 against 8703 contacts in this scene; the device reports 8771, profiles/r03_peer/numpy_reading_gpu.log).
+    With the criterion in f32 the counts agree exactly at every step and the states to f32 noise — the template for comparing
+    the device with the reading directly."""
+    lower, upper, v_lower, v_upper, floor, wall, g = two_fluid_scene()
+    o = O.OracleWorld(R, 2.0, O.DFSPH if solver == "dfsph" else O.IISPH, f64=False)
+    o.set_solver_params(max_divergence_iter=5, max_pressure_iter=8)
+    f0 = o.add_fluid(lower, 1000.0, v_lower, memberships=g["lower"][0], filter=g["lower"][1])
+    f1 = o.add_fluid(upper, 500.0, v_upper, memberships=g["upper"][0], filter=g["upper"][1])
+    o.add_xsph(f0, 0.5, 0.2)
+    o.add_akinci2013(f0, 0.6, 1.5)
+    o.add_xsph(f1, 0.3, 0.4)
+    o.add_he2014(f1, 0.5, 0.3)
+    o.add_boundary(floor, memberships=g["floor"][0], filter=g["floor"][1])
+    o.add_boundary(wall, memberships=g["wall"][0], filter=g["wall"][1])
+    w = DenseWorld(R32, 2.0, solver, f32_contacts=True)
+    w.max_divergence_iter, w.max_pressure_iter = 5, 8
+    w.add_fluid(lower, 1000.0, v_lower, *g["lower"])
+    w.add_fluid(upper, 500.0, v_upper, *g["upper"])
+    w.set_xsph(f32(0.5), f32(0.2), fluid=0)
+    w.add_force("akinci2013", f32(0.6), 1.5, fluid=0)
+    w.set_xsph(f32(0.3), f32(0.4), fluid=1)
+    w.add_force("he2014", 0.5, f32(0.3), fluid=1)
+    w.add_boundary(floor, *g["floor"])
+    w.add_boundary(wall, *g["wall"])
+    plain = DenseWorld(R32, 2.0, solver)
+    plain.add_fluid(lower, 1000.0, v_lower, *g["lower"]); plain.add_fluid(upper, 500.0, v_upper, *g["upper"])
+    plain.add_boundary(floor, *g["floor"]); plain.add_boundary(wall, *g["wall"])
+    plain.step(DT32, G32)
+    r0, r1 = w.fluid_rows(0), w.fluid_rows(1)
+    for k in range(6):
+        so = o.step(DT, G)
+        w.step(DT32, G32)
+        if k == 0:
+            assert w.ncontacts != plain.ncontacts, "the scene was meant to hold pairs at exactly d = h"
+        assert int(so.ncontacts) == w.ncontacts, f"step {k}: contacts {so.ncontacts} vs {w.ncontacts}"
+        for fid, rows in ((f0, r0), (f1, r1)):
+            dx = np.abs(o.fluid_vec(fid, "positions") - w.x[rows]).max()
+            dv = np.abs(o.fluid_vec(fid, "velocities") - w.v[rows]).max()
+            # (measured: 1e-6 h and 4e-6 m/s after six steps — f32 rounding of sums of ~40 terms)
+            assert dx < 1e-5 * w.h and dv < 5e-5, f"step {k}: fluid {fid} differs by {dx / w.h:.2e} h, {dv:.2e} m/s"
+            assert rel(o.fluid_scalar(fid, "densities"), w.rho[rows]) < 2e-5, f"step {k}: densities of fluid {fid}"
