@@ -421,6 +421,7 @@ void salva_hip_comm_destroy(SalvaHipComm* comm) {
 int salva_hip_comm_selftest(SalvaHipComm* comm, uint64_t max_bytes, int32_t rounds) {
     return guarded([&]() -> int {
         if (!comm || !comm->t) throw salva::HipError(SALVA_HIP_E_INVALID, "null communicator");
+        if (comm->t->device() >= 0) SALVA_HIP_CHECK(hipSetDevice(comm->t->device()));  // (a stream belongs to the current device)
         hipStream_t s = nullptr;
         SALVA_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         try {
@@ -436,6 +437,7 @@ int salva_hip_comm_selftest(SalvaHipComm* comm, uint64_t max_bytes, int32_t roun
 int salva_hip_comm_time(SalvaHipComm* comm, uint64_t bytes, int32_t iters, float* us_exchange, float* us_allreduce) {
     return guarded([&]() -> int {
         if (!comm || !comm->t) throw salva::HipError(SALVA_HIP_E_INVALID, "null communicator");
+        if (comm->t->device() >= 0) SALVA_HIP_CHECK(hipSetDevice(comm->t->device()));  // (a stream belongs to the current device)
         hipStream_t s = nullptr;
         SALVA_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         try {

@@ -24,6 +24,8 @@ class Transport {
     virtual ~Transport() = default;
     virtual int rank() const = 0;
     virtual int size() const = 0;
+    // the HIP device this transport's buffers live on (-1: whichever device the calling thread has current — the loopback)
+    virtual int device() const { return -1; }
     bool has_lo() const { return rank() > 0; }
     bool has_hi() const { return rank() + 1 < size(); }
 

@@ -157,7 +157,7 @@ void rccl_unique_id(unsigned char out[RCCL_ID_BYTES]) {
 
 class RcclTransport : public Transport {
   public:
-    RcclTransport(int rank, int size, const unsigned char idb[RCCL_ID_BYTES], int device) : rank_(rank), size_(size) {
+    RcclTransport(int rank, int size, const unsigned char idb[RCCL_ID_BYTES], int device) : rank_(rank), size_(size), device_(device) {
         SALVA_HIP_CHECK(hipSetDevice(device));
         ncclUniqueId id;
         memcpy(&id, idb, RCCL_ID_BYTES);
@@ -172,6 +172,7 @@ class RcclTransport : public Transport {
     }
     int rank() const override { return rank_; }
     int size() const override { return size_; }
+    int device() const override { return device_; }
 
     void sendrecv(const void* send_lo, size_t n_lo, const void* send_hi, size_t n_hi, void* recv_lo, size_t m_lo, void* recv_hi,
                   size_t m_hi, hipStream_t s) override {
@@ -216,7 +217,7 @@ class RcclTransport : public Transport {
     }
 
   private:
-    int rank_, size_;
+    int rank_, size_, device_;
     ncclComm_t comm_ = nullptr;
     uint64_t* d_cnt_ = nullptr;
     uint64_t* h_cnt_ = nullptr;

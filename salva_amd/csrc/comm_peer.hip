@@ -238,6 +238,7 @@ class PeerTransport : public Transport {
     }
     int rank() const override { return rank_; }
     int size() const override { return size_; }
+    int device() const override { return device_; }
 
     void sendrecv(const void* send_lo, size_t n_lo, const void* send_hi, size_t n_hi, void* recv_lo, size_t m_lo, void* recv_hi,
                   size_t m_hi, hipStream_t s) override {

@@ -203,6 +203,10 @@ class DenseWorld:
                 setattr(self, name, getattr(self, name)[keep])
             self.deleted = np.zeros(int(keep.sum()), bool)
 
+    def set_fluid_volumes(self, fluid, volumes):
+        """`fluid.volumes` is a pub field (fluid.rs:24): scenes may override the default."""
+        self.vol[self.model == fluid] = np.asarray(volumes, np.float64)
+
     def set_fluid(self, positions, density0=1000.0, velocities=None):
         self._reset_fluids()
         self.add_fluid(positions, density0, velocities)
@@ -400,10 +404,18 @@ class DenseWorld:
         betas[:, :, :3] *= inv_diag[:, None, :3]                # column c scaled by inv_diag[c], c < SPATIAL_DIM
         self.visc_betas = betas
 
+        # The two pair sums of the loop as matrix-vector products (the loop runs up to 50 times per step):
+        #   rate_i  = sum_j Gi_ij (v_j - v_i)                    = A v - (sum_j Gi_ij) v_i,       A: (6N x 3N)
+        #   acc_i   = m_i inv_dt sum_j G_ij^T (u_i + u_j) m_j / 2 = m_i inv_dt (S_i^T u_i + B u),  B: (3N x 6N), S_i = sum_j G_ij m_j / 2
+        nall = len(self.x)
+        A = Gi.transpose(0, 2, 1, 3).reshape(6 * nall, 3 * nall)
+        Hm = G * (m[None, :] / 2.0)[:, :, None, None]
+        B = Hm.transpose(0, 3, 1, 2).reshape(3 * nall, 6 * nall)
+        S = Hm.sum(axis=1)
+
         def rates(acc):
             v = self.v + acc * self.dt
-            vji = v[None, :, :] - v[:, None, :]
-            return np.einsum("ijab,ijb->ia", Gi, vji)
+            return (A @ v.ravel()).reshape(nall, 6) - np.einsum("iab,ib->ia", gsum, v)
 
         a = self.a.copy()
         target = rates(a) * (1.0 - coefficient)
@@ -415,8 +427,7 @@ class DenseWorld:
             if avg <= max_error and i >= int(min_iter):
                 break
             u = np.einsum("iab,ib->ia", betas, error) / (rho * rho)[:, None]
-            coeff = (u[:, None, :] + u[None, :, :]) * (m[None, :] / 2.0)[:, :, None]
-            a = a + np.einsum("ijab,ija->ib", G, coeff) * (m * self.inv_dt)[:, None]
+            a = a + (np.einsum("iab,ia->ib", S, u) + (B @ u.ravel()).reshape(nall, 3)) * (m * self.inv_dt)[:, None]
             self.visc_iters += 1
         return a - self.a
 
