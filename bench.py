@@ -254,11 +254,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path to measure")
+    # More ranks than GPUs (a self-test aid on the single-GPU boxes, not a scaling measurement): the ranks share the devices
+    # round-robin.  RCCL refuses two ranks on one device, so such a run needs --transport peer, and torch.distributed (used here
+    # for the barrier and the max-over-ranks of the elapsed time only) runs over gloo.
+    ndev = torch.cuda.device_count()
+    shared = world > ndev
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        slab.single_node_rccl_env()  # one node by contract: keep RCCL's bootstrap off the (absent) network
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared:
+            if args.transport != "peer":
+                raise SystemExit(f"{world} ranks on {ndev} GPU(s): RCCL needs one GPU per rank; --transport peer accepts ranks sharing a device")
+            dist.init_process_group("gloo")
+        else:
+            slab.single_node_rccl_env()  # one node by contract: keep RCCL's bootstrap off the (absent) network
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     comm = None
     decomposed = world > 1 or args.force_slabs
@@ -322,7 +333,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -363,7 +374,8 @@ def main():
             "metric": cfg["metric"],
             "value": value,
             "unit": "particle-steps/s",
-            "n_gpus": world,
+            "n_gpus": min(world, ndev),
+            "ranks": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -375,7 +387,8 @@ def main():
             "config": {
                 "workload": f"BASELINE config {args.config if not decomposed else 5}: 3D {cfg['solver'].upper()} {n * world} fluid particles "
                             f"(+{nshell_total} boundary), {cfg['what']}, r=0.025 h=0.1 dt=1/200",
-                "particles_per_gpu": n,
+                "particles_per_gpu": n * world // min(world, ndev),
+                "ranks_sharing_gpus": bool(shared),  # true: a functional run of the multi-process path, not a scaling measurement
                 "parallelism": "single domain" if not decomposed else
                 (f"{world} x-slabs, one per GPU: RCCL send/recv of two ghost planes per face with the 2 neighbours (one exchange per "
                  f"solver iteration) + all-reduced convergence test" if args.transport == "rccl" else

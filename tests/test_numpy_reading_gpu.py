@@ -1,0 +1,87 @@
+"""The HIP path against the INDEPENDENT numpy reading (tests/numpy_reading.py) directly — no oracle in between: the same small
+two-fluid scene tests/test_second_reading.py uses to compare the oracle with that reading (two fluids of density0 1000 / 500 in
+contact, XSPH + Akinci2013 on one, XSPH + He2014 on the other, a floor, a wall hidden from the light fluid by its
+InteractionGroups), stepped on the device (f32) and in numpy (f64).  The chain HIP == oracle == numpy reading closes into a
+triangle: a misreading shared by the kernels and the oracle cannot hide behind their agreement.
+
+The reading decides contacts in f32 arithmetic here (`f32_contacts`): the lattice floor and wall hold pairs at exactly d = h, and the
+first run of this test (round 3, profiles/r03_peer/numpy_reading_gpu.log) stopped on 8771 contacts on the device against 8703 in
+plain f64 — the oracle's f32 build counts 8771 too (tests/test_second_reading.py::test_f32_build_against_the_reading_with_f32_contacts,
+where the same comparison passes on the CPU at 1e-6 h).  NOT YET RUN ON HARDWARE in this form; tighten the tolerances after the
+first run."""
+import numpy as np
+import pytest
+
+from numpy_reading import DenseWorld
+from salva_amd import (Akinci2013SurfaceTension, Boundary, DFSPHSolver, Fluid, He2014SurfaceTension, IISPHSolver, InteractionGroups,
+                       LiquidWorld, XSPHViscosity, scenes)
+
+pytestmark = pytest.mark.gpu
+
+R = 0.025
+DT = 1.0 / 200.0
+G = (0.0, -9.81, 0.0)
+R32, DT32 = float(np.float32(R)), float(np.float32(DT))
+G32 = tuple(float(np.float32(g)) for g in G)
+
+
+def f32(x):
+    return float(np.float32(x))
+
+
+@pytest.mark.parametrize("solver", ["dfsph", "iisph"])
+def test_two_fluid_scene_device_against_the_numpy_reading(hip_lib, solver):
+    n = 5
+    d = 2 * R
+    lower = (scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.12 * R, 21) * 0.9).astype(np.float32)
+    upper = (scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.12 * R, 22) * 0.9).astype(np.float32)
+    upper[:, 1] += np.float32(lower[:, 1].max() - upper[:, 1].min() + 0.9 * d)
+    v_lower = scenes.random_velocities(len(lower), 0.5, 23).astype(np.float32)
+    v_upper = scenes.random_velocities(len(upper), 0.5, 24).astype(np.float32)
+    v_upper[:, 1] -= 0.5
+    lo = lower.min(axis=0)
+    gx, gz = np.meshgrid(np.arange(-2, n + 2), np.arange(-2, n + 2), indexing="ij")
+    floor = np.stack([lo[0] + gx.ravel() * d, np.full(gx.size, lo[1] - d), lo[2] + gz.ravel() * d], axis=1).astype(np.float32)
+    gy, gz2 = np.meshgrid(np.arange(0, 2 * n + 1), np.arange(0, n), indexing="ij")
+    wall = np.stack([np.full(gy.size, lo[0] - d), lo[1] + gy.ravel() * d, lo[2] + gz2.ravel() * d], axis=1).astype(np.float32)
+    G_LOWER, G_UPPER, G_FLOOR, G_WALL = (1, 0xFFFFFFFF), (2, 0xFFFFFFFF), (1, 0xFFFFFFFF), (1, 1)
+
+    s = DFSPHSolver() if solver == "dfsph" else IISPHSolver()
+    s.max_pressure_iter = 8
+    if solver == "dfsph":
+        s.max_divergence_iter = 5
+    w = LiquidWorld(s, R, 2.0)
+    fa = Fluid(lower, R, 1000.0, InteractionGroups(*G_LOWER))
+    fa.velocities = v_lower
+    fa.nonpressure_forces += [XSPHViscosity(0.5, 0.2), Akinci2013SurfaceTension(0.6, 1.5)]
+    fb = Fluid(upper, R, 500.0, InteractionGroups(*G_UPPER))
+    fb.velocities = v_upper
+    fb.nonpressure_forces += [XSPHViscosity(0.3, 0.4), He2014SurfaceTension(0.5, 0.3)]
+    w.add_fluid(fa)
+    w.add_fluid(fb)
+    w.add_boundary(Boundary(floor, InteractionGroups(*G_FLOOR)))
+    w.add_boundary(Boundary(wall, InteractionGroups(*G_WALL)))
+
+    dw = DenseWorld(R32, 2.0, solver, f32_contacts=True)
+    dw.max_divergence_iter, dw.max_pressure_iter = 5, 8
+    dw.add_fluid(lower, 1000.0, v_lower, *G_LOWER)
+    dw.add_fluid(upper, 500.0, v_upper, *G_UPPER)
+    dw.set_xsph(f32(0.5), f32(0.2), fluid=0)
+    dw.add_force("akinci2013", f32(0.6), 1.5, fluid=0)
+    dw.set_xsph(f32(0.3), f32(0.4), fluid=1)
+    dw.add_force("he2014", 0.5, f32(0.3), fluid=1)
+    dw.add_boundary(floor, *G_FLOOR)
+    dw.add_boundary(wall, *G_WALL)
+    r0, r1 = dw.fluid_rows(0), dw.fluid_rows(1)
+    h = dw.h
+    for k in range(6):
+        st = w.step(DT, G)
+        dw.step(DT32, G32)
+        assert int(st.ncontacts) == dw.ncontacts, f"step {k}: contacts {st.ncontacts} vs {dw.ncontacts}"
+        for fl, rows in ((fa, r0), (fb, r1)):
+            dx = np.abs(np.asarray(fl.positions, np.float64) - dw.x[rows]).max()
+            dv = np.abs(np.asarray(fl.velocities, np.float64) - dw.v[rows]).max()
+            assert dx < 5e-5 * h, f"step {k}: positions differ by {dx / h:.2e} h"
+            assert dv < 2e-4, f"step {k}: velocities differ by {dv:.2e} m/s"
+        rho = np.concatenate([w.densities(fa), w.densities(fb)])
+        assert np.abs(rho - dw.rho).max() < 1e-4 * dw.rho.max(), f"step {k}: densities"
