@@ -3,6 +3,9 @@
 
   python bench.py --gpus 1 --steps K --warmup W [--config {2,3,4}]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...          (no launcher: bench.py starts torch.distributed.run itself, N ranks, one per GPU)
+`--gpus` decides the number of ranks: it must equal WORLD_SIZE under a launcher, and the node must show N GPUs (ranks sharing
+devices — a functional run only, flagged `ranks_sharing_gpus` — needs `--transport peer --share-devices`).
 
 A "step" is one `LiquidWorld::step(dt = 1/200, g = -9.81 y)`.  Default workload = BASELINE config[1] ("3D DFSPH 1M particles,
 single fluid, XSPH viscosity, 1xMI355X", concretised in SURVEY.md §8d config 2 (A)): a 100^3 lattice block (spacing 2r,
@@ -247,17 +250,40 @@ def main():
                          "xGMI peer-direct transport (flagged stores into hipIpc-mapped windows, salva_amd/csrc/comm_peer.hip)")
     ap.add_argument("--force-slabs", action="store_true",
                     help="take the decomposed (RCCL transport) code path even with one rank; a self-test aid, not a bench mode")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="allow more ranks than GPUs (ranks share the devices round-robin; needs --transport peer): a functional run of "
+                         "the multi-process path on a single-GPU box, never a scaling measurement")
     args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path to measure")
+    ndev = torch.cuda.device_count()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > ndev and not (args.share_devices and args.transport == "peer"):
+        raise SystemExit(f"--gpus {args.gpus} but this node shows {ndev} GPU(s): one rank per GPU over RCCL needs {args.gpus} devices "
+                         f"(a functional run with ranks sharing devices: --transport peer --share-devices)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1), so that
+        # the flag alone decides how many ranks step — the line's n_gpus is then the ranks that actually ran
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: there is no CPU path to measure")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): the two must agree (n_gpus in the line = ranks that stepped)")
     # More ranks than GPUs (a self-test aid on the single-GPU boxes, not a scaling measurement): the ranks share the devices
     # round-robin.  RCCL refuses two ranks on one device, so such a run needs --transport peer, and torch.distributed (used here
     # for the barrier and the max-over-ranks of the elapsed time only) runs over gloo.
-    ndev = torch.cuda.device_count()
     shared = world > ndev
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)

@@ -27,14 +27,29 @@ pub enum ColliderSampling {
 struct HostShapeCtx {
     shape: rapier3d::geometry::SharedShape,
     position: na::Isometry3<Real>,
+    panicked: std::sync::atomic::AtomicBool,
 }
 
+// A panic must not unwind across `extern "C"` (UB): both callbacks run their bodies under catch_unwind.  A panicking aabb
+// hands the library a NaN box, which fails the step with SALVA_HIP_E_INVALID; a panicking projection leaves the points where
+// they are and outside the shape, and sets `panicked`, which `FluidsPipeline::step` turns into an `Err` after the step.
 unsafe extern "C" fn host_aabb(user: *mut std::ffi::c_void, mins: *mut f32, maxs: *mut f32) {
     let ctx = &*(user as *const HostShapeCtx);
-    let aabb = ctx.shape.compute_aabb(&ctx.position); // fluids_pipeline.rs:196-198 (the library loosens it)
+    let r = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| ctx.shape.compute_aabb(&ctx.position))); // fluids_pipeline.rs:196-198 (the library loosens it)
     for a in 0..3 {
-        *mins.add(a) = aabb.mins[a];
-        *maxs.add(a) = aabb.maxs[a];
+        match &r {
+            Ok(aabb) => {
+                *mins.add(a) = aabb.mins[a];
+                *maxs.add(a) = aabb.maxs[a];
+            }
+            Err(_) => {
+                *mins.add(a) = f32::NAN;
+                *maxs.add(a) = f32::NAN;
+            }
+        }
+    }
+    if r.is_err() {
+        ctx.panicked.store(true, std::sync::atomic::Ordering::Relaxed);
     }
 }
 
@@ -42,11 +57,22 @@ unsafe extern "C" fn host_project(user: *mut std::ffi::c_void, n: u32, points: *
     let ctx = &*(user as *const HostShapeCtx);
     for k in 0..n as usize {
         let pt = Point::new(*points.add(3 * k), *points.add(3 * k + 1), *points.add(3 * k + 2));
-        let (proj, _feature) = ctx.shape.project_point_and_get_feature(&ctx.position, &pt); // :213-217
-        for a in 0..3 {
-            *projections.add(3 * k + a) = proj.point[a];
+        let r = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| ctx.shape.project_point_and_get_feature(&ctx.position, &pt))); // :213-217
+        match r {
+            Ok((proj, _feature)) => {
+                for a in 0..3 {
+                    *projections.add(3 * k + a) = proj.point[a];
+                }
+                *is_inside.add(k) = proj.is_inside as u8;
+            }
+            Err(_) => {
+                for a in 0..3 {
+                    *projections.add(3 * k + a) = pt[a];
+                }
+                *is_inside.add(k) = 0;
+                ctx.panicked.store(true, std::sync::atomic::Ordering::Relaxed);
+            }
         }
-        *is_inside.add(k) = proj.is_inside as u8;
     }
 }
 
@@ -59,9 +85,15 @@ struct Entry {
 }
 
 /// fluids_pipeline.rs:64-136.
+///
+/// The library keeps the sampling method of an uploaded entry — for a host shape: two function pointers and the address of
+/// the entry's `HostShapeCtx` — and calls it in every step until `salva_hip_clear_boundary_sampling` detaches it.  An entry that
+/// is unregistered or replaced after its upload therefore moves to `retired`: its context stays alive there until the next
+/// `FluidsPipeline::step` (the first place that can reach the world) has detached the boundary.
 #[derive(Default)]
 pub struct ColliderCouplingSet {
     entries: HashMap<ColliderHandle, Entry>,
+    retired: Vec<Entry>,
 }
 
 impl ColliderCouplingSet {
@@ -69,10 +101,19 @@ impl ColliderCouplingSet {
         Self::default()
     }
     pub fn register_coupling(&mut self, boundary: BoundaryHandle, collider: ColliderHandle, sampling: ColliderSampling) -> Option<BoundaryHandle> {
-        self.entries.insert(collider, Entry { sampling, boundary, uploaded: false, host_shape: None }).map(|e| e.boundary)
+        let old = self.entries.insert(collider, Entry { sampling, boundary, uploaded: false, host_shape: None });
+        old.map(|e| self.retire(e))
     }
     pub fn unregister_coupling(&mut self, collider: ColliderHandle) -> Option<BoundaryHandle> {
-        self.entries.remove(&collider).map(|e| e.boundary)
+        let old = self.entries.remove(&collider);
+        old.map(|e| self.retire(e))
+    }
+    fn retire(&mut self, e: Entry) -> BoundaryHandle {
+        let b = e.boundary;
+        if e.uploaded {
+            self.retired.push(e); // (keeps the host-shape context alive until the library has forgotten it)
+        }
+        b
     }
 }
 
@@ -99,6 +140,17 @@ impl FluidsPipeline {
 
     /// `step(gravity, dt, colliders, bodies)` (fluids_pipeline.rs:48-60) = update_boundaries -> the substep -> transmit_forces.
     pub fn step(&mut self, gravity: &Vector<Real>, dt: Real, colliders: &ColliderSet, bodies: &mut RigidBodySet) -> Result<(), Error> {
+        // ---- entries unregistered or replaced since the last step: detach their boundaries in the library FIRST (it would call
+        // a retired host shape's callbacks otherwise), then let their contexts go.  The boundary keeps its last particles, as the
+        // reference's does after unregister_coupling (fluids_pipeline.rs:116-125).
+        while let Some(e) = self.coupling.retired.last() {
+            // (an entry leaves `retired` only after its detach has succeeded: an early return keeps its context alive)
+            let still_coupled = self.coupling.entries.values().any(|o| o.boundary == e.boundary && o.uploaded);
+            if let (false, Some(slot)) = (still_coupled, self.liquid_world.boundaries().iter().position(|(h, _)| h == e.boundary)) {
+                check(unsafe { ffi::salva_hip_clear_boundary_sampling(self.liquid_world.raw(), slot as u32) })?;
+            }
+            self.coupling.retired.pop();
+        }
         // ---- update_boundaries (:146-264): one pose per collider
         let mut poses: Vec<(u32, ffi::SalvaHipRigidPose, Option<rapier3d::dynamics::RigidBodyHandle>)> = Vec::new();
         for (co_handle, entry) in self.coupling.entries.iter_mut() {
@@ -130,7 +182,7 @@ impl FluidsPipeline {
                             Some(shape) => check(unsafe { ffi::salva_hip_set_boundary_dynamic_sampling(raw, slot, &shape, groups.memberships.bits(), groups.filter.bits()) })?,
                             None => {
                                 // any other parry shape: the two parry calls of the loop stay here
-                                let ctx = Box::new(HostShapeCtx { shape: collider.shared_shape().clone(), position: *collider.position() });
+                                let ctx = Box::new(HostShapeCtx { shape: collider.shared_shape().clone(), position: *collider.position(), panicked: Default::default() });
                                 let host = ffi::SalvaHipHostShape {
                                     aabb: Some(host_aabb),
                                     project: Some(host_project),
@@ -171,7 +223,15 @@ impl FluidsPipeline {
             poses.push((slot, pose, body.map(|(p, _)| p)));
         }
         // ---- the substep
-        self.liquid_world.step(dt, &na::Vector3::new(gravity.x, gravity.y, gravity.z))?;
+        let stepped = self.liquid_world.step(dt, &na::Vector3::new(gravity.x, gravity.y, gravity.z));
+        for entry in self.coupling.entries.values() {
+            if let Some(ctx) = entry.host_shape.as_ref() {
+                if ctx.panicked.swap(false, std::sync::atomic::Ordering::Relaxed) {
+                    return Err(Error { code: ffi::SALVA_HIP_E_INVALID, message: "a host-shape callback (compute_aabb / project_point) panicked during the step".into() });
+                }
+            }
+        }
+        stepped?;
         // ---- transmit_forces (:266-287): sum_i apply_impulse_at_point(f_i dt, x_i) = apply_impulse(F dt) + apply_torque_impulse(T dt)
         for (slot, pose, parent) in poses {
             let Some(parent) = parent else { continue };

@@ -410,6 +410,13 @@ typedef struct SalvaHipHostShape {
 int salva_hip_set_boundary_dynamic_sampling_host(SalvaHipWorld* world, uint32_t slot, const SalvaHipHostShape* collider_shape,
                                                  uint32_t memberships, uint32_t filter);
 /* (salva_hip_boundary_len reports what the last step emitted.) */
+/* `ColliderCouplingSet::unregister_coupling` (fluids_pipeline.rs:116-125) as the library sees it: forget the sampling method of
+ * boundary `slot` — static sample points, collider shape, host callbacks and their `user` pointer.  The boundary keeps the
+ * particles it holds at that moment and is a plain boundary from then on (the reference's boundary object likewise stays in
+ * the world with its last particles once its coupling entry is gone).  MUST be called before the memory behind a
+ * SalvaHipHostShape's callbacks or `user` is released: the library calls them in every step while they are registered.
+ * No-op for a boundary without a sampling method. */
+int salva_hip_clear_boundary_sampling(SalvaHipWorld* world, uint32_t slot);
 /* For a dynamically sampled boundary: (fluid slot, particle index) of the fluid particle behind each of its points, in the
  * order of salva_hip_get_boundary_particles (the order itself is unspecified, as the reference's hash-grid walk is). */
 int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t* fluid_slots, uint32_t* indices);

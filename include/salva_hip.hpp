@@ -514,6 +514,20 @@ class LiquidWorld {  // liquid_world.rs
         if (pose.has_body) boundaries_[h].wants_forces = pose.is_dynamic != 0;
         check(salva_hip_update_boundary_pose(w_, (uint32_t)h, &pose));
     }
+    // `unregister_coupling` as the library sees it (salva_hip_clear_boundary_sampling): the boundary keeps the particles it holds
+    // and becomes a plain boundary; call it before the memory behind Boundary::dynamic_host's callbacks / user pointer goes away
+    void clear_boundary_sampling(BoundaryHandle h) {
+        Boundary& b = boundaries_[h];
+        upload(b, (uint32_t)h);
+        const uint64_t n = salva_hip_boundary_len(w_, (uint32_t)h);
+        b.positions.assign(n, Vec3{0, 0, 0}); b.velocities.assign(n, Vec3{0, 0, 0});
+        if (n) check(salva_hip_get_boundary_particles(w_, (uint32_t)h, b.positions[0].data(), b.velocities[0].data()));
+        check(salva_hip_clear_boundary_sampling(w_, (uint32_t)h));
+        b.sampling.clear();
+        b.dynamic_shape = SalvaHipShape{};
+        b.dynamic_host = SalvaHipHostShape{nullptr, nullptr, nullptr};
+        b.dirty_ = false;  // (the device holds exactly these particles)
+    }
     void boundary_wrench(BoundaryHandle h, const Vec3& point, Vec3& force, Vec3& torque) {
         check(salva_hip_get_boundary_wrench(w_, (uint32_t)h, point.data(), force.data(), torque.data()));
     }

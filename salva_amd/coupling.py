@@ -139,16 +139,31 @@ class HostShapeSampling:
     def __init__(self, aabb, project):
         self._aabb, self._project = aabb, project
 
+        # An exception raised inside a ctypes callback is printed and swallowed by ctypes: the step would go on with whatever the
+        # output arrays held.  The thunks therefore catch it, park it on this object and hand the library a NaN box / all-outside
+        # projections (a NaN box makes the step fail with E_INVALID); LiquidWorld.step_with_coupling re-raises it after the step.
+        self._error = None
+
         def aabb_cb(_user, mins, maxs):
-            lo, hi = self._aabb()
-            for a in range(3):
-                mins[a], maxs[a] = float(lo[a]), float(hi[a])
+            try:
+                lo, hi = self._aabb()
+                for a in range(3):
+                    mins[a], maxs[a] = float(lo[a]), float(hi[a])
+            except BaseException as e:  # noqa: BLE001
+                self._error = self._error or e
+                for a in range(3):
+                    mins[a] = maxs[a] = float("nan")
 
         def project_cb(_user, n, pts, proj, inside):
-            p = np.ctypeslib.as_array(pts, shape=(n, 3))
-            out, ins = self._project(p.copy())
-            np.ctypeslib.as_array(proj, shape=(n, 3))[:] = np.asarray(out, F32).reshape(n, 3)
-            np.ctypeslib.as_array(inside, shape=(n,))[:] = np.asarray(ins).astype(np.uint8).reshape(n)
+            try:
+                p = np.ctypeslib.as_array(pts, shape=(n, 3))
+                out, ins = self._project(p.copy())
+                np.ctypeslib.as_array(proj, shape=(n, 3))[:] = np.asarray(out, F32).reshape(n, 3)
+                np.ctypeslib.as_array(inside, shape=(n,))[:] = np.asarray(ins).astype(np.uint8).reshape(n)
+            except BaseException as e:  # noqa: BLE001
+                self._error = self._error or e
+                np.ctypeslib.as_array(proj, shape=(n, 3))[:] = np.ctypeslib.as_array(pts, shape=(n, 3))
+                np.ctypeslib.as_array(inside, shape=(n,))[:] = 0
 
         # (the ctypes thunks must outlive the registration: they hang on this object, which the coupling entry keeps)
         self._thunks = (L.HOST_AABB_FN(aabb_cb), L.HOST_PROJECT_FN(project_cb))
@@ -172,12 +187,41 @@ class ColliderCouplingSet:
 
     def register_coupling(self, boundary, collider, body: Optional[RigidBody], sampling_method):
         old = self.entries.get(collider)
+        if old is not None:
+            self._detach(old)
         self.entries[collider] = _Entry(boundary, body, sampling_method)
         return old.boundary if old else None
 
     def unregister_coupling(self, collider):
         e = self.entries.pop(collider, None)
+        if e is not None:
+            self._detach(e)
         return e.boundary if e else None
+
+    @staticmethod
+    def _detach(e: _Entry):
+        """fluids_pipeline.rs:116-125: the entry goes, the boundary stays in the world with the particles it holds.  The library
+        must forget the sampling method BEFORE the entry is dropped: a host shape's ctypes thunks die with it, and every step calls
+        them while they are registered (salva_hip_clear_boundary_sampling)."""
+        b = e.boundary
+        w = b._world
+        if not e.uploaded or w is None or b._slot < 0:
+            return
+        pos, vel = w._boundary_particles(b)
+        L.check(w._L.salva_hip_clear_boundary_sampling(w._h, b._slot))
+        b._positions, b._velocities = np.ascontiguousarray(pos, F32).copy(), np.ascontiguousarray(vel, F32).copy()
+        b._sampled = b._dynamic = False
+        b._n_sampled = 0
+        b._dirty = False  # (the device already holds exactly these particles)
+        e.uploaded = False
+
+    def raise_pending(self):
+        """Re-raise an exception a host-shape callback parked during the last step (HostShapeSampling)."""
+        for e in self.entries.values():
+            err = getattr(e.sampling, "_error", None)
+            if err is not None:
+                e.sampling._error = None
+                raise err
 
     # CouplingManager::update_boundaries (:146-264), StaticSampling arm
     def update_boundaries(self, world):

@@ -206,6 +206,15 @@ int salva_hip_set_boundary_dynamic_sampling_host(SalvaHipWorld* world, uint32_t 
     });
 }
 
+int salva_hip_clear_boundary_sampling(SalvaHipWorld* world, uint32_t slot) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
+        world->w->clear_boundary_sampling(slot);
+        return SALVA_HIP_OK;
+    });
+}
+
 int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t* fluid_slots, uint32_t* indices) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");

@@ -73,6 +73,7 @@ class World {
     void update_boundary_pose(uint32_t slot, const SalvaHipRigidPose& pose);
     void set_boundary_dynamic_sampling(uint32_t slot, const SalvaHipShape& shape, uint32_t memberships, uint32_t filter);
     void set_boundary_dynamic_sampling_host(uint32_t slot, const SalvaHipHostShape& shape, uint32_t memberships, uint32_t filter);
+    void clear_boundary_sampling(uint32_t slot);
     uint64_t boundary_len(uint32_t slot) const;
     void get_boundary_sources(uint32_t slot, uint32_t* fluid_slots, uint32_t* indices);
     void set_force_callback(SalvaHipForceCallback cb, void* user, SalvaHipWorld* owner) { force_cb = cb; force_user = user; force_owner = owner; }

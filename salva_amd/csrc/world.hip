@@ -1828,6 +1828,18 @@ void World::set_boundary_dynamic_sampling_host(uint32_t slot, const SalvaHipHost
     b.dyn_src = std::make_shared<DevBuf<uint32_t>>();
 }
 
+// unregister_coupling (fluids_pipeline.rs:116-125): the boundary stays, with the particles it holds now, as a plain boundary;
+// nothing of the sampling method — in particular no host callback or user pointer — is kept
+void World::clear_boundary_sampling(uint32_t slot) {
+    if (slot >= bounds.size()) throw HipError(SALVA_HIP_E_INVALID, "boundary slot out of range");
+    BoundarySlot& b = bounds[slot];
+    b.sampling.reset();
+    b.dyn_kind = 0;
+    b.dyn_shape = SalvaHipShape{};
+    b.dyn_host = SalvaHipHostShape{};
+    b.dyn_src.reset();
+}
+
 // parameters of a built-in collider shape (include/salva_hip.h); throws for any other kind
 int shape_param_count(int kind) {
     switch (kind) {

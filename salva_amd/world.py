@@ -966,7 +966,13 @@ class LiquidWorld:
         update_boundaries -> the substep -> transmit_forces."""
         self.sync_to_device()
         coupling.update_boundaries(self)
-        st = self.step(dt, gravity)
+        try:
+            st = self.step(dt, gravity)
+        finally:
+            # an exception inside a host-shape callback was parked by its thunk (ctypes cannot propagate it): it is the cause,
+            # whatever the library made of the NaN box it was handed instead
+            if hasattr(coupling, "raise_pending"):
+                coupling.raise_pending()
         coupling.transmit_forces(self, dt)
         return st
 

@@ -215,6 +215,84 @@ def test_host_shape_errors():
         w.step_with_coupling(DT, GRAVITY, c)
 
 
+def test_unregistering_a_host_shape_detaches_it_before_its_callbacks_die():
+    """the library keeps the host shape's callbacks and calls them in every step; `unregister_coupling` /
+    replacing the entry dropped the ctypes thunks while they were still registered.  Now the set detaches the boundary first
+    (salva_hip_clear_boundary_sampling): it stays in the world as a plain boundary with the particles it last held, as the
+    reference's does (fluids_pipeline.rs:116-125), and later steps never enter the retired callbacks."""
+    import gc
+
+    n = 10
+    pos = scenes.jitter(scenes.cube_fluid_positions(n, n, n, R), 0.1 * R, seed=5)
+    pos[:, 1] += F(TORUS_r + n * R + 0.01)
+    w = LiquidWorld(DFSPHSolver(), R, 2.0)
+    fl = Fluid(pos, R, 1000.0)
+    fl.nonpressure_forces.append(XSPHViscosity(0.5, 0.5))
+    h = w.add_fluid(fl)
+    b = w.add_boundary(Boundary(np.zeros((0, 3), F)))
+    calls = {"n": 0}
+    aabb, project = torus_callbacks()
+
+    def counted_project(p):
+        calls["n"] += 1
+        return project(p)
+
+    c = ColliderCouplingSet()
+    c.register_coupling(b, "torus", None, HostShapeSampling(aabb, counted_project))
+    for _ in range(40):
+        w.step_with_coupling(DT, GRAVITY, c)
+        if b.num_particles() > 20:
+            break
+    held = b.num_particles()
+    assert held > 20 and calls["n"] > 0
+    before_p = np.array(b.positions)
+    assert c.unregister_coupling("torus") is b
+    gc.collect()  # the thunks are gone now: a library that still held them would call freed memory below
+    seen = calls["n"]
+    for _ in range(5):
+        w.step_with_coupling(DT, GRAVITY, c)
+    assert calls["n"] == seen, "a retired host shape was called"
+    assert b.num_particles() == held and np.array_equal(b.positions, before_p), "the detached boundary keeps its last particles"
+    assert np.isfinite(h.positions).all()
+    # replacing an uploaded entry detaches the old sampling the same way; the new one takes over at the next step
+    c.register_coupling(b, "torus", None, HostShapeSampling(aabb, counted_project))
+    w.step_with_coupling(DT, GRAVITY, c)
+    old = c.register_coupling(b, "torus", None, HostShapeSampling(*torus_callbacks()))
+    assert old is b
+    gc.collect()
+    seen = calls["n"]
+    for _ in range(3):
+        w.step_with_coupling(DT, GRAVITY, c)
+    assert calls["n"] == seen
+
+
+def test_an_exception_in_a_host_shape_callback_surfaces_from_the_step():
+    """ctypes prints and swallows an exception raised inside a callback; the thunks park it and the step re-raises it."""
+    w = LiquidWorld(DFSPHSolver(), R, 2.0)
+    pos = scenes.cube_fluid_positions(6, 6, 6, R)
+    w.add_fluid(Fluid(pos, R, 1000.0))
+    b = w.add_boundary(Boundary(np.zeros((0, 3), F)))
+    c = ColliderCouplingSet()
+
+    class Boom(RuntimeError):
+        pass
+
+    def bad_project(p):
+        raise Boom("projection failed")
+
+    e = F([1.0, 1.0, 1.0])
+    c.register_coupling(b, "x", None, HostShapeSampling(lambda: (-e, e), bad_project))
+    with pytest.raises(Boom):
+        w.step_with_coupling(DT, GRAVITY, c)
+
+    def bad_aabb():
+        raise Boom("no box")
+
+    c.register_coupling(b, "x", None, HostShapeSampling(bad_aabb, lambda p: (p, np.zeros(len(p), bool))))
+    with pytest.raises(Boom):
+        w.step_with_coupling(DT, GRAVITY, c)
+
+
 def test_cpp_mirror_host_shape_example():
     """examples/host_shape3.cpp: the torus through include/salva_hip.hpp's `Boundary::dynamic_host_shape`, with
     `DFSPHSolverT<Poly6Kernel, SpikyKernel>` as the solver (the C++ mirror of the two round-3 additions in one program)."""
