@@ -459,6 +459,8 @@ def main():
 if __name__ == "__main__":
     try:
         main()
+    except SystemExit:
+        raise
     except BaseException:  # noqa: BLE001
         # in a multi-rank run the other ranks are blocked in a neighbour exchange: die at once so that the launcher
         # tears the job down instead of waiting for a timeout

@@ -16,10 +16,19 @@
 // rank can be at most one message ahead of the neighbour that still reads the previous one (put(t+2) needs get(t+1), which
 // needs the neighbour's put(t+1), which follows its get(t)).  The same argument covers the all-reduce mailboxes.
 //
-// A wait that is not satisfied within PEER_TIMEOUT_TICKS of the 100 MHz wall clock (30 s: ranks reach their first exchange
-// seconds apart) gives up, records the fact in a host-mapped word and lets the kernel finish: the host throws at its next call
-// instead of leaving a kernel spinning.
+// A wait that is not satisfied within the transport's timeout (30 s by default: ranks reach their first exchange seconds
+// apart; SALVA_HIP_PEER_TIMEOUT_S = seconds, read when the transport is connected — raise it under a debugger or when first-step
+// allocations are slow, 0 = wait for ever) gives up, records the fact in a host-mapped word and lets the kernel finish: the host
+// throws at its next call instead of leaving a kernel spinning.
+//
+// STATUS: EXPERIMENTAL.  Every run so far had all ranks on ONE GPU (the boxes available have one): the IPC mapping then stays
+// inside one HBM, and no store has crossed xGMI.  What that leaves unexercised is the coherence of remote stores against the
+// reader GPU's caches; the reads of a window after its flag are therefore system-scope / nontemporal loads (they must not be
+// served from a line cached before the flag was seen), on top of the acquire + fence the memory model already asks for.
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <string>
 #include <vector>
 
 #include "comm.h"
@@ -31,7 +40,7 @@ namespace {
 
 constexpr int PEER_MAX_RANKS = 64;
 constexpr int PEER_RED_CHUNK = 256;                       // values per all-reduce pass
-constexpr unsigned long long PEER_TIMEOUT_TICKS = 3000000000ull;  // 30 s of the 100 MHz wall clock
+constexpr unsigned long long PEER_TICKS_PER_S = 100000000ull;  // wall_clock64(): 100 MHz
 constexpr int PEER_COPY_BLOCKS = 64;                      // most blocks per direction of a put / get (16 KB each)
 constexpr size_t PEER_ALIGN = 256;
 
@@ -48,11 +57,13 @@ __device__ __forceinline__ unsigned char* peer_slot(void* window, int side, int 
     return (unsigned char*)window + PEER_HEADER_BYTES + (size_t)(side * 2 + parity) * slot_bytes;
 }
 
-__device__ __forceinline__ bool peer_wait(unsigned long long* flag, unsigned long long seq, unsigned int* timed_out) {
+// `timeout_ticks` == 0: no timeout
+__device__ __forceinline__ bool peer_wait(unsigned long long* flag, unsigned long long seq, unsigned int* timed_out,
+                                          unsigned long long timeout_ticks) {
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
         __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
+        if (timeout_ticks && wall_clock64() - t0 > timeout_ticks) {
             __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return false;
         }
@@ -60,17 +71,20 @@ __device__ __forceinline__ bool peer_wait(unsigned long long* flag, unsigned lon
     return true;
 }
 
-// bytes [0, n): 16-byte vectors where both pointers allow it, single bytes for the rest
+// bytes [0, n): 16-byte vectors where both pointers allow it, single bytes for the rest.  FROM_WINDOW: `src` is this rank's
+// window, filled by a neighbour's stores — nontemporal loads, which do not take a line an earlier message left in a cache.
+template <bool FROM_WINDOW>
 __device__ __forceinline__ void peer_copy(unsigned char* dst, const unsigned char* src, size_t n, unsigned int part, unsigned int parts) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const unsigned int tid = part * blockDim.x + threadIdx.x, nthreads = parts * blockDim.x;
     size_t body = 0;
     if (((uintptr_t)dst & 15u) == 0 && ((uintptr_t)src & 15u) == 0) {
         body = n & ~(size_t)15;
-        const uint4* s4 = (const uint4*)src;
-        uint4* d4 = (uint4*)dst;
-        for (size_t i = tid; i < body / 16; i += nthreads) d4[i] = s4[i];
+        const u32x4* s4 = (const u32x4*)src;
+        u32x4* d4 = (u32x4*)dst;
+        for (size_t i = tid; i < body / 16; i += nthreads) d4[i] = FROM_WINDOW ? __builtin_nontemporal_load(s4 + i) : s4[i];
     }
-    for (size_t i = body + tid; i < n; i += nthreads) dst[i] = src[i];
+    for (size_t i = body + tid; i < n; i += nthreads) dst[i] = FROM_WINDOW ? __builtin_nontemporal_load(src + i) : src[i];
 }
 
 struct PeerPut {
@@ -88,7 +102,7 @@ __global__ void __launch_bounds__(256) k_peer_put(PeerPut a) {
     const int link = blockIdx.y;
     if (!a.window[link]) return;
     unsigned char* dst = peer_slot(a.window[link], a.side_there[link], (int)(a.seq[link] & 1ull), a.slot_bytes);
-    peer_copy(dst, a.src[link], a.n[link], blockIdx.x, gridDim.x);
+    peer_copy<false>(dst, a.src[link], a.n[link], blockIdx.x, gridDim.x);
     __threadfence_system();  // my stores have reached the neighbour's memory before the ticket is drawn
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -109,6 +123,7 @@ struct PeerGet {
     unsigned long long seq[2];
     size_t slot_bytes;
     unsigned int* timed_out;       // host-mapped
+    unsigned long long timeout_ticks;
 };
 
 __global__ void __launch_bounds__(256) k_peer_get(PeerGet a) {
@@ -116,11 +131,11 @@ __global__ void __launch_bounds__(256) k_peer_get(PeerGet a) {
     if (!a.active[link]) return;
     PeerHeader* h = (PeerHeader*)a.window;
     __shared__ int ok;
-    if (threadIdx.x == 0) ok = peer_wait(&h->msg_flag[link], a.seq[link], a.timed_out) ? 1 : 0;
+    if (threadIdx.x == 0) ok = peer_wait(&h->msg_flag[link], a.seq[link], a.timed_out, a.timeout_ticks) ? 1 : 0;
     __syncthreads();
     if (!ok) return;
     __threadfence_system();  // every wave of the block reads the window after the flag
-    peer_copy(a.dst[link], peer_slot(a.window, link, (int)(a.seq[link] & 1ull), a.slot_bytes), a.n[link], blockIdx.x, gridDim.x);
+    peer_copy<true>(a.dst[link], peer_slot(a.window, link, (int)(a.seq[link] & 1ull), a.slot_bytes), a.n[link], blockIdx.x, gridDim.x);
 }
 
 struct PeerReduce {
@@ -128,6 +143,7 @@ struct PeerReduce {
     int rank, size, n;
     unsigned long long seq;
     unsigned int* timed_out;
+    unsigned long long timeout_ticks;
 };
 
 // One block of PEER_RED_CHUNK threads.  T = float or unsigned long long; every rank adds the contributions in rank order, so
@@ -149,14 +165,14 @@ __global__ void __launch_bounds__(PEER_RED_CHUNK) k_peer_allreduce(PeerReduce a,
     if (k == 0) bad = 0;
     __syncthreads();
     PeerHeader* mine = (PeerHeader*)a.windows[a.rank];
-    if (k < a.size && !peer_wait(&mine->red_flag[k], a.seq, a.timed_out)) bad = 1;
+    if (k < a.size && !peer_wait(&mine->red_flag[k], a.seq, a.timed_out, a.timeout_ticks)) bad = 1;
     __syncthreads();
     if (bad) return;
     __threadfence_system();
     if (k < a.n) {
         T acc = T(0);
         for (int r = 0; r < a.size; ++r) {
-            const unsigned long long bits = mine->red[par][r][k];
+            const unsigned long long bits = __hip_atomic_load(&mine->red[par][r][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             T v;
             memcpy(&v, &bits, sizeof(T));
             acc += v;
@@ -204,6 +220,12 @@ class PeerTransport : public Transport {
     // because the all-reduce writes to all of them
     PeerTransport(PeerSetup* setup, const unsigned char* handles) : rank_(setup->rank), size_(setup->size), device_(setup->device), slot_(setup->slot_bytes) {
         std::unique_ptr<PeerSetup> own(setup);
+        if (const char* e = getenv("SALVA_HIP_PEER_TIMEOUT_S")) {
+            char* end = nullptr;
+            const double sec = strtod(e, &end);
+            if (end == e || !(sec >= 0.0) || sec > 1.0e6) throw HipError(-2, "SALVA_HIP_PEER_TIMEOUT_S: seconds, 0 (no timeout) .. 1e6");
+            timeout_ticks_ = (unsigned long long)(sec * (double)PEER_TICKS_PER_S);
+        }
         SALVA_HIP_CHECK(hipSetDevice(device_));
         win_.assign(size_, nullptr);
         try {
@@ -262,6 +284,7 @@ class PeerTransport : public Transport {
             put.tickets = tickets_;
             get.window = win_[rank_];
             get.timed_out = timed_out_;
+            get.timeout_ticks = timeout_ticks_;
             for (int l = 0; l < 2; ++l) {
                 if (!act[l] || r >= rounds[l]) continue;
                 const size_t off = r * slot_;
@@ -313,13 +336,15 @@ class PeerTransport : public Transport {
             a.rank = rank_; a.size = size_; a.n = n < PEER_RED_CHUNK ? n : PEER_RED_CHUNK;
             a.seq = ++red_seq_;
             a.timed_out = timed_out_;
+            a.timeout_ticks = timeout_ticks_;
             hipLaunchKernelGGL(k_peer_allreduce<T>, dim3(1), dim3(PEER_RED_CHUNK), 0, s, a, buf);
         }
         SALVA_HIP_CHECK(hipGetLastError());
     }
     void check_timeout() {
         if (timed_out_ && *(volatile unsigned int*)timed_out_)
-            throw HipError(-1, "peer transport: a neighbour's message did not arrive within 30 s (a rank died, or the ranks' calls do not match)");
+            throw HipError(-1, "peer transport: a neighbour's message did not arrive within " + std::to_string(timeout_ticks_ / PEER_TICKS_PER_S) +
+                                   " s (a rank died, or the ranks' calls do not match; SALVA_HIP_PEER_TIMEOUT_S moves the limit)");
     }
     void release() {
         for (int r = 0; r < (int)win_.size(); ++r)
@@ -336,6 +361,7 @@ class PeerTransport : public Transport {
     size_t slot_;
     std::vector<void*> win_;
     unsigned long long msg_seq_[2] = {0, 0}, red_seq_ = 0;
+    unsigned long long timeout_ticks_ = 30ull * PEER_TICKS_PER_S;
     unsigned int* tickets_ = nullptr;
     uint64_t* d_cnt_ = nullptr;
     uint64_t* h_cnt_ = nullptr;

@@ -41,10 +41,13 @@ struct TileAcc {
     uint32_t nonempty;  // tiles that own at least one particle
     uint32_t max_s, max_sb, max_nsl;  // running maxima of the three (carried through the same scan)
     uint32_t max_sum;  // running maximum of (fluid halo slots padded to 64) + (boundary halo slots) of one tile (TileLds::max_sum)
+    uint32_t max_raw;  // running maximum of (fluid halo slots) + (boundary halo slots) of one tile, no padding: the plane layouts
+                       // (tile.h stage_p3), which are filled through registers, slot by slot
+    uint32_t pad_;
     __host__ __device__ TileAcc operator+(const TileAcc& o) const {
         return TileAcc{s + o.s, sb + o.sb, nsl + o.nsl, nonempty + o.nonempty, max_s > o.max_s ? max_s : o.max_s,
                        max_sb > o.max_sb ? max_sb : o.max_sb, max_nsl > o.max_nsl ? max_nsl : o.max_nsl,
-                       max_sum > o.max_sum ? max_sum : o.max_sum};
+                       max_sum > o.max_sum ? max_sum : o.max_sum, max_raw > o.max_raw ? max_raw : o.max_raw, 0u};
     }
 };
 
@@ -140,6 +143,11 @@ struct StepCtx {
     uint32_t nmodels, nbmodels;
     const float* rho0_tab;     // density0 of each fluid model
     float rho0_single;         // = rho0_tab[0]; used when nmodels == 1 (saves a dependent load)
+    // > 0: EVERY fluid particle of the working set (ghosts included) has exactly this mass (k_cell_keys reduces min / max of
+    // posm.w every step): the evaluate kernels then stage 24 bytes per halo slot instead of 32 (no mass in LDS; tile.h stage_p3)
+    // and multiply the finished sum by it.  0: masses differ (non-uniform volumes, fluids of different density0), or unknown.
+    float mass_uniform;
+    uint32_t bvel_zero;        // 1: every boundary velocity is exactly zero (plain boundaries uploaded at rest, the usual tank)
     const uint8_t* ff_ok;      // [nmodels*nmodels] InteractionGroups::test between fluids (diagonal = 1)
     const uint8_t* fb_ok;      // [nmodels*nbmodels]
     const uint8_t* bb_ok;      // [nbmodels*nbmodels] (diagonal = 1)
@@ -166,6 +174,8 @@ struct StepCtx {
 #endif
 };
 
+constexpr uint32_t MASS_SLOTS = 64;  // {min, max} pairs k_cell_keys spreads its mass range over (grid.hip)
+
 // Result block the host reads back (pinned mirror).
 struct Readback {
     float err;            // max over models of (sum / nparticles)
@@ -178,6 +188,9 @@ struct Readback {
     uint32_t max_cnt_ff, max_cnt_fb;       // } longest contact lists of the step (capacity check)
     uint32_t dcs_count, pad_;          // points emitted by the last DynamicContactSampling pass
     uint64_t ncontacts_own_ff, ncontacts_own_fb;  // list totals over the particles this rank owns (decomposed runs)
+    uint32_t mass_mm[2];  // bit patterns of the smallest / largest posm.w seen by k_cell_keys since the last publication of the totals
+                          // (host side of the publication only; on the device the range lives in World::mass_slots)
+    uint32_t pad2_[2];
 };
 
 }  // namespace salva

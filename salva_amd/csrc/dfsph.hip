@@ -238,8 +238,69 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
     });
     E.finish(c, t.slot);
 }
+// The same pass over the 24-byte plane layout (tile.h stage_p3), taken when every particle has the same mass
+// (c.mass_uniform > 0): three tiles per CU instead of two while the halos stay below P3_DS_THREE slots.
+// Register budget: P3_DS_THREE only pays with 24 waves per CU, i.e. at most 80 VGPRs.
+#define SALVA_P3_BOUNDS(DS) __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? 6 : 5)
+template <uint32_t DS>
+__global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
+    const SolveCtl* const rec = solve_record(c);
+    if (rec && rec->done) return;  // the solve converged earlier in this batch
+    const float4* const win = rec ? solve_w_in(c, rec) : c.w;
+    lds_base_check();
+    Tile t;
+    t.setup(c);
+    if (t.skipped()) return;
+    if (t.empty()) { TileErr::zero(c, t.slot); return; }
+    struct Own { float4 pi, wi; float alpha; uint32_t mi, cnt, cntb, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], win[i], c.alpha[i], c.model[i], c.nff[i], c.nb ? c.nfb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist8 = p3_dist8<DS>(t);
+    t.stage_p3(c, static_cast<const float4*>(c.posm), win, dist8);
+    const float4* Bp = nullptr;
+    t.stage_boundary(c, Bp);
+    TileErrC E;
+    E.init(reinterpret_cast<float*>(t.pool + t.pool_used), c);
+    Tile::staged_barrier();
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
+        float err = 0.0f;
+        uint32_t mi = 0;
+        if (active) {
+            mi = o.mi;
+            const float rho0 = rho0_of(c, mi);
+            float div = 0.0f;
+            if (o.cnt + o.cntb >= c.min_neighbors_for_divergence) {
+                const float4 pi = o.pi, wi = o.wi;
+                div += near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8)
+                            : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8);
+                for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                    const float4 pj = Bp[s];
+                    const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                    const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                    div += (wi.x * dx + wi.y * dy + wi.z * dz) * g * (pj.w * rho0);  // boundary velocity ignored (:332-333)
+                });
+                div = fmaxf(div, 0.0f);
+            }
+            c.kappa[i] = div * o.alpha;
+            err = div / rho0;
+        }
+        E.add(c, err, mi, active && !is_ghost(c, i));
+    });
+    E.finish(c, t.slot);
+}
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence, c, L, s);
+    if (c.mass_uniform > 0.0f) {
+        const uint32_t ds = pick_ds_p3(L.max_halo_fluid);
+        SALVA_LAUNCH_P3(k_divergence_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
+        return;
+    }
     const uint32_t ds = pick_ds(pw_slots(L));
     SALVA_LAUNCH_FIXED(k_divergence, ds, c, L, pw_bytes(L, ds, true), s, c);
 }
@@ -306,8 +367,72 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
         wout[i] = d;
     });
 }
+// the plane-layout form (tile.h stage_p2): every particle has the mass c.mass_uniform
+#ifndef SALVA_P2_WAVES
+#define SALVA_P2_WAVES 6
+#endif
+#define SALVA_P2_BOUNDS(DS) __launch_bounds__(TILE_MAX_THREADS, (DS) == P2_DS_THREE ? SALVA_P2_WAVES : 5)
+template <uint32_t DS>
+__global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_dt_prev) {
+    const SolveCtl* const rec = solve_record(c);
+    const bool was_done = rec && rec->done;
+    const float4* const win = rec ? solve_w_in(c, rec) : c.w;
+    float4* const wout = c.spec_k >= 0 ? ((win == c.w) ? c.w2 : c.w) : c.w;
+    lds_base_check();
+    if (c.spec_k >= 0 && blockIdx.x == 0) {
+        spec_decide(c, reinterpret_cast<float*>(tile_smem));
+        __syncthreads();
+    }
+    if (was_done) return;
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    struct Own { float4 pi, wi; float ki; uint32_t cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], win[i], c.kappa[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist8 = p2_dist8<DS>(t);
+    t.stage_p2(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), dist8);
+    Tile::staged_barrier();
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
+        if (!active) return;
+        const float4 pi = o.pi;
+        const uint32_t mi = __float_as_uint(o.wi.w);
+        const float rho0 = rho0_of(c, mi);
+        const float ki = o.ki;
+        float4 d = o.wi;
+        float sx, sy, sz;
+        if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, [&](float kj) { return ki + kj; }, sx, sy, sz);
+        else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, [&](float ka, float kb) { return f2{ki + ka, ki + kb}; }, sx, sy, sz);
+        d.x -= sx; d.y -= sy; d.z -= sz;
+        for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+            const float4 pj = p2_boundary_pos(t, s, dist8);
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+            const float coeff = -ki * pj.w * rho0 * g;
+            const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
+            d.x += ex; d.y += ey; d.z += ez;
+            if (c.bforce && !is_ghost(c, i)) {
+                const float fs = -inv_dt_prev * pi.w;
+                const uint32_t jb = boundary_sorted_of_slot(c, t, s);
+                apply_boundary_force(c, jb, __float_as_uint(c.bvel[jb].w), ex * fs, ey * fs, ez * fs);
+            }
+        });
+        wout[i] = d;
+    });
+}
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence_apply, c, L, inv_dt_prev, s);
+    if (c.mass_uniform > 0.0f) {
+        const uint32_t ds = pick_ds_p2(L.raw_slots());
+        SALVA_LAUNCH_P2(k_divergence_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt_prev);
+        return;
+    }
     const uint32_t ds = pick_ds(pk_slots(L));
     SALVA_LAUNCH_FIXED(k_divergence_apply, ds, c, L, pk_bytes(L, ds), s, c, inv_dt_prev);
 }
@@ -423,8 +548,67 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
     }
 #endif
 }
+// the plane-layout form (see k_divergence_p3)
+template <uint32_t DS>
+__global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
+    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
+    lds_base_check();
+    Tile t;
+    t.setup(c);
+    if (t.skipped()) return;
+    if (t.empty()) { TileErr::zero(c, t.slot); return; }
+    struct Own { float4 pi, wi; float rho, alpha; uint32_t mi, cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.w[i], c.rho[i], c.alpha[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist8 = p3_dist8<DS>(t);
+    t.stage_p3(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), dist8);
+    // (boundaries at rest — the usual tank — contribute w_i alone: their velocities are not staged, which is what keeps a
+    // 1770-slot fluid halo plus 330 wall slots at three tiles per CU)
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    if (c.bvel_zero) t.stage_boundary(c, Bp);
+    else t.stage_boundary(c, Bp, Bv);
+    TileErrC E;
+    E.init(reinterpret_cast<float*>(t.pool + t.pool_used), c);
+    Tile::staged_barrier();
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
+        float err = 0.0f;
+        uint32_t mi = 0;
+        if (active) {
+            mi = o.mi;
+            const float rho0 = rho0_of(c, mi);
+            const float4 pi = o.pi, wi = o.wi;
+            float delta = near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8)
+                               : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8);
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const float4 pj = Bp[s];
+                const float4 vj = c.bvel_zero ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : Bv[s];  // (w - 0 = w exactly)
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                delta += pj.w * rho0 * (((wi.x - vj.x) * dx + (wi.y - vj.y) * dy + (wi.z - vj.z) * dz) * g);
+            });
+            const float rs = o.rho + delta * dt;
+            if (!(rs != 0.0f)) atomicOr(c.flags, 1u);  // assert!(!predicted_density.is_zero()) :145 (also catches NaN)
+            err = (rs < rho0) ? 0.0f : rs / rho0 - 1.0f;
+            c.kappa[i] = (rs - rho0) * o.alpha;
+        }
+        E.add(c, err, mi, active && !is_ghost(c, i));
+    });
+    E.finish(c, t.slot);
+}
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pred_density, c, L, dt, s);
+    if (c.mass_uniform > 0.0f) {
+        const uint32_t ds = pick_ds_p3(L.max_halo_fluid);
+        SALVA_LAUNCH_P3(k_pred_density_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
+        return;
+    }
     const uint32_t ds = pick_ds(pw_slots(L));
     SALVA_LAUNCH_FIXED(k_pred_density, ds, c, L, pw_bytes(L, ds, true), s, c, dt);
 }
@@ -486,8 +670,64 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
         c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
     });
 }
+template <uint32_t DS>
+__global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt) {
+    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
+    lds_base_check();
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    struct Own { float4 pi, d, v; float ki; uint32_t mi, cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.dv[i], c.vel[i], c.kappa[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist8 = p2_dist8<DS>(t);
+    t.stage_p2(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.kappa), dist8);
+    Tile::staged_barrier();
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
+        if (!active) return;
+        const float4 pi = o.pi;
+        const uint32_t mi = o.mi;
+        const float rho0 = rho0_of(c, mi);
+        const float ki = o.ki;
+        const float kip = fmaxf(ki, 0.0f);
+        float4 d = o.d;
+        float sx, sy, sz;
+        if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, sx, sy, sz);
+        else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, [&](float ka, float kb) { return f2{kip + fmaxf(ka, 0.0f), kip + fmaxf(kb, 0.0f)}; }, sx, sy, sz);
+        d.x -= sx * inv_dt; d.y -= sy * inv_dt; d.z -= sz * inv_dt;
+        if (ki > 0.0f) {
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const float4 pj = p2_boundary_pos(t, s, dist8);
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                const float coeff = ki * pj.w * rho0 * inv_dt * g;
+                const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
+                d.x -= ex; d.y -= ey; d.z -= ez;
+                if (c.bforce && !is_ghost(c, i)) {
+                    const float fs = inv_dt * pi.w;
+                    const uint32_t jb = boundary_sorted_of_slot(c, t, s);
+                    apply_boundary_force(c, jb, __float_as_uint(c.bvel[jb].w), ex * fs, ey * fs, ez * fs);
+                }
+            });
+        }
+        c.dv[i] = d;
+        const float4 v = o.v;
+        c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
+    });
+}
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pressure_apply, c, L, inv_dt, s);
+    if (c.mass_uniform > 0.0f) {
+        const uint32_t ds = pick_ds_p2(L.raw_slots());
+        SALVA_LAUNCH_P2(k_pressure_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt);
+        return;
+    }
     const uint32_t ds = pick_ds(pk_slots(L));
     SALVA_LAUNCH_FIXED(k_pressure_apply, ds, c, L, pk_bytes(L, ds), s, c, inv_dt);
 }

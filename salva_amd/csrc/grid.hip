@@ -57,12 +57,29 @@ void launch_bbox_final(const int32_t* partials, unsigned nblocks, int32_t* bbox6
 }
 
 // ------------------------------------------------------------------------------------------------ keys
+// `mass_mm` (may be null): MASS_SLOTS pairs {min, max} of the bit patterns of pts[i].w — the fluid masses — as unsigned integers;
+// a wave folds its range into the pair blockIdx selects (64 pairs: sixteen thousand waves on ONE address cost 0.3 ms per step at
+// 10^6 particles), and only where that changes the pair.  k_publish_readback folds the pairs and resets them; min == max there
+// means every particle has the same mass (StepCtx::mass_uniform).  (For non-negative floats the unsigned order is the float
+// order; a negative or NaN mass can only make the two differ more, or — if ALL are the same bits — equal, which is still "uniform".)
 __global__ __launch_bounds__(BLOCK) void k_cell_keys(const float4* __restrict__ pts, uint32_t n, float h, TileGrid g,
                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ idx,
-                                                     uint32_t* flags) {
+                                                     uint32_t* flags, uint32_t* mass_mm) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pts[i];
+    const bool on = i < n;
+    const float4 p = pts[on ? i : 0u];
+    if (mass_mm) {  // (wave-uniform; every lane takes part in the reductions)
+        const uint32_t mb = __float_as_uint(p.w);
+        const uint32_t lo = ~wave_max_u32(~mb), hi = wave_max_u32(mb);
+        // (a stale read can only cause an atomic too many: a minimum only falls and a maximum only rises between two resets,
+        // which happen in stream order)
+        if ((threadIdx.x & (WAVE - 1)) == 0) {
+            uint32_t* mm = mass_mm + 2u * (blockIdx.x & (MASS_SLOTS - 1u));
+            if (lo < *(volatile uint32_t*)mm) atomicMin(mm, lo);
+            if (hi > *(volatile uint32_t*)(mm + 1)) atomicMax(mm + 1, hi);
+        }
+    }
+    if (!on) return;
     bool bad = false, inside;
     uint32_t k = tile_key(g, cell_coord(p.x, h, bad), cell_coord(p.y, h, bad), cell_coord(p.z, h, bad), inside);
     if (!inside) { atomicOr(flags, 2u); k = 0; }  // cannot happen while the bbox is maintained with the positions
@@ -71,9 +88,9 @@ __global__ __launch_bounds__(BLOCK) void k_cell_keys(const float4* __restrict__ 
     idx[i] = i;
 }
 void launch_cell_keys(const float4* pts, uint32_t n, float h, TileGrid g, uint32_t* keys, uint32_t* idx,
-                      uint32_t* flags, hipStream_t s) {
+                      uint32_t* flags, uint32_t* mass_mm, hipStream_t s) {
     if (n == 0) return;
-    k_cell_keys<<<div_up(n, BLOCK), BLOCK, 0, s>>>(pts, n, h, g, keys, idx, flags);
+    k_cell_keys<<<div_up(n, BLOCK), BLOCK, 0, s>>>(pts, n, h, g, keys, idx, flags, mass_mm);
 }
 
 // ------------------------------------------------------------------------------------------------ sort / scan (rocPRIM via hipCUB)
@@ -385,7 +402,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc
     Tile t;
     if (!t.setup_geom(c)) return;  // surplus workgroup: its entry was zeroed by the host
     if (threadIdx.x == 0) slot_desc[t.slot] = make_uint4(t.tile, t.own_begin, t.own_end, 0u);
-    TileAcc a{0, 0, 0, 0, 0, 0, 0, 0};
+    TileAcc a{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     {
         TileCells tc;
         tc.build(c, t);
@@ -395,6 +412,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc
         a.nonempty = 1;
         a.max_s = (uint32_t)a.s; a.max_sb = (uint32_t)a.sb; a.max_nsl = a.nsl;
         a.max_sum = (((uint32_t)a.s + 63u) & ~63u) + (uint32_t)a.sb;
+        a.max_raw = (uint32_t)a.s + (uint32_t)a.sb;
     }
     if (threadIdx.x == 0) tile_cnt[t.slot] = a;
 }
@@ -424,11 +442,11 @@ void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo
 }
 size_t scan_tiles_temp_bytes(uint32_t n) {
     size_t b = 0;
-    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0}, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n);
     return b;
 }
 void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s) {
-    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0}, (int)n, s));
+    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n, s));
 }
 
 // ------------------------------------------------------------------------------------------------ neighbour lists
@@ -447,8 +465,14 @@ struct TileListStats { uint32_t sum_ff, sum_fb, max_ff, max_fb, own_ff, own_fb; 
 // Both write the same lists in the same order.  (Parking the completed dwords in a per-wave LDS buffer and writing them out
 // with 16-byte stores was tried too: the 6 KiB per wave halve the resident waves and the kernel time doubles — the loop is
 // bound by per-wave latency, not by the stores)
+// V = 1 is held to 64 VGPRs (8 waves per SIMD) and asks for the LDS it really carves (12 bytes per fluid slot): FOUR tiles then
+// share a CU (32 waves, the CU's limit) where three did — like the solver kernels this one spends a third of a tile's life in
+// dependent fixed phases (cell tables, halo staging, barriers) that only another resident tile can overlap.
+#ifndef SALVA_NBR_MIN_WAVES
+#define SALVA_NBR_MIN_WAVES 8
+#endif
 template <int V>
-__global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileListStats* __restrict__ tile_stats) {
+__global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4) void k_nbr_tile(StepCtx c, TileListStats* __restrict__ tile_stats) {
     __shared__ uint32_t red[6][TILE_MAX_WAVES];
     Tile t;
     t.setup(c, false);
@@ -462,7 +486,11 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_nbr_tile(StepCtx c, TileLi
     // V = 1: the staged positions as three planes (x | y | z): four consecutive candidates of a row are then ONE 16-byte read per
     // axis that lands as two aligned register pairs, which is what the packed f32 instructions want (see the candidate loop)
     float4* Lp = V == 0 ? t.carve<float4>(t.S + 3u) : nullptr;
-    const uint32_t plane = (t.S + 8u) & ~3u;  // (rows are walked from the 4-aligned slot at or below their start, four at a time)
+    // (rows are walked from the 4-aligned slot at or below their start, four at a time: S + 8, rounded to 4)
+    // and the planes an odd multiple of 256 bytes apart (tile.h, P3_DS_THREE): the three reads of a trip share their base
+    // address (-2 % on this kernel)
+    uint32_t plane = (t.S + 8u + 63u) & ~63u;
+    if (!(plane & 64u)) plane += 64u;
     float* Lx = V != 0 ? t.carve<float>(plane) : nullptr;
     float* Ly = V != 0 ? t.carve<float>(plane) : nullptr;
     float* Lz = V != 0 ? t.carve<float>(plane) : nullptr;
@@ -671,7 +699,13 @@ void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsi
     if (c.nmodels > 32u || c.nbmodels > 32u) {  // (the bit-mask group tests of V = 1 hold 32 models)
         SALVA_LAUNCH_TILE(k_nbr_tile<0>, c, L, L.bytes(20, 32, 4, true) + 64u, s, c, ts);
     } else {
-        SALVA_LAUNCH_TILE(k_nbr_tile<1>, c, L, L.bytes(20, 32, 4, true) + 64u, s, c, ts);
+        // what V = 1 carves: the cell tables, three 4-byte planes of (S + 8 rounded to 4) slots, the model ids when there is more
+        // than one fluid, two 16-byte boundary arrays
+        auto r16 = [](uint32_t b) { return (b + 15u) & ~15u; };
+        const uint32_t plane = ((L.max_halo_fluid + 8u + 63u) & ~63u) + 64u;
+        const uint32_t lds = r16(TILE_TABLE_BYTES) + 3u * r16(plane * 4u) + (c.nmodels > 1 ? r16(L.max_halo_fluid * 4u) : 0u) +
+                             2u * L.max_halo_boundary * 16u + 64u;
+        SALVA_LAUNCH_TILE(k_nbr_tile<1>, c, L, lds, s, c, ts);
     }
     k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.nlaunch, totals2, maxima2, own2);
 }

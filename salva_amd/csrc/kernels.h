@@ -15,7 +15,7 @@ unsigned bbox_blocks(uint32_t n);
 void launch_bbox(const float4* pts, uint32_t n, float h, int32_t* partials, int32_t* bbox6, uint32_t* flags, hipStream_t s);
 void launch_bbox_final(const int32_t* partials, unsigned nblocks, int32_t* bbox6, hipStream_t s);
 void launch_cell_keys(const float4* pts, uint32_t n, float h, TileGrid g, uint32_t* keys, uint32_t* idx,
-                      uint32_t* flags, hipStream_t s);
+                      uint32_t* flags, uint32_t* mass_mm, hipStream_t s);
 size_t sort_pairs_temp_bytes(uint32_t n, int end_bit);
 void sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
                 uint32_t* idx_out, uint32_t n, int end_bit, hipStream_t s);

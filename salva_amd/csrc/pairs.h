@@ -1,5 +1,7 @@
 // pairs.h — the pair loops of the DFSPH solver kernels (dfsph.hip; shared with the kernel-development skeletons in diag/).
 #pragma once
+#include <cstdlib>
+
 #include "tile.h"
 
 namespace salva {
@@ -43,22 +45,7 @@ __device__ __forceinline__ float pair_sum_velocity_divergence(const StepCtx& c, 
                                                               const float4& pi, const float4& wi, uint32_t dist) {
     f2 acc2 = {0.0f, 0.0f};
     const f2 tiny = {1.0e-30f, 1.0e-30f};
-#ifdef SALVA_EXP  // kernel-time decomposition experiments (tools/gpu_r03c.sh; never defined in the product build)
-#if SALVA_EXP == 1   // no pair loop at all: what the per-tile phases cost
-    return pi.x * 0.0f;
-#elif SALVA_EXP == 2  // the LDS reads of the loop with (almost) no arithmetic
-    for_each_ff2<AHEAD, false, true>(c, gs, nqu, lh, [&](uint32_t o) { return load_pw(o, dist); }, [&](const RecPW& A, const RecPW& B) {
-        acc2 += f2{A.p.x + A.w.y, B.p.z + B.w.x};
-    });
-    return acc2.x + acc2.y;
-#endif
-#endif
-    for_each_ff2<AHEAD, false, true>(c, gs, nqu, lh, [&](uint32_t o) {
-#if defined(SALVA_EXP) && SALVA_EXP == 3  // the arithmetic of the loop with every lane reading slot 0 (no bank conflicts, reads hoistable)
-        return load_pw(o & 0u, dist);
-#else
-        return load_pw(o, dist);
-#endif
+    for_each_ff2<AHEAD, false, true>(c, gs, nqu, lh, [&](uint32_t o) { return load_pw(o, dist);
     }, [&](const RecPW& A, const RecPW& B) { SALVA_PAIR_MATH
         const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
         f2 r2 = dz * dz + tiny;
@@ -83,6 +70,86 @@ __device__ __forceinline__ float pair_sum_velocity_divergence_exact(const StepCt
     });
     return acc;
 }
+// ---- the same sums over the 24-byte plane layout (tile.h stage_p3; every particle has the mass c.mass_uniform) ----
+// Three ds_read_b64 per contact from ONE address VGPR (slot * 8; the planes at compile-time distances in the DS != 0
+// instantiations); no multiplication by m_j per contact: the constant multiplies the finished sum.
+struct RecP3 { lds_v2f xy, zu, vw; };  // (x, y) | (z, w.x) | (w.y, w.z)
+template <uint32_t DS>
+__device__ __forceinline__ uint32_t p3_dist8(const Tile& t) { return DS ? DS * 8u : ((t.S * 8u + 15u) & ~15u); }
+template <uint32_t DS>
+__device__ __forceinline__ uint32_t p2_dist8(const Tile& t) { return DS ? DS * 8u : (((t.S + t.SB) * 8u + 15u) & ~15u); }
+__device__ __forceinline__ RecP3 load_p3(uint32_t o, uint32_t dist8) { return RecP3{lds_ld8(o), lds_ld8(o + dist8), lds_ld8(o + 2u * dist8)}; }
+template <bool AHEAD = true>
+__device__ __forceinline__ float pair_sum_velocity_divergence_p3(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh,
+                                                                 const float4& pi, const float4& wi, uint32_t dist8) {
+    f2 acc2 = {0.0f, 0.0f};
+    const f2 tiny = {1.0e-30f, 1.0e-30f};
+    for_each_ff2<AHEAD, false, 2>(c, gs, nqu, lh, [&](uint32_t o) { return load_p3(o, dist8); }, [&](const RecP3& A, const RecP3& B) { SALVA_PAIR_MATH
+        const f2 dx = {pi.x - A.xy.x, pi.x - B.xy.x}, dy = {pi.y - A.xy.y, pi.y - B.xy.y}, dz = {pi.z - A.zu.x, pi.z - B.zu.x};
+        f2 r2 = dz * dz + tiny;
+        r2 = dy * dy + r2;
+        r2 = dx * dx + r2;
+        const f2 g = kernel_gfac2(r2, c.sc);
+        const f2 ux = {wi.x - A.zu.y, wi.x - B.zu.y}, uy = {wi.y - A.vw.x, wi.y - B.vw.x}, uz = {wi.z - A.vw.y, wi.z - B.vw.y};
+        acc2 += (ux * dx + uy * dy + uz * dz) * g;
+    });
+    return (acc2.x + acc2.y) * c.sc.gscale * c.mass_uniform;
+}
+__device__ __forceinline__ float pair_sum_velocity_divergence_exact_p3(const StepCtx& c, uint32_t i, uint32_t gs, const float4& pi,
+                                                                       const float4& wi, uint32_t dist8) {
+    float acc = 0.0f;
+    for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+        const RecP3 A = load_p3(s << 3, dist8);
+        const float dx = pi.x - A.xy.x, dy = pi.y - A.xy.y, dz = pi.z - A.zu.x;
+        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+        acc += ((wi.x - A.zu.y) * dx + (wi.y - A.vw.x) * dy + (wi.z - A.vw.y) * dz) * g;
+    });
+    return acc * c.mass_uniform;
+}
+// sum_j grad W_ij k_ij over the 16-byte plane layout (tile.h stage_p2), times the uniform mass
+struct RecP2 { lds_v2f xy, zk; };  // (x, y) | (z, kappa)
+__device__ __forceinline__ RecP2 load_p2(uint32_t o, uint32_t dist8) { return RecP2{lds_ld8(o), lds_ld8(o + dist8)}; }
+template <typename K2>
+__device__ __forceinline__ void pair_sum_gradient_p2(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh, const float4& pi,
+                                                     uint32_t dist8, K2&& kij2, float& sx, float& sy, float& sz) {
+    f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
+    const f2 tiny = {1.0e-30f, 1.0e-30f};
+    for_each_ff2<true, false, 2>(c, gs, nqu, lh, [&](uint32_t o) { return load_p2(o, dist8); }, [&](const RecP2& A, const RecP2& B) { SALVA_PAIR_MATH
+        const f2 dx = {pi.x - A.xy.x, pi.x - B.xy.x}, dy = {pi.y - A.xy.y, pi.y - B.xy.y}, dz = {pi.z - A.zk.x, pi.z - B.zk.x};
+        f2 r2 = dz * dz + tiny;
+        r2 = dy * dy + r2;
+        r2 = dx * dx + r2;
+        const f2 g = kernel_gfac2(r2, c.sc);
+        const f2 coeff = kij2(A.zk.y, B.zk.y) * g;
+        ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
+    });
+    const float f = c.sc.gscale * c.mass_uniform;
+    sx = (ax.x + ax.y) * f; sy = (ay.x + ay.y) * f; sz = (az.x + az.y) * f;
+}
+template <typename K1>
+__device__ __forceinline__ void pair_sum_gradient_exact_p2(const StepCtx& c, uint32_t i, uint32_t gs, const float4& pi, uint32_t dist8,
+                                                           K1&& kij1, float& sx, float& sy, float& sz) {
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+        const RecP2 A = load_p2(s << 3, dist8);
+        const float dx = pi.x - A.xy.x, dy = pi.y - A.xy.y, dz = pi.z - A.zk.x;
+        const float coeff = kij1(A.zk.y) * kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+        ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
+    });
+    sx = ax * c.mass_uniform; sy = ay * c.mass_uniform; sz = az * c.mass_uniform;
+}
+// a boundary halo slot of that layout: (x, y, z, V_b)
+__device__ __forceinline__ float4 p2_boundary_pos(const Tile& t, uint32_t s, uint32_t dist8) {
+    const uint32_t o = (t.S + s) * 8u;
+    const lds_v2f xy = lds_ld8(o), zv = lds_ld8(o + dist8);
+    return make_float4(xy.x, xy.y, zv.x, zv.y);
+}
+static inline uint32_t p2_bytes(const TileLds& L, uint32_t ds) {
+    const uint32_t n = L.raw_slots();
+    const uint32_t dist8 = ds ? ds * 8u : ((n * 8u + 15u) & ~15u);
+    return dist8 + n * 8u + 32u;
+}
+
 // sum_j grad W_ij m_j k_ij with k_ij = f(k_j) supplied by `kij2` (two contacts at once) / `kij1`
 template <typename K2>
 __device__ __forceinline__ void pair_sum_gradient(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh, const float4& pi,
@@ -141,6 +208,39 @@ static inline uint32_t pw_slots(const TileLds& L) { return L.sum_slots(); }
 static inline uint32_t pw_bytes(const TileLds& L, uint32_t ds, bool errtab) {
     return (ds ? 2u * ds : 2u * pw_slots(L)) * 16u + (errtab ? TILE_ERR_BYTES : 0u) + 32u;
 }
+// plane layout (P3): 16 DS + 8 S bytes of planes (S = the launch's largest fluid halo), the boundary halo in one or two 16-byte
+// arrays, the compact error table
+static inline uint32_t pick_ds_p3(uint32_t s) {
+    return s <= P3_DS_THREE ? P3_DS_THREE : (s <= P3_DS_TWO ? P3_DS_TWO : (s <= P3_DS_ONE ? P3_DS_ONE : 0u));
+}
+static inline uint32_t p3_bytes(const TileLds& L, uint32_t ds, uint32_t nmodels, bool with_bv) {
+    const uint32_t dist8 = ds ? ds * 8u : ((L.max_halo_fluid * 8u + 15u) & ~15u);
+    // behind the second plane: 8 S + 16 k SB bytes of the fullest tile (k = 1 or 2 boundary arrays).  The tile with the fullest
+    // fluid halo lies inside the fluid and the tile with the most boundary slots at a wall: bound the sum by the largest
+    // (S + SB) of one tile (TileLds::max_raw) as well as by the two maxima
+    const uint32_t bb = with_bv ? 32u : 16u;
+    const uint32_t by_maxima = ((L.max_halo_fluid * 8u + 15u) & ~15u) + bb * L.max_halo_boundary;
+    const uint32_t by_raw = ((L.raw_slots() * 8u + 15u) & ~15u) + (bb - 8u) * L.max_halo_boundary;
+    static const uint32_t pad = getenv("SALVA_HIP_P3_PAD") ? (uint32_t)atoi(getenv("SALVA_HIP_P3_PAD")) : 0u;  // (A/B: where a CU stops taking three tiles)
+    return 2u * dist8 + (by_raw < by_maxima ? by_raw : by_maxima) + ((TILE_MAX_WAVES * nmodels * 4u + 15u) & ~15u) + 32u + pad;
+}
+static inline uint32_t pick_ds_p2(uint32_t n) {
+    return n <= P2_DS_THREE ? P2_DS_THREE : (n <= P3_DS_TWO ? P3_DS_TWO : (n <= P3_DS_ONE ? P3_DS_ONE : 0u));
+}
+#define SALVA_LAUNCH_P3(kernel, DSV, c, L, lds, s, ...)                                                          \
+    do {                                                                                                         \
+        if ((DSV) == P3_DS_THREE) SALVA_LAUNCH_TILE(kernel<P3_DS_THREE>, c, L, lds, s, __VA_ARGS__);             \
+        else if ((DSV) == P3_DS_TWO) SALVA_LAUNCH_TILE(kernel<P3_DS_TWO>, c, L, lds, s, __VA_ARGS__);            \
+        else if ((DSV) == P3_DS_ONE) SALVA_LAUNCH_TILE(kernel<P3_DS_ONE>, c, L, lds, s, __VA_ARGS__);            \
+        else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                           \
+    } while (0)
+#define SALVA_LAUNCH_P2(kernel, DSV, c, L, lds, s, ...)                                                          \
+    do {                                                                                                         \
+        if ((DSV) == P2_DS_THREE) SALVA_LAUNCH_TILE(kernel<P2_DS_THREE>, c, L, lds, s, __VA_ARGS__);             \
+        else if ((DSV) == P3_DS_TWO) SALVA_LAUNCH_TILE(kernel<P3_DS_TWO>, c, L, lds, s, __VA_ARGS__);            \
+        else if ((DSV) == P3_DS_ONE) SALVA_LAUNCH_TILE(kernel<P3_DS_ONE>, c, L, lds, s, __VA_ARGS__);            \
+        else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                           \
+    } while (0)
 // P | K kernels: P holds fluid halo + 2 x boundary halo, K the fluid halo (4 bytes each)
 static inline uint32_t pk_slots(const TileLds& L) { return L.sum_slots() + L.max_halo_boundary; }
 static inline uint32_t pk_bytes(const TileLds& L, uint32_t ds) {

@@ -49,6 +49,10 @@ struct TileLds {
     // 10 KB of LDS per workgroup in the bench scene, the difference between one and two resident tiles per CU for the
     // 36-byte-per-slot force kernels
     uint32_t max_sum = 0;
+    // largest (fluid halo) + (boundary halo) of any one tile WITHOUT padding (0: unknown — a speculative pass): the slot count of
+    // the plane layouts (stage_p3), which are filled through registers and need no 64-slot granularity
+    uint32_t max_raw = 0;
+    uint32_t raw_slots() const { return max_raw ? max_raw : max_halo_fluid + max_halo_boundary; }
     uint32_t sum_slots() const {
         const uint32_t worst = ((max_halo_fluid + 63u) & ~63u) + max_halo_boundary;
         return max_sum ? (max_sum < worst ? max_sum : worst) : worst;
@@ -65,10 +69,33 @@ struct TileLds {
 
 // Fixed LDS layouts of the four DFSPH solver kernels (dfsph.hip): the second staged array sits at a COMPILE-TIME distance
 // from the first, so both LDS reads of a contact take their address from one VGPR (the list entry << 4) plus an immediate
-// offset — one VALU instruction per contact instead of three.  Two instantiations: 2432 slots (two such workgroups still
-// share a CU's 160 KB) and 3968 (the 16-bit offset field ends at 65535); fuller halos take the runtime-distance
+// offset — one VALU instruction per contact instead of three.  Two instantiations: 2448 slots (two such workgroups still
+// share a CU's 160 KB) and 3984 (the 16-bit offset field ends at 65535); fuller halos take the runtime-distance
 // instantiation (DS = 0).
-constexpr uint32_t FIXED_DS_SMALL = 2432, FIXED_DS_LARGE = 3968;
+#ifndef SALVA_FIXED_DS_SMALL
+#define SALVA_FIXED_DS_SMALL 2448  // (an odd multiple of 16 slots = of 256 bytes, see P3_DS_THREE below: k_iisph_dij_pj 49.7 -> 43.5 us against 2432)
+#endif
+constexpr uint32_t FIXED_DS_SMALL = SALVA_FIXED_DS_SMALL, FIXED_DS_LARGE = 3984;
+// Plane layout of the evaluate kernels (stage_p3 below): plane k starts at LDS byte k * 8 * DS whatever the halo's size, and the
+// workgroup's LDS ends behind the slots it really uses — so ONE instantiation serves every halo of up to DS slots and costs
+// 16 DS + 8 n bytes (+ the boundary halo, 16 bytes per slot and array).  2080: three workgroups per CU (3 x 54.6 KB) with up to
+// ~330 boundary slots beside a full fluid halo — the compressed column of the bench scene, where the 50-iteration solves live,
+// holds 1940-2000 fluid slots per tile; 3328: two; 4095: the offset field of ds_read_b64 ends at 65535.
+// The plane distance must be an ODD multiple of 256 bytes (DS an odd multiple of 32): measured, k_pred_density takes 40.2 us with
+// planes 69 x 256 bytes apart and 46.4 us with 64 x 256 or 66 x 256 (profiles/r04_experiments/r04c_plane_distance.log) — the three
+// ds_read_b64 of a contact, which share their base address, then land in three different 256-byte phases of a 1 KB period
+// (0, 256 or 768, 512); at an even multiple two or all three coincide and the reads serialise.  (MI355X_MICROARCH.md documents
+// the 64 banks of one 256-byte row, not what lies above them.)
+#ifndef SALVA_P3_DS3
+#define SALVA_P3_DS3 2080
+#endif
+constexpr uint32_t P3_DS_THREE = SALVA_P3_DS3, P3_DS_TWO = 3360, P3_DS_ONE = 4064;  // evaluate kernels: fluid halo slots
+#ifndef SALVA_P2_DS3
+#define SALVA_P2_DS3 2464
+#endif
+constexpr uint32_t P2_DS_THREE = SALVA_P2_DS3;                               // apply kernels: fluid + boundary halo slots
+static_assert(P3_DS_THREE % 64 == 32 && P3_DS_TWO % 64 == 32 && P3_DS_ONE % 64 == 32 && P2_DS_THREE % 64 == 32 || SALVA_P3_DS3 != 2080 || SALVA_P2_DS3 != 2464,
+              "plane distances: odd multiples of 256 bytes");
 constexpr uint32_t TILE_ERR_BYTES = 12u * 32u * 4u;  // TileErr table (TILE_MAX_WAVES x MAX_MODELS floats), carved from the pool
 
 #ifdef __HIPCC__
@@ -134,6 +161,13 @@ __device__ __forceinline__ float4 lds_ld16(uint32_t byte_addr) {
 }
 __device__ __forceinline__ float lds_ld4(uint32_t byte_addr) {
     return *(const __attribute__((address_space(3))) float*)(uintptr_t)byte_addr;
+}
+typedef float lds_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lds_v2f lds_ld8(uint32_t byte_addr) {
+    return *(const __attribute__((address_space(3))) lds_v2f*)(uintptr_t)byte_addr;
+}
+__device__ __forceinline__ void lds_st8(uint32_t byte_addr, float a, float b) {
+    *(__attribute__((address_space(3))) lds_v2f*)(uintptr_t)byte_addr = lds_v2f{a, b};
 }
 
 // LDS-DMA (global_load_lds): every lane names its own global source, the 64 lanes' data land in LDS side by side from a
@@ -383,6 +417,84 @@ struct Tile {
         for_halo_boundary(c, [&](uint32_t s, uint32_t g) { ba[s] = c.bposv[g]; bb[s] = c.bvel[g]; });
         bp = ba; bv = bb;
         pool_used = dist + cap * 4u;
+    }
+    // ---- P3: the evaluate kernels' layout when every particle has the same mass (StepCtx::mass_uniform) ----
+    // Three 8-byte planes XY | ZU | VW, (U, V, W) = w = v + dv, at LDS bytes 0, dist8, 2 dist8: the fluid halo, slots [0, S).  The
+    // boundary halo (few slots, wall tiles only) stays in 16-byte arrays behind the last plane (stage_boundary).
+    // 24 bytes per slot against the 32 of P | W (the mass is a constant of the launch, the model id is not used): a
+    // 2100-slot halo is 50 KB, and THREE workgroups share a CU's 160 KB where two did — the third resident tile is what overlaps
+    // one tile's index / stage / barrier phases with another's pair loop (+11-13 % measured in round 3 on a scene
+    // whose halos fitted).  A contact then costs three ds_read_b64 (2 LDS cycles each) instead of two ds_read_b128 (4 each).
+    // Filled through registers — two 16-byte loads and three ds_write_b64 per slot: LDS-DMA moves 4 or 16 bytes per lane, so it
+    // could only fill 4-byte planes, with three times the staging instructions.  No padding to 64 slots is needed this way.
+    // Requires dist8 >= S * 8, a multiple of 8.  Afterwards pool_used = the end of the third plane.
+    __device__ __forceinline__ void p3_store(uint32_t slot, uint32_t dist8, const float4& a, const float4& b) const {
+        lds_st8(slot * 8u, a.x, a.y);
+        lds_st8(slot * 8u + dist8, a.z, b.x);
+        lds_st8(slot * 8u + 2u * dist8, b.y, b.z);
+    }
+    __device__ __forceinline__ void stage_p3(const StepCtx& c, const float4* __restrict__ posm, const float4* __restrict__ w, uint32_t dist8) {
+        const uint32_t nt = blockDim.x, s0 = threadIdx.x;
+        if (c.halo_stride) {
+            // every load of the thread's (up to) four slots is issued before the first store waits for one
+            const uint32_t pre[PRE] = {pre0, pre1, pre2, pre3};
+            float4 a[PRE], b[PRE];
+#pragma unroll
+            for (int k = 0; k < PRE; ++k) {
+                const uint32_t sl = s0 + (uint32_t)k * nt;
+                const uint32_t g = sl < S ? pre[k] : own_begin;
+                a[k] = posm[g]; b[k] = w[g];
+            }
+#pragma unroll
+            for (int k = 0; k < PRE; ++k) {
+                const uint32_t sl = s0 + (uint32_t)k * nt;
+                if (sl < S) p3_store(sl, dist8, a[k], b[k]);
+            }
+            for (uint32_t sl = s0 + PRE * nt; sl < S; sl += nt) {
+                const uint32_t g = c.halo_src[hoff + sl];
+                p3_store(sl, dist8, posm[g], w[g]);
+            }
+        } else {
+            for_halo(c, [&](uint32_t sl, uint32_t g) { p3_store(sl, dist8, posm[g], w[g]); });
+        }
+        pool_used = 2u * dist8 + ((S * 8u + 15u) & ~15u);  // (the boundary halo follows as 16-byte arrays: stage_boundary)
+    }
+    // ---- P2: the apply kernels' layout under the same condition: two 8-byte planes XY | ZK (K = kappa) at LDS bytes 0 and dist8;
+    // the boundary halo in slots [S, S + SB) as (x, y) | (z, V_b).  16 bytes per slot against the 20 of P | K, and two
+    // ds_read_b64 per contact instead of a ds_read_b128 and a ds_read_b32.  pool_used = the end of the second plane afterwards.
+    __device__ __forceinline__ void stage_p2(const StepCtx& c, const float4* __restrict__ posm, const float* __restrict__ k, uint32_t dist8) {
+        const uint32_t nt = blockDim.x, s0 = threadIdx.x;
+        if (c.halo_stride) {
+            const uint32_t pre[PRE] = {pre0, pre1, pre2, pre3};
+            float4 a[PRE];
+            float b[PRE];
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) {
+                const uint32_t sl = s0 + (uint32_t)q * nt;
+                const uint32_t g = sl < S ? pre[q] : own_begin;
+                a[q] = posm[g]; b[q] = k[g];
+            }
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) {
+                const uint32_t sl = s0 + (uint32_t)q * nt;
+                if (sl < S) { lds_st8(sl * 8u, a[q].x, a[q].y); lds_st8(sl * 8u + dist8, a[q].z, b[q]); }
+            }
+            for (uint32_t sl = s0 + PRE * nt; sl < S; sl += nt) {
+                const uint32_t g = c.halo_src[hoff + sl];
+                const float4 p = posm[g];
+                lds_st8(sl * 8u, p.x, p.y); lds_st8(sl * 8u + dist8, p.z, k[g]);
+            }
+        } else {
+            for_halo(c, [&](uint32_t sl, uint32_t g) {
+                const float4 p = posm[g];
+                lds_st8(sl * 8u, p.x, p.y); lds_st8(sl * 8u + dist8, p.z, k[g]);
+            });
+        }
+        for_halo_boundary(c, [&](uint32_t sl, uint32_t g) {
+            const float4 p = c.bposv[g];
+            lds_st8((S + sl) * 8u, p.x, p.y); lds_st8((S + sl) * 8u + dist8, p.z, p.w);
+        });
+        pool_used = dist8 + (S + SB) * 8u;
     }
     // the barrier that publishes the staged halo: the DMA of this wave has landed (vmcnt), then everybody's has
     static __device__ __forceinline__ void staged_barrier() {
@@ -653,12 +765,15 @@ __device__ __forceinline__ uint32_t entry_off16_hi(uint32_t a) { uint32_t o; asm
 __device__ __forceinline__ uint32_t entry_off16_lo(uint32_t a) { return (a & 0xffffu) << 4; }
 __device__ __forceinline__ uint32_t entry_off16_hi(uint32_t a) { return (a >> 16) << 4; }
 #endif
-template <bool OFF> __device__ __forceinline__ uint32_t entry_lo(uint32_t a) { return OFF ? entry_off16_lo(a) : (a & 0xffffu); }
-template <bool OFF> __device__ __forceinline__ uint32_t entry_hi(uint32_t a) { return OFF ? entry_off16_hi(a) : (a >> 16); }
+__device__ __forceinline__ uint32_t entry_off8_lo(uint32_t a) { uint32_t o; asm("v_mad_u32_u16 %0, %1, 8, 0" : "=v"(o) : "v"(a)); return o; }
+__device__ __forceinline__ uint32_t entry_off8_hi(uint32_t a) { uint32_t o; asm("v_mad_u32_u16 %0, %1, 8, 0 op_sel:[1,0,0,0]" : "=v"(o) : "v"(a)); return o; }
+// OFF: 0 = the slot, 1 (true) = slot * 16, 2 = slot * 8 (the 8-byte planes of stage_p3)
+template <int OFF> __device__ __forceinline__ uint32_t entry_lo(uint32_t a) { return OFF == 1 ? entry_off16_lo(a) : OFF == 2 ? entry_off8_lo(a) : (a & 0xffffu); }
+template <int OFF> __device__ __forceinline__ uint32_t entry_hi(uint32_t a) { return OFF == 1 ? entry_off16_hi(a) : OFF == 2 ? entry_off8_hi(a) : (a >> 16); }
 
 // FUSED: a step over two list dwords (four contacts) is ONE basic block — the two packed chains are independent, and only
 // inside one block can the scheduler interleave them (each chain alone is ~20 dependent packed operations deep).
-template <bool AHEAD = true, bool FUSED = false, bool OFF = false, typename L, typename C2>
+template <bool AHEAD = true, bool FUSED = false, int OFF = 0, typename L, typename C2>
 __device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, uint32_t nq, const ListRegs& lr, L&& load,
                                              C2&& compute2) {
 #pragma unroll
@@ -841,6 +956,39 @@ struct TileErr {
     }
     static __device__ __forceinline__ void zero(const StepCtx& c, uint32_t tile) {
         if (threadIdx.x < c.nmodels) c.partials[(size_t)tile * c.nmodels + threadIdx.x] = 0.0f;
+    }
+};
+
+// The same with rows of nmodels floats instead of MAX_MODELS (48 bytes for one fluid instead of 1536: the plane-layout kernels
+// count their LDS in hundreds of bytes, tile.h P3_DS_THREE).  Same sums in the same order as TileErr.
+struct TileErrC {
+    float* tab;
+    uint32_t nm;
+    static __device__ __forceinline__ uint32_t bytes(const StepCtx& c) { return (TILE_MAX_WAVES * c.nmodels * 4u + 15u) & ~15u; }
+    __device__ __forceinline__ void init(float* t, const StepCtx& c) {
+        tab = t; nm = c.nmodels;
+        const uint32_t lane = threadIdx.x & (WAVE - 1);
+        if (lane < nm) tab[(threadIdx.x / WAVE) * nm + lane] = 0.0f;
+    }
+    __device__ __forceinline__ void add(const StepCtx& c, float err, uint32_t mi, bool active) {
+        const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+        if (nm == 1) {
+            const float s = wave_sum(active ? err : 0.0f);
+            if (lane == 0) tab[wv] += s;
+        } else {
+            for (uint32_t m = 0; m < nm; ++m) {
+                const float s = wave_sum((active && mi == m) ? err : 0.0f);
+                if (lane == 0) tab[wv * nm + m] += s;
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(const StepCtx& c, uint32_t tile) {
+        __syncthreads();
+        if (threadIdx.x < nm) {
+            float s = 0.0f;
+            for (int w = 0; w < (int)(blockDim.x / WAVE); ++w) s += tab[(uint32_t)w * nm + threadIdx.x];
+            c.partials[(size_t)tile * nm + threadIdx.x] = s;
+        }
     }
 };
 

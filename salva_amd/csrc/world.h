@@ -27,6 +27,7 @@ struct BoundarySlot {
     uint64_t n = 0;
     uint32_t memberships = 1u, filter = 0xffffffffu;
     bool wants_forces = false;
+    bool vel_zero = true;  // every velocity of the last upload was exactly zero (a sampled boundary's are written on the device: treated as moving)
     // ColliderSampling::StaticSampling(points): collider-local sample points (integrations/rapier/fluids_pipeline.rs:36-41)
     std::shared_ptr<DevBuf<float4>> sampling;
     // ColliderSampling::DynamicContactSampling (:42-43): the collider's shape and its last pose; the boundary's particles are
@@ -190,6 +191,9 @@ class World {
     DevBuf<uint32_t> slice_near;   // per slice: a pair closer than 1e-5 h exists (written by k_density_alpha, read by the DFSPH solver kernels)
     DevBuf<int32_t> bbox_partials;
     TileLds lds;
+    float mass_uniform = 0.0f;  // StepCtx::mass_uniform of the current step (0: masses differ, or not known)
+    bool tile_trace = false;    // SALVA_HIP_TILE_TRACE=1: one line of tile statistics per step on stderr
+    bool no_planes = false;     // SALVA_HIP_NO_PLANES=1 (A/B): keep the 32-byte-per-slot evaluate kernels
 #ifdef SALVA_HIP_DIAG
     PipeCfg pipe;          // launch shape of the persistent pipeline kernels of this step (pipe.h)
 #endif
@@ -228,6 +232,7 @@ class World {
     // reductions / readback
     DevBuf<float> partials;
     DevBuf<Readback> d_rb;
+    DevBuf<uint32_t> mass_slots;  // k_cell_keys' {min, max} pairs of the mass bits (grid.hip), folded and reset by k_publish_readback
     struct FlagsPtr { uint32_t* p = nullptr; } d_flags;  // = &d_rb.p->flags: flags and the next step's box come back in one copy
     DevBuf<unsigned long long> d_counters;
     Readback* h_rb = nullptr;

@@ -132,6 +132,8 @@ World::World(const SalvaHipParams& p) : prm(p) {
     spec_tight = getenv("SALVA_HIP_SPEC_TIGHT") != nullptr;
     defer_off = getenv("SALVA_HIP_NO_DEFER_LISTS") != nullptr;
     spec_apply_off = getenv("SALVA_HIP_NO_SPEC_APPLY") != nullptr;
+    no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
+    tile_trace = getenv("SALVA_HIP_TILE_TRACE") != nullptr;
 #ifdef SALVA_HIP_DIAG
     if (const char* e = getenv("SALVA_HIP_SCHED")) sched_mode = atoi(e);
 #endif
@@ -153,6 +155,12 @@ World::World(const SalvaHipParams& p) : prm(p) {
     d_rb.ensure(1);
     d_flags.p = &d_rb.p->flags;
     SALVA_HIP_CHECK(hipMemset(d_rb.p, 0, sizeof(Readback)));
+    {
+        uint32_t mm0[2 * MASS_SLOTS];  // (k_cell_keys' running {min, max} pairs of the mass bits)
+        for (uint32_t k = 0; k < MASS_SLOTS; ++k) { mm0[2 * k] = 0xffffffffu; mm0[2 * k + 1] = 0u; }
+        mass_slots.ensure(2 * MASS_SLOTS);
+        SALVA_HIP_CHECK(hipMemcpy(mass_slots.p, mm0, sizeof(mm0), hipMemcpyHostToDevice));
+    }
     d_counters.ensure(4);
     for (auto& e2 : ev) SALVA_HIP_CHECK(hipEventCreate(&e2));
     for (auto& e2 : evc) SALVA_HIP_CHECK(hipEventCreate(&e2));
@@ -521,11 +529,15 @@ void World::set_boundary(uint32_t slot, uint64_t nn, const float* pos, const flo
     BoundarySlot& b = bounds[slot];
     b.n = nn; b.memberships = memberships; b.filter = filter; b.wants_forces = wants_forces;
     b.dyn_kind = 0;  // (re)uploading particles makes it a plain boundary; the sampling setters mark it again
+    b.vel_zero = true;
     if (nn) {
         scratch_f.ensure(3 * nn, stream, false, 1.1f);
         SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, pos, 3 * nn * sizeof(float), hipMemcpyHostToDevice, stream));
         k_pack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, scratch_f.p, bst_pos.p + off, 0, 0.0f);
         SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        b.vel_zero = true;
+        if (vel_h)
+            for (uint64_t k = 0; k < 3 * nn && b.vel_zero; ++k) b.vel_zero = vel_h[k] == 0.0f;
         if (vel_h) {
             SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, vel_h, 3 * nn * sizeof(float), hipMemcpyHostToDevice, stream));
             k_pack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, scratch_f.p, bst_vel.p + off, 0, 0.0f);
@@ -646,6 +658,9 @@ StepCtx World::make_ctx() {
     c.gb = TileGrid{gb.o[0], gb.o[1], gb.o[2], gb.nt[0], gb.nt[1], gb.nt[2], cell_start_b.p};
     c.nmodels = (uint32_t)std::max<size_t>(fluids.size(), 1);
     c.nbmodels = (uint32_t)std::max<size_t>(bounds.size(), 1);
+    c.mass_uniform = mass_uniform;
+    c.bvel_zero = 1u;  // no boundary particle moves: the passes that subtract a boundary velocity need not stage it
+    for (const BoundarySlot& b : bounds) if (b.n && (!b.vel_zero || b.sampling || b.dyn_kind)) c.bvel_zero = 0u;
     c.rho0_tab = rho0_tab.p; c.rho0_single = fluids.empty() ? 1000.0f : fluids[0].density0; c.ff_ok = ff_ok.p; c.fb_ok = fb_ok.p; c.bb_ok = bb_ok.p;
     c.partials = partials.p;
     c.spec_k = -1; c.spec_ring = spec_ring.p; c.spec_pub = nullptr; c.model_counts = model_counts.p; c.w2 = w2.p;
@@ -709,7 +724,7 @@ void World::build_boundary_grid() {
     bkeys[0].ensure(nb); bkeys[1].ensure(nb); bidx[0].ensure(nb); bidx[1].ensure(nb);
     bposv.ensure(nb); bvel.ensure(nb); bperm.ensure(nb); cell_start_b.ensure(nc + 1);
     TileGrid gv{gb.o[0], gb.o[1], gb.o[2], gb.nt[0], gb.nt[1], gb.nt[2], nullptr};
-    launch_cell_keys(bst_pos.p, nb, sc.h, gv, bkeys[0].p, bidx[0].p, d_flags.p, stream);
+    launch_cell_keys(bst_pos.p, nb, sc.h, gv, bkeys[0].p, bidx[0].p, d_flags.p, nullptr, stream);
     const int end_bit = bits_for(nc);
     const size_t tb = sort_pairs_temp_bytes(nb, end_bit);
     ensure_cub_temp(tb);
@@ -731,9 +746,19 @@ void World::build_boundary_grid() {
 // fences to system scope, then bumps the sequence word the host polls.  (A hipMemcpyAsync + event costs ~20 us of idle GPU each
 // time the host has to wait for it: tools/gap_tsv_report.py.)
 __global__ void k_publish_readback(const Readback* __restrict__ src, const TileAcc* __restrict__ totals, int lists, int end_of_step,
-                                   Readback* pub_rb, volatile uint32_t* pub_seq, uint32_t seq) {
+                                   uint32_t* mass_slots, Readback* pub_rb, volatile uint32_t* pub_seq, uint32_t seq) {
+    uint32_t mlo = 0xffffffffu, mhi = 0u;
+    if (totals) {  // (wave-uniform) the mass range k_cell_keys saw since the last such publication; start the next one
+        static_assert(MASS_SLOTS == WAVE, "one pair per lane of the publishing wave");
+        const uint32_t a = mass_slots[2 * threadIdx.x], b = mass_slots[2 * threadIdx.x + 1];
+        mass_slots[2 * threadIdx.x] = 0xffffffffu; mass_slots[2 * threadIdx.x + 1] = 0u;
+        mlo = ~wave_max_u32(~a); mhi = wave_max_u32(b);
+    }
     if (threadIdx.x == 0) {
-        if (totals) pub_rb->tile_total = *totals;
+        if (totals) {
+            pub_rb->tile_total = *totals;
+            pub_rb->mass_mm[0] = mlo; pub_rb->mass_mm[1] = mhi;
+        }
         if (lists) {
             pub_rb->ncontacts_ff = src->ncontacts_ff; pub_rb->ncontacts_fb = src->ncontacts_fb;
             pub_rb->max_cnt_ff = src->max_cnt_ff; pub_rb->max_cnt_fb = src->max_cnt_fb;
@@ -750,7 +775,7 @@ __global__ void k_publish_readback(const Readback* __restrict__ src, const TileA
 // enqueue the publication on the world's stream ...
 uint32_t World::publish_enqueue(const TileAcc* totals, bool lists, bool end_of_step) {
     const uint32_t seq = ++hostpub_seq;
-    k_publish_readback<<<1, WAVE, 0, stream>>>(d_rb.p, totals, lists ? 1 : 0, end_of_step ? 1 : 0, &h_hostpub->rb, &h_hostpub->seq, seq);
+    k_publish_readback<<<1, WAVE, 0, stream>>>(d_rb.p, totals, lists ? 1 : 0, end_of_step ? 1 : 0, mass_slots.p, &h_hostpub->rb, &h_hostpub->seq, seq);
     SALVA_HIP_CHECK(hipGetLastError());
     return seq;
 }
@@ -770,7 +795,7 @@ void World::publish_wait(uint32_t seq, bool totals, bool lists, bool end_of_step
             throw HipError(SALVA_HIP_E_HIP, "internal error: the stream drained without publishing its read-back");
     }
     const Readback& p = h_hostpub->rb;
-    if (totals) h_rb->tile_total = p.tile_total;
+    if (totals) { h_rb->tile_total = p.tile_total; h_rb->mass_mm[0] = p.mass_mm[0]; h_rb->mass_mm[1] = p.mass_mm[1]; }
     if (lists) {
         h_rb->ncontacts_ff = p.ncontacts_ff; h_rb->ncontacts_fb = p.ncontacts_fb; h_rb->max_cnt_ff = p.max_cnt_ff; h_rb->max_cnt_fb = p.max_cnt_fb;
         h_rb->ncontacts_own_ff = p.ncontacts_own_ff; h_rb->ncontacts_own_fb = p.ncontacts_own_fb;
@@ -1155,7 +1180,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
     {
         TileGrid gv{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], nullptr};
-        launch_cell_keys(posm[cur].p, n, sc.h, gv, keys[0].p, idx[0].p, d_flags.p, stream);
+        launch_cell_keys(posm[cur].p, n, sc.h, gv, keys[0].p, idx[0].p, d_flags.p, mass_slots.p, stream);
         if (has_dyn) {  // coupling.update_boundaries (liquid_world.rs:94-103): may push particles, cells stay
             // (host clock: the pass ends with a read-back of the emitted count, so the stream is drained when it returns)
             if (timers) wait_stream();
@@ -1212,13 +1237,23 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             reorder();
             publish_wait(seq, true, false, false);
             tt = h_rb->tile_total;
+            {   // every particle of the working set has the same mass: the evaluate kernels stage 24 bytes per halo slot
+                float m;
+                memcpy(&m, &h_rb->mass_mm[0], sizeof(m));
+                mass_uniform = (h_rb->mass_mm[0] == h_rb->mass_mm[1] && m > 0.0f && std::isfinite(m) && !no_planes) ? m : 0.0f;
+            }
         } else {
             reorder();
+            mass_uniform = 0.0f;  // (a speculative pass does not wait for the publication that carries the mass range)
         }
         nlaunch = tt.nonempty;
         lds.max_halo_fluid = tt.max_s;
         lds.max_halo_boundary = tt.max_sb;
         lds.max_sum = spec ? 0u : tt.max_sum;  // (a speculative pass knows the two maxima only: TileLds::sum_slots falls back to their sum)
+        lds.max_raw = spec ? 0u : tt.max_raw;
+        if (tile_trace)
+            fprintf(stderr, "salva_hip tiles: nonempty %u max_s %u max_sb %u max_sum %u max_raw %u mass_uniform %g\n", tt.nonempty, tt.max_s,
+                    tt.max_sb, tt.max_sum, tt.max_raw, (double)mass_uniform);
         // one wave per 64-particle slice of the average non-empty tile (fuller tiles loop over their extra slices),
         // never fewer waves than the halo-table build needs threads
         {
