@@ -371,12 +371,32 @@ def main():
         kbar = float(sum(w.contact_counts(h).sum() + w.contact_counts(h, True).sum() for h in handles)) / n
     else:  # host-order fields do not exist in a decomposed run: list entries per local particle, from the step report
         kbar = float(st.reserved[3])
-    algo_bytes = n * (4.0 * kbar + sbytes)  # N (4K + S) bytes per launch
-    achieved = algo_bytes / (kernel_us * 1e-6) / 1e9
-    traffic, traffic_src = committed_traffic(kname, args.config, args.side) if not decomposed else (None, None)
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_us": kernel_us,
-                "algorithmic_bytes": algo_bytes, "mean_contacts": kbar}
+
+    def kernel_roofline(name, us, s_bytes):
+        """One kernel against the HBM roofline, both ways: `frac` / `frac_algorithmic` = SURVEY.md §8d's byte
+        model N (4K + S) over the measured duration; `frac_measured_traffic` = the HBM bytes the kernel really moved (PMC
+        FETCH_SIZE x 2 + WRITE_SIZE of the committed profile of this workload; list entries are 16-bit slots, so this is the
+        smaller figure wherever the lists dominate) over the same duration."""
+        algo = n * (4.0 * kbar + s_bytes)
+        traffic, src = committed_traffic(name, args.config, args.side) if not decomposed else (None, None)
+        ach = algo / (us * 1e-6) / 1e9
+        return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "frac_algorithmic": ach / HBM_PEAK_GBS,
+                "frac_measured_traffic": None if traffic is None else traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": src, "kernel_us": us, "algorithmic_bytes": algo, "mean_contacts": kbar}
+
+    roofline = kernel_roofline(kname, kernel_us, sbytes)
+    # the other kernels a step lives in (DFSPH: the divergence solve's two passes — 86 % of a settled step — and the list build)
+    others = {}
+    if cfg["solver"] == "dfsph":
+        for oid, oname, os_ in ((1, "k_divergence", 48.0), (6, "k_divergence_apply", 44.0), (4, "k_nbr_tile", 12.0)):
+            if oid == 4 and decomposed:
+                continue
+            try:
+                others[oname] = kernel_roofline(oname, w.time_kernel(oid, 30), os_)
+            except Exception as e:  # noqa: BLE001 - a timing aid must not cost the line
+                others[oname] = {"error": str(e)}
+    roofline["other_kernels"] = others
 
     if rank == 0:
         # ---- the regimes the run went through (see the docstring): rates over the first 20 timed steps and over the timed

@@ -286,7 +286,8 @@ uint64_t salva_hip_device_bytes(const SalvaHipWorld* world);
 float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps);
 /* The same for the other neighbour-sum kernels bench.py reports a roofline for: `kernel` = 0 k_pred_density (DFSPH, N (4K + 52)
  * algorithmic bytes), 1 k_divergence (N (4K + 48)), 2 k_iisph_next_pressure (IISPH, N (4K + 60)), 3 k_iisph_dij_pj (N (4K + 36))
- * — SURVEY.md §8d.  The IISPH kernels rewrite scratch only (next pressures into the spare buffer). */
+ * — SURVEY.md §8d; 4 k_nbr_tile (the neighbour-list build, N (12 + 4K)), 6 k_divergence_apply (DFSPH, N (4K + 44); runs on a copy
+ * of w).  The IISPH kernels rewrite scratch only (next pressures into the spare buffer). */
 float salva_hip_time_kernel(SalvaHipWorld* world, int32_t kernel, int32_t reps);
 /* `world.counters` after the last step — counters/mod.rs:17-72 */
 int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out);
@@ -420,6 +421,26 @@ int salva_hip_clear_boundary_sampling(SalvaHipWorld* world, uint32_t slot);
 /* For a dynamically sampled boundary: (fluid slot, particle index) of the fluid particle behind each of its points, in the
  * order of salva_hip_get_boundary_particles (the order itself is unspecified, as the reference's hash-grid walk is). */
 int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t* fluid_slots, uint32_t* indices);
+
+/* ---- Asynchronous read-back.  The reference's users read `fluid.positions` / `velocities` after every step
+ * (src/integrations/rapier/testbed_plugin.rs:361-367: the renderer walks them each frame).  salva_hip_get_fluid does that
+ * synchronously and serially with the step (4.2 ms for the 24 MB of 10^6 particles into pageable memory).  This pair takes the
+ * copy off the critical path: salva_hip_get_fluid_async enqueues the read-back of the state AS IT IS NOW (after the last completed
+ * step, host order, AoS [x,y,z] like salva_hip_get_fluid; either pointer may be NULL) and returns at once; the copy runs on the
+ * world's copy stream while the next salva_hip_step is already computing; salva_hip_wait_download blocks until the arrays are
+ * complete.  The destinations must stay valid and untouched until then.  One read-back is in flight at a time (a second
+ * salva_hip_get_fluid_async waits for the first).  A destination in pinned memory — from salva_hip_host_alloc, or the caller's own
+ * array after salva_hip_host_register (a Rust Vec / numpy array that is not reallocated) — is written by DMA directly at PCIe
+ * speed; any other destination is served through the library's own pinned buffers plus one memcpy inside the wait.
+ * Not available in a decomposed run (salva_hip_get_owned). */
+int salva_hip_get_fluid_async(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz);
+int salva_hip_wait_download(SalvaHipWorld* world);
+/* Pinned host memory on the world's device context: NULL on failure (salva_hip_last_error).  Release with salva_hip_host_free. */
+void* salva_hip_host_alloc(SalvaHipWorld* world, uint64_t bytes);
+int salva_hip_host_free(void* p);
+/* Pin a caller-owned array in place (hipHostRegister) / undo it.  The array must not move or be freed while registered. */
+int salva_hip_host_register(SalvaHipWorld* world, void* p, uint64_t bytes);
+int salva_hip_host_unregister(void* p);
 
 /* `Fluid::add_particles(positions, velocities)` (object/fluid.rs:126-150): append to the fluid on the device — default
  * volume, zero acceleration and velocity change — without re-uploading the particles it already holds.

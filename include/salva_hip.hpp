@@ -488,6 +488,15 @@ class LiquidWorld {  // liquid_world.rs
         }
         check(rc);
     }
+    // Asynchronous read-back of one fluid (salva_hip_get_fluid_async): start it after a step, run the next step, collect the
+    // arrays of the earlier state with wait_download().  `positions` / `velocities` must hold num_particles() entries and
+    // stay untouched until the wait; pin them with host_register() once for a read-back at PCIe speed.
+    void download_async(FluidHandle h, Vec3* positions, Vec3* velocities) {
+        check(salva_hip_get_fluid_async(w_, (uint32_t)h, positions ? positions[0].data() : nullptr, velocities ? velocities[0].data() : nullptr));
+    }
+    void wait_download() { check(salva_hip_wait_download(w_)); }
+    void host_register(void* p, size_t bytes) { check(salva_hip_host_register(w_, p, bytes)); }
+    static void host_unregister(void* p) { check(salva_hip_host_unregister(p)); }
     // LiquidWorld::step_with_coupling (liquid_world.rs:67-158): update_boundaries -> the substep -> transmit_forces
     void step_with_coupling(Real dt, const Vec3& gravity, CouplingManager& coupling) {
         for (size_t s = 0; s < boundaries_.size(); ++s) upload(boundaries_[s], (uint32_t)s);

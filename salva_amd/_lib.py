@@ -38,7 +38,8 @@ EXPORTED_SYMBOLS = [
     "salva_hip_set_timestep", "salva_hip_get_counters", "salva_hip_time_kernel", "salva_hip_particles_intersecting_shape", "salva_hip_rebalance",
     "salva_hip_set_boundary_dynamic_sampling", "salva_hip_get_boundary_sources", "salva_hip_set_boundary_dynamic_sampling_host",
     "salva_hip_delete_owned", "salva_hip_enable_counters", "salva_hip_comm_peer_begin", "salva_hip_comm_peer_connect",
-    "salva_hip_comm_peer_abort", "salva_hip_comm_selftest", "salva_hip_comm_time", "salva_hip_clear_boundary_sampling",
+    "salva_hip_comm_peer_abort", "salva_hip_comm_selftest", "salva_hip_comm_time", "salva_hip_clear_boundary_sampling", "salva_hip_get_fluid_async", "salva_hip_wait_download",
+    "salva_hip_host_alloc", "salva_hip_host_free", "salva_hip_host_register", "salva_hip_host_unregister",
 ]
 
 
@@ -186,6 +187,13 @@ def lib():
     L.salva_hip_set_boundary_dynamic_sampling.argtypes = [vp, u32, C.POINTER(Shape), u32, u32]
     L.salva_hip_set_boundary_dynamic_sampling_host.argtypes = [vp, u32, C.POINTER(HostShape), u32, u32]
     L.salva_hip_clear_boundary_sampling.argtypes = [vp, u32]
+    L.salva_hip_get_fluid_async.argtypes = [vp, u32, fp, fp]
+    L.salva_hip_wait_download.argtypes = [vp]
+    L.salva_hip_host_alloc.argtypes = [vp, C.c_uint64]
+    L.salva_hip_host_alloc.restype = C.c_void_p
+    L.salva_hip_host_free.argtypes = [C.c_void_p]
+    L.salva_hip_host_register.argtypes = [vp, C.c_void_p, C.c_uint64]
+    L.salva_hip_host_unregister.argtypes = [C.c_void_p]
     L.salva_hip_get_boundary_sources.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u32)]
     L.salva_hip_get_boundary_particles.argtypes = [vp, u32, fp, fp]
     L.salva_hip_get_boundary_wrench.argtypes = [vp, u32, fp, fp, fp]

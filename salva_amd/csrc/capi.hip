@@ -206,6 +206,52 @@ int salva_hip_set_boundary_dynamic_sampling_host(SalvaHipWorld* world, uint32_t 
     });
 }
 
+int salva_hip_get_fluid_async(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
+        world->w->get_fluid_async(slot, positions_xyz, velocities_xyz);
+        return SALVA_HIP_OK;
+    });
+}
+int salva_hip_wait_download(SalvaHipWorld* world) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->wait_download();
+        return SALVA_HIP_OK;
+    });
+}
+void* salva_hip_host_alloc(SalvaHipWorld* world, uint64_t bytes) {
+    void* p = nullptr;
+    const int rc = guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        SALVA_HIP_CHECK(hipSetDevice(world->w->prm.device));
+        SALVA_HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? p : nullptr;
+}
+int salva_hip_host_free(void* p) {
+    return guarded([&]() -> int {
+        if (p) SALVA_HIP_CHECK(hipHostFree(p));
+        return SALVA_HIP_OK;
+    });
+}
+int salva_hip_host_register(SalvaHipWorld* world, void* p, uint64_t bytes) {
+    return guarded([&]() -> int {
+        if (!world || !p || !bytes) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        SALVA_HIP_CHECK(hipSetDevice(world->w->prm.device));
+        SALVA_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+        return SALVA_HIP_OK;
+    });
+}
+int salva_hip_host_unregister(void* p) {
+    return guarded([&]() -> int {
+        if (p) SALVA_HIP_CHECK(hipHostUnregister(p));
+        return SALVA_HIP_OK;
+    });
+}
+
 int salva_hip_clear_boundary_sampling(SalvaHipWorld* world, uint32_t slot) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");

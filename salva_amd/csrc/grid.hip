@@ -596,10 +596,30 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
                         uint32_t mask = __builtin_bitreverse32(rev) >> (32u - 4u * nq);
                         if (base < b) mask &= ~((1u << (b - base)) - 1u);
                         mask &= nc >= 32u ? 0xffffffffu : ((1u << nc) - 1u);
-                        while (mask) {
-                            const uint32_t s = base + (uint32_t)__builtin_ctz(mask);
-                            mask &= mask - 1u;
-                            if (!multi || ff_allowed(s)) append(s);
+                        if (!multi) {
+                            // two accepted candidates per trip = one finished list dword per trip: the lanes of a wave leave this
+                            // loop after max(ceil(bits / 2)) trips instead of max(bits), and no trip branches on the parity of cnt
+                            if ((cnt & 1u) && mask) {  // complete the dword the previous chunk left half full
+                                const uint32_t s = base + (uint32_t)__builtin_ctz(mask);
+                                mask &= mask - 1u;
+                                if ((cnt >> 1) < c.cap_ff) out[ellq(cnt >> 1)] = pend | (s << 16);
+                                ++cnt;
+                            }
+                            while (mask & (mask - 1u)) {  // at least two bits left
+                                const uint32_t s0 = base + (uint32_t)__builtin_ctz(mask);
+                                mask &= mask - 1u;
+                                const uint32_t s1 = base + (uint32_t)__builtin_ctz(mask);
+                                mask &= mask - 1u;
+                                if ((cnt >> 1) < c.cap_ff) out[ellq(cnt >> 1)] = s0 | (s1 << 16);
+                                cnt += 2u;
+                            }
+                            if (mask) { pend = base + (uint32_t)__builtin_ctz(mask); ++cnt; }
+                        } else {
+                            while (mask) {
+                                const uint32_t s = base + (uint32_t)__builtin_ctz(mask);
+                                mask &= mask - 1u;
+                                if (ff_allowed(s)) append(s);
+                            }
                         }
                     }
                 }

@@ -75,6 +75,8 @@ class World {
     void set_boundary_dynamic_sampling(uint32_t slot, const SalvaHipShape& shape, uint32_t memberships, uint32_t filter);
     void set_boundary_dynamic_sampling_host(uint32_t slot, const SalvaHipHostShape& shape, uint32_t memberships, uint32_t filter);
     void clear_boundary_sampling(uint32_t slot);
+    void get_fluid_async(uint32_t slot, float* pos, float* vel_out);
+    void wait_download();
     uint64_t boundary_len(uint32_t slot) const;
     void get_boundary_sources(uint32_t slot, uint32_t* fluid_slots, uint32_t* indices);
     void set_force_callback(SalvaHipForceCallback cb, void* user, SalvaHipWorld* owner) { force_cb = cb; force_user = user; force_owner = owner; }
@@ -156,6 +158,15 @@ class World {
     hipStream_t stream = nullptr;
     // decomposed runs: evaluate passes over interior tiles run here while the ghost exchange is in flight on `stream`
     hipStream_t stream2 = nullptr;
+    // Asynchronous read-back (salva_hip_get_fluid_async / _wait_download): positions / velocities are scattered into host order
+    // on the main stream (into dl_dev), copied out by the copy stream behind an event, and — for pageable destinations —
+    // handed over from the pinned ring in wait_download.  One download in flight at a time.
+    hipStream_t dl_stream = nullptr;
+    hipEvent_t ev_dl_ready = nullptr, ev_dl_done = nullptr;
+    DevBuf<float> dl_dev[2];
+    float* h_dl[2] = {nullptr, nullptr};
+    size_t h_dl_cap[2] = {0, 0};
+    struct PendingDownload { bool active = false; float* dst[2] = {nullptr, nullptr}; bool staged[2] = {false, false}; size_t bytes = 0; } dl;
     hipEvent_t ev_pre_refresh = nullptr, ev_interior = nullptr;
     bool overlap_exchange = true;   // SALVA_HIP_NO_OVERLAP=1 turns it off (diagnostics)
     template <typename Launch> void evaluate_split(const StepCtx& c, int iteration, Launch&& launch);

@@ -171,6 +171,10 @@ World::~World() {
     (void)hipSetDevice(prm.device);
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+    if (dl_stream) { (void)hipStreamSynchronize(dl_stream); (void)hipStreamDestroy(dl_stream); }
+    if (ev_dl_ready) (void)hipEventDestroy(ev_dl_ready);
+    if (ev_dl_done) (void)hipEventDestroy(ev_dl_done);
+    for (float* p : h_dl) if (p) (void)hipHostFree(p);
     if (ev_pre_refresh) (void)hipEventDestroy(ev_pre_refresh);
     if (ev_interior) (void)hipEventDestroy(ev_interior);
     if (h_rb) (void)hipHostFree(h_rb);
@@ -1650,6 +1654,85 @@ void World::get_fluid(uint32_t slot, float* pos, float* vel_out) {
     }
 }
 
+// ---- asynchronous read-back.  The reference's users read fluid.positions / velocities after every step
+// (integrations/rapier/testbed_plugin.rs:361-367); the synchronous salva_hip_get_fluid costs 4.2 ms per step at 10^6 particles
+// (un-sort into the staging arrays, unpack, a copy into pageable memory at 5.7 GB/s and a stream synchronisation, per array,
+// serial with the step).  Here: two scatter kernels on the main stream write (x, y, z) in host order straight from the sorted
+// working set (~10 us), the copy stream takes them out behind an event while the main stream already runs the next step, and
+// the host collects them with salva_hip_wait_download.  A destination in pinned memory (salva_hip_host_alloc / _register) is
+// written by the DMA engine directly; a pageable one goes through the library's pinned buffers and one memcpy in the wait.
+__global__ void k_scatter_xyz(uint32_t n, const uint32_t* __restrict__ perm, uint32_t off, uint32_t nn, const float4* __restrict__ src,
+                              float* __restrict__ dst) {
+    const uint32_t s = blockIdx.x * BLOCK + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t h = perm[s] - off;
+    if (h >= nn) return;  // (another fluid's particle)
+    const float4 v = src[s];
+    dst[3 * (size_t)h] = v.x; dst[3 * (size_t)h + 1] = v.y; dst[3 * (size_t)h + 2] = v.z;
+}
+static bool host_pointer_is_pinned(const void* p) {
+    hipPointerAttribute_t a{};
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }  // (plain malloc'ed memory is unknown to the runtime)
+    return a.type == hipMemoryTypeHost;
+}
+void World::get_fluid_async(uint32_t slot, float* pos, float* vel_out) {
+    use_device();
+    if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
+    if (comm && dist_started) throw HipError(SALVA_HIP_E_INVALID, "host-order fluid arrays are not maintained in a multi-GPU run: use salva_hip_get_owned");
+    wait_download();  // one download in flight
+    const uint64_t nn = fluids[slot].n, off = fluid_offset(slot);
+    if (nn == 0 || (!pos && !vel_out)) return;
+    if (!dl_stream) {
+        SALVA_HIP_CHECK(hipStreamCreateWithFlags(&dl_stream, hipStreamNonBlocking));
+        SALVA_HIP_CHECK(hipEventCreateWithFlags(&ev_dl_ready, hipEventDisableTiming));
+        SALVA_HIP_CHECK(hipEventCreateWithFlags(&ev_dl_done, hipEventDisableTiming));
+    }
+    const size_t bytes = 3 * nn * sizeof(float);
+    float* dsts[2] = {pos, vel_out};
+    const float4* sorted_src[2] = {posm[cur].p, vel[cur].p};
+    const float4* staged_src[2] = {st_pos.p + off, st_vel.p + off};
+    const bool from_sorted = sorted_valid && !staging_current;
+    for (int a = 0; a < 2; ++a) {
+        if (!dsts[a]) continue;
+        dl_dev[a].ensure(3 * nn, stream, false, 1.1f);
+        if (from_sorted) k_scatter_xyz<<<nblk(n), BLOCK, 0, stream>>>(n, perm[cur].p, (uint32_t)off, (uint32_t)nn, sorted_src[a], dl_dev[a].p);
+        else k_unpack_xyz<<<nblk(nn), BLOCK, 0, stream>>>((uint32_t)nn, staged_src[a], dl_dev[a].p);
+    }
+    SALVA_HIP_CHECK(hipGetLastError());
+    SALVA_HIP_CHECK(hipEventRecord(ev_dl_ready, stream));
+    SALVA_HIP_CHECK(hipStreamWaitEvent(dl_stream, ev_dl_ready, 0));
+    dl = PendingDownload{};
+    dl.bytes = bytes;
+    for (int a = 0; a < 2; ++a) {
+        if (!dsts[a]) continue;
+        dl.dst[a] = dsts[a];
+        dl.staged[a] = !host_pointer_is_pinned(dsts[a]);
+        float* target = dsts[a];
+        if (dl.staged[a]) {
+            if (h_dl_cap[a] < bytes) {
+                if (h_dl[a]) SALVA_HIP_CHECK(hipHostFree(h_dl[a]));
+                h_dl[a] = nullptr; h_dl_cap[a] = 0;
+                const size_t cap = bytes + bytes / 8;
+                SALVA_HIP_CHECK(hipHostMalloc((void**)&h_dl[a], cap, hipHostMallocDefault));
+                h_dl_cap[a] = cap;
+            }
+            target = h_dl[a];
+        }
+        SALVA_HIP_CHECK(hipMemcpyAsync(target, dl_dev[a].p, bytes, hipMemcpyDeviceToHost, dl_stream));
+    }
+    SALVA_HIP_CHECK(hipEventRecord(ev_dl_done, dl_stream));
+    dl.active = true;
+}
+void World::wait_download() {
+    if (!dl.active) return;
+    use_device();
+    dl.active = false;
+    SALVA_HIP_CHECK(hipEventSynchronize(ev_dl_done));
+    for (int a = 0; a < 2; ++a)
+        if (dl.dst[a] && dl.staged[a]) memcpy(dl.dst[a], h_dl[a], dl.bytes);
+}
+
 void World::get_fluid_field(uint32_t slot, int field, float* out) {
     use_device();
     if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
@@ -2172,9 +2255,16 @@ float World::time_kernel(int kernel, int reps) {
     if (kernel == 1 && iisph) throw HipError(SALVA_HIP_E_INVALID, "k_divergence needs a DFSPH world");
     StepCtx cd = last_ctx;
     cd.ctl = nullptr;
+    if (kernel == 6) {  // the apply pass updates w in place: let it run on a copy (w2 is free outside a speculative solve)
+        if (iisph) throw HipError(SALVA_HIP_E_INVALID, "k_divergence_apply needs a DFSPH world");
+        w2.ensure(n, stream, false, 1.1f);
+        SALVA_HIP_CHECK(hipMemcpyAsync(w2.p, w.p, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+        cd.w = w2.p; cd.w2 = w2.p; cd.spec_k = -1; cd.bforce = nullptr;
+    }
     auto launch = [&]() {
         switch (kernel) {
             case 1: launch_divergence(cd, lds, stream); break;
+            case 6: launch_divergence_apply(cd, lds, inv_dt_prev, stream); break;
             case 2: launch_iisph_next_pressure(cd, lds, last_dt, 0.5f, kappa.p, kappa2.p, stream); break;
             case 3: launch_iisph_dij_pj(cd, lds, last_dt, kappa.p, stream); break;
             case 4:  // rebuilds the lists on the tables of the last step.  The positions have moved since those were built, so every

@@ -607,6 +607,18 @@ class _ObjectSet:
         return len(self._items)
 
 
+class _PinnedBlock:
+    """Owner of one salva_hip_host_alloc block."""
+
+    def __init__(self, lib, p):
+        self._lib, self._p = lib, p
+
+    def __del__(self):
+        if self._p:
+            self._lib.salva_hip_host_free(self._p)
+            self._p = None
+
+
 class LiquidWorld:
     """liquid_world.rs:17-209.  `LiquidWorld::new(solver, particle_radius, smoothing_factor)`."""
 
@@ -636,12 +648,18 @@ class LiquidWorld:
         self._counters = Counters(_world=self)
         self._counters_stale = False
         self.last_stats = L.StepStats()
+        self._nsteps = 0
+        self._pending_download = None
 
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            self._L.salva_hip_destroy(h)
-            self._h = None
+            try:
+                if getattr(self, "_pending_download", None) is not None:
+                    self._L.salva_hip_wait_download(h)
+            finally:
+                self._L.salva_hip_destroy(h)
+                self._h = None
 
     # ---- liquid_world.rs:161-208
     def add_fluid(self, fluid: Fluid) -> Fluid:
@@ -701,10 +719,60 @@ class LiquidWorld:
 
     # ---- host <-> device synchronisation
     def _download_fluid(self, f: Fluid):
+        pend = getattr(self, "_pending_download", None)
+        if pend is not None and pend[0] is f:
+            self.wait_download()
+            if not f._device_newer:
+                return
         n = f.num_particles()
         if n:
             L.check(self._L.salva_hip_get_fluid(self._h, f._slot, _fp(f._positions), _fp(f._velocities)))
         f._device_newer = False
+
+    # ---- asynchronous read-back (salva_hip_get_fluid_async): the renderer's per-frame read of fluid.positions / velocities
+    # (testbed_plugin.rs:361-367) off the step's critical path
+    def _pinned(self, n: int):
+        """An (n, 3) float32 array in pinned host memory; the block is released when the last view of it is gone."""
+        nfloat = max(3 * n, 1)
+        p = self._L.salva_hip_host_alloc(self._h, 4 * nfloat)
+        if not p:
+            raise L.SalvaHipError(-1, self._L.salva_hip_last_error().decode())
+        buf = (C.c_float * nfloat).from_address(p)
+        buf._block = _PinnedBlock(self._L, p)  # (rides on the ctypes object numpy keeps as the array's base)
+        return np.frombuffer(buf, dtype=F32, count=3 * n).reshape(n, 3)
+
+    def download_async(self, f: Fluid):
+        """Start reading `f`'s positions and velocities back as they are after the last step; returns at once.  The copy runs on
+        the world's copy stream, into pinned arrays, while the next `step` computes; `wait_download()` completes it and returns
+        the two arrays.  Two pairs of arrays alternate, so the pair returned by one wait stays intact while the next read-back is
+        in flight (render frame k while frame k + 1 is copied)."""
+        self.wait_download()
+        n = f.num_particles()
+        if n == 0:
+            return
+        pins = getattr(f, "_pins", None)
+        if pins is None or len(pins[0][0]) != n:
+            f._pins = pins = [(self._pinned(n), self._pinned(n)), (self._pinned(n), self._pinned(n))]
+            f._pin_next = 0
+        pin = pins[f._pin_next]
+        f._pin_next ^= 1
+        self.sync_to_device()
+        L.check(self._L.salva_hip_get_fluid_async(self._h, f._slot, _fp(pin[0]), _fp(pin[1])))
+        self._pending_download = (f, pin, self._nsteps)
+
+    def wait_download(self):
+        """Complete the read-back started by `download_async`: (positions, velocities) of the state it was started from (None
+        when nothing is pending).  If no step has run since, they also become f.positions / f.velocities (no copy)."""
+        pend = getattr(self, "_pending_download", None)
+        if pend is None:
+            return None
+        self._pending_download = None
+        f, pin, at = pend
+        L.check(self._L.salva_hip_wait_download(self._h))
+        if at == self._nsteps and f._device_newer:
+            f._positions, f._velocities = pin
+            f._device_newer = False
+        return pin
 
     def _fetch_velocity_changes(self, f: Fluid) -> np.ndarray:
         """The solver state that must survive a re-upload of the fluid, n x 4: velocity_changes (dfsph_solver.rs:41) and, in
@@ -850,6 +918,7 @@ class LiquidWorld:
         g = (C.c_float * 3)(*[float(x) for x in gravity])
         st = L.StepStats()
         rc = self._L.salva_hip_step(self._h, dt, g, C.byref(st))
+        self._nsteps += 1
         for f in self._fluids:
             f._device_newer = True
             if f._acc_touched:
