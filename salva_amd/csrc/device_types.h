@@ -174,7 +174,7 @@ struct StepCtx {
 #endif
 };
 
-constexpr uint32_t MASS_SLOTS = 64;  // {min, max} pairs k_cell_keys spreads its mass range over (grid.hip)
+constexpr uint32_t MASS_SLOTS = 64;  // flag words k_cell_keys spreads "a mass differs from particle 0's" over (grid.hip)
 
 // Result block the host reads back (pinned mirror).
 struct Readback {
@@ -188,8 +188,8 @@ struct Readback {
     uint32_t max_cnt_ff, max_cnt_fb;       // } longest contact lists of the step (capacity check)
     uint32_t dcs_count, pad_;          // points emitted by the last DynamicContactSampling pass
     uint64_t ncontacts_own_ff, ncontacts_own_fb;  // list totals over the particles this rank owns (decomposed runs)
-    uint32_t mass_mm[2];  // bit patterns of the smallest / largest posm.w seen by k_cell_keys since the last publication of the totals
-                          // (host side of the publication only; on the device the range lives in World::mass_slots)
+    uint32_t mass_mm[2];  // [0] = bits of particle 0's mass, [1] = the same if no particle's mass differed since the last publication
+                          // of the totals (host side of the publication only; on the device: World::mass_slots, grid.hip k_cell_keys)
     uint32_t pad2_[2];
 };
 

@@ -213,8 +213,62 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_normals(StepCtx c, 
         c.normal[i] = make_float4(nx * c.sc.h, ny * c.sc.h, nz * c.sc.h, c.rho[i]);
     });
 }
+// The same pass for a world with ONE fluid on the packed pair loop of the solver kernels (pairs.h): n_i = h sum_j grad W_ij (m_j / rho_j)
+// is pair_sum_gradient over P = posmr = (x_j, m_j / rho_j) — the record k_density_alpha writes — with k_ij = 1; two contacts per step,
+// kernel_gfac2, no branch; padded lists (a self contact adds no gradient); slices that hold a pair closer than 1e-5 h walk their
+// exact lists with kernel_grad.  One 16-byte array: four or five tiles per CU.
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_normals_one_fluid(StepCtx c) {
+    lds_base_check();
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    struct Own { float4 pi; float rho; uint32_t cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) { return Own{c.posm[i], c.rho[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)}; };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const float4* Lp = nullptr;
+    t.stage(c, static_cast<const float4*>(c.posmr), Lp);  // first carve: LDS byte 0 (lds_ld16)
+    Tile::staged_barrier();
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
+        if (!active) return;
+        const float4 pi = o.pi;
+        float nx, ny, nz;
+        if (near) {
+            nx = ny = nz = 0.0f;
+            for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const float4 pj = lds_ld16(s << 4);
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * pj.w;
+                nx += dx * sc; ny += dy * sc; nz += dz * sc;
+            });
+        } else {
+            f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
+            const f2 tiny = {1.0e-30f, 1.0e-30f};
+            for_each_ff2<true, false, 1>(c, gs, nqu, o.lh, [&](uint32_t off) { return lds_ld16(off); }, [&](const float4& A, const float4& B) { SALVA_PAIR_MATH
+                const f2 dx = {pi.x - A.x, pi.x - B.x}, dy = {pi.y - A.y, pi.y - B.y}, dz = {pi.z - A.z, pi.z - B.z};
+                f2 r2 = dz * dz + tiny;
+                r2 = dy * dy + r2;
+                r2 = dx * dx + r2;
+                const f2 coeff = kernel_gfac2(r2, c.sc) * f2{A.w, B.w};
+                ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
+            });
+            nx = (ax.x + ax.y) * c.sc.gscale; ny = (ay.x + ay.y) * c.sc.gscale; nz = (az.x + az.y) * c.sc.gscale;
+        }
+        c.normal[i] = make_float4(nx * c.sc.h, ny * c.sc.h, nz * c.sc.h, o.rho);  // (.w carries rho_i: see k_akinci_normals)
+    });
+}
+// the packed loops do not reproduce `|d|^2 <= eps^2 -> zero` per contact: they rely on the slices k_density_alpha flags for pairs
+// closer than 1e-5 h, which covers eps only while 1e-5 h >= eps (h >= 0.012)
+static inline bool akinci_fast_ok(const StepCtx& c) { return c.nmodels == 1 && c.sc.tiny_r2 >= c.sc.eps2 && (c.sc.kd | c.sc.kg) == 0; }
 void launch_akinci_normals(const StepCtx& c, const TileLds& L, uint32_t model, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_akinci_normals, c, L, model, s);
+    if (akinci_fast_ok(c)) {
+        SALVA_LAUNCH_TILE(k_akinci_normals_one_fluid, c, L, L.bytes(16, 0, 1), s, c);
+        return;
+    }
     SALVA_LAUNCH_TILE(k_akinci_normals, c, L, L.bytes(24, 0, 3), s, c, model);
 }
 
@@ -302,6 +356,102 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces(StepCtx c, u
         c.acc[i] = a;
     });
 }
+// One fluid: the cohesion + curvature sum on the fixed P | N layout (pairs.h load_pw: position + mass at LDS byte 0, normal + density
+// at a compile-time distance), two contacts per step, no branch:
+//   C(r) / cnorm = (r <= h / 2) ? 2 (h - r)^3 r^3 - h^6 / 64 : (h - r)^3 r^3      (list contacts have r <= h)
+// as one select between two values both contacts compute anyway; the division of k_ij = 2 rho0 / (rho_i + rho_j) is v_rcp_f32;
+// r^2 = 0 (the self contact and the padding) is kept finite by the 1e-30 that rides in the first FMA and contributes dx * (...) = 0.
+// 45 VALU per pair of contacts against ~90 for the scalar walk with its two branches per contact.
+template <uint32_t DS>
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_akinci_forces_one_fluid(StepCtx c, float tc, float ac, float cnorm, float h6_64, float anorm) {
+    lds_base_check();
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    struct Own { float4 pi, ni, a; uint32_t cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) { return Own{c.posm[i], c.normal[i], c.acc[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)}; };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist = pw_dist<DS>(c, t);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    t.stage_pw(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.normal), dist, Bp, Bv, true);
+    Tile::staged_barrier();
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
+        if (!active) return;
+        const float4 pi = o.pi, ni = o.ni;
+        const float ri = ni.w;  // (k_akinci_normals_one_fluid stored rho_i there)
+        const float rho0 = c.rho0_single;
+        const float h = c.sc.h;
+        float4 a = o.a;
+        if (tc != 0.0f) {
+            if (near) {
+                for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                    const RecPW A = load_pw(s << 4, dist);
+                    const float dx = pi.x - A.p.x, dy = pi.y - A.p.y, dz = pi.z - A.p.z;
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    float cs = 0.0f;
+                    if (r2 > c.sc.eps2) {
+                        const float rinv = __builtin_amdgcn_rsqf(r2);
+                        cs = cohesion_kernel(r2 * rinv, h, cnorm, h6_64) * rinv * (-tc * A.p.w);
+                    }
+                    const float kij = fast_div(2.0f * rho0, ri + A.w.w);
+                    a.x += ((ni.x - A.w.x) * -tc + dx * cs) * kij;
+                    a.y += ((ni.y - A.w.y) * -tc + dy * cs) * kij;
+                    a.z += ((ni.z - A.w.z) * -tc + dz * cs) * kij;
+                });
+            } else {
+                f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
+                const f2 tiny = {1.0e-30f, 1.0e-30f};
+                const float hh = 0.5f * h, two_rho0 = 2.0f * rho0, mtc = -tc, ctc = -tc * cnorm;
+                for_each_ff2<true, false, 1>(c, gs, nqu, o.lh, [&](uint32_t off) { return load_pw(off, dist); },
+                                             [&](const RecPW& A, const RecPW& B) { SALVA_PAIR_MATH
+                    const f2 dx = {pi.x - A.p.x, pi.x - B.p.x}, dy = {pi.y - A.p.y, pi.y - B.p.y}, dz = {pi.z - A.p.z, pi.z - B.p.z};
+                    f2 r2 = dz * dz + tiny;
+                    r2 = dy * dy + r2;
+                    r2 = dx * dx + r2;
+                    f2 rinv;
+                    rinv.x = __builtin_amdgcn_rsqf(r2.x); rinv.y = __builtin_amdgcn_rsqf(r2.y);
+                    const f2 r = r2 * rinv;
+                    const f2 hm = h - r;
+                    const f2 q = (hm * hm * hm) * (r * r * r);
+                    const f2 q2 = q * 2.0f - h6_64;
+                    f2 v;
+                    v.x = (r.x <= hh) ? q2.x : q.x; v.y = (r.y <= hh) ? q2.y : q.y;
+                    const f2 cs = v * rinv * (f2{A.p.w, B.p.w} * ctc);
+                    f2 kij;
+                    kij.x = __builtin_amdgcn_rcpf(ri + A.w.w); kij.y = __builtin_amdgcn_rcpf(ri + B.w.w);
+                    kij = kij * two_rho0;
+                    const f2 nx = {ni.x - A.w.x, ni.x - B.w.x}, ny = {ni.y - A.w.y, ni.y - B.w.y}, nz = {ni.z - A.w.z, ni.z - B.w.z};
+                    ax += (nx * mtc + dx * cs) * kij;
+                    ay += (ny * mtc + dy * cs) * kij;
+                    az += (nz * mtc + dz * cs) * kij;
+                });
+                a.x += ax.x + ax.y; a.y += ay.x + ay.y; a.z += az.x + az.y;
+            }
+        }
+        if (ac != 0.0f) {
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const float4 pj = Bp[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                float sc = 0.0f;
+                if (r2 > c.sc.eps2) {
+                    const float rinv = __builtin_amdgcn_rsqf(r2);
+                    sc = adhesion_kernel(r2 * rinv, h, anorm) * rinv * (ac * pj.w * rho0);
+                }
+                const float ex = dx * sc, ey = dy * sc, ez = dz * sc;
+                a.x -= ex; a.y -= ey; a.z -= ez;
+                if (c.bforce && !is_ghost(c, i))
+                    apply_boundary_force(c, boundary_sorted_of_slot(c, t, s), __float_as_uint(Bv[s].w), ex * pi.w, ey * pi.w, ez * pi.w);
+            });
+        }
+        c.acc[i] = a;
+    });
+}
 void launch_akinci_forces(const StepCtx& c, const TileLds& L, uint32_t model, float tension, float adhesion, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_akinci_forces, c, L, model, tension, adhesion, s);
     const double h = c.sc.h;
@@ -309,6 +459,11 @@ void launch_akinci_forces(const StepCtx& c, const TileLds& L, uint32_t model, fl
     const float cnorm = (float)(32.0 / (3.14159265358979323846 * pow(h, 9)));
     const float h6_64 = (float)(pow(h, 6) / 64.0);
     const float anorm = (float)(0.007 / pow(h, 3.25));
+    if (akinci_fast_ok(c)) {
+        const uint32_t ds = pick_ds(pw_slots(L));
+        SALVA_LAUNCH_FIXED(k_akinci_forces_one_fluid, ds, c, L, pw_bytes(L, ds, false), s, c, tension, adhesion, cnorm, h6_64, anorm);
+        return;
+    }
     SALVA_LAUNCH_TILE(k_akinci_forces, c, L, L.bytes(36, 32, 5), s, c, model, tension, adhesion, cnorm, h6_64, anorm);
 }
 

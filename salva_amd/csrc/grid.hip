@@ -57,27 +57,25 @@ void launch_bbox_final(const int32_t* partials, unsigned nblocks, int32_t* bbox6
 }
 
 // ------------------------------------------------------------------------------------------------ keys
-// `mass_mm` (may be null): MASS_SLOTS pairs {min, max} of the bit patterns of pts[i].w — the fluid masses — as unsigned integers;
-// a wave folds its range into the pair blockIdx selects (64 pairs: sixteen thousand waves on ONE address cost 0.3 ms per step at
-// 10^6 particles), and only where that changes the pair.  k_publish_readback folds the pairs and resets them; min == max there
-// means every particle has the same mass (StepCtx::mass_uniform).  (For non-negative floats the unsigned order is the float
-// order; a negative or NaN mass can only make the two differ more, or — if ALL are the same bits — equal, which is still "uniform".)
+// `mass_mm` (may be null): "does every fluid particle have the same mass?" (StepCtx::mass_uniform), at no cost in the usual case.
+// Every thread compares its particle's mass, pts[i].w, with that of particle 0 (one address for all: a scalar load); a wave that
+// sees a different one raises one of MASS_SLOTS flag words (the one blockIdx selects — a two-fluid scene has thousands of such
+// waves, and as many atomics on ONE address cost 0.3 ms), and only if a plain load still finds it clear.  mass_mm[MASS_SLOTS] = the
+// reference bits.  k_publish_readback folds the flags and clears them.  (The first version kept running minima / maxima with
+// system-scope reads before every atomic: 76 us per launch instead of 5, profiles/r04_experiments/r04g_cfg3_kernel_stats.csv.)
 __global__ __launch_bounds__(BLOCK) void k_cell_keys(const float4* __restrict__ pts, uint32_t n, float h, TileGrid g,
                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ idx,
                                                      uint32_t* flags, uint32_t* mass_mm) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const bool on = i < n;
     const float4 p = pts[on ? i : 0u];
-    if (mass_mm) {  // (wave-uniform; every lane takes part in the reductions)
-        const uint32_t mb = __float_as_uint(p.w);
-        const uint32_t lo = ~wave_max_u32(~mb), hi = wave_max_u32(mb);
-        // (a stale read can only cause an atomic too many: a minimum only falls and a maximum only rises between two resets,
-        // which happen in stream order)
-        if ((threadIdx.x & (WAVE - 1)) == 0) {
-            uint32_t* mm = mass_mm + 2u * (blockIdx.x & (MASS_SLOTS - 1u));
-            if (lo < *(volatile uint32_t*)mm) atomicMin(mm, lo);
-            if (hi > *(volatile uint32_t*)(mm + 1)) atomicMax(mm + 1, hi);
+    if (mass_mm) {  // (wave-uniform)
+        const uint32_t ref = __float_as_uint(pts[0].w);
+        if (__builtin_amdgcn_ballot_w64(__float_as_uint(p.w) != ref) != 0ull && (threadIdx.x & (WAVE - 1)) == 0) {
+            uint32_t* f = mass_mm + (blockIdx.x & (MASS_SLOTS - 1u));
+            if (*f == 0u) atomicOr(f, 1u);
         }
+        if (i == 0) mass_mm[MASS_SLOTS] = ref;
     }
     if (!on) return;
     bool bad = false, inside;

@@ -130,8 +130,55 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_pred_density(StepCtx
         c.rho_star[i] = rs;
     });
 }
+// the plane-layout form (tile.h stage_p3; every particle has the mass c.mass_uniform): three tiles per CU, see dfsph.hip
+#define SALVA_IISPH_P3_BOUNDS(DS) __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? 6 : 5)
+template <uint32_t DS>
+__global__ SALVA_IISPH_P3_BOUNDS(DS) void k_iisph_pred_density_p3(StepCtx c, float dt) {
+    lds_base_check();
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    struct Own { float4 pi, wi; float rho; uint32_t mi, cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.w[i], c.rho[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist8 = p3_dist8<DS>(t);
+    t.stage_p3(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), dist8);
+    const float4* Bp = nullptr;
+    const float4* Bv = nullptr;
+    if (c.bvel_zero) t.stage_boundary(c, Bp);
+    else t.stage_boundary(c, Bp, Bv);
+    Tile::staged_barrier();
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
+        if (!active) return;
+        const float4 pi = o.pi, wi = o.wi;
+        const float rho0 = rho0_of(c, o.mi);
+        float delta = near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8)
+                           : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8);
+        for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+            const float4 pj = Bp[s];
+            const float4 vj = c.bvel_zero ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : Bv[s];
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+            delta += pj.w * rho0 * (((wi.x - vj.x) * dx + (wi.y - vj.y) * dy + (wi.z - vj.z) * dz) * g);
+        });
+        const float rs = o.rho + delta * dt;
+        if (!(rs != 0.0f)) atomicOr(c.flags, 1u);  // :140
+        c.rho_star[i] = rs;
+    });
+}
 void launch_iisph_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_iisph_pred_density, c, L, dt, s);
+    if (c.mass_uniform > 0.0f) {
+        const uint32_t ds = pick_ds_p3(L.max_halo_fluid);
+        SALVA_LAUNCH_P3(k_iisph_pred_density_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
+        return;
+    }
     const uint32_t ds = pick_ds(pw_slots(L));
     SALVA_LAUNCH_FIXED(k_iisph_pred_density, ds, c, L, pw_bytes(L, ds, false), s, c, dt);
 }
@@ -334,9 +381,97 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
     });
     E.finish(c, t.slot);
 }
+// the plane-layout form: planes (x, y) | (z, q.x) | (q.y, q.z), the uniform mass applied to the two finished sums
+template <uint32_t DS>
+__global__ SALVA_IISPH_P3_BOUNDS(DS) void k_iisph_next_pressure_p3(StepCtx c, float dt, float omega, const float* __restrict__ p,
+                                                                   float* __restrict__ p_next) {
+    if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
+    lds_base_check();
+    Tile t;
+    t.setup(c);
+    if (t.empty()) { TileErr::zero(c, t.slot); return; }
+    struct Own { float4 pi, dpi; float a, prs, rhoi, rstar; uint32_t mi, cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.dijpj[i], c.aii[i], p[i], c.rho[i], c.rho_star[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist8 = p3_dist8<DS>(t);
+    t.stage_p3(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.iisph_q), dist8);
+    const float4* Bp = nullptr;
+    t.stage_boundary(c, Bp);
+    TileErrC E;
+    E.init(reinterpret_cast<float*>(t.pool + t.pool_used), c);
+    Tile::staged_barrier();
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
+        float err = 0.0f;
+        uint32_t mi = 0;
+        if (active) {
+            mi = o.mi;
+            const float a = o.a;
+            float pn = 0.0f;
+            if (fabsf(a) > 1.0e-9f) {
+                const float rho0 = rho0_of(c, mi);
+                const float4 pi = o.pi, dpi = o.dpi;
+                const float prs = o.prs;
+                const float derr = rho0 - o.rstar;
+                const float fji = dt * dt * pi.w / (o.rhoi * o.rhoi);
+                float sum = 0.0f;
+                if (near) {
+                    for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                        const RecP3 A = load_p3(s << 3, dist8);
+                        const float dx = pi.x - A.xy.x, dy = pi.y - A.xy.y, dz = pi.z - A.zu.x;
+                        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                        const float gx = dx * g, gy = dy * g, gz = dz * g;
+                        const float fx = (dpi.x - A.zu.y) + gx * fji * prs;
+                        const float fy = (dpi.y - A.vw.x) + gy * fji * prs;
+                        const float fz = (dpi.z - A.vw.y) + gz * fji * prs;
+                        sum += fx * gx + fy * gy + fz * gz;
+                    });
+                    sum *= c.mass_uniform;
+                } else {
+                    f2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+                    const f2 tiny = {1.0e-30f, 1.0e-30f};
+                    for_each_ff2<true, false, 2>(c, gs, nqu, o.lh, [&](uint32_t off) { return load_p3(off, dist8); },
+                                                 [&](const RecP3& A, const RecP3& B) { SALVA_PAIR_MATH
+                        const f2 dx = {pi.x - A.xy.x, pi.x - B.xy.x}, dy = {pi.y - A.xy.y, pi.y - B.xy.y}, dz = {pi.z - A.zu.x, pi.z - B.zu.x};
+                        f2 r2 = dz * dz + tiny;
+                        r2 = dy * dy + r2;
+                        r2 = dx * dx + r2;
+                        const f2 g = kernel_gfac2(r2, c.sc);
+                        const f2 ex = {dpi.x - A.zu.y, dpi.x - B.zu.y}, ey = {dpi.y - A.vw.x, dpi.y - B.vw.x}, ez = {dpi.z - A.vw.y, dpi.z - B.vw.y};
+                        sa += (ex * dx + ey * dy + ez * dz) * g;
+                        sb += (g * g) * r2;
+                    });
+                    sum = ((sa.x + sa.y) * c.sc.gscale + (sb.x + sb.y) * (c.sc.gscale * c.sc.gscale) * (fji * prs)) * c.mass_uniform;
+                }
+                for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                    const float4 pj = Bp[s];
+                    const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                    const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                    sum += pj.w * rho0 * ((dpi.x * dx + dpi.y * dy + dpi.z * dz) * g);
+                });
+                pn = (1.0f - omega) * prs + omega * (derr - sum) / a;
+                if (pn > 0.0f) err = (-sum - a * pn) / rho0;
+                else pn = 0.0f;  // clamp negative pressures (:336-339)
+            }
+            p_next[i] = pn;
+        }
+        E.add(c, err, mi, active && !is_ghost(c, i));
+    });
+    E.finish(c, t.slot);
+}
 void launch_iisph_next_pressure(const StepCtx& c, const TileLds& L, float dt, float omega, const float* p, float* p_next,
                                 hipStream_t s) {
     SALVA_OK_DISPATCH(launch_iisph_next_pressure, c, L, dt, omega, p, p_next, s);
+    if (c.mass_uniform > 0.0f) {
+        const uint32_t ds = pick_ds_p3(L.max_halo_fluid);
+        SALVA_LAUNCH_P3(k_iisph_next_pressure_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c, dt, omega, p, p_next);
+        return;
+    }
     const uint32_t ds = pick_ds(pw_slots(L));
     SALVA_LAUNCH_FIXED(k_iisph_next_pressure, ds, c, L, pw_bytes(L, ds, true), s, c, dt, omega, p, p_next);
 }
@@ -392,10 +527,58 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_velocity_changes(Ste
         c.dv[i] = d;
     });
 }
+// the 16-byte plane form (tile.h stage_p2)
+template <uint32_t DS>
+__global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P2_DS_THREE ? 6 : 5) void k_iisph_velocity_changes_p2(StepCtx c, float dt) {
+    lds_base_check();
+    Tile t;
+    t.setup(c);
+    if (t.empty()) return;
+    struct Own { float4 pi, d; float pri; uint32_t mi, cnt, near; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.dv[i], c.alpha[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist8 = p2_dist8<DS>(t);
+    t.stage_p2(c, static_cast<const float4*>(c.posm), static_cast<const float*>(c.alpha), dist8);
+    Tile::staged_barrier();
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const bool near = slice_is_near(c, o.near);
+        if (!active) return;
+        const float4 pi = o.pi;
+        const float rho0 = rho0_of(c, o.mi);
+        const float pri = o.pri;
+        float4 d = o.d;
+        float sx, sy, sz;
+        if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, [&](float kj) { return pri + kj; }, sx, sy, sz);
+        else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, [&](float ka, float kb) { return f2{pri + ka, pri + kb}; }, sx, sy, sz);
+        d.x -= sx * dt; d.y -= sy * dt; d.z -= sz * dt;
+        for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+            const float4 pj = p2_boundary_pos(t, s, dist8);
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            const float sc = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc) * (pj.w * rho0 * pri);
+            const float ax = dx * sc, ay = dy * sc, az = dz * sc;
+            d.x -= ax * dt; d.y -= ay * dt; d.z -= az * dt;
+            if (c.bforce && !is_ghost(c, i)) {
+                const uint32_t jb = boundary_sorted_of_slot(c, t, s);
+                apply_boundary_force(c, jb, __float_as_uint(c.bvel[jb].w), ax * pi.w, ay * pi.w, az * pi.w);
+            }
+        });
+        c.dv[i] = d;
+    });
+}
 void launch_iisph_velocity_changes(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_iisph_velocity_changes, c, L, dt, p, s);
     if (!c.n) return;
     k_iisph_pr2<<<num_blocks(c.n), BLOCK, 0, s>>>(c, p);
+    if (c.mass_uniform > 0.0f) {
+        const uint32_t ds = pick_ds_p2(L.raw_slots());
+        SALVA_LAUNCH_P2(k_iisph_velocity_changes_p2, ds, c, L, p2_bytes(L, ds), s, c, dt);
+        return;
+    }
     const uint32_t ds = pick_ds(pk_slots(L));
     SALVA_LAUNCH_FIXED(k_iisph_velocity_changes, ds, c, L, pk_bytes(L, ds), s, c, dt);
 }

@@ -156,10 +156,8 @@ World::World(const SalvaHipParams& p) : prm(p) {
     d_flags.p = &d_rb.p->flags;
     SALVA_HIP_CHECK(hipMemset(d_rb.p, 0, sizeof(Readback)));
     {
-        uint32_t mm0[2 * MASS_SLOTS];  // (k_cell_keys' running {min, max} pairs of the mass bits)
-        for (uint32_t k = 0; k < MASS_SLOTS; ++k) { mm0[2 * k] = 0xffffffffu; mm0[2 * k + 1] = 0u; }
-        mass_slots.ensure(2 * MASS_SLOTS);
-        SALVA_HIP_CHECK(hipMemcpy(mass_slots.p, mm0, sizeof(mm0), hipMemcpyHostToDevice));
+        mass_slots.ensure(2 * MASS_SLOTS);  // (k_cell_keys' "a mass differs" flags + the reference bits, grid.hip)
+        SALVA_HIP_CHECK(hipMemset(mass_slots.p, 0, 2 * MASS_SLOTS * sizeof(uint32_t)));
     }
     d_counters.ensure(4);
     for (auto& e2 : ev) SALVA_HIP_CHECK(hipEventCreate(&e2));
@@ -751,12 +749,13 @@ void World::build_boundary_grid() {
 // time the host has to wait for it: tools/gap_tsv_report.py.)
 __global__ void k_publish_readback(const Readback* __restrict__ src, const TileAcc* __restrict__ totals, int lists, int end_of_step,
                                    uint32_t* mass_slots, Readback* pub_rb, volatile uint32_t* pub_seq, uint32_t seq) {
-    uint32_t mlo = 0xffffffffu, mhi = 0u;
-    if (totals) {  // (wave-uniform) the mass range k_cell_keys saw since the last such publication; start the next one
-        static_assert(MASS_SLOTS == WAVE, "one pair per lane of the publishing wave");
-        const uint32_t a = mass_slots[2 * threadIdx.x], b = mass_slots[2 * threadIdx.x + 1];
-        mass_slots[2 * threadIdx.x] = 0xffffffffu; mass_slots[2 * threadIdx.x + 1] = 0u;
-        mlo = ~wave_max_u32(~a); mhi = wave_max_u32(b);
+    uint32_t mlo = 0u, mhi = 0u;
+    if (totals) {  // (wave-uniform) did k_cell_keys see a mass other than particle 0's since the last such publication?  start the next one
+        static_assert(MASS_SLOTS == WAVE, "one flag per lane of the publishing wave");
+        const uint32_t differs = wave_max_u32(mass_slots[threadIdx.x]);
+        mass_slots[threadIdx.x] = 0u;
+        mlo = mass_slots[MASS_SLOTS];
+        mhi = differs ? ~mlo : mlo;
     }
     if (threadIdx.x == 0) {
         if (totals) {

@@ -119,40 +119,42 @@ def test_config4_two_phase_2m():
 def long_run_against_oracle(scene, nsteps, gravity, label):
     """>= 30 steps at full size, so that the regime the bench headline lives in (the divergence solve pinned at its
     50-iteration cap once the block has hit the floor) is compared with the oracle, not only the first free-fall steps:
-    per-step contact counts within a bounded slack, iteration traces within +-1, final positions / velocities within
-    max(1e-4 r N, 2 x oracle f32-vs-f64) — the f64 oracle is only run when the stated tolerance alone does not hold."""
+    per-step contact counts within a bounded slack, iteration traces within +-1 wherever the oracle's f32 and f64 builds agree with
+    each other, final positions / velocities within max(1e-4 r N, 2 x oracle f32-vs-f64)."""
     w, fls, _ = scene.make_hip()
     o = scene.make_oracle(threads=host_threads())
+    # the oracle's f64 build runs along (VERDICT r03, item 8): where its iteration counts equal the f32 build's, the device must
+    # hit them within +-1; only at the steps where the restatement's OWN two precisions disagree — the solve creeping along its
+    # tolerance, where the stopping iteration is rounding noise — does the +-10 % allowance of round 3 remain
+    o64 = scene.make_oracle(threads=host_threads(), f64=True)
     trace = []
+    loose_steps = 0
     for k in range(nsteps):
         st = w.step(DT, gravity)
         so = o.step(DT, gravity)
+        s64 = o64.step(DT, gravity)
         slack = 0 if k == 0 else max(4, int(2e-6 * so.ncontacts) * (k + 1))
         assert abs(int(st.ncontacts) - int(so.ncontacts)) <= slack, f"{label} step {k}: contacts {st.ncontacts} vs {so.ncontacts}"
-        # +-1 where a solve converges in a few iterations; while the divergence solve climbs towards its cap the error
-        # creeps along the tolerance (it falls by a few per cent per iteration) and the stopping iteration is worth +-10 %
-        # (observed: 30 vs 28 at step 22 of config 2; the oracle's own f64 run differs from its f32 run as much)
-        tol_it = lambda a, b: max(1, -(-max(a, b) // 10))
-        assert abs(st.n_pressure_iters - so.n_press_iters) <= tol_it(st.n_pressure_iters, so.n_press_iters), f"{label} step {k}: pressure iterations {st.n_pressure_iters} vs {so.n_press_iters}"
-        assert abs(st.n_divergence_iters - so.n_div_iters) <= tol_it(st.n_divergence_iters, so.n_div_iters), f"{label} step {k}: divergence iterations {st.n_divergence_iters} vs {so.n_div_iters}"
-        trace.append((st.n_divergence_iters, st.n_pressure_iters, so.n_div_iters, so.n_press_iters))
-    o64 = None
+
+        def tol_it(a, b, a64):
+            return 1 if b == a64 else max(1, abs(b - a64), -(-max(a, b) // 10))
+        tp = tol_it(st.n_pressure_iters, so.n_press_iters, s64.n_press_iters)
+        td = tol_it(st.n_divergence_iters, so.n_div_iters, s64.n_div_iters)
+        loose_steps += (tp > 1) or (td > 1)
+        assert abs(st.n_pressure_iters - so.n_press_iters) <= tp, f"{label} step {k}: pressure iterations {st.n_pressure_iters} vs {so.n_press_iters} (f64 oracle: {s64.n_press_iters})"
+        assert abs(st.n_divergence_iters - so.n_div_iters) <= td, f"{label} step {k}: divergence iterations {st.n_divergence_iters} vs {so.n_div_iters} (f64 oracle: {s64.n_div_iters})"
+        trace.append((st.n_divergence_iters, st.n_pressure_iters, so.n_div_iters, so.n_press_iters, s64.n_div_iters, s64.n_press_iters))
     for f, h in enumerate(fls):
         po, vo = o.fluid_vec(f, "positions"), o.fluid_vec(f, "velocities")
         d = max_norm_diff(h.positions, po) / R
         vref = max(float(np.abs(vo).max()), 2 * R / DT * 1e-2)
         dv = max_norm_diff(h.velocities, vo) / vref
-        tol_p, tol_v = 1e-4 * nsteps, 1e-4 * nsteps
-        if d >= tol_p or dv >= tol_v:
-            if o64 is None:
-                o64 = scene.make_oracle(threads=host_threads(), f64=True)
-                for _ in range(nsteps):
-                    o64.step(DT, gravity)
-            tol_p = max(tol_p, 2 * max_norm_diff(po, o64.fluid_vec(f, "positions")) / R)
-            tol_v = max(tol_v, 2 * max_norm_diff(vo, o64.fluid_vec(f, "velocities")) / vref)
+        tol_p = max(1e-4 * nsteps, 2 * max_norm_diff(po, o64.fluid_vec(f, "positions")) / R)
+        tol_v = max(1e-4 * nsteps, 2 * max_norm_diff(vo, o64.fluid_vec(f, "velocities")) / vref)
         assert d < tol_p, f"{label}: positions of fluid {f} differ by {d:.2e} r after {nsteps} steps (tolerance {tol_p:.2e})"
         assert dv < tol_v, f"{label}: velocities of fluid {f} differ by {dv:.2e} v_ref (tolerance {tol_v:.2e})"
-    print(label, "iterations (gpu div, gpu press, oracle div, oracle press):", trace)
+    print(label, f"steps with the loose iteration allowance (oracle f32 != f64): {loose_steps} of {nsteps}")
+    print(label, "iterations (gpu div, gpu press, oracle div, oracle press, oracle-f64 div, oracle-f64 press):", trace)
     return trace
 
 

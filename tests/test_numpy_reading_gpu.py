@@ -29,6 +29,12 @@ def f32(x):
     return float(np.float32(x))
 
 
+# f32 device against the f64 reading over 6 steps (both solvers).  The first hardware runs (round 4, profiles/r04_experiments/
+# r04f_numpy_reading_gpu.log) passed the provisional 5e-5 h / 2e-4 m/s / 1e-4 and printed max |dx| 5.7e-7 h, |dv| 2.8e-6 m/s,
+# |drho| / rho 8.9e-7: the bounds below are those figures with a factor ~8 of headroom (f32 summation order x 6 steps).
+TOL_X, TOL_V, TOL_RHO = 5e-6, 2e-5, 8e-6
+
+
 @pytest.mark.parametrize("solver", ["dfsph", "iisph"])
 def test_two_fluid_scene_device_against_the_numpy_reading(hip_lib, solver):
     n = 5
@@ -74,6 +80,7 @@ def test_two_fluid_scene_device_against_the_numpy_reading(hip_lib, solver):
     dw.add_boundary(wall, *G_WALL)
     r0, r1 = dw.fluid_rows(0), dw.fluid_rows(1)
     h = dw.h
+    worst = {"dx": 0.0, "dv": 0.0, "rho": 0.0}
     for k in range(6):
         st = w.step(DT, G)
         dw.step(DT32, G32)
@@ -81,7 +88,11 @@ def test_two_fluid_scene_device_against_the_numpy_reading(hip_lib, solver):
         for fl, rows in ((fa, r0), (fb, r1)):
             dx = np.abs(np.asarray(fl.positions, np.float64) - dw.x[rows]).max()
             dv = np.abs(np.asarray(fl.velocities, np.float64) - dw.v[rows]).max()
-            assert dx < 5e-5 * h, f"step {k}: positions differ by {dx / h:.2e} h"
-            assert dv < 2e-4, f"step {k}: velocities differ by {dv:.2e} m/s"
+            worst["dx"] = max(worst["dx"], dx / h); worst["dv"] = max(worst["dv"], dv)
+            assert dx < TOL_X * h, f"step {k}: positions differ by {dx / h:.2e} h"
+            assert dv < TOL_V, f"step {k}: velocities differ by {dv:.2e} m/s"
         rho = np.concatenate([w.densities(fa), w.densities(fb)])
-        assert np.abs(rho - dw.rho).max() < 1e-4 * dw.rho.max(), f"step {k}: densities"
+        drho = np.abs(rho - dw.rho).max() / dw.rho.max()
+        worst["rho"] = max(worst["rho"], drho)
+        assert drho < TOL_RHO, f"step {k}: densities differ by {drho:.2e} relative"
+    print(f"device vs numpy reading ({solver}): max |dx| {worst['dx']:.2e} h, max |dv| {worst['dv']:.2e} m/s, max |drho| / rho {worst['rho']:.2e}")
