@@ -422,9 +422,35 @@ int salva_hip_clear_boundary_sampling(SalvaHipWorld* world, uint32_t slot);
  * order of salva_hip_get_boundary_particles (the order itself is unspecified, as the reference's hash-grid walk is). */
 int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t* fluid_slots, uint32_t* indices);
 
+/* ---- The working set as it is ("local view"): every fluid particle this world holds — in a decomposed run the particles the
+ * rank owns AND its ghosts — in the order of the last step's cell sort, with global ids.  This is the per-rank form of what
+ * salva_hip_get_fluid / salva_hip_get_fluid_contacts / salva_hip_force_get_state give a single-domain world in host order
+ * (host order does not exist on a rank: particles migrate), and it is what a user-defined `NonPressureForce`
+ * (nonpressure_force.rs:10-30, custom_forces3.rs:67-90) works on in a decomposed run: the callback of
+ * salva_hip_set_force_callback runs on every rank, at its place in the force list, reads its rank's particles and contacts
+ * here and returns accelerations in the same order.  Valid after a completed step and inside a force callback (where
+ * velocities are w = v + dv, like salva_hip_force_get_state); the order changes with every step.
+ *   salva_hip_local_len                   particles in the working set
+ *   salva_hip_get_local                   ids (single domain: the particle's index over all fluids in slot order; decomposed: its
+ *                                         global id), fluid slots, ghost flags (1 = not owned by this rank), positions, velocities,
+ *                                         densities of the last density pass, particle volumes; any pointer may be NULL
+ *   salva_hip_get_local_contacts          ParticlesContacts (contacts.rs:57-131) of ALL local particles as CSR: offsets has
+ *                                         local_len + 1 entries; an entry is (j_model, j) with j a LOCAL index (fluid-fluid) or the
+ *                                         index inside boundary j_model's arrays as this rank uploaded them (fluid-boundary).
+ *                                         Returns the total; entries are written only if `capacity` holds them all.  The lists of
+ *                                         ghost particles are complete for the inner ghost plane only.
+ *   salva_hip_force_add_local_accelerations   inside a force callback: accelerations += a, local order, local_len x 3; what is
+ *                                         added to a ghost is ignored (its owner computes it). */
+uint64_t salva_hip_local_len(const SalvaHipWorld* world);
+int salva_hip_get_local(SalvaHipWorld* world, uint32_t* ids, uint32_t* fluid_slots, uint8_t* is_ghost, float* positions_xyz,
+                        float* velocities_xyz, float* densities, float* volumes);
+int64_t salva_hip_get_local_contacts(SalvaHipWorld* world, int32_t boundary_contacts, uint64_t* offsets, uint32_t* j_model, uint32_t* j,
+                                     uint64_t capacity);
+int salva_hip_force_add_local_accelerations(SalvaHipWorld* world, const float* accelerations_xyz);
+
 /* ---- Asynchronous read-back.  The reference's users read `fluid.positions` / `velocities` after every step
  * (src/integrations/rapier/testbed_plugin.rs:361-367: the renderer walks them each frame).  salva_hip_get_fluid does that
- * synchronously and serially with the step (4.2 ms for the 24 MB of 10^6 particles into pageable memory).  This pair takes the
+ * synchronously and serially with the step (0.6 ms for the 24 MB of 10^6 particles).  This pair takes the
  * copy off the critical path: salva_hip_get_fluid_async enqueues the read-back of the state AS IT IS NOW (after the last completed
  * step, host order, AoS [x,y,z] like salva_hip_get_fluid; either pointer may be NULL) and returns at once; the copy runs on the
  * world's copy stream while the next salva_hip_step is already computing; salva_hip_wait_download blocks until the arrays are

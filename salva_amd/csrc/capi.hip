@@ -206,6 +206,32 @@ int salva_hip_set_boundary_dynamic_sampling_host(SalvaHipWorld* world, uint32_t 
     });
 }
 
+uint64_t salva_hip_local_len(const SalvaHipWorld* world) { return world ? world->w->local_len() : 0; }
+int salva_hip_get_local(SalvaHipWorld* world, uint32_t* ids, uint32_t* fluid_slots, uint8_t* is_ghost, float* positions_xyz,
+                        float* velocities_xyz, float* densities, float* volumes) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->get_local(ids, fluid_slots, is_ghost, positions_xyz, velocities_xyz, densities, volumes);
+        return SALVA_HIP_OK;
+    });
+}
+int64_t salva_hip_get_local_contacts(SalvaHipWorld* world, int32_t boundary_contacts, uint64_t* offsets, uint32_t* j_model, uint32_t* j,
+                                     uint64_t capacity) {
+    int64_t total = 0;
+    const int rc = guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        total = (int64_t)world->w->get_local_contacts(boundary_contacts, offsets, j_model, j, capacity);
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? total : (int64_t)rc;
+}
+int salva_hip_force_add_local_accelerations(SalvaHipWorld* world, const float* accelerations_xyz) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->force_add_local_accelerations(accelerations_xyz);
+        return SALVA_HIP_OK;
+    });
+}
 int salva_hip_get_fluid_async(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");

@@ -358,6 +358,43 @@ __global__ __launch_bounds__(BLOCK) void k_export_contacts(StepCtx c, const uint
         ++o;
     }
 }
+// the same lists over the working set as it is: rows in sorted (local) order for every particle, fluid neighbours as local indices
+__global__ __launch_bounds__(BLOCK) void k_export_contacts_local(StepCtx c, const uint32_t* __restrict__ keys, int boundary,
+                                                                 const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ bmodel_off,
+                                                                 uint32_t* __restrict__ out_model, uint32_t* __restrict__ out_j) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= c.n) return;
+    uint64_t o = offsets[i];
+    const uint32_t cnt = boundary ? c.nfb[i] : c.nff[i];
+    const uint32_t tile = keys[i] / TCELLS;
+    const uint32_t own_begin = c.gf.cell_start[(size_t)tile * TCELLS];
+    const uint32_t slot_t = c.tile_rank[tile];
+    const TileAcc a0 = c.tile_off[slot_t];
+    const uint32_t gs = a0.nsl + (i - own_begin) / WAVE, lane = (i - own_begin) % WAVE;
+    const uint32_t cap = boundary ? c.cap_fb : c.cap_ff;
+    const uint32_t* __restrict__ p = (boundary ? c.nbr_fb : c.nbr_ff) + (size_t)gs * cap * WAVE + 4u * lane;
+    const uint64_t hoff = boundary ? (c.halo_stride ? (uint64_t)slot_t * c.bhalo_stride : a0.sb)
+                                   : (c.halo_stride ? (uint64_t)slot_t * c.halo_stride : a0.s);
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t d = p[ellq(k >> 1)];
+        const uint32_t s = (k & 1u) ? (d >> 16) : (d & 0xffffu);
+        if (boundary) {
+            const uint32_t g = c.bhalo_src[hoff + s];
+            const uint32_t bm = __float_as_uint(c.bvel[g].w);
+            out_model[o] = bm;
+            out_j[o] = c.bperm[g] - bmodel_off[bm];
+        } else {
+            const uint32_t g = c.halo_src[hoff + s];
+            out_model[o] = c.model[g];
+            out_j[o] = g;
+        }
+        ++o;
+    }
+}
+void launch_export_contacts_local(const StepCtx& c, const uint32_t* keys, int boundary, const uint64_t* offsets, const uint32_t* bmodel_off,
+                                  uint32_t* out_model, uint32_t* out_j, hipStream_t s) {
+    if (c.n) k_export_contacts_local<<<div_up(c.n, BLOCK), BLOCK, 0, s>>>(c, keys, boundary, offsets, bmodel_off, out_model, out_j);
+}
 void launch_export_contacts(const StepCtx& c, const uint32_t* keys, uint32_t slot, int boundary, const uint64_t* offsets,
                             const uint32_t* model_off, const uint32_t* bmodel_off, uint32_t* out_model, uint32_t* out_j, hipStream_t s) {
     if (c.n) k_export_contacts<<<div_up(c.n, BLOCK), BLOCK, 0, s>>>(c, keys, slot, boundary, offsets, model_off, bmodel_off, out_model, out_j);

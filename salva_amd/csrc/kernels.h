@@ -36,6 +36,8 @@ void launch_sorted_to_stage(uint32_t n, FluidArrays in, float4* st_pos, float4* 
 void launch_unsort_f32(uint32_t n, const uint32_t* perm, const float* in, float* out, hipStream_t s);
 void launch_export_contacts(const StepCtx& c, const uint32_t* keys, uint32_t slot, int boundary, const uint64_t* offsets,
                             const uint32_t* model_off, const uint32_t* bmodel_off, uint32_t* out_model, uint32_t* out_j, hipStream_t s);
+void launch_export_contacts_local(const StepCtx& c, const uint32_t* keys, int boundary, const uint64_t* offsets, const uint32_t* bmodel_off,
+                                  uint32_t* out_model, uint32_t* out_j, hipStream_t s);
 void launch_unsort_u32(uint32_t n, const uint32_t* perm, const uint32_t* in, uint32_t* out, hipStream_t s);
 void launch_unsort_u32_as_f32(uint32_t n, const uint32_t* perm, const uint32_t* in, float* out, hipStream_t s);
 void launch_unsort_f4(uint32_t n, const uint32_t* perm, const float4* in, float4* out, hipStream_t s);

@@ -75,6 +75,10 @@ class World {
     void set_boundary_dynamic_sampling(uint32_t slot, const SalvaHipShape& shape, uint32_t memberships, uint32_t filter);
     void set_boundary_dynamic_sampling_host(uint32_t slot, const SalvaHipHostShape& shape, uint32_t memberships, uint32_t filter);
     void clear_boundary_sampling(uint32_t slot);
+    uint64_t local_len() const { return n; }
+    void get_local(uint32_t* ids, uint32_t* fluid_slots, uint8_t* is_ghost, float* positions, float* velocities, float* densities, float* volumes);
+    uint64_t get_local_contacts(int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity);
+    void force_add_local_accelerations(const float* acc_h);
     void get_fluid_async(uint32_t slot, float* pos, float* vel_out);
     void wait_download();
     uint64_t boundary_len(uint32_t slot) const;
@@ -203,6 +207,7 @@ class World {
     DevBuf<int32_t> bbox_partials;
     TileLds lds;
     float mass_uniform = 0.0f;  // StepCtx::mass_uniform of the current step (0: masses differ, or not known)
+    bool mass_known = false;    // mass_uniform describes the particles as they are (set by a publication, cleared by host edits)
     bool tile_trace = false;    // SALVA_HIP_TILE_TRACE=1: one line of tile statistics per step on stderr
     bool no_planes = false;     // SALVA_HIP_NO_PLANES=1 (A/B): keep the 32-byte-per-slot evaluate kernels
 #ifdef SALVA_HIP_DIAG

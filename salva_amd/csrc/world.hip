@@ -930,7 +930,8 @@ void World::run_forces(const StepCtx& c) {
                 case SALVA_HIP_FORCE_CUSTOM: {
                     // a host `NonPressureForce::solve` at its place in the list (nonpressure_force.rs:10-30)
                     if (!force_cb) throw HipError(SALVA_HIP_E_INVALID, "a SALVA_HIP_FORCE_CUSTOM entry needs salva_hip_set_force_callback");
-                    if (comm) throw HipError(SALVA_HIP_E_INVALID, "host force callbacks are not available in a multi-GPU run");
+                    // (in a decomposed run the callback runs on every rank and works on the rank's local view:
+                    // salva_hip_get_local / _get_local_contacts / _force_add_local_accelerations)
                     last_ctx = c; last_ctx.ctl = nullptr; have_last_ctx = true;  // what the contact export reads
                     wait_stream();
                     in_force_cb = true;
@@ -1089,6 +1090,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
 
     // ---- (re)build the sorted working set from the canonical arrays after host edits
     if (!sorted_valid) {
+        mass_known = false;  // (the host edited the particles: their masses are read again by this step's k_cell_keys)
         launch_stage_to_sorted(n, st_pos.p, st_vel.p, st_dv.p, st_model.p, rho0_tab.p, arrays(cur), stream);
         sorted_valid = true;
         if (comm) {  // global particle ids replace the host-order permutation; nothing is a ghost yet
@@ -1150,7 +1152,9 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     if (has_dyn && comm) throw HipError(SALVA_HIP_E_INVALID, "DynamicContactSampling is not available in a multi-GPU run");
     // a pass can be repeated from the untouched pre-sort buffers iff it has no side effect outside the world's own arrays
     const bool can_redo = !comm && !any_wants_forces && !has_custom && !has_dyn;
-    const bool can_speculate = !spec_off && can_redo && !b_dirty && pred_valid && pred_n == n;
+    // (mass_known: the kernels of a pass are chosen by StepCtx::mass_uniform, which a speculative pass — it does not wait for the
+    // publication that carries it — can only inherit; a host edit since the last publication may have changed the masses)
+    const bool can_speculate = !spec_off && can_redo && !b_dirty && pred_valid && pred_n == n && mass_known;
     // The neighbour-list capacity check (longest list <= ELL capacity) costs a read-back with an idle GPU in the middle of the
     // step although it fails about once per run (the capacity follows the longest list seen so far): where the pass can be
     // repeated, check at the end of the step with the read-back that happens there anyway, and repeat on overflow.
@@ -1244,10 +1248,10 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
                 float m;
                 memcpy(&m, &h_rb->mass_mm[0], sizeof(m));
                 mass_uniform = (h_rb->mass_mm[0] == h_rb->mass_mm[1] && m > 0.0f && std::isfinite(m) && !no_planes) ? m : 0.0f;
+                mass_known = true;
             }
         } else {
-            reorder();
-            mass_uniform = 0.0f;  // (a speculative pass does not wait for the publication that carries the mass range)
+            reorder();  // (mass_uniform: what the last exact pass found — nothing has touched the particles since, see can_speculate)
         }
         nlaunch = tt.nonempty;
         lds.max_halo_fluid = tt.max_s;
@@ -1594,7 +1598,7 @@ uint64_t World::particles_in_shape(const float t[3], const float q[4], const Sal
 uint64_t World::get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity) {
     use_device();
     if (slot >= fluids.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot out of range");
-    if (comm) throw HipError(SALVA_HIP_E_INVALID, "contact export is not available in a multi-GPU run");
+    if (comm) throw HipError(SALVA_HIP_E_INVALID, "host-order contact export does not exist in a multi-GPU run: use salva_hip_get_local_contacts");
     if (!have_last_ctx || !sorted_valid) throw HipError(SALVA_HIP_E_INVALID, "no completed step: there are no contact lists yet");
     const uint64_t nn = fluids[slot].n, off = fluid_offset(slot);
     std::vector<uint32_t> cnt(nn, 0);
@@ -1626,6 +1630,87 @@ uint64_t World::get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offset
     return total;
 }
 
+// ---- the working set as it is (include/salva_hip.h "local view"): sorted order, global ids; per rank in a decomposed run
+__global__ void k_local_ghost_flags(uint32_t n, const uint32_t* __restrict__ gtag, uint8_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (gtag && (gtag[i] & 0x80000000u)) ? 1 : 0;
+}
+void World::get_local(uint32_t* ids, uint32_t* fluid_slots, uint8_t* is_ghost, float* positions, float* velocities, float* densities, float* volumes) {
+    use_device();
+    if (!sorted_valid || (!have_last_ctx && !in_force_cb)) throw HipError(SALVA_HIP_E_INVALID, "no completed step: the working set has no order yet");
+    if (n == 0) return;
+    if (ids) SALVA_HIP_CHECK(hipMemcpyAsync(ids, perm[cur].p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (fluid_slots) SALVA_HIP_CHECK(hipMemcpyAsync(fluid_slots, model[cur].p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (is_ghost) {
+        DevBuf<uint8_t> flags;
+        flags.ensure(n);
+        k_local_ghost_flags<<<nblk(n), BLOCK, 0, stream>>>(n, comm ? gtag[cur].p : nullptr, flags.p);
+        SALVA_HIP_CHECK(hipMemcpyAsync(is_ghost, flags.p, (size_t)n, hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    scratch_f.ensure(3 * (size_t)n, stream, false, 1.1f);
+    for (int k = 0; k < 2; ++k) {
+        float* out = k == 0 ? positions : velocities;
+        if (!out) continue;
+        // inside a force callback fluid.velocities equal w = v + dv (dfsph_solver.rs:688-693), as in force_get_state
+        const float4* src = k == 0 ? posm[cur].p : (in_force_cb ? last_ctx.w : vel[cur].p);
+        k_unpack_xyz<<<nblk(n), BLOCK, 0, stream>>>(n, src, scratch_f.p);
+        SALVA_HIP_CHECK(hipMemcpyAsync(out, scratch_f.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    if (densities) SALVA_HIP_CHECK(hipMemcpyAsync(densities, rho.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (volumes) {  // (they ride in vel.w, device_types.h)
+        k_unpack_w<<<nblk(n), BLOCK, 0, stream>>>(n, vel[cur].p, scratch_f.p);
+        SALVA_HIP_CHECK(hipMemcpyAsync(volumes, scratch_f.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    }
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+}
+uint64_t World::get_local_contacts(int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity) {
+    use_device();
+    if (!have_last_ctx || !sorted_valid) throw HipError(SALVA_HIP_E_INVALID, "no completed step: there are no contact lists yet");
+    std::vector<uint32_t> cnt(n, 0);
+    if (!(boundary && nb == 0) && n) {
+        SALVA_HIP_CHECK(hipMemcpyAsync(cnt.data(), boundary ? nfb.p : nff.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    std::vector<uint64_t> offs((size_t)n + 1, 0);
+    for (uint64_t k = 0; k < n; ++k) offs[k + 1] = offs[k] + cnt[k];
+    const uint64_t total = offs[n];
+    if (offsets) memcpy(offsets, offs.data(), ((size_t)n + 1) * sizeof(uint64_t));
+    if (!j_model || !j || capacity < total || total == 0) return total;
+    std::vector<uint32_t> boff(std::max<size_t>(bounds.size(), 1), 0);
+    for (uint32_t s = 0; s < bounds.size(); ++s) boff[s] = (uint32_t)boundary_offset(s);
+    DevBuf<uint64_t> d_offs;
+    DevBuf<uint32_t> d_boff, d_jm, d_j;
+    d_offs.ensure((size_t)n + 1); d_boff.ensure(boff.size()); d_jm.ensure(total); d_j.ensure(total);
+    SALVA_HIP_CHECK(hipMemcpyAsync(d_offs.p, offs.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(d_boff.p, boff.data(), boff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    launch_export_contacts_local(last_ctx, keys[1].p, boundary, d_offs.p, d_boff.p, d_jm.p, d_j.p, stream);
+    SALVA_HIP_CHECK(hipMemcpyAsync(j_model, d_jm.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipMemcpyAsync(j, d_j.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    return total;
+}
+__global__ void k_add_acc_local(uint32_t n, const float* __restrict__ in, float4* __restrict__ acc) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    float4 a = acc[s];
+    a.x += in[3 * (size_t)s]; a.y += in[3 * (size_t)s + 1]; a.z += in[3 * (size_t)s + 2];
+    acc[s] = a;
+}
+void World::force_add_local_accelerations(const float* acc_h) {
+    use_device();
+    if (!in_force_cb) throw HipError(SALVA_HIP_E_INVALID, "only available inside a force callback");
+    if (!acc_h) throw HipError(SALVA_HIP_E_INVALID, "null accelerations");
+    if (n == 0) return;
+    scratch_f.ensure(3 * (size_t)n, stream, false, 1.1f);
+    SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, acc_h, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
+    // (what lands on a ghost is overwritten by the refresh of w that follows the forces, world_dist)
+    k_add_acc_local<<<nblk(n), BLOCK, 0, stream>>>(n, scratch_f.p, last_ctx.acc);
+    SALVA_HIP_CHECK(hipGetLastError());
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
 void World::get_force_stats(uint32_t slot, uint32_t force, int32_t* iters, float* err) {
     if (slot >= fluids.size() || force >= fluids[slot].forces.size()) throw HipError(SALVA_HIP_E_INVALID, "fluid slot / force index out of range");
     const FluidSlot& f = fluids[slot];
@@ -1654,9 +1739,9 @@ void World::get_fluid(uint32_t slot, float* pos, float* vel_out) {
 }
 
 // ---- asynchronous read-back.  The reference's users read fluid.positions / velocities after every step
-// (integrations/rapier/testbed_plugin.rs:361-367); the synchronous salva_hip_get_fluid costs 4.2 ms per step at 10^6 particles
-// (un-sort into the staging arrays, unpack, a copy into pageable memory at 5.7 GB/s and a stream synchronisation, per array,
-// serial with the step).  Here: two scatter kernels on the main stream write (x, y, z) in host order straight from the sorted
+// (integrations/rapier/testbed_plugin.rs:361-367); the synchronous salva_hip_get_fluid costs 0.6 ms per step at 10^6 particles
+// (un-sort into the staging arrays, unpack, copy, stream synchronisation, per array, serial with the step: 1.91 against 1.31 ms per
+// step over the bench protocol, tools/pcie_probe.py — round 3's "5.57 ms" compared different steps of the scene).  Here: two scatter kernels on the main stream write (x, y, z) in host order straight from the sorted
 // working set (~10 us), the copy stream takes them out behind an event while the main stream already runs the next step, and
 // the host collects them with salva_hip_wait_download.  A destination in pinned memory (salva_hip_host_alloc / _register) is
 // written by the DMA engine directly; a pageable one goes through the library's pinned buffers and one memcpy in the wait.

@@ -947,6 +947,9 @@ class LiquidWorld:
             try:
                 f = next(x for x in self._fluids if x._slot == slot)
                 force = f.nonpressure_forces[index]
+                if getattr(self, "_comm", None) is not None:
+                    self._solve_custom_force_locally(f, force, dt, inv_dt)
+                    return 0
                 n = f.num_particles()
                 pos, vel, dens = np.zeros((n, 3), F32), np.zeros((n, 3), F32), np.zeros(n, F32)
                 L.check(self._L.salva_hip_force_get_state(self._h, slot, _fp(pos), _fp(vel), _fp(dens)))
@@ -984,6 +987,80 @@ class LiquidWorld:
         self._force_cb = L.FORCE_CALLBACK(callback)
         self._force_cb_error = None
         L.check(self._L.salva_hip_set_force_callback(self._h, self._force_cb, None))
+
+    # ---- the working set as it is (include/salva_hip.h "local view"): what a rank of a decomposed run can look at
+    def local_view(self):
+        """dict of the particles this world holds after the last step (or inside a force callback), in the order of its cell sort:
+        ids (global ids in a decomposed run), fluid_slots, is_ghost, positions, velocities, densities, volumes."""
+        n = int(self._L.salva_hip_local_len(self._h))
+        v = dict(ids=np.zeros(n, np.uint32), fluid_slots=np.zeros(n, np.uint32), is_ghost=np.zeros(n, np.uint8),
+                 positions=np.zeros((n, 3), F32), velocities=np.zeros((n, 3), F32), densities=np.zeros(n, F32), volumes=np.zeros(n, F32))
+        if n:
+            u32p, u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+            L.check(self._L.salva_hip_get_local(self._h, v["ids"].ctypes.data_as(u32p), v["fluid_slots"].ctypes.data_as(u32p),
+                                                v["is_ghost"].ctypes.data_as(u8p), _fp(v["positions"]), _fp(v["velocities"]),
+                                                _fp(v["densities"]), _fp(v["volumes"])))
+        v["is_ghost"] = v["is_ghost"].astype(bool)
+        return v
+
+    def local_contacts(self, boundary: bool = False):
+        """(offsets[n + 1], j_model, j) over the local view: `j` is a local index (fluid-fluid) or an index into boundary j_model's
+        arrays as this rank uploaded them."""
+        n = int(self._L.salva_hip_local_len(self._h))
+        offsets = np.zeros(n + 1, np.uint64)
+        u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        total = int(self._L.salva_hip_get_local_contacts(self._h, int(boundary), offsets.ctypes.data_as(u64p), None, None, 0))
+        if total < 0:
+            L.check(total)
+        jm, j = np.zeros(max(total, 1), np.uint32), np.zeros(max(total, 1), np.uint32)
+        if total:
+            rc = int(self._L.salva_hip_get_local_contacts(self._h, int(boundary), offsets.ctypes.data_as(u64p), jm.ctypes.data_as(u32p),
+                                                          j.ctypes.data_as(u32p), total))
+            if rc < 0:
+                L.check(rc)
+        return offsets, jm[:total], j[:total]
+
+    def _solve_custom_force_locally(self, f, force, dt, inv_dt):
+        """A user `NonPressureForce::solve` on ONE rank of a decomposed run: the fluid it sees is the rank's part of it (owned
+        particles and ghosts, local order), the contacts are the rank's lists re-indexed to that part; the accelerations it adds
+        to the ghosts are dropped (their owners compute them)."""
+        lv = self.local_view()
+        slot = f._slot
+        slots = lv["fluid_slots"]
+        within = np.zeros(len(slots), np.int64)  # index of a local particle inside its own fluid's local part
+        parts = {}
+        for m in np.unique(slots):
+            sel = np.nonzero(slots == m)[0]
+            within[sel] = np.arange(len(sel))
+            parts[int(m)] = sel
+        sel = parts.get(slot, np.zeros(0, np.int64))
+
+        def rows_of(offsets, jm, j, fluid_neighbours):
+            cnt = (offsets[1:] - offsets[:-1]).astype(np.int64)[sel]
+            new_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+            idx = np.concatenate([np.arange(int(offsets[i]), int(offsets[i + 1])) for i in sel]) if len(sel) else np.zeros(0, np.int64)
+            jm2, j2 = jm[idx], j[idx]
+            if fluid_neighbours:
+                j2 = within[j2].astype(np.uint32)
+            return new_off, jm2, j2
+
+        pos = lv["positions"]
+        bpos = {}
+
+        def positions_of_boundary(m):
+            if m not in bpos:
+                b = next(x for x in self._boundaries if x._slot == m)
+                bpos[m] = self._boundary_particles(b)[0]
+            return bpos[m]
+
+        ff = ParticlesContacts(slot, *rows_of(*self.local_contacts(False), True), pos[sel], lambda m: pos[parts[int(m)]], self.h())
+        fb = ParticlesContacts(slot, *rows_of(*self.local_contacts(True), False), pos[sel], positions_of_boundary, self.h())
+        view = FluidView(pos[sel], lv["velocities"][sel], lv["volumes"][sel], f.density0)
+        view.ids, view.is_ghost = lv["ids"][sel], lv["is_ghost"][sel]
+        force.solve(TimestepView(dt, inv_dt), self.h(), ff, fb, view, list(self._boundaries), lv["densities"][sel])
+        acc = np.zeros((len(slots), 3), F32)
+        acc[sel] = np.asarray(view.accelerations, F32)
+        L.check(self._L.salva_hip_force_add_local_accelerations(self._h, _fp(acc)))
 
     # ---- checkpoint / restart (SURVEY.md §8 row f4; include/salva_hip.h "Checkpoint / restart")
     def checkpoint(self) -> dict:
