@@ -104,6 +104,17 @@ impl Comm {
 }
 
 /// The particles a rank owns after a step of a decomposed run (`salva_hip_get_owned`), in no particular order.
+/// `LiquidWorld::local_view`
+pub struct LocalView {
+    pub ids: Vec<u32>,
+    pub fluid_slots: Vec<u32>,
+    pub is_ghost: Vec<u8>,
+    pub positions: Vec<Point3<Real>>,
+    pub velocities: Vec<Vector3<Real>>,
+    pub densities: Vec<Real>,
+    pub volumes: Vec<Real>,
+}
+
 pub struct OwnedParticles {
     /// global ids: `gid_offset` + upload index of the rank that created the particle
     pub gids: Vec<u32>,
@@ -123,6 +134,60 @@ impl LiquidWorld {
         check(unsafe { ffi::salva_hip_set_domain(self.raw(), comm.raw, cell_lo, cell_hi, gid_offset) })?;
         self.set_auto_sync(false);
         Ok(())
+    }
+
+    /// The working set as it is (`salva_hip_get_local`): every particle this world holds — on a rank of a decomposed run the
+    /// owned particles and the ghosts — in the order of the last step's cell sort.  Also valid inside a force callback, where
+    /// `velocities` are v + dv; that is what a user `NonPressureForce` works on in a decomposed run (`local_contacts`,
+    /// `force_add_local_accelerations`).
+    pub fn local_view(&mut self) -> Result<LocalView, Error> {
+        let n = unsafe { ffi::salva_hip_local_len(self.raw()) } as usize;
+        let mut v = LocalView {
+            ids: vec![0; n],
+            fluid_slots: vec![0; n],
+            is_ghost: vec![0; n],
+            positions: vec![Point3::origin(); n],
+            velocities: vec![Vector3::zeros(); n],
+            densities: vec![0.0; n],
+            volumes: vec![0.0; n],
+        };
+        check(unsafe {
+            ffi::salva_hip_get_local(
+                self.raw(),
+                v.ids.as_mut_ptr(),
+                v.fluid_slots.as_mut_ptr(),
+                v.is_ghost.as_mut_ptr(),
+                v.positions.as_mut_ptr() as *mut f32,
+                v.velocities.as_mut_ptr() as *mut f32,
+                v.densities.as_mut_ptr(),
+                v.volumes.as_mut_ptr(),
+            )
+        })?;
+        Ok(v)
+    }
+
+    /// `ParticlesContacts` of every local particle as CSR (`salva_hip_get_local_contacts`): (offsets, j_model, j) with `j` a
+    /// local index (fluid-fluid) or an index into boundary `j_model`'s arrays as this rank uploaded them.
+    pub fn local_contacts(&mut self, boundary: bool) -> Result<(Vec<u64>, Vec<u32>, Vec<u32>), Error> {
+        let n = unsafe { ffi::salva_hip_local_len(self.raw()) } as usize;
+        let mut offsets = vec![0u64; n + 1];
+        let total = unsafe { ffi::salva_hip_get_local_contacts(self.raw(), boundary as i32, offsets.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut(), 0) };
+        if total < 0 {
+            check(total as i32)?;
+        }
+        let (mut jm, mut j) = (vec![0u32; total as usize], vec![0u32; total as usize]);
+        if total > 0 {
+            let rc = unsafe { ffi::salva_hip_get_local_contacts(self.raw(), boundary as i32, offsets.as_mut_ptr(), jm.as_mut_ptr(), j.as_mut_ptr(), total as u64) };
+            if rc < 0 {
+                check(rc as i32)?;
+            }
+        }
+        Ok((offsets, jm, j))
+    }
+
+    /// Inside a force callback: accelerations += `acc` (local order; what lands on a ghost is ignored).
+    pub fn force_add_local_accelerations(&mut self, acc: &[Vector3<Real>]) -> Result<(), Error> {
+        check(unsafe { ffi::salva_hip_force_add_local_accelerations(self.raw(), acc.as_ptr() as *const f32) })
     }
 
     pub fn owned(&mut self) -> Result<OwnedParticles, Error> {

@@ -488,6 +488,36 @@ class LiquidWorld {  // liquid_world.rs
         }
         check(rc);
     }
+    // The working set as it is (salva_hip_get_local): every particle this world holds — on a rank of a decomposed run the owned
+    // particles and the ghosts — in the order of the last step's cell sort; what a user NonPressureForce works on there.
+    struct LocalView {
+        std::vector<uint32_t> ids, fluid_slots;
+        std::vector<uint8_t> is_ghost;
+        std::vector<Vec3> positions, velocities;
+        std::vector<Real> densities, volumes;
+    };
+    LocalView local_view() {
+        const size_t n = (size_t)salva_hip_local_len(w_);
+        LocalView v;
+        v.ids.resize(n); v.fluid_slots.resize(n); v.is_ghost.resize(n); v.positions.resize(n); v.velocities.resize(n);
+        v.densities.resize(n); v.volumes.resize(n);
+        if (n)
+            check(salva_hip_get_local(w_, v.ids.data(), v.fluid_slots.data(), v.is_ghost.data(), v.positions[0].data(), v.velocities[0].data(),
+                                      v.densities.data(), v.volumes.data()));
+        return v;
+    }
+    // CSR contact lists over the local view: j = local index (fluid-fluid) / index in boundary j_model's arrays (fluid-boundary)
+    void local_contacts(bool boundary, std::vector<uint64_t>& offsets, std::vector<uint32_t>& j_model, std::vector<uint32_t>& j) {
+        offsets.assign((size_t)salva_hip_local_len(w_) + 1, 0);
+        const int64_t total = salva_hip_get_local_contacts(w_, boundary ? 1 : 0, offsets.data(), nullptr, nullptr, 0);
+        if (total < 0) check((int)total);
+        j_model.assign((size_t)total, 0); j.assign((size_t)total, 0);
+        if (total) {
+            const int64_t rc = salva_hip_get_local_contacts(w_, boundary ? 1 : 0, offsets.data(), j_model.data(), j.data(), (uint64_t)total);
+            if (rc < 0) check((int)rc);
+        }
+    }
+    void force_add_local_accelerations(const std::vector<Vec3>& acc) { check(salva_hip_force_add_local_accelerations(w_, acc[0].data())); }
     // Asynchronous read-back of one fluid (salva_hip_get_fluid_async): start it after a step, run the next step, collect the
     // arrays of the earlier state with wait_download().  `positions` / `velocities` must hold num_particles() entries and
     // stay untouched until the wait; pin them with host_register() once for a read-back at PCIe speed.

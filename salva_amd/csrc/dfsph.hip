@@ -128,6 +128,135 @@ void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// compute_densities + compute_alphas + the FIRST compute_divergences of the step (dfsph_solver.rs:628-665, :165-216, :279-356) in
+// one pass.  The first evaluate of the divergence solve sums m_j (w_i - w_j) . grad W_ij over the same lists with the gradient
+// factor this pass computes anyway, and needs nothing the density pass has not got (alpha_i follows from the particle's own
+// sums; w = v + dv is written by the reorder): staging w next to the positions — the plane layout of the evaluate kernels — and
+// ~8 more VALU per pair of contacts replace a whole neighbour pass, ~40 us of every DFSPH step at 10^6 particles.  Taken when
+// every particle has the same mass (the plane layout's condition; the mass multiplies the finished sums) in a DFSPH world with
+// the default kernels; World::dfsph_solve then skips the launch of its iteration 0.  Writes what k_density_alpha writes (rho,
+// alpha, posmr, slice_near) and what k_divergence writes (kappa = D rho alpha, the tile's error partials).
+// ------------------------------------------------------------------------------------------------
+// (96 VGPRs, two tiles per CU: held to 80 for a third tile the kernel spills 20 registers and is slower — free-fall step 0.664
+// against 0.656 ms, 0.683 without the fusion; profiles/r04_experiments/r04j_fused_first_divergence.log)
+#ifndef SALVA_DAD_WAVES
+#define SALVA_DAD_WAVES 5
+#endif
+template <uint32_t DS>
+__global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_WAVES : 5) void k_density_alpha_div_p3(StepCtx c) {
+    lds_base_check();
+    Tile t;
+    t.setup(c);
+    if (t.empty()) { TileErr::zero(c, t.slot); return; }
+    struct Own { float4 pi, wi; uint32_t mi, cnt, cntb; ListRegs lh; };
+    auto load_own = [&](uint32_t i, uint32_t gs) {
+        return Own{c.posm[i], c.w[i], c.model[i], c.nff[i], c.nb ? c.nfb[i] : 0u, list_regs(c, gs)};
+    };
+    uint32_t i0, gs0;
+    t.first_own(i0, gs0);
+    const Own own0 = load_own(i0, gs0);
+    const uint32_t dist8 = p3_dist8<DS>(t);
+    t.stage_p3(c, static_cast<const float4*>(c.posm), static_cast<const float4*>(c.w), dist8);
+    const float4* Bp = nullptr;
+    t.stage_boundary(c, Bp);
+    TileErrC E;
+    E.init(reinterpret_cast<float*>(t.pool + t.pool_used), c);
+    Tile::staged_barrier();
+    const float m = c.mass_uniform;
+    t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
+        const uint32_t nqu = slice_list_dwords(o.cnt, active);
+        const float4 pi = o.pi, wi = o.wi;
+        float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f, div = 0.0f;
+        uint32_t nnear = 0;
+        if (active) {  // (an idle lane's list row was never written)
+            f2 rw = {0.0f, 0.0f}, ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f}, s2 = {0.0f, 0.0f}, dv2 = {0.0f, 0.0f};
+            const f2 tiny = {1.0e-30f, 1.0e-30f};
+            for_each_ff2<true, false, 2>(c, gs, nqu, o.lh, [&](uint32_t off) { return load_p3(off, dist8); }, [&](const RecP3& A, const RecP3& B) { SALVA_PAIR_MATH
+                const f2 dx = {pi.x - A.xy.x, pi.x - B.xy.x}, dy = {pi.y - A.xy.y, pi.y - B.xy.y}, dz = {pi.z - A.zu.x, pi.z - B.zu.x};
+                f2 r2 = dz * dz + tiny;
+                r2 = dy * dy + r2;
+                r2 = dx * dx + r2;
+                const bool za = r2.x <= c.sc.tiny_r2, zb = r2.y <= c.sc.tiny_r2;
+                nnear += (za ? 1u : 0u) + (zb ? 1u : 0u);
+                const KernelWG2 k = kernel_wg2(r2, c.sc);
+                // (the particle itself — its one real self contact and the padding — adds nothing: its weight goes in once below)
+                f2 wm = k.w;
+                wm.x = za ? 0.0f : wm.x; wm.y = zb ? 0.0f : wm.y;
+                rw += wm;
+                ax += dx * k.g; ay += dy * k.g; az += dz * k.g;
+                s2 += (k.g * k.g) * r2;
+                const f2 ux = {wi.x - A.zu.y, wi.x - B.zu.y}, uy = {wi.y - A.vw.x, wi.y - B.vw.x}, uz = {wi.z - A.vw.y, wi.z - B.vw.y};
+                dv2 += (ux * dx + uy * dy + uz * dz) * k.g;
+            });
+            const uint32_t npad = 2u * nqu - o.cnt;  // self contacts appended by k_nbr_tile
+            const float gm = c.sc.gscale * m;
+            rho = (rw.x + rw.y) * c.sc.wscale * m + m * c.sc.wnorm;
+            gsx = (ax.x + ax.y) * gm; gsy = (ay.x + ay.y) * gm; gsz = (az.x + az.y) * gm;
+            sq = (s2.x + s2.y) * (gm * gm);
+            div = (dv2.x + dv2.y) * gm;
+            nnear -= npad;  // (the self contact itself stays counted: "> 1" below means another particle)
+        }
+        const bool any_near = __builtin_amdgcn_ballot_w64(active && nnear > 1u) != 0ull;
+        if (any_near && active) {  // rare: the slice's sums again, the reference's way
+            rho = gsx = gsy = gsz = sq = div = 0.0f;
+            for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const RecP3 A = load_p3(s << 3, dist8);
+                const float dx = pi.x - A.xy.x, dy = pi.y - A.xy.y, dz = pi.z - A.zu.x;
+                const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
+                rho += m * e.w;
+                const float gmj = e.g * m;
+                const float gx = dx * gmj, gy = dy * gmj, gz = dz * gmj;
+                sq += gx * gx + gy * gy + gz * gz;
+                gsx += gx; gsy += gy; gsz += gz;
+                div += ((wi.x - A.zu.y) * dx + (wi.y - A.vw.x) * dy + (wi.z - A.vw.y) * dz) * gmj;
+            });
+        }
+        float err = 0.0f;
+        uint32_t mi = 0;
+        if (active) {
+            mi = o.mi;
+            const float rho0 = rho0_of(c, mi);
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const float4 pj = Bp[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const KernelEval e = kernel_eval(dx * dx + dy * dy + dz * dz, c.sc);
+                const float mb = pj.w * rho0;
+                rho += mb * e.w;
+                const float gmb = e.g * mb;
+                const float gx = dx * gmb, gy = dy * gmb, gz = dz * gmb;
+                sq += gx * gx + gy * gy + gz * gz;
+                gsx += gx; gsy += gy; gsz += gz;
+                div += (wi.x * dx + wi.y * dy + wi.z * dz) * gmb;  // boundary velocity ignored (:332-333)
+            });
+            if (!(rho > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!density.is_zero()) :662
+            const float denom = sq + (gsx * gsx + gsy * gsy + gsz * gsz);
+            const float alpha = (denom <= 1.0e-5f) ? 0.0f : 1.0f / denom;
+            c.rho[i] = rho;
+            c.alpha[i] = alpha;
+            c.posmr[i] = make_float4(pi.x, pi.y, pi.z, pi.w / rho);
+            div = (o.cnt + o.cntb >= c.min_neighbors_for_divergence) ? fmaxf(div, 0.0f) : 0.0f;
+            c.kappa[i] = div * alpha;
+            err = div / rho0;
+        }
+        if ((threadIdx.x & (WAVE - 1)) == 0) c.slice_near[gs] = any_near ? 1u : 0u;
+        E.add(c, err, mi, active && !is_ghost(c, i));
+    });
+    E.finish(c, t.slot);
+}
+// true: the pass above ran and the divergence solve's iteration 0 must not launch its evaluate
+bool launch_density_alpha_div(const StepCtx& c, const TileLds& L, hipStream_t s) {
+#ifndef SALVA_OTHER_KERNELS
+    static const bool off = getenv("SALVA_HIP_NO_FUSED_DIV") != nullptr;  // (A/B)
+    if (off || !(c.mass_uniform > 0.0f) || (c.sc.kd | c.sc.kg) != 0) return false;
+    const uint32_t ds = pick_ds_p3(L.max_halo_fluid);
+    SALVA_LAUNCH_P3(k_density_alpha_div_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
+    return true;
+#else
+    return false;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Speculative applies (StepCtx::spec_k >= 0; single-domain divergence solves that ran more than a few iterations last step).
 // The convergence test needs the error sums of the WHOLE evaluate pass, which is why it was a one-workgroup kernel between
 // evaluate and apply — 4.7 us plus two launch gaps, a hundred times per settled step.  Here the apply pass does not wait for it:

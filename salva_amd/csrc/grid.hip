@@ -435,9 +435,15 @@ void launch_tile_slots(const uint32_t* cell_start, uint32_t ntiles, uint32_t* fl
 
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc* __restrict__ tile_cnt, uint4* __restrict__ slot_desc) {
     Tile t;
-    if (!t.setup_geom(c)) return;  // surplus workgroup: its entry was zeroed by the host
-    if (threadIdx.x == 0) slot_desc[t.slot] = make_uint4(t.tile, t.own_begin, t.own_end, 0u);
     TileAcc a{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // (launched over an upper bound of the slot count: a surplus workgroup contributes a zero entry; workgroup 0 also zeroes the
+    // extra element the exclusive scan reads behind the last one)
+    if (blockIdx.x == 0 && threadIdx.x == 1) tile_cnt[gridDim.x] = a;
+    if (!t.setup_geom(c)) {
+        if (threadIdx.x == 0) tile_cnt[blockIdx.x] = a;
+        return;
+    }
+    if (threadIdx.x == 0) slot_desc[t.slot] = make_uint4(t.tile, t.own_begin, t.own_end, 0u);
     {
         TileCells tc;
         tc.build(c, t);

@@ -69,6 +69,8 @@ void launch_boundary_volumes(const StepCtx& c, unsigned long long* ncontacts_bb,
 // ---------------------------------------------------------------- dfsph.hip
 unsigned num_blocks(uint32_t n);
 void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s);
+// density + alpha + the first divergence evaluate of the step in one pass (DFSPH, uniform mass, default kernels): false = not taken
+bool launch_density_alpha_div(const StepCtx& c, const TileLds& L, hipStream_t s);
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s);                 // -> kappa = div*alpha, partials
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s);
 void launch_finish_divergence(const StepCtx& c, float gx, float gy, float gz, bool acc_has_user, hipStream_t s);

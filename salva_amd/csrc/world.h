@@ -207,6 +207,8 @@ class World {
     DevBuf<int32_t> bbox_partials;
     TileLds lds;
     float mass_uniform = 0.0f;  // StepCtx::mass_uniform of the current step (0: masses differ, or not known)
+    bool fused_first_divergence = false;  // this step's density pass also ran the divergence solve's first evaluate (dfsph.hip)
+    bool flags_clean = false;   // d_flags were cleared by the last end-of-step publication and nothing has run since
     bool mass_known = false;    // mass_uniform describes the particles as they are (set by a publication, cleared by host edits)
     bool tile_trace = false;    // SALVA_HIP_TILE_TRACE=1: one line of tile statistics per step on stderr
     bool no_planes = false;     // SALVA_HIP_NO_PLANES=1 (A/B): keep the 32-byte-per-slot evaluate kernels

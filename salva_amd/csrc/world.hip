@@ -747,7 +747,7 @@ void World::build_boundary_grid() {
 // The per-step read-backs without a copy engine: one wave copies the few words the host is waiting for into host-mapped memory,
 // fences to system scope, then bumps the sequence word the host polls.  (A hipMemcpyAsync + event costs ~20 us of idle GPU each
 // time the host has to wait for it: tools/gap_tsv_report.py.)
-__global__ void k_publish_readback(const Readback* __restrict__ src, const TileAcc* __restrict__ totals, int lists, int end_of_step,
+__global__ void k_publish_readback(Readback* __restrict__ src, const TileAcc* __restrict__ totals, int lists, int end_of_step,
                                    uint32_t* mass_slots, Readback* pub_rb, volatile uint32_t* pub_seq, uint32_t seq) {
     uint32_t mlo = 0u, mhi = 0u;
     if (totals) {  // (wave-uniform) did k_cell_keys see a mass other than particle 0's since the last such publication?  start the next one
@@ -769,6 +769,7 @@ __global__ void k_publish_readback(const Readback* __restrict__ src, const TileA
         }
         if (end_of_step) {
             pub_rb->flags = src->flags;
+            src->flags = 0u;  // (the next step starts from clear flags without a memset of its own: World::flags_clean)
             for (int a = 0; a < 6; ++a) pub_rb->bbox[a] = src->bbox[a];
         }
         __threadfence_system();
@@ -822,18 +823,21 @@ void World::wait_stream() {
 //   for i in 0..max { err = evaluate(); if err <= tol && i >= min { break }; apply(); }
 // The break decision is taken on the device (k_finalize_error -> SolveCtl); iterations are enqueued in growing batches
 // and the control block is read back once per batch.  Kernels enqueued after convergence return immediately.
+__global__ void k_init_ctl(SolveCtl* ctl, SolveCtl* ring, SolveCtl init) {
+    *ctl = init;
+    if (ring) { ring[0] = init; ring[1] = init; }  // (dfsph.hip spec_decide: the test rides in the apply pass; iteration k reads spec_ring[k & 1])
+}
 template <typename Eval, typename Apply>
 World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval,
                                     Apply&& apply, bool spec_apply) {
     SolveCtl& init = h_ctl[NUM_SOLVES + which];
     init = SolveCtl{0u, 0u, 0.0f, 0u, tol, (uint32_t)std::max(min_iter, 0), mode, 0u};
     h_ctl[which] = init;
-    SALVA_HIP_CHECK(hipMemcpyAsync(d_ctl.p + which, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
+    // (one tiny kernel with the record as its argument instead of up to three copies from pageable host memory, each of which
+    // stalls the host until its staging copy is done)
     c.ctl = d_ctl.p + which;
-    if (spec_apply) {  // (dfsph.hip spec_decide: the test rides in the apply pass; iteration k reads spec_ring[k & 1])
-        SALVA_HIP_CHECK(hipMemcpyAsync(spec_ring.p, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
-        SALVA_HIP_CHECK(hipMemcpyAsync(spec_ring.p + 1, &init, sizeof(SolveCtl), hipMemcpyHostToDevice, stream));
-    }
+    k_init_ctl<<<1, 1, 0, stream>>>(d_ctl.p + which, spec_apply ? spec_ring.p : nullptr, init);
+    SALVA_HIP_CHECK(hipGetLastError());
     // Every convergence test publishes its outcome to host-mapped memory (k_finalize_error; in a decomposed run k_decide,
     // behind the all-reduce), and the host waits for the test count it enqueued — it then decides (and enqueues what
     // follows) while the batch's last apply pass is still running.
@@ -990,7 +994,10 @@ void World::dfsph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStat
     if (spec_apply) { w2.ensure(n, stream, false, 1.1f); spec_ring.ensure(2); c.w2 = w2.p; c.spec_ring = spec_ring.p; }
     const SolveResult rd = run_solve(
         c, 0, prm.max_divergence_error * inv_dt_prev * 0.01f, prm.min_divergence_iter, prm.max_divergence_iter, 0u,
-        [&](const StepCtx& cc, int it) { evaluate_split(cc, it, [&](const StepCtx& cs, hipStream_t s) { launch_divergence(cs, lds, s); }); },
+        [&](const StepCtx& cc, int it) {
+            if (it == 0 && fused_first_divergence) return;  // (k_density_alpha_div_p3 wrote kappa and the error partials already)
+            evaluate_split(cc, it, [&](const StepCtx& cs, hipStream_t s) { launch_divergence(cs, lds, s); });
+        },
         [&](const StepCtx& cc, int) {
             // decomposed runs: kappa of the inner ghost plane was computed here from refreshed w — the applies of the
             // owned particles read nothing else, so only w travels, once per iteration
@@ -1083,7 +1090,10 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     const bool timers = prm.enable_timers != 0;
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
     upload_tables();
-    SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));
+    // (the end-of-step publication of the previous step left the flags clear; anything else — the first step, a step that threw —
+    // clears them here)
+    if (!flags_clean) SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));
+    flags_clean = false;
 
     // ---- persistent particle arrays (double buffered for the sort)
     ensure_particle_capacity(n);
@@ -1223,7 +1233,9 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         const size_t tb = std::max(scan_tiles_temp_bytes(nslots_bound + 1), scan_temp_bytes(ntiles + 1));
         ensure_cub_temp(tb);
         launch_tile_slots(cell_start_f.p, ntiles, tile_flags.p, tile_rank.p, tile_ids.p, cub_temp.p, tb, stream);
-        SALVA_HIP_CHECK(hipMemsetAsync(tile_cnt.p, 0, ((size_t)nslots_bound + 1) * sizeof(TileAcc), stream));
+        // (k_tile_count zeroes the entries of its surplus workgroups and the scan's extra element itself: no memset —
+        // unless there is no workgroup at all, a rank that holds no particle)
+        if (nslots_bound == 0) SALVA_HIP_CHECK(hipMemsetAsync(tile_cnt.p, 0, sizeof(TileAcc), stream));
         launch_tile_count(c, nslots_bound, tile_cnt.p, slot_desc.p, stream);
         scan_tiles(cub_temp.p, tb, tile_cnt.p, tile_off.p, nslots_bound + 1, stream);
         if (spec) {
@@ -1337,7 +1349,9 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
 
     // ---- solver   (evaluate_kernels + compute_densities + solver.step, liquid_world.rs:123-144)
-    launch_density_alpha(c, lds, stream);
+    // (DFSPH: the first evaluate of the divergence solve rides in the density pass when the plane layout applies, dfsph.hip)
+    fused_first_divergence = prm.solver == SALVA_HIP_SOLVER_DFSPH && launch_density_alpha_div(c, lds, stream);
+    if (!fused_first_divergence) launch_density_alpha(c, lds, stream);
     if (comm) refresh_f32(rho.p);
     if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[2], stream));
     if (prm.solver == SALVA_HIP_SOLVER_DFSPH) dfsph_solve(c, dt, g, st);
@@ -1347,6 +1361,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     static_assert(offsetof(Readback, bbox) == offsetof(Readback, flags) + sizeof(uint32_t), "flags and bbox travel in one copy");
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[2], stream));
     publish_and_wait(spec ? tile_off.p + nslots_bound : nullptr, spec || defer_lists, true);
+    flags_clean = true;  // (k_publish_readback cleared them behind the copy)
     if (defer_lists && !spec) {
         const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;
         if (need_ff > cap_ff || need_fb > cap_fb) {
