@@ -344,6 +344,15 @@ def main():
     for _ in range(args.warmup):
         stw = w.step(DT, GRAVITY)
         warm.append((stw.grid_ms, stw.solver_ms))
+    # decomposed runs: what the exchanges cost inside the last warm-up step (HIP events around every ghost refresh and every
+    # all-reduced convergence test, the wait for the neighbour included) — VERDICT r03, item 2
+    exchange = None
+    if decomposed and warm:
+        t = w.dist_timing()
+        exchange = {"what": "last warm-up step, this rank: ghost refresh = gather + exchange with the neighbours + scatter; test = error sum + "
+                            "all-reduce + decision; HIP events on the world's stream, waiting for the neighbour included",
+                    "refreshes_per_step": t["refreshes"], "us_per_refresh": (1e3 * t["refresh_ms"] / t["refreshes"]) if t["refreshes"] else None,
+                    "tests_per_step": t["tests"], "us_per_test": (1e3 * t["test_ms"] / t["tests"]) if t["tests"] else None}
     w.counters.disable()
     barrier()
     t0 = time.perf_counter()
@@ -447,6 +456,7 @@ def main():
                 "warmup_grid_ms": float(warm[-1][0]) if warm else None,
                 "warmup_solver_ms": float(warm[-1][1]) if warm else None,
                 "tiles": tile_stats,
+                "exchange": exchange,
                 "speculative_passes": int(w.counters.speculative_passes), "discarded_passes": int(w.counters.discarded_passes),
             },
             "regimes": regimes,

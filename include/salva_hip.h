@@ -422,6 +422,13 @@ int salva_hip_clear_boundary_sampling(SalvaHipWorld* world, uint32_t slot);
  * order of salva_hip_get_boundary_particles (the order itself is unspecified, as the reference's hash-grid walk is). */
 int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t* fluid_slots, uint32_t* indices);
 
+/* Decomposed runs with the stage timers on (salva_hip_enable_counters): what the exchanges of the LAST step cost on this rank, from
+ * HIP event pairs around them on the world's stream — out4 = {ms in ghost refreshes (gather -> exchange with the neighbours ->
+ * scatter), number of refreshes, ms in all-reduced convergence tests (sum -> all-reduce -> decide), number of tests}.  The
+ * times include waiting for the neighbour's data: they are what an exchange costs inside a real step, not the transport alone
+ * (salva_hip_comm_time).  Zeros without a domain or with the timers off. */
+int salva_hip_get_dist_timing(const SalvaHipWorld* world, double out4[4]);
+
 /* ---- The working set as it is ("local view"): every fluid particle this world holds — in a decomposed run the particles the
  * rank owns AND its ghosts — in the order of the last step's cell sort, with global ids.  This is the per-rank form of what
  * salva_hip_get_fluid / salva_hip_get_fluid_contacts / salva_hip_force_get_state give a single-domain world in host order

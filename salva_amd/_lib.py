@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_delete_owned", "salva_hip_enable_counters", "salva_hip_comm_peer_begin", "salva_hip_comm_peer_connect",
     "salva_hip_comm_peer_abort", "salva_hip_comm_selftest", "salva_hip_comm_time", "salva_hip_clear_boundary_sampling", "salva_hip_get_fluid_async", "salva_hip_wait_download",
     "salva_hip_host_alloc", "salva_hip_host_free", "salva_hip_host_register", "salva_hip_host_unregister",
-    "salva_hip_local_len", "salva_hip_get_local", "salva_hip_get_local_contacts", "salva_hip_force_add_local_accelerations",
+    "salva_hip_get_dist_timing", "salva_hip_local_len", "salva_hip_get_local", "salva_hip_get_local_contacts", "salva_hip_force_add_local_accelerations",
 ]
 
 
@@ -189,6 +189,7 @@ def lib():
     L.salva_hip_set_boundary_dynamic_sampling_host.argtypes = [vp, u32, C.POINTER(HostShape), u32, u32]
     L.salva_hip_clear_boundary_sampling.argtypes = [vp, u32]
     L.salva_hip_get_fluid_async.argtypes = [vp, u32, fp, fp]
+    L.salva_hip_get_dist_timing.argtypes = [vp, C.POINTER(C.c_double)]
     L.salva_hip_local_len.argtypes = [vp]
     L.salva_hip_local_len.restype = u64
     L.salva_hip_get_local.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint8), fp, fp, fp, fp]

@@ -206,6 +206,13 @@ int salva_hip_set_boundary_dynamic_sampling_host(SalvaHipWorld* world, uint32_t 
     });
 }
 
+int salva_hip_get_dist_timing(const SalvaHipWorld* world, double out4[4]) {
+    return guarded([&]() -> int {
+        if (!world || !out4) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        world->w->get_dist_timing(out4);
+        return SALVA_HIP_OK;
+    });
+}
 uint64_t salva_hip_local_len(const SalvaHipWorld* world) { return world ? world->w->local_len() : 0; }
 int salva_hip_get_local(SalvaHipWorld* world, uint32_t* ids, uint32_t* fluid_slots, uint8_t* is_ghost, float* positions_xyz,
                         float* velocities_xyz, float* densities, float* volumes) {

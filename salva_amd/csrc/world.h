@@ -79,6 +79,7 @@ class World {
     void get_local(uint32_t* ids, uint32_t* fluid_slots, uint8_t* is_ghost, float* positions, float* velocities, float* densities, float* volumes);
     uint64_t get_local_contacts(int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity);
     void force_add_local_accelerations(const float* acc_h);
+    void get_dist_timing(double out[4]) const { for (int k = 0; k < 4; ++k) out[k] = dist_times[k]; }
     void get_fluid_async(uint32_t slot, float* pos, float* vel_out);
     void wait_download();
     uint64_t boundary_len(uint32_t slot) const;
@@ -207,6 +208,16 @@ class World {
     DevBuf<int32_t> bbox_partials;
     TileLds lds;
     float mass_uniform = 0.0f;  // StepCtx::mass_uniform of the current step (0: masses differ, or not known)
+    // Decomposed runs, timers enabled (salva_hip_enable_counters): HIP event pairs around every ghost refresh (gather -> exchange ->
+    // scatter) and every all-reduced convergence test (sum -> all-reduce -> decide) of a step, folded into `dist_times` at its end:
+    // {refresh ms, refreshes, test ms, tests} — what an exchange costs INSIDE a decomposed step, waiting for the neighbour included
+    std::vector<hipEvent_t> dist_ev;
+    size_t dist_ev_used = 0;
+    std::vector<std::pair<size_t, int>> dist_ev_pairs;  // (index of the first event of a pair, 0 = refresh / 1 = test)
+    double dist_times[4] = {0.0, 0.0, 0.0, 0.0};
+    size_t dist_time_begin(int kind);
+    void dist_time_end(size_t first);
+    void dist_time_fold();
     bool fused_first_divergence = false;  // this step's density pass also ran the divergence solve's first evaluate (dfsph.hip)
     bool flags_clean = false;   // d_flags were cleared by the last end-of-step publication and nothing has run since
     bool mass_known = false;    // mass_uniform describes the particles as they are (set by a publication, cleared by host edits)

@@ -173,6 +173,7 @@ World::~World() {
     if (ev_dl_ready) (void)hipEventDestroy(ev_dl_ready);
     if (ev_dl_done) (void)hipEventDestroy(ev_dl_done);
     for (float* p : h_dl) if (p) (void)hipHostFree(p);
+    for (hipEvent_t e : dist_ev) if (e) (void)hipEventDestroy(e);
     if (ev_pre_refresh) (void)hipEventDestroy(ev_pre_refresh);
     if (ev_interior) (void)hipEventDestroy(ev_interior);
     if (h_rb) (void)hipHostFree(h_rb);
@@ -823,6 +824,12 @@ void World::wait_stream() {
 //   for i in 0..max { err = evaluate(); if err <= tol && i >= min { break }; apply(); }
 // The break decision is taken on the device (k_finalize_error -> SolveCtl); iterations are enqueued in growing batches
 // and the control block is read back once per batch.  Kernels enqueued after convergence return immediately.
+__global__ void k_ghost_posmr(uint32_t n, const uint32_t* __restrict__ gtag, const float4* __restrict__ posm, const float* __restrict__ rho,
+                              float4* __restrict__ posmr) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !(gtag[i] & 0x80000000u)) return;
+    reinterpret_cast<float*>(&posmr[i])[3] = posm[i].w / rho[i];
+}
 __global__ void k_init_ctl(SolveCtl* ctl, SolveCtl* ring, SolveCtl init) {
     *ctl = init;
     if (ring) { ring[0] = init; ring[1] = init; }  // (dfsph.hip spec_decide: the test rides in the apply pass; iteration k reads spec_ring[k & 1])
@@ -1352,7 +1359,12 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     // (DFSPH: the first evaluate of the divergence solve rides in the density pass when the plane layout applies, dfsph.hip)
     fused_first_divergence = prm.solver == SALVA_HIP_SOLVER_DFSPH && launch_density_alpha_div(c, lds, stream);
     if (!fused_first_divergence) launch_density_alpha(c, lds, stream);
-    if (comm) refresh_f32(rho.p);
+    if (comm) {
+        refresh_f32(rho.p);
+        // (the density pass wrote posmr.w = m / rho from each rank's OWN sum; a ghost's rho has just been replaced by its owner's,
+        // so its volume follows — XSPH takes the neighbour's volume from there.  ADVICE r03)
+        if (nghost_lo + nghost_hi) k_ghost_posmr<<<nblk(n), BLOCK, 0, stream>>>(n, gtag[cur].p, posm[cur].p, rho.p, posmr.p);
+    }
     if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[2], stream));
     if (prm.solver == SALVA_HIP_SOLVER_DFSPH) dfsph_solve(c, dt, g, st);
     else iisph_solve(c, dt, g, st);
@@ -1362,6 +1374,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[2], stream));
     publish_and_wait(spec ? tile_off.p + nslots_bound : nullptr, spec || defer_lists, true);
     flags_clean = true;  // (k_publish_readback cleared them behind the copy)
+    if (comm && prm.enable_timers) dist_time_fold();  // (the stream has drained up to the publication: every pair has completed)
     if (defer_lists && !spec) {
         const uint32_t need_ff = (h_rb->max_cnt_ff + 1) / 2, need_fb = (h_rb->max_cnt_fb + 1) / 2;
         if (need_ff > cap_ff || need_fb > cap_fb) {

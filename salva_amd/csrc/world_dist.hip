@@ -4,6 +4,8 @@
 #include <climits>
 #include <cstring>
 
+#include <string>
+
 #include "world.h"
 
 namespace salva {
@@ -259,9 +261,39 @@ void World::dist_build_lists() {
 
 // Refresh one per-particle field of the ghosts from its owners: gather the mirrored edge-plane particles into a dense
 // buffer, one sendrecv with both neighbours, scatter into the ghost slots.  All on the world's stream.
+// ---- event pairs around the exchanges of a step (world.h dist_times); only while the stage timers are on
+size_t World::dist_time_begin(int kind) {
+    if (!prm.enable_timers) return (size_t)-1;
+    if (dist_ev_used + 2 > dist_ev.size()) {
+        const size_t old = dist_ev.size();
+        dist_ev.resize(old + 64, nullptr);
+        for (size_t k = old; k < dist_ev.size(); ++k) SALVA_HIP_CHECK(hipEventCreate(&dist_ev[k]));
+    }
+    const size_t first = dist_ev_used;
+    dist_ev_used += 2;
+    dist_ev_pairs.emplace_back(first, kind);
+    SALVA_HIP_CHECK(hipEventRecord(dist_ev[first], stream));
+    return first;
+}
+void World::dist_time_end(size_t first) {
+    if (first != (size_t)-1) SALVA_HIP_CHECK(hipEventRecord(dist_ev[first + 1], stream));
+}
+void World::dist_time_fold() {
+    dist_times[0] = dist_times[1] = dist_times[2] = dist_times[3] = 0.0;
+    for (const auto& pr : dist_ev_pairs) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, dist_ev[pr.first], dist_ev[pr.first + 1]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        dist_times[2 * pr.second] += ms;
+        dist_times[2 * pr.second + 1] += 1.0;
+    }
+    dist_ev_pairs.clear();
+    dist_ev_used = 0;
+}
+
 void World::refresh_f32(float* field) {
     if (!comm->has_lo() && !comm->has_hi()) return;
     SALVA_HIP_CHECK(hipEventRecord(ev_pre_refresh, stream));  // (what evaluate_split lets the interior tiles start after)
+    const size_t tm = dist_time_begin(0);
     float* sb = reinterpret_cast<float*>(fbuf_send.p);
     float* rb = reinterpret_cast<float*>(fbuf_recv.p);
     launch_gather_f32(nborder_lo, send_lo_idx.p, field, sb, stream);
@@ -270,10 +302,12 @@ void World::refresh_f32(float* field) {
                    rb + nghost_lo, nghost_hi * sizeof(float), stream);
     launch_scatter_f32(nghost_lo, ghost_lo_idx.p, rb, field, stream);
     launch_scatter_f32(nghost_hi, ghost_hi_idx.p, rb + nghost_lo, field, stream);
+    dist_time_end(tm);
 }
 void World::refresh_f4(float4* field) {
     if (!comm->has_lo() && !comm->has_hi()) return;
     SALVA_HIP_CHECK(hipEventRecord(ev_pre_refresh, stream));
+    const size_t tm = dist_time_begin(0);
     float4* sb = fbuf_send.p;
     float4* rb = fbuf_recv.p;
     launch_gather_idx_f4(nborder_lo, send_lo_idx.p, field, sb, stream);
@@ -282,6 +316,7 @@ void World::refresh_f4(float4* field) {
                    rb + nghost_lo, nghost_hi * sizeof(float4), stream);
     launch_scatter_idx_f4(nghost_lo, ghost_lo_idx.p, rb, field, stream);
     launch_scatter_idx_f4(nghost_hi, ghost_hi_idx.p, rb + nghost_lo, field, stream);
+    dist_time_end(tm);
 }
 
 // Error reduction + break test of an iterative solve; with a transport the per-fluid sums are all-reduced first.
@@ -294,9 +329,11 @@ void World::finalize_solve(SolveCtl* ctl, SolveCtl* pub) {
         launch_finalize_error(partials.p, ntiles, nm, model_counts.p, ctl, pub, stream);
         return;
     }
+    const size_t tm = dist_time_begin(1);
     launch_sum_partials(partials.p, ntiles, nm, ctl, d_sums.p, stream);
     comm->allreduce_sum_f32(d_sums.p, (int)nm, stream);
     launch_decide(d_sums.p, nm, model_counts.p, ctl, pub, stream);
+    dist_time_end(tm);
 }
 
 // ---- particle creation and removal in a running decomposed world.  Both are COLLECTIVE: every rank calls them between the
@@ -343,14 +380,31 @@ void World::dist_update_counts(const std::vector<long long>& delta) {
 // step's migration hands it over).  Ids continue after the largest id in the run, rank by rank.
 void World::dist_add_particles(uint32_t slot, uint64_t n_add, const float* pos, const float* vel_h) {
     const int size = comm->size(), rank = comm->rank();
-    if (n_add && !pos) throw HipError(SALVA_HIP_E_INVALID, "positions are required");
-    std::vector<unsigned long long> adds((size_t)size, 0ull);
-    adds[rank] = n_add;
-    plane_hist.ensure(std::max<size_t>((size_t)size, 64));
+    // Whatever can fail on ONE rank is tried before the collective and travels in it as a flag: a rank that threw on
+    // its own after the all-reduces would leave the others in the next collective, with the global ids and counts already advanced.
+    std::string local_error;
+    if (n_add && !pos) local_error = "positions are required";
+    else if (slot >= fluids.size()) local_error = "fluid slot out of range";
+    else if ((uint64_t)n + n_add >= 0xfffffff0ull) local_error = "too many particles in one slab";
+    else {
+        try {
+            ensure_particle_capacity((size_t)n + n_add);
+            scratch_f.ensure(6 * std::max<uint64_t>(n_add, 1), stream, false, 1.1f);
+        } catch (const HipError& e) {
+            local_error = e.what();
+        }
+    }
+    std::vector<unsigned long long> adds((size_t)size + 1, 0ull);
+    adds[rank] = local_error.empty() ? n_add : 0ull;
+    adds[size] = local_error.empty() ? 0ull : 1ull;  // ranks that cannot take their particles
+    plane_hist.ensure(std::max<size_t>((size_t)size + 1, 64));
     SALVA_HIP_CHECK(hipMemcpyAsync(plane_hist.p, adds.data(), adds.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
-    comm->allreduce_sum_u64(plane_hist.p, size, stream);
+    comm->allreduce_sum_u64(plane_hist.p, size + 1, stream);
     SALVA_HIP_CHECK(hipMemcpyAsync(adds.data(), plane_hist.p, adds.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    if (adds[size] != 0)  // every rank leaves here, together, with nothing changed
+        throw HipError(local_error.empty() ? SALVA_HIP_E_CAPACITY : SALVA_HIP_E_INVALID,
+                       local_error.empty() ? "add_particles failed on another rank of the run: nothing was added anywhere" : local_error);
     uint64_t before = 0, total = 0;
     for (int r = 0; r < size; ++r) { if (r < rank) before += adds[r]; total += adds[r]; }
     if (gid_next + total >= 0xfffffff0ull) throw HipError(SALVA_HIP_E_CAPACITY, "global particle ids exhausted");
@@ -360,9 +414,6 @@ void World::dist_add_particles(uint32_t slot, uint64_t n_add, const float* pos, 
     delta[slot] = (long long)n_add;
     dist_update_counts(delta);
     if (n_add == 0) return;
-    if ((uint64_t)n + n_add >= 0xfffffff0ull) throw HipError(SALVA_HIP_E_CAPACITY, "too many particles in one slab");
-    ensure_particle_capacity((size_t)n + n_add);
-    scratch_f.ensure(6 * n_add, stream, false, 1.1f);
     SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, pos, 3 * n_add * sizeof(float), hipMemcpyHostToDevice, stream));
     if (vel_h) SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p + 3 * n_add, vel_h, 3 * n_add * sizeof(float), hipMemcpyHostToDevice, stream));
     const float r = prm.particle_radius, vol = r * r * r * 6.4f;  // Fluid::particle_volume default (fluid.rs:110-120)

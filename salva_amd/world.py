@@ -1130,6 +1130,12 @@ class LiquidWorld:
         L.check(self._L.salva_hip_set_domain(self._h, comm._h, int(cell_lo), int(cell_hi), int(gid_offset)))
         self._comm = comm
 
+    def dist_timing(self):
+        """dict of what the exchanges of the last step cost on this rank (salva_hip_get_dist_timing; `world.counters.enable()` first)."""
+        out = (C.c_double * 4)()
+        L.check(self._L.salva_hip_get_dist_timing(self._h, out))
+        return {"refresh_ms": out[0], "refreshes": int(out[1]), "test_ms": out[2], "tests": int(out[3])}
+
     def delete_owned(self, gids) -> int:
         """Collective (every rank, between the same two steps): remove the particles of `gids` this rank owns from the next
         step on (salva_hip_delete_owned); returns how many particles the rank still owns."""
