@@ -220,6 +220,7 @@ class World {
     void dist_time_fold();
     bool fused_first_divergence = false;  // this step's density pass also ran the divergence solve's first evaluate (dfsph.hip)
     bool flags_clean = false;   // d_flags were cleared by the last end-of-step publication and nothing has run since
+    bool check_mass = true;     // this step's k_cell_keys compares the masses (not while a scene is known to hold different ones)
     bool mass_known = false;    // mass_uniform describes the particles as they are (set by a publication, cleared by host edits)
     bool tile_trace = false;    // SALVA_HIP_TILE_TRACE=1: one line of tile statistics per step on stderr
     bool no_planes = false;     // SALVA_HIP_NO_PLANES=1 (A/B): keep the 32-byte-per-slot evaluate kernels
