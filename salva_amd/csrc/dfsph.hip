@@ -246,8 +246,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
 // true: the pass above ran and the divergence solve's iteration 0 must not launch its evaluate
 bool launch_density_alpha_div(const StepCtx& c, const TileLds& L, hipStream_t s) {
 #ifndef SALVA_OTHER_KERNELS
-    static const bool off = getenv("SALVA_HIP_NO_FUSED_DIV") != nullptr;  // (A/B)
-    if (off || !(c.mass_uniform > 0.0f) || (c.sc.kd | c.sc.kg) != 0) return false;
+    if (!(c.mass_uniform > 0.0f) || (c.sc.kd | c.sc.kg) != 0) return false;
     const uint32_t ds = pick_ds_p3(L.max_halo_fluid);
     SALVA_LAUNCH_P3(k_density_alpha_div_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
     return true;

@@ -223,6 +223,7 @@ class World {
     bool check_mass = true;     // this step's k_cell_keys compares the masses (not while a scene is known to hold different ones)
     bool mass_known = false;    // mass_uniform describes the particles as they are (set by a publication, cleared by host edits)
     bool tile_trace = false;    // SALVA_HIP_TILE_TRACE=1: one line of tile statistics per step on stderr
+    bool no_fused_div = false;  // SALVA_HIP_NO_FUSED_DIV=1 (A/B): the first divergence evaluate stays a pass of its own
     bool no_planes = false;     // SALVA_HIP_NO_PLANES=1 (A/B): keep the 32-byte-per-slot evaluate kernels
 #ifdef SALVA_HIP_DIAG
     PipeCfg pipe;          // launch shape of the persistent pipeline kernels of this step (pipe.h)

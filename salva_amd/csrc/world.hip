@@ -134,6 +134,7 @@ World::World(const SalvaHipParams& p) : prm(p) {
     spec_apply_off = getenv("SALVA_HIP_NO_SPEC_APPLY") != nullptr;
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
     tile_trace = getenv("SALVA_HIP_TILE_TRACE") != nullptr;
+    no_fused_div = getenv("SALVA_HIP_NO_FUSED_DIV") != nullptr;
 #ifdef SALVA_HIP_DIAG
     if (const char* e = getenv("SALVA_HIP_SCHED")) sched_mode = atoi(e);
 #endif
@@ -1360,7 +1361,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
 
     // ---- solver   (evaluate_kernels + compute_densities + solver.step, liquid_world.rs:123-144)
     // (DFSPH: the first evaluate of the divergence solve rides in the density pass when the plane layout applies, dfsph.hip)
-    fused_first_divergence = prm.solver == SALVA_HIP_SOLVER_DFSPH && launch_density_alpha_div(c, lds, stream);
+    fused_first_divergence = prm.solver == SALVA_HIP_SOLVER_DFSPH && !no_fused_div && launch_density_alpha_div(c, lds, stream);
     if (!fused_first_divergence) launch_density_alpha(c, lds, stream);
     if (comm) {
         refresh_f32(rho.p);

@@ -665,6 +665,7 @@ class LiquidWorld:
     def add_fluid(self, fluid: Fluid) -> Fluid:
         fluid._world, fluid._slot = self, len(self._fluids._items)
         fluid._resized, fluid._dirty = True, L.DIRTY_ALL
+        fluid._forces_uploaded = None
         self._fluids._items.append(fluid)
         return fluid  # the handle is the object itself
 
@@ -854,7 +855,11 @@ class LiquidWorld:
             if state is not None and n and state[:, 3].any():
                 L.check(self._L.salva_hip_set_fluid_field(self._h, f._slot, L.FIELD_PRESSURE, _fp(np.ascontiguousarray(state[:, 3]))))
             f._resized, f._dirty, f._pending_dv, f._acc_set = False, 0, None, False
-        L.check(self._L.salva_hip_set_fluid_forces(self._h, f._slot, descs, len(f.nonpressure_forces)))
+        # (the force list goes down again only when it, or a coefficient in it, changed: a ctypes call per fluid and step otherwise)
+        sig = (f._slot, len(f.nonpressure_forces), bytes(descs))
+        if getattr(f, "_forces_uploaded", None) != sig:
+            L.check(self._L.salva_hip_set_fluid_forces(self._h, f._slot, descs, len(f.nonpressure_forces)))
+            f._forces_uploaded = sig
 
     def _sync_boundaries(self):
         for b in self._boundaries:
@@ -915,7 +920,10 @@ class LiquidWorld:
     # ---- liquid_world.rs:62-158
     def step(self, dt: float, gravity=(0.0, -9.81, 0.0)) -> L.StepStats:
         self.sync_to_device()
-        g = (C.c_float * 3)(*[float(x) for x in gravity])
+        gk = tuple(gravity)
+        if getattr(self, "_gravity_key", None) != gk:
+            self._gravity_key, self._gravity_c = gk, (C.c_float * 3)(*[float(x) for x in gravity])
+        g = self._gravity_c
         st = L.StepStats()
         rc = self._L.salva_hip_step(self._h, dt, g, C.byref(st))
         self._nsteps += 1

@@ -473,6 +473,35 @@ def test_sparse_scene_and_compact_slot_tables(compact, monkeypatch):
         compare(run_hip(scene, nsteps), run_oracle(scene, nsteps), scene, nsteps, f"sparse/compact={compact}")
 
 
+def test_plane_layouts_and_the_fused_first_divergence_change_rounding_only(monkeypatch):
+    """Round 4: with a uniform particle mass the solver kernels stage 24 / 16 bytes per halo slot as 8-byte planes and the first
+    divergence evaluate rides in the density pass.  Both are other kernels for the same sums: against the
+    32 / 20-byte layouts and the separate pass (SALVA_HIP_NO_PLANES, SALVA_HIP_NO_FUSED_DIV) the iteration counts and contact
+    counts are identical and the states agree to f32 summation order; a scene whose masses differ takes the old kernels whatever
+    the switches say and is bit-identical."""
+    def run(scene, nsteps, env):
+        for k in ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        return run_hip(scene, nsteps)
+
+    tank = SCENES["dfsph_tank"][0]()
+    nsteps = 12
+    base = run(tank, nsteps, ())
+    for env in (("SALVA_HIP_NO_FUSED_DIV",), ("SALVA_HIP_NO_PLANES",)):
+        other = run(tank, nsteps, env)
+        assert np.array_equal(base["iters"], other["iters"]), f"{env}: iteration or contact counts differ"
+        dp, dv = np.abs(base["pos_0"] - other["pos_0"]).max(), np.abs(base["vel_0"] - other["vel_0"]).max()
+        assert dp < 2e-5 * R * nsteps, f"{env}: positions differ by {dp / R:.2e} r"
+        assert dv < 1e-4, f"{env}: velocities differ by {dv:.2e} m/s"
+    two = SCENES["two_phase"][0]()  # fluids of different density0: the masses differ, nothing above applies
+    a, b = run(two, 6, ()), run(two, 6, ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV"))
+    assert np.array_equal(a["iters"], b["iters"])
+    for f in range(2):
+        assert np.array_equal(a[f"pos_{f}"], b[f"pos_{f}"]) and np.array_equal(a[f"vel_{f}"], b[f"vel_{f}"])
+
+
 def test_stray_particles_far_from_the_bulk():
     """A few particles hundreds of cells away from the block (what a leaking wall produces, in the reference too) blow
     the cell bounding box up to tens of millions of empty cells: per-tile tables are compact over non-empty tiles and the

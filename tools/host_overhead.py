@@ -1,4 +1,5 @@
-"""Where the time between two steps goes: Python mirror vs the C call vs the GPU-timed part of the step (1M-particle bench scene)."""
+"""Where the time of a free-fall step goes on the host: the Python mirror's `step` against the raw C call, each on a fresh world over the
+same steps (6..13 of the bench scene: one divergence and one pressure iteration each, ~0.63 ms)."""
 import ctypes as C
 import os
 import sys
@@ -11,22 +12,27 @@ import bench  # noqa: E402
 from salva_amd import _lib as L  # noqa: E402
 
 fluid, shell = bench.build_scene(100)
-w, f = bench.make_world(fluid, shell, 0)
-w.counters.enable()  # (step_ms / grid_ms come from the stage timers, off by default)
-for _ in range(5):
-    w.step(bench.DT, bench.GRAVITY)
-N = 20
-t_py, t_c, t_gpu = [], [], []
-g = (C.c_float * 3)(*bench.GRAVITY)
-for _ in range(N):
-    t0 = time.perf_counter()
-    st = w.step(bench.DT, bench.GRAVITY)
-    t_py.append(time.perf_counter() - t0)
-    t_gpu.append(st.step_ms)
-for _ in range(N):
+N = 8
+
+
+def run(raw):
+    w, f = bench.make_world(fluid, shell, 0)
+    for _ in range(5):
+        w.step(bench.DT, bench.GRAVITY)
+    g = (C.c_float * 3)(*bench.GRAVITY)
     st = L.StepStats()
-    t0 = time.perf_counter()
-    L.check(w._L.salva_hip_step(w._h, bench.DT, g, C.byref(st)))
-    t_c.append(time.perf_counter() - t0)
-    t_gpu.append(st.step_ms)
-print(f"python step {np.mean(t_py) * 1e3:.3f} ms | raw C call {np.mean(t_c) * 1e3:.3f} ms | GPU-timed (events) first loop {np.mean(t_gpu[:N]):.3f} ms, second {np.mean(t_gpu[N:]):.3f} ms")
+    ts = []
+    for _ in range(N):
+        t0 = time.perf_counter()
+        if raw:
+            L.check(w._L.salva_hip_step(w._h, bench.DT, g, C.byref(st)))
+        else:
+            w.step(bench.DT, bench.GRAVITY)
+        ts.append(time.perf_counter() - t0)
+    return np.asarray(ts) * 1e3
+
+
+for rep in range(2):
+    py, raw = run(False), run(True)
+    print(f"rep {rep}: python mirror step {py.mean():.4f} ms (min {py.min():.4f}) | raw C call {raw.mean():.4f} ms (min {raw.min():.4f}) | "
+          f"mirror overhead {1e3 * (py.mean() - raw.mean()):.1f} us per step", flush=True)
