@@ -382,8 +382,13 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
     E.finish(c, t.slot);
 }
 // the plane-layout form: planes (x, y) | (z, q.x) | (q.y, q.z), the uniform mass applied to the two finished sums
+// (87 VGPRs, two tiles per CU: held to 80 for a third tile this kernel spills nine registers — 61.8 us against 57.8, and 59.0 on
+// the 32-byte layout; profiles/r04_experiments/r04l_iisph_next_pressure.log)
+#ifndef SALVA_IISPH_NP_WAVES
+#define SALVA_IISPH_NP_WAVES 5
+#endif
 template <uint32_t DS>
-__global__ SALVA_IISPH_P3_BOUNDS(DS) void k_iisph_next_pressure_p3(StepCtx c, float dt, float omega, const float* __restrict__ p,
+__global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_IISPH_NP_WAVES : 5) void k_iisph_next_pressure_p3(StepCtx c, float dt, float omega, const float* __restrict__ p,
                                                                    float* __restrict__ p_next) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     lds_base_check();
