@@ -390,7 +390,11 @@ int64_t salva_hip_particles_intersecting_shape(SalvaHipWorld* world, const float
  * velocity; one boundary particle per projection within 1.5 h is emitted (velocity = body.velocity_at_point(projection)).
  * As in the reference the grid is not rebuilt after the push-out: a pushed particle is searched from the cell of its old
  * position for that substep.  The collider's pose is handed over with salva_hip_update_boundary_pose before the step.
- * Registers boundary `slot` (created empty if slot == number of boundaries). */
+ * Registers boundary `slot` (created empty if slot == number of boundaries).
+ * Decomposed (multi-GPU) worlds: COLLECTIVE — every rank registers the same collider in the same slot and hands over the same
+ * pose.  Each rank emits for the fluid particles it owns, and every rank ends up with every rank's points, in rank order
+ * (two all-reduces per collider and step); the force accumulator of a rank holds what that rank's own fluid exerts, so the
+ * wrench on the collider is the sum of the ranks' salva_hip_get_boundary_wrench. */
 int salva_hip_set_boundary_dynamic_sampling(SalvaHipWorld* world, uint32_t slot, const SalvaHipShape* collider_shape,
                                             uint32_t memberships, uint32_t filter);
 /* The same arm for every other parry shape (triangle mesh, height field, convex polyhedron, compound, ...): the loop is the
@@ -419,7 +423,9 @@ int salva_hip_set_boundary_dynamic_sampling_host(SalvaHipWorld* world, uint32_t 
  * No-op for a boundary without a sampling method. */
 int salva_hip_clear_boundary_sampling(SalvaHipWorld* world, uint32_t slot);
 /* For a dynamically sampled boundary: (fluid slot, particle index) of the fluid particle behind each of its points, in the
- * order of salva_hip_get_boundary_particles (the order itself is unspecified, as the reference's hash-grid walk is). */
+ * order of salva_hip_get_boundary_particles (the order itself is unspecified, as the reference's hash-grid walk is).
+ * Decomposed worlds: `indices` receives the particle's global id (the `ids` of salva_hip_get_local / _get_owned) — it may be
+ * held by another rank. */
 int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t* fluid_slots, uint32_t* indices);
 
 /* Decomposed runs with the stage timers on (salva_hip_enable_counters): what the exchanges of the LAST step cost on this rank, from

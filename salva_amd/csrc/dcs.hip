@@ -28,6 +28,7 @@
 // This file is compiled with -ffp-contract=off (see Makefile): Rust never fuses a*b+c, and the emitted points feed the
 // exact d^2 <= h^2 contact test.
 #include "dcs.h"
+#include "dist.h"
 #include "tile.h"
 #include <cmath>
 
@@ -80,8 +81,8 @@ __device__ __forceinline__ bool dcs_finish(uint32_t i, float4 p, float4 v, float
 
 __global__ __launch_bounds__(BLOCK) void k_dcs_project(uint32_t n, float4* __restrict__ posm, float4* __restrict__ vel,
                                                        const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
-                                                       TileGrid g, DcsParams s, float4* __restrict__ cand,
-                                                       uint8_t* __restrict__ flag) {
+                                                       const uint32_t* __restrict__ gtag, TileGrid g, DcsParams s,
+                                                       float4* __restrict__ cand, uint8_t* __restrict__ flag) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     flag[i] = 0;
@@ -168,7 +169,10 @@ __global__ __launch_bounds__(BLOCK) void k_dcs_project(uint32_t n, float4* __res
     quat_rot(s.q[0], s.q[1], s.q[2], s.q[3], jx, jy, jz, wx, wy, wz);
     wx += s.t[0]; wy += s.t[1]; wz += s.t[2];
     if (dcs_finish(i, p, v, px, py, pz, wx, wy, wz, inside, s, posm, vel)) {
-        cand[i] = make_float4(wx, wy, wz, __uint_as_float(perm[i]));
+        // decomposed run (gtag != nullptr): a ghost is pushed like its owner — same inputs, same arithmetic — but only the owner
+        // emits; the row then carries the SORTED index (k_dcs_pack turns it into global id + fluid)
+        if (gtag && (gtag[i] & GTAG_GHOST)) return;
+        cand[i] = make_float4(wx, wy, wz, __uint_as_float(gtag ? i : perm[i]));
         flag[i] = 1;
     }
 }
@@ -192,15 +196,30 @@ __global__ __launch_bounds__(BLOCK) void k_dcs_gather(uint32_t n, const float4* 
 }
 __global__ __launch_bounds__(BLOCK) void k_dcs_apply(uint32_t cnt, const float4* __restrict__ pred, const float4* __restrict__ proj,
                                                      float4* __restrict__ posm, float4* __restrict__ vel, const uint32_t* __restrict__ perm,
-                                                     DcsParams s, float4* __restrict__ cand, uint8_t* __restrict__ flag) {
+                                                     const uint32_t* __restrict__ gtag, DcsParams s, float4* __restrict__ cand,
+                                                     uint8_t* __restrict__ flag) {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= cnt) return;
     const float4 pr = pred[k], w = proj[k];
     const uint32_t i = __float_as_uint(pr.w);
     const float4 p = posm[i], v = vel[i];
-    const bool keep = dcs_finish(i, p, v, pr.x, pr.y, pr.z, w.x, w.y, w.z, w.w != 0.0f, s, posm, vel);
+    bool keep = dcs_finish(i, p, v, pr.x, pr.y, pr.z, w.x, w.y, w.z, w.w != 0.0f, s, posm, vel);
+    if (gtag && (gtag[i] & GTAG_GHOST)) keep = false;  // (decomposed run: pushed here too, emitted by its owner; see k_dcs_project)
     flag[k] = keep ? 1 : 0;
-    if (keep) cand[k] = make_float4(w.x, w.y, w.z, __uint_as_float(perm[i]));
+    if (keep) cand[k] = make_float4(w.x, w.y, w.z, __uint_as_float(gtag ? i : perm[i]));
+}
+
+// Decomposed run: this rank's compacted rows (point, sorted index of the source particle) -> its section of the table every
+// rank assembles (World::dist_gather_emitted): (point, global id of the source) and the source's fluid.
+__global__ __launch_bounds__(BLOCK) void k_dcs_pack(uint32_t cnt, const float4* __restrict__ rows, const uint32_t* __restrict__ gid,
+                                                    const uint32_t* __restrict__ model, float4* __restrict__ out_rows,
+                                                    uint32_t* __restrict__ out_models) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= cnt) return;
+    const float4 r = rows[k];
+    const uint32_t i = __float_as_uint(r.w);
+    out_rows[k] = make_float4(r.x, r.y, r.z, __uint_as_float(gid[i]));
+    out_models[k] = model[i];
 }
 
 __global__ __launch_bounds__(BLOCK) void k_dcs_emit(uint32_t cnt, const float4* __restrict__ cand, SalvaHipRigidPose pose, uint32_t slot,
@@ -290,10 +309,10 @@ DcsParams dcs_params_host(const float mins[3], const float maxs[3], float h, flo
     return s;
 }
 
-void launch_dcs_project(uint32_t n, float4* posm, float4* vel, const uint32_t* keys, const uint32_t* perm, TileGrid g,
+void launch_dcs_project(uint32_t n, float4* posm, float4* vel, const uint32_t* keys, const uint32_t* perm, const uint32_t* gtag, TileGrid g,
                         const DcsParams& s, float4* cand, uint8_t* flag, hipStream_t st) {
     if (n == 0) return;
-    k_dcs_project<<<div_up(n, BLOCK), BLOCK, 0, st>>>(n, posm, vel, keys, perm, g, s, cand, flag);
+    k_dcs_project<<<div_up(n, BLOCK), BLOCK, 0, st>>>(n, posm, vel, keys, perm, gtag, g, s, cand, flag);
     SALVA_HIP_CHECK(hipGetLastError());
 }
 void launch_dcs_gather(uint32_t n, const float4* posm, const float4* vel, const uint32_t* keys, TileGrid g, const DcsParams& s, float4* cand,
@@ -303,9 +322,15 @@ void launch_dcs_gather(uint32_t n, const float4* posm, const float4* vel, const 
     SALVA_HIP_CHECK(hipGetLastError());
 }
 void launch_dcs_apply(uint32_t cnt, const float4* pred, const float4* proj, float4* posm, float4* vel, const uint32_t* perm,
-                      const DcsParams& s, float4* cand, uint8_t* flag, hipStream_t st) {
+                      const uint32_t* gtag, const DcsParams& s, float4* cand, uint8_t* flag, hipStream_t st) {
     if (cnt == 0) return;
-    k_dcs_apply<<<div_up(cnt, BLOCK), BLOCK, 0, st>>>(cnt, pred, proj, posm, vel, perm, s, cand, flag);
+    k_dcs_apply<<<div_up(cnt, BLOCK), BLOCK, 0, st>>>(cnt, pred, proj, posm, vel, perm, gtag, s, cand, flag);
+    SALVA_HIP_CHECK(hipGetLastError());
+}
+void launch_dcs_pack(uint32_t cnt, const float4* rows, const uint32_t* gid, const uint32_t* model, float4* out_rows, uint32_t* out_models,
+                     hipStream_t st) {
+    if (cnt == 0) return;
+    k_dcs_pack<<<div_up(cnt, BLOCK), BLOCK, 0, st>>>(cnt, rows, gid, model, out_rows, out_models);
     SALVA_HIP_CHECK(hipGetLastError());
 }
 void launch_dcs_emit(uint32_t cnt, const float4* cand, const SalvaHipRigidPose& pose, uint32_t slot, float4* pos, float4* vel,

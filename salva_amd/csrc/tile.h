@@ -94,7 +94,7 @@ constexpr uint32_t P3_DS_THREE = SALVA_P3_DS3, P3_DS_TWO = 3360, P3_DS_ONE = 406
 #define SALVA_P2_DS3 2464
 #endif
 constexpr uint32_t P2_DS_THREE = SALVA_P2_DS3;                               // apply kernels: fluid + boundary halo slots
-static_assert(P3_DS_THREE % 64 == 32 && P3_DS_TWO % 64 == 32 && P3_DS_ONE % 64 == 32 && P2_DS_THREE % 64 == 32 || SALVA_P3_DS3 != 2080 || SALVA_P2_DS3 != 2464,
+static_assert((P3_DS_THREE % 64 == 32 && P3_DS_TWO % 64 == 32 && P3_DS_ONE % 64 == 32 && P2_DS_THREE % 64 == 32) || SALVA_P3_DS3 != 2080 || SALVA_P2_DS3 != 2464,
               "plane distances: odd multiples of 256 bytes");
 constexpr uint32_t TILE_ERR_BYTES = 12u * 32u * 4u;  // TileErr table (TILE_MAX_WAVES x MAX_MODELS floats), carved from the pool
 

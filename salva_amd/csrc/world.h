@@ -32,11 +32,12 @@ struct BoundarySlot {
     std::shared_ptr<DevBuf<float4>> sampling;
     // ColliderSampling::DynamicContactSampling (:42-43): the collider's shape and its last pose; the boundary's particles are
     // re-emitted by every step (World::run_dynamic_sampling), `dyn_src` = host index of the fluid particle behind each
+    // (decomposed run: its global id, and `dyn_src_model` its fluid — the particle may live on another rank)
     int dyn_kind = 0;
     SalvaHipShape dyn_shape{};
     SalvaHipHostShape dyn_host{};  // dyn_kind == SALVA_HIP_SHAPE_HOST: the host's compute_aabb / project_point callbacks
     SalvaHipRigidPose dyn_pose{};
-    std::shared_ptr<DevBuf<uint32_t>> dyn_src;
+    std::shared_ptr<DevBuf<uint32_t>> dyn_src, dyn_src_model;
 };
 
 struct GridDims {          // tile-aligned dense grid (tile.h)
@@ -138,6 +139,9 @@ class World {
     std::vector<uint8_t> dcs_h_inside;
     DevBuf<uint8_t> dcs_flag;
     DevBuf<uint32_t> dcs_num;
+    // decomposed run: every rank's emitted points, in rank order (dist_gather_emitted): rows, then one uint32 fluid per row
+    DevBuf<unsigned long long> dcs_all;
+    uint32_t dist_gather_emitted(const float4* rows, uint32_t cnt, const float4** all_rows, const uint32_t** all_models);
     void ensure_cub_temp(size_t bytes);
     StepCtx make_ctx();
     struct SolveResult { uint32_t iters; float err; };

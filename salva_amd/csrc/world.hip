@@ -1167,7 +1167,6 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     for (auto& f : fluids) for (auto& d : f.forces) has_custom |= d.kind == SALVA_HIP_FORCE_CUSTOM;
     const bool has_dyn = has_dynamic_sampling();
     double dcs_ms = 0.0;
-    if (has_dyn && comm) throw HipError(SALVA_HIP_E_INVALID, "DynamicContactSampling is not available in a multi-GPU run");
     // a pass can be repeated from the untouched pre-sort buffers iff it has no side effect outside the world's own arrays
     const bool can_redo = !comm && !any_wants_forces && !has_custom && !has_dyn;
     // (mass_known: the kernels of a pass are chosen by StepCtx::mass_uniform, which a speculative pass — it does not wait for the
@@ -2032,7 +2031,6 @@ void World::update_boundary_pose(uint32_t slot, const SalvaHipRigidPose& pose) {
 // ColliderCouplingSet::register_coupling(boundary, collider, ColliderSampling::DynamicContactSampling) (fluids_pipeline.rs:42-43,
 // 96-114): the boundary starts empty; every step re-emits its particles from the fluid near the collider.
 void World::set_boundary_dynamic_sampling(uint32_t slot, const SalvaHipShape& shape, uint32_t memberships, uint32_t filter) {
-    if (comm) throw HipError(SALVA_HIP_E_INVALID, "DynamicContactSampling is not available in a multi-GPU run");
     const int np = shape_param_count(shape.kind);
     for (int a = 0; a < np; ++a)
         if (!(shape.params[a] > 0.0f) || !std::isfinite(shape.params[a])) throw HipError(SALVA_HIP_E_INVALID, "shape parameters must be positive");
@@ -2048,7 +2046,6 @@ void World::set_boundary_dynamic_sampling(uint32_t slot, const SalvaHipShape& sh
 }
 
 void World::set_boundary_dynamic_sampling_host(uint32_t slot, const SalvaHipHostShape& shape, uint32_t memberships, uint32_t filter) {
-    if (comm) throw HipError(SALVA_HIP_E_INVALID, "DynamicContactSampling is not available in a multi-GPU run");
     if (!shape.aabb || !shape.project) throw HipError(SALVA_HIP_E_INVALID, "a host shape needs both callbacks");
     const bool keep_forces = slot < bounds.size() ? bounds[slot].wants_forces : false;
     set_boundary(slot, 0, nullptr, nullptr, memberships, filter, keep_forces);
@@ -2071,7 +2068,7 @@ void World::clear_boundary_sampling(uint32_t slot) {
     b.dyn_kind = 0;
     b.dyn_shape = SalvaHipShape{};
     b.dyn_host = SalvaHipHostShape{};
-    b.dyn_src.reset();
+    b.dyn_src.reset(); b.dyn_src_model.reset();
 }
 
 // parameters of a built-in collider shape (include/salva_hip.h); throws for any other kind
@@ -2155,7 +2152,8 @@ void World::run_dynamic_sampling() {
                 dcs_proj.ensure(ng, stream, false, 1.5f); dcs_cand2.ensure(ng, stream, false, 1.5f);
                 SALVA_HIP_CHECK(hipMemcpyAsync(dcs_proj.p, dcs_h_f4.data(), (size_t)ng * sizeof(float4), hipMemcpyHostToDevice, stream));
                 // (dcs_out holds the gathered candidates; its compaction goes back into dcs_cand, which is free again)
-                launch_dcs_apply(ng, dcs_out.p, dcs_proj.p, posm[cur].p, vel[cur].p, perm[cur].p, prm_d, dcs_cand2.p, dcs_flag.p, stream);
+                launch_dcs_apply(ng, dcs_out.p, dcs_proj.p, posm[cur].p, vel[cur].p, perm[cur].p, comm ? gtag[cur].p : nullptr, prm_d,
+                                 dcs_cand2.p, dcs_flag.p, stream);
                 select_flagged_f4(cub_temp.p, tb, dcs_cand2.p, dcs_flag.p, dcs_cand.p, dcs_num.p, ng, stream);
                 SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->dcs_count, dcs_num.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 wait_stream();  // (also: dcs_h_f4 has been read)
@@ -2166,7 +2164,8 @@ void World::run_dynamic_sampling() {
             const DcsParams prm_d = dcs_params(b.dyn_shape, b.dyn_pose, sc.h, prm.particle_radius, dt_prev);
             dcs_cand.ensure(n, stream, false, 1.1f); dcs_out.ensure(n, stream, false, 1.1f); dcs_flag.ensure(n, stream, false, 1.1f);
             dcs_num.ensure(1);
-            launch_dcs_project(n, posm[cur].p, vel[cur].p, keys[0].p, perm[cur].p, gv, prm_d, dcs_cand.p, dcs_flag.p, stream);
+            launch_dcs_project(n, posm[cur].p, vel[cur].p, keys[0].p, perm[cur].p, comm ? gtag[cur].p : nullptr, gv, prm_d, dcs_cand.p,
+                               dcs_flag.p, stream);
             const size_t tb = select_flagged_temp_bytes(n);
             ensure_cub_temp(tb);
             select_flagged_f4(cub_temp.p, tb, dcs_cand.p, dcs_flag.p, dcs_out.p, dcs_num.p, n, stream);
@@ -2175,12 +2174,25 @@ void World::run_dynamic_sampling() {
             cnt = h_rb->dcs_count;
             emit_src = dcs_out.p;
         }
+        // Decomposed run: each rank has emitted for the particles it OWNS; every rank then holds every rank's points (a collider's
+        // contact layer: thousands of rows), so a boundary particle near a slab face has its whole boundary neighbourhood — its
+        // volume — and acts on the fluid of both slabs, wherever its source particle lives.  (Mirroring more ghost planes instead
+        // has no bound that holds: the point is the projection of the PREDICTED position, |v| dt + 1.5 h + the penetration depth
+        // from its source.)  Each rank's force accumulator receives what its own fluid exerts: the rows are the same on every
+        // rank, the per-rank forces add up.
+        const uint32_t* emit_models = nullptr;
+        if (comm) cnt = dist_gather_emitted(emit_src, cnt, &emit_src, &emit_models);
         resize_boundary_slot(slot, cnt);
         b_dirty = true;  // same count, new positions
         if (cnt) {
             const uint64_t off = boundary_offset(slot);
             b.dyn_src->ensure(cnt, stream, false, 1.5f);
             launch_dcs_emit(cnt, emit_src, b.dyn_pose, slot, bst_pos.p + off, bst_vel.p + off, b.dyn_src->p, stream);
+            if (emit_models) {
+                if (!b.dyn_src_model) b.dyn_src_model = std::make_shared<DevBuf<uint32_t>>();
+                b.dyn_src_model->ensure(cnt, stream, false, 1.5f);
+                SALVA_HIP_CHECK(hipMemcpyAsync(b.dyn_src_model->p, emit_models, (size_t)cnt * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            }
             SALVA_HIP_CHECK(hipMemsetAsync(bforce.p + off, 0, (size_t)cnt * sizeof(float4), stream));  // clear_forces(true) :262
         }
     }
@@ -2195,6 +2207,12 @@ void World::get_boundary_sources(uint32_t slot, uint32_t* fluid_slots, uint32_t*
     if (!b.n) return;
     std::vector<uint32_t> src(b.n);
     SALVA_HIP_CHECK(hipMemcpyAsync(src.data(), b.dyn_src->p, b.n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (comm) {  // decomposed run: the global id of the source particle (salva_hip_get_local's `ids`) and its fluid
+        if (indices) SALVA_HIP_CHECK(hipMemcpyAsync(indices, b.dyn_src->p, b.n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (fluid_slots) SALVA_HIP_CHECK(hipMemcpyAsync(fluid_slots, b.dyn_src_model->p, b.n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        return;
+    }
     SALVA_HIP_CHECK(hipStreamSynchronize(stream));
     for (uint64_t k = 0; k < b.n; ++k) {
         uint32_t f = 0;

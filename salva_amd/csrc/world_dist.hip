@@ -6,6 +6,7 @@
 
 #include <string>
 
+#include "dcs.h"
 #include "world.h"
 
 namespace salva {
@@ -253,6 +254,45 @@ void World::dist_prepare() {
     } else {
         bbox_known = false;  // first step / after host edits: reduce the box over the particles (World::step)
     }
+}
+
+// DynamicContactSampling in a decomposed run: this rank's emitted rows (point, sorted index of the source) -> the table of all
+// ranks' rows in rank order, the same on every rank.  The transport has sums, not gathers: every rank writes its section of a
+// zeroed table and the sections are added as 64-bit integers — x + 0 is exact on the bit patterns, and the 32-bit fluid words of
+// two ranks that share a 64-bit word cannot carry into each other.  Two all-reduces (counts, rows) per sampled collider and
+// step; collective — every rank registers the same dynamically sampled boundaries in the same slots.
+uint32_t World::dist_gather_emitted(const float4* rows, uint32_t cnt, const float4** all_rows, const uint32_t** all_models) {
+    const int size = comm->size(), rank = comm->rank();
+    std::vector<unsigned long long> counts((size_t)size, 0ull);
+    counts[rank] = cnt;
+    if (size > 1) {
+        plane_hist.ensure(std::max<size_t>((size_t)size, 64));
+        SALVA_HIP_CHECK(hipMemcpyAsync(plane_hist.p, counts.data(), counts.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+        comm->allreduce_sum_u64(plane_hist.p, size, stream);
+        SALVA_HIP_CHECK(hipMemcpyAsync(counts.data(), plane_hist.p, counts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    unsigned long long total = 0, before = 0;
+    for (int r = 0; r < size; ++r) { if (r < rank) before += counts[r]; total += counts[r]; }
+    if (total >= 0x3fffffffull) throw HipError(SALVA_HIP_E_CAPACITY, "too many dynamically sampled boundary particles");
+    *all_rows = nullptr; *all_models = nullptr;
+    if (total == 0) return 0;
+    const size_t words = 2 * (size_t)total + ((size_t)total + 1) / 2;  // float4 rows, then uint32 fluids
+    dcs_all.ensure(words, stream, false, 1.5f);
+    SALVA_HIP_CHECK(hipMemsetAsync(dcs_all.p, 0, words * sizeof(unsigned long long), stream));
+    float4* out_rows = reinterpret_cast<float4*>(dcs_all.p);
+    uint32_t* out_models = reinterpret_cast<uint32_t*>(dcs_all.p + 2 * (size_t)total);
+    launch_dcs_pack(cnt, rows, perm[cur].p, model[cur].p, out_rows + before, out_models + before, stream);
+    if (size > 1) {
+        // (an int count per call: a contact layer is far below 2^31 words; cut larger tables anyway)
+        for (size_t at = 0; at < words;) {
+            const size_t len = std::min<size_t>(words - at, (size_t)1 << 28);
+            comm->allreduce_sum_u64(dcs_all.p + at, (int)len, stream);
+            at += len;
+        }
+    }
+    *all_rows = out_rows; *all_models = out_models;
+    return (uint32_t)total;
 }
 
 void World::dist_build_lists() {

@@ -499,7 +499,8 @@ class Boundary:
         return self._n_sampled if self._sampled else len(self._positions)
 
     def sources(self):
-        """Dynamically sampled boundaries: (fluid slot, particle index) behind each boundary particle."""
+        """Dynamically sampled boundaries: (fluid slot, particle index) behind each boundary particle; in a decomposed world the
+        index is the particle's global id (LiquidWorld.owned() / local_view()), which another rank may hold."""
         n = self.num_particles()
         f, i = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
         if n:

@@ -463,6 +463,126 @@ def test_boundary_forces_sum_to_the_single_domain_ones(hip_lib):
     assert np.abs(got - ref).max() < 5e-3 * scale, f"summed boundary forces differ by {np.abs(got - ref).max() / scale:.2e} of the largest force"
 
 
+@pytest.mark.parametrize("host_shape", [False, True])
+def test_dynamic_contact_sampling_in_a_decomposed_world(hip_lib, host_shape):
+    """ColliderSampling::DynamicContactSampling (fluids_pipeline.rs:193-259) across a slab face: a spinning ball sits on the cut
+    while the fluid drifts through it.  Each rank emits boundary particles for the fluid particles it owns and all ranks assemble
+    the same table (World::dist_gather_emitted), ghosts are pushed out of the ball like their owners, and the reaction forces of the
+    ranks add up to the undivided world's — per boundary particle, identified by the fluid particle it was projected from.
+    host_shape: the arm whose two geometry calls come back to the host (salva_hip_set_boundary_dynamic_sampling_host), on the slabs only
+    — the undivided world keeps the device's ball, which that arm matches bit for bit (test_host_shape_gpu.py)."""
+    from salva_amd.coupling import ColliderCouplingSet, DynamicContactSampling, HostShapeSampling, RigidBody
+    from test_host_shape_gpu import ball_callbacks
+
+    pos, vel, bpos = make_scene()
+    nsteps, nranks = 10, 2
+    BALL_R = 0.12
+
+    def ball():
+        return RigidBody(translation=np.float32([0.02, 0.17, 0.01]), linvel=np.float32([-0.4, 0.1, 0.0]), angvel=np.float32([0.0, 0.5, 3.0]),
+                         mass=5.0, principal_inertia=np.float32([0.03, 0.03, 0.03]))
+
+    def run(w, host):
+        empty = w.add_boundary(Boundary(np.zeros((0, 3), np.float32)))
+        coupling = ColliderCouplingSet()
+        body = ball()
+        sampling = HostShapeSampling(*ball_callbacks(body, BALL_R)) if host else DynamicContactSampling(("ball", BALL_R))
+        coupling.register_coupling(empty, "ball", body, sampling)
+        return empty, coupling
+
+    w = LiquidWorld(solver(), R, SF)
+    f = Fluid(pos, R, 1000.0)
+    f.velocities = vel
+    f.nonpressure_forces.append(XSPHViscosity(0.5, 0.3))
+    w.add_fluid(f)
+    w.add_boundary(Boundary(bpos))
+    b, coupling = run(w, False)
+    counts_ref = []
+    for _ in range(nsteps):
+        w.sync_to_device()
+        coupling.update_boundaries(w)  # (the body is not integrated: the same pose every step, on every rank)
+        w.step(DT, G)
+        counts_ref.append(b.num_particles())
+    ref_p, ref_v = f.positions.copy(), f.velocities.copy()
+    _, ref_src = b.sources()
+    ref_force = b.forces.astype(np.float64)
+    ref_pts = b.positions.copy()
+    assert counts_ref[-1] > 40, f"only {counts_ref[-1]} boundary particles: the ball was meant to sit in the fluid"
+
+    cx = dist.cell_x(pos, H)
+    slabs = dist.split_slabs(cx, nranks)
+    owner = dist.owner_of(cx, slabs)
+    comms = dist.Comm.loopback(nranks)
+    offsets = np.concatenate([[0], np.cumsum([(owner == r).sum() for r in range(nranks)])])
+    gid_to_global = np.concatenate([np.nonzero(owner == r)[0] for r in range(nranks)])
+    out, errors = [None] * nranks, [None] * nranks
+
+    def rank_main(r):
+        try:
+            wr = LiquidWorld(solver(), R, SF)
+            mine = np.nonzero(owner == r)[0]
+            fr = Fluid(pos[mine], R, 1000.0)
+            fr.velocities = vel[mine]
+            fr.nonpressure_forces.append(XSPHViscosity(0.5, 0.3))
+            wr.add_fluid(fr)
+            wr.add_boundary(Boundary(bpos[dist.boundary_subset(bpos, H, slabs[r], r, nranks)]))
+            br, cr = run(wr, host_shape)
+            wr.set_domain(comms[r], slabs[r][0], slabs[r][1], int(offsets[r]))
+            counts = []
+            for _ in range(nsteps):
+                wr.sync_to_device()
+                cr.update_boundaries(wr)
+                wr.step(DT, G)
+                counts.append(br.num_particles())
+            slot, gid = br.sources()
+            out[r] = (wr.owned(), counts, slot, gid, br.positions.copy(), br.velocities.copy(), br.forces.astype(np.float64))
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    for e in errors:
+        if e is not None:
+            raise e
+    assert not any(t.is_alive() for t in threads), "a rank hung"
+    for c in comms:
+        c.destroy()
+    # the same table on both ranks, in rank order
+    (_, counts0, slot0, gid0, pts0, bv0, force0), (_, counts1, slot1, gid1, pts1, bv1, force1) = out
+    assert counts0 == counts1
+    assert np.array_equal(gid0, gid1) and np.array_equal(pts0, pts1) and np.array_equal(bv0, bv1) and (slot0 == 0).all() and (slot1 == 0).all()
+    src = gid_to_global[gid0]
+    assert len(np.unique(src)) == len(src)
+    final_owner = np.full(len(pos), -1)
+    got_p, got_v = np.full_like(pos, np.nan), np.full_like(vel, np.nan)
+    for r in range(nranks):
+        gid, p, v, _slot = out[r][0]
+        final_owner[gid_to_global[gid]] = r
+        got_p[gid_to_global[gid]] = p
+        got_v[gid_to_global[gid]] = v
+    emitted_by = final_owner[src]
+    assert (emitted_by == 0).sum() > 10 and (emitted_by == 1).sum() > 10, "the ball was meant to straddle the cut"
+    assert (np.diff(emitted_by) >= 0).all(), "rows are in rank order"
+    # against the undivided world: the same fluid particles emitted (a particle at the very edge of the reach may differ), the same
+    # points, and per point the ranks' forces add up to the single force
+    assert max(abs(a - b0) for a, b0 in zip(counts0, counts_ref)) <= 2, f"{counts0} vs {counts_ref}"
+    common, i_ref, i_got = np.intersect1d(ref_src, src, return_indices=True)
+    assert len(common) >= len(ref_src) - 2 and len(common) >= len(src) - 2
+    assert np.abs(pts0[i_got] - ref_pts[i_ref]).max() < 2e-4 * H
+    scale = np.abs(ref_force).max()
+    assert scale > 0
+    summed = force0 + force1
+    assert np.abs(force0[i_got]).max() > 0.01 * scale and np.abs(force1[i_got]).max() > 0.01 * scale, "both slabs press on the ball"
+    assert np.abs(summed[i_got] - ref_force[i_ref]).max() < 5e-3 * scale, \
+        f"summed forces differ by {np.abs(summed[i_got] - ref_force[i_ref]).max() / scale:.2e} of the largest"
+    dp, dv = np.abs(got_p - ref_p).max(), np.abs(got_v - ref_v).max()
+    assert dp < 2e-4 * H, f"positions differ by {dp / H:.2e} h"
+    assert dv < 5e-3, f"velocities differ by {dv:.2e} m/s"
+
+
 def test_rebalance_recuts_the_slabs_and_keeps_the_physics(hip_lib):
     """salva_hip_rebalance: three ranks start from deliberately lopsided cuts (one rank owns 60 % of the particles), re-cut
     every second step, and must end up within a few per cent of N / 3 each — while the particle states keep following the
