@@ -247,7 +247,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
 bool launch_density_alpha_div(const StepCtx& c, const TileLds& L, hipStream_t s) {
 #ifndef SALVA_OTHER_KERNELS
     if (!(c.mass_uniform > 0.0f) || (c.sc.kd | c.sc.kg) != 0) return false;
-    const uint32_t ds = pick_ds_p3(L.max_halo_fluid);
+    const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
     SALVA_LAUNCH_P3(k_density_alpha_div_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
     return true;
 #else
@@ -425,11 +425,11 @@ __global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence, c, L, s);
     if (c.mass_uniform > 0.0f) {
-        const uint32_t ds = pick_ds_p3(L.max_halo_fluid);
+        const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
         SALVA_LAUNCH_P3(k_divergence_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
         return;
     }
-    const uint32_t ds = pick_ds(pw_slots(L));
+    const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
     SALVA_LAUNCH_FIXED(k_divergence, ds, c, L, pw_bytes(L, ds, true), s, c);
 }
 
@@ -557,11 +557,11 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence_apply, c, L, inv_dt_prev, s);
     if (c.mass_uniform > 0.0f) {
-        const uint32_t ds = pick_ds_p2(L.raw_slots());
+        const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
         SALVA_LAUNCH_P2(k_divergence_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt_prev);
         return;
     }
-    const uint32_t ds = pick_ds(pk_slots(L));
+    const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
     SALVA_LAUNCH_FIXED(k_divergence_apply, ds, c, L, pk_bytes(L, ds), s, c, inv_dt_prev);
 }
 
@@ -733,11 +733,11 @@ __global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pred_density, c, L, dt, s);
     if (c.mass_uniform > 0.0f) {
-        const uint32_t ds = pick_ds_p3(L.max_halo_fluid);
+        const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
         SALVA_LAUNCH_P3(k_pred_density_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
         return;
     }
-    const uint32_t ds = pick_ds(pw_slots(L));
+    const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
     SALVA_LAUNCH_FIXED(k_pred_density, ds, c, L, pw_bytes(L, ds, true), s, c, dt);
 }
 
@@ -852,11 +852,11 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pressure_apply, c, L, inv_dt, s);
     if (c.mass_uniform > 0.0f) {
-        const uint32_t ds = pick_ds_p2(L.raw_slots());
+        const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
         SALVA_LAUNCH_P2(k_pressure_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt);
         return;
     }
-    const uint32_t ds = pick_ds(pk_slots(L));
+    const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
     SALVA_LAUNCH_FIXED(k_pressure_apply, ds, c, L, pk_bytes(L, ds), s, c, inv_dt);
 }
 

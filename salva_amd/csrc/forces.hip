@@ -102,7 +102,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_xsph(StepCtx c, uint32_t m
 void launch_xsph(const StepCtx& c, const TileLds& L, uint32_t model, float fluid_coeff, float boundary_coeff,
                  float inv_dt_prev, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_xsph, c, L, model, fluid_coeff, boundary_coeff, inv_dt_prev, s);
-    const uint32_t ds = pick_ds(pw_slots(L));
+    const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
     SALVA_LAUNCH_FIXED(k_xsph, ds, c, L, pw_bytes(L, ds, false), s, c, model, fluid_coeff, boundary_coeff, inv_dt_prev);
 }
 
@@ -460,7 +460,7 @@ void launch_akinci_forces(const StepCtx& c, const TileLds& L, uint32_t model, fl
     const float h6_64 = (float)(pow(h, 6) / 64.0);
     const float anorm = (float)(0.007 / pow(h, 3.25));
     if (akinci_fast_ok(c)) {
-        const uint32_t ds = pick_ds(pw_slots(L));
+        const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
         SALVA_LAUNCH_FIXED(k_akinci_forces_one_fluid, ds, c, L, pw_bytes(L, ds, false), s, c, tension, adhesion, cnorm, h6_64, anorm);
         return;
     }

@@ -175,11 +175,11 @@ __global__ SALVA_IISPH_P3_BOUNDS(DS) void k_iisph_pred_density_p3(StepCtx c, flo
 void launch_iisph_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_iisph_pred_density, c, L, dt, s);
     if (c.mass_uniform > 0.0f) {
-        const uint32_t ds = pick_ds_p3(L.max_halo_fluid);
+        const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
         SALVA_LAUNCH_P3(k_iisph_pred_density_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
         return;
     }
-    const uint32_t ds = pick_ds(pw_slots(L));
+    const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
     SALVA_LAUNCH_FIXED(k_iisph_pred_density, ds, c, L, pw_bytes(L, ds, false), s, c, dt);
 }
 
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_dij_pj(StepCtx c, fl
 }
 void launch_iisph_dij_pj(const StepCtx& c, const TileLds& L, float dt, const float* p, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_iisph_dij_pj, c, L, dt, p, s);
-    const uint32_t ds = pick_ds(pk_slots(L));
+    const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
     SALVA_LAUNCH_FIXED(k_iisph_dij_pj, ds, c, L, pk_bytes(L, ds), s, c, dt, p);
 }
 
@@ -473,11 +473,11 @@ void launch_iisph_next_pressure(const StepCtx& c, const TileLds& L, float dt, fl
                                 hipStream_t s) {
     SALVA_OK_DISPATCH(launch_iisph_next_pressure, c, L, dt, omega, p, p_next, s);
     if (c.mass_uniform > 0.0f) {
-        const uint32_t ds = pick_ds_p3(L.max_halo_fluid);
+        const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
         SALVA_LAUNCH_P3(k_iisph_next_pressure_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c, dt, omega, p, p_next);
         return;
     }
-    const uint32_t ds = pick_ds(pw_slots(L));
+    const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
     SALVA_LAUNCH_FIXED(k_iisph_next_pressure, ds, c, L, pw_bytes(L, ds, true), s, c, dt, omega, p, p_next);
 }
 
@@ -580,11 +580,11 @@ void launch_iisph_velocity_changes(const StepCtx& c, const TileLds& L, float dt,
     if (!c.n) return;
     k_iisph_pr2<<<num_blocks(c.n), BLOCK, 0, s>>>(c, p);
     if (c.mass_uniform > 0.0f) {
-        const uint32_t ds = pick_ds_p2(L.raw_slots());
+        const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
         SALVA_LAUNCH_P2(k_iisph_velocity_changes_p2, ds, c, L, p2_bytes(L, ds), s, c, dt);
         return;
     }
-    const uint32_t ds = pick_ds(pk_slots(L));
+    const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
     SALVA_LAUNCH_FIXED(k_iisph_velocity_changes, ds, c, L, pk_bytes(L, ds), s, c, dt);
 }
 

@@ -200,8 +200,13 @@ __device__ __forceinline__ float (*carve_errtab(Tile& t))[MAX_MODELS] {
         else if ((DSV) == FIXED_DS_LARGE) SALVA_LAUNCH_TILE(kernel<FIXED_DS_LARGE>, c, L, lds, s, __VA_ARGS__);    \
         else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                             \
     } while (0)
-static inline uint32_t pick_ds(uint32_t slots_needed) {
-    return slots_needed <= FIXED_DS_SMALL ? FIXED_DS_SMALL : (slots_needed <= FIXED_DS_LARGE ? FIXED_DS_LARGE : 0u);
+// (`level`, TileLds::ds_level = SALVA_HIP_DS_LEVEL: take the level-th larger layout than the halo needs — the tests' way to run every
+// instantiation on scenes whose halos would all pick the smallest; the arithmetic does not depend on the layout)
+static inline uint32_t pick_ds(uint32_t slots_needed, uint32_t level) {
+    const uint32_t ds[3] = {FIXED_DS_SMALL, FIXED_DS_LARGE, 0u};
+    uint32_t k = slots_needed <= FIXED_DS_SMALL ? 0u : (slots_needed <= FIXED_DS_LARGE ? 1u : 2u);
+    k += level;
+    return ds[k < 2u ? k : 2u];
 }
 // P | W kernels: both arrays hold fluid halo + boundary halo
 static inline uint32_t pw_slots(const TileLds& L) { return L.sum_slots(); }
@@ -210,8 +215,11 @@ static inline uint32_t pw_bytes(const TileLds& L, uint32_t ds, bool errtab) {
 }
 // plane layout (P3): 16 DS + 8 S bytes of planes (S = the launch's largest fluid halo), the boundary halo in one or two 16-byte
 // arrays, the compact error table
-static inline uint32_t pick_ds_p3(uint32_t s) {
-    return s <= P3_DS_THREE ? P3_DS_THREE : (s <= P3_DS_TWO ? P3_DS_TWO : (s <= P3_DS_ONE ? P3_DS_ONE : 0u));
+static inline uint32_t pick_ds_p3(uint32_t s, uint32_t level) {
+    const uint32_t ds[4] = {P3_DS_THREE, P3_DS_TWO, P3_DS_ONE, 0u};
+    uint32_t k = s <= P3_DS_THREE ? 0u : (s <= P3_DS_TWO ? 1u : (s <= P3_DS_ONE ? 2u : 3u));
+    k += level;
+    return ds[k < 3u ? k : 3u];
 }
 static inline uint32_t p3_bytes(const TileLds& L, uint32_t ds, uint32_t nmodels, bool with_bv) {
     const uint32_t dist8 = ds ? ds * 8u : ((L.max_halo_fluid * 8u + 15u) & ~15u);
@@ -224,8 +232,11 @@ static inline uint32_t p3_bytes(const TileLds& L, uint32_t ds, uint32_t nmodels,
     static const uint32_t pad = getenv("SALVA_HIP_P3_PAD") ? (uint32_t)atoi(getenv("SALVA_HIP_P3_PAD")) : 0u;  // (A/B: where a CU stops taking three tiles)
     return 2u * dist8 + (by_raw < by_maxima ? by_raw : by_maxima) + ((TILE_MAX_WAVES * nmodels * 4u + 15u) & ~15u) + 32u + pad;
 }
-static inline uint32_t pick_ds_p2(uint32_t n) {
-    return n <= P2_DS_THREE ? P2_DS_THREE : (n <= P3_DS_TWO ? P3_DS_TWO : (n <= P3_DS_ONE ? P3_DS_ONE : 0u));
+static inline uint32_t pick_ds_p2(uint32_t n, uint32_t level) {
+    const uint32_t ds[4] = {P2_DS_THREE, P3_DS_TWO, P3_DS_ONE, 0u};
+    uint32_t k = n <= P2_DS_THREE ? 0u : (n <= P3_DS_TWO ? 1u : (n <= P3_DS_ONE ? 2u : 3u));
+    k += level;
+    return ds[k < 3u ? k : 3u];
 }
 #define SALVA_LAUNCH_P3(kernel, DSV, c, L, lds, s, ...)                                                          \
     do {                                                                                                         \

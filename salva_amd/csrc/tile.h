@@ -52,6 +52,7 @@ struct TileLds {
     // largest (fluid halo) + (boundary halo) of any one tile WITHOUT padding (0: unknown — a speculative pass): the slot count of
     // the plane layouts (stage_p3), which are filled through registers and need no 64-slot granularity
     uint32_t max_raw = 0;
+    uint32_t ds_level = 0;  // SALVA_HIP_DS_LEVEL (pairs.h pick_ds*): 0 in production
     uint32_t raw_slots() const { return max_raw ? max_raw : max_halo_fluid + max_halo_boundary; }
     uint32_t sum_slots() const {
         const uint32_t worst = ((max_halo_fluid + 63u) & ~63u) + max_halo_boundary;

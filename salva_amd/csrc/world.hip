@@ -135,6 +135,7 @@ World::World(const SalvaHipParams& p) : prm(p) {
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
     tile_trace = getenv("SALVA_HIP_TILE_TRACE") != nullptr;
     no_fused_div = getenv("SALVA_HIP_NO_FUSED_DIV") != nullptr;
+    if (const char* e = getenv("SALVA_HIP_DS_LEVEL")) lds.ds_level = (uint32_t)std::max(0, atoi(e));  // (tests: pairs.h pick_ds*)
 #ifdef SALVA_HIP_DIAG
     if (const char* e = getenv("SALVA_HIP_SCHED")) sched_mode = atoi(e);
 #endif

@@ -502,6 +502,31 @@ def test_plane_layouts_and_the_fused_first_divergence_change_rounding_only(monke
         assert np.array_equal(a[f"pos_{f}"], b[f"pos_{f}"]) and np.array_equal(a[f"vel_{f}"], b[f"vel_{f}"])
 
 
+@pytest.mark.parametrize("name", ["dfsph_tank", "iisph_akinci", "dfsph_xsph_block", "two_phase"])
+def test_every_lds_layout_instantiation_computes_the_same_bits(monkeypatch, name):
+    """The solver kernels exist in up to four instantiations each — the second staged array / plane at one of three compile-time
+    distances (three, two, one tile per CU) or at a run-time distance — picked from the launch's largest halo (pairs.h pick_ds*).
+    Halos large enough for the upper ones take a 10^6-particle column under compression, so SALVA_HIP_DS_LEVEL pushes the pick up
+    by one, two, three levels on a small scene.  The layout moves LDS addresses and nothing else: every level must reproduce
+    level 0 bit for bit, in both kernel families (plane layouts / SALVA_HIP_NO_PLANES)."""
+    builder, nsteps = SCENES[name]
+    for planes in (True, False):
+        runs = []
+        for level in (0, 1, 2, 3):
+            monkeypatch.setenv("SALVA_HIP_DS_LEVEL", str(level))
+            if planes:
+                monkeypatch.delenv("SALVA_HIP_NO_PLANES", raising=False)
+            else:
+                monkeypatch.setenv("SALVA_HIP_NO_PLANES", "1")
+            runs.append(run_hip(builder(), nsteps))
+        for level in (1, 2, 3):
+            for key in runs[0]:
+                if key.startswith("bforce_"):  # (atomically accumulated: the last bit depends on the order the tiles arrive in)
+                    continue
+                a, b = np.asarray(runs[0][key]), np.asarray(runs[level][key])
+                assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), f"{name} planes={planes} level {level}: {key} differs"
+
+
 def test_stray_particles_far_from_the_bulk():
     """A few particles hundreds of cells away from the block (what a leaking wall produces, in the reference too) blow
     the cell bounding box up to tens of millions of empty cells: per-tile tables are compact over non-empty tiles and the
