@@ -1169,7 +1169,9 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     const bool has_dyn = has_dynamic_sampling();
     double dcs_ms = 0.0;
     // a pass can be repeated from the untouched pre-sort buffers iff it has no side effect outside the world's own arrays
-    const bool can_redo = !comm && !any_wants_forces && !has_custom && !has_dyn;
+    // (a communicator of one rank exchanges nothing: its passes are as repeatable as the plain world's)
+    const bool solo = comm && !comm->has_lo() && !comm->has_hi();
+    const bool can_redo = (!comm || solo) && !any_wants_forces && !has_custom && !has_dyn;
     // (mass_known: the kernels of a pass are chosen by StepCtx::mass_uniform, which a speculative pass — it does not wait for the
     // publication that carries it — can only inherit; a host edit since the last publication may have changed the masses)
     const bool can_speculate = !spec_off && can_redo && !b_dirty && pred_valid && pred_n == n && mass_known;
