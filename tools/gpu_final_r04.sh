@@ -29,9 +29,11 @@ except Exception as e:
     print('$f', 'FAILED', e)
 PY
 done
+if [ -z "$SKIP_PROFILES" ]; then
 bash tools/profile_r04.sh r04_cfg2 2>&1 | tail -25
 bash tools/profile_r04.sh r04_cfg3 --config 3 2>&1 | tail -22
 bash tools/profile_r04.sh r04_cfg4 --config 4 2>&1 | tail -22
 bash tools/profile_r04.sh r04_8m --side 200 2>&1 | tail -22
+fi
 STEPS=25 bash tools/gap_trace.sh > /dev/null 2>&1; python tools/gap_tsv_report.py gpurun_out/gaps/kernels.tsv 3 8 > $OUT/gap_report_free_fall.txt 2>&1; python tools/gap_tsv_report.py gpurun_out/gaps/kernels.tsv > $OUT/gap_report_last_steps.txt 2>&1
 head -4 $OUT/gap_report_free_fall.txt
