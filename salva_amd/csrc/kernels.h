@@ -14,8 +14,12 @@ namespace salva {
 unsigned bbox_blocks(uint32_t n);
 void launch_bbox(const float4* pts, uint32_t n, float h, int32_t* partials, int32_t* bbox6, uint32_t* flags, hipStream_t s);
 void launch_bbox_final(const int32_t* partials, unsigned nblocks, int32_t* bbox6, hipStream_t s);
+// counts != nullptr: the first half of the counting sort (cell_sort) — counts[key] += 1, rank[i] = the value before; idx is not written
 void launch_cell_keys(const float4* pts, uint32_t n, float h, TileGrid g, uint32_t* keys, uint32_t* idx,
-                      uint32_t* flags, uint32_t* mass_mm, hipStream_t s);
+                      uint32_t* flags, uint32_t* mass_mm, uint32_t* counts, uint32_t* rank, hipStream_t s);
+size_t cell_sort_temp_bytes(uint32_t ncells);
+void cell_sort(void* temp, size_t temp_bytes, uint32_t n, uint32_t ncells, const uint32_t* keys, const uint32_t* rank, uint32_t* cell_start,
+               uint32_t* keys_out, uint32_t* idx_tmp, uint32_t* idx_out, hipStream_t s);
 size_t sort_pairs_temp_bytes(uint32_t n, int end_bit);
 void sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
                 uint32_t* idx_out, uint32_t n, int end_bit, hipStream_t s);

@@ -135,6 +135,7 @@ World::World(const SalvaHipParams& p) : prm(p) {
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
     tile_trace = getenv("SALVA_HIP_TILE_TRACE") != nullptr;
     no_fused_div = getenv("SALVA_HIP_NO_FUSED_DIV") != nullptr;
+    radix_sort = getenv("SALVA_HIP_RADIX_SORT") != nullptr;
     if (const char* e = getenv("SALVA_HIP_DS_LEVEL")) lds.ds_level = (uint32_t)std::max(0, atoi(e));  // (tests: pairs.h pick_ds*)
 #ifdef SALVA_HIP_DIAG
     if (const char* e = getenv("SALVA_HIP_SCHED")) sched_mode = atoi(e);
@@ -729,7 +730,7 @@ void World::build_boundary_grid() {
     bkeys[0].ensure(nb); bkeys[1].ensure(nb); bidx[0].ensure(nb); bidx[1].ensure(nb);
     bposv.ensure(nb); bvel.ensure(nb); bperm.ensure(nb); cell_start_b.ensure(nc + 1);
     TileGrid gv{gb.o[0], gb.o[1], gb.o[2], gb.nt[0], gb.nt[1], gb.nt[2], nullptr};
-    launch_cell_keys(bst_pos.p, nb, sc.h, gv, bkeys[0].p, bidx[0].p, d_flags.p, nullptr, stream);
+    launch_cell_keys(bst_pos.p, nb, sc.h, gv, bkeys[0].p, bidx[0].p, d_flags.p, nullptr, nullptr, nullptr, stream);
     const int end_bit = bits_for(nc);
     const size_t tb = sort_pairs_temp_bytes(nb, end_bit);
     ensure_cub_temp(tb);
@@ -1210,7 +1211,15 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         // (a scene known to hold different masses — two fluids of different density0 — is not asked again until the host edits the
         // particles: every wave of the lighter fluid would raise a flag, 71 us per launch at 2 x 10^6 particles)
         check_mass = !(mass_known && mass_uniform == 0.0f);
-        launch_cell_keys(posm[cur].p, n, sc.h, gv, keys[0].p, idx[0].p, d_flags.p, check_mass ? mass_slots.p : nullptr, stream);
+        // The sort is a counting sort by cell (grid.hip cell_sort) unless SALVA_HIP_RADIX_SORT=1 asks for the radix sort it replaced:
+        // same result, bit for bit
+        const bool counting = !radix_sort && ncf + 1 < 0x7fffffffull;
+        if (counting) {
+            cell_rank.ensure(n, stream, false, 1.1f);
+            SALVA_HIP_CHECK(hipMemsetAsync(cell_start_f.p, 0, (ncf + 1) * sizeof(uint32_t), stream));
+        }
+        launch_cell_keys(posm[cur].p, n, sc.h, gv, keys[0].p, idx[0].p, d_flags.p, check_mass ? mass_slots.p : nullptr,
+                         counting ? cell_start_f.p : nullptr, counting ? cell_rank.p : nullptr, stream);
         if (has_dyn) {  // coupling.update_boundaries (liquid_world.rs:94-103): may push particles, cells stay
             // (host clock: the pass ends with a read-back of the emitted count, so the stream is drained when it returns)
             if (timers) wait_stream();
@@ -1218,11 +1227,17 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
             run_dynamic_sampling();
             dcs_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
         }
-        const int end_bit = bits_for(ncf);
-        const size_t tb = sort_pairs_temp_bytes(n, end_bit);
-        ensure_cub_temp(tb);
-        sort_pairs(cub_temp.p, tb, keys[0].p, keys[1].p, idx[0].p, idx[1].p, n, end_bit, stream);
-        launch_cell_start(keys[1].p, n, (uint32_t)ncf, cell_start_f.p, stream);
+        if (counting) {
+            const size_t tb = cell_sort_temp_bytes((uint32_t)ncf);
+            ensure_cub_temp(tb);
+            cell_sort(cub_temp.p, tb, n, (uint32_t)ncf, keys[0].p, cell_rank.p, cell_start_f.p, keys[1].p, idx[0].p, idx[1].p, stream);
+        } else {
+            const int end_bit = bits_for(ncf);
+            const size_t tb = sort_pairs_temp_bytes(n, end_bit);
+            ensure_cub_temp(tb);
+            sort_pairs(cub_temp.p, tb, keys[0].p, keys[1].p, idx[0].p, idx[1].p, n, end_bit, stream);
+            launch_cell_start(keys[1].p, n, (uint32_t)ncf, cell_start_f.p, stream);
+        }
     }
     // The particle arrays are permuted into the sorted order AFTER the tile tables have been counted: those need the cell table
     // only, and the host then waits for their totals while the GPU moves the 136 bytes per particle of the reorder.

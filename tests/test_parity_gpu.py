@@ -527,6 +527,48 @@ def test_every_lds_layout_instantiation_computes_the_same_bits(monkeypatch, name
                 assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), f"{name} planes={planes} level {level}: {key} differs"
 
 
+def test_counting_sort_by_cell_is_the_radix_sort_bit_for_bit(monkeypatch):
+    """Round 4: the fluid's sort of every step is a counting sort by cell (atomic counts -> scan = the cell table -> scatter ->
+    ascending source index within each cell, grid.hip cell_sort); SALVA_HIP_RADIX_SORT=1 brings back the stable radix sort +
+    k_cell_start it replaced.  A stable sort from the identity is "by key, then by index", so both must give the same permutation
+    — the same summation orders, the same bits — on dense scenes, with two fluids, with a bounding box of 3 x 10^7 mostly empty cells,
+    and with a few hundred particles crowded into one cell (k_cell_order is linear in a cell's population per particle)."""
+    def both(make, nsteps):
+        monkeypatch.delenv("SALVA_HIP_RADIX_SORT", raising=False)
+        a = run_hip(make(), nsteps)
+        monkeypatch.setenv("SALVA_HIP_RADIX_SORT", "1")
+        b = run_hip(make(), nsteps)
+        monkeypatch.delenv("SALVA_HIP_RADIX_SORT", raising=False)
+        for key in a:
+            if key.startswith("bforce_"):  # (atomically accumulated)
+                continue
+            assert np.array_equal(np.asarray(a[key]), np.asarray(b[key]), equal_nan=True), f"{key} differs"
+
+    both(SCENES["dfsph_tank"][0], 8)
+    both(SCENES["two_phase"][0], 6)
+
+    def strays():
+        s = Scene(R, 2.0, "dfsph")
+        block = scenes.jitter(scenes.cube_fluid_positions(8, 8, 8, R), 0.1 * R, seed=42)
+        far = np.array([[30.0, 40.0, -25.0], [-12.0, 3.0, 8.0], [0.3, -35.0, 0.1], [30.02, 40.01, -25.0]], np.float32)
+        pos = np.concatenate([block, far]).astype(np.float32)
+        s.add_fluid(pos, scenes.random_velocities(len(pos), 0.3, seed=5), 1000.0, forces=[("xsph", 0.5, 0.0)])
+        return s
+
+    both(strays, 4)
+
+    def crowd():
+        s = Scene(R, 2.0, "dfsph")
+        rng = np.random.default_rng(3)
+        block = scenes.jitter(scenes.cube_fluid_positions(6, 6, 6, R), 0.1 * R, seed=42)
+        knot = (np.float32([0.505, 0.505, 0.505]) + rng.uniform(0.0, 0.9 * 4 * R, size=(300, 3))).astype(np.float32)  # one cell, h = 4 r
+        pos = np.concatenate([block, knot]).astype(np.float32)
+        s.add_fluid(pos, scenes.random_velocities(len(pos), 0.1, seed=6), 1000.0, forces=[("xsph", 0.5, 0.0)])
+        return s
+
+    both(crowd, 3)
+
+
 def test_stray_particles_far_from_the_bulk():
     """A few particles hundreds of cells away from the block (what a leaking wall produces, in the reference too) blow
     the cell bounding box up to tens of millions of empty cells: per-tile tables are compact over non-empty tiles and the
