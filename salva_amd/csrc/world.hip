@@ -135,7 +135,7 @@ World::World(const SalvaHipParams& p) : prm(p) {
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
     tile_trace = getenv("SALVA_HIP_TILE_TRACE") != nullptr;
     no_fused_div = getenv("SALVA_HIP_NO_FUSED_DIV") != nullptr;
-    radix_sort = getenv("SALVA_HIP_RADIX_SORT") != nullptr;
+    if (const char* e = getenv("SALVA_HIP_RADIX_SORT")) sort_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("SALVA_HIP_DS_LEVEL")) lds.ds_level = (uint32_t)std::max(0, atoi(e));  // (tests: pairs.h pick_ds*)
 #ifdef SALVA_HIP_DIAG
     if (const char* e = getenv("SALVA_HIP_SCHED")) sched_mode = atoi(e);
@@ -1211,9 +1211,11 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         // (a scene known to hold different masses — two fluids of different density0 — is not asked again until the host edits the
         // particles: every wave of the lighter fluid would raise a flag, 71 us per launch at 2 x 10^6 particles)
         check_mass = !(mass_known && mass_uniform == 0.0f);
-        // The sort is a counting sort by cell (grid.hip cell_sort) unless SALVA_HIP_RADIX_SORT=1 asks for the radix sort it replaced:
-        // same result, bit for bit
-        const bool counting = !radix_sort && ncf + 1 < 0x7fffffffull;
+        // The sort is a counting sort by cell (grid.hip cell_sort: same result as the radix sort it replaced, bit for bit) while the
+        // cell table is not much larger than the particle set — it costs a memset and a scan of that table, where the radix sort
+        // with k_cell_start writes it once: a bounding box blown up by a few strays (4 x 10^8 cells around 25 k particles) keeps
+        // the radix sort.  SALVA_HIP_RADIX_SORT=1 / 0 forces one or the other.
+        const bool counting = ncf + 1 < 0x7fffffffull && (sort_mode == 0 || (sort_mode < 0 && ncf <= 16ull * n + (1ull << 20)));
         if (counting) {
             cell_rank.ensure(n, stream, false, 1.1f);
             SALVA_HIP_CHECK(hipMemsetAsync(cell_start_f.p, 0, (ncf + 1) * sizeof(uint32_t), stream));
