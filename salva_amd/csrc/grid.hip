@@ -491,33 +491,8 @@ __global__ __launch_bounds__(BLOCK) void k_tile_ids(const uint32_t* __restrict__
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     if (t < ntiles && rank[t + 1] != rank[t]) tile_ids[rank[t]] = t;
 }
-// The same three steps in ONE workgroup for grids of up to 2^18 tiles (10^6 particles: 3.4 k tiles, 8 x 10^6: 27 k): flags, their
-// exclusive prefix and the list of non-empty tiles, 1024 tiles per trip — one launch instead of four (flags, look-back
-// initialisation, scan, ids: 19.5 us of a free-fall step at 10^6, each of them launch latency).
-constexpr int ONE_WG = 1024;
-__global__ __launch_bounds__(ONE_WG) void k_tile_slots_one(const uint32_t* __restrict__ cell_start, uint32_t ntiles, uint32_t* __restrict__ rank,
-                                                           uint32_t* __restrict__ tile_ids) {
-    using Scan = hipcub::BlockScan<uint32_t, ONE_WG>;
-    __shared__ typename Scan::TempStorage tmp;
-    uint32_t base = 0u;
-    for (uint32_t t0 = 0; t0 < ntiles; t0 += ONE_WG) {
-        const uint32_t t = t0 + threadIdx.x;
-        const uint32_t f = (t < ntiles && cell_start[(size_t)t * TCELLS + TCELLS] > cell_start[(size_t)t * TCELLS]) ? 1u : 0u;
-        uint32_t ex, total;
-        Scan(tmp).ExclusiveSum(f, ex, total);
-        __syncthreads();  // (tmp is reused by the next trip)
-        if (t < ntiles) rank[t] = base + ex;
-        if (f) tile_ids[base + ex] = t;
-        base += total;
-    }
-    if (threadIdx.x == 0) rank[ntiles] = base;
-}
 void launch_tile_slots(const uint32_t* cell_start, uint32_t ntiles, uint32_t* flags, uint32_t* rank, uint32_t* tile_ids, void* temp,
                        size_t temp_bytes, hipStream_t s) {
-    if (ntiles <= (1u << 18)) {
-        k_tile_slots_one<<<1, ONE_WG, 0, s>>>(cell_start, ntiles, rank, tile_ids);
-        return;
-    }
     k_tile_flags<<<div_up((size_t)ntiles + 1, BLOCK), BLOCK, 0, s>>>(cell_start, ntiles, flags);
     SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, flags, rank, (int)(ntiles + 1), s));
     k_tile_ids<<<div_up((size_t)ntiles, BLOCK), BLOCK, 0, s>>>(rank, ntiles, tile_ids);
@@ -576,27 +551,7 @@ size_t scan_tiles_temp_bytes(uint32_t n) {
     (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n);
     return b;
 }
-// (one workgroup for up to 2^16 entries — one launch instead of look-back initialisation + scan; sums of integers and maxima:
-// the same values in any association)
-__global__ __launch_bounds__(ONE_WG) void k_scan_tiles_one(const TileAcc* __restrict__ in, TileAcc* __restrict__ out, uint32_t n) {
-    using Scan = hipcub::BlockScan<TileAcc, ONE_WG>;
-    __shared__ typename Scan::TempStorage tmp;
-    TileAcc base{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t k0 = 0; k0 < n; k0 += ONE_WG) {
-        const uint32_t k = k0 + threadIdx.x;
-        const TileAcc v = k < n ? in[k] : TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        TileAcc ex, total;
-        Scan(tmp).ExclusiveScan(v, ex, base, hipcub::Sum(), total);
-        __syncthreads();
-        if (k < n) out[k] = ex;
-        base = base + total;
-    }
-}
 void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s) {
-    if (n <= (1u << 16)) {
-        k_scan_tiles_one<<<1, ONE_WG, 0, s>>>(in, out, n);
-        return;
-    }
     SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n, s));
 }
 
