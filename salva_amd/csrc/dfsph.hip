@@ -33,7 +33,14 @@ using namespace salva;
 // zero — is summed again with kernel_eval over the exact lists.  The padding entries of a list are the particle itself: their
 // gradients vanish exactly and zero-distance weights are masked out of the sum (the self weight is added once, separately).
 // Also writes posmr = (x, m / rho): what a neighbour contributes to the sums that weigh by volume m_j / rho_j (XSPH).
-__global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
+// IISPH = true (single-domain IISPH worlds): d_ii = -dt^2 / rho_i^2 (sum_j m_j grad W_ij + sum_b V_b rho0 grad W_ib) (iisph_solver.rs:144-186) is
+// that gradient sum times a factor of the density this pass has just finished — so the pass writes d_ii, p_i = p_i(previous step) / 2
+// (:673-677) and the (x, m / rho^2) record of k_iisph_dij_pj itself, and k_iisph_dii (a whole neighbour pass: 39 us at 10^6
+// particles) is not launched; alpha, which IISPH never reads, and its sum of squares are not computed.  The factor multiplies the
+// finished sum instead of every boundary term: rounding only.  Decomposed runs keep the separate pass (a ghost's density is
+// replaced by its owner's between the two).
+template <bool IISPH>
+__global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c, float dt) {
     lds_base_check();
     Tile t;
     t.setup(c);
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
                 rw += wm;
                 const f2 gm = k.g * m;
                 ax += dx * gm; ay += dy * gm; az += dz * gm;
-                s2 += (gm * gm) * r2;
+                if (!IISPH) s2 += (gm * gm) * r2;
             });
             const uint32_t npad = 2u * nqu - o.cnt;  // self contacts appended by k_nbr_tile
             rho = (rw.x + rw.y) * c.sc.wscale + pi.w * c.sc.wnorm;
@@ -114,17 +121,26 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c) {
                 gsx += gx; gsy += gy; gsz += gz;
             });
             if (!(rho > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!density.is_zero()) :662
-            const float denom = sq + (gsx * gsx + gsy * gsy + gsz * gsz);
             c.rho[i] = rho;
-            c.alpha[i] = (denom <= 1.0e-5f) ? 0.0f : 1.0f / denom;
+            if (IISPH) {
+                const float factor = -dt * dt / (rho * rho);
+                c.dii[i] = make_float4(gsx * factor, gsy * factor, gsz * factor, 0.0f);
+                c.kappa[i] = c.dv[i].w * 0.5f;
+                c.iisph_pr[i] = make_float4(pi.x, pi.y, pi.z, pi.w / (rho * rho));
+            } else {
+                const float denom = sq + (gsx * gsx + gsy * gsy + gsz * gsz);
+                c.alpha[i] = (denom <= 1.0e-5f) ? 0.0f : 1.0f / denom;
+            }
             c.posmr[i] = make_float4(pi.x, pi.y, pi.z, pi.w / rho);
         }
         if ((threadIdx.x & (WAVE - 1)) == 0) c.slice_near[gs] = any_near ? 1u : 0u;
     });
 }
-void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s) {
-    SALVA_OK_DISPATCH(launch_density_alpha, c, L, s);
-    SALVA_LAUNCH_TILE(k_density_alpha, c, L, L.bytes(16, 16, 2), s, c);
+// iisph_dt > 0: the IISPH form (d_ii and its companions ride along, see above)
+void launch_density_alpha(const StepCtx& c, const TileLds& L, float iisph_dt, hipStream_t s) {
+    SALVA_OK_DISPATCH(launch_density_alpha, c, L, iisph_dt, s);
+    if (iisph_dt > 0.0f) SALVA_LAUNCH_TILE(k_density_alpha<true>, c, L, L.bytes(16, 16, 2), s, c, iisph_dt);
+    else SALVA_LAUNCH_TILE(k_density_alpha<false>, c, L, L.bytes(16, 16, 2), s, c, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -72,7 +72,8 @@ void launch_boundary_volumes(const StepCtx& c, unsigned long long* ncontacts_bb,
 
 // ---------------------------------------------------------------- dfsph.hip
 unsigned num_blocks(uint32_t n);
-void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s);
+// iisph_dt > 0: the IISPH form — d_ii, p = p_prev / 2 and the dij record ride along (no k_iisph_dii), no alpha
+void launch_density_alpha(const StepCtx& c, const TileLds& L, float iisph_dt, hipStream_t s);
 // density + alpha + the first divergence evaluate of the step in one pass (DFSPH, uniform mass, default kernels): false = not taken
 bool launch_density_alpha_div(const StepCtx& c, const TileLds& L, hipStream_t s);
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s);                 // -> kappa = div*alpha, partials
@@ -137,7 +138,7 @@ void launch_iisph_finish(const StepCtx& c, float dt, const float* p, int32_t* bb
 // hands a world with a non-default KernelDensity / KernelGradient to.
 namespace salva_ok {
 using namespace salva;
-void launch_density_alpha(const StepCtx& c, const TileLds& L, hipStream_t s);
+void launch_density_alpha(const StepCtx& c, const TileLds& L, float iisph_dt, hipStream_t s);
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s);
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s);
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s);

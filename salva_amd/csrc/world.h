@@ -229,6 +229,7 @@ class World {
     bool tile_trace = false;    // SALVA_HIP_TILE_TRACE=1: one line of tile statistics per step on stderr
     bool no_fused_div = false;  // SALVA_HIP_NO_FUSED_DIV=1 (A/B): the first divergence evaluate stays a pass of its own
     bool no_planes = false;     // SALVA_HIP_NO_PLANES=1 (A/B): keep the 32-byte-per-slot evaluate kernels
+    bool iisph_dii_fused = false;  // this step's density pass wrote d_ii (k_density_alpha<true>): iisph_solve skips k_iisph_dii
     int sort_mode = -1;         // SALVA_HIP_RADIX_SORT: 1 = always the radix sort + k_cell_start, 0 = always the counting sort by cell, unset = by size
     DevBuf<uint32_t> cell_rank; // counting sort: a particle's place among those of its cell (k_cell_keys)
 #ifdef SALVA_HIP_DIAG

@@ -1051,7 +1051,7 @@ void World::iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStat
     const float inv_dt = (dt == 0.0f) ? 0.0f : 1.0f / dt;
     launch_integrate(c, dt, stream);
     if (comm) refresh_f4(w.p);             // a ghost's own forces were summed over an incomplete neighbourhood
-    launch_iisph_dii(c, lds, dt, stream);  // also p = 0.5 * p_prev (a per-particle operation: right for ghosts too)
+    if (!iisph_dii_fused) launch_iisph_dii(c, lds, dt, stream);  // also p = 0.5 * p_prev (a per-particle operation: right for ghosts too)
     // (d_ii depends on positions only: right on the inner ghost plane without an exchange)
     launch_iisph_pred_density(c, lds, dt, stream);
     launch_iisph_aii(c, lds, dt, stream);
@@ -1381,7 +1381,9 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     // ---- solver   (evaluate_kernels + compute_densities + solver.step, liquid_world.rs:123-144)
     // (DFSPH: the first evaluate of the divergence solve rides in the density pass when the plane layout applies, dfsph.hip)
     fused_first_divergence = prm.solver == SALVA_HIP_SOLVER_DFSPH && !no_fused_div && launch_density_alpha_div(c, lds, stream);
-    if (!fused_first_divergence) launch_density_alpha(c, lds, stream);
+    // (single-domain IISPH: d_ii rides in the density pass, dfsph.hip k_density_alpha<true>)
+    iisph_dii_fused = prm.solver == SALVA_HIP_SOLVER_IISPH && !comm && !no_fused_div;
+    if (!fused_first_divergence) launch_density_alpha(c, lds, iisph_dii_fused ? dt : 0.0f, stream);
     if (comm) {
         refresh_f32(rho.p);
         // (the density pass wrote posmr.w = m / rho from each rank's OWN sum; a ghost's rho has just been replaced by its owner's,
