@@ -37,8 +37,9 @@ using namespace salva;
 // that gradient sum times a factor of the density this pass has just finished — so the pass writes d_ii, p_i = p_i(previous step) / 2
 // (:673-677) and the (x, m / rho^2) record of k_iisph_dij_pj itself, and k_iisph_dii (a whole neighbour pass: 39 us at 10^6
 // particles) is not launched; alpha, which IISPH never reads, and its sum of squares are not computed.  The factor multiplies the
-// finished sum instead of every boundary term: rounding only.  Decomposed runs keep the separate pass (a ghost's density is
-// replaced by its owner's between the two).
+// finished sum instead of every boundary term: rounding only.  a_ii (:188-233) is made of own quantities and sums over the same
+// contacts as well — d_ii . G_i - dt^2 m_i / rho_i^2 sum_j m_j |grad W_ij|^2 — and comes out of this pass too (no k_iisph_aii:
+// another 38 us).  Decomposed runs keep the separate passes (a ghost's density is replaced by its owner's in between).
 template <bool IISPH>
 __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c, float dt) {
     lds_base_check();
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c, f
                 rw += wm;
                 const f2 gm = k.g * m;
                 ax += dx * gm; ay += dy * gm; az += dz * gm;
-                if (!IISPH) s2 += (gm * gm) * r2;
+                if (!IISPH) s2 += (gm * gm) * r2;  // sum |m_j grad W_ij|^2 (alpha)
+                else s2 += (k.g * gm) * r2;        // sum m_j |grad W_ij|^2 (a_ii)
             });
             const uint32_t npad = 2u * nqu - o.cnt;  // self contacts appended by k_nbr_tile
             rho = (rw.x + rw.y) * c.sc.wscale + pi.w * c.sc.wnorm;
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c, f
                 rho += pj.w * e.w;
                 const float gm = e.g * pj.w;
                 const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
-                sq += gx * gx + gy * gy + gz * gz;
+                if (!IISPH) sq += gx * gx + gy * gy + gz * gz;
+                else sq += (dx * e.g) * gx + (dy * e.g) * gy + (dz * e.g) * gz;
                 gsx += gx; gsy += gy; gsz += gz;
             });
         }
@@ -117,14 +120,20 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c, f
                 rho += m * e.w;
                 const float gm = e.g * m;
                 const float gx = dx * gm, gy = dy * gm, gz = dz * gm;
-                sq += gx * gx + gy * gy + gz * gz;
+                if (!IISPH) sq += gx * gx + gy * gy + gz * gz;
+                else sq += (dx * e.g) * gx + (dy * e.g) * gy + (dz * e.g) * gz;
                 gsx += gx; gsy += gy; gsz += gz;
             });
             if (!(rho > 0.0f)) atomicOr(c.flags, 1u);  // assert!(!density.is_zero()) :662
             c.rho[i] = rho;
             if (IISPH) {
-                const float factor = -dt * dt / (rho * rho);
-                c.dii[i] = make_float4(gsx * factor, gsy * factor, gsz * factor, 0.0f);
+                // d_ii = -dt^2 / rho_i^2 G_i with G_i = sum m_j grad W_ij (fluid and boundary neighbours), and
+                // a_ii = sum m_j (d_ii - d_ji) . grad W_ij with d_ji = grad W_ij dt^2 m_i / rho_i^2 (iisph_solver.rs:188-233)
+                //      = d_ii . G_i - dt^2 m_i / rho_i^2 sum m_j |grad W_ij|^2: own quantities and the two sums of this pass
+                const float f0 = dt * dt / (rho * rho);
+                const float dxi = -(gsx * f0), dyi = -(gsy * f0), dzi = -(gsz * f0);
+                c.dii[i] = make_float4(dxi, dyi, dzi, 0.0f);
+                c.aii[i] = (dxi * gsx + dyi * gsy + dzi * gsz) - (f0 * pi.w) * sq;
                 c.kappa[i] = c.dv[i].w * 0.5f;
                 c.iisph_pr[i] = make_float4(pi.x, pi.y, pi.z, pi.w / (rho * rho));
             } else {

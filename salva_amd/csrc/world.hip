@@ -1054,7 +1054,7 @@ void World::iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStat
     if (!iisph_dii_fused) launch_iisph_dii(c, lds, dt, stream);  // also p = 0.5 * p_prev (a per-particle operation: right for ghosts too)
     // (d_ii depends on positions only: right on the inner ghost plane without an exchange)
     launch_iisph_pred_density(c, lds, dt, stream);
-    launch_iisph_aii(c, lds, dt, stream);
+    if (!iisph_dii_fused) launch_iisph_aii(c, lds, dt, stream);  // (fused: a_ii came out of the density pass with d_ii)
     float* const pa = kappa.p;
     float* const pb = kappa2.p;
     const float omega = 0.5f;  // :53
