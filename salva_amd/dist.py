@@ -175,3 +175,33 @@ def apply_owned_deletions(owned_ids: np.ndarray, doomed_ids: np.ndarray) -> np.n
     """`salva_hip_delete_owned`: every rank gets the same list and drops what it owns; ids owned elsewhere are ignored.
     Returns the keep mask over `owned_ids`."""
     return ~np.isin(np.asarray(owned_ids), np.asarray(doomed_ids))
+
+
+# ---- DynamicContactSampling in a decomposed world (csrc/world_dist.hip dist_gather_emitted): every rank ends up with every rank's
+# emitted points, in rank order.  The transport has sums, not gathers: each rank writes its section of a zeroed table and the
+# sections are added as 64-bit integers (x + 0 is exact on bit patterns; the 32-bit fluid words of two ranks that share a 64-bit word
+# cannot carry into each other).  These three functions are the host mirror of that packing, used by the gloo protocol test.
+def emitted_table_words(total: int) -> int:
+    """64-bit words of the table: `total` rows of (x, y, z, source id) as two words each, then one 32-bit fluid index per row."""
+    return 2 * total + (total + 1) // 2
+
+
+def pack_emitted(points: np.ndarray, source_ids: np.ndarray, fluids: np.ndarray, before: int, total: int) -> np.ndarray:
+    """This rank's section of the table: `points` (k, 3) f32, `source_ids` / `fluids` (k,) u32, written behind the `before` rows of
+    the lower ranks; zero everywhere else."""
+    k = len(points)
+    rows = np.zeros((total, 4), np.uint32)
+    rows[before:before + k, :3] = np.ascontiguousarray(points, np.float32).view(np.uint32).reshape(k, 3)
+    rows[before:before + k, 3] = np.asarray(source_ids, np.uint32)
+    models = np.zeros(2 * ((total + 1) // 2), np.uint32)
+    models[before:before + k] = np.asarray(fluids, np.uint32)
+    return np.concatenate([rows.reshape(-1).view(np.uint64), models.view(np.uint64)])
+
+
+def unpack_emitted(words: np.ndarray, total: int):
+    """The summed table -> (points (total, 3) f32, source ids (total,) u32, fluids (total,) u32)."""
+    words = np.ascontiguousarray(words, np.uint64)
+    rows = words[:2 * total].view(np.uint32).reshape(total, 4)
+    models = words[2 * total:].view(np.uint32)[:total]
+    return rows[:, :3].copy().view(np.float32), rows[:, 3].copy(), models.copy()
+

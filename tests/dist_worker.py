@@ -152,6 +152,51 @@ def main():
     assert len(np.unique(allids)) == len(allids) == expect, "an id exists on two ranks or was lost"
     assert not np.isin(doomed, allids).any()
 
+    # DynamicContactSampling is collective (World::dist_gather_emitted): a rank projects everything it holds — a ghost is pushed out
+    # of the collider exactly like its owner — emits for the particles it OWNS, and the ranks assemble one table, the same on
+    # every rank, by adding zero-padded sections as 64-bit integers.  Here: a ball on the cut; the oracle's DynamicContactSampling
+    # arm on each rank's local set and on the undivided domain; the summed table must be the concatenation in rank order, and as a
+    # set of (source particle, point) it must be the undivided domain's, bit for bit.
+    ball_t = np.float32([(slabs[0][1] + 1) * H, 0.05, 0.0])
+    ball_r, dt_prev = 0.12, 0.004
+
+    def emitted(fluid_pos, fluid_vel):
+        w = O.OracleWorld(R, SF, O.DFSPH)
+        f = w.add_fluid(np.asarray(fluid_pos, np.float32), 1000.0, np.asarray(fluid_vel, np.float32))
+        b = w.add_boundary(np.zeros((0, 3), np.float32))
+        w.set_boundary_dynamic_sampling(b, 1, [ball_r])
+        w.update_boundary_pose(b, ball_t, np.float32([0, 0, 0, 1]), np.float32([0.2, 0.0, 0.1]), np.float32([0.0, 1.0, 0.0]), ball_t, True, False)
+        w.set_timestep(dt_prev, 1.0 / dt_prev)
+        w.step(1e-4, (0.0, 0.0, 0.0))
+        _, src = w.boundary_sources(b)
+        return np.asarray(src, np.int64), w.boundary_vec(b, "positions").astype(np.float32)
+
+    vel_all = scenes.random_velocities(len(pos), 1.5, seed=4)  # (the prediction x + v dt decides who emits)
+    gsrc, gpts = emitted(pos, vel_all)
+    assert len(gsrc) > 30, "the ball was meant to sit in the fluid"
+    lsrc, lpts = emitted(local[:, 1:4], vel_all[local[:, 0].astype(int)])
+    mine_e = lsrc < no  # (ghosts emit on their owner's rank)
+    my_gids = owned[lsrc[mine_e], 0].astype(np.uint32)
+    counts_e = torch.zeros(world, dtype=torch.int64)
+    counts_e[rank] = int(mine_e.sum())
+    td.all_reduce(counts_e)
+    total_e, before_e = int(counts_e.sum()), int(counts_e[:rank].sum())
+    assert int(counts_e.min()) > 0, "the ball was meant to straddle the cut"
+    words = dist.pack_emitted(lpts[mine_e], my_gids, np.zeros(len(my_gids), np.uint32), before_e, total_e)
+    assert len(words) == dist.emitted_table_words(total_e)
+    tw = torch.from_numpy(words.view(np.int64).copy())
+    td.all_reduce(tw)  # (two's-complement addition: the same bits as the device's unsigned sum)
+    pts_all, src_all, fl_all = dist.unpack_emitted(tw.numpy().view(np.uint64), total_e)
+    assert np.array_equal(src_all[before_e:before_e + len(my_gids)], my_gids) and not fl_all.any()
+    assert np.array_equal(pts_all[before_e:before_e + len(my_gids)].view(np.uint32), lpts[mine_e].view(np.uint32))
+    tables = [torch.zeros_like(tw) for _ in range(world)]
+    td.all_gather(tables, tw)
+    assert all(torch.equal(t, tw) for t in tables), "every rank holds the same table"
+    assert len(np.unique(src_all)) == total_e == len(gsrc), (total_e, len(gsrc))
+    go, ao = np.argsort(gsrc), np.argsort(src_all)
+    assert np.array_equal(gsrc[go], src_all[ao].astype(np.int64))
+    assert np.array_equal(gpts[go].view(np.uint32), pts_all[ao].view(np.uint32)), "an emitted point differs from the undivided domain's"
+
     td.barrier()
     print(f"OK {rank}", flush=True)
     td.destroy_process_group()

@@ -51,6 +51,26 @@ def test_cell_x_is_f32_floor():
     assert dist.cell_x(x, 0.1)[0] in (-1, -2) and dist.cell_x(x, 0.1)[2] == 0
 
 
+def test_emitted_table_sections_add_up_to_the_concatenation():
+    """World::dist_gather_emitted's packing (dist.pack_emitted / unpack_emitted): zero-padded sections of (point, source id) rows and
+    32-bit fluid indices, added as 64-bit integers, are the concatenation in rank order — also when two ranks share a 64-bit word
+    of the fluid indices (odd counts) and when a rank has nothing."""
+    rng = np.random.default_rng(5)
+    counts = [3, 0, 5, 1]
+    total = sum(counts)
+    parts, acc = [], np.zeros(dist.emitted_table_words(total), np.uint64)
+    for r, k in enumerate(counts):
+        pts = rng.normal(size=(k, 3)).astype(np.float32)
+        pts[:1] *= -1e-30  # (sign bits and tiny exponents survive the integer addition)
+        ids = rng.integers(0, 2 ** 32, size=k, dtype=np.uint64).astype(np.uint32)
+        fl = rng.integers(0, 2 ** 32, size=k, dtype=np.uint64).astype(np.uint32)
+        parts.append((pts, ids, fl))
+        acc = acc + dist.pack_emitted(pts, ids, fl, sum(counts[:r]), total)  # uint64 addition wraps like the device's
+    pts, ids, fl = dist.unpack_emitted(acc, total)
+    assert np.array_equal(pts.view(np.uint32), np.concatenate([p[0] for p in parts]).view(np.uint32))
+    assert np.array_equal(ids, np.concatenate([p[1] for p in parts])) and np.array_equal(fl, np.concatenate([p[2] for p in parts]))
+
+
 def test_selection_rules():
     cx = np.arange(-2, 12)
     slab = (3, 6)
