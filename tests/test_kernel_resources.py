@@ -1,0 +1,63 @@
+"""Register budgets of the kernels a step lives in, checked without a GPU: hipcc cross-compiles dfsph.hip and grid.hip for gfx950
+with `-Rpass-analysis=kernel-resource-usage` (the Makefile's flags) and the remarks are compared with what the residency of
+DESIGN.md §3.2 / §3.3 rests on — three tiles per CU need the plane-layout kernels at <= 80 VGPRs (6 waves per SIMD) without scratch,
+four tiles need k_nbr_tile at <= 64 (8 waves).  A change that pushes one of them over an occupancy step costs 10-15 % of that
+kernel on the hardware and would otherwise only show in the next profile."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "salva_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result", "-ffp-contract=off", "-fno-slp-vectorize",
+         "-I.", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c"]
+
+pytestmark = pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="no hipcc")
+
+
+def resources(source, tmp_path):
+    out = subprocess.run([HIPCC] + FLAGS + [source, "-o", str(tmp_path / (source + ".o"))], cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    table = {}
+    for block in re.split(r"remark: Function Name: ", out.stderr)[1:]:
+        name = block.split(" ")[0]
+
+        def field(key):
+            return int(re.search(key + r": (\d+)", block).group(1))
+
+        table[name] = {"vgprs": field("VGPRs"), "waves": field(r"Occupancy \[waves/SIMD\]"), "scratch": field(r"ScratchSize \[bytes/lane\]"),
+                       "spilled": field("VGPRs Spill")}
+    return table
+
+
+def one(table, fragment):
+    hits = [k for k in table if fragment in k]
+    assert len(hits) == 1, (fragment, hits)
+    return table[hits[0]]
+
+
+def test_solver_kernels_keep_three_tiles_per_cu(tmp_path):
+    t = resources("dfsph.hip", tmp_path)
+    # the plane-layout kernels of the divergence and pressure solves at their three-tile distance (pairs.h P3_DS_THREE / P2_DS_THREE)
+    for fragment in ("k_divergence_p3ILj2080E", "k_pred_density_p3ILj2080E", "k_divergence_apply_p2ILj2464E", "k_pressure_apply_p2ILj2464E"):
+        r = one(t, fragment)
+        assert r["vgprs"] <= 80 and r["waves"] >= 6 and r["scratch"] == 0 and r["spilled"] == 0, (fragment, r)
+    # the density pass of the 32-byte family: 16 bytes per slot, three tiles by registers as well
+    r = one(t, "k_density_alphaILb0E")
+    assert r["vgprs"] <= 80 and r["waves"] >= 6 and r["scratch"] == 0, r
+    # the fused density + alpha + first divergence pass is the one kernel that lives with two tiles: it must not
+    # lose the second one
+    r = one(t, "k_density_alpha_div_p3ILj2080E")
+    assert r["vgprs"] <= 96 and r["waves"] >= 5 and r["scratch"] <= 32, r
+
+
+def test_neighbour_list_kernel_keeps_four_tiles_per_cu(tmp_path):
+    t = resources("grid.hip", tmp_path)
+    r = one(t, "k_nbr_tileILi1E")
+    # (held to 64 VGPRs by its launch bounds: two registers live in scratch, 12 bytes per lane — measured faster than three tiles
+    # without them, profiles/r04_experiments/r04b_*; more than that would be a change worth looking at)
+    assert r["vgprs"] <= 64 and r["waves"] >= 8 and r["scratch"] <= 16 and r["spilled"] <= 2, r
