@@ -40,8 +40,11 @@ using namespace salva;
 // finished sum instead of every boundary term: rounding only.  a_ii (:188-233) is made of own quantities and sums over the same
 // contacts as well — d_ii . G_i - dt^2 m_i / rho_i^2 sum_j m_j |grad W_ij|^2 — and comes out of this pass too (no k_iisph_aii:
 // another 38 us).  Decomposed runs keep the separate passes (a ghost's density is replaced by its owner's in between).
+#ifndef SALVA_DA_IISPH_WAVES
+#define SALVA_DA_IISPH_WAVES 6  // (the IISPH form asks for 84 VGPRs by itself: two tiles per CU; held to 80 = three, two registers in scratch)
+#endif
 template <bool IISPH>
-__global__ __launch_bounds__(TILE_MAX_THREADS) void k_density_alpha(StepCtx c, float dt) {
+__global__ __launch_bounds__(TILE_MAX_THREADS, IISPH ? SALVA_DA_IISPH_WAVES : 1) void k_density_alpha(StepCtx c, float dt) {
     lds_base_check();
     Tile t;
     t.setup(c);
