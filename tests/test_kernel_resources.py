@@ -49,6 +49,9 @@ def test_solver_kernels_keep_three_tiles_per_cu(tmp_path):
     # the density pass of the 32-byte family: 16 bytes per slot, three tiles by registers as well
     r = one(t, "k_density_alphaILb0E")
     assert r["vgprs"] <= 80 and r["waves"] >= 6 and r["scratch"] == 0, r
+    # its IISPH form (d_ii and a_ii ride along) is held to the same step by its launch bounds, two registers in scratch
+    r = one(t, "k_density_alphaILb1E")
+    assert r["vgprs"] <= 80 and r["waves"] >= 6 and r["scratch"] <= 16, r
     # the fused density + alpha + first divergence pass is the one kernel that lives with two tiles: it must not
     # lose the second one
     r = one(t, "k_density_alpha_div_p3ILj2080E")
