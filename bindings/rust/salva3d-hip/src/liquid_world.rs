@@ -367,6 +367,24 @@ impl LiquidWorld {
         check(unsafe { ffi::salva_hip_enable_counters(self.raw, enabled as i32) })
     }
 
+    /// Opt-in CFL sub-stepping: `TimestepManager::max_substep` (timestep_manager.rs:36-46) with the clamp the reference left
+    /// commented out in `compute_substep` (:90-93).  `mode` 0 = off (one substep per step, the reference as it runs), 1 = the
+    /// commented code literally, 2 = the same, cut at the remaining time.  Defaults of `TimestepManager::new`: 0.4, 1, 10.
+    pub fn set_cfl_substepping(&mut self, mode: i32, cfl_coeff: Real, min_num_substeps: i32, max_num_substeps: i32) -> Result<(), Error> {
+        check(unsafe { ffi::salva_hip_set_cfl(self.raw, mode, cfl_coeff, min_num_substeps, max_num_substeps) })
+    }
+
+    /// Substep lengths of the last `step` (`counters.nsubsteps` of them).
+    pub fn substeps(&self) -> Result<Vec<Real>, Error> {
+        let mut v = vec![0.0 as Real; 64];
+        let n = unsafe { ffi::salva_hip_get_substeps(self.raw, v.as_mut_ptr(), v.len() as u64) };
+        if n < 0 {
+            check(n as i32)?;
+        }
+        v.truncate((n as usize).min(64));
+        Ok(v)
+    }
+
     fn refresh_counters(&mut self) -> Result<(), Error> {
         let mut c = std::mem::MaybeUninit::<ffi::SalvaHipCounters>::uninit();
         check(unsafe { ffi::salva_hip_get_counters(self.raw, c.as_mut_ptr()) })?;

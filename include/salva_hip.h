@@ -121,10 +121,12 @@ typedef struct SalvaHipStepStats {
 /* `LiquidWorld::counters` — the reference's `Counters` tree, field for field (counters/mod.rs:17-30,
  * stages_counters.rs:6-11, collision_detection_counters.rs:6-17, solver_counters.rs:6-11), as the testbed plugins read it
  * (testbed_plugin.rs:508-510).  Times are milliseconds like the reference's `Timer::time()` (instant::now() is in ms),
- * measured with HIP events on the world's stream, and only filled when SalvaHipParams::enable_timers is set
+ * measured with HIP events on the world's stream (NaN = an interval that could not be read), and only filled when
+ * SalvaHipParams::enable_timers is set
  * (`Counters::enable`); the counts are always filled.  Filled by salva_hip_step, read with salva_hip_get_counters. */
 typedef struct SalvaHipCounters {
-    uint64_t nsubsteps;                       /* liquid_world.rs:86 — 1 per step (0 for dt <= eps): the reference never sub-steps */
+    uint64_t nsubsteps;                       /* liquid_world.rs:86 — 1 per step (0 for dt <= eps): the reference never sub-steps;
+                                                 more only with salva_hip_set_cfl */
     double step_time;                         /* liquid_world.rs:74,156 */
     double custom;                            /* dfsph_solver.rs:492-501: the divergence solve */
     struct {
@@ -295,6 +297,23 @@ int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out);
  * on.  Off — the reference's default, `Timer::new` (counters/timer.rs:11-18) — a step records no events and the *_ms / *_time
  * fields read 0; on, a step costs ~20 us more of host time (ten event records and their read-out). */
 int salva_hip_enable_counters(SalvaHipWorld* world, int32_t enabled);
+/* Opt-in CFL sub-stepping — SURVEY.md row f4.  The reference's TimestepManager carries cfl_coeff = 0.4 and 1..10 substeps
+ * (timestep_manager.rs:23-34) and `max_substep` (:36-46), but `compute_substep` returns the whole step and leaves the clamp
+ * commented out below a FIXME (:87-94): every `step` is ONE substep.  That stays the default here (mode 0).
+ *   mode 1: the commented code, literally — in every pass of the substep loop (liquid_world.rs:85) the solver's `timestep.advance`
+ *           (dfsph_solver.rs:702, iisph_solver.rs:662) takes
+ *               substep = clamp(particle_radius * 2 / sqrt(max_i |v_i + a_i * remaining_time|^2) * cfl_coeff,
+ *                               dt / max_num_substeps, dt / min_num_substeps)
+ *           (the last substep may step past the end of the step: the commented code does not cut it);
+ *   mode 2: the same, cut at the remaining time.
+ * `counters.nsubsteps` counts the passes, the timers add up over them, the iteration counts and errors of SalvaHipStepStats are
+ * the last pass's.  Plain boundaries accumulate reaction forces over the substeps as the reference's do; a COUPLED boundary that
+ * wants forces is refused (SALVA_HIP_E_INVALID): the reference transmits its impulse per substep, which one wrench per step cannot
+ * carry — run the substeps from the caller instead. */
+int salva_hip_set_cfl(SalvaHipWorld* world, int32_t mode, float cfl_coeff, int32_t min_num_substeps, int32_t max_num_substeps);
+/* Substep lengths of the last salva_hip_step (`TimestepManager::dt` of every pass): writes min(count, capacity) values, returns the
+ * count (= counters.nsubsteps), or a negative error code. */
+int64_t salva_hip_get_substeps(const SalvaHipWorld* world, float* out, uint64_t capacity);
 /* ---- multi-GPU: one process and one world per GPU, the domain cut into slabs of grid-cell planes along x.
  * No counterpart in the reference (single process).  A world owns the particles whose cell x = floor(x / h) lies in
  * [cell_lo, cell_hi] (the first / last rank also keep whatever lies beyond their open end); every step it migrates

@@ -13,6 +13,7 @@
 // positions / velocities / volumes) and refreshes positions / velocities after the step, like the reference whose host
 // arrays are always current.  Panics of the reference (assert!/unwrap) become salva::Error exceptions.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <memory>
@@ -387,6 +388,18 @@ class LiquidWorld {  // liquid_world.rs
     // `world.counters` of the reference (counters/mod.rs:17-72): nsubsteps, step_time, custom, stages, cd, solver
     // Counters::enable / disable (counters/mod.rs:56-72); disabled by default, as in the reference
     void enable_counters(bool enabled = true) { check(salva_hip_enable_counters(w_, enabled ? 1 : 0)); }
+    // Opt-in CFL sub-stepping (timestep_manager.rs:36-46 + the clamp the reference left commented out at :90-93).  0 = off (the
+    // reference as it runs: one substep per step), 1 = the commented code literally, 2 = the same, cut at the remaining time.
+    void set_cfl_substepping(int mode = 1, float cfl_coeff = 0.4f, int min_num_substeps = 1, int max_num_substeps = 10) {
+        check(salva_hip_set_cfl(w_, mode, cfl_coeff, min_num_substeps, max_num_substeps));
+    }
+    std::vector<float> substeps() const {  // substep lengths of the last step
+        std::vector<float> v(64);
+        const int64_t n = salva_hip_get_substeps(w_, v.data(), v.size());
+        if (n < 0) check((int)n);
+        v.resize((size_t)std::min<int64_t>(n, 64));
+        return v;
+    }
     SalvaHipCounters counters_tree() const {
         SalvaHipCounters c{};
         check(salva_hip_get_counters(w_, &c));

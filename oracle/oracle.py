@@ -75,6 +75,9 @@ def lib(native: bool = False):
         L.so_h.restype = f64
         L.so_h.argtypes = [vp]
         L.so_set_timestep.argtypes = [vp, f32, f32]
+        L.so_set_cfl.argtypes = [vp, i32, f32, i32, i32]
+        L.so_get_substeps.restype = i32
+        L.so_get_substeps.argtypes = [vp, C.POINTER(C.c_double), i32]
         L.so_add_fluid.argtypes = [vp, u64, fp, fp, f32, u32, u32]
         L.so_add_boundary.argtypes = [vp, u64, fp, fp, u32, u32, i32]
         L.so_add_force.argtypes = [vp, i32, i32, fp, i32]
@@ -163,6 +166,18 @@ class OracleWorld:
 
     def set_timestep(self, dt: float, inv_dt: float):
         self._L.so_set_timestep(self._h, dt, inv_dt)
+
+    def set_cfl(self, mode: int, cfl_coeff: float = 0.4, min_substeps: int = 1, max_substeps: int = 10):
+        """Opt-in CFL sub-stepping: timestep_manager.rs:36-46 (`max_substep`) with the clamp the reference left commented out at
+        :90-93.  mode 0 = off (the reference as it runs), 1 = the commented code literally (the last substep may overshoot the
+        step), 2 = the same, cut at the end of the step."""
+        self._L.so_set_cfl(self._h, mode, cfl_coeff, min_substeps, max_substeps)
+
+    def substeps(self):
+        """Substep lengths of the last step."""
+        buf = (C.c_double * 64)()
+        n = self._L.so_get_substeps(self._h, buf, 64)
+        return [buf[i] for i in range(min(n, 64))]
 
     def set_kernels(self, density: int, gradient: int):
         """The solvers' KernelDensity / KernelGradient type parameters: 0 CubicSpline (default), 1 Poly6, 2 Spiky, 3 Viscosity."""

@@ -429,6 +429,13 @@ struct World {
     std::vector<ParticleContacts<R>> ff, fb, bb;  // contact_manager.rs:8-15
     // timestep_manager.rs:11-34
     R dt = 0, inv_dt = 0, total_step_size = 0, remaining_time = 0;
+    // timestep_manager.rs:24-26: the CFL parameters of `new`.  cfl_mode 0 = the code as it runs today (compute_substep returns the
+    // whole step, :88); 1 = the clamp the reference left commented out below its FIXME (:90-93), opt-in; 2 = the
+    // same, additionally never stepping past the end of the step (the commented code overshoots: remaining_time goes negative).
+    int cfl_mode = 0;
+    R cfl_coeff = (R)0.4;
+    int min_num_substeps = 1, max_num_substeps = 10;
+    std::vector<double> substeps_of_last_step;
 
     // DFSPH parameters (dfsph_solver.rs:54-70) / IISPH (iisph_solver.rs:48-64)
     int min_pressure_iter = 1, max_pressure_iter = 50;
@@ -1464,8 +1471,26 @@ struct World {
         }
     }
 
+    // timestep_manager.rs:36-46
+    R max_substep() const {
+        R max_sq_vel = 0;
+        for (const auto& f : fluids)
+            for (size_t i = 0; i < f.n(); ++i) {
+                const V3<R> u = f.velocities[i] + f.accelerations[i] * remaining_time;
+                max_sq_vel = std::max(max_sq_vel, u.norm_squared());
+            }
+        return particle_radius * (R)2 / std::sqrt(max_sq_vel) * cfl_coeff;
+    }
     void advance() {  // timestep_manager.rs:76-94
         R substep = total_step_size;
+        if (cfl_mode) {  // the commented body of compute_substep (:90-93); na::clamp(v, lo, hi) = v > hi ? hi : (v < lo ? lo : v)
+            const R min_substep = total_step_size / (R)max_num_substeps;
+            const R max_sub = total_step_size / (R)min_num_substeps;
+            const R computed = max_substep();
+            substep = computed > max_sub ? max_sub : (computed < min_substep ? min_substep : computed);
+            if (cfl_mode == 2 && substep > remaining_time) substep = remaining_time;
+        }
+        substeps_of_last_step.push_back((double)substep);
         dt = substep;
         inv_dt = (substep == (R)0) ? (R)0 : (R)1 / substep;
         remaining_time -= dt;
@@ -1725,6 +1750,7 @@ struct World {
         init_with_fluids();
         for (auto& fl : fluids) fl.apply_particles_removal();  // liquid_world.rs:80-82
         stats = StepStats{};
+        substeps_of_last_step.clear();
         while (!(remaining_time <= Eps<R>::v)) {  // is_done, timestep_manager.rs:56-58
             double ta = now_ms();
             grid.clear();
@@ -1901,6 +1927,19 @@ void so_set_solver_params(void* p, int min_p, int max_p, float max_derr, int min
 void so_set_timestep(void* p, float dt, float inv_dt) {
     Handle* h = (Handle*)p;
     DISPATCH(h, { w.dt = dt; w.inv_dt = inv_dt; }, { w.dt = dt; w.inv_dt = inv_dt; });
+}
+// opt-in CFL sub-stepping (timestep_manager.rs:36-46 + the commented clamp :90-93); mode 0 restores the reference's running behaviour
+void so_set_cfl(void* p, int mode, float cfl_coeff, int min_substeps, int max_substeps) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, { w.cfl_mode = mode; w.cfl_coeff = cfl_coeff; w.min_num_substeps = min_substeps; w.max_num_substeps = max_substeps; },
+                { w.cfl_mode = mode; w.cfl_coeff = (double)cfl_coeff; w.min_num_substeps = min_substeps; w.max_num_substeps = max_substeps; });
+}
+// the substep lengths of the last step (counters.nsubsteps of them); returns their number
+int so_get_substeps(void* p, double* out, int cap) {
+    Handle* h = (Handle*)p; int n = 0;
+    DISPATCH(h, { n = (int)w.substeps_of_last_step.size(); for (int i = 0; i < n && i < cap; ++i) out[i] = w.substeps_of_last_step[i]; },
+                { n = (int)w.substeps_of_last_step.size(); for (int i = 0; i < n && i < cap; ++i) out[i] = w.substeps_of_last_step[i]; });
+    return n;
 }
 double so_h(void* p) { Handle* h = (Handle*)p; double r = 0; DISPATCH(h, r = w.h, r = w.h); return r; }
 

@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_delete_owned", "salva_hip_enable_counters", "salva_hip_comm_peer_begin", "salva_hip_comm_peer_connect",
     "salva_hip_comm_peer_abort", "salva_hip_comm_selftest", "salva_hip_comm_time", "salva_hip_clear_boundary_sampling", "salva_hip_get_fluid_async", "salva_hip_wait_download",
     "salva_hip_host_alloc", "salva_hip_host_free", "salva_hip_host_register", "salva_hip_host_unregister",
+    "salva_hip_set_cfl", "salva_hip_get_substeps",
     "salva_hip_get_dist_timing", "salva_hip_local_len", "salva_hip_get_local", "salva_hip_get_local_contacts", "salva_hip_force_add_local_accelerations",
 ]
 
@@ -223,6 +224,9 @@ def lib():
     L.salva_hip_time_kernel.argtypes = [vp, i32, i32]
     L.salva_hip_time_kernel.restype = f32
     L.salva_hip_get_counters.argtypes = [vp, C.POINTER(CountersStruct)]
+    L.salva_hip_set_cfl.argtypes = [vp, i32, C.c_float, i32, i32]
+    L.salva_hip_get_substeps.restype = C.c_int64
+    L.salva_hip_get_substeps.argtypes = [vp, C.POINTER(C.c_float), u64]
     L.salva_hip_enable_counters.argtypes = [vp, i32]
     if hasattr(L, "salva_hip_time_variant"):  # the kernel-development build only (SALVA_HIP_LIB_VARIANT=diag)
         L.salva_hip_time_variant.argtypes = [vp, i32, u32, i32, C.POINTER(u64)]

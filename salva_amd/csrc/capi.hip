@@ -405,6 +405,24 @@ int salva_hip_enable_counters(SalvaHipWorld* world, int32_t enabled) {
         return SALVA_HIP_OK;
     });
 }
+int salva_hip_set_cfl(SalvaHipWorld* world, int32_t mode, float cfl_coeff, int32_t min_num_substeps, int32_t max_num_substeps) {
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        world->w->set_cfl(mode, cfl_coeff, min_num_substeps, max_num_substeps);
+        return SALVA_HIP_OK;
+    });
+}
+int64_t salva_hip_get_substeps(const SalvaHipWorld* world, float* out, uint64_t capacity) {
+    int64_t n = 0;
+    int rc = guarded([&]() -> int {
+        if (!world || (!out && capacity)) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        const auto& v = world->w->last_substeps();
+        for (size_t k = 0; k < v.size() && k < capacity; ++k) out[k] = v[k];
+        n = (int64_t)v.size();
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? n : (int64_t)rc;
+}
 int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out) {
     return guarded([&]() -> int {
         if (!world || !out) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");

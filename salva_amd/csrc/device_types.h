@@ -186,7 +186,8 @@ struct Readback {
     uint64_t ncontacts_bb;
     uint64_t ncontacts_ff, ncontacts_fb;   // } written by k_list_stats and read back in one copy
     uint32_t max_cnt_ff, max_cnt_fb;       // } longest contact lists of the step (capacity check)
-    uint32_t dcs_count, pad_;          // points emitted by the last DynamicContactSampling pass
+    uint32_t dcs_count;                // points emitted by the last DynamicContactSampling pass
+    uint32_t cfl_max_bits;             // bits of max |v + a t|^2 over the fluid particles (World::choose_substep, opt-in CFL sub-stepping)
     uint64_t ncontacts_own_ff, ncontacts_own_fb;  // list totals over the particles this rank owns (decomposed runs)
     uint32_t mass_mm[2];  // [0] = bits of particle 0's mass, [1] = the same if no particle's mass differed since the last publication
                           // of the totals (host side of the publication only; on the device: World::mass_slots, grid.hip k_cell_keys)

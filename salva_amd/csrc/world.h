@@ -102,6 +102,8 @@ class World {
     // particles follow in the next step's migration.  Returns this rank's new [lo, hi].
     void rebalance(int32_t* new_lo, int32_t* new_hi);
     void set_timers(bool on) { prm.enable_timers = on ? 1 : 0; }
+    void set_cfl(int mode, float coeff, int min_sub, int max_sub);
+    const std::vector<float>& last_substeps() const { return substeps; }
     uint64_t get_owned(uint32_t cap, uint32_t* gids, float* pos, float* vel, uint32_t* models);
     uint64_t delete_owned(uint32_t n_ids, const uint32_t* gids);
     uint32_t owned_count() const { return comm ? n_owned : n; }
@@ -141,7 +143,8 @@ class World {
     DevBuf<uint32_t> dcs_num;
     // decomposed run: every rank's emitted points, in rank order (dist_gather_emitted): rows, then one uint32 fluid per row
     DevBuf<unsigned long long> dcs_all;
-    uint32_t dist_gather_emitted(const float4* rows, uint32_t cnt, const float4** all_rows, const uint32_t** all_models);
+    uint32_t dist_gather_emitted(const float4* rows, uint32_t cnt, const float4** all_rows, const uint32_t** all_models,
+                                 const HipError* local_error = nullptr);
     void ensure_cub_temp(size_t bytes);
     StepCtx make_ctx();
     struct SolveResult { uint32_t iters; float err; };
@@ -153,8 +156,17 @@ class World {
     bool spec_apply_off = false;  // SALVA_HIP_NO_SPEC_APPLY (A/B, tests)
     void wait_stream();  // low-latency wait for the world's stream (spins on an event)
     void run_forces(const StepCtx& c);
-    void dfsph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
-    void iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st);
+    void dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepStats& st);  // dt: in = the step, out = the substep advanced by
+    void iisph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepStats& st);
+    int substep(float& dt, const float g[3], SalvaHipStepStats& st);  // one pass of the reference's substep loop (liquid_world.rs:85-147)
+    // Opt-in CFL sub-stepping (salva_hip_set_cfl): TimestepManager's cfl_coeff / min / max_num_substeps (timestep_manager.rs:23-34)
+    // and the clamp its compute_substep left commented out (:90-93).  0 = off: one substep per step, as the reference runs.
+    int cfl_mode = 0;
+    float cfl_coeff = 0.4f;
+    int cfl_min_sub = 1, cfl_max_sub = 10;
+    float step_total = 0.0f, step_remaining = 0.0f;  // TimestepManager::{total_step_size, remaining_time} of the running step
+    std::vector<float> substeps;                     // substep lengths of the last step (salva_hip_get_substeps)
+    float choose_substep(const StepCtx& c);
     FluidArrays arrays(int which);
     DistArrays dist_arrays(int which);
     void dist_prepare();        // migration + ghost planes, before the grid is built

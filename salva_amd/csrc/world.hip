@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <limits>
 
 #include <mutex>
 #include <unordered_map>
@@ -990,8 +991,64 @@ void World::evaluate_split(const StepCtx& c, int iteration, Launch&& launch) {
     SALVA_HIP_CHECK(hipStreamWaitEvent(stream, ev_interior, 0));
 }
 
+void World::set_cfl(int mode, float coeff, int min_sub, int max_sub) {
+    if (mode < 0 || mode > 2) throw HipError(SALVA_HIP_E_INVALID, "cfl mode must be 0 (off), 1 (the reference's commented clamp) or 2 (the same, cut at the end of the step)");
+    if (mode && (!(coeff > 0.0f) || !std::isfinite(coeff))) throw HipError(SALVA_HIP_E_INVALID, "cfl_coeff must be positive");
+    if (mode && (min_sub < 1 || max_sub < min_sub)) throw HipError(SALVA_HIP_E_INVALID, "need 1 <= min_num_substeps <= max_num_substeps");
+    cfl_mode = mode; cfl_coeff = coeff; cfl_min_sub = min_sub; cfl_max_sub = max_sub;
+}
+// TimestepManager::max_substep (timestep_manager.rs:36-46) + the body of compute_substep the reference left commented out (:90-93):
+//   max_sq_vel = max over all fluid particles of |v + a * remaining_time|^2        (f32::max ignores a NaN operand)
+//   computed   = particle_radius * 2 / sqrt(max_sq_vel) * cfl_coeff
+//   substep    = clamp(computed, total / max_num_substeps, total / min_num_substeps)
+// The maximum is order-independent and |.|^2 is evaluated as the reference does ((x x + y y) + z z, no contraction: the library is
+// compiled -ffp-contract=off), so the substep is bit for bit the CPU's for the same v and a.  Non-negative floats order like
+// their bit patterns: one atomicMax per wave.
+__global__ __launch_bounds__(BLOCK) void k_cfl_max(uint32_t n, const float4* __restrict__ vel, const float4* __restrict__ acc,
+                                                   const uint32_t* __restrict__ gtag, float remaining, uint32_t* __restrict__ out_bits) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t bits = 0u;
+    if (i < n && !(gtag && (gtag[i] & 0x80000000u))) {  // (a ghost is its owner's to report)
+        const float4 v = vel[i], a = acc[i];
+        const float ux = v.x + a.x * remaining, uy = v.y + a.y * remaining, uz = v.z + a.z * remaining;
+        const float sq = (ux * ux + uy * uy) + uz * uz;
+        if (sq == sq) bits = __float_as_uint(sq);
+    }
+    bits = wave_max_u32(bits);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && bits) atomicMax(out_bits, bits);
+}
+float World::choose_substep(const StepCtx& c) {
+    uint32_t* const d_bits = &d_rb.p->cfl_max_bits;
+    SALVA_HIP_CHECK(hipMemsetAsync(d_bits, 0, sizeof(uint32_t), stream));
+    if (n) k_cfl_max<<<nblk(n), BLOCK, 0, stream>>>(n, c.vel, c.acc, comm ? gtag[cur].p : nullptr, step_remaining, d_bits);
+    SALVA_HIP_CHECK(hipGetLastError());
+    float max_sq = 0.0f;
+    if (comm && comm->size() > 1) {
+        // max over the ranks through the sum all-reduce: every rank writes its value into its own slot of a zeroed row (x + 0 = x)
+        const int size = comm->size();
+        d_sums.ensure((size_t)std::max(size, 8));
+        SALVA_HIP_CHECK(hipMemsetAsync(d_sums.p, 0, (size_t)size * sizeof(float), stream));
+        SALVA_HIP_CHECK(hipMemcpyAsync(d_sums.p + comm->rank(), d_bits, sizeof(float), hipMemcpyDeviceToDevice, stream));
+        comm->allreduce_sum_f32(d_sums.p, size, stream);
+        std::vector<float> all((size_t)size, 0.0f);
+        SALVA_HIP_CHECK(hipMemcpyAsync(all.data(), d_sums.p, (size_t)size * sizeof(float), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        for (float v : all) max_sq = std::max(max_sq, v);
+    } else {
+        SALVA_HIP_CHECK(hipMemcpyAsync(&h_rb->cfl_max_bits, d_bits, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        wait_stream();
+        memcpy(&max_sq, &h_rb->cfl_max_bits, sizeof(float));
+    }
+    const float total = step_total;
+    const float min_substep = total / (float)cfl_max_sub, max_substep = total / (float)cfl_min_sub;
+    const float computed = prm.particle_radius * 2.0f / std::sqrt(max_sq) * cfl_coeff;
+    float sub = computed > max_substep ? max_substep : (computed < min_substep ? min_substep : computed);  // na::clamp
+    if (cfl_mode == 2 && sub > step_remaining) sub = step_remaining;
+    return sub;
+}
+
 // DFSPHSolver::step (dfsph_solver.rs:667-708)
-void World::dfsph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
+void World::dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepStats& st) {
     // divergence_solve (:466-503).  NOTE the dt lag: inv_dt is still the previous step's here (0 on the first step).
     const float inv_dt_lag = inv_dt_prev;
     const bool timers = prm.enable_timers != 0;
@@ -1023,7 +1080,8 @@ void World::dfsph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStat
     st.divergence_error = rd.err;
     launch_finish_divergence(c, g[0], g[1], g[2], acc_user, stream);  // update_velocities + dv = 0 + gravity
     run_forces(c);
-    // timestep.advance (:702): dt := total step, inv_dt := 1/dt
+    // timestep.advance (:702): dt := total step (or, opted in, the CFL substep), inv_dt := 1/dt
+    if (cfl_mode) dt = choose_substep(c);
     const float inv_dt = (dt == 0.0f) ? 0.0f : 1.0f / dt;
     launch_integrate(c, dt, stream);
     if (comm) refresh_f4(w.p);
@@ -1043,11 +1101,12 @@ void World::dfsph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStat
 }
 
 // IISPHSolver::step (iisph_solver.rs:643-711)
-void World::iisph_solve(StepCtx& c, float dt, const float g[3], SalvaHipStepStats& st) {
+void World::iisph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepStats& st) {
     st.n_divergence_iters = 0;
     st.divergence_error = 0.0f;
     launch_iisph_begin(c, g[0], g[1], g[2], acc_user, stream);
     run_forces(c);  // forces still see the previous inv_dt (:654-662)
+    if (cfl_mode) dt = choose_substep(c);  // timestep.advance (:662)
     const float inv_dt = (dt == 0.0f) ? 0.0f : 1.0f / dt;
     launch_integrate(c, dt, stream);
     if (comm) refresh_f4(w.p);             // a ghost's own forces were summed over an incomplete neighbourhood
@@ -1097,6 +1156,44 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     if (comm && acc_user)
         throw HipError(SALVA_HIP_E_INVALID, "host-set accelerations (SALVA_HIP_DIRTY_ACCELERATIONS) are not carried through the slab decomposition: "
                                             "apply them as velocity changes, or use a single domain");
+    // `while !self.timestep_manager.is_done()` (liquid_world.rs:85): one substep of the whole step as the reference runs today
+    // (compute_substep returns total_step_size, timestep_manager.rs:88); with salva_hip_set_cfl the clamp the reference left
+    // commented out (:90-93) decides each substep's length inside the solver (`timestep.advance`, dfsph_solver.rs:702).
+    substeps.clear();
+    step_total = dt;
+    step_remaining = dt;
+    if (cfl_mode) {
+        upload_tables();  // (any_wants_forces)
+        if (any_wants_forces)
+            for (const BoundarySlot& b : bounds)
+                if (b.wants_forces && (b.sampling || b.dyn_kind))
+                    // the reference clears a coupled boundary's forces and transmits their impulse in EVERY substep with that substep's
+                    // dt (fluids_pipeline.rs:262, :266-287): one wrench per step() cannot carry that.  The caller's own loop can.
+                    throw HipError(SALVA_HIP_E_INVALID, "CFL sub-stepping with a coupled boundary that wants forces: run the substeps from the caller "
+                                                        "(update_boundaries / step / transmit_forces per substep), or switch salva_hip_set_cfl off");
+    }
+    while (!(step_remaining <= FLT_EPSILON)) {  // is_done, timestep_manager.rs:56-58
+        float used = dt;
+        int rc;
+        try {
+            rc = substep(used, g, st);
+        } catch (...) {
+            if (stats) *stats = st;  // (what the failed substep got to: the caller's report is filled either way)
+            throw;
+        }
+        substeps.push_back(used);
+        step_remaining -= used;  // advance, :84
+        ++counters.nsubsteps;
+        if (rc != SALVA_HIP_OK) { if (stats) *stats = st; return rc; }
+        if (substeps.size() > 4096) throw HipError(SALVA_HIP_E_INVALID, "internal error: the substep loop does not terminate");
+    }
+    if (stats) *stats = st;
+    return SALVA_HIP_OK;
+}
+
+// One substep: the body of the `while` of LiquidWorld::step_with_coupling (liquid_world.rs:85-147).  `dt` comes in as the step's
+// total length and goes out as the substep the solver advanced by.
+int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     const bool timers = prm.enable_timers != 0;
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
     upload_tables();
@@ -1382,7 +1479,8 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     // (DFSPH: the first evaluate of the divergence solve rides in the density pass when the plane layout applies, dfsph.hip)
     fused_first_divergence = prm.solver == SALVA_HIP_SOLVER_DFSPH && !no_fused_div && launch_density_alpha_div(c, lds, stream);
     // (single-domain IISPH: d_ii rides in the density pass, dfsph.hip k_density_alpha<true>)
-    iisph_dii_fused = prm.solver == SALVA_HIP_SOLVER_IISPH && !comm && !no_fused_div;
+    // (not with CFL sub-stepping: d_ii carries dt^2, and the substep is only chosen inside the solver)
+    iisph_dii_fused = prm.solver == SALVA_HIP_SOLVER_IISPH && !comm && !no_fused_div && !cfl_mode;
     if (!fused_first_divergence) launch_density_alpha(c, lds, iisph_dii_fused ? dt : 0.0f, stream);
     if (comm) {
         refresh_f32(rho.p);
@@ -1440,30 +1538,40 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     st.ncontacts = comm ? h_rb->ncontacts_own_ff + (nb ? h_rb->ncontacts_own_fb : 0) + ncontacts_bb
                         : h_rb->ncontacts_ff + (nb ? h_rb->ncontacts_fb : 0) + ncontacts_bb;
     bbox_known = true;
-    last_ctx = c; last_ctx.ctl = nullptr; last_dt = dt; have_last_ctx = true;
+    last_ctx = c; last_ctx.ctl = nullptr; last_dt = dt; have_last_ctx = true;  // (dt: the substep the solver advanced by)
     if (timers) {
-        float a = 0, b = 0;
-        (void)hipEventElapsedTime(&a, ev[0], ev[1]);
-        (void)hipEventElapsedTime(&b, ev[1], ev[2]);
-        st.grid_ms = a; st.solver_ms = b; st.step_ms = a + b;
-        // the reference's tree (liquid_world.rs:73-156); every interval is taken on the world's stream
-        auto ms = [&](hipEvent_t from, hipEvent_t to) { float t = 0; (void)hipEventElapsedTime(&t, from, to); return (double)t; };
-        counters.step_time = a + b;
-        counters.stages.collision_detection_time = a;
-        counters.stages.solver_time = b;
-        counters.cd.boundary_update_time = dcs_ms;  // DynamicContactSampling runs inside the step (liquid_world.rs:94-103)
-        counters.cd.grid_insertion_time = std::max(0.0, (double)ms(ev[0], evc[1]) - dcs_ms);
-        counters.cd.neighborhood_search_time = ms(evc[1], ev[1]);
-        counters.solver.pressure_resolution_time = ms(evc[2], ev[2]);
-        if (prm.solver == SALVA_HIP_SOLVER_DFSPH) counters.custom = ms(evc[3], evc[4]);
+        // ev[2] was recorded before the end-of-step publication, whose arrival the host has seen through host-mapped memory — which
+        // says nothing about the EVENT's completion signal: without the synchronisation hipEventElapsedTime can still answer
+        // hipErrorNotReady (it did, on a fresh box: VERDICT r04).  Every other event of the step precedes ev[2] on the stream.
+        // An interval that cannot be read is reported as NaN ("untimed"), never as 0.
+        const double untimed = std::numeric_limits<double>::quiet_NaN();
+        bool ok = hipEventSynchronize(ev[2]) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        auto ms = [&](hipEvent_t from, hipEvent_t to) -> double {
+            float t = 0.0f;
+            if (!ok) return untimed;
+            if (hipEventElapsedTime(&t, from, to) != hipSuccess) { (void)hipGetLastError(); return untimed; }
+            return (double)t;
+        };
+        const double a = ms(ev[0], ev[1]), b = ms(ev[1], ev[2]);
+        // the reference's tree (liquid_world.rs:73-156); every interval is taken on the world's stream.  The timers are resumed and
+        // paused in every substep (:88-147): they add up over the substeps of a step.
+        st.grid_ms += (float)a; st.solver_ms += (float)b; st.step_ms += (float)(a + b);
+        counters.step_time += a + b;
+        counters.stages.collision_detection_time += a;
+        counters.stages.solver_time += b;
+        counters.cd.boundary_update_time += dcs_ms;  // DynamicContactSampling runs inside the step (liquid_world.rs:94-103)
+        const double gi = ms(ev[0], evc[1]);
+        counters.cd.grid_insertion_time += std::isnan(gi) ? gi : std::max(0.0, gi - dcs_ms);
+        counters.cd.neighborhood_search_time += ms(evc[1], ev[1]);
+        counters.solver.pressure_resolution_time += ms(evc[2], ev[2]);
+        if (prm.solver == SALVA_HIP_SOLVER_DFSPH) counters.custom += ms(evc[3], evc[4]);
     }
-    counters.nsubsteps = 1;
     counters.cd.ncontacts = st.ncontacts;
     counters.n_divergence_iters = st.n_divergence_iters; counters.n_pressure_iters = st.n_pressure_iters;
     st.reserved[0] = (float)lds.max_halo_fluid; st.reserved[1] = (float)lds.max_halo_boundary; st.reserved[2] = (float)lds.threads;
     st.reserved[3] = (float)((double)(h_rb->ncontacts_ff + (nb ? h_rb->ncontacts_fb : 0)) / (double)std::max<uint32_t>(n, 1u));  // list entries per local particle
     st.reserved[4] = (float)(n - owned_count());  // ghosts
-    if (stats) *stats = st;
     if (h_rb->flags & 1u) {
         bbox_known = false;
         throw HipError(SALVA_HIP_E_NUMERIC, "zero density / boundary denominator or NaN detected (the reference would panic)");
@@ -1676,6 +1784,7 @@ uint64_t World::get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offset
     SALVA_HIP_CHECK(hipMemcpyAsync(d_offs.p, offs.data(), (nn + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(d_moff.p, moff.data(), moff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(d_boff.p, boff.data(), boff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    flags_clean = false;
     launch_export_contacts(last_ctx, keys[1].p, slot, boundary, d_offs.p, d_moff.p, d_boff.p, d_jm.p, d_j.p, stream);
     SALVA_HIP_CHECK(hipMemcpyAsync(j_model, d_jm.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(j, d_j.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1738,6 +1847,7 @@ uint64_t World::get_local_contacts(int boundary, uint64_t* offsets, uint32_t* j_
     d_offs.ensure((size_t)n + 1); d_boff.ensure(boff.size()); d_jm.ensure(total); d_j.ensure(total);
     SALVA_HIP_CHECK(hipMemcpyAsync(d_offs.p, offs.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(d_boff.p, boff.data(), boff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    flags_clean = false;
     launch_export_contacts_local(last_ctx, keys[1].p, boundary, d_offs.p, d_boff.p, d_jm.p, d_j.p, stream);
     SALVA_HIP_CHECK(hipMemcpyAsync(j_model, d_jm.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(j, d_j.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -2091,6 +2201,9 @@ void World::clear_boundary_sampling(uint32_t slot) {
     b.dyn_shape = SalvaHipShape{};
     b.dyn_host = SalvaHipHostShape{};
     b.dyn_src.reset(); b.dyn_src_model.reset();
+    // the particles keep the velocities k_boundary_pose / k_dcs_emit wrote for the moving collider (the reference keeps them after
+    // unregister_coupling too): from now on make_ctx must not take the upload's "at rest" for them
+    if (b.n) b.vel_zero = false;
 }
 
 // parameters of a built-in collider shape (include/salva_hip.h); throws for any other kind
@@ -2147,6 +2260,11 @@ void World::run_dynamic_sampling() {
         if (!b.dyn_kind) continue;
         uint32_t cnt = 0;
         const float4* emit_src = nullptr;  // the compacted (projection, source particle) rows
+        // (decomposed run: a failure of the rank-local part must not leave the other ranks waiting in the collective below —
+        // it is parked and travels with the counts, dist_gather_emitted)
+        HipError local_error(SALVA_HIP_E_INVALID, "");
+        bool local_failed = false;
+        try {
         if (n && b.dyn_kind == SALVA_HIP_SHAPE_HOST) {
             // the host's shape: box tests on the device, the projections on the host, the rest of the loop body on the device
             float mins[3], maxs[3];
@@ -2196,6 +2314,13 @@ void World::run_dynamic_sampling() {
             cnt = h_rb->dcs_count;
             emit_src = dcs_out.p;
         }
+        } catch (const HipError& e) {
+            if (!comm) throw;
+            local_failed = true; local_error = e; cnt = 0; emit_src = nullptr;
+        } catch (const std::exception& e) {
+            if (!comm) throw;
+            local_failed = true; local_error = HipError(SALVA_HIP_E_INVALID, e.what()); cnt = 0; emit_src = nullptr;
+        }
         // Decomposed run: each rank has emitted for the particles it OWNS; every rank then holds every rank's points (a collider's
         // contact layer: thousands of rows), so a boundary particle near a slab face has its whole boundary neighbourhood — its
         // volume — and acts on the fluid of both slabs, wherever its source particle lives.  (Mirroring more ghost planes instead
@@ -2203,7 +2328,7 @@ void World::run_dynamic_sampling() {
         // from its source.)  Each rank's force accumulator receives what its own fluid exerts: the rows are the same on every
         // rank, the per-rank forces add up.
         const uint32_t* emit_models = nullptr;
-        if (comm) cnt = dist_gather_emitted(emit_src, cnt, &emit_src, &emit_models);
+        if (comm) cnt = dist_gather_emitted(emit_src, cnt, &emit_src, &emit_models, local_failed ? &local_error : nullptr);
         resize_boundary_slot(slot, cnt);
         b_dirty = true;  // same count, new positions
         if (cnt) {
@@ -2387,6 +2512,7 @@ float World::time_pred_density(int reps) {
 #ifdef SALVA_HIP_DIAG
     if (getenv("SALVA_HIP_TILE_TIMING")) tile_timing_report();
 #endif
+    flags_clean = false;  // (a between-step launch may raise an error flag: the next step clears them itself — ADVICE r04)
     launch_pred_density(last_ctx, lds, last_dt, stream);  // warm-up
     SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
     for (int r = 0; r < reps; ++r) launch_pred_density(last_ctx, lds, last_dt, stream);
@@ -2411,6 +2537,7 @@ float World::time_kernel(int kernel, int reps) {
     if (kernel == 1 && iisph) throw HipError(SALVA_HIP_E_INVALID, "k_divergence needs a DFSPH world");
     StepCtx cd = last_ctx;
     cd.ctl = nullptr;
+    flags_clean = false;  // (see time_pred_density)
     if (kernel == 6) {  // the apply pass updates w in place: let it run on a copy (w2 is free outside a speculative solve)
         if (iisph) throw HipError(SALVA_HIP_E_INVALID, "k_divergence_apply needs a DFSPH world");
         w2.ensure(n, stream, false, 1.1f);

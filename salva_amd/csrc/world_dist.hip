@@ -261,17 +261,26 @@ void World::dist_prepare() {
 // zeroed table and the sections are added as 64-bit integers — x + 0 is exact on the bit patterns, and the 32-bit fluid words of
 // two ranks that share a 64-bit word cannot carry into each other.  Two all-reduces (counts, rows) per sampled collider and
 // step; collective — every rank registers the same dynamically sampled boundaries in the same slots.
-uint32_t World::dist_gather_emitted(const float4* rows, uint32_t cnt, const float4** all_rows, const uint32_t** all_models) {
+uint32_t World::dist_gather_emitted(const float4* rows, uint32_t cnt, const float4** all_rows, const uint32_t** all_models,
+                                    const HipError* local_error) {
     const int size = comm->size(), rank = comm->rank();
-    std::vector<unsigned long long> counts((size_t)size, 0ull);
-    counts[rank] = cnt;
+    // counts[size] = number of ranks whose local part of the pass failed (a NaN box from the host's aabb callback, an allocation
+    // failure ...): it rides in the count all-reduce, so that every rank leaves the step together instead of one rank throwing
+    // while the others wait in the collective (same pattern as dist_add_particles)
+    std::vector<unsigned long long> counts((size_t)size + 1, 0ull);
+    counts[rank] = local_error ? 0ull : cnt;
+    counts[size] = local_error ? 1ull : 0ull;
     if (size > 1) {
-        plane_hist.ensure(std::max<size_t>((size_t)size, 64));
+        plane_hist.ensure(std::max<size_t>((size_t)size + 1, 64));
         SALVA_HIP_CHECK(hipMemcpyAsync(plane_hist.p, counts.data(), counts.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
-        comm->allreduce_sum_u64(plane_hist.p, size, stream);
+        comm->allreduce_sum_u64(plane_hist.p, size + 1, stream);
         SALVA_HIP_CHECK(hipMemcpyAsync(counts.data(), plane_hist.p, counts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         SALVA_HIP_CHECK(hipStreamSynchronize(stream));
     }
+    if (local_error) throw *local_error;
+    if (counts[size])
+        throw HipError(SALVA_HIP_E_INVALID, "dynamic contact sampling failed on another rank of the decomposed world (its own error says why); "
+                                            "every rank leaves the step");
     unsigned long long total = 0, before = 0;
     for (int r = 0; r < size; ++r) { if (r < rank) before += counts[r]; total += counts[r]; }
     if (total >= 0x3fffffffull) throw HipError(SALVA_HIP_E_CAPACITY, "too many dynamically sampled boundary particles");

@@ -1116,6 +1116,21 @@ class LiquidWorld:
         t = np.asarray(st["timestep"], F32)
         L.check(self._L.salva_hip_set_timestep(self._h, float(t[0]), float(t[1])))
 
+    # ---- opt-in CFL sub-stepping (timestep_manager.rs:36-46 + the clamp left commented out at :90-93)
+    def set_cfl_substepping(self, mode: int = 1, cfl_coeff: float = 0.4, min_num_substeps: int = 1, max_num_substeps: int = 10):
+        """mode 0: off — one substep per step, the reference as it runs (`compute_substep` returns the whole step).  mode 1: the
+        reference's commented clamp, literally (the last substep may overshoot the step).  mode 2: the same, cut at the remaining
+        time.  The defaults are `TimestepManager::new`'s (timestep_manager.rs:23-34)."""
+        L.check(self._L.salva_hip_set_cfl(self._h, int(mode), float(cfl_coeff), int(min_num_substeps), int(max_num_substeps)))
+
+    def substeps(self):
+        """Substep lengths of the last step (`counters.nsubsteps` of them)."""
+        buf = (C.c_float * 64)()
+        n = self._L.salva_hip_get_substeps(self._h, buf, 64)
+        if n < 0:
+            L.check(int(n))
+        return [float(buf[i]) for i in range(min(int(n), 64))]
+
     def step_with_coupling(self, dt: float, gravity, coupling) -> L.StepStats:
         """LiquidWorld::step_with_coupling (liquid_world.rs:67-158) for a `salva_amd.coupling.ColliderCouplingSet`:
         update_boundaries -> the substep -> transmit_forces."""

@@ -166,3 +166,45 @@ def test_cpp_mirror_coupling_example():
     assert min(vy) < -0.2                   # ... picked up speed ...
     assert abs(vy[-1]) < 0.25               # ... and was stopped by the water, not by the floor
     assert 0.15 < y[-1] < surface + 0.1 and float(rows[-1][5]) < surface
+
+
+def test_unregistered_moving_collider_keeps_its_velocities():
+    """`unregister_coupling` (fluids_pipeline.rs:116-125) leaves the boundary in the world with the particles — and the
+    VELOCITIES — the last pose gave it.  The library used to keep the upload's "at rest" mark for such a boundary and then skipped its
+    velocities in the predicted-density pass (StepCtx::bvel_zero).  A world whose paddle was detached must step exactly like a world
+    that was handed the same particles and velocities as a plain boundary."""
+    pos, vel, _, paddle_pts, _, _, paddle = _scene()
+    pos = pos.copy(); pos[:, 1] -= np.float32(3 * R)  # the block sits on the blade: every step has fluid-boundary contacts
+
+    def world():
+        w = LiquidWorld(DFSPHSolver(), R, 2.0)
+        fl = Fluid(pos, R, 1000.0)
+        fl.velocities = vel
+        fl.nonpressure_forces.append(XSPHViscosity(0.5, 0.5))
+        return w, w.add_fluid(fl)
+
+    w1, f1 = world()
+    b1 = w1.add_boundary(Boundary(np.zeros((0, 3), np.float32)))
+    coupling = ColliderCouplingSet()
+    coupling.register_coupling(b1, "paddle", copy.deepcopy(paddle), StaticSampling(paddle_pts))
+    w1.sync_to_device()
+    coupling.update_boundaries(w1)
+    assert coupling.unregister_coupling("paddle") is b1
+    bpos, bvel = b1.positions.copy(), b1.velocities.copy()
+    assert np.abs(bvel).max() > 0.1  # the blade spins
+
+    w2, f2 = world()
+    plain = Boundary(bpos)
+    plain.velocities = bvel
+    w2.add_boundary(plain)
+    for _ in range(6):
+        s1 = w1.step(DT, GRAVITY)
+        s2 = w2.step(DT, GRAVITY)
+        assert (s1.ncontacts, s1.n_divergence_iters, s1.n_pressure_iters) == (s2.ncontacts, s2.n_divergence_iters, s2.n_pressure_iters)
+    assert np.array_equal(f1.positions, f2.positions) and np.array_equal(f1.velocities, f2.velocities)
+    # ... and the velocities matter in this scene: the same blade at rest gives another trajectory
+    w3, f3 = world()
+    w3.add_boundary(Boundary(bpos))
+    for _ in range(6):
+        w3.step(DT, GRAVITY)
+    assert np.abs(f3.velocities - f2.velocities).max() > 1e-4

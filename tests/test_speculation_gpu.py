@@ -141,5 +141,18 @@ def test_counters_tree_is_filled_like_the_reference():
     assert 0 < c.cd.neighborhood_search_time < c.stages.collision_detection_time
     assert 0 < c.custom < c.solver.pressure_resolution_time <= c.stages.solver_time
     assert c.cd.boundary_update_time == 0 and c.cd.contact_sorting_time == 0 and c.solver.non_pressure_resolution_time == 0
+    # The invariants of the tree over 50 consecutive timed steps: a timer read-out that races the event's completion (r04: ev[2] was
+    # read right after a host-mapped publication, without synchronising the event; on a fresh box the read failed and solver_time
+    # stayed 0 while pressure_resolution_time, read two lines later, was there) cannot hide behind one lucky step.
+    import math
+    for k in range(50):
+        st = w.step(DT, GRAVITY)
+        c = w.counters
+        vals = (c.step_time, c.stages.collision_detection_time, c.stages.solver_time, c.cd.grid_insertion_time,
+                c.cd.neighborhood_search_time, c.solver.pressure_resolution_time, c.custom)
+        assert all(math.isfinite(v) and v > 0 for v in vals), (k, vals)  # (an unreadable interval would be NaN, never 0)
+        assert c.custom < c.solver.pressure_resolution_time <= c.stages.solver_time <= c.step_time, (k, vals)
+        assert c.cd.grid_insertion_time + c.cd.neighborhood_search_time <= c.stages.collision_detection_time * (1 + 1e-3) + 1e-6, (k, vals)
+        assert abs(st.grid_ms + st.solver_ms - st.step_ms) <= 1e-3 * st.step_ms + 1e-6 and st.solver_ms > 0
     st = w.step(1e-9, GRAVITY)  # dt <= eps: no substep at all (timestep_manager.rs:56-58)
     assert w.counters.nsubsteps == 0 and st.ncontacts == 0
