@@ -244,6 +244,10 @@ def main():
                     help="BASELINE configuration (SURVEY.md §8d): 2 DFSPH + XSPH (headline, default), 3 IISPH + Akinci2013, 4 two-phase DFSPH")
     ap.add_argument("--side", type=int, default=100, help="particles per edge of the fluid block (100 -> 1M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-download-leg", action="store_true",
+                    help="skip the second run of the same steps with positions + velocities read back after every step (`with_download`)")
+    ap.add_argument("--no-big-leg", action="store_true",
+                    help="skip the roofline of the dominant kernel at 8 x 10^6 particles (`roofline.at_8m`; default run of config 2 only)")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host time for the multi-thread CPU leg")
     ap.add_argument("--transport", choices=("rccl", "peer"), default="rccl",
                     help="slab exchange of a multi-GPU run: RCCL send/recv + all-reduce (default, what BASELINE.json names), or the "
@@ -406,12 +410,65 @@ def main():
             except Exception as e:  # noqa: BLE001 - a timing aid must not cost the line
                 others[oname] = {"error": str(e)}
     roofline["other_kernels"] = others
+    spec_passes, disc_passes = int(w.counters.speculative_passes), int(w.counters.discarded_passes)
+    div_cap = float(getattr(w.solver, "max_divergence_iter", 50))
+
+    # ---- what a user pays who looks at the particles after every step (the reference's API leaves positions / velocities on the
+    # host after `step`; testbed_plugin.rs:361-367 reads them each frame): the SAME warm-up + timed steps on a fresh world, with an
+    # asynchronous read-back of positions and velocities into pinned host arrays after every step, one step late
+    # (salva_hip_get_fluid_async / _wait_download).  Reported beside `value`, never as `value` (state resident: the contract).
+    with_download = None
+    if not decomposed and not args.no_download_leg and rank == 0:
+        try:
+            w = None  # (release the first world's device memory)
+            w2, handles2 = make_config_world(args.config, fluids, shell, local_rank)
+            for _ in range(args.warmup):
+                w2.step(DT, GRAVITY)
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            for _ in range(args.steps):
+                w2.step(DT, GRAVITY)
+                w2.wait_download()
+                for hd in handles2:
+                    w2.download_async(hd)
+            w2.wait_download()
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - td
+            with_download = {"value": n * args.steps / el2, "unit": "particle-steps/s", "ms_per_step": el2 / args.steps * 1e3,
+                             "what": "the same warm-up and timed steps on a fresh world, positions + velocities of every fluid read back after "
+                                     "every step: asynchronously, into pinned host arrays, overlapping the next step (one step late)",
+                             "bytes_per_step": int(24 * n)}
+            w = w2
+        except Exception as e:  # noqa: BLE001 - a reporting leg must not cost the line
+            with_download = {"error": str(e)}
+
+    # ---- the same kernel where the state does NOT fit the 256 MiB Infinity Cache: 200^3 = 8 x 10^6 particles (config 2 only, a few
+    # steps of free fall; about 5 s with the scene build).  At 10^6 the launch is ~3 rounds of resident tiles deep; at 8 x 10^6, 23.
+    at_8m = None
+    if not decomposed and args.config == 2 and args.side == 100 and not args.no_big_leg and rank == 0:
+        try:
+            w = None
+            fl8, sh8 = build_config(2, 200)
+            w8, h8 = make_config_world(2, fl8, sh8, local_rank)
+            for _ in range(4):
+                w8.step(DT, GRAVITY)
+            n8 = sum(len(p_) for p_, _ in fl8)
+            k8 = float(sum(w8.contact_counts(h).sum() + w8.contact_counts(h, True).sum() for h in h8)) / n8
+            us8 = w8.time_kernel(kid, 30)
+            algo8 = n8 * (4.0 * k8 + sbytes)
+            at_8m = {"kernel": kname, "particles": n8, "kernel_us": us8, "mean_contacts": k8, "algorithmic_bytes": algo8,
+                     "achieved": algo8 / (us8 * 1e-6) / 1e9, "frac": algo8 / (us8 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "what": "the same kernel on a 200^3 block after 4 steps (free fall): state beyond the Infinity Cache"}
+            w8 = None
+        except Exception as e:  # noqa: BLE001
+            at_8m = {"error": str(e)}
+    roofline["at_8m"] = at_8m
 
     if rank == 0:
         # ---- the regimes the run went through (see the docstring): rates over the first 20 timed steps and over the timed
         # steps whose divergence solve ran into its iteration cap
         sm = np.asarray(step_ms)
-        cap = float(getattr(w.solver, "max_divergence_iter", 50))
+        cap = div_cap
         first = sm[:20]
         settled = sm[it[:, 0] >= cap] if cfg["solver"] == "dfsph" else sm[:0]
         regimes = {
@@ -457,9 +514,10 @@ def main():
                 "warmup_solver_ms": float(warm[-1][1]) if warm else None,
                 "tiles": tile_stats,
                 "exchange": exchange,
-                "speculative_passes": int(w.counters.speculative_passes), "discarded_passes": int(w.counters.discarded_passes),
+                "speculative_passes": spec_passes, "discarded_passes": disc_passes,
             },
             "regimes": regimes,
+            "with_download": with_download,
             "per_step_ms": [round(float(x), 4) for x in step_ms],
             "iters": [[int(a), int(b)] for a, b in it[:, :2]],
             "roofline": roofline,
@@ -471,7 +529,7 @@ def main():
         if world > 1:
             dist.barrier()
         if comm is not None:
-            del w
+            w = None
             comm.destroy()
         flush_c_stdio()
         if world > 1:

@@ -40,6 +40,24 @@ using namespace salva;
 // finished sum instead of every boundary term: rounding only.  a_ii (:188-233) is made of own quantities and sums over the same
 // contacts as well — d_ii . G_i - dt^2 m_i / rho_i^2 sum_j m_j |grad W_ij|^2 — and comes out of this pass too (no k_iisph_aii:
 // another 38 us).  Decomposed runs keep the separate passes (a ghost's density is replaced by its owner's in between).
+// Tile classes (device_types.h StepCtx::cls_slots; worlds with more than one mass): a pass is two launches — `uniform` over the
+// tiles whose whole halo has one mass (the plane-layout kernels, with Tile::mass = that tile's mass), `mixed` over the others
+// (the general kernels).  Every non-empty tile is in exactly one class, so outputs and error partials are complete.
+static inline uint32_t xcd_groups_for(uint32_t nl) {
+    uint32_t lg = 1u;
+    while (lg < 7u && (16u << lg) <= nl) ++lg;
+    return lg;
+}
+template <typename FU, typename FM>
+static inline void launch_by_class(const StepCtx& c, FU&& uniform, FM&& mixed) {
+    StepCtx cu = c, cm = c;
+    cu.cls_off = 0u; cu.nlaunch = c.n_uniform; cu.xcd = xcd_groups_for(cu.nlaunch);
+    cm.cls_off = c.n_uniform; cm.nlaunch = c.nlaunch - c.n_uniform; cm.xcd = xcd_groups_for(cm.nlaunch); cm.tile_mass_bits = nullptr;
+    if (cu.nlaunch) uniform(cu);
+    if (cm.nlaunch) mixed(cm);
+}
+static inline bool by_class(const StepCtx& c) { return c.cls_slots != nullptr && c.tile_mass_bits != nullptr && c.cls_off == 0u && c.n_uniform > 0u; }
+
 #ifndef SALVA_DA_IISPH_WAVES
 #define SALVA_DA_IISPH_WAVES 6  // (the IISPH form asks for 84 VGPRs by itself: two tiles per CU; held to 80 = three, two registers in scratch)
 #endif
@@ -190,7 +208,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
     TileErrC E;
     E.init(reinterpret_cast<float*>(t.pool + t.pool_used), c);
     Tile::staged_barrier();
-    const float m = c.mass_uniform;
+    const float m = t.mass;
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
         const float4 pi = o.pi, wi = o.wi;
@@ -271,10 +289,27 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
     });
     E.finish(c, t.slot);
 }
+template <uint32_t DS> __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c);  // (below)
 // true: the pass above ran and the divergence solve's iteration 0 must not launch its evaluate
 bool launch_density_alpha_div(const StepCtx& c, const TileLds& L, hipStream_t s) {
 #ifndef SALVA_OTHER_KERNELS
-    if (!(c.mass_uniform > 0.0f) || (c.sc.kd | c.sc.kg) != 0) return false;
+    if ((c.sc.kd | c.sc.kg) != 0) return false;
+    if (by_class(c)) {
+        launch_by_class(c, [&](const StepCtx& cu) {
+            const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
+            SALVA_LAUNCH_P3(k_density_alpha_div_p3, ds, cu, L, p3_bytes(L, ds, cu.nmodels, false), s, cu);
+        }, [&](const StepCtx& cm) {
+            // the mixed tiles: the density pass, then the solve's first evaluate as a pass of its own (their alpha is ready: the
+            // stream orders the two; the control block is the previous solve's, hence none)
+            SALVA_LAUNCH_TILE(k_density_alpha<false>, cm, L, L.bytes(16, 16, 2), s, cm, 0.0f);
+            StepCtx ce = cm;
+            ce.ctl = nullptr; ce.spec_k = -1;
+            const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
+            SALVA_LAUNCH_FIXED(k_divergence, ds, ce, L, pw_bytes(L, ds, true), s, ce);
+        });
+        return true;
+    }
+    if (!(c.mass_uniform > 0.0f)) return false;
     const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
     SALVA_LAUNCH_P3(k_density_alpha_div_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
     return true;
@@ -433,8 +468,8 @@ __global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
             float div = 0.0f;
             if (o.cnt + o.cntb >= c.min_neighbors_for_divergence) {
                 const float4 pi = o.pi, wi = o.wi;
-                div += near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8)
-                            : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8);
+                div += near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8, t.mass)
+                            : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8, t.mass);
                 for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                     const float4 pj = Bp[s];
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -452,6 +487,16 @@ __global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
 }
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence, c, L, s);
+    if (by_class(c)) {
+        launch_by_class(c, [&](const StepCtx& cu) {
+            const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
+            SALVA_LAUNCH_P3(k_divergence_p3, ds, cu, L, p3_bytes(L, ds, cu.nmodels, false), s, cu);
+        }, [&](const StepCtx& cm) {
+            const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
+            SALVA_LAUNCH_FIXED(k_divergence, ds, cm, L, pw_bytes(L, ds, true), s, cm);
+        });
+        return;
+    }
     if (c.mass_uniform > 0.0f) {
         const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
         SALVA_LAUNCH_P3(k_divergence_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
@@ -563,8 +608,8 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
         const float ki = o.ki;
         float4 d = o.wi;
         float sx, sy, sz;
-        if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, [&](float kj) { return ki + kj; }, sx, sy, sz);
-        else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, [&](float ka, float kb) { return f2{ki + ka, ki + kb}; }, sx, sy, sz);
+        if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, t.mass, [&](float kj) { return ki + kj; }, sx, sy, sz);
+        else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, t.mass, [&](float ka, float kb) { return f2{ki + ka, ki + kb}; }, sx, sy, sz);
         d.x -= sx; d.y -= sy; d.z -= sz;
         for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = p2_boundary_pos(t, s, dist8);
@@ -584,6 +629,16 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
 }
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence_apply, c, L, inv_dt_prev, s);
+    if (by_class(c)) {  // (never with speculative applies: World::dfsph_solve — the test would ride in both launches)
+        launch_by_class(c, [&](const StepCtx& cu) {
+            const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
+            SALVA_LAUNCH_P2(k_divergence_apply_p2, ds, cu, L, p2_bytes(L, ds), s, cu, inv_dt_prev);
+        }, [&](const StepCtx& cm) {
+            const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
+            SALVA_LAUNCH_FIXED(k_divergence_apply, ds, cm, L, pk_bytes(L, ds), s, cm, inv_dt_prev);
+        });
+        return;
+    }
     if (c.mass_uniform > 0.0f) {
         const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
         SALVA_LAUNCH_P2(k_divergence_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt_prev);
@@ -740,8 +795,8 @@ __global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
             mi = o.mi;
             const float rho0 = rho0_of(c, mi);
             const float4 pi = o.pi, wi = o.wi;
-            float delta = near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8)
-                               : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8);
+            float delta = near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8, t.mass)
+                               : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8, t.mass);
             for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Bp[s];
                 const float4 vj = c.bvel_zero ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : Bv[s];  // (w - 0 = w exactly)
@@ -760,6 +815,16 @@ __global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
 }
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pred_density, c, L, dt, s);
+    if (by_class(c)) {
+        launch_by_class(c, [&](const StepCtx& cu) {
+            const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
+            SALVA_LAUNCH_P3(k_pred_density_p3, ds, cu, L, p3_bytes(L, ds, cu.nmodels, !cu.bvel_zero), s, cu, dt);
+        }, [&](const StepCtx& cm) {
+            const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
+            SALVA_LAUNCH_FIXED(k_pred_density, ds, cm, L, pw_bytes(L, ds, true), s, cm, dt);
+        });
+        return;
+    }
     if (c.mass_uniform > 0.0f) {
         const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
         SALVA_LAUNCH_P3(k_pred_density_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
@@ -854,8 +919,8 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
         const float kip = fmaxf(ki, 0.0f);
         float4 d = o.d;
         float sx, sy, sz;
-        if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, sx, sy, sz);
-        else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, [&](float ka, float kb) { return f2{kip + fmaxf(ka, 0.0f), kip + fmaxf(kb, 0.0f)}; }, sx, sy, sz);
+        if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, t.mass, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, sx, sy, sz);
+        else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, t.mass, [&](float ka, float kb) { return f2{kip + fmaxf(ka, 0.0f), kip + fmaxf(kb, 0.0f)}; }, sx, sy, sz);
         d.x -= sx * inv_dt; d.y -= sy * inv_dt; d.z -= sz * inv_dt;
         if (ki > 0.0f) {
             for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
@@ -879,6 +944,16 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
 }
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pressure_apply, c, L, inv_dt, s);
+    if (by_class(c)) {
+        launch_by_class(c, [&](const StepCtx& cu) {
+            const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
+            SALVA_LAUNCH_P2(k_pressure_apply_p2, ds, cu, L, p2_bytes(L, ds), s, cu, inv_dt);
+        }, [&](const StepCtx& cm) {
+            const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
+            SALVA_LAUNCH_FIXED(k_pressure_apply, ds, cm, L, pk_bytes(L, ds), s, cm, inv_dt);
+        });
+        return;
+    }
     if (c.mass_uniform > 0.0f) {
         const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
         SALVA_LAUNCH_P2(k_pressure_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt);

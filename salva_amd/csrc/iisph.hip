@@ -158,8 +158,8 @@ __global__ SALVA_IISPH_P3_BOUNDS(DS) void k_iisph_pred_density_p3(StepCtx c, flo
         if (!active) return;
         const float4 pi = o.pi, wi = o.wi;
         const float rho0 = rho0_of(c, o.mi);
-        float delta = near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8)
-                           : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8);
+        float delta = near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8, t.mass)
+                           : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8, t.mass);
         for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = Bp[s];
             const float4 vj = c.bvel_zero ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : Bv[s];
@@ -558,8 +558,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P2_DS_THREE ? 6 : 5) void
         const float pri = o.pri;
         float4 d = o.d;
         float sx, sy, sz;
-        if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, [&](float kj) { return pri + kj; }, sx, sy, sz);
-        else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, [&](float ka, float kb) { return f2{pri + ka, pri + kb}; }, sx, sy, sz);
+        if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, t.mass, [&](float kj) { return pri + kj; }, sx, sy, sz);
+        else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, t.mass, [&](float ka, float kb) { return f2{pri + ka, pri + kb}; }, sx, sy, sz);
         d.x -= sx * dt; d.y -= sy * dt; d.z -= sz * dt;
         for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = p2_boundary_pos(t, s, dist8);

@@ -80,8 +80,9 @@ template <uint32_t DS>
 __device__ __forceinline__ uint32_t p2_dist8(const Tile& t) { return DS ? DS * 8u : (((t.S + t.SB) * 8u + 15u) & ~15u); }
 __device__ __forceinline__ RecP3 load_p3(uint32_t o, uint32_t dist8) { return RecP3{lds_ld8(o), lds_ld8(o + dist8), lds_ld8(o + 2u * dist8)}; }
 template <bool AHEAD = true>
+// (`mass`: Tile::mass — the launch's uniform mass, or with tile classes the uniform mass of THIS tile's halo)
 __device__ __forceinline__ float pair_sum_velocity_divergence_p3(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh,
-                                                                 const float4& pi, const float4& wi, uint32_t dist8) {
+                                                                 const float4& pi, const float4& wi, uint32_t dist8, float mass) {
     f2 acc2 = {0.0f, 0.0f};
     const f2 tiny = {1.0e-30f, 1.0e-30f};
     for_each_ff2<AHEAD, false, 2>(c, gs, nqu, lh, [&](uint32_t o) { return load_p3(o, dist8); }, [&](const RecP3& A, const RecP3& B) { SALVA_PAIR_MATH
@@ -93,10 +94,10 @@ __device__ __forceinline__ float pair_sum_velocity_divergence_p3(const StepCtx& 
         const f2 ux = {wi.x - A.zu.y, wi.x - B.zu.y}, uy = {wi.y - A.vw.x, wi.y - B.vw.x}, uz = {wi.z - A.vw.y, wi.z - B.vw.y};
         acc2 += (ux * dx + uy * dy + uz * dz) * g;
     });
-    return (acc2.x + acc2.y) * c.sc.gscale * c.mass_uniform;
+    return (acc2.x + acc2.y) * c.sc.gscale * mass;
 }
 __device__ __forceinline__ float pair_sum_velocity_divergence_exact_p3(const StepCtx& c, uint32_t i, uint32_t gs, const float4& pi,
-                                                                       const float4& wi, uint32_t dist8) {
+                                                                       const float4& wi, uint32_t dist8, float mass) {
     float acc = 0.0f;
     for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
         const RecP3 A = load_p3(s << 3, dist8);
@@ -104,14 +105,14 @@ __device__ __forceinline__ float pair_sum_velocity_divergence_exact_p3(const Ste
         const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
         acc += ((wi.x - A.zu.y) * dx + (wi.y - A.vw.x) * dy + (wi.z - A.vw.y) * dz) * g;
     });
-    return acc * c.mass_uniform;
+    return acc * mass;
 }
 // sum_j grad W_ij k_ij over the 16-byte plane layout (tile.h stage_p2), times the uniform mass
 struct RecP2 { lds_v2f xy, zk; };  // (x, y) | (z, kappa)
 __device__ __forceinline__ RecP2 load_p2(uint32_t o, uint32_t dist8) { return RecP2{lds_ld8(o), lds_ld8(o + dist8)}; }
 template <typename K2>
 __device__ __forceinline__ void pair_sum_gradient_p2(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh, const float4& pi,
-                                                     uint32_t dist8, K2&& kij2, float& sx, float& sy, float& sz) {
+                                                     uint32_t dist8, float mass, K2&& kij2, float& sx, float& sy, float& sz) {
     f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
     const f2 tiny = {1.0e-30f, 1.0e-30f};
     for_each_ff2<true, false, 2>(c, gs, nqu, lh, [&](uint32_t o) { return load_p2(o, dist8); }, [&](const RecP2& A, const RecP2& B) { SALVA_PAIR_MATH
@@ -123,12 +124,12 @@ __device__ __forceinline__ void pair_sum_gradient_p2(const StepCtx& c, uint32_t 
         const f2 coeff = kij2(A.zk.y, B.zk.y) * g;
         ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
     });
-    const float f = c.sc.gscale * c.mass_uniform;
+    const float f = c.sc.gscale * mass;
     sx = (ax.x + ax.y) * f; sy = (ay.x + ay.y) * f; sz = (az.x + az.y) * f;
 }
 template <typename K1>
 __device__ __forceinline__ void pair_sum_gradient_exact_p2(const StepCtx& c, uint32_t i, uint32_t gs, const float4& pi, uint32_t dist8,
-                                                           K1&& kij1, float& sx, float& sy, float& sz) {
+                                                           float mass, K1&& kij1, float& sx, float& sy, float& sz) {
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
     for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
         const RecP2 A = load_p2(s << 3, dist8);
@@ -136,7 +137,7 @@ __device__ __forceinline__ void pair_sum_gradient_exact_p2(const StepCtx& c, uin
         const float coeff = kij1(A.zk.y) * kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
         ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
     });
-    sx = ax * c.mass_uniform; sy = ay * c.mass_uniform; sz = az * c.mass_uniform;
+    sx = ax * mass; sy = ay * mass; sz = az * mass;
 }
 // a boundary halo slot of that layout: (x, y, z, V_b)
 __device__ __forceinline__ float4 p2_boundary_pos(const Tile& t, uint32_t s, uint32_t dist8) {

@@ -204,6 +204,8 @@ struct Tile {
     static constexpr int PRE = 4;
     uint32_t pre0, pre1, pre2, pre3, preb;
     bool skip;  // this launch is not the one that handles the tile (StepCtx::phase): leave every output alone
+    float mass; // what the plane-layout kernels multiply their finished sums by: StepCtx::mass_uniform, or — tile classes — the
+                // uniform mass of THIS tile's halo (StepCtx::tile_mass_bits)
 
     __device__ __forceinline__ bool empty() const { return own_begin == own_end; }
     __device__ __forceinline__ bool skipped() const { return skip; }
@@ -214,6 +216,7 @@ struct Tile {
         pool = tile_smem;
         pool_used = 0;
         skip = false;
+        mass = 0.0f;
         slot = blockIdx.x;
         S = SB = 0; slice_base = 0; hoff = hboff = 0;
         pre0 = pre1 = pre2 = pre3 = preb = 0u;
@@ -244,13 +247,17 @@ struct Tile {
             if (rk < 64u)
                 for (unsigned i = 0; i < ((rk >> 4) & 3u); ++i) __builtin_amdgcn_s_sleep(64);
         }
-        setup_at(c, xcd_block(blockIdx.x, gridDim.x, c.xcd));
+        uint32_t at = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+        // tile classes (worlds with more than one mass, device_types.h): this launch covers the slots cls_slots[cls_off ..) names
+        if (c.cls_slots) at = c.cls_slots[c.cls_off + at];
+        setup_at(c, at);
     }
     __device__ __forceinline__ void setup_at(const StepCtx& c, uint32_t at_slot) {
         pool = tile_smem;
         pool_used = 0;
         slot = at_slot;
         const uint4 desc = c.slot_desc[slot];
+        mass = c.tile_mass_bits ? __uint_as_float(c.tile_mass_bits[slot]) : c.mass_uniform;
         pre0 = pre1 = pre2 = pre3 = preb = 0u;
         if (c.halo_stride) {
             const uint32_t* __restrict__ src = c.halo_src + (size_t)slot * c.halo_stride;

@@ -224,6 +224,13 @@ class World {
     DevBuf<int32_t> bbox_partials;
     TileLds lds;
     float mass_uniform = 0.0f;  // StepCtx::mass_uniform of the current step (0: masses differ, or not known)
+    // Tile classes (device_types.h StepCtx::cls_slots): worlds known to hold more than one mass run their DFSPH passes as two
+    // launches, plane-layout kernels over the tiles whose halo has one mass and general kernels over the rest.
+    DevBuf<uint32_t> cls_slots, tile_mass_bits;
+    bool classes_off = false;     // SALVA_HIP_NO_TILE_CLASSES=1 (A/B, tests)
+    bool classes_wanted = false;  // this pass builds the class tables (k_nbr_tile reduces the halo masses)
+    bool classes_active = false;  // ... and they are known on the host: make_ctx hands them to the launchers
+    uint32_t n_uniform_tiles = 0;
     // Decomposed runs, timers enabled (salva_hip_enable_counters): HIP event pairs around every ghost refresh (gather -> exchange ->
     // scatter) and every all-reduced convergence test (sum -> all-reduce -> decide) of a step, folded into `dist_times` at its end:
     // {refresh ms, refreshes, test ms, tests} — what an exchange costs INSIDE a decomposed step, waiting for the neighbour included

@@ -134,6 +134,7 @@ World::World(const SalvaHipParams& p) : prm(p) {
     defer_off = getenv("SALVA_HIP_NO_DEFER_LISTS") != nullptr;
     spec_apply_off = getenv("SALVA_HIP_NO_SPEC_APPLY") != nullptr;
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
+    classes_off = getenv("SALVA_HIP_NO_TILE_CLASSES") != nullptr;
     tile_trace = getenv("SALVA_HIP_TILE_TRACE") != nullptr;
     no_fused_div = getenv("SALVA_HIP_NO_FUSED_DIV") != nullptr;
     if (const char* e = getenv("SALVA_HIP_RADIX_SORT")) sort_mode = atoi(e) != 0 ? 1 : 0;
@@ -666,6 +667,10 @@ StepCtx World::make_ctx() {
     c.nmodels = (uint32_t)std::max<size_t>(fluids.size(), 1);
     c.nbmodels = (uint32_t)std::max<size_t>(bounds.size(), 1);
     c.mass_uniform = mass_uniform;
+    c.want_tile_mass = classes_wanted ? 1u : 0u;
+    c.cls_slots = classes_active ? cls_slots.p : nullptr;
+    c.tile_mass_bits = classes_active ? tile_mass_bits.p : nullptr;
+    c.cls_off = 0u; c.n_uniform = classes_active ? n_uniform_tiles : 0u;
     c.bvel_zero = 1u;  // no boundary particle moves: the passes that subtract a boundary velocity need not stage it
     for (const BoundarySlot& b : bounds) if (b.n && (!b.vel_zero || b.sampling || b.dyn_kind)) c.bvel_zero = 0u;
     c.rho0_tab = rho0_tab.p; c.rho0_single = fluids.empty() ? 1000.0f : fluids[0].density0; c.ff_ok = ff_ok.p; c.fb_ok = fb_ok.p; c.bb_ok = bb_ok.p;
@@ -771,6 +776,7 @@ __global__ void k_publish_readback(Readback* __restrict__ src, const TileAcc* __
             pub_rb->ncontacts_ff = src->ncontacts_ff; pub_rb->ncontacts_fb = src->ncontacts_fb;
             pub_rb->max_cnt_ff = src->max_cnt_ff; pub_rb->max_cnt_fb = src->max_cnt_fb;
             pub_rb->ncontacts_own_ff = src->ncontacts_own_ff; pub_rb->ncontacts_own_fb = src->ncontacts_own_fb;
+            pub_rb->n_uniform_tiles = src->n_uniform_tiles;
         }
         if (end_of_step) {
             pub_rb->flags = src->flags;
@@ -808,6 +814,7 @@ void World::publish_wait(uint32_t seq, bool totals, bool lists, bool end_of_step
     if (lists) {
         h_rb->ncontacts_ff = p.ncontacts_ff; h_rb->ncontacts_fb = p.ncontacts_fb; h_rb->max_cnt_ff = p.max_cnt_ff; h_rb->max_cnt_fb = p.max_cnt_fb;
         h_rb->ncontacts_own_ff = p.ncontacts_own_ff; h_rb->ncontacts_own_fb = p.ncontacts_own_fb;
+        h_rb->n_uniform_tiles = p.n_uniform_tiles;
     }
     if (end_of_step) { h_rb->flags = p.flags; memcpy(h_rb->bbox, p.bbox, sizeof(p.bbox)); }
 }
@@ -1057,7 +1064,7 @@ void World::dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepSta
     // Worth ~3 us per iteration (measured: a 50-iteration step 5.13 -> 4.99 ms); the apply that follows the converging evaluate is
     // then computed in vain (~30 us once per solve), so: only when the previous step's solve ran 16 iterations or more; not with boundary reaction forces (an
     // apply that is thrown away must not have added to them) and not in decomposed runs (the test sits behind an all-reduce).
-    const bool spec_apply = !spec_apply_off && !comm && !any_wants_forces && last_iters[0] >= 16u;
+    const bool spec_apply = !spec_apply_off && !comm && !any_wants_forces && last_iters[0] >= 16u && !classes_active;
     if (spec_apply) { w2.ensure(n, stream, false, 1.1f); spec_ring.ensure(2); c.w2 = w2.p; c.spec_ring = spec_ring.p; }
     const SolveResult rd = run_solve(
         c, 0, prm.max_divergence_error * inv_dt_prev * 0.01f, prm.min_divergence_iter, prm.max_divergence_iter, 0u,
@@ -1272,7 +1279,13 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     const bool can_redo = (!comm || solo) && !any_wants_forces && !has_custom && !has_dyn;
     // (mass_known: the kernels of a pass are chosen by StepCtx::mass_uniform, which a speculative pass — it does not wait for the
     // publication that carries it — can only inherit; a host edit since the last publication may have changed the masses)
-    const bool can_speculate = !spec_off && can_redo && !b_dirty && pred_valid && pred_n == n && mass_known;
+    // Tile classes: a single-domain DFSPH world (default kernels) whose particles are KNOWN not to share one mass.  The class tables
+    // are this step's own product and the launch shapes need their split: such a world waits for the list statistics in the
+    // middle of the step (one host round trip of a multi-millisecond step) and never sizes speculatively.
+    const bool classes_possible = !classes_off && !no_planes && !comm && prm.solver == SALVA_HIP_SOLVER_DFSPH && prm.kernel_density == 0 &&
+                                  prm.kernel_gradient == 0 && fluids.size() <= 32 && bounds.size() <= 32;
+    const bool can_speculate = !spec_off && can_redo && !b_dirty && pred_valid && pred_n == n && mass_known &&
+                               !(classes_possible && mass_uniform == 0.0f);
     // The neighbour-list capacity check (longest list <= ELL capacity) costs a read-back with an idle GPU in the middle of the
     // step although it fails about once per run (the capacity follows the longest list seen so far): where the pass can be
     // repeated, check at the end of the step with the read-back that happens there anyway, and repeat on overflow.
@@ -1300,7 +1313,11 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     StepCtx c{};
     for (int attempt = 0;; ++attempt) {
     bool spec = can_speculate && attempt == 0;
-    const bool defer_lists = can_redo && !defer_off && attempt == 0 && lists_checked;
+    classes_wanted = classes_active = false;
+    // (mass_known && mass_uniform == 0: what the last exact pass found; a host edit clears mass_known and the first pass after it
+    // runs without classes — its k_cell_keys finds out)
+    const bool classes_now = classes_possible && mass_known && mass_uniform == 0.0f;
+    const bool defer_lists = can_redo && !defer_off && attempt == 0 && lists_checked && !classes_now;
     if (attempt > 0) SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));  // (whatever the discarded pass flagged)
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
     {
@@ -1451,6 +1468,10 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         // ---- neighbour lists   (compute_contacts, contacts.rs:154-252): one pass into fixed-capacity ELL rows; if a list
         // turns out longer than the capacity the pass is repeated with room to spare (rare: the capacity follows the
         // longest list seen so far).  Speculative passes check at the end of the step instead.
+        // (the mass verdict of THIS pass's publication may differ from the one classes_now was taken from — a scene whose second
+        // fluid has just been removed: then no classes)
+        classes_wanted = classes_now && mass_uniform == 0.0f && !spec;
+        if (classes_wanted) { cls_slots.ensure(std::max<uint32_t>(nlaunch, 1u), stream, false, 1.5f); tile_mass_bits.ensure(std::max<uint32_t>(nlaunch, 1u), stream, false, 1.5f); }
         for (int nattempt = 0;; ++nattempt) {
             const bool r1 = nbr_ff.ensure((size_t)nslices * cap_ff * WAVE + 1, stream, false, 1.1f);
             const bool r2 = nbr_fb.ensure(nb ? (size_t)nslices * cap_fb * WAVE + 1 : 1, stream, false, 1.1f);
@@ -1459,6 +1480,7 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             c = make_ctx();
             launch_nbr_build(c, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff,
                              comm ? reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_own_ff) : nullptr, stream);
+            if (classes_wanted) launch_tile_classes(c, tile_list_stats.p, cls_slots.p, tile_mass_bits.p, &d_rb.p->n_uniform_tiles, stream);
             if (spec || defer_lists) break;
             static_assert(offsetof(Readback, max_cnt_ff) == offsetof(Readback, ncontacts_ff) + 2 * sizeof(uint64_t), "list statistics travel in one copy");
             publish_and_wait(nullptr, true, false);
@@ -1472,6 +1494,12 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         // kernel-development builds: bank-conflict-aware list order (diag/sched.hip), SALVA_HIP_SCHED=1
         if (sched_mode > 0) launch_list_schedule(c, lds, stream);
 #endif
+        if (classes_wanted) {  // (the list statistics have been waited for: defer_lists and spec are off in such a world)
+            n_uniform_tiles = std::min(h_rb->n_uniform_tiles, nlaunch);
+            classes_active = n_uniform_tiles > 0u;
+            classes_wanted = false;
+            c = make_ctx();
+        }
     }
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
 

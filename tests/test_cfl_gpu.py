@@ -1,0 +1,87 @@
+"""Opt-in CFL sub-stepping: `TimestepManager::max_substep` (timestep_manager.rs:36-46) with the clamp
+`compute_substep` leaves commented out (:90-93), HIP path against the oracle's restatement of the same on the dam break.
+Off — the default — a step is one substep, as the reference runs."""
+import numpy as np
+import pytest
+
+from parity import GRAVITY, Scene, max_norm_diff
+from salva_amd import _lib, scenes
+
+pytestmark = pytest.mark.gpu
+R = 0.025
+DT = 1.0 / 60.0  # a frame: the reference's 1/200 never trips the CFL bound in this scene
+
+
+def _dam_break(solver="dfsph", forces=(("xsph", 0.5, 0.0),)):
+    s = Scene(R, 2.0, solver)
+    fluid, shell = scenes.tank(12, 16, 12, R, wall_cells=10)
+    s.add_fluid(scenes.jitter(fluid, 0.05 * R, seed=42), None, 1000.0, forces=list(forces))
+    s.add_boundary(shell)
+    return s
+
+
+@pytest.mark.parametrize("solver,mode", [("dfsph", 1), ("dfsph", 2), ("iisph", 1)])
+def test_cfl_substeps_match_the_oracle_on_the_dam_break(solver, mode):
+    s = _dam_break(solver)
+    w, (fl,), _ = s.make_hip()
+    o = s.make_oracle(threads=4)
+    w.set_cfl_substepping(mode)
+    o.set_cfl(mode)
+    w.counters.enable()
+    nsub_total, multi = 0, 0
+    n = 36
+    for k in range(n):
+        st = w.step(DT, GRAVITY)
+        so = o.step(DT, GRAVITY)
+        sw, sr = w.substeps(), o.substeps()
+        assert w.counters.nsubsteps == len(sw) == len(sr), (k, sw, sr)
+        # the substep is a function of max |v + a t|: equal up to the rounding of the sums behind v and a
+        assert np.allclose(sw, sr, rtol=2e-4 * (k + 1)), (k, sw, sr)
+        assert all(DT / 10 * (1 - 1e-6) <= x <= DT * (1 + 1e-6) for x in sw)
+        assert sum(sw) >= DT * (1 - 1e-6) and (mode == 1 or abs(sum(sw) - DT) < 1e-6)
+        assert abs(int(st.ncontacts) - int(so.ncontacts)) <= (0 if k == 0 else max(4, int(2e-5 * so.ncontacts) * (k + 1))), (k, st.ncontacts, so.ncontacts)
+        assert abs(st.n_pressure_iters - so.n_press_iters) <= 1 and abs(st.n_divergence_iters - so.n_div_iters) <= 2, k
+        c = w.counters
+        assert c.step_time > 0 and c.stages.solver_time > 0  # the timers add up over the substeps
+        nsub_total += len(sw)
+        multi += len(sw) > 1
+    assert multi >= 5, "the scene never sub-stepped: the test would prove nothing"
+    d = max_norm_diff(fl.positions, o.fluid_vec(0, "positions")) / R
+    assert d < 1e-3 * nsub_total, d  # 1e-3 r per substep, as test_longer_trajectory_dam_break allows per step
+    assert fl.positions[:, 1].min() > -3 * R
+
+
+def test_cfl_is_off_by_default_and_can_be_switched_off_again():
+    s = _dam_break()
+    w0, (f0,), _ = s.make_hip()
+    w1, (f1,), _ = s.make_hip()
+    w1.set_cfl_substepping(1)
+    w1.set_cfl_substepping(0)
+    for _ in range(30):
+        w0.step(DT, GRAVITY)
+        w1.step(DT, GRAVITY)
+        assert w0.substeps() == w1.substeps() == [np.float32(DT)] and w0.counters.nsubsteps == 1
+    assert np.array_equal(f0.positions, f1.positions)
+    with pytest.raises(_lib.SalvaHipError):
+        w1.set_cfl_substepping(3)
+    with pytest.raises(_lib.SalvaHipError):
+        w1.set_cfl_substepping(1, 0.4, 3, 2)
+
+
+def test_cfl_refuses_coupled_boundaries_that_want_forces():
+    """The reference transmits a coupled collider's impulse per substep (fluids_pipeline.rs:266-287): one wrench per step() cannot
+    carry that, so the combination is refused instead of answered wrongly."""
+    from salva_amd import Boundary, DFSPHSolver, Fluid, LiquidWorld
+    from salva_amd.coupling import ColliderCouplingSet, RigidBody, StaticSampling
+
+    w = LiquidWorld(DFSPHSolver(), R, 2.0)
+    w.add_fluid(Fluid(scenes.cube_fluid_positions(6, 6, 6, R) + np.float32([0, 8 * R, 0]), R, 1000.0))
+    b = w.add_boundary(Boundary(np.zeros((0, 3), np.float32)))
+    c = ColliderCouplingSet()
+    c.register_coupling(b, "raft", RigidBody(translation=np.float32([0, 0, 0]), mass=1.0, principal_inertia=np.float32([1, 1, 1])),
+                        StaticSampling(scenes.plane_lattice(8, 8, 0.0, R, -8 * R, -8 * R, layers=1)))
+    w.set_cfl_substepping(1)
+    with pytest.raises(_lib.SalvaHipError, match="substep"):
+        w.step_with_coupling(DT, GRAVITY, c)
+    w.set_cfl_substepping(0)
+    w.step_with_coupling(DT, GRAVITY, c)

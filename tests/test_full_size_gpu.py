@@ -124,8 +124,9 @@ def long_run_against_oracle(scene, nsteps, gravity, label):
     w, fls, _ = scene.make_hip()
     o = scene.make_oracle(threads=host_threads())
     # the oracle's f64 build runs along: where its iteration counts equal the f32 build's, the device must
-    # hit them within +-1; only at the steps where the restatement's OWN two precisions disagree — the solve creeping along its
-    # tolerance, where the stopping iteration is rounding noise — does the +-10 % allowance of round 3 remain
+    # hit them within +-1; at the steps where the restatement's OWN two precisions disagree — the solve creeping along its
+    # tolerance, where the stopping iteration is rounding noise — the allowance is that disagreement, and such steps are bounded
+    # (at most a fifth of the run)
     o64 = scene.make_oracle(threads=host_threads(), f64=True)
     trace = []
     loose_steps = 0
@@ -137,7 +138,8 @@ def long_run_against_oracle(scene, nsteps, gravity, label):
         assert abs(int(st.ncontacts) - int(so.ncontacts)) <= slack, f"{label} step {k}: contacts {st.ncontacts} vs {so.ncontacts}"
 
         def tol_it(a, b, a64):
-            return 1 if b == a64 else max(1, abs(b - a64), -(-max(a, b) // 10))
+            # (round 5: the 10 % allowance of rounds 3-4 is gone — what remains is the restatement's own f32-vs-f64 distance at this step)
+            return max(1, abs(b - a64))
         tp = tol_it(st.n_pressure_iters, so.n_press_iters, s64.n_press_iters)
         td = tol_it(st.n_divergence_iters, so.n_div_iters, s64.n_div_iters)
         loose_steps += (tp > 1) or (td > 1)
@@ -154,6 +156,7 @@ def long_run_against_oracle(scene, nsteps, gravity, label):
         assert d < tol_p, f"{label}: positions of fluid {f} differ by {d:.2e} r after {nsteps} steps (tolerance {tol_p:.2e})"
         assert dv < tol_v, f"{label}: velocities of fluid {f} differ by {dv:.2e} v_ref (tolerance {tol_v:.2e})"
     print(label, f"steps with the loose iteration allowance (oracle f32 != f64): {loose_steps} of {nsteps}")
+    assert loose_steps <= nsteps // 5, f"{label}: the oracle's two precisions disagree by more than one iteration in {loose_steps} of {nsteps} steps"
     print(label, "iterations (gpu div, gpu press, oracle div, oracle press, oracle-f64 div, oracle-f64 press):", trace)
     return trace
 

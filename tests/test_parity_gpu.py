@@ -480,7 +480,7 @@ def test_plane_layouts_and_the_fused_first_divergence_change_rounding_only(monke
     counts are identical and the states agree to f32 summation order; a scene whose masses differ takes the old kernels whatever
     the switches say and is bit-identical."""
     def run(scene, nsteps, env):
-        for k in ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV"):
+        for k in ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV", "SALVA_HIP_NO_TILE_CLASSES"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
@@ -495,11 +495,51 @@ def test_plane_layouts_and_the_fused_first_divergence_change_rounding_only(monke
         dp, dv = np.abs(base["pos_0"] - other["pos_0"]).max(), np.abs(base["vel_0"] - other["vel_0"]).max()
         assert dp < 2e-5 * R * nsteps, f"{env}: positions differ by {dp / R:.2e} r"
         assert dv < 1e-4, f"{env}: velocities differ by {dv:.2e} m/s"
-    two = SCENES["two_phase"][0]()  # fluids of different density0: the masses differ, nothing above applies
-    a, b = run(two, 6, ()), run(two, 6, ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV"))
+    # fluids of different density0: the masses differ, and without the per-tile classes of round 5 (next test) nothing above applies
+    two = SCENES["two_phase"][0]()
+    a, b = run(two, 6, ("SALVA_HIP_NO_TILE_CLASSES",)), run(two, 6, ("SALVA_HIP_NO_TILE_CLASSES", "SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV"))
     assert np.array_equal(a["iters"], b["iters"])
     for f in range(2):
         assert np.array_equal(a[f"pos_{f}"], b[f"pos_{f}"]) and np.array_equal(a[f"vel_{f}"], b[f"vel_{f}"])
+
+
+def _two_phase_side_by_side():
+    """BASELINE config 4 in small: two blocks of different density0 side by side along x over a floor — most tiles see one mass in
+    their whole halo, the tiles around the interface two."""
+    s = Scene(R, 2.0, "dfsph")
+    a = scenes.jitter(scenes.cube_fluid_positions(24, 12, 12, R), 0.05 * R, seed=42)
+    b = scenes.jitter(scenes.cube_fluid_positions(24, 12, 12, R), 0.05 * R, seed=43)
+    a[:, 0] -= np.float32(24 * R)
+    b[:, 0] += np.float32(24 * R)
+    a[:, 1] += np.float32(12 * R + 2 * R)
+    b[:, 1] += np.float32(12 * R + 2 * R)
+    s.add_fluid(a, scenes.random_velocities(len(a), 0.05, seed=5), 1000.0, forces=[("xsph", 0.5, 0.0)])
+    s.add_fluid(b, scenes.random_velocities(len(b), 0.05, seed=6), 500.0, forces=[("xsph", 0.5, 0.0)])
+    s.add_boundary(scenes.plane_lattice(56, 20, 0.0, R, -28 * 2 * R + R, -10 * 2 * R + R, layers=2))
+    return s
+
+
+def test_tile_classes_change_rounding_only(monkeypatch):
+    """Round 5: a world whose particles do not share one mass (two fluids of different density0, BASELINE config 4) runs every DFSPH
+    pass as two launches — the plane-layout kernels over the tiles whose whole halo has one mass, with that tile's mass, and the
+    general kernels over the tiles that see both.  Other kernels for the same sums: against a run with
+    SALVA_HIP_NO_TILE_CLASSES=1 the contact and iteration counts are identical and the states agree to f32 summation order — but
+    not bit for bit, or the classes were never on — and both agree with the oracle."""
+    scene = _two_phase_side_by_side()
+    nsteps = 10
+    monkeypatch.delenv("SALVA_HIP_NO_TILE_CLASSES", raising=False)
+    on = run_hip(scene, nsteps)
+    monkeypatch.setenv("SALVA_HIP_NO_TILE_CLASSES", "1")
+    off = run_hip(scene, nsteps)
+    monkeypatch.delenv("SALVA_HIP_NO_TILE_CLASSES", raising=False)
+    assert np.array_equal(on["iters"], off["iters"]), "iteration or contact counts differ"
+    differs = False
+    for f in range(2):
+        dp, dv = np.abs(on[f"pos_{f}"] - off[f"pos_{f}"]).max(), np.abs(on[f"vel_{f}"] - off[f"vel_{f}"]).max()
+        assert dp < 2e-5 * R * nsteps and dv < 1e-4, (f, dp / R, dv)
+        differs |= not np.array_equal(on[f"vel_{f}"], off[f"vel_{f}"])
+    assert differs, "bit-identical runs: the tile classes never switched on"
+    compare(on, run_oracle(scene, nsteps), scene, nsteps, "two-phase side by side vs oracle")
 
 
 @pytest.mark.parametrize("name", ["dfsph_tank", "iisph_akinci", "dfsph_xsph_block", "two_phase"])
