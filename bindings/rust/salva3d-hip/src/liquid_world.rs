@@ -408,7 +408,72 @@ impl LiquidWorld {
         &self.last_stats
     }
 
-    /// The raw handle, for the entry points this wrapper does not cover (coupling, queries, multi-GPU).
+    /// `LiquidWorld::particles_intersecting_shape` (liquid_world.rs:245-280), generic over parry's `Shape` like the reference's:
+    /// `shape.compute_aabb(pos)` and `shape.distance_to_point(pos, &pt, true)` stay on the host (the two callbacks of
+    /// `salva_hip_particles_intersecting_host_shape`), the cell filter and the particle scan run on the device.
+    pub fn particles_intersecting_shape<S: ?Sized + parry3d::shape::Shape>(
+        &mut self,
+        pos: &na::Isometry3<Real>,
+        shape: &S,
+    ) -> Result<Vec<salva3d::object::ParticleId>, Error> {
+        use parry3d::query::PointQuery;
+        struct Ctx<'a, S: ?Sized> {
+            pos: &'a na::Isometry3<Real>,
+            shape: &'a S,
+        }
+        unsafe extern "C" fn aabb_cb<S: ?Sized + parry3d::shape::Shape>(user: *mut std::ffi::c_void, mins: *mut f32, maxs: *mut f32) {
+            let c = &*(user as *const Ctx<S>);
+            // (a panic must not unwind into C: an empty box makes the library refuse the query)
+            let b = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| c.shape.compute_aabb(c.pos)));
+            for k in 0..3 {
+                *mins.add(k) = b.as_ref().map(|b| b.mins[k]).unwrap_or(f32::NAN);
+                *maxs.add(k) = b.as_ref().map(|b| b.maxs[k]).unwrap_or(f32::NAN);
+            }
+        }
+        unsafe extern "C" fn dist_cb<S: ?Sized + parry3d::shape::Shape>(user: *mut std::ffi::c_void, n: u32, pts: *const f32, out: *mut f32) {
+            let c = &*(user as *const Ctx<S>);
+            for k in 0..n as usize {
+                let pt = na::Point3::new(*pts.add(3 * k), *pts.add(3 * k + 1), *pts.add(3 * k + 2));
+                let d = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| c.shape.distance_to_point(c.pos, &pt, true)));
+                *out.add(k) = d.unwrap_or(f32::INFINITY);
+            }
+        }
+        let ctx = Ctx { pos, shape };
+        let sh = ffi::SalvaHipHostQueryShape {
+            aabb: Some(aabb_cb::<S>),
+            distance: Some(dist_cb::<S>),
+            user: &ctx as *const Ctx<S> as *mut std::ffi::c_void,
+        };
+        let mut cap = 1024usize;
+        loop {
+            let (mut k, mut s, mut i) = (vec![0u32; cap], vec![0u32; cap], vec![0u32; cap]);
+            let total = unsafe {
+                ffi::salva_hip_particles_intersecting_host_shape(self.raw, &sh, cap as u64, k.as_mut_ptr(), s.as_mut_ptr(), i.as_mut_ptr())
+            };
+            if total < 0 {
+                check(total as i32)?;
+            }
+            let total = total as usize;
+            if total > cap {
+                cap = total;
+                continue;
+            }
+            // dense slot -> handle, as the reference maps its grid entries (`get_from_contiguous_index`, liquid_world.rs:257, :266)
+            return Ok((0..total)
+                .filter_map(|j| {
+                    if k[j] == 0 {
+                        let (_, h) = self.fluids.get_from_contiguous_index(s[j] as usize)?;
+                        Some(salva3d::object::ParticleId::FluidParticle(h, i[j] as usize))
+                    } else {
+                        let (_, h) = self.boundaries.get_from_contiguous_index(s[j] as usize)?;
+                        Some(salva3d::object::ParticleId::BoundaryParticle(h, i[j] as usize))
+                    }
+                })
+                .collect());
+        }
+    }
+
+    /// The raw handle, for the entry points this wrapper does not cover (coupling, AABB / analytic-shape queries, multi-GPU).
     pub fn raw(&mut self) -> *mut ffi::SalvaHipWorld {
         self.raw
     }

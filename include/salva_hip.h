@@ -382,8 +382,8 @@ int64_t salva_hip_delete_owned(SalvaHipWorld* world, uint32_t n, const uint32_t*
 int64_t salva_hip_particles_intersecting_aabb(SalvaHipWorld* world, const float mins[3], const float maxs[3], uint64_t capacity,
                                              uint32_t* kinds, uint32_t* slots, uint32_t* indices);
 
-/* `LiquidWorld::particles_intersecting_shape(pos, shape)` (liquid_world.rs:245-280) for the analytic shapes the examples use
- * (parry itself is out of scope): the particles in the grid cells the posed shape's AABB touches whose distance to the
+/* `LiquidWorld::particles_intersecting_shape(pos, shape)` (liquid_world.rs:245-280) for the analytic shapes the examples use,
+ * entirely on the device (every other shape: salva_hip_particles_intersecting_host_shape below): the particles in the grid cells the posed shape's AABB touches whose distance to the
  * (solid) shape is <= the particle radius.  `rotation_ijkw` is the unit quaternion of the isometry.  Output and return value
  * as salva_hip_particles_intersecting_aabb; like it, current positions are tested. */
 enum {
@@ -400,6 +400,21 @@ typedef struct SalvaHipShape {
 int64_t salva_hip_particles_intersecting_shape(SalvaHipWorld* world, const float translation[3], const float rotation_ijkw[4],
                                               const SalvaHipShape* shape, uint64_t capacity, uint32_t* kinds, uint32_t* slots,
                                               uint32_t* indices);
+
+/* The same query for ANY other shape (the reference's is generic over parry's `Shape`, liquid_world.rs:247-250): the geometry
+ * stays with the host.  The library calls `aabb` once (`shape.compute_aabb(pos)`), collects the particles of the grid cells that
+ * box touches on the device (hgrid.cells_intersecting_aabb, hgrid.rs:122-133), calls `distance` once for all of them
+ * (`shape.distance_to_point(pos, &pt, true)` per point) and reports those within the particle radius — one PCIe round trip of
+ * 16 bytes per candidate.  Both callbacks run on the calling thread, inside this call; neither may call back into the world. */
+typedef void (*SalvaHipHostAabbFn)(void* user, float* mins_xyz, float* maxs_xyz);
+typedef void (*SalvaHipHostDistanceFn)(void* user, uint32_t n, const float* points_xyz, float* distances);
+typedef struct SalvaHipHostQueryShape {
+    SalvaHipHostAabbFn aabb;
+    SalvaHipHostDistanceFn distance;
+    void* user;
+} SalvaHipHostQueryShape;
+int64_t salva_hip_particles_intersecting_host_shape(SalvaHipWorld* world, const SalvaHipHostQueryShape* shape, uint64_t capacity,
+                                                    uint32_t* kinds, uint32_t* slots, uint32_t* indices);
 
 /* ---- Rigid-body coupling, the DynamicContactSampling arm (src/integrations/rapier/fluids_pipeline.rs:42-43, 193-259) for
  * ball, cuboid, capsule (y) and cylinder (y) colliders: no sample points are kept; inside every salva_hip_step — after the fluids went into the grid and
@@ -424,7 +439,6 @@ int salva_hip_set_boundary_dynamic_sampling(SalvaHipWorld* world, uint32_t slot,
  * world-space projection and `proj.is_inside`), and finishes the loop body — push-out, reach test, emission — on the device
  * as for the built-in shapes.  Cost: two small PCIe round trips per step and collider.  The pose given to
  * salva_hip_update_boundary_pose is used for `velocity_at_point` only.  Neither callback may call back into the world. */
-typedef void (*SalvaHipHostAabbFn)(void* user, float* mins_xyz, float* maxs_xyz);
 typedef void (*SalvaHipHostProjectFn)(void* user, uint32_t n, const float* points_xyz, float* projections_xyz, uint8_t* is_inside);
 typedef struct SalvaHipHostShape {
     SalvaHipHostAabbFn aabb;

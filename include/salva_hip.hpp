@@ -385,6 +385,23 @@ class LiquidWorld {  // liquid_world.rs
             return salva_hip_particles_intersecting_shape(w_, translation.data(), rotation_ijkw.data(), &shape, cap, k, s, i);
         });
     }
+    // ... and for any other shape (the reference's query is generic over parry's `Shape`): `compute_aabb()` = shape.compute_aabb(pos)
+    // as (mins, maxs), `distance_to_point(n, points_xyz, out)` = shape.distance_to_point(pos, &pt, true) per point
+    std::vector<ParticleId> particles_intersecting_host_shape(std::function<std::pair<Vec3, Vec3>()> compute_aabb,
+                                                              std::function<void(uint32_t, const float*, float*)> distance_to_point) {
+        sync_for_query();
+        struct Ctx { decltype(compute_aabb)* a; decltype(distance_to_point)* d; } ctx{&compute_aabb, &distance_to_point};
+        SalvaHipHostQueryShape sh{};
+        sh.user = &ctx;
+        sh.aabb = [](void* u, float* mins, float* maxs) {
+            const auto box = (*static_cast<Ctx*>(u)->a)();
+            for (int k = 0; k < 3; ++k) { mins[k] = box.first[k]; maxs[k] = box.second[k]; }
+        };
+        sh.distance = [](void* u, uint32_t n, const float* pts, float* out) { (*static_cast<Ctx*>(u)->d)(n, pts, out); };
+        return run_query([&](uint64_t cap, uint32_t* k, uint32_t* s, uint32_t* i) {
+            return salva_hip_particles_intersecting_host_shape(w_, &sh, cap, k, s, i);
+        });
+    }
     // `world.counters` of the reference (counters/mod.rs:17-72): nsubsteps, step_time, custom, stages, cd, solver
     // Counters::enable / disable (counters/mod.rs:56-72); disabled by default, as in the reference
     void enable_counters(bool enabled = true) { check(salva_hip_enable_counters(w_, enabled ? 1 : 0)); }

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_delete_owned", "salva_hip_enable_counters", "salva_hip_comm_peer_begin", "salva_hip_comm_peer_connect",
     "salva_hip_comm_peer_abort", "salva_hip_comm_selftest", "salva_hip_comm_time", "salva_hip_clear_boundary_sampling", "salva_hip_get_fluid_async", "salva_hip_wait_download",
     "salva_hip_host_alloc", "salva_hip_host_free", "salva_hip_host_register", "salva_hip_host_unregister",
-    "salva_hip_set_cfl", "salva_hip_get_substeps",
+    "salva_hip_set_cfl", "salva_hip_get_substeps", "salva_hip_particles_intersecting_host_shape",
     "salva_hip_get_dist_timing", "salva_hip_local_len", "salva_hip_get_local", "salva_hip_get_local_contacts", "salva_hip_force_add_local_accelerations",
 ]
 
@@ -123,6 +123,14 @@ SHAPE_BALL, SHAPE_CUBOID, SHAPE_CAPSULE, SHAPE_CYLINDER = 1, 2, 3, 4
 
 HOST_AABB_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float))
 HOST_PROJECT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint8))
+
+
+HOST_DISTANCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+
+class HostQueryShape(C.Structure):
+    """SalvaHipHostQueryShape (include/salva_hip.h): a query shape whose geometry stays with the host."""
+    _fields_ = [("aabb", HOST_AABB_FN), ("distance", HOST_DISTANCE_FN), ("user", C.c_void_p)]
 
 
 class HostShape(C.Structure):
@@ -218,6 +226,8 @@ def lib():
     L.salva_hip_time_pred_density.restype = f32
     L.salva_hip_particles_intersecting_shape.argtypes = [vp, fp, fp, C.POINTER(Shape), u64, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.salva_hip_particles_intersecting_shape.restype = C.c_int64
+    L.salva_hip_particles_intersecting_host_shape.argtypes = [vp, C.POINTER(HostQueryShape), u64, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.salva_hip_particles_intersecting_host_shape.restype = C.c_int64
     L.salva_hip_delete_owned.argtypes = [vp, u32, C.POINTER(u32)]
     L.salva_hip_delete_owned.restype = C.c_int64
     L.salva_hip_rebalance.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]

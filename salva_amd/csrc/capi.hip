@@ -614,6 +614,17 @@ int64_t salva_hip_particles_intersecting_shape(SalvaHipWorld* world, const float
     });
     return rc == SALVA_HIP_OK ? total : (int64_t)rc;
 }
+int64_t salva_hip_particles_intersecting_host_shape(SalvaHipWorld* world, const SalvaHipHostQueryShape* shape, uint64_t capacity,
+                                                    uint32_t* kinds, uint32_t* slots, uint32_t* indices) {
+    int64_t total = 0;
+    const int rc = guarded([&]() -> int {
+        if (!world || !shape) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
+        not_in_force_callback(world);
+        total = (int64_t)world->w->particles_in_host_shape(*shape, capacity, kinds, slots, indices);
+        return SALVA_HIP_OK;
+    });
+    return rc == SALVA_HIP_OK ? total : (int64_t)rc;
+}
 int salva_hip_add_particles(SalvaHipWorld* world, uint32_t slot, uint64_t n_add, const float* positions_xyz, const float* velocities_xyz) {
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");

@@ -49,12 +49,22 @@ static inline uint32_t xcd_groups_for(uint32_t nl) {
     return lg;
 }
 template <typename FU, typename FM>
-static inline void launch_by_class(const StepCtx& c, FU&& uniform, FM&& mixed) {
+static inline void launch_by_class(const StepCtx& c, const TileLds& L, hipStream_t s, FU&& uniform, FM&& mixed) {
     StepCtx cu = c, cm = c;
     cu.cls_off = 0u; cu.nlaunch = c.n_uniform; cu.xcd = xcd_groups_for(cu.nlaunch);
     cm.cls_off = c.n_uniform; cm.nlaunch = c.nlaunch - c.n_uniform; cm.xcd = xcd_groups_for(cm.nlaunch); cm.tile_mass_bits = nullptr;
-    if (cu.nlaunch) uniform(cu);
-    if (cm.nlaunch) mixed(cm);
+    const bool fork = L.side_stream && L.side_stream != s && cm.nlaunch && cu.nlaunch;
+    if (fork) {  // the mixed tiles beside the uniform ones (TileLds::side_stream)
+        SALVA_HIP_CHECK(hipEventRecord(L.ev_fork, s));
+        SALVA_HIP_CHECK(hipStreamWaitEvent(L.side_stream, L.ev_fork, 0));
+        mixed(cm, L.side_stream);
+        SALVA_HIP_CHECK(hipEventRecord(L.ev_join, L.side_stream));
+        uniform(cu, s);
+        SALVA_HIP_CHECK(hipStreamWaitEvent(s, L.ev_join, 0));
+        return;
+    }
+    if (cu.nlaunch) uniform(cu, s);
+    if (cm.nlaunch) mixed(cm, s);
 }
 static inline bool by_class(const StepCtx& c) { return c.cls_slots != nullptr && c.tile_mass_bits != nullptr && c.cls_off == 0u && c.n_uniform > 0u; }
 
@@ -295,10 +305,10 @@ bool launch_density_alpha_div(const StepCtx& c, const TileLds& L, hipStream_t s)
 #ifndef SALVA_OTHER_KERNELS
     if ((c.sc.kd | c.sc.kg) != 0) return false;
     if (by_class(c)) {
-        launch_by_class(c, [&](const StepCtx& cu) {
+        launch_by_class(c, L, s, [&](const StepCtx& cu, hipStream_t s) {
             const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
             SALVA_LAUNCH_P3(k_density_alpha_div_p3, ds, cu, L, p3_bytes(L, ds, cu.nmodels, false), s, cu);
-        }, [&](const StepCtx& cm) {
+        }, [&](const StepCtx& cm, hipStream_t s) {
             // the mixed tiles: the density pass, then the solve's first evaluate as a pass of its own (their alpha is ready: the
             // stream orders the two; the control block is the previous solve's, hence none)
             SALVA_LAUNCH_TILE(k_density_alpha<false>, cm, L, L.bytes(16, 16, 2), s, cm, 0.0f);
@@ -488,10 +498,10 @@ __global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence, c, L, s);
     if (by_class(c)) {
-        launch_by_class(c, [&](const StepCtx& cu) {
+        launch_by_class(c, L, s, [&](const StepCtx& cu, hipStream_t s) {
             const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
             SALVA_LAUNCH_P3(k_divergence_p3, ds, cu, L, p3_bytes(L, ds, cu.nmodels, false), s, cu);
-        }, [&](const StepCtx& cm) {
+        }, [&](const StepCtx& cm, hipStream_t s) {
             const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
             SALVA_LAUNCH_FIXED(k_divergence, ds, cm, L, pw_bytes(L, ds, true), s, cm);
         });
@@ -630,10 +640,10 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence_apply, c, L, inv_dt_prev, s);
     if (by_class(c)) {  // (never with speculative applies: World::dfsph_solve — the test would ride in both launches)
-        launch_by_class(c, [&](const StepCtx& cu) {
+        launch_by_class(c, L, s, [&](const StepCtx& cu, hipStream_t s) {
             const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
             SALVA_LAUNCH_P2(k_divergence_apply_p2, ds, cu, L, p2_bytes(L, ds), s, cu, inv_dt_prev);
-        }, [&](const StepCtx& cm) {
+        }, [&](const StepCtx& cm, hipStream_t s) {
             const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
             SALVA_LAUNCH_FIXED(k_divergence_apply, ds, cm, L, pk_bytes(L, ds), s, cm, inv_dt_prev);
         });
@@ -816,10 +826,10 @@ __global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pred_density, c, L, dt, s);
     if (by_class(c)) {
-        launch_by_class(c, [&](const StepCtx& cu) {
+        launch_by_class(c, L, s, [&](const StepCtx& cu, hipStream_t s) {
             const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
             SALVA_LAUNCH_P3(k_pred_density_p3, ds, cu, L, p3_bytes(L, ds, cu.nmodels, !cu.bvel_zero), s, cu, dt);
-        }, [&](const StepCtx& cm) {
+        }, [&](const StepCtx& cm, hipStream_t s) {
             const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
             SALVA_LAUNCH_FIXED(k_pred_density, ds, cm, L, pw_bytes(L, ds, true), s, cm, dt);
         });
@@ -945,10 +955,10 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pressure_apply, c, L, inv_dt, s);
     if (by_class(c)) {
-        launch_by_class(c, [&](const StepCtx& cu) {
+        launch_by_class(c, L, s, [&](const StepCtx& cu, hipStream_t s) {
             const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
             SALVA_LAUNCH_P2(k_pressure_apply_p2, ds, cu, L, p2_bytes(L, ds), s, cu, inv_dt);
-        }, [&](const StepCtx& cm) {
+        }, [&](const StepCtx& cm, hipStream_t s) {
             const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
             SALVA_LAUNCH_FIXED(k_pressure_apply, ds, cm, L, pk_bytes(L, ds), s, cm, inv_dt);
         });

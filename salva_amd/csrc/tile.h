@@ -53,6 +53,11 @@ struct TileLds {
     // the plane layouts (stage_p3), which are filled through registers and need no 64-slot granularity
     uint32_t max_raw = 0;
     uint32_t ds_level = 0;  // SALVA_HIP_DS_LEVEL (pairs.h pick_ds*): 0 in production
+    // tile classes (device_types.h StepCtx::cls_slots): the launch over the mixed tiles — a few hundred workgroups, one round of a
+    // few microseconds that would otherwise run alone between two full launches — goes to a second stream, forked and joined by
+    // events, so that it shares the chip with the launch over the uniform tiles.  Null: one after the other on the pass's stream.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t raw_slots() const { return max_raw ? max_raw : max_halo_fluid + max_halo_boundary; }
     uint32_t sum_slots() const {
         const uint32_t worst = ((max_halo_fluid + 63u) & ~63u) + max_halo_boundary;

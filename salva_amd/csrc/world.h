@@ -66,6 +66,8 @@ class World {
                                uint32_t* indices);
     uint64_t particles_in_shape(const float t[3], const float q[4], const SalvaHipShape& shape, uint64_t capacity, uint32_t* kinds,
                                 uint32_t* slots, uint32_t* indices);
+    uint64_t particles_in_host_shape(const SalvaHipHostQueryShape& shape, uint64_t capacity, uint32_t* kinds, uint32_t* slots, uint32_t* indices);
+    void map_query_hits(std::vector<uint64_t>& keys, uint32_t* kinds, uint32_t* slots, uint32_t* indices);
     void get_fluid(uint32_t slot, float* pos, float* vel);
     void get_force_stats(uint32_t slot, uint32_t force, int32_t* iters, float* err);
     uint64_t get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offsets, uint32_t* j_model, uint32_t* j, uint64_t capacity);

@@ -1314,6 +1314,7 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     for (int attempt = 0;; ++attempt) {
     bool spec = can_speculate && attempt == 0;
     classes_wanted = classes_active = false;
+    lds.side_stream = nullptr;
     // (mass_known && mass_uniform == 0: what the last exact pass found; a host edit clears mass_known and the first pass after it
     // runs without classes — its k_cell_keys finds out)
     const bool classes_now = classes_possible && mass_known && mass_uniform == 0.0f;
@@ -1498,6 +1499,10 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             n_uniform_tiles = std::min(h_rb->n_uniform_tiles, nlaunch);
             classes_active = n_uniform_tiles > 0u;
             classes_wanted = false;
+            // (the two events are the decomposed runs' — which never have classes)
+            static const bool no_fork = getenv("SALVA_HIP_NO_CLASS_FORK") != nullptr;  // A/B: the two launches one after the other
+            lds.side_stream = (classes_active && !no_fork) ? stream2 : nullptr;
+            lds.ev_fork = ev_pre_refresh; lds.ev_join = ev_interior;
             c = make_ctx();
         }
     }
@@ -1668,6 +1673,12 @@ uint64_t World::collect_query(unsigned int* d_count, uint32_t* d_kind, uint32_t*
     SALVA_HIP_CHECK(hipMemcpy(hi_.data(), d_index, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::vector<uint64_t> keys(m);
     for (uint32_t k = 0; k < m; ++k) keys[k] = ((uint64_t)hk[k] << 32) | hi_[k];
+    map_query_hits(keys, kinds, slots, indices);
+    return total;
+}
+// (kind word << 32 | global index) keys -> sorted (kind, slot, index-in-slot) triples
+void World::map_query_hits(std::vector<uint64_t>& keys, uint32_t* kinds, uint32_t* slots, uint32_t* indices) {
+    const uint32_t m = (uint32_t)keys.size();
     std::sort(keys.begin(), keys.end());
     for (uint32_t k = 0; k < m; ++k) {
         uint32_t kind = (uint32_t)(keys[k] >> 32);
@@ -1682,7 +1693,6 @@ uint64_t World::collect_query(unsigned int* d_count, uint32_t* d_kind, uint32_t*
         else { while (s + 1 < bounds.size() && g >= bounds[s].n) { g -= bounds[s].n; ++s; } }
         kinds[k] = kind; slots[k] = s; indices[k] = (uint32_t)g;
     }
-    return total;
 }
 
 uint64_t World::particles_in_aabb(const float mins[3], const float maxs[3], uint64_t capacity, uint32_t* kinds, uint32_t* slots,
@@ -1780,6 +1790,72 @@ uint64_t World::particles_in_shape(const float t[3], const float q[4], const Sal
     if (qf.n) k_shape_query<<<nblk(qf.n), BLOCK, 0, stream>>>(qf, s, 0u, cnt.p, cap, dk.p, di.p);
     if (nb) k_shape_query<<<nblk(nb), BLOCK, 0, stream>>>(qb, s, 1u, cnt.p, cap, dk.p, di.p);
     return collect_query(cnt.p, dk.p, di.p, cap, kinds, slots, indices);
+}
+
+// LiquidWorld::particles_intersecting_shape for a shape whose geometry stays with the host (any parry `Shape`: the reference's
+// query is generic, liquid_world.rs:247-280): the two parry calls — `shape.compute_aabb(pos)` and `shape.distance_to_point(pos,
+// &pt, true)` — are callbacks; the device keeps the cell filter (hgrid.cells_intersecting_aabb, hgrid.rs:122-133) and hands the
+// particles of those cells to the host in one copy.
+__global__ __launch_bounds__(BLOCK) void k_cell_range_query(QuerySrc q, int clo0, int clo1, int clo2, int chi0, int chi1, int chi2, float h,
+                                                            uint32_t kind, unsigned int* __restrict__ counter, uint32_t cap,
+                                                            uint32_t* __restrict__ out_kind, uint32_t* __restrict__ out_index,
+                                                            float4* __restrict__ out_pos) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= q.n || query_skip(q, i)) return;
+    const float4 pt = q.pos[i];
+    bool bad = false;
+    const int cx = cell_coord(pt.x, h, bad), cy = cell_coord(pt.y, h, bad), cz = cell_coord(pt.z, h, bad);
+    if (bad || cx < clo0 || cx > chi0 || cy < clo1 || cy > chi1 || cz < clo2 || cz > chi2) return;
+    const uint32_t k = atomicAdd(counter, 1u);
+    if (k < cap) { out_kind[k] = kind | (q.model ? q.model[i] << 8 : 0u); out_index[k] = q.gid ? q.gid[i] : i; out_pos[k] = pt; }
+}
+uint64_t World::particles_in_host_shape(const SalvaHipHostQueryShape& shape, uint64_t capacity, uint32_t* kinds, uint32_t* slots,
+                                        uint32_t* indices) {
+    use_device();
+    if (!shape.aabb || !shape.distance) throw HipError(SALVA_HIP_E_INVALID, "a host query shape needs both callbacks");
+    float mins[3], maxs[3];
+    shape.aabb(shape.user, mins, maxs);
+    int clo[3], chi[3];
+    for (int a = 0; a < 3; ++a) {
+        if (!(mins[a] <= maxs[a]) || !std::isfinite(mins[a]) || !std::isfinite(maxs[a]))
+            throw HipError(SALVA_HIP_E_INVALID, "host query shape: the aabb callback returned an empty, infinite or NaN box");
+        clo[a] = (int)std::min(std::max(floorf(mins[a] / sc.h), -1073741824.0f), 1073741824.0f);
+        chi[a] = (int)std::min(std::max(floorf(maxs[a] / sc.h), -1073741824.0f), 1073741824.0f);
+    }
+    const QuerySrc qf = query_fluid_source(), qb{bst_pos.p, nb, nullptr, nullptr, nullptr};
+    const uint32_t ccap = qf.n + nb;  // every particle can be a candidate
+    DevBuf<unsigned int> cnt;
+    DevBuf<uint32_t> dk, di;
+    DevBuf<float4> dp;
+    cnt.ensure(1); dk.ensure(std::max(ccap, 1u)); di.ensure(std::max(ccap, 1u)); dp.ensure(std::max(ccap, 1u));
+    SALVA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(unsigned int), stream));
+    if (qf.n) k_cell_range_query<<<nblk(qf.n), BLOCK, 0, stream>>>(qf, clo[0], clo[1], clo[2], chi[0], chi[1], chi[2], sc.h, 0u, cnt.p, ccap, dk.p, di.p, dp.p);
+    if (nb) k_cell_range_query<<<nblk(nb), BLOCK, 0, stream>>>(qb, clo[0], clo[1], clo[2], chi[0], chi[1], chi[2], sc.h, 1u, cnt.p, ccap, dk.p, di.p, dp.p);
+    unsigned int m = 0;
+    SALVA_HIP_CHECK(hipMemcpyAsync(&m, cnt.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+    m = std::min<unsigned int>(m, ccap);
+    if (m == 0) return 0;
+    std::vector<uint32_t> hk(m), hi_(m);
+    std::vector<float4> hp(m);
+    SALVA_HIP_CHECK(hipMemcpy(hk.data(), dk.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SALVA_HIP_CHECK(hipMemcpy(hi_.data(), di.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    SALVA_HIP_CHECK(hipMemcpy(hp.data(), dp.p, m * sizeof(float4), hipMemcpyDeviceToHost));
+    std::vector<float> pts(3 * (size_t)m), dist((size_t)m, std::numeric_limits<float>::infinity());
+    for (unsigned int k = 0; k < m; ++k) { pts[3 * k] = hp[k].x; pts[3 * k + 1] = hp[k].y; pts[3 * k + 2] = hp[k].z; }
+    shape.distance(shape.user, m, pts.data(), dist.data());
+    std::vector<uint64_t> keys;
+    keys.reserve(m);
+    for (unsigned int k = 0; k < m; ++k)
+        if (dist[k] <= prm.particle_radius) keys.push_back(((uint64_t)hk[k] << 32) | hi_[k]);  // liquid_world.rs:263, :272 (NaN: not a hit)
+    const uint64_t total = keys.size();
+    if (total == 0 || !kinds || !slots || !indices) return total;
+    if (keys.size() > capacity) {  // the first `capacity` in the sorted order, like the device arms
+        std::sort(keys.begin(), keys.end());
+        keys.resize((size_t)capacity);
+    }
+    map_query_hits(keys, kinds, slots, indices);
+    return total;
 }
 
 // The contact lists of the last step (they describe the positions the step started from, as the reference's

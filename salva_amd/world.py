@@ -1293,6 +1293,52 @@ class LiquidWorld:
             out.append(("boundary" if k[j] else "fluid", owner, int(i[j])))
         return out
 
+    def particles_intersecting_host_shape(self, compute_aabb, distance_to_point):
+        """liquid_world.rs:245-280 for any shape the host can describe (the reference's query is generic over parry's `Shape`):
+        `compute_aabb() -> (mins, maxs)` is `shape.compute_aabb(pos)`, `distance_to_point(points (n, 3)) -> (n,)` is
+        `shape.distance_to_point(pos, &pt, true)` per point.  Same output as `particles_intersecting_shape`."""
+        self.sync_to_device(apply_removal=False)
+        err = []
+
+        def aabb_cb(_user, mins, maxs):
+            try:
+                lo, hi = compute_aabb()
+                for a in range(3):
+                    mins[a], maxs[a] = float(lo[a]), float(hi[a])
+            except BaseException as e:  # noqa: BLE001 - ctypes cannot propagate it: parked, re-raised below
+                err.append(e)
+                for a in range(3):
+                    mins[a] = maxs[a] = float("nan")
+
+        def dist_cb(_user, n, pts, out):
+            try:
+                d = np.asarray(distance_to_point(np.ctypeslib.as_array(pts, shape=(n, 3)).copy()), F32).reshape(n)
+                np.ctypeslib.as_array(out, shape=(n,))[:] = d
+            except BaseException as e:  # noqa: BLE001
+                err.append(e)
+                np.ctypeslib.as_array(out, shape=(n,))[:] = np.inf
+
+        thunks = (L.HOST_AABB_FN(aabb_cb), L.HOST_DISTANCE_FN(dist_cb))
+        sh = L.HostQueryShape(thunks[0], thunks[1], None)
+        u32p = C.POINTER(C.c_uint32)
+        cap = 1024
+        while True:
+            k, s, i = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+            total = int(self._L.salva_hip_particles_intersecting_host_shape(self._h, C.byref(sh), cap, k.ctypes.data_as(u32p),
+                                                                             s.ctypes.data_as(u32p), i.ctypes.data_as(u32p)))
+            if err:
+                raise err[0]
+            if total < 0:
+                L.check(total)
+            if total <= cap:
+                break
+            cap = total
+        out = []
+        for j in range(total):
+            owner = self._boundaries._items[int(s[j])] if k[j] else self._fluids._items[int(s[j])]
+            out.append(("boundary" if k[j] else "fluid", owner, int(i[j])))
+        return out
+
     def device_bytes(self) -> int:
         return int(self._L.salva_hip_device_bytes(self._h))
 

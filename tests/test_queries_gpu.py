@@ -71,3 +71,60 @@ def test_shape_query_matches_the_reference_formula(shape):
     assert len(gf) > 100 and len(gb) > 10
     # the AABB query the reference pairs it with still answers (liquid_world.rs:210-243)
     assert len(w.particles_intersecting_aabb(t - 0.1, t + 0.1)) > 0
+
+
+def test_host_shape_query_is_the_generic_arm_of_the_reference():
+    """`particles_intersecting_shape` is generic over parry's `Shape` in the reference (liquid_world.rs:247-250).  Shapes the device
+    does not know keep their geometry on the host: `compute_aabb` and `distance_to_point` are callbacks
+    (salva_hip_particles_intersecting_host_shape), the cell filter and the scan stay on the device.  (a) A ball and a cuboid handed
+    over that way answer exactly like the device arms; (b) a torus — no device arm exists — matches a numpy restatement."""
+    pos = scenes.jitter(scenes.cube_fluid_positions(20, 20, 20, R), 0.3 * R, seed=9)
+    bpos = scenes.plane_lattice(30, 30, -0.55, R, -0.75, -0.75)
+    w = LiquidWorld(DFSPHSolver(), R, 2.0)
+    f = w.add_fluid(Fluid(pos, R, 1000.0))
+    b = w.add_boundary(Boundary(bpos))
+    t = np.array([0.13, -0.42, 0.05], F)
+    ang = 0.7
+    axis = np.array([1.0, 2.0, -0.5]) / np.linalg.norm([1.0, 2.0, -0.5])
+    q = np.concatenate([axis * np.sin(ang / 2), [np.cos(ang / 2)]]).astype(F)
+    for shape in (("ball", 0.22), ("cuboid", (0.3, 0.1, 0.2))):
+        # the same f32 arithmetic as the device's (dcs.hip shape_world_extent; k_shape_query) would be needed for set equality on
+        # the rounding band: compare outside that band
+        def aabb(shape=shape):
+            Rm = np.stack([quat_rotate(np.asarray(q, np.float64), e) for e in np.eye(3)], axis=1)
+            ext = np.full(3, shape[1]) if shape[0] == "ball" else np.abs(Rm) @ np.asarray(shape[1], np.float64)
+            return t - ext, t + ext
+
+        def dist(pts, shape=shape):
+            return reference(pts, t, q, shape)[0]
+
+        got = set((k, id(h), i) for k, h, i in w.particles_intersecting_host_shape(aabb, dist))
+        dev = set((k, id(h), i) for k, h, i in w.particles_intersecting_shape(t, q, shape))
+        band = set()
+        for kind, owner, pts in (("fluid", f, pos), ("boundary", b, bpos)):
+            d, inside = reference(pts, t, q, shape)
+            band |= {(kind, id(owner), int(i)) for i in np.nonzero((np.abs(d - R) <= 1e-4 * R) | ~inside)[0]}
+        assert (got ^ dev) <= band, len(got ^ dev)
+        assert len(got) > 100
+
+    # (b) a torus around the y axis (major radius 0.3, minor 0.08), translated: distance = | (|xz| - R_major, y) | - r_minor
+    RM, rm = 0.3, 0.08
+    c = np.array([0.05, -0.3, 0.0])
+
+    def torus_dist(pts):
+        l = pts.astype(np.float64) - c
+        return np.maximum(np.hypot(np.hypot(l[:, 0], l[:, 2]) - RM, l[:, 1]) - rm, 0.0)
+
+    lo, hi = c - np.array([RM + rm, rm, RM + rm]), c + np.array([RM + rm, rm, RM + rm])
+    got = w.particles_intersecting_host_shape(lambda: (lo, hi), torus_dist)
+    gf = sorted(i for kind, h, i in got if kind == "fluid" and h is f)
+    gb = sorted(i for kind, h, i in got if kind == "boundary" and h is b)
+    assert len(gf) + len(gb) == len(got) and len(gf) > 50
+    for pts, g in ((pos, gf), (bpos, gb)):
+        cell = np.floor(pts.astype(np.float32) / np.float32(H))  # (f32, correctly rounded: the device's cell_coord)
+        inside = ((cell >= np.floor(lo.astype(np.float32) / np.float32(H))) & (cell <= np.floor(hi.astype(np.float32) / np.float32(H)))).all(axis=1)
+        want = set(np.nonzero(inside & (torus_dist(pts).astype(np.float32) <= np.float32(R)))[0].tolist())
+        assert set(g) == want, (len(g), len(want))
+    # a callback that raises is re-raised here, not swallowed (ctypes cannot propagate it: the thunk parks it)
+    with pytest.raises(ZeroDivisionError):
+        w.particles_intersecting_host_shape(lambda: (lo, hi), lambda pts: 1 / 0)
