@@ -204,9 +204,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
     Tile t;
     t.setup(c);
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
-    struct Own { float4 pi, wi; uint32_t mi, cnt, cntb; ListRegs lh; };
+    struct Own { float px, py, pz, ux, uy, uz; uint32_t cnt; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.w[i], c.model[i], c.nff[i], c.nb ? c.nfb[i] : 0u, list_regs(c, gs)};
+        const float4 p = c.posm[i], u = c.w[i];
+        return Own{p.x, p.y, p.z, u.x, u.y, u.z, c.nff[i], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
     const float m = t.mass;
     t.for_own_pre(own0, load_own, [&](const Own& o, uint32_t i, uint32_t gs, bool active) {
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
-        const float4 pi = o.pi, wi = o.wi;
+        // (the own mass, the model and the boundary count are loaded after the loop: nothing the loop does not need is carried across it)
+        const float3 pi = make_float3(o.px, o.py, o.pz), wi = make_float3(o.ux, o.uy, o.uz);
         float rho = 0.0f, gsx = 0.0f, gsy = 0.0f, gsz = 0.0f, sq = 0.0f, div = 0.0f;
         uint32_t nnear = 0;
         if (active) {  // (an idle lane's list row was never written)
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
-            mi = o.mi;
+            mi = c.model[i];
             const float rho0 = rho0_of(c, mi);
             for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Bp[s];
@@ -289,8 +291,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
             const float alpha = (denom <= 1.0e-5f) ? 0.0f : 1.0f / denom;
             c.rho[i] = rho;
             c.alpha[i] = alpha;
-            c.posmr[i] = make_float4(pi.x, pi.y, pi.z, pi.w / rho);
-            div = (o.cnt + o.cntb >= c.min_neighbors_for_divergence) ? fmaxf(div, 0.0f) : 0.0f;
+            c.posmr[i] = make_float4(pi.x, pi.y, pi.z, c.posm[i].w / rho);
+            const uint32_t cntb = c.nb ? c.nfb[i] : 0u;
+            div = (o.cnt + cntb >= c.min_neighbors_for_divergence) ? fmaxf(div, 0.0f) : 0.0f;
             c.kappa[i] = div * alpha;
             err = div / rho0;
         }

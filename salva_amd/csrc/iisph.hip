@@ -138,9 +138,12 @@ __global__ SALVA_IISPH_P3_BOUNDS(DS) void k_iisph_pred_density_p3(StepCtx c, flo
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    struct Own { float4 pi, wi; float rho; uint32_t mi, cnt, near; ListRegs lh; };
+    // (three-component vectors, and rho_i / the model are loaded after the loop: no register carries them across it — the kernel
+    // held to 80 VGPRs for the third tile spilled eight before, none now)
+    struct Own { float px, py, pz, ux, uy, uz; uint32_t cnt, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.w[i], c.rho[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+        const float4 p = c.posm[i], u = c.w[i];
+        return Own{p.x, p.y, p.z, u.x, u.y, u.z, c.nff[i], c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -156,8 +159,8 @@ __global__ SALVA_IISPH_P3_BOUNDS(DS) void k_iisph_pred_density_p3(StepCtx c, flo
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
         const bool near = slice_is_near(c, o.near);
         if (!active) return;
-        const float4 pi = o.pi, wi = o.wi;
-        const float rho0 = rho0_of(c, o.mi);
+        const float4 pi = make_float4(o.px, o.py, o.pz, 0.0f), wi = make_float4(o.ux, o.uy, o.uz, 0.0f);
+        const float rho0 = t.SB ? rho0_of(c, c.model[i]) : 0.0f;  // (only the boundary arm weighs by it)
         float delta = near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8, t.mass)
                            : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8, t.mass);
         for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
@@ -167,7 +170,7 @@ __global__ SALVA_IISPH_P3_BOUNDS(DS) void k_iisph_pred_density_p3(StepCtx c, flo
             const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
             delta += pj.w * rho0 * (((wi.x - vj.x) * dx + (wi.y - vj.y) * dy + (wi.z - vj.z) * dz) * g);
         });
-        const float rs = o.rho + delta * dt;
+        const float rs = c.rho[i] + delta * dt;
         if (!(rs != 0.0f)) atomicOr(c.flags, 1u);  // :140
         c.rho_star[i] = rs;
     });
@@ -382,10 +385,13 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_iisph_next_pressure(StepCt
     E.finish(c, t.slot);
 }
 // the plane-layout form: planes (x, y) | (z, q.x) | (q.y, q.z), the uniform mass applied to the two finished sums
-// (87 VGPRs, two tiles per CU: held to 80 for a third tile this kernel spills nine registers — 61.8 us against 57.8, and 59.0 on
-// the 32-byte layout; profiles/r04_experiments/r04l_iisph_next_pressure.log)
+// (round 4: 87 VGPRs, two tiles per CU; held to 80 for a third tile it spilled nine registers — 61.8 us against 57.8, and 59.0 on
+// the 32-byte layout, profiles/r04_experiments/r04l_iisph_next_pressure.log.  Round 5: 80 VGPRs without scratch, see the Own record below)
 #ifndef SALVA_IISPH_NP_WAVES
-#define SALVA_IISPH_NP_WAVES 5
+#define SALVA_IISPH_NP_WAVES 6
+#endif
+#ifndef SALVA_IISPH_NP_NARROW
+#define SALVA_IISPH_NP_NARROW false
 #endif
 template <uint32_t DS>
 __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_IISPH_NP_WAVES : 5) void k_iisph_next_pressure_p3(StepCtx c, float dt, float omega, const float* __restrict__ p,
@@ -395,9 +401,13 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_IISPH
     Tile t;
     t.setup(c);
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
-    struct Own { float4 pi, dpi; float a, prs, rhoi, rstar; uint32_t mi, cnt, near; ListRegs lh; };
+    // (the per-lane record holds what the LOOP needs and nothing else: the position and sum_j d_ij p_j.  Everything the result is
+    // made of afterwards — a_ii, p_i, rho_i, rho*_i, m_i — is loaded after the loop (five cached words per particle), so that no
+    // register carries it across the loop: the kernel then fits 80 VGPRs, i.e. a third resident tile)
+    struct Own { float px, py, pz, ex, ey, ez; uint32_t cnt, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.dijpj[i], c.aii[i], p[i], c.rho[i], c.rho_star[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+        const float4 pi = c.posm[i], dpi = c.dijpj[i];
+        return Own{pi.x, pi.y, pi.z, dpi.x, dpi.y, dpi.z, c.nff[i], c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -415,50 +425,52 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_IISPH
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
-            mi = o.mi;
-            const float a = o.a;
+            const float3 pi = make_float3(o.px, o.py, o.pz), dpi = make_float3(o.ex, o.ey, o.ez);
+            // sum_j m_j (sum d p - q_j + grad W f p_i) . grad W with grad W = G d: m (sum_a + f p_i sum_b), the two sums below
+            float suma = 0.0f, sumb = 0.0f;
+            if (near) {
+                for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                    const RecP3 A = load_p3(s << 3, dist8);
+                    const float dx = pi.x - A.xy.x, dy = pi.y - A.xy.y, dz = pi.z - A.zu.x;
+                    const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                    const float gx = dx * g, gy = dy * g, gz = dz * g;
+                    suma += (dpi.x - A.zu.y) * gx + (dpi.y - A.vw.x) * gy + (dpi.z - A.vw.y) * gz;
+                    sumb += gx * gx + gy * gy + gz * gz;
+                });
+            } else {
+                f2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+                const f2 tiny = {1.0e-30f, 1.0e-30f};
+                for_each_ff2<true, false, 2>(c, gs, nqu, o.lh, [&](uint32_t off) { return load_p3(off, dist8); },
+                                             [&](const RecP3& A, const RecP3& B) { SALVA_PAIR_MATH
+                    const f2 dx = {pi.x - A.xy.x, pi.x - B.xy.x}, dy = {pi.y - A.xy.y, pi.y - B.xy.y}, dz = {pi.z - A.zu.x, pi.z - B.zu.x};
+                    f2 r2 = dz * dz + tiny;
+                    r2 = dy * dy + r2;
+                    r2 = dx * dx + r2;
+                    const f2 g = kernel_gfac2(r2, c.sc);
+                    const f2 ex = {dpi.x - A.zu.y, dpi.x - B.zu.y}, ey = {dpi.y - A.vw.x, dpi.y - B.vw.x}, ez = {dpi.z - A.vw.y, dpi.z - B.vw.y};
+                    sa += (ex * dx + ey * dy + ez * dz) * g;
+                    sb += (g * g) * r2;
+                });
+                suma = (sa.x + sa.y) * c.sc.gscale;
+                sumb = (sb.x + sb.y) * (c.sc.gscale * c.sc.gscale);
+            }
+            float bsum = 0.0f;
+            for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
+                const float4 pj = Bp[s];
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+                bsum += pj.w * ((dpi.x * dx + dpi.y * dy + dpi.z * dz) * g);
+            });
+            // ---- the particle's own scalars, only now
+            mi = c.model[i];
+            const float a = c.aii[i];
             float pn = 0.0f;
             if (fabsf(a) > 1.0e-9f) {
                 const float rho0 = rho0_of(c, mi);
-                const float4 pi = o.pi, dpi = o.dpi;
-                const float prs = o.prs;
-                const float derr = rho0 - o.rstar;
-                const float fji = dt * dt * pi.w / (o.rhoi * o.rhoi);
-                float sum = 0.0f;
-                if (near) {
-                    for_each_ff(c, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
-                        const RecP3 A = load_p3(s << 3, dist8);
-                        const float dx = pi.x - A.xy.x, dy = pi.y - A.xy.y, dz = pi.z - A.zu.x;
-                        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-                        const float gx = dx * g, gy = dy * g, gz = dz * g;
-                        const float fx = (dpi.x - A.zu.y) + gx * fji * prs;
-                        const float fy = (dpi.y - A.vw.x) + gy * fji * prs;
-                        const float fz = (dpi.z - A.vw.y) + gz * fji * prs;
-                        sum += fx * gx + fy * gy + fz * gz;
-                    });
-                    sum *= c.mass_uniform;
-                } else {
-                    f2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
-                    const f2 tiny = {1.0e-30f, 1.0e-30f};
-                    for_each_ff2<true, false, 2>(c, gs, nqu, o.lh, [&](uint32_t off) { return load_p3(off, dist8); },
-                                                 [&](const RecP3& A, const RecP3& B) { SALVA_PAIR_MATH
-                        const f2 dx = {pi.x - A.xy.x, pi.x - B.xy.x}, dy = {pi.y - A.xy.y, pi.y - B.xy.y}, dz = {pi.z - A.zu.x, pi.z - B.zu.x};
-                        f2 r2 = dz * dz + tiny;
-                        r2 = dy * dy + r2;
-                        r2 = dx * dx + r2;
-                        const f2 g = kernel_gfac2(r2, c.sc);
-                        const f2 ex = {dpi.x - A.zu.y, dpi.x - B.zu.y}, ey = {dpi.y - A.vw.x, dpi.y - B.vw.x}, ez = {dpi.z - A.vw.y, dpi.z - B.vw.y};
-                        sa += (ex * dx + ey * dy + ez * dz) * g;
-                        sb += (g * g) * r2;
-                    });
-                    sum = ((sa.x + sa.y) * c.sc.gscale + (sb.x + sb.y) * (c.sc.gscale * c.sc.gscale) * (fji * prs)) * c.mass_uniform;
-                }
-                for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
-                    const float4 pj = Bp[s];
-                    const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                    const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
-                    sum += pj.w * rho0 * ((dpi.x * dx + dpi.y * dy + dpi.z * dz) * g);
-                });
+                const float prs = p[i], rhoi = c.rho[i];
+                const float derr = rho0 - c.rho_star[i];
+                const float fp = dt * dt * c.posm[i].w / (rhoi * rhoi) * prs;  // f_ji p_i, f_ji = dt^2 m_i / rho_i^2
+                const float sum = (suma + sumb * fp) * c.mass_uniform + rho0 * bsum;
                 pn = (1.0f - omega) * prs + omega * (derr - sum) / a;
                 if (pn > 0.0f) err = (-sum - a * pn) / rho0;
                 else pn = 0.0f;  // clamp negative pressures (:336-339)

@@ -786,9 +786,22 @@ template <int OFF> __device__ __forceinline__ uint32_t entry_hi(uint32_t a) { re
 
 // FUSED: a step over two list dwords (four contacts) is ONE basic block — the two packed chains are independent, and only
 // inside one block can the scheduler interleave them (each chain alone is ~20 dependent packed operations deep).
-template <bool AHEAD = true, bool FUSED = false, int OFF = 0, typename L, typename C2>
+// NARROW: one list dword (two contacts) in flight instead of two (four) — 12 VGPRs fewer in the plane layouts, for kernels whose
+// per-lane state would otherwise cost them a resident tile (k_iisph_next_pressure_p3).
+template <bool AHEAD = true, bool FUSED = false, int OFF = 0, bool NARROW = false, typename L, typename C2>
 __device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, uint32_t nq, const ListRegs& lr, L&& load,
                                              C2&& compute2) {
+    if (NARROW) {
+#pragma unroll
+        for (int k = 0; k < LIST_REGS; ++k) {
+            if ((uint32_t)k < nq) {
+                const uint32_t a = lr.d[k];
+                const auto d0 = load(entry_lo<OFF>(a));
+                const auto d1 = load(entry_hi<OFF>(a));
+                compute2(d0, d1);
+            }
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < LIST_REGS; k += 2) {
         if (FUSED) {
@@ -817,6 +830,7 @@ __device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, 
             compute2(d0, d1);
             if (two) compute2(d2, d3);
         }
+    }
     }
     if (nq > (uint32_t)LIST_REGS) {  // unusually long lists: the rest comes from memory, one dword ahead
         const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + 4u * (threadIdx.x & (WAVE - 1));
