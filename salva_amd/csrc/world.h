@@ -229,7 +229,7 @@ class World {
     // Tile classes (device_types.h StepCtx::cls_slots): worlds known to hold more than one mass run their DFSPH passes as two
     // launches, plane-layout kernels over the tiles whose halo has one mass and general kernels over the rest.
     DevBuf<uint32_t> cls_slots, tile_mass_bits;
-    bool classes_off = false;     // SALVA_HIP_NO_TILE_CLASSES=1 (A/B, tests)
+    bool classes_off = true;      // on with SALVA_HIP_TILE_CLASSES=1 only: measured slower than the general kernels
     bool classes_wanted = false;  // this pass builds the class tables (k_nbr_tile reduces the halo masses)
     bool classes_active = false;  // ... and they are known on the host: make_ctx hands them to the launchers
     uint32_t n_uniform_tiles = 0;

@@ -134,7 +134,9 @@ World::World(const SalvaHipParams& p) : prm(p) {
     defer_off = getenv("SALVA_HIP_NO_DEFER_LISTS") != nullptr;
     spec_apply_off = getenv("SALVA_HIP_NO_SPEC_APPLY") != nullptr;
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
-    classes_off = getenv("SALVA_HIP_NO_TILE_CLASSES") != nullptr;
+    // (measured slower than the general kernels on BASELINE config 4 — 2.67 against 2.60 ms per step: the second launch of every pass,
+    // a few hundred mixed tiles running alone, costs more than the third resident tile returns on the others; DESIGN.md §3.3.  Opt-in.)
+    classes_off = getenv("SALVA_HIP_TILE_CLASSES") == nullptr;
     tile_trace = getenv("SALVA_HIP_TILE_TRACE") != nullptr;
     no_fused_div = getenv("SALVA_HIP_NO_FUSED_DIV") != nullptr;
     if (const char* e = getenv("SALVA_HIP_RADIX_SORT")) sort_mode = atoi(e) != 0 ? 1 : 0;
@@ -1500,8 +1502,8 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             classes_active = n_uniform_tiles > 0u;
             classes_wanted = false;
             // (the two events are the decomposed runs' — which never have classes)
-            static const bool no_fork = getenv("SALVA_HIP_NO_CLASS_FORK") != nullptr;  // A/B: the two launches one after the other
-            lds.side_stream = (classes_active && !no_fork) ? stream2 : nullptr;
+            static const bool fork = getenv("SALVA_HIP_CLASS_FORK") != nullptr;  // A/B: the mixed tiles' launch on a second stream (measured slower still)
+            lds.side_stream = (classes_active && fork) ? stream2 : nullptr;
             lds.ev_fork = ev_pre_refresh; lds.ev_join = ev_interior;
             c = make_ctx();
         }

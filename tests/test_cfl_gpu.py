@@ -22,35 +22,50 @@ def _dam_break(solver="dfsph", forces=(("xsph", 0.5, 0.0),)):
 
 @pytest.mark.parametrize("solver,mode", [("dfsph", 1), ("dfsph", 2), ("iisph", 1)])
 def test_cfl_substeps_match_the_oracle_on_the_dam_break(solver, mode):
+    """Frame-sized steps (1/60 s) of a collapsing column: the substep is 0.4 * 2r / max_i |v_i + a_i t| — a maximum, i.e. the fastest
+    splash particle decides, and at up to 0.4 particle diameters per substep two f32 trajectories part by rounding within a dozen
+    steps.  The yardstick is therefore the oracle's own f32-vs-f64 distance: the device must follow the f32 build
+    within max(rounding growth, 3 x that distance), and where the oracle's two precisions take a different NUMBER of substeps the
+    device must take one of the two."""
     s = _dam_break(solver)
     w, (fl,), _ = s.make_hip()
     o = s.make_oracle(threads=4)
+    o64 = s.make_oracle(threads=4, f64=True)
     w.set_cfl_substepping(mode)
     o.set_cfl(mode)
+    o64.set_cfl(mode)
     w.counters.enable()
-    nsub_total, multi = 0, 0
+    nsub_total, multi, split = 0, 0, 0
     n = 36
     for k in range(n):
         st = w.step(DT, GRAVITY)
         so = o.step(DT, GRAVITY)
-        sw, sr = w.substeps(), o.substeps()
-        assert w.counters.nsubsteps == len(sw) == len(sr), (k, sw, sr)
-        # the substep is a function of max |v + a t|: equal up to the rounding of the sums behind v and a
-        assert np.allclose(sw, sr, rtol=2e-4 * (k + 1)), (k, sw, sr)
+        s64 = o64.step(DT, GRAVITY)
+        sw, sr, sd = np.asarray(w.substeps()), np.asarray(o.substeps()), np.asarray(o64.substeps())
+        assert w.counters.nsubsteps == len(sw)
+        if len(sr) == len(sd):
+            assert len(sw) == len(sr), (k, sw, sr, sd)
+            tol = np.maximum(2e-4 * (k + 1) * sr, 3 * np.abs(sr - sd))
+            assert (np.abs(sw - sr) <= tol).all(), (k, sw, sr, sd)
+        else:  # the restatement disagrees with itself about this step
+            split += 1
+            assert len(sw) in (len(sr), len(sd)), (k, sw, sr, sd)
         # (mode 2 cuts the last substep at the end of the step: only that one may fall below dt / max_num_substeps)
         assert all(DT / 10 * (1 - 1e-6) <= x <= DT * (1 + 1e-6) for x in (sw if mode == 1 else sw[:-1])) and 0 < sw[-1] <= DT * (1 + 1e-6)
         assert sum(sw) >= DT * (1 - 1e-6) and (mode == 1 or abs(sum(sw) - DT) < 1e-6)
-        # (frame-sized steps: a step moves a particle up to 0.4 of its diameter per substep, the trajectories part by rounding sooner
-        # than at dt = 1/200 — a pair on d = h may fall on either side: 1e-4 of the contacts per step so far, never a waiver)
-        assert abs(int(st.ncontacts) - int(so.ncontacts)) <= (0 if k == 0 else max(4, int(1e-4 * so.ncontacts) * (k + 1))), (k, st.ncontacts, so.ncontacts)
-        assert abs(st.n_pressure_iters - so.n_press_iters) <= 1 and abs(st.n_divergence_iters - so.n_div_iters) <= 2, k
+        slack = 0 if k == 0 else max(4, int(1e-4 * so.ncontacts) * (k + 1), 3 * abs(int(so.ncontacts) - int(s64.ncontacts)))
+        assert abs(int(st.ncontacts) - int(so.ncontacts)) <= slack, (k, st.ncontacts, so.ncontacts, s64.ncontacts)
+        assert abs(st.n_pressure_iters - so.n_press_iters) <= max(1, abs(so.n_press_iters - s64.n_press_iters)), k
+        assert abs(st.n_divergence_iters - so.n_div_iters) <= max(2, abs(so.n_div_iters - s64.n_div_iters)), k
         c = w.counters
         assert c.step_time > 0 and c.stages.solver_time > 0  # the timers add up over the substeps
         nsub_total += len(sw)
         multi += len(sw) > 1
     assert multi >= 5, "the scene never sub-stepped: the test would prove nothing"
+    assert split <= n // 5, split
     d = max_norm_diff(fl.positions, o.fluid_vec(0, "positions")) / R
-    assert d < 1e-3 * nsub_total, d  # 1e-3 r per substep, as test_longer_trajectory_dam_break allows per step
+    d64 = max_norm_diff(o.fluid_vec(0, "positions"), o64.fluid_vec(0, "positions")) / R
+    assert d < max(1e-3 * nsub_total, 3 * d64), (d, d64)
     # (no claim about the physics: at dt = 1/60 IISPH lets particles through this single-layer floor in the oracle just the same)
 
 

@@ -480,7 +480,7 @@ def test_plane_layouts_and_the_fused_first_divergence_change_rounding_only(monke
     counts are identical and the states agree to f32 summation order; a scene whose masses differ takes the old kernels whatever
     the switches say and is bit-identical."""
     def run(scene, nsteps, env):
-        for k in ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV", "SALVA_HIP_NO_TILE_CLASSES"):
+        for k in ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV", "SALVA_HIP_TILE_CLASSES"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
@@ -495,9 +495,9 @@ def test_plane_layouts_and_the_fused_first_divergence_change_rounding_only(monke
         dp, dv = np.abs(base["pos_0"] - other["pos_0"]).max(), np.abs(base["vel_0"] - other["vel_0"]).max()
         assert dp < 2e-5 * R * nsteps, f"{env}: positions differ by {dp / R:.2e} r"
         assert dv < 1e-4, f"{env}: velocities differ by {dv:.2e} m/s"
-    # fluids of different density0: the masses differ, and without the per-tile classes of round 5 (next test) nothing above applies
+    # fluids of different density0: the masses differ, and without the opt-in per-tile classes of round 5 (next test) nothing above applies
     two = SCENES["two_phase"][0]()
-    a, b = run(two, 6, ("SALVA_HIP_NO_TILE_CLASSES",)), run(two, 6, ("SALVA_HIP_NO_TILE_CLASSES", "SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV"))
+    a, b = run(two, 6, ()), run(two, 6, ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV"))
     assert np.array_equal(a["iters"], b["iters"])
     for f in range(2):
         assert np.array_equal(a[f"pos_{f}"], b[f"pos_{f}"]) and np.array_equal(a[f"vel_{f}"], b[f"vel_{f}"])
@@ -520,18 +520,27 @@ def _two_phase_side_by_side():
 
 
 def test_tile_classes_change_rounding_only(monkeypatch):
-    """Round 5: a world whose particles do not share one mass (two fluids of different density0, BASELINE config 4) runs every DFSPH
-    pass as two launches — the plane-layout kernels over the tiles whose whole halo has one mass, with that tile's mass, and the
-    general kernels over the tiles that see both.  Other kernels for the same sums: against a run with
-    SALVA_HIP_NO_TILE_CLASSES=1 the contact and iteration counts are identical and the states agree to f32 summation order — but
-    not bit for bit, or the classes were never on — and both agree with the oracle."""
+    """Round 5, opt-in (SALVA_HIP_TILE_CLASSES=1): a world whose particles do not share one mass (two fluids of different density0,
+    BASELINE config 4) can run every DFSPH pass as two launches — the plane-layout kernels over the tiles whose whole halo has one
+    mass, with that tile's mass, and the general kernels over the tiles that see both (built, measured, slower than
+    the general kernels alone on config 4, hence not the default).  Other kernels for the same sums: against the default run the
+    contact and iteration counts are identical and the states agree to f32 summation order — but not bit for bit, or the classes
+    were never on — and both agree with the oracle."""
     scene = _two_phase_side_by_side()
     nsteps = 10
-    monkeypatch.delenv("SALVA_HIP_NO_TILE_CLASSES", raising=False)
-    on = run_hip(scene, nsteps)
-    monkeypatch.setenv("SALVA_HIP_NO_TILE_CLASSES", "1")
+    monkeypatch.delenv("SALVA_HIP_TILE_CLASSES", raising=False)
     off = run_hip(scene, nsteps)
-    monkeypatch.delenv("SALVA_HIP_NO_TILE_CLASSES", raising=False)
+    ons = []
+    for fork in (False, True):
+        monkeypatch.setenv("SALVA_HIP_TILE_CLASSES", "1")
+        if fork:
+            monkeypatch.setenv("SALVA_HIP_CLASS_FORK", "1")
+        ons.append(run_hip(scene, nsteps))
+        monkeypatch.delenv("SALVA_HIP_TILE_CLASSES", raising=False)
+        monkeypatch.delenv("SALVA_HIP_CLASS_FORK", raising=False)
+    on = ons[0]
+    for key in on:  # (the side stream moves a launch, not a bit)
+        assert np.array_equal(np.asarray(on[key]), np.asarray(ons[1][key]), equal_nan=True), key
     assert np.array_equal(on["iters"], off["iters"]), "iteration or contact counts differ"
     differs = False
     for f in range(2):
@@ -539,7 +548,7 @@ def test_tile_classes_change_rounding_only(monkeypatch):
         assert dp < 2e-5 * R * nsteps and dv < 1e-4, (f, dp / R, dv)
         differs |= not np.array_equal(on[f"vel_{f}"], off[f"vel_{f}"])
     assert differs, "bit-identical runs: the tile classes never switched on"
-    compare(on, run_oracle(scene, nsteps), scene, nsteps, "two-phase side by side vs oracle")
+    compare(on, run_oracle(scene, nsteps), scene, nsteps, "two-phase side by side (tile classes) vs oracle")
 
 
 @pytest.mark.parametrize("name", ["dfsph_tank", "iisph_akinci", "dfsph_xsph_block", "two_phase"])
