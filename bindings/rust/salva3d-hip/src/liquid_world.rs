@@ -106,8 +106,11 @@ pub struct LiquidWorld {
     host_dirty: bool,    // fluids_mut() / boundaries_mut() / add_* was called since the last upload
     device_newer: bool,  // a step ran since the last download
     auto_sync: bool,
-    /// (address, bytes) of the host arrays pinned in place for the read-back (`salva_hip_host_register`): a `Vec` that was
-    /// reallocated or resized since is registered again, the stale range released
+    /// (address, bytes) of the host arrays pinned in place for the read-back (`salva_hip_host_register`).  A registration never
+    /// outlives a point at which its `Vec` could be reallocated or freed: `fluids_mut()` (which hands out `&mut FluidSet`),
+    /// and `remove_fluid` release every range first (`unpin_all`) and the next `sync` registers afresh (`add_fluid` only moves
+    /// `Fluid` headers, not the heap blocks of their `Vec`s) — page-locked
+    /// memory is never left behind in freed heap, and `hipHostUnregister` never runs on an address that is no longer mapped.
     pinned: Vec<(usize, usize)>,
     decomposed: bool,    // set_domain was called (dist.rs): particles are read with owned()
     last_stats: ffi::SalvaHipStepStats,
@@ -132,6 +135,16 @@ impl Drop for LiquidWorld {
 }
 
 impl LiquidWorld {
+    /// Release every in-place registration (see `pinned`); called before anything that may move or free a fluid's `Vec`s.
+    fn unpin_all(&mut self) {
+        unsafe {
+            ffi::salva_hip_wait_download(self.raw); // (no DMA may still target the ranges)
+            for (p, _) in self.pinned.drain(..) {
+                ffi::salva_hip_host_unregister(p as *mut std::ffi::c_void);
+            }
+        }
+    }
+
     /// `LiquidWorld::new(solver, particle_radius, smoothing_factor)` (liquid_world.rs:39-57).
     pub fn new(solver: impl GpuPressureSolver, particle_radius: Real, smoothing_factor: Real) -> Result<Self, Error> {
         let mut params = solver.params(particle_radius, smoothing_factor);
@@ -177,6 +190,7 @@ impl LiquidWorld {
     /// Swap-remove on both sides (liquid_world.rs:171-173; the solver's per-slot buffers stay positional there and here).
     pub fn remove_fluid(&mut self, handle: FluidHandle) -> Result<Option<Fluid>, Error> {
         self.sync()?;
+        self.unpin_all(); // (the removed fluid's Vecs are about to leave the world, the last fluid's to change slot)
         let slot = self.fluids.iter().position(|(h, _)| h == handle);
         if let Some(slot) = slot {
             if (slot as u32) < unsafe { ffi::salva_hip_num_fluids(self.raw) } {
@@ -204,6 +218,7 @@ impl LiquidWorld {
     /// uploaded again before the next step.
     pub fn fluids_mut(&mut self) -> Result<&mut FluidSet, Error> {
         self.sync()?;
+        self.unpin_all(); // (the caller may push particles, replace or drop the Vecs: nothing stays page-locked behind its back)
         self.host_dirty = true;
         Ok(&mut self.fluids)
     }
@@ -232,7 +247,8 @@ impl LiquidWorld {
             let (pp, vp) = (fluid.positions.as_mut_ptr() as *mut f32, fluid.velocities.as_mut_ptr() as *mut f32);
             for ptr in [pp as usize, vp as usize] {
                 if !self.pinned.iter().any(|&(p, b)| p == ptr && b == bytes) {
-                    // (a range that overlaps a stale registration of a freed Vec: release that one first)
+                    // (every path that can move a Vec went through unpin_all: an entry that overlaps without being equal cannot
+                    // exist — the defensive sweep stays, it costs nothing)
                     self.pinned.retain(|&(p, b)| {
                         let overlap = p < ptr + bytes && ptr < p + b;
                         if overlap {

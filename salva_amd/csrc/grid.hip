@@ -478,7 +478,7 @@ void launch_unsort_u32(uint32_t n, const uint32_t* perm, const uint32_t* in, uin
 // of 64-particle slices of the tile -> tile_cnt[tile], plus their maxima (which size the LDS staging area and the
 // workgroup of every tile kernel of this step).  After an exclusive scan, k_tile_halo_fill writes the flat slot
 // tables: halo_src[tile_off[tile].s + slot] = sorted index of the particle staged in that slot.
-constexpr int TABLE_THREADS = 256;  // >= HCELLS
+constexpr int TABLE_THREADS = HCELLS <= 256 ? 256 : 320;  // >= HCELLS
 static_assert(TABLE_THREADS >= HCELLS, "one thread per halo cell");
 
 // one thread per tile of the dense grid: does it hold particles?

@@ -596,13 +596,14 @@ struct TileCells {
         __syncthreads();
         if (threadIdx.x < WAVE) {  // exclusive prefix of the HCELLS counts by one wave, PER lane each
             constexpr int PER = (HCELLS + WAVE - 1) / WAVE;
-            static_assert(HCELLS % PER == 0, "halo cell count must split evenly over the lanes");
+            constexpr int NL = (HCELLS + PER - 1) / PER;  // lanes that hold cells (the last one maybe fewer than PER)
             const int l = threadIdx.x;
             uint32_t a[PER], b[PER], sa = 0, sb = 0;
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
-                a[k] = (l < HCELLS / PER) ? lstart[PER * l + k] : 0u;
-                b[k] = (l < HCELLS / PER) ? blstart[PER * l + k] : 0u;
+                const bool in = PER * l + k < HCELLS;
+                a[k] = in ? lstart[PER * l + k] : 0u;
+                b[k] = in ? blstart[PER * l + k] : 0u;
                 sa += a[k]; sb += b[k];
             }
             uint32_t ia = sa, ib = sb;
@@ -612,14 +613,14 @@ struct TileCells {
                 if (l >= o) { ia += ta; ib += tb; }
             }
             uint32_t ea = ia - sa, eb = ib - sb;
-            if (l < HCELLS / PER) {
+            if (l < NL) {
 #pragma unroll
                 for (int k = 0; k < PER; ++k) {
-                    lstart[PER * l + k] = ea; blstart[PER * l + k] = eb;
+                    if (PER * l + k < HCELLS) { lstart[PER * l + k] = ea; blstart[PER * l + k] = eb; }
                     ea += a[k]; eb += b[k];
                 }
             }
-            if (l == HCELLS / PER - 1) { lstart[HCELLS] = ia; blstart[HCELLS] = ib; }
+            if (l == NL - 1) { lstart[HCELLS] = ia; blstart[HCELLS] = ib; }
         }
         __syncthreads();
         if (clamp_to_staged && c.spec) {  // speculative pass: no cell range may reach beyond the slots that were staged

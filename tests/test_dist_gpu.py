@@ -25,6 +25,7 @@ def make_scene(nx=40, ny=10, nz=10, seed=5):
 
 
 SOLVER = {"kind": "dfsph"}  # switched by the IISPH test
+STEP = {"dt": DT, "cfl": 0}  # switched by the CFL sub-stepping test
 FORCES = {"make": lambda: [XSPHViscosity(0.5, 0.0)]}  # switched by the surface-tension test
 
 
@@ -43,7 +44,12 @@ def run_single(pos, vel, bpos, nsteps, two_fluids):
         f.nonpressure_forces.extend(FORCES["make"]())
         fls.append((w.add_fluid(f), part))
     w.add_boundary(Boundary(bpos))
-    stats = [w.step(DT, G) for _ in range(nsteps)]
+    if STEP["cfl"]:
+        w.set_cfl_substepping(STEP["cfl"])
+    stats = []
+    for _ in range(nsteps):
+        stats.append(w.step(STEP["dt"], G))
+        stats[-1].substeps = w.substeps()
     out_p = np.zeros_like(pos)
     out_v = np.zeros_like(vel)
     for f, part in fls:
@@ -86,7 +92,12 @@ def run_slabs(pos, vel, bpos, nsteps, nranks, two_fluids):
                 w.add_fluid(f)
             w.add_boundary(Boundary(bpos[dist.boundary_subset(bpos, H, slabs[r], r, nranks)]))
             w.set_domain(comms[r], slabs[r][0], slabs[r][1], offsets[r])
-            stats[r] = [w.step(DT, G) for _ in range(nsteps)]
+            if STEP["cfl"]:
+                w.set_cfl_substepping(STEP["cfl"])
+            stats[r] = []
+            for _ in range(nsteps):
+                stats[r].append(w.step(STEP["dt"], G))
+                stats[r][-1].substeps = w.substeps()
             results[r] = w.owned()
         except BaseException as e:  # noqa: BLE001 - reported by the main thread
             errors[r] = e
@@ -141,6 +152,29 @@ def test_slabs_match_single_domain(hip_lib, nranks, two_fluids):
     dv = np.abs(got_v - ref_v).max()
     assert dp < 2e-4 * H, f"positions differ by {dp / H:.2e} h"
     assert dv < 5e-3, f"velocities differ by {dv:.2e} m/s"
+
+
+def test_cfl_substeps_in_a_decomposed_run(hip_lib):
+    """Opt-in CFL sub-stepping (row f4) across slabs: max_i |v_i + a_i t| is a maximum over ALL particles, so the ranks all-reduce it
+    (each rank's own maximum in its own slot of a summed row: exact) and every rank takes the substeps of the undivided world."""
+    pos, vel, bpos = make_scene()
+    nsteps = 5
+    STEP.update(dt=1.0 / 60.0, cfl=2)
+    try:
+        ref_p, ref_v, ref_stats = run_single(pos, vel, bpos, nsteps, False)
+        got_p, got_v, stats, seen, counts, slabs = run_slabs(pos, vel, bpos, nsteps, 2, False)
+    finally:
+        STEP.update(dt=DT, cfl=0)
+    assert (seen == 1).all()
+    assert max(len(s.substeps) for s in ref_stats) >= 3, "the scene was meant to sub-step"
+    for k in range(nsteps):
+        subs = [tuple(s[k].substeps) for s in stats]
+        assert subs[0] == subs[1], f"step {k}: the ranks took different substeps {subs}"
+        assert len(subs[0]) == len(ref_stats[k].substeps) and np.allclose(subs[0], ref_stats[k].substeps, rtol=1e-4), (k, subs[0], ref_stats[k].substeps)
+    dp = np.abs(got_p - ref_p).max()
+    dv = np.abs(got_v - ref_v).max()
+    assert dp < 5e-4 * H, f"positions differ by {dp / H:.2e} h"
+    assert dv < 1e-2, f"velocities differ by {dv:.2e} m/s"
 
 
 class _HostField:
