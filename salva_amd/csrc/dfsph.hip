@@ -601,9 +601,11 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    struct Own { float4 pi, wi; float ki; uint32_t cnt, near; ListRegs lh; };
+    // (the loop needs the position and kappa_i; w_i, the mass and the model are loaded after it: no register carries them across)
+    struct Own { float px, py, pz, ki; uint32_t cnt, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], win[i], c.kappa[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+        const float4 p = c.posm[i];
+        return Own{p.x, p.y, p.z, c.kappa[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -615,14 +617,14 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
         const bool near = slice_is_near(c, o.near);
         if (!active) return;
-        const float4 pi = o.pi;
-        const uint32_t mi = __float_as_uint(o.wi.w);
-        const float rho0 = rho0_of(c, mi);
+        const float4 pi = make_float4(o.px, o.py, o.pz, 0.0f);
         const float ki = o.ki;
-        float4 d = o.wi;
         float sx, sy, sz;
         if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, t.mass, [&](float kj) { return ki + kj; }, sx, sy, sz);
         else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, t.mass, [&](float ka, float kb) { return f2{ki + ka, ki + kb}; }, sx, sy, sz);
+        float4 d = win[i];
+        const uint32_t mi = __float_as_uint(d.w);
+        const float rho0 = rho0_of(c, mi);
         d.x -= sx; d.y -= sy; d.z -= sz;
         for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
             const float4 pj = p2_boundary_pos(t, s, dist8);
@@ -632,7 +634,7 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
             const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
             d.x += ex; d.y += ey; d.z += ez;
             if (c.bforce && !is_ghost(c, i)) {
-                const float fs = -inv_dt_prev * pi.w;
+                const float fs = -inv_dt_prev * c.posm[i].w;
                 const uint32_t jb = boundary_sorted_of_slot(c, t, s);
                 apply_boundary_force(c, jb, __float_as_uint(c.bvel[jb].w), ex * fs, ey * fs, ez * fs);
             }
@@ -911,9 +913,11 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
     Tile t;
     t.setup(c);
     if (t.empty()) return;
-    struct Own { float4 pi, d, v; float ki; uint32_t mi, cnt, near; ListRegs lh; };
+    // (the loop needs the position and kappa_i; dv_i, v_i, the mass and the model are loaded after it)
+    struct Own { float px, py, pz, ki; uint32_t cnt, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.dv[i], c.vel[i], c.kappa[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+        const float4 p = c.posm[i];
+        return Own{p.x, p.y, p.z, c.kappa[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -925,15 +929,15 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
         const uint32_t nqu = slice_list_dwords(o.cnt, active);
         const bool near = slice_is_near(c, o.near);
         if (!active) return;
-        const float4 pi = o.pi;
-        const uint32_t mi = o.mi;
-        const float rho0 = rho0_of(c, mi);
+        const float4 pi = make_float4(o.px, o.py, o.pz, 0.0f);
         const float ki = o.ki;
         const float kip = fmaxf(ki, 0.0f);
-        float4 d = o.d;
         float sx, sy, sz;
         if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, t.mass, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, sx, sy, sz);
         else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, t.mass, [&](float ka, float kb) { return f2{kip + fmaxf(ka, 0.0f), kip + fmaxf(kb, 0.0f)}; }, sx, sy, sz);
+        const uint32_t mi = c.model[i];
+        const float rho0 = rho0_of(c, mi);
+        float4 d = c.dv[i];
         d.x -= sx * inv_dt; d.y -= sy * inv_dt; d.z -= sz * inv_dt;
         if (ki > 0.0f) {
             for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
@@ -944,14 +948,14 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
                 const float ex = dx * coeff, ey = dy * coeff, ez = dz * coeff;
                 d.x -= ex; d.y -= ey; d.z -= ez;
                 if (c.bforce && !is_ghost(c, i)) {
-                    const float fs = inv_dt * pi.w;
+                    const float fs = inv_dt * c.posm[i].w;
                     const uint32_t jb = boundary_sorted_of_slot(c, t, s);
                     apply_boundary_force(c, jb, __float_as_uint(c.bvel[jb].w), ex * fs, ey * fs, ez * fs);
                 }
             });
         }
         c.dv[i] = d;
-        const float4 v = o.v;
+        const float4 v = c.vel[i];
         c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
     });
 }

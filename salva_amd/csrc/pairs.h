@@ -110,12 +110,15 @@ __device__ __forceinline__ float pair_sum_velocity_divergence_exact_p3(const Ste
 // sum_j grad W_ij k_ij over the 16-byte plane layout (tile.h stage_p2), times the uniform mass
 struct RecP2 { lds_v2f xy, zk; };  // (x, y) | (z, kappa)
 __device__ __forceinline__ RecP2 load_p2(uint32_t o, uint32_t dist8) { return RecP2{lds_ld8(o), lds_ld8(o + dist8)}; }
+#ifndef SALVA_P2_NARROW
+#define SALVA_P2_NARROW false
+#endif
 template <typename K2>
 __device__ __forceinline__ void pair_sum_gradient_p2(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh, const float4& pi,
                                                      uint32_t dist8, float mass, K2&& kij2, float& sx, float& sy, float& sz) {
     f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
     const f2 tiny = {1.0e-30f, 1.0e-30f};
-    for_each_ff2<true, false, 2>(c, gs, nqu, lh, [&](uint32_t o) { return load_p2(o, dist8); }, [&](const RecP2& A, const RecP2& B) { SALVA_PAIR_MATH
+    for_each_ff2<true, false, 2, SALVA_P2_NARROW>(c, gs, nqu, lh, [&](uint32_t o) { return load_p2(o, dist8); }, [&](const RecP2& A, const RecP2& B) { SALVA_PAIR_MATH
         const f2 dx = {pi.x - A.xy.x, pi.x - B.xy.x}, dy = {pi.y - A.xy.y, pi.y - B.xy.y}, dz = {pi.z - A.zk.x, pi.z - B.zk.x};
         f2 r2 = dz * dz + tiny;
         r2 = dy * dy + r2;
