@@ -422,8 +422,12 @@ def main():
         try:
             w = None  # (release the first world's device memory)
             w2, handles2 = make_config_world(args.config, fluids, shell, local_rank)
-            for _ in range(args.warmup):
+            for _ in range(args.warmup):  # (the warm-up steps read back too: the first read-back allocates the pinned arrays, 6-19 ms once)
                 w2.step(DT, GRAVITY)
+                w2.wait_download()
+                for hd in handles2:
+                    w2.download_async(hd)
+            w2.wait_download()
             torch.cuda.synchronize()
             td = time.perf_counter()
             for _ in range(args.steps):
