@@ -147,16 +147,17 @@ struct StepCtx {
     // posm.w every step): the evaluate kernels then stage 24 bytes per halo slot instead of 32 (no mass in LDS; tile.h stage_p3)
     // and multiply the finished sum by it.  0: masses differ (non-uniform volumes, fluids of different density0), or unknown.
     float mass_uniform;
-    // Tile classes — worlds whose particles do NOT all have one mass (two fluids of different density0, BASELINE config 4), but
-    // where most TILES still see one mass in their whole halo (the bulk of each fluid): k_nbr_tile finds, per tile, whether every
-    // fluid halo slot has the same mass (it stages posm anyway); k_tile_classes sorts the slots into "uniform" (first) and
-    // "mixed" (behind them); every DFSPH pass is then two launches — the plane-layout kernel over the uniform tiles with the
-    // tile's own mass, the general 32-byte kernel over the mixed ones.  Null / 0 otherwise.
-    const uint32_t* cls_slots;       // [nlaunch] slots: the n_uniform uniform tiles in ascending order, then the mixed ones
-    const uint32_t* tile_mass_bits;  // [nlaunch] by slot: bits of the tile's uniform halo mass, 0 = mixed
-    uint32_t cls_off;                // first entry of cls_slots this launch covers
-    uint32_t n_uniform;              // number of uniform tiles
-    uint32_t want_tile_mass;         // k_nbr_tile: reduce the halo's mass range into TileListStats::mass_bits
+    // Two-mass worlds (BASELINE config 4: two fluids of different density0, each with `Fluid::new`'s uniform volumes): the host knows
+    // that there are exactly two particle masses and which fluids carry the heavier one (`bmask`, one bit per fluid).  k_nbr_tile then
+    // writes the lists of a tile whose halo holds both with the lighter class first and the heavier behind it (nffb[i] = length of
+    // that second segment) and, per slot, the mass of the first segment and of the second (0: the whole halo has one mass).  The
+    // plane-layout kernels run over ALL tiles in one launch and compute m_a S_all + (m_b - m_a) S_b, the second sum over the tail
+    // segment only and only in the tiles that have one (pairs.h pair_tail_*).
+    uint32_t* tile_mass_bits;   // [nlaunch] by slot: bits of the mass of the list's first segment (written by k_nbr_tile)
+    uint32_t* tile_massb_bits;  // [nlaunch] by slot: bits of the mass of the second segment, 0 = there is none
+    uint32_t* nffb;             // [n] number of entries in the second segment of particle i's list
+    uint32_t two_mass;          // 1: the above is on (DFSPH, default kernels, single domain)
+    uint32_t bmask;             // fluids whose particles have the heavier mass
     uint32_t bvel_zero;        // 1: every boundary velocity is exactly zero (plain boundaries uploaded at rest, the usual tank)
     const uint8_t* ff_ok;      // [nmodels*nmodels] InteractionGroups::test between fluids (diagonal = 1)
     const uint8_t* fb_ok;      // [nmodels*nbmodels]
@@ -201,8 +202,7 @@ struct Readback {
     uint64_t ncontacts_own_ff, ncontacts_own_fb;  // list totals over the particles this rank owns (decomposed runs)
     uint32_t mass_mm[2];  // [0] = bits of particle 0's mass, [1] = the same if no particle's mass differed since the last publication
                           // of the totals (host side of the publication only; on the device: World::mass_slots, grid.hip k_cell_keys)
-    uint32_t n_uniform_tiles;  // tile classes (StepCtx::cls_slots): tiles whose whole halo has one mass; travels with the list statistics
-    uint32_t pad2_;
+    uint32_t pad2_[2];
 };
 
 }  // namespace salva

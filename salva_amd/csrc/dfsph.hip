@@ -40,33 +40,8 @@ using namespace salva;
 // finished sum instead of every boundary term: rounding only.  a_ii (:188-233) is made of own quantities and sums over the same
 // contacts as well — d_ii . G_i - dt^2 m_i / rho_i^2 sum_j m_j |grad W_ij|^2 — and comes out of this pass too (no k_iisph_aii:
 // another 38 us).  Decomposed runs keep the separate passes (a ghost's density is replaced by its owner's in between).
-// Tile classes (device_types.h StepCtx::cls_slots; worlds with more than one mass): a pass is two launches — `uniform` over the
-// tiles whose whole halo has one mass (the plane-layout kernels, with Tile::mass = that tile's mass), `mixed` over the others
-// (the general kernels).  Every non-empty tile is in exactly one class, so outputs and error partials are complete.
-static inline uint32_t xcd_groups_for(uint32_t nl) {
-    uint32_t lg = 1u;
-    while (lg < 7u && (16u << lg) <= nl) ++lg;
-    return lg;
-}
-template <typename FU, typename FM>
-static inline void launch_by_class(const StepCtx& c, const TileLds& L, hipStream_t s, FU&& uniform, FM&& mixed) {
-    StepCtx cu = c, cm = c;
-    cu.cls_off = 0u; cu.nlaunch = c.n_uniform; cu.xcd = xcd_groups_for(cu.nlaunch);
-    cm.cls_off = c.n_uniform; cm.nlaunch = c.nlaunch - c.n_uniform; cm.xcd = xcd_groups_for(cm.nlaunch); cm.tile_mass_bits = nullptr;
-    const bool fork = L.side_stream && L.side_stream != s && cm.nlaunch && cu.nlaunch;
-    if (fork) {  // the mixed tiles beside the uniform ones (TileLds::side_stream)
-        SALVA_HIP_CHECK(hipEventRecord(L.ev_fork, s));
-        SALVA_HIP_CHECK(hipStreamWaitEvent(L.side_stream, L.ev_fork, 0));
-        mixed(cm, L.side_stream);
-        SALVA_HIP_CHECK(hipEventRecord(L.ev_join, L.side_stream));
-        uniform(cu, s);
-        SALVA_HIP_CHECK(hipStreamWaitEvent(s, L.ev_join, 0));
-        return;
-    }
-    if (cu.nlaunch) uniform(cu, s);
-    if (cm.nlaunch) mixed(cm, s);
-}
-static inline bool by_class(const StepCtx& c) { return c.cls_slots != nullptr && c.tile_mass_bits != nullptr && c.cls_off == 0u && c.n_uniform > 0u; }
+// The plane-layout kernels serve worlds with one particle mass (StepCtx::mass_uniform) and two-mass worlds (StepCtx::two_mass).
+static inline bool plane_layouts(const StepCtx& c) { return c.mass_uniform > 0.0f || c.two_mass != 0u; }
 
 #ifndef SALVA_DA_IISPH_WAVES
 #define SALVA_DA_IISPH_WAVES 6  // (the IISPH form asks for 84 VGPRs by itself: two tiles per CU; held to 80 = three, two registers in scratch)
@@ -248,7 +223,9 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
             });
             const uint32_t npad = 2u * nqu - o.cnt;  // self contacts appended by k_nbr_tile
             const float gm = c.sc.gscale * m;
-            rho = (rw.x + rw.y) * c.sc.wscale * m + m * c.sc.wnorm;
+            // (the particle's own weight takes its OWN mass: in a two-mass world it may be the heavier one in a tile whose first
+            // segment is the lighter; with one mass the two are the same number)
+            rho = (rw.x + rw.y) * c.sc.wscale * m + c.posm[i].w * c.sc.wnorm;
             gsx = (ax.x + ax.y) * gm; gsy = (ay.x + ay.y) * gm; gsz = (az.x + az.y) * gm;
             sq = (s2.x + s2.y) * (gm * gm);
             div = (dv2.x + dv2.y) * gm;
@@ -268,6 +245,29 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
                 gsx += gx; gsy += gy; gsz += gz;
                 div += ((wi.x - A.zu.y) * dx + (wi.y - A.vw.x) * dy + (wi.z - A.vw.y) * dz) * gmj;
             });
+        }
+        if (active && t.massb != 0.0f) {  // two-mass world, this tile holds both: the heavier neighbours' share on top of every sum
+            const uint32_t nb2 = c.nffb[i];
+            if (nb2) {
+                float rwb = 0.0f, gxb = 0.0f, gyb = 0.0f, gzb = 0.0f, s2b = 0.0f, dvb = 0.0f;
+                for_each_ff_range(c, gs, o.cnt - nb2, o.cnt, [&](uint32_t s) { SALVA_PAIR_MATH
+                    const RecP3 A = load_p3(s << 3, dist8);
+                    const float dx = pi.x - A.xy.x, dy = pi.y - A.xy.y, dz = pi.z - A.zu.x;
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    const KernelEval e = kernel_eval(r2, c.sc);
+                    // (the packed walk left zero-distance weights out and the particle's own weight went in apart; the exact walk of
+                    // a slice with a near-coincident pair summed every entry)
+                    if (any_near || r2 > c.sc.tiny_r2) rwb += e.w;
+                    const float gx = dx * e.g, gy = dy * e.g, gz = dz * e.g;
+                    gxb += gx; gyb += gy; gzb += gz;
+                    s2b += gx * gx + gy * gy + gz * gz;
+                    dvb += ((wi.x - A.zu.y) * dx + (wi.y - A.vw.x) * dy + (wi.z - A.vw.y) * dz) * e.g;
+                });
+                const float dm = t.massb - m;
+                rho += dm * rwb; gsx += dm * gxb; gsy += dm * gyb; gsz += dm * gzb;
+                sq += (t.massb * t.massb - m * m) * s2b;
+                div += dm * dvb;
+            }
         }
         float err = 0.0f;
         uint32_t mi = 0;
@@ -302,27 +302,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
     });
     E.finish(c, t.slot);
 }
-template <uint32_t DS> __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c);  // (below)
 // true: the pass above ran and the divergence solve's iteration 0 must not launch its evaluate
 bool launch_density_alpha_div(const StepCtx& c, const TileLds& L, hipStream_t s) {
 #ifndef SALVA_OTHER_KERNELS
-    if ((c.sc.kd | c.sc.kg) != 0) return false;
-    if (by_class(c)) {
-        launch_by_class(c, L, s, [&](const StepCtx& cu, hipStream_t s) {
-            const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
-            SALVA_LAUNCH_P3(k_density_alpha_div_p3, ds, cu, L, p3_bytes(L, ds, cu.nmodels, false), s, cu);
-        }, [&](const StepCtx& cm, hipStream_t s) {
-            // the mixed tiles: the density pass, then the solve's first evaluate as a pass of its own (their alpha is ready: the
-            // stream orders the two; the control block is the previous solve's, hence none)
-            SALVA_LAUNCH_TILE(k_density_alpha<false>, cm, L, L.bytes(16, 16, 2), s, cm, 0.0f);
-            StepCtx ce = cm;
-            ce.ctl = nullptr; ce.spec_k = -1;
-            const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
-            SALVA_LAUNCH_FIXED(k_divergence, ds, ce, L, pw_bytes(L, ds, true), s, ce);
-        });
-        return true;
-    }
-    if (!(c.mass_uniform > 0.0f)) return false;
+    if (!plane_layouts(c) || (c.sc.kd | c.sc.kg) != 0) return false;
     const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
     SALVA_LAUNCH_P3(k_density_alpha_div_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
     return true;
@@ -456,9 +439,11 @@ __global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
     t.setup(c);
     if (t.skipped()) return;
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
-    struct Own { float4 pi, wi; float alpha; uint32_t mi, cnt, cntb, near; ListRegs lh; };
+    // (the loop needs the position, w_i and the two contact counts of the < 20 rule; alpha_i and the model are loaded after it)
+    struct Own { float px, py, pz, ux, uy, uz; uint32_t cnt, cntb, nb2, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], win[i], c.alpha[i], c.model[i], c.nff[i], c.nb ? c.nfb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
+        const float4 p = c.posm[i], u = win[i];
+        return Own{p.x, p.y, p.z, u.x, u.y, u.z, c.nff[i], c.nb ? c.nfb[i] : 0u, t.massb != 0.0f ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -476,13 +461,19 @@ __global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
-            mi = o.mi;
+            mi = c.model[i];
             const float rho0 = rho0_of(c, mi);
             float div = 0.0f;
             if (o.cnt + o.cntb >= c.min_neighbors_for_divergence) {
-                const float4 pi = o.pi, wi = o.wi;
-                div += near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8, t.mass)
-                            : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8, t.mass);
+                const float4 pi = make_float4(o.px, o.py, o.pz, 0.0f), wi = make_float4(o.ux, o.uy, o.uz, 0.0f);
+                if (t.massb != 0.0f && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
+                    div += pair_sum_velocity_divergence_p3_two(c, gs, nqu, o.lh, pi, wi, dist8, o.cnt - o.nb2, t.mass, t.massb);
+                } else {
+                    div += near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8, t.mass)
+                                : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8, t.mass);
+                    if (t.massb != 0.0f && o.nb2)  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
+                        div += (t.massb - t.mass) * pair_tail_velocity_divergence_p3(c, gs, o.cnt - o.nb2, o.cnt, pi, wi, dist8);
+                }
                 for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                     const float4 pj = Bp[s];
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -491,7 +482,7 @@ __global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
                 });
                 div = fmaxf(div, 0.0f);
             }
-            c.kappa[i] = div * o.alpha;
+            c.kappa[i] = div * c.alpha[i];
             err = div / rho0;
         }
         E.add(c, err, mi, active && !is_ghost(c, i));
@@ -500,17 +491,7 @@ __global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
 }
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence, c, L, s);
-    if (by_class(c)) {
-        launch_by_class(c, L, s, [&](const StepCtx& cu, hipStream_t s) {
-            const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
-            SALVA_LAUNCH_P3(k_divergence_p3, ds, cu, L, p3_bytes(L, ds, cu.nmodels, false), s, cu);
-        }, [&](const StepCtx& cm, hipStream_t s) {
-            const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
-            SALVA_LAUNCH_FIXED(k_divergence, ds, cm, L, pw_bytes(L, ds, true), s, cm);
-        });
-        return;
-    }
-    if (c.mass_uniform > 0.0f) {
+    if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
         SALVA_LAUNCH_P3(k_divergence_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
         return;
@@ -602,10 +583,10 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
     t.setup(c);
     if (t.empty()) return;
     // (the loop needs the position and kappa_i; w_i, the mass and the model are loaded after it: no register carries them across)
-    struct Own { float px, py, pz, ki; uint32_t cnt, near; ListRegs lh; };
+    struct Own { float px, py, pz, ki; uint32_t cnt, nb2, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
         const float4 p = c.posm[i];
-        return Own{p.x, p.y, p.z, c.kappa[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+        return Own{p.x, p.y, p.z, c.kappa[i], c.nff[i], t.massb != 0.0f ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -620,8 +601,18 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
         const float4 pi = make_float4(o.px, o.py, o.pz, 0.0f);
         const float ki = o.ki;
         float sx, sy, sz;
-        if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, t.mass, [&](float kj) { return ki + kj; }, sx, sy, sz);
-        else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, t.mass, [&](float ka, float kb) { return f2{ki + ka, ki + kb}; }, sx, sy, sz);
+        if (t.massb != 0.0f && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
+            pair_sum_gradient_p2_two(c, gs, nqu, o.lh, pi, dist8, o.cnt - o.nb2, t.mass, t.massb, [&](float ka, float kb) { return f2{ki + ka, ki + kb}; }, sx, sy, sz);
+        } else {
+            if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, t.mass, [&](float kj) { return ki + kj; }, sx, sy, sz);
+            else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, t.mass, [&](float ka, float kb) { return f2{ki + ka, ki + kb}; }, sx, sy, sz);
+            if (t.massb != 0.0f && o.nb2) {  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
+                float bx, by, bz;
+                pair_tail_gradient_p2(c, gs, o.cnt - o.nb2, o.cnt, pi, dist8, [&](float kj) { return ki + kj; }, bx, by, bz);
+                const float dm = t.massb - t.mass;
+                sx += dm * bx; sy += dm * by; sz += dm * bz;
+            }
+        }
         float4 d = win[i];
         const uint32_t mi = __float_as_uint(d.w);
         const float rho0 = rho0_of(c, mi);
@@ -644,17 +635,7 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
 }
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence_apply, c, L, inv_dt_prev, s);
-    if (by_class(c)) {  // (never with speculative applies: World::dfsph_solve — the test would ride in both launches)
-        launch_by_class(c, L, s, [&](const StepCtx& cu, hipStream_t s) {
-            const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
-            SALVA_LAUNCH_P2(k_divergence_apply_p2, ds, cu, L, p2_bytes(L, ds), s, cu, inv_dt_prev);
-        }, [&](const StepCtx& cm, hipStream_t s) {
-            const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
-            SALVA_LAUNCH_FIXED(k_divergence_apply, ds, cm, L, pk_bytes(L, ds), s, cm, inv_dt_prev);
-        });
-        return;
-    }
-    if (c.mass_uniform > 0.0f) {
+    if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
         SALVA_LAUNCH_P2(k_divergence_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt_prev);
         return;
@@ -783,9 +764,11 @@ __global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
     t.setup(c);
     if (t.skipped()) return;
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
-    struct Own { float4 pi, wi; float rho, alpha; uint32_t mi, cnt, near; ListRegs lh; };
+    // (the loop needs the position and w_i; rho_i, alpha_i and the model are loaded after it: no register carries them across)
+    struct Own { float px, py, pz, ux, uy, uz; uint32_t cnt, nb2, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
-        return Own{c.posm[i], c.w[i], c.rho[i], c.alpha[i], c.model[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+        const float4 p = c.posm[i], u = c.w[i];
+        return Own{p.x, p.y, p.z, u.x, u.y, u.z, c.nff[i], t.massb != 0.0f ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -807,11 +790,18 @@ __global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
-            mi = o.mi;
+            const float4 pi = make_float4(o.px, o.py, o.pz, 0.0f), wi = make_float4(o.ux, o.uy, o.uz, 0.0f);
+            float delta;
+            if (t.massb != 0.0f && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
+                delta = pair_sum_velocity_divergence_p3_two(c, gs, nqu, o.lh, pi, wi, dist8, o.cnt - o.nb2, t.mass, t.massb);
+            } else {
+                delta = near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8, t.mass)
+                             : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8, t.mass);
+                if (t.massb != 0.0f && o.nb2)  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
+                    delta += (t.massb - t.mass) * pair_tail_velocity_divergence_p3(c, gs, o.cnt - o.nb2, o.cnt, pi, wi, dist8);
+            }
+            mi = c.model[i];
             const float rho0 = rho0_of(c, mi);
-            const float4 pi = o.pi, wi = o.wi;
-            float delta = near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8, t.mass)
-                               : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8, t.mass);
             for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Bp[s];
                 const float4 vj = c.bvel_zero ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : Bv[s];  // (w - 0 = w exactly)
@@ -819,10 +809,10 @@ __global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
                 const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
                 delta += pj.w * rho0 * (((wi.x - vj.x) * dx + (wi.y - vj.y) * dy + (wi.z - vj.z) * dz) * g);
             });
-            const float rs = o.rho + delta * dt;
+            const float rs = c.rho[i] + delta * dt;
             if (!(rs != 0.0f)) atomicOr(c.flags, 1u);  // assert!(!predicted_density.is_zero()) :145 (also catches NaN)
             err = (rs < rho0) ? 0.0f : rs / rho0 - 1.0f;
-            c.kappa[i] = (rs - rho0) * o.alpha;
+            c.kappa[i] = (rs - rho0) * c.alpha[i];
         }
         E.add(c, err, mi, active && !is_ghost(c, i));
     });
@@ -830,17 +820,7 @@ __global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
 }
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pred_density, c, L, dt, s);
-    if (by_class(c)) {
-        launch_by_class(c, L, s, [&](const StepCtx& cu, hipStream_t s) {
-            const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
-            SALVA_LAUNCH_P3(k_pred_density_p3, ds, cu, L, p3_bytes(L, ds, cu.nmodels, !cu.bvel_zero), s, cu, dt);
-        }, [&](const StepCtx& cm, hipStream_t s) {
-            const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
-            SALVA_LAUNCH_FIXED(k_pred_density, ds, cm, L, pw_bytes(L, ds, true), s, cm, dt);
-        });
-        return;
-    }
-    if (c.mass_uniform > 0.0f) {
+    if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
         SALVA_LAUNCH_P3(k_pred_density_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
         return;
@@ -914,10 +894,10 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
     t.setup(c);
     if (t.empty()) return;
     // (the loop needs the position and kappa_i; dv_i, v_i, the mass and the model are loaded after it)
-    struct Own { float px, py, pz, ki; uint32_t cnt, near; ListRegs lh; };
+    struct Own { float px, py, pz, ki; uint32_t cnt, nb2, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
         const float4 p = c.posm[i];
-        return Own{p.x, p.y, p.z, c.kappa[i], c.nff[i], c.slice_near[gs], list_regs(c, gs)};
+        return Own{p.x, p.y, p.z, c.kappa[i], c.nff[i], t.massb != 0.0f ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -933,8 +913,19 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
         const float ki = o.ki;
         const float kip = fmaxf(ki, 0.0f);
         float sx, sy, sz;
-        if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, t.mass, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, sx, sy, sz);
-        else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, t.mass, [&](float ka, float kb) { return f2{kip + fmaxf(ka, 0.0f), kip + fmaxf(kb, 0.0f)}; }, sx, sy, sz);
+        if (t.massb != 0.0f && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
+            pair_sum_gradient_p2_two(c, gs, nqu, o.lh, pi, dist8, o.cnt - o.nb2, t.mass, t.massb,
+                                     [&](float ka, float kb) { return f2{kip + fmaxf(ka, 0.0f), kip + fmaxf(kb, 0.0f)}; }, sx, sy, sz);
+        } else {
+            if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, t.mass, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, sx, sy, sz);
+            else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, t.mass, [&](float ka, float kb) { return f2{kip + fmaxf(ka, 0.0f), kip + fmaxf(kb, 0.0f)}; }, sx, sy, sz);
+            if (t.massb != 0.0f && o.nb2) {  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
+                float bx, by, bz;
+                pair_tail_gradient_p2(c, gs, o.cnt - o.nb2, o.cnt, pi, dist8, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, bx, by, bz);
+                const float dm = t.massb - t.mass;
+                sx += dm * bx; sy += dm * by; sz += dm * bz;
+            }
+        }
         const uint32_t mi = c.model[i];
         const float rho0 = rho0_of(c, mi);
         float4 d = c.dv[i];
@@ -961,17 +952,7 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
 }
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pressure_apply, c, L, inv_dt, s);
-    if (by_class(c)) {
-        launch_by_class(c, L, s, [&](const StepCtx& cu, hipStream_t s) {
-            const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
-            SALVA_LAUNCH_P2(k_pressure_apply_p2, ds, cu, L, p2_bytes(L, ds), s, cu, inv_dt);
-        }, [&](const StepCtx& cm, hipStream_t s) {
-            const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
-            SALVA_LAUNCH_FIXED(k_pressure_apply, ds, cm, L, pk_bytes(L, ds), s, cm, inv_dt);
-        });
-        return;
-    }
-    if (c.mass_uniform > 0.0f) {
+    if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
         SALVA_LAUNCH_P2(k_pressure_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt);
         return;

@@ -561,8 +561,7 @@ void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, 
 // ones to the particle's ELL row, two 16-bit slots per dword: fluid-fluid contacts (contacts.rs:347-392) and
 // fluid-boundary contacts (:329-346, :378-383).  Writes nff / nfb, and per tile {sum, max} of the list lengths
 // (the sums are counters.cd.ncontacts; the maxima tell the host whether the fixed ELL capacity was enough).
-struct TileListStats { uint32_t sum_ff, sum_fb, max_ff, max_fb, own_ff, own_fb, mass_bits, pad; };  // own_*: lists of particles this rank OWNS (no ghosts);
-                                                                                                   // mass_bits: the halo's one mass, 0 = several (StepCtx::want_tile_mass)
+struct TileListStats { uint32_t sum_ff, sum_fb, max_ff, max_fb, own_ff, own_fb; };  // own_*: lists of particles this rank OWNS (no ghosts)
 
 // V = 0: one candidate per iteration, nested branches on every accepted candidate (the round-1 kernel; kept as the fallback for
 //        worlds with more than 32 fluid or boundary models).
@@ -584,7 +583,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
     Tile t;
     t.setup(c, false);
     if (t.empty()) {
-        if (threadIdx.x == 0) tile_stats[t.slot] = TileListStats{0, 0, 0, 0, 0, 0, 0, 0};
+        if (threadIdx.x == 0) {
+            tile_stats[t.slot] = TileListStats{0, 0, 0, 0, 0, 0};
+            if (c.two_mass) { c.tile_mass_bits[t.slot] = 0u; c.tile_massb_bits[t.slot] = 0u; }
+        }
         return;
     }
     TileCells tc;
@@ -605,27 +607,35 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
     float4* Bp = t.carve<float4>(t.SB);
     float4* Bv = t.carve<float4>(t.SB);
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    // (tile classes: masses are positive floats, whose order is that of their bit patterns — min == max <=> one mass in the halo)
+    // (two-mass worlds: masses are positive floats, whose order is that of their bit patterns — min != max <=> this halo holds both)
     uint32_t mlo = 0xffffffffu, mhi = 0u;
     t.for_halo(c, [&](uint32_t s, uint32_t g) {
         const float4 p = c.posm[g];
         if (V == 0) Lp[s] = p;
         else { Lx[s] = p.x; Ly[s] = p.y; Lz[s] = p.z; }
         if (multi) Lm[s] = c.model[g];
-        if (c.want_tile_mass) { mlo = min(mlo, __float_as_uint(p.w)); mhi = max(mhi, __float_as_uint(p.w)); }
+        if (c.two_mass) { mlo = min(mlo, __float_as_uint(p.w)); mhi = max(mhi, __float_as_uint(p.w)); }
     });
     t.for_halo_boundary(c, [&](uint32_t s, uint32_t g) { Bp[s] = c.bposv[g]; Bv[s] = c.bvel[g]; });
-    if (c.want_tile_mass) {
+    if (c.two_mass) {
         mlo = ~wave_max_u32(~mlo); mhi = wave_max_u32(mhi);
         if (lane == 0) { red[6][threadIdx.x / WAVE] = mlo; red[7][threadIdx.x / WAVE] = mhi; }
     }
     __syncthreads();
-    uint32_t tile_mass_bits = 0u;
-    if (c.want_tile_mass && threadIdx.x == 0) {  // (red[6..7] are not written again: the fold below reads rows 0..5 after its own barrier)
+    // mixed: the halo holds both masses — the lists get the lighter class first and the heavier behind it (two walks of the
+    // candidates, the second over what the first left out), so that the plane-layout kernels can sum the second segment apart
+    bool mixed = false;
+    if (c.two_mass) {  // (every thread folds the per-wave rows: red[6..7] are not written again)
         uint32_t lo = 0xffffffffu, hi = 0u;
         for (uint32_t k = 0; k < blockDim.x / WAVE; ++k) { lo = min(lo, red[6][k]); hi = max(hi, red[7][k]); }
-        const float m = __uint_as_float(lo);
-        tile_mass_bits = (lo == hi && m > 0.0f && m < __builtin_inff()) ? lo : 0u;
+        lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo); hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);  // (workgroup-uniform: scalar registers)
+        mixed = lo != hi;
+        if (mixed)  // the host promised two masses: a third one is an internal error, reported with the step's flags
+            t.for_halo(c, [&](uint32_t, uint32_t g) {
+                const uint32_t mb = __float_as_uint(c.posm[g].w);
+                if (mb != lo && mb != hi) atomicOr(c.flags, 8u);
+            });
+        if (threadIdx.x == 0) { c.tile_mass_bits[t.slot] = lo; c.tile_massb_bits[t.slot] = mixed ? hi : 0u; }
     }
     uint32_t sum_ff = 0, sum_fb = 0, max_ff = 0, max_fb = 0, own_ff = 0, own_fb = 0;
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
@@ -658,7 +668,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
             if (t.SB)
                 for (uint32_t m = 0; m < c.nbmodels; ++m) fbmask |= (c.fb_ok[mi * c.nbmodels + m] ? 1u : 0u) << m;
         }
+        int pass = 0;            // mixed tiles walk the candidates twice: pass 0 takes the lighter class, pass 1 the heavier
+        uint32_t cnta = 0;       // length of the first segment
         auto ff_allowed = [&](uint32_t s) -> bool {
+            if (V != 0 && mixed && ((c.bmask >> Lm[s]) & 1u) != (uint32_t)pass) return false;
             return V != 0 ? ((ffmask >> Lm[s]) & 1u) != 0u : c.ff_ok[mi * c.nmodels + Lm[s]] != 0;
         };
         auto append = [&](uint32_t s) {
@@ -666,6 +679,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
             else pend = s;
             ++cnt;
         };
+#pragma unroll 1
+        for (pass = 0; pass < (mixed ? 2 : 1); ++pass) {
 #pragma unroll 1
         for (int dx = -1; dx <= 1; ++dx) {
 #pragma unroll 1
@@ -744,7 +759,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
                         }
                     }
                 }
-                if (t.SB) {
+                if (t.SB && pass == 0) {
                     const uint32_t bb = tc.blstart[row], be = tc.blstart[row + 3];
                     for (uint32_t s = bb; s < be; ++s) {
                         const float4 pj = Bp[s];
@@ -759,6 +774,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
                 }
             }
         }
+        if (pass == 0) cnta = cnt;
+        }  // passes
         // an odd list is padded with the particle's own slot (for_each_ff2: the self contact adds nothing to gradient sums)
         const int hself = (lx * HY + ly) * HZ + lz;
         self_slot = tc.lstart[hself] + (i - tc.gstart[hself]);
@@ -768,6 +785,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
         // keep the true lengths, from which the host sees the overflow, grows the capacity and repeats the pass)
         c.nff[i] = min(cnt, 2u * c.cap_ff);
         c.nfb[i] = min(cntb, 2u * c.cap_fb);
+        if (c.two_mass) c.nffb[i] = min(cnt, 2u * c.cap_ff) - min(cnta, 2u * c.cap_ff);  // (0 in a tile of one mass: cnta == cnt)
         sum_ff += cnt; sum_fb += cntb;
         max_ff = max(max_ff, cnt); max_fb = max(max_fb, cntb);
         if (!is_ghost(c, i)) { own_ff += cnt; own_fb += cntb; }  // (a decomposed run reports the contacts of the particles it owns)
@@ -794,7 +812,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
     if (lane == 0) { red[0][wv] = sum_ff; red[1][wv] = sum_fb; red[2][wv] = max_ff; red[3][wv] = max_fb; red[4][wv] = own_ff; red[5][wv] = own_fb; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        TileListStats st{0, 0, 0, 0, 0, 0, tile_mass_bits, 0};
+        TileListStats st{0, 0, 0, 0, 0, 0};
         for (uint32_t k = 0; k < nw; ++k) {
             st.sum_ff += red[0][k]; st.sum_fb += red[1][k]; st.own_ff += red[4][k]; st.own_fb += red[5][k];
             st.max_ff = max(st.max_ff, red[2][k]); st.max_fb = max(st.max_fb, red[3][k]);
@@ -830,42 +848,6 @@ __global__ __launch_bounds__(BLOCK) void k_list_stats(const TileListStats* __res
         totals2[0] = ta; totals2[1] = tb; maxima2[0] = xa; maxima2[1] = xb;
         if (own2) { own2[0] = toa; own2[1] = tob; }
     }
-}
-
-// Tile classes (device_types.h StepCtx::cls_slots): one workgroup sorts the launched slots into "whole halo of one mass" — ascending,
-// first — and the rest — ascending, behind them — and writes the per-slot mass table the plane-layout kernels read.
-constexpr int CLS_THREADS = 1024;
-__global__ __launch_bounds__(CLS_THREADS) void k_tile_classes(const TileListStats* __restrict__ ts, uint32_t nslots, uint32_t* __restrict__ cls_slots,
-                                                              uint32_t* __restrict__ tile_mass_bits, uint32_t* __restrict__ n_uniform) {
-    __shared__ uint32_t wsum[CLS_THREADS / WAVE];
-    const uint32_t per = (nslots + CLS_THREADS - 1) / CLS_THREADS;
-    const uint32_t b = min(threadIdx.x * per, nslots), e = min(b + per, nslots);
-    uint32_t mine = 0;
-    for (uint32_t k = b; k < e; ++k) mine += ts[k].mass_bits != 0u ? 1u : 0u;
-    // exclusive prefix of `mine` over the block: inclusive scan within the wave, then the waves' totals
-    uint32_t inc = mine;
-    const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const uint32_t v = (uint32_t)__shfl_up((int)inc, o, WAVE);
-        if (lane >= (uint32_t)o) inc += v;
-    }
-    if (lane == WAVE - 1) wsum[wv] = inc;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-    for (uint32_t k = 0; k < CLS_THREADS / WAVE; ++k) { if (k < wv) before += wsum[k]; total += wsum[k]; }
-    uint32_t u = before + inc - mine;  // uniform slots before this thread's chunk
-    for (uint32_t k = b; k < e; ++k) {
-        const uint32_t mb = ts[k].mass_bits;
-        tile_mass_bits[k] = mb;
-        if (mb) cls_slots[u++] = k;
-        else cls_slots[total + (k - u)] = k;  // (k - u = mixed slots before k)
-    }
-    if (threadIdx.x == 0) *n_uniform = total;
-}
-void launch_tile_classes(const StepCtx& c, const void* tile_stats, uint32_t* cls_slots, uint32_t* tile_mass_bits, uint32_t* n_uniform, hipStream_t s) {
-    k_tile_classes<<<1, CLS_THREADS, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.nlaunch, cls_slots, tile_mass_bits, n_uniform);
-    SALVA_HIP_CHECK(hipGetLastError());
 }
 
 size_t tile_list_stats_bytes(uint32_t ntiles) { return (size_t)ntiles * sizeof(TileListStats); }

@@ -61,8 +61,6 @@ size_t tile_list_stats_bytes(uint32_t ntiles);
 // own2 (may be null) = the same totals over the particles this rank owns (no ghosts)
 void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsigned long long* totals2, uint32_t* maxima2,
                       unsigned long long* own2, hipStream_t s);
-// tile classes (StepCtx::cls_slots): sort the launched slots by "whole halo of one mass" from k_nbr_tile's per-tile statistics
-void launch_tile_classes(const StepCtx& c, const void* tile_stats, uint32_t* cls_slots, uint32_t* tile_mass_bits, uint32_t* n_uniform, hipStream_t s);
 size_t select_flagged_temp_bytes(uint32_t n);
 void select_flagged_f4(void* temp, size_t temp_bytes, const float4* in, const uint8_t* flags, float4* out, uint32_t* num_selected,
                        uint32_t n, hipStream_t s);

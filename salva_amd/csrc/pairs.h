@@ -80,7 +80,7 @@ template <uint32_t DS>
 __device__ __forceinline__ uint32_t p2_dist8(const Tile& t) { return DS ? DS * 8u : (((t.S + t.SB) * 8u + 15u) & ~15u); }
 __device__ __forceinline__ RecP3 load_p3(uint32_t o, uint32_t dist8) { return RecP3{lds_ld8(o), lds_ld8(o + dist8), lds_ld8(o + 2u * dist8)}; }
 template <bool AHEAD = true>
-// (`mass`: Tile::mass — the launch's uniform mass, or with tile classes the uniform mass of THIS tile's halo)
+// (`mass`: Tile::mass — the launch's uniform mass, or in a two-mass world the mass of the first segment of THIS tile's lists)
 __device__ __forceinline__ float pair_sum_velocity_divergence_p3(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh,
                                                                  const float4& pi, const float4& wi, uint32_t dist8, float mass) {
     f2 acc2 = {0.0f, 0.0f};
@@ -96,6 +96,25 @@ __device__ __forceinline__ float pair_sum_velocity_divergence_p3(const StepCtx& 
     });
     return (acc2.x + acc2.y) * c.sc.gscale * mass;
 }
+// Two-mass worlds, a tile whose halo holds both masses: the same sum with the mass INSIDE — entries [0, na) of the list carry ma,
+// the entries behind them mb (k_nbr_tile wrote the list that way; padding entries contribute nothing whatever their mass).  Two
+// compares, two selects and one packed multiply per pair of contacts more than the uniform loop; taken by the mixed tiles only.
+__device__ __forceinline__ float pair_sum_velocity_divergence_p3_two(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh, const float4& pi,
+                                                                     const float4& wi, uint32_t dist8, uint32_t na, float ma, float mb) {
+    f2 acc2 = {0.0f, 0.0f};
+    const f2 tiny = {1.0e-30f, 1.0e-30f};
+    for_each_ff2_indexed<2>(c, gs, nqu, lh, [&](uint32_t o) { return load_p3(o, dist8); }, [&](const RecP3& A, const RecP3& B, uint32_t q) { SALVA_PAIR_MATH
+        const f2 dx = {pi.x - A.xy.x, pi.x - B.xy.x}, dy = {pi.y - A.xy.y, pi.y - B.xy.y}, dz = {pi.z - A.zu.x, pi.z - B.zu.x};
+        f2 r2 = dz * dz + tiny;
+        r2 = dy * dy + r2;
+        r2 = dx * dx + r2;
+        const f2 g = kernel_gfac2(r2, c.sc);
+        const f2 ux = {wi.x - A.zu.y, wi.x - B.zu.y}, uy = {wi.y - A.vw.x, wi.y - B.vw.x}, uz = {wi.z - A.vw.y, wi.z - B.vw.y};
+        const f2 m = {2u * q < na ? ma : mb, 2u * q + 1u < na ? ma : mb};
+        acc2 += (ux * dx + uy * dy + uz * dz) * (g * m);
+    });
+    return (acc2.x + acc2.y) * c.sc.gscale;
+}
 __device__ __forceinline__ float pair_sum_velocity_divergence_exact_p3(const StepCtx& c, uint32_t i, uint32_t gs, const float4& pi,
                                                                        const float4& wi, uint32_t dist8, float mass) {
     float acc = 0.0f;
@@ -106,6 +125,29 @@ __device__ __forceinline__ float pair_sum_velocity_divergence_exact_p3(const Ste
         acc += ((wi.x - A.zu.y) * dx + (wi.y - A.vw.x) * dy + (wi.z - A.vw.y) * dz) * g;
     });
     return acc * mass;
+}
+// ---- two-mass worlds (device_types.h StepCtx::two_mass): the second segment of a list, entries [first, cnt), read from memory —
+// only in the tiles whose halo holds both masses and only for the particles that have such neighbours.  The callers add
+// (m_b - m_a) x these sums to m_a x the sum over the whole list.  f(slot) per entry.
+template <typename F>
+__device__ __forceinline__ void for_each_ff_range(const StepCtx& c, uint32_t gs, uint32_t first, uint32_t cnt, F&& f) {
+    const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gs * c.cap_ff * WAVE + 4u * (threadIdx.x & (WAVE - 1));
+    for (uint32_t e = first; e < cnt; ++e) {
+        const uint32_t d = p[ellq(e >> 1)];
+        f((e & 1u) ? (d >> 16) : (d & 0xffffu));
+    }
+}
+// sum over the second segment of (w_i - w_j) . grad W_ij (no mass)
+__device__ __forceinline__ float pair_tail_velocity_divergence_p3(const StepCtx& c, uint32_t gs, uint32_t first, uint32_t cnt, const float4& pi,
+                                                                  const float4& wi, uint32_t dist8) {
+    float acc = 0.0f;
+    for_each_ff_range(c, gs, first, cnt, [&](uint32_t s) { SALVA_PAIR_MATH
+        const RecP3 A = load_p3(s << 3, dist8);
+        const float dx = pi.x - A.xy.x, dy = pi.y - A.xy.y, dz = pi.z - A.zu.x;
+        const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+        acc += ((wi.x - A.zu.y) * dx + (wi.y - A.vw.x) * dy + (wi.z - A.vw.y) * dz) * g;
+    });
+    return acc;
 }
 // sum_j grad W_ij k_ij over the 16-byte plane layout (tile.h stage_p2), times the uniform mass
 struct RecP2 { lds_v2f xy, zk; };  // (x, y) | (z, kappa)
@@ -130,6 +172,24 @@ __device__ __forceinline__ void pair_sum_gradient_p2(const StepCtx& c, uint32_t 
     const float f = c.sc.gscale * mass;
     sx = (ax.x + ax.y) * f; sy = (ay.x + ay.y) * f; sz = (az.x + az.y) * f;
 }
+// the two-mass form of pair_sum_gradient_p2 (see pair_sum_velocity_divergence_p3_two)
+template <typename K2>
+__device__ __forceinline__ void pair_sum_gradient_p2_two(const StepCtx& c, uint32_t gs, uint32_t nqu, const ListRegs& lh, const float4& pi,
+                                                         uint32_t dist8, uint32_t na, float ma, float mb, K2&& kij2, float& sx, float& sy, float& sz) {
+    f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};
+    const f2 tiny = {1.0e-30f, 1.0e-30f};
+    for_each_ff2_indexed<2>(c, gs, nqu, lh, [&](uint32_t o) { return load_p2(o, dist8); }, [&](const RecP2& A, const RecP2& B, uint32_t q) { SALVA_PAIR_MATH
+        const f2 dx = {pi.x - A.xy.x, pi.x - B.xy.x}, dy = {pi.y - A.xy.y, pi.y - B.xy.y}, dz = {pi.z - A.zk.x, pi.z - B.zk.x};
+        f2 r2 = dz * dz + tiny;
+        r2 = dy * dy + r2;
+        r2 = dx * dx + r2;
+        const f2 g = kernel_gfac2(r2, c.sc);
+        const f2 m = {2u * q < na ? ma : mb, 2u * q + 1u < na ? ma : mb};
+        const f2 coeff = kij2(A.zk.y, B.zk.y) * (g * m);
+        ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
+    });
+    sx = (ax.x + ax.y) * c.sc.gscale; sy = (ay.x + ay.y) * c.sc.gscale; sz = (az.x + az.y) * c.sc.gscale;
+}
 template <typename K1>
 __device__ __forceinline__ void pair_sum_gradient_exact_p2(const StepCtx& c, uint32_t i, uint32_t gs, const float4& pi, uint32_t dist8,
                                                            float mass, K1&& kij1, float& sx, float& sy, float& sz) {
@@ -141,6 +201,19 @@ __device__ __forceinline__ void pair_sum_gradient_exact_p2(const StepCtx& c, uin
         ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
     });
     sx = ax * mass; sy = ay * mass; sz = az * mass;
+}
+// sum over the second segment of grad W_ij k_ij (no mass)
+template <typename K1>
+__device__ __forceinline__ void pair_tail_gradient_p2(const StepCtx& c, uint32_t gs, uint32_t first, uint32_t cnt, const float4& pi, uint32_t dist8,
+                                                      K1&& kij1, float& sx, float& sy, float& sz) {
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    for_each_ff_range(c, gs, first, cnt, [&](uint32_t s) { SALVA_PAIR_MATH
+        const RecP2 A = load_p2(s << 3, dist8);
+        const float dx = pi.x - A.xy.x, dy = pi.y - A.xy.y, dz = pi.z - A.zk.x;
+        const float coeff = kij1(A.zk.y) * kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
+        ax += dx * coeff; ay += dy * coeff; az += dz * coeff;
+    });
+    sx = ax; sy = ay; sz = az;
 }
 // a boundary halo slot of that layout: (x, y, z, V_b)
 __device__ __forceinline__ float4 p2_boundary_pos(const Tile& t, uint32_t s, uint32_t dist8) {

@@ -53,11 +53,6 @@ struct TileLds {
     // the plane layouts (stage_p3), which are filled through registers and need no 64-slot granularity
     uint32_t max_raw = 0;
     uint32_t ds_level = 0;  // SALVA_HIP_DS_LEVEL (pairs.h pick_ds*): 0 in production
-    // tile classes (device_types.h StepCtx::cls_slots): the launch over the mixed tiles — a few hundred workgroups, one round of a
-    // few microseconds that would otherwise run alone between two full launches — goes to a second stream, forked and joined by
-    // events, so that it shares the chip with the launch over the uniform tiles.  Null: one after the other on the pass's stream.
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t raw_slots() const { return max_raw ? max_raw : max_halo_fluid + max_halo_boundary; }
     uint32_t sum_slots() const {
         const uint32_t worst = ((max_halo_fluid + 63u) & ~63u) + max_halo_boundary;
@@ -209,8 +204,9 @@ struct Tile {
     static constexpr int PRE = 4;
     uint32_t pre0, pre1, pre2, pre3, preb;
     bool skip;  // this launch is not the one that handles the tile (StepCtx::phase): leave every output alone
-    float mass; // what the plane-layout kernels multiply their finished sums by: StepCtx::mass_uniform, or — tile classes — the
-                // uniform mass of THIS tile's halo (StepCtx::tile_mass_bits)
+    float mass;   // what the plane-layout kernels multiply their finished sums by: StepCtx::mass_uniform, or — two-mass worlds — the
+                  // mass of the first segment of THIS tile's lists (StepCtx::tile_mass_bits)
+    float massb;  // two-mass worlds: the mass of the second segment, 0 = this tile's halo holds one mass only
 
     __device__ __forceinline__ bool empty() const { return own_begin == own_end; }
     __device__ __forceinline__ bool skipped() const { return skip; }
@@ -221,7 +217,7 @@ struct Tile {
         pool = tile_smem;
         pool_used = 0;
         skip = false;
-        mass = 0.0f;
+        mass = massb = 0.0f;
         slot = blockIdx.x;
         S = SB = 0; slice_base = 0; hoff = hboff = 0;
         pre0 = pre1 = pre2 = pre3 = preb = 0u;
@@ -252,17 +248,15 @@ struct Tile {
             if (rk < 64u)
                 for (unsigned i = 0; i < ((rk >> 4) & 3u); ++i) __builtin_amdgcn_s_sleep(64);
         }
-        uint32_t at = xcd_block(blockIdx.x, gridDim.x, c.xcd);
-        // tile classes (worlds with more than one mass, device_types.h): this launch covers the slots cls_slots[cls_off ..) names
-        if (c.cls_slots) at = c.cls_slots[c.cls_off + at];
-        setup_at(c, at);
+        setup_at(c, xcd_block(blockIdx.x, gridDim.x, c.xcd));
     }
     __device__ __forceinline__ void setup_at(const StepCtx& c, uint32_t at_slot) {
         pool = tile_smem;
         pool_used = 0;
         slot = at_slot;
         const uint4 desc = c.slot_desc[slot];
-        mass = c.tile_mass_bits ? __uint_as_float(c.tile_mass_bits[slot]) : c.mass_uniform;
+        mass = c.two_mass ? __uint_as_float(c.tile_mass_bits[slot]) : c.mass_uniform;
+        massb = c.two_mass ? __uint_as_float(c.tile_massb_bits[slot]) : 0.0f;
         pre0 = pre1 = pre2 = pre3 = preb = 0u;
         if (c.halo_stride) {
             const uint32_t* __restrict__ src = c.halo_src + (size_t)slot * c.halo_stride;
@@ -851,6 +845,37 @@ __device__ __forceinline__ void for_each_ff2(const StepCtx& c, uint32_t gslice, 
                 const auto d1 = load(entry_hi<OFF>(a));
                 compute2(d0, d1);
             }
+        }
+    }
+}
+// The same walk with the list position handed to the body: compute2(A, B, q) gets the dword index q (entries 2q and 2q + 1) — a
+// compile-time constant in the unrolled part.  For the loops whose summand depends on WHERE in the list a contact sits (two-mass
+// worlds: the lighter class first, the heavier behind it; pairs.h).
+template <int OFF, typename L, typename C2>
+__device__ __forceinline__ void for_each_ff2_indexed(const StepCtx& c, uint32_t gslice, uint32_t nq, const ListRegs& lr, L&& load, C2&& compute2) {
+#pragma unroll
+    for (int k = 0; k < LIST_REGS; k += 2) {
+        if ((uint32_t)k < nq) {
+            const uint32_t a = lr.d[k];
+            const bool two = (uint32_t)(k + 1) < nq;
+            const uint32_t b = two ? lr.d[k + 1] : a;
+            const auto d0 = load(entry_lo<OFF>(a));
+            const auto d1 = load(entry_hi<OFF>(a));
+            const auto d2 = load(entry_lo<OFF>(b));
+            const auto d3 = load(entry_hi<OFF>(b));
+            compute2(d0, d1, (uint32_t)k);
+            if (two) compute2(d2, d3, (uint32_t)(k + 1));
+        }
+    }
+    if (nq > (uint32_t)LIST_REGS) {
+        const uint32_t* __restrict__ p = c.nbr_ff + (size_t)gslice * c.cap_ff * WAVE + 4u * (threadIdx.x & (WAVE - 1));
+        uint32_t nx = p[ellq(LIST_REGS)];
+        for (uint32_t q = LIST_REGS; q < nq; ++q) {
+            const uint32_t a = nx;
+            if (q + 1 < nq) nx = p[ellq(q + 1)];
+            const auto d0 = load(entry_lo<OFF>(a));
+            const auto d1 = load(entry_hi<OFF>(a));
+            compute2(d0, d1, q);
         }
     }
 }

@@ -18,6 +18,9 @@ namespace salva {
 struct FluidSlot {
     uint64_t n = 0;
     float density0 = 1000.0f;
+    // the one volume every particle of this fluid has (`Fluid::new`'s default, fluid.rs:110-120, or a uniform user array), NaN when the
+    // volumes differ: what lets the host know the particle masses without looking at the device (World::decide_two_mass)
+    float vol_uniform = 0.0f;
     uint32_t memberships = 1u, filter = 0xffffffffu;
     std::vector<SalvaHipForceDesc> forces;
     std::vector<uint32_t> force_iters;  // iterative forces (DFSPHViscosity): iterations / last error of the last step
@@ -226,13 +229,14 @@ class World {
     DevBuf<int32_t> bbox_partials;
     TileLds lds;
     float mass_uniform = 0.0f;  // StepCtx::mass_uniform of the current step (0: masses differ, or not known)
-    // Tile classes (device_types.h StepCtx::cls_slots): worlds known to hold more than one mass run their DFSPH passes as two
-    // launches, plane-layout kernels over the tiles whose halo has one mass and general kernels over the rest.
-    DevBuf<uint32_t> cls_slots, tile_mass_bits;
-    bool classes_off = true;      // on with SALVA_HIP_TILE_CLASSES=1 only: measured slower than the general kernels
-    bool classes_wanted = false;  // this pass builds the class tables (k_nbr_tile reduces the halo masses)
-    bool classes_active = false;  // ... and they are known on the host: make_ctx hands them to the launchers
-    uint32_t n_uniform_tiles = 0;
+    // Two-mass worlds (device_types.h StepCtx::two_mass; BASELINE config 4): every fluid has one particle mass (uniform volumes:
+    // FluidSlot::vol_uniform) and exactly two different masses occur.  The plane-layout kernels then serve the whole world in one
+    // launch per pass, the heavier class as a tail segment of the lists in the tiles that hold both.
+    DevBuf<uint32_t> tile_mass_bits, tile_massb_bits, nffb;
+    bool two_mass_off = false;    // SALVA_HIP_NO_TWO_MASS=1 (A/B, tests): such a world keeps the general kernels
+    bool two_mass = false;        // this step runs that way
+    uint32_t two_mass_bmask = 0;  // fluids with the heavier mass
+    bool decide_two_mass();
     // Decomposed runs, timers enabled (salva_hip_enable_counters): HIP event pairs around every ghost refresh (gather -> exchange ->
     // scatter) and every all-reduced convergence test (sum -> all-reduce -> decide) of a step, folded into `dist_times` at its end:
     // {refresh ms, refreshes, test ms, tests} — what an exchange costs INSIDE a decomposed step, waiting for the neighbour included

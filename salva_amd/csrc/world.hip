@@ -134,9 +134,7 @@ World::World(const SalvaHipParams& p) : prm(p) {
     defer_off = getenv("SALVA_HIP_NO_DEFER_LISTS") != nullptr;
     spec_apply_off = getenv("SALVA_HIP_NO_SPEC_APPLY") != nullptr;
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
-    // (measured slower than the general kernels on BASELINE config 4 — 2.67 against 2.60 ms per step: the second launch of every pass,
-    // a few hundred mixed tiles running alone, costs more than the third resident tile returns on the others; DESIGN.md §3.3.  Opt-in.)
-    classes_off = getenv("SALVA_HIP_TILE_CLASSES") == nullptr;
+    two_mass_off = getenv("SALVA_HIP_NO_TWO_MASS") != nullptr;
     tile_trace = getenv("SALVA_HIP_TILE_TRACE") != nullptr;
     no_fused_div = getenv("SALVA_HIP_NO_FUSED_DIV") != nullptr;
     if (const char* e = getenv("SALVA_HIP_RADIX_SORT")) sort_mode = atoi(e) != 0 ? 1 : 0;
@@ -282,6 +280,15 @@ void World::set_fluid(uint32_t slot, uint64_t nn, const float* pos, const float*
     }
     FluidSlot& f = fluids[slot];
     f.density0 = density0; f.memberships = memberships; f.filter = filter;
+    {   // the fluid's one volume, if it has one (FluidSlot::vol_uniform): a resize filled the default in, an upload may change it
+        const float r = prm.particle_radius;
+        if (resized) f.vol_uniform = r * r * r * 6.4f;
+        if (nn && (dirty & SALVA_HIP_DIRTY_VOLUMES) && vol) {
+            bool same = true;
+            for (uint64_t k = 1; k < nn && same; ++k) same = vol[k] == vol[0];
+            f.vol_uniform = same ? vol[0] : std::numeric_limits<float>::quiet_NaN();
+        }
+    }
     auto upload3 = [&](const float* src, float4* dst, int keep_w) {
         scratch_f.ensure(3 * nn, stream, false, 1.1f);
         SALVA_HIP_CHECK(hipMemcpyAsync(scratch_f.p, src, 3 * nn * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -331,6 +338,12 @@ void World::add_particles(uint32_t slot, uint64_t n_add, const float* pos, const
     rebuild(st_model, pieces, new_total, stream);
     n = (uint32_t)new_total;
     fluids[slot].n = old_n + n_add;
+    {   // (the new particles have the default volume: the fluid keeps ONE volume only if that is the one it had)
+        const float r = prm.particle_radius, default_vol = r * r * r * 6.4f;
+        FluidSlot& f = fluids[slot];
+        if (old_n == 0) f.vol_uniform = default_vol;
+        else if (!(f.vol_uniform == default_vol)) f.vol_uniform = std::numeric_limits<float>::quiet_NaN();
+    }
     const float r = prm.particle_radius;
     k_fill_f4<<<nblk(n_add), BLOCK, 0, stream>>>((uint32_t)n_add, st_pos.p + at, make_float4(0, 0, 0, r * r * r * 6.4f), 0);
     k_fill_f4<<<nblk(n_add), BLOCK, 0, stream>>>((uint32_t)n_add, st_vel.p + at, make_float4(0, 0, 0, 0), 0);
@@ -669,10 +682,11 @@ StepCtx World::make_ctx() {
     c.nmodels = (uint32_t)std::max<size_t>(fluids.size(), 1);
     c.nbmodels = (uint32_t)std::max<size_t>(bounds.size(), 1);
     c.mass_uniform = mass_uniform;
-    c.want_tile_mass = classes_wanted ? 1u : 0u;
-    c.cls_slots = classes_active ? cls_slots.p : nullptr;
-    c.tile_mass_bits = classes_active ? tile_mass_bits.p : nullptr;
-    c.cls_off = 0u; c.n_uniform = classes_active ? n_uniform_tiles : 0u;
+    c.two_mass = two_mass ? 1u : 0u;
+    c.bmask = two_mass_bmask;
+    c.tile_mass_bits = two_mass ? tile_mass_bits.p : nullptr;
+    c.tile_massb_bits = two_mass ? tile_massb_bits.p : nullptr;
+    c.nffb = two_mass ? nffb.p : nullptr;
     c.bvel_zero = 1u;  // no boundary particle moves: the passes that subtract a boundary velocity need not stage it
     for (const BoundarySlot& b : bounds) if (b.n && (!b.vel_zero || b.sampling || b.dyn_kind)) c.bvel_zero = 0u;
     c.rho0_tab = rho0_tab.p; c.rho0_single = fluids.empty() ? 1000.0f : fluids[0].density0; c.ff_ok = ff_ok.p; c.fb_ok = fb_ok.p; c.bb_ok = bb_ok.p;
@@ -778,7 +792,6 @@ __global__ void k_publish_readback(Readback* __restrict__ src, const TileAcc* __
             pub_rb->ncontacts_ff = src->ncontacts_ff; pub_rb->ncontacts_fb = src->ncontacts_fb;
             pub_rb->max_cnt_ff = src->max_cnt_ff; pub_rb->max_cnt_fb = src->max_cnt_fb;
             pub_rb->ncontacts_own_ff = src->ncontacts_own_ff; pub_rb->ncontacts_own_fb = src->ncontacts_own_fb;
-            pub_rb->n_uniform_tiles = src->n_uniform_tiles;
         }
         if (end_of_step) {
             pub_rb->flags = src->flags;
@@ -816,7 +829,6 @@ void World::publish_wait(uint32_t seq, bool totals, bool lists, bool end_of_step
     if (lists) {
         h_rb->ncontacts_ff = p.ncontacts_ff; h_rb->ncontacts_fb = p.ncontacts_fb; h_rb->max_cnt_ff = p.max_cnt_ff; h_rb->max_cnt_fb = p.max_cnt_fb;
         h_rb->ncontacts_own_ff = p.ncontacts_own_ff; h_rb->ncontacts_own_fb = p.ncontacts_own_fb;
-        h_rb->n_uniform_tiles = p.n_uniform_tiles;
     }
     if (end_of_step) { h_rb->flags = p.flags; memcpy(h_rb->bbox, p.bbox, sizeof(p.bbox)); }
 }
@@ -1000,6 +1012,32 @@ void World::evaluate_split(const StepCtx& c, int iteration, Launch&& launch) {
     SALVA_HIP_CHECK(hipStreamWaitEvent(stream, ev_interior, 0));
 }
 
+// Two-mass worlds (device_types.h StepCtx::two_mass): a single-domain DFSPH world with the default kernels in which every non-empty
+// fluid has one particle mass (FluidSlot::vol_uniform x density0, the product launch_stage_to_sorted forms) and exactly two
+// different masses occur — BASELINE config 4.  Sets two_mass_bmask (the fluids with the heavier mass).
+bool World::decide_two_mass() {
+    two_mass_bmask = 0u;
+    if (two_mass_off || no_planes || comm || prm.solver != SALVA_HIP_SOLVER_DFSPH || prm.kernel_density != 0 || prm.kernel_gradient != 0) return false;
+    if (fluids.size() < 2 || fluids.size() > 32 || bounds.size() > 32) return false;
+    float lo = 0.0f, hi = 0.0f;
+    int distinct = 0;
+    for (const FluidSlot& f : fluids) {
+        if (f.n == 0) continue;
+        const float m = f.vol_uniform * f.density0;
+        if (!(m > 0.0f) || !std::isfinite(m)) return false;  // (NaN: the fluid's volumes differ)
+        if (distinct == 0) { lo = hi = m; distinct = 1; }
+        else if (m != lo && m != hi) {
+            if (distinct == 2) return false;  // a third mass
+            if (m < lo) lo = m; else hi = m;
+            distinct = 2;
+        }
+    }
+    if (distinct != 2) return false;
+    for (uint32_t k = 0; k < fluids.size(); ++k)
+        if (fluids[k].n && fluids[k].vol_uniform * fluids[k].density0 == hi) two_mass_bmask |= 1u << k;
+    return true;
+}
+
 void World::set_cfl(int mode, float coeff, int min_sub, int max_sub) {
     if (mode < 0 || mode > 2) throw HipError(SALVA_HIP_E_INVALID, "cfl mode must be 0 (off), 1 (the reference's commented clamp) or 2 (the same, cut at the end of the step)");
     if (mode && (!(coeff > 0.0f) || !std::isfinite(coeff))) throw HipError(SALVA_HIP_E_INVALID, "cfl_coeff must be positive");
@@ -1066,7 +1104,7 @@ void World::dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepSta
     // Worth ~3 us per iteration (measured: a 50-iteration step 5.13 -> 4.99 ms); the apply that follows the converging evaluate is
     // then computed in vain (~30 us once per solve), so: only when the previous step's solve ran 16 iterations or more; not with boundary reaction forces (an
     // apply that is thrown away must not have added to them) and not in decomposed runs (the test sits behind an all-reduce).
-    const bool spec_apply = !spec_apply_off && !comm && !any_wants_forces && last_iters[0] >= 16u && !classes_active;
+    const bool spec_apply = !spec_apply_off && !comm && !any_wants_forces && last_iters[0] >= 16u;
     if (spec_apply) { w2.ensure(n, stream, false, 1.1f); spec_ring.ensure(2); c.w2 = w2.p; c.spec_ring = spec_ring.p; }
     const SolveResult rd = run_solve(
         c, 0, prm.max_divergence_error * inv_dt_prev * 0.01f, prm.min_divergence_iter, prm.max_divergence_iter, 0u,
@@ -1237,6 +1275,8 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     if (has_akinci) normal.ensure(n, stream, false, 1.1f);
     if (prm.solver == SALVA_HIP_SOLVER_IISPH) { kappa2.ensure(n); rho_star.ensure(n); aii.ensure(n); dii.ensure(n); dijpj.ensure(n); iisph_q.ensure(n); iisph_pr.ensure(n); }
     bbox_partials.ensure(6 * std::max<size_t>(std::max<size_t>(num_blocks(n), bbox_blocks(n)), 1024));
+    two_mass = decide_two_mass();
+    if (two_mass) nffb.ensure(n, stream, false, 1.1f);
 
     // ---- cell bounding box (known from the previous step's position update unless the host moved particles)
     if (!bbox_known) {
@@ -1264,6 +1304,10 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     // every tile wastes less than one 64-particle slice
     const uint32_t ns_cap = n / WAVE + nslots_bound + 1;
     tile_list_stats.ensure(tile_list_stats_bytes(std::max<uint32_t>(nslots_bound, 1u)), stream, false, 1.5f);
+    if (two_mass) {  // (per slot; Tile::setup reads them in every tile kernel, k_nbr_tile writes them)
+        tile_mass_bits.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
+        tile_massb_bits.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
+    }
 
     // ---- One pass over the step.  The sizes of the tile tables (number of non-empty tiles, largest halo, slices) and the
     // longest neighbour list are results of this step's own kernels; waiting for them costs two host round trips with an
@@ -1281,13 +1325,7 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     const bool can_redo = (!comm || solo) && !any_wants_forces && !has_custom && !has_dyn;
     // (mass_known: the kernels of a pass are chosen by StepCtx::mass_uniform, which a speculative pass — it does not wait for the
     // publication that carries it — can only inherit; a host edit since the last publication may have changed the masses)
-    // Tile classes: a single-domain DFSPH world (default kernels) whose particles are KNOWN not to share one mass.  The class tables
-    // are this step's own product and the launch shapes need their split: such a world waits for the list statistics in the
-    // middle of the step (one host round trip of a multi-millisecond step) and never sizes speculatively.
-    const bool classes_possible = !classes_off && !no_planes && !comm && prm.solver == SALVA_HIP_SOLVER_DFSPH && prm.kernel_density == 0 &&
-                                  prm.kernel_gradient == 0 && fluids.size() <= 32 && bounds.size() <= 32;
-    const bool can_speculate = !spec_off && can_redo && !b_dirty && pred_valid && pred_n == n && mass_known &&
-                               !(classes_possible && mass_uniform == 0.0f);
+    const bool can_speculate = !spec_off && can_redo && !b_dirty && pred_valid && pred_n == n && mass_known;
     // The neighbour-list capacity check (longest list <= ELL capacity) costs a read-back with an idle GPU in the middle of the
     // step although it fails about once per run (the capacity follows the longest list seen so far): where the pass can be
     // repeated, check at the end of the step with the read-back that happens there anyway, and repeat on overflow.
@@ -1315,12 +1353,7 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     StepCtx c{};
     for (int attempt = 0;; ++attempt) {
     bool spec = can_speculate && attempt == 0;
-    classes_wanted = classes_active = false;
-    lds.side_stream = nullptr;
-    // (mass_known && mass_uniform == 0: what the last exact pass found; a host edit clears mass_known and the first pass after it
-    // runs without classes — its k_cell_keys finds out)
-    const bool classes_now = classes_possible && mass_known && mass_uniform == 0.0f;
-    const bool defer_lists = can_redo && !defer_off && attempt == 0 && lists_checked && !classes_now;
+    const bool defer_lists = can_redo && !defer_off && attempt == 0 && lists_checked;
     if (attempt > 0) SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));  // (whatever the discarded pass flagged)
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
     {
@@ -1471,10 +1504,6 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         // ---- neighbour lists   (compute_contacts, contacts.rs:154-252): one pass into fixed-capacity ELL rows; if a list
         // turns out longer than the capacity the pass is repeated with room to spare (rare: the capacity follows the
         // longest list seen so far).  Speculative passes check at the end of the step instead.
-        // (the mass verdict of THIS pass's publication may differ from the one classes_now was taken from — a scene whose second
-        // fluid has just been removed: then no classes)
-        classes_wanted = classes_now && mass_uniform == 0.0f && !spec;
-        if (classes_wanted) { cls_slots.ensure(std::max<uint32_t>(nlaunch, 1u), stream, false, 1.5f); tile_mass_bits.ensure(std::max<uint32_t>(nlaunch, 1u), stream, false, 1.5f); }
         for (int nattempt = 0;; ++nattempt) {
             const bool r1 = nbr_ff.ensure((size_t)nslices * cap_ff * WAVE + 1, stream, false, 1.1f);
             const bool r2 = nbr_fb.ensure(nb ? (size_t)nslices * cap_fb * WAVE + 1 : 1, stream, false, 1.1f);
@@ -1483,7 +1512,6 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             c = make_ctx();
             launch_nbr_build(c, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff,
                              comm ? reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_own_ff) : nullptr, stream);
-            if (classes_wanted) launch_tile_classes(c, tile_list_stats.p, cls_slots.p, tile_mass_bits.p, &d_rb.p->n_uniform_tiles, stream);
             if (spec || defer_lists) break;
             static_assert(offsetof(Readback, max_cnt_ff) == offsetof(Readback, ncontacts_ff) + 2 * sizeof(uint64_t), "list statistics travel in one copy");
             publish_and_wait(nullptr, true, false);
@@ -1497,16 +1525,6 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         // kernel-development builds: bank-conflict-aware list order (diag/sched.hip), SALVA_HIP_SCHED=1
         if (sched_mode > 0) launch_list_schedule(c, lds, stream);
 #endif
-        if (classes_wanted) {  // (the list statistics have been waited for: defer_lists and spec are off in such a world)
-            n_uniform_tiles = std::min(h_rb->n_uniform_tiles, nlaunch);
-            classes_active = n_uniform_tiles > 0u;
-            classes_wanted = false;
-            // (the two events are the decomposed runs' — which never have classes)
-            static const bool fork = getenv("SALVA_HIP_CLASS_FORK") != nullptr;  // A/B: the mixed tiles' launch on a second stream (measured slower still)
-            lds.side_stream = (classes_active && fork) ? stream2 : nullptr;
-            lds.ev_fork = ev_pre_refresh; lds.ev_join = ev_interior;
-            c = make_ctx();
-        }
     }
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[1], stream));
 
@@ -1614,6 +1632,10 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     if (h_rb->flags & 2u) {
         bbox_known = false;
         throw HipError(SALVA_HIP_E_HIP, "internal error: particle outside the cell table");
+    }
+    if (h_rb->flags & 8u) {
+        bbox_known = false;
+        throw HipError(SALVA_HIP_E_HIP, "internal error: a third particle mass in a world the host took for a two-mass world");
     }
     if (h_rb->flags & 4u)
         // k_dist_flags: such a particle was handed to the adjacent rank, which does not own its cells either — it would

@@ -43,6 +43,7 @@ def one(table, fragment):
 def test_solver_kernels_keep_three_tiles_per_cu(tmp_path):
     t = resources("dfsph.hip", tmp_path)
     # the plane-layout kernels of the divergence and pressure solves at their three-tile distance (pairs.h P3_DS_THREE / P2_DS_THREE)
+    # (each of them carries the uniform loop AND the two-mass loop of round 5: the budget covers both)
     for fragment in ("k_divergence_p3ILj2080E", "k_pred_density_p3ILj2080E", "k_divergence_apply_p2ILj2464E", "k_pressure_apply_p2ILj2464E"):
         r = one(t, fragment)
         assert r["vgprs"] <= 80 and r["waves"] >= 6 and r["scratch"] == 0 and r["spilled"] == 0, (fragment, r)
@@ -61,6 +62,7 @@ def test_solver_kernels_keep_three_tiles_per_cu(tmp_path):
 def test_neighbour_list_kernel_keeps_four_tiles_per_cu(tmp_path):
     t = resources("grid.hip", tmp_path)
     r = one(t, "k_nbr_tileILi1E")
-    # (held to 64 VGPRs by its launch bounds: two registers live in scratch, 12 bytes per lane — measured faster than three tiles
-    # without them, profiles/r04_experiments/r04b_*; more than that would be a change worth looking at)
-    assert r["vgprs"] <= 64 and r["waves"] >= 8 and r["scratch"] <= 16 and r["spilled"] <= 2, r
+    # (held to 64 VGPRs by its launch bounds: three registers live in scratch, 16 bytes per lane — two until round 5, measured faster
+    # than three tiles without them, profiles/r04_experiments/r04b_*; the third came with the two-mass walk and costs nothing
+    # measurable, profiles/r05_experiments/r05i_*; more than that would be a change worth looking at)
+    assert r["vgprs"] <= 64 and r["waves"] >= 8 and r["scratch"] <= 16 and r["spilled"] <= 3, r

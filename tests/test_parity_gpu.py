@@ -480,7 +480,7 @@ def test_plane_layouts_and_the_fused_first_divergence_change_rounding_only(monke
     counts are identical and the states agree to f32 summation order; a scene whose masses differ takes the old kernels whatever
     the switches say and is bit-identical."""
     def run(scene, nsteps, env):
-        for k in ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV", "SALVA_HIP_TILE_CLASSES"):
+        for k in ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV", "SALVA_HIP_NO_TWO_MASS"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
@@ -495,9 +495,10 @@ def test_plane_layouts_and_the_fused_first_divergence_change_rounding_only(monke
         dp, dv = np.abs(base["pos_0"] - other["pos_0"]).max(), np.abs(base["vel_0"] - other["vel_0"]).max()
         assert dp < 2e-5 * R * nsteps, f"{env}: positions differ by {dp / R:.2e} r"
         assert dv < 1e-4, f"{env}: velocities differ by {dv:.2e} m/s"
-    # fluids of different density0: the masses differ, and without the opt-in per-tile classes of round 5 (next test) nothing above applies
+    # fluids of different density0: the masses differ, and without the two-mass form of the plane layouts (round 5, next test) nothing
+    # above applies
     two = SCENES["two_phase"][0]()
-    a, b = run(two, 6, ()), run(two, 6, ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV"))
+    a, b = run(two, 6, ("SALVA_HIP_NO_TWO_MASS",)), run(two, 6, ("SALVA_HIP_NO_TWO_MASS", "SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV"))
     assert np.array_equal(a["iters"], b["iters"])
     for f in range(2):
         assert np.array_equal(a[f"pos_{f}"], b[f"pos_{f}"]) and np.array_equal(a[f"vel_{f}"], b[f"vel_{f}"])
@@ -519,36 +520,52 @@ def _two_phase_side_by_side():
     return s
 
 
-def test_tile_classes_change_rounding_only(monkeypatch):
-    """Round 5, opt-in (SALVA_HIP_TILE_CLASSES=1): a world whose particles do not share one mass (two fluids of different density0,
-    BASELINE config 4) can run every DFSPH pass as two launches — the plane-layout kernels over the tiles whose whole halo has one
-    mass, with that tile's mass, and the general kernels over the tiles that see both (built, measured, slower than
-    the general kernels alone on config 4, hence not the default).  Other kernels for the same sums: against the default run the
-    contact and iteration counts are identical and the states agree to f32 summation order — but not bit for bit, or the classes
-    were never on — and both agree with the oracle."""
+def test_two_mass_worlds_take_the_plane_layouts(monkeypatch):
+    """Round 5: a world with exactly two particle masses — two fluids of different density0 with `Fluid::new`'s uniform volumes,
+    BASELINE config 4 — runs the plane-layout kernels too: k_nbr_tile writes the lists of the tiles that see both
+    masses with the lighter class first, and the kernels add (m_b - m_a) x the sum over the heavier tail segment to m_a x the sum
+    over the whole list.  Other kernels for the same sums: against a run with SALVA_HIP_NO_TWO_MASS=1 (the general kernels) the
+    contact and iteration counts are identical and the states agree to f32 summation order — but not bit for bit, or the path
+    never switched on — and both agree with the oracle.  A third fluid with one of the two masses changes nothing; a third MASS, or
+    a fluid with non-uniform volumes, falls back to the general kernels (bit-identical to NO_TWO_MASS)."""
     scene = _two_phase_side_by_side()
     nsteps = 10
-    monkeypatch.delenv("SALVA_HIP_TILE_CLASSES", raising=False)
+    monkeypatch.delenv("SALVA_HIP_NO_TWO_MASS", raising=False)
+    on = run_hip(scene, nsteps)
+    monkeypatch.setenv("SALVA_HIP_NO_TWO_MASS", "1")
     off = run_hip(scene, nsteps)
-    ons = []
-    for fork in (False, True):
-        monkeypatch.setenv("SALVA_HIP_TILE_CLASSES", "1")
-        if fork:
-            monkeypatch.setenv("SALVA_HIP_CLASS_FORK", "1")
-        ons.append(run_hip(scene, nsteps))
-        monkeypatch.delenv("SALVA_HIP_TILE_CLASSES", raising=False)
-        monkeypatch.delenv("SALVA_HIP_CLASS_FORK", raising=False)
-    on = ons[0]
-    for key in on:  # (the side stream moves a launch, not a bit)
-        assert np.array_equal(np.asarray(on[key]), np.asarray(ons[1][key]), equal_nan=True), key
+    monkeypatch.delenv("SALVA_HIP_NO_TWO_MASS", raising=False)
     assert np.array_equal(on["iters"], off["iters"]), "iteration or contact counts differ"
     differs = False
     for f in range(2):
         dp, dv = np.abs(on[f"pos_{f}"] - off[f"pos_{f}"]).max(), np.abs(on[f"vel_{f}"] - off[f"vel_{f}"]).max()
         assert dp < 2e-5 * R * nsteps and dv < 1e-4, (f, dp / R, dv)
         differs |= not np.array_equal(on[f"vel_{f}"], off[f"vel_{f}"])
-    assert differs, "bit-identical runs: the tile classes never switched on"
-    compare(on, run_oracle(scene, nsteps), scene, nsteps, "two-phase side by side (tile classes) vs oracle")
+    assert differs, "bit-identical runs: the two-mass path never switched on"
+    compare(on, run_oracle(scene, nsteps), scene, nsteps, "two-phase side by side (two-mass plane layouts) vs oracle")
+
+    # three fluids, two masses (the third shares the first one's): still the two-mass path, still the oracle's results
+    three = _two_phase_side_by_side()
+    top = scenes.jitter(scenes.cube_fluid_positions(10, 6, 10, R), 0.05 * R, seed=44)
+    top[:, 1] += np.float32(12 * R + 2 * R + 24 * R + 4 * R)
+    three.add_fluid(top, None, 1000.0, forces=[("xsph", 0.5, 0.0)])
+    compare(run_hip(three, 6), run_oracle(three, 6), three, 6, "three fluids, two masses vs oracle")
+
+    # a third mass, and non-uniform volumes: the general kernels, whatever the switch says
+    for variant in ("third_mass", "volumes"):
+        sc = _two_phase_side_by_side()
+        if variant == "third_mass":
+            sc.add_fluid(top, None, 800.0, forces=[("xsph", 0.5, 0.0)])
+        else:
+            vol = np.full(len(sc.fluids[0]["pos"]), 0.8 * (2 * R) ** 3, np.float32)
+            vol[::7] *= np.float32(1.01)
+            sc.fluids[0]["volumes"] = vol
+        a = run_hip(sc, 4)
+        monkeypatch.setenv("SALVA_HIP_NO_TWO_MASS", "1")
+        b = run_hip(sc, 4)
+        monkeypatch.delenv("SALVA_HIP_NO_TWO_MASS", raising=False)
+        for key in a:
+            assert np.array_equal(np.asarray(a[key]), np.asarray(b[key]), equal_nan=True), (variant, key)
 
 
 @pytest.mark.parametrize("name", ["dfsph_tank", "iisph_akinci", "dfsph_xsph_block", "two_phase"])
