@@ -173,8 +173,10 @@ void launch_density_alpha(const StepCtx& c, const TileLds& L, float iisph_dt, hi
 #ifndef SALVA_DAD_WAVES
 #define SALVA_DAD_WAVES 5
 #endif
-template <uint32_t DS>
-__global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_WAVES : 5) void k_density_alpha_div_p3(StepCtx c) {
+// (one body, two instantiations: the uniform-mass kernel carries none of the two-mass code — its second pair loop, the extra
+// list word — so that worlds with one mass run exactly what they ran before; device_types.h StepCtx::two_mass)
+template <uint32_t DS, bool TWO>
+__device__ __forceinline__ void k_density_alpha_div_p3_body(StepCtx c) {
     lds_base_check();
     Tile t;
     t.setup(c);
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
                 div += ((wi.x - A.zu.y) * dx + (wi.y - A.vw.x) * dy + (wi.z - A.vw.y) * dz) * gmj;
             });
         }
-        if (active && t.massb != 0.0f) {  // two-mass world, this tile holds both: the heavier neighbours' share on top of every sum
+        if (active && (TWO && t.massb != 0.0f)) {  // two-mass world, this tile holds both: the heavier neighbours' share on top of every sum
             const uint32_t nb2 = c.nffb[i];
             if (nb2) {
                 float rwb = 0.0f, gxb = 0.0f, gyb = 0.0f, gzb = 0.0f, s2b = 0.0f, dvb = 0.0f;
@@ -302,12 +304,17 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_W
     });
     E.finish(c, t.slot);
 }
+template <uint32_t DS>
+__global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_WAVES : 5) void k_density_alpha_div_p3(StepCtx c) { k_density_alpha_div_p3_body<DS, false>(c); }
+template <uint32_t DS>
+__global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_WAVES : 5) void k_density_alpha_div_p3_two(StepCtx c) { k_density_alpha_div_p3_body<DS, true>(c); }
 // true: the pass above ran and the divergence solve's iteration 0 must not launch its evaluate
 bool launch_density_alpha_div(const StepCtx& c, const TileLds& L, hipStream_t s) {
 #ifndef SALVA_OTHER_KERNELS
     if (!plane_layouts(c) || (c.sc.kd | c.sc.kg) != 0) return false;
     const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
-    SALVA_LAUNCH_P3(k_density_alpha_div_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
+    if (c.two_mass) SALVA_LAUNCH_P3(k_density_alpha_div_p3_two, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
+    else SALVA_LAUNCH_P3(k_density_alpha_div_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
     return true;
 #else
     return false;
@@ -429,8 +436,13 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
 // (c.mass_uniform > 0): three tiles per CU instead of two while the halos stay below P3_DS_THREE slots.
 // Register budget: P3_DS_THREE only pays with 24 waves per CU, i.e. at most 80 VGPRs.
 #define SALVA_P3_BOUNDS(DS) __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? 6 : 5)
-template <uint32_t DS>
-__global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
+#ifndef SALVA_EVAL_POST
+#define SALVA_EVAL_POST false  // (A/B: the uniform evaluate kernels load rho / alpha / model after the pair loop too)
+#endif
+// (one body, two instantiations: the uniform-mass kernel carries none of the two-mass code — its second pair loop, the extra
+// list word — so that worlds with one mass run exactly what they ran before; device_types.h StepCtx::two_mass)
+template <uint32_t DS, bool TWO>
+__device__ __forceinline__ void k_divergence_p3_body(StepCtx c) {
     const SolveCtl* const rec = solve_record(c);
     if (rec && rec->done) return;  // the solve converged earlier in this batch
     const float4* const win = rec ? solve_w_in(c, rec) : c.w;
@@ -439,11 +451,15 @@ __global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
     t.setup(c);
     if (t.skipped()) return;
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
-    // (the loop needs the position, w_i and the two contact counts of the < 20 rule; alpha_i and the model are loaded after it)
-    struct Own { float px, py, pz, ux, uy, uz; uint32_t cnt, cntb, nb2, near; ListRegs lh; };
+    // (the loop needs the position, w_i and the two contact counts of the < 20 rule.  alpha_i and the model: before the staging
+    // barrier with everything else in the uniform kernel — their latency hides behind the halo copy; AFTER the loop in the two-mass
+    // kernel, whose second pair loop needs the registers — SALVA_EVAL_POST)
+    constexpr bool POST = TWO || SALVA_EVAL_POST;
+    struct Own { float px, py, pz, ux, uy, uz, alpha; uint32_t mi, cnt, cntb, nb2, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
         const float4 p = c.posm[i], u = win[i];
-        return Own{p.x, p.y, p.z, u.x, u.y, u.z, c.nff[i], c.nb ? c.nfb[i] : 0u, t.massb != 0.0f ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
+        return Own{p.x, p.y, p.z, u.x, u.y, u.z, POST ? 0.0f : c.alpha[i], POST ? 0u : c.model[i], c.nff[i], c.nb ? c.nfb[i] : 0u,
+                   (TWO && t.massb != 0.0f) ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -461,17 +477,17 @@ __global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
         float err = 0.0f;
         uint32_t mi = 0;
         if (active) {
-            mi = c.model[i];
+            mi = POST ? c.model[i] : o.mi;
             const float rho0 = rho0_of(c, mi);
             float div = 0.0f;
             if (o.cnt + o.cntb >= c.min_neighbors_for_divergence) {
                 const float4 pi = make_float4(o.px, o.py, o.pz, 0.0f), wi = make_float4(o.ux, o.uy, o.uz, 0.0f);
-                if (t.massb != 0.0f && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
+                if ((TWO && t.massb != 0.0f) && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
                     div += pair_sum_velocity_divergence_p3_two(c, gs, nqu, o.lh, pi, wi, dist8, o.cnt - o.nb2, t.mass, t.massb);
                 } else {
                     div += near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8, t.mass)
                                 : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8, t.mass);
-                    if (t.massb != 0.0f && o.nb2)  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
+                    if ((TWO && t.massb != 0.0f) && o.nb2)  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
                         div += (t.massb - t.mass) * pair_tail_velocity_divergence_p3(c, gs, o.cnt - o.nb2, o.cnt, pi, wi, dist8);
                 }
                 for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
@@ -482,18 +498,23 @@ __global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) {
                 });
                 div = fmaxf(div, 0.0f);
             }
-            c.kappa[i] = div * c.alpha[i];
+            c.kappa[i] = div * (POST ? c.alpha[i] : o.alpha);
             err = div / rho0;
         }
         E.add(c, err, mi, active && !is_ghost(c, i));
     });
     E.finish(c, t.slot);
 }
+template <uint32_t DS>
+__global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) { k_divergence_p3_body<DS, false>(c); }
+template <uint32_t DS>
+__global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3_two(StepCtx c) { k_divergence_p3_body<DS, true>(c); }
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence, c, L, s);
     if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
-        SALVA_LAUNCH_P3(k_divergence_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
+        if (c.two_mass) SALVA_LAUNCH_P3(k_divergence_p3_two, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
+        else SALVA_LAUNCH_P3(k_divergence_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
         return;
     }
     const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
@@ -567,8 +588,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
 #define SALVA_P2_WAVES 6
 #endif
 #define SALVA_P2_BOUNDS(DS) __launch_bounds__(TILE_MAX_THREADS, (DS) == P2_DS_THREE ? SALVA_P2_WAVES : 5)
-template <uint32_t DS>
-__global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_dt_prev) {
+// (one body, two instantiations: the uniform-mass kernel carries none of the two-mass code — its second pair loop, the extra
+// list word — so that worlds with one mass run exactly what they ran before; device_types.h StepCtx::two_mass)
+template <uint32_t DS, bool TWO>
+__device__ __forceinline__ void k_divergence_apply_p2_body(StepCtx c, float inv_dt_prev) {
     const SolveCtl* const rec = solve_record(c);
     const bool was_done = rec && rec->done;
     const float4* const win = rec ? solve_w_in(c, rec) : c.w;
@@ -586,7 +609,7 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
     struct Own { float px, py, pz, ki; uint32_t cnt, nb2, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
         const float4 p = c.posm[i];
-        return Own{p.x, p.y, p.z, c.kappa[i], c.nff[i], t.massb != 0.0f ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
+        return Own{p.x, p.y, p.z, c.kappa[i], c.nff[i], (TWO && t.massb != 0.0f) ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -601,12 +624,12 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
         const float4 pi = make_float4(o.px, o.py, o.pz, 0.0f);
         const float ki = o.ki;
         float sx, sy, sz;
-        if (t.massb != 0.0f && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
+        if ((TWO && t.massb != 0.0f) && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
             pair_sum_gradient_p2_two(c, gs, nqu, o.lh, pi, dist8, o.cnt - o.nb2, t.mass, t.massb, [&](float ka, float kb) { return f2{ki + ka, ki + kb}; }, sx, sy, sz);
         } else {
             if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, t.mass, [&](float kj) { return ki + kj; }, sx, sy, sz);
             else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, t.mass, [&](float ka, float kb) { return f2{ki + ka, ki + kb}; }, sx, sy, sz);
-            if (t.massb != 0.0f && o.nb2) {  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
+            if ((TWO && t.massb != 0.0f) && o.nb2) {  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
                 float bx, by, bz;
                 pair_tail_gradient_p2(c, gs, o.cnt - o.nb2, o.cnt, pi, dist8, [&](float kj) { return ki + kj; }, bx, by, bz);
                 const float dm = t.massb - t.mass;
@@ -633,11 +656,16 @@ __global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_d
         wout[i] = d;
     });
 }
+template <uint32_t DS>
+__global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_dt_prev) { k_divergence_apply_p2_body<DS, false>(c, inv_dt_prev); }
+template <uint32_t DS>
+__global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2_two(StepCtx c, float inv_dt_prev) { k_divergence_apply_p2_body<DS, true>(c, inv_dt_prev); }
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence_apply, c, L, inv_dt_prev, s);
     if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
-        SALVA_LAUNCH_P2(k_divergence_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt_prev);
+        if (c.two_mass) SALVA_LAUNCH_P2(k_divergence_apply_p2_two, ds, c, L, p2_bytes(L, ds), s, c, inv_dt_prev);
+        else SALVA_LAUNCH_P2(k_divergence_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt_prev);
         return;
     }
     const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
@@ -756,19 +784,24 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
 #endif
 }
 // the plane-layout form (see k_divergence_p3)
-template <uint32_t DS>
-__global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
+// (one body, two instantiations: the uniform-mass kernel carries none of the two-mass code — its second pair loop, the extra
+// list word — so that worlds with one mass run exactly what they ran before; device_types.h StepCtx::two_mass)
+template <uint32_t DS, bool TWO>
+__device__ __forceinline__ void k_pred_density_p3_body(StepCtx c, float dt) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     lds_base_check();
     Tile t;
     t.setup(c);
     if (t.skipped()) return;
     if (t.empty()) { TileErr::zero(c, t.slot); return; }
-    // (the loop needs the position and w_i; rho_i, alpha_i and the model are loaded after it: no register carries them across)
-    struct Own { float px, py, pz, ux, uy, uz; uint32_t cnt, nb2, near; ListRegs lh; };
+    // (the loop needs the position and w_i; rho_i, alpha_i and the model come before the barrier in the uniform kernel and after the
+    // loop in the two-mass kernel: see k_divergence_p3_body)
+    constexpr bool POST = TWO || SALVA_EVAL_POST;
+    struct Own { float px, py, pz, ux, uy, uz, rho, alpha; uint32_t mi, cnt, nb2, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
         const float4 p = c.posm[i], u = c.w[i];
-        return Own{p.x, p.y, p.z, u.x, u.y, u.z, c.nff[i], t.massb != 0.0f ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
+        return Own{p.x, p.y, p.z, u.x, u.y, u.z, POST ? 0.0f : c.rho[i], POST ? 0.0f : c.alpha[i], POST ? 0u : c.model[i], c.nff[i],
+                   (TWO && t.massb != 0.0f) ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -792,15 +825,15 @@ __global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
         if (active) {
             const float4 pi = make_float4(o.px, o.py, o.pz, 0.0f), wi = make_float4(o.ux, o.uy, o.uz, 0.0f);
             float delta;
-            if (t.massb != 0.0f && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
+            if ((TWO && t.massb != 0.0f) && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
                 delta = pair_sum_velocity_divergence_p3_two(c, gs, nqu, o.lh, pi, wi, dist8, o.cnt - o.nb2, t.mass, t.massb);
             } else {
                 delta = near ? pair_sum_velocity_divergence_exact_p3(c, i, gs, pi, wi, dist8, t.mass)
                              : pair_sum_velocity_divergence_p3(c, gs, nqu, o.lh, pi, wi, dist8, t.mass);
-                if (t.massb != 0.0f && o.nb2)  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
+                if ((TWO && t.massb != 0.0f) && o.nb2)  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
                     delta += (t.massb - t.mass) * pair_tail_velocity_divergence_p3(c, gs, o.cnt - o.nb2, o.cnt, pi, wi, dist8);
             }
-            mi = c.model[i];
+            mi = POST ? c.model[i] : o.mi;
             const float rho0 = rho0_of(c, mi);
             for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                 const float4 pj = Bp[s];
@@ -809,20 +842,25 @@ __global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) {
                 const float g = kernel_grad(dx * dx + dy * dy + dz * dz, c.sc);
                 delta += pj.w * rho0 * (((wi.x - vj.x) * dx + (wi.y - vj.y) * dy + (wi.z - vj.z) * dz) * g);
             });
-            const float rs = c.rho[i] + delta * dt;
+            const float rs = (POST ? c.rho[i] : o.rho) + delta * dt;
             if (!(rs != 0.0f)) atomicOr(c.flags, 1u);  // assert!(!predicted_density.is_zero()) :145 (also catches NaN)
             err = (rs < rho0) ? 0.0f : rs / rho0 - 1.0f;
-            c.kappa[i] = (rs - rho0) * c.alpha[i];
+            c.kappa[i] = (rs - rho0) * (POST ? c.alpha[i] : o.alpha);
         }
         E.add(c, err, mi, active && !is_ghost(c, i));
     });
     E.finish(c, t.slot);
 }
+template <uint32_t DS>
+__global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) { k_pred_density_p3_body<DS, false>(c, dt); }
+template <uint32_t DS>
+__global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3_two(StepCtx c, float dt) { k_pred_density_p3_body<DS, true>(c, dt); }
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pred_density, c, L, dt, s);
     if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
-        SALVA_LAUNCH_P3(k_pred_density_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
+        if (c.two_mass) SALVA_LAUNCH_P3(k_pred_density_p3_two, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
+        else SALVA_LAUNCH_P3(k_pred_density_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
         return;
     }
     const uint32_t ds = pick_ds(pw_slots(L), L.ds_level);
@@ -886,8 +924,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
         c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
     });
 }
-template <uint32_t DS>
-__global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt) {
+// (one body, two instantiations: the uniform-mass kernel carries none of the two-mass code — its second pair loop, the extra
+// list word — so that worlds with one mass run exactly what they ran before; device_types.h StepCtx::two_mass)
+template <uint32_t DS, bool TWO>
+__device__ __forceinline__ void k_pressure_apply_p2_body(StepCtx c, float inv_dt) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     lds_base_check();
     Tile t;
@@ -897,7 +937,7 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
     struct Own { float px, py, pz, ki; uint32_t cnt, nb2, near; ListRegs lh; };
     auto load_own = [&](uint32_t i, uint32_t gs) {
         const float4 p = c.posm[i];
-        return Own{p.x, p.y, p.z, c.kappa[i], c.nff[i], t.massb != 0.0f ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
+        return Own{p.x, p.y, p.z, c.kappa[i], c.nff[i], (TWO && t.massb != 0.0f) ? c.nffb[i] : 0u, c.slice_near[gs], list_regs(c, gs)};
     };
     uint32_t i0, gs0;
     t.first_own(i0, gs0);
@@ -913,13 +953,13 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
         const float ki = o.ki;
         const float kip = fmaxf(ki, 0.0f);
         float sx, sy, sz;
-        if (t.massb != 0.0f && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
+        if ((TWO && t.massb != 0.0f) && !near) {  // two-mass world, this tile holds both: the mass inside the loop, by list position
             pair_sum_gradient_p2_two(c, gs, nqu, o.lh, pi, dist8, o.cnt - o.nb2, t.mass, t.massb,
                                      [&](float ka, float kb) { return f2{kip + fmaxf(ka, 0.0f), kip + fmaxf(kb, 0.0f)}; }, sx, sy, sz);
         } else {
             if (near) pair_sum_gradient_exact_p2(c, i, gs, pi, dist8, t.mass, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, sx, sy, sz);
             else pair_sum_gradient_p2(c, gs, nqu, o.lh, pi, dist8, t.mass, [&](float ka, float kb) { return f2{kip + fmaxf(ka, 0.0f), kip + fmaxf(kb, 0.0f)}; }, sx, sy, sz);
-            if (t.massb != 0.0f && o.nb2) {  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
+            if ((TWO && t.massb != 0.0f) && o.nb2) {  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
                 float bx, by, bz;
                 pair_tail_gradient_p2(c, gs, o.cnt - o.nb2, o.cnt, pi, dist8, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, bx, by, bz);
                 const float dm = t.massb - t.mass;
@@ -950,11 +990,16 @@ __global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt)
         c.w[i] = make_float4(v.x + d.x, v.y + d.y, v.z + d.z, __uint_as_float(mi));
     });
 }
+template <uint32_t DS>
+__global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt) { k_pressure_apply_p2_body<DS, false>(c, inv_dt); }
+template <uint32_t DS>
+__global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2_two(StepCtx c, float inv_dt) { k_pressure_apply_p2_body<DS, true>(c, inv_dt); }
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pressure_apply, c, L, inv_dt, s);
     if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
-        SALVA_LAUNCH_P2(k_pressure_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt);
+        if (c.two_mass) SALVA_LAUNCH_P2(k_pressure_apply_p2_two, ds, c, L, p2_bytes(L, ds), s, c, inv_dt);
+        else SALVA_LAUNCH_P2(k_pressure_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt);
         return;
     }
     const uint32_t ds = pick_ds(pk_slots(L), L.ds_level);
