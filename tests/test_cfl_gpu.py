@@ -20,53 +20,91 @@ def _dam_break(solver="dfsph", forces=(("xsph", 0.5, 0.0),)):
     return s
 
 
+def _falling_block(solver="dfsph"):
+    """A stirred block (random velocities, XSPH) released 2.4 m above a floor it does not reach within the test: gravity takes it
+    through the CFL bound after a few frame-sized steps and the flow stays smooth, so two f32 runs stay together to rounding and the
+    substeps can be compared one by one."""
+    s = Scene(R, 2.0, solver)
+    fluid = scenes.jitter(scenes.cube_fluid_positions(12, 16, 12, R), 0.05 * R, seed=42)
+    fluid[:, 1] += np.float32(2.4 + 16 * R)
+    s.add_fluid(fluid, scenes.random_velocities(len(fluid), 0.2, seed=7), 1000.0, forces=[("xsph", 0.5, 0.0)])
+    s.add_boundary(scenes.plane_lattice(24, 24, 0.0, R, -24 * R, -24 * R, layers=2))
+    return s
+
+
+def _structure(w, sw, mode):
+    assert w.counters.nsubsteps == len(sw)
+    # (mode 2 cuts the last substep at the end of the step: only that one may fall below dt / max_num_substeps)
+    assert all(DT / 10 * (1 - 1e-6) <= x <= DT * (1 + 1e-6) for x in (sw if mode == 1 else sw[:-1])) and 0 < sw[-1] <= DT * (1 + 1e-6)
+    assert sum(sw) >= DT * (1 - 1e-6) and (mode == 1 or abs(sum(sw) - DT) < 1e-6)
+    c = w.counters
+    assert c.step_time > 0 and c.stages.solver_time > 0  # the timers add up over the substeps
+
+
 @pytest.mark.parametrize("solver,mode", [("dfsph", 1), ("dfsph", 2), ("iisph", 1)])
-def test_cfl_substeps_match_the_oracle_on_the_dam_break(solver, mode):
-    """Frame-sized steps (1/60 s) of a collapsing column: the substep is 0.4 * 2r / max_i |v_i + a_i t| — a maximum, i.e. the fastest
-    splash particle decides, and at up to 0.4 particle diameters per substep two f32 trajectories part by rounding within a dozen
-    steps.  The yardstick is therefore the oracle's own f32-vs-f64 distance: the device must follow the f32 build
-    within max(rounding growth, 3 x that distance), and where the oracle's two precisions take a different NUMBER of substeps the
-    device must take one of the two."""
-    s = _dam_break(solver)
+def test_cfl_substeps_match_the_oracle(solver, mode):
+    """Frame-sized steps (1/60 s) of a falling, stirred block: from about step 8 on every step is cut into 2 ... 10 substeps of
+    0.4 * 2r / max_i |v_i + a_i t|.  The flow is smooth, so the device follows the oracle's f32 build substep by substep: the same
+    NUMBER of substeps in every step, lengths within max(1e-4 (k + 1), 3 x the oracle's own f32-vs-f64 distance), contacts and
+    iteration counts under the same yardstick, final positions to 1e-4 r per substep."""
+    s = _falling_block(solver)
     w, (fl,), _ = s.make_hip()
-    o = s.make_oracle(threads=4)
-    o64 = s.make_oracle(threads=4, f64=True)
+    o = s.make_oracle()          # (one thread: the oracle's summation order, hence its trajectory, is the same in every run)
+    o64 = s.make_oracle(f64=True)
+    for x in (o, o64):
+        x.set_cfl(mode)
     w.set_cfl_substepping(mode)
-    o.set_cfl(mode)
-    o64.set_cfl(mode)
     w.counters.enable()
-    nsub_total, multi, split = 0, 0, 0
+    nsub_total, multi = 0, 0
     n = 36
     for k in range(n):
         st = w.step(DT, GRAVITY)
         so = o.step(DT, GRAVITY)
         s64 = o64.step(DT, GRAVITY)
         sw, sr, sd = np.asarray(w.substeps()), np.asarray(o.substeps()), np.asarray(o64.substeps())
-        assert w.counters.nsubsteps == len(sw)
-        if len(sr) == len(sd):
-            assert len(sw) == len(sr), (k, sw, sr, sd)
-            tol = np.maximum(4e-4 * (k + 1) * sr, 3 * np.abs(sr - sd))
-            assert (np.abs(sw - sr) <= tol).all(), (k, sw, sr, sd)
-        else:  # the restatement disagrees with itself about this step
-            split += 1
-            assert len(sw) in (len(sr), len(sd)), (k, sw, sr, sd)
-        # (mode 2 cuts the last substep at the end of the step: only that one may fall below dt / max_num_substeps)
-        assert all(DT / 10 * (1 - 1e-6) <= x <= DT * (1 + 1e-6) for x in (sw if mode == 1 else sw[:-1])) and 0 < sw[-1] <= DT * (1 + 1e-6)
-        assert sum(sw) >= DT * (1 - 1e-6) and (mode == 1 or abs(sum(sw) - DT) < 1e-6)
-        slack = 0 if k == 0 else max(4, int(1e-4 * so.ncontacts) * (k + 1), 3 * abs(int(so.ncontacts) - int(s64.ncontacts)))
+        _structure(w, sw, mode)
+        assert len(sw) == len(sr) == len(sd), (k, sw, sr, sd)
+        tol = np.maximum(1e-4 * (k + 1) * sr, 3 * np.abs(sr - sd))
+        if mode == 2:  # (the cut last substep is a difference of nearly equal numbers: absolute, not relative, agreement)
+            tol[-1] = max(tol[-1], np.sum(tol[:-1]))
+        assert (np.abs(sw - sr) <= tol).all(), (k, sw, sr, sd)
+        slack = 0 if k == 0 else max(4, int(2e-5 * so.ncontacts) * (k + 1), 3 * abs(int(so.ncontacts) - int(s64.ncontacts)))
         assert abs(int(st.ncontacts) - int(so.ncontacts)) <= slack, (k, st.ncontacts, so.ncontacts, s64.ncontacts)
         assert abs(st.n_pressure_iters - so.n_press_iters) <= max(1, abs(so.n_press_iters - s64.n_press_iters)), k
-        assert abs(st.n_divergence_iters - so.n_div_iters) <= max(2, abs(so.n_div_iters - s64.n_div_iters)), k
-        c = w.counters
-        assert c.step_time > 0 and c.stages.solver_time > 0  # the timers add up over the substeps
+        assert abs(st.n_divergence_iters - so.n_div_iters) <= max(1, abs(so.n_div_iters - s64.n_div_iters)), k
         nsub_total += len(sw)
         multi += len(sw) > 1
-    assert multi >= 5, "the scene never sub-stepped: the test would prove nothing"
-    assert split <= n // 5, split
+    assert multi >= 20 and max(len(w.substeps()), 2) >= 2, "the scene never sub-stepped: the test would prove nothing"
+    assert len(w.substeps()) >= 5  # by the end a frame is cut into many substeps
     d = max_norm_diff(fl.positions, o.fluid_vec(0, "positions")) / R
     d64 = max_norm_diff(o.fluid_vec(0, "positions"), o64.fluid_vec(0, "positions")) / R
-    assert d < max(1e-3 * nsub_total, 3 * d64), (d, d64)
-    # (no claim about the physics: at dt = 1/60 IISPH lets particles through this single-layer floor in the oracle just the same)
+    assert d < max(1e-4 * nsub_total, 3 * d64), (d, d64)
+
+
+@pytest.mark.parametrize("solver,mode", [("dfsph", 1), ("dfsph", 2), ("iisph", 1)])
+def test_cfl_substepping_through_a_dam_break(solver, mode):
+    """The same through an impact (a column collapsing in a tank, 30 frame-sized steps).  Here the substep is decided by the fastest
+    splash particle and two f32 trajectories part by rounding within a dozen steps — in mode 2 the cut last substep of one step
+    even sets the next step's XSPH scale (1 / dt of the previous substep) — so only what does not depend on shadowing a chaotic
+    trajectory is asserted: the structure of every step, and that the device sub-steps as much as the oracle does."""
+    s = _dam_break(solver)
+    w, (fl,), _ = s.make_hip()
+    o = s.make_oracle()
+    w.set_cfl_substepping(mode)
+    o.set_cfl(mode)
+    w.counters.enable()
+    nd, no = [], []
+    for k in range(30):
+        w.step(DT, GRAVITY)
+        o.step(DT, GRAVITY)
+        sw = np.asarray(w.substeps())
+        _structure(w, sw, mode)
+        nd.append(len(sw)); no.append(len(o.substeps()))
+        if k < 10:  # (before the impact the two still agree step by step)
+            assert nd[-1] == no[-1] and np.allclose(sw, o.substeps(), rtol=1e-3), (k, sw, o.substeps())
+    assert sum(x > 1 for x in nd) >= 5, nd
+    assert abs(sum(nd) - sum(no)) <= max(3, sum(no) // 10), (nd, no)
+    assert np.isfinite(fl.positions).all()
 
 
 def test_cfl_is_off_by_default_and_can_be_switched_off_again():
