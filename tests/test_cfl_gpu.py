@@ -101,7 +101,8 @@ def test_cfl_substepping_through_a_dam_break(solver, mode):
         _structure(w, sw, mode)
         nd.append(len(sw)); no.append(len(o.substeps()))
         if k < 10:  # (before the impact the two still agree step by step)
-            assert nd[-1] == no[-1] and np.allclose(sw, o.substeps(), rtol=1e-3), (k, sw, o.substeps())
+            # (atol: mode 2's cut last substep is a difference of nearly equal numbers)
+            assert nd[-1] == no[-1] and np.allclose(sw, o.substeps(), rtol=1e-3, atol=1e-3 * DT), (k, sw, o.substeps())
     assert sum(x > 1 for x in nd) >= 5, nd
     assert abs(sum(nd) - sum(no)) <= max(3, sum(no) // 10), (nd, no)
     assert np.isfinite(fl.positions).all()
