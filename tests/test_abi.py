@@ -100,3 +100,25 @@ def test_cpp_mirror_header_compiles():
         subprocess.check_call(["g++", "-std=c++17", "-Wall", "-fsyntax-only", path])
     finally:
         os.unlink(path)
+
+
+def test_c_header_is_plain_c():
+    """include/salva_hip.h is the boundary a Rust `bindgen` / cgo / ctypes user parses as C, not C++: it compiles as strict C99
+    with the host compiler (no HIP, no C++ constructs), and every declared entry point is callable from a C translation unit."""
+    import re
+    import subprocess
+    import tempfile
+
+    hdr = os.path.join(ROOT, "include", "salva_hip.h")
+    names = sorted(set(re.findall(r"\b(salva_hip_[a-z0-9_]+)\s*\(", open(hdr).read())))
+    assert len(names) >= 60
+    # taking every function's address forces the declaration to be complete and consistent C
+    body = "".join(f"    sink((void (*)(void)){n});\n" for n in names)
+    src = ('#include "%s"\nstatic void sink(void (*f)(void)) { (void)f; }\nint main(void) {\n%s    return 0;\n}\n' % (hdr, body))
+    with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as f:
+        f.write(src)
+        path = f.name
+    try:
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Wstrict-prototypes", "-pedantic", "-Werror", "-fsyntax-only", path])
+    finally:
+        os.unlink(path)
