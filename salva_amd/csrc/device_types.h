@@ -27,9 +27,21 @@ namespace salva {
 // minimum corner of the occupied cells' bounding box.  cell_start has ncells+1 entries with lower-bound semantics:
 // cell_start[k] = first sorted index whose key >= k, so cell k is [cell_start[k], cell_start[k+1]) and a whole tile
 // is [cell_start[64 t], cell_start[64 t + 64)).
+//
+// Folding (world.hip dims_from_bbox): the reference's grid is a hash map and costs nothing per EMPTY cell; this table costs four bytes
+// for every cell of the bounding box, and a few particles that have left the scene (an open tank leaks, a faucet is never stopped)
+// blow the box up without bound.  When the box holds far more cells than particles, the axes are therefore FOLDED: the cell
+// coordinate relative to the origin is taken modulo a power-of-two period P (mx / my / mz = P - 1; 0xffffffff = the axis is not
+// folded), so the table is a torus of P cells in that axis and cells P apart share an entry.  Cells next to each other stay next to
+// each other (the halo of a tile wraps around), so every true neighbour is still a candidate; the particles of the other images
+// that share a cell are candidates too and fail the exact d^2 <= h^2 test on their true positions like any other non-neighbour —
+// the contact SETS are the unfolded grid's.  (The order inside a cell is the order of the previous step's sort, which follows the
+// numbering of the tiles: a folded and an unfolded run of the same scene agree bit for bit in their first step and to summation
+// order afterwards — like two runs whose boxes have different origins.)
 struct TileGrid {
     int ox, oy, oz;
     int ntx, nty, ntz;
+    uint32_t mx, my, mz;
     const uint32_t* cell_start;
 };
 

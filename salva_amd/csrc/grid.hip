@@ -651,8 +651,11 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
             const uint32_t loc = c.stale_keys[i] % TCELLS;
             lx = 1 + (int)(loc / (TY * TZ)); ly = 1 + (int)((loc / TZ) % TY); lz = 1 + (int)(loc % TZ);
         } else {
-            lx = cell_coord(pi.x, c.sc.h, bad) - t.hcx; ly = cell_coord(pi.y, c.sc.h, bad) - t.hcy;
-            lz = cell_coord(pi.z, c.sc.h, bad) - t.hcz;
+            // (relative to the grid's origin first, modulo the axis' period where the grid is folded: device_types.h TileGrid)
+            const TileGrid& g = c.gf;
+            lx = (int)(((uint32_t)cell_coord(pi.x, c.sc.h, bad) - (uint32_t)g.ox) & g.mx) - (t.hcx - g.ox);
+            ly = (int)(((uint32_t)cell_coord(pi.y, c.sc.h, bad) - (uint32_t)g.oy) & g.my) - (t.hcy - g.oy);
+            lz = (int)(((uint32_t)cell_coord(pi.z, c.sc.h, bad) - (uint32_t)g.oz) & g.mz) - (t.hcz - g.oz);
         }
         uint32_t* __restrict__ outb = c.nbr_fb + (size_t)gs * c.cap_fb * WAVE + 4u * lane;
         uint32_t pend = 0, pendb = 0;

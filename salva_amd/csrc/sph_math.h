@@ -227,7 +227,12 @@ __device__ __forceinline__ f2 kernel_gfac2(f2 r2, const SphConsts& c) {
 // Weight and gradient factor of two contacts at once from the same intermediates as kernel_gfac2.  With a1 = h - r >= 0 and
 // a2 = (h - 2r)+ the cubic spline is W = (wnorm / h^3) (2 a1^3 - a2^3)  [q <= 1/2: 1 - 6q^2 + 6q^3; q <= 1: 2 (1 - q)^3] and
 // (dW/dr)/r = gscale (a2^2 - a1^2) / r.  Returns {2 a1^3 - a2^3, (a2^2 - a1^2) / r}: the callers apply wnorm / h^3 and gscale to
-// the finished sums.  r2 = 0 (self contact, padding; the caller adds 1e-30): weight h^3 exactly, gradient factor 0.
+// the finished sums.  r2 = 0 (self contact, padding; the caller adds 1e-30): weight h^3 exactly; the gradient factor is SET to 0 at
+// r2 <= tiny_r2, as the reference does (cubic_spline_kernel.rs:63-65) — a2^2 - a1^2 is a2 a2 - fl(a1 a1) once the compiler contracts
+// it, a rounding residue of ~4e-10 that 1 / r = 1e15 turns into a factor of 4e5: harmless in every sum that multiplies it by a zero
+// distance, but sum |m grad W|^2 takes it squared times 1e-30, and fifteen padded trips of an ISOLATED particle that shares its
+// slice with a dense clump then add up to 1.2e-5 — above the 1e-5 below which alpha is 0 (dfsph_solver.rs:208; found by the
+// folded-grid test, which puts stray particles into the block's slices).
 struct KernelWG2 { f2 w, g; };
 __device__ __forceinline__ KernelWG2 kernel_wg2(f2 r2, const SphConsts& c) {
     SALVA_PAIR_MATH
@@ -241,6 +246,8 @@ __device__ __forceinline__ KernelWG2 kernel_wg2(f2 r2, const SphConsts& c) {
     const f2 a1s = a1 * a1, a2s = a2 * a2;
     KernelWG2 o;
     o.g = (a2s - a1s) * rinv;
+    o.g.x = (r2.x <= c.tiny_r2) ? 0.0f : o.g.x;
+    o.g.y = (r2.y <= c.tiny_r2) ? 0.0f : o.g.y;
     o.w = (a1s * a1) * 2.0f - a2s * a2;
     return o;
 }

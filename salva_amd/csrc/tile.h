@@ -118,13 +118,18 @@ inline void ensure_tile_lds(K kernel, uint32_t bytes) {
         }                                                                  \
     } while (0)
 
-// key of cell (cx,cy,cz) (absolute cell coords) in grid g, or inside = false
+// key of cell (cx,cy,cz) (absolute cell coords) in grid g, or inside = false.  (mx, my, mz): the folding masks of the grid the
+// COORDINATES belong to (device_types.h TileGrid) — g's own, except where a tile of the folded fluid grid looks up the cells of the
+// boundary grid, which is never folded itself but is then addressed modulo the fluid grid's periods (they are at least as long as
+// the boundary grid is wide: at most one of its cells answers).
+__device__ __forceinline__ uint32_t tile_key_m(const TileGrid& g, int cx, int cy, int cz, bool& inside, uint32_t mx, uint32_t my, uint32_t mz) {
+    const uint32_t ix = ((uint32_t)cx - (uint32_t)g.ox) & mx, iy = ((uint32_t)cy - (uint32_t)g.oy) & my, iz = ((uint32_t)cz - (uint32_t)g.oz) & mz;
+    inside = ix < (uint32_t)(g.ntx * TX) && iy < (uint32_t)(g.nty * TY) && iz < (uint32_t)(g.ntz * TZ);
+    const uint32_t tile = ((ix / TX) * (uint32_t)g.nty + (iy / TY)) * (uint32_t)g.ntz + (iz / TZ);
+    return tile * TCELLS + (((ix % TX) * TY + (iy % TY)) * TZ + (iz % TZ));
+}
 __device__ __forceinline__ uint32_t tile_key(const TileGrid& g, int cx, int cy, int cz, bool& inside) {
-    const int ix = cx - g.ox, iy = cy - g.oy, iz = cz - g.oz;
-    inside = (unsigned)ix < (unsigned)(g.ntx * TX) && (unsigned)iy < (unsigned)(g.nty * TY) &&
-             (unsigned)iz < (unsigned)(g.ntz * TZ);
-    const uint32_t tile = ((uint32_t)(ix / TX) * g.nty + (uint32_t)(iy / TY)) * g.ntz + (uint32_t)(iz / TZ);
-    return tile * TCELLS + (uint32_t)(((ix % TX) * TY + (iy % TY)) * TZ + (iz % TZ));
+    return tile_key_m(g, cx, cy, cz, inside, g.mx, g.my, g.mz);
 }
 
 // floor(x / h) exactly as hgrid.rs:41-43 (IEEE f32 division, then floor), clamped to +-2^30; NaN -> bad.
@@ -582,7 +587,7 @@ struct TileCells {
             gstart[h] = b; lstart[h] = e - b;
             b = e = 0;
             if (c.nb) {
-                const uint32_t kb = tile_key(c.gb, t.hcx + hx, t.hcy + hy, t.hcz + hz, in);
+                const uint32_t kb = tile_key_m(c.gb, t.hcx + hx, t.hcy + hy, t.hcz + hz, in, c.gf.mx, c.gf.my, c.gf.mz);
                 if (in) { b = c.gb.cell_start[kb]; e = c.gb.cell_start[kb + 1]; }
             }
             bgstart[h] = b; blstart[h] = e - b;

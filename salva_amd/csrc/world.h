@@ -46,6 +46,9 @@ struct BoundarySlot {
 struct GridDims {          // tile-aligned dense grid (tile.h)
     int o[3] = {0, 0, 0};  // cell coords of the first cell, multiples of the tile shape
     int nt[3] = {1, 1, 1}; // tiles per axis
+    uint32_t mask[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};  // folded axes: period in cells - 1 (device_types.h TileGrid)
+    bool folded() const { return (mask[0] & mask[1] & mask[2]) != 0xffffffffu; }
+    TileGrid device(const uint32_t* cell_start) const { return TileGrid{o[0], o[1], o[2], nt[0], nt[1], nt[2], mask[0], mask[1], mask[2], cell_start}; }
     size_t ntiles() const { return (size_t)nt[0] * nt[1] * nt[2]; }
     size_t ncells() const { return ntiles() * TCELLS; }
 };
@@ -234,6 +237,8 @@ class World {
     // launch per pass, the heavier class as a tail segment of the lists in the tiles that hold both.
     DevBuf<uint32_t> tile_mass_bits, tile_massb_bits, nffb;
     bool two_mass_off = false;    // SALVA_HIP_NO_TWO_MASS=1 (A/B, tests): such a world keeps the general kernels
+    bool fold_off = false;        // SALVA_HIP_NO_FOLD=1: the fluid grid is never folded (device_types.h TileGrid)
+    uint32_t fold_forced = 0;     // SALVA_HIP_FOLD_CELLS=P: every axis longer than P cells is folded to exactly P (tests)
     bool two_mass = false;        // this step runs that way
     uint32_t two_mass_bmask = 0;  // fluids with the heavier mass
     bool decide_two_mass();

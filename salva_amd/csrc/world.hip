@@ -135,6 +135,11 @@ World::World(const SalvaHipParams& p) : prm(p) {
     spec_apply_off = getenv("SALVA_HIP_NO_SPEC_APPLY") != nullptr;
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
     two_mass_off = getenv("SALVA_HIP_NO_TWO_MASS") != nullptr;
+    fold_off = getenv("SALVA_HIP_NO_FOLD") != nullptr;
+    if (const char* e = getenv("SALVA_HIP_FOLD_CELLS")) {
+        const long v = atol(e);
+        if (v >= 8 && v <= (1 << 20) && (v & (v - 1)) == 0) fold_forced = (uint32_t)v;
+    }
     tile_trace = getenv("SALVA_HIP_TILE_TRACE") != nullptr;
     no_fused_div = getenv("SALVA_HIP_NO_FUSED_DIV") != nullptr;
     if (const char* e = getenv("SALVA_HIP_RADIX_SORT")) sort_mode = atoi(e) != 0 ? 1 : 0;
@@ -672,13 +677,13 @@ StepCtx World::make_ctx() {
     c.tile_ids = tile_ids.p; c.tile_rank = tile_rank.p; c.nlaunch = nlaunch; c.slot_desc = slot_desc.p; c.slot_info = slot_info.p;
     c.spec = spec_mode ? 1u : 0u; c.halo_cap = halo_cap; c.bhalo_cap = bhalo_cap; c.nslices_cap = nslices_cap;
     c.halo_len = halo_len; c.bhalo_len = bhalo_len;
-    c.gf = TileGrid{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], cell_start_f.p};
+    c.gf = gf.device(cell_start_f.p);
     c.stale_keys = has_dynamic_sampling() ? keys[1].p : nullptr;
     c.nb = nb;
     c.bposv = bposv.p; c.bvel = bvel.p; c.bperm = bperm.p;
     c.bforce = any_wants_forces ? bforce.p : nullptr;
     c.bwants = bwants.p;
-    c.gb = TileGrid{gb.o[0], gb.o[1], gb.o[2], gb.nt[0], gb.nt[1], gb.nt[2], cell_start_b.p};
+    c.gb = gb.device(cell_start_b.p);
     c.nmodels = (uint32_t)std::max<size_t>(fluids.size(), 1);
     c.nbmodels = (uint32_t)std::max<size_t>(bounds.size(), 1);
     c.mass_uniform = mass_uniform;
@@ -704,21 +709,45 @@ StepCtx World::make_ctx() {
 // the same number of tiles wherever it sits (an absolute tile lattice would add a partially filled layer of tiles per
 // axis whenever the block is not aligned with it).  Fluid and boundary grids have independent origins: a fluid
 // tile looks boundary cells up by absolute cell coordinates.
-static void dims_from_bbox(const int32_t* bb, GridDims& g) {
+// `fold` (fluid grid only): when the box holds more than fold->budget cells, fold its longest axes to power-of-two periods — never
+// below fold->min_period[a] — until it does (device_types.h TileGrid: the table becomes a torus, the lists stay what they were).
+struct FoldRule { double budget; uint32_t min_period[3]; };
+static void dims_from_bbox(const int32_t* bb, GridDims& g, const FoldRule* fold = nullptr) {
     static const int T[3] = {TX, TY, TZ};
-    double nc = TCELLS;
+    int64_t cells[3];
     for (int a = 0; a < 3; ++a) {
         if (bb[a] > bb[3 + a]) throw HipError(SALVA_HIP_E_CAPACITY, "empty cell bounding box");
         const int64_t extent = (int64_t)bb[3 + a] - (int64_t)bb[a] + 1;
         if (extent > (1 << 30)) throw HipError(SALVA_HIP_E_CAPACITY, "cell bounding box too large");
         g.o[a] = bb[a];
         g.nt[a] = (int)((extent + T[a] - 1) / T[a]);
-        nc *= (double)g.nt[a];
+        g.mask[a] = 0xffffffffu;
+        cells[a] = (int64_t)g.nt[a] * T[a];
     }
+    if (fold) {
+        for (;;) {
+            if ((double)cells[0] * (double)cells[1] * (double)cells[2] <= fold->budget) break;
+            // the longest axis that can still be folded: to the largest power of two below its present length
+            int best = -1;
+            int64_t best_p = 0;
+            for (int a = 0; a < 3; ++a) {
+                int64_t p = 1;
+                while (p * 2 < cells[a]) p *= 2;
+                if (p < (int64_t)fold->min_period[a] || p >= cells[a]) continue;
+                if (best < 0 || cells[a] > cells[best]) { best = a; best_p = p; }
+            }
+            if (best < 0) break;  // (nothing left to fold: the budget check below decides)
+            cells[best] = best_p;
+            g.nt[best] = (int)(best_p / T[best]);
+            g.mask[best] = (uint32_t)best_p - 1u;
+        }
+    }
+    const double nc = (double)cells[0] * (double)cells[1] * (double)cells[2];
     if (nc >= 4.0e9) throw HipError(SALVA_HIP_E_CAPACITY, "dense cell table would exceed 2^32 cells; particles are too spread out");
-    // The reference's hash grid costs memory per OCCUPIED cell; this table costs 4 bytes per cell of the bounding box (plus
-    // 8 bytes per tile of 64 cells).  A few stray particles far from the rest therefore cost memory here that they do not
-    // cost there: refuse beyond a budget, with a message that says what to do, rather than exhaust HBM.
+    // The reference's hash grid costs memory per OCCUPIED cell; this table costs 4 bytes per cell of the (folded) bounding box, plus
+    // 8 bytes per tile of 64 cells.  Where folding is not possible (decomposed runs, dynamic contact sampling, a boundary set as wide
+    // as the box) a few stray particles far from the rest cost memory here that they do not cost there: refuse beyond a budget, with
+    // a message that says what to do, rather than exhaust HBM.
     static const double budget_gib = [] {
         const char* e = getenv("SALVA_HIP_CELL_TABLE_GIB");
         const double v = e ? atof(e) : 8.0;
@@ -751,7 +780,7 @@ void World::build_boundary_grid() {
     const size_t nc = gb.ncells();
     bkeys[0].ensure(nb); bkeys[1].ensure(nb); bidx[0].ensure(nb); bidx[1].ensure(nb);
     bposv.ensure(nb); bvel.ensure(nb); bperm.ensure(nb); cell_start_b.ensure(nc + 1);
-    TileGrid gv{gb.o[0], gb.o[1], gb.o[2], gb.nt[0], gb.nt[1], gb.nt[2], nullptr};
+    TileGrid gv = gb.device(nullptr);
     launch_cell_keys(bst_pos.p, nb, sc.h, gv, bkeys[0].p, bidx[0].p, d_flags.p, nullptr, nullptr, nullptr, stream);
     const int end_bit = bits_for(nc);
     const size_t tb = sort_pairs_temp_bytes(nb, end_bit);
@@ -1285,7 +1314,27 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         wait_stream();
         bbox_known = true;
     }
-    dims_from_bbox(h_rb->bbox, gf);
+    // Fold the fluid grid when its box is mostly empty (device_types.h TileGrid): more than 4 cells per particle + 2^20 — a block at
+    // rest fills a cell with eight particles, the box of an L-shaped or splashing scene a few times the cells it occupies; leaked or
+    // sprayed particles falling away from the scene are what this is for (tools/r05/soak.sh: the bench scene's box grows from 1.2 x 10^5
+    // to 2.3 x 10^8 cells in a thousand steps).  The periods stay at least 64 cells and at least as long as the boundary grid is wide
+    // (a folded fluid tile addresses the boundary cells modulo its own periods: tile.h TileCells::build), so the boundary grid has
+    // to exist first.  Not in decomposed runs (ghost planes are found by absolute cell coordinate) and not with dynamic contact
+    // sampling (dcs.hip decodes cell coordinates from the keys).  SALVA_HIP_NO_FOLD=1: never; SALVA_HIP_FOLD_CELLS=P: every axis
+    // longer than P cells to exactly P (a power of two >= 8; the tests' way to fold small scenes).
+    {
+        const uint32_t forced = fold_forced;
+        const bool can_fold = !fold_off && !comm && !has_dynamic_sampling();
+        if (can_fold && nb && b_dirty) build_boundary_grid();
+        FoldRule rule{forced ? 0.0 : 4.0 * (double)n + 1048576.0, {forced ? forced : 64u, forced ? forced : 64u, forced ? forced : 64u}};
+        if (nb)
+            for (int a = 0; a < 3; ++a) {
+                static const int T[3] = {TX, TY, TZ};
+                const uint64_t bcells = (uint64_t)gb.nt[a] * T[a];
+                while (rule.min_period[a] < bcells) rule.min_period[a] *= 2u;
+            }
+        dims_from_bbox(h_rb->bbox, gf, can_fold ? &rule : nullptr);
+    }
     const size_t ncf = gf.ncells();
     const uint32_t ntiles = (uint32_t)gf.ntiles();
     // only the cell table and one flag per tile are dense over the bounding box; every other per-tile table is compact
@@ -1357,7 +1406,7 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     if (attempt > 0) SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));  // (whatever the discarded pass flagged)
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
     {
-        TileGrid gv{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], nullptr};
+        TileGrid gv = gf.device(nullptr);
         // (a scene known to hold different masses — two fluids of different density0 — is not asked again until the host edits the
         // particles: every wave of the lighter fluid would raise a flag, 71 us per launch at 2 x 10^6 particles)
         check_mass = !(mass_known && mass_uniform == 0.0f);
@@ -1453,11 +1502,22 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         if (tile_trace)
             fprintf(stderr, "salva_hip tiles: nonempty %u max_s %u max_sb %u max_sum %u max_raw %u mass_uniform %g\n", tt.nonempty, tt.max_s,
                     tt.max_sb, tt.max_sum, tt.max_raw, (double)mass_uniform);
-        // one wave per 64-particle slice of the average non-empty tile (fuller tiles loop over their extra slices),
-        // never fewer waves than the halo-table build needs threads
+        // one wave per 64-particle slice of the average non-empty tile (fuller tiles loop over their extra slices), never fewer
+        // waves than the halo-table build needs threads — and never more than EIGHT: the neighbour-sum kernels hold 80 VGPRs so that
+        // three tiles of eight waves share a CU (24 of its waves), k_nbr_tile 64 for four; a ninth wave per tile costs each of them
+        // a whole resident tile.  Where the fluid is compressed past 512 particles per tile — every bench scene, from the impact
+        // on — round 4's limit of twelve waves did exactly that: 6.2 against 4.9 ms per step in steps 100..150 of config 2, 3.2
+        // against 2.5 in steps 150..200 (profiles/r05_experiments/r05l_waves_ab.log; seven waves lose to eight there, and six / seven
+        // to eight on the block at rest: 1.31 / 1.32 against 1.20 ms).
+        // (Sizing the workgroups for the tile the average PARTICLE lives in — sum of slices^2 / sum of slices, so that a few thousand
+        // stray particles with a tile each do not halve the waves of the full tiles — was measured too and lost: r05k_fold_ab.log.)
         {
+#ifndef SALVA_TILE_WAVES_CAP
+#define SALVA_TILE_WAVES_CAP 8
+#endif
+            static_assert(SALVA_TILE_WAVES_CAP <= TILE_MAX_WAVES, "the launch bounds are written for TILE_MAX_WAVES");
             const uint32_t avg = (n + tt.nonempty - 1) / std::max<uint32_t>(tt.nonempty, 1u);
-            const uint32_t lo = (HCELLS + WAVE - 1) / WAVE, hi = std::min<uint32_t>(std::max<uint32_t>(tt.max_nsl, lo), (uint32_t)TILE_MAX_WAVES);
+            const uint32_t lo = (HCELLS + WAVE - 1) / WAVE, hi = std::min<uint32_t>(std::max<uint32_t>(tt.max_nsl, lo), (uint32_t)(SALVA_TILE_WAVES_CAP));
             lds.threads = WAVE * std::min<uint32_t>(std::max<uint32_t>((avg + WAVE - 1) / WAVE, lo), hi);
         }
 #ifdef SALVA_HIP_DIAG
@@ -2382,7 +2442,7 @@ void World::resize_boundary_slot(uint32_t slot, uint64_t nn) {
 // insertion, liquid_world.rs:90-91), the boundaries are not in the grid yet (:106).  Works on the sorted working set of the
 // previous step (posm[cur] / vel[cur], keys[0] = this step's keys in that order).
 void World::run_dynamic_sampling() {
-    TileGrid gv{gf.o[0], gf.o[1], gf.o[2], gf.nt[0], gf.nt[1], gf.nt[2], nullptr};
+    TileGrid gv = gf.device(nullptr);
     for (uint32_t slot = 0; slot < bounds.size(); ++slot) {
         BoundarySlot& b = bounds[slot];
         if (!b.dyn_kind) continue;

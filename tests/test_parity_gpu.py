@@ -652,23 +652,123 @@ def test_stray_particles_far_from_the_bulk():
     assert st.step_ms < 20.0, f"a step over a mostly empty 30M-cell box took {st.step_ms:.1f} ms"
 
 
-def test_strays_beyond_the_cell_table_budget_are_refused_with_advice():
-    """The dense cell table costs 4 bytes per cell of the bounding box (the reference's hash grid: per occupied cell).  Past
-    the budget (8 GiB, SALVA_HIP_CELL_TABLE_GIB) the step fails with E_CAPACITY and says what to do; the world stays usable
-    once the stray is gone."""
+def test_strays_beyond_the_cell_table_budget_fold_the_grid_or_are_refused_with_advice(monkeypatch):
+    """The dense cell table costs 4 bytes per cell of the bounding box (the reference's hash grid: per occupied cell).  Round 5: a box
+    that is mostly empty is FOLDED (device_types.h TileGrid) — a stray 1500 cells away costs a table of a few 10^5 cells and the step
+    agrees with the oracle.  Where folding is off (SALVA_HIP_NO_FOLD=1; decomposed runs, dynamic contact sampling) the step fails
+    past the budget (8 GiB, SALVA_HIP_CELL_TABLE_GIB) with E_CAPACITY and says what to do; the world stays usable once the stray is
+    gone."""
     from salva_amd import _lib
 
     s = Scene(R, 2.0, "dfsph")
     block = scenes.jitter(scenes.cube_fluid_positions(6, 6, 6, R), 0.1 * R, seed=42)
     pos = np.concatenate([block, np.float32([[150.0, 140.0, 160.0]])]).astype(np.float32)  # 1500 x 1400 x 1600 cells = 12.5 GiB
     s.add_fluid(pos, None, 1000.0)
+    monkeypatch.delenv("SALVA_HIP_NO_FOLD", raising=False)
+    compare(run_hip(s, 3), run_oracle(s, 3), s, 3, "a stray 1500 cells away (folded grid)")
+    monkeypatch.setenv("SALVA_HIP_NO_FOLD", "1")
     w, (fl,), _ = s.make_hip()
+    monkeypatch.delenv("SALVA_HIP_NO_FOLD", raising=False)
     with pytest.raises(_lib.SalvaHipError) as e:
         w.step(DT, GRAVITY)
     assert e.value.code == _lib.E_CAPACITY and "SALVA_HIP_CELL_TABLE_GIB" in str(e.value) and "delete strays" in str(e.value)
     fl.delete_particle_at_next_timestep(len(pos) - 1)
     st = w.step(DT, GRAVITY)
     assert st.nparticles == len(block)
+
+
+def _scene_with_leaked_particles(solver="dfsph", two=False):
+    """A tank with its block of fluid, and particles that have left it: singles, a pair in contact, and a small cluster — some of them
+    exactly a multiple of a small power of two of cells away from the block, so that a folded grid puts them into the block's own
+    cells."""
+    s = Scene(R, 2.0, solver)
+    fluid, shell = scenes.tank(10, 8, 10, R)
+    fluid = scenes.jitter(fluid, 0.1 * R, seed=11)
+    h = 4.0 * R
+    rng = np.random.default_rng(3)
+    cluster = scenes.jitter(scenes.cube_fluid_positions(3, 3, 3, R), 0.1 * R, seed=12) + np.float32([37.0 * h, -64.0 * h, 5.0 * h])
+    images = fluid[rng.choice(len(fluid), 6, replace=False)] + np.float32([32.0 * h, 0.0, 0.0]) * np.arange(1, 7, dtype=np.float32)[:, None]
+    far = np.float32([[90.0 * h, -200.0 * h, -75.0 * h], [90.0 * h + R, -200.0 * h, -75.0 * h], [-128.0 * h, 16.0 * h, 64.0 * h]])
+    pos = np.concatenate([fluid, cluster, images, far]).astype(np.float32)
+    vel = scenes.random_velocities(len(pos), 0.2, seed=13)
+    forces = [("xsph", 0.5, 0.0)] if solver == "dfsph" else [("akinci", 1.0, 10.0)]
+    if two:
+        half = len(pos) // 2
+        s.add_fluid(pos[:half], vel[:half], 1000.0, forces=forces)
+        s.add_fluid(pos[half:], vel[half:], 500.0, forces=forces)
+    else:
+        s.add_fluid(pos, vel, 1000.0, forces=forces)
+    s.add_boundary(shell)
+    return s
+
+
+@pytest.mark.parametrize("variant", ["dfsph", "iisph", "two_mass"])
+def test_a_folded_grid_changes_nothing_but_the_table(monkeypatch, variant):
+    """device_types.h TileGrid: with the cell coordinates taken modulo a power-of-two period the table is a torus; particles of other
+    images become candidates and fail the exact distance test, so the contact SETS — hence every sum, up to the order of its terms —
+    are the unfolded grid's.  Three worlds of one scene (a tank, leaked particles up to 200 cells away, some of them folded right into
+    the block's cells): never folded, folded by the rule (the box holds far more cells than particles), folded as hard as the
+    boundary grid allows (SALVA_HIP_FOLD_CELLS=8 -> the periods the tank's own width dictates).  The first step — whose sort starts
+    from the host's order in all three — is the same bit for bit; afterwards the order inside a cell is the previous step's order,
+    which follows the numbering of the tiles, so later steps agree in every count and to summation order in the state.  All agree
+    with the oracle."""
+    s = _scene_with_leaked_particles("iisph" if variant == "iisph" else "dfsph", two=variant == "two_mass")
+    nsteps = 5
+    runs = {}
+    for name, env in (("never", {"SALVA_HIP_NO_FOLD": "1"}), ("rule", {}), ("hard", {"SALVA_HIP_FOLD_CELLS": "8"})):
+        for k in ("SALVA_HIP_NO_FOLD", "SALVA_HIP_FOLD_CELLS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        runs[name] = run_hip(s, nsteps)
+    for k in ("SALVA_HIP_NO_FOLD", "SALVA_HIP_FOLD_CELLS"):
+        monkeypatch.delenv(k, raising=False)
+    ref = runs["never"]
+    for name in ("rule", "hard"):
+        got = runs[name]
+        assert np.array_equal(got["iters"], ref["iters"]), (name, got["iters"], ref["iters"])
+        for f in range(len(s.fluids)):
+            for key in (f"s1_nff_{f}", f"s1_nfb_{f}", f"s1_density_{f}", f"s1_alpha_{f}", f"s1_pos_{f}", f"s1_vel_{f}"):
+                assert np.array_equal(got[key], ref[key]), (name, key)
+            dp, dv = np.abs(got[f"pos_{f}"] - ref[f"pos_{f}"]).max(), np.abs(got[f"vel_{f}"] - ref[f"vel_{f}"]).max()
+            assert dp < 2e-5 * R * nsteps and dv < 1e-4, (name, f, dp / R, dv)
+    compare(runs["hard"], run_oracle(s, nsteps), s, nsteps, f"leaked particles, folded grid ({variant}) vs oracle")
+
+
+def test_an_isolated_particle_in_a_dense_slice_has_alpha_zero():
+    """dfsph_solver.rs:208: alpha = 0 where sum |m grad W|^2 + |sum m grad W|^2 <= 1e-5 — a particle whose only contact is itself.
+    Here such a particle shares its tile, hence its 64-particle slice and the slice's padded trip count, with a dense block one empty
+    cell away: every padded trip evaluates the kernel at distance zero, and the gradient factor there has to be exactly 0 (sph_math.h
+    kernel_wg2: a contracted a2 a2 - a1 a1 left 4e-10 x 1e15 in it, sixteen trips of which crossed the 1e-5).  Default path and the
+    general kernels, DFSPH alpha and the IISPH diagonal a_ii of the same pass."""
+    import os
+
+    h = 4 * R
+    block = scenes.jitter(scenes.cube_fluid_positions(4, 8, 8, R), 0.05 * R, seed=3)   # cells 0..1 x 0..3 x 0..3 of one tile
+    block += np.float32([R, R, R]) - block.min(axis=0)
+    lone = np.float32([[3.5 * h, 1.5 * h, 1.5 * h]])                                     # cell 3: one empty cell from the block
+    pos = np.concatenate([block, lone]).astype(np.float32)
+    for solver in ("dfsph", "iisph"):
+        s = Scene(R, 2.0, solver)
+        s.add_fluid(pos, None, 1000.0)
+        for env in ({}, {"SALVA_HIP_NO_PLANES": "1", "SALVA_HIP_NO_FUSED_DIV": "1"}):
+            old = {k: os.environ.pop(k, None) for k in ("SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FUSED_DIV")}
+            os.environ.update(env)
+            try:
+                w, (fl,), _ = s.make_hip()
+                w.step(DT, GRAVITY)
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+                os.environ.update({k: v for k, v in old.items() if v is not None})
+            o = s.make_oracle()
+            o.step(DT, GRAVITY)
+            assert w.contact_counts(fl)[-1] == 1 and w.contact_counts(fl)[:-1].min() >= 7 and w.contact_counts(fl)[:-1].max() >= 27
+            if solver == "dfsph":
+                a, ao = w.alphas(fl), o.fluid_scalar(0, "alphas")
+                assert ao[-1] == 0.0 and a[-1] == 0.0, (env, a[-1])
+                assert rel_err(a[:-1], ao[:-1], floor=float(np.abs(ao).max()) * 1e-3) < 1e-4
+            assert max_norm_diff(fl.positions, o.fluid_vec(0, "positions")) < 1e-4 * R, (solver, env)
 
 
 def test_device_side_add_and_delete_match_the_host_path():
