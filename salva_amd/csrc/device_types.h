@@ -55,11 +55,12 @@ struct TileAcc {
     uint32_t max_sum;  // running maximum of (fluid halo slots padded to 64) + (boundary halo slots) of one tile (TileLds::max_sum)
     uint32_t max_raw;  // running maximum of (fluid halo slots) + (boundary halo slots) of one tile, no padding: the plane layouts
                        // (tile.h stage_p3), which are filled through registers, slot by slot
-    uint32_t pad_;
+    uint32_t wsl;      // sum of (slices of the tile)^2: wsl / nsl = the slice count of the tile the average PARTICLE lives in (world.hip:
+                       // the workgroup size)
     __host__ __device__ TileAcc operator+(const TileAcc& o) const {
         return TileAcc{s + o.s, sb + o.sb, nsl + o.nsl, nonempty + o.nonempty, max_s > o.max_s ? max_s : o.max_s,
                        max_sb > o.max_sb ? max_sb : o.max_sb, max_nsl > o.max_nsl ? max_nsl : o.max_nsl,
-                       max_sum > o.max_sum ? max_sum : o.max_sum, max_raw > o.max_raw ? max_raw : o.max_raw, 0u};
+                       max_sum > o.max_sum ? max_sum : o.max_sum, max_raw > o.max_raw ? max_raw : o.max_raw, wsl + o.wsl};
     }
 };
 

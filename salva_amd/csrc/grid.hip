@@ -515,6 +515,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc
         a.s = tc.lstart[HCELLS];
         a.sb = tc.blstart[HCELLS];
         a.nsl = (t.own_end - t.own_begin + WAVE - 1) / WAVE;
+        a.wsl = min(a.nsl, 1024u) * min(a.nsl, 1024u);
         a.nonempty = 1;
         a.max_s = (uint32_t)a.s; a.max_sb = (uint32_t)a.sb; a.max_nsl = a.nsl;
         a.max_sum = (((uint32_t)a.s + 63u) & ~63u) + (uint32_t)a.sb;

@@ -711,7 +711,7 @@ StepCtx World::make_ctx() {
 // tile looks boundary cells up by absolute cell coordinates.
 // `fold` (fluid grid only): when the box holds more than fold->budget cells, fold its longest axes to power-of-two periods — never
 // below fold->min_period[a] — until it does (device_types.h TileGrid: the table becomes a torus, the lists stay what they were).
-struct FoldRule { double budget; uint32_t min_period[3]; };
+struct FoldRule { double budget, target; uint32_t min_period[3]; };  // fold when the box exceeds `budget` cells, then down to `target`
 static void dims_from_bbox(const int32_t* bb, GridDims& g, const FoldRule* fold = nullptr) {
     static const int T[3] = {TX, TY, TZ};
     int64_t cells[3];
@@ -724,9 +724,9 @@ static void dims_from_bbox(const int32_t* bb, GridDims& g, const FoldRule* fold 
         g.mask[a] = 0xffffffffu;
         cells[a] = (int64_t)g.nt[a] * T[a];
     }
-    if (fold) {
+    if (fold && (double)cells[0] * (double)cells[1] * (double)cells[2] > fold->budget) {
         for (;;) {
-            if ((double)cells[0] * (double)cells[1] * (double)cells[2] <= fold->budget) break;
+            if ((double)cells[0] * (double)cells[1] * (double)cells[2] <= fold->target) break;
             // the longest axis that can still be folded: to the largest power of two below its present length
             int best = -1;
             int64_t best_p = 0;
@@ -1326,7 +1326,10 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         const uint32_t forced = fold_forced;
         const bool can_fold = !fold_off && !comm && !has_dynamic_sampling();
         if (can_fold && nb && b_dirty) build_boundary_grid();
-        FoldRule rule{forced ? 0.0 : 4.0 * (double)n + 1048576.0, {forced ? forced : 64u, forced ? forced : 64u, forced ? forced : 64u}};
+        // (once it folds, it folds tight — to half a cell per particle if the periods allow: the particles that have left the scene
+        // then land on the tiles of the bulk instead of owning a tile each; a tile with one particle costs a quarter of a full one)
+        FoldRule rule{forced ? 0.0 : 4.0 * (double)n + 1048576.0, forced ? 0.0 : std::max(0.5 * (double)n, 262144.0),
+                      {forced ? forced : 64u, forced ? forced : 64u, forced ? forced : 64u}};
         if (nb)
             for (int a = 0; a < 3; ++a) {
                 static const int T[3] = {TX, TY, TZ};
@@ -1502,15 +1505,17 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         if (tile_trace)
             fprintf(stderr, "salva_hip tiles: nonempty %u max_s %u max_sb %u max_sum %u max_raw %u mass_uniform %g\n", tt.nonempty, tt.max_s,
                     tt.max_sb, tt.max_sum, tt.max_raw, (double)mass_uniform);
-        // one wave per 64-particle slice of the average non-empty tile (fuller tiles loop over their extra slices), never fewer
-        // waves than the halo-table build needs threads — and never more than EIGHT: the neighbour-sum kernels hold 80 VGPRs so that
-        // three tiles of eight waves share a CU (24 of its waves), k_nbr_tile 64 for four; a ninth wave per tile costs each of them
-        // a whole resident tile.  Where the fluid is compressed past 512 particles per tile — every bench scene, from the impact
-        // on — round 4's limit of twelve waves did exactly that: 6.2 against 4.9 ms per step in steps 100..150 of config 2, 3.2
-        // against 2.5 in steps 150..200 (profiles/r05_experiments/r05l_waves_ab.log; seven waves lose to eight there, and six / seven
-        // to eight on the block at rest: 1.31 / 1.32 against 1.20 ms).
-        // (Sizing the workgroups for the tile the average PARTICLE lives in — sum of slices^2 / sum of slices, so that a few thousand
-        // stray particles with a tile each do not halve the waves of the full tiles — was measured too and lost: r05k_fold_ab.log.)
+        // Workgroup size: one wave per 64-particle slice of the tile the average PARTICLE lives in (TileAcc::wsl / nsl; fuller tiles
+        // loop over their extra slices) — the plain average over the tiles drops to four waves as soon as a few thousand stray
+        // particles own a tile each, and the full tiles, where nearly all the work is, then run on half the waves.  Never fewer waves
+        // than the halo-table build needs threads, and never more than EIGHT: the neighbour-sum kernels hold 80 VGPRs so that three
+        // tiles of eight waves share a CU (24 of its waves), k_nbr_tile 64 for four; a ninth wave per tile costs each of them a
+        // whole resident tile.  Where the fluid is compressed past 512 particles per tile — every bench scene, from the impact on —
+        // round 4's limit of twelve waves did exactly that: 6.2 against 4.9 ms per step in steps 100..150 of config 2, 3.2 against
+        // 2.5 in steps 150..200 (profiles/r05_experiments/r05l_waves_ab.log; seven waves lose to eight there, and six / seven to
+        // eight on the block at rest: 1.31 / 1.32 against 1.20 ms).  The particle-weighted size lost while the limit was twelve
+        // (r05k_fold_ab.log, session 1: it asked for nine and ten waves) and wins under the limit of eight (r05m_weighted_ab.log:
+        // 1000 steps of config 2 2.73 -> 2.58 ms per step, 500 of config 3 2.84 -> 2.41, 300 of config 4 9.98 -> 9.57).
         {
 #ifndef SALVA_TILE_WAVES_CAP
 #define SALVA_TILE_WAVES_CAP 8
@@ -1518,7 +1523,12 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             static_assert(SALVA_TILE_WAVES_CAP <= TILE_MAX_WAVES, "the launch bounds are written for TILE_MAX_WAVES");
             const uint32_t avg = (n + tt.nonempty - 1) / std::max<uint32_t>(tt.nonempty, 1u);
             const uint32_t lo = (HCELLS + WAVE - 1) / WAVE, hi = std::min<uint32_t>(std::max<uint32_t>(tt.max_nsl, lo), (uint32_t)(SALVA_TILE_WAVES_CAP));
-            lds.threads = WAVE * std::min<uint32_t>(std::max<uint32_t>((avg + WAVE - 1) / WAVE, lo), hi);
+#ifdef SALVA_TILE_WAVES_PLAIN_AVERAGE  // (A/B: round 4's rule)
+            const uint32_t weighted = 0u;
+#else
+            const uint32_t weighted = tt.nsl ? (uint32_t)((double)tt.wsl / (double)tt.nsl + 0.5) : 0u;
+#endif
+            lds.threads = WAVE * std::min<uint32_t>(std::max<uint32_t>(std::max<uint32_t>((avg + WAVE - 1) / WAVE, weighted), lo), hi);
         }
 #ifdef SALVA_HIP_DIAG
         if (const char* e = getenv("SALVA_HIP_TILE_THREADS")) lds.threads = (uint32_t)atoi(e);
