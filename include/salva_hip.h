@@ -151,6 +151,13 @@ typedef struct SalvaHipCounters {
     uint64_t speculative_passes;              /* steps whose table sizes were predicted from the previous step (no mid-step read-back) */
     uint64_t discarded_passes;                /* passes discarded and repeated: a failed prediction, or a neighbour list longer than
                                                  the capacity it was built with (checked at the end of the step) */
+    uint64_t chained_passes;                  /* DFSPH passes whose solves and everything behind them were enqueued without a host
+                                                 wait in between and whose chain held (one wait per step: its last read-back) */
+    uint64_t chain_breaks;                    /* ... whose chain broke: a solve needed more iterations than the batch enqueued for it,
+                                                 the kernels behind it returned at once and the host continued the classic way */
+    uint64_t pregrid_adopted;                 /* steps that found their grid part (keys, cell sort, tile tables) on the device already,
+                                                 enqueued by the end of the step before */
+    uint64_t pregrid_dropped;                 /* ... that found one they could not use (the cell box moved, the host edited the world) */
 } SalvaHipCounters;
 
 /* fields of salva_hip_get_fluid_field (solver scratch the reference keeps private; exposed for parity tests) */

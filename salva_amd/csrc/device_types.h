@@ -82,6 +82,9 @@ struct alignas(16) SolveCtl {
 };
 static_assert(sizeof(SolveCtl) == 32, "SolveCtl: two 16-byte halves");
 
+// what the end-of-step publication needs to decide Readback::pre_ok
+struct PrePub { int32_t on, chained; int32_t bbox[6]; };
+
 struct StepCtx {
     SphConsts sc;
     uint32_t xcd;  // workgroup -> slot mapping: 1 + log2 of the consecutive slots one XCD takes at a time (common.h xcd_block); 0 = off
@@ -193,6 +196,15 @@ struct StepCtx {
     // the exchange).  0: every tile.  ghost_lo_cx / ghost_hi_cx: the cell planes next to the slab that hold ghosts.
     int32_t phase, ghost_lo_cx, ghost_hi_cx;
     const SolveCtl* ctl;       // non-null inside an iterative solve: kernels return at once when ctl->done
+    // Chained steps (World::dfsph_solve, round 6): the host enqueues the divergence solve's batch, the kernels between the two
+    // solves, the pressure solve's batch and the end of the step WITHOUT waiting for either solve's outcome.  Everything behind a
+    // solve is then "gated": non-null, and the word it points to (Readback::chain_ok) is 0 when a solve upstream did not converge
+    // within the batch it was given — such a kernel returns at once, the end-of-step publication says where the chain broke, and
+    // the host continues from there the classic way (enqueue, wait, decide).  nullptr: not gated.
+    const uint32_t* gate;
+    // the kernels of a chained SOLVE carry its number here (1 = divergence, 2 = pressure; 0 = behind every solve): when the gate was
+    // shut by the last test of this very solve, the apply pass that test has just counted still runs — only a solve upstream stops them
+    uint32_t gate_stage;
 #ifdef SALVA_HIP_DIAG
     unsigned long long* dbg;   // kernel-development builds: per-tile phase timestamps (k_pred_density, SALVA_HIP_TILE_TIMING=1)
 #endif
@@ -216,6 +228,20 @@ struct Readback {
     uint32_t mass_mm[2];  // [0] = bits of particle 0's mass, [1] = the same if no particle's mass differed since the last publication
                           // of the totals (host side of the publication only; on the device: World::mass_slots, grid.hip k_cell_keys)
     uint32_t pad2_[2];
+    // chained steps (StepCtx::gate): 1 while every solve of the step has converged within the batch the host enqueued for it; the
+    // last convergence test of a batch that fails clears it and leaves the solve's number (1 = divergence, 2 = pressure) in
+    // chain_stage.  solve[k] = {done, iters, err, seq} of d_ctl[k] at the end-of-step publication.
+    uint32_t chain_ok, chain_stage;
+    uint32_t solve[2][4];
+    // the grid part of the NEXT step enqueued at the end of this one (World::pre_enqueue_grid): 1 when the box the position update
+    // found is the box that part was enqueued for (and the chain held) — the gate of those launches
+    uint32_t pre_ok;
+    uint32_t pad3_;
 };
+#ifdef __HIPCC__
+// gate[0] = Readback::chain_ok (or pre_ok), gate[1] = the word behind it (chain_stage)
+__device__ __forceinline__ bool gate_words_closed(uint32_t ok, uint32_t stage, uint32_t my_stage) { return ok == 0u && !(my_stage != 0u && stage == my_stage); }
+__device__ __forceinline__ bool gate_closed(const StepCtx& c) { return c.gate && gate_words_closed(c.gate[0], c.gate[1], c.gate_stage); }
+#endif
 
 }  // namespace salva

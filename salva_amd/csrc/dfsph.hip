@@ -678,7 +678,7 @@ void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_pr
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_finish_divergence(StepCtx c, float gx, float gy, float gz, int acc_has_user) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= c.n) return;
+    if (i >= c.n || gate_closed(c)) return;
     const float4 wi = c.w[i];
     const float4 v = c.vel[i];
     const float4 d = c.dv[i];
@@ -697,7 +697,7 @@ void launch_finish_divergence(const StepCtx& c, float gx, float gy, float gz, bo
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_integrate(StepCtx c, float dt) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= c.n) return;
+    if (i >= c.n || gate_closed(c)) return;
     const float4 a = c.acc[i];
     float4 d = c.dv[i];
     d.x += a.x * dt; d.y += a.y * dt; d.z += a.z * dt;
@@ -1014,6 +1014,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_positions(StepCtx c, float dt,
     __shared__ int red[6 * (BLOCK / WAVE)];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+    if (gate_closed(c)) return;  // (wave-uniform; k_bbox_final behind it is gated the same way)
     if (i < c.n) {
         float4 p = c.posm[i];
         const float4 wi = c.w[i];
@@ -1030,7 +1031,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_positions(StepCtx c, float dt,
 void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox_partials, int32_t* bbox6, hipStream_t s) {
     if (!c.n) return;
     k_update_positions<<<num_blocks(c.n), BLOCK, 0, s>>>(c, dt, bbox_partials);
-    launch_bbox_final(bbox_partials, num_blocks(c.n), bbox6, s);
+    launch_bbox_final(bbox_partials, num_blocks(c.n), bbox6, s, c.gate);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1055,9 +1056,12 @@ __device__ __forceinline__ void publish_ctl(const SolveCtl* ctl, SolveCtl* pub, 
 constexpr int FINALIZE_THREADS = 1024;
 __global__ __launch_bounds__(FINALIZE_THREADS) void k_finalize_error(const float* __restrict__ partials, unsigned nblocks,
                                                                      uint32_t nmodels, const uint32_t* __restrict__ model_counts,
-                                                                     SolveCtl* ctl, SolveCtl* pub) {
+                                                                     SolveCtl* ctl, SolveCtl* pub, const uint32_t* gate, uint32_t* close,
+                                                                     uint32_t close_stage) {
     __shared__ float red[FINALIZE_THREADS / WAVE];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // chained step, the chain broke upstream (device_types.h StepCtx::gate): this test does not exist
+    if (gate && gate_words_closed(gate[0], gate[1], close_stage)) return;
     const u32x4 c0 = reinterpret_cast<const u32x4*>(ctl)[0], c1 = reinterpret_cast<const u32x4*>(ctl)[1];
     const uint32_t done = c0.x, iters = c0.y, seq = c0.w + 1u, min_iter = c1.y, mode = c1.z;
     const float tol = __uint_as_float(c1.x);
@@ -1079,6 +1083,9 @@ __global__ __launch_bounds__(FINALIZE_THREADS) void k_finalize_error(const float
         const u32x4 out = {ok ? 1u : 0u, (mode == 0 && ok) ? iters : iters + 1u, __float_as_uint(best), seq};
         reinterpret_cast<u32x4*>(ctl)[0] = out;
         if (pub) *reinterpret_cast<volatile u32x4*>(pub) = out;
+        // the last test of a chained batch: not converged -> everything enqueued behind this solve returns at once, and the host,
+        // which learns it from the end-of-step publication, continues the solve from here (close = &Readback::chain_ok, [1] = stage)
+        if (close && !ok) { close[0] = 0u; close[1] = close_stage; }
     }
 }
 // multi-GPU: the same reduction split around an all-reduce over the ranks
@@ -1124,8 +1131,8 @@ void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_co
     k_decide<<<1, 64, 0, s>>>(sums, nmodels, model_counts, ctl, pub);
 }
 void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
-                           SolveCtl* ctl, SolveCtl* pub, hipStream_t s) {
-    k_finalize_error<<<1, FINALIZE_THREADS, 0, s>>>(partials, nblocks, nmodels, model_counts, ctl, pub);
+                           SolveCtl* ctl, SolveCtl* pub, hipStream_t s, const uint32_t* gate, uint32_t* close, uint32_t close_stage) {
+    k_finalize_error<<<1, FINALIZE_THREADS, 0, s>>>(partials, nblocks, nmodels, model_counts, ctl, pub, gate, close, close_stage);
 }
 
 // ------------------------------------------------------------------------------------------------ boundary volumes

@@ -33,8 +33,9 @@ __global__ __launch_bounds__(BLOCK) void k_bbox(const float4* __restrict__ pts, 
     block_bbox_store(mn, mx, red, partials + 6 * blockIdx.x);
     if (bad) atomicOr(flags, 1u);
 }
-__global__ __launch_bounds__(BLOCK) void k_bbox_final(const int32_t* __restrict__ partials, unsigned nblocks, int32_t* bbox6) {
+__global__ __launch_bounds__(BLOCK) void k_bbox_final(const int32_t* __restrict__ partials, unsigned nblocks, int32_t* bbox6, const uint32_t* gate) {
     __shared__ int red[6 * (BLOCK / WAVE)];
+    if (gate && *gate == 0u) return;  // (device_types.h StepCtx::gate: the position update it follows did not run)
     int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
     for (unsigned b = threadIdx.x; b < nblocks; b += BLOCK) {
 #pragma unroll
@@ -50,10 +51,10 @@ void launch_bbox(const float4* pts, uint32_t n, float h, int32_t* partials, int3
     if (n == 0) return;
     const unsigned nb = bbox_blocks(n);
     k_bbox<<<nb, BLOCK, 0, s>>>(pts, n, h, partials, flags);
-    k_bbox_final<<<1, BLOCK, 0, s>>>(partials, nb, bbox6);
+    k_bbox_final<<<1, BLOCK, 0, s>>>(partials, nb, bbox6, nullptr);
 }
-void launch_bbox_final(const int32_t* partials, unsigned nblocks, int32_t* bbox6, hipStream_t s) {
-    k_bbox_final<<<1, BLOCK, 0, s>>>(partials, nblocks, bbox6);
+void launch_bbox_final(const int32_t* partials, unsigned nblocks, int32_t* bbox6, hipStream_t s, const uint32_t* gate) {
+    k_bbox_final<<<1, BLOCK, 0, s>>>(partials, nblocks, bbox6, gate);
 }
 
 // ------------------------------------------------------------------------------------------------ keys
@@ -66,7 +67,10 @@ void launch_bbox_final(const int32_t* partials, unsigned nblocks, int32_t* bbox6
 __global__ __launch_bounds__(BLOCK) void k_cell_keys(const float4* __restrict__ pts, uint32_t n, float h, TileGrid g,
                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ idx,
                                                      uint32_t* flags, uint32_t* mass_mm, uint32_t* __restrict__ counts,
-                                                     uint32_t* __restrict__ rank) {
+                                                     uint32_t* __restrict__ rank, const uint32_t* gate) {
+    // (gate: this launch was enqueued at the end of the PREVIOUS step for a grid that step could only predict — World::pre_enqueue_grid;
+    // 0 = the prediction did not hold, the step will run its own)
+    if (gate && *gate == 0u) return;
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const bool on = i < n;
     const float4 p = pts[on ? i : 0u];
@@ -107,9 +111,9 @@ __global__ __launch_bounds__(BLOCK) void k_cell_keys(const float4* __restrict__ 
     if (on) rank[i] = base + (lane - hl);
 }
 void launch_cell_keys(const float4* pts, uint32_t n, float h, TileGrid g, uint32_t* keys, uint32_t* idx,
-                      uint32_t* flags, uint32_t* mass_mm, uint32_t* counts, uint32_t* rank, hipStream_t s) {
+                      uint32_t* flags, uint32_t* mass_mm, uint32_t* counts, uint32_t* rank, hipStream_t s, const uint32_t* gate) {
     if (n == 0) return;
-    k_cell_keys<<<div_up(n, BLOCK), BLOCK, 0, s>>>(pts, n, h, g, keys, idx, flags, mass_mm, counts, rank);
+    k_cell_keys<<<div_up(n, BLOCK), BLOCK, 0, s>>>(pts, n, h, g, keys, idx, flags, mass_mm, counts, rank, gate);
 }
 
 // ------------------------------------------------------------------------------------------------ sort / scan (rocPRIM via hipCUB)
@@ -195,18 +199,18 @@ void scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, 
 // particles (two 9-bit one-sweep passes with their five fills + k_cell_start), and it grows with n, not with n log(cells).
 __global__ __launch_bounds__(BLOCK) void k_cell_scatter(uint32_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ rank,
                                                         const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ keys_out,
-                                                        uint32_t* __restrict__ idx_tmp) {
+                                                        uint32_t* __restrict__ idx_tmp, const uint32_t* gate) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || (gate && *gate == 0u)) return;
     const uint32_t k = keys[i], p = cell_start[k] + rank[i];
     keys_out[p] = k;
     idx_tmp[p] = i;
 }
 __global__ __launch_bounds__(BLOCK) void k_cell_order(uint32_t n, const uint32_t* __restrict__ keys_sorted,
                                                       const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ idx_tmp,
-                                                      uint32_t* __restrict__ idx_out) {
+                                                      uint32_t* __restrict__ idx_out, const uint32_t* gate) {
     const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= n) return;
+    if (p >= n || (gate && *gate == 0u)) return;
     const uint32_t k = keys_sorted[p], b = cell_start[k], e = cell_start[k + 1], v = idx_tmp[p];
     uint32_t below = 0;
     for (uint32_t q = b; q < e; ++q) below += idx_tmp[q] < v ? 1u : 0u;
@@ -219,11 +223,12 @@ size_t cell_sort_temp_bytes(uint32_t ncells) {
 }
 // cell_start holds the counts of k_cell_keys on entry (ncells + 1 entries, the last one 0) and the cell table on return
 void cell_sort(void* temp, size_t temp_bytes, uint32_t n, uint32_t ncells, const uint32_t* keys, const uint32_t* rank, uint32_t* cell_start,
-               uint32_t* keys_out, uint32_t* idx_tmp, uint32_t* idx_out, hipStream_t s) {
+               uint32_t* keys_out, uint32_t* idx_tmp, uint32_t* idx_out, hipStream_t s, const uint32_t* gate) {
+    // (the library scan cannot be gated: behind a closed gate it sums whatever the table holds, in bounds, and nobody indexes by it)
     SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, cell_start, cell_start, (int)(ncells + 1u), s));
     if (n == 0) return;
-    k_cell_scatter<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, keys, rank, cell_start, keys_out, idx_tmp);
-    k_cell_order<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, keys_out, cell_start, idx_tmp, idx_out);
+    k_cell_scatter<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, keys, rank, cell_start, keys_out, idx_tmp, gate);
+    k_cell_order<<<div_up(n, BLOCK), BLOCK, 0, s>>>(n, keys_out, cell_start, idx_tmp, idx_out, gate);
 }
 
 // ------------------------------------------------------------------------------------------------ cell table
@@ -482,20 +487,24 @@ constexpr int TABLE_THREADS = HCELLS <= 256 ? 256 : 320;  // >= HCELLS
 static_assert(TABLE_THREADS >= HCELLS, "one thread per halo cell");
 
 // one thread per tile of the dense grid: does it hold particles?
-__global__ __launch_bounds__(BLOCK) void k_tile_flags(const uint32_t* __restrict__ cell_start, uint32_t ntiles, uint32_t* __restrict__ flags) {
+__global__ __launch_bounds__(BLOCK) void k_tile_flags(const uint32_t* __restrict__ cell_start, uint32_t ntiles, uint32_t* __restrict__ flags,
+                                                      const uint32_t* gate) {
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    if (gate && *gate == 0u) return;
     if (t < ntiles) flags[t] = cell_start[(size_t)t * TCELLS + TCELLS] > cell_start[(size_t)t * TCELLS] ? 1u : 0u;
     if (t == ntiles) flags[t] = 0u;
 }
-__global__ __launch_bounds__(BLOCK) void k_tile_ids(const uint32_t* __restrict__ rank, uint32_t ntiles, uint32_t* __restrict__ tile_ids) {
+__global__ __launch_bounds__(BLOCK) void k_tile_ids(const uint32_t* __restrict__ rank, uint32_t ntiles, uint32_t* __restrict__ tile_ids,
+                                                    const uint32_t* gate) {
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    if (gate && *gate == 0u) return;  // (must not index by ranks scanned from stale flags)
     if (t < ntiles && rank[t + 1] != rank[t]) tile_ids[rank[t]] = t;
 }
 void launch_tile_slots(const uint32_t* cell_start, uint32_t ntiles, uint32_t* flags, uint32_t* rank, uint32_t* tile_ids, void* temp,
-                       size_t temp_bytes, hipStream_t s) {
-    k_tile_flags<<<div_up((size_t)ntiles + 1, BLOCK), BLOCK, 0, s>>>(cell_start, ntiles, flags);
+                       size_t temp_bytes, hipStream_t s, const uint32_t* gate) {
+    k_tile_flags<<<div_up((size_t)ntiles + 1, BLOCK), BLOCK, 0, s>>>(cell_start, ntiles, flags, gate);
     SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, flags, rank, (int)(ntiles + 1), s));
-    k_tile_ids<<<div_up((size_t)ntiles, BLOCK), BLOCK, 0, s>>>(rank, ntiles, tile_ids);
+    k_tile_ids<<<div_up((size_t)ntiles, BLOCK), BLOCK, 0, s>>>(rank, ntiles, tile_ids, gate);
 }
 
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc* __restrict__ tile_cnt, uint4* __restrict__ slot_desc) {
@@ -503,6 +512,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc
     TileAcc a{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // (launched over an upper bound of the slot count: a surplus workgroup contributes a zero entry; workgroup 0 also zeroes the
     // extra element the exclusive scan reads behind the last one)
+    if (gate_closed(c)) return;  // (a pre-enqueued launch whose grid did not come true: World::pre_enqueue_grid)
     if (blockIdx.x == 0 && threadIdx.x == 1) tile_cnt[gridDim.x] = a;
     if (!t.setup_geom(c)) {
         if (threadIdx.x == 0) tile_cnt[blockIdx.x] = a;

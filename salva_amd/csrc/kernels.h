@@ -13,13 +13,13 @@ namespace salva {
 // cell bbox of `n` points (xyz of float4) -> bbox6 = {min x,y,z, max x,y,z}; partials needs 6 * bbox_blocks(n) ints
 unsigned bbox_blocks(uint32_t n);
 void launch_bbox(const float4* pts, uint32_t n, float h, int32_t* partials, int32_t* bbox6, uint32_t* flags, hipStream_t s);
-void launch_bbox_final(const int32_t* partials, unsigned nblocks, int32_t* bbox6, hipStream_t s);
+void launch_bbox_final(const int32_t* partials, unsigned nblocks, int32_t* bbox6, hipStream_t s, const uint32_t* gate = nullptr);
 // counts != nullptr: the first half of the counting sort (cell_sort) — counts[key] += 1, rank[i] = the value before; idx is not written
 void launch_cell_keys(const float4* pts, uint32_t n, float h, TileGrid g, uint32_t* keys, uint32_t* idx,
-                      uint32_t* flags, uint32_t* mass_mm, uint32_t* counts, uint32_t* rank, hipStream_t s);
+                      uint32_t* flags, uint32_t* mass_mm, uint32_t* counts, uint32_t* rank, hipStream_t s, const uint32_t* gate = nullptr);
 size_t cell_sort_temp_bytes(uint32_t ncells);
 void cell_sort(void* temp, size_t temp_bytes, uint32_t n, uint32_t ncells, const uint32_t* keys, const uint32_t* rank, uint32_t* cell_start,
-               uint32_t* keys_out, uint32_t* idx_tmp, uint32_t* idx_out, hipStream_t s);
+               uint32_t* keys_out, uint32_t* idx_tmp, uint32_t* idx_out, hipStream_t s, const uint32_t* gate = nullptr);
 size_t sort_pairs_temp_bytes(uint32_t n, int end_bit);
 void sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
                 uint32_t* idx_out, uint32_t n, int end_bit, hipStream_t s);
@@ -50,7 +50,7 @@ void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4
 // per-tile {halo slots, boundary halo slots, slices} (-> scan_tiles -> tile_off) and their maxima; then the flat
 // halo slot tables
 void launch_tile_slots(const uint32_t* cell_start, uint32_t ntiles, uint32_t* flags, uint32_t* rank, uint32_t* tile_ids, void* temp,
-                       size_t temp_bytes, hipStream_t s);
+                       size_t temp_bytes, hipStream_t s, const uint32_t* gate = nullptr);
 void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, uint4* slot_desc, hipStream_t s);
 void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, uint4* slot_info, hipStream_t s);
 size_t scan_tiles_temp_bytes(uint32_t n);
@@ -92,8 +92,11 @@ void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hip
 // x += w dt; per-block cell bounds into bbox_partials (6 * num_blocks(n) ints), folded into bbox6
 void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox_partials, int32_t* bbox6, hipStream_t s);
 // err = max_m (sum_b partials[b][m] / count[m]) -> ctl->err, then the break test of the solve (nblocks = ntiles)
+// gate / close / close_stage: chained steps (device_types.h StepCtx::gate) — skip when *gate == 0; a failed test clears close[0] and
+// leaves close_stage in close[1]
 void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
-                           SolveCtl* ctl, SolveCtl* pub, hipStream_t s);
+                           SolveCtl* ctl, SolveCtl* pub, hipStream_t s, const uint32_t* gate = nullptr, uint32_t* close = nullptr,
+                           uint32_t close_stage = 0u);
 // multi-GPU form: per-fluid sums of this rank -> sums[nmodels]; (all-reduce over ranks); break test on the global sums
 void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmodels, const SolveCtl* ctl, float* sums, hipStream_t s);
 void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, SolveCtl* pub, hipStream_t s);

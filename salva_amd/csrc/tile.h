@@ -259,6 +259,10 @@ struct Tile {
         pool = tile_smem;
         pool_used = 0;
         slot = at_slot;
+        // A chained step whose chain broke upstream (device_types.h StepCtx::gate): nothing to do.  The word is fetched here and looked
+        // at behind the other loads of the set-up — tested first, it puts a dependent round trip (a word the previous kernel wrote) in
+        // front of every tile's life: +8-10 us per free-fall step when it went in (profiles/r06_experiments/r06a_chain.log).
+        const uint32_t gate_word = c.gate ? (gate_words_closed(c.gate[0], c.gate[1], c.gate_stage) ? 0u : 1u) : 1u;
         const uint4 desc = c.slot_desc[slot];
         mass = c.two_mass ? __uint_as_float(c.tile_mass_bits[slot]) : c.mass_uniform;
         massb = c.two_mass ? __uint_as_float(c.tile_massb_bits[slot]) : 0.0f;
@@ -298,6 +302,7 @@ struct Tile {
             }
             if (slot >= c.tile_rank[c.ntiles] || a1.nsl > c.nslices_cap) { own_end = own_begin; S = SB = 0; }
         }
+        if (gate_word == 0u) { skip = true; own_end = own_begin; S = SB = 0; }
     }
 
     template <typename T>

@@ -158,13 +158,22 @@ class World {
     struct SolveResult { uint32_t iters; float err; };
     template <typename Eval, typename Apply>
     SolveResult run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval, Apply&& apply,
-                          bool spec_apply = false);
+                          bool spec_apply = false, int chain_stage = 0, int from = 0, bool chain_open = false);
+    // Chained steps (device_types.h StepCtx::gate, World::dfsph_solve): both solves of a DFSPH step and everything between and behind
+    // them are enqueued without a wait; the end-of-step publication carries their outcome.
+    bool chain_allowed() const;
+    bool chain_off = false;       // SALVA_HIP_NO_CHAIN=1 (A/B, tests)
+    bool chain_pending = false;   // this pass was enqueued that way and its outcome has not been read yet
+    bool chain_div_pending = false;  // ... the divergence solve included (not while its iteration count is rising)
+    int chain_batch[2] = {0, 0};  // iterations enqueued for the divergence / the pressure solve (where a continuation starts)
+    float chain_dt_prev = 0.0f, chain_inv_dt_prev = 0.0f;  // TimestepManager::{dt, inv_dt} as the chained attempt found them
+    uint64_t chain_steps = 0, chain_breaks = 0;  // passes whose chain held / broke (SALVA_HIP_TILE_TRACE prints them)
     DevBuf<float4> w2;            // the second w buffer of speculative divergence applies (dfsph.hip, spec_decide)
     DevBuf<SolveCtl> spec_ring;   // their two alternating control records
     bool spec_apply_off = false;  // SALVA_HIP_NO_SPEC_APPLY (A/B, tests)
     void wait_stream();  // low-latency wait for the world's stream (spins on an event)
     void run_forces(const StepCtx& c);
-    void dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepStats& st);  // dt: in = the step, out = the substep advanced by
+    void dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepStats& st, int resume = 0);  // dt: in = the step, out = the substep advanced by
     void iisph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepStats& st);
     int substep(float& dt, const float g[3], SalvaHipStepStats& st);  // one pass of the reference's substep loop (liquid_world.rs:85-147)
     // Opt-in CFL sub-stepping (salva_hip_set_cfl): TimestepManager's cfl_coeff / min / max_num_substeps (timestep_manager.rs:23-34)
@@ -217,13 +226,24 @@ class World {
     DevBuf<double> wrench_partial;       // per-block partial sums of salva_hip_get_boundary_wrench
     DevBuf<float> he_colors, he_gradcs;  // He2014SurfaceTension state (he2014_surface_tension.rs:15-16)
     DevBuf<float> rho, alpha, kappa, kappa2, rho_star, aii;
-    DevBuf<uint32_t> nff, nfb, keys[2], idx[2], cell_start_f;
-    DevBuf<TileAcc> tile_cnt, tile_off;
-    DevBuf<uint4> slot_desc, slot_info;
-    DevBuf<uint32_t> d_maxhalo, halo_src, bhalo_src, tile_ids, tile_flags, tile_rank;
+    DevBuf<uint32_t> nff, nfb;
+    // What the first part of a step builds from the positions alone — keys, the sort's permutation, the cell table, the non-empty
+    // tiles and their halo / slice counts — exists TWICE: the end of a step may enqueue this part of the NEXT step already
+    // (World::pre_enqueue_grid, round 6) while the tables of the step that has just run still serve contact exports and queries.
+    struct GridTabs {
+        DevBuf<uint32_t> keys[2], idx[2], cell_start_f, cell_rank, tile_ids, tile_flags, tile_rank;
+        DevBuf<TileAcc> tile_cnt, tile_off;
+        DevBuf<uint4> slot_desc;
+    };
+    GridTabs gtab[2];
+    int gsel = 0;  // the set the current step works on
+    GridTabs& G() { return gtab[gsel]; }
+    DevBuf<uint4> slot_info;
+    DevBuf<uint32_t> d_maxhalo, halo_src, bhalo_src;
     uint32_t nlaunch = 0;  // non-empty tiles of the current step = grid size of the solver kernels
     int sched_mode = 0;  // kernel-development builds: 1 = run diag/sched.hip after the list build (SALVA_HIP_SCHED)
     uint32_t last_iters[NUM_SOLVES] = {1u, 1u, 1u};  // iterations of the previous step's divergence / pressure solve (batch sizing)
+    uint32_t prev_iters[NUM_SOLVES] = {1u, 1u, 1u};  // ... and of the step before it (a rising count widens a chained batch)
     uint32_t halo_stride = 0, bhalo_stride = 0;  // fixed row stride of the slot tables (0 = compact)
     DevBuf<char> tile_list_stats;
     uint32_t cap_ff = 24, cap_fb = 8;  // ELL capacity (dwords per particle), grown on demand
@@ -261,7 +281,6 @@ class World {
     bool no_planes = false;     // SALVA_HIP_NO_PLANES=1 (A/B): keep the 32-byte-per-slot evaluate kernels
     bool iisph_dii_fused = false;  // this step's density pass wrote d_ii (k_density_alpha<true>): iisph_solve skips k_iisph_dii
     int sort_mode = -1;         // SALVA_HIP_RADIX_SORT: 1 = always the radix sort + k_cell_start, 0 = always the counting sort by cell, unset = by size
-    DevBuf<uint32_t> cell_rank; // counting sort: a particle's place among those of its cell (k_cell_keys)
 #ifdef SALVA_HIP_DIAG
     PipeCfg pipe;          // launch shape of the persistent pipeline kernels of this step (pipe.h)
 #endif
@@ -309,7 +328,27 @@ class World {
     struct HostPub { uint32_t seq, pad[3]; Readback rb; };
     HostPub* h_hostpub = nullptr;
     uint32_t hostpub_seq = 0;
-    uint32_t publish_enqueue(const TileAcc* totals, bool lists, bool end_of_step);
+    uint32_t publish_enqueue(const TileAcc* totals, bool lists, bool end_of_step, const PrePub* pre = nullptr, const uint32_t* gate = nullptr);
+    // The grid part of the next step, enqueued at the end of this one (round 6).  A step starts with ~14 launches of kernels that
+    // take a few microseconds each, on an empty queue, right after the host has returned from one step and entered the next: the
+    // GPU waits for the host all the way (tools/r06/slow_host.c: 10-15 launches of a free-fall step sit on its critical path).
+    // When the particles' cell box did not change over the last step, the end of a step therefore enqueues keys -> counting sort ->
+    // non-empty tiles -> per-tile counts -> totals publication for the SAME grid, into the other set of tables (gtab[gsel ^ 1]),
+    // gated on the device by Readback::pre_ok = "the box the position update found is that box".  The next step adopts the work
+    // when nothing has touched the world in between, and runs its own otherwise.
+    struct PreGrid {
+        bool valid = false;
+        uint32_t n = 0, seq = 0, nslots_bound = 0, ntiles = 0;
+        size_t ncf = 0;
+        bool check_mass = false;
+        GridDims gf;
+    } pre;
+    bool pre_off = false;          // SALVA_HIP_NO_PREGRID=1 (A/B, tests)
+    int32_t bbox_used_last[6] = {0, 0, 0, 0, 0, 0};  // the cell box the previous step ran on
+    bool bbox_used_valid = false;
+    uint64_t pre_adopted = 0, pre_dropped = 0;
+    void pre_enqueue_grid(uint32_t nslots_bound);
+    void pre_drop();
     void publish_wait(uint32_t seq, bool totals, bool lists, bool end_of_step);
     void publish_and_wait(const TileAcc* totals, bool lists, bool end_of_step);
     DevBuf<SolveCtl> d_ctl;      // [0] divergence solve, [1] pressure solve, [2] viscosity solve (DFSPHViscosity)

@@ -133,6 +133,8 @@ World::World(const SalvaHipParams& p) : prm(p) {
     spec_tight = getenv("SALVA_HIP_SPEC_TIGHT") != nullptr;
     defer_off = getenv("SALVA_HIP_NO_DEFER_LISTS") != nullptr;
     spec_apply_off = getenv("SALVA_HIP_NO_SPEC_APPLY") != nullptr;
+    chain_off = getenv("SALVA_HIP_NO_CHAIN") != nullptr;
+    pre_off = getenv("SALVA_HIP_NO_PREGRID") != nullptr;
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
     two_mass_off = getenv("SALVA_HIP_NO_TWO_MASS") != nullptr;
     fold_off = getenv("SALVA_HIP_NO_FOLD") != nullptr;
@@ -671,14 +673,14 @@ StepCtx World::make_ctx() {
     c.nff = nff.p; c.nfb = nfb.p;
     c.nbr_ff = nbr_ff.p; c.nbr_fb = nbr_fb.p; c.cap_ff = cap_ff; c.cap_fb = cap_fb;
     c.slice_near = slice_near.p;
-    c.tile_off = tile_off.p; c.halo_src = halo_src.p; c.bhalo_src = bhalo_src.p;
+    c.tile_off = G().tile_off.p; c.halo_src = halo_src.p; c.bhalo_src = bhalo_src.p;
     c.halo_stride = halo_stride; c.bhalo_stride = bhalo_stride;
     c.ntiles = (uint32_t)gf.ntiles();
-    c.tile_ids = tile_ids.p; c.tile_rank = tile_rank.p; c.nlaunch = nlaunch; c.slot_desc = slot_desc.p; c.slot_info = slot_info.p;
+    c.tile_ids = G().tile_ids.p; c.tile_rank = G().tile_rank.p; c.nlaunch = nlaunch; c.slot_desc = G().slot_desc.p; c.slot_info = slot_info.p;
     c.spec = spec_mode ? 1u : 0u; c.halo_cap = halo_cap; c.bhalo_cap = bhalo_cap; c.nslices_cap = nslices_cap;
     c.halo_len = halo_len; c.bhalo_len = bhalo_len;
-    c.gf = gf.device(cell_start_f.p);
-    c.stale_keys = has_dynamic_sampling() ? keys[1].p : nullptr;
+    c.gf = gf.device(G().cell_start_f.p);
+    c.stale_keys = has_dynamic_sampling() ? G().keys[1].p : nullptr;
     c.nb = nb;
     c.bposv = bposv.p; c.bvel = bvel.p; c.bperm = bperm.p;
     c.bforce = any_wants_forces ? bforce.p : nullptr;
@@ -803,7 +805,9 @@ void World::build_boundary_grid() {
 // fences to system scope, then bumps the sequence word the host polls.  (A hipMemcpyAsync + event costs ~20 us of idle GPU each
 // time the host has to wait for it: tools/gap_tsv_report.py.)
 __global__ void k_publish_readback(Readback* __restrict__ src, const TileAcc* __restrict__ totals, int lists, int end_of_step,
-                                   uint32_t* mass_slots, Readback* pub_rb, volatile uint32_t* pub_seq, uint32_t seq) {
+                                   uint32_t* mass_slots, Readback* pub_rb, volatile uint32_t* pub_seq, uint32_t seq,
+                                   const SolveCtl* __restrict__ ctl, PrePub pre, const uint32_t* gate) {
+    if (gate && *gate == 0u) return;  // (the totals of a pre-enqueued grid that did not come true: nobody waits for them)
     uint32_t mlo = 0u, mhi = 0u;
     if (totals) {  // (wave-uniform) did k_cell_keys see a mass other than particle 0's since the last such publication?  start the next one
         static_assert(MASS_SLOTS == WAVE, "one flag per lane of the publishing wave");
@@ -826,23 +830,35 @@ __global__ void k_publish_readback(Readback* __restrict__ src, const TileAcc* __
             pub_rb->flags = src->flags;
             src->flags = 0u;  // (the next step starts from clear flags without a memset of its own: World::flags_clean)
             for (int a = 0; a < 6; ++a) pub_rb->bbox[a] = src->bbox[a];
+            // chained steps (device_types.h StepCtx::gate): did every solve converge within its batch, and what they found
+            pub_rb->chain_ok = src->chain_ok; pub_rb->chain_stage = src->chain_stage;
+            uint32_t pok = (pre.on && (!pre.chained || src->chain_ok)) ? 1u : 0u;
+            for (int a = 0; a < 6; ++a) pok &= (src->bbox[a] == pre.bbox[a]) ? 1u : 0u;
+            src->pre_ok = pok; pub_rb->pre_ok = pok;
+            for (int k = 0; k < 2; ++k) {
+                pub_rb->solve[k][0] = ctl[k].done; pub_rb->solve[k][1] = ctl[k].iters;
+                pub_rb->solve[k][2] = __float_as_uint(ctl[k].err); pub_rb->solve[k][3] = ctl[k].seq;
+            }
         }
         __threadfence_system();
         *pub_seq = seq;
     }
 }
 // enqueue the publication on the world's stream ...
-uint32_t World::publish_enqueue(const TileAcc* totals, bool lists, bool end_of_step) {
+uint32_t World::publish_enqueue(const TileAcc* totals, bool lists, bool end_of_step, const PrePub* pre, const uint32_t* gate) {
     const uint32_t seq = ++hostpub_seq;
-    k_publish_readback<<<1, WAVE, 0, stream>>>(d_rb.p, totals, lists ? 1 : 0, end_of_step ? 1 : 0, mass_slots.p, &h_hostpub->rb, &h_hostpub->seq, seq);
+    k_publish_readback<<<1, WAVE, 0, stream>>>(d_rb.p, totals, lists ? 1 : 0, end_of_step ? 1 : 0, mass_slots.p, &h_hostpub->rb, &h_hostpub->seq, seq,
+                                               d_ctl.p, pre ? *pre : PrePub{0, 0, {0, 0, 0, 0, 0, 0}}, gate);
     SALVA_HIP_CHECK(hipGetLastError());
     return seq;
 }
 // ... and wait for it (kernels enqueued in between keep the GPU busy meanwhile); the published words are folded into h_rb
 void World::publish_wait(uint32_t seq, bool totals, bool lists, bool end_of_step) {
     auto last_query = std::chrono::steady_clock::now();
-    // (sequence numbers only grow and one publication is outstanding at a time)
-    for (uint32_t spins = 0; __atomic_load_n(&h_hostpub->seq, __ATOMIC_ACQUIRE) != seq; ++spins) {
+    // (sequence numbers only grow; the totals of a pre-enqueued grid may follow the end-of-step publication before the host has
+    // looked — the two write different fields)
+    auto arrived = [&] { return (int32_t)(__atomic_load_n(&h_hostpub->seq, __ATOMIC_ACQUIRE) - seq) >= 0; };
+    for (uint32_t spins = 0; !arrived(); ++spins) {
         __builtin_ia32_pause();
         if ((spins & 0xffu) != 0xffu) continue;
         const auto now = std::chrono::steady_clock::now();
@@ -850,7 +866,7 @@ void World::publish_wait(uint32_t seq, bool totals, bool lists, bool end_of_step
         last_query = now;
         const hipError_t e = hipStreamQuery(stream);  // a fault on the stream would otherwise spin forever
         if (e != hipSuccess && e != hipErrorNotReady) SALVA_HIP_CHECK(e);
-        if (e == hipSuccess && __atomic_load_n(&h_hostpub->seq, __ATOMIC_ACQUIRE) != seq)
+        if (e == hipSuccess && !arrived())
             throw HipError(SALVA_HIP_E_HIP, "internal error: the stream drained without publishing its read-back");
     }
     const Readback& p = h_hostpub->rb;
@@ -859,7 +875,11 @@ void World::publish_wait(uint32_t seq, bool totals, bool lists, bool end_of_step
         h_rb->ncontacts_ff = p.ncontacts_ff; h_rb->ncontacts_fb = p.ncontacts_fb; h_rb->max_cnt_ff = p.max_cnt_ff; h_rb->max_cnt_fb = p.max_cnt_fb;
         h_rb->ncontacts_own_ff = p.ncontacts_own_ff; h_rb->ncontacts_own_fb = p.ncontacts_own_fb;
     }
-    if (end_of_step) { h_rb->flags = p.flags; memcpy(h_rb->bbox, p.bbox, sizeof(p.bbox)); }
+    if (end_of_step) {
+        h_rb->flags = p.flags; memcpy(h_rb->bbox, p.bbox, sizeof(p.bbox));
+        h_rb->chain_ok = p.chain_ok; h_rb->chain_stage = p.chain_stage; memcpy(h_rb->solve, p.solve, sizeof(p.solve));
+        h_rb->pre_ok = p.pre_ok;
+    }
 }
 void World::publish_and_wait(const TileAcc* totals, bool lists, bool end_of_step) {
     publish_wait(publish_enqueue(totals, lists, end_of_step), totals != nullptr, lists, end_of_step);
@@ -884,31 +904,54 @@ __global__ void k_ghost_posmr(uint32_t n, const uint32_t* __restrict__ gtag, con
     if (i >= n || !(gtag[i] & 0x80000000u)) return;
     reinterpret_cast<float*>(&posmr[i])[3] = posm[i].w / rho[i];
 }
-__global__ void k_init_ctl(SolveCtl* ctl, SolveCtl* ring, SolveCtl init) {
+__global__ void k_init_ctl(SolveCtl* ctl, SolveCtl* ring, SolveCtl init, uint32_t* chain_open) {
     *ctl = init;
+    if (chain_open) { chain_open[0] = 1u; chain_open[1] = 0u; }  // (Readback::chain_ok / chain_stage: the first solve of a chained step)
     if (ring) { ring[0] = init; ring[1] = init; }  // (dfsph.hip spec_decide: the test rides in the apply pass; iteration k reads spec_ring[k & 1])
 }
 template <typename Eval, typename Apply>
 World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_iter, int max_iter, uint32_t mode, Eval&& eval,
-                                    Apply&& apply, bool spec_apply) {
-    SolveCtl& init = h_ctl[NUM_SOLVES + which];
-    init = SolveCtl{0u, 0u, 0.0f, 0u, tol, (uint32_t)std::max(min_iter, 0), mode, 0u};
-    h_ctl[which] = init;
-    // (one tiny kernel with the record as its argument instead of up to three copies from pageable host memory, each of which
-    // stalls the host until its staging copy is done)
-    c.ctl = d_ctl.p + which;
-    k_init_ctl<<<1, 1, 0, stream>>>(d_ctl.p + which, spec_apply ? spec_ring.p : nullptr, init);
-    SALVA_HIP_CHECK(hipGetLastError());
+                                    Apply&& apply, bool spec_apply, int chain_stage, int from, bool chain_open) {
     // Every convergence test publishes its outcome to host-mapped memory (k_finalize_error; in a decomposed run k_decide,
     // behind the all-reduce), and the host waits for the test count it enqueued — it then decides (and enqueues what
     // follows) while the batch's last apply pass is still running.
     static const bool no_publish = getenv("SALVA_HIP_NO_PUBLISH") != nullptr;  // (diagnostics: A/B against the copy + wait)
     SolveCtl* const pub = no_publish ? nullptr : h_pub + which;
-    if (pub) { pub->done = 0u; pub->iters = 0u; pub->err = 0.0f; __atomic_store_n(&pub->seq, 0u, __ATOMIC_RELEASE); }
+    c.ctl = d_ctl.p + which;
+    if (from == 0) {
+        SolveCtl& init = h_ctl[NUM_SOLVES + which];
+        init = SolveCtl{0u, 0u, 0.0f, 0u, tol, (uint32_t)std::max(min_iter, 0), mode, 0u};
+        h_ctl[which] = init;
+        // (one tiny kernel with the record as its argument instead of up to three copies from pageable host memory, each of which
+        // stalls the host until its staging copy is done; the first solve of a chained step also opens the chain)
+        k_init_ctl<<<1, 1, 0, stream>>>(d_ctl.p + which, spec_apply ? spec_ring.p : nullptr, init, chain_open ? &d_rb.p->chain_ok : nullptr);
+        SALVA_HIP_CHECK(hipGetLastError());
+        if (pub) { pub->done = 0u; pub->iters = 0u; pub->err = 0.0f; __atomic_store_n(&pub->seq, 0u, __ATOMIC_RELEASE); }
+    }
     // First batch: what the previous step's solve needed (iters applies + the converged evaluate) — consecutive steps
     // need about the same, so the usual cost is one read-back per solve; a batch that overshoots only enqueues kernels
     // that return at once, one that falls short continues in doubling batches.
-    int i = 0, batch = std::max(2, std::min<int>((int)last_iters[which] + 1, max_iter));
+    int i = from, batch = std::max(2, std::min<int>((int)last_iters[which] + 1, max_iter));
+    if (chain_stage) {
+        // Chained (device_types.h StepCtx::gate): ONE batch and no wait.  The batch is what the previous step needed plus, while the
+        // count is rising (the impact: 2, 4, 14, 18, 30 ... iterations in consecutive steps), what it rose by last time — a surplus
+        // iteration costs three kernels that return at once, a batch that falls short costs the chain (every kernel behind this
+        // solve returns at once and the host comes back here with `from` = this batch).  Its LAST test closes the chain when it
+        // fails, unless the batch runs to max_iter: then the solve is over whatever that test says.
+        const int rise = (int)last_iters[which] > (int)prev_iters[which] ? std::min((int)last_iters[which] - (int)prev_iters[which], 8) : 0;
+        const int nbatch = std::min(batch + rise, max_iter);
+        c.gate_stage = (uint32_t)chain_stage;  // (its own last test may shut the gate: the apply behind that test still runs)
+        for (int k = 0; k < nbatch; ++k) {
+            eval(c, k);
+            const bool closes = k == nbatch - 1 && nbatch < max_iter;
+            launch_finalize_error(partials.p, nlaunch, (uint32_t)std::max<size_t>(fluids.size(), 1), model_counts.p, d_ctl.p + which, pub, stream, c.gate,
+                                  closes ? &d_rb.p->chain_ok : nullptr, (uint32_t)chain_stage);
+            apply(c, k);
+        }
+        chain_batch[which] = nbatch;
+        return SolveResult{0u, 0.0f};  // (pending: World::substep reads the outcome from the end-of-step publication)
+    }
+    if (from > 0) batch = (from <= 2) ? 4 : 8;
     while (i < max_iter) {
         const int nbatch = std::min(batch, max_iter - i);
         for (int k = 0; k < nbatch; ++k) {
@@ -944,6 +987,7 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
         if (h_ctl[which].done) break;
         batch = (i <= 2) ? 4 : 8;
     }
+    prev_iters[which] = last_iters[which];
     last_iters[which] = h_ctl[which].iters;
     return SolveResult{h_ctl[which].iters, h_ctl[which].err};
 }
@@ -1123,57 +1167,91 @@ float World::choose_substep(const StepCtx& c) {
     return sub;
 }
 
+// Can this step's solves be chained (device_types.h StepCtx::gate)?  Everything between the first solve and the end of the step has
+// to be a kernel that honours the gate and needs no host decision: a single domain, no CFL choice (a read-back inside the solver), no
+// host force callback, no force with a solve of its own (DFSPHViscosity).  SALVA_HIP_NO_CHAIN=1 switches it off (A/B, tests).
+bool World::chain_allowed() const {
+    if (chain_off || comm || cfl_mode || spec_mode || prm.solver != SALVA_HIP_SOLVER_DFSPH) return false;
+    for (const FluidSlot& f : fluids)
+        for (const SalvaHipForceDesc& d : f.forces)
+            if (d.kind == SALVA_HIP_FORCE_CUSTOM || d.kind == SALVA_HIP_FORCE_DFSPH_VISCOSITY) return false;
+    return true;
+}
+
 // DFSPHSolver::step (dfsph_solver.rs:667-708)
-void World::dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepStats& st) {
+// `resume`: 0 = the step's solver part from its start.  Chained, it returns with everything enqueued and nothing waited for
+// (chain_pending); World::substep learns from the end-of-step publication whether both solves converged within their batches and,
+// if one did not, calls again with resume = 1 (continue the divergence solve, then everything behind it) or 2 (continue the pressure
+// solve, then the position update) — the classic way, one wait per batch.
+void World::dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepStats& st, int resume) {
+    if (resume) { dt_prev = chain_dt_prev; inv_dt_prev = chain_inv_dt_prev; }  // (TimestepManager's state as the chained attempt found it)
+    chain_dt_prev = dt_prev; chain_inv_dt_prev = inv_dt_prev;
     // divergence_solve (:466-503).  NOTE the dt lag: inv_dt is still the previous step's here (0 on the first step).
     const float inv_dt_lag = inv_dt_prev;
     const bool timers = prm.enable_timers != 0;
-    if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[3], stream));  // counters.custom (:492)
+    if (timers && !resume) SALVA_HIP_CHECK(hipEventRecord(evc[3], stream));  // counters.custom (:492)
     // Speculative applies (dfsph.hip, spec_decide): the convergence test rides in the apply pass instead of a launch of its own.
     // Worth ~3 us per iteration (measured: a 50-iteration step 5.13 -> 4.99 ms); the apply that follows the converging evaluate is
     // then computed in vain (~30 us once per solve), so: only when the previous step's solve ran 16 iterations or more; not with boundary reaction forces (an
     // apply that is thrown away must not have added to them) and not in decomposed runs (the test sits behind an all-reduce).
-    const bool spec_apply = !spec_apply_off && !comm && !any_wants_forces && last_iters[0] >= 16u;
+    const bool spec_apply = !resume && !spec_apply_off && !comm && !any_wants_forces && last_iters[0] >= 16u;
     if (spec_apply) { w2.ensure(n, stream, false, 1.1f); spec_ring.ensure(2); c.w2 = w2.p; c.spec_ring = spec_ring.p; }
-    const SolveResult rd = run_solve(
-        c, 0, prm.max_divergence_error * inv_dt_prev * 0.01f, prm.min_divergence_iter, prm.max_divergence_iter, 0u,
-        [&](const StepCtx& cc, int it) {
-            if (it == 0 && fused_first_divergence) return;  // (k_density_alpha_div_p3 wrote kappa and the error partials already)
-            evaluate_split(cc, it, [&](const StepCtx& cs, hipStream_t s) { launch_divergence(cs, lds, s); });
-        },
-        [&](const StepCtx& cc, int) {
-            // decomposed runs: kappa of the inner ghost plane was computed here from refreshed w — the applies of the
-            // owned particles read nothing else, so only w travels, once per iteration
-            launch_divergence_apply(cc, lds, inv_dt_lag, stream);
-            if (comm) refresh_f4(w.p);
-        }, spec_apply);
-    if (spec_apply && (rd.iters & 1u)) {  // an odd number of committed applies: w lives in the second buffer
-        std::swap(w.p, w2.p); std::swap(w.cap, w2.cap);
-        c.w = w.p; c.w2 = w2.p;
+    // Chained: neither solve is waited for (the w / w2 swap below is a host decision on the iteration count: not with speculative applies)
+    const bool chain = !resume && !spec_apply && chain_allowed();
+    // ... except that the divergence solve keeps its waits while its iteration count is RISING (the impact: 2, 4, 14, 18, 30, 44
+    // iterations in consecutive steps): every such step's batch would fall short, and a broken chain costs more than the wait it was
+    // meant to save (the gated kernels behind it, a publication, the continuation).  The chain then starts behind it.
+    const bool chain_div = chain && !(last_iters[0] > prev_iters[0]);
+    StepCtx cg = c;   // the context of everything BEHIND the first chained solve: gated
+    if (chain) cg.gate = &d_rb.p->chain_ok;
+    const StepCtx& ca = chain_div ? cg : c;  // ... which the kernels between the two solves are only when the first one is chained
+    auto div_eval = [&](const StepCtx& cc, int it) {
+        if (it == 0 && fused_first_divergence) return;  // (k_density_alpha_div_p3 wrote kappa and the error partials already)
+        evaluate_split(cc, it, [&](const StepCtx& cs, hipStream_t s) { launch_divergence(cs, lds, s); });
+    };
+    auto div_apply = [&](const StepCtx& cc, int) {
+        // decomposed runs: kappa of the inner ghost plane was computed here from refreshed w — the applies of the
+        // owned particles read nothing else, so only w travels, once per iteration
+        launch_divergence_apply(cc, lds, inv_dt_lag, stream);
+        if (comm) refresh_f4(w.p);
+    };
+    const float div_tol = prm.max_divergence_error * inv_dt_prev * 0.01f;
+    SolveResult rd{0u, 0.0f};
+    if (resume <= 1) {
+        rd = run_solve(c, 0, div_tol, prm.min_divergence_iter, prm.max_divergence_iter, 0u, div_eval, div_apply, spec_apply, chain_div ? 1 : 0,
+                       resume == 1 ? chain_batch[0] : 0, chain_div);
+        if (spec_apply && (rd.iters & 1u)) {  // an odd number of committed applies: w lives in the second buffer
+            std::swap(w.p, w2.p); std::swap(w.cap, w2.cap);
+            c.w = w.p; c.w2 = w2.p; cg.w = w.p; cg.w2 = w2.p;
+        }
+        if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[4], stream));  // :501
+        st.n_divergence_iters = (int32_t)rd.iters;
+        st.divergence_error = rd.err;
+        launch_finish_divergence(ca, g[0], g[1], g[2], acc_user, stream);  // update_velocities + dv = 0 + gravity
+        run_forces(ca);
     }
-    if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[4], stream));  // :501
-    st.n_divergence_iters = (int32_t)rd.iters;
-    st.divergence_error = rd.err;
-    launch_finish_divergence(c, g[0], g[1], g[2], acc_user, stream);  // update_velocities + dv = 0 + gravity
-    run_forces(c);
     // timestep.advance (:702): dt := total step (or, opted in, the CFL substep), inv_dt := 1/dt
     if (cfl_mode) dt = choose_substep(c);
     const float inv_dt = (dt == 0.0f) ? 0.0f : 1.0f / dt;
-    launch_integrate(c, dt, stream);
-    if (comm) refresh_f4(w.p);
+    if (resume <= 1) {
+        launch_integrate(ca, dt, stream);
+        if (comm) refresh_f4(w.p);
+    }
     // pressure_solve (:432-464)
     const SolveResult rp = run_solve(
-        c, 1, prm.max_density_error, prm.min_pressure_iter, prm.max_pressure_iter, 0u,
+        cg, 1, prm.max_density_error, prm.min_pressure_iter, prm.max_pressure_iter, 0u,
         [&](const StepCtx& cc, int it) { evaluate_split(cc, it, [&](const StepCtx& cs, hipStream_t s) { launch_pred_density(cs, lds, dt, s); }); },
         [&](const StepCtx& cc, int) {
             launch_pressure_apply(cc, lds, inv_dt, stream);
             if (comm) refresh_f4(w.p);
-        });
+        }, false, chain ? 2 : 0, resume == 2 ? chain_batch[1] : 0, chain && !chain_div);
     st.n_pressure_iters = (int32_t)rp.iters;
     st.density_error = rp.err;
-    launch_update_positions(c, dt, bbox_partials.p, d_rb.p->bbox, stream);
+    launch_update_positions(cg, dt, bbox_partials.p, d_rb.p->bbox, stream);
     dt_prev = dt;
     inv_dt_prev = inv_dt;
+    chain_pending = chain;
+    chain_div_pending = chain_div;
 }
 
 // IISPHSolver::step (iisph_solver.rs:643-711)
@@ -1220,8 +1298,10 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     st.nparticles = n;
     {   // self.counters.reset() (liquid_world.rs:73); the pass counters of this implementation are cumulative
         const uint64_t sp = counters.speculative_passes, dp = counters.discarded_passes;
+        const uint64_t keep4[4] = {counters.chained_passes, counters.chain_breaks, counters.pregrid_adopted, counters.pregrid_dropped};
         counters = SalvaHipCounters{};
         counters.speculative_passes = sp; counters.discarded_passes = dp;
+        counters.chained_passes = keep4[0]; counters.chain_breaks = keep4[1]; counters.pregrid_adopted = keep4[2]; counters.pregrid_dropped = keep4[3];
     }
     sticky.clear();  // init_with_fluids runs at the top of every step, substeps or not (liquid_world.rs:76)
     // TimestepManager::is_done (timestep_manager.rs:56-58): no substep at all for dt <= eps
@@ -1267,11 +1347,62 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     return SALVA_HIP_OK;
 }
 
+// The grid part of the NEXT step, behind this step's end-of-step publication (world.h PreGrid): the same launches World::substep
+// makes at its start — cell keys + counts, the counting sort by cell, the non-empty tiles, the per-tile counts, their scan, the
+// publication of the totals — on the positions this step leaves behind, for the grid this step ran on, into the OTHER set of
+// tables, every kernel gated by Readback::pre_ok.
+void World::pre_enqueue_grid(uint32_t nslots_bound) {
+    GridTabs& T = gtab[gsel ^ 1];
+    const size_t ncf = gf.ncells();
+    const uint32_t ntiles = (uint32_t)gf.ntiles();
+    const uint32_t* gate = &d_rb.p->pre_ok;
+    T.cell_start_f.ensure(ncf + 1, stream, false, 1.5f);
+    T.cell_rank.ensure(n, stream, false, 1.1f);
+    T.tile_flags.ensure((size_t)ntiles + 1, stream, false, 1.5f);
+    T.tile_rank.ensure((size_t)ntiles + 1, stream, false, 1.5f);
+    T.tile_ids.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
+    T.slot_desc.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
+    T.tile_cnt.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
+    T.tile_off.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
+    pre.check_mass = !(mass_known && mass_uniform == 0.0f);
+    SALVA_HIP_CHECK(hipMemsetAsync(T.cell_start_f.p, 0, (ncf + 1) * sizeof(uint32_t), stream));
+    launch_cell_keys(posm[cur].p, n, sc.h, gf.device(nullptr), T.keys[0].p, T.idx[0].p, d_flags.p, pre.check_mass ? mass_slots.p : nullptr,
+                     T.cell_start_f.p, T.cell_rank.p, stream, gate);
+    {
+        const size_t tb = cell_sort_temp_bytes((uint32_t)ncf);
+        ensure_cub_temp(tb);
+        cell_sort(cub_temp.p, tb, n, (uint32_t)ncf, T.keys[0].p, T.cell_rank.p, T.cell_start_f.p, T.keys[1].p, T.idx[0].p, T.idx[1].p, stream, gate);
+    }
+    {
+        const size_t tb = std::max(scan_tiles_temp_bytes(nslots_bound + 1), scan_temp_bytes(ntiles + 1));
+        ensure_cub_temp(tb);
+        launch_tile_slots(T.cell_start_f.p, ntiles, T.tile_flags.p, T.tile_rank.p, T.tile_ids.p, cub_temp.p, tb, stream, gate);
+        StepCtx cp = make_ctx();
+        cp.gf = gf.device(T.cell_start_f.p);
+        cp.tile_off = T.tile_off.p; cp.tile_ids = T.tile_ids.p; cp.tile_rank = T.tile_rank.p; cp.slot_desc = T.slot_desc.p;
+        cp.gate = gate;
+        launch_tile_count(cp, nslots_bound, T.tile_cnt.p, T.slot_desc.p, stream);
+        scan_tiles(cub_temp.p, tb, T.tile_cnt.p, T.tile_off.p, nslots_bound + 1, stream);
+    }
+    pre.seq = publish_enqueue(T.tile_off.p + nslots_bound, false, false, nullptr, gate);
+    pre.n = n; pre.ncf = ncf; pre.ntiles = ntiles; pre.nslots_bound = nslots_bound; pre.gf = gf;
+    pre.valid = true;
+}
+// The next step could not use it.  If its launches ran (the gate was open) they have raised flags and mass marks that belong to no step.
+void World::pre_drop() {
+    ++pre_dropped; ++counters.pregrid_dropped;
+    if (!h_rb->pre_ok) return;
+    SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));
+    SALVA_HIP_CHECK(hipMemsetAsync(mass_slots.p, 0, MASS_SLOTS * sizeof(uint32_t), stream));
+}
+
 // One substep: the body of the `while` of LiquidWorld::step_with_coupling (liquid_world.rs:85-147).  `dt` comes in as the step's
 // total length and goes out as the substep the solver advanced by.
 int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     const bool timers = prm.enable_timers != 0;
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[0], stream));
+    // (what decides below whether the grid part the previous step enqueued for this one still describes the world)
+    const bool world_touched = tables_dirty || !sorted_valid || !bbox_known || b_dirty;
     upload_tables();
     // (the end-of-step publication of the previous step left the flags clear; anything else — the first step, a step that threw —
     // clears them here)
@@ -1343,14 +1474,23 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     // only the cell table and one flag per tile are dense over the bounding box; every other per-tile table is compact
     // over the non-empty tiles ("slots"), of which there are at most min(ntiles, n)
     const uint32_t nslots_bound = (uint32_t)std::min<uint64_t>(ntiles, n);
-    cell_start_f.ensure(ncf + 1, stream, false, 1.5f);
-    tile_flags.ensure((size_t)ntiles + 1, stream, false, 1.5f);
-    tile_rank.ensure((size_t)ntiles + 1, stream, false, 1.5f);
-    tile_ids.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
-    slot_desc.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
+    // ---- the grid part of this step may be on the device already (world.h PreGrid): adopt the other set of tables, or drop it
+    bool adopted = false;
+    if (pre.valid) {
+        pre.valid = false;
+        adopted = h_rb->pre_ok && !world_touched && !timers && !comm && pre.n == n && pre.ncf == ncf && pre.ntiles == ntiles &&
+                  pre.nslots_bound == nslots_bound && memcmp(&pre.gf, &gf, sizeof(GridDims)) == 0;
+        if (adopted) { gsel ^= 1; ++pre_adopted; ++counters.pregrid_adopted; }
+        else pre_drop();
+    }
+    G().cell_start_f.ensure(ncf + 1, stream, false, 1.5f);
+    G().tile_flags.ensure((size_t)ntiles + 1, stream, false, 1.5f);
+    G().tile_rank.ensure((size_t)ntiles + 1, stream, false, 1.5f);
+    G().tile_ids.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
+    G().slot_desc.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
     slot_info.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
-    tile_cnt.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
-    tile_off.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
+    G().tile_cnt.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
+    G().tile_off.ensure((size_t)nslots_bound + 1, stream, false, 1.5f);
     d_maxhalo.ensure(4);
     partials.ensure((size_t)std::max<uint32_t>(nslots_bound, 1u) * std::max<size_t>(fluids.size(), 1), stream, false, 1.5f);
     // every tile wastes less than one 64-particle slice
@@ -1400,30 +1540,33 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     memcpy(bbox_pre, h_rb->bbox, sizeof(bbox_pre));
     const float dt_prev0 = dt_prev, inv_dt_prev0 = inv_dt_prev;
     const int cur0 = cur;
-    uint32_t last_iters0[NUM_SOLVES];
+    uint32_t last_iters0[NUM_SOLVES], prev_iters0[NUM_SOLVES];
     memcpy(last_iters0, last_iters, sizeof(last_iters0));
+    memcpy(prev_iters0, prev_iters, sizeof(prev_iters0));
     StepCtx c{};
     for (int attempt = 0;; ++attempt) {
     bool spec = can_speculate && attempt == 0;
+    chain_pending = false;
     const bool defer_lists = can_redo && !defer_off && attempt == 0 && lists_checked;
     if (attempt > 0) SALVA_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), stream));  // (whatever the discarded pass flagged)
+    const bool have_grid = adopted && attempt == 0;  // keys, sort, tile tables and the totals publication are enqueued already
+    // (a scene known to hold different masses — two fluids of different density0 — is not asked again until the host edits the
+    // particles: every wave of the lighter fluid would raise a flag, 71 us per launch at 2 x 10^6 particles)
+    check_mass = have_grid ? pre.check_mass : !(mass_known && mass_uniform == 0.0f);
     // ---- grid: keys -> radix sort -> reorder -> cell table   (hgrid.clear + insert_fluids_to_grid, liquid_world.rs:90-91)
-    {
+    if (!have_grid) {
         TileGrid gv = gf.device(nullptr);
-        // (a scene known to hold different masses — two fluids of different density0 — is not asked again until the host edits the
-        // particles: every wave of the lighter fluid would raise a flag, 71 us per launch at 2 x 10^6 particles)
-        check_mass = !(mass_known && mass_uniform == 0.0f);
         // The sort is a counting sort by cell (grid.hip cell_sort: same result as the radix sort it replaced, bit for bit) while the
         // cell table is not much larger than the particle set — it costs a memset and a scan of that table, where the radix sort
         // with k_cell_start writes it once: a bounding box blown up by a few strays (4 x 10^8 cells around 25 k particles) keeps
         // the radix sort.  SALVA_HIP_RADIX_SORT=1 / 0 forces one or the other.
         const bool counting = ncf + 1 < 0x7fffffffull && (sort_mode == 0 || (sort_mode < 0 && ncf <= 16ull * n + (1ull << 20)));
         if (counting) {
-            cell_rank.ensure(n, stream, false, 1.1f);
-            SALVA_HIP_CHECK(hipMemsetAsync(cell_start_f.p, 0, (ncf + 1) * sizeof(uint32_t), stream));
+            G().cell_rank.ensure(n, stream, false, 1.1f);
+            SALVA_HIP_CHECK(hipMemsetAsync(G().cell_start_f.p, 0, (ncf + 1) * sizeof(uint32_t), stream));
         }
-        launch_cell_keys(posm[cur].p, n, sc.h, gv, keys[0].p, idx[0].p, d_flags.p, check_mass ? mass_slots.p : nullptr,
-                         counting ? cell_start_f.p : nullptr, counting ? cell_rank.p : nullptr, stream);
+        launch_cell_keys(posm[cur].p, n, sc.h, gv, G().keys[0].p, G().idx[0].p, d_flags.p, check_mass ? mass_slots.p : nullptr,
+                         counting ? G().cell_start_f.p : nullptr, counting ? G().cell_rank.p : nullptr, stream);
         if (has_dyn) {  // coupling.update_boundaries (liquid_world.rs:94-103): may push particles, cells stay
             // (host clock: the pass ends with a read-back of the emitted count, so the stream is drained when it returns)
             if (timers) wait_stream();
@@ -1434,19 +1577,19 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         if (counting) {
             const size_t tb = cell_sort_temp_bytes((uint32_t)ncf);
             ensure_cub_temp(tb);
-            cell_sort(cub_temp.p, tb, n, (uint32_t)ncf, keys[0].p, cell_rank.p, cell_start_f.p, keys[1].p, idx[0].p, idx[1].p, stream);
+            cell_sort(cub_temp.p, tb, n, (uint32_t)ncf, G().keys[0].p, G().cell_rank.p, G().cell_start_f.p, G().keys[1].p, G().idx[0].p, G().idx[1].p, stream);
         } else {
             const int end_bit = bits_for(ncf);
             const size_t tb = sort_pairs_temp_bytes(n, end_bit);
             ensure_cub_temp(tb);
-            sort_pairs(cub_temp.p, tb, keys[0].p, keys[1].p, idx[0].p, idx[1].p, n, end_bit, stream);
-            launch_cell_start(keys[1].p, n, (uint32_t)ncf, cell_start_f.p, stream);
+            sort_pairs(cub_temp.p, tb, G().keys[0].p, G().keys[1].p, G().idx[0].p, G().idx[1].p, n, end_bit, stream);
+            launch_cell_start(G().keys[1].p, n, (uint32_t)ncf, G().cell_start_f.p, stream);
         }
     }
     // The particle arrays are permuted into the sorted order AFTER the tile tables have been counted: those need the cell table
     // only, and the host then waits for their totals while the GPU moves the 136 bytes per particle of the reorder.
     auto reorder = [&]() {
-        launch_reorder_fluid(n, idx[1].p, arrays(cur), arrays(cur ^ 1), w.p, stream);
+        launch_reorder_fluid(n, G().idx[1].p, arrays(cur), arrays(cur ^ 1), w.p, stream);
         cur ^= 1;
         if (timers) SALVA_HIP_CHECK(hipEventRecord(evc[0], stream));
         if (acc_user && !comm) launch_gather_f4(n, perm[cur].p, st_acc.p, acc.p, stream);
@@ -1464,12 +1607,14 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     {
         const size_t tb = std::max(scan_tiles_temp_bytes(nslots_bound + 1), scan_temp_bytes(ntiles + 1));
         ensure_cub_temp(tb);
-        launch_tile_slots(cell_start_f.p, ntiles, tile_flags.p, tile_rank.p, tile_ids.p, cub_temp.p, tb, stream);
+        if (!have_grid) {
+        launch_tile_slots(G().cell_start_f.p, ntiles, G().tile_flags.p, G().tile_rank.p, G().tile_ids.p, cub_temp.p, tb, stream);
         // (k_tile_count zeroes the entries of its surplus workgroups and the scan's extra element itself: no memset —
         // unless there is no workgroup at all, a rank that holds no particle)
-        if (nslots_bound == 0) SALVA_HIP_CHECK(hipMemsetAsync(tile_cnt.p, 0, sizeof(TileAcc), stream));
-        launch_tile_count(c, nslots_bound, tile_cnt.p, slot_desc.p, stream);
-        scan_tiles(cub_temp.p, tb, tile_cnt.p, tile_off.p, nslots_bound + 1, stream);
+        if (nslots_bound == 0) SALVA_HIP_CHECK(hipMemsetAsync(G().tile_cnt.p, 0, sizeof(TileAcc), stream));
+        launch_tile_count(c, nslots_bound, G().tile_cnt.p, G().slot_desc.p, stream);
+        scan_tiles(cub_temp.p, tb, G().tile_cnt.p, G().tile_off.p, nslots_bound + 1, stream);
+        }
         if (spec) {
             // previous totals + margin; the LDS must hold the padded halo (else: no speculation this step)
             const TileAcc& l = pred_tt;
@@ -1484,7 +1629,7 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             if (probe.bytes(52, 32, 6) > 160u * 1024u || tt.max_s >= 65536u || tt.max_sb >= 65536u) spec = false;
         }
         if (!spec) {
-            const uint32_t seq = publish_enqueue(tile_off.p + nslots_bound, false, false);
+            const uint32_t seq = have_grid ? pre.seq : publish_enqueue(G().tile_off.p + nslots_bound, false, false);
             reorder();
             publish_wait(seq, true, false, false);
             tt = h_rb->tile_total;
@@ -1618,7 +1763,21 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     // ---- end of step: next bbox + flags (+ in a speculative pass: the true table totals and list statistics)
     static_assert(offsetof(Readback, bbox) == offsetof(Readback, flags) + sizeof(uint32_t), "flags and bbox travel in one copy");
     if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[2], stream));
-    publish_and_wait(spec ? tile_off.p + nslots_bound : nullptr, spec || defer_lists, true);
+    {
+        // The next step's grid part rides behind this step's publication when the cell box has been standing still (world.h PreGrid):
+        // the device compares the box this step's position update found with the one this step ran on, and opens the gate if equal.
+        bool has_custom_f = false;
+        for (auto& f : fluids) for (auto& d : f.forces) has_custom_f |= d.kind == SALVA_HIP_FORCE_CUSTOM;
+        const bool counting_now = ncf + 1 < 0x7fffffffull && (sort_mode == 0 || (sort_mode < 0 && ncf <= 16ull * n + (1ull << 20)));
+        const bool stable = bbox_used_valid && memcmp(bbox_used_last, bbox_pre, sizeof(bbox_pre)) == 0;
+        const bool want_pre = !pre_off && attempt == 0 && !spec && !comm && !timers && !has_dyn && !has_custom_f && !cfl_mode && counting_now && stable &&
+                              n > 0 && nslots_bound > 0;
+        memcpy(bbox_used_last, bbox_pre, sizeof(bbox_pre)); bbox_used_valid = true;
+        PrePub pp{want_pre ? 1 : 0, chain_pending ? 1 : 0, {bbox_pre[0], bbox_pre[1], bbox_pre[2], bbox_pre[3], bbox_pre[4], bbox_pre[5]}};
+        const uint32_t seq_end = publish_enqueue(spec ? G().tile_off.p + nslots_bound : nullptr, spec || defer_lists, true, &pp);
+        if (want_pre) pre_enqueue_grid(nslots_bound);
+        publish_wait(seq_end, spec, spec || defer_lists, true);
+    }
     flags_clean = true;  // (k_publish_readback cleared them behind the copy)
     if (comm && prm.enable_timers) dist_time_fold();  // (the stream has drained up to the publication: every pair has completed)
     if (defer_lists && !spec) {
@@ -1628,9 +1787,10 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             ++counters.discarded_passes;
             cur = cur0; dt_prev = dt_prev0; inv_dt_prev = inv_dt_prev0;
             memcpy(h_rb->bbox, bbox_pre, sizeof(bbox_pre));
-            memcpy(last_iters, last_iters0, sizeof(last_iters0));
+            memcpy(last_iters, last_iters0, sizeof(last_iters0)); memcpy(prev_iters, prev_iters0, sizeof(prev_iters0));
             if (need_ff > cap_ff) cap_ff = (need_ff + need_ff / 4 + 4u) & ~3u;
             if (need_fb > cap_fb) cap_fb = (need_fb + need_fb / 4 + 4u) & ~3u;
+            if (pre.valid) { pre.valid = false; pre_drop(); }
             continue;
         }
     }
@@ -1644,13 +1804,44 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             ++spec_misses; ++counters.speculative_passes; ++counters.discarded_passes;
             cur = cur0; dt_prev = dt_prev0; inv_dt_prev = inv_dt_prev0;
             memcpy(h_rb->bbox, bbox_pre, sizeof(bbox_pre));
-            memcpy(last_iters, last_iters0, sizeof(last_iters0));
+            memcpy(last_iters, last_iters0, sizeof(last_iters0)); memcpy(prev_iters, prev_iters0, sizeof(prev_iters0));
             if (need_ff > cap_ff) cap_ff = (need_ff + need_ff / 4 + 4u) & ~3u;
             if (need_fb > cap_fb) cap_fb = (need_fb + need_fb / 4 + 4u) & ~3u;
+            if (pre.valid) { pre.valid = false; pre_drop(); }
             continue;
         }
     }
     if (spec) ++counters.speculative_passes;
+    if (chain_pending) {
+        // A chained step (World::dfsph_solve): the publication says whether both solves converged within the batches they were given.
+        chain_pending = false;
+        auto adopt = [&](int which) {  // the outcome of a solve nobody waited for
+            prev_iters[which] = last_iters[which];
+            last_iters[which] = h_rb->solve[which][1];
+            h_ctl[which].done = h_rb->solve[which][0]; h_ctl[which].iters = h_rb->solve[which][1];
+            memcpy(&h_ctl[which].err, &h_rb->solve[which][2], sizeof(float));
+        };
+        uint32_t stage = h_rb->chain_ok ? 0u : h_rb->chain_stage;
+        if (stage == 0u) {
+            if (chain_div_pending) adopt(0);
+            adopt(1);
+            ++chain_steps; ++counters.chained_passes;
+        } else {
+            // one of them fell short: every kernel behind it returned at once.  Continue that solve the classic way (batches with a
+            // wait each) and run what follows it; the flags raised so far were published (and cleared) by the first publication.
+            if (stage != 1u && stage != 2u) throw HipError(SALVA_HIP_E_HIP, "internal error: a chained step broke at an unknown stage");
+            ++chain_breaks; ++counters.chain_breaks;
+            pre.valid = false;  // (its gate stayed shut: Readback::pre_ok needs the chain)
+            const uint32_t flags0 = h_rb->flags;
+            if (stage == 2u && chain_div_pending) adopt(0);
+            dfsph_solve(c, dt, g, st, (int)stage);
+            if (timers) SALVA_HIP_CHECK(hipEventRecord(ev[2], stream));  // (the solver's part of the step ends here, not at the first publication)
+            publish_and_wait(nullptr, false, true);
+            h_rb->flags |= flags0;
+        }
+        if (stage != 1u) { st.n_divergence_iters = (int32_t)h_ctl[0].iters; st.divergence_error = h_ctl[0].err; }
+        if (stage == 0u) { st.n_pressure_iters = (int32_t)h_ctl[1].iters; st.density_error = h_ctl[1].err; }
+    }
     pred_tt = h_rb->tile_total; pred_n = n; pred_valid = true;
     lists_checked = true;  // (every path to here has compared the longest lists with the capacity)
     break;
@@ -1983,7 +2174,7 @@ uint64_t World::get_fluid_contacts(uint32_t slot, int boundary, uint64_t* offset
     SALVA_HIP_CHECK(hipMemcpyAsync(d_moff.p, moff.data(), moff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(d_boff.p, boff.data(), boff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     flags_clean = false;
-    launch_export_contacts(last_ctx, keys[1].p, slot, boundary, d_offs.p, d_moff.p, d_boff.p, d_jm.p, d_j.p, stream);
+    launch_export_contacts(last_ctx, G().keys[1].p, slot, boundary, d_offs.p, d_moff.p, d_boff.p, d_jm.p, d_j.p, stream);
     SALVA_HIP_CHECK(hipMemcpyAsync(j_model, d_jm.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(j, d_j.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipStreamSynchronize(stream));
@@ -2046,7 +2237,7 @@ uint64_t World::get_local_contacts(int boundary, uint64_t* offsets, uint32_t* j_
     SALVA_HIP_CHECK(hipMemcpyAsync(d_offs.p, offs.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(d_boff.p, boff.data(), boff.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     flags_clean = false;
-    launch_export_contacts_local(last_ctx, keys[1].p, boundary, d_offs.p, d_boff.p, d_jm.p, d_j.p, stream);
+    launch_export_contacts_local(last_ctx, G().keys[1].p, boundary, d_offs.p, d_boff.p, d_jm.p, d_j.p, stream);
     SALVA_HIP_CHECK(hipMemcpyAsync(j_model, d_jm.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipMemcpyAsync(j, d_j.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SALVA_HIP_CHECK(hipStreamSynchronize(stream));
@@ -2450,7 +2641,7 @@ void World::resize_boundary_slot(uint32_t slot, uint64_t nn) {
 // The DynamicContactSampling arm of ColliderCouplingManager::update_boundaries (fluids_pipeline.rs:193-259, :262) for every
 // boundary registered with it, in slot order, at the reference's point of the substep: the fluid cell keys exist (grid
 // insertion, liquid_world.rs:90-91), the boundaries are not in the grid yet (:106).  Works on the sorted working set of the
-// previous step (posm[cur] / vel[cur], keys[0] = this step's keys in that order).
+// previous step (posm[cur] / vel[cur], G().keys[0] = this step's keys in that order).
 void World::run_dynamic_sampling() {
     TileGrid gv = gf.device(nullptr);
     for (uint32_t slot = 0; slot < bounds.size(); ++slot) {
@@ -2472,7 +2663,7 @@ void World::run_dynamic_sampling() {
             const DcsParams prm_d = dcs_params_host(mins, maxs, sc.h, prm.particle_radius, dt_prev);
             dcs_cand.ensure(n, stream, false, 1.1f); dcs_out.ensure(n, stream, false, 1.1f); dcs_flag.ensure(n, stream, false, 1.1f);
             dcs_num.ensure(1);
-            launch_dcs_gather(n, posm[cur].p, vel[cur].p, keys[0].p, gv, prm_d, dcs_cand.p, dcs_flag.p, stream);
+            launch_dcs_gather(n, posm[cur].p, vel[cur].p, G().keys[0].p, gv, prm_d, dcs_cand.p, dcs_flag.p, stream);
             const size_t tb = select_flagged_temp_bytes(n);
             ensure_cub_temp(tb);
             select_flagged_f4(cub_temp.p, tb, dcs_cand.p, dcs_flag.p, dcs_out.p, dcs_num.p, n, stream);
@@ -2502,7 +2693,7 @@ void World::run_dynamic_sampling() {
             const DcsParams prm_d = dcs_params(b.dyn_shape, b.dyn_pose, sc.h, prm.particle_radius, dt_prev);
             dcs_cand.ensure(n, stream, false, 1.1f); dcs_out.ensure(n, stream, false, 1.1f); dcs_flag.ensure(n, stream, false, 1.1f);
             dcs_num.ensure(1);
-            launch_dcs_project(n, posm[cur].p, vel[cur].p, keys[0].p, perm[cur].p, comm ? gtag[cur].p : nullptr, gv, prm_d, dcs_cand.p,
+            launch_dcs_project(n, posm[cur].p, vel[cur].p, G().keys[0].p, perm[cur].p, comm ? gtag[cur].p : nullptr, gv, prm_d, dcs_cand.p,
                                dcs_flag.p, stream);
             const size_t tb = select_flagged_temp_bytes(n);
             ensure_cub_temp(tb);
@@ -2689,12 +2880,13 @@ uint64_t World::device_bytes() const {
     add(st_pos.bytes()); add(st_vel.bytes()); add(st_dv.bytes()); add(st_acc.bytes()); add(st_model.bytes());
     for (int k = 0; k < 2; ++k) {
         add(posm[k].bytes()); add(vel[k].bytes()); add(dv[k].bytes()); add(model[k].bytes()); add(perm[k].bytes());
-        add(keys[k].bytes()); add(idx[k].bytes()); add(bkeys[k].bytes()); add(bidx[k].bytes());
+        for (const GridTabs& t : gtab) { add(t.keys[k].bytes()); add(t.idx[k].bytes()); }
+        add(bkeys[k].bytes()); add(bidx[k].bytes());
     }
     add(acc.bytes()); add(w.bytes()); add(normal.bytes()); add(dii.bytes()); add(dijpj.bytes()); add(iisph_q.bytes()); add(iisph_pr.bytes()); add(posmr.bytes()); add(w2.bytes());
     add(rho.bytes()); add(alpha.bytes()); add(kappa.bytes()); add(kappa2.bytes()); add(rho_star.bytes()); add(aii.bytes());
     add(visc_beta.bytes()); add(visc_target.bytes()); add(visc_u0.bytes()); add(visc_u1.bytes()); add(visc_va.bytes()); add(he_colors.bytes()); add(he_gradcs.bytes());
-    add(nff.bytes()); add(nfb.bytes()); add(cell_start_f.bytes()); add(halo_src.bytes()); add(bhalo_src.bytes());
+    add(nff.bytes()); add(nfb.bytes()); add(gtab[0].cell_start_f.bytes()); add(gtab[1].cell_start_f.bytes()); add(halo_src.bytes()); add(bhalo_src.bytes());
     add(nbr_ff.bytes()); add(nbr_fb.bytes()); add(slice_near.bytes()); add(cub_temp.bytes()); add(scratch_f.bytes());
     add(scratch_f4.bytes()); add(bst_pos.bytes()); add(bst_vel.bytes()); add(bposv.bytes()); add(bvel.bytes());
     add(bforce.bytes()); add(bperm.bytes()); add(cell_start_b.bytes()); add(partials.bytes());
@@ -2751,7 +2943,7 @@ float World::time_kernel(int kernel, int reps) {
             case 4:  // rebuilds the lists on the tables of the last step.  The positions have moved since those were built, so every
                      // particle's cell is taken from its sorted key (as after a DynamicContactSampling push-out): without that a
                      // particle that left its cell indexes the tile's cell table out of range and the kernel never returns.
-                cd.stale_keys = keys[1].p;
+                cd.stale_keys = G().keys[1].p;
                 launch_nbr_build(cd, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff, nullptr, stream);
                 break;
 #ifdef SALVA_HIP_DIAG

@@ -119,7 +119,7 @@ void World::ensure_particle_capacity(size_t cap) {
     for (int k = 0; k < 2; ++k) {
         posm[k].ensure(cap, stream, true, slack); vel[k].ensure(cap, stream, true, slack); dv[k].ensure(cap, stream, true, slack);
         model[k].ensure(cap, stream, true, slack); perm[k].ensure(cap, stream, true, slack);
-        keys[k].ensure(cap, stream, false, slack); idx[k].ensure(cap, stream, false, slack);
+        for (GridTabs& t : gtab) { t.keys[k].ensure(cap, stream, false, slack); t.idx[k].ensure(cap, stream, false, slack); }
         if (comm) gtag[k].ensure(cap, stream, true, slack);
     }
 }

@@ -565,6 +565,10 @@ class Counters:
     solver: SolverCounters = field(default_factory=SolverCounters)
     speculative_passes: int = 0
     discarded_passes: int = 0
+    chained_passes: int = 0    # passes enqueued without a host wait between their solves (include/salva_hip.h SalvaHipCounters)
+    chain_breaks: int = 0
+    pregrid_adopted: int = 0   # steps whose grid part the previous step had enqueued already
+    pregrid_dropped: int = 0
     ncontacts: int = 0
     n_divergence_iters: int = 0
     n_pressure_iters: int = 0
@@ -916,6 +920,8 @@ class LiquidWorld:
                                               t.cd.neighborhood_search_time, t.cd.contact_sorting_time)
             c.solver = SolverCounters(t.solver.non_pressure_resolution_time, t.solver.pressure_resolution_time)
             c.speculative_passes, c.discarded_passes = int(t.speculative_passes), int(t.discarded_passes)
+            c.chained_passes, c.chain_breaks = int(t.chained_passes), int(t.chain_breaks)
+            c.pregrid_adopted, c.pregrid_dropped = int(t.pregrid_adopted), int(t.pregrid_dropped)
         return self._counters
 
     # ---- liquid_world.rs:62-158
