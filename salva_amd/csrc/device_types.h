@@ -82,6 +82,9 @@ struct alignas(16) SolveCtl {
 };
 static_assert(sizeof(SolveCtl) == 32, "SolveCtl: two 16-byte halves");
 
+// per-tile list statistics of k_nbr_tile (grid.hip), folded by k_list_stats or by the end-of-step publication
+struct TileListStats { uint32_t sum_ff, sum_fb, max_ff, max_fb, own_ff, own_fb; };  // own_*: lists of particles this rank OWNS (no ghosts)
+
 // what the end-of-step publication needs to decide Readback::pre_ok
 struct PrePub { int32_t on, chained; int32_t bbox[6]; };
 

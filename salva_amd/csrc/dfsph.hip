@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_positions(StepCtx c, float dt,
 void launch_update_positions(const StepCtx& c, float dt, int32_t* bbox_partials, int32_t* bbox6, hipStream_t s) {
     if (!c.n) return;
     k_update_positions<<<num_blocks(c.n), BLOCK, 0, s>>>(c, dt, bbox_partials);
-    launch_bbox_final(bbox_partials, num_blocks(c.n), bbox6, s, c.gate);
+    if (bbox6) launch_bbox_final(bbox_partials, num_blocks(c.n), bbox6, s, c.gate);  // (nullptr: the end-of-step publication folds them)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1057,13 +1057,15 @@ constexpr int FINALIZE_THREADS = 1024;
 __global__ __launch_bounds__(FINALIZE_THREADS) void k_finalize_error(const float* __restrict__ partials, unsigned nblocks,
                                                                      uint32_t nmodels, const uint32_t* __restrict__ model_counts,
                                                                      SolveCtl* ctl, SolveCtl* pub, const uint32_t* gate, uint32_t* close,
-                                                                     uint32_t close_stage) {
+                                                                     uint32_t close_stage, uint32_t skipped) {
     __shared__ float red[FINALIZE_THREADS / WAVE];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     // chained step, the chain broke upstream (device_types.h StepCtx::gate): this test does not exist
     if (gate && gate_words_closed(gate[0], gate[1], close_stage)) return;
     const u32x4 c0 = reinterpret_cast<const u32x4*>(ctl)[0], c1 = reinterpret_cast<const u32x4*>(ctl)[1];
-    const uint32_t done = c0.x, iters = c0.y, seq = c0.w + 1u, min_iter = c1.y, mode = c1.z;
+    // (skipped: the tests of earlier iterations that were not launched because they could not end the solve — i < min_iter, World::run_solve
+    // — count as failed ones: one apply / iteration and one tick each)
+    const uint32_t done = c0.x, iters = c0.y + skipped, seq = c0.w + 1u + skipped, min_iter = c1.y, mode = c1.z;
     const float tol = __uint_as_float(c1.x);
     if (done) {
         if (threadIdx.x == 0) { ctl->seq = seq; publish_ctl(ctl, pub, seq); }
@@ -1104,8 +1106,9 @@ __global__ __launch_bounds__(BLOCK) void k_sum_partials(const float* __restrict_
     }
 }
 __global__ void k_decide(const float* __restrict__ sums, uint32_t nmodels, const uint32_t* __restrict__ model_counts, SolveCtl* ctl,
-                         SolveCtl* pub) {
+                         SolveCtl* pub, uint32_t skipped) {
     if (threadIdx.x != 0) return;
+    if (skipped) { ctl->iters += skipped; ctl->seq += skipped; }  // (tests that were not launched: k_finalize_error)
     if (!ctl->done) {
         float best = 0.0f;
         for (uint32_t m = 0; m < nmodels; ++m)
@@ -1127,12 +1130,13 @@ __global__ void k_decide(const float* __restrict__ sums, uint32_t nmodels, const
 void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmodels, const SolveCtl* ctl, float* sums, hipStream_t s) {
     k_sum_partials<<<1, BLOCK, 0, s>>>(partials, nblocks, nmodels, ctl, sums);
 }
-void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, SolveCtl* pub, hipStream_t s) {
-    k_decide<<<1, 64, 0, s>>>(sums, nmodels, model_counts, ctl, pub);
+void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, SolveCtl* pub, hipStream_t s, uint32_t skipped) {
+    k_decide<<<1, 64, 0, s>>>(sums, nmodels, model_counts, ctl, pub, skipped);
 }
 void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmodels, const uint32_t* model_counts,
-                           SolveCtl* ctl, SolveCtl* pub, hipStream_t s, const uint32_t* gate, uint32_t* close, uint32_t close_stage) {
-    k_finalize_error<<<1, FINALIZE_THREADS, 0, s>>>(partials, nblocks, nmodels, model_counts, ctl, pub, gate, close, close_stage);
+                           SolveCtl* ctl, SolveCtl* pub, hipStream_t s, const uint32_t* gate, uint32_t* close, uint32_t close_stage,
+                           uint32_t skipped) {
+    k_finalize_error<<<1, FINALIZE_THREADS, 0, s>>>(partials, nblocks, nmodels, model_counts, ctl, pub, gate, close, close_stage, skipped);
 }
 
 // ------------------------------------------------------------------------------------------------ boundary volumes

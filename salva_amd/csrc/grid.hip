@@ -572,7 +572,6 @@ void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, 
 // ones to the particle's ELL row, two 16-bit slots per dword: fluid-fluid contacts (contacts.rs:347-392) and
 // fluid-boundary contacts (:329-346, :378-383).  Writes nff / nfb, and per tile {sum, max} of the list lengths
 // (the sums are counters.cd.ncontacts; the maxima tell the host whether the fixed ELL capacity was enough).
-struct TileListStats { uint32_t sum_ff, sum_fb, max_ff, max_fb, own_ff, own_fb; };  // own_*: lists of particles this rank OWNS (no ghosts)
 
 // V = 0: one candidate per iteration, nested branches on every accepted candidate (the round-1 kernel; kept as the fallback for
 //        worlds with more than 32 fluid or boundary models).
@@ -880,7 +879,8 @@ void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsi
                              2u * L.max_halo_boundary * 16u + 64u;
         SALVA_LAUNCH_TILE(k_nbr_tile<1>, c, L, lds, s, c, ts);
     }
-    k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.nlaunch, totals2, maxima2, own2);
+    // (totals2 == nullptr: the statistics are folded by the end-of-step publication, World::publish_enqueue — one launch less per step)
+    if (totals2) k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.nlaunch, totals2, maxima2, own2);
 }
 
 }  // namespace salva

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(BLOCK) void k_iisph_finish(StepCtx c, float dt, con
 void launch_iisph_finish(const StepCtx& c, float dt, const float* p, int32_t* bbox_partials, int32_t* bbox6, hipStream_t s) {
     if (!c.n) return;
     k_iisph_finish<<<num_blocks(c.n), BLOCK, 0, s>>>(c, dt, p, bbox_partials);
-    launch_bbox_final(bbox_partials, num_blocks(c.n), bbox6, s);
+    if (bbox6) launch_bbox_final(bbox_partials, num_blocks(c.n), bbox6, s);  // (nullptr: the end-of-step publication folds them)
 }
 
 }  // namespace SALVA_KNS

@@ -162,6 +162,8 @@ class World {
     // Chained steps (device_types.h StepCtx::gate, World::dfsph_solve): both solves of a DFSPH step and everything between and behind
     // them are enqueued without a wait; the end-of-step publication carries their outcome.
     bool chain_allowed() const;
+    SolveCtl pre_init1{};          // the pressure solve's initial control block, written by the divergence solve's k_init_ctl launch
+    bool pre_init1_valid = false;
     bool chain_off = false;       // SALVA_HIP_NO_CHAIN=1 (A/B, tests)
     bool chain_pending = false;   // this pass was enqueued that way and its outcome has not been read yet
     bool chain_div_pending = false;  // ... the divergence solve included (not while its iteration count is rising)
@@ -191,7 +193,8 @@ class World {
     void refresh_f32(float* field);
     void refresh_f4(float4* field);
     void ensure_particle_capacity(size_t cap);
-    void finalize_solve(SolveCtl* ctl, SolveCtl* pub);
+    void finalize_solve(SolveCtl* ctl, SolveCtl* pub, uint32_t skipped = 0);
+    bool solve_owes_apply[3] = {false, false, false};  // the apply behind a batch's last test, left to whoever continues the solve
 
     hipStream_t stream = nullptr;
     // decomposed runs: evaluate passes over interior tiles run here while the ghost exchange is in flight on `stream`
@@ -350,6 +353,10 @@ class World {
     void pre_enqueue_grid(uint32_t nslots_bound);
     void pre_drop();
     void publish_wait(uint32_t seq, bool totals, bool lists, bool end_of_step);
+    // what the next end-of-step publication folds (world.hip Epilogue): the list statistics of this pass, the position update's boxes
+    bool fold_stats = false;
+    uint32_t fold_bbox_blocks = 0;
+    const uint32_t* fold_bbox_gate = nullptr;
     void publish_and_wait(const TileAcc* totals, bool lists, bool end_of_step);
     DevBuf<SolveCtl> d_ctl;      // [0] divergence solve, [1] pressure solve, [2] viscosity solve (DFSPHViscosity)
     SolveCtl* h_ctl = nullptr;   // pinned: [0..NUM_SOLVES) read-back, [NUM_SOLVES..2 NUM_SOLVES) initial values

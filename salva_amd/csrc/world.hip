@@ -7,6 +7,7 @@
 // few scalars (convergence errors, list sizes, the next cell bounding box).
 #include "world.h"
 #include "dcs.h"
+#include "bbox.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -804,15 +805,60 @@ void World::build_boundary_grid() {
 // The per-step read-backs without a copy engine: one wave copies the few words the host is waiting for into host-mapped memory,
 // fences to system scope, then bumps the sequence word the host polls.  (A hipMemcpyAsync + event costs ~20 us of idle GPU each
 // time the host has to wait for it: tools/gap_tsv_report.py.)
-__global__ void k_publish_readback(Readback* __restrict__ src, const TileAcc* __restrict__ totals, int lists, int end_of_step,
-                                   uint32_t* mass_slots, Readback* pub_rb, volatile uint32_t* pub_seq, uint32_t seq,
-                                   const SolveCtl* __restrict__ ctl, PrePub pre, const uint32_t* gate) {
+// What an end-of-step publication folds before it publishes (round 6: one launch where k_list_stats, k_bbox_final and the publication
+// were three, each a few microseconds long with a launch gap on either side).
+struct Epilogue {
+    const TileListStats* ts; uint32_t nts; int own;   // k_nbr_tile's per-tile list statistics -> ncontacts_*, max_cnt_* (nullptr: k_list_stats ran)
+    const int32_t* bbox_partials; uint32_t nbb;        // the position update's per-block cell boxes -> bbox (nullptr: nothing to fold)
+    const uint32_t* chain_gate;                        // ... which was gated by this word (a chained step; nullptr: it ran)
+};
+__global__ __launch_bounds__(BLOCK) void k_publish_readback(Readback* __restrict__ src, const TileAcc* __restrict__ totals, int lists, int end_of_step,
+                                                            uint32_t* mass_slots, Readback* pub_rb, volatile uint32_t* pub_seq, uint32_t seq,
+                                                            const SolveCtl* __restrict__ ctl, PrePub pre, const uint32_t* gate, Epilogue ep) {
     if (gate && *gate == 0u) return;  // (the totals of a pre-enqueued grid that did not come true: nobody waits for them)
+    __shared__ unsigned long long sred[4][BLOCK / WAVE];
+    __shared__ int ired[6 * (BLOCK / WAVE)];
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
+    if (ep.ts) {  // (block-uniform) the fold of k_list_stats, grid.hip
+        unsigned long long a = 0, b = 0, oa = 0, ob = 0;
+        uint32_t ma = 0, mb = 0;
+        for (uint32_t k = threadIdx.x; k < ep.nts; k += blockDim.x) {
+            const TileListStats t = ep.ts[k];
+            a += t.sum_ff; b += t.sum_fb; oa += t.own_ff; ob += t.own_fb; ma = max(ma, t.max_ff); mb = max(mb, t.max_fb);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, WAVE); b += __shfl_xor(b, o, WAVE);
+            oa += __shfl_xor(oa, o, WAVE); ob += __shfl_xor(ob, o, WAVE);
+        }
+        ma = wave_max_u32(ma); mb = wave_max_u32(mb);
+        if (lane == 0) { sred[0][wv] = a; sred[1][wv] = b; sred[2][wv] = oa; sred[3][wv] = ob; ired[wv] = (int)ma; ired[nw + wv] = (int)mb; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long ta = 0, tb = 0, toa = 0, tob = 0; uint32_t xa = 0, xb = 0;
+            for (int k = 0; k < nw; ++k) {
+                ta += sred[0][k]; tb += sred[1][k]; toa += sred[2][k]; tob += sred[3][k];
+                xa = max(xa, (uint32_t)ired[k]); xb = max(xb, (uint32_t)ired[nw + k]);
+            }
+            src->ncontacts_ff = ta; src->ncontacts_fb = tb; src->max_cnt_ff = xa; src->max_cnt_fb = xb;
+            if (ep.own) { src->ncontacts_own_ff = toa; src->ncontacts_own_fb = tob; }
+        }
+        __syncthreads();
+    }
+    if (ep.bbox_partials && !(ep.chain_gate && gate_words_closed(ep.chain_gate[0], ep.chain_gate[1], 0u))) {  // the fold of k_bbox_final
+        int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+        for (uint32_t k = threadIdx.x; k < ep.nbb; k += blockDim.x) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], ep.bbox_partials[6 * k + a]); mx[a] = max(mx[a], ep.bbox_partials[6 * k + 3 + a]); }
+        }
+        block_bbox_store(mn, mx, ired, src->bbox);  // (ends with a barrier: thread 0 below reads what threads 0..5 stored)
+        __threadfence_block();
+    }
     uint32_t mlo = 0u, mhi = 0u;
-    if (totals) {  // (wave-uniform) did k_cell_keys see a mass other than particle 0's since the last such publication?  start the next one
+    if (totals && wv == 0) {  // did k_cell_keys see a mass other than particle 0's since the last such publication?  start the next one
         static_assert(MASS_SLOTS == WAVE, "one flag per lane of the publishing wave");
-        const uint32_t differs = wave_max_u32(mass_slots[threadIdx.x]);
-        mass_slots[threadIdx.x] = 0u;
+        const uint32_t differs = wave_max_u32(mass_slots[lane]);
+        mass_slots[lane] = 0u;
         mlo = mass_slots[MASS_SLOTS];
         mhi = differs ? ~mlo : mlo;
     }
@@ -829,11 +875,13 @@ __global__ void k_publish_readback(Readback* __restrict__ src, const TileAcc* __
         if (end_of_step) {
             pub_rb->flags = src->flags;
             src->flags = 0u;  // (the next step starts from clear flags without a memset of its own: World::flags_clean)
-            for (int a = 0; a < 6; ++a) pub_rb->bbox[a] = src->bbox[a];
+            const volatile int32_t* bb = src->bbox;  // (stored by threads 0..5 of this block a moment ago: not through a stale register)
+            int32_t box[6];
+            for (int a = 0; a < 6; ++a) { box[a] = bb[a]; pub_rb->bbox[a] = box[a]; }
             // chained steps (device_types.h StepCtx::gate): did every solve converge within its batch, and what they found
             pub_rb->chain_ok = src->chain_ok; pub_rb->chain_stage = src->chain_stage;
             uint32_t pok = (pre.on && (!pre.chained || src->chain_ok)) ? 1u : 0u;
-            for (int a = 0; a < 6; ++a) pok &= (src->bbox[a] == pre.bbox[a]) ? 1u : 0u;
+            for (int a = 0; a < 6; ++a) pok &= (box[a] == pre.bbox[a]) ? 1u : 0u;
             src->pre_ok = pok; pub_rb->pre_ok = pok;
             for (int k = 0; k < 2; ++k) {
                 pub_rb->solve[k][0] = ctl[k].done; pub_rb->solve[k][1] = ctl[k].iters;
@@ -847,8 +895,15 @@ __global__ void k_publish_readback(Readback* __restrict__ src, const TileAcc* __
 // enqueue the publication on the world's stream ...
 uint32_t World::publish_enqueue(const TileAcc* totals, bool lists, bool end_of_step, const PrePub* pre, const uint32_t* gate) {
     const uint32_t seq = ++hostpub_seq;
-    k_publish_readback<<<1, WAVE, 0, stream>>>(d_rb.p, totals, lists ? 1 : 0, end_of_step ? 1 : 0, mass_slots.p, &h_hostpub->rb, &h_hostpub->seq, seq,
-                                               d_ctl.p, pre ? *pre : PrePub{0, 0, {0, 0, 0, 0, 0, 0}}, gate);
+    Epilogue ep{nullptr, 0u, 0, nullptr, 0u, nullptr};
+    if (end_of_step) {  // what this step left for the publication to fold (World::substep sets them, one publication consumes them)
+        if (fold_stats) { ep.ts = reinterpret_cast<const TileListStats*>(tile_list_stats.p); ep.nts = nlaunch; ep.own = comm ? 1 : 0; }
+        if (fold_bbox_blocks) { ep.bbox_partials = bbox_partials.p; ep.nbb = fold_bbox_blocks; ep.chain_gate = fold_bbox_gate; }
+        fold_stats = false; fold_bbox_blocks = 0u; fold_bbox_gate = nullptr;
+    }
+    const unsigned threads = (ep.ts || ep.bbox_partials) ? BLOCK : WAVE;
+    k_publish_readback<<<1, threads, 0, stream>>>(d_rb.p, totals, lists ? 1 : 0, end_of_step ? 1 : 0, mass_slots.p, &h_hostpub->rb, &h_hostpub->seq, seq,
+                                                  d_ctl.p, pre ? *pre : PrePub{0, 0, {0, 0, 0, 0, 0, 0}}, gate, ep);
     SALVA_HIP_CHECK(hipGetLastError());
     return seq;
 }
@@ -904,8 +959,9 @@ __global__ void k_ghost_posmr(uint32_t n, const uint32_t* __restrict__ gtag, con
     if (i >= n || !(gtag[i] & 0x80000000u)) return;
     reinterpret_cast<float*>(&posmr[i])[3] = posm[i].w / rho[i];
 }
-__global__ void k_init_ctl(SolveCtl* ctl, SolveCtl* ring, SolveCtl init, uint32_t* chain_open) {
+__global__ void k_init_ctl(SolveCtl* ctl, SolveCtl* ring, SolveCtl init, uint32_t* chain_open, SolveCtl* ctl_b, SolveCtl init_b) {
     *ctl = init;
+    if (ctl_b) *ctl_b = init_b;  // (the step's second solve, whose parameters are known as well: one launch for both)
     if (chain_open) { chain_open[0] = 1u; chain_open[1] = 0u; }  // (Readback::chain_ok / chain_stage: the first solve of a chained step)
     if (ring) { ring[0] = init; ring[1] = init; }  // (dfsph.hip spec_decide: the test rides in the apply pass; iteration k reads spec_ring[k & 1])
 }
@@ -924,14 +980,38 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
         h_ctl[which] = init;
         // (one tiny kernel with the record as its argument instead of up to three copies from pageable host memory, each of which
         // stalls the host until its staging copy is done; the first solve of a chained step also opens the chain)
-        k_init_ctl<<<1, 1, 0, stream>>>(d_ctl.p + which, spec_apply ? spec_ring.p : nullptr, init, chain_open ? &d_rb.p->chain_ok : nullptr);
-        SALVA_HIP_CHECK(hipGetLastError());
+        const bool have = which == 1 && pre_init1_valid && memcmp(&pre_init1, &init, sizeof(SolveCtl)) == 0 && !chain_open;
+        if (!have) {
+            const bool both = which == 0 && pre_init1_valid;  // (World::dfsph_solve has said what the pressure solve will start from)
+            k_init_ctl<<<1, 1, 0, stream>>>(d_ctl.p + which, spec_apply ? spec_ring.p : nullptr, init, chain_open ? &d_rb.p->chain_ok : nullptr,
+                                            both ? d_ctl.p + 1 : nullptr, both ? pre_init1 : init);
+            SALVA_HIP_CHECK(hipGetLastError());
+        }
+        if (which == 1) pre_init1_valid = false;
         if (pub) { pub->done = 0u; pub->iters = 0u; pub->err = 0.0f; __atomic_store_n(&pub->seq, 0u, __ATOMIC_RELEASE); }
     }
     // First batch: what the previous step's solve needed (iters applies + the converged evaluate) — consecutive steps
     // need about the same, so the usual cost is one read-back per solve; a batch that overshoots only enqueues kernels
     // that return at once, one that falls short continues in doubling batches.
     int i = from, batch = std::max(2, std::min<int>((int)last_iters[which] + 1, max_iter));
+    const bool multi = comm && comm->size() > 1;
+    // Two launches a solve does not need (round 6; a kernel that returns at once still costs a launch of 2 200 workgroups, ~5 us, and
+    // a one-block test ~4.6 us plus its gaps — 23 us of a 0.61 ms free-fall step):
+    //  * the tests of iterations i < min_iter cannot end the solve (`err <= tol && i >= min`): they are not launched — the next test
+    //    that is counts them (`skipped`: iters and seq advance as if they had failed).  In a decomposed run that is an all-reduce less.
+    //  * the apply behind the LAST test of a batch runs only if that test fails, which the batch is sized not to expect: it is
+    //    enqueued by whoever continues the solve (`owed`), and never when the solve has converged.  Not in decomposed runs (a ghost
+    //    refresh rides behind every apply) and not where the test rides in the apply pass itself (spec_apply).
+    const bool lazy_apply = !multi && !spec_apply;
+    uint32_t skipped = 0u;
+    auto test = [&](int it, bool last_of_batch, const uint32_t* gate, uint32_t* close, uint32_t stage) {
+        if (it < min_iter && it + 1 < max_iter && !last_of_batch) { ++skipped; return; }
+        if (!multi) launch_finalize_error(partials.p, nlaunch, (uint32_t)std::max<size_t>(fluids.size(), 1), model_counts.p, d_ctl.p + which, pub, stream, gate, close, stage, skipped);
+        else finalize_solve(d_ctl.p + which, pub, skipped);
+        skipped = 0u;
+    };
+    if (from > 0 && solve_owes_apply[which]) apply(c, from - 1);  // (the apply the batch before left to its successor)
+    solve_owes_apply[which] = false;
     if (chain_stage) {
         // Chained (device_types.h StepCtx::gate): ONE batch and no wait.  The batch is what the previous step needed plus, while the
         // count is rising (the impact: 2, 4, 14, 18, 30 ... iterations in consecutive steps), what it rose by last time — a surplus
@@ -944,9 +1024,9 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
         for (int k = 0; k < nbatch; ++k) {
             eval(c, k);
             const bool closes = k == nbatch - 1 && nbatch < max_iter;
-            launch_finalize_error(partials.p, nlaunch, (uint32_t)std::max<size_t>(fluids.size(), 1), model_counts.p, d_ctl.p + which, pub, stream, c.gate,
-                                  closes ? &d_rb.p->chain_ok : nullptr, (uint32_t)chain_stage);
-            apply(c, k);
+            test(k, k == nbatch - 1, c.gate, closes ? &d_rb.p->chain_ok : nullptr, (uint32_t)chain_stage);
+            if (closes && lazy_apply) solve_owes_apply[which] = true;  // (only a continuation needs it)
+            else apply(c, k);
         }
         chain_batch[which] = nbatch;
         return SolveResult{0u, 0.0f};  // (pending: World::substep reads the outcome from the end-of-step publication)
@@ -954,11 +1034,13 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
     if (from > 0) batch = (from <= 2) ? 4 : 8;
     while (i < max_iter) {
         const int nbatch = std::min(batch, max_iter - i);
+        bool owes = false;
         for (int k = 0; k < nbatch; ++k) {
             if (spec_apply) { c.spec_k = i + k; c.spec_pub = pub; }
             eval(c, i + k);
-            if (!spec_apply) finalize_solve(d_ctl.p + which, pub);
-            apply(c, i + k);
+            if (!spec_apply) test(i + k, k == nbatch - 1, nullptr, nullptr, 0u);
+            if (lazy_apply && k == nbatch - 1 && i + nbatch < max_iter) owes = true;
+            else apply(c, i + k);
         }
         if (pub) {
             const uint32_t expect = (uint32_t)(i + nbatch);
@@ -985,6 +1067,7 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
         }
         i += nbatch;
         if (h_ctl[which].done) break;
+        if (owes) apply(c, i - 1);  // the batch's last test failed: the apply it counted
         batch = (i <= 2) ? 4 : 8;
     }
     prev_iters[which] = last_iters[which];
@@ -1217,6 +1300,12 @@ void World::dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepSta
     };
     const float div_tol = prm.max_divergence_error * inv_dt_prev * 0.01f;
     SolveResult rd{0u, 0.0f};
+    // (the pressure solve's control block is initialised by the divergence solve's launch — unless that solve has to open the chain)
+    pre_init1_valid = false;
+    if (resume == 0 && (!chain || chain_div)) {
+        pre_init1 = SolveCtl{0u, 0u, 0.0f, 0u, prm.max_density_error, (uint32_t)std::max(prm.min_pressure_iter, 0), 0u, 0u};
+        pre_init1_valid = true;
+    }
     if (resume <= 1) {
         rd = run_solve(c, 0, div_tol, prm.min_divergence_iter, prm.max_divergence_iter, 0u, div_eval, div_apply, spec_apply, chain_div ? 1 : 0,
                        resume == 1 ? chain_batch[0] : 0, chain_div);
@@ -1247,7 +1336,8 @@ void World::dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepSta
         }, false, chain ? 2 : 0, resume == 2 ? chain_batch[1] : 0, chain && !chain_div);
     st.n_pressure_iters = (int32_t)rp.iters;
     st.density_error = rp.err;
-    launch_update_positions(cg, dt, bbox_partials.p, d_rb.p->bbox, stream);
+    launch_update_positions(cg, dt, bbox_partials.p, nullptr, stream);  // (the per-block boxes are folded by the end-of-step publication)
+    fold_bbox_blocks = n ? num_blocks(n) : 0u; fold_bbox_gate = cg.gate;
     dt_prev = dt;
     inv_dt_prev = inv_dt;
     chain_pending = chain;
@@ -1286,7 +1376,8 @@ void World::iisph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepSta
     st.density_error = rp.err;
     const float* p = (rp.iters & 1u) ? pb : pa;
     launch_iisph_velocity_changes(c, lds, dt, p, stream);
-    launch_iisph_finish(c, dt, p, bbox_partials.p, d_rb.p->bbox, stream);
+    launch_iisph_finish(c, dt, p, bbox_partials.p, nullptr, stream);  // (the per-block boxes are folded by the end-of-step publication)
+    fold_bbox_blocks = n ? num_blocks(n) : 0u; fold_bbox_gate = nullptr;
     dt_prev = dt;
     inv_dt_prev = inv_dt;
 }
@@ -1725,8 +1816,10 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             slice_near.ensure((size_t)nslices + 1, stream, false, 1.1f);
             (void)r1; (void)r2;
             c = make_ctx();
-            launch_nbr_build(c, lds, tile_list_stats.p, reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff), &d_rb.p->max_cnt_ff,
-                             comm ? reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_own_ff) : nullptr, stream);
+            // (a pass whose list statistics are only looked at with the end-of-step publication lets that publication fold them)
+            fold_stats = (spec || defer_lists) && n > 0;
+            launch_nbr_build(c, lds, tile_list_stats.p, fold_stats ? nullptr : reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_ff),
+                             &d_rb.p->max_cnt_ff, comm ? reinterpret_cast<unsigned long long*>(&d_rb.p->ncontacts_own_ff) : nullptr, stream);
             if (spec || defer_lists) break;
             static_assert(offsetof(Readback, max_cnt_ff) == offsetof(Readback, ncontacts_ff) + 2 * sizeof(uint64_t), "list statistics travel in one copy");
             publish_and_wait(nullptr, true, false);

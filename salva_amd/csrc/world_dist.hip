@@ -369,19 +369,19 @@ void World::refresh_f4(float4* field) {
 }
 
 // Error reduction + break test of an iterative solve; with a transport the per-fluid sums are all-reduced first.
-void World::finalize_solve(SolveCtl* ctl, SolveCtl* pub) {
+void World::finalize_solve(SolveCtl* ctl, SolveCtl* pub, uint32_t skipped) {
     const unsigned ntiles = nlaunch;  // one partial per launched (non-empty) tile
     const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1);
     if (!comm || comm->size() == 1) {
         // (folding this into the evaluate kernels through a last-workgroup reduction was measured 7x slower: the
         // device-scope release every workgroup needs writes the XCD's whole L2 back)
-        launch_finalize_error(partials.p, ntiles, nm, model_counts.p, ctl, pub, stream);
+        launch_finalize_error(partials.p, ntiles, nm, model_counts.p, ctl, pub, stream, nullptr, nullptr, 0u, skipped);
         return;
     }
     const size_t tm = dist_time_begin(1);
     launch_sum_partials(partials.p, ntiles, nm, ctl, d_sums.p, stream);
     comm->allreduce_sum_f32(d_sums.p, (int)nm, stream);
-    launch_decide(d_sums.p, nm, model_counts.p, ctl, pub, stream);
+    launch_decide(d_sums.p, nm, model_counts.p, ctl, pub, stream, skipped);
     dist_time_end(tm);
 }
 
