@@ -57,10 +57,12 @@ struct TileAcc {
                        // (tile.h stage_p3), which are filled through registers, slot by slot
     uint32_t wsl;      // sum of (slices of the tile)^2: wsl / nsl = the slice count of the tile the average PARTICLE lives in (world.hip:
                        // the workgroup size)
+    uint32_t heavy;    // slots that are PARTS of a split tile + whole tiles whose fluid halo is beyond the three-tiles-per-CU layouts
+                       // (tile.h TILE_SPLIT_S): what World::substep decides the next step's splitting by
     __host__ __device__ TileAcc operator+(const TileAcc& o) const {
         return TileAcc{s + o.s, sb + o.sb, nsl + o.nsl, nonempty + o.nonempty, max_s > o.max_s ? max_s : o.max_s,
                        max_sb > o.max_sb ? max_sb : o.max_sb, max_nsl > o.max_nsl ? max_nsl : o.max_nsl,
-                       max_sum > o.max_sum ? max_sum : o.max_sum, max_raw > o.max_raw ? max_raw : o.max_raw, wsl + o.wsl};
+                       max_sum > o.max_sum ? max_sum : o.max_sum, max_raw > o.max_raw ? max_raw : o.max_raw, wsl + o.wsl, heavy + o.heavy};
     }
 };
 
@@ -126,14 +128,19 @@ struct StepCtx {
     uint32_t halo_stride;       // > 0: tile t's slot table starts at t * halo_stride (address known before any load
     uint32_t bhalo_stride;      //      returns); 0: compact tables at tile_off[t].s / .sb
     uint32_t ntiles;            // tiles of the dense grid (only the cell table and one flag per tile are dense)
+    // > 0: a tile whose fluid halo holds more than this many particles is cut along x into halves (own cells ux 0-1 | 2-3, four of
+    // the six halo planes each) or quarters (one plane of own cells, three halo planes), each part a slot of its own (tile.h
+    // Tile::part) — so that a few over-full tiles at the bottom of a tank do not move EVERY tile of every pass to the two-tiles-per-CU
+    // layouts (round 6).  0: every non-empty tile is one slot.
+    uint32_t split_s;
     // Everything per tile lives in a compact table over the NON-EMPTY tiles ("slots", in dense-index order), and every
     // tile kernel is launched over slots: widely scattered particles then cost nothing per empty tile.
-    const uint32_t* tile_ids;   // [nlaunch] dense tile index of slot k
-    const uint4* slot_desc;     // [nlaunch] {dense tile index, first own particle, one past the last, -}: everything
+    const uint32_t* tile_ids;   // [nlaunch] dense tile index of slot k | its part code << 28 (tile.h Tile::part)
+    const uint4* slot_desc;     // [nlaunch] {dense tile index, first own particle, one past the last, part code}: everything
                                 //           Tile::setup needs besides tile_off, in one load that depends on nothing
     const uint4* slot_info;     // [nlaunch] {first own particle, one past the last, first slice, S | SB << 16}: all a solver
                                 //           kernel needs to know about a tile's sizes, written by k_tile_halo_fill
-    const uint32_t* tile_rank;  // [ntiles+1] exclusive prefix of the non-empty flags: slot of a dense tile; [ntiles] = nlaunch
+    const uint32_t* tile_rank;  // [ntiles+1] exclusive prefix of the tiles' slot counts: FIRST slot of a dense tile; [ntiles] = nlaunch
     uint32_t nlaunch;           // number of slots launched (= the number of non-empty tiles, or in a speculative pass an upper bound)
     // Speculative passes (World::step): launch shapes and buffers were cut from the previous step's totals, so every
     // tile kernel clamps itself to what it was given — surplus slots are empty, a halo is cut at the staged capacity, a tile

@@ -403,8 +403,10 @@ __global__ __launch_bounds__(BLOCK) void k_export_contacts(StepCtx c, const uint
     uint64_t o = offsets[host_local];
     const uint32_t cnt = boundary ? c.nfb[i] : c.nff[i];
     const uint32_t tile = keys[i] / TCELLS;
-    const uint32_t own_begin = c.gf.cell_start[(size_t)tile * TCELLS];
-    const uint32_t slot_t = c.tile_rank[tile];
+    // (the slot that owns particle i: the tile's only one, or — a split tile, tile.h Tile::part — the part whose range holds it)
+    uint32_t slot_t = c.tile_rank[tile];
+    for (const uint32_t last = c.tile_rank[tile + 1]; slot_t + 1 < last && i >= c.slot_desc[slot_t].z; ++slot_t) {}
+    const uint32_t own_begin = c.slot_desc[slot_t].y;
     const TileAcc a0 = c.tile_off[slot_t];
     const uint32_t gs = a0.nsl + (i - own_begin) / WAVE, lane = (i - own_begin) % WAVE;
     const uint32_t cap = boundary ? c.cap_fb : c.cap_ff;
@@ -437,8 +439,10 @@ __global__ __launch_bounds__(BLOCK) void k_export_contacts_local(StepCtx c, cons
     uint64_t o = offsets[i];
     const uint32_t cnt = boundary ? c.nfb[i] : c.nff[i];
     const uint32_t tile = keys[i] / TCELLS;
-    const uint32_t own_begin = c.gf.cell_start[(size_t)tile * TCELLS];
-    const uint32_t slot_t = c.tile_rank[tile];
+    // (the slot that owns particle i: the tile's only one, or — a split tile, tile.h Tile::part — the part whose range holds it)
+    uint32_t slot_t = c.tile_rank[tile];
+    for (const uint32_t last = c.tile_rank[tile + 1]; slot_t + 1 < last && i >= c.slot_desc[slot_t].z; ++slot_t) {}
+    const uint32_t own_begin = c.slot_desc[slot_t].y;
     const TileAcc a0 = c.tile_off[slot_t];
     const uint32_t gs = a0.nsl + (i - own_begin) / WAVE, lane = (i - own_begin) % WAVE;
     const uint32_t cap = boundary ? c.cap_fb : c.cap_ff;
@@ -486,30 +490,74 @@ void launch_unsort_u32(uint32_t n, const uint32_t* perm, const uint32_t* in, uin
 constexpr int TABLE_THREADS = HCELLS <= 256 ? 256 : 320;  // >= HCELLS
 static_assert(TABLE_THREADS >= HCELLS, "one thread per halo cell");
 
-// one thread per tile of the dense grid: does it hold particles?
-__global__ __launch_bounds__(BLOCK) void k_tile_flags(const uint32_t* __restrict__ cell_start, uint32_t ntiles, uint32_t* __restrict__ flags,
-                                                      const uint32_t* gate) {
+// The slots of one tile of the dense grid: none when it is empty, one (the whole tile) unless StepCtx::split_s says otherwise — then a
+// tile whose fluid halo holds more than split_s particles is cut along x into halves, or, where a half's halo is still too full,
+// into single planes of own cells (tile.h Tile::part); parts without a particle of their own get no slot.  codes[k] = part code of
+// the k-th slot.  One thread per tile: 36 cell-row lookups per halo plane, only for the non-empty tiles of a world that splits.
+__device__ __forceinline__ uint32_t tile_parts(const TileGrid& g, uint32_t t, uint32_t split_s, uint32_t (&codes)[TX]) {
+    const uint32_t* __restrict__ cs = g.cell_start;
+    const size_t base = (size_t)t * TCELLS;
+    if (cs[base + TCELLS] == cs[base]) return 0u;
+    codes[0] = TILE_PART_WHOLE;
+    if (split_s == 0u || TX != 4) return 1u;
+    // fluid particles per halo plane hx = 0 .. 5
+    const uint32_t ttz = t % g.ntz, tty = (t / g.ntz) % g.nty, ttx = t / (g.ntz * g.nty);
+    const int hcx = g.ox + (int)ttx * TX - 1, hcy = g.oy + (int)tty * TY - 1, hcz = g.oz + (int)ttz * TZ - 1;
+    uint32_t P[HX];
+    uint32_t total = 0u;
+    for (int hx = 0; hx < HX; ++hx) {
+        uint32_t cnt = 0u;
+        for (int hy = 0; hy < HY; ++hy)
+            for (int hz = 0; hz < HZ; ++hz) {
+                bool in;
+                const uint32_t k = tile_key(g, hcx + hx, hcy + hy, hcz + hz, in);
+                if (in) cnt += cs[(size_t)k + 1] - cs[k];
+            }
+        P[hx] = cnt; total += cnt;
+    }
+    if (total <= split_s) return 1u;
+    auto own = [&](uint32_t ux0, uint32_t len) { return cs[base + (ux0 + len) * (TY * TZ)] - cs[base + ux0 * (TY * TZ)]; };
+    uint32_t n = 0u;
+    const uint32_t lo = P[0] + P[1] + P[2] + P[3], hi = P[2] + P[3] + P[4] + P[5];
+    if (lo <= split_s && hi <= split_s) {
+        if (own(0, 2)) codes[n++] = tile_part_code(0, 2);
+        if (own(2, 2)) codes[n++] = tile_part_code(2, 2);
+    } else {
+        for (uint32_t ux = 0; ux < (uint32_t)TX; ++ux)
+            if (own(ux, 1)) codes[n++] = tile_part_code(ux, 1);
+    }
+    return n;
+}
+// one thread per tile of the dense grid: how many slots does it get?
+__global__ __launch_bounds__(BLOCK) void k_tile_flags(TileGrid g, uint32_t ntiles, uint32_t* __restrict__ flags, const uint32_t* gate, uint32_t split_s) {
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     if (gate && *gate == 0u) return;
-    if (t < ntiles) flags[t] = cell_start[(size_t)t * TCELLS + TCELLS] > cell_start[(size_t)t * TCELLS] ? 1u : 0u;
+    uint32_t codes[TX];
+    if (t < ntiles) flags[t] = tile_parts(g, t, split_s, codes);
     if (t == ntiles) flags[t] = 0u;
 }
-__global__ __launch_bounds__(BLOCK) void k_tile_ids(const uint32_t* __restrict__ rank, uint32_t ntiles, uint32_t* __restrict__ tile_ids,
-                                                    const uint32_t* gate) {
+__global__ __launch_bounds__(BLOCK) void k_tile_ids(TileGrid g, const uint32_t* __restrict__ rank, uint32_t ntiles, uint32_t* __restrict__ tile_ids,
+                                                    const uint32_t* gate, uint32_t split_s) {
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     if (gate && *gate == 0u) return;  // (must not index by ranks scanned from stale flags)
-    if (t < ntiles && rank[t + 1] != rank[t]) tile_ids[rank[t]] = t;
+    if (t >= ntiles) return;
+    const uint32_t r = rank[t], cnt = rank[t + 1] - r;
+    if (cnt == 0u) return;
+    if (cnt == 1u && split_s == 0u) { tile_ids[r] = t | (TILE_PART_WHOLE << TILE_PART_SHIFT); return; }
+    uint32_t codes[TX];
+    const uint32_t n = tile_parts(g, t, split_s, codes);  // (the decision k_tile_flags took: the same cells, the same sums)
+    for (uint32_t k = 0; k < n && k < cnt; ++k) tile_ids[r + k] = t | (codes[k] << TILE_PART_SHIFT);
 }
-void launch_tile_slots(const uint32_t* cell_start, uint32_t ntiles, uint32_t* flags, uint32_t* rank, uint32_t* tile_ids, void* temp,
-                       size_t temp_bytes, hipStream_t s, const uint32_t* gate) {
-    k_tile_flags<<<div_up((size_t)ntiles + 1, BLOCK), BLOCK, 0, s>>>(cell_start, ntiles, flags, gate);
+void launch_tile_slots(TileGrid g, uint32_t ntiles, uint32_t* flags, uint32_t* rank, uint32_t* tile_ids, void* temp,
+                       size_t temp_bytes, hipStream_t s, const uint32_t* gate, uint32_t split_s) {
+    k_tile_flags<<<div_up((size_t)ntiles + 1, BLOCK), BLOCK, 0, s>>>(g, ntiles, flags, gate, split_s);
     SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, flags, rank, (int)(ntiles + 1), s));
-    k_tile_ids<<<div_up((size_t)ntiles, BLOCK), BLOCK, 0, s>>>(rank, ntiles, tile_ids, gate);
+    k_tile_ids<<<div_up((size_t)ntiles, BLOCK), BLOCK, 0, s>>>(g, rank, ntiles, tile_ids, gate, split_s);
 }
 
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc* __restrict__ tile_cnt, uint4* __restrict__ slot_desc) {
     Tile t;
-    TileAcc a{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    TileAcc a{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // (launched over an upper bound of the slot count: a surplus workgroup contributes a zero entry; workgroup 0 also zeroes the
     // extra element the exclusive scan reads behind the last one)
     if (gate_closed(c)) return;  // (a pre-enqueued launch whose grid did not come true: World::pre_enqueue_grid)
@@ -518,7 +566,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc
         if (threadIdx.x == 0) tile_cnt[blockIdx.x] = a;
         return;
     }
-    if (threadIdx.x == 0) slot_desc[t.slot] = make_uint4(t.tile, t.own_begin, t.own_end, 0u);
+    if (threadIdx.x == 0) slot_desc[t.slot] = make_uint4(t.tile, t.own_begin, t.own_end, t.part);
     {
         TileCells tc;
         tc.build(c, t);
@@ -530,6 +578,7 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc
         a.max_s = (uint32_t)a.s; a.max_sb = (uint32_t)a.sb; a.max_nsl = a.nsl;
         a.max_sum = (((uint32_t)a.s + 63u) & ~63u) + (uint32_t)a.sb;
         a.max_raw = (uint32_t)a.s + (uint32_t)a.sb;
+        a.heavy = (t.part != TILE_PART_WHOLE || a.s > TILE_SPLIT_S) ? 1u : 0u;
     }
     if (threadIdx.x == 0) tile_cnt[t.slot] = a;
 }
@@ -559,11 +608,11 @@ void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo
 }
 size_t scan_tiles_temp_bytes(uint32_t n) {
     size_t b = 0;
-    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n);
     return b;
 }
 void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s) {
-    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n, s));
+    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n, s));
 }
 
 // ------------------------------------------------------------------------------------------------ neighbour lists

@@ -49,8 +49,9 @@ void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4
 
 // per-tile {halo slots, boundary halo slots, slices} (-> scan_tiles -> tile_off) and their maxima; then the flat
 // halo slot tables
-void launch_tile_slots(const uint32_t* cell_start, uint32_t ntiles, uint32_t* flags, uint32_t* rank, uint32_t* tile_ids, void* temp,
-                       size_t temp_bytes, hipStream_t s, const uint32_t* gate = nullptr);
+// g: the fluid grid WITH its cell table; split_s: StepCtx::split_s (0 = one slot per non-empty tile)
+void launch_tile_slots(TileGrid g, uint32_t ntiles, uint32_t* flags, uint32_t* rank, uint32_t* tile_ids, void* temp,
+                       size_t temp_bytes, hipStream_t s, const uint32_t* gate = nullptr, uint32_t split_s = 0u);
 void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, uint4* slot_desc, hipStream_t s);
 void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, uint4* slot_info, hipStream_t s);
 size_t scan_tiles_temp_bytes(uint32_t n);

@@ -97,6 +97,14 @@ constexpr uint32_t P3_DS_THREE = SALVA_P3_DS3, P3_DS_TWO = 3360, P3_DS_ONE = 406
 constexpr uint32_t P2_DS_THREE = SALVA_P2_DS3;                               // apply kernels: fluid + boundary halo slots
 static_assert((P3_DS_THREE % 64 == 32 && P3_DS_TWO % 64 == 32 && P3_DS_ONE % 64 == 32 && P2_DS_THREE % 64 == 32) || SALVA_P3_DS3 != 2080 || SALVA_P2_DS3 != 2464,
               "plane distances: odd multiples of 256 bytes");
+// Parts of a split tile (StepCtx::split_s).  A part owns the cells ux in [ux0, ux0 + len) of its tile — one contiguous particle
+// range, the cell key being x-major inside a tile — and stages the halo planes hx in [ux0, ux0 + len + 2) only.  Code = ux0 | (len - 1) << 2,
+// 4 bits; the whole tile is ux0 = 0, len = TX.  It rides in the top bits of a tile_ids entry and in slot_desc.w.
+constexpr uint32_t TILE_PART_SHIFT = 28;
+constexpr uint32_t TILE_PART_WHOLE = (uint32_t)(TX - 1) << 2;
+__host__ __device__ inline uint32_t tile_part_code(uint32_t ux0, uint32_t len) { return ux0 | ((len - 1u) << 2); }
+// the fluid halo beyond which a tile does not fit the three-tiles-per-CU plane layouts (P3_DS_THREE)
+constexpr uint32_t TILE_SPLIT_S = P3_DS_THREE;
 constexpr uint32_t TILE_ERR_BYTES = 12u * 32u * 4u;  // TileErr table (TILE_MAX_WAVES x MAX_MODELS floats), carved from the pool
 
 #ifdef __HIPCC__
@@ -200,6 +208,7 @@ struct Tile {
     uint32_t pool_used;
     uint32_t S, SB;       // halo slot counts (fluid / boundary)
     uint32_t tile;        // index in the dense tile grid
+    uint32_t part;        // which x-planes of it this slot owns (tile_part_code; TILE_PART_WHOLE unless the tile was split)
     uint32_t slot;        // index among the launched (non-empty) tiles: per-workgroup outputs (error partials, list stats)
     uint32_t own_begin, own_end, slice_base;
     uint64_t hoff, hboff; // offsets of this tile's slot tables in halo_src / bhalo_src
@@ -227,16 +236,21 @@ struct Tile {
         S = SB = 0; slice_base = 0; hoff = hboff = 0;
         pre0 = pre1 = pre2 = pre3 = preb = 0u;
         own_begin = own_end = 0; tile = 0; hcx = hcy = hcz = 0;
+        part = TILE_PART_WHOLE;
         if (slot >= c.tile_rank[c.ntiles]) return false;
-        tile = c.tile_ids[slot];
+        const uint32_t id = c.tile_ids[slot];
+        tile = id & ((1u << TILE_PART_SHIFT) - 1u);
+        part = id >> TILE_PART_SHIFT;
         geometry(c);
         return true;
     }
+    __device__ __forceinline__ uint32_t part_ux0() const { return part & 3u; }
+    __device__ __forceinline__ uint32_t part_len() const { return (part >> 2) + 1u; }
     __device__ __forceinline__ void geometry(const StepCtx& c) {
         const TileGrid& g = c.gf;
         const uint32_t ttz = tile % g.ntz, tty = (tile / g.ntz) % g.nty, ttx = tile / (g.ntz * g.nty);
-        own_begin = g.cell_start[(size_t)tile * TCELLS];
-        own_end = g.cell_start[(size_t)tile * TCELLS + TCELLS];
+        own_begin = g.cell_start[(size_t)tile * TCELLS + part_ux0() * (TY * TZ)];
+        own_end = g.cell_start[(size_t)tile * TCELLS + (part_ux0() + part_len()) * (TY * TZ)];
         hcx = g.ox + (int)ttx * TX - 1; hcy = g.oy + (int)tty * TY - 1; hcz = g.oz + (int)ttz * TZ - 1;
     }
 
@@ -276,7 +290,7 @@ struct Tile {
             if (s0 + 3 * nt < lim) pre3 = src[s0 + 3 * nt];
             if (c.bhalo_stride && s0 < c.bhalo_stride) preb = c.bhalo_src[(size_t)slot * c.bhalo_stride + s0];
         }
-        tile = desc.x; own_begin = desc.y; own_end = desc.z;
+        tile = desc.x; own_begin = desc.y; own_end = desc.z; part = desc.w;
         {
             const TileGrid& g = c.gf;
             const uint32_t ttz = tile % g.ntz, tty = (tile / g.ntz) % g.nty, ttx = tile / (g.ntz * g.nty);
@@ -585,13 +599,15 @@ struct TileCells {
         const int h = threadIdx.x;
         if (h < HCELLS) {
             const int hz = h % HZ, hy = (h / HZ) % HY, hx = h / (HZ * HY);
+            // (a part of a split tile stages the x-planes around its own cells only: the others hold no neighbour of its particles)
+            const bool plane = (uint32_t)hx >= t.part_ux0() && (uint32_t)hx < t.part_ux0() + t.part_len() + 2u;
             bool in;
             const uint32_t k = tile_key(c.gf, t.hcx + hx, t.hcy + hy, t.hcz + hz, in);
             uint32_t b = 0, e = 0;
-            if (in) { b = c.gf.cell_start[k]; e = c.gf.cell_start[k + 1]; }
+            if (in && plane) { b = c.gf.cell_start[k]; e = c.gf.cell_start[k + 1]; }
             gstart[h] = b; lstart[h] = e - b;
             b = e = 0;
-            if (c.nb) {
+            if (c.nb && plane) {
                 const uint32_t kb = tile_key_m(c.gb, t.hcx + hx, t.hcy + hy, t.hcz + hz, in, c.gf.mx, c.gf.my, c.gf.mz);
                 if (in) { b = c.gb.cell_start[kb]; e = c.gb.cell_start[kb + 1]; }
             }

@@ -344,9 +344,15 @@ class World {
         uint32_t n = 0, seq = 0, nslots_bound = 0, ntiles = 0;
         size_t ncf = 0;
         bool check_mass = false;
+        uint32_t split_s = 0;
         GridDims gf;
     } pre;
     bool pre_off = false;          // SALVA_HIP_NO_PREGRID=1 (A/B, tests)
+    // splitting of over-full tiles (device_types.h StepCtx::split_s)
+    bool split_off = false;        // SALVA_HIP_NO_SPLIT=1
+    uint32_t split_forced = 0;     // SALVA_HIP_SPLIT_S=k: split at k halo particles whatever the statistics say (tests)
+    bool split_on = false;         // the previous step's totals say: a few tiles are over-full
+    uint32_t split_s_cur = 0;      // what this step's tables are built with
     int32_t bbox_used_last[6] = {0, 0, 0, 0, 0, 0};  // the cell box the previous step ran on
     bool bbox_used_valid = false;
     uint64_t pre_adopted = 0, pre_dropped = 0;

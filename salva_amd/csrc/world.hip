@@ -136,6 +136,8 @@ World::World(const SalvaHipParams& p) : prm(p) {
     spec_apply_off = getenv("SALVA_HIP_NO_SPEC_APPLY") != nullptr;
     chain_off = getenv("SALVA_HIP_NO_CHAIN") != nullptr;
     pre_off = getenv("SALVA_HIP_NO_PREGRID") != nullptr;
+    split_off = getenv("SALVA_HIP_NO_SPLIT") != nullptr;
+    if (const char* e = getenv("SALVA_HIP_SPLIT_S")) split_forced = (uint32_t)std::max(atoi(e), 1);
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
     two_mass_off = getenv("SALVA_HIP_NO_TWO_MASS") != nullptr;
     fold_off = getenv("SALVA_HIP_NO_FOLD") != nullptr;
@@ -677,6 +679,7 @@ StepCtx World::make_ctx() {
     c.tile_off = G().tile_off.p; c.halo_src = halo_src.p; c.bhalo_src = bhalo_src.p;
     c.halo_stride = halo_stride; c.bhalo_stride = bhalo_stride;
     c.ntiles = (uint32_t)gf.ntiles();
+    c.split_s = split_s_cur;
     c.tile_ids = G().tile_ids.p; c.tile_rank = G().tile_rank.p; c.nlaunch = nlaunch; c.slot_desc = G().slot_desc.p; c.slot_info = slot_info.p;
     c.spec = spec_mode ? 1u : 0u; c.halo_cap = halo_cap; c.bhalo_cap = bhalo_cap; c.nslices_cap = nslices_cap;
     c.halo_len = halo_len; c.bhalo_len = bhalo_len;
@@ -1467,7 +1470,7 @@ void World::pre_enqueue_grid(uint32_t nslots_bound) {
     {
         const size_t tb = std::max(scan_tiles_temp_bytes(nslots_bound + 1), scan_temp_bytes(ntiles + 1));
         ensure_cub_temp(tb);
-        launch_tile_slots(T.cell_start_f.p, ntiles, T.tile_flags.p, T.tile_rank.p, T.tile_ids.p, cub_temp.p, tb, stream, gate);
+        launch_tile_slots(gf.device(T.cell_start_f.p), ntiles, T.tile_flags.p, T.tile_rank.p, T.tile_ids.p, cub_temp.p, tb, stream, gate, split_s_cur);
         StepCtx cp = make_ctx();
         cp.gf = gf.device(T.cell_start_f.p);
         cp.tile_off = T.tile_off.p; cp.tile_ids = T.tile_ids.p; cp.tile_rank = T.tile_rank.p; cp.slot_desc = T.slot_desc.p;
@@ -1476,7 +1479,7 @@ void World::pre_enqueue_grid(uint32_t nslots_bound) {
         scan_tiles(cub_temp.p, tb, T.tile_cnt.p, T.tile_off.p, nslots_bound + 1, stream);
     }
     pre.seq = publish_enqueue(T.tile_off.p + nslots_bound, false, false, nullptr, gate);
-    pre.n = n; pre.ncf = ncf; pre.ntiles = ntiles; pre.nslots_bound = nslots_bound; pre.gf = gf;
+    pre.n = n; pre.ncf = ncf; pre.ntiles = ntiles; pre.nslots_bound = nslots_bound; pre.gf = gf; pre.split_s = split_s_cur;
     pre.valid = true;
 }
 // The next step could not use it.  If its launches ran (the gate was open) they have raised flags and mass marks that belong to no step.
@@ -1564,13 +1567,19 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     const uint32_t ntiles = (uint32_t)gf.ntiles();
     // only the cell table and one flag per tile are dense over the bounding box; every other per-tile table is compact
     // over the non-empty tiles ("slots"), of which there are at most min(ntiles, n)
-    const uint32_t nslots_bound = (uint32_t)std::min<uint64_t>(ntiles, n);
+    // Splitting of over-full tiles (device_types.h StepCtx::split_s): where the plane layouts run (one or two particle masses, single
+    // domain), and while the tiles beyond the three-per-CU layouts are a minority — decided from the totals of the step before
+    // (split_on, below).  SALVA_HIP_NO_SPLIT=1: never; SALVA_HIP_SPLIT_S=k: always, at k halo particles (tests).
+    split_s_cur = 0u;
+    if (split_forced) split_s_cur = split_forced;
+    else if (!split_off && split_on && !comm && spec_off && mass_known && (mass_uniform != 0.0f || two_mass)) split_s_cur = TILE_SPLIT_S;
+    const uint32_t nslots_bound = (uint32_t)std::min<uint64_t>((uint64_t)ntiles * (split_s_cur ? (uint64_t)TX : 1ull), n);
     // ---- the grid part of this step may be on the device already (world.h PreGrid): adopt the other set of tables, or drop it
     bool adopted = false;
     if (pre.valid) {
         pre.valid = false;
         adopted = h_rb->pre_ok && !world_touched && !timers && !comm && pre.n == n && pre.ncf == ncf && pre.ntiles == ntiles &&
-                  pre.nslots_bound == nslots_bound && memcmp(&pre.gf, &gf, sizeof(GridDims)) == 0;
+                  pre.nslots_bound == nslots_bound && pre.split_s == split_s_cur && memcmp(&pre.gf, &gf, sizeof(GridDims)) == 0;
         if (adopted) { gsel ^= 1; ++pre_adopted; ++counters.pregrid_adopted; }
         else pre_drop();
     }
@@ -1699,7 +1708,7 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         const size_t tb = std::max(scan_tiles_temp_bytes(nslots_bound + 1), scan_temp_bytes(ntiles + 1));
         ensure_cub_temp(tb);
         if (!have_grid) {
-        launch_tile_slots(G().cell_start_f.p, ntiles, G().tile_flags.p, G().tile_rank.p, G().tile_ids.p, cub_temp.p, tb, stream);
+        launch_tile_slots(gf.device(G().cell_start_f.p), ntiles, G().tile_flags.p, G().tile_rank.p, G().tile_ids.p, cub_temp.p, tb, stream, nullptr, split_s_cur);
         // (k_tile_count zeroes the entries of its surplus workgroups and the scan's extra element itself: no memset —
         // unless there is no workgroup at all, a rank that holds no particle)
         if (nslots_bound == 0) SALVA_HIP_CHECK(hipMemsetAsync(G().tile_cnt.p, 0, sizeof(TileAcc), stream));
@@ -1739,8 +1748,17 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         lds.max_sum = spec ? 0u : tt.max_sum;  // (a speculative pass knows the two maxima only: TileLds::sum_slots falls back to their sum)
         lds.max_raw = spec ? 0u : tt.max_raw;
         if (tile_trace)
-            fprintf(stderr, "salva_hip tiles: nonempty %u max_s %u max_sb %u max_sum %u max_raw %u mass_uniform %g\n", tt.nonempty, tt.max_s,
-                    tt.max_sb, tt.max_sum, tt.max_raw, (double)mass_uniform);
+            fprintf(stderr, "salva_hip tiles: nonempty %u max_s %u max_sb %u max_sum %u max_raw %u heavy %u split_s %u mass_uniform %g | chained %llu breaks %llu pregrid %llu dropped %llu\n",
+                    tt.nonempty, tt.max_s, tt.max_sb, tt.max_sum, tt.max_raw, tt.heavy, split_s_cur, (double)mass_uniform,
+                    (unsigned long long)chain_steps, (unsigned long long)chain_breaks, (unsigned long long)pre_adopted, (unsigned long long)pre_dropped);
+        if (!spec) {
+            // next step's splitting: on while the over-full tiles are few (each costs a second workgroup and a third more staging, and
+            // buys every other tile of every pass its third resident neighbour); off again when they are the rule — a uniformly
+            // compressed fluid is better served by the two-tiles-per-CU layouts than by twice the tiles (smaller
+            // tiles lose).  `heavy` counts whole over-full tiles, or — while splitting — the parts they were cut into.
+            if (!split_on) split_on = tt.heavy > 0u && (uint64_t)tt.heavy * 5u <= tt.nonempty;
+            else if ((uint64_t)tt.heavy * 2u > tt.nonempty) split_on = false;
+        }
         // Workgroup size: one wave per 64-particle slice of the tile the average PARTICLE lives in (TileAcc::wsl / nsl; fuller tiles
         // loop over their extra slices) — the plain average over the tiles drops to four waves as soon as a few thousand stray
         // particles own a tile each, and the full tiles, where nearly all the work is, then run on half the waves.  Never fewer waves
