@@ -126,6 +126,9 @@ fn check(code: i32) -> Result<(), Error> {
     }
 }
 
+/// a coupled collider's boundary slot, the pose it was last given, and its parent body
+type Pose = (u32, ffi::SalvaHipRigidPose, Option<rapier3d::dynamics::RigidBodyHandle>);
+
 /// fluids_pipeline.rs:18-61: the liquid world (DFSPH, :35) and the couplings.
 pub struct FluidsPipeline {
     pub liquid_world: LiquidWorld,
@@ -151,8 +154,80 @@ impl FluidsPipeline {
             }
             self.coupling.retired.pop();
         }
-        // ---- update_boundaries (:146-264): one pose per collider
-        let mut poses: Vec<(u32, ffi::SalvaHipRigidPose, Option<rapier3d::dynamics::RigidBodyHandle>)> = Vec::new();
+        if self.liquid_world.cfl_mode() != 0 {
+            return self.step_substepping(gravity, dt, colliders, bodies);
+        }
+        let poses = self.update_boundaries(colliders, bodies)?;
+        // ---- the substep
+        let stepped = self.liquid_world.step(dt, &na::Vector3::new(gravity.x, gravity.y, gravity.z));
+        self.check_host_shapes()?;
+        stepped?;
+        self.transmit_forces(&poses, bodies, dt)
+    }
+
+    /// CFL sub-stepping (`LiquidWorld::set_cfl_substepping`): the reference's manager is called INSIDE the substep loop
+    /// (liquid_world.rs:94-103 `update_boundaries`, :146 `transmit_forces`), so that each substep's impulse (force * timestep.dt(),
+    /// fluids_pipeline.rs:266-287) reaches the bodies before the next substep samples their velocities.  The library calls back at
+    /// both points (`salva_hip_set_coupling_callback`).
+    fn step_substepping(&mut self, gravity: &Vector<Real>, dt: Real, colliders: &ColliderSet, bodies: &mut RigidBodySet) -> Result<(), Error> {
+        struct Ctx<'a> {
+            pipeline: *mut FluidsPipeline,
+            colliders: &'a ColliderSet,
+            bodies: *mut RigidBodySet,
+            poses: Vec<Pose>,
+            error: Option<Error>,
+        }
+        unsafe extern "C" fn cb(user: *mut std::ffi::c_void, _world: *mut ffi::SalvaHipWorld, phase: i32, sub_dt: f32) -> i32 {
+            let c = &mut *(user as *mut Ctx);
+            // (a panic must not unwind into C)
+            let r = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| {
+                let p = &mut *c.pipeline;
+                if phase == 0 {
+                    p.update_boundaries(c.colliders, &*c.bodies).map(|poses| c.poses = poses)
+                } else {
+                    p.transmit_forces(&c.poses, &mut *c.bodies, sub_dt)
+                }
+            }));
+            match r {
+                Ok(Ok(())) => 0,
+                Ok(Err(e)) => {
+                    c.error = Some(e);
+                    1
+                }
+                Err(_) => {
+                    c.error = Some(Error { code: ffi::SALVA_HIP_E_INVALID, message: "the coupling callback panicked".into() });
+                    1
+                }
+            }
+        }
+        let mut ctx = Ctx { pipeline: self as *mut FluidsPipeline, colliders, bodies: bodies as *mut RigidBodySet, poses: Vec::new(), error: None };
+        let raw = self.liquid_world.raw();
+        check(unsafe { ffi::salva_hip_set_coupling_callback(raw, Some(cb), &mut ctx as *mut Ctx as *mut std::ffi::c_void) })?;
+        // (the callback reaches `self` through the raw pointer while `step` holds `&mut self.liquid_world`: the library calls it on
+        // this thread, inside salva_hip_step, and the step touches nothing of the Rust-side mirrors until it returns)
+        let stepped = self.liquid_world.step(dt, &na::Vector3::new(gravity.x, gravity.y, gravity.z));
+        unsafe { ffi::salva_hip_set_coupling_callback(raw, None, std::ptr::null_mut()) };
+        self.check_host_shapes()?;
+        if let Some(e) = ctx.error.take() {
+            return Err(e);
+        }
+        stepped
+    }
+
+    fn check_host_shapes(&self) -> Result<(), Error> {
+        for entry in self.coupling.entries.values() {
+            if let Some(ctx) = entry.host_shape.as_ref() {
+                if ctx.panicked.swap(false, std::sync::atomic::Ordering::Relaxed) {
+                    return Err(Error { code: ffi::SALVA_HIP_E_INVALID, message: "a host-shape callback (compute_aabb / project_point) panicked during the step".into() });
+                }
+            }
+        }
+        Ok(())
+    }
+
+    /// `update_boundaries` (fluids_pipeline.rs:146-264): one pose per collider
+    fn update_boundaries(&mut self, colliders: &ColliderSet, bodies: &RigidBodySet) -> Result<Vec<Pose>, Error> {
+        let mut poses: Vec<Pose> = Vec::new();
         for (co_handle, entry) in self.coupling.entries.iter_mut() {
             let (Some(collider), Some(slot)) = (colliders.get(*co_handle), self.liquid_world.boundaries().iter().position(|(h, _)| h == entry.boundary)) else {
                 continue;
@@ -222,18 +297,12 @@ impl FluidsPipeline {
             check(unsafe { ffi::salva_hip_update_boundary_pose(raw, slot, &pose) })?;
             poses.push((slot, pose, body.map(|(p, _)| p)));
         }
-        // ---- the substep
-        let stepped = self.liquid_world.step(dt, &na::Vector3::new(gravity.x, gravity.y, gravity.z));
-        for entry in self.coupling.entries.values() {
-            if let Some(ctx) = entry.host_shape.as_ref() {
-                if ctx.panicked.swap(false, std::sync::atomic::Ordering::Relaxed) {
-                    return Err(Error { code: ffi::SALVA_HIP_E_INVALID, message: "a host-shape callback (compute_aabb / project_point) panicked during the step".into() });
-                }
-            }
-        }
-        stepped?;
-        // ---- transmit_forces (:266-287): sum_i apply_impulse_at_point(f_i dt, x_i) = apply_impulse(F dt) + apply_torque_impulse(T dt)
-        for (slot, pose, parent) in poses {
+        Ok(poses)
+    }
+
+    /// `transmit_forces` (fluids_pipeline.rs:266-287): sum_i apply_impulse_at_point(f_i dt, x_i) = apply_impulse(F dt) + apply_torque_impulse(T dt)
+    fn transmit_forces(&mut self, poses: &[Pose], bodies: &mut RigidBodySet, dt: Real) -> Result<(), Error> {
+        for (slot, pose, parent) in poses.iter().copied() {
             let Some(parent) = parent else { continue };
             if pose.is_dynamic == 0 {
                 continue;

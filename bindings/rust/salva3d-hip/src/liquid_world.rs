@@ -114,13 +114,28 @@ pub struct LiquidWorld {
     pinned: Vec<(usize, usize)>,
     decomposed: bool,    // set_domain was called (dist.rs): particles are read with owned()
     last_stats: ffi::SalvaHipStepStats,
+    cfl_mode: i32,       // what set_cfl_substepping was last called with (coupling.rs: the manager's calls move into the substep loop)
 }
 
 // Send: the C side keeps no thread-affine state — every entry point selects the world's device and stream itself, and the
-// last-error string is thread-local.  NOT Sync: entry points that take `&self` here (queries, read-backs) still reuse scratch
-// buffers and the world's stream on the C side, so two threads must not call into the same world at once; share it behind a
-// Mutex like any other `!Sync` handle.  (salva3d's own LiquidWorld is Send + Sync by composition of plain data.)
+// last-error string is thread-local.
+// Sync (round 6): every C entry point that takes a world holds that world's lock for its duration (a recursive mutex in
+// `SalvaHipWorld`, salva_amd/csrc/capi.hip — the C side reuses scratch buffers, one stream and lazily refreshed staging arrays per
+// world), so the `&self` methods here, which touch nothing but the C handle, may be called from several threads at once; the
+// methods that touch the Rust-side mirrors take `&mut self` and the borrow checker does the rest.  The reference pins the same two
+// bounds at compile time (src/liquid_world.rs:283-287); tests/cpp/two_threads.cpp is the run-time half of it on this side.
 unsafe impl Send for LiquidWorld {}
+unsafe impl Sync for LiquidWorld {}
+
+#[cfg(test)]
+mod send_sync {
+    // the reference's own test, liquid_world.rs:283-287
+    #[test]
+    fn world_is_send_and_sync() {
+        fn check<T: Send + Sync>() {}
+        check::<super::LiquidWorld>();
+    }
+}
 
 impl Drop for LiquidWorld {
     fn drop(&mut self) {
@@ -164,6 +179,7 @@ impl LiquidWorld {
             pinned: Vec::new(),
             decomposed: false,
             last_stats: unsafe { std::mem::zeroed() },
+            cfl_mode: 0,
         })
     }
 
@@ -387,17 +403,31 @@ impl LiquidWorld {
     /// commented out in `compute_substep` (:90-93).  `mode` 0 = off (one substep per step, the reference as it runs), 1 = the
     /// commented code literally, 2 = the same, cut at the remaining time.  Defaults of `TimestepManager::new`: 0.4, 1, 10.
     pub fn set_cfl_substepping(&mut self, mode: i32, cfl_coeff: Real, min_num_substeps: i32, max_num_substeps: i32) -> Result<(), Error> {
-        check(unsafe { ffi::salva_hip_set_cfl(self.raw, mode, cfl_coeff, min_num_substeps, max_num_substeps) })
+        check(unsafe { ffi::salva_hip_set_cfl(self.raw, mode, cfl_coeff, min_num_substeps, max_num_substeps) })?;
+        self.cfl_mode = mode;
+        Ok(())
+    }
+
+    /// 0 = one substep per step (the reference as it runs); see `set_cfl_substepping`.
+    pub fn cfl_mode(&self) -> i32 {
+        self.cfl_mode
     }
 
     /// Substep lengths of the last `step` (`counters.nsubsteps` of them).
     pub fn substeps(&self) -> Result<Vec<Real>, Error> {
-        let mut v = vec![0.0 as Real; 64];
-        let n = unsafe { ffi::salva_hip_get_substeps(self.raw, v.as_mut_ptr(), v.len() as u64) };
+        // (the count first: max_num_substeps is the caller's to choose)
+        let n = unsafe { ffi::salva_hip_get_substeps(self.raw, std::ptr::null_mut(), 0) };
         if n < 0 {
             check(n as i32)?;
         }
-        v.truncate((n as usize).min(64));
+        let mut v = vec![0.0 as Real; n as usize];
+        if n > 0 {
+            let m = unsafe { ffi::salva_hip_get_substeps(self.raw, v.as_mut_ptr(), v.len() as u64) };
+            if m < 0 {
+                check(m as i32)?;
+            }
+            v.truncate((m as usize).min(v.len()));
+        }
         Ok(v)
     }
 
@@ -427,6 +457,7 @@ impl LiquidWorld {
     /// `LiquidWorld::particles_intersecting_shape` (liquid_world.rs:245-280), generic over parry's `Shape` like the reference's:
     /// `shape.compute_aabb(pos)` and `shape.distance_to_point(pos, &pt, true)` stay on the host (the two callbacks of
     /// `salva_hip_particles_intersecting_host_shape`), the cell filter and the particle scan run on the device.
+    #[cfg(feature = "parry")]
     pub fn particles_intersecting_shape<S: ?Sized + parry3d::shape::Shape>(
         &mut self,
         pos: &na::Isometry3<Real>,

@@ -267,6 +267,23 @@ int salva_hip_force_get_state(SalvaHipWorld* world, uint32_t slot, float* positi
 /* `fluid.accelerations[i] += acc[i]` */
 int salva_hip_force_add_accelerations(SalvaHipWorld* world, uint32_t slot, const float* accelerations_xyz);
 
+/* ---- `CouplingManager` inside the substep loop (coupling_manager.rs:9-28; liquid_world.rs:85-147).
+ * `LiquidWorld::step_with_coupling` calls `coupling.update_boundaries(&timestep, h, r, &hgrid, fluids, boundaries)` at the top of
+ * EVERY substep (:94-103) and `coupling.transmit_forces(&timestep, boundaries)` at its end (:146); with one substep per step — the
+ * reference as it runs — a caller can do both around salva_hip_step (salva_hip_update_boundary_pose before, salva_hip_get_boundary_wrench
+ * after).  With salva_hip_set_cfl the substeps are chosen inside the solver, and the rapier manager applies each substep's impulse
+ * (force * timestep.dt(), fluids_pipeline.rs:266-287) to its bodies before the next substep samples their velocities
+ * (:160-193): one wrench per step cannot carry that.  A coupling callback puts the host back where the reference has it:
+ *   phase 0  = update_boundaries: at the top of every substep, before anything of the substep has run; `dt` = timestep.dt(), the
+ *              previous substep's length.  Call salva_hip_update_boundary_pose (which clears the boundary's forces, :262) here.
+ *   phase 1  = transmit_forces: the substep is complete, boundary forces are final; `dt` = the length of THIS substep.  Call
+ *              salva_hip_get_boundary_wrench (or salva_hip_get_boundary) and apply force * dt to the body.
+ * Inside either phase the pose / wrench / boundary read-back entry points are available; the fluids and the object sets must not
+ * be edited.  A non-zero return aborts the step with SALVA_HIP_E_INVALID.  With a callback registered the combination
+ * "CFL sub-stepping + coupled boundary that wants forces" is accepted; without one it stays refused.  NULL unregisters. */
+typedef int (*SalvaHipCouplingCallback)(void* user, SalvaHipWorld* world, int32_t phase, float dt);
+int salva_hip_set_coupling_callback(SalvaHipWorld* world, SalvaHipCouplingCallback cb, void* user);
+
 /* ---- Checkpoint / restart.  The state `LiquidWorld::step` carries from one call to the next is:
  * positions, velocities and volumes of every fluid (salva_hip_get_fluid / get_fluid_field(VOLUME)), the solver's
  * `velocity_changes` (dfsph_solver.rs:41, applied at the top of the next step) and, for IISPH, the `pressures` its Jacobi
@@ -315,8 +332,9 @@ int salva_hip_enable_counters(SalvaHipWorld* world, int32_t enabled);
  *   mode 2: the same, cut at the remaining time.
  * `counters.nsubsteps` counts the passes, the timers add up over them, the iteration counts and errors of SalvaHipStepStats are
  * the last pass's.  Plain boundaries accumulate reaction forces over the substeps as the reference's do; a COUPLED boundary that
- * wants forces is refused (SALVA_HIP_E_INVALID): the reference transmits its impulse per substep, which one wrench per step cannot
- * carry — run the substeps from the caller instead. */
+ * wants forces needs salva_hip_set_coupling_callback (the reference transmits its impulse per substep, which one wrench per step
+ * cannot carry) and is refused with SALVA_HIP_E_INVALID without one.
+ * In a decomposed run every rank must make the same call: the substep is chosen from an all-reduced maximum. */
 int salva_hip_set_cfl(SalvaHipWorld* world, int32_t mode, float cfl_coeff, int32_t min_num_substeps, int32_t max_num_substeps);
 /* Substep lengths of the last salva_hip_step (`TimestepManager::dt` of every pass): writes min(count, capacity) values, returns the
  * count (= counters.nsubsteps), or a negative error code. */

@@ -17,6 +17,7 @@
 #include <array>
 #include <cstdint>
 #include <memory>
+#include <exception>
 #include <stdexcept>
 #include <string>
 #include <functional>
@@ -409,12 +410,14 @@ class LiquidWorld {  // liquid_world.rs
     // reference as it runs: one substep per step), 1 = the commented code literally, 2 = the same, cut at the remaining time.
     void set_cfl_substepping(int mode = 1, float cfl_coeff = 0.4f, int min_num_substeps = 1, int max_num_substeps = 10) {
         check(salva_hip_set_cfl(w_, mode, cfl_coeff, min_num_substeps, max_num_substeps));
+        cfl_mode_ = mode;
     }
     std::vector<float> substeps() const {  // substep lengths of the last step
-        std::vector<float> v(64);
-        const int64_t n = salva_hip_get_substeps(w_, v.data(), v.size());
+        int64_t n = salva_hip_get_substeps(w_, nullptr, 0);  // (the count first: max_num_substeps is the caller's to choose)
         if (n < 0) check((int)n);
-        v.resize((size_t)std::min<int64_t>(n, 64));
+        std::vector<float> v((size_t)n);
+        if (n) n = salva_hip_get_substeps(w_, v.data(), v.size());
+        if (n < 0) check((int)n);
         return v;
     }
     SalvaHipCounters counters_tree() const {
@@ -560,6 +563,26 @@ class LiquidWorld {  // liquid_world.rs
     // LiquidWorld::step_with_coupling (liquid_world.rs:67-158): update_boundaries -> the substep -> transmit_forces
     void step_with_coupling(Real dt, const Vec3& gravity, CouplingManager& coupling) {
         for (size_t s = 0; s < boundaries_.size(); ++s) upload(boundaries_[s], (uint32_t)s);
+        if (cfl_mode_) {
+            // CFL sub-stepping: the manager's two calls belong inside the substep loop (liquid_world.rs:94-103, :146) — the library calls back
+            struct Ctx { LiquidWorld* w; CouplingManager* c; std::exception_ptr err; } ctx{this, &coupling, nullptr};
+            auto thunk = [](void* user, SalvaHipWorld*, int32_t phase, float sub_dt) -> int {
+                Ctx& x = *static_cast<Ctx*>(user);
+                try {
+                    if (phase == 0) x.c->update_boundaries(*x.w);
+                    else x.c->transmit_forces(*x.w, sub_dt);
+                    return 0;
+                } catch (...) { x.err = std::current_exception(); return 1; }  // (never unwind through C)
+            };
+            check(salva_hip_set_coupling_callback(w_, thunk, &ctx));
+            try { step(dt, gravity); } catch (...) {
+                salva_hip_set_coupling_callback(w_, nullptr, nullptr);
+                if (ctx.err) std::rethrow_exception(ctx.err);
+                throw;
+            }
+            salva_hip_set_coupling_callback(w_, nullptr, nullptr);
+            return;
+        }
         coupling.update_boundaries(*this);
         step(dt, gravity);
         coupling.transmit_forces(*this, dt);
@@ -743,6 +766,7 @@ class LiquidWorld {  // liquid_world.rs
     }
 
     SalvaHipWorld* w_ = nullptr;
+    int cfl_mode_ = 0;  // set_cfl_substepping
     Real particle_radius_;
     std::vector<Fluid> fluids_;
     std::vector<Boundary> boundaries_;

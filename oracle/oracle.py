@@ -106,6 +106,7 @@ def lib(native: bool = False):
         L.so_remove_boundary.argtypes = [vp, i32]
         L.so_set_boundary_particles.argtypes = [vp, i32, u64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.so_set_force_callback.argtypes = [vp, FORCE_CB, vp]
+        L.so_set_substep_callback.argtypes = [vp, SUBSTEP_CB, vp]
         L.so_num_forces.argtypes = [vp, i32]
         L.so_num_forces.restype = i32
         L.so_reference_would_panic.restype = i32
@@ -125,6 +126,7 @@ def lib(native: bool = False):
     return _libs[native]
 
 
+SUBSTEP_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double)
 FORCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                        C.POINTER(C.c_double), C.POINTER(C.c_double))
 
@@ -278,6 +280,16 @@ class OracleWorld:
         k = self._L.so_num_forces(self._h, fluid)
         self._L.so_add_force(self._h, fluid, FORCE_CUSTOM, _fp(p), 1)
         self._custom[(fluid, k)] = fn
+
+    def set_coupling_callback(self, fn):
+        """The `CouplingManager` of `step_with_coupling` (coupling_manager.rs:9-28): fn(phase, dt) is called inside every substep —
+        phase 0 where the reference calls `coupling.update_boundaries` (liquid_world.rs:94-103; dt = the last substep's), phase 1
+        where it calls `coupling.transmit_forces` (:146; dt = this substep's).  None unregisters."""
+        if fn is None:
+            self._substep_cb = SUBSTEP_CB()
+        else:
+            self._substep_cb = SUBSTEP_CB(lambda _user, phase, dt: fn(int(phase), float(dt)))
+        self._L.so_set_substep_callback(self._h, self._substep_cb, None)
 
     def reference_would_panic(self) -> bool:
         return bool(self._L.so_reference_would_panic(self._h))

@@ -436,6 +436,9 @@ struct World {
     R cfl_coeff = (R)0.4;
     int min_num_substeps = 1, max_num_substeps = 10;
     std::vector<double> substeps_of_last_step;
+    // CouplingManager::{update_boundaries, transmit_forces} inside the substep loop (coupling_manager.rs:9-28), driven by the host
+    void (*substep_cb)(void*, int, double) = nullptr;
+    void* substep_user = nullptr;
 
     // DFSPH parameters (dfsph_solver.rs:54-70) / IISPH (iisph_solver.rs:48-64)
     int min_pressure_iter = 1, max_pressure_iter = 50;
@@ -1755,6 +1758,8 @@ struct World {
             double ta = now_ms();
             grid.clear();
             insert_fluids_to_grid();
+            // coupling.update_boundaries(&timestep, ...) (liquid_world.rs:94-103): the host's manager, with timestep.dt() of the LAST substep
+            if (substep_cb) substep_cb(substep_user, 0, (double)dt);
             update_boundaries_dynamic();
             insert_boundaries_to_grid();
             double tb = now_ms();
@@ -1765,6 +1770,8 @@ struct World {
             double td = now_ms();
             compute_densities();
             if (solver_kind == 0) dfsph_step(gravity); else iisph_step(gravity);
+            // coupling.transmit_forces(&timestep, boundaries) (liquid_world.rs:146): timestep.dt() is now THIS substep's
+            if (substep_cb) substep_cb(substep_user, 1, (double)dt);
             double te = now_ms();
             stats.t_grid_ms += tb - ta; stats.t_contacts_ms += tc - tb;
             stats.t_kernels_ms += td - tc; stats.t_solver_ms += te - td;
@@ -2007,6 +2014,11 @@ void so_get_fluid_vec(void* p, int fluid, int field, double* out) {
 #undef GETV
 }
 // 1 if a step hit a code path on which the reference would panic (WCSPHSurfaceTension's boundary loop, see solve_wcsph_tension)
+// the coupling manager's two calls per substep: phase 0 = update_boundaries (dt of the last substep), 1 = transmit_forces (this substep's)
+void so_set_substep_callback(void* p, void (*cb)(void*, int, double), void* user) {
+    Handle* h = (Handle*)p;
+    DISPATCH(h, { w.substep_cb = cb; w.substep_user = user; }, { w.substep_cb = cb; w.substep_user = user; });
+}
 // user force callback for FORCE_CUSTOM entries (kind 7 of so_add_force)
 void so_set_force_callback(void* p, void (*cb)(void*, int, int, uint64_t, const double*, const double*, const double*, double*), void* user) {
     Handle* h = (Handle*)p;

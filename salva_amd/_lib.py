@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = [
     "salva_hip_comm_peer_abort", "salva_hip_comm_selftest", "salva_hip_comm_time", "salva_hip_clear_boundary_sampling", "salva_hip_get_fluid_async", "salva_hip_wait_download",
     "salva_hip_host_alloc", "salva_hip_host_free", "salva_hip_host_register", "salva_hip_host_unregister",
     "salva_hip_set_cfl", "salva_hip_get_substeps", "salva_hip_particles_intersecting_host_shape",
+    "salva_hip_set_coupling_callback",
     "salva_hip_get_dist_timing", "salva_hip_local_len", "salva_hip_get_local", "salva_hip_get_local_contacts", "salva_hip_force_add_local_accelerations",
 ]
 
@@ -70,6 +71,8 @@ class ForceDesc(C.Structure):
 
 # SalvaHipForceCallback (include/salva_hip.h)
 FORCE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float)
+# SalvaHipCouplingCallback: (user, world, phase, dt)
+COUPLING_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_float)
 
 
 class RigidPose(C.Structure):
@@ -216,6 +219,7 @@ def lib():
     L.salva_hip_get_boundary_particles.argtypes = [vp, u32, fp, fp]
     L.salva_hip_get_boundary_wrench.argtypes = [vp, u32, fp, fp, fp]
     L.salva_hip_set_force_callback.argtypes = [vp, FORCE_CALLBACK, vp]
+    L.salva_hip_set_coupling_callback.argtypes = [vp, COUPLING_CALLBACK, vp]
     L.salva_hip_force_get_state.argtypes = [vp, u32, fp, fp, fp]
     L.salva_hip_force_add_accelerations.argtypes = [vp, u32, fp]
     L.salva_hip_set_fluid_field.argtypes = [vp, u32, i32, fp]

@@ -4,13 +4,24 @@
 #include <string>
 
 #include <memory>
+#include <mutex>
 
 #include "world.h"
 
 using salva::World;
 
+// Every entry point that takes a world holds the world's lock for its duration: the `&self` methods of the salva3d API
+// (`particles_intersecting_aabb`, `fluids()`, `counters` ...) may be called from several threads at once — `LiquidWorld: Send + Sync` is
+// pinned by the reference's own test (/root/reference/src/liquid_world.rs:283-287), and a bevy `Res<FluidsPipeline>` is shared between
+// systems — while the C side keeps scratch buffers, a stream and lazily refreshed staging arrays per world.  Recursive: a force or
+// shape callback re-enters the library from inside salva_hip_step on the thread that holds the lock.
 struct SalvaHipWorld {
     World* w;
+    mutable std::recursive_mutex mu;
+};
+struct WorldLock {
+    std::unique_lock<std::recursive_mutex> l;
+    explicit WorldLock(const SalvaHipWorld* world) { if (world) l = std::unique_lock<std::recursive_mutex>(world->mu); }
 };
 
 static thread_local std::string g_last_error;
@@ -59,23 +70,27 @@ int salva_hip_create(const SalvaHipParams* params, SalvaHipWorld** out) {
         if (!params || !out) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
         *out = nullptr;
         World* w = new World(*params);
-        *out = new SalvaHipWorld{w};
+        *out = new SalvaHipWorld{w, {}};
         return SALVA_HIP_OK;
     });
 }
 
 void salva_hip_destroy(SalvaHipWorld* world) {
     if (!world) return;
-    try { delete world->w; } catch (...) {}
+    {   // (whoever still runs an entry point on another thread finishes first; using the world after this call is the caller's bug)
+        WorldLock _lk(world);
+        try { delete world->w; } catch (...) {}
+        world->w = nullptr;
+    }
     delete world;
 }
 
-float salva_hip_h(const SalvaHipWorld* world) { return world ? world->w->sc.h : 0.0f; }
+float salva_hip_h(const SalvaHipWorld* world) { WorldLock _lk(world); return world ? world->w->sc.h : 0.0f; }
 
 int salva_hip_set_fluid(SalvaHipWorld* world, uint32_t slot, uint64_t n, const float* positions_xyz,
                         const float* velocities_xyz, const float* volumes, const float* accelerations_xyz,
                         const float* velocity_changes_xyz, float density0, uint32_t memberships, uint32_t filter,
-                        uint32_t dirty_mask) {
+                        uint32_t dirty_mask) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -85,7 +100,7 @@ int salva_hip_set_fluid(SalvaHipWorld* world, uint32_t slot, uint64_t n, const f
     });
 }
 
-int salva_hip_set_fluid_forces(SalvaHipWorld* world, uint32_t slot, const SalvaHipForceDesc* forces, uint32_t nforces) {
+int salva_hip_set_fluid_forces(SalvaHipWorld* world, uint32_t slot, const SalvaHipForceDesc* forces, uint32_t nforces) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world || (nforces && !forces)) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
         not_in_force_callback(world);
@@ -94,7 +109,7 @@ int salva_hip_set_fluid_forces(SalvaHipWorld* world, uint32_t slot, const SalvaH
     });
 }
 
-int salva_hip_remove_fluid(SalvaHipWorld* world, uint32_t slot) {
+int salva_hip_remove_fluid(SalvaHipWorld* world, uint32_t slot) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -104,7 +119,7 @@ int salva_hip_remove_fluid(SalvaHipWorld* world, uint32_t slot) {
 }
 
 int salva_hip_set_boundary(SalvaHipWorld* world, uint32_t slot, uint64_t n, const float* positions_xyz,
-                           const float* velocities_xyz, uint32_t memberships, uint32_t filter, int32_t wants_forces) {
+                           const float* velocities_xyz, uint32_t memberships, uint32_t filter, int32_t wants_forces) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -113,7 +128,7 @@ int salva_hip_set_boundary(SalvaHipWorld* world, uint32_t slot, uint64_t n, cons
     });
 }
 
-int salva_hip_remove_boundary(SalvaHipWorld* world, uint32_t slot) {
+int salva_hip_remove_boundary(SalvaHipWorld* world, uint32_t slot) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -122,16 +137,16 @@ int salva_hip_remove_boundary(SalvaHipWorld* world, uint32_t slot) {
     });
 }
 
-uint32_t salva_hip_num_fluids(const SalvaHipWorld* world) { return world ? (uint32_t)world->w->fluids.size() : 0; }
-uint32_t salva_hip_num_boundaries(const SalvaHipWorld* world) { return world ? (uint32_t)world->w->bounds.size() : 0; }
-uint64_t salva_hip_fluid_len(const SalvaHipWorld* world, uint32_t slot) {
+uint32_t salva_hip_num_fluids(const SalvaHipWorld* world) { WorldLock _lk(world); return world ? (uint32_t)world->w->fluids.size() : 0; }
+uint32_t salva_hip_num_boundaries(const SalvaHipWorld* world) { WorldLock _lk(world); return world ? (uint32_t)world->w->bounds.size() : 0; }
+uint64_t salva_hip_fluid_len(const SalvaHipWorld* world, uint32_t slot) { WorldLock _lk(world);
     return (world && slot < world->w->fluids.size()) ? world->w->fluids[slot].n : 0;
 }
-uint64_t salva_hip_boundary_len(const SalvaHipWorld* world, uint32_t slot) {
+uint64_t salva_hip_boundary_len(const SalvaHipWorld* world, uint32_t slot) { WorldLock _lk(world);
     return (world && slot < world->w->bounds.size()) ? world->w->bounds[slot].n : 0;
 }
 
-int salva_hip_step(SalvaHipWorld* world, float dt, const float gravity[3], SalvaHipStepStats* stats) {
+int salva_hip_step(SalvaHipWorld* world, float dt, const float gravity[3], SalvaHipStepStats* stats) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world || !gravity) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
         not_in_force_callback(world);
@@ -139,7 +154,7 @@ int salva_hip_step(SalvaHipWorld* world, float dt, const float gravity[3], Salva
     });
 }
 
-int salva_hip_get_fluid(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) {
+int salva_hip_get_fluid(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -148,7 +163,7 @@ int salva_hip_get_fluid(SalvaHipWorld* world, uint32_t slot, float* positions_xy
     });
 }
 
-int salva_hip_get_fluid_field(SalvaHipWorld* world, uint32_t slot, int32_t field, float* out) {
+int salva_hip_get_fluid_field(SalvaHipWorld* world, uint32_t slot, int32_t field, float* out) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->get_fluid_field(slot, field, out);
@@ -156,7 +171,7 @@ int salva_hip_get_fluid_field(SalvaHipWorld* world, uint32_t slot, int32_t field
     });
 }
 
-int salva_hip_get_boundary(SalvaHipWorld* world, uint32_t slot, float* volumes, float* forces_xyz) {
+int salva_hip_get_boundary(SalvaHipWorld* world, uint32_t slot, float* volumes, float* forces_xyz) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->get_boundary(slot, volumes, forces_xyz);
@@ -165,7 +180,7 @@ int salva_hip_get_boundary(SalvaHipWorld* world, uint32_t slot, float* volumes, 
 }
 
 int salva_hip_set_boundary_sampling(SalvaHipWorld* world, uint32_t slot, uint64_t n, const float* local_points_xyz,
-                                    uint32_t memberships, uint32_t filter) {
+                                    uint32_t memberships, uint32_t filter) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -174,7 +189,7 @@ int salva_hip_set_boundary_sampling(SalvaHipWorld* world, uint32_t slot, uint64_
     });
 }
 
-int salva_hip_update_boundary_pose(SalvaHipWorld* world, uint32_t slot, const SalvaHipRigidPose* pose) {
+int salva_hip_update_boundary_pose(SalvaHipWorld* world, uint32_t slot, const SalvaHipRigidPose* pose) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         if (!pose) throw salva::HipError(SALVA_HIP_E_INVALID, "null pose");
@@ -185,7 +200,7 @@ int salva_hip_update_boundary_pose(SalvaHipWorld* world, uint32_t slot, const Sa
 }
 
 int salva_hip_set_boundary_dynamic_sampling(SalvaHipWorld* world, uint32_t slot, const SalvaHipShape* collider_shape,
-                                            uint32_t memberships, uint32_t filter) {
+                                            uint32_t memberships, uint32_t filter) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         if (!collider_shape) throw salva::HipError(SALVA_HIP_E_INVALID, "null shape");
@@ -196,7 +211,7 @@ int salva_hip_set_boundary_dynamic_sampling(SalvaHipWorld* world, uint32_t slot,
 }
 
 int salva_hip_set_boundary_dynamic_sampling_host(SalvaHipWorld* world, uint32_t slot, const SalvaHipHostShape* collider_shape,
-                                                 uint32_t memberships, uint32_t filter) {
+                                                 uint32_t memberships, uint32_t filter) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         if (!collider_shape) throw salva::HipError(SALVA_HIP_E_INVALID, "null shape");
@@ -206,16 +221,16 @@ int salva_hip_set_boundary_dynamic_sampling_host(SalvaHipWorld* world, uint32_t 
     });
 }
 
-int salva_hip_get_dist_timing(const SalvaHipWorld* world, double out4[4]) {
+int salva_hip_get_dist_timing(const SalvaHipWorld* world, double out4[4]) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world || !out4) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
         world->w->get_dist_timing(out4);
         return SALVA_HIP_OK;
     });
 }
-uint64_t salva_hip_local_len(const SalvaHipWorld* world) { return world ? world->w->local_len() : 0; }
+uint64_t salva_hip_local_len(const SalvaHipWorld* world) { WorldLock _lk(world); return world ? world->w->local_len() : 0; }
 int salva_hip_get_local(SalvaHipWorld* world, uint32_t* ids, uint32_t* fluid_slots, uint8_t* is_ghost, float* positions_xyz,
-                        float* velocities_xyz, float* densities, float* volumes) {
+                        float* velocities_xyz, float* densities, float* volumes) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->get_local(ids, fluid_slots, is_ghost, positions_xyz, velocities_xyz, densities, volumes);
@@ -223,7 +238,7 @@ int salva_hip_get_local(SalvaHipWorld* world, uint32_t* ids, uint32_t* fluid_slo
     });
 }
 int64_t salva_hip_get_local_contacts(SalvaHipWorld* world, int32_t boundary_contacts, uint64_t* offsets, uint32_t* j_model, uint32_t* j,
-                                     uint64_t capacity) {
+                                     uint64_t capacity) { WorldLock _lk(world);
     int64_t total = 0;
     const int rc = guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
@@ -232,14 +247,14 @@ int64_t salva_hip_get_local_contacts(SalvaHipWorld* world, int32_t boundary_cont
     });
     return rc == SALVA_HIP_OK ? total : (int64_t)rc;
 }
-int salva_hip_force_add_local_accelerations(SalvaHipWorld* world, const float* accelerations_xyz) {
+int salva_hip_force_add_local_accelerations(SalvaHipWorld* world, const float* accelerations_xyz) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->force_add_local_accelerations(accelerations_xyz);
         return SALVA_HIP_OK;
     });
 }
-int salva_hip_get_fluid_async(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) {
+int salva_hip_get_fluid_async(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -247,14 +262,14 @@ int salva_hip_get_fluid_async(SalvaHipWorld* world, uint32_t slot, float* positi
         return SALVA_HIP_OK;
     });
 }
-int salva_hip_wait_download(SalvaHipWorld* world) {
+int salva_hip_wait_download(SalvaHipWorld* world) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->wait_download();
         return SALVA_HIP_OK;
     });
 }
-void* salva_hip_host_alloc(SalvaHipWorld* world, uint64_t bytes) {
+void* salva_hip_host_alloc(SalvaHipWorld* world, uint64_t bytes) { WorldLock _lk(world);
     void* p = nullptr;
     const int rc = guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
@@ -270,7 +285,7 @@ int salva_hip_host_free(void* p) {
         return SALVA_HIP_OK;
     });
 }
-int salva_hip_host_register(SalvaHipWorld* world, void* p, uint64_t bytes) {
+int salva_hip_host_register(SalvaHipWorld* world, void* p, uint64_t bytes) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world || !p || !bytes) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
         SALVA_HIP_CHECK(hipSetDevice(world->w->prm.device));
@@ -285,7 +300,7 @@ int salva_hip_host_unregister(void* p) {
     });
 }
 
-int salva_hip_clear_boundary_sampling(SalvaHipWorld* world, uint32_t slot) {
+int salva_hip_clear_boundary_sampling(SalvaHipWorld* world, uint32_t slot) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -294,7 +309,7 @@ int salva_hip_clear_boundary_sampling(SalvaHipWorld* world, uint32_t slot) {
     });
 }
 
-int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t* fluid_slots, uint32_t* indices) {
+int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t* fluid_slots, uint32_t* indices) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->get_boundary_sources(slot, fluid_slots, indices);
@@ -302,7 +317,7 @@ int salva_hip_get_boundary_sources(SalvaHipWorld* world, uint32_t slot, uint32_t
     });
 }
 
-int salva_hip_set_force_callback(SalvaHipWorld* world, SalvaHipForceCallback cb, void* user) {
+int salva_hip_set_force_callback(SalvaHipWorld* world, SalvaHipForceCallback cb, void* user) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->set_force_callback(cb, user, world);
@@ -310,7 +325,16 @@ int salva_hip_set_force_callback(SalvaHipWorld* world, SalvaHipForceCallback cb,
     });
 }
 
-int salva_hip_force_get_state(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz, float* densities) {
+int salva_hip_set_coupling_callback(SalvaHipWorld* world, SalvaHipCouplingCallback cb, void* user) { WorldLock _lk(world);
+    return guarded([&]() -> int {
+        if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
+        not_in_force_callback(world);
+        world->w->set_coupling_callback(cb, user, world);
+        return SALVA_HIP_OK;
+    });
+}
+
+int salva_hip_force_get_state(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz, float* densities) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->force_get_state(slot, positions_xyz, velocities_xyz, densities);
@@ -318,7 +342,7 @@ int salva_hip_force_get_state(SalvaHipWorld* world, uint32_t slot, float* positi
     });
 }
 
-int salva_hip_force_add_accelerations(SalvaHipWorld* world, uint32_t slot, const float* accelerations_xyz) {
+int salva_hip_force_add_accelerations(SalvaHipWorld* world, uint32_t slot, const float* accelerations_xyz) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->force_add_accelerations(slot, accelerations_xyz);
@@ -326,7 +350,7 @@ int salva_hip_force_add_accelerations(SalvaHipWorld* world, uint32_t slot, const
     });
 }
 
-int salva_hip_set_fluid_field(SalvaHipWorld* world, uint32_t slot, int32_t field, const float* data) {
+int salva_hip_set_fluid_field(SalvaHipWorld* world, uint32_t slot, int32_t field, const float* data) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -335,13 +359,13 @@ int salva_hip_set_fluid_field(SalvaHipWorld* world, uint32_t slot, int32_t field
     });
 }
 
-int salva_hip_get_timestep(const SalvaHipWorld* world, float* dt, float* inv_dt) {
+int salva_hip_get_timestep(const SalvaHipWorld* world, float* dt, float* inv_dt) { WorldLock _lk(world);
     if (!world) return SALVA_HIP_E_INVALID;
     world->w->get_timestep(dt, inv_dt);
     return SALVA_HIP_OK;
 }
 
-int salva_hip_set_timestep(SalvaHipWorld* world, float dt, float inv_dt) {
+int salva_hip_set_timestep(SalvaHipWorld* world, float dt, float inv_dt) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -350,7 +374,7 @@ int salva_hip_set_timestep(SalvaHipWorld* world, float dt, float inv_dt) {
     });
 }
 
-int salva_hip_get_boundary_particles(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) {
+int salva_hip_get_boundary_particles(SalvaHipWorld* world, uint32_t slot, float* positions_xyz, float* velocities_xyz) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->get_boundary_particles(slot, positions_xyz, velocities_xyz);
@@ -358,7 +382,7 @@ int salva_hip_get_boundary_particles(SalvaHipWorld* world, uint32_t slot, float*
     });
 }
 
-int salva_hip_get_boundary_wrench(SalvaHipWorld* world, uint32_t slot, const float point[3], float force[3], float torque[3]) {
+int salva_hip_get_boundary_wrench(SalvaHipWorld* world, uint32_t slot, const float point[3], float force[3], float torque[3]) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         if (!point || !force || !torque) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
@@ -367,7 +391,7 @@ int salva_hip_get_boundary_wrench(SalvaHipWorld* world, uint32_t slot, const flo
     });
 }
 
-int salva_hip_clear_boundary_forces(SalvaHipWorld* world, uint32_t slot) {
+int salva_hip_clear_boundary_forces(SalvaHipWorld* world, uint32_t slot) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -376,9 +400,9 @@ int salva_hip_clear_boundary_forces(SalvaHipWorld* world, uint32_t slot) {
     });
 }
 
-uint64_t salva_hip_device_bytes(const SalvaHipWorld* world) { return world ? world->w->device_bytes() : 0; }
+uint64_t salva_hip_device_bytes(const SalvaHipWorld* world) { WorldLock _lk(world); return world ? world->w->device_bytes() : 0; }
 
-float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps) {
+float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps) { WorldLock _lk(world);
     float us = -1.0f;
     int rc = guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
@@ -388,7 +412,7 @@ float salva_hip_time_pred_density(SalvaHipWorld* world, int32_t reps) {
     return rc == SALVA_HIP_OK ? us : (float)rc;
 }
 
-float salva_hip_time_kernel(SalvaHipWorld* world, int32_t kernel, int32_t reps) {
+float salva_hip_time_kernel(SalvaHipWorld* world, int32_t kernel, int32_t reps) { WorldLock _lk(world);
     float us = -1.0f;
     int rc = guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
@@ -398,21 +422,21 @@ float salva_hip_time_kernel(SalvaHipWorld* world, int32_t kernel, int32_t reps) 
     return rc == SALVA_HIP_OK ? us : (float)rc;
 }
 
-int salva_hip_enable_counters(SalvaHipWorld* world, int32_t enabled) {
+int salva_hip_enable_counters(SalvaHipWorld* world, int32_t enabled) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->set_timers(enabled != 0);
         return SALVA_HIP_OK;
     });
 }
-int salva_hip_set_cfl(SalvaHipWorld* world, int32_t mode, float cfl_coeff, int32_t min_num_substeps, int32_t max_num_substeps) {
+int salva_hip_set_cfl(SalvaHipWorld* world, int32_t mode, float cfl_coeff, int32_t min_num_substeps, int32_t max_num_substeps) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->set_cfl(mode, cfl_coeff, min_num_substeps, max_num_substeps);
         return SALVA_HIP_OK;
     });
 }
-int64_t salva_hip_get_substeps(const SalvaHipWorld* world, float* out, uint64_t capacity) {
+int64_t salva_hip_get_substeps(const SalvaHipWorld* world, float* out, uint64_t capacity) { WorldLock _lk(world);
     int64_t n = 0;
     int rc = guarded([&]() -> int {
         if (!world || (!out && capacity)) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
@@ -423,7 +447,7 @@ int64_t salva_hip_get_substeps(const SalvaHipWorld* world, float* out, uint64_t 
     });
     return rc == SALVA_HIP_OK ? n : (int64_t)rc;
 }
-int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out) {
+int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world || !out) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
         *out = world->w->counters;
@@ -433,7 +457,7 @@ int salva_hip_get_counters(const SalvaHipWorld* world, SalvaHipCounters* out) {
 
 #ifdef SALVA_HIP_DIAG
 // kernel experiments (declared in diag/salva_hip_diag.h; `make VARIANT=diag` only — not an entry point of libsalva_hip.so)
-float salva_hip_time_variant(SalvaHipWorld* world, int32_t variant, uint32_t param, int32_t reps, uint64_t* checksum) {
+float salva_hip_time_variant(SalvaHipWorld* world, int32_t variant, uint32_t param, int32_t reps, uint64_t* checksum) { WorldLock _lk(world);
     float us = -1.0f;
     int rc = guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
@@ -556,7 +580,7 @@ int salva_hip_comm_time(SalvaHipComm* comm, uint64_t bytes, int32_t iters, float
         return SALVA_HIP_OK;
     });
 }
-int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_lo, int32_t cell_hi, uint32_t gid_offset) {
+int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_lo, int32_t cell_hi, uint32_t gid_offset) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world || !comm) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
         not_in_force_callback(world);
@@ -564,7 +588,7 @@ int salva_hip_set_domain(SalvaHipWorld* world, SalvaHipComm* comm, int32_t cell_
         return SALVA_HIP_OK;
     });
 }
-int salva_hip_rebalance(SalvaHipWorld* world, int32_t* cell_lo, int32_t* cell_hi) {
+int salva_hip_rebalance(SalvaHipWorld* world, int32_t* cell_lo, int32_t* cell_hi) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->rebalance(cell_lo, cell_hi);
@@ -572,7 +596,7 @@ int salva_hip_rebalance(SalvaHipWorld* world, int32_t* cell_lo, int32_t* cell_hi
     });
 }
 int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* gids, float* positions_xyz, float* velocities_xyz,
-                            uint32_t* fluid_slots) {
+                            uint32_t* fluid_slots) { WorldLock _lk(world);
     int64_t count = 0;
     const int rc = guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
@@ -582,7 +606,7 @@ int64_t salva_hip_get_owned(SalvaHipWorld* world, uint32_t capacity, uint32_t* g
     return rc == SALVA_HIP_OK ? count : (int64_t)rc;
 }
 
-int64_t salva_hip_delete_owned(SalvaHipWorld* world, uint32_t n, const uint32_t* gids) {
+int64_t salva_hip_delete_owned(SalvaHipWorld* world, uint32_t n, const uint32_t* gids) { WorldLock _lk(world);
     int64_t count = 0;
     const int rc = guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
@@ -594,7 +618,7 @@ int64_t salva_hip_delete_owned(SalvaHipWorld* world, uint32_t n, const uint32_t*
 }
 
 int64_t salva_hip_particles_intersecting_aabb(SalvaHipWorld* world, const float mins[3], const float maxs[3], uint64_t capacity,
-                                             uint32_t* kinds, uint32_t* slots, uint32_t* indices) {
+                                             uint32_t* kinds, uint32_t* slots, uint32_t* indices) { WorldLock _lk(world);
     int64_t total = 0;
     const int rc = guarded([&]() -> int {
         if (!world || !mins || !maxs) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
@@ -605,7 +629,7 @@ int64_t salva_hip_particles_intersecting_aabb(SalvaHipWorld* world, const float 
 }
 int64_t salva_hip_particles_intersecting_shape(SalvaHipWorld* world, const float translation[3], const float rotation_ijkw[4],
                                               const SalvaHipShape* shape, uint64_t capacity, uint32_t* kinds, uint32_t* slots,
-                                              uint32_t* indices) {
+                                              uint32_t* indices) { WorldLock _lk(world);
     int64_t total = 0;
     const int rc = guarded([&]() -> int {
         if (!world || !translation || !rotation_ijkw || !shape) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
@@ -615,7 +639,7 @@ int64_t salva_hip_particles_intersecting_shape(SalvaHipWorld* world, const float
     return rc == SALVA_HIP_OK ? total : (int64_t)rc;
 }
 int64_t salva_hip_particles_intersecting_host_shape(SalvaHipWorld* world, const SalvaHipHostQueryShape* shape, uint64_t capacity,
-                                                    uint32_t* kinds, uint32_t* slots, uint32_t* indices) {
+                                                    uint32_t* kinds, uint32_t* slots, uint32_t* indices) { WorldLock _lk(world);
     int64_t total = 0;
     const int rc = guarded([&]() -> int {
         if (!world || !shape) throw salva::HipError(SALVA_HIP_E_INVALID, "null argument");
@@ -625,7 +649,7 @@ int64_t salva_hip_particles_intersecting_host_shape(SalvaHipWorld* world, const 
     });
     return rc == SALVA_HIP_OK ? total : (int64_t)rc;
 }
-int salva_hip_add_particles(SalvaHipWorld* world, uint32_t slot, uint64_t n_add, const float* positions_xyz, const float* velocities_xyz) {
+int salva_hip_add_particles(SalvaHipWorld* world, uint32_t slot, uint64_t n_add, const float* positions_xyz, const float* velocities_xyz) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         not_in_force_callback(world);
@@ -633,7 +657,7 @@ int salva_hip_add_particles(SalvaHipWorld* world, uint32_t slot, uint64_t n_add,
         return SALVA_HIP_OK;
     });
 }
-int64_t salva_hip_delete_particles(SalvaHipWorld* world, uint32_t slot, const uint8_t* deleted_mask) {
+int64_t salva_hip_delete_particles(SalvaHipWorld* world, uint32_t slot, const uint8_t* deleted_mask) { WorldLock _lk(world);
     int64_t kept = 0;
     const int rc = guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
@@ -645,7 +669,7 @@ int64_t salva_hip_delete_particles(SalvaHipWorld* world, uint32_t slot, const ui
 }
 
 int64_t salva_hip_get_fluid_contacts(SalvaHipWorld* world, uint32_t slot, int32_t boundary_contacts, uint64_t* offsets,
-                                     uint32_t* j_model, uint32_t* j, uint64_t capacity) {
+                                     uint32_t* j_model, uint32_t* j, uint64_t capacity) { WorldLock _lk(world);
     int64_t total = 0;
     const int rc = guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
@@ -655,7 +679,7 @@ int64_t salva_hip_get_fluid_contacts(SalvaHipWorld* world, uint32_t slot, int32_
     return rc == SALVA_HIP_OK ? total : (int64_t)rc;
 }
 
-int salva_hip_get_force_stats(SalvaHipWorld* world, uint32_t slot, uint32_t force, int32_t* iters, float* error) {
+int salva_hip_get_force_stats(SalvaHipWorld* world, uint32_t slot, uint32_t force, int32_t* iters, float* error) { WorldLock _lk(world);
     return guarded([&]() -> int {
         if (!world) throw salva::HipError(SALVA_HIP_E_INVALID, "null world");
         world->w->get_force_stats(slot, force, iters, error);

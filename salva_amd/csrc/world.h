@@ -97,6 +97,8 @@ class World {
     void force_get_state(uint32_t slot, float* positions, float* velocities, float* densities);
     void force_add_accelerations(uint32_t slot, const float* acc);
     bool in_force_callback() const { return in_force_cb; }
+    // CouplingManager::update_boundaries / transmit_forces inside the substep loop (include/salva_hip.h, salva_hip_set_coupling_callback)
+    void set_coupling_callback(SalvaHipCouplingCallback cb, void* user, SalvaHipWorld* owner) { coupling_cb = cb; coupling_user = user; coupling_owner = owner; }
     void set_fluid_field(uint32_t slot, int field, const float* data);
     void get_timestep(float* dt, float* inv_dt) const { if (dt) *dt = dt_prev; if (inv_dt) *inv_dt = inv_dt_prev; }
     void set_timestep(float dt, float inv_dt) { dt_prev = dt; inv_dt_prev = inv_dt; }
@@ -261,6 +263,9 @@ class World {
     DevBuf<uint32_t> tile_mass_bits, tile_massb_bits, nffb;
     bool two_mass_off = false;    // SALVA_HIP_NO_TWO_MASS=1 (A/B, tests): such a world keeps the general kernels
     bool fold_off = false;        // SALVA_HIP_NO_FOLD=1: the fluid grid is never folded (device_types.h TileGrid)
+    struct FoldRetry {};          // thrown by substep when the tile totals show a fold that piled the bulk onto itself (World::step retries)
+    uint32_t fold_relax = 0;      // how often that happened: the fold rule is loosened eightfold per level, given up at 3
+    bool fold_locked = false;     // the looser fold did not fit the cell-table budget: keep the tighter one
     uint32_t fold_forced = 0;     // SALVA_HIP_FOLD_CELLS=P: every axis longer than P cells is folded to exactly P (tests)
     bool two_mass = false;        // this step runs that way
     uint32_t two_mass_bmask = 0;  // fluids with the heavier mass
@@ -379,6 +384,10 @@ class World {
     void* force_user = nullptr;
     SalvaHipWorld* force_owner = nullptr;
     bool in_force_cb = false;
+    SalvaHipCouplingCallback coupling_cb = nullptr;
+    void* coupling_user = nullptr;
+    SalvaHipWorld* coupling_owner = nullptr;
+    void call_coupling(int phase, float dt);
     float dt_prev = 0.0f, inv_dt_prev = 0.0f;  // TimestepManager::{dt, inv_dt} persist across steps (timestep_manager.rs:23-34)
     StepCtx last_ctx{};
     float last_dt = 0.0f;

@@ -1398,6 +1398,7 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
         counters.chained_passes = keep4[0]; counters.chain_breaks = keep4[1]; counters.pregrid_adopted = keep4[2]; counters.pregrid_dropped = keep4[3];
     }
     sticky.clear();  // init_with_fluids runs at the top of every step, substeps or not (liquid_world.rs:76)
+    substeps.clear();  // (also for a step that runs no substep at all: salva_hip_get_substeps then agrees with counters.nsubsteps = 0)
     // TimestepManager::is_done (timestep_manager.rs:56-58): no substep at all for dt <= eps
     if ((n == 0 && !comm) || !(dt > FLT_EPSILON)) {
         if (stats) *stats = st;
@@ -1414,19 +1415,24 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     step_remaining = dt;
     if (cfl_mode) {
         upload_tables();  // (any_wants_forces)
-        if (any_wants_forces)
+        if (any_wants_forces && !coupling_cb)
             for (const BoundarySlot& b : bounds)
                 if (b.wants_forces && (b.sampling || b.dyn_kind))
                     // the reference clears a coupled boundary's forces and transmits their impulse in EVERY substep with that substep's
                     // dt (fluids_pipeline.rs:262, :266-287): one wrench per step() cannot carry that.  The caller's own loop can.
-                    throw HipError(SALVA_HIP_E_INVALID, "CFL sub-stepping with a coupled boundary that wants forces: run the substeps from the caller "
-                                                        "(update_boundaries / step / transmit_forces per substep), or switch salva_hip_set_cfl off");
+                    throw HipError(SALVA_HIP_E_INVALID, "CFL sub-stepping with a coupled boundary that wants forces needs salva_hip_set_coupling_callback "
+                                                        "(update_boundaries / transmit_forces per substep, as the reference's manager does), or salva_hip_set_cfl off");
     }
     while (!(step_remaining <= FLT_EPSILON)) {  // is_done, timestep_manager.rs:56-58
         float used = dt;
         int rc;
         try {
-            rc = substep(used, g, st);
+            call_coupling(0, dt_prev);  // coupling.update_boundaries(&timestep, ...) (liquid_world.rs:94-103): dt() is the last substep's
+            for (;;) {
+                try { rc = substep(used, g, st); break; }
+                catch (const FoldRetry&) { used = dt; pre.valid = false; flags_clean = false; }  // (the grid changes: again from the top)
+            }
+            if (rc == SALVA_HIP_OK) call_coupling(1, used);  // coupling.transmit_forces(&timestep, boundaries) (:146): this substep's dt
         } catch (...) {
             if (stats) *stats = st;  // (what the failed substep got to: the caller's report is filled either way)
             throw;
@@ -1490,6 +1496,12 @@ void World::pre_drop() {
     SALVA_HIP_CHECK(hipMemsetAsync(mass_slots.p, 0, MASS_SLOTS * sizeof(uint32_t), stream));
 }
 
+void World::call_coupling(int phase, float dt) {
+    if (!coupling_cb) return;
+    if (coupling_cb(coupling_user, coupling_owner, phase, dt) != 0)
+        throw HipError(SALVA_HIP_E_INVALID, "the coupling callback reported an error");
+}
+
 // One substep: the body of the `while` of LiquidWorld::step_with_coupling (liquid_world.rs:85-147).  `dt` comes in as the step's
 // total length and goes out as the substep the solver advanced by.
 int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
@@ -1548,12 +1560,17 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     // sampling (dcs.hip decodes cell coordinates from the keys).  SALVA_HIP_NO_FOLD=1: never; SALVA_HIP_FOLD_CELLS=P: every axis
     // longer than P cells to exactly P (a power of two >= 8; the tests' way to fold small scenes).
     {
-        const uint32_t forced = fold_forced;
-        const bool can_fold = !fold_off && !comm && !has_dynamic_sampling();
+        // (fold_relax: a fold that piled the bulk of the fluid onto itself — the rule below looks at the box, not at where the particles
+        // sit — was found out by the tile totals of an earlier attempt, which then threw FoldRetry: every level loosens the fold
+        // eightfold, the third gives it up.  Sticky for the world.)
+        const uint32_t forced = fold_forced ? fold_forced << (2u * std::min(fold_relax, 3u)) : 0u;
+        constexpr bool tiles_pow2 = (TX & (TX - 1)) == 0 && (TY & (TY - 1)) == 0 && (TZ & (TZ - 1)) == 0;  // (a period is a whole number of tiles)
+        const bool can_fold = tiles_pow2 && !fold_off && !comm && !has_dynamic_sampling() && fold_relax < 3u;
         if (can_fold && nb && b_dirty) build_boundary_grid();
         // (once it folds, it folds tight — to half a cell per particle if the periods allow: the particles that have left the scene
         // then land on the tiles of the bulk instead of owning a tile each; a tile with one particle costs a quarter of a full one)
-        FoldRule rule{forced ? 0.0 : 4.0 * (double)n + 1048576.0, forced ? 0.0 : std::max(0.5 * (double)n, 262144.0),
+        const double loosen = (double)(1u << (3u * std::min(fold_relax, 3u)));
+        FoldRule rule{forced ? 0.0 : 4.0 * (double)n + 1048576.0, forced ? 0.0 : std::max(0.5 * (double)n, 262144.0) * loosen,
                       {forced ? forced : 64u, forced ? forced : 64u, forced ? forced : 64u}};
         if (nb)
             for (int a = 0; a < 3; ++a) {
@@ -1561,7 +1578,14 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
                 const uint64_t bcells = (uint64_t)gb.nt[a] * T[a];
                 while (rule.min_period[a] < bcells) rule.min_period[a] *= 2u;
             }
-        dims_from_bbox(h_rb->bbox, gf, can_fold ? &rule : nullptr);
+        try {
+            dims_from_bbox(h_rb->bbox, gf, can_fold ? &rule : nullptr);
+        } catch (const HipError& e) {
+            // the looser fold does not fit the cell-table budget: back to the tighter one, and live with what its tiles hold
+            if (e.code != SALVA_HIP_E_CAPACITY || fold_relax == 0u || fold_locked) throw;
+            --fold_relax; fold_locked = true;
+            throw FoldRetry{};
+        }
     }
     const size_t ncf = gf.ncells();
     const uint32_t ntiles = (uint32_t)gf.ntiles();
@@ -1787,6 +1811,17 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
 #ifdef SALVA_HIP_DIAG
         if (const char* e = getenv("SALVA_HIP_TILE_THREADS")) lds.threads = (uint32_t)atoi(e);
 #endif
+        if (gf.folded() && !fold_locked && !spec) {
+            // Did the fold pile the fluid onto itself?  (a long sheet of fluid without an enclosing boundary folds onto its
+            // own bulk, cells hold several times the particles, and a scene that ran fine on the unfolded table dies of "halo does
+            // not fit".)  The totals say so before any solver kernel has run: loosen the fold and run the pass again — the
+            // particle arrays are merely permuted so far.
+            TileLds probe; probe.max_halo_fluid = tt.max_s; probe.max_halo_boundary = tt.max_sb; probe.max_sum = tt.max_sum;
+            if (tt.max_s >= 65536u || tt.max_sb >= 65536u || probe.bytes(52, 32, 6) > 160u * 1024u) {
+                ++fold_relax;
+                throw FoldRetry{};
+            }
+        }
         if (lds.max_halo_fluid >= 65536u || lds.max_halo_boundary >= 65536u)
             throw HipError(SALVA_HIP_E_CAPACITY, "more than 65535 particles in one tile halo");
         if (tt.nsl > ns_cap) throw HipError(SALVA_HIP_E_HIP, "internal error: slice count exceeds its bound");

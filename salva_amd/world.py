@@ -1128,19 +1128,27 @@ class LiquidWorld:
         reference's commented clamp, literally (the last substep may overshoot the step).  mode 2: the same, cut at the remaining
         time.  The defaults are `TimestepManager::new`'s (timestep_manager.rs:23-34)."""
         L.check(self._L.salva_hip_set_cfl(self._h, int(mode), float(cfl_coeff), int(min_num_substeps), int(max_num_substeps)))
+        self._cfl_mode = int(mode)
 
     def substeps(self):
         """Substep lengths of the last step (`counters.nsubsteps` of them)."""
-        buf = (C.c_float * 64)()
-        n = self._L.salva_hip_get_substeps(self._h, buf, 64)
+        n = int(self._L.salva_hip_get_substeps(self._h, None, 0))  # (the count first: max_num_substeps is the caller's to choose)
         if n < 0:
-            L.check(int(n))
-        return [float(buf[i]) for i in range(min(int(n), 64))]
+            L.check(n)
+        buf = (C.c_float * max(n, 1))()
+        n = int(self._L.salva_hip_get_substeps(self._h, buf, max(n, 1)))
+        if n < 0:
+            L.check(n)
+        return [float(buf[i]) for i in range(n)]
 
     def step_with_coupling(self, dt: float, gravity, coupling) -> L.StepStats:
         """LiquidWorld::step_with_coupling (liquid_world.rs:67-158) for a `salva_amd.coupling.ColliderCouplingSet`:
         update_boundaries -> the substep -> transmit_forces."""
         self.sync_to_device()
+        if getattr(self, "_cfl_mode", 0):
+            # CFL sub-stepping: the manager's two calls belong INSIDE the substep loop (liquid_world.rs:94-103, :146) — each substep's
+            # impulse reaches the bodies before the next substep samples their velocities.  The library calls back at both points.
+            return self._step_with_coupling_callback(dt, gravity, coupling)
         coupling.update_boundaries(self)
         try:
             st = self.step(dt, gravity)
@@ -1150,6 +1158,34 @@ class LiquidWorld:
             if hasattr(coupling, "raise_pending"):
                 coupling.raise_pending()
         coupling.transmit_forces(self, dt)
+        return st
+
+    def _step_with_coupling_callback(self, dt: float, gravity, coupling) -> L.StepStats:
+        errors = []
+
+        def callback(_user, _world, phase, sub_dt):
+            try:
+                if phase == 0:
+                    coupling.update_boundaries(self)
+                else:
+                    coupling.transmit_forces(self, float(sub_dt))
+                return 0
+            except BaseException as e:  # noqa: BLE001 - ctypes cannot propagate it: park it, fail the step
+                errors.append(e)
+                return 1
+
+        cb = L.COUPLING_CALLBACK(callback)
+        L.check(self._L.salva_hip_set_coupling_callback(self._h, cb, None))
+        try:
+            st = self.step(dt, gravity)
+        except Exception:
+            if errors:
+                raise errors[0]
+            raise
+        finally:
+            self._L.salva_hip_set_coupling_callback(self._h, L.COUPLING_CALLBACK(), None)
+            if hasattr(coupling, "raise_pending"):
+                coupling.raise_pending()
         return st
 
     # ---- multi-GPU (no counterpart in the reference; include/salva_hip.h "multi-GPU")

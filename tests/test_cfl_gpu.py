@@ -125,9 +125,103 @@ def test_cfl_is_off_by_default_and_can_be_switched_off_again():
         w1.set_cfl_substepping(1, 0.4, 3, 2)
 
 
-def test_cfl_refuses_coupled_boundaries_that_want_forces():
-    """The reference transmits a coupled collider's impulse per substep (fluids_pipeline.rs:266-287): one wrench per step() cannot
-    carry that, so the combination is refused instead of answered wrongly."""
+def _raft_scene():
+    """A stirred block dropped onto a light dynamic raft (two layers of collider-local samples, StaticSampling) beside a kinematic
+    paddle: the raft wants forces, and every substep's impulse changes the velocity its boundary particles take in the next."""
+    from salva_amd.coupling import RigidBody
+
+    pos = scenes.jitter(scenes.cube_fluid_positions(10, 12, 10, R), 0.05 * R, seed=11)
+    pos[:, 1] += np.float32(float(-pos[:, 1].min()) + 4 * R)  # its lowest layer two diameters above the raft's upper one
+    vel = scenes.random_velocities(len(pos), 0.1, seed=12)
+    vel[:, 1] -= np.float32(2.5)  # fast enough for the CFL bound to cut a frame-sized step
+    raft_pts = scenes.plane_lattice(16, 16, 0.0, R, -16 * R + R, -16 * R + R, layers=2)
+    paddle_pts = scenes.plane_lattice(3, 8, 0.0, R, -3 * R + R, -8 * R + R, layers=1)[:, [0, 2, 1]]
+    raft = RigidBody(translation=np.float32([10 * R, 0.0, 10 * R]), mass=1.5, principal_inertia=np.float32([0.02, 0.04, 0.02]),
+                     local_com=np.float32([0.0, -R, 0.0]))
+    paddle = RigidBody(translation=np.float32([10 * R, 40 * R, 10 * R]), angvel=np.float32([0.0, 4.0, 0.0]), dynamic=False)
+    return pos, vel, raft_pts, paddle_pts, raft, paddle
+
+
+def test_cfl_substepping_with_a_force_transmitting_collider():
+    """`coupling.update_boundaries` and `coupling.transmit_forces` run INSIDE the substep loop in the reference (liquid_world.rs:94-103,
+    :146; fluids_pipeline.rs:160-193, 266-287): the impulse of one substep (force * that substep's dt) reaches the body before the next
+    substep samples its velocity.  salva_hip_set_coupling_callback puts the host at the same two points of every substep; the oracle
+    has the same hook.  Same bodies, same frame-sized steps, CFL mode 1: the substep COUNTS agree step by step, and the raft ends up
+    where the oracle's does."""
+    import copy
+
+    from oracle import oracle as O
+    from salva_amd import Boundary, DFSPHSolver, Fluid, LiquidWorld, XSPHViscosity
+    from salva_amd.coupling import ColliderCouplingSet, StaticSampling
+
+    nsteps = 8
+
+    def run_oracle():
+        pos, vel, raft_pts, paddle_pts, raft, paddle = _raft_scene()
+        w = O.OracleWorld(R, 2.0, O.DFSPH)
+        f = w.add_fluid(pos, 1000.0, vel)
+        w.add_xsph(f, 0.5, 0.5)
+        empty = np.zeros((0, 3), np.float32)
+        bodies = [raft, paddle]
+        for pts in (raft_pts, paddle_pts):
+            w.set_boundary_sampling(w.add_boundary(empty), pts)
+        w.set_cfl(1, 0.4, 1, 10)
+        impulses = []
+
+        def manager(phase, dt):
+            for b, body in enumerate(bodies):
+                if phase == 0:
+                    w.update_boundary_pose(b, body.translation, body.rotation, body.linvel, body.angvel, body.center_of_mass(), True, body.is_dynamic())
+                elif body.is_dynamic():
+                    F, T = w.boundary_wrench(b, body.center_of_mass())
+                    body.apply_impulse(np.float32(F) * np.float32(dt))
+                    body.apply_torque_impulse(np.float32(T) * np.float32(dt))
+                    impulses.append(float(np.linalg.norm(F)) * dt)
+
+        w.set_coupling_callback(manager)
+        subs = []
+        for _ in range(nsteps):
+            w.step(DT, GRAVITY)
+            subs.append(w.substeps())
+            for body in bodies:
+                body.integrate(DT, (0.0, 0.0, 0.0))  # (the raft only feels the fluid)
+        return w.fluid_vec(f, "positions"), copy.deepcopy(raft), subs, impulses
+
+    def run_hip():
+        pos, vel, raft_pts, paddle_pts, raft, paddle = _raft_scene()
+        w = LiquidWorld(DFSPHSolver(), R, 2.0)
+        fl = Fluid(pos, R, 1000.0)
+        fl.velocities = vel
+        fl.nonpressure_forces.append(XSPHViscosity(0.5, 0.5))
+        h = w.add_fluid(fl)
+        c = ColliderCouplingSet()
+        c.register_coupling(w.add_boundary(Boundary(np.zeros((0, 3), np.float32))), "raft", raft, StaticSampling(raft_pts))
+        c.register_coupling(w.add_boundary(Boundary(np.zeros((0, 3), np.float32))), "paddle", paddle, StaticSampling(paddle_pts))
+        w.set_cfl_substepping(1)
+        subs = []
+        for _ in range(nsteps):
+            w.step_with_coupling(DT, GRAVITY, c)
+            subs.append(w.substeps())
+            for body in (raft, paddle):
+                body.integrate(DT, (0.0, 0.0, 0.0))
+        return h.positions.copy(), copy.deepcopy(raft), subs
+
+    opos, oraft, osubs, oimp = run_oracle()
+    hpos, hraft, hsubs = run_hip()
+    assert max(len(s) for s in osubs) >= 3 and sum(oimp) > 0  # the steps were cut, and the raft was pushed in between
+    assert [len(s) for s in hsubs] == [len(s) for s in osubs], (hsubs, osubs)
+    for a, b in zip(hsubs, osubs):
+        assert np.allclose(a, b, rtol=2e-3, atol=1e-6), (a, b)
+    assert abs(oraft.linvel[1]) > 0.05  # it moved
+    assert np.abs(hraft.linvel - oraft.linvel).max() <= 2e-3 * max(1.0, float(np.abs(oraft.linvel).max())), (hraft.linvel, oraft.linvel)
+    assert np.abs(hraft.angvel - oraft.angvel).max() <= 5e-3 * max(1.0, float(np.abs(oraft.angvel).max())), (hraft.angvel, oraft.angvel)
+    assert np.abs(hraft.translation - oraft.translation).max() <= 1e-4
+    assert max_norm_diff(hpos, opos) / R <= 2e-2  # (eight frames through an impact: rounding-level drift of a chaotic splash)
+
+
+def test_cfl_with_a_coupled_boundary_needs_the_callback():
+    """Without salva_hip_set_coupling_callback one wrench per step() cannot carry what the reference transmits per substep: the raw
+    combination stays refused (the Python and C++ mirrors' step_with_coupling register the callback themselves)."""
     from salva_amd import Boundary, DFSPHSolver, Fluid, LiquidWorld
     from salva_amd.coupling import ColliderCouplingSet, RigidBody, StaticSampling
 
@@ -137,8 +231,10 @@ def test_cfl_refuses_coupled_boundaries_that_want_forces():
     c = ColliderCouplingSet()
     c.register_coupling(b, "raft", RigidBody(translation=np.float32([0, 0, 0]), mass=1.0, principal_inertia=np.float32([1, 1, 1])),
                         StaticSampling(scenes.plane_lattice(8, 8, 0.0, R, -8 * R, -8 * R, layers=1)))
-    w.set_cfl_substepping(1)
-    with pytest.raises(_lib.SalvaHipError, match="substep"):
-        w.step_with_coupling(DT, GRAVITY, c)
     w.set_cfl_substepping(0)
-    w.step_with_coupling(DT, GRAVITY, c)
+    w.step_with_coupling(DT, GRAVITY, c)  # (uploads the sampling, marks the boundary as wanting forces)
+    w.set_cfl_substepping(1)
+    with pytest.raises(_lib.SalvaHipError, match="coupling_callback"):
+        w.step(DT, GRAVITY)
+    w.step_with_coupling(DT, GRAVITY, c)  # with the manager in the loop it runs
+    assert w.counters.nsubsteps >= 1
