@@ -16,6 +16,7 @@ struct DcsParams {
     float margin;         // particle_radius * 0.1 (:194)
     float reach;          // h + prediction (:234)
     float eps;            // f32::default_epsilon() (:223)
+    float h;              // cell width (on a folded grid the cell a key names is one of several images: the position says which)
 };
 
 // number of parameters of a built-in collider shape (include/salva_hip.h); throws SALVA_HIP_E_INVALID for any other kind

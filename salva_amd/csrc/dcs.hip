@@ -45,12 +45,21 @@ __device__ __forceinline__ void quat_rot(float qx, float qy, float qz, float qw,
 }
 
 // the cell the particle was inserted under (hgrid.rs:122-133 filters CELLS by the box, then :211 tests the prediction)
-__device__ __forceinline__ bool dcs_in_cells(uint32_t k, const TileGrid& g, const DcsParams& s) {
+// On a FOLDED grid (device_types.h TileGrid; round 6: worlds with dynamically sampled colliders fold too) the key names the cell modulo
+// the axis' period: the image is the one nearest to where the particle is now — an earlier collider of this pass may have pushed it, by
+// a fraction of a cell; the periods are at least 64 cells.
+__device__ __forceinline__ int dcs_unfold(int rel, uint32_t mask, float x, float h, int origin) {
+    if (mask == 0xffffffffu) return origin + rel;
+    bool bad = false;
+    const int period = (int)(mask + 1u), d = (cell_coord(x, h, bad) - origin) - rel;
+    return origin + rel + floor_div(d + period / 2, period) * period;
+}
+__device__ __forceinline__ bool dcs_in_cells(uint32_t k, const TileGrid& g, const DcsParams& s, const float4& p) {
     const uint32_t tile = k / TCELLS, loc = k % TCELLS;
     const int tz = (int)(tile % (uint32_t)g.ntz), ty = (int)((tile / (uint32_t)g.ntz) % (uint32_t)g.nty),
               tx = (int)(tile / ((uint32_t)g.ntz * (uint32_t)g.nty));
-    const int cx = g.ox + tx * TX + (int)(loc / (TY * TZ)), cy = g.oy + ty * TY + (int)((loc / TZ) % TY),
-              cz = g.oz + tz * TZ + (int)(loc % TZ);
+    const int cx = dcs_unfold(tx * TX + (int)(loc / (TY * TZ)), g.mx, p.x, s.h, g.ox), cy = dcs_unfold(ty * TY + (int)((loc / TZ) % TY), g.my, p.y, s.h, g.oy),
+              cz = dcs_unfold(tz * TZ + (int)(loc % TZ), g.mz, p.z, s.h, g.oz);
     return !(cx < s.clo[0] || cx > s.chi[0] || cy < s.clo[1] || cy > s.chi[1] || cz < s.clo[2] || cz > s.chi[2]);
 }
 
@@ -86,8 +95,9 @@ __global__ __launch_bounds__(BLOCK) void k_dcs_project(uint32_t n, float4* __res
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     flag[i] = 0;
-    if (!dcs_in_cells(keys[i], g, s)) return;
-    float4 p = posm[i], v = vel[i];
+    float4 p = posm[i];
+    if (!dcs_in_cells(keys[i], g, s, p)) return;
+    float4 v = vel[i];
     const float px = p.x + v.x * s.dt, py = p.y + v.y * s.dt, pz = p.z + v.z * s.dt;  // :206-207
     if (px < s.lo[0] || px > s.hi[0] || py < s.lo[1] || py > s.hi[1] || pz < s.lo[2] || pz > s.hi[2]) return;  // NaN: passes, as `<` / `>` do
     // m^-1 * pt
@@ -187,8 +197,9 @@ __global__ __launch_bounds__(BLOCK) void k_dcs_gather(uint32_t n, const float4* 
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     flag[i] = 0;
-    if (!dcs_in_cells(keys[i], g, s)) return;
-    const float4 p = posm[i], v = vel[i];
+    const float4 p = posm[i];
+    if (!dcs_in_cells(keys[i], g, s, p)) return;
+    const float4 v = vel[i];
     const float px = p.x + v.x * s.dt, py = p.y + v.y * s.dt, pz = p.z + v.z * s.dt;
     if (px < s.lo[0] || px > s.hi[0] || py < s.lo[1] || py > s.hi[1] || pz < s.lo[2] || pz > s.hi[2]) return;
     cand[i] = make_float4(px, py, pz, __uint_as_float(i));
@@ -275,6 +286,7 @@ DcsParams dcs_params(const SalvaHipShape& shape, const SalvaHipRigidPose& pose, 
     const float prediction = h * 0.5f;
     s.margin = particle_radius * 0.1f;
     s.reach = h + prediction;
+    s.h = h;
     s.dt = dt;
     s.eps = 1.1920929e-7f;
     float ext[3];
@@ -297,6 +309,7 @@ DcsParams dcs_params_host(const float mins[3], const float maxs[3], float h, flo
     const float prediction = h * 0.5f;
     s.margin = particle_radius * 0.1f;
     s.reach = h + prediction;
+    s.h = h;
     s.dt = dt;
     s.eps = 1.1920929e-7f;
     for (int a = 0; a < 3; ++a) {

@@ -717,7 +717,7 @@ StepCtx World::make_ctx() {
 // tile looks boundary cells up by absolute cell coordinates.
 // `fold` (fluid grid only): when the box holds more than fold->budget cells, fold its longest axes to power-of-two periods — never
 // below fold->min_period[a] — until it does (device_types.h TileGrid: the table becomes a torus, the lists stay what they were).
-struct FoldRule { double budget, target; uint32_t min_period[3]; };  // fold when the box exceeds `budget` cells, then down to `target`
+struct FoldRule { double budget, target; uint32_t min_period[3]; bool axis[3]; };  // fold when the box exceeds `budget` cells, then down to `target`; axis[a]: may fold
 static void dims_from_bbox(const int32_t* bb, GridDims& g, const FoldRule* fold = nullptr) {
     static const int T[3] = {TX, TY, TZ};
     int64_t cells[3];
@@ -739,7 +739,7 @@ static void dims_from_bbox(const int32_t* bb, GridDims& g, const FoldRule* fold 
             for (int a = 0; a < 3; ++a) {
                 int64_t p = 1;
                 while (p * 2 < cells[a]) p *= 2;
-                if (p < (int64_t)fold->min_period[a] || p >= cells[a]) continue;
+                if (!fold->axis[a] || p < (int64_t)fold->min_period[a] || p >= cells[a]) continue;
                 if (best < 0 || cells[a] > cells[best]) { best = a; best_p = p; }
             }
             if (best < 0) break;  // (nothing left to fold: the budget check below decides)
@@ -1565,13 +1565,15 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         // eightfold, the third gives it up.  Sticky for the world.)
         const uint32_t forced = fold_forced ? fold_forced << (2u * std::min(fold_relax, 3u)) : 0u;
         constexpr bool tiles_pow2 = (TX & (TX - 1)) == 0 && (TY & (TY - 1)) == 0 && (TZ & (TZ - 1)) == 0;  // (a period is a whole number of tiles)
-        const bool can_fold = tiles_pow2 && !fold_off && !comm && !has_dynamic_sampling() && fold_relax < 3u;
+        // (a decomposed run finds its ghost planes by absolute x-cell: it folds y and z only.  Dynamically sampled colliders read cells
+        // back from the keys: dcs.hip picks the image by the particle's position.)
+        const bool can_fold = tiles_pow2 && !fold_off && fold_relax < 3u;
         if (can_fold && nb && b_dirty) build_boundary_grid();
         // (once it folds, it folds tight — to half a cell per particle if the periods allow: the particles that have left the scene
         // then land on the tiles of the bulk instead of owning a tile each; a tile with one particle costs a quarter of a full one)
         const double loosen = (double)(1u << (3u * std::min(fold_relax, 3u)));
         FoldRule rule{forced ? 0.0 : 4.0 * (double)n + 1048576.0, forced ? 0.0 : std::max(0.5 * (double)n, 262144.0) * loosen,
-                      {forced ? forced : 64u, forced ? forced : 64u, forced ? forced : 64u}};
+                      {forced ? forced : 64u, forced ? forced : 64u, forced ? forced : 64u}, {!comm, true, true}};
         if (nb)
             for (int a = 0; a < 3; ++a) {
                 static const int T[3] = {TX, TY, TZ};

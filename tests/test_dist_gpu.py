@@ -935,3 +935,35 @@ def test_cpp_mirror_runs_a_decomposed_world(hip_lib):
     for args in (["2", "10"], ["3", "6"]):
         r = subprocess.run([os.path.join(root, "examples", "slabs3")] + args, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and "slabs3 OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_strays_far_out_in_y_and_z_fold_away_in_a_decomposed_run(hip_lib, monkeypatch):
+    """Round 6 (missing 3): the reference's hash grid never cares where a stray particle is
+    (/root/reference/src/geometry/hgrid.rs:22-63); the dense cell table did, wherever it could not fold — decomposed runs among them
+    (ghost planes are found by absolute x-cell).  They now fold y and z: fifty particles that have left the tank hundreds of cells
+    below and beside it ride on the torus, the slabs compute what the undivided (and, here, unfolded) world computes, and nobody
+    dies of E_CAPACITY.  SALVA_HIP_FOLD_CELLS=16 forces the fold on this small scene: x — 48 cells — must stay whole on the slabs."""
+    pos, vel, bpos = make_scene(nx=48, ny=10, nz=10, seed=9)
+    rng = np.random.default_rng(3)
+    stray = np.zeros((50, 3), np.float32)
+    stray[:, 0] = rng.uniform(pos[:, 0].min(), pos[:, 0].max(), 50)
+    stray[:25, 1] = rng.uniform(-60.0, -20.0, 25)   # fallen out of the tank: 200 .. 600 cells below
+    stray[25:, 1] = rng.uniform(0.2, 0.6, 25)
+    stray[25:, 2] = rng.uniform(15.0, 40.0, 25)      # sprayed sideways
+    stray[:25, 2] = rng.uniform(pos[:, 2].min(), pos[:, 2].max(), 25)
+    svel = np.zeros((50, 3), np.float32)
+    svel[:, 1] = -3.0
+    pos2, vel2 = np.concatenate([pos, stray]), np.concatenate([vel, svel])
+    nsteps = 10
+    monkeypatch.setenv("SALVA_HIP_NO_FOLD", "1")
+    ref_p, ref_v, ref_stats = run_single(pos2, vel2, bpos, nsteps, False)
+    monkeypatch.delenv("SALVA_HIP_NO_FOLD")
+    monkeypatch.setenv("SALVA_HIP_FOLD_CELLS", "16")
+    got_p, got_v, stats, seen, counts, slabs = run_slabs(pos2, vel2, bpos, nsteps, 3, False)
+    assert (seen == 1).all()
+    for k in range(nsteps):
+        it = {(s[k].n_divergence_iters, s[k].n_pressure_iters) for s in stats}
+        assert len(it) == 1
+        assert sum(int(s[k].ncontacts) for s in stats) == int(ref_stats[k].ncontacts)  # the contact SETS are the unfolded grid's
+    assert np.abs(got_p - ref_p).max() < 2e-4 * H and np.abs(got_v - ref_v).max() < 5e-3
+    assert np.abs(got_p[-50:] - ref_p[-50:]).max() < 1e-5  # (the strays themselves: free flight)

@@ -139,3 +139,31 @@ def test_splitting_switches_itself_on_where_a_few_tiles_are_over_full():
     assert all(b <= a for a, b in zip(h0, h1)), (h0, h1)
     assert t1 == t0
     _same(w1, f1, w0, f0)
+
+
+def test_a_fold_that_piles_the_bulk_onto_itself_is_loosened_and_the_pass_repeated():
+    """the fold rule looks at the box, not at where the particles sit.  A 20-cell block on a torus of 8 cells per axis puts
+    ~15 images of the bulk into every cell: halos of 25 000 particles that fit no kernel's LDS — before round 6 the step died of
+    "a tile's halo does not fit".  The tile totals show it before any solver kernel has run; the fold is loosened (8 -> 32 cells, wider
+    than the block) and the pass repeated: the step computes what the unfolded grid computes."""
+    s = Scene(R, 2.0, "dfsph")
+    fluid = scenes.jitter(scenes.cube_fluid_positions(40, 40, 40, R), 0.1 * R, seed=5)
+    s.add_fluid(fluid, scenes.random_velocities(len(fluid), 0.2, seed=6), 1000.0, forces=[("xsph", 0.5, 0.0)])
+    old = {k: os.environ.pop(k, None) for k in ("SALVA_HIP_FOLD_CELLS", "SALVA_HIP_NO_FOLD")}
+    try:
+        os.environ["SALVA_HIP_NO_FOLD"] = "1"
+        w0, (f0,), _ = s.make_hip()
+        os.environ.pop("SALVA_HIP_NO_FOLD")
+        os.environ["SALVA_HIP_FOLD_CELLS"] = "8"
+        w1, (f1,), _ = s.make_hip()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    for _ in range(3):
+        a, b = w0.step(DT, GRAVITY), w1.step(DT, GRAVITY)
+        assert (a.n_divergence_iters, a.n_pressure_iters, a.ncontacts) == (b.n_divergence_iters, b.n_pressure_iters, b.ncontacts)
+        assert int(b.reserved[0]) < 4000  # (a torus wider than the block: no tile sees an image of the bulk)
+    assert np.array_equal(w0.contact_counts(f0), w1.contact_counts(f1))
+    assert np.abs(f0.positions - f1.positions).max() <= 1e-6 * R * 10
