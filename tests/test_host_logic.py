@@ -1,6 +1,8 @@
 """CPU-only checks of the host-side mirror code that sits above the C ABI (no device needed): the rigid-body stand-in
 of salva_amd.coupling (rapier's formulas), the contact / kernel helpers handed to user-defined forces, and the
 bookkeeping flags that keep the per-step host work O(1)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -94,3 +96,17 @@ def test_custom_force_descriptor_and_host_flags():
     assert f._acc_touched
     f.delete_particle_at_next_timestep(4)
     assert f._maybe_deleted and f.num_deleted_particles() == 1
+
+
+def test_the_pinning_kit_still_names_things_the_reference_has():
+    """bench/rust_ref has never met cargo: at least every `use salva3d::...` item and every method its main.rs calls must exist in the
+    reference tree (/root/reference/src/lib.rs:86-118 and below).  Skipped where the reference is absent (the GPU boxes)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("no reference tree here")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench", "rust_ref", "check_against_reference.py"), "/root/reference"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
