@@ -29,6 +29,7 @@ struct LoopbackShared {
         uint64_t cnt_to_lo[2] = {0, 0}, cnt_to_hi[2] = {0, 0};
         double red_f64[64];
         unsigned long long red_u64[64];
+        const unsigned long long* gather_src = nullptr;  // allgather_u64: where this rank's section lies (device memory of the one process)
     };
     std::vector<Box> box;
     explicit LoopbackShared(int n) : size(n), box(n) {}
@@ -124,6 +125,18 @@ class LoopbackTransport : public Transport {
         SALVA_HIP_CHECK(hipMemcpyAsync(buf, h, n * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
         SALVA_HIP_CHECK(hipStreamSynchronize(s));
     }
+    void allgather_u64(const unsigned long long* mine, unsigned long long* all, int n_each, hipStream_t s) override {
+        if (n_each <= 0) return;
+        if (trace()) fprintf(stderr, "[loopback %d] allgather_u64 %d\n", rank_, n_each);
+        // (one address space: every rank posts where its section lies and copies the others' device to device)
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        g_->box[rank_].gather_src = mine;
+        g_->barrier();
+        for (int r = 0; r < g_->size; ++r)
+            SALVA_HIP_CHECK(hipMemcpyAsync(all + (size_t)r * n_each, g_->box[r].gather_src, (size_t)n_each * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        g_->barrier();  // (nobody reuses its section before everybody has copied it)
+    }
 
   private:
     std::shared_ptr<LoopbackShared> g_;
@@ -215,6 +228,9 @@ class RcclTransport : public Transport {
     void allreduce_sum_u64(unsigned long long* buf, int n, hipStream_t s) override {
         SALVA_NCCL_CHECK(ncclAllReduce(buf, buf, n, ncclUint64, ncclSum, comm_, s));
     }
+    void allgather_u64(const unsigned long long* mine, unsigned long long* all, int n_each, hipStream_t s) override {
+        if (n_each > 0) SALVA_NCCL_CHECK(ncclAllGather(mine, all, (size_t)n_each, ncclUint64, comm_, s));
+    }
 
   private:
     int rank_, size_, device_;
@@ -301,6 +317,20 @@ void transport_selftest(Transport& t, size_t max_bytes, int rounds, hipStream_t 
             if (hf[k] != ef) fail("wrong f32 all-reduce sum", r, (size_t)k);
             if (hu[k] != eu) fail("wrong u64 all-reduce sum", r, (size_t)k);
         }
+        // the all-gather: lengths below, at and beyond one pass of the peer transport's mailbox
+        const int ne = (r % 3 == 0) ? 5 : (r % 3 == 1 ? 256 : 701);
+        DevBuf<unsigned long long> gm, ga;
+        gm.ensure((size_t)ne); ga.ensure((size_t)ne * size);
+        std::vector<unsigned long long> hm((size_t)ne), ha((size_t)ne * size);
+        for (int k = 0; k < ne; ++k) hm[k] = ((unsigned long long)(rank + 1) << 40) ^ ((unsigned long long)k * 2654435761ull) ^ (unsigned long long)r;
+        SALVA_HIP_CHECK(hipMemcpyAsync(gm.p, hm.data(), hm.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        t.allgather_u64(gm.p, ga.p, ne, s);
+        SALVA_HIP_CHECK(hipMemcpyAsync(ha.data(), ga.p, ha.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        SALVA_HIP_CHECK(hipStreamSynchronize(s));
+        for (int q = 0; q < size; ++q)
+            for (int k = 0; k < ne; ++k)
+                if (ha[(size_t)q * ne + k] != (((unsigned long long)(q + 1) << 40) ^ ((unsigned long long)k * 2654435761ull) ^ (unsigned long long)r))
+                    fail("wrong all-gather entry", r, (size_t)q * ne + k);
     }
 }
 

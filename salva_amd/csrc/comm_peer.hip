@@ -181,6 +181,31 @@ __global__ void __launch_bounds__(PEER_RED_CHUNK) k_peer_allreduce(PeerReduce a,
     }
 }
 
+// The all-gather over the same mailbox: every rank stores its <= PEER_RED_CHUNK values into its row of every window, raises its flag,
+// waits for everybody's, and copies the ROWS out side by side instead of adding them up: out[r * stride + k] = rank r's value k.
+__global__ void __launch_bounds__(PEER_RED_CHUNK) k_peer_allgather(PeerReduce a, const unsigned long long* mine, unsigned long long* out, size_t stride) {
+    const int k = threadIdx.x, par = (int)(a.seq & 1ull);
+    if (k < a.n) {
+        const unsigned long long bits = mine[k];
+        for (int r = 0; r < a.size; ++r) ((PeerHeader*)a.windows[r])->red[par][a.rank][k] = bits;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (k < a.size)
+        __hip_atomic_store(&((PeerHeader*)a.windows[k])->red_flag[a.rank], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __shared__ int bad;
+    if (k == 0) bad = 0;
+    __syncthreads();
+    PeerHeader* me = (PeerHeader*)a.windows[a.rank];
+    if (k < a.size && !peer_wait(&me->red_flag[k], a.seq, a.timed_out, a.timeout_ticks)) bad = 1;
+    __syncthreads();
+    if (bad) return;
+    __threadfence_system();
+    if (k < a.n)
+        for (int r = 0; r < a.size; ++r)
+            out[(size_t)r * stride + k] = __hip_atomic_load(&me->red[par][r][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -321,6 +346,19 @@ class PeerTransport : public Transport {
 
     void allreduce_sum_f32(float* buf, int n, hipStream_t s) override { allreduce(buf, n, s); }
     void allreduce_sum_u64(unsigned long long* buf, int n, hipStream_t s) override { allreduce(buf, n, s); }
+    void allgather_u64(const unsigned long long* mine, unsigned long long* all, int n_each, hipStream_t s) override {
+        check_timeout();
+        for (int at = 0; at < n_each; at += PEER_RED_CHUNK) {
+            PeerReduce a{};
+            for (int r = 0; r < size_; ++r) a.windows[r] = win_[r];
+            a.rank = rank_; a.size = size_; a.n = n_each - at < PEER_RED_CHUNK ? n_each - at : PEER_RED_CHUNK;
+            a.seq = ++red_seq_;
+            a.timed_out = timed_out_;
+            a.timeout_ticks = timeout_ticks_;
+            hipLaunchKernelGGL(k_peer_allgather, dim3(1), dim3(PEER_RED_CHUNK), 0, s, a, mine + at, all + at, (size_t)n_each);
+        }
+        SALVA_HIP_CHECK(hipGetLastError());
+    }
 
   private:
     static unsigned int copy_blocks(size_t a, size_t b) {

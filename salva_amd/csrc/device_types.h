@@ -195,6 +195,9 @@ struct StepCtx {
     // spec_ring[k & 1] and the apply pass's workgroup 0 writes spec_ring[(k + 1) & 1]; w lives in w / w2 by the parity of the
     // committed applies.  spec_k < 0: off (the control block `ctl` and one k_finalize_error launch per iteration).
     int spec_k;
+    // 1: a DECOMPOSED solve runs its applies speculatively (round 6): the records are written by k_decide_ring behind the all-reduce,
+    // on the main stream, while the apply pass runs beside it on the second stream — the apply's workgroup 0 decides nothing
+    uint32_t spec_external;
     SolveCtl* spec_ring;
     SolveCtl* spec_pub;            // host-mapped copy of the first half of the newest record (may be null)
     const uint32_t* model_counts;  // particles per fluid: the denominators of the error averages

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
     const float4* const win = rec ? solve_w_in(c, rec) : c.w;
     float4* const wout = c.spec_k >= 0 ? ((win == c.w) ? c.w2 : c.w) : c.w;  // (speculative: the other buffer; else in place)
     lds_base_check();
-    if (c.spec_k >= 0 && blockIdx.x == 0) {  // the convergence test of this iteration rides in workgroup 0 (spec_decide)
+    if (c.spec_k >= 0 && !c.spec_external && blockIdx.x == 0) {  // the convergence test of this iteration rides in workgroup 0 (spec_decide)
         spec_decide(c, reinterpret_cast<float*>(tile_smem));
         __syncthreads();
     }
@@ -597,7 +597,7 @@ __device__ __forceinline__ void k_divergence_apply_p2_body(StepCtx c, float inv_
     const float4* const win = rec ? solve_w_in(c, rec) : c.w;
     float4* const wout = c.spec_k >= 0 ? ((win == c.w) ? c.w2 : c.w) : c.w;
     lds_base_check();
-    if (c.spec_k >= 0 && blockIdx.x == 0) {
+    if (c.spec_k >= 0 && !c.spec_external && blockIdx.x == 0) {
         spec_decide(c, reinterpret_cast<float*>(tile_smem));
         __syncthreads();
     }
@@ -1126,6 +1126,28 @@ __global__ void k_decide(const float* __restrict__ sums, uint32_t nmodels, const
     const uint32_t s = ctl->seq + 1u;  // one tick per convergence test, converged or not: the host waits for the count it enqueued
     ctl->seq = s;
     publish_ctl(ctl, pub, s);
+}
+// the same decision for a speculative decomposed solve (World::run_solve, spec_dist): iteration k reads ring[k & 1] and the record of
+// iteration k + 1 goes to ring[(k + 1) & 1] — the apply pass of iteration k runs beside this kernel and still reads the old one
+__global__ void k_decide_ring(const float* __restrict__ sums, uint32_t nmodels, const uint32_t* __restrict__ model_counts, SolveCtl* ring, int k,
+                              SolveCtl* pub) {
+    if (threadIdx.x != 0) return;
+    const SolveCtl r = ring[k & 1];
+    SolveCtl n = r;
+    if (!r.done) {
+        float best = 0.0f;
+        for (uint32_t m = 0; m < nmodels; ++m)
+            if (model_counts[m] != 0) best = fmaxf(best, sums[m] / (float)model_counts[m]);
+        n.err = best;
+        if (best <= r.tol && r.iters >= r.min_iter) n.done = 1u;
+        else n.iters = r.iters + 1u;
+    }
+    n.seq = r.seq + 1u;
+    ring[(k + 1) & 1] = n;
+    publish_ctl(&n, pub, n.seq);
+}
+void launch_decide_ring(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ring, int k, SolveCtl* pub, hipStream_t s) {
+    k_decide_ring<<<1, 64, 0, s>>>(sums, nmodels, model_counts, ring, k, pub);
 }
 void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmodels, const SolveCtl* ctl, float* sums, hipStream_t s) {
     k_sum_partials<<<1, BLOCK, 0, s>>>(partials, nblocks, nmodels, ctl, sums);

@@ -100,6 +100,7 @@ void launch_finalize_error(const float* partials, unsigned nblocks, uint32_t nmo
                            uint32_t close_stage = 0u, uint32_t skipped = 0u);
 // multi-GPU form: per-fluid sums of this rank -> sums[nmodels]; (all-reduce over ranks); break test on the global sums
 void launch_sum_partials(const float* partials, unsigned nblocks, uint32_t nmodels, const SolveCtl* ctl, float* sums, hipStream_t s);
+void launch_decide_ring(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ring, int k, SolveCtl* pub, hipStream_t s);
 // skipped: tests of earlier iterations that were not launched because they could not end the solve (i < min_iter): counted here
 void launch_decide(const float* sums, uint32_t nmodels, const uint32_t* model_counts, SolveCtl* ctl, SolveCtl* pub, hipStream_t s, uint32_t skipped = 0u);
 

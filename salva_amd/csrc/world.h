@@ -211,6 +211,11 @@ class World {
     size_t h_dl_cap[2] = {0, 0};
     struct PendingDownload { bool active = false; float* dst[2] = {nullptr, nullptr}; bool staged[2] = {false, false}; size_t bytes = 0; } dl;
     hipEvent_t ev_pre_refresh = nullptr, ev_interior = nullptr;
+    // decomposed solves with speculative applies (World::run_solve): evaluate done -> the apply may start on stream2; apply done ->
+    // the main stream may refresh what it wrote
+    hipEvent_t ev_spec_eval = nullptr, ev_spec_apply = nullptr;
+    hipStream_t spec_dist_stream = nullptr;  // non-null while run_solve launches such an apply: where its kernel goes
+    bool spec_dist_off = false;              // SALVA_HIP_NO_SPEC_DIST=1 (A/B, tests)
     bool overlap_exchange = true;   // SALVA_HIP_NO_OVERLAP=1 turns it off (diagnostics)
     template <typename Launch> void evaluate_split(const StepCtx& c, int iteration, Launch&& launch);
     uint32_t n = 0, nb = 0;

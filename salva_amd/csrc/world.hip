@@ -125,6 +125,9 @@ World::World(const SalvaHipParams& p) : prm(p) {
     SALVA_HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     SALVA_HIP_CHECK(hipEventCreateWithFlags(&ev_pre_refresh, hipEventDisableTiming));
     SALVA_HIP_CHECK(hipEventCreateWithFlags(&ev_interior, hipEventDisableTiming));
+    SALVA_HIP_CHECK(hipEventCreateWithFlags(&ev_spec_eval, hipEventDisableTiming));
+    SALVA_HIP_CHECK(hipEventCreateWithFlags(&ev_spec_apply, hipEventDisableTiming));
+    spec_dist_off = getenv("SALVA_HIP_NO_SPEC_DIST") != nullptr;
     overlap_exchange = getenv("SALVA_HIP_NO_OVERLAP") == nullptr;
     // Speculative sizing is OFF unless asked for (SALVA_HIP_SPECULATE=1).  Measured on the bench scene (10^6 particles): it
     // removes two ~20 us host round trips from a ~0.9 ms free-fall step (-2 %), but a failed prediction costs a whole extra
@@ -191,6 +194,8 @@ World::~World() {
     for (hipEvent_t e : dist_ev) if (e) (void)hipEventDestroy(e);
     if (ev_pre_refresh) (void)hipEventDestroy(ev_pre_refresh);
     if (ev_interior) (void)hipEventDestroy(ev_interior);
+    if (ev_spec_eval) (void)hipEventDestroy(ev_spec_eval);
+    if (ev_spec_apply) (void)hipEventDestroy(ev_spec_apply);
     if (h_rb) (void)hipHostFree(h_rb);
     if (h_ctl) (void)hipHostFree(h_ctl);
     if (h_pub) (void)hipHostFree(h_pub);
@@ -1039,6 +1044,31 @@ World::SolveResult World::run_solve(StepCtx c, int which, float tol, int min_ite
         const int nbatch = std::min(batch, max_iter - i);
         bool owes = false;
         for (int k = 0; k < nbatch; ++k) {
+            if (spec_apply && multi) {
+                // A decomposed solve with speculative applies (round 6): the all-reduced test and the apply pass do not wait for
+                // each other.  Main stream: error sums -> all-reduce -> k_decide_ring (the record of iteration it + 1).  Second
+                // stream: the apply pass, into the other w buffer, reading the record of iteration `it` only.  Then the ghost
+                // refresh of what the apply wrote, behind both — one communicator, one operation at a time.  A converged test leaves
+                // the apply and its refresh unused (w stays where it was), exactly as in the single domain (dfsph.hip spec_decide).
+                const int it = i + k;
+                c.spec_k = it; c.spec_external = 1u; c.spec_pub = nullptr;
+                eval(c, it);
+                SALVA_HIP_CHECK(hipEventRecord(ev_spec_eval, stream));
+                SALVA_HIP_CHECK(hipStreamWaitEvent(stream2, ev_spec_eval, 0));
+                spec_dist_stream = stream2;
+                apply(c, it);  // (the kernel only: World::dfsph_solve's lambda leaves the refresh to the lines below)
+                spec_dist_stream = nullptr;
+                SALVA_HIP_CHECK(hipEventRecord(ev_spec_apply, stream2));
+                const uint32_t nm = (uint32_t)std::max<size_t>(fluids.size(), 1);
+                const size_t tm = dist_time_begin(1);
+                launch_sum_partials(partials.p, nlaunch, nm, spec_ring.p + (it & 1), d_sums.p, stream);
+                comm->allreduce_sum_f32(d_sums.p, (int)nm, stream);
+                launch_decide_ring(d_sums.p, nm, model_counts.p, spec_ring.p, it, pub, stream);
+                dist_time_end(tm);
+                SALVA_HIP_CHECK(hipStreamWaitEvent(stream, ev_spec_apply, 0));
+                refresh_f4((it & 1) ? w.p : w2.p);  // what the apply of iteration `it` wrote: the buffer of parity it + 1
+                continue;
+            }
             if (spec_apply) { c.spec_k = i + k; c.spec_pub = pub; }
             eval(c, i + k);
             if (!spec_apply) test(i + k, k == nbatch - 1, nullptr, nullptr, 0u);
@@ -1280,7 +1310,11 @@ void World::dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepSta
     // Worth ~3 us per iteration (measured: a 50-iteration step 5.13 -> 4.99 ms); the apply that follows the converging evaluate is
     // then computed in vain (~30 us once per solve), so: only when the previous step's solve ran 16 iterations or more; not with boundary reaction forces (an
     // apply that is thrown away must not have added to them) and not in decomposed runs (the test sits behind an all-reduce).
-    const bool spec_apply = !resume && !spec_apply_off && !comm && !any_wants_forces && last_iters[0] >= 16u;
+    // Decomposed runs (round 6): the same double buffer lets the apply run BESIDE the all-reduced test instead of behind it
+    // (World::run_solve); there the wasted apply is cheaper than the all-reduces it hides from four iterations on.
+    const bool multi_rank = comm && comm->size() > 1;
+    const bool spec_apply = !resume && !spec_apply_off && !any_wants_forces &&
+                            (multi_rank ? (!spec_dist_off && last_iters[0] >= 4u) : (!comm && last_iters[0] >= 16u));
     if (spec_apply) { w2.ensure(n, stream, false, 1.1f); spec_ring.ensure(2); c.w2 = w2.p; c.spec_ring = spec_ring.p; }
     // Chained: neither solve is waited for (the w / w2 swap below is a host decision on the iteration count: not with speculative applies)
     const bool chain = !resume && !spec_apply && chain_allowed();
@@ -1298,8 +1332,8 @@ void World::dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepSta
     auto div_apply = [&](const StepCtx& cc, int) {
         // decomposed runs: kappa of the inner ghost plane was computed here from refreshed w — the applies of the
         // owned particles read nothing else, so only w travels, once per iteration
-        launch_divergence_apply(cc, lds, inv_dt_lag, stream);
-        if (comm) refresh_f4(w.p);
+        launch_divergence_apply(cc, lds, inv_dt_lag, spec_dist_stream ? spec_dist_stream : stream);
+        if (comm && !spec_dist_stream) refresh_f4(w.p);  // (a speculative decomposed apply: run_solve refreshes the buffer it wrote)
     };
     const float div_tol = prm.max_divergence_error * inv_dt_prev * 0.01f;
     SolveResult rd{0u, 0.0f};
@@ -1312,6 +1346,10 @@ void World::dfsph_solve(StepCtx& c, float& dt, const float g[3], SalvaHipStepSta
     if (resume <= 1) {
         rd = run_solve(c, 0, div_tol, prm.min_divergence_iter, prm.max_divergence_iter, 0u, div_eval, div_apply, spec_apply, chain_div ? 1 : 0,
                        resume == 1 ? chain_batch[0] : 0, chain_div);
+        if (spec_apply && multi_rank) {
+            static const bool trace = getenv("SALVA_HIP_DIST_TRACE") != nullptr;
+            if (trace) fprintf(stderr, "salva_hip dist[%d]: divergence solve with applies beside the all-reduce, %u iterations\n", comm->rank(), rd.iters);
+        }
         if (spec_apply && (rd.iters & 1u)) {  // an odd number of committed applies: w lives in the second buffer
             std::swap(w.p, w2.p); std::swap(w.cap, w2.cap);
             c.w = w.p; c.w2 = w2.p; cg.w = w.p; cg.w2 = w2.p;

@@ -287,19 +287,36 @@ uint32_t World::dist_gather_emitted(const float4* rows, uint32_t cnt, const floa
     *all_rows = nullptr; *all_models = nullptr;
     if (total == 0) return 0;
     const size_t words = 2 * (size_t)total + ((size_t)total + 1) / 2;  // float4 rows, then uint32 fluids
-    dcs_all.ensure(words, stream, false, 1.5f);
-    SALVA_HIP_CHECK(hipMemsetAsync(dcs_all.p, 0, words * sizeof(unsigned long long), stream));
+    unsigned long long maxc = 0;
+    for (int r = 0; r < size; ++r) maxc = std::max(maxc, counts[r]);
+    // every rank's section — rows, then fluids — in a block of one stride, gathered (Transport::allgather_u64), then copied side by
+    // side into the table every rank builds its boundary from.  (Round 5 summed a zeroed table through the sum all-reduce: over the
+    // peer transport a 256-value pass per 256 table words, whatever the number of ranks.)
+    const size_t blk = (2 * (size_t)maxc + ((size_t)maxc + 1) / 2 + 1) & ~(size_t)1;  // (even: float4 rows start every section)
+    const size_t words_al = (words + 1) & ~(size_t)1;
+    dcs_all.ensure(words_al + blk * ((size_t)size + 1), stream, false, 1.5f);
     float4* out_rows = reinterpret_cast<float4*>(dcs_all.p);
     uint32_t* out_models = reinterpret_cast<uint32_t*>(dcs_all.p + 2 * (size_t)total);
-    launch_dcs_pack(cnt, rows, perm[cur].p, model[cur].p, out_rows + before, out_models + before, stream);
-    if (size > 1) {
-        // (an int count per call: a contact layer is far below 2^31 words; cut larger tables anyway)
-        for (size_t at = 0; at < words;) {
-            const size_t len = std::min<size_t>(words - at, (size_t)1 << 28);
-            comm->allreduce_sum_u64(dcs_all.p + at, (int)len, stream);
-            at += len;
+    if (size == 1) {
+        launch_dcs_pack(cnt, rows, perm[cur].p, model[cur].p, out_rows, out_models, stream);
+    } else {
+        if (blk >= ((size_t)1 << 30)) throw HipError(SALVA_HIP_E_CAPACITY, "too many dynamically sampled boundary particles");
+        unsigned long long* mine = dcs_all.p + words_al;
+        unsigned long long* all = mine + blk;
+        SALVA_HIP_CHECK(hipMemsetAsync(mine, 0, blk * sizeof(unsigned long long), stream));
+        launch_dcs_pack(cnt, rows, perm[cur].p, model[cur].p, reinterpret_cast<float4*>(mine), reinterpret_cast<uint32_t*>(mine + 2 * (size_t)maxc), stream);
+        comm->allgather_u64(mine, all, (int)blk, stream);
+        unsigned long long at = 0;
+        for (int r = 0; r < size; ++r) {
+            const unsigned long long* src = all + (size_t)r * blk;
+            if (counts[r]) {
+                SALVA_HIP_CHECK(hipMemcpyAsync(out_rows + at, src, (size_t)counts[r] * sizeof(float4), hipMemcpyDeviceToDevice, stream));
+                SALVA_HIP_CHECK(hipMemcpyAsync(out_models + at, src + 2 * (size_t)maxc, (size_t)counts[r] * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            }
+            at += counts[r];
         }
     }
+    (void)before;
     *all_rows = out_rows; *all_models = out_models;
     return (uint32_t)total;
 }

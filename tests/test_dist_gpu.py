@@ -967,3 +967,28 @@ def test_strays_far_out_in_y_and_z_fold_away_in_a_decomposed_run(hip_lib, monkey
         assert sum(int(s[k].ncontacts) for s in stats) == int(ref_stats[k].ncontacts)  # the contact SETS are the unfolded grid's
     assert np.abs(got_p - ref_p).max() < 2e-4 * H and np.abs(got_v - ref_v).max() < 5e-3
     assert np.abs(got_p[-50:] - ref_p[-50:]).max() < 1e-5  # (the strays themselves: free flight)
+
+
+def test_decomposed_solves_run_their_applies_beside_the_all_reduce(hip_lib, monkeypatch):
+    """Round 6: in a decomposed divergence solve the all-reduced convergence test and the apply pass no longer
+    wait for each other — the apply runs speculatively into the second w buffer on the second stream while error sums -> all-reduce
+    -> decision run on the main one (World::run_solve; the single domain's double buffer, dfsph.hip spec_decide).  Same sums, same
+    decisions: three slabs with it and without it (SALVA_HIP_NO_SPEC_DIST=1) end bit for bit in the same state, iteration by
+    iteration — and both agree with the undivided world as before."""
+    pos, vel, bpos = make_scene(nx=44, ny=12, nz=10, seed=21)
+    vel[:, 1] -= np.float32(2.5)  # driven into the tank's floor: the divergence solve needs 10 .. 50 iterations step after step
+    nsteps = 12
+    ref_p, ref_v, ref_stats = run_single(pos, vel, bpos, nsteps, False)
+    monkeypatch.setenv("SALVA_HIP_NO_SPEC_DIST", "1")
+    p0, v0, s0, seen0, _, _ = run_slabs(pos, vel, bpos, nsteps, 3, False)
+    monkeypatch.delenv("SALVA_HIP_NO_SPEC_DIST")
+    p1, v1, s1, seen1, _, _ = run_slabs(pos, vel, bpos, nsteps, 3, False)
+    its = [s1[0][k].n_divergence_iters for k in range(nsteps)]
+    assert sum(i >= 4 for i in its[:-1]) >= 5, its  # the speculative path switches on from four iterations (of the previous step) on
+    assert (seen0 == 1).all() and (seen1 == 1).all()
+    for k in range(nsteps):
+        a = {(s[k].n_divergence_iters, s[k].n_pressure_iters, float(s[k].divergence_error)) for s in s0}
+        b = {(s[k].n_divergence_iters, s[k].n_pressure_iters, float(s[k].divergence_error)) for s in s1}
+        assert len(a) == 1 and a == b, (k, a, b)
+    assert np.array_equal(p0, p1) and np.array_equal(v0, v1)
+    assert np.abs(p1 - ref_p).max() < 2e-4 * H and np.abs(v1 - ref_v).max() < 5e-3
