@@ -557,7 +557,7 @@ void launch_tile_slots(TileGrid g, uint32_t ntiles, uint32_t* flags, uint32_t* r
 
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc* __restrict__ tile_cnt, uint4* __restrict__ slot_desc) {
     Tile t;
-    TileAcc a{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    TileAcc a{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // (launched over an upper bound of the slot count: a surplus workgroup contributes a zero entry; workgroup 0 also zeroes the
     // extra element the exclusive scan reads behind the last one)
     if (gate_closed(c)) return;  // (a pre-enqueued launch whose grid did not come true: World::pre_enqueue_grid)
@@ -579,14 +579,22 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc
         a.max_sum = (((uint32_t)a.s + 63u) & ~63u) + (uint32_t)a.sb;
         a.max_raw = (uint32_t)a.s + (uint32_t)a.sb;
         a.heavy = (t.part != TILE_PART_WHOLE || a.s > TILE_SPLIT_S) ? 1u : 0u;
+        a.ntiny = (a.nsl <= 1u && a.s <= TILE_TINY_S && a.sb <= TILE_TINY_SB) ? 1u : 0u;
     }
     if (threadIdx.x == 0) tile_cnt[t.slot] = a;
 }
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uint32_t* __restrict__ halo_src,
-                                                                 uint32_t* __restrict__ bhalo_src, uint4* __restrict__ slot_info) {
+                                                                 uint32_t* __restrict__ bhalo_src, uint4* __restrict__ slot_info,
+                                                                 uint32_t* __restrict__ slot_order, uint32_t nbig) {
     Tile t;
     t.setup(c, false);
-    if (threadIdx.x == 0) slot_info[t.slot] = make_uint4(t.own_begin, t.own_end, t.slice_base, t.S | (t.SB << 16));
+    if (threadIdx.x == 0) {
+        slot_info[t.slot] = make_uint4(t.own_begin, t.own_end, t.slice_base, t.S | (t.SB << 16));
+        if (slot_order) {  // two launch classes this step (StepCtx::slot_order): the sparse slots behind the others, each kind in slot order
+            const uint32_t before = c.tile_off[t.slot].ntiny, tiny = c.tile_off[t.slot + 1].ntiny - before;
+            slot_order[tiny ? nbig + before : t.slot - before] = t.slot;
+        }
+    }
     TileCells tc;
     tc.build(c, t, true);
     const int sub = threadIdx.x % 16, grp = threadIdx.x / 16;
@@ -603,16 +611,17 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uin
 void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, uint4* slot_desc, hipStream_t s) {
     if (nslots_bound) k_tile_count<<<nslots_bound, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, tile_cnt, slot_desc);
 }
-void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, uint4* slot_info, hipStream_t s) {
-    if (c.nlaunch) k_tile_halo_fill<<<c.nlaunch, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, halo_src, bhalo_src, slot_info);
+void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, uint4* slot_info, hipStream_t s, uint32_t* slot_order,
+                           uint32_t nbig) {
+    if (c.nlaunch) k_tile_halo_fill<<<c.nlaunch, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, halo_src, bhalo_src, slot_info, slot_order, nbig);
 }
 size_t scan_tiles_temp_bytes(uint32_t n) {
     size_t b = 0;
-    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n);
     return b;
 }
 void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s) {
-    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n, s));
+    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n, s));
 }
 
 // ------------------------------------------------------------------------------------------------ neighbour lists
@@ -922,11 +931,13 @@ void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsi
     } else {
         // what V = 1 carves: the cell tables, three 4-byte planes of (S + 8 rounded to 4) slots, the model ids when there is more
         // than one fluid, two 16-byte boundary arrays
-        auto r16 = [](uint32_t b) { return (b + 15u) & ~15u; };
-        const uint32_t plane = ((L.max_halo_fluid + 8u + 63u) & ~63u) + 64u;
-        const uint32_t lds = r16(TILE_TABLE_BYTES) + 3u * r16(plane * 4u) + (c.nmodels > 1 ? r16(L.max_halo_fluid * 4u) : 0u) +
-                             2u * L.max_halo_boundary * 16u + 64u;
-        SALVA_LAUNCH_TILE(k_nbr_tile<1>, c, L, lds, s, c, ts);
+        // (a function of the TileLds it is handed: the launch macro evaluates it once per launch class)
+        auto nbr_lds = [](const TileLds& T, uint32_t nmodels) {
+            auto r16 = [](uint32_t b) { return (b + 15u) & ~15u; };
+            const uint32_t plane = ((T.max_halo_fluid + 8u + 63u) & ~63u) + 64u;
+            return r16(TILE_TABLE_BYTES) + 3u * r16(plane * 4u) + (nmodels > 1 ? r16(T.max_halo_fluid * 4u) : 0u) + 2u * T.max_halo_boundary * 16u + 64u;
+        };
+        SALVA_LAUNCH_TILE(k_nbr_tile<1>, c, L, nbr_lds(L, c.nmodels), s, c, ts);
     }
     // (totals2 == nullptr: the statistics are folded by the end-of-step publication, World::publish_enqueue — one launch less per step)
     if (totals2) k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.nlaunch, totals2, maxima2, own2);

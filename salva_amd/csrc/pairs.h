@@ -273,8 +273,8 @@ __device__ __forceinline__ float (*carve_errtab(Tile& t))[MAX_MODELS] {
 // launch one of the three layout instantiations of a solver kernel (tile.h: FIXED_DS_SMALL / _LARGE / runtime distance)
 #define SALVA_LAUNCH_FIXED(kernel, DSV, c, L, lds, s, ...)                                                         \
     do {                                                                                                           \
-        if ((DSV) == FIXED_DS_SMALL) SALVA_LAUNCH_TILE(kernel<FIXED_DS_SMALL>, c, L, lds, s, __VA_ARGS__);         \
-        else if ((DSV) == FIXED_DS_LARGE) SALVA_LAUNCH_TILE(kernel<FIXED_DS_LARGE>, c, L, lds, s, __VA_ARGS__);    \
+        if ((DSV) == FIXED_DS_SMALL) SALVA_LAUNCH_TILE_2(kernel<FIXED_DS_SMALL>, kernel<0u>, c, L, lds, s, __VA_ARGS__);         \
+        else if ((DSV) == FIXED_DS_LARGE) SALVA_LAUNCH_TILE_2(kernel<FIXED_DS_LARGE>, kernel<0u>, c, L, lds, s, __VA_ARGS__);    \
         else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                             \
     } while (0)
 // (`level`, TileLds::ds_level = SALVA_HIP_DS_LEVEL: take the level-th larger layout than the halo needs — the tests' way to run every
@@ -317,16 +317,16 @@ static inline uint32_t pick_ds_p2(uint32_t n, uint32_t level) {
 }
 #define SALVA_LAUNCH_P3(kernel, DSV, c, L, lds, s, ...)                                                          \
     do {                                                                                                         \
-        if ((DSV) == P3_DS_THREE) SALVA_LAUNCH_TILE(kernel<P3_DS_THREE>, c, L, lds, s, __VA_ARGS__);             \
-        else if ((DSV) == P3_DS_TWO) SALVA_LAUNCH_TILE(kernel<P3_DS_TWO>, c, L, lds, s, __VA_ARGS__);            \
-        else if ((DSV) == P3_DS_ONE) SALVA_LAUNCH_TILE(kernel<P3_DS_ONE>, c, L, lds, s, __VA_ARGS__);            \
+        if ((DSV) == P3_DS_THREE) SALVA_LAUNCH_TILE_2(kernel<P3_DS_THREE>, kernel<0u>, c, L, lds, s, __VA_ARGS__);             \
+        else if ((DSV) == P3_DS_TWO) SALVA_LAUNCH_TILE_2(kernel<P3_DS_TWO>, kernel<0u>, c, L, lds, s, __VA_ARGS__);            \
+        else if ((DSV) == P3_DS_ONE) SALVA_LAUNCH_TILE_2(kernel<P3_DS_ONE>, kernel<0u>, c, L, lds, s, __VA_ARGS__);            \
         else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                           \
     } while (0)
 #define SALVA_LAUNCH_P2(kernel, DSV, c, L, lds, s, ...)                                                          \
     do {                                                                                                         \
-        if ((DSV) == P2_DS_THREE) SALVA_LAUNCH_TILE(kernel<P2_DS_THREE>, c, L, lds, s, __VA_ARGS__);             \
-        else if ((DSV) == P3_DS_TWO) SALVA_LAUNCH_TILE(kernel<P3_DS_TWO>, c, L, lds, s, __VA_ARGS__);            \
-        else if ((DSV) == P3_DS_ONE) SALVA_LAUNCH_TILE(kernel<P3_DS_ONE>, c, L, lds, s, __VA_ARGS__);            \
+        if ((DSV) == P2_DS_THREE) SALVA_LAUNCH_TILE_2(kernel<P2_DS_THREE>, kernel<0u>, c, L, lds, s, __VA_ARGS__);             \
+        else if ((DSV) == P3_DS_TWO) SALVA_LAUNCH_TILE_2(kernel<P3_DS_TWO>, kernel<0u>, c, L, lds, s, __VA_ARGS__);            \
+        else if ((DSV) == P3_DS_ONE) SALVA_LAUNCH_TILE_2(kernel<P3_DS_ONE>, kernel<0u>, c, L, lds, s, __VA_ARGS__);            \
         else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                           \
     } while (0)
 // P | K kernels: P holds fluid halo + 2 x boundary halo, K the fluid halo (4 bytes each)

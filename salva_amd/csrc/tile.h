@@ -105,6 +105,8 @@ constexpr uint32_t TILE_PART_WHOLE = (uint32_t)(TX - 1) << 2;
 __host__ __device__ inline uint32_t tile_part_code(uint32_t ux0, uint32_t len) { return ux0 | ((len - 1u) << 2); }
 // the fluid halo beyond which a tile does not fit the three-tiles-per-CU plane layouts (P3_DS_THREE)
 constexpr uint32_t TILE_SPLIT_S = P3_DS_THREE;
+// the sparse class (StepCtx::slot_order): a slot with at most one slice of own particles and a halo this small
+constexpr uint32_t TILE_TINY_S = 192, TILE_TINY_SB = 64, TILE_TINY_THREADS = 64;
 constexpr uint32_t TILE_ERR_BYTES = 12u * 32u * 4u;  // TileErr table (TILE_MAX_WAVES x MAX_MODELS floats), carved from the pool
 
 #ifdef __HIPCC__
@@ -116,15 +118,50 @@ template <typename K>
 inline void ensure_tile_lds(K kernel, uint32_t bytes) {
     if (bytes > 48u * 1024u) raise_tile_lds_limit(reinterpret_cast<const void*>(kernel), bytes);
 }
-#define SALVA_LAUNCH_TILE(kernel, c, L, lds, s, ...)                          \
-    do {                                                                   \
-        if ((c).n && (c).nlaunch) {                                        \
-            const uint32_t _lds = (lds);                                   \
-            ::salva::ensure_tile_lds(kernel, _lds);                        \
-            kernel<<<(c).nlaunch, (L).threads, _lds, s>>>(__VA_ARGS__);    \
-            SALVA_HIP_CHECK(hipGetLastError());                            \
-        }                                                                  \
+// One launch per pass — or two, when this step's sparse slots have a class of their own (StepCtx::ntiny): the other slots with the
+// kernel, workgroup and LDS the call site asks for; then the sparse ones with `kernel_tiny` (the same kernel, or its run-time-layout
+// instantiation where the layout is a template parameter: a compile-time plane distance would pin the LDS request at tens of KB),
+// TILE_TINY_THREADS threads and the LDS the SAME size expression yields for a halo of TILE_TINY_S + TILE_TINY_SB slots.  The
+// expression and the kernel arguments are re-read under shadowed names: every call site calls them `c`, `L` and (where it has one) `ds`.
+inline TileLds tile_tiny_lds(const TileLds& L) {
+    TileLds t = L;
+    t.max_halo_fluid = TILE_TINY_S; t.max_halo_boundary = L.max_halo_boundary ? TILE_TINY_SB : 0u;
+    t.max_sum = ((TILE_TINY_S + 63u) & ~63u) + t.max_halo_boundary; t.max_raw = TILE_TINY_S + t.max_halo_boundary;
+    t.threads = TILE_TINY_THREADS;
+    return t;
+}
+#define SALVA_LAUNCH_TILE_2(kernel, kernel_tiny, c, L, lds, s, ...)                                   \
+    do {                                                                                           \
+        if ((c).n && (c).nlaunch) {                                                                \
+            if ((c).ntiny == 0u || (c).slot_order == nullptr) {                                    \
+                const uint32_t _lds = (lds);                                                       \
+                ::salva::ensure_tile_lds(kernel, _lds);                                            \
+                kernel<<<(c).nlaunch, (L).threads, _lds, s>>>(__VA_ARGS__);                        \
+            } else {                                                                               \
+                const uint32_t _nbig = (c).nlaunch - (c).ntiny, _ntiny = (c).ntiny;                \
+                ::salva::StepCtx _c2 = (c);                                                        \
+                const ::salva::TileLds _lt = ::salva::tile_tiny_lds(L);                            \
+                const unsigned _thr = (L).threads;                                                 \
+                if (_nbig) {                                                                       \
+                    const uint32_t _lds = (lds);                                                   \
+                    ::salva::ensure_tile_lds(kernel, _lds);                                        \
+                    _c2.slot_base = 0u; _c2.nlaunch = _nbig;                                       \
+                    { const ::salva::StepCtx c = _c2; kernel<<<_nbig, _thr, _lds, s>>>(__VA_ARGS__); } \
+                }                                                                                  \
+                {                                                                                  \
+                    _c2.slot_base = _nbig; _c2.nlaunch = _ntiny;                                   \
+                    const ::salva::TileLds L = _lt;                                                \
+                    const uint32_t ds = 0u; (void)ds;                                              \
+                    const ::salva::StepCtx c = _c2;                                                \
+                    const uint32_t _lds = (lds);                                                   \
+                    ::salva::ensure_tile_lds(kernel_tiny, _lds);                                   \
+                    kernel_tiny<<<_ntiny, TILE_TINY_THREADS, _lds, s>>>(__VA_ARGS__);              \
+                }                                                                                  \
+            }                                                                                      \
+            SALVA_HIP_CHECK(hipGetLastError());                                                    \
+        }                                                                                          \
     } while (0)
+#define SALVA_LAUNCH_TILE(kernel, c, L, lds, s, ...) SALVA_LAUNCH_TILE_2(kernel, kernel, c, L, lds, s, __VA_ARGS__)
 
 // key of cell (cx,cy,cz) (absolute cell coords) in grid g, or inside = false.  (mx, my, mz): the folding masks of the grid the
 // COORDINATES belong to (device_types.h TileGrid) — g's own, except where a tile of the folded fluid grid looks up the cells of the
@@ -267,7 +304,8 @@ struct Tile {
             if (rk < 64u)
                 for (unsigned i = 0; i < ((rk >> 4) & 3u); ++i) __builtin_amdgcn_s_sleep(64);
         }
-        setup_at(c, xcd_block(blockIdx.x, gridDim.x, c.xcd));
+        const uint32_t b = xcd_block(blockIdx.x, gridDim.x, c.xcd);
+        setup_at(c, c.slot_order ? c.slot_order[c.slot_base + b] : b);  // (two launch classes: StepCtx::slot_order)
     }
     __device__ __forceinline__ void setup_at(const StepCtx& c, uint32_t at_slot) {
         pool = tile_smem;
@@ -596,8 +634,7 @@ struct TileCells {
     __device__ __forceinline__ void build(const StepCtx& c, Tile& t, bool clamp_to_staged = false) {
         uint32_t* tab = t.carve<uint32_t>(2 * (HCELLS + 1) + 2 * HCELLS);
         lstart = tab; gstart = tab + (HCELLS + 1); blstart = gstart + HCELLS; bgstart = blstart + (HCELLS + 1);
-        const int h = threadIdx.x;
-        if (h < HCELLS) {
+        for (int h = threadIdx.x; h < HCELLS; h += blockDim.x) {  // (one trip at >= HCELLS threads; the sparse class runs 64)
             const int hz = h % HZ, hy = (h / HZ) % HY, hx = h / (HZ * HY);
             // (a part of a split tile stages the x-planes around its own cells only: the others hold no neighbour of its particles)
             const bool plane = (uint32_t)hx >= t.part_ux0() && (uint32_t)hx < t.part_ux0() + t.part_len() + 2u;

@@ -140,6 +140,8 @@ World::World(const SalvaHipParams& p) : prm(p) {
     chain_off = getenv("SALVA_HIP_NO_CHAIN") != nullptr;
     pre_off = getenv("SALVA_HIP_NO_PREGRID") != nullptr;
     split_off = getenv("SALVA_HIP_NO_SPLIT") != nullptr;
+    classes_off = getenv("SALVA_HIP_NO_CLASSES") != nullptr;
+    classes_forced = getenv("SALVA_HIP_CLASSES") != nullptr;
     if (const char* e = getenv("SALVA_HIP_SPLIT_S")) split_forced = (uint32_t)std::max(atoi(e), 1);
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
     two_mass_off = getenv("SALVA_HIP_NO_TWO_MASS") != nullptr;
@@ -685,6 +687,7 @@ StepCtx World::make_ctx() {
     c.halo_stride = halo_stride; c.bhalo_stride = bhalo_stride;
     c.ntiles = (uint32_t)gf.ntiles();
     c.split_s = split_s_cur;
+    c.slot_order = class_ntiny ? slot_order.p : nullptr; c.slot_base = 0u; c.ntiny = class_ntiny;
     c.tile_ids = G().tile_ids.p; c.tile_rank = G().tile_rank.p; c.nlaunch = nlaunch; c.slot_desc = G().slot_desc.p; c.slot_info = slot_info.p;
     c.spec = spec_mode ? 1u : 0u; c.halo_cap = halo_cap; c.bhalo_cap = bhalo_cap; c.nslices_cap = nslices_cap;
     c.halo_len = halo_len; c.bhalo_len = bhalo_len;
@@ -1812,8 +1815,8 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         lds.max_sum = spec ? 0u : tt.max_sum;  // (a speculative pass knows the two maxima only: TileLds::sum_slots falls back to their sum)
         lds.max_raw = spec ? 0u : tt.max_raw;
         if (tile_trace)
-            fprintf(stderr, "salva_hip tiles: nonempty %u max_s %u max_sb %u max_sum %u max_raw %u heavy %u split_s %u mass_uniform %g | chained %llu breaks %llu pregrid %llu dropped %llu\n",
-                    tt.nonempty, tt.max_s, tt.max_sb, tt.max_sum, tt.max_raw, tt.heavy, split_s_cur, (double)mass_uniform,
+            fprintf(stderr, "salva_hip tiles: nonempty %u max_s %u max_sb %u max_sum %u max_raw %u heavy %u tiny %u split_s %u mass_uniform %g | chained %llu breaks %llu pregrid %llu dropped %llu\n",
+                    tt.nonempty, tt.max_s, tt.max_sb, tt.max_sum, tt.max_raw, tt.heavy, tt.ntiny, split_s_cur, (double)mass_uniform,
                     (unsigned long long)chain_steps, (unsigned long long)chain_breaks, (unsigned long long)pre_adopted, (unsigned long long)pre_dropped);
         if (!spec) {
             // next step's splitting: on while the over-full tiles are few (each costs a second workgroup and a third more staging, and
@@ -1897,8 +1900,20 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             halo_cap = lds.max_halo_fluid; bhalo_cap = lds.max_halo_boundary; nslices_cap = nslices;
             halo_len = need_f; bhalo_len = need_b;
         }
+        // Two launch classes (device_types.h StepCtx::slot_order): worth a second launch per pass once the sparse slots are many —
+        // a thousand of them hold a CU's LDS for a round and a third of the chip each pass; SALVA_HIP_NO_CLASSES=1: never,
+        // SALVA_HIP_CLASSES=1: whenever there is one of each kind (tests).
+        class_ntiny = 0u;
+        if (!spec && !classes_off && tt.ntiny > 0u && tt.ntiny < tt.nonempty && (classes_forced || tt.ntiny >= 512u)) class_ntiny = tt.ntiny;
+        if (class_ntiny) slot_order.ensure(nlaunch, stream, false, 1.5f);
+        {
+            const uint32_t keep = class_ntiny;
+            class_ntiny = 0u;  // (the table builder itself runs over every slot in one launch)
+            c = make_ctx();
+            launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, slot_info.p, stream, keep ? slot_order.p : nullptr, nlaunch - keep);
+            class_ntiny = keep;
+        }
         c = make_ctx();
-        launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, slot_info.p, stream);
 
         // ---- neighbour lists   (compute_contacts, contacts.rs:154-252): one pass into fixed-capacity ELL rows; if a list
         // turns out longer than the capacity the pass is repeated with room to spare (rare: the capacity follows the
