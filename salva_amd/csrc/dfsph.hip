@@ -533,7 +533,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
     const float4* const win = rec ? solve_w_in(c, rec) : c.w;
     float4* const wout = c.spec_k >= 0 ? ((win == c.w) ? c.w2 : c.w) : c.w;  // (speculative: the other buffer; else in place)
     lds_base_check();
-    if (c.spec_k >= 0 && !c.spec_external && blockIdx.x == 0) {  // the convergence test of this iteration rides in workgroup 0 (spec_decide)
+    if (c.spec_k >= 0 && !c.spec_external && blockIdx.x == 0 && c.slot_base == 0u) {  // the convergence test of this iteration rides in workgroup 0 of the pass's (first) launch (spec_decide)
         spec_decide(c, reinterpret_cast<float*>(tile_smem));
         __syncthreads();
     }
@@ -597,7 +597,7 @@ __device__ __forceinline__ void k_divergence_apply_p2_body(StepCtx c, float inv_
     const float4* const win = rec ? solve_w_in(c, rec) : c.w;
     float4* const wout = c.spec_k >= 0 ? ((win == c.w) ? c.w2 : c.w) : c.w;
     lds_base_check();
-    if (c.spec_k >= 0 && !c.spec_external && blockIdx.x == 0) {
+    if (c.spec_k >= 0 && !c.spec_external && blockIdx.x == 0 && c.slot_base == 0u) {
         spec_decide(c, reinterpret_cast<float*>(tile_smem));
         __syncthreads();
     }

@@ -145,11 +145,11 @@ inline TileLds tile_tiny_lds(const TileLds& L) {
                 if (_nbig) {                                                                       \
                     const uint32_t _lds = (lds);                                                   \
                     ::salva::ensure_tile_lds(kernel, _lds);                                        \
-                    _c2.slot_base = 0u; _c2.nlaunch = _nbig;                                       \
+                    _c2.slot_base = 0u;                                                        \
                     { const ::salva::StepCtx c = _c2; kernel<<<_nbig, _thr, _lds, s>>>(__VA_ARGS__); } \
                 }                                                                                  \
                 {                                                                                  \
-                    _c2.slot_base = _nbig; _c2.nlaunch = _ntiny;                                   \
+                    _c2.slot_base = _nbig;                                                     \
                     const ::salva::TileLds L = _lt;                                                \
                     const uint32_t ds = 0u; (void)ds;                                              \
                     const ::salva::StepCtx c = _c2;                                                \

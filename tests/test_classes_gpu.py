@@ -123,3 +123,24 @@ def test_the_classes_switch_themselves_on_when_the_strays_are_many():
     w1, f1, t1 = _run({}, s, 6)
     assert t1 == t0
     _same(w1, f1, w0, f0)
+
+
+def test_the_convergence_test_that_rides_in_an_apply_pass_runs_once_per_pass():
+    """A solve that needs many iterations step after step runs its applies speculatively, with the convergence test of the
+    iteration in workgroup 0 of the apply (dfsph.hip spec_decide) — of the pass's FIRST launch only: found in round 6, the sparse
+    class's launch decided a second time, over its own share of the error partials, and solves stopped early (1 iteration where 3
+    were due).  A block driven into the tank's floor, with strays around it."""
+    s = Scene(R, 2.0, "dfsph")
+    fluid, shell = scenes.tank(14, 14, 14, R)
+    fluid = scenes.jitter(fluid, 0.1 * R, seed=13)
+    pos = _with_strays(fluid)
+    vel = scenes.random_velocities(len(pos), 0.3, seed=14)
+    vel[: len(fluid), 1] -= np.float32(2.5)
+    s.add_fluid(pos, vel, 1000.0, forces=[("xsph", 0.5, 0.0)])
+    s.add_boundary(shell)
+    w0, f0, t0 = _run({"SALVA_HIP_NO_CLASSES": "1"}, s, 12)
+    w1, f1, t1 = _run({"SALVA_HIP_CLASSES": "1"}, s, 12)
+    its = [t[0] for t in t0]
+    assert sum(a >= 4 and b >= 4 for a, b in zip(its, its[1:])) >= 4, its  # (the speculative path follows a step of four iterations or more)
+    assert t1 == t0
+    _same(w1, f1, w0, f0)
