@@ -158,6 +158,10 @@ typedef struct SalvaHipCounters {
     uint64_t pregrid_adopted;                 /* steps that found their grid part (keys, cell sort, tile tables) on the device already,
                                                  enqueued by the end of the step before */
     uint64_t pregrid_dropped;                 /* ... that found one they could not use (the cell box moved, the host edited the world) */
+    uint64_t light_class_passes;              /* passes whose tile kernels ran the slots with small halos in launches of their own, on the
+                                                 three-workgroups-per-CU layouts, beside slots whose halos are beyond those */
+    uint64_t sparse_class_passes;             /* passes whose tile kernels ran the sparse slots (a stray particle or a few, alone in
+                                                 their tile) in launches of their own: 64 threads, a few KB of LDS */
 } SalvaHipCounters;
 
 /* fields of salva_hip_get_fluid_field (solver scratch the reference keeps private; exposed for parity tests) */

@@ -114,7 +114,8 @@ class CountersStruct(C.Structure):
     _fields_ = [("nsubsteps", C.c_uint64), ("step_time", C.c_double), ("custom", C.c_double), ("stages", _StagesCounters),
                 ("cd", _CollisionDetectionCounters), ("solver", _SolverCounters), ("n_divergence_iters", C.c_int32),
                 ("n_pressure_iters", C.c_int32), ("speculative_passes", C.c_uint64), ("discarded_passes", C.c_uint64),
-                ("chained_passes", C.c_uint64), ("chain_breaks", C.c_uint64), ("pregrid_adopted", C.c_uint64), ("pregrid_dropped", C.c_uint64)]
+                ("chained_passes", C.c_uint64), ("chain_breaks", C.c_uint64), ("pregrid_adopted", C.c_uint64), ("pregrid_dropped", C.c_uint64),
+                ("light_class_passes", C.c_uint64), ("sparse_class_passes", C.c_uint64)]
 
 
 class Shape(C.Structure):

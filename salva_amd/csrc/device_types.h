@@ -61,10 +61,12 @@ struct TileAcc {
                        // prefix gives a sparse slot its rank among its kind, the total decides whether they get a launch of their own
     uint32_t heavy;    // slots that are PARTS of a split tile + whole tiles whose fluid halo is beyond the three-tiles-per-CU layouts
                        // (tile.h TILE_SPLIT_S): what World::substep decides the next step's splitting by
+    uint32_t nlight;   // slots of the LIGHT class (tile.h tile_is_light: not sparse, and the halo fits the smallest compile-time layout
+                       // of every kernel family): when other slots of the step do not, these get a launch of their own on that layout
     __host__ __device__ TileAcc operator+(const TileAcc& o) const {
         return TileAcc{s + o.s, sb + o.sb, nsl + o.nsl, nonempty + o.nonempty, max_s > o.max_s ? max_s : o.max_s,
                        max_sb > o.max_sb ? max_sb : o.max_sb, max_nsl > o.max_nsl ? max_nsl : o.max_nsl,
-                       max_sum > o.max_sum ? max_sum : o.max_sum, max_raw > o.max_raw ? max_raw : o.max_raw, wsl + o.wsl, ntiny + o.ntiny, heavy + o.heavy};
+                       max_sum > o.max_sum ? max_sum : o.max_sum, max_raw > o.max_raw ? max_raw : o.max_raw, wsl + o.wsl, ntiny + o.ntiny, heavy + o.heavy, nlight + o.nlight};
     }
 };
 
@@ -143,14 +145,17 @@ struct StepCtx {
     const uint4* slot_info;     // [nlaunch] {first own particle, one past the last, first slice, S | SB << 16}: all a solver
                                 //           kernel needs to know about a tile's sizes, written by k_tile_halo_fill
     const uint32_t* tile_rank;  // [ntiles+1] exclusive prefix of the tiles' slot counts: FIRST slot of a dense tile; [ntiles] = nlaunch
-    // Two launch classes per pass (round 6): when thousands of stray particles own a tile each, those slots —
+    // Launch classes per pass (round 6).  SPARSE: when thousands of stray particles own a tile each, those slots —
     // one slice, a halo of a few particles — run in a launch of their own, 64 threads and a few KB of LDS per workgroup (two dozen
-    // per CU), instead of holding a full tile's LDS for a list of one entry, three per CU.  slot_order = [the other slots, in slot
-    // order | the sparse slots, in slot order] (k_tile_halo_fill); a launch works on slot_order[slot_base + mapped block].
+    // per CU), instead of holding a full tile's LDS for a list of one entry, three per CU.  LIGHT: when some halos of the step are
+    // beyond the three-per-CU layouts (the settled bench scene: half of its tiles), the slots that are not run in a launch of their
+    // own on those layouts instead of sharing the two-per-CU launch of the full ones.  slot_order = [the full slots | the light slots |
+    // the sparse slots], each kind in slot order (k_tile_halo_fill); a launch works on slot_order[slot_base + mapped block].
     // nullptr: one class, block -> slot directly.
     const uint32_t* slot_order;
     uint32_t slot_base;
-    uint32_t ntiny;             // sparse slots of this step when they have their own launches (0: one launch per pass)
+    uint32_t ntiny;             // sparse slots of this step when they have their own launches (0: they run with the others)
+    uint32_t nlight;            // light slots of this step when they have their own launches (0: they run with the full ones)
     uint32_t nlaunch;           // number of slots launched (= the number of non-empty tiles, or in a speculative pass an upper bound)
     // Speculative passes (World::step): launch shapes and buffers were cut from the previous step's totals, so every
     // tile kernel clamps itself to what it was given — surplus slots are empty, a halo is cut at the staged capacity, a tile

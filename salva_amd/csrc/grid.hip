@@ -557,7 +557,7 @@ void launch_tile_slots(TileGrid g, uint32_t ntiles, uint32_t* flags, uint32_t* r
 
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc* __restrict__ tile_cnt, uint4* __restrict__ slot_desc) {
     Tile t;
-    TileAcc a{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    TileAcc a{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // (launched over an upper bound of the slot count: a surplus workgroup contributes a zero entry; workgroup 0 also zeroes the
     // extra element the exclusive scan reads behind the last one)
     if (gate_closed(c)) return;  // (a pre-enqueued launch whose grid did not come true: World::pre_enqueue_grid)
@@ -580,19 +580,26 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_count(StepCtx c, TileAcc
         a.max_raw = (uint32_t)a.s + (uint32_t)a.sb;
         a.heavy = (t.part != TILE_PART_WHOLE || a.s > TILE_SPLIT_S) ? 1u : 0u;
         a.ntiny = (a.nsl <= 1u && a.s <= TILE_TINY_S && a.sb <= TILE_TINY_SB) ? 1u : 0u;
+        a.nlight = (!a.ntiny && tile_is_light((uint32_t)a.s, (uint32_t)a.sb)) ? 1u : 0u;
     }
     if (threadIdx.x == 0) tile_cnt[t.slot] = a;
 }
 __global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uint32_t* __restrict__ halo_src,
                                                                  uint32_t* __restrict__ bhalo_src, uint4* __restrict__ slot_info,
-                                                                 uint32_t* __restrict__ slot_order, uint32_t nbig) {
+                                                                 uint32_t* __restrict__ slot_order, uint32_t nfull, uint32_t nlight,
+                                                                 uint32_t use) {
     Tile t;
     t.setup(c, false);
     if (threadIdx.x == 0) {
         slot_info[t.slot] = make_uint4(t.own_begin, t.own_end, t.slice_base, t.S | (t.SB << 16));
-        if (slot_order) {  // two launch classes this step (StepCtx::slot_order): the sparse slots behind the others, each kind in slot order
-            const uint32_t before = c.tile_off[t.slot].ntiny, tiny = c.tile_off[t.slot + 1].ntiny - before;
-            slot_order[tiny ? nbig + before : t.slot - before] = t.slot;
+        if (slot_order) {  // launch classes this step (StepCtx::slot_order): full | light | sparse, each kind in slot order
+            // (`use` bit 0: the light slots have a launch of their own, bit 1: the sparse ones; a class without one counts as full)
+            const TileAcc a0 = c.tile_off[t.slot], a1 = c.tile_off[t.slot + 1];
+            const uint32_t tb = (use & 2u) ? a0.ntiny : 0u, tiny = (use & 2u) ? a1.ntiny - a0.ntiny : 0u;
+            // (sparse slots that have no launch of their own are light ones: tile_is_light holds for them)
+            const uint32_t l0 = a0.nlight + ((use & 2u) ? 0u : a0.ntiny), l1 = a1.nlight + ((use & 2u) ? 0u : a1.ntiny);
+            const uint32_t lb = (use & 1u) ? l0 : 0u, light = (use & 1u) ? l1 - l0 : 0u;
+            slot_order[tiny ? nfull + nlight + tb : (light ? nfull + lb : t.slot - tb - lb)] = t.slot;
         }
     }
     TileCells tc;
@@ -612,16 +619,19 @@ void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cn
     if (nslots_bound) k_tile_count<<<nslots_bound, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, tile_cnt, slot_desc);
 }
 void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, uint4* slot_info, hipStream_t s, uint32_t* slot_order,
-                           uint32_t nbig) {
-    if (c.nlaunch) k_tile_halo_fill<<<c.nlaunch, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, halo_src, bhalo_src, slot_info, slot_order, nbig);
+                           uint32_t nlight, uint32_t ntiny) {
+    const uint32_t use = (nlight ? 1u : 0u) | (ntiny ? 2u : 0u);
+    if (c.nlaunch)
+        k_tile_halo_fill<<<c.nlaunch, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, halo_src, bhalo_src, slot_info, slot_order, c.nlaunch - nlight - ntiny,
+                                                                            nlight, use);
 }
 size_t scan_tiles_temp_bytes(uint32_t n) {
     size_t b = 0;
-    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, b, (const TileAcc*)nullptr, (TileAcc*)nullptr, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n);
     return b;
 }
 void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s) {
-    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n, s));
+    SALVA_HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(temp, temp_bytes, in, out, hipcub::Sum(), TileAcc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, (int)n, s));
 }
 
 // ------------------------------------------------------------------------------------------------ neighbour lists

@@ -53,9 +53,10 @@ void launch_gather_f4(uint32_t n, const uint32_t* perm, const float4* in, float4
 void launch_tile_slots(TileGrid g, uint32_t ntiles, uint32_t* flags, uint32_t* rank, uint32_t* tile_ids, void* temp,
                        size_t temp_bytes, hipStream_t s, const uint32_t* gate = nullptr, uint32_t split_s = 0u);
 void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, uint4* slot_desc, hipStream_t s);
-// slot_order != nullptr: also the order of the step's two launch classes (StepCtx::slot_order; nbig = slots of the first class)
+// slot_order != nullptr: also the order of the step's launch classes (StepCtx::slot_order; nlight / ntiny: the light / sparse slots when
+// they get launches of their own, else 0)
 void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, uint4* slot_info, hipStream_t s, uint32_t* slot_order = nullptr,
-                           uint32_t nbig = 0u);
+                           uint32_t nlight = 0u, uint32_t ntiny = 0u);
 size_t scan_tiles_temp_bytes(uint32_t n);
 void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s);
 // neighbour lists (per-slice ELL blocks of 16-bit halo slots, capacity c.cap_ff / c.cap_fb dwords per particle), built

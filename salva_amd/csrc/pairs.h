@@ -273,9 +273,9 @@ __device__ __forceinline__ float (*carve_errtab(Tile& t))[MAX_MODELS] {
 // launch one of the three layout instantiations of a solver kernel (tile.h: FIXED_DS_SMALL / _LARGE / runtime distance)
 #define SALVA_LAUNCH_FIXED(kernel, DSV, c, L, lds, s, ...)                                                         \
     do {                                                                                                           \
-        if ((DSV) == FIXED_DS_SMALL) SALVA_LAUNCH_TILE_2(kernel<FIXED_DS_SMALL>, kernel<0u>, c, L, lds, s, __VA_ARGS__);         \
-        else if ((DSV) == FIXED_DS_LARGE) SALVA_LAUNCH_TILE_2(kernel<FIXED_DS_LARGE>, kernel<0u>, c, L, lds, s, __VA_ARGS__);    \
-        else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                             \
+        if ((DSV) == FIXED_DS_SMALL) SALVA_LAUNCH_TILE_3(kernel<FIXED_DS_SMALL>, kernel<FIXED_DS_SMALL>, FIXED_DS_SMALL, kernel<0u>, c, L, lds, s, __VA_ARGS__); \
+        else if ((DSV) == FIXED_DS_LARGE) SALVA_LAUNCH_TILE_3(kernel<FIXED_DS_LARGE>, kernel<FIXED_DS_SMALL>, FIXED_DS_SMALL, kernel<0u>, c, L, lds, s, __VA_ARGS__); \
+        else SALVA_LAUNCH_TILE_3(kernel<0u>, kernel<FIXED_DS_SMALL>, FIXED_DS_SMALL, kernel<0u>, c, L, lds, s, __VA_ARGS__); \
     } while (0)
 // (`level`, TileLds::ds_level = SALVA_HIP_DS_LEVEL: take the level-th larger layout than the halo needs — the tests' way to run every
 // instantiation on scenes whose halos would all pick the smallest; the arithmetic does not depend on the layout)
@@ -315,19 +315,19 @@ static inline uint32_t pick_ds_p2(uint32_t n, uint32_t level) {
     k += level;
     return ds[k < 3u ? k : 3u];
 }
-#define SALVA_LAUNCH_P3(kernel, DSV, c, L, lds, s, ...)                                                          \
-    do {                                                                                                         \
-        if ((DSV) == P3_DS_THREE) SALVA_LAUNCH_TILE_2(kernel<P3_DS_THREE>, kernel<0u>, c, L, lds, s, __VA_ARGS__);             \
-        else if ((DSV) == P3_DS_TWO) SALVA_LAUNCH_TILE_2(kernel<P3_DS_TWO>, kernel<0u>, c, L, lds, s, __VA_ARGS__);            \
-        else if ((DSV) == P3_DS_ONE) SALVA_LAUNCH_TILE_2(kernel<P3_DS_ONE>, kernel<0u>, c, L, lds, s, __VA_ARGS__);            \
-        else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                           \
+#define SALVA_LAUNCH_P3(kernel, DSV, c, L, lds, s, ...)                                                                                          \
+    do {                                                                                                                                         \
+        if ((DSV) == P3_DS_THREE) SALVA_LAUNCH_TILE_3(kernel<P3_DS_THREE>, kernel<P3_DS_THREE>, P3_DS_THREE, kernel<0u>, c, L, lds, s, __VA_ARGS__); \
+        else if ((DSV) == P3_DS_TWO) SALVA_LAUNCH_TILE_3(kernel<P3_DS_TWO>, kernel<P3_DS_THREE>, P3_DS_THREE, kernel<0u>, c, L, lds, s, __VA_ARGS__); \
+        else if ((DSV) == P3_DS_ONE) SALVA_LAUNCH_TILE_3(kernel<P3_DS_ONE>, kernel<P3_DS_THREE>, P3_DS_THREE, kernel<0u>, c, L, lds, s, __VA_ARGS__); \
+        else SALVA_LAUNCH_TILE_3(kernel<0u>, kernel<P3_DS_THREE>, P3_DS_THREE, kernel<0u>, c, L, lds, s, __VA_ARGS__);                             \
     } while (0)
-#define SALVA_LAUNCH_P2(kernel, DSV, c, L, lds, s, ...)                                                          \
-    do {                                                                                                         \
-        if ((DSV) == P2_DS_THREE) SALVA_LAUNCH_TILE_2(kernel<P2_DS_THREE>, kernel<0u>, c, L, lds, s, __VA_ARGS__);             \
-        else if ((DSV) == P3_DS_TWO) SALVA_LAUNCH_TILE_2(kernel<P3_DS_TWO>, kernel<0u>, c, L, lds, s, __VA_ARGS__);            \
-        else if ((DSV) == P3_DS_ONE) SALVA_LAUNCH_TILE_2(kernel<P3_DS_ONE>, kernel<0u>, c, L, lds, s, __VA_ARGS__);            \
-        else SALVA_LAUNCH_TILE(kernel<0u>, c, L, lds, s, __VA_ARGS__);                                           \
+#define SALVA_LAUNCH_P2(kernel, DSV, c, L, lds, s, ...)                                                                                          \
+    do {                                                                                                                                         \
+        if ((DSV) == P2_DS_THREE) SALVA_LAUNCH_TILE_3(kernel<P2_DS_THREE>, kernel<P2_DS_THREE>, P2_DS_THREE, kernel<0u>, c, L, lds, s, __VA_ARGS__); \
+        else if ((DSV) == P3_DS_TWO) SALVA_LAUNCH_TILE_3(kernel<P3_DS_TWO>, kernel<P2_DS_THREE>, P2_DS_THREE, kernel<0u>, c, L, lds, s, __VA_ARGS__); \
+        else if ((DSV) == P3_DS_ONE) SALVA_LAUNCH_TILE_3(kernel<P3_DS_ONE>, kernel<P2_DS_THREE>, P2_DS_THREE, kernel<0u>, c, L, lds, s, __VA_ARGS__); \
+        else SALVA_LAUNCH_TILE_3(kernel<0u>, kernel<P2_DS_THREE>, P2_DS_THREE, kernel<0u>, c, L, lds, s, __VA_ARGS__);                             \
     } while (0)
 // P | K kernels: P holds fluid halo + 2 x boundary halo, K the fluid halo (4 bytes each)
 static inline uint32_t pk_slots(const TileLds& L) { return L.sum_slots() + L.max_halo_boundary; }

@@ -118,11 +118,12 @@ template <typename K>
 inline void ensure_tile_lds(K kernel, uint32_t bytes) {
     if (bytes > 48u * 1024u) raise_tile_lds_limit(reinterpret_cast<const void*>(kernel), bytes);
 }
-// One launch per pass — or two, when this step's sparse slots have a class of their own (StepCtx::ntiny): the other slots with the
-// kernel, workgroup and LDS the call site asks for; then the sparse ones with `kernel_tiny` (the same kernel, or its run-time-layout
-// instantiation where the layout is a template parameter: a compile-time plane distance would pin the LDS request at tens of KB),
-// TILE_TINY_THREADS threads and the LDS the SAME size expression yields for a halo of TILE_TINY_S + TILE_TINY_SB slots.  The
-// expression and the kernel arguments are re-read under shadowed names: every call site calls them `c`, `L` and (where it has one) `ds`.
+// One launch per pass — or one per launch class of the step (StepCtx::slot_order): the full slots with the kernel, workgroup and LDS
+// the call site asks for; the light ones (StepCtx::nlight) with `kernel_light` — the family's instantiation for its smallest
+// compile-time layout, `ds_light` — and the LDS the SAME size expression yields for the light class's bounds; the sparse ones
+// (StepCtx::ntiny) with `kernel_tiny` (the run-time-layout instantiation: a compile-time plane distance would pin the LDS request at
+// tens of KB), TILE_TINY_THREADS threads and the LDS of a halo of TILE_TINY_S + TILE_TINY_SB slots.  The expression and the kernel
+// arguments are re-read under shadowed names: every call site calls them `c`, `L` and (where it has one) `ds`.
 inline TileLds tile_tiny_lds(const TileLds& L) {
     TileLds t = L;
     t.max_halo_fluid = TILE_TINY_S; t.max_halo_boundary = L.max_halo_boundary ? TILE_TINY_SB : 0u;
@@ -130,26 +131,51 @@ inline TileLds tile_tiny_lds(const TileLds& L) {
     t.threads = TILE_TINY_THREADS;
     return t;
 }
-#define SALVA_LAUNCH_TILE_2(kernel, kernel_tiny, c, L, lds, s, ...)                                   \
+// the light class: a halo every kernel family serves from its smallest compile-time layout — the plane layouts' three-per-CU
+// distances (P3_DS_THREE fluid slots; P2_DS_THREE fluid + boundary slots) and FIXED_DS_SMALL for both uses of the 16-byte layouts
+// (pairs.h pw_slots: padded fluid + boundary; pk_slots: padded fluid + 2 x boundary)
+__host__ __device__ inline bool tile_is_light(uint32_t s, uint32_t sb) {
+    return s <= P3_DS_THREE && ((s + 63u) & ~63u) + 2u * sb <= FIXED_DS_SMALL;
+}
+inline TileLds tile_light_lds(const TileLds& L) {
+    TileLds t = L;
+    t.max_halo_fluid = L.max_halo_fluid < P3_DS_THREE ? L.max_halo_fluid : P3_DS_THREE;
+    t.max_halo_boundary = L.max_halo_boundary < FIXED_DS_SMALL / 2u ? L.max_halo_boundary : FIXED_DS_SMALL / 2u;
+    t.max_sum = (L.max_sum && L.max_sum < FIXED_DS_SMALL) ? L.max_sum : FIXED_DS_SMALL;
+    t.max_raw = (L.max_raw && L.max_raw < FIXED_DS_SMALL) ? L.max_raw : FIXED_DS_SMALL;
+    return t;
+}
+#define SALVA_LAUNCH_TILE_3(kernel, kernel_light, ds_light, kernel_tiny, c, L, lds, s, ...)         \
     do {                                                                                           \
         if ((c).n && (c).nlaunch) {                                                                \
-            if ((c).ntiny == 0u || (c).slot_order == nullptr) {                                    \
+            if (((c).ntiny == 0u && (c).nlight == 0u) || (c).slot_order == nullptr) {              \
                 const uint32_t _lds = (lds);                                                       \
                 ::salva::ensure_tile_lds(kernel, _lds);                                            \
                 kernel<<<(c).nlaunch, (L).threads, _lds, s>>>(__VA_ARGS__);                        \
             } else {                                                                               \
-                const uint32_t _nbig = (c).nlaunch - (c).ntiny, _ntiny = (c).ntiny;                \
+                const uint32_t _ntiny = (c).ntiny, _nlight = (c).nlight;                           \
+                const uint32_t _nfull = (c).nlaunch - _nlight - _ntiny;                            \
                 ::salva::StepCtx _c2 = (c);                                                        \
                 const ::salva::TileLds _lt = ::salva::tile_tiny_lds(L);                            \
+                const ::salva::TileLds _ll = ::salva::tile_light_lds(L);                           \
                 const unsigned _thr = (L).threads;                                                 \
-                if (_nbig) {                                                                       \
+                if (_nfull) {                                                                      \
                     const uint32_t _lds = (lds);                                                   \
                     ::salva::ensure_tile_lds(kernel, _lds);                                        \
-                    _c2.slot_base = 0u;                                                        \
-                    { const ::salva::StepCtx c = _c2; kernel<<<_nbig, _thr, _lds, s>>>(__VA_ARGS__); } \
+                    _c2.slot_base = 0u;                                                            \
+                    { const ::salva::StepCtx c = _c2; kernel<<<_nfull, _thr, _lds, s>>>(__VA_ARGS__); } \
                 }                                                                                  \
-                {                                                                                  \
-                    _c2.slot_base = _nbig;                                                     \
+                if (_nlight) {                                                                     \
+                    _c2.slot_base = _nfull;                                                        \
+                    const ::salva::TileLds L = _ll;                                                \
+                    const uint32_t ds = (ds_light); (void)ds;                                      \
+                    const ::salva::StepCtx c = _c2;                                                \
+                    const uint32_t _lds = (lds);                                                   \
+                    ::salva::ensure_tile_lds(kernel_light, _lds);                                  \
+                    kernel_light<<<_nlight, _thr, _lds, s>>>(__VA_ARGS__);                         \
+                }                                                                                  \
+                if (_ntiny) {                                                                      \
+                    _c2.slot_base = _nfull + _nlight;                                              \
                     const ::salva::TileLds L = _lt;                                                \
                     const uint32_t ds = 0u; (void)ds;                                              \
                     const ::salva::StepCtx c = _c2;                                                \
@@ -161,7 +187,7 @@ inline TileLds tile_tiny_lds(const TileLds& L) {
             SALVA_HIP_CHECK(hipGetLastError());                                                    \
         }                                                                                          \
     } while (0)
-#define SALVA_LAUNCH_TILE(kernel, c, L, lds, s, ...) SALVA_LAUNCH_TILE_2(kernel, kernel, c, L, lds, s, __VA_ARGS__)
+#define SALVA_LAUNCH_TILE(kernel, c, L, lds, s, ...) SALVA_LAUNCH_TILE_3(kernel, kernel, 0u, kernel, c, L, lds, s, __VA_ARGS__)
 
 // key of cell (cx,cy,cz) (absolute cell coords) in grid g, or inside = false.  (mx, my, mz): the folding masks of the grid the
 // COORDINATES belong to (device_types.h TileGrid) — g's own, except where a tile of the folded fluid grid looks up the cells of the

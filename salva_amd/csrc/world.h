@@ -360,8 +360,9 @@ class World {
     bool pre_off = false;          // SALVA_HIP_NO_PREGRID=1 (A/B, tests)
     // two launch classes per pass (device_types.h StepCtx::slot_order)
     DevBuf<uint32_t> slot_order;
-    uint32_t class_ntiny = 0;      // sparse slots of this step, when they run in launches of their own (0: one launch per pass)
-    bool classes_off = false, classes_forced = false;  // SALVA_HIP_NO_CLASSES=1 / SALVA_HIP_CLASSES=1
+    uint32_t class_ntiny = 0;      // sparse slots of this step, when they run in launches of their own (0: with the others)
+    uint32_t class_nlight = 0;     // light slots of this step, when they run in launches of their own (0: with the full ones)
+    bool classes_off = false, classes_forced = false, light_on = false;  // SALVA_HIP_NO_CLASSES=1 / SALVA_HIP_CLASSES=1 / SALVA_HIP_LIGHT=1 (the light class: opt-in, it lost)
     // splitting of over-full tiles (device_types.h StepCtx::split_s)
     bool split_off = false;        // SALVA_HIP_NO_SPLIT=1
     uint32_t split_forced = 0;     // SALVA_HIP_SPLIT_S=k: split at k halo particles whatever the statistics say (tests)

@@ -142,6 +142,7 @@ World::World(const SalvaHipParams& p) : prm(p) {
     split_off = getenv("SALVA_HIP_NO_SPLIT") != nullptr;
     classes_off = getenv("SALVA_HIP_NO_CLASSES") != nullptr;
     classes_forced = getenv("SALVA_HIP_CLASSES") != nullptr;
+    light_on = getenv("SALVA_HIP_LIGHT") != nullptr;
     if (const char* e = getenv("SALVA_HIP_SPLIT_S")) split_forced = (uint32_t)std::max(atoi(e), 1);
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
     two_mass_off = getenv("SALVA_HIP_NO_TWO_MASS") != nullptr;
@@ -687,7 +688,7 @@ StepCtx World::make_ctx() {
     c.halo_stride = halo_stride; c.bhalo_stride = bhalo_stride;
     c.ntiles = (uint32_t)gf.ntiles();
     c.split_s = split_s_cur;
-    c.slot_order = class_ntiny ? slot_order.p : nullptr; c.slot_base = 0u; c.ntiny = class_ntiny;
+    c.slot_order = (class_ntiny || class_nlight) ? slot_order.p : nullptr; c.slot_base = 0u; c.ntiny = class_ntiny; c.nlight = class_nlight;
     c.tile_ids = G().tile_ids.p; c.tile_rank = G().tile_rank.p; c.nlaunch = nlaunch; c.slot_desc = G().slot_desc.p; c.slot_info = slot_info.p;
     c.spec = spec_mode ? 1u : 0u; c.halo_cap = halo_cap; c.bhalo_cap = bhalo_cap; c.nslices_cap = nslices_cap;
     c.halo_len = halo_len; c.bhalo_len = bhalo_len;
@@ -1433,10 +1434,12 @@ int World::step(float dt, const float g[3], SalvaHipStepStats* stats) {
     st.nparticles = n;
     {   // self.counters.reset() (liquid_world.rs:73); the pass counters of this implementation are cumulative
         const uint64_t sp = counters.speculative_passes, dp = counters.discarded_passes;
-        const uint64_t keep4[4] = {counters.chained_passes, counters.chain_breaks, counters.pregrid_adopted, counters.pregrid_dropped};
+        const uint64_t keep4[6] = {counters.chained_passes, counters.chain_breaks, counters.pregrid_adopted, counters.pregrid_dropped,
+                                   counters.light_class_passes, counters.sparse_class_passes};
         counters = SalvaHipCounters{};
         counters.speculative_passes = sp; counters.discarded_passes = dp;
         counters.chained_passes = keep4[0]; counters.chain_breaks = keep4[1]; counters.pregrid_adopted = keep4[2]; counters.pregrid_dropped = keep4[3];
+        counters.light_class_passes = keep4[4]; counters.sparse_class_passes = keep4[5];
     }
     sticky.clear();  // init_with_fluids runs at the top of every step, substeps or not (liquid_world.rs:76)
     substeps.clear();  // (also for a step that runs no substep at all: salva_hip_get_substeps then agrees with counters.nsubsteps = 0)
@@ -1815,8 +1818,8 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
         lds.max_sum = spec ? 0u : tt.max_sum;  // (a speculative pass knows the two maxima only: TileLds::sum_slots falls back to their sum)
         lds.max_raw = spec ? 0u : tt.max_raw;
         if (tile_trace)
-            fprintf(stderr, "salva_hip tiles: nonempty %u max_s %u max_sb %u max_sum %u max_raw %u heavy %u tiny %u split_s %u mass_uniform %g | chained %llu breaks %llu pregrid %llu dropped %llu\n",
-                    tt.nonempty, tt.max_s, tt.max_sb, tt.max_sum, tt.max_raw, tt.heavy, tt.ntiny, split_s_cur, (double)mass_uniform,
+            fprintf(stderr, "salva_hip tiles: nonempty %u max_s %u max_sb %u max_sum %u max_raw %u heavy %u light %u tiny %u split_s %u mass_uniform %g | chained %llu breaks %llu pregrid %llu dropped %llu\n",
+                    tt.nonempty, tt.max_s, tt.max_sb, tt.max_sum, tt.max_raw, tt.heavy, tt.nlight, tt.ntiny, split_s_cur, (double)mass_uniform,
                     (unsigned long long)chain_steps, (unsigned long long)chain_breaks, (unsigned long long)pre_adopted, (unsigned long long)pre_dropped);
         if (!spec) {
             // next step's splitting: on while the over-full tiles are few (each costs a second workgroup and a third more staging, and
@@ -1900,18 +1903,33 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             halo_cap = lds.max_halo_fluid; bhalo_cap = lds.max_halo_boundary; nslices_cap = nslices;
             halo_len = need_f; bhalo_len = need_b;
         }
-        // Two launch classes (device_types.h StepCtx::slot_order): worth a second launch per pass once the sparse slots are many —
-        // a thousand of them hold a CU's LDS for a round and a third of the chip each pass; SALVA_HIP_NO_CLASSES=1: never,
-        // SALVA_HIP_CLASSES=1: whenever there is one of each kind (tests).
-        class_ntiny = 0u;
-        if (!spec && !classes_off && tt.ntiny > 0u && tt.ntiny < tt.nonempty && (classes_forced || tt.ntiny >= 512u)) class_ntiny = tt.ntiny;
-        if (class_ntiny) slot_order.ensure(nlaunch, stream, false, 1.5f);
+        // Launch classes (device_types.h StepCtx::slot_order).  Sparse slots: worth a launch of their own per pass once they are many —
+        // a thousand of them hold a CU's LDS for a round and a third of the chip each pass.  Light slots: the class the round-5 review
+        // asked for (tiles under the three-per-CU limit in one launch, those above it in another) — built, bit-identical, and a
+        // LOSS on the scene it was meant for: in steps 300-399 of config 2 (1015 full tiles, 860 light ones) 2.35 against 2.00 ms per
+        // step, 2.71 against 2.36 in steps 900-999 (profiles/r06_experiments/r06j_light_class_lost.log) — a second launch per pass
+        // ends in a second tail of straggling tiles (~13 us per pass here), which is more than the third resident tile gives back
+        // to the light half.  Opt-in: SALVA_HIP_LIGHT=1 (when the fullest halo is beyond a three-per-CU layout and the light slots
+        // are >= 256).  SALVA_HIP_NO_CLASSES=1: no class ever; SALVA_HIP_CLASSES=1: both, whenever there is a slot of the kind and
+        // one outside it (tests).
+        class_ntiny = class_nlight = 0u;
+        if (!spec && !classes_off) {
+            if (tt.ntiny > 0u && tt.ntiny < tt.nonempty && (classes_forced || tt.ntiny >= 512u)) class_ntiny = tt.ntiny;
+            const bool beyond = tt.max_s > P3_DS_THREE || tt.max_raw > P2_DS_THREE || tt.max_sum > FIXED_DS_SMALL;
+            const uint32_t nfull = tt.nonempty - tt.nlight - tt.ntiny;
+            if (tt.nlight > 0u && nfull > 0u && (classes_forced || (light_on && beyond && tt.nlight >= 256u))) class_nlight = tt.nlight;
+            // (sparse slots without a launch of their own are light ones — tile_is_light holds for them — when the light class runs)
+            if (class_nlight && !class_ntiny) class_nlight += tt.ntiny;
+        }
+        if (class_ntiny || class_nlight) slot_order.ensure(nlaunch, stream, false, 1.5f);
+        if (class_nlight) ++counters.light_class_passes;
+        if (class_ntiny) ++counters.sparse_class_passes;
         {
-            const uint32_t keep = class_ntiny;
-            class_ntiny = 0u;  // (the table builder itself runs over every slot in one launch)
+            const uint32_t keep_t = class_ntiny, keep_l = class_nlight;
+            class_ntiny = class_nlight = 0u;  // (the table builder itself runs over every slot in one launch)
             c = make_ctx();
-            launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, slot_info.p, stream, keep ? slot_order.p : nullptr, nlaunch - keep);
-            class_ntiny = keep;
+            launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, slot_info.p, stream, (keep_t || keep_l) ? slot_order.p : nullptr, keep_l, keep_t);
+            class_ntiny = keep_t; class_nlight = keep_l;
         }
         c = make_ctx();
 

@@ -569,6 +569,8 @@ class Counters:
     chain_breaks: int = 0
     pregrid_adopted: int = 0   # steps whose grid part the previous step had enqueued already
     pregrid_dropped: int = 0
+    light_class_passes: int = 0   # passes that ran small-halo / sparse slots in launches of their own (SalvaHipCounters)
+    sparse_class_passes: int = 0
     ncontacts: int = 0
     n_divergence_iters: int = 0
     n_pressure_iters: int = 0
@@ -922,6 +924,7 @@ class LiquidWorld:
             c.speculative_passes, c.discarded_passes = int(t.speculative_passes), int(t.discarded_passes)
             c.chained_passes, c.chain_breaks = int(t.chained_passes), int(t.chain_breaks)
             c.pregrid_adopted, c.pregrid_dropped = int(t.pregrid_adopted), int(t.pregrid_dropped)
+            c.light_class_passes, c.sparse_class_passes = int(t.light_class_passes), int(t.sparse_class_passes)
         return self._counters
 
     # ---- liquid_world.rs:62-158

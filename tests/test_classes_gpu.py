@@ -15,7 +15,7 @@ from salva_amd import scenes
 
 pytestmark = pytest.mark.gpu
 R = 0.025
-SWITCHES = ("SALVA_HIP_NO_CLASSES", "SALVA_HIP_CLASSES", "SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FOLD")
+SWITCHES = ("SALVA_HIP_NO_CLASSES", "SALVA_HIP_CLASSES", "SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FOLD", "SALVA_HIP_NO_SPLIT", "SALVA_HIP_LIGHT")
 
 
 def _make(env, scene):
@@ -142,5 +142,68 @@ def test_the_convergence_test_that_rides_in_an_apply_pass_runs_once_per_pass():
     w1, f1, t1 = _run({"SALVA_HIP_CLASSES": "1"}, s, 12)
     its = [t[0] for t in t0]
     assert sum(a >= 4 and b >= 4 for a, b in zip(its, its[1:])) >= 4, its  # (the speculative path follows a step of four iterations or more)
+    assert t1 == t0
+    _same(w1, f1, w0, f0)
+
+
+# ---- the light class: slots whose halo fits the three-per-CU layouts, beside slots whose halo does not (StepCtx::nlight)
+def _squeezed_column(nx, ny, nz, frac=0.34, solver="dfsph", forces=(("xsph", 0.5, 0.0),), two=False, strays=True):
+    """A column whose foot (the lower `frac` of it) is squeezed to 1.6x the rest density: halos beyond 2080 particles there, ordinary
+    ones above, a few strays around it."""
+    s = Scene(R, 2.0, solver)
+    fluid, shell = scenes.tank(nx, ny, nz, R)
+    fluid = scenes.jitter(fluid, 0.1 * R, seed=2)
+    y0 = float(fluid[:, 1].min())
+    cut = int(ny * frac) * 2 * R
+    low = fluid[:, 1] < y0 + cut
+    fluid[low, 1] = (y0 + (fluid[low, 1] - y0) * np.float32(0.62)).astype(np.float32)
+    fluid[~low, 1] -= np.float32(cut * 0.38)
+    pos = _with_strays(fluid, nstray=20) if strays else fluid
+    if two:
+        upper = pos[:, 1] > np.median(pos[:, 1])
+        s.add_fluid(np.ascontiguousarray(pos[~upper]), None, 1000.0, forces=list(forces))
+        s.add_fluid(np.ascontiguousarray(pos[upper]), None, 500.0, forces=list(forces))
+    else:
+        s.add_fluid(pos, None, 1000.0, forces=list(forces))
+    s.add_boundary(shell)
+    return s
+
+
+LIGHT_CASES = {
+    "dfsph+xsph": dict(),
+    "dfsph general kernels": dict(env={"SALVA_HIP_NO_PLANES": "1"}),
+    "two masses": dict(two=True),
+    "iisph+akinci": dict(solver="iisph", forces=(("akinci", 1.0, 10.0),)),
+    "artificial+he2014": dict(forces=(("artificial", 0.05, 0.02), ("he2014", 0.5, 0.2))),
+}
+
+
+@pytest.mark.parametrize("case", sorted(LIGHT_CASES))
+def test_light_slots_on_the_small_layouts_beside_full_ones_change_nothing(case):
+    kw = dict(LIGHT_CASES[case])
+    env = dict(kw.pop("env", {}), SALVA_HIP_NO_SPLIT="1")  # (or the over-full tiles of so small a scene would simply be cut)
+    sc = _squeezed_column(24, 36, 24, **kw)
+    w0, f0, t0 = _run(dict(env, SALVA_HIP_NO_CLASSES="1"), sc, 8)
+    w1, f1, t1 = _run(dict(env, SALVA_HIP_CLASSES="1"), sc, 8)
+    # (the squeezed foot expands within a few steps, sooner under the stronger forces: then no halo is beyond the small layouts)
+    assert w0.counters.light_class_passes == 0 and w1.counters.light_class_passes >= 2, w1.counters
+    assert w1.counters.sparse_class_passes >= 8, w1.counters  # (three launches per pass while it lasts: full | light | sparse)
+    assert t1 == t0
+    _same(w1, f1, w0, f0)
+    a, b = w0.fluid_contacts(f0[0]), w1.fluid_contacts(f1[0])
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_the_light_class_when_asked_for_runs_where_many_halos_fit_the_small_layouts_and_some_do_not():
+    """A third of a million particles whose lower 40 % are over-full — too many tiles to cut them all (World::substep keeps tiles
+    whole when more than a fifth are over-full), and hundreds that are not: with SALVA_HIP_LIGHT=1 those run three per CU again, in
+    launches of their own.  (Opt-in: on the bench scene the second launch per pass costs more than it brings, world.hip.)"""
+    sc = _squeezed_column(64, 80, 64, frac=0.4, strays=False)
+    os.environ.pop("SALVA_HIP_SPLIT_S", None)
+    w0, f0, t0 = _run({"SALVA_HIP_NO_CLASSES": "1"}, sc, 4)
+    w2, f2, t2 = _run({}, sc, 4)
+    assert w2.counters.light_class_passes == 0 and t2 == t0
+    w1, f1, t1 = _run({"SALVA_HIP_LIGHT": "1"}, sc, 4)
+    assert w1.counters.light_class_passes >= 2 and w1.counters.sparse_class_passes == 0, w1.counters  # (until the foot has expanded)
     assert t1 == t0
     _same(w1, f1, w0, f0)

@@ -23,7 +23,7 @@ for k in range(steps):
         print(f"steps {k-99:4d}..{k:4d}: {np.mean(ms[a]):.3f} ms/step, div iters {np.mean(it[a]):.1f}, max halo {min(halo[a])}..{max(halo[a])}, threads {int(st.reserved[2])}", flush=True)
 print(f"whole {steps}: {np.mean(ms):.3f} ms/step = {1e6 / (np.mean(ms) * 1e-3):.3e} particle-steps/s")
 c = w.counters
-print("counters: chained", c.chained_passes, "breaks", c.chain_breaks, "pregrid", c.pregrid_adopted, "dropped", c.pregrid_dropped, "discarded", c.discarded_passes)
+print("counters: light", c.light_class_passes, "sparse", c.sparse_class_passes, "chained", c.chained_passes, "breaks", c.chain_breaks, "pregrid", c.pregrid_adopted, "dropped", c.pregrid_dropped, "discarded", c.discarded_passes)
 for kid, name in ((1, "k_divergence"), (6, "k_divergence_apply"), (0, "k_pred_density"), (4, "k_nbr_tile")):
     print(name, "%.1f us" % w.time_kernel(kid, 20))
 PY
