@@ -153,10 +153,6 @@ struct StepCtx {
     // the sparse slots], each kind in slot order (k_tile_halo_fill); a launch works on slot_order[slot_base + mapped block].
     // nullptr: one class, block -> slot directly.
     const uint32_t* slot_order;
-    // A/B (SALVA_HIP_TILE_ORDER=1): the halo's positions in tile order, [nlaunch x halo_stride] each (strided tables only); nullptr: off
-    const float2* tpos_xy;
-    const float* tpos_z;
-    uint32_t tpos_dma;          // 1: the XY plane goes global -> LDS by DMA (SALVA_HIP_TILE_ORDER=2)
     uint32_t slot_base;
     uint32_t ntiny;             // sparse slots of this step when they have their own launches (0: they run with the others)
     uint32_t nlight;            // light slots of this step when they have their own launches (0: they run with the full ones)

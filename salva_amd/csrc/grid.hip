@@ -614,20 +614,6 @@ __global__ __launch_bounds__(TABLE_THREADS) void k_tile_halo_fill(StepCtx c, uin
         }
     }
 }
-// A/B (SALVA_HIP_TILE_ORDER=1): the positions of every halo slot, in tile order (tile.h Tile::tile_pos)
-__global__ __launch_bounds__(BLOCK) void k_tile_order_pos(StepCtx c, float2* __restrict__ xy, float* __restrict__ z) {
-    const uint4 info = c.slot_info[blockIdx.x];
-    const uint32_t S = info.w & 0xffffu;
-    const size_t row = (size_t)blockIdx.x * c.halo_stride;
-    for (uint32_t s = threadIdx.x; s < S; s += BLOCK) {
-        const float4 p = c.posm[c.halo_src[row + s]];
-        xy[row + s] = make_float2(p.x, p.y);
-        z[row + s] = p.z;
-    }
-}
-void launch_tile_order_pos(const StepCtx& c, float2* xy, float* z, hipStream_t s) {
-    if (c.nlaunch && c.halo_stride) k_tile_order_pos<<<c.nlaunch, BLOCK, 0, s>>>(c, xy, z);
-}
 // `nslots_bound` >= number of non-empty tiles (the host does not know the exact count yet)
 void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cnt, uint4* slot_desc, hipStream_t s) {
     if (nslots_bound) k_tile_count<<<nslots_bound, TABLE_THREADS, TILE_TABLE_BYTES, s>>>(c, tile_cnt, slot_desc);

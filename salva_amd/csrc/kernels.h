@@ -57,7 +57,6 @@ void launch_tile_count(const StepCtx& c, uint32_t nslots_bound, TileAcc* tile_cn
 // they get launches of their own, else 0)
 void launch_tile_halo_fill(const StepCtx& c, uint32_t* halo_src, uint32_t* bhalo_src, uint4* slot_info, hipStream_t s, uint32_t* slot_order = nullptr,
                            uint32_t nlight = 0u, uint32_t ntiny = 0u);
-void launch_tile_order_pos(const StepCtx& c, float2* xy, float* z, hipStream_t s);  // A/B: SALVA_HIP_TILE_ORDER=1
 size_t scan_tiles_temp_bytes(uint32_t n);
 void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, uint32_t n, hipStream_t s);
 // neighbour lists (per-slice ELL blocks of 16-bit halo slots, capacity c.cap_ff / c.cap_fb dwords per particle), built

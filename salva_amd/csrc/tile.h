@@ -523,23 +523,6 @@ struct Tile {
     // Filled through registers — two 16-byte loads and three ds_write_b64 per slot: LDS-DMA moves 4 or 16 bytes per lane, so it
     // could only fill 4-byte planes, with three times the staging instructions.  No padding to 64 slots is needed this way.
     // Requires dist8 >= S * 8, a multiple of 8.  Afterwards pool_used = the end of the third plane.
-    // A/B (round 6, the round-5 review's item 3): the positions of the halo, gathered once per step into TILE order
-    // (StepCtx::tpos_xy / tpos_z, k_tile_order_pos) — every pass then reads the static half of its staged record as two coalesced
-    // streams instead of a 16-byte gather by index
-    __device__ __forceinline__ float4 tile_pos(const StepCtx& c, uint32_t sl) const {
-        const float2 xy = c.tpos_xy[hoff + sl];
-        return make_float4(xy.x, xy.y, c.tpos_z[hoff + sl], 0.0f);
-    }
-    // ... and its second form (SALVA_HIP_TILE_ORDER=2): the XY plane of the tile-ordered copy IS the LDS plane, so whole 128-slot
-    // pieces of it go global -> LDS by DMA, 16 bytes per lane, no register and no ds_write; returns the first slot NOT copied that way
-    __device__ __forceinline__ uint32_t dma_xy_plane(const StepCtx& c) const {
-        const uint32_t full = S & ~127u, lane = threadIdx.x & (WAVE - 1), nw = blockDim.x / WAVE;
-        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(c.tpos_xy + hoff);
-        for (uint32_t q = wv * 128u; q < full; q += nw * 128u)
-            glds16(src + (q >> 1) + lane, reinterpret_cast<float4*>(pool + q * 8u));
-        return full;
-    }
     __device__ __forceinline__ void p3_store(uint32_t slot, uint32_t dist8, const float4& a, const float4& b) const {
         lds_st8(slot * 8u, a.x, a.y);
         lds_st8(slot * 8u + dist8, a.z, b.x);
@@ -547,28 +530,6 @@ struct Tile {
     }
     __device__ __forceinline__ void stage_p3(const StepCtx& c, const float4* __restrict__ posm, const float4* __restrict__ w, uint32_t dist8) {
         const uint32_t nt = blockDim.x, s0 = threadIdx.x;
-        if (c.halo_stride && c.tpos_xy && c.tpos_dma) {
-            const uint32_t full = dma_xy_plane(c);
-            const uint32_t pre[PRE] = {pre0, pre1, pre2, pre3};
-            float z[PRE]; float4 b[PRE];
-#pragma unroll
-            for (int k = 0; k < PRE; ++k) {
-                const uint32_t sl = s0 + (uint32_t)k * nt;
-                z[k] = c.tpos_z[hoff + (sl < S ? sl : 0u)]; b[k] = w[sl < S ? pre[k] : own_begin];
-            }
-#pragma unroll
-            for (int k = 0; k < PRE; ++k) {
-                const uint32_t sl = s0 + (uint32_t)k * nt;
-                if (sl < S) { lds_st8(sl * 8u + dist8, z[k], b[k].x); lds_st8(sl * 8u + 2u * dist8, b[k].y, b[k].z); }
-            }
-            for (uint32_t sl = s0 + PRE * nt; sl < S; sl += nt) {
-                const float4 q = w[c.halo_src[hoff + sl]];
-                lds_st8(sl * 8u + dist8, c.tpos_z[hoff + sl], q.x); lds_st8(sl * 8u + 2u * dist8, q.y, q.z);
-            }
-            for (uint32_t sl = full + s0; sl < S; sl += nt) { const float2 xy = c.tpos_xy[hoff + sl]; lds_st8(sl * 8u, xy.x, xy.y); }
-            pool_used = 2u * dist8 + ((S * 8u + 15u) & ~15u);
-            return;
-        }
         if (c.halo_stride) {
             // every load of the thread's (up to) four slots is issued before the first store waits for one
             const uint32_t pre[PRE] = {pre0, pre1, pre2, pre3};
@@ -577,7 +538,7 @@ struct Tile {
             for (int k = 0; k < PRE; ++k) {
                 const uint32_t sl = s0 + (uint32_t)k * nt;
                 const uint32_t g = sl < S ? pre[k] : own_begin;
-                a[k] = c.tpos_xy ? tile_pos(c, sl < S ? sl : 0u) : posm[g]; b[k] = w[g];
+                a[k] = posm[g]; b[k] = w[g];
             }
 #pragma unroll
             for (int k = 0; k < PRE; ++k) {
@@ -586,7 +547,7 @@ struct Tile {
             }
             for (uint32_t sl = s0 + PRE * nt; sl < S; sl += nt) {
                 const uint32_t g = c.halo_src[hoff + sl];
-                p3_store(sl, dist8, c.tpos_xy ? tile_pos(c, sl) : posm[g], w[g]);
+                p3_store(sl, dist8, posm[g], w[g]);
             }
         } else {
             for_halo(c, [&](uint32_t sl, uint32_t g) { p3_store(sl, dist8, posm[g], w[g]); });
@@ -598,29 +559,6 @@ struct Tile {
     // ds_read_b64 per contact instead of a ds_read_b128 and a ds_read_b32.  pool_used = the end of the second plane afterwards.
     __device__ __forceinline__ void stage_p2(const StepCtx& c, const float4* __restrict__ posm, const float* __restrict__ k, uint32_t dist8) {
         const uint32_t nt = blockDim.x, s0 = threadIdx.x;
-        if (c.halo_stride && c.tpos_xy && c.tpos_dma) {
-            const uint32_t full = dma_xy_plane(c);
-            const uint32_t pre[PRE] = {pre0, pre1, pre2, pre3};
-            float z[PRE], b[PRE];
-#pragma unroll
-            for (int q = 0; q < PRE; ++q) {
-                const uint32_t sl = s0 + (uint32_t)q * nt;
-                z[q] = c.tpos_z[hoff + (sl < S ? sl : 0u)]; b[q] = k[sl < S ? pre[q] : own_begin];
-            }
-#pragma unroll
-            for (int q = 0; q < PRE; ++q) {
-                const uint32_t sl = s0 + (uint32_t)q * nt;
-                if (sl < S) lds_st8(sl * 8u + dist8, z[q], b[q]);
-            }
-            for (uint32_t sl = s0 + PRE * nt; sl < S; sl += nt) lds_st8(sl * 8u + dist8, c.tpos_z[hoff + sl], k[c.halo_src[hoff + sl]]);
-            for (uint32_t sl = full + s0; sl < S; sl += nt) { const float2 xy = c.tpos_xy[hoff + sl]; lds_st8(sl * 8u, xy.x, xy.y); }
-            for_halo_boundary(c, [&](uint32_t sl, uint32_t g) {
-                const float4 p = c.bposv[g];
-                lds_st8((S + sl) * 8u, p.x, p.y); lds_st8((S + sl) * 8u + dist8, p.z, p.w);
-            });
-            pool_used = dist8 + (S + SB) * 8u;
-            return;
-        }
         if (c.halo_stride) {
             const uint32_t pre[PRE] = {pre0, pre1, pre2, pre3};
             float4 a[PRE];
@@ -629,7 +567,7 @@ struct Tile {
             for (int q = 0; q < PRE; ++q) {
                 const uint32_t sl = s0 + (uint32_t)q * nt;
                 const uint32_t g = sl < S ? pre[q] : own_begin;
-                a[q] = c.tpos_xy ? tile_pos(c, sl < S ? sl : 0u) : posm[g]; b[q] = k[g];
+                a[q] = posm[g]; b[q] = k[g];
             }
 #pragma unroll
             for (int q = 0; q < PRE; ++q) {
@@ -638,7 +576,7 @@ struct Tile {
             }
             for (uint32_t sl = s0 + PRE * nt; sl < S; sl += nt) {
                 const uint32_t g = c.halo_src[hoff + sl];
-                const float4 p = c.tpos_xy ? tile_pos(c, sl) : posm[g];
+                const float4 p = posm[g];
                 lds_st8(sl * 8u, p.x, p.y); lds_st8(sl * 8u + dist8, p.z, k[g]);
             }
         } else {

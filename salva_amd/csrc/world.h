@@ -360,10 +360,6 @@ class World {
     bool pre_off = false;          // SALVA_HIP_NO_PREGRID=1 (A/B, tests)
     // two launch classes per pass (device_types.h StepCtx::slot_order)
     DevBuf<uint32_t> slot_order;
-    // A/B (SALVA_HIP_TILE_ORDER=1): the halo's positions in tile order (device_types.h StepCtx::tpos_xy)
-    DevBuf<float2> tpos_xy;
-    DevBuf<float> tpos_z;
-    bool tile_order = false, tile_order_dma = false, tile_order_now = false;
     uint32_t class_ntiny = 0;      // sparse slots of this step, when they run in launches of their own (0: with the others)
     uint32_t class_nlight = 0;     // light slots of this step, when they run in launches of their own (0: with the full ones)
     bool classes_off = false, classes_forced = false, light_on = false;  // SALVA_HIP_NO_CLASSES=1 / SALVA_HIP_CLASSES=1 / SALVA_HIP_LIGHT=1 (the light class: opt-in, it lost)

@@ -143,8 +143,6 @@ World::World(const SalvaHipParams& p) : prm(p) {
     classes_off = getenv("SALVA_HIP_NO_CLASSES") != nullptr;
     classes_forced = getenv("SALVA_HIP_CLASSES") != nullptr;
     light_on = getenv("SALVA_HIP_LIGHT") != nullptr;
-    tile_order = getenv("SALVA_HIP_TILE_ORDER") != nullptr;
-    tile_order_dma = tile_order && atoi(getenv("SALVA_HIP_TILE_ORDER")) == 2;
     if (const char* e = getenv("SALVA_HIP_SPLIT_S")) split_forced = (uint32_t)std::max(atoi(e), 1);
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
     two_mass_off = getenv("SALVA_HIP_NO_TWO_MASS") != nullptr;
@@ -690,7 +688,6 @@ StepCtx World::make_ctx() {
     c.halo_stride = halo_stride; c.bhalo_stride = bhalo_stride;
     c.ntiles = (uint32_t)gf.ntiles();
     c.split_s = split_s_cur;
-    c.tpos_xy = tile_order_now ? tpos_xy.p : nullptr; c.tpos_z = tile_order_now ? tpos_z.p : nullptr; c.tpos_dma = tile_order_dma ? 1u : 0u;
     c.slot_order = (class_ntiny || class_nlight) ? slot_order.p : nullptr; c.slot_base = 0u; c.ntiny = class_ntiny; c.nlight = class_nlight;
     c.tile_ids = G().tile_ids.p; c.tile_rank = G().tile_rank.p; c.nlaunch = nlaunch; c.slot_desc = G().slot_desc.p; c.slot_info = slot_info.p;
     c.spec = spec_mode ? 1u : 0u; c.halo_cap = halo_cap; c.bhalo_cap = bhalo_cap; c.nslices_cap = nslices_cap;
@@ -1933,12 +1930,6 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
             c = make_ctx();
             launch_tile_halo_fill(c, halo_src.p, bhalo_src.p, slot_info.p, stream, (keep_t || keep_l) ? slot_order.p : nullptr, keep_l, keep_t);
             class_ntiny = keep_t; class_nlight = keep_l;
-            tile_order_now = false;
-            if (tile_order && halo_stride && !spec && !has_dyn) {  // A/B: the halo's positions in tile order, once per pass
-                tpos_xy.ensure(need_f + 128, stream, false, 1.2f); tpos_z.ensure(need_f + 128, stream, false, 1.2f);
-                launch_tile_order_pos(c, tpos_xy.p, tpos_z.p, stream);
-                tile_order_now = true;
-            }
         }
         c = make_ctx();
 
