@@ -2,7 +2,7 @@
 //!
 //!   cargo run --release -- [--side 100] [--steps 50] [--warmup 5] [--dump DIR]        (the bench.py tank, built here)
 //!   cargo run --release -- --scene scenes/NAME.scene --dump DIR                        (a scene written by
-//!       tests/golden/export_scenes.py: the six golden scenes are committed under scenes/; `--bench 100` adds config 2)
+//!       tests/golden/export_scenes.py: the seven golden scenes are committed under scenes/; `--bench 100` adds config 2)
 //!
 //! Scene mode dumps, after the first step (prefix s1_) and after the last (no prefix): pos_F.f32 / vel_F.f32 per fluid
 //! (xyz, f32 LE), bvol_B.f32 per boundary, bforce_B.f32 for boundaries that receive forces, and ncontacts.txt (one line per

@@ -188,17 +188,22 @@ struct StepCtx {
     // posm.w every step): the evaluate kernels then stage 24 bytes per halo slot instead of 32 (no mass in LDS; tile.h stage_p3)
     // and multiply the finished sum by it.  0: masses differ (non-uniform volumes, fluids of different density0), or unknown.
     float mass_uniform;
-    // Two-mass worlds (BASELINE config 4: two fluids of different density0, each with `Fluid::new`'s uniform volumes): the host knows
-    // that there are exactly two particle masses and which fluids carry the heavier one (`bmask`, one bit per fluid).  k_nbr_tile then
-    // writes the lists of a tile whose halo holds both with the lighter class first and the heavier behind it (nffb[i] = length of
-    // that second segment) and, per slot, the mass of the first segment and of the second (0: the whole halo has one mass).  The
-    // plane-layout kernels run over ALL tiles in one launch and compute m_a S_all + (m_b - m_a) S_b, the second sum over the tail
-    // segment only and only in the tiles that have one (pairs.h pair_tail_*).
+    // Worlds with a few particle masses (BASELINE config 4: two fluids of different density0, each with `Fluid::new`'s uniform volumes;
+    // round 6: up to FOUR masses): the host knows the masses (`class_mass`, ascending) and which fluid carries which (`cmask`, two bits
+    // per fluid).  k_nbr_tile then writes the lists of a tile whose halo holds several with the lightest class first and the heavier
+    // ones behind it, class by class (nffb[i] = entries behind the first segment; nffc[i] = lengths of the third and fourth segment)
+    // and, per slot, the masses of the segments (0: there is no such segment).  The plane-layout kernels run over ALL tiles in one
+    // launch and compute m_a S_all + (m_b - m_a) S_b (+ (m_c - m_b) S_c + (m_d - m_b) S_d), the later sums over the tail segments only
+    // and only in the tiles that have them (pairs.h pair_tail_*).
     uint32_t* tile_mass_bits;   // [nlaunch] by slot: bits of the mass of the list's first segment (written by k_nbr_tile)
     uint32_t* tile_massb_bits;  // [nlaunch] by slot: bits of the mass of the second segment, 0 = there is none
-    uint32_t* nffb;             // [n] number of entries in the second segment of particle i's list
+    uint2* tile_masscd_bits;    // [nlaunch] by slot: ... of the third and fourth segment (worlds with more than two masses only, else nullptr)
+    uint32_t* nffb;             // [n] number of entries behind the first segment of particle i's list
+    uint32_t* nffc;             // [n] entries of the third segment | of the fourth << 16 (worlds with more than two masses only)
     uint32_t two_mass;          // 1: the above is on (DFSPH, default kernels, single domain)
-    uint32_t bmask;             // fluids whose particles have the heavier mass
+    uint32_t nmass;             // number of masses (2 ... 4) when it is
+    uint64_t cmask;             // mass class of fluid f: (cmask >> 2 f) & 3
+    float class_mass[4];        // the masses, ascending
     uint32_t bvel_zero;        // 1: every boundary velocity is exactly zero (plain boundaries uploaded at rest, the usual tank)
     const uint8_t* ff_ok;      // [nmodels*nmodels] InteractionGroups::test between fluids (diagonal = 1)
     const uint8_t* fb_ok;      // [nmodels*nbmodels]

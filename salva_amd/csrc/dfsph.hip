@@ -175,7 +175,7 @@ void launch_density_alpha(const StepCtx& c, const TileLds& L, float iisph_dt, hi
 #endif
 // (one body, two instantiations: the uniform-mass kernel carries none of the two-mass code — its second pair loop, the extra
 // list word — so that worlds with one mass run exactly what they ran before; device_types.h StepCtx::two_mass)
-template <uint32_t DS, bool TWO>
+template <uint32_t DS, int TWO>  // TWO: 0 one mass, 1 two masses, 2 three or four (StepCtx::nmass)
 __device__ __forceinline__ void k_density_alpha_div_p3_body(StepCtx c) {
     lds_base_check();
     Tile t;
@@ -248,11 +248,11 @@ __device__ __forceinline__ void k_density_alpha_div_p3_body(StepCtx c) {
                 div += ((wi.x - A.zu.y) * dx + (wi.y - A.vw.x) * dy + (wi.z - A.vw.y) * dz) * gmj;
             });
         }
-        if (active && (TWO && t.massb != 0.0f)) {  // two-mass world, this tile holds both: the heavier neighbours' share on top of every sum
-            const uint32_t nb2 = c.nffb[i];
-            if (nb2) {
+        if (active && (TWO && t.massb != 0.0f)) {  // several masses in this tile's halo: the heavier neighbours' shares on top of every sum
+            // entries [first, last) of the list carry `mnew` where the sums so far counted them with `mold`
+            auto on_top = [&](uint32_t first, uint32_t last, float mold, float mnew) {
                 float rwb = 0.0f, gxb = 0.0f, gyb = 0.0f, gzb = 0.0f, s2b = 0.0f, dvb = 0.0f;
-                for_each_ff_range(c, gs, o.cnt - nb2, o.cnt, [&](uint32_t s) { SALVA_PAIR_MATH
+                for_each_ff_range(c, gs, first, last, [&](uint32_t s) { SALVA_PAIR_MATH
                     const RecP3 A = load_p3(s << 3, dist8);
                     const float dx = pi.x - A.xy.x, dy = pi.y - A.xy.y, dz = pi.z - A.zu.x;
                     const float r2 = dx * dx + dy * dy + dz * dz;
@@ -265,10 +265,17 @@ __device__ __forceinline__ void k_density_alpha_div_p3_body(StepCtx c) {
                     s2b += gx * gx + gy * gy + gz * gz;
                     dvb += ((wi.x - A.zu.y) * dx + (wi.y - A.vw.x) * dy + (wi.z - A.vw.y) * dz) * e.g;
                 });
-                const float dm = t.massb - m;
+                const float dm = mnew - mold;
                 rho += dm * rwb; gsx += dm * gxb; gsy += dm * gyb; gsz += dm * gzb;
-                sq += (t.massb * t.massb - m * m) * s2b;
+                sq += (mnew * mnew - mold * mold) * s2b;
                 div += dm * dvb;
+            };
+            const uint32_t nb2 = c.nffb[i];
+            if (nb2) on_top(o.cnt - nb2, o.cnt, m, t.massb);
+            if (TWO == 2 && t.massc != 0.0f) {  // (three or four masses: the third and fourth segment were just counted with the second one's)
+                const uint32_t cd = c.nffc[i], l2 = cd & 0xffffu, l3 = cd >> 16;
+                if (l2) on_top(o.cnt - l3 - l2, o.cnt - l3, t.massb, t.massc);
+                if (l3) on_top(o.cnt - l3, o.cnt, t.massb, t.massd);
             }
         }
         float err = 0.0f;
@@ -305,15 +312,18 @@ __device__ __forceinline__ void k_density_alpha_div_p3_body(StepCtx c) {
     E.finish(c, t.slot);
 }
 template <uint32_t DS>
-__global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_WAVES : 5) void k_density_alpha_div_p3(StepCtx c) { k_density_alpha_div_p3_body<DS, false>(c); }
+__global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_WAVES : 5) void k_density_alpha_div_p3(StepCtx c) { k_density_alpha_div_p3_body<DS, 0>(c); }
 template <uint32_t DS>
-__global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_WAVES : 5) void k_density_alpha_div_p3_two(StepCtx c) { k_density_alpha_div_p3_body<DS, true>(c); }
+__global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_WAVES : 5) void k_density_alpha_div_p3_two(StepCtx c) { k_density_alpha_div_p3_body<DS, 1>(c); }
+template <uint32_t DS>
+__global__ __launch_bounds__(TILE_MAX_THREADS, (DS) == P3_DS_THREE ? SALVA_DAD_WAVES : 5) void k_density_alpha_div_p3_multi(StepCtx c) { k_density_alpha_div_p3_body<DS, 2>(c); }
 // true: the pass above ran and the divergence solve's iteration 0 must not launch its evaluate
 bool launch_density_alpha_div(const StepCtx& c, const TileLds& L, hipStream_t s) {
 #ifndef SALVA_OTHER_KERNELS
     if (!plane_layouts(c) || (c.sc.kd | c.sc.kg) != 0) return false;
     const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
-    if (c.two_mass) SALVA_LAUNCH_P3(k_density_alpha_div_p3_two, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
+    if (c.two_mass && c.nmass > 2u) SALVA_LAUNCH_P3(k_density_alpha_div_p3_multi, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
+    else if (c.two_mass) SALVA_LAUNCH_P3(k_density_alpha_div_p3_two, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
     else SALVA_LAUNCH_P3(k_density_alpha_div_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
     return true;
 #else
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence(StepCtx c) {
 #endif
 // (one body, two instantiations: the uniform-mass kernel carries none of the two-mass code — its second pair loop, the extra
 // list word — so that worlds with one mass run exactly what they ran before; device_types.h StepCtx::two_mass)
-template <uint32_t DS, bool TWO>
+template <uint32_t DS, int TWO>  // TWO: 0 one mass, 1 two masses, 2 three or four (StepCtx::nmass)
 __device__ __forceinline__ void k_divergence_p3_body(StepCtx c) {
     const SolveCtl* const rec = solve_record(c);
     if (rec && rec->done) return;  // the solve converged earlier in this batch
@@ -490,6 +500,11 @@ __device__ __forceinline__ void k_divergence_p3_body(StepCtx c) {
                     if ((TWO && t.massb != 0.0f) && o.nb2)  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
                         div += (t.massb - t.mass) * pair_tail_velocity_divergence_p3(c, gs, o.cnt - o.nb2, o.cnt, pi, wi, dist8);
                 }
+                if (TWO == 2 && t.massc != 0.0f) {  // three or four masses: the third and fourth segment were just counted with the second one's
+                    const uint32_t cd = c.nffc[i], l2 = cd & 0xffffu, l3 = cd >> 16;
+                    if (l2) div += (t.massc - t.massb) * pair_tail_velocity_divergence_p3(c, gs, o.cnt - l3 - l2, o.cnt - l3, pi, wi, dist8);
+                    if (l3) div += (t.massd - t.massb) * pair_tail_velocity_divergence_p3(c, gs, o.cnt - l3, o.cnt, pi, wi, dist8);
+                }
                 for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
                     const float4 pj = Bp[s];
                     const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -506,14 +521,17 @@ __device__ __forceinline__ void k_divergence_p3_body(StepCtx c) {
     E.finish(c, t.slot);
 }
 template <uint32_t DS>
-__global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) { k_divergence_p3_body<DS, false>(c); }
+__global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3(StepCtx c) { k_divergence_p3_body<DS, 0>(c); }
 template <uint32_t DS>
-__global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3_two(StepCtx c) { k_divergence_p3_body<DS, true>(c); }
+__global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3_two(StepCtx c) { k_divergence_p3_body<DS, 1>(c); }
+template <uint32_t DS>
+__global__ SALVA_P3_BOUNDS(DS) void k_divergence_p3_multi(StepCtx c) { k_divergence_p3_body<DS, 2>(c); }
 void launch_divergence(const StepCtx& c, const TileLds& L, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence, c, L, s);
     if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
-        if (c.two_mass) SALVA_LAUNCH_P3(k_divergence_p3_two, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
+        if (c.two_mass && c.nmass > 2u) SALVA_LAUNCH_P3(k_divergence_p3_multi, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
+        else if (c.two_mass) SALVA_LAUNCH_P3(k_divergence_p3_two, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
         else SALVA_LAUNCH_P3(k_divergence_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, false), s, c);
         return;
     }
@@ -590,7 +608,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_divergence_apply(StepCtx c
 #define SALVA_P2_BOUNDS(DS) __launch_bounds__(TILE_MAX_THREADS, (DS) == P2_DS_THREE ? SALVA_P2_WAVES : 5)
 // (one body, two instantiations: the uniform-mass kernel carries none of the two-mass code — its second pair loop, the extra
 // list word — so that worlds with one mass run exactly what they ran before; device_types.h StepCtx::two_mass)
-template <uint32_t DS, bool TWO>
+template <uint32_t DS, int TWO>  // TWO: 0 one mass, 1 two masses, 2 three or four (StepCtx::nmass)
 __device__ __forceinline__ void k_divergence_apply_p2_body(StepCtx c, float inv_dt_prev) {
     const SolveCtl* const rec = solve_record(c);
     const bool was_done = rec && rec->done;
@@ -636,6 +654,20 @@ __device__ __forceinline__ void k_divergence_apply_p2_body(StepCtx c, float inv_
                 sx += dm * bx; sy += dm * by; sz += dm * bz;
             }
         }
+        if (TWO == 2 && t.massc != 0.0f) {  // three or four masses: the third and fourth segment were just counted with the second one's
+            const uint32_t cd = c.nffc[i], l2 = cd & 0xffffu, l3 = cd >> 16;
+            float bx, by, bz;
+            if (l2) {
+                pair_tail_gradient_p2(c, gs, o.cnt - l3 - l2, o.cnt - l3, pi, dist8, [&](float kj) { return ki + kj; }, bx, by, bz);
+                const float dm = t.massc - t.massb;
+                sx += dm * bx; sy += dm * by; sz += dm * bz;
+            }
+            if (l3) {
+                pair_tail_gradient_p2(c, gs, o.cnt - l3, o.cnt, pi, dist8, [&](float kj) { return ki + kj; }, bx, by, bz);
+                const float dm = t.massd - t.massb;
+                sx += dm * bx; sy += dm * by; sz += dm * bz;
+            }
+        }
         float4 d = win[i];
         const uint32_t mi = __float_as_uint(d.w);
         const float rho0 = rho0_of(c, mi);
@@ -657,14 +689,17 @@ __device__ __forceinline__ void k_divergence_apply_p2_body(StepCtx c, float inv_
     });
 }
 template <uint32_t DS>
-__global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_dt_prev) { k_divergence_apply_p2_body<DS, false>(c, inv_dt_prev); }
+__global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2(StepCtx c, float inv_dt_prev) { k_divergence_apply_p2_body<DS, 0>(c, inv_dt_prev); }
 template <uint32_t DS>
-__global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2_two(StepCtx c, float inv_dt_prev) { k_divergence_apply_p2_body<DS, true>(c, inv_dt_prev); }
+__global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2_two(StepCtx c, float inv_dt_prev) { k_divergence_apply_p2_body<DS, 1>(c, inv_dt_prev); }
+template <uint32_t DS>
+__global__ SALVA_P2_BOUNDS(DS) void k_divergence_apply_p2_multi(StepCtx c, float inv_dt_prev) { k_divergence_apply_p2_body<DS, 2>(c, inv_dt_prev); }
 void launch_divergence_apply(const StepCtx& c, const TileLds& L, float inv_dt_prev, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_divergence_apply, c, L, inv_dt_prev, s);
     if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
-        if (c.two_mass) SALVA_LAUNCH_P2(k_divergence_apply_p2_two, ds, c, L, p2_bytes(L, ds), s, c, inv_dt_prev);
+        if (c.two_mass && c.nmass > 2u) SALVA_LAUNCH_P2(k_divergence_apply_p2_multi, ds, c, L, p2_bytes(L, ds), s, c, inv_dt_prev);
+        else if (c.two_mass) SALVA_LAUNCH_P2(k_divergence_apply_p2_two, ds, c, L, p2_bytes(L, ds), s, c, inv_dt_prev);
         else SALVA_LAUNCH_P2(k_divergence_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt_prev);
         return;
     }
@@ -786,7 +821,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pred_density(StepCtx c, fl
 // the plane-layout form (see k_divergence_p3)
 // (one body, two instantiations: the uniform-mass kernel carries none of the two-mass code — its second pair loop, the extra
 // list word — so that worlds with one mass run exactly what they ran before; device_types.h StepCtx::two_mass)
-template <uint32_t DS, bool TWO>
+template <uint32_t DS, int TWO>  // TWO: 0 one mass, 1 two masses, 2 three or four (StepCtx::nmass)
 __device__ __forceinline__ void k_pred_density_p3_body(StepCtx c, float dt) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     lds_base_check();
@@ -833,6 +868,11 @@ __device__ __forceinline__ void k_pred_density_p3_body(StepCtx c, float dt) {
                 if ((TWO && t.massb != 0.0f) && o.nb2)  // (the exact walk of a slice with a near-coincident pair: the heavier share on top)
                     delta += (t.massb - t.mass) * pair_tail_velocity_divergence_p3(c, gs, o.cnt - o.nb2, o.cnt, pi, wi, dist8);
             }
+            if (TWO == 2 && t.massc != 0.0f) {  // three or four masses: the third and fourth segment were just counted with the second one's
+                const uint32_t cd = c.nffc[i], l2 = cd & 0xffffu, l3 = cd >> 16;
+                if (l2) delta += (t.massc - t.massb) * pair_tail_velocity_divergence_p3(c, gs, o.cnt - l3 - l2, o.cnt - l3, pi, wi, dist8);
+                if (l3) delta += (t.massd - t.massb) * pair_tail_velocity_divergence_p3(c, gs, o.cnt - l3, o.cnt, pi, wi, dist8);
+            }
             mi = POST ? c.model[i] : o.mi;
             const float rho0 = rho0_of(c, mi);
             for_each_fb(c, t, i, gs, [&](uint32_t s) { SALVA_PAIR_MATH
@@ -852,14 +892,17 @@ __device__ __forceinline__ void k_pred_density_p3_body(StepCtx c, float dt) {
     E.finish(c, t.slot);
 }
 template <uint32_t DS>
-__global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) { k_pred_density_p3_body<DS, false>(c, dt); }
+__global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3(StepCtx c, float dt) { k_pred_density_p3_body<DS, 0>(c, dt); }
 template <uint32_t DS>
-__global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3_two(StepCtx c, float dt) { k_pred_density_p3_body<DS, true>(c, dt); }
+__global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3_two(StepCtx c, float dt) { k_pred_density_p3_body<DS, 1>(c, dt); }
+template <uint32_t DS>
+__global__ SALVA_P3_BOUNDS(DS) void k_pred_density_p3_multi(StepCtx c, float dt) { k_pred_density_p3_body<DS, 2>(c, dt); }
 void launch_pred_density(const StepCtx& c, const TileLds& L, float dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pred_density, c, L, dt, s);
     if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p3(L.max_halo_fluid, L.ds_level);
-        if (c.two_mass) SALVA_LAUNCH_P3(k_pred_density_p3_two, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
+        if (c.two_mass && c.nmass > 2u) SALVA_LAUNCH_P3(k_pred_density_p3_multi, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
+        else if (c.two_mass) SALVA_LAUNCH_P3(k_pred_density_p3_two, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
         else SALVA_LAUNCH_P3(k_pred_density_p3, ds, c, L, p3_bytes(L, ds, c.nmodels, !c.bvel_zero), s, c, dt);
         return;
     }
@@ -926,7 +969,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS) void k_pressure_apply(StepCtx c, 
 }
 // (one body, two instantiations: the uniform-mass kernel carries none of the two-mass code — its second pair loop, the extra
 // list word — so that worlds with one mass run exactly what they ran before; device_types.h StepCtx::two_mass)
-template <uint32_t DS, bool TWO>
+template <uint32_t DS, int TWO>  // TWO: 0 one mass, 1 two masses, 2 three or four (StepCtx::nmass)
 __device__ __forceinline__ void k_pressure_apply_p2_body(StepCtx c, float inv_dt) {
     if (c.ctl && c.ctl->done) return;  // the solve converged earlier in this batch
     lds_base_check();
@@ -966,6 +1009,20 @@ __device__ __forceinline__ void k_pressure_apply_p2_body(StepCtx c, float inv_dt
                 sx += dm * bx; sy += dm * by; sz += dm * bz;
             }
         }
+        if (TWO == 2 && t.massc != 0.0f) {  // three or four masses: the third and fourth segment were just counted with the second one's
+            const uint32_t cd = c.nffc[i], l2 = cd & 0xffffu, l3 = cd >> 16;
+            float bx, by, bz;
+            if (l2) {
+                pair_tail_gradient_p2(c, gs, o.cnt - l3 - l2, o.cnt - l3, pi, dist8, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, bx, by, bz);
+                const float dm = t.massc - t.massb;
+                sx += dm * bx; sy += dm * by; sz += dm * bz;
+            }
+            if (l3) {
+                pair_tail_gradient_p2(c, gs, o.cnt - l3, o.cnt, pi, dist8, [&](float kj) { return kip + fmaxf(kj, 0.0f); }, bx, by, bz);
+                const float dm = t.massd - t.massb;
+                sx += dm * bx; sy += dm * by; sz += dm * bz;
+            }
+        }
         const uint32_t mi = c.model[i];
         const float rho0 = rho0_of(c, mi);
         float4 d = c.dv[i];
@@ -991,14 +1048,17 @@ __device__ __forceinline__ void k_pressure_apply_p2_body(StepCtx c, float inv_dt
     });
 }
 template <uint32_t DS>
-__global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt) { k_pressure_apply_p2_body<DS, false>(c, inv_dt); }
+__global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2(StepCtx c, float inv_dt) { k_pressure_apply_p2_body<DS, 0>(c, inv_dt); }
 template <uint32_t DS>
-__global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2_two(StepCtx c, float inv_dt) { k_pressure_apply_p2_body<DS, true>(c, inv_dt); }
+__global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2_two(StepCtx c, float inv_dt) { k_pressure_apply_p2_body<DS, 1>(c, inv_dt); }
+template <uint32_t DS>
+__global__ SALVA_P2_BOUNDS(DS) void k_pressure_apply_p2_multi(StepCtx c, float inv_dt) { k_pressure_apply_p2_body<DS, 2>(c, inv_dt); }
 void launch_pressure_apply(const StepCtx& c, const TileLds& L, float inv_dt, hipStream_t s) {
     SALVA_OK_DISPATCH(launch_pressure_apply, c, L, inv_dt, s);
     if (plane_layouts(c)) {
         const uint32_t ds = pick_ds_p2(L.raw_slots(), L.ds_level);
-        if (c.two_mass) SALVA_LAUNCH_P2(k_pressure_apply_p2_two, ds, c, L, p2_bytes(L, ds), s, c, inv_dt);
+        if (c.two_mass && c.nmass > 2u) SALVA_LAUNCH_P2(k_pressure_apply_p2_multi, ds, c, L, p2_bytes(L, ds), s, c, inv_dt);
+        else if (c.two_mass) SALVA_LAUNCH_P2(k_pressure_apply_p2_two, ds, c, L, p2_bytes(L, ds), s, c, inv_dt);
         else SALVA_LAUNCH_P2(k_pressure_apply_p2, ds, c, L, p2_bytes(L, ds), s, c, inv_dt);
         return;
     }

@@ -655,7 +655,8 @@ void scan_tiles(void* temp, size_t temp_bytes, const TileAcc* in, TileAcc* out, 
 #ifndef SALVA_NBR_MIN_WAVES
 #define SALVA_NBR_MIN_WAVES 8
 #endif
-template <int V>
+// MM: 0 = one mass or the general kernels (no mass code at all), 1 = two masses, 2 = three or four (StepCtx::two_mass / nmass)
+template <int V, int MM>
 __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4) void k_nbr_tile(StepCtx c, TileListStats* __restrict__ tile_stats) {
     __shared__ uint32_t red[8][TILE_MAX_WAVES];
     Tile t;
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
     if (t.empty()) {
         if (threadIdx.x == 0) {
             tile_stats[t.slot] = TileListStats{0, 0, 0, 0, 0, 0};
-            if (c.two_mass) { c.tile_mass_bits[t.slot] = 0u; c.tile_massb_bits[t.slot] = 0u; }
+            if (MM != 0) { c.tile_mass_bits[t.slot] = 0u; c.tile_massb_bits[t.slot] = 0u; if (MM == 2) c.tile_masscd_bits[t.slot] = make_uint2(0u, 0u); }
         }
         return;
     }
@@ -685,35 +686,55 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
     float4* Bp = t.carve<float4>(t.SB);
     float4* Bv = t.carve<float4>(t.SB);
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    // (two-mass worlds: masses are positive floats, whose order is that of their bit patterns — min != max <=> this halo holds both)
-    uint32_t mlo = 0xffffffffu, mhi = 0u;
+    // (worlds with a few masses, StepCtx::two_mass: which of the host's mass classes does this halo hold?  One bit per class)
+    uint32_t pm = 0u;
+    const uint32_t cm0 = __float_as_uint(c.class_mass[0]), cm1 = __float_as_uint(c.class_mass[1]), cm2 = __float_as_uint(c.class_mass[2]),
+                   cm3 = __float_as_uint(c.class_mass[3]);
     t.for_halo(c, [&](uint32_t s, uint32_t g) {
         const float4 p = c.posm[g];
         if (V == 0) Lp[s] = p;
         else { Lx[s] = p.x; Ly[s] = p.y; Lz[s] = p.z; }
         if (multi) Lm[s] = c.model[g];
-        if (c.two_mass) { mlo = min(mlo, __float_as_uint(p.w)); mhi = max(mhi, __float_as_uint(p.w)); }
+        if (MM != 0) {
+            const uint32_t mb = __float_as_uint(p.w);
+            const uint32_t cls = mb == cm0 ? 0u : (mb == cm1 ? 1u : (mb == cm2 ? 2u : 3u));
+            if (cls == 3u && mb != cm3) atomicOr(c.flags, 8u);  // the host promised these masses: another one is an internal error, reported with the step's flags
+            pm |= 1u << cls;
+        }
     });
     t.for_halo_boundary(c, [&](uint32_t s, uint32_t g) { Bp[s] = c.bposv[g]; Bv[s] = c.bvel[g]; });
-    if (c.two_mass) {
-        mlo = ~wave_max_u32(~mlo); mhi = wave_max_u32(mhi);
-        if (lane == 0) { red[6][threadIdx.x / WAVE] = mlo; red[7][threadIdx.x / WAVE] = mhi; }
+    if (MM != 0) {
+        uint32_t w = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) w |= __builtin_amdgcn_ballot_w64((pm >> k) & 1u) != 0ull ? (1u << k) : 0u;
+        if (lane == 0) red[6][threadIdx.x / WAVE] = w;
     }
     __syncthreads();
-    // mixed: the halo holds both masses — the lists get the lighter class first and the heavier behind it (two walks of the
-    // candidates, the second over what the first left out), so that the plane-layout kernels can sum the second segment apart
+    // mixed: the halo holds several masses — the lists get the lightest class first and the heavier ones behind it, class by class
+    // (one walk of the candidates per class present, each over what the others leave out), so that the plane-layout kernels can sum
+    // the later segments apart
     bool mixed = false;
-    if (c.two_mass) {  // (every thread folds the per-wave rows: red[6..7] are not written again)
-        uint32_t lo = 0xffffffffu, hi = 0u;
-        for (uint32_t k = 0; k < blockDim.x / WAVE; ++k) { lo = min(lo, red[6][k]); hi = max(hi, red[7][k]); }
-        lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo); hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);  // (workgroup-uniform: scalar registers)
-        mixed = lo != hi;
-        if (mixed)  // the host promised two masses: a third one is an internal error, reported with the step's flags
-            t.for_halo(c, [&](uint32_t, uint32_t g) {
-                const uint32_t mb = __float_as_uint(c.posm[g].w);
-                if (mb != lo && mb != hi) atomicOr(c.flags, 8u);
-            });
-        if (threadIdx.x == 0) { c.tile_mass_bits[t.slot] = lo; c.tile_massb_bits[t.slot] = mixed ? hi : 0u; }
+    uint32_t npass = 1u, clspack = 0u;  // classes present, ascending, two bits each
+    if (MM != 0) {  // (every thread folds the per-wave rows: red[6] is not written again)
+        uint32_t present = 0u;
+        for (uint32_t k = 0; k < blockDim.x / WAVE; ++k) present |= red[6][k];
+        present = (uint32_t)__builtin_amdgcn_readfirstlane((int)present);  // (workgroup-uniform: scalar registers)
+        npass = 0u;
+        uint32_t mb0 = 0u, mb1 = 0u, mb2 = 0u, mb3 = 0u;  // (scalars: no indexed array, no scratch)
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (!((present >> k) & 1u)) continue;
+            const uint32_t b = k == 0u ? cm0 : (k == 1u ? cm1 : (k == 2u ? cm2 : cm3));
+            if (npass == 0u) mb0 = b; else if (npass == 1u) mb1 = b; else if (npass == 2u) mb2 = b; else mb3 = b;
+            clspack |= k << (2u * npass);
+            ++npass;
+        }
+        mixed = npass > 1u;
+        if (npass == 0u) npass = 1u;
+        if (threadIdx.x == 0) {
+            c.tile_mass_bits[t.slot] = mb0; c.tile_massb_bits[t.slot] = mb1;
+            if (MM == 2) c.tile_masscd_bits[t.slot] = make_uint2(mb2, mb3);
+        }
     }
     uint32_t sum_ff = 0, sum_fb = 0, max_ff = 0, max_fb = 0, own_ff = 0, own_fb = 0;
     t.for_own([&](uint32_t i, uint32_t gs, bool active) {
@@ -749,10 +770,11 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
             if (t.SB)
                 for (uint32_t m = 0; m < c.nbmodels; ++m) fbmask |= (c.fb_ok[mi * c.nbmodels + m] ? 1u : 0u) << m;
         }
-        int pass = 0;            // mixed tiles walk the candidates twice: pass 0 takes the lighter class, pass 1 the heavier
-        uint32_t cnta = 0;       // length of the first segment
+        int pass = 0;            // mixed tiles walk the candidates once per class present: pass 0 takes the lightest, ...
+        uint32_t cnta = 0, cpack = 0;  // list length behind the first segment; behind the second | behind the third << 16
+        uint32_t cur_cls = clspack & 3u;
         auto ff_allowed = [&](uint32_t s) -> bool {
-            if (V != 0 && mixed && ((c.bmask >> Lm[s]) & 1u) != (uint32_t)pass) return false;
+            if (V != 0 && MM != 0 && mixed && (uint32_t)((c.cmask >> (2u * Lm[s])) & 3ull) != cur_cls) return false;
             return V != 0 ? ((ffmask >> Lm[s]) & 1u) != 0u : c.ff_ok[mi * c.nmodels + Lm[s]] != 0;
         };
         auto append = [&](uint32_t s) {
@@ -761,7 +783,8 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
             ++cnt;
         };
 #pragma unroll 1
-        for (pass = 0; pass < (mixed ? 2 : 1); ++pass) {
+        for (pass = 0; pass < (MM == 0 ? 1 : (int)npass); ++pass) {
+        cur_cls = (clspack >> (2u * (uint32_t)pass)) & 3u;
 #pragma unroll 1
         for (int dx = -1; dx <= 1; ++dx) {
 #pragma unroll 1
@@ -856,6 +879,10 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
             }
         }
         if (pass == 0) cnta = cnt;
+        if (MM == 2) {
+            if (pass <= 1) cpack = cnt * 0x10001u;
+            else if (pass == 2) cpack = (cpack & 0xffffu) | (cnt << 16);
+        }
         }  // passes
         // an odd list is padded with the particle's own slot (for_each_ff2: the self contact adds nothing to gradient sums)
         const int hself = (lx * HY + ly) * HZ + lz;
@@ -866,7 +893,14 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
         // keep the true lengths, from which the host sees the overflow, grows the capacity and repeats the pass)
         c.nff[i] = min(cnt, 2u * c.cap_ff);
         c.nfb[i] = min(cntb, 2u * c.cap_fb);
-        if (c.two_mass) c.nffb[i] = min(cnt, 2u * c.cap_ff) - min(cnta, 2u * c.cap_ff);  // (0 in a tile of one mass: cnta == cnt)
+        if (MM != 0) {
+            const uint32_t cap2 = 2u * c.cap_ff;
+            c.nffb[i] = min(cnt, cap2) - min(cnta, cap2);  // (0 in a tile of one mass: cnta == cnt)
+            if (MM == 2) {
+                const uint32_t cb = min(cpack & 0xffffu, cap2), cc = min(cpack >> 16, cap2);
+                c.nffc[i] = (cc - cb) | ((min(cnt, cap2) - cc) << 16);
+            }
+        }
         sum_ff += cnt; sum_fb += cntb;
         max_ff = max(max_ff, cnt); max_fb = max(max_fb, cntb);
         if (!is_ghost(c, i)) { own_ff += cnt; own_fb += cntb; }  // (a decomposed run reports the contacts of the particles it owns)
@@ -937,7 +971,7 @@ void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsi
     if (c.n == 0) return;
     TileListStats* ts = static_cast<TileListStats*>(tile_stats);
     if (c.nmodels > 32u || c.nbmodels > 32u) {  // (the bit-mask group tests of V = 1 hold 32 models)
-        SALVA_LAUNCH_TILE(k_nbr_tile<0>, c, L, L.bytes(20, 32, 4, true) + 64u, s, c, ts);
+        SALVA_LAUNCH_TILE((k_nbr_tile<0, 0>), c, L, L.bytes(20, 32, 4, true) + 64u, s, c, ts);  // (worlds with a few masses have at most 32 fluids)
     } else {
         // what V = 1 carves: the cell tables, three 4-byte planes of (S + 8 rounded to 4) slots, the model ids when there is more
         // than one fluid, two 16-byte boundary arrays
@@ -947,7 +981,9 @@ void launch_nbr_build(const StepCtx& c, const TileLds& L, void* tile_stats, unsi
             const uint32_t plane = ((T.max_halo_fluid + 8u + 63u) & ~63u) + 64u;
             return r16(TILE_TABLE_BYTES) + 3u * r16(plane * 4u) + (nmodels > 1 ? r16(T.max_halo_fluid * 4u) : 0u) + 2u * T.max_halo_boundary * 16u + 64u;
         };
-        SALVA_LAUNCH_TILE(k_nbr_tile<1>, c, L, nbr_lds(L, c.nmodels), s, c, ts);
+        if (!c.two_mass) SALVA_LAUNCH_TILE((k_nbr_tile<1, 0>), c, L, nbr_lds(L, c.nmodels), s, c, ts);
+        else if (c.nmass <= 2u) SALVA_LAUNCH_TILE((k_nbr_tile<1, 1>), c, L, nbr_lds(L, c.nmodels), s, c, ts);
+        else SALVA_LAUNCH_TILE((k_nbr_tile<1, 2>), c, L, nbr_lds(L, c.nmodels), s, c, ts);
     }
     // (totals2 == nullptr: the statistics are folded by the end-of-step publication, World::publish_enqueue — one launch less per step)
     if (totals2) k_list_stats<<<1, BLOCK, 0, s>>>(static_cast<const TileListStats*>(tile_stats), c.nlaunch, totals2, maxima2, own2);

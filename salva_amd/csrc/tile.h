@@ -284,6 +284,7 @@ struct Tile {
     float mass;   // what the plane-layout kernels multiply their finished sums by: StepCtx::mass_uniform, or — two-mass worlds — the
                   // mass of the first segment of THIS tile's lists (StepCtx::tile_mass_bits)
     float massb;  // two-mass worlds: the mass of the second segment, 0 = this tile's halo holds one mass only
+    float massc, massd;  // worlds with three / four masses: the masses of the third and fourth segment, 0 = there is none
 
     __device__ __forceinline__ bool empty() const { return own_begin == own_end; }
     __device__ __forceinline__ bool skipped() const { return skip; }
@@ -294,7 +295,7 @@ struct Tile {
         pool = tile_smem;
         pool_used = 0;
         skip = false;
-        mass = massb = 0.0f;
+        mass = massb = massc = massd = 0.0f;
         slot = blockIdx.x;
         S = SB = 0; slice_base = 0; hoff = hboff = 0;
         pre0 = pre1 = pre2 = pre3 = preb = 0u;
@@ -344,6 +345,8 @@ struct Tile {
         const uint4 desc = c.slot_desc[slot];
         mass = c.two_mass ? __uint_as_float(c.tile_mass_bits[slot]) : c.mass_uniform;
         massb = c.two_mass ? __uint_as_float(c.tile_massb_bits[slot]) : 0.0f;
+        massc = massd = 0.0f;
+        if (c.tile_masscd_bits) { const uint2 cd = c.tile_masscd_bits[slot]; massc = __uint_as_float(cd.x); massd = __uint_as_float(cd.y); }
         pre0 = pre1 = pre2 = pre3 = preb = 0u;
         if (c.halo_stride) {
             const uint32_t* __restrict__ src = c.halo_src + (size_t)slot * c.halo_stride;

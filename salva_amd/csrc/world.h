@@ -265,7 +265,11 @@ class World {
     // Two-mass worlds (device_types.h StepCtx::two_mass; BASELINE config 4): every fluid has one particle mass (uniform volumes:
     // FluidSlot::vol_uniform) and exactly two different masses occur.  The plane-layout kernels then serve the whole world in one
     // launch per pass, the heavier class as a tail segment of the lists in the tiles that hold both.
-    DevBuf<uint32_t> tile_mass_bits, tile_massb_bits, nffb;
+    // Round 6: up to four masses — the third and fourth class as further tail segments (tile_masscd_bits, nffc).
+    DevBuf<uint32_t> tile_mass_bits, tile_massb_bits, nffb, nffc;
+    DevBuf<uint2> tile_masscd_bits;
+    uint32_t max_masses = 2;      // SALVA_HIP_MAX_MASSES=3 / 4: opt-in — on the one 10^6-particle scene it was measured on (four columns,
+                                  // tools/r06/multi_mass_probe.py) the general kernels are 8-10 % faster than the segments of three and four masses
     bool two_mass_off = false;    // SALVA_HIP_NO_TWO_MASS=1 (A/B, tests): such a world keeps the general kernels
     bool fold_off = false;        // SALVA_HIP_NO_FOLD=1: the fluid grid is never folded (device_types.h TileGrid)
     struct FoldRetry {};          // thrown by substep when the tile totals show a fold that piled the bulk onto itself (World::step retries)
@@ -273,7 +277,9 @@ class World {
     bool fold_locked = false;     // the looser fold did not fit the cell-table budget: keep the tighter one
     uint32_t fold_forced = 0;     // SALVA_HIP_FOLD_CELLS=P: every axis longer than P cells is folded to exactly P (tests)
     bool two_mass = false;        // this step runs that way
-    uint32_t two_mass_bmask = 0;  // fluids with the heavier mass
+    uint32_t nmass = 0;           // ... with this many masses,
+    float mass_classes[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // these, ascending,
+    uint64_t mass_cmask = 0;      // and this class per fluid (two bits each)
     bool decide_two_mass();
     // Decomposed runs, timers enabled (salva_hip_enable_counters): HIP event pairs around every ghost refresh (gather -> exchange ->
     // scatter) and every all-reduced convergence test (sum -> all-reduce -> decide) of a step, folded into `dist_times` at its end:

@@ -146,6 +146,7 @@ World::World(const SalvaHipParams& p) : prm(p) {
     if (const char* e = getenv("SALVA_HIP_SPLIT_S")) split_forced = (uint32_t)std::max(atoi(e), 1);
     no_planes = getenv("SALVA_HIP_NO_PLANES") != nullptr;
     two_mass_off = getenv("SALVA_HIP_NO_TWO_MASS") != nullptr;
+    if (const char* e = getenv("SALVA_HIP_MAX_MASSES")) max_masses = (uint32_t)std::min(std::max(atoi(e), 2), 4);  // (2 = round 5's rule, the default)
     fold_off = getenv("SALVA_HIP_NO_FOLD") != nullptr;
     if (const char* e = getenv("SALVA_HIP_FOLD_CELLS")) {
         const long v = atol(e);
@@ -703,10 +704,13 @@ StepCtx World::make_ctx() {
     c.nbmodels = (uint32_t)std::max<size_t>(bounds.size(), 1);
     c.mass_uniform = mass_uniform;
     c.two_mass = two_mass ? 1u : 0u;
-    c.bmask = two_mass_bmask;
+    c.nmass = two_mass ? nmass : 0u; c.cmask = mass_cmask;
+    for (int k = 0; k < 4; ++k) c.class_mass[k] = mass_classes[k];
     c.tile_mass_bits = two_mass ? tile_mass_bits.p : nullptr;
     c.tile_massb_bits = two_mass ? tile_massb_bits.p : nullptr;
+    c.tile_masscd_bits = (two_mass && nmass > 2u) ? tile_masscd_bits.p : nullptr;
     c.nffb = two_mass ? nffb.p : nullptr;
+    c.nffc = (two_mass && nmass > 2u) ? nffc.p : nullptr;
     c.bvel_zero = 1u;  // no boundary particle moves: the passes that subtract a boundary velocity need not stage it
     for (const BoundarySlot& b : bounds) if (b.n && (!b.vel_zero || b.sampling || b.dyn_kind)) c.bvel_zero = 0u;
     c.rho0_tab = rho0_tab.p; c.rho0_single = fluids.empty() ? 1000.0f : fluids[0].density0; c.ff_ok = ff_ok.p; c.fb_ok = fb_ok.p; c.bb_ok = bb_ok.p;
@@ -1205,29 +1209,36 @@ void World::evaluate_split(const StepCtx& c, int iteration, Launch&& launch) {
     SALVA_HIP_CHECK(hipStreamWaitEvent(stream, ev_interior, 0));
 }
 
-// Two-mass worlds (device_types.h StepCtx::two_mass): a single-domain DFSPH world with the default kernels in which every non-empty
-// fluid has one particle mass (FluidSlot::vol_uniform x density0, the product launch_stage_to_sorted forms) and exactly two
-// different masses occur — BASELINE config 4.  Sets two_mass_bmask (the fluids with the heavier mass).
+// Worlds with a few masses (device_types.h StepCtx::two_mass): a single-domain DFSPH world with the default kernels in which every
+// non-empty fluid has one particle mass (FluidSlot::vol_uniform x density0, the product launch_stage_to_sorted forms) and two, three
+// or four different masses occur — BASELINE config 4 has two.  Sets mass_classes / mass_cmask / nmass.
 bool World::decide_two_mass() {
-    two_mass_bmask = 0u;
+    mass_cmask = 0ull; nmass = 0u;
+    for (float& m : mass_classes) m = 0.0f;
     if (two_mass_off || no_planes || comm || prm.solver != SALVA_HIP_SOLVER_DFSPH || prm.kernel_density != 0 || prm.kernel_gradient != 0) return false;
     if (fluids.size() < 2 || fluids.size() > 32 || bounds.size() > 32) return false;
-    float lo = 0.0f, hi = 0.0f;
-    int distinct = 0;
+    float ms[4];
+    uint32_t distinct = 0;
     for (const FluidSlot& f : fluids) {
         if (f.n == 0) continue;
         const float m = f.vol_uniform * f.density0;
         if (!(m > 0.0f) || !std::isfinite(m)) return false;  // (NaN: the fluid's volumes differ)
-        if (distinct == 0) { lo = hi = m; distinct = 1; }
-        else if (m != lo && m != hi) {
-            if (distinct == 2) return false;  // a third mass
-            if (m < lo) lo = m; else hi = m;
-            distinct = 2;
-        }
+        bool seen = false;
+        for (uint32_t k = 0; k < distinct; ++k) seen |= ms[k] == m;
+        if (seen) continue;
+        if (distinct == max_masses) return false;  // one mass too many: the general kernels
+        ms[distinct++] = m;
     }
-    if (distinct != 2) return false;
-    for (uint32_t k = 0; k < fluids.size(); ++k)
-        if (fluids[k].n && fluids[k].vol_uniform * fluids[k].density0 == hi) two_mass_bmask |= 1u << k;
+    if (distinct < 2) return false;
+    std::sort(ms, ms + distinct);
+    for (uint32_t k = 0; k < distinct; ++k) mass_classes[k] = ms[k];
+    for (uint32_t f = 0; f < fluids.size(); ++f) {
+        if (!fluids[f].n) continue;  // (an empty fluid has no particle whose class could be asked for)
+        const float m = fluids[f].vol_uniform * fluids[f].density0;
+        for (uint32_t k = 0; k < distinct; ++k)
+            if (ms[k] == m) mass_cmask |= (uint64_t)k << (2u * f);
+    }
+    nmass = distinct;
     return true;
 }
 
@@ -1587,6 +1598,7 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     bbox_partials.ensure(6 * std::max<size_t>(std::max<size_t>(num_blocks(n), bbox_blocks(n)), 1024));
     two_mass = decide_two_mass();
     if (two_mass) nffb.ensure(n, stream, false, 1.1f);
+    if (two_mass && nmass > 2u) nffc.ensure(n, stream, false, 1.1f);
 
     // ---- cell bounding box (known from the previous step's position update unless the host moved particles)
     if (!bbox_known) {
@@ -1669,6 +1681,7 @@ int World::substep(float& dt, const float g[3], SalvaHipStepStats& st) {
     if (two_mass) {  // (per slot; Tile::setup reads them in every tile kernel, k_nbr_tile writes them)
         tile_mass_bits.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
         tile_massb_bits.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
+        if (nmass > 2u) tile_masscd_bits.ensure(std::max<uint32_t>(nslots_bound, 1u), stream, false, 1.5f);
     }
 
     // ---- One pass over the step.  The sizes of the tile tables (number of non-empty tiles, largest halo, slices) and the

@@ -2,7 +2,7 @@
 """Pin the oracle against real salva: compare a dump written by bench/rust_ref with what the oracle produced.
 
   python tests/golden/compare_rust_dump.py --scene NAME DIR     DIR = `cargo run --release -- --scene scenes/NAME.scene --dump DIR`;
-                                                                compared with tests/golden/NAME.npz (all six golden scenes)
+                                                                compared with tests/golden/NAME.npz (all seven golden scenes)
   python tests/golden/compare_rust_dump.py --all ROOT           ROOT/NAME for every golden scene
   python tests/golden/compare_rust_dump.py DIR --side S --steps K --warmup W     the bench.py tank (oracle re-run here)
 

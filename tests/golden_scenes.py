@@ -96,6 +96,22 @@ def scene_surface_tension():
     return s
 
 
+def scene_four_phase():
+    """Four fluids of different density0 (1000 / 800 / 600 / 400, `Fluid::new`'s uniform volumes: four particle masses) as 2 x 2 blocks
+    that meet along a vertical line, over a floor: the tiles around that line hold all four masses in their halo, the tiles along the
+    four faces two, the rest one (round 6: worlds with up to four masses run the plane-layout kernels)."""
+    s = Scene(R, 2.0, "dfsph")
+    for k, (sx, sz, rho0) in enumerate(((-1, -1, 1000.0), (1, -1, 800.0), (-1, 1, 600.0), (1, 1, 400.0))):
+        p = scenes.jitter(scenes.cube_fluid_positions(8, 6, 8, R), 0.05 * R, seed=42 + k)
+        p[:, 0] += np.float32(sx * 8 * R)
+        p[:, 2] += np.float32(sz * 8 * R)
+        p[:, 1] += np.float32(6 * R + 2 * R)
+        s.add_fluid(p, scenes.random_velocities(len(p), 0.05, seed=7 + k), rho0, forces=[("xsph", 0.5, 0.0)])
+    floor = scenes.plane_lattice(20, 20, 0.0, R, -10 * 2 * R + R, -10 * 2 * R + R, layers=1)
+    s.add_boundary(floor, wants_forces=True)
+    return s
+
+
 SCENES = {
     "dfsph_xsph_block": (scene_dfsph_xsph_block, 6),
     "dfsph_tank": (scene_dfsph_tank, 6),
@@ -103,6 +119,7 @@ SCENES = {
     "two_phase": (scene_two_phase, 6),
     "dfsph_viscous": (scene_dfsph_viscous, 6),
     "surface_tension": (scene_surface_tension, 6),
+    "four_phase": (scene_four_phase, 6),
 }
 
 

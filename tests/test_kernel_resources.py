@@ -61,8 +61,10 @@ def test_solver_kernels_keep_three_tiles_per_cu(tmp_path):
 
 def test_neighbour_list_kernel_keeps_four_tiles_per_cu(tmp_path):
     t = resources("grid.hip", tmp_path)
-    r = one(t, "k_nbr_tileILi1E")
     # (held to 64 VGPRs by its launch bounds: three registers live in scratch, 16 bytes per lane — two until round 5, measured faster
     # than three tiles without them, profiles/r04_experiments/r04b_*; the third came with the two-mass walk and costs nothing
-    # measurable, profiles/r05_experiments/r05i_*; more than that would be a change worth looking at)
-    assert r["vgprs"] <= 64 and r["waves"] >= 8 and r["scratch"] <= 16 and r["spilled"] <= 3, r
+    # measurable, profiles/r05_experiments/r05i_*; more than that would be a change worth looking at.  Round 6: the mass code is a
+    # template parameter — worlds with one mass carry none of it, worlds with three or four masses pay for their segment counters)
+    for mm, scratch, spilled in ((0, 16, 3), (1, 16, 3), (2, 32, 6)):
+        r = one(t, "k_nbr_tileILi1ELi%dE" % mm)
+        assert r["vgprs"] <= 64 and r["waves"] >= 8 and r["scratch"] <= scratch and r["spilled"] <= spilled, (mm, r)

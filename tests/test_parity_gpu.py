@@ -526,8 +526,9 @@ def test_two_mass_worlds_take_the_plane_layouts(monkeypatch):
     masses with the lighter class first, and the kernels add (m_b - m_a) x the sum over the heavier tail segment to m_a x the sum
     over the whole list.  Other kernels for the same sums: against a run with SALVA_HIP_NO_TWO_MASS=1 (the general kernels) the
     contact and iteration counts are identical and the states agree to f32 summation order — but not bit for bit, or the path
-    never switched on — and both agree with the oracle.  A third fluid with one of the two masses changes nothing; a third MASS, or
-    a fluid with non-uniform volumes, falls back to the general kernels (bit-identical to NO_TWO_MASS)."""
+    never switched on — and both agree with the oracle.  A third fluid with one of the two masses changes nothing; a third MASS under
+    round 5's rule (SALVA_HIP_MAX_MASSES=2; round 6 takes up to four, next test), or a fluid with non-uniform volumes, falls back to
+    the general kernels (bit-identical to NO_TWO_MASS)."""
     scene = _two_phase_side_by_side()
     nsteps = 10
     monkeypatch.delenv("SALVA_HIP_NO_TWO_MASS", raising=False)
@@ -556,6 +557,7 @@ def test_two_mass_worlds_take_the_plane_layouts(monkeypatch):
         sc = _two_phase_side_by_side()
         if variant == "third_mass":
             sc.add_fluid(top, None, 800.0, forces=[("xsph", 0.5, 0.0)])
+            monkeypatch.setenv("SALVA_HIP_MAX_MASSES", "2")
         else:
             vol = np.full(len(sc.fluids[0]["pos"]), 0.8 * (2 * R) ** 3, np.float32)
             vol[::7] *= np.float32(1.01)
@@ -564,11 +566,60 @@ def test_two_mass_worlds_take_the_plane_layouts(monkeypatch):
         monkeypatch.setenv("SALVA_HIP_NO_TWO_MASS", "1")
         b = run_hip(sc, 4)
         monkeypatch.delenv("SALVA_HIP_NO_TWO_MASS", raising=False)
+        monkeypatch.delenv("SALVA_HIP_MAX_MASSES", raising=False)
         for key in a:
             assert np.array_equal(np.asarray(a[key]), np.asarray(b[key]), equal_nan=True), (variant, key)
 
 
-@pytest.mark.parametrize("name", ["dfsph_tank", "iisph_akinci", "dfsph_xsph_block", "two_phase"])
+def _phases_around_a_line(rho0s, lift=2):
+    """2 x 2 blocks of different density0 (the last may repeat) meeting along a vertical line over a floor, dropped from `lift` radii:
+    tiles around the line see every mass, tiles along the faces two, the others one."""
+    s = Scene(R, 2.0, "dfsph")
+    for k, ((sx, sz), rho0) in enumerate(zip(((-1, -1), (1, -1), (-1, 1), (1, 1)), rho0s)):
+        p = scenes.jitter(scenes.cube_fluid_positions(12, 10, 12, R), 0.05 * R, seed=42 + k)
+        p[:, 0] += np.float32(sx * 12 * R)
+        p[:, 2] += np.float32(sz * 12 * R)
+        p[:, 1] += np.float32(10 * R + lift * R)
+        s.add_fluid(p, scenes.random_velocities(len(p), 0.05, seed=7 + k), rho0, forces=[("xsph", 0.5, 0.0)])
+    s.add_boundary(scenes.plane_lattice(30, 30, 0.0, R, -15 * 2 * R + R, -15 * 2 * R + R, layers=2))
+    return s
+
+
+@pytest.mark.parametrize("rho0s", [(1000.0, 800.0, 600.0, 600.0), (1000.0, 800.0, 600.0, 400.0), (400.0, 1000.0, 600.0, 800.0)])
+def test_worlds_with_three_and_four_masses_take_the_plane_layouts_too(monkeypatch, rho0s):
+    """Round 6: up to four particle masses — the lists of a tile whose halo holds several get one segment per
+    mass class, lightest first (one walk of the candidates per class present), the kernels count everything behind the first segment
+    with the second class's mass inside their loop and add (m_c - m_b) / (m_d - m_b) x the sums over the third / fourth segment on
+    top (pairs.h pair_tail_*).  Same protocol as for two masses: iteration and contact counts of the general kernels
+    (SALVA_HIP_NO_TWO_MASS=1), states equal to f32 summation order but not bit for bit, and the oracle's results.  With
+    SALVA_HIP_MAX_MASSES one below the scene's count the world falls back to the general kernels, bit for bit.  (Opt-in through
+    that switch: on four columns of 10^6 particles the general kernels were 8-10 % faster, profiles/r06_experiments/r06l_*.)"""
+    scene = _phases_around_a_line(rho0s)
+    nsteps = 10
+    monkeypatch.delenv("SALVA_HIP_NO_TWO_MASS", raising=False)
+    monkeypatch.setenv("SALVA_HIP_MAX_MASSES", "4")  # (opt-in: world.h max_masses)
+    on = run_hip(scene, nsteps)
+    monkeypatch.setenv("SALVA_HIP_NO_TWO_MASS", "1")
+    off = run_hip(scene, nsteps)
+    monkeypatch.delenv("SALVA_HIP_NO_TWO_MASS", raising=False)
+    assert np.array_equal(on["iters"], off["iters"]), "iteration or contact counts differ"
+    assert on["iters"][:, 0].max() >= 5  # (the blocks do land within the run)
+    differs = False
+    for f in range(4):
+        dp, dv = np.abs(on[f"pos_{f}"] - off[f"pos_{f}"]).max(), np.abs(on[f"vel_{f}"] - off[f"vel_{f}"]).max()
+        assert dp < 2e-5 * R * nsteps and dv < 1e-4, (f, dp / R, dv)
+        differs |= not np.array_equal(on[f"vel_{f}"], off[f"vel_{f}"])
+    assert differs, "bit-identical runs: the plane layouts never switched on"
+    compare(on, run_oracle(scene, nsteps), scene, nsteps, f"{len(set(rho0s))} masses around a line (plane layouts) vs oracle")
+    monkeypatch.setenv("SALVA_HIP_MAX_MASSES", str(len(set(rho0s)) - 1))
+    capped = run_hip(scene, 4)
+    monkeypatch.setenv("SALVA_HIP_NO_TWO_MASS", "1")
+    general = run_hip(scene, 4)
+    for key in capped:
+        assert np.array_equal(np.asarray(capped[key]), np.asarray(general[key]), equal_nan=True), key
+
+
+@pytest.mark.parametrize("name", ["dfsph_tank", "iisph_akinci", "dfsph_xsph_block", "two_phase", "four_phase"])
 def test_every_lds_layout_instantiation_computes_the_same_bits(monkeypatch, name):
     """The solver kernels exist in up to four instantiations each — the second staged array / plane at one of three compile-time
     distances (three, two, one tile per CU) or at a run-time distance — picked from the launch's largest halo (pairs.h pick_ds*).
@@ -576,6 +627,8 @@ def test_every_lds_layout_instantiation_computes_the_same_bits(monkeypatch, name
     by one, two, three levels on a small scene.  The layout moves LDS addresses and nothing else: every level must reproduce
     level 0 bit for bit, in both kernel families (plane layouts / SALVA_HIP_NO_PLANES)."""
     builder, nsteps = SCENES[name]
+    if name == "four_phase":
+        monkeypatch.setenv("SALVA_HIP_MAX_MASSES", "4")  # (the instantiations for three and four masses: opt-in, world.h max_masses)
     for planes in (True, False):
         runs = []
         for level in (0, 1, 2, 3):

@@ -45,7 +45,7 @@ def test_committed_scene_files_match_the_python_builders(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(root, "tests", "golden", "export_scenes.py"), "--out", str(tmp_path)],
                           stdout=subprocess.DEVNULL)
     names = sorted(os.listdir(tmp_path))
-    assert len(names) == 6
+    assert len(names) == 7
     for n in names:
         assert open(os.path.join(tmp_path, n), "rb").read() == open(os.path.join(root, "bench", "rust_ref", "scenes", n), "rb").read(), n
 
