@@ -15,7 +15,7 @@ from salva_amd import scenes
 
 pytestmark = pytest.mark.gpu
 R = 0.025
-SWITCHES = ("SALVA_HIP_NO_CLASSES", "SALVA_HIP_CLASSES", "SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FOLD", "SALVA_HIP_NO_SPLIT", "SALVA_HIP_LIGHT")
+SWITCHES = ("SALVA_HIP_NO_CLASSES", "SALVA_HIP_CLASSES", "SALVA_HIP_NO_PLANES", "SALVA_HIP_NO_FOLD", "SALVA_HIP_NO_SPLIT", "SALVA_HIP_LIGHT", "SALVA_HIP_SPLIT_S")
 
 
 def _make(env, scene):
