@@ -333,7 +333,8 @@ int salva_hip_enable_counters(SalvaHipWorld* world, int32_t enabled);
  *               substep = clamp(particle_radius * 2 / sqrt(max_i |v_i + a_i * remaining_time|^2) * cfl_coeff,
  *                               dt / max_num_substeps, dt / min_num_substeps)
  *           (the last substep may step past the end of the step: the commented code does not cut it);
- *   mode 2: the same, cut at the remaining time.
+ *   mode 2: the same, cut at the remaining time; a remainder below 1e-4 dt is taken along with the substep before it (no last substep
+ *           of float residue).
  * `counters.nsubsteps` counts the passes, the timers add up over them, the iteration counts and errors of SalvaHipStepStats are
  * the last pass's.  Plain boundaries accumulate reaction forces over the substeps as the reference's do; a COUPLED boundary that
  * wants forces needs salva_hip_set_coupling_callback (the reference transmits its impulse per substep, which one wrench per step

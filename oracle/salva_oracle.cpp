@@ -1491,7 +1491,9 @@ struct World {
             const R max_sub = total_step_size / (R)min_num_substeps;
             const R computed = max_substep();
             substep = computed > max_sub ? max_sub : (computed < min_substep ? min_substep : computed);
-            if (cfl_mode == 2 && substep > remaining_time) substep = remaining_time;
+            // mode 2: cut at the remaining time — and a remainder of float residue (below 1e-4 of the step) is taken along now instead
+            // of becoming a last substep of a few ulps with inv_dt ~ 1e6
+            if (cfl_mode == 2 && (substep > remaining_time || remaining_time - substep < total_step_size * (R)1e-4)) substep = remaining_time;
         }
         substeps_of_last_step.push_back((double)substep);
         dt = substep;

@@ -366,6 +366,11 @@ class World {
     bool pre_off = false;          // SALVA_HIP_NO_PREGRID=1 (A/B, tests)
     // two launch classes per pass (device_types.h StepCtx::slot_order)
     DevBuf<uint32_t> slot_order;
+    // scratch of particles_in_host_shape: candidate kinds / indices / positions, kept between queries
+    DevBuf<unsigned int> hq_cnt;
+    DevBuf<uint32_t> hq_kind, hq_index;
+    DevBuf<float4> hq_pos;
+    uint32_t hq_need = 0;
     uint32_t class_ntiny = 0;      // sparse slots of this step, when they run in launches of their own (0: with the others)
     uint32_t class_nlight = 0;     // light slots of this step, when they run in launches of their own (0: with the full ones)
     bool classes_off = false, classes_forced = false, light_on = false;  // SALVA_HIP_NO_CLASSES=1 / SALVA_HIP_CLASSES=1 / SALVA_HIP_LIGHT=1 (the light class: opt-in, it lost)

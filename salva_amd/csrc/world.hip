@@ -1294,7 +1294,9 @@ float World::choose_substep(const StepCtx& c) {
     const float min_substep = total / (float)cfl_max_sub, max_substep = total / (float)cfl_min_sub;
     const float computed = prm.particle_radius * 2.0f / std::sqrt(max_sq) * cfl_coeff;
     float sub = computed > max_substep ? max_substep : (computed < min_substep ? min_substep : computed);  // na::clamp
-    if (cfl_mode == 2 && sub > step_remaining) sub = step_remaining;
+    // (mode 2: cut at the remaining time; a remainder of float residue — below 1e-4 of the step — goes along with this substep instead
+    // of becoming a last one of a few ulps with inv_dt ~ 1e6; the oracle's twin does the same)
+    if (cfl_mode == 2 && (sub > step_remaining || step_remaining - sub < total * 1e-4f)) sub = step_remaining;
     return sub;
 }
 
@@ -2340,18 +2342,25 @@ uint64_t World::particles_in_host_shape(const SalvaHipHostQueryShape& shape, uin
         chi[a] = (int)std::min(std::max(floorf(maxs[a] / sc.h), -1073741824.0f), 1073741824.0f);
     }
     const QuerySrc qf = query_fluid_source(), qb{bst_pos.p, nb, nullptr, nullptr, nullptr};
-    const uint32_t ccap = qf.n + nb;  // every particle can be a candidate
-    DevBuf<unsigned int> cnt;
-    DevBuf<uint32_t> dk, di;
-    DevBuf<float4> dp;
-    cnt.ensure(1); dk.ensure(std::max(ccap, 1u)); di.ensure(std::max(ccap, 1u)); dp.ensure(std::max(ccap, 1u));
-    SALVA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(unsigned int), stream));
-    if (qf.n) k_cell_range_query<<<nblk(qf.n), BLOCK, 0, stream>>>(qf, clo[0], clo[1], clo[2], chi[0], chi[1], chi[2], sc.h, 0u, cnt.p, ccap, dk.p, di.p, dp.p);
-    if (nb) k_cell_range_query<<<nblk(nb), BLOCK, 0, stream>>>(qb, clo[0], clo[1], clo[2], chi[0], chi[1], chi[2], sc.h, 1u, cnt.p, ccap, dk.p, di.p, dp.p);
+    // Candidates go into scratch buffers the world keeps (three fresh (n + nb)-sized buffers per call were 190 MB at
+    // 8 x 10^6 particles, allocated and freed synchronously): sized for what queries have needed so far; the kernel counts every
+    // candidate and stores those that fit, so a box that holds more than the buffers do costs one repetition with room.
+    const uint32_t all = qf.n + nb;
     unsigned int m = 0;
-    SALVA_HIP_CHECK(hipMemcpyAsync(&m, cnt.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
-    SALVA_HIP_CHECK(hipStreamSynchronize(stream));
-    m = std::min<unsigned int>(m, ccap);
+    for (int attempt = 0;; ++attempt) {
+        const uint32_t ccap = std::min<uint32_t>(std::max<uint32_t>(hq_need, 65536u), std::max(all, 1u));
+        hq_cnt.ensure(1); hq_kind.ensure(ccap, stream, false, 1.25f); hq_index.ensure(ccap, stream, false, 1.25f); hq_pos.ensure(ccap, stream, false, 1.25f);
+        SALVA_HIP_CHECK(hipMemsetAsync(hq_cnt.p, 0, sizeof(unsigned int), stream));
+        if (qf.n) k_cell_range_query<<<nblk(qf.n), BLOCK, 0, stream>>>(qf, clo[0], clo[1], clo[2], chi[0], chi[1], chi[2], sc.h, 0u, hq_cnt.p, ccap, hq_kind.p, hq_index.p, hq_pos.p);
+        if (nb) k_cell_range_query<<<nblk(nb), BLOCK, 0, stream>>>(qb, clo[0], clo[1], clo[2], chi[0], chi[1], chi[2], sc.h, 1u, hq_cnt.p, ccap, hq_kind.p, hq_index.p, hq_pos.p);
+        SALVA_HIP_CHECK(hipGetLastError());
+        SALVA_HIP_CHECK(hipMemcpyAsync(&m, hq_cnt.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+        SALVA_HIP_CHECK(hipStreamSynchronize(stream));
+        if (m <= ccap) break;
+        if (attempt >= 1) throw HipError(SALVA_HIP_E_HIP, "internal error: the candidate count of a host shape query grew between two passes");
+        hq_need = m + m / 4u;
+    }
+    DevBuf<uint32_t>& dk = hq_kind; DevBuf<uint32_t>& di = hq_index; DevBuf<float4>& dp = hq_pos;
     if (m == 0) return 0;
     std::vector<uint32_t> hk(m), hi_(m);
     std::vector<float4> hp(m);
