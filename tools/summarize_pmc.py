@@ -17,8 +17,8 @@ acc = defaultdict(lambda: [0, 0.0])
 for f in sorted(glob.glob(os.path.join(d, "pmc*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("salva::", "").replace("void ", "")
-        name = re.sub(r"<\d+u?>$", "", name)  # (layout / variant instantiations of one kernel are summed under its name)
-        name = re.sub(r"_p[23](_two)?$", "", name)   # (the plane-layout forms of the DFSPH solver kernels, uniform and two-mass: the same pass)
+        name = re.sub(r"<[\du, ]+>$", "", name)  # (layout / variant instantiations of one kernel are summed under its name)
+        name = re.sub(r"_p[23](_two|_multi)?$", "", name)   # (the plane-layout forms of the DFSPH solver kernels, uniform and two-mass: the same pass)
         k = (name, r["Counter_Name"])
         acc[k][0] += 1
         acc[k][1] += float(r["Counter_Value"])
