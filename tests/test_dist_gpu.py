@@ -937,12 +937,20 @@ def test_cpp_mirror_runs_a_decomposed_world(hip_lib):
         assert r.returncode == 0 and "slabs3 OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
-def test_strays_far_out_in_y_and_z_fold_away_in_a_decomposed_run(hip_lib, monkeypatch):
+@pytest.mark.parametrize("classes", [False, True])
+def test_strays_far_out_in_y_and_z_fold_away_in_a_decomposed_run(hip_lib, monkeypatch, classes):
     """Round 6 (missing 3): the reference's hash grid never cares where a stray particle is
     (/root/reference/src/geometry/hgrid.rs:22-63); the dense cell table did, wherever it could not fold — decomposed runs among them
     (ghost planes are found by absolute x-cell).  They now fold y and z: fifty particles that have left the tank hundreds of cells
     below and beside it ride on the torus, the slabs compute what the undivided (and, here, unfolded) world computes, and nobody
-    dies of E_CAPACITY.  SALVA_HIP_FOLD_CELLS=16 forces the fold on this small scene: x — 48 cells — must stay whole on the slabs."""
+    dies of E_CAPACITY.  SALVA_HIP_FOLD_CELLS=16 forces the fold on this small scene: x — 48 cells — must stay whole on the slabs.
+    `classes`: the same with the strays' slots in launches of their own (SALVA_HIP_CLASSES=1) — in the undivided world, where a
+    speculative apply's convergence test once ran per launch (fixed in round 6), and on the slabs, whose evaluate passes launch
+    twice already (interior | border tiles, World::evaluate_split): four launches per pass, the same sums."""
+    if classes:
+        monkeypatch.setenv("SALVA_HIP_CLASSES", "1")
+    else:
+        monkeypatch.delenv("SALVA_HIP_CLASSES", raising=False)
     pos, vel, bpos = make_scene(nx=48, ny=10, nz=10, seed=9)
     rng = np.random.default_rng(3)
     stray = np.zeros((50, 3), np.float32)
