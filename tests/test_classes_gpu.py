@@ -207,3 +207,35 @@ def test_the_light_class_when_asked_for_runs_where_many_halos_fit_the_small_layo
     assert w1.counters.light_class_passes >= 2 and w1.counters.sparse_class_passes == 0, w1.counters  # (until the foot has expanded)
     assert t1 == t0
     _same(w1, f1, w0, f0)
+
+
+def test_launch_classes_under_chained_steps_and_the_pre_enqueued_grid():
+    """The fast paths of tests/test_chain_gpu.py (solves enqueued without a host wait behind device-side gates, the next step's grid part
+    enqueued ahead) with two launches per pass: a block in free fall, then on the floor, amid strays — against the plain world (no chain,
+    no pre-enqueued grid, one launch per pass), bit for bit.  Every class launch honours the gate; the order table belongs to the step
+    whose tables it was built from."""
+    s = Scene(R, 2.0, "dfsph")
+    fluid, shell = scenes.tank(16, 16, 16, R)
+    fluid = scenes.jitter(fluid, 0.1 * R, seed=42)
+    fluid[:, 1] += np.float32(0.12)
+    pos = _with_strays(fluid, nstray=40, seed=3)
+    s.add_fluid(pos, None, 1000.0, forces=[("xsph", 0.5, 0.0)])
+    s.add_boundary(shell)
+    switches = ("SALVA_HIP_NO_CHAIN", "SALVA_HIP_NO_PREGRID")
+    old = {k: os.environ.pop(k, None) for k in switches}
+    try:
+        os.environ.update({"SALVA_HIP_NO_CHAIN": "1", "SALVA_HIP_NO_PREGRID": "1"})
+        w0, f0, t0 = _run({"SALVA_HIP_NO_CLASSES": "1"}, s, 40)
+        for k in switches:
+            os.environ.pop(k, None)
+        w1, f1, t1 = _run({"SALVA_HIP_CLASSES": "1"}, s, 40)
+    finally:
+        for k in switches:
+            os.environ.pop(k, None)
+            if old[k] is not None:
+                os.environ[k] = old[k]
+    c = w1.counters
+    assert c.chained_passes >= 10 and c.chain_breaks >= 1 and c.pregrid_adopted >= 10 and c.sparse_class_passes >= 40, c
+    assert max(t[0] for t in t0) >= 8  # (the block did land)
+    assert t1 == t0
+    _same(w1, f1, w0, f0)
