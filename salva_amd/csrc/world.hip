@@ -1295,7 +1295,7 @@ float World::choose_substep(const StepCtx& c) {
     const float computed = prm.particle_radius * 2.0f / std::sqrt(max_sq) * cfl_coeff;
     float sub = computed > max_substep ? max_substep : (computed < min_substep ? min_substep : computed);  // na::clamp
     // (mode 2: cut at the remaining time; a remainder of float residue — below 1e-4 of the step — goes along with this substep instead
-    // of becoming a last one of a few ulps with inv_dt ~ 1e6; the oracle's twin does the same)
+    // of becoming a last one of a few ulps with inv_dt ~ 1e6; the CPU restatement the tests hold this against does the same)
     if (cfl_mode == 2 && (sub > step_remaining || step_remaining - sub < total * 1e-4f)) sub = step_remaining;
     return sub;
 }
