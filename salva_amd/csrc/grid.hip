@@ -770,6 +770,16 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
             if (t.SB)
                 for (uint32_t m = 0; m < c.nbmodels; ++m) fbmask |= (c.fb_ok[mi * c.nbmodels + m] ? 1u : 0u) << m;
         }
+        // The paired append below (two accepted candidates per trip, no test per candidate) is the single-fluid path; a world of
+        // several fluids takes it too wherever no candidate can be refused: every lane of the wave interacts with every fluid
+        // (InteractionGroups::default, interaction_groups.rs:64-69 — nearly every scene) and the tile's halo holds one mass class
+        // (round 6: k_nbr_tile 117 -> 100 us on a block of two fluids; a wave with a restricted lane, and the mixed tiles of a
+        // world with several masses, walk candidate by candidate as before)
+        bool paired = !multi;
+        if (V != 0 && multi && !(MM != 0 && mixed)) {
+            const uint32_t allm = c.nmodels >= 32u ? 0xffffffffu : ((1u << c.nmodels) - 1u);
+            paired = __builtin_amdgcn_ballot_w64((ffmask & allm) != allm) == 0ull;
+        }
         int pass = 0;            // mixed tiles walk the candidates once per class present: pass 0 takes the lightest, ...
         uint32_t cnta = 0, cpack = 0;  // list length behind the first segment; behind the second | behind the third << 16
         uint32_t cur_cls = clspack & 3u;
@@ -836,7 +846,7 @@ __global__ __launch_bounds__(TILE_MAX_THREADS, V == 1 ? SALVA_NBR_MIN_WAVES : 4)
                         uint32_t mask = __builtin_bitreverse32(rev) >> (32u - 4u * nq);
                         if (base < b) mask &= ~((1u << (b - base)) - 1u);
                         mask &= nc >= 32u ? 0xffffffffu : ((1u << nc) - 1u);
-                        if (!multi) {
+                        if (paired) {
                             // two accepted candidates per trip = one finished list dword per trip: the lanes of a wave leave this
                             // loop after max(ceil(bits / 2)) trips instead of max(bits), and no trip branches on the parity of cnt
                             if ((cnt & 1u) && mask) {  // complete the dword the previous chunk left half full
